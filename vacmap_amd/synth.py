@@ -1,0 +1,110 @@
+"""Seeded synthetic references and long reads (SURVEY §8(d) "Data rule"): everything large is generated on the box.
+
+  make_reference(lengths, seed)                 i.i.d. uniform ACGT contigs
+  sample_reads(contigs, n, ..., seed)           ONT-shape (gamma lengths, 10 % error 4:3:3 sub:del:ins) or
+                                                HiFi-shape (normal lengths, 0.5 % error) reads, 50/50 strand
+  implant_svs(seq, ops)                         donor sequence with simple / nested SVs (vacsim grammar subset:
+                                                DEL, INS, INV, DUP[:times], TRA-like cut&paste)
+Pure NumPy; byte arrays (uint8 ASCII) in, byte arrays out.
+"""
+import numpy as np
+
+_ACGT = np.frombuffer(b'ACGT', dtype=np.uint8)
+_COMP = np.zeros(256, np.uint8)
+_COMP[:] = ord('N')
+for a, b in zip(b'ACGTacgt', b'TGCATGCA'):
+    _COMP[a] = b
+
+
+def revcomp(a):
+    return _COMP[np.asarray(a, dtype=np.uint8)][::-1].copy()
+
+
+def make_reference(lengths, seed=1):
+    rng = np.random.default_rng(seed)
+    return [_ACGT[rng.integers(0, 4, size=int(n), dtype=np.uint8)] for n in lengths]
+
+
+def mutate(seq, err, rng, ratio=(4, 3, 3)):
+    """i.i.d. per-base errors split sub:del:ins = ratio; insertions add a random base before the position."""
+    n = len(seq)
+    if err <= 0 or n == 0:
+        return seq.copy()
+    tot = float(sum(ratio))
+    u = rng.random(n)
+    ps, pd = err * ratio[0] / tot, err * ratio[1] / tot
+    is_sub = u < ps
+    is_del = (u >= ps) & (u < ps + pd)
+    is_ins = (u >= ps + pd) & (u < err)
+    out = seq.copy()
+    # substitutions: shift to a different base
+    idx = np.nonzero(is_sub)[0]
+    if len(idx):
+        code = np.searchsorted(_ACGT, out[idx])  # ACGT sorted ascending in ASCII: A C G T
+        code = (code + rng.integers(1, 4, size=len(idx))) % 4
+        out[idx] = _ACGT[code]
+    keep = ~is_del
+    rep = keep.astype(np.int64) + is_ins.astype(np.int64)
+    res = np.repeat(out, rep)
+    # positions of inserted bases: the first copy of every is_ins position that is also kept, or the only copy if deleted
+    ins_idx = np.nonzero(is_ins)[0]
+    if len(ins_idx):
+        starts = np.cumsum(rep) - rep
+        res[starts[ins_idx]] = _ACGT[rng.integers(0, 4, size=len(ins_idx))]
+    return res
+
+
+def sample_reads(contigs, n, mean_len=15000, err=0.10, seed=2, shape='ont', min_len=1000, max_len=100000, sd=2000):
+    """returns list of (name, uint8 array, truth dict). shape 'ont': Gamma(2, mean/2); 'hifi': Normal(mean, sd)."""
+    rng = np.random.default_rng(seed)
+    lens = np.array([len(c) for c in contigs], dtype=np.int64)
+    cum = np.concatenate([[0], np.cumsum(lens)])
+    out = []
+    for i in range(n):
+        if shape == 'ont':
+            L = int(np.clip(rng.gamma(2.0, mean_len / 2.0), min_len, max_len))
+        else:
+            L = int(max(rng.normal(mean_len, sd), min_len))
+        while True:
+            g = int(rng.integers(0, cum[-1]))
+            c = int(np.searchsorted(cum, g, side='right') - 1)
+            st = g - int(cum[c])
+            if st + L <= lens[c]:
+                break
+            if lens[c] < L:
+                L = int(lens[c]); st = 0
+                break
+        frag = contigs[c][st:st + L]
+        strand = int(rng.integers(0, 2))
+        if strand:
+            frag = revcomp(frag)
+        rd = mutate(frag, err, rng)
+        out.append(('read%d' % i, rd, {'contig': c, 'start': st, 'end': st + L, 'strand': '-' if strand else '+'}))
+    return out
+
+
+def implant_svs(seq, ops):
+    """ops: list of (kind, pos, length[, extra]) applied right-to-left on the ORIGINAL coordinates:
+    ('DEL', p, n) ('INS', p, n, seed) ('INV', p, n) ('DUP', p, n, times) ('INVDUP', p, n)"""
+    seq = np.asarray(seq, dtype=np.uint8)
+    for op in sorted(ops, key=lambda o: -o[1]):
+        kind, p, n = op[0], int(op[1]), int(op[2])
+        if kind == 'DEL':
+            seq = np.concatenate([seq[:p], seq[p + n:]])
+        elif kind == 'INS':
+            rng = np.random.default_rng(op[3] if len(op) > 3 else 0)
+            seq = np.concatenate([seq[:p], _ACGT[rng.integers(0, 4, size=n)], seq[p:]])
+        elif kind == 'INV':
+            seq = np.concatenate([seq[:p], revcomp(seq[p:p + n]), seq[p + n:]])
+        elif kind == 'DUP':
+            t = int(op[3]) if len(op) > 3 else 1
+            seq = np.concatenate([seq[:p + n]] + [seq[p:p + n]] * t + [seq[p + n:]])
+        elif kind == 'INVDUP':
+            seq = np.concatenate([seq[:p + n], revcomp(seq[p:p + n]), seq[p + n:]])
+        else:
+            raise ValueError(kind)
+    return seq
+
+
+def tostr(a):
+    return np.asarray(a, dtype=np.uint8).tobytes().decode()
