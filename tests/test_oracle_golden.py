@@ -1,0 +1,151 @@
+"""CPU tests: the oracle (oracle/liboracle.so) against the golden vectors captured from the reference's own Python
+(tools/harness/gen_golden.py). No GPU, no /root/reference needed."""
+import hashlib, json, os, zlib
+import numpy as np
+import pytest
+
+CASES = ['A', 'B', 'C', 'D']
+
+
+def _index(O, meta, arrays, cid):
+    c = meta[cid]
+    contigs = [arrays['%s_contig%d' % (cid, i)].tobytes().decode() for i in range(len(c['names']))]
+    return O.Index.from_seqs(c['names'], contigs, k=c['k'], w=c['w'])
+
+
+def _seq(arrays, cid, ri):
+    return arrays['%s_r%d_seq' % (cid, ri)].tobytes().decode()
+
+
+def test_tables_bit_identical(oracle):
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'tables.json')))
+    which = {'extra': 0, 'readgap_h': 1, 'readgap_r': 2, 'large_readgap': 3, 'log2cache': 4, 'log2int': 5}
+    for name, w in which.items():
+        t = oracle.table(w)
+        g = gold[name]
+        assert str(t.dtype) == g['dtype'] and len(t) == g['len']
+        assert hashlib.sha256(t.tobytes()).hexdigest() == g['sha256'], name
+
+
+@pytest.mark.parametrize('cid', CASES)
+def test_map_is_stable(oracle, golden, cid):
+    """own-spec map(): the anchors stored in the fixture (inputs of the reference run) are reproduced"""
+    meta, arrays = golden
+    ix = _index(oracle, meta, arrays, cid)
+    for ri, r in enumerate(meta[cid]['reads']):
+        a = ix.map(_seq(arrays, cid, ri))
+        assert np.array_equal(a, arrays['%s_r%d_anchors' % (cid, ri)].reshape(-1, 4))
+
+
+@pytest.mark.parametrize('cid', CASES)
+def test_v1_strand_flip(oracle, golden, cid):
+    meta, arrays = golden
+    for ri, r in enumerate(meta[cid]['reads']):
+        a = arrays['%s_r%d_anchors' % (cid, ri)].reshape(-1, 4)
+        flag, out = oracle.strand_flip(a, r['len'])
+        assert flag == r['v1_flag']
+        assert np.array_equal(out, arrays['%s_r%d_v1' % (cid, ri)].reshape(-1, 4))
+
+
+@pytest.mark.parametrize('cid', CASES)
+def test_v2_global_chain(oracle, golden, cid):
+    meta, arrays = golden
+    c = meta[cid]
+    prm = oracle.params(c['mode'])
+    for ri, r in enumerate(c['reads']):
+        key = '%s_r%d' % (cid, ri)
+        a = arrays[key + '_anchors'].reshape(-1, 4)
+        if 'v2_gmax' in r:
+            fl = arrays[key + '_v1'].reshape(-1, 4)
+            srt = fl[np.argsort(fl[:, 0], kind='stable')]
+            g, S, P, SA = oracle.chain_global_raw(srt, c['k'], prm.global_skipcost, prm.global_maxdiff, 1000, 0, c['mode'])
+            assert g == r['v2_gmax']
+            assert np.array_equal(S.view(np.uint64), arrays[key + '_v2_S'].view(np.uint64)), 'S not bit-identical'
+            assert np.array_equal(P, arrays[key + '_v2_P'])
+            assert np.array_equal(SA, arrays[key + '_v2_Sarg'])
+        res = oracle.decode_hit(a, r['len'], c['k'], prm)
+        assert res['rc'] == 0
+        assert res['mapq'] == r['v2_mapq']
+        assert res['score'] == r['v2_score']
+        assert [p.tolist() for p in res['paths']] == r['v2_paths']
+
+
+@pytest.mark.parametrize('cid', CASES)
+def test_v3_local_chain(oracle, golden, cid):
+    meta, arrays = golden
+    c = meta[cid]
+    prm = oracle.params(c['mode'])
+    ix = _index(oracle, meta, arrays, cid)
+    comp = bytes.maketrans(b'ACGTN', b'TGCAN')
+    for ri, r in enumerate(c['reads']):
+        key = '%s_r%d' % (cid, ri)
+        if 'v3_score' not in r:
+            continue
+        seq = _seq(arrays, cid, ri)
+        rd = seq if r['v2_score'] > 0 else seq.encode().translate(comp)[::-1].decode()
+        res = oracle.local_chain(ix, rd, [np.array(p, dtype=np.int64) for p in r['v2_paths']], prm)
+        assert res['rc'] == 0
+        raw = res['raw']
+        raw = raw[np.argsort(raw[:, 0] + raw[:, 3], kind='stable')]
+        assert np.array_equal(raw, arrays[key + '_v3_raw'].reshape(-1, 4)), 'local anchors differ'
+        assert res['variant'] == r['v3_variant']
+        assert res['score'] == r['v3_score']
+        assert np.array_equal(res['chain'], arrays[key + '_v3_path'].reshape(-1, 4))
+
+
+@pytest.mark.parametrize('cid', CASES)
+def test_v5_v6_records_and_dp_problems(oracle, golden, cid):
+    meta, arrays = golden
+    c = meta[cid]
+    prm = oracle.params(c['mode'])
+    ix = _index(oracle, meta, arrays, cid)
+    for ri, r in enumerate(c['reads']):
+        seq = _seq(arrays, cid, ri)
+        (st, recs), calls = oracle.dplog(lambda: oracle.align_read(ix, seq, prm))
+        assert (st == 0) == (r['v6_status'] == 0)
+        got = [[c['names'][t[1]], t[2], t[3], t[4], t[5], t[6], t[7], t[8]] for t in recs]
+        assert got == r['v6_records'], (cid, ri)
+        dp = [[kd, len(t), len(q), zlib.crc32(t.encode()), zlib.crc32(q.encode())] for kd, t, q in calls]
+        assert dp == r['v5'], (cid, ri)
+
+
+def test_testdata_three_alignments(oracle, golden):
+    """README.md:124 — testdata yields three alignments (+, -, +: a 16 kb inversion)"""
+    meta, arrays = golden
+    recs = meta['A']['reads'][0]['v6_records']
+    assert [r[1] for r in recs] == ['+', '-', '+']
+    assert len(recs) == 3
+
+
+def test_primitives_properties(oracle):
+    rng = np.random.default_rng(5)
+    for _ in range(30):
+        n, m = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        a = ''.join('ACGT'[i] for i in rng.integers(0, 4, n)); b = ''.join('ACGT'[i] for i in rng.integers(0, 4, m))
+        # edit distance vs the textbook DP
+        D = np.arange(m + 1)
+        for i in range(1, n + 1):
+            prev = D.copy(); D[0] = i
+            for j in range(1, m + 1):
+                D[j] = min(prev[j] + 1, D[j - 1] + 1, prev[j - 1] + (a[i - 1] != b[j - 1]))
+        assert oracle.edit_distance(a, b) == D[m]
+        # CIGAR consumes both sequences exactly and re-scores to the reported score
+        cg, sc = oracle.k_cigar_global(a, b, eqx=True)
+        import re
+        i = j = 0; s = 0
+        for num, op in re.findall(r'(\d+)([=XID])', cg):
+            num = int(num)
+            if op in '=X':
+                for x in range(num):
+                    assert (a[i + x] == b[j + x]) == (op == '=')
+                s += (2 if op == '=' else -4) * num; i += num; j += num
+            elif op == 'D':
+                s -= min(4 + 2 * num, 24 + num); i += num
+            else:
+                s -= min(4 + 2 * num, 24 + num); j += num
+        assert (i, j) == (n, m) and s == sc
+    assert oracle.edit_distance('', 'ACG') == 3
+    sc, te, qe = oracle.k_extend('ACGTACGTAC', 'ACGTACGTAC')
+    assert (sc, te, qe) == (20, 10, 10)
+    sc, te, qe = oracle.k_extend('', 'ACGT')
+    assert (sc, te, qe) == (0, 0, 0)

@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE's own Python (build container only).
+
+Vectors:
+  V1 get_reversed_chain_numpy_rough      anchors -> (flag, anchors)
+  V2 hit2work_1 / decode_hit             anchors -> paths, scores, mapq, secondaries; raw S, P, S_arg of GC-exact
+  V3 ..._guide_list                      guide paths + read -> raw local anchors (argument of the LC DP), (score, path)
+  V5 DP problem list                     every k_cigar / edlib call the reference makes for the read (kind, |t|, |q|, crc)
+  V6 get_readmap_DP_test                 read -> onemapinfolist 9-tuples (the record type of the path)
+  V7 tests/test_nm_from_cigar.py         the reference's 9 known-answer triples for nm_from_cigar
+  V8 cost tables                         tools/gen_tables.py (tests/golden/tables.json)
+Inputs (reference contigs, reads) are stored next to the outputs, so the fixtures are self-contained.
+The reference sources are imported in place and never copied.
+"""
+import json, os, sys, zlib
+import numpy as np
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+sys.path.insert(0, _ROOT); sys.path.insert(0, _HERE)
+import refrun
+from refrun import O
+from vacmap_amd import synth
+
+GOLD = os.path.join(_ROOT, 'tests', 'golden')
+
+
+def rows(x):
+    return [[int(v) for v in r] for r in x]
+
+
+def run_case(cid, mode, names, contigs, reads, k, arrays, meta):
+    ix = O.Index.from_seqs(names, contigs, k=k, w=10)
+    al = refrun.Aligner(oracle_index=ix)
+    ctx = refrun.RefContext(mode, al)
+    m = ctx.m
+    case = {'mode': mode, 'k': k, 'w': 10, 'names': names, 'reads': []}
+    for ci, c in enumerate(contigs):
+        arrays['%s_contig%d' % (cid, ci)] = np.frombuffer(c.encode(), dtype=np.uint8)
+    for ri, (rname, seq) in enumerate(reads):
+        key = '%s_r%d' % (cid, ri)
+        arrays[key + '_seq'] = np.frombuffer(seq.encode(), dtype=np.uint8)
+        L = len(seq)
+        rec = {'name': rname, 'len': L}
+        anchors = np.array(al.map(seq, check_num=100, mid_occ=-1), dtype=np.int64).reshape(-1, 4)
+        arrays[key + '_anchors'] = anchors
+        # V1
+        flag, flipped = m.get_reversed_chain_numpy_rough(anchors.copy(), L)
+        rec['v1_flag'] = bool(flag)
+        arrays[key + '_v1'] = np.ascontiguousarray(flipped)
+        # V2 raw GC-exact on the q-sorted flipped anchors + hit2work_1
+        if len(flipped) > 2:
+            srt = np.ascontiguousarray(flipped)[np.argsort(np.ascontiguousarray(flipped)[:, 0])]
+            g, S, P, SA, fac = m.get_optimal_chain_sortbyreadpos_forSV_inv_test_merged_fine_list_d_all(
+                srt, kmersize=k, skipcost=ctx.option['golbal_skipcost'], maxdiff=ctx.option['golbal_maxdiff'], maxgap=1000)
+            rec['v2_gmax'] = int(g)
+            arrays[key + '_v2_S'] = np.asarray(S, dtype=np.float64)
+            arrays[key + '_v2_P'] = np.asarray(P, dtype=np.int64)
+            arrays[key + '_v2_Sarg'] = np.asarray(SA, dtype=np.int64)
+        mapq, scores, path, factor, rpl = m.decode_hit(al, ctx.index2contig, seq, L, ctx.contig2start, k, ctx.contig2seq,
+                                                     skipcost=(ctx.option['golbal_skipcost'],) * 2,
+                                                     maxdiff=(ctx.option['golbal_maxdiff'],) * 2, maxgap=200, check_num=100,
+                                                     c_bias=5000, bin_size=100, overlapprecentage=0.5, hastra=False, H=False, mid_occ=-1)
+        rec['v2_mapq'] = int(mapq); rec['v2_score'] = float(scores)
+        rec['v2_paths'] = [rows(p) for p in rpl]
+        # V3: capture the LC DP's input (raw local anchors, sorted by q+l) and its output
+        cap = {}
+        names_lc = ['get_optimal_chain_sortbyreadpos_forSV_inv_test_merged_fine_list',
+                    'get_optimal_chain_sortbyreadpos_forSV_inv_test_merged_fine_list_mismatch']
+        orig = {n: getattr(m, n) for n in names_lc}
+
+        def mk(n):
+            def f(one_mapinfo, **kw):
+                cap['variant'] = names_lc.index(n); cap['raw'] = np.array(one_mapinfo); cap['kw'] = {a: float(b) for a, b in kw.items()}
+                return orig[n](one_mapinfo, **kw)
+            return f
+        for n in names_lc:
+            setattr(m, n, mk(n))
+        refrun.DPLOG = []
+        st, one = ctx.align(rname, seq)
+        dplog = refrun.DPLOG; refrun.DPLOG = None
+        for n in names_lc:
+            setattr(m, n, orig[n])
+        rec['v6_status'] = st
+        rec['v6_records'] = [[t[1], t[2], int(t[3]), int(t[4]), int(t[5]), int(t[6]), int(t[7]), t[8]] for t in one]
+        if 'raw' in cap:
+            rec['v3_variant'] = cap['variant']; rec['v3_kw'] = cap['kw']
+            arrays[key + '_v3_raw'] = cap['raw'].astype(np.int64).reshape(-1, 4)
+            if scores != 0:
+                need_rev = scores < 0
+                rd = seq if not need_rev else synth.tostr(synth.revcomp(np.frombuffer(seq.encode(), np.uint8)))
+                from numba.typed import List
+                npl = List([np.array(p) for p in rpl])
+                rc_rd = synth.tostr(synth.revcomp(np.frombuffer(rd.encode(), np.uint8)))
+                lsc, lpath = m.get_localmap_multi_all_forDP_inv_guide_list(
+                    npl, rd, rc_rd, ctx.contig2start, ctx.contig2seq, kmersize=9, skipcost=ctx.option['local_skipcost'],
+                    maxdiff=ctx.option['local_maxdiff'], maxgap=(50 if mode == 'L' else 99), shift=1)
+                rec['v3_score'] = float(lsc)
+                arrays[key + '_v3_path'] = np.array(lpath, dtype=np.int64).reshape(-1, 4)
+        # V5: DP problems, compact (kind, tl, ql, crc32(t), crc32(q))
+        rec['v5'] = [[kd, len(t), len(q), zlib.crc32(t.encode()), zlib.crc32(q.encode())] for kd, t, q in dplog]
+        case['reads'].append(rec)
+    meta[cid] = case
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    arrays, meta = {}, {}
+    # case A: the reference's testdata (config 1)
+    ref = refrun.read_fasta('/root/reference/testdata/reference.fasta')
+    rds = refrun.read_fasta('/root/reference/testdata/read.fasta')
+    run_case('A', 'H', [n for n, _ in ref], [s.upper() for _, s in ref], [(n, s.upper()) for n, s in rds], 15, arrays, meta)
+    # case B: ONT-shape reads from an SV donor (mode H)
+    L = 120000
+    contigs = synth.make_reference([L, 40000], seed=101)
+    ops = [('INV', 10000, 2500), ('DEL', 25000, 900), ('INS', 40000, 500, 5), ('DUP', 55000, 1800, 2), ('INVDUP', 70000, 1500),
+           ('INV', 85000, 400), ('DEL', 95000, 200)]
+    d0 = synth.implant_svs(contigs[0], ops)
+    d0 = np.concatenate([d0[:105000], contigs[1][2000:5000], d0[105000:]])
+    rB = synth.sample_reads([d0, contigs[1]], 8, mean_len=7000, err=0.10, seed=102, shape='ont', min_len=2000, max_len=12000)
+    run_case('B', 'H', ['chrA', 'chrB'], [synth.tostr(c) for c in contigs], [(n, synth.tostr(s)) for n, s, _ in rB], 15, arrays, meta)
+    # case C: HiFi-shape reads (mode L, k=19)
+    rC = synth.sample_reads([d0, contigs[1]], 5, mean_len=8000, err=0.005, seed=103, shape='hifi', min_len=4000, sd=1500)
+    run_case('C', 'L', ['chrA', 'chrB'], [synth.tostr(c) for c in contigs], [(n, synth.tostr(s)) for n, s, _ in rC], 19, arrays, meta)
+    # case D: chimeras, repeats, unmappable, short and N-bearing reads (mode H)
+    rng = np.random.default_rng(104)
+    c0 = contigs[0].copy()
+    elem = synth.make_reference([2000], seed=105)[0]
+    for t in range(12):
+        p = int(rng.integers(0, len(c0) - 2000)); c0[p:p + 2000] = synth.mutate(elem, 0.02, rng, ratio=(1, 0, 0))[:2000]
+    unit = synth.make_reference([31], seed=106)[0]
+    c0[60000:60000 + 31 * 60] = np.tile(unit, 60)
+    rr = synth.sample_reads([c0, contigs[1]], 6, mean_len=6000, err=0.08, seed=107, shape='ont', min_len=3000, max_len=9000)
+    rD = [('chim0', np.concatenate([rr[0][1][:3000], rr[1][1][1000:]])), ('chim1', np.concatenate([rr[2][1][:2500], synth.revcomp(rr[3][1][:3000])])),
+          ('rep0', rr[4][1]), ('rand0', synth.make_reference([3000], seed=108)[0]), ('short0', rr[5][1][:200]), ('tiny0', rr[5][1][:12])]
+    wn = rr[5][1].copy(); wn[500:530] = ord('N'); wn[2000] = ord('N')
+    rD.append(('withN', wn))
+    tandem = synth.mutate(c0[59000:63500], 0.08, rng)
+    rD.append(('tandem0', tandem))
+    run_case('D', 'H', ['chrA', 'chrB'], [synth.tostr(c0), synth.tostr(contigs[1])], [(n, synth.tostr(s)) for n, s in rD], 15, arrays, meta)
+    # V7: the reference's own known-answer tests for nm_from_cigar (tests/test_nm_from_cigar.py) — evaluate the inputs of each
+    # test through the reference function and store (cigar, query, ref, expected NM)
+    of = refrun.refload.load_output_functions()
+    import ast
+    src = open('/root/reference/tests/test_nm_from_cigar.py').read()
+    v7 = []
+    for fn in ast.parse(src).body:
+        if not isinstance(fn, ast.FunctionDef):
+            continue
+        env = {}
+        for st in fn.body:   # local string constants (test_mixed_ops)
+            if isinstance(st, ast.Assign) and isinstance(st.value, ast.Constant):
+                env[st.targets[0].id] = st.value.value
+        for node in ast.walk(fn):
+            if isinstance(node, ast.Compare) and isinstance(node.left, ast.Call) and getattr(node.left.func, 'id', '') == 'nm_from_cigar':
+                args = [env[a.id] if isinstance(a, ast.Name) else ast.literal_eval(a) for a in node.left.args]
+                expected = ast.literal_eval(node.comparators[0])
+                got = int(of.nm_from_cigar(*args))
+                assert got == expected, (fn.name, got, expected)
+                v7.append({'test': fn.name, 'args': args, 'nm': expected})
+    meta['V7_nm_from_cigar'] = v7
+    np.savez_compressed(os.path.join(GOLD, 'cases.npz'), **arrays)
+    json.dump(meta, open(os.path.join(GOLD, 'cases.json'), 'w'), indent=0, sort_keys=True)
+    nrec = sum(len(r['v6_records']) for c in meta.values() if isinstance(c, dict) for r in c['reads'])
+    print('cases', [k for k in meta], 'records', nrec, 'npz bytes', os.path.getsize(os.path.join(GOLD, 'cases.npz')),
+          'json bytes', os.path.getsize(os.path.join(GOLD, 'cases.json')))
+
+
+if __name__ == '__main__':
+    main()
