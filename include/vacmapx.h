@@ -1,0 +1,199 @@
+/* vacmapx.h — C-ABI of libvacmapx.so: MI355X-native seed -> non-linear chain -> extend for long reads.
+ *
+ * Drop-in boundary: these entry points are what the reference's Python would bind through ctypes
+ * in place of its native dependencies `vacmap_index` (pip vacmap-index==0.0.3) and `edlib`, plus ONE batched
+ * entry (`vm_align_batch`) that replaces the whole per-read function `get_readmap_DP_test`
+ * (/root/reference/src/vacmap/mammap_clrnano.py:24023-24084) called by the worker loop (:24117).
+ * Every compute entry runs hand-written HIP kernels on gfx950; there is no CPU fallback: without a GPU / the HIP
+ * runtime, `vm_ctx_create` fails with VM_ERR_NO_DEVICE and every compute call returns VM_ERR_NO_CTX.
+ *
+ * Conventions: plain pointers and sizes; inputs are borrowed for the duration of the call; outputs are
+ * library-allocated host memory released with vm_free(); every function returns 0 or a negative vm_status;
+ * vm_last_error() gives a thread-local message. Anchor rows are int64 (q, r, s, l) = (read pos, global ref pos,
+ * strand +-1, length) exactly like the reference's (n,4) int64 arrays (:23985).
+ */
+#ifndef VACMAPX_H
+#define VACMAPX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum vm_status {
+    VM_OK = 0,
+    VM_ERR_ARG = -1,
+    VM_ERR_NO_DEVICE = -2,      /* no HIP device / runtime: the product never falls back to the CPU */
+    VM_ERR_NO_CTX = -3,
+    VM_ERR_OOM = -4,
+    VM_ERR_IO = -5,
+    VM_ERR_HIP = -6,
+    VM_ERR_UNSUPPORTED = -7,
+    /* per-read statuses (status_per_read of vm_align_batch); the reference skips such reads (:24116-24125) */
+    VM_READ_RAISED = -10,       /* the reference's Python would have raised inside the per-read path */
+    VM_READ_CAPACITY = -20      /* a device work buffer overflowed for this read (reported, never silently truncated) */
+} vm_status;
+
+enum { VM_MODE_H = 0, VM_MODE_L = 1, VM_MODE_S = 2, VM_MODE_R = 3 };   /* -mode (src/vacmap/vacmap:87) */
+
+/* option dict `pdict` of the reference driver (src/vacmap/vacmap:177-296) as one POD */
+typedef struct vm_params {
+    int32_t mode;            /* VM_MODE_* */
+    int32_t check_num;       /* -c (100) */
+    int32_t mid_occ;         /* -1 = index default (mammap_clrnano.py:23985) */
+    int32_t global_maxdiff;  /* -globalmaxdiff (50) */
+    int32_t local_maxdiff;   /* -localmaxdiff (30) */
+    int32_t local_kmersize;  /* 9 (src/vacmap/vacmap:255) */
+    int32_t eqx;             /* --eqx */
+    int32_t hardclip;        /* --H */
+    int32_t nodiscard;       /* --nodiscard */
+    int32_t reserved;
+    double global_skipcost;  /* -globalpenalty */
+    double local_skipcost;   /* -localpenalty */
+    double maxdivergence;    /* -maxdivergence */
+} vm_params;
+void vm_params_default(vm_params* p, int mode);            /* mode defaults of src/vacmap/vacmap:257-296 */
+
+/* ------------------------------------------------------------------ index (replaces mp.Aligner, vacmap:344-367) */
+typedef struct vm_index vm_index;
+typedef struct vm_ctx vm_ctx;
+
+/* one context = one GPU (device_id) + its streams and work buffers; one per host thread per GPU */
+int vm_ctx_create(int device_id, vm_ctx** out);
+void vm_ctx_destroy(vm_ctx*);
+int vm_device_count(void);
+
+/* build the minimizer index of a FASTA file / in-memory contigs ON THE GPU and keep it resident in HBM
+ * (replaces `mp.Aligner(path, w=, k=)`, src/vacmap/vacmap:344; index.py:26) */
+int vm_index_build_fasta(vm_ctx*, const char* fasta_path, int k, int w, vm_index** out);
+int vm_index_build_mem(vm_ctx*, int nseq, const char* const* names, const char* const* seqs, const int64_t* lens,
+                       int k, int w, vm_index** out);
+/* own on-disk format `<ref>.w<w>_k<k>.vmx` (the reference's naming rule `<ref>.w<w>_k<k>.mmi`, vacmap:326) */
+int vm_index_save(const vm_index*, const char* path);
+int vm_index_load(vm_ctx*, const char* path, vm_index** out);
+void vm_index_free(vm_index*);
+int vm_index_k(const vm_index*);                            /* Aligner.k      (:24024) */
+int vm_index_w(const vm_index*);
+int vm_index_nseq(const vm_index*);
+int vm_index_mid_occ(const vm_index*);
+int64_t vm_index_n_minimizers(const vm_index*);
+/* Aligner.seq_offset (vacmap:358-361): name, length, global offset of contig i */
+int vm_index_seq_info(const vm_index*, int i, const char** name, int64_t* len, int64_t* offset);
+/* Aligner.seq(name)  (vacmap:363): copies upper-case bases [start,end) of contig i; returns the count */
+int64_t vm_index_seq(const vm_index*, int i, int64_t start, int64_t end, char* out);
+/* device-resident sorted minimizer arrays copied back to the host (tests): hashes[n], positions[n] (gpos<<1|strand) */
+int vm_index_minimizers(const vm_index*, uint64_t** hashes, uint64_t** positions, int64_t* n);
+/* raw device pointers + sizes of the index blob pieces, for the multi-GPU broadcast (RCCL over xGMI) */
+int vm_index_blob_count(const vm_index*);
+int vm_index_blob(const vm_index*, int i, void** dev_ptr, int64_t* bytes);
+/* allocate an empty replica with the same geometry on another ctx (receiver side of the broadcast) */
+int vm_index_clone_geometry(vm_ctx*, const vm_index* src_host_meta, vm_index** out);
+int vm_index_meta_size(const vm_index*, int64_t* bytes);
+int vm_index_meta_get(const vm_index*, void* buf, int64_t bytes);
+int vm_index_from_meta(vm_ctx*, const void* buf, int64_t bytes, vm_index** out);
+
+/* ------------------------------------------------------------------ stage entry points (batched; GPU) */
+/* minimizer sketch of n reads: outputs concatenated per read, off[n+1] (tests; part of `.map`) */
+int vm_sketch_batch(vm_ctx*, int k, int w, int64_t n, const char* seqs, const int64_t* offsets,
+                    uint64_t** hash, int32_t** pos, int8_t** strand, int64_t** off);
+/* `.map(seq, check_num=, mid_occ=)` (:23985) for n reads: anchors rows concatenated, anchor_off[n+1] */
+int vm_map_batch(vm_ctx*, const vm_index*, int check_num, int mid_occ, int64_t n, const char* seqs,
+                 const int64_t* offsets, int64_t** anchors, int64_t** anchor_off);
+/* single-read form with the exact shape of the reference call */
+int vm_map(vm_ctx*, const vm_index*, const char* seq, int64_t len, int check_num, int mid_occ, int64_t** anchors, int64_t* n);
+
+/* global non-linear chain of n reads: strand flip (:21202) + hit2work_1 (:23491) + decode_hit (:23981).
+ * in: anchors (as returned by map), readlens. out per read: need_reverse, mapq, signed score (0 = unmapped),
+ * paths (primary + secondaries, descending read order): path_off[n_paths_total+1], read_path_off[n+1] */
+typedef struct vm_chains_out {
+    int32_t* need_reverse;   /* n */
+    int32_t* mapq;           /* n */
+    double* score;           /* n */
+    int32_t* fast_used;      /* n: 1 if GC-fast (:25033) produced the chain */
+    int64_t* read_path_off;  /* n+1: first path of each read */
+    int64_t* path_off;       /* total_paths+1: first anchor row of each path */
+    int64_t* path_anchors;   /* rows */
+    /* raw DP state of the LAST run of the exact DP (tests; null unless want_raw) : concatenated per read */
+    double* S; int64_t* P; int64_t* S_arg; int64_t* gmax; int64_t* opcount;
+} vm_chains_out;
+int vm_chain_global_batch(vm_ctx*, const vm_params*, int kmersize, int64_t n, const int64_t* anchors,
+                          const int64_t* anchor_off, const int64_t* readlens, int want_raw, vm_chains_out* out);
+void vm_chains_out_free(vm_chains_out*);
+
+/* local re-seeding + local chain (:28479) of n reads. reads must be in chain orientation (reverse-complemented by the
+ * caller when need_reverse). out: chain rows per read (descending read order), raw local anchors (pre-DP order) */
+typedef struct vm_local_out {
+    int32_t* status;         /* n: 0 or VM_READ_* */
+    int32_t* variant;        /* n: 0 = LC-exact (:27305), 1 = LC-mm (:28250) */
+    double* score;           /* n */
+    int64_t* chain_off;      /* n+1 */
+    int64_t* chain;          /* rows */
+    int64_t* raw_off;        /* n+1 */
+    int64_t* raw;            /* rows, sorted by (q+l) stable = the DP's input order */
+} vm_local_out;
+int vm_local_chain_batch(vm_ctx*, const vm_index*, const vm_params*, int64_t n, const char* seqs, const int64_t* offsets,
+                         const int64_t* read_path_off, const int64_t* path_off, const int64_t* path_anchors, vm_local_out* out);
+void vm_local_out_free(vm_local_out*);
+
+/* `mp.k_cigar(target, query, match, mismatch, o1, e1, o2, e2, bw=-1, zdropvalue=-1, eqx)` (:21554): global dual-affine
+ * alignment with traceback, n problems. t/q concatenated with offsets [n+1]. out: CIGAR strings concatenated
+ * (NUL-separated) with cigar_off[n+1], scores[n] */
+typedef struct vm_score { int32_t match, mismatch, o1, e1, o2, e2; } vm_score;
+int vm_k_cigar_batch(vm_ctx*, const vm_score*, int eqx, int64_t n, const char* t, const int64_t* t_off, const char* q,
+                     const int64_t* q_off, char** cigars, int64_t** cigar_off, int32_t** scores);
+/* `mp.k_cigar(..., 4,4,4,4, bw=100, zdropvalue=50)` (:2381): banded x-drop extension from (0,0); out t_e[n], q_e[n], score[n] */
+int vm_k_extend_batch(vm_ctx*, int match, int mismatch, int o, int e, int bw, int zdrop, int64_t n, const char* t,
+                      const int64_t* t_off, const char* q, const int64_t* q_off, int32_t** t_e, int32_t** q_e, int32_t** score);
+/* single-problem form with the reference's argument list; out mirrors the returned tuple (cigar, q_e, t_e) */
+typedef struct vm_cigar_out { char* cigar; int32_t q_e, t_e, score; } vm_cigar_out;
+int vm_k_cigar(vm_ctx*, const char* t, int64_t tl, const char* q, int64_t ql, const vm_score* sc, int bw, int zdrop,
+               int eqx, vm_cigar_out* out);
+/* `edlib.align(query, target, task='distance')['editDistance']` (:19251), n problems */
+int vm_edit_distance_batch(vm_ctx*, int64_t n, const char* q, const int64_t* q_off, const char* t, const int64_t* t_off,
+                           int64_t** dist);
+int64_t vm_edit_distance(vm_ctx*, const char* q, int64_t ql, const char* t, int64_t tl);
+
+/* ------------------------------------------------------------------ the batched path (the GPU entry) */
+/* record = one 9-tuple of get_onemapinfolist (:20760): (readid, contig, strand, q_st, q_en, r_st, r_en, mapq, cigar) */
+typedef struct vm_record {
+    int32_t read_idx;
+    int32_t contig;          /* index into vm_index_seq_info */
+    int32_t strand;          /* +1 '+', -1 '-' (label as emitted by the reference, :20760/:20776/:20810/:20826) */
+    int32_t mapq;
+    int64_t q_st, q_en;      /* aligned-strand coordinates (:20762-20763) */
+    int64_t r_st, r_en;      /* contig-local */
+    int64_t cigar_off, cigar_len;   /* into cigar_blob (NUL-terminated strings) */
+} vm_record;
+
+typedef struct vm_batch_stats {     /* measured on the device, for bench.py's roofline arithmetic */
+    int64_t n_reads, read_bases, n_minimizers, n_hits, n_anchors, n_local_hits, n_local_anchors;
+    int64_t n_segments, n_ed_problems, ed_cells, n_ext_problems, ext_cells, n_dp_problems, dp_cells;
+    int64_t n_records, cigar_bytes, aligned_bases, n_unmapped, n_failed;
+    double ms_total;                /* device time of the whole batch (HIP events on the ctx stream) */
+    double ms_stage[16];            /* per stage, same events */
+} vm_batch_stats;
+
+/* Align n reads (replaces get_readmap_DP_test per read). seqs concatenated, offsets[n+1].
+ * recs are ordered by (read_idx, emission order of the reference). status_per_read[n]: 0 (n_recs may be 0 = unmapped,
+ * :24132) or a negative VM_READ_* (read skipped like the reference's swallowed exception). stats may be NULL. */
+int vm_align_batch(vm_ctx*, const vm_index*, const vm_params*, int64_t n_reads, const char* seqs, const int64_t* offsets,
+                   vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats);
+/* the same with reads already resident in HBM (bench: inputs resident when the timed region starts).
+ * vm_reads_upload copies host reads to the device once; vm_align_resident runs the path on them. */
+typedef struct vm_reads vm_reads;
+int vm_reads_upload(vm_ctx*, int64_t n_reads, const char* seqs, const int64_t* offsets, vm_reads** out);
+void vm_reads_free(vm_reads*);
+int vm_align_resident(vm_ctx*, const vm_index*, const vm_params*, const vm_reads*, vm_record** recs, int64_t* n_recs,
+                      char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats);
+
+/* cost tables C0 as uploaded to the device (tests): which = 0 extra,1 readgap_h,2 readgap_r,3 large_readgap (f32),
+ * 4 log2cache, 5 log2int (f64). returns length, *data = host copy read back FROM THE DEVICE (vm_free) */
+int64_t vm_table(vm_ctx*, int which, void** data);
+
+void vm_free(void*);
+const char* vm_last_error(void);
+const char* vm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,116 @@
+"""Shared parity checks: the HIP path (real library on a GPU, or its emulator build in CPU tests) against the oracle.
+`ctx` is a vacmap_amd.lib.Context; `O` is tests/oracle_lib."""
+import numpy as np
+
+
+def rand_seq(rng, n):
+    return ''.join('ACGT'[i] for i in rng.integers(0, 4, n))
+
+
+def mutate(rng, s, rate):
+    out = []
+    for ch in s:
+        u = rng.random()
+        if u < rate * 0.4:
+            out.append('ACGT'[rng.integers(0, 4)])
+        elif u < rate * 0.7:
+            continue
+        elif u < rate:
+            out.append(ch); out.append('ACGT'[rng.integers(0, 4)])
+        else:
+            out.append(ch)
+    return ''.join(out)
+
+
+def check_tables(ctx, O):
+    for w in range(6):
+        a, b = ctx.table(w), O.table(w)
+        assert a.dtype == b.dtype and a.tobytes() == b.tobytes(), 'table %d' % w
+
+
+def check_edit_distance(ctx, O, n=32, maxlen=600, seed=1, minlen=0):
+    rng = np.random.default_rng(seed)
+    qs, ts = [], []
+    for i in range(n):
+        L = int(rng.integers(minlen, maxlen)) if i else max(minlen, 1)
+        a = rand_seq(rng, L)
+        b = mutate(rng, a, float(rng.choice([0.0, 0.05, 0.2, 0.6])))
+        if i == 1:
+            b = ''
+        if i == 2:
+            a = a[:1]
+        if i == 3:
+            a = a.replace('A', 'N', 2)
+        qs.append(a); ts.append(b)
+    got = ctx.edit_distance_batch(qs, ts)
+    exp = [O.edit_distance(q, t) for q, t in zip(qs, ts)]
+    assert got.tolist() == exp
+
+
+def check_extend(ctx, O, n=64, seed=3, maxlen=700):
+    rng = np.random.default_rng(seed)
+    ts, qs = [], []
+    for i in range(n):
+        L = int(rng.integers(1, maxlen))
+        a = rand_seq(rng, L)
+        b = mutate(rng, a, float(rng.choice([0.0, 0.1, 0.3])))
+        cut = int(rng.integers(0, len(b) + 1))
+        b = b[:cut] + rand_seq(rng, int(rng.integers(0, 300)))   # diverges -> x-drop must stop
+        if i == 0:
+            a = ''
+        if i == 1:
+            b = ''
+        ts.append(a); qs.append(b)
+    sc, te, qe = ctx.k_extend_batch(ts, qs)
+    for i in range(n):
+        e = O.k_extend(ts[i], qs[i])
+        assert (int(sc[i]), int(te[i]), int(qe[i])) == e, (i, len(ts[i]), len(qs[i]))
+
+
+def check_gapfill(ctx, O, n=64, maxlen=500, seed=4):
+    rng = np.random.default_rng(seed)
+    ts, qs = [], []
+    for i in range(n):
+        L = int(rng.integers(1, maxlen))
+        a = rand_seq(rng, L)
+        b = mutate(rng, a, float(rng.choice([0.0, 0.1, 0.3])))
+        if i % 7 == 3 and len(b) > 40:   # long gap -> second affine piece
+            b = b[:10] + b[10 + 30:]
+        if i % 7 == 5:
+            b = b[:5] + rand_seq(rng, 40) + b[5:]
+        if not b:
+            b = 'A'
+        ts.append(a); qs.append(b)
+    for eqx in (False, True):
+        cg, sc = ctx.k_cigar_batch(ts, qs, eqx=eqx)
+        for i in range(n):
+            e_cg, e_sc = O.k_cigar_global(ts[i], qs[i], eqx=eqx)
+            assert int(sc[i]) == e_sc, (i, 'score')
+            assert cg[i] == e_cg, (i, len(ts[i]), len(qs[i]))
+
+
+def check_chain_global_golden(ctx, O, golden, cases=('A', 'B', 'C', 'D')):
+    meta, arrays = golden
+    for cid in cases:
+        c = meta[cid]
+        prm = ctx.lib.params(c['mode'])
+        oprm = O.params(c['mode'])
+        al, rl = [], []
+        for ri, r in enumerate(c['reads']):
+            al.append(arrays['%s_r%d_anchors' % (cid, ri)].reshape(-1, 4)); rl.append(r['len'])
+        res = ctx.chain_global_batch(prm, c['k'], al, rl, want_raw=True)
+        for ri, r in enumerate(c['reads']):
+            key = '%s_r%d' % (cid, ri)
+            g = res[ri]
+            assert g['need_reverse'] == r['v1_flag'], key
+            if 'v2_gmax' in r:
+                assert g['gmax'] == r['v2_gmax'], key
+                assert np.array_equal(g['S'].view(np.uint64), arrays[key + '_v2_S'].view(np.uint64)), key + ' S'
+                assert np.array_equal(g['P'], arrays[key + '_v2_P']), key + ' P'
+                assert np.array_equal(g['S_arg'], arrays[key + '_v2_Sarg']), key + ' S_arg'
+            assert g['mapq'] == r['v2_mapq'], key
+            assert g['score'] == r['v2_score'], key
+            assert [p.tolist() for p in g['paths']] == r['v2_paths'], key
+            # and against the oracle run live (same inputs)
+            o = O.decode_hit(al[ri], rl[ri], c['k'], oprm)
+            assert [p.tolist() for p in o['paths']] == [p.tolist() for p in g['paths']]

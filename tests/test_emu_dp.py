@@ -1,0 +1,32 @@
+"""CPU tests (no GPU): the PRODUCT's HIP kernels, compiled unchanged against the fiber emulator (tests/emu), vs the oracle.
+These check kernel logic in the GPU-less container; the `-m gpu` twins in test_gpu_*.py run the real library."""
+import numpy as np
+import pytest
+import kernel_cases as KC
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    import emu_lib
+    return emu_lib.context()
+
+
+def test_emu_tables(ctx, oracle):
+    KC.check_tables(ctx, oracle)
+
+
+def test_emu_edit_distance(ctx, oracle):
+    KC.check_edit_distance(ctx, oracle, n=12, maxlen=300, seed=1)
+    KC.check_edit_distance(ctx, oracle, n=2, maxlen=4500, seed=2, minlen=4200)   # > 64 blocks: multi-pass carry
+
+
+def test_emu_extend(ctx, oracle):
+    KC.check_extend(ctx, oracle, n=16, seed=3)
+
+
+def test_emu_gapfill(ctx, oracle):
+    KC.check_gapfill(ctx, oracle, n=10, maxlen=150, seed=4)
+
+
+def test_emu_chain_global(ctx, oracle, golden):
+    KC.check_chain_global_golden(ctx, oracle, golden, cases=['B', 'D'])

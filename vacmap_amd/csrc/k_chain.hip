@@ -1,0 +1,268 @@
+// k_chain.hip — global non-linear (SV-aware) anchor chaining on gfx950.
+//
+//   k_flip_sort      S2 get_reversed_chain_numpy_rough (/root/reference/src/vacmap/mammap_clrnano.py:21202-21217)
+//                    + the stable argsort by read position of hit2work_1 (:23572)
+//   k_chain_global   G2 get_optimal_chain_sortbyreadpos_forSV_inv_test_merged_fine_list_d_all (:24828-25031), "GC-exact":
+//                    one wavefront per read; anchors, S, P and the score-sorted index S_arg live in LDS (32 B per
+//                    anchor) when they fit, else in HBM. The candidate scan visits 64 predecessors per wave step in
+//                    descending-S order; an exclusive prefix-max recovers the exact sequential break index, `opcount`
+//                    and the strict-'>' winner.
+//   k_chain_select   G1 hit2work_1 peel / primary / MAPQ / secondaries (:23588-23707) + decode_hit (:23981-24020):
+//                    one thread per read (serial, tiny).
+// Scores are IEEE double in the reference's evaluation order; the library is compiled with -ffp-contract=off.
+#include "vmx_device.h"
+#include "vmx_kernels.h"
+#include "vmx_select.h"
+
+// ------------------------------------------------------------------------------------------------ block bitonic sort
+__device__ void vmx_block_bitonic_u64(uint64_t* a, int N) {   // N power of two, all threads of the block call it
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    uint64_t x = a[i], y = a[ixj];
+                    bool asc = (i & k) == 0;
+                    if ((x > y) == asc) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ S2 + sort by q
+// rows: int64 (q, r, s, l) as produced by map(); keys: scratch of pow2(n) uint64 per read at key_off[r]
+__global__ void k_flip_sort(const int64_t* __restrict__ rows, const int64_t* __restrict__ aoff, const int64_t* __restrict__ readlens,
+                            int n_reads, uint64_t* __restrict__ key_pool, const int64_t* __restrict__ key_off,
+                            vmx_anchor* __restrict__ sorted, int32_t* __restrict__ need_reverse) {
+    __shared__ int s_cnt[2];
+    for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        const int64_t* A = rows + 4 * aoff[r];
+        const int n = (int)(aoff[r + 1] - aoff[r]);
+        const int64_t L = readlens[r];
+        if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+        __syncthreads();
+        int neg = 0, pos = 0;
+        for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) { int64_t s = A[4 * i + 2]; if (s == -1) ++neg; else if (s == 1) ++pos; }
+        neg = vmx_wave_sum_i32(neg); pos = vmx_wave_sum_i32(pos);
+        if (vmx_lane() == 0) { atomicAdd(&s_cnt[0], neg); atomicAdd(&s_cnt[1], pos); }
+        __syncthreads();
+        const bool flip = n >= 3 && s_cnt[0] > s_cnt[1];
+        int N = 1; while (N < n) N <<= 1;
+        uint64_t* keys = key_pool + key_off[r];
+        for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) {
+            uint64_t k = ~0ULL;
+            if (i < n) {
+                int64_t q = A[4 * i], l = A[4 * i + 3];
+                if (flip) { q = L - q - l; k = ((uint64_t)q << 32) | (uint64_t)(n - 1 - i); }
+                else k = ((uint64_t)q << 32) | (uint64_t)i;
+            }
+            keys[i] = k;
+        }
+        __syncthreads();
+        if (N > 1) vmx_block_bitonic_u64(keys, N);
+        vmx_anchor* out = sorted + aoff[r];
+        for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
+            uint64_t k = keys[i];
+            int src = (int)(k & 0xffffffffu);
+            if (flip) src = n - 1 - src;
+            vmx_anchor a;
+            a.q = (int32_t)(k >> 32);
+            a.l = (int16_t)A[4 * src + 3];
+            a.s = (int16_t)(flip ? -A[4 * src + 2] : A[4 * src + 2]);
+            a.r = A[4 * src + 1];
+            out[i] = a;
+        }
+        if (threadIdx.x == 0) need_reverse[r] = flip ? 1 : 0;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ G2 GC-exact
+// :19369-19387 literal (equal keys return mid+1 at the first probe that hits one)
+__device__ __forceinline__ int vmx_insertpoint_score(const double* S, double target, int k, const int* SA) {
+    int i = 0, j = k;
+    if (S[SA[0]] > target) return 0;
+    if (S[SA[k - 1]] < target) return k;
+    while (i < j) {
+        int mid = (i + j) >> 1;
+        double now = S[SA[mid]];
+        if (now < target) i = mid + 1;
+        else if (now > target) j = mid;
+        else return mid + 1;
+    }
+    return j;
+}
+
+// wave-cooperative S_arg[loc+1 : k+1] = S_arg[loc : k]; S_arg[loc] = k
+__device__ __forceinline__ void vmx_sarg_insert(int* SA, int loc, int k, int lane) {
+    for (int hi = k; hi > loc; hi -= 64) {
+        int x = hi - lane;
+        int v = 0;
+        if (x > loc) v = SA[x - 1];
+        __syncthreads();
+        if (x > loc) SA[x] = v;
+        __syncthreads();
+    }
+    if (lane == 0) SA[loc] = k;
+    __syncthreads();
+}
+
+// shared gap geometry of GC and LC (:24953-24984, :27418-27456)
+__device__ __forceinline__ void vmx_gap_geometry(int qi, long long ri, int si, int li, int qj, long long rj, int sj, int lj,
+                                                 long long& readgap, long long& refgap, long long& bonus) {
+    readgap = (long long)qi - qj - lj;
+    if (readgap < 0) {
+        bonus = (long long)qi + li - qj - lj;
+        readgap = 0;
+        long long overlap = (long long)qj + lj - qi;
+        if (si == sj) { if (si == 1) refgap = ri + overlap - (rj + lj); else refgap = rj - (ri + bonus); }
+        else { if (sj == -1) refgap = ri + overlap - rj + 1; else refgap = ri + bonus - 1 - (rj + lj); }
+    } else {
+        bonus = li;
+        if (si == sj) { if (si == 1) refgap = ri - rj - lj; else refgap = rj - ri - li; }
+        else { if (sj == -1) refgap = ri - rj + 1; else refgap = ri + li - 1 - rj - lj; }
+    }
+}
+
+
+__global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ aoff,
+                                                     const int32_t* __restrict__ rlist, int nlist, int lds_cap, vmx_tables tab,
+                                                     const double* __restrict__ gapcost_list, double oskipcost, int omaxdiff,
+                                                     int maxgap, double* __restrict__ S_out, int32_t* __restrict__ P_out,
+                                                     int32_t* __restrict__ SA_out, uint8_t* __restrict__ cov_pool,
+                                                     int64_t* __restrict__ gmax_out, int64_t* __restrict__ opcount_out) {
+    VMX_DYN_SHARED(char, smem);
+    __shared__ double s_gapcost[64];
+    const int lane = vmx_lane();
+    for (int x = lane; x <= omaxdiff && x < 64; x += 64) s_gapcost[x] = gapcost_list[x];
+    __syncthreads();
+    const long long extra_size = (long long)tab.extra_n - 1;
+    for (int li_ = blockIdx.x; li_ < nlist; li_ += gridDim.x) {
+        const int rd = rlist[li_];
+        const int64_t a0 = aoff[rd];
+        const int n = (int)(aoff[rd + 1] - a0);
+        if (n <= 0) { if (lane == 0) { gmax_out[rd] = -2; opcount_out[rd] = 0; } continue; }
+        const vmx_anchor* A = anchors + a0;
+        // working arrays: LDS when the read fits, else straight in the HBM output arrays
+        double* S; int* P; int* SA; int* Q; long long* R; int* LS; uint8_t* COV;
+        const bool in_lds = n <= lds_cap;
+        if (in_lds) {
+            S = (double*)smem; R = (long long*)(S + lds_cap); Q = (int*)(R + lds_cap); LS = Q + lds_cap; P = LS + lds_cap;
+            SA = P + lds_cap; COV = (uint8_t*)(SA + lds_cap);
+        } else {
+            S = S_out + a0; P = P_out + a0; SA = SA_out + a0; COV = cov_pool + a0;
+            Q = nullptr; R = nullptr; LS = nullptr;
+        }
+        // stage anchors + coverage (number of anchors sharing the read position, capped at 20: :24865-24868)
+        for (int i = lane; i < n; i += 64) {
+            vmx_anchor a = A[i];
+            if (in_lds) { Q[i] = a.q; R[i] = a.r; LS[i] = ((int)a.l & 0xffff) | ((int)a.s << 16); }
+            int c = 1;
+            for (int x = i - 1; x >= 0 && A[x].q == a.q && c < 20; --x) ++c;
+            for (int x = i + 1; x < n && A[x].q == a.q && c < 20; ++x) ++c;
+            COV[i] = (uint8_t)c;
+        }
+        __syncthreads();
+#define AQ(i) (in_lds ? Q[i] : A[i].q)
+#define AR(i) (in_lds ? R[i] : (long long)A[i].r)
+#define AL(i) (in_lds ? (LS[i] & 0xffff) : (int)A[i].l)
+#define AS(i) (in_lds ? (LS[i] >> 16) : (int)A[i].s)
+        int prereadloc = AQ(0);
+        double skipcost = oskipcost + (double)COV[0];
+        int maxdiff = omaxdiff - (int)COV[0]; if (maxdiff < 10) maxdiff = 10;
+        int testspace_en = 1;
+        if (lane == 0) { SA[0] = 0; S[0] = (double)AL(0); P[0] = VMX_NOPRE; }
+        __syncthreads();
+        double g_max_scores = (double)AL(0); int g_max_index = 0;
+        long long opcount = 0;
+        bool bailed = false;
+        for (int i = 1; i < n; ++i) {
+            const int qi = AQ(i); const long long ri = AR(i); const int li = AL(i); const int si = AS(i);
+            if (prereadloc < qi) {
+                if (((double)opcount / (double)i) > 1000.0) { bailed = true; break; }   // :24914 max_factor
+                for (int k = testspace_en; k < i; ++k) {
+                    int loc = vmx_insertpoint_score(S, S[k], k, SA);
+                    vmx_sarg_insert(SA, loc, k, lane);
+                }
+                testspace_en = i;
+                skipcost = oskipcost + (double)COV[i];
+                maxdiff = omaxdiff - (int)COV[i]; if (maxdiff < 10) maxdiff = 10;
+                prereadloc = qi;
+            }
+            const double dli = (double)li;
+            double max_scores = dli; int pre_index = VMX_NOPRE;
+            for (int base = testspace_en - 1; base >= 0; base -= 64) {
+                const int x = base - lane;
+                const bool valid = x >= 0;
+                int j = 0; double Sj = 0.0; double test = -1e300;
+                if (valid) {
+                    j = SA[x]; Sj = S[j];
+                    long long readgap, refgap, bonus;
+                    const int sj = AS(j);
+                    vmx_gap_geometry(qi, ri, si, li, AQ(j), AR(j), sj, AL(j), readgap, refgap, bonus);
+                    long long gapcost = readgap - refgap; if (gapcost < 0) gapcost = -gapcost;
+                    if (si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
+                        test = Sj + (double)bonus - s_gapcost[gapcost];
+                    } else {
+                        if (gapcost > extra_size) gapcost = extra_size;
+                        test = Sj - skipcost + (double)bonus - (double)tab.extra[gapcost];
+                    }
+                }
+                const double m_before = vmx_wave_excl_max_f64(test, max_scores);
+                const bool brk = !valid || !(Sj > (m_before - dli));
+                const unsigned long long mask = __ballot(brk);
+                const int first = mask ? (__ffsll((unsigned long long)mask) - 1) : 64;
+                opcount += first;
+                double best = lane < first ? test : -1e300; int bl = lane;
+                for (int off = 32; off > 0; off >>= 1) {
+                    double ob = __shfl_xor(best, off); int ol = __shfl_xor(bl, off);
+                    if (ob > best || (ob == best && ol < bl)) { best = ob; bl = ol; }
+                }
+                const int jb = __shfl(j, bl);
+                if (best > max_scores) { max_scores = best; pre_index = jb; }
+                if (first < 64) break;
+            }
+            if (lane == 0) { S[i] = max_scores; P[i] = pre_index; }
+            if (max_scores > g_max_scores) { g_max_scores = max_scores; g_max_index = i; }
+            __syncthreads();
+        }
+        if (!bailed) {
+            for (int k = testspace_en; k < n; ++k) {
+                int loc = vmx_insertpoint_score(S, S[k], k, SA);
+                vmx_sarg_insert(SA, loc, k, lane);
+            }
+        }
+        if (in_lds) {
+            for (int i = lane; i < n; i += 64) { S_out[a0 + i] = S[i]; P_out[a0 + i] = P[i]; SA_out[a0 + i] = SA[i]; }
+        }
+        if (lane == 0) { gmax_out[rd] = bailed ? -1 : g_max_index; opcount_out[rd] = opcount; }
+        __syncthreads();
+#undef AQ
+#undef AR
+#undef AL
+#undef AS
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ G1 select
+__global__ void k_chain_select(const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ aoff, const int64_t* __restrict__ readlens,
+                               int n_reads, const double* __restrict__ S, const int32_t* __restrict__ P, const int32_t* __restrict__ SA,
+                               const int64_t* __restrict__ gmax, const int32_t* __restrict__ need_reverse, int mode,
+                               char* __restrict__ scratch, const int64_t* __restrict__ scratch_off,
+                               int32_t* __restrict__ out_mapq, double* __restrict__ out_score, int32_t* __restrict__ out_npaths,
+                               int32_t* __restrict__ out_path_len, vmx_anchor* __restrict__ out_path_anchors) {
+    int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r >= n_reads) return;
+    const int64_t a0 = aoff[r];
+    const int n = (int)(aoff[r + 1] - a0);
+    vmx_select_out o;
+    o.mapq = 0; o.score = 0.0; o.n_paths = 0;
+    if (n > 2 && gmax[r] >= 0)
+        vmx_chain_select(anchors + a0, n, readlens[r], S + a0, P + a0, SA + a0, (int)gmax[r], mode, scratch + scratch_off[r],
+                         out_path_len + a0, out_path_anchors + a0, &o);
+    out_mapq[r] = o.mapq;
+    out_score[r] = need_reverse[r] ? -o.score : o.score;
+    out_npaths[r] = o.n_paths;
+}

@@ -1,0 +1,299 @@
+// k_dp.hip — hand-written gfx950 kernels for the three DP primitives of the extend stage.
+//
+//   k_edit_distance   E2  edlib.align(task='distance')   (/root/reference/src/vacmap/mammap_clrnano.py:19251)
+//   k_extend          E3  mp.k_cigar(.., 4,4,4,4, bw=100, zdropvalue=50)   (:2381, :2410, :2477, :2505)
+//   k_gapfill_fill/_trace  E5  mp.k_cigar(.., 2,-4, 4,2, 24,1, bw=-1, zdropvalue=-1, eqx)   (:21554, :21598)
+//
+// The native libraries behind those calls (vacmap-index==0.0.3, edlib==1.3.9) are not in /root/reference; the kernels
+// implement the build's normative spec VMX-DP / VMX-ED and are parity-tested bit-for-bit against
+// oracle/vmo_dp.cc. All three are integer, wave64, anti-diagonal ("one lane = one row of a 64-row stripe") kernels:
+// no MFMA (nothing here is a contraction); one wavefront per problem, problems taken grid-stride.
+#include "vmx_device.h"
+#include "vmx_kernels.h"
+
+// ------------------------------------------------------------------------------------------------ encode
+__global__ void k_encode(const char* __restrict__ in, uint8_t* __restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = vmx_code((uint8_t)in[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ E2 edit distance
+// Myers/Hyyro bit-vector, global distance. Pattern = query split into 64-row blocks; lane = block, step = anti-diagonal
+// (lane b works on text column step-b). Blocks beyond 64 are processed in passes; the horizontal deltas leaving block 63
+// of a pass are parked in `carry` (one int8 per text column) for the next pass.
+__global__ void __launch_bounds__(64) k_edit_distance(const uint8_t* __restrict__ qcodes, const int64_t* __restrict__ q_off,
+                                                      const uint8_t* __restrict__ tcodes, const int64_t* __restrict__ t_off,
+                                                      int8_t* __restrict__ carry_pool, const int64_t* __restrict__ carry_off,
+                                                      int n_prob, int64_t* __restrict__ out) {
+    const int lane = vmx_lane();
+    for (int p = blockIdx.x; p < n_prob; p += gridDim.x) {
+        const uint8_t* pat = qcodes + q_off[p];
+        const uint8_t* txt = tcodes + t_off[p];
+        const int m = (int)(q_off[p + 1] - q_off[p]);
+        const int n = (int)(t_off[p + 1] - t_off[p]);
+        int8_t* carry = carry_pool + carry_off[p];
+        if (m == 0 || n == 0) { if (lane == 0) out[p] = m == 0 ? n : m; continue; }
+        const int B = (m + 63) >> 6;
+        const int passes = (B + 63) >> 6;
+        long long score = m;
+        for (int ps = 0; ps < passes; ++ps) {
+            const int b = ps * 64 + lane;
+            const bool active_b = b < B;
+            int nact = B - ps * 64; if (nact > 64) nact = 64;
+            unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0;
+            if (active_b) {
+                int base = b << 6;
+                int lim = m - base; if (lim > 64) lim = 64;
+                for (int x = 0; x < lim; ++x) {
+                    uint8_t c = pat[base + x];
+                    unsigned long long bit = 1ULL << x;
+                    if (c == 0) p0 |= bit; else if (c == 1) p1 |= bit; else if (c == 2) p2 |= bit; else if (c == 3) p3 |= bit; else p4 |= bit;
+                }
+            }
+            unsigned long long Pv = ~0ULL, Mv = 0ULL;
+            const unsigned long long HIGH = (b == B - 1) ? (1ULL << ((m - 1) & 63)) : (1ULL << 63);
+            int hout_cur = 0; int c_cur = 0;
+            const int steps = n + nact - 1;
+            for (int t = 0; t < steps; ++t) {
+                int c_up = __shfl_up(c_cur, 1);
+                int h_up = __shfl_up(hout_cur, 1);
+                int hin;
+                if (lane == 0) {
+                    c_cur = t < n ? (int)txt[t] : 4;
+                    hin = ps == 0 ? 1 : (t < n ? (int)carry[t] : 0);
+                } else { c_cur = c_up; hin = h_up; }
+                const int j = t - lane;
+                if (active_b && j >= 0 && j < n) {
+                    unsigned long long Eq = c_cur == 0 ? p0 : c_cur == 1 ? p1 : c_cur == 2 ? p2 : c_cur == 3 ? p3 : p4;
+                    unsigned long long Xv = Eq | Mv;
+                    if (hin < 0) Eq |= 1ULL;
+                    unsigned long long Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+                    unsigned long long Ph = Mv | ~(Xh | Pv);
+                    unsigned long long Mh = Pv & Xh;
+                    int hout = 0;
+                    if (Ph & HIGH) hout = 1;
+                    if (Mh & HIGH) hout = -1;
+                    Ph <<= 1; Mh <<= 1;
+                    if (hin < 0) Mh |= 1ULL; else if (hin > 0) Ph |= 1ULL;
+                    Pv = Mh | ~(Xv | Ph);
+                    Mv = Ph & Xv;
+                    hout_cur = hout;
+                    if (b == B - 1) score += hout;
+                    else if (lane == 63) carry[j] = (int8_t)hout;
+                }
+            }
+            __syncthreads();   // carry[] of this pass visible to lane 0 of the next one
+        }
+        // the score lives in the lane that owns block B-1
+        long long s = __shfl(score, (B - 1) & 63);
+        if (lane == 0) out[p] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ E3 extension
+// VMX-DP-X: single affine (o,e), band |i-j| <= bw, anchored at (0,0), anti-diagonal x-drop. Ring buffers in LDS indexed by
+// i & (RING-1): H of d-1, d-2 and the diagonal being written, E/F of d-1 and current.
+#define VMX_EXT_RING 512
+__global__ void __launch_bounds__(64) k_extend(const uint8_t* __restrict__ tcodes, const int64_t* __restrict__ t_off,
+                                               const uint8_t* __restrict__ qcodes, const int64_t* __restrict__ q_off, int n_prob,
+                                               int match, int mismatch, int o, int e, int bw_in, int zdrop,
+                                               int32_t* __restrict__ out_te, int32_t* __restrict__ out_qe, int32_t* __restrict__ out_sc) {
+    __shared__ int sH[3][VMX_EXT_RING];
+    __shared__ int sE[2][VMX_EXT_RING];
+    __shared__ int sF[2][VMX_EXT_RING];
+    const int lane = vmx_lane();
+    const int RM = VMX_EXT_RING - 1;
+    for (int p = blockIdx.x; p < n_prob; p += gridDim.x) {
+        const uint8_t* T = tcodes + t_off[p];
+        const uint8_t* Q = qcodes + q_off[p];
+        const int tl = (int)(t_off[p + 1] - t_off[p]);
+        const int ql = (int)(q_off[p + 1] - q_off[p]);
+        int bw = bw_in; if (bw < 0 || bw > VMX_EXT_RING - 16) bw = VMX_EXT_RING - 16;   // host rejects wider bands
+        for (int x = lane; x < VMX_EXT_RING; x += 64) {
+            sH[0][x] = VMX_NEG; sH[1][x] = VMX_NEG; sH[2][x] = VMX_NEG;
+            sE[0][x] = VMX_NEG; sE[1][x] = VMX_NEG; sF[0][x] = VMX_NEG; sF[1][x] = VMX_NEG;
+        }
+        __syncthreads();
+        if (lane == 0) sH[0][0] = 0;    // diagonal 0
+        __syncthreads();
+        int M = 0, bi = 0, bj = 0, m_prev = 0;
+        for (int d = 1; d <= tl + ql; ++d) {
+            int ilo = d - ql; if (ilo < 0) ilo = 0;
+            int ihi = d < tl ? d : tl;
+            if (d - bw > 0) { int b2 = (d - bw + 1) >> 1; if (b2 > ilo) ilo = b2; }
+            { int b3 = (d + bw) >> 1; if (b3 < ihi) ihi = b3; }
+            if (ilo > ihi) break;
+            int* Hc = sH[d % 3]; const int* H1 = sH[(d + 2) % 3]; const int* H2 = sH[(d + 1) % 3];
+            int* Ec = sE[d & 1]; const int* E1 = sE[(d + 1) & 1];
+            int* Fc = sF[d & 1]; const int* F1 = sF[(d + 1) & 1];
+            int best_h = VMX_NEG, best_i = 0x7fffffff;
+            for (int i0 = ilo; i0 <= ihi; i0 += 64) {
+                int i = i0 + lane;
+                if (i <= ihi) {
+                    int j = d - i;
+                    int ev = VMX_NEG, fv = VMX_NEG, dv = VMX_NEG;
+                    if (i >= 1) { int hu = H1[(i - 1) & RM], eu = E1[(i - 1) & RM]; if (hu > VMX_NEG || eu > VMX_NEG) { int a = hu - o; ev = (a > eu ? a : eu) - e; } }
+                    if (j >= 1) { int hl = H1[i & RM], fl = F1[i & RM]; if (hl > VMX_NEG || fl > VMX_NEG) { int a = hl - o; fv = (a > fl ? a : fl) - e; } }
+                    if (i >= 1 && j >= 1) {
+                        int h2 = H2[(i - 1) & RM];
+                        if (h2 > VMX_NEG) { uint8_t a = T[i - 1], b = Q[j - 1]; dv = h2 + ((a == b && a < 4) ? match : mismatch); }
+                    }
+                    if (ev < VMX_NEG) ev = VMX_NEG;
+                    if (fv < VMX_NEG) fv = VMX_NEG;
+                    int h = dv > ev ? dv : ev; h = h > fv ? h : fv;
+                    Hc[i & RM] = h; Ec[i & RM] = ev; Fc[i & RM] = fv;
+                    if (h > best_h) { best_h = h; best_i = i; }
+                }
+            }
+            if (lane == 0) {
+                if (ilo - 1 >= 0) { Hc[(ilo - 1) & RM] = VMX_NEG; Ec[(ilo - 1) & RM] = VMX_NEG; Fc[(ilo - 1) & RM] = VMX_NEG; }
+                if (ihi + 1 <= tl) { Hc[(ihi + 1) & RM] = VMX_NEG; Ec[(ihi + 1) & RM] = VMX_NEG; Fc[(ihi + 1) & RM] = VMX_NEG; }
+            }
+            // wave max of (h, then smallest i)
+            for (int off = 32; off > 0; off >>= 1) {
+                int oh = __shfl_xor(best_h, off), oi = __shfl_xor(best_i, off);
+                if (oh > best_h || (oh == best_h && oi < best_i)) { best_h = oh; best_i = oi; }
+            }
+            const int m_d = best_h;
+            if (m_d > M) { M = m_d; bi = best_i; bj = d - best_i; }
+            __syncthreads();
+            if ((m_d > m_prev ? m_d : m_prev) < M - zdrop) break;
+            m_prev = m_d;
+        }
+        if (lane == 0) { out_te[p] = bi; out_qe[p] = bj; out_sc[p] = M; }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ E5 gap fill
+// VMX-DP-G: global dual-affine DP with a 7-bit traceback byte per cell (bits 0-2 source of H: 0 diag,1 E1,2 E2,3 F1,4 F2;
+// bit3 extE1, bit4 extE2, bit5 extF1, bit6 extF2). lane = target row inside a 64-row stripe, step = anti-diagonal of the
+// stripe; the row above a stripe comes from bnd[] (H, E1, E2 of the previous stripe's last row).
+// Traceback bytes are stored as tb[(stripe*(ql+63) + step)*64 + lane]: one coalesced 64-byte line per step.
+__device__ __forceinline__ int vmx_gap_open_row(int i, int o1, int e1, int o2, int e2) {   // H(i,0) = H(0,i), i >= 1
+    int a = -(o1 + i * e1), b = -(o2 + i * e2);
+    return a > b ? a : b;
+}
+
+__global__ void __launch_bounds__(64) k_gapfill_fill(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
+                                                     const vmx_dp_prob* __restrict__ probs, int n_prob, int match, int mismatch,
+                                                     int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb_pool,
+                                                     int32_t* __restrict__ bnd_pool, int32_t* __restrict__ out_score) {
+    const int lane = vmx_lane();
+    for (int p = blockIdx.x; p < n_prob; p += gridDim.x) {
+        const vmx_dp_prob pr = probs[p];
+        const uint8_t* T = tcodes + pr.t_off;
+        const uint8_t* Q = qcodes + pr.q_off;
+        const int tl = pr.tl, ql = pr.ql;
+        if (tl == 0 || ql == 0) { if (lane == 0) out_score[p] = (tl + ql) ? vmx_gap_open_row(tl + ql, o1, e1, o2, e2) : 0; continue; }
+        uint8_t* tb = tb_pool + pr.tb_off;
+        int32_t* bH = bnd_pool + pr.bnd_off;
+        int32_t* bE1 = bH + (ql + 1);
+        int32_t* bE2 = bE1 + (ql + 1);
+        const int W = ql + 63;
+        const int nstr = (tl + 63) >> 6;
+        for (int s = 0; s < nstr; ++s) {
+            const int i = s * 64 + lane + 1;
+            const bool row_active = i <= tl;
+            const int ti = row_active ? (int)T[i - 1] : 4;
+            int Hleft = vmx_gap_open_row(i, o1, e1, o2, e2);
+            int F1 = VMX_NEG, F2 = VMX_NEG;
+            int Hdiag = (i - 1 == 0) ? 0 : vmx_gap_open_row(i - 1, o1, e1, o2, e2);
+            int outH = 0, outE1 = VMX_NEG, outE2 = VMX_NEG;
+            uint8_t* tbs = tb + (size_t)s * (size_t)W * 64;
+            for (int t = 0; t < W; ++t) {
+                int upH = __shfl_up(outH, 1), upE1 = __shfl_up(outE1, 1), upE2 = __shfl_up(outE2, 1);
+                const int j = t - lane + 1;
+                if (lane == 0) {
+                    if (j <= ql) {
+                        if (s == 0) { upH = vmx_gap_open_row(j, o1, e1, o2, e2); upE1 = VMX_NEG; upE2 = VMX_NEG; }
+                        else { upH = bH[j]; upE1 = bE1[j]; upE2 = bE2[j]; }
+                    }
+                }
+                if (row_active && j >= 1 && j <= ql) {
+                    int b = 0;
+                    int a1 = upH - o1, a2 = upH - o2;
+                    if (upE1 > a1) b |= 8;
+                    if (upE2 > a2) b |= 16;
+                    int e1v = (a1 > upE1 ? a1 : upE1) - e1, e2v = (a2 > upE2 ? a2 : upE2) - e2;
+                    int c1 = Hleft - o1, c2 = Hleft - o2;
+                    if (F1 > c1) b |= 32;
+                    if (F2 > c2) b |= 64;
+                    F1 = (c1 > F1 ? c1 : F1) - e1; F2 = (c2 > F2 ? c2 : F2) - e2;
+                    int qc = (int)Q[j - 1];
+                    int h = Hdiag + ((ti == qc && ti < 4) ? match : mismatch);
+                    int src = 0;
+                    if (e1v > h) { h = e1v; src = 1; }
+                    if (e2v > h) { h = e2v; src = 2; }
+                    if (F1 > h) { h = F1; src = 3; }
+                    if (F2 > h) { h = F2; src = 4; }
+                    tbs[(size_t)t * 64 + lane] = (uint8_t)(b | src);
+                    Hdiag = upH; Hleft = h;
+                    outH = h; outE1 = e1v; outE2 = e2v;
+                    if (lane == 63) { bH[j] = h; bE1[j] = e1v; bE2[j] = e2v; }
+                    if (i == tl && j == ql) out_score[p] = h;
+                }
+            }
+            __syncthreads();   // bnd[] written by lane 63 is read by lane 0 of the next stripe
+        }
+    }
+}
+
+// serial traceback, one THREAD per problem (thousands of independent dependent-load chains hide each other's latency)
+__global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
+                                const vmx_dp_prob* __restrict__ probs, int n_prob, int eqx, const uint8_t* __restrict__ tb_pool,
+                                uint32_t* __restrict__ run_pool, char* __restrict__ cig_pool, int32_t* __restrict__ cig_len) {
+    int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (p >= n_prob) return;
+    const vmx_dp_prob pr = probs[p];
+    const uint8_t* T = tcodes + pr.t_off;
+    const uint8_t* Q = qcodes + pr.q_off;
+    const int tl = pr.tl, ql = pr.ql;
+    const uint8_t* tb = tb_pool + pr.tb_off;
+    uint32_t* runs = run_pool + pr.run_off;
+    char* cig = cig_pool + pr.cig_off;
+    const int W = ql + 63;
+    int nruns = 0; int cur_op = -1; uint32_t cur_len = 0;
+#define VMX_EMIT(op)                                                                   \
+    do {                                                                               \
+        if ((op) == cur_op) ++cur_len;                                                 \
+        else { if (cur_op >= 0) runs[nruns++] = (cur_len << 8) | (uint32_t)cur_op; cur_op = (op); cur_len = 1; } \
+    } while (0)
+    int i = tl, j = ql, state = 0;
+    while (i > 0 && j > 0) {
+        const int s = (i - 1) >> 6, l = (i - 1) & 63, t = (j - 1) + l;
+        const int b = tb[((size_t)s * (size_t)W + (size_t)t) * 64 + l];
+        if (state == 0) {
+            int src = b & 7;
+            if (src == 0) {
+                int op = 'M';
+                if (eqx) { uint8_t a = T[i - 1], c = Q[j - 1]; op = (a == c && a < 4) ? '=' : 'X'; }
+                VMX_EMIT(op); --i; --j;
+            } else state = src;
+        } else if (state <= 2) {
+            VMX_EMIT('D');
+            int ext = state == 1 ? (b >> 3) & 1 : (b >> 4) & 1;
+            --i; if (!ext) state = 0;
+        } else {
+            VMX_EMIT('I');
+            int ext = state == 3 ? (b >> 5) & 1 : (b >> 6) & 1;
+            --j; if (!ext) state = 0;
+        }
+    }
+    while (i > 0) { VMX_EMIT('D'); --i; }
+    while (j > 0) { VMX_EMIT('I'); --j; }
+    if (cur_op >= 0) runs[nruns++] = (cur_len << 8) | (uint32_t)cur_op;
+#undef VMX_EMIT
+    // runs were produced end-to-start: print them in reverse
+    int w = 0;
+    for (int r = nruns - 1; r >= 0; --r) {
+        uint32_t len = runs[r] >> 8; char op = (char)(runs[r] & 0xff);
+        char tmp[12]; int nd = 0;
+        do { tmp[nd++] = (char)('0' + len % 10); len /= 10; } while (len);
+        while (nd) cig[w++] = tmp[--nd];
+        cig[w++] = op;
+    }
+    cig[w] = 0;
+    cig_len[p] = w;
+}

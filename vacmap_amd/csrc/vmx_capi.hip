@@ -1,0 +1,352 @@
+// vmx_capi.hip — C-ABI entry points of libvacmapx.so (include/vacmapx.h): context, tables, DP and chain stage entries.
+// Everything that computes runs the HIP kernels of this directory on the context's stream; there is no CPU path.
+#include "vmx_host.h"
+#include "vmx_select.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+namespace vmx {
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    g_err = std::string("HIP error: ") + hipGetErrorString(e) + " at " + what + " (" + file + ":" + std::to_string(line) + ")";
+    return e == hipErrorOutOfMemory ? VM_ERR_OOM : VM_ERR_HIP;
+}
+}  // namespace vmx
+using namespace vmx;
+
+static inline int grid_for(const vm_ctx* c, int64_t n_items, int per_cu = 8) {
+    int64_t g = std::min<int64_t>(n_items, (int64_t)c->num_cu * per_cu);
+    return (int)std::max<int64_t>(g, 1);
+}
+template <class T> static T* host_alloc(size_t n) { return (T*)malloc(sizeof(T) * (n ? n : 1)); }
+
+extern "C" {
+
+const char* vm_last_error(void) { return g_err.c_str(); }
+const char* vm_version(void) { return "vacmapx 0.1 (gfx950)"; }
+void vm_free(void* p) { free(p); }
+
+void vm_params_default(vm_params* p, int mode) {
+    memset(p, 0, sizeof(*p));
+    p->mode = mode; p->check_num = 100; p->mid_occ = -1;
+    p->global_maxdiff = 50; p->local_maxdiff = 30; p->local_kmersize = 9;
+    if (mode == VM_MODE_L) { p->local_skipcost = 59.; p->global_skipcost = 40.; p->maxdivergence = 0.1; }
+    else if (mode == VM_MODE_H) { p->local_skipcost = 40.; p->global_skipcost = 40.; p->maxdivergence = 0.2; }
+    else { p->local_skipcost = 30.; p->global_skipcost = 30.; p->maxdivergence = 0.5; }
+    p->nodiscard = !(mode == VM_MODE_L || mode == VM_MODE_H);
+}
+
+int vm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int vm_ctx_create(int device_id, vm_ctx** out) {
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device: libvacmapx has no CPU fallback"); return VM_ERR_NO_DEVICE; }
+    if (device_id < 0 || device_id >= n) { set_error("bad device id"); return VM_ERR_ARG; }
+    VMX_HIP(hipSetDevice(device_id));
+    vm_ctx* c = new vm_ctx();
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; set_error("hipStreamCreate failed"); return VM_ERR_HIP; }
+    for (int i = 0; i < 24; ++i) (void)hipEventCreate(&c->ev[i]);
+    // cost tables -> one device blob
+    const HostTables& T = host_tables();
+    size_t o_extra = 0, o_rh = o_extra + T.extra.size() * 4, o_rr = o_rh + 400, o_lr = o_rr + 400;
+    size_t o_l2c = (o_lr + 400 + 15) & ~(size_t)15, o_l2i = o_l2c + T.log2cache.size() * 8, tot = o_l2i + T.log2int.size() * 8;
+    std::vector<char> blob(tot);
+    memcpy(&blob[o_extra], T.extra.data(), T.extra.size() * 4);
+    memcpy(&blob[o_rh], T.readgap_h.data(), 400); memcpy(&blob[o_rr], T.readgap_r.data(), 400); memcpy(&blob[o_lr], T.large_readgap.data(), 400);
+    memcpy(&blob[o_l2c], T.log2cache.data(), T.log2cache.size() * 8); memcpy(&blob[o_l2i], T.log2int.data(), T.log2int.size() * 8);
+    if (c->tab_buf.reserve(tot) < 0) { delete c; return VM_ERR_OOM; }
+    if (hipMemcpy(c->tab_buf.p, blob.data(), tot, hipMemcpyHostToDevice) != hipSuccess) { delete c; set_error("table upload failed"); return VM_ERR_HIP; }
+    char* base = (char*)c->tab_buf.p;
+    c->tables.extra = (const float*)(base + o_extra); c->tables.extra_n = (int)T.extra.size();
+    c->tables.readgap_h = (const float*)(base + o_rh); c->tables.readgap_r = (const float*)(base + o_rr);
+    c->tables.large_readgap = (const float*)(base + o_lr);
+    c->tables.log2cache = (const double*)(base + o_l2c); c->tables.log2cache_n = (int)T.log2cache.size();
+    c->tables.log2int = (const double*)(base + o_l2i);
+    *out = c;
+    return VM_OK;
+}
+
+void vm_ctx_destroy(vm_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < VMX_NBUF; ++i) c->b[i].release();
+    c->tab_buf.release();
+    for (int i = 0; i < 24; ++i) (void)hipEventDestroy(c->ev[i]);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int64_t vm_table(vm_ctx* c, int which, void** data) {
+    if (!c) return VM_ERR_NO_CTX;
+    const vmx_tables& t = c->tables;
+    const void* src; size_t n, es;
+    switch (which) {
+        case 0: src = t.extra; n = t.extra_n; es = 4; break;
+        case 1: src = t.readgap_h; n = 100; es = 4; break;
+        case 2: src = t.readgap_r; n = 100; es = 4; break;
+        case 3: src = t.large_readgap; n = 100; es = 4; break;
+        case 4: src = t.log2cache; n = t.log2cache_n; es = 8; break;
+        case 5: src = t.log2int; n = 1025; es = 8; break;
+        default: return VM_ERR_ARG;
+    }
+    *data = malloc(n * es);
+    VMX_HIP(hipMemcpy(*data, src, n * es, hipMemcpyDeviceToHost));
+    return (int64_t)n;
+}
+
+}  // extern "C"
+
+// upload concatenated ASCII + encode to codes in buf_codes; offsets uploaded to buf_off
+static int upload_encode(vm_ctx* c, const char* s, const int64_t* off, int64_t n, DevBuf& raw, DevBuf& codes, DevBuf& doff) {
+    const int64_t tot = off[n];
+    VMX_TRY(upload(raw, s, (size_t)tot, c->stream));
+    VMX_TRY(codes.reserve((size_t)tot + 64));
+    VMX_TRY(upload(doff, off, (size_t)n + 1, c->stream));
+    if (tot) hipLaunchKernelGGL(k_encode, dim3(grid_for(c, (tot + 255) / 256)), dim3(256), 0, c->stream, raw.as<char>(), codes.as<uint8_t>(), tot);
+    return 0;
+}
+
+extern "C" {
+
+int vm_edit_distance_batch(vm_ctx* c, int64_t n, const char* q, const int64_t* q_off, const char* t, const int64_t* t_off, int64_t** dist) {
+    if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
+    *dist = nullptr;
+    VMX_HIP(hipSetDevice(c->device));
+    VMX_TRY(upload_encode(c, q, q_off, n, c->b[0], c->b[1], c->b[2]));
+    VMX_TRY(upload_encode(c, t, t_off, n, c->b[3], c->b[4], c->b[5]));
+    VMX_TRY(c->b[6].reserve((size_t)t_off[n] + 64));     // carry pool: one int8 per text column, same offsets as t
+    VMX_TRY(c->b[7].reserve(sizeof(int64_t) * (size_t)(n + 1)));
+    if (n) hipLaunchKernelGGL(k_edit_distance, dim3(grid_for(c, n, 16)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[2].as<int64_t>(),
+                              c->b[4].as<uint8_t>(), c->b[5].as<int64_t>(), c->b[6].as<int8_t>(), c->b[5].as<int64_t>(), (int)n, c->b[7].as<int64_t>());
+    *dist = host_alloc<int64_t>((size_t)n);
+    VMX_TRY(download(*dist, c->b[7].p, (size_t)n, c->stream));
+    VMX_HIP(hipStreamSynchronize(c->stream));
+    VMX_HIP(hipGetLastError());
+    return VM_OK;
+}
+
+int64_t vm_edit_distance(vm_ctx* c, const char* q, int64_t ql, const char* t, int64_t tl) {
+    int64_t qo[2] = {0, ql}, to[2] = {0, tl};
+    int64_t* d = nullptr;
+    int rc = vm_edit_distance_batch(c, 1, q, qo, t, to, &d);
+    if (rc < 0) return rc;
+    int64_t v = d[0]; free(d);
+    return v;
+}
+
+int vm_k_extend_batch(vm_ctx* c, int match, int mismatch, int o, int e, int bw, int zdrop, int64_t n, const char* t, const int64_t* t_off,
+                      const char* q, const int64_t* q_off, int32_t** t_e, int32_t** q_e, int32_t** score) {
+    if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
+    if (bw > 496) { set_error("vm_k_extend_batch: band wider than 496 unsupported"); return VM_ERR_UNSUPPORTED; }
+    VMX_HIP(hipSetDevice(c->device));
+    VMX_TRY(upload_encode(c, t, t_off, n, c->b[0], c->b[1], c->b[2]));
+    VMX_TRY(upload_encode(c, q, q_off, n, c->b[3], c->b[4], c->b[5]));
+    VMX_TRY(c->b[6].reserve(sizeof(int32_t) * 3 * (size_t)(n + 1)));
+    int32_t* d_te = c->b[6].as<int32_t>(); int32_t* d_qe = d_te + n; int32_t* d_sc = d_qe + n;
+    if (n) hipLaunchKernelGGL(k_extend, dim3(grid_for(c, n, 16)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[2].as<int64_t>(),
+                              c->b[4].as<uint8_t>(), c->b[5].as<int64_t>(), (int)n, match, mismatch, o, e, bw, zdrop, d_te, d_qe, d_sc);
+    *t_e = host_alloc<int32_t>((size_t)n); *q_e = host_alloc<int32_t>((size_t)n); *score = host_alloc<int32_t>((size_t)n);
+    VMX_TRY(download(*t_e, d_te, (size_t)n, c->stream)); VMX_TRY(download(*q_e, d_qe, (size_t)n, c->stream));
+    VMX_TRY(download(*score, d_sc, (size_t)n, c->stream));
+    VMX_HIP(hipStreamSynchronize(c->stream));
+    VMX_HIP(hipGetLastError());
+    return VM_OK;
+}
+
+int vm_k_cigar_batch(vm_ctx* c, const vm_score* sc, int eqx, int64_t n, const char* t, const int64_t* t_off, const char* q,
+                     const int64_t* q_off, char** cigars, int64_t** cigar_off, int32_t** scores) {
+    if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
+    VMX_HIP(hipSetDevice(c->device));
+    VMX_TRY(upload_encode(c, t, t_off, n, c->b[0], c->b[1], c->b[2]));
+    VMX_TRY(upload_encode(c, q, q_off, n, c->b[3], c->b[4], c->b[5]));
+    std::vector<vmx_dp_prob> probs((size_t)n);
+    int64_t tb = 0, bnd = 0, run = 0, cig = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        vmx_dp_prob& p = probs[i];
+        p.t_off = t_off[i]; p.q_off = q_off[i]; p.tl = (int32_t)(t_off[i + 1] - t_off[i]); p.ql = (int32_t)(q_off[i + 1] - q_off[i]);
+        p.tb_off = tb; p.bnd_off = bnd; p.run_off = run; p.cig_off = cig;
+        tb += (int64_t)((p.tl + 63) / 64) * (p.ql + 63) * 64;
+        bnd += 3 * (int64_t)(p.ql + 1); run += (int64_t)p.tl + p.ql + 2; cig += 2 * ((int64_t)p.tl + p.ql) + 16;
+    }
+    VMX_TRY(upload(c->b[6], probs.data(), (size_t)n, c->stream));
+    VMX_TRY(c->b[7].reserve((size_t)tb + 64)); VMX_TRY(c->b[8].reserve(sizeof(int32_t) * (size_t)(bnd + 4)));
+    VMX_TRY(c->b[9].reserve(sizeof(uint32_t) * (size_t)(run + 4))); VMX_TRY(c->b[10].reserve((size_t)cig + 16));
+    VMX_TRY(c->b[11].reserve(sizeof(int32_t) * 2 * (size_t)(n + 1)));
+    int32_t* d_score = c->b[11].as<int32_t>(); int32_t* d_len = d_score + n;
+    if (n) {
+        hipLaunchKernelGGL(k_gapfill_fill, dim3(grid_for(c, n, 16)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[4].as<uint8_t>(),
+                           c->b[6].as<vmx_dp_prob>(), (int)n, sc->match, sc->mismatch, sc->o1, sc->e1, sc->o2, sc->e2, c->b[7].as<uint8_t>(),
+                           c->b[8].as<int32_t>(), d_score);
+        hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[4].as<uint8_t>(),
+                           c->b[6].as<vmx_dp_prob>(), (int)n, eqx, c->b[7].as<uint8_t>(), c->b[9].as<uint32_t>(), c->b[10].as<char>(), d_len);
+    }
+    std::vector<char> hc((size_t)cig + 16); std::vector<int32_t> hl((size_t)n);
+    *scores = host_alloc<int32_t>((size_t)n);
+    VMX_TRY(download(hc.data(), c->b[10].p, (size_t)cig, c->stream));
+    VMX_TRY(download(hl.data(), d_len, (size_t)n, c->stream));
+    VMX_TRY(download(*scores, d_score, (size_t)n, c->stream));
+    VMX_HIP(hipStreamSynchronize(c->stream));
+    VMX_HIP(hipGetLastError());
+    *cigar_off = host_alloc<int64_t>((size_t)n + 1);
+    int64_t tot = 0;
+    for (int64_t i = 0; i < n; ++i) { (*cigar_off)[i] = tot; tot += hl[i] + 1; }
+    (*cigar_off)[n] = tot;
+    *cigars = host_alloc<char>((size_t)tot + 1);
+    for (int64_t i = 0; i < n; ++i) { memcpy(*cigars + (*cigar_off)[i], hc.data() + probs[i].cig_off, (size_t)hl[i]); (*cigars)[(*cigar_off)[i] + hl[i]] = 0; }
+    return VM_OK;
+}
+
+int vm_k_cigar(vm_ctx* c, const char* t, int64_t tl, const char* q, int64_t ql, const vm_score* sc, int bw, int zdrop, int eqx, vm_cigar_out* out) {
+    memset(out, 0, sizeof(*out));
+    int64_t to[2] = {0, tl}, qo[2] = {0, ql};
+    if (zdrop < 0) {   // global end-to-end (:21554)
+        char* cg = nullptr; int64_t* co = nullptr; int32_t* s = nullptr;
+        int rc = vm_k_cigar_batch(c, sc, eqx, 1, t, to, q, qo, &cg, &co, &s);
+        if (rc < 0) return rc;
+        out->cigar = cg; out->q_e = (int32_t)ql; out->t_e = (int32_t)tl; out->score = s[0];
+        free(co); free(s);
+        return VM_OK;
+    }
+    if (sc->o1 != sc->o2 || sc->e1 != sc->e2) { set_error("vm_k_cigar: z-drop extension needs identical gap pieces (the reference calls it with 4,4,4,4)"); return VM_ERR_UNSUPPORTED; }
+    int32_t *te = nullptr, *qe = nullptr, *s = nullptr;
+    int rc = vm_k_extend_batch(c, sc->match, sc->mismatch, sc->o1, sc->e1, bw, zdrop, 1, t, to, q, qo, &te, &qe, &s);
+    if (rc < 0) return rc;
+    out->cigar = (char*)calloc(1, 1); out->t_e = te[0]; out->q_e = qe[0]; out->score = s[0];
+    free(te); free(qe); free(s);
+    return VM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ global chain stage
+void vm_chains_out_free(vm_chains_out* o) {
+    free(o->need_reverse); free(o->mapq); free(o->score); free(o->fast_used); free(o->read_path_off); free(o->path_off);
+    free(o->path_anchors); free(o->S); free(o->P); free(o->S_arg); free(o->gmax); free(o->opcount);
+    memset(o, 0, sizeof(*o));
+}
+
+int vm_chain_global_batch(vm_ctx* c, const vm_params* prm, int kmersize, int64_t n, const int64_t* anchors, const int64_t* aoff,
+                          const int64_t* readlens, int want_raw, vm_chains_out* out) {
+    memset(out, 0, sizeof(*out));
+    if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
+    if (prm->mode == VM_MODE_R) { set_error("mode R chain variant not built yet"); return VM_ERR_UNSUPPORTED; }
+    if (prm->global_maxdiff > 62) { set_error("global_maxdiff > 62 unsupported"); return VM_ERR_UNSUPPORTED; }
+    VMX_HIP(hipSetDevice(c->device));
+    const int64_t tot = aoff[n];
+    DevBuf &d_rows = c->b[0], &d_aoff = c->b[1], &d_len = c->b[2], &d_keys = c->b[3], &d_koff = c->b[4], &d_sorted = c->b[5], &d_flip = c->b[6];
+    DevBuf &d_S = c->b[7], &d_P = c->b[8], &d_SA = c->b[9], &d_cov = c->b[10], &d_gmax = c->b[11], &d_opc = c->b[12], &d_rl = c->b[13];
+    DevBuf &d_gap = c->b[14], &d_scr = c->b[15], &d_soff = c->b[16], &d_res = c->b[17], &d_plen = c->b[18], &d_prow = c->b[19];
+    VMX_TRY(upload(d_rows, anchors, (size_t)tot * 4, c->stream));
+    VMX_TRY(upload(d_aoff, aoff, (size_t)n + 1, c->stream));
+    VMX_TRY(upload(d_len, readlens, (size_t)n, c->stream));
+    std::vector<int64_t> koff((size_t)n + 1), soff((size_t)n + 1);
+    int64_t kt = 0, st = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        int64_t m = aoff[r + 1] - aoff[r]; int64_t N = 1; while (N < m) N <<= 1;
+        koff[r] = kt; kt += N;
+        soff[r] = st; st += (vmx_select_scratch_bytes(m) + 15) & ~(int64_t)15;
+    }
+    koff[n] = kt; soff[n] = st;
+    VMX_TRY(d_keys.reserve(sizeof(uint64_t) * (size_t)(kt + 1)));
+    VMX_TRY(upload(d_koff, koff.data(), (size_t)n + 1, c->stream));
+    VMX_TRY(d_sorted.reserve(sizeof(vmx_anchor) * (size_t)(tot + 1)));
+    VMX_TRY(d_flip.reserve(sizeof(int32_t) * (size_t)(n + 1)));
+    if (n) hipLaunchKernelGGL(k_flip_sort, dim3(grid_for(c, n, 8)), dim3(256), 0, c->stream, d_rows.as<int64_t>(), d_aoff.as<int64_t>(),
+                              d_len.as<int64_t>(), (int)n, d_keys.as<uint64_t>(), d_koff.as<int64_t>(), d_sorted.as<vmx_anchor>(), d_flip.as<int32_t>());
+    VMX_TRY(d_S.reserve(sizeof(double) * (size_t)(tot + 1))); VMX_TRY(d_P.reserve(sizeof(int32_t) * (size_t)(tot + 1)));
+    VMX_TRY(d_SA.reserve(sizeof(int32_t) * (size_t)(tot + 1))); VMX_TRY(d_cov.reserve((size_t)tot + 16));
+    VMX_TRY(d_gmax.reserve(sizeof(int64_t) * (size_t)(n + 1))); VMX_TRY(d_opc.reserve(sizeof(int64_t) * (size_t)(n + 1)));
+    // gapcost_list (:24843-24846): 0.01*k*g + 0.5*log2(g), evaluated in double exactly like the reference
+    const HostTables& T = host_tables();
+    std::vector<double> gap(64, 0.0);
+    for (int g = 1; g <= prm->global_maxdiff; ++g) gap[g] = (0.01 * kmersize * g + 0.5 * T.log2int[g]);
+    VMX_TRY(upload(d_gap, gap.data(), 64, c->stream));
+    // bucket the reads by anchor count so that each launch asks for no more LDS than it needs (160 KiB per CU on gfx950)
+    const int caps[4] = {768, 1536, 3072, 4736};
+    std::vector<int32_t> lists[5];
+    std::vector<char> fastflag((size_t)n, 0);
+    for (int64_t r = 0; r < n; ++r) {
+        int64_t m = aoff[r + 1] - aoff[r];
+        if ((double)m / (double)readlens[r] > 5.0) { fastflag[r] = 1; continue; }   // fast_enable (:23570)
+        int bk = 4; for (int k = 0; k < 4; ++k) if (m <= caps[k]) { bk = k; break; }
+        lists[bk].push_back((int32_t)r);
+    }
+    std::vector<int32_t> rl; std::vector<int64_t> rl_off(6, 0);
+    for (int k = 0; k < 5; ++k) { rl_off[k] = (int64_t)rl.size(); rl.insert(rl.end(), lists[k].begin(), lists[k].end()); }
+    rl_off[5] = (int64_t)rl.size();
+    VMX_TRY(upload(d_rl, rl.data(), rl.size(), c->stream));
+    VMX_HIP(hipMemsetAsync(d_gmax.p, 0xff, sizeof(int64_t) * (size_t)n, c->stream));   // -1 = needs GC-fast
+    for (int k = 0; k < 5; ++k) {
+        int cnt = (int)lists[k].size();
+        if (!cnt) continue;
+        int cap = k < 4 ? caps[k] : 0;
+        size_t shmem = (size_t)cap * VMX_GC_BYTES_PER_ANCHOR + 64;
+#ifndef VMX_EMU
+        if (shmem > 48 * 1024) VMX_HIP(hipFuncSetAttribute((const void*)k_chain_global, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+#endif
+        hipLaunchKernelGGL(k_chain_global, dim3(grid_for(c, cnt, 8)), dim3(64), shmem, c->stream, d_sorted.as<vmx_anchor>(), d_aoff.as<int64_t>(),
+                           d_rl.as<int32_t>() + rl_off[k], cnt, cap, c->tables, d_gap.as<double>(), prm->global_skipcost, prm->global_maxdiff,
+                           1000, d_S.as<double>(), d_P.as<int32_t>(), d_SA.as<int32_t>(), d_cov.as<uint8_t>(), d_gmax.as<int64_t>(), d_opc.as<int64_t>());
+    }
+    // TODO(G3): reads with gmax == -1 (fast_enable or bail-out) go through GC-fast; until that kernel lands they are reported
+    VMX_TRY(d_scr.reserve((size_t)st + 64));
+    VMX_TRY(upload(d_soff, soff.data(), (size_t)n + 1, c->stream));
+    VMX_TRY(d_res.reserve((sizeof(double) + 2 * sizeof(int32_t)) * (size_t)(n + 1) + 64));
+    double* d_score = d_res.as<double>(); int32_t* d_mapq = (int32_t*)(d_score + n + 1); int32_t* d_np = d_mapq + n + 1;
+    VMX_TRY(d_plen.reserve(sizeof(int32_t) * (size_t)(tot + 1))); VMX_TRY(d_prow.reserve(sizeof(vmx_anchor) * (size_t)(tot + 1)));
+    if (n) hipLaunchKernelGGL(k_chain_select, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, d_sorted.as<vmx_anchor>(), d_aoff.as<int64_t>(),
+                              d_len.as<int64_t>(), (int)n, d_S.as<double>(), d_P.as<int32_t>(), d_SA.as<int32_t>(), d_gmax.as<int64_t>(),
+                              d_flip.as<int32_t>(), prm->mode, d_scr.as<char>(), d_soff.as<int64_t>(), d_mapq, d_score, d_np,
+                              d_plen.as<int32_t>(), d_prow.as<vmx_anchor>());
+    // download
+    std::vector<int32_t> h_np((size_t)n), h_plen((size_t)tot);
+    std::vector<vmx_anchor> h_prow((size_t)tot);
+    out->need_reverse = host_alloc<int32_t>((size_t)n); out->mapq = host_alloc<int32_t>((size_t)n); out->score = host_alloc<double>((size_t)n);
+    out->fast_used = host_alloc<int32_t>((size_t)n); out->gmax = host_alloc<int64_t>((size_t)n); out->opcount = host_alloc<int64_t>((size_t)n);
+    VMX_TRY(download(out->need_reverse, d_flip.p, (size_t)n, c->stream)); VMX_TRY(download(out->mapq, d_mapq, (size_t)n, c->stream));
+    VMX_TRY(download(out->score, d_score, (size_t)n, c->stream)); VMX_TRY(download(h_np.data(), d_np, (size_t)n, c->stream));
+    VMX_TRY(download(h_plen.data(), d_plen.p, (size_t)tot, c->stream)); VMX_TRY(download(h_prow.data(), d_prow.p, (size_t)tot, c->stream));
+    VMX_TRY(download(out->gmax, d_gmax.p, (size_t)n, c->stream)); VMX_TRY(download(out->opcount, d_opc.p, (size_t)n, c->stream));
+    std::vector<int32_t> hP, hSA;
+    if (want_raw) {
+        out->S = host_alloc<double>((size_t)tot); out->P = host_alloc<int64_t>((size_t)tot); out->S_arg = host_alloc<int64_t>((size_t)tot);
+        hP.resize((size_t)tot); hSA.resize((size_t)tot);
+        VMX_TRY(download(out->S, d_S.p, (size_t)tot, c->stream)); VMX_TRY(download(hP.data(), d_P.p, (size_t)tot, c->stream));
+        VMX_TRY(download(hSA.data(), d_SA.p, (size_t)tot, c->stream));
+    }
+    VMX_HIP(hipStreamSynchronize(c->stream));
+    VMX_HIP(hipGetLastError());
+    if (want_raw) for (int64_t i = 0; i < tot; ++i) { out->P[i] = hP[i]; out->S_arg[i] = hSA[i]; }
+    int64_t npaths = 0, nrows = 0;
+    for (int64_t r = 0; r < n; ++r) { npaths += h_np[r]; for (int p = 0; p < h_np[r]; ++p) nrows += h_plen[aoff[r] + p]; out->fast_used[r] = fastflag[r] || out->gmax[r] == -1; }
+    out->read_path_off = host_alloc<int64_t>((size_t)n + 1); out->path_off = host_alloc<int64_t>((size_t)npaths + 1);
+    out->path_anchors = host_alloc<int64_t>((size_t)nrows * 4);
+    int64_t pi = 0, ro = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        out->read_path_off[r] = pi;
+        int64_t src = aoff[r];
+        for (int p = 0; p < h_np[r]; ++p) {
+            out->path_off[pi++] = ro;
+            for (int x = 0; x < h_plen[aoff[r] + p]; ++x) {
+                const vmx_anchor& a = h_prow[src++];
+                int64_t* o = out->path_anchors + 4 * ro++;
+                o[0] = a.q; o[1] = a.r; o[2] = a.s; o[3] = a.l;
+            }
+        }
+    }
+    out->read_path_off[n] = pi; out->path_off[pi] = ro;
+    return VM_OK;
+}
+
+}  // extern "C"

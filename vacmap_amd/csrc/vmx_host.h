@@ -1,0 +1,88 @@
+// vmx_host.h — host-side internals of libvacmapx (context, buffers, kernel prototypes).
+#ifndef VMX_HOST_H
+#define VMX_HOST_H
+#include "vmx_device.h"
+#include "vmx_kernels.h"
+#include "../../include/vacmapx.h"
+#include <string>
+#include <vector>
+
+namespace vmx {
+
+void set_error(const std::string& s);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define VMX_HIP(expr)                                                              \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) return vmx::hip_fail(_e, #expr, __FILE__, __LINE__);  \
+    } while (0)
+#define VMX_TRY(expr) do { int _rc = (expr); if (_rc < 0) return _rc; } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap && p) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct HostTables {
+    std::vector<float> extra, readgap_h, readgap_r, large_readgap;
+    std::vector<double> log2cache, log2int;
+};
+const HostTables& host_tables();
+
+template <class T> int upload(DevBuf& b, const T* host, size_t n, hipStream_t st) {
+    VMX_TRY(b.reserve(sizeof(T) * (n ? n : 1)));
+    if (n) VMX_HIP(hipMemcpyAsync(b.p, host, sizeof(T) * n, hipMemcpyHostToDevice, st));
+    return 0;
+}
+template <class T> int download(T* host, const void* dev, size_t n, hipStream_t st) {
+    if (n) VMX_HIP(hipMemcpyAsync(host, dev, sizeof(T) * n, hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
+}  // namespace vmx
+
+enum { VMX_NBUF = 64 };
+struct vm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    vmx_tables tables{};
+    vmx::DevBuf tab_buf;
+    vmx::DevBuf b[VMX_NBUF];     // scratch buffers reused by the entry points (grow-only)
+    int num_cu = 256;
+    hipEvent_t ev[24];
+};
+
+// ---- kernels (k_dp.hip, k_chain.hip, ...) ----
+__global__ void k_encode(const char* in, uint8_t* out, int64_t n);
+__global__ void k_edit_distance(const uint8_t* qcodes, const int64_t* q_off, const uint8_t* tcodes, const int64_t* t_off,
+                                int8_t* carry_pool, const int64_t* carry_off, int n_prob, int64_t* out);
+__global__ void k_extend(const uint8_t* tcodes, const int64_t* t_off, const uint8_t* qcodes, const int64_t* q_off, int n_prob,
+                         int match, int mismatch, int o, int e, int bw_in, int zdrop, int32_t* out_te, int32_t* out_qe, int32_t* out_sc);
+__global__ void k_gapfill_fill(const uint8_t* tcodes, const uint8_t* qcodes, const vmx_dp_prob* probs, int n_prob, int match,
+                               int mismatch, int o1, int e1, int o2, int e2, uint8_t* tb_pool, int32_t* bnd_pool, int32_t* out_score);
+__global__ void k_gapfill_trace(const uint8_t* tcodes, const uint8_t* qcodes, const vmx_dp_prob* probs, int n_prob, int eqx,
+                                const uint8_t* tb_pool, uint32_t* run_pool, char* cig_pool, int32_t* cig_len);
+__global__ void k_flip_sort(const int64_t* rows, const int64_t* aoff, const int64_t* readlens, int n_reads, uint64_t* key_pool,
+                            const int64_t* key_off, vmx_anchor* sorted, int32_t* need_reverse);
+__global__ void k_chain_global(const vmx_anchor* anchors, const int64_t* aoff, const int32_t* rlist, int nlist, int lds_cap,
+                               vmx_tables tab, const double* gapcost_list, double oskipcost, int omaxdiff, int maxgap,
+                               double* S_out, int32_t* P_out, int32_t* SA_out, uint8_t* cov_pool, int64_t* gmax_out, int64_t* opcount_out);
+__global__ void k_chain_select(const vmx_anchor* anchors, const int64_t* aoff, const int64_t* readlens, int n_reads, const double* S,
+                               const int32_t* P, const int32_t* SA, const int64_t* gmax, const int32_t* need_reverse, int mode,
+                               char* scratch, const int64_t* scratch_off, int32_t* out_mapq, double* out_score, int32_t* out_npaths,
+                               int32_t* out_path_len, vmx_anchor* out_path_anchors);
+
+#endif

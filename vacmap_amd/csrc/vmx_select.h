@@ -1,0 +1,155 @@
+// vmx_select.h — chain peeling, primary/MAPQ and secondary selection (serial per read; host+device).
+// Follows hit2work_1 (/root/reference/src/vacmap/mammap_clrnano.py:23588-23707, nested select_secondary_alignment
+// :23505-23538) and decode_hit (:23981-24020). np.argsort is taken as stable.
+// Mode deltas: accept threshold 60 (H) / 40 (L,S,R) (:23650, mammap_ccs.py:23649); secondary min span 50 / 100 (R).
+#ifndef VMX_SELECT_H
+#define VMX_SELECT_H
+#include "vmx_kernels.h"
+#include <math.h>
+
+#ifndef __host__
+#define __host__
+#define __device__
+#endif
+
+struct vmx_select_out { int mapq; double score; int n_paths; };
+
+__host__ __device__ inline int64_t vmx_select_scratch_bytes(int64_t n) { return 8 * n + 4 * (7 * n + 8) + n + 64; }
+
+// |A ∩ B| of two strictly descending int lists
+__host__ __device__ inline int vmx_desc_intersect(const int* a, int na, const int* b, int nb) {
+    int i = 0, j = 0, c = 0;
+    while (i < na && j < nb) {
+        if (a[i] == b[j]) { ++c; ++i; ++j; }
+        else if (a[i] > b[j]) ++i;
+        else ++j;
+    }
+    return c;
+}
+
+__host__ __device__ inline void vmx_chain_select(const vmx_anchor* A, int n, int64_t L, const double* S, const int32_t* P,
+                                                 const int32_t* SA, int gmax, int mode, char* scratch, int32_t* out_path_len,
+                                                 vmx_anchor* out_rows, vmx_select_out* o) {
+    (void)L;
+    double* cscore = (double*)scratch;
+    int* cidx = (int*)(cscore + n);
+    int* coff = cidx + n;            // n+1
+    int* order = coff + n + 1;       // n
+    int* bins = order + n;           // n
+    int* boff = bins + n;            // n+1
+    int* prim = boff + n + 1;        // n
+    int* sec = prim + n;             // n
+    unsigned char* used = (unsigned char*)(sec + n + 4);
+    for (int i = 0; i < n; ++i) used[i] = 0;
+    const double accept = (mode == 0) ? 60.0 : 40.0;
+    const int sec_min_span = (mode == 3) ? 100 : 50;
+    int nch = 0, w = 0;
+    bool hit = false;
+    const double scores = S[gmax];
+    {
+        int take = gmax; used[take] = 1; double score = S[take]; int start = w;
+        while (true) { cidx[w++] = take; if (P[take] == VMX_NOPRE) break; take = P[take]; used[take] = 1; }
+        if (score > 40) { hit = true; cscore[nch] = score; coff[nch] = start; ++nch; } else w = start;
+    }
+    const double max_scores = scores > 0 ? scores : 0;
+    if (!hit) { o->mapq = 0; o->score = 0; o->n_paths = 0; return; }   // hit == False -> unmapped whatever follows
+    for (int x = n - 1; x >= 0; --x) {
+        int take = SA[x];
+        if (used[take]) continue;
+        int start = w; used[take] = 1; double score = S[take];
+        while (true) {
+            cidx[w++] = take;
+            if (P[take] == VMX_NOPRE) break;
+            take = P[take];
+            if (used[take]) { score = score - S[take]; break; }
+            used[take] = 1;
+        }
+        if (score > 40) { cscore[nch] = score; coff[nch] = start; ++nch; } else w = start;
+    }
+    coff[nch] = w;
+    if (!(max_scores > accept)) { o->mapq = 0; o->score = 0; o->n_paths = 0; return; }
+    // order = argsort(scores)[::-1] (stable): descending score, equal scores in descending index
+    for (int c = 0; c < nch; ++c) {
+        int pos = 0;
+        while (pos < c && cscore[order[pos]] > cscore[c]) ++pos;
+        for (int t = c; t > pos; --t) order[t] = order[t - 1];
+        order[pos] = c;
+    }
+    if (order[0] != 0) { for (int i = 0; i < nch; ++i) if (order[i] == 0) { order[i] = order[0]; order[0] = 0; break; } }
+    // read-position bins (//100) per chain, unique, descending
+    {
+        int bw = 0;
+        for (int c = 0; c < nch; ++c) {
+            boff[c] = bw; int last = -1;
+            for (int t = coff[c]; t < coff[c + 1]; ++t) { int b = A[cidx[t]].q / 100; if (b != last) { bins[bw++] = b; last = b; } }
+        }
+        boff[nch] = bw;
+    }
+    int np = 0; prim[np++] = order[0];
+    double f2 = 0.0;
+    for (int oi = 1; oi < nch; ++oi) {
+        int c = order[oi]; int lc = boff[c + 1] - boff[c];
+        double maxov = 0.0; int prefer = 0;
+        for (int p = 0; p < np; ++p) {
+            int pc = prim[p]; int lp = boff[pc + 1] - boff[pc];
+            int inter = vmx_desc_intersect(bins + boff[c], lc, bins + boff[pc], lp);
+            double ov = (double)inter / (double)(lc < lp ? lc : lp);
+            if (ov > maxov) { maxov = ov; prefer = p; }
+        }
+        if (maxov < 0.5) prim[np++] = c;
+        else if (prefer == 0) { f2 = cscore[c]; break; }   // = primary_scores_List[0][1]; later members never matter
+    }
+    {
+        const double f1 = cscore[0];
+        const double mlen = (double)(coff[1] - coff[0]);
+        double v = 40 * (1 - f2 / f1);
+        double mm = mlen / 10; if (mm > 1.0) mm = 1.0;
+        v = v * mm;
+        v = v * log(f1);
+        long long iv = (long long)v;
+        o->mapq = (int)(iv < 60 ? iv : 60);
+    }
+    // select_secondary_alignment
+    int nsec = 0;
+    if (nch > 1) {
+        const int b0 = coff[0], b1 = coff[1];   // best path, descending q
+        for (int oi = 1; oi < nch; ++oi) {
+            int c = order[oi];
+            int en = A[cidx[coff[c]]].q, st = A[cidx[coff[c + 1] - 1]].q;
+            if (en - st < sec_min_span) continue;
+            double v_en = 0.0, v_st = 0.0;
+            for (int pass = 0; pass < 2; ++pass) {   // loc2score[x] = S of the best-path anchor with the largest q <= x (0 if none)
+                int x = pass == 0 ? en : st;
+                int lo = b0, hi = b1;   // first t in [b0,b1) with q <= x (q descending)
+                while (lo < hi) { int mid = (lo + hi) >> 1; if (A[cidx[mid]].q <= x) hi = mid; else lo = mid + 1; }
+                double v = lo < b1 ? S[cidx[lo]] : 0.0;
+                if (pass == 0) v_en = v; else v_st = v;
+            }
+            double f1s = v_en - v_st; if (f1s < 1.0) f1s = 1.0;
+            double f2s = cscore[c];
+            double df = f1s - f2s; if (df < 0) df = -df;
+            if (f2s / f1s > 0.9 || df < 40) {
+                bool skip = false;
+                for (int s2 = 0; s2 < nsec; ++s2) {
+                    int pc = sec[s2];
+                    int pen = A[cidx[coff[pc]]].q, pst = A[cidx[coff[pc + 1] - 1]].q;
+                    int lo = pst > st ? pst : st, hi = en < pen ? en : pen;
+                    int ov = hi - lo; if (ov < 0) ov = 0;
+                    if (((double)ov / (double)(en - st)) > 0.5) { skip = true; break; }
+                }
+                if (!skip) sec[nsec++] = c;
+            }
+        }
+    }
+    // decode_hit: return_path_list = [best path] + secondaries
+    int wr = 0;
+    for (int pi = 0; pi <= nsec; ++pi) {
+        int c = pi == 0 ? 0 : sec[pi - 1];
+        out_path_len[pi] = coff[c + 1] - coff[c];
+        for (int t = coff[c]; t < coff[c + 1]; ++t) out_rows[wr++] = A[cidx[t]];
+    }
+    o->n_paths = nsec + 1;
+    o->score = cscore[0];
+}
+
+#endif
