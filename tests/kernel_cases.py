@@ -114,3 +114,61 @@ def check_chain_global_golden(ctx, O, golden, cases=('A', 'B', 'C', 'D')):
             # and against the oracle run live (same inputs)
             o = O.decode_hit(al[ri], rl[ri], c['k'], oprm)
             assert [p.tolist() for p in o['paths']] == [p.tolist() for p in g['paths']]
+
+
+def _case_index(ctx, O, meta, arrays, cid):
+    from vacmap_amd.lib import Index
+    c = meta[cid]
+    contigs = [arrays['%s_contig%d' % (cid, i)].tobytes().decode() for i in range(len(c['names']))]
+    return Index.from_seqs(ctx, c['names'], contigs, k=c['k'], w=c['w']), O.Index.from_seqs(c['names'], contigs, k=c['k'], w=c['w'])
+
+
+def check_seed_golden(ctx, O, golden, cases=('A', 'B', 'C', 'D')):
+    meta, arrays = golden
+    for cid in cases:
+        c = meta[cid]
+        gi, oi = _case_index(ctx, O, meta, arrays, cid)
+        assert gi.mid_occ == oi.mid_occ and gi.names == oi.names and gi.offsets == oi.offsets
+        gh, gp = gi.minimizers(); oh, op = oi.minimizers()
+        assert np.array_equal(gh, oh) and np.array_equal(gp, op), 'index minimizers differ'
+        seqs = [arrays['%s_r%d_seq' % (cid, ri)].tobytes().decode() for ri in range(len(c['reads']))]
+        sk = ctx.sketch_batch(c['k'], c['w'], seqs)
+        for s, (h, p, z) in zip(seqs, sk):
+            eh, ep, ez = O.sketch(s, c['k'], c['w'])
+            assert np.array_equal(h, eh) and np.array_equal(p, ep) and np.array_equal(z, ez), 'sketch differs'
+        mp = ctx.map_batch(gi, seqs)
+        for ri, a in enumerate(mp):
+            assert np.array_equal(a, arrays['%s_r%d_anchors' % (cid, ri)].reshape(-1, 4)), (cid, ri, 'anchors differ')
+        assert gi.seq(0, 5, 25) == oi.seq(0, 5, 25)
+
+
+_COMP = bytes.maketrans(b'ACGTN', b'TGCAN')
+
+
+def check_local_golden(ctx, O, golden, cases=('A', 'B', 'C', 'D')):
+    """local re-seeding + local chain: HIP vs the reference goldens (V3) and vs the oracle run on the same inputs"""
+    from vacmap_amd.lib import local_chain_batch
+    meta, arrays = golden
+    for cid in cases:
+        c = meta[cid]
+        gi, oi = _case_index(ctx, O, meta, arrays, cid)
+        prm = ctx.lib.params(c['mode']); oprm = O.params(c['mode'])
+        seqs, paths, keys = [], [], []
+        for ri, r in enumerate(c['reads']):
+            if not r['v2_paths']:
+                continue
+            s = arrays['%s_r%d_seq' % (cid, ri)].tobytes()
+            seqs.append(s if r['v2_score'] > 0 else s.translate(_COMP)[::-1])
+            paths.append([np.array(p, dtype=np.int64) for p in r['v2_paths']]); keys.append(ri)
+        res = local_chain_batch(ctx, gi, prm, seqs, paths)
+        for x, ri in enumerate(keys):
+            r = c['reads'][ri]; key = '%s_r%d' % (cid, ri); g = res[x]
+            o = O.local_chain(oi, seqs[x], paths[x], oprm)
+            oraw = o['raw'][np.argsort(o['raw'][:, 0] + o['raw'][:, 3], kind='stable')] if len(o['raw']) else o['raw']
+            assert g['status'] == 0, (key, g['status'])
+            assert np.array_equal(g['raw'], oraw), key + ' raw local anchors differ from the oracle'
+            assert g['variant'] == o['variant'] and g['score'] == o['score'] and np.array_equal(g['chain'], o['chain']), key + ' chain vs oracle'
+            if 'v3_score' in r:
+                assert np.array_equal(g['raw'], arrays[key + '_v3_raw'].reshape(-1, 4)), key + ' raw vs golden'
+                assert g['variant'] == r['v3_variant'] and g['score'] == r['v3_score'], key
+                assert np.array_equal(g['chain'], arrays[key + '_v3_path'].reshape(-1, 4)), key + ' chain vs golden'

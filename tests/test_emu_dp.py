@@ -30,3 +30,11 @@ def test_emu_gapfill(ctx, oracle):
 
 def test_emu_chain_global(ctx, oracle, golden):
     KC.check_chain_global_golden(ctx, oracle, golden, cases=['B', 'D'])
+
+
+def test_emu_seed(ctx, oracle, golden):
+    KC.check_seed_golden(ctx, oracle, golden, cases=['B', 'D'])
+
+
+def test_emu_local(ctx, oracle, golden):
+    KC.check_local_golden(ctx, oracle, golden, cases=['B', 'D'])

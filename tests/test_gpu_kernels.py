@@ -34,3 +34,11 @@ def test_gapfill(ctx, oracle):
 
 def test_chain_global_golden(ctx, oracle, golden):
     KC.check_chain_global_golden(ctx, oracle, golden)
+
+
+def test_seed_golden(ctx, oracle, golden):
+    KC.check_seed_golden(ctx, oracle, golden)
+
+
+def test_local_golden(ctx, oracle, golden):
+    KC.check_local_golden(ctx, oracle, golden)

@@ -21,6 +21,9 @@ struct vmx_anchor {
     int64_t r;     // global reference position
 };
 
+// hashed minimizer index slot (16 B): open addressing, empty key = ~0
+struct vmx_slot { uint64_t key; uint32_t start; uint32_t count; };
+
 // cost tables on the device
 struct vmx_tables {
     const float* extra; int32_t extra_n;
@@ -29,6 +32,23 @@ struct vmx_tables {
     const double* log2int;
 };
 
+// arguments of k_local_seed (L2): inputs, per-workgroup-slot scratch pools, outputs
+struct vmx_lseed_args {
+    const uint8_t* ocodes; const int64_t* roff;            // oriented read codes
+    const uint8_t* ref; const int64_t* coff; int32_t nseq;  // reference codes + contig offsets (nseq+1)
+    const vmx_anchor* guide_rows; const int32_t* guide_len; const int32_t* n_guides_used; const int64_t* aoff;
+    int32_t n_reads, k, look_span, read_span;
+    int32_t* cnt_pool; int32_t* cur_pool;                   // 4^k+1 / 4^k per slot
+    int64_t* tpos_pool; int64_t tpos_cap;
+    uint64_t* hkey_pool; int64_t* hval_pool; int32_t* hq_pool; int32_t* goff_pool; int64_t hit_cap;
+    int32_t* pcnt_pool; int64_t pcnt_cap;
+    uint64_t* gkey_pool; int32_t* gq_pool; int64_t* gr_pool; int64_t gkey_cap;
+    vmx_anchor* la_rows; uint64_t* la_ekey; vmx_anchor* la_sorted; const int64_t* la_off; int32_t* la_cnt; int32_t* status;
+};
+
+#define VMX_SORT_LDS 4096            // uint64 keys sorted in LDS by vmx_block_sort_u64 (larger sorts run in HBM)
+#define VM_READ_FASTPATH_DEV (-21)   // the reference would switch to a *_fast heuristic that is not built yet
+#define VMX_LC_BYTES_PER_ANCHOR 32   // q4 + r8 + ls4 + S8 + P4 + SA4
 #define VMX_GC_BYTES_PER_ANCHOR 33   // q4 + r8 + ls4 + S8 + P4 + SA4 + cov1 (LDS bytes per anchor in k_chain_global)
 
 #endif

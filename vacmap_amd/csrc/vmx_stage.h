@@ -1,0 +1,30 @@
+// vmx_stage.h — device-buffer bundles and internal stage functions shared by the stage entry points and vm_align_batch.
+#ifndef VMX_STAGE_H
+#define VMX_STAGE_H
+#include "vmx_host.h"
+
+struct vm_index_view {
+    const uint8_t* codes; const int64_t* coff; int nseq; int64_t total_len;
+    const uint64_t* pos; const vmx_slot* table; int table_bits; int k, w, mid_occ;
+};
+void vmx_index_view(const vm_index* mi, vm_index_view* v);
+
+struct vmx_local_bufs {
+    vmx::DevBuf guide_rows, guide_len, ng_used, ng_total, cnt, cur, tpos, hkey, hval, hq, goff, pcnt, gkey, gq, gr;
+    vmx::DevBuf la_rows, la_ekey, la_sorted, la_off, la_cnt, status, gap, rlist, S, P, SA, chain, chain_len, score, variant;
+    std::vector<int64_t> h_la_off;
+    std::vector<int32_t> h_la_cnt;
+    void release() {
+        vmx::DevBuf* all[] = {&guide_rows, &guide_len, &ng_used, &ng_total, &cnt, &cur, &tpos, &hkey, &hval, &hq, &goff, &pcnt, &gkey, &gq, &gr,
+                              &la_rows, &la_ekey, &la_sorted, &la_off, &la_cnt, &status, &gap, &rlist, &S, &P, &SA, &chain, &chain_len, &score, &variant};
+        for (auto* b : all) b->release();
+    }
+};
+vmx_local_bufs* vmx_ctx_local_bufs(vm_ctx* c);
+
+int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, int64_t total_bases,
+                   vmx::DevBuf* B, std::vector<int64_t>& h_koff, std::vector<int64_t>& h_nhits);
+int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, int64_t n, const uint8_t* d_ocodes, const int64_t* d_roff,
+                    const std::vector<int64_t>& h_roff, const vmx_anchor* d_path_rows, const int32_t* d_path_len, const int32_t* d_npaths,
+                    const int64_t* d_aoff, const std::vector<int64_t>& h_aoff, const double* d_gscore, vmx_local_bufs& L);
+#endif

@@ -1,0 +1,180 @@
+// vmx_stage_local.hip — host orchestration of the local stage (L1-L4): vmx_local_stage() is shared by the stage entry
+// vm_local_chain_batch and by vm_align_batch. Kernels: k_local.hip.
+#include "vmx_host.h"
+#include "vmx_local.h"
+#include "vmx_stage.h"
+#include <algorithm>
+#include <cstring>
+
+using namespace vmx;
+
+__global__ void k_local_prep(const vmx_anchor* path_rows, const int32_t* path_len, const int32_t* n_paths, const int64_t* aoff, const double* gscore,
+                             int n_reads, int mode, vmx_anchor* guide_rows, int32_t* guide_len, int32_t* n_guides_used, int32_t* n_guides_total);
+__global__ void k_local_seed(vmx_lseed_args A);
+__global__ void k_chain_local(const vmx_anchor* anchors, const int64_t* la_off, const int32_t* la_cnt, const int32_t* n_guides_total,
+                              const int32_t* rlist, int nlist, int lds_cap, vmx_tables tab, const double* gapcost_list, double skip_exact,
+                              double skip_mm, int maxdiff, int maxgap, int mode, double* S_pool, int32_t* P_pool, int32_t* SA_pool, double* out_score,
+                              vmx_anchor* out_chain, int32_t* out_len, int32_t* out_variant, int32_t* status);
+
+// Inputs on the device: oriented read codes + offsets; paths (rows at aoff[r], lengths at aoff[r]+p, n_paths[r]); gscore[r] (0 = unmapped).
+// h_roff / h_aoff are the host copies of the offsets. Leaves in L: la_off (device+host), chain rows / len / score / variant / status.
+int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, int64_t n, const uint8_t* d_ocodes, const int64_t* d_roff,
+                    const std::vector<int64_t>& h_roff, const vmx_anchor* d_path_rows, const int32_t* d_path_len, const int32_t* d_npaths,
+                    const int64_t* d_aoff, const std::vector<int64_t>& h_aoff, const double* d_gscore, vmx_local_bufs& L) {
+    const int k = prm->local_kmersize;
+    if (k < 5 || k > 11) { set_error("local k-mer size must be in [5,11]"); return VM_ERR_UNSUPPORTED; }
+    if (prm->mode == VM_MODE_R) { set_error("mode R local stage (scar chain, +-2000/+-500 windows) not built yet"); return VM_ERR_UNSUPPORTED; }
+    if (prm->local_maxdiff > 62) { set_error("local_maxdiff > 62 unsupported"); return VM_ERR_UNSUPPORTED; }
+    const int64_t tot_anchors = h_aoff[n];
+    int64_t Lmax = 1;
+    L.h_la_off.assign((size_t)n + 1, 0);
+    for (int64_t r = 0; r < n; ++r) { int64_t len = h_roff[r + 1] - h_roff[r]; Lmax = std::max(Lmax, len); L.h_la_off[r + 1] = L.h_la_off[r] + 2 * len + 4096; }
+    const int64_t la_tot = L.h_la_off[n];
+    VMX_TRY(L.guide_rows.reserve(sizeof(vmx_anchor) * (size_t)(tot_anchors + 1))); VMX_TRY(L.guide_len.reserve(4 * (size_t)(tot_anchors + 1)));
+    VMX_TRY(L.ng_used.reserve(4 * (size_t)(n + 1))); VMX_TRY(L.ng_total.reserve(4 * (size_t)(n + 1)));
+    hipLaunchKernelGGL(k_local_prep, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, d_path_rows, d_path_len, d_npaths, d_aoff, d_gscore, (int)n,
+                       prm->mode, L.guide_rows.as<vmx_anchor>(), L.guide_len.as<int32_t>(), L.ng_used.as<int32_t>(), L.ng_total.as<int32_t>());
+    // scratch per workgroup slot
+    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)c->num_cu * 2));
+    const int64_t nkey = (int64_t)1 << (2 * k);
+    int64_t tpos_cap = 2 * Lmax + 5 * 14000 + 65536;
+    int64_t hit_cap = 1; while (hit_cap < 4 * (Lmax + 14000)) hit_cap <<= 1;
+    int64_t pcnt_cap = Lmax + 16;
+    int64_t gkey_cap = 1; { int64_t mx = 1; for (int64_t r = 0; r < n; ++r) mx = std::max(mx, h_aoff[r + 1] - h_aoff[r]); while (gkey_cap < mx) gkey_cap <<= 1; }
+    VMX_TRY(L.cnt.reserve(4 * (size_t)G * (size_t)(nkey + 1))); VMX_TRY(L.cur.reserve(4 * (size_t)G * (size_t)nkey));
+    VMX_TRY(L.tpos.reserve(8 * (size_t)G * (size_t)tpos_cap)); VMX_TRY(L.hkey.reserve(8 * (size_t)G * (size_t)hit_cap));
+    VMX_TRY(L.hval.reserve(8 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.hq.reserve(4 * (size_t)G * (size_t)hit_cap));
+    VMX_TRY(L.goff.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.pcnt.reserve(4 * (size_t)G * (size_t)pcnt_cap));
+    VMX_TRY(L.gkey.reserve(8 * (size_t)G * (size_t)gkey_cap)); VMX_TRY(L.gq.reserve(4 * (size_t)G * (size_t)gkey_cap)); VMX_TRY(L.gr.reserve(8 * (size_t)G * (size_t)gkey_cap));
+    VMX_TRY(L.la_rows.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1))); VMX_TRY(L.la_ekey.reserve(8 * (size_t)(la_tot + 1)));
+    VMX_TRY(L.la_sorted.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1)));
+    VMX_TRY(upload(L.la_off, L.h_la_off.data(), (size_t)n + 1, c->stream));
+    VMX_TRY(L.la_cnt.reserve(4 * (size_t)(n + 1))); VMX_TRY(L.status.reserve(4 * (size_t)(n + 1)));
+    vmx_lseed_args A;
+    A.ocodes = d_ocodes; A.roff = d_roff; A.ref = ix.codes; A.coff = ix.coff; A.nseq = ix.nseq;
+    A.guide_rows = L.guide_rows.as<vmx_anchor>(); A.guide_len = L.guide_len.as<int32_t>(); A.n_guides_used = L.ng_used.as<int32_t>(); A.aoff = d_aoff;
+    A.n_reads = (int)n; A.k = k; A.look_span = 7000; A.read_span = 7000;   // :23094, :23190
+    A.cnt_pool = L.cnt.as<int32_t>(); A.cur_pool = L.cur.as<int32_t>(); A.tpos_pool = L.tpos.as<int64_t>(); A.tpos_cap = tpos_cap;
+    A.hkey_pool = L.hkey.as<uint64_t>(); A.hval_pool = L.hval.as<int64_t>(); A.hq_pool = L.hq.as<int32_t>(); A.goff_pool = L.goff.as<int32_t>(); A.hit_cap = hit_cap;
+    A.pcnt_pool = L.pcnt.as<int32_t>(); A.pcnt_cap = pcnt_cap; A.gkey_pool = L.gkey.as<uint64_t>(); A.gq_pool = L.gq.as<int32_t>(); A.gr_pool = L.gr.as<int64_t>();
+    A.gkey_cap = gkey_cap;
+    A.la_rows = L.la_rows.as<vmx_anchor>(); A.la_ekey = L.la_ekey.as<uint64_t>(); A.la_sorted = L.la_sorted.as<vmx_anchor>(); A.la_off = L.la_off.as<int64_t>();
+    A.la_cnt = L.la_cnt.as<int32_t>(); A.status = L.status.as<int32_t>();
+    hipLaunchKernelGGL(k_local_seed, dim3((unsigned)G), dim3(256), 0, c->stream, A);
+    // sizing sync #2: local anchor counts decide the LDS bucket of every read in the local chain DP
+    L.h_la_cnt.resize((size_t)n);
+    VMX_TRY(download(L.h_la_cnt.data(), L.la_cnt.p, (size_t)n, c->stream));
+    VMX_HIP(hipStreamSynchronize(c->stream));
+    VMX_HIP(hipGetLastError());
+    // LC DP
+    const HostTables& T = host_tables();
+    std::vector<double> gap(64, 0.0);
+    for (int g = 1; g <= prm->local_maxdiff; ++g) gap[g] = g <= 10 ? (0.01 * k * g + 0.5 * T.log2int[g]) : (0.01 * k * g + 2 * T.log2int[g]);   // :27317-27322
+    VMX_TRY(upload(L.gap, gap.data(), 64, c->stream));
+    const int caps[4] = {768, 1536, 3072, 4864};
+    std::vector<int32_t> lists[5];
+    for (int64_t r = 0; r < n; ++r) {
+        int m = L.h_la_cnt[r];
+        if (m <= 0) continue;   // no guide / capacity failure: nothing to chain (status already set by the seeding kernel or stays 0 for unmapped reads)
+        int bk = 4; for (int q = 0; q < 4; ++q) if (m <= caps[q]) { bk = q; break; }
+        lists[bk].push_back((int32_t)r);
+    }
+    std::vector<int32_t> rl; int64_t rl_off[6];
+    for (int q = 0; q < 5; ++q) { rl_off[q] = (int64_t)rl.size(); rl.insert(rl.end(), lists[q].begin(), lists[q].end()); }
+    rl_off[5] = (int64_t)rl.size();
+    VMX_TRY(upload(L.rlist, rl.data(), rl.size(), c->stream));
+    VMX_TRY(L.S.reserve(8 * (size_t)(la_tot + 1))); VMX_TRY(L.P.reserve(4 * (size_t)(la_tot + 1))); VMX_TRY(L.SA.reserve(4 * (size_t)(la_tot + 1)));
+    VMX_TRY(L.chain.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1)));
+    VMX_TRY(L.chain_len.reserve(4 * (size_t)(n + 1))); VMX_TRY(L.score.reserve(8 * (size_t)(n + 1))); VMX_TRY(L.variant.reserve(4 * (size_t)(n + 1)));
+    VMX_HIP(hipMemsetAsync(L.chain_len.p, 0, 4 * (size_t)n, c->stream)); VMX_HIP(hipMemsetAsync(L.score.p, 0, 8 * (size_t)n, c->stream));
+    VMX_HIP(hipMemsetAsync(L.variant.p, 0, 4 * (size_t)n, c->stream));
+    const int maxgap = prm->mode == VM_MODE_L ? 50 : 99;                                        // :24061 / mammap_ccs.py:24061
+    const double skip_exact = prm->local_skipcost;
+    const double skip_mm = prm->mode == VM_MODE_L ? std::min(prm->local_skipcost, 40.0) : prm->local_skipcost;   // mammap_ccs.py:28587
+    for (int q = 0; q < 5; ++q) {
+        int cnt = (int)lists[q].size();
+        if (!cnt) continue;
+        int cap = q < 4 ? caps[q] : 0;
+        size_t shmem = (size_t)cap * VMX_LC_BYTES_PER_ANCHOR + 64;
+#ifndef VMX_EMU
+        if (shmem > 48 * 1024) VMX_HIP(hipFuncSetAttribute((const void*)k_chain_local, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+#endif
+        hipLaunchKernelGGL(k_chain_local, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 8)), dim3(64), shmem, c->stream, L.la_sorted.as<vmx_anchor>(),
+                           L.la_off.as<int64_t>(), L.la_cnt.as<int32_t>(), L.ng_total.as<int32_t>(), L.rlist.as<int32_t>() + rl_off[q], cnt, cap, c->tables,
+                           L.gap.as<double>(), skip_exact, skip_mm, prm->local_maxdiff, maxgap, prm->mode, L.S.as<double>(), L.P.as<int32_t>(), L.SA.as<int32_t>(),
+                           L.score.as<double>(), L.chain.as<vmx_anchor>(), L.chain_len.as<int32_t>(), L.variant.as<int32_t>(), L.status.as<int32_t>());
+    }
+    return 0;
+}
+
+extern "C" {
+
+void vm_local_out_free(vm_local_out* o) {
+    free(o->status); free(o->variant); free(o->score); free(o->chain_off); free(o->chain); free(o->raw_off); free(o->raw);
+    memset(o, 0, sizeof(*o));
+}
+
+int vm_local_chain_batch(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const char* seqs, const int64_t* offsets,
+                         const int64_t* read_path_off, const int64_t* path_off, const int64_t* path_anchors, vm_local_out* out) {
+    memset(out, 0, sizeof(*out));
+    if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
+    VMX_HIP(hipSetDevice(c->device));
+    vm_index_view ix; vmx_index_view(mi, &ix);
+    // reads
+    DevBuf &raw = c->b[0], &codes = c->b[1], &roff = c->b[2];
+    const int64_t tot = offsets[n];
+    VMX_TRY(upload(raw, seqs, (size_t)tot, c->stream)); VMX_TRY(codes.reserve((size_t)tot + 64)); VMX_TRY(upload(roff, offsets, (size_t)n + 1, c->stream));
+    if (tot) hipLaunchKernelGGL(k_encode, dim3((unsigned)std::min<int64_t>((tot + 255) / 256, 4096)), dim3(256), 0, c->stream, raw.as<char>(), codes.as<uint8_t>(), tot);
+    // paths -> device layout (rows at aoff[r], lengths at aoff[r]+p)
+    std::vector<int64_t> h_roff(offsets, offsets + n + 1), h_aoff((size_t)n + 1, 0);
+    for (int64_t r = 0; r < n; ++r) { int64_t rows = path_off[read_path_off[r + 1]] - path_off[read_path_off[r]]; h_aoff[r + 1] = h_aoff[r] + rows; }
+    const int64_t ta = h_aoff[n];
+    std::vector<vmx_anchor> rows((size_t)ta + 1); std::vector<int32_t> plen((size_t)ta + 1, 0), npaths((size_t)n); std::vector<double> gscore((size_t)n);
+    for (int64_t r = 0; r < n; ++r) {
+        int64_t p0 = read_path_off[r], p1 = read_path_off[r + 1];
+        npaths[r] = (int32_t)(p1 - p0); gscore[r] = p1 > p0 ? 1.0 : 0.0;
+        int64_t w = h_aoff[r];
+        for (int64_t p = p0; p < p1; ++p) {
+            plen[h_aoff[r] + (p - p0)] = (int32_t)(path_off[p + 1] - path_off[p]);
+            for (int64_t x = path_off[p]; x < path_off[p + 1]; ++x) { vmx_anchor a; a.q = (int32_t)path_anchors[4 * x]; a.r = path_anchors[4 * x + 1]; a.s = (int16_t)path_anchors[4 * x + 2]; a.l = (int16_t)path_anchors[4 * x + 3]; rows[w++] = a; }
+        }
+    }
+    DevBuf &d_rows = c->b[3], &d_plen = c->b[4], &d_np = c->b[5], &d_aoff = c->b[6], &d_gs = c->b[7];
+    VMX_TRY(upload(d_rows, rows.data(), (size_t)ta + 1, c->stream)); VMX_TRY(upload(d_plen, plen.data(), (size_t)ta + 1, c->stream));
+    VMX_TRY(upload(d_np, npaths.data(), (size_t)n, c->stream)); VMX_TRY(upload(d_aoff, h_aoff.data(), (size_t)n + 1, c->stream));
+    VMX_TRY(upload(d_gs, gscore.data(), (size_t)n, c->stream));
+    vmx_local_bufs& L = *vmx_ctx_local_bufs(c);
+    VMX_TRY(vmx_local_stage(c, ix, prm, n, codes.as<uint8_t>(), roff.as<int64_t>(), h_roff, d_rows.as<vmx_anchor>(), d_plen.as<int32_t>(), d_np.as<int32_t>(),
+                            d_aoff.as<int64_t>(), h_aoff, d_gs.as<double>(), L));
+    // download
+    const int64_t la_tot = L.h_la_off[n];
+    std::vector<int32_t> clen((size_t)n); std::vector<vmx_anchor> chain((size_t)la_tot), sorted((size_t)la_tot);
+    out->status = (int32_t*)malloc(4 * (size_t)std::max<int64_t>(n, 1)); out->variant = (int32_t*)malloc(4 * (size_t)std::max<int64_t>(n, 1));
+    out->score = (double*)malloc(8 * (size_t)std::max<int64_t>(n, 1));
+    VMX_TRY(download(out->status, L.status.p, (size_t)n, c->stream)); VMX_TRY(download(out->variant, L.variant.p, (size_t)n, c->stream));
+    VMX_TRY(download(out->score, L.score.p, (size_t)n, c->stream)); VMX_TRY(download(clen.data(), L.chain_len.p, (size_t)n, c->stream));
+    VMX_TRY(download(chain.data(), L.chain.p, (size_t)la_tot, c->stream)); VMX_TRY(download(sorted.data(), L.la_sorted.p, (size_t)la_tot, c->stream));
+    VMX_HIP(hipStreamSynchronize(c->stream)); VMX_HIP(hipGetLastError());
+    int64_t tc = 0, tr = 0;
+    for (int64_t r = 0; r < n; ++r) { tc += clen[r]; tr += L.h_la_cnt[r]; }
+    out->chain_off = (int64_t*)malloc(8 * (size_t)(n + 1)); out->raw_off = (int64_t*)malloc(8 * (size_t)(n + 1));
+    out->chain = (int64_t*)malloc(32 * (size_t)std::max<int64_t>(tc, 1)); out->raw = (int64_t*)malloc(32 * (size_t)std::max<int64_t>(tr, 1));
+    int64_t oc = 0, orw = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        out->chain_off[r] = oc; out->raw_off[r] = orw;
+        for (int x = 0; x < clen[r]; ++x) { const vmx_anchor& a = chain[L.h_la_off[r] + x]; int64_t* o = out->chain + 4 * oc++; o[0] = a.q; o[1] = a.r; o[2] = a.s; o[3] = a.l; }
+        for (int x = 0; x < L.h_la_cnt[r]; ++x) { const vmx_anchor& a = sorted[L.h_la_off[r] + x]; int64_t* o = out->raw + 4 * orw++; o[0] = a.q; o[1] = a.r; o[2] = a.s; o[3] = a.l; }
+    }
+    out->chain_off[n] = oc; out->raw_off[n] = orw;
+    return VM_OK;
+}
+
+}  // extern "C"
+
+vmx_local_bufs* vmx_ctx_local_bufs(vm_ctx* c) {
+    if (!c->lbufs) c->lbufs = new vmx_local_bufs();
+    return c->lbufs;
+}
+void vmx_ctx_free_local_bufs(vm_ctx* c) {
+    if (c->lbufs) { c->lbufs->release(); delete c->lbufs; c->lbufs = nullptr; }
+}

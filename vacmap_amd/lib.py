@@ -96,6 +96,24 @@ class VmxLib:
         L.vm_k_cigar.argtypes = [vp, cp, i64, cp, i64, P(Score), C.c_int, C.c_int, C.c_int, P(CigarOut)]
         L.vm_chain_global_batch.argtypes = [vp, P(Params), C.c_int, i64, vp, vp, vp, C.c_int, P(ChainsOut)]
         L.vm_chains_out_free.argtypes = [P(ChainsOut)]
+        L.vm_index_build_fasta.argtypes = [vp, cp, C.c_int, C.c_int, P(vp)]
+        L.vm_index_build_mem.argtypes = [vp, C.c_int, P(cp), P(cp), P(i64), C.c_int, C.c_int, P(vp)]
+        L.vm_index_save.argtypes = [vp, cp]; L.vm_index_load.argtypes = [vp, cp, P(vp)]
+        L.vm_index_free.argtypes = [vp]
+        for f in ('vm_index_k', 'vm_index_w', 'vm_index_nseq', 'vm_index_mid_occ', 'vm_index_blob_count'):
+            getattr(L, f).argtypes = [vp]
+        L.vm_index_n_minimizers.argtypes = [vp]; L.vm_index_n_minimizers.restype = i64
+        L.vm_index_seq_info.argtypes = [vp, C.c_int, P(cp), P(i64), P(i64)]
+        L.vm_index_seq.argtypes = [vp, C.c_int, i64, i64, vp]; L.vm_index_seq.restype = i64
+        L.vm_index_minimizers.argtypes = [vp, P(P(C.c_uint64)), P(P(C.c_uint64)), P(i64)]
+        L.vm_index_blob.argtypes = [vp, C.c_int, P(vp), P(i64)]
+        L.vm_index_meta_size.argtypes = [vp, P(i64)]; L.vm_index_meta_get.argtypes = [vp, vp, i64]
+        L.vm_index_from_meta.argtypes = [vp, vp, i64, P(vp)]
+        L.vm_sketch_batch.argtypes = [vp, C.c_int, C.c_int, i64, cp, vp, P(P(C.c_uint64)), P(P(i32)), P(P(C.c_int8)), P(P(i64))]
+        L.vm_map_batch.argtypes = [vp, vp, C.c_int, C.c_int, i64, cp, vp, P(P(i64)), P(P(i64))]
+        L.vm_map.argtypes = [vp, vp, cp, i64, C.c_int, C.c_int, P(P(i64)), P(i64)]
+        L.vm_local_chain_batch.argtypes = [vp, vp, P(Params), i64, cp, vp, vp, vp, vp, P(LocalOut)]
+        L.vm_local_out_free.argtypes = [P(LocalOut)]
 
     def err(self):
         return self.L.vm_last_error().decode()
@@ -230,3 +248,114 @@ class Context:
             res.append(d)
         self.lib.L.vm_chains_out_free(C.byref(out))
         return res
+
+    # ---- seed stage
+    def sketch_batch(self, k, w, seqs):
+        s, off = _cat(seqs)
+        n = len(seqs)
+        h = C.POINTER(C.c_uint64)(); p = C.POINTER(C.c_int32)(); z = C.POINTER(C.c_int8)(); oo = C.POINTER(C.c_int64)()
+        self.lib.check(self.lib.L.vm_sketch_batch(self.h, k, w, n, s, off.ctypes.data, C.byref(h), C.byref(p), C.byref(z), C.byref(oo)))
+        o = self._take(oo, n + 1, np.int64)
+        m = int(o[-1])
+        H = self._take(h, m, np.uint64); Pp = self._take(p, m, np.int32); Z = self._take(z, m, np.int8)
+        return [(H[o[i]:o[i + 1]], Pp[o[i]:o[i + 1]], Z[o[i]:o[i + 1]]) for i in range(n)]
+
+    def map_batch(self, index, seqs, check_num=100, mid_occ=-1):
+        s, off = _cat(seqs)
+        n = len(seqs)
+        a = C.POINTER(C.c_int64)(); ao = C.POINTER(C.c_int64)()
+        self.lib.check(self.lib.L.vm_map_batch(self.h, index.h, check_num, mid_occ, n, s, off.ctypes.data, C.byref(a), C.byref(ao)))
+        o = self._take(ao, n + 1, np.int64)
+        tot = int(o[-1])
+        rows = np.ctypeslib.as_array(a, shape=(max(tot, 1), 4))[:tot].copy()
+        self.lib.L.vm_free(a)
+        return [rows[o[i]:o[i + 1]] for i in range(n)]
+
+
+def local_chain_batch(ctx, index, prm, seqs, paths_per_read):
+    """seqs in chain orientation; paths_per_read: list (per read) of lists of (m,4) arrays (descending read order)"""
+    s, off = _cat(seqs)
+    n = len(seqs)
+    rpo = np.zeros(n + 1, np.int64); po = [0]; rows = []
+    for r, paths in enumerate(paths_per_read):
+        rpo[r + 1] = rpo[r] + len(paths)
+        for p in paths:
+            p = np.asarray(p, dtype=np.int64).reshape(-1, 4)
+            rows.append(p); po.append(po[-1] + len(p))
+    po = np.asarray(po, dtype=np.int64)
+    pa = np.ascontiguousarray(np.concatenate(rows) if rows else np.zeros((0, 4), np.int64))
+    out = LocalOut()
+    ctx.lib.check(ctx.lib.L.vm_local_chain_batch(ctx.h, index.h, C.byref(prm), n, s, off.ctypes.data, rpo.ctypes.data, po.ctypes.data,
+                                                 pa.ctypes.data, C.byref(out)))
+    co = np.ctypeslib.as_array(out.chain_off, shape=(n + 1,)).copy(); ro = np.ctypeslib.as_array(out.raw_off, shape=(n + 1,)).copy()
+    ch = np.ctypeslib.as_array(out.chain, shape=(max(int(co[-1]), 1), 4))[:int(co[-1])].copy()
+    rw = np.ctypeslib.as_array(out.raw, shape=(max(int(ro[-1]), 1), 4))[:int(ro[-1])].copy()
+    res = [{'status': int(out.status[r]), 'variant': int(out.variant[r]), 'score': float(out.score[r]), 'chain': ch[co[r]:co[r + 1]],
+            'raw': rw[ro[r]:ro[r + 1]]} for r in range(n)]
+    ctx.lib.L.vm_local_out_free(C.byref(out))
+    return res
+
+
+class Index:
+    """HBM-resident minimizer index (vm_index); mirrors what the reference reads from `mp.Aligner` (vacmap:344-367)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.h = handle
+        L = ctx.lib.L
+        self.k = L.vm_index_k(handle); self.w = L.vm_index_w(handle); self.nseq = L.vm_index_nseq(handle)
+        self.mid_occ = L.vm_index_mid_occ(handle)
+        self.names, self.lens, self.offsets = [], [], []
+        for i in range(self.nseq):
+            nm = C.c_char_p(); ln = C.c_int64(); of = C.c_int64()
+            L.vm_index_seq_info(handle, i, C.byref(nm), C.byref(ln), C.byref(of))
+            self.names.append(nm.value.decode()); self.lens.append(ln.value); self.offsets.append(of.value)
+
+    @classmethod
+    def from_fasta(cls, ctx, path, k=15, w=10):
+        h = C.c_void_p()
+        ctx.lib.check(ctx.lib.L.vm_index_build_fasta(ctx.h, _b(path), k, w, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_seqs(cls, ctx, names, seqs, k=15, w=10):
+        n = len(names)
+        bs = [_b(s) for s in seqs]
+        na = (C.c_char_p * n)(*[_b(x) for x in names]); sa = (C.c_char_p * n)(*bs); la = (C.c_int64 * n)(*[len(b) for b in bs])
+        h = C.c_void_p()
+        ctx.lib.check(ctx.lib.L.vm_index_build_mem(ctx.h, n, na, sa, la, k, w, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def load(cls, ctx, path):
+        h = C.c_void_p()
+        ctx.lib.check(ctx.lib.L.vm_index_load(ctx.h, _b(path), C.byref(h)))
+        return cls(ctx, h)
+
+    def save(self, path):
+        self.ctx.lib.check(self.ctx.lib.L.vm_index_save(self.h, _b(path)))
+
+    def seq(self, i, st=0, en=None):
+        en = self.lens[i] if en is None else en
+        buf = C.create_string_buffer(max(en - st, 1))
+        n = self.ctx.lib.L.vm_index_seq(self.h, i, st, en, buf)
+        return buf.raw[:max(n, 0)].decode()
+
+    def n_minimizers(self):
+        return self.ctx.lib.L.vm_index_n_minimizers(self.h)
+
+    def minimizers(self):
+        hh = C.POINTER(C.c_uint64)(); pp = C.POINTER(C.c_uint64)(); n = C.c_int64()
+        self.ctx.lib.check(self.ctx.lib.L.vm_index_minimizers(self.h, C.byref(hh), C.byref(pp), C.byref(n)))
+        return self.ctx._take(hh, n.value, np.uint64), self.ctx._take(pp, n.value, np.uint64)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.L.vm_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
