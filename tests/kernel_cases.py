@@ -142,6 +142,28 @@ def check_seed_golden(ctx, O, golden, cases=('A', 'B', 'C', 'D')):
         assert gi.seq(0, 5, 25) == oi.seq(0, 5, 25)
 
 
+def check_align_golden(ctx, O, golden, cases=('A', 'B', 'C', 'D'), reads=None):
+    """the whole batched path (vm_align_batch) vs the reference's records (V6) and vs the oracle run live"""
+    from vacmap_amd.lib import align_batch
+    meta, arrays = golden
+    for cid in cases:
+        c = meta[cid]
+        gi, oi = _case_index(ctx, O, meta, arrays, cid)
+        prm = ctx.lib.params(c['mode']); oprm = O.params(c['mode'])
+        idx = list(range(len(c['reads']))) if reads is None else [i for i in reads if i < len(c['reads'])]
+        seqs = [arrays['%s_r%d_seq' % (cid, ri)].tobytes().decode() for ri in idx]
+        status, recs, stats = align_batch(ctx, gi, prm, seqs)
+        for x, ri in enumerate(idx):
+            r = c['reads'][ri]
+            mine = [[c['names'][t[1]], t[2], t[3], t[4], t[5], t[6], t[7], t[8]] for t in recs if t[0] == x]
+            ost, orecs = O.align_read(oi, seqs[x], oprm)
+            omine = [[c['names'][t[1]], t[2], t[3], t[4], t[5], t[6], t[7], t[8]] for t in orecs]
+            assert (status[x] == 0) == (ost == 0), (cid, ri, int(status[x]), ost)
+            assert mine == omine, (cid, ri, 'records differ from the oracle')
+            assert (status[x] == 0) == (r['v6_status'] == 0) and mine == r['v6_records'], (cid, ri, 'records differ from the reference golden')
+        assert stats['n_reads'] == len(seqs)
+
+
 _COMP = bytes.maketrans(b'ACGTN', b'TGCAN')
 
 

@@ -38,3 +38,8 @@ def test_emu_seed(ctx, oracle, golden):
 
 def test_emu_local(ctx, oracle, golden):
     KC.check_local_golden(ctx, oracle, golden, cases=['B', 'D'])
+
+
+def test_emu_align_end_to_end(ctx, oracle, golden):
+    KC.check_align_golden(ctx, oracle, golden, cases=['B'], reads=[0, 1, 2])
+    KC.check_align_golden(ctx, oracle, golden, cases=['D'])

@@ -42,3 +42,7 @@ def test_seed_golden(ctx, oracle, golden):
 
 def test_local_golden(ctx, oracle, golden):
     KC.check_local_golden(ctx, oracle, golden)
+
+
+def test_align_golden(ctx, oracle, golden):
+    KC.check_align_golden(ctx, oracle, golden)

@@ -1,0 +1,279 @@
+// k_ext.hip — kernels of the extend stage that surround the DP kernels of k_dp.hip (SURVEY §8(a) rows E1, E4, E6 + problem plumbing).
+//
+//   k_ext_phase   one THREAD per read: runs one phase of extend_func (/root/reference/src/vacmap/mammap_clrnano.py:19238-19303) on the
+//                 read's segment list (vmx_extend.h): applies the results of the previous DP round and emits the string
+//                 descriptors of the next one. Phases: 0 rebuild + divergence problems, 1 filter + right-end extensions,
+//                 2 left-end extensions, 3 drop_misplaced (+ right ends again), 4 left ends again, 5 merge / fix_simple_inv /
+//                 checkpoints -> gap-fill problems, 6 records (+ pairedindel -> redo with nofilter, :24079-24080).
+//   k_desc_lens / k_gather   materialise the (target, query) strings of all problems of a round into code pools
+//                 (plain / reversed / complemented / reverse-complemented views of the read or the reference).
+#include "vmx_device.h"
+#include "vmx_kernels.h"
+#include "vmx_extend.h"
+#include "vmx_ext_state.h"
+
+__device__ __forceinline__ vmx_segs vmx_read_segs(const vmx_ext_args& A, int r, bool snap) {
+    vmx_segs S;
+    const int64_t c0 = A.coff3[r];            // 3*chain_len+8 slots per read
+    const int64_t s0 = A.soff[r];             // chain_len+2 per read
+    S.A = (snap ? A.segA_snap : A.segA) + c0; S.st = (snap ? A.st_snap : A.st) + s0; S.en = (snap ? A.en_snap : A.en) + s0;
+    S.capA = (int)(A.coff3[r + 1] - c0); S.capS = (int)(A.soff[r + 1] - s0);
+    S.nseg = 0;
+    return S;
+}
+
+// allocate n contiguous problem slots of the current round
+__device__ __forceinline__ int vmx_alloc_probs(const vmx_ext_args& A, int n) {
+    if (n <= 0) return 0;
+    int b = atomicAdd(A.round_count, n);
+    if ((long long)b + n > A.round_cap) { atomicExch(A.overflow, 1); return -1; }
+    return b;
+}
+
+__global__ void k_ext_phase(vmx_ext_args A, int phase) {
+    const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r >= A.n_reads) return;
+    vmx_ext_read& E = A.er[r];
+    if (phase == 0) { E.status = A.lstatus[r]; E.nseg = 0; E.nseg_snap = 0; E.filtered = 0; E.redo = 0; E.prob_base = 0; E.prob_n = 0; E.dp_base = 0; E.dp_n = 0; E.nrec = 0; E.active = 0; E.pass = 0; E.skip_ext = 0; }
+    const int cl = A.chain_len[r];
+    if (phase == 0) { if (E.status == 0 && cl > 1) E.active = 1; }     // len(raw_alignment_list) <= 1 -> unmapped (:24067)
+    if (!E.active || E.status != 0) return;
+    if (A.redo_only && !(E.redo == 1 && E.pass == 1)) return;
+    vmx_ref_view R; R.codes = A.ref; R.coff = A.coff; R.nseq = A.nseq;
+    const long long L = A.roff[r + 1] - A.roff[r];
+    const uint8_t* RD = A.ocodes + A.roff[r];
+    vmx_segs S = vmx_read_segs(A, r, false);
+    S.nseg = E.nseg;
+    int32_t* segprob = A.seg_prob + A.soff[r];
+    const bool nofilter = A.nodiscard || E.pass == 1;
+    if (phase == 0) {
+        int rc = vmx_rebuild_chain_break(A.chain + A.la_off[r], cl, R, A.local_maxdiff, 50, S);
+        if (rc < 0) { E.status = rc; return; }
+        E.nseg = S.nseg;
+        int b = vmx_alloc_probs(A, S.nseg);
+        if (b < 0) { E.status = VM_READ_CAPACITY_DEV; return; }
+        E.prob_base = b; E.prob_n = S.nseg;
+        for (int s = 0; s < S.nseg; ++s) {
+            vmx_pair_desc d; vmx_qt_for_cigar(SEG_FIRST(S, s), SEG_LAST(S, s), L, R, &d);
+            A.desc[b + s] = d;
+        }
+        return;
+    }
+    if (phase == 1) {
+        // divergence filter :19246-19254
+        int b = E.prob_base; int w = 0;
+        const int n0 = S.nseg;
+        for (int s = 0; s < n0; ++s) {
+            const vmx_pair_desc d = A.desc_prev[b + s];
+            const long long mn = d.t.len < d.q.len ? d.t.len : d.q.len;
+            if (mn == 0) { E.status = VM_READ_RAISED_DEV; return; }           // ZeroDivisionError
+            const double ratio = (double)A.ed_out[b + s] / (double)mn;
+            if (ratio > A.maxdivergence) continue;
+            S.st[w] = S.st[s]; S.en[w] = S.en[s]; ++w;
+        }
+        S.nseg = w; E.nseg = w;
+    }
+    if (phase == 2 || (phase == 4 && E.skip_ext == 0)) {
+        // apply right-end results, then set up the left ends (they see the extended right end of their left neighbour)
+        for (int s = 0; s < S.nseg; ++s) if (segprob[s] >= 0) vmx_ext_apply(S, s, 1, A.ext_te[E.prob_base + segprob[s]], A.ext_qe[E.prob_base + segprob[s]]);
+    }
+    if (phase == 3 || phase == 5) {
+        if (E.skip_ext == 0) for (int s = 0; s < S.nseg; ++s) if (segprob[s] >= 0) vmx_ext_apply(S, s, 0, A.ext_te[E.prob_base + segprob[s]], A.ext_qe[E.prob_base + segprob[s]]);
+    }
+    if (phase >= 1 && phase <= 5) E.prob_n = 0;      // results of the previous round are consumed; a new round may follow below
+    if (phase == 3) {
+        // snapshot for the nofilter redo (:24080 restarts extend_func; everything up to here is identical in both runs)
+        if (E.pass == 0) {
+            vmx_segs P = vmx_read_segs(A, r, true);
+            for (int s = 0; s < S.nseg; ++s) { P.st[s] = S.st[s]; P.en[s] = S.en[s]; for (int t = S.st[s] - 1; t <= S.en[s]; ++t) P.A[t] = S.A[t]; }
+            E.nseg_snap = S.nseg;
+        }
+        const int o_len = S.nseg;
+        if (S.nseg > 2 && !nofilter) { int iloc = 0; while (iloc < S.nseg - 2) { if (vmx_drop_misplaced(S, iloc)) continue; else iloc += 1; } }
+        E.nseg = S.nseg;
+        E.skip_ext = 1;
+        if (S.nseg < o_len) { E.filtered = 1; E.skip_ext = 0; }
+    }
+    if (phase == 1 || (phase == 3 && E.skip_ext == 0)) {
+        // right ends
+        int np = 0;
+        for (int s = 0; s < S.nseg; ++s) segprob[s] = -1;
+        // two passes: count, allocate, fill
+        vmx_pair_desc tmp;
+        // descriptors are cheap to recompute: first decide which segments issue a DP call (setup also rewrites end anchors when no call is made)
+        int b = -1;
+        for (int pass = 0; pass < 2; ++pass) {
+            int k = 0;
+            for (int s = 0; s < S.nseg; ++s) {
+                if (pass == 0) { if (vmx_ext_setup(S, s, 1, L, R, &tmp)) { segprob[s] = k++; } }
+                else if (segprob[s] >= 0) { vmx_ext_setup(S, s, 1, L, R, &tmp); A.desc[b + segprob[s]] = tmp; }
+            }
+            if (pass == 0) { np = k; b = vmx_alloc_probs(A, np); if (b < 0) { E.status = VM_READ_CAPACITY_DEV; return; } }
+        }
+        E.prob_base = b < 0 ? 0 : b; E.prob_n = np;
+        return;
+    }
+    if (phase == 2 || (phase == 4 && E.skip_ext == 0)) {
+        int np = 0; vmx_pair_desc tmp; int b = -1;
+        for (int s = 0; s < S.nseg; ++s) segprob[s] = -1;
+        for (int pass = 0; pass < 2; ++pass) {
+            int k = 0;
+            for (int s = 0; s < S.nseg; ++s) {
+                if (pass == 0) { if (vmx_ext_setup(S, s, 0, L, R, &tmp)) { segprob[s] = k++; } }
+                else if (segprob[s] >= 0) { vmx_ext_setup(S, s, 0, L, R, &tmp); A.desc[b + segprob[s]] = tmp; }
+            }
+            if (pass == 0) { np = k; b = vmx_alloc_probs(A, np); if (b < 0) { E.status = VM_READ_CAPACITY_DEV; return; } }
+        }
+        E.prob_base = b < 0 ? 0 : b; E.prob_n = np;
+        return;
+    }
+    if (phase == 5) {
+        vmx_merge_conjacent(S, R, A.dup + A.soff[r]);
+        int rc = vmx_fix_simple_inv(S, R, RD, L);
+        if (rc < 0) { E.status = rc; return; }
+        E.nseg = S.nseg;
+        // checkpoints -> gap-fill problems. capacity: at most one problem per anchor
+        int total = 0;
+        for (int s = 0; s < S.nseg; ++s) total += SEG_LEN(S, s);
+        int b = vmx_alloc_probs(A, total);
+        if (b < 0) { E.status = VM_READ_CAPACITY_DEV; return; }
+        int k = 0;
+        for (int s = 0; s < S.nseg; ++s) {
+            int np = vmx_split_alignment(S, s, L, R, A.desc + b + k, total - k);
+            if (np < 0) { E.status = np; return; }
+            segprob[s] = np; k += np;
+        }
+        // slots beyond k stay unused: mark them empty so the DP kernels skip them
+        for (int x = k; x < total; ++x) { vmx_pair_desc d; d.t.len = 0; d.q.len = 0; d.t.start = 0; d.q.start = 0; d.t.src = 1; d.q.src = 0; d.t.op = 0; d.q.op = 0; A.desc[b + x] = d; }
+        E.dp_base = b; E.dp_n = k; E.prob_base = b; E.prob_n = total;
+        return;
+    }
+}
+
+// lengths of the strings of every problem of the round (for the offset scans)
+__global__ void k_desc_lens(const vmx_pair_desc* __restrict__ desc, const int32_t* __restrict__ n_prob, int64_t* __restrict__ tl, int64_t* __restrict__ ql) {
+    const int n = *n_prob;
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x)) { tl[i] = desc[i].t.len; ql[i] = desc[i].q.len; }
+}
+
+__device__ __forceinline__ void vmx_gather_one(const vmx_sdesc& d, const uint8_t* rd, const uint8_t* ref, uint8_t* out) {
+    const uint8_t* src = d.src == 0 ? rd : ref;
+    const int n = d.len;
+    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
+        uint8_t c;
+        if (d.op == 0) c = src[d.start + i];
+        else if (d.op == 1) c = src[d.start + n - 1 - i];
+        else if (d.op == 2) { c = src[d.start + i]; c = c < 4 ? 3 - c : 4; }
+        else { c = src[d.start + n - 1 - i]; c = c < 4 ? 3 - c : 4; }
+        out[i] = c;
+    }
+}
+
+// prob_read[i] = read index of problem i (to find the oriented read codes)
+__global__ void __launch_bounds__(256) k_gather(const vmx_pair_desc* __restrict__ desc, const int32_t* __restrict__ n_prob, const int32_t* __restrict__ prob_read,
+                                                const uint8_t* __restrict__ ocodes, const int64_t* __restrict__ roff, const uint8_t* __restrict__ ref,
+                                                const int64_t* __restrict__ t_off, const int64_t* __restrict__ q_off, uint8_t* __restrict__ tpool,
+                                                uint8_t* __restrict__ qpool, int64_t pool_cap, int32_t* __restrict__ overflow) {
+    const int n = *n_prob;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const vmx_pair_desc d = desc[i];
+        if (t_off[i] + d.t.len > pool_cap || q_off[i] + d.q.len > pool_cap) { if (threadIdx.x == 0) atomicExch(overflow, 1); continue; }
+        const uint8_t* rd = ocodes + roff[prob_read[i]];
+        vmx_gather_one(d.t, rd, ref, tpool + t_off[i]);
+        vmx_gather_one(d.q, rd, ref, qpool + q_off[i]);
+    }
+}
+
+// mark which read owns each problem slot of the round
+__global__ void k_prob_owner(const vmx_ext_read* __restrict__ er, int n_reads, int use_dp, int32_t* __restrict__ prob_read) {
+    const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r >= n_reads) return;
+    const vmx_ext_read E = er[r];
+    if (!E.active || E.status != 0) return;
+    if (use_dp /* redo_only */ && !(E.redo == 1 && E.pass == 1)) return;
+    for (int i = 0; i < E.prob_n; ++i) prob_read[E.prob_base + i] = r;
+}
+
+// gap-fill problem table from the descriptors + offsets; tb/bnd/run/cig sizes per problem go to size arrays for the scans
+__global__ void k_dp_sizes(const vmx_pair_desc* __restrict__ desc, const int32_t* __restrict__ n_prob, int64_t* __restrict__ tb_sz, int64_t* __restrict__ bnd_sz,
+                           int64_t* __restrict__ run_sz, int64_t* __restrict__ cig_sz) {
+    const int n = *n_prob;
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x)) {
+        const long long tl = desc[i].t.len, ql = desc[i].q.len;
+        tb_sz[i] = (tl > 0 && ql > 0) ? ((tl + 63) / 64) * (ql + 63) * 64 : 0;
+        bnd_sz[i] = 3 * (ql + 1); run_sz[i] = tl + ql + 2; cig_sz[i] = 2 * (tl + ql) + 16;
+    }
+}
+__global__ void k_dp_table(const vmx_pair_desc* __restrict__ desc, const int32_t* __restrict__ n_prob, const int64_t* __restrict__ t_off, const int64_t* __restrict__ q_off,
+                           const int64_t* __restrict__ tb_off, const int64_t* __restrict__ bnd_off, const int64_t* __restrict__ run_off,
+                           const int64_t* __restrict__ cig_off, vmx_dp_prob* __restrict__ probs) {
+    const int n = *n_prob;
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x)) {
+        vmx_dp_prob p; p.t_off = t_off[i]; p.q_off = q_off[i]; p.tl = desc[i].t.len; p.ql = desc[i].q.len;
+        p.tb_off = tb_off[i]; p.bnd_off = bnd_off[i]; p.run_off = run_off[i]; p.cig_off = cig_off[i];
+        probs[i] = p;
+    }
+}
+
+// E6 records (:20731-20838) + pairedindel (:5604). one thread per read.
+__global__ void k_ext_records(vmx_ext_args A, const vmx_dp_prob* __restrict__ probs, const char* __restrict__ cig_pool, const int32_t* __restrict__ cig_len) {
+    const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r >= A.n_reads) return;
+    vmx_ext_read& E = A.er[r];
+    if (!E.active || E.status != 0) return;
+    if (A.redo_only && !(E.redo == 1 && E.pass == 1)) return;
+    vmx_ref_view R; R.codes = A.ref; R.coff = A.coff; R.nseq = A.nseq;
+    const long long L = A.roff[r + 1] - A.roff[r];
+    vmx_segs S = vmx_read_segs(A, r, false); S.nseg = E.nseg;
+    const int32_t* segprob = A.seg_prob + A.soff[r];
+    vm_record* REC = A.rec + A.soff[r];
+    char* BLOB = A.rec_blob + A.blob_off[r];
+    const long long blob_cap = A.blob_off[r + 1] - A.blob_off[r];
+    int64_t* roffs = A.rec_coff + A.soff[r]; int32_t* rlens = A.rec_clen + A.soff[r];
+    const bool need_reverse = A.gscore[r] < 0.0;
+    const char clip = A.hardclip ? 'H' : 'S';
+    long long w = 0; int k = 0;
+    for (int s = 0; s < S.nseg; ++s) {
+        const vmx_anchor a0 = S.A[S.st[s]].s == 1 ? S.A[S.st[s]] : S.A[S.en[s] - 1];     // new_alignment[0]
+        const vmx_anchor a1 = S.A[S.st[s]].s == 1 ? S.A[S.en[s] - 1] : S.A[S.st[s]];     // new_alignment[-1]
+        const int c = vmx_p2c(R, a0.r); const long long bias = R.coff[c];
+        vm_record rec; rec.read_idx = r; rec.contig = c; rec.mapq = A.mapq[r];
+        long long q_st, q_en;
+        if (a0.s == 1) { q_st = a0.q; q_en = (long long)a1.q + a1.l; rec.strand = need_reverse ? -1 : 1; }
+        else { q_st = L - a0.q - a0.l; q_en = L - a1.q; rec.strand = need_reverse ? 1 : -1; }
+        rec.q_st = q_st; rec.q_en = q_en; rec.r_st = a0.r - bias; rec.r_en = a1.r + a1.l - bias;
+        // worst-case length check before writing
+        long long need = 48; for (int x = 0; x < segprob[s]; ++x) need += cig_len[E.dp_base + k + x];
+        if (w + need > blob_cap) { E.status = VM_READ_CAPACITY_DEV; return; }
+        const long long st = w;
+        if (q_st > 0) { w += vmx_put_int(BLOB + w, q_st); BLOB[w++] = clip; }
+        for (int x = 0; x < segprob[s]; ++x) {
+            const int p = E.dp_base + k + x; const char* src = cig_pool + probs[p].cig_off; const int n = cig_len[p];
+            for (int i = 0; i < n; ++i) BLOB[w++] = src[i];
+        }
+        k += segprob[s];
+        if (a0.s == 1 && a1.l > 0) { w += vmx_put_int(BLOB + w, a1.l); BLOB[w++] = 'M'; }
+        if (L - q_en > 0) { w += vmx_put_int(BLOB + w, L - q_en); BLOB[w++] = clip; }
+        BLOB[w] = 0;
+        rec.cigar_off = st; rec.cigar_len = w - st;
+        roffs[s] = st; rlens[s] = (int32_t)(w - st);
+        ++w;
+        // :20779-20786
+        const long long ql = vmx_cigar_qlen(BLOB + st, (int)(w - 1 - st));
+        if (!A.hardclip) { if (L != ql) { E.status = VM_READ_RAISED_DEV; return; } }
+        else { if ((q_en - q_st) != ql) { E.status = VM_READ_RAISED_DEV; return; } }
+        REC[s] = rec;
+    }
+    E.nrec = S.nseg;
+    if (need_reverse) { for (int a = 0, b = S.nseg - 1; a < b; ++a, --b) { vm_record t = REC[a]; REC[a] = REC[b]; REC[b] = t; } }
+    // redo with nofilter (:24079-24080)
+    if (E.pass == 0 && !A.nodiscard && E.filtered && S.nseg > 0) {
+        if (vmx_pairedindel(BLOB, roffs, rlens, S.nseg, 30.0, (double*)(A.dup_d + A.blob_off[r] / 8), (int)(blob_cap / 8 - 1))) {
+            E.redo = 1; E.pass = 1; E.nrec = 0;
+            // restore the state saved after the first extension round
+            vmx_segs P = vmx_read_segs(A, r, true);
+            for (int s = 0; s < E.nseg_snap; ++s) { S.st[s] = P.st[s]; S.en[s] = P.en[s]; for (int t = P.st[s] - 1; t <= P.en[s]; ++t) S.A[t] = P.A[t]; }
+            E.nseg = E.nseg_snap; E.filtered = 0; E.skip_ext = 1;
+        }
+    }
+}

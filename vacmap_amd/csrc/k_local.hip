@@ -17,7 +17,7 @@
 #include "vmx_kernels.h"
 #include "vmx_local.h"
 
-__device__ void vmx_block_sort_u64(uint64_t* g, int N, uint64_t* lds);   // k_seed.hip
+#define vmx_block_sort_u64(g, N, lds) vmx_block_sort_u64_impl((g), (N), (lds), VMX_SORT_LDS)
 
 // ------------------------------------------------------------------------------------------------ orient
 __global__ void k_orient(const uint8_t* __restrict__ codes, const int64_t* __restrict__ roff, const double* __restrict__ gscore, int n_reads,

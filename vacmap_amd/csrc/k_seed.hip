@@ -162,26 +162,7 @@ __global__ void __launch_bounds__(256) k_fill_hits(const uint32_t* __restrict__ 
     }
 }
 
-__device__ void vmx_block_sort_u64(uint64_t* g, int N, uint64_t* lds) {
-    uint64_t* a = g;
-    const bool in_lds = N <= VMX_SORT_LDS;
-    if (in_lds) { for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) lds[i] = g[i]; a = lds; }
-    __syncthreads();
-    for (int k = 2; k <= N; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) {
-                int ixj = i ^ j;
-                if (ixj > i) {
-                    uint64_t x = a[i], y = a[ixj];
-                    bool asc = (i & k) == 0;
-                    if ((x > y) == asc) { a[i] = y; a[ixj] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    if (in_lds) { for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) g[i] = lds[i]; __syncthreads(); }
-}
+#define vmx_block_sort_u64(g, N, lds) vmx_block_sort_u64_impl((g), (N), (lds), VMX_SORT_LDS)
 
 // sort hits, cut clusters (ref gap > 5000), rank by (size desc, first ref asc), emit the first check_num clusters.
 // cl_keys: scratch with the same geometry as keys. rows out at key_off[r] (capacity nhits[r]).

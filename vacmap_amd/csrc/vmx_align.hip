@@ -1,0 +1,353 @@
+// vmx_align.hip — the batched path: vm_align_batch / vm_reads_upload / vm_align_resident (include/vacmapx.h).
+// Replaces get_readmap_DP_test (/root/reference/src/vacmap/mammap_clrnano.py:24023-24084) for a whole batch of reads: seed -> global
+// chain -> local re-seed + chain -> extend, every stage a HIP kernel on the context's stream; the host only sizes buffers
+// (a few small device->host reads of totals per batch) and launches. No CPU compute path exists.
+#include "vmx_host.h"
+#include "vmx_stage.h"
+#include "vmx_select.h"
+#include "vmx_ext_state.h"
+#include <algorithm>
+#include <cstring>
+
+using namespace vmx;
+
+__global__ void k_orient(const uint8_t* codes, const int64_t* roff, const double* gscore, int n_reads, uint8_t* ocodes);
+__global__ void k_scan_i64(const int64_t* in, int64_t* out, int64_t n, int pow2_round);
+__global__ void k_ext_phase(vmx_ext_args A, int phase);
+__global__ void k_desc_lens(const vmx_pair_desc* desc, const int32_t* n_prob, int64_t* tl, int64_t* ql);
+__global__ void k_gather(const vmx_pair_desc* desc, const int32_t* n_prob, const int32_t* prob_read, const uint8_t* ocodes, const int64_t* roff,
+                         const uint8_t* ref, const int64_t* t_off, const int64_t* q_off, uint8_t* tpool, uint8_t* qpool, int64_t pool_cap, int32_t* overflow);
+__global__ void k_prob_owner(const vmx_ext_read* er, int n_reads, int use_dp, int32_t* prob_read);
+__global__ void k_dp_sizes(const vmx_pair_desc* desc, const int32_t* n_prob, int64_t* tb_sz, int64_t* bnd_sz, int64_t* run_sz, int64_t* cig_sz);
+__global__ void k_dp_table(const vmx_pair_desc* desc, const int32_t* n_prob, const int64_t* t_off, const int64_t* q_off, const int64_t* tb_off,
+                           const int64_t* bnd_off, const int64_t* run_off, const int64_t* cig_off, vmx_dp_prob* probs);
+__global__ void k_ext_records(vmx_ext_args A, const vmx_dp_prob* probs, const char* cig_pool, const int32_t* cig_len);
+
+// ---- small utility kernels
+__global__ void k_compact_rows(const int64_t* __restrict__ rows, const int64_t* __restrict__ koff, const int64_t* __restrict__ aoff, int n_reads, int64_t* __restrict__ out) {
+    for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        const int64_t n4 = 4 * (aoff[r + 1] - aoff[r]);
+        const int64_t* s = rows + 4 * koff[r]; int64_t* d = out + 4 * aoff[r];
+        for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) d[i] = s[i];
+    }
+}
+__global__ void k_i32_to_i64(const int32_t* __restrict__ in, int64_t* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+__global__ void k_readlens(const int64_t* __restrict__ roff, int64_t* __restrict__ lens, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) lens[i] = roff[i + 1] - roff[i];
+}
+
+struct vm_reads { vm_ctx* ctx; int64_t n; std::vector<int64_t> h_off; DevBuf raw, codes, off; };
+
+struct vmx_batch_bufs {
+    DevBuf seed[12];
+    DevBuf nanc64, aoff, rows, lens, keys, koff, sorted, flip, S, P, SA, cov, gmax, opc, rl, gap, scr, soff, res, plen, prow, ocodes;
+    // extend stage
+    DevBuf er, coff3, soff2, segA, st, en, segA_s, st_s, en_s, segprob, dup, desc[2], rcount, oflow, probread, tl, ql, toff, qoff, tpool, qpool;
+    DevBuf edout, carry, ext3, dpsz[4], dpoff[4], dptab, tb, bnd, run, cig, ciglen, dpscore, rec, blob, bloboff, reccoff, recclen, dupd, totals;
+    DevBuf raw, codes, off;
+    void release() { DevBuf* p = (DevBuf*)this; for (size_t i = 0; i < sizeof(*this) / sizeof(DevBuf); ++i) p[i].release(); }
+};
+static vmx_batch_bufs* batch_bufs(vm_ctx* c) { if (!c->bbufs) c->bbufs = new vmx_batch_bufs(); return c->bbufs; }
+void vmx_ctx_free_batch_bufs(vm_ctx* c) { if (c->bbufs) { c->bbufs->release(); delete c->bbufs; c->bbufs = nullptr; } }
+
+#define LAUNCH1D(kernel, n, ...) hipLaunchKernelGGL(kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(((n) + 255) / 256, 4096))), dim3(256), 0, c->stream, __VA_ARGS__)
+
+// one DP round of the extend stage: descriptors (count on device) -> offsets -> gathered pools. returns host copy of the count
+static int ext_gather_round(vm_ctx* c, vmx_batch_bufs& B, const vm_index_view& ix, int64_t n, const uint8_t* d_ocodes, const int64_t* d_roff, int cur, int redo_only,
+                            int64_t round_cap, int64_t pool_cap) {
+    const int G = c->num_cu * 4;
+    hipLaunchKernelGGL(k_prob_owner, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, B.er.as<vmx_ext_read>(), (int)n, redo_only, B.probread.as<int32_t>());
+    hipLaunchKernelGGL(k_desc_lens, dim3(G), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.tl.as<int64_t>(), B.ql.as<int64_t>());
+    // scans over the full capacity would be wasteful: the count lives on the device, so read it (4 bytes) — also needed to size the DP launches
+    int32_t cnt = 0;
+    VMX_TRY(download(&cnt, B.rcount.p, 1, c->stream));
+    VMX_HIP(hipStreamSynchronize(c->stream));
+    if (cnt > round_cap) cnt = (int32_t)round_cap;
+    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, B.tl.as<int64_t>(), B.toff.as<int64_t>(), (int64_t)cnt, 0);
+    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, B.ql.as<int64_t>(), B.qoff.as<int64_t>(), (int64_t)cnt, 0);
+    if (cnt) hipLaunchKernelGGL(k_gather, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(),
+                                B.probread.as<int32_t>(), d_ocodes, d_roff, ix.codes, B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), pool_cap,
+                                B.oflow.as<int32_t>());
+    return cnt;
+}
+
+static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
+                        vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats) {
+    *recs = nullptr; *n_recs = 0; *cigar_blob = nullptr;
+    if (prm->mode == VM_MODE_R) { set_error("mode R (fixed-penalty chain variants) not built yet"); return VM_ERR_UNSUPPORTED; }
+    vmx_batch_bufs& B = *batch_bufs(c);
+    vm_index_view ix; vmx_index_view(mi, &ix);
+    const int64_t total_bases = h_roff[n];
+    vm_batch_stats st; memset(&st, 0, sizeof st);
+    st.n_reads = n; st.read_bases = total_bases;
+    hipEvent_t* ev = c->ev; int nev = 0;
+    VMX_HIP(hipEventRecord(ev[nev++], c->stream));
+    if (n == 0) { *recs = (vm_record*)malloc(sizeof(vm_record)); *cigar_blob = (char*)malloc(1); if (stats) *stats = st; return VM_OK; }
+
+    // ---------------- S1 seed
+    std::vector<int64_t> h_koff, h_nhits;
+    VMX_TRY(vmx_seed_stage(c, mi, prm->check_num, prm->mid_occ, n, d_codes, d_roff, total_bases, B.seed, h_koff, h_nhits));
+    for (int64_t r = 0; r < n; ++r) st.n_hits += h_nhits[r];
+    // compact anchors: aoff = scan(n_anchors)
+    VMX_TRY(B.nanc64.reserve(8 * (size_t)(n + 2))); VMX_TRY(B.aoff.reserve(8 * (size_t)(n + 2)));
+    LAUNCH1D(k_i32_to_i64, n, B.seed[11].as<int32_t>(), B.nanc64.as<int64_t>(), n);
+    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, B.nanc64.as<int64_t>(), B.aoff.as<int64_t>(), n, 0);
+    std::vector<int64_t> h_aoff((size_t)n + 1);
+    VMX_TRY(download(h_aoff.data(), B.aoff.p, (size_t)n + 1, c->stream));
+    VMX_HIP(hipStreamSynchronize(c->stream));
+    const int64_t tot = h_aoff[n];
+    st.n_anchors = tot;
+    VMX_TRY(B.rows.reserve(32 * (size_t)(tot + 1)));
+    hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 8)), dim3(128), 0, c->stream, B.seed[10].as<int64_t>(), B.seed[7].as<int64_t>(),
+                       B.aoff.as<int64_t>(), (int)n, B.rows.as<int64_t>());
+    VMX_TRY(B.lens.reserve(8 * (size_t)(n + 1)));
+    LAUNCH1D(k_readlens, n, d_roff, B.lens.as<int64_t>(), n);
+    VMX_HIP(hipEventRecord(ev[nev++], c->stream));
+
+    // ---------------- S2 + G1/G2 global chain
+    std::vector<int64_t> koff((size_t)n + 1), soff((size_t)n + 1);
+    int64_t kt = 0, stt = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        int64_t m = h_aoff[r + 1] - h_aoff[r]; int64_t N = 1; while (N < m) N <<= 1;
+        koff[r] = kt; kt += N; soff[r] = stt; stt += (vmx_select_scratch_bytes(m) + 15) & ~(int64_t)15;
+    }
+    koff[n] = kt; soff[n] = stt;
+    VMX_TRY(B.keys.reserve(8 * (size_t)(kt + 1))); VMX_TRY(upload(B.koff, koff.data(), (size_t)n + 1, c->stream));
+    VMX_TRY(B.sorted.reserve(sizeof(vmx_anchor) * (size_t)(tot + 1))); VMX_TRY(B.flip.reserve(4 * (size_t)(n + 1)));
+    hipLaunchKernelGGL(k_flip_sort, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, B.rows.as<int64_t>(), B.aoff.as<int64_t>(), B.lens.as<int64_t>(),
+                       (int)n, B.keys.as<uint64_t>(), B.koff.as<int64_t>(), B.sorted.as<vmx_anchor>(), B.flip.as<int32_t>());
+    VMX_TRY(B.S.reserve(8 * (size_t)(tot + 1))); VMX_TRY(B.P.reserve(4 * (size_t)(tot + 1))); VMX_TRY(B.SA.reserve(4 * (size_t)(tot + 1)));
+    VMX_TRY(B.cov.reserve((size_t)tot + 16)); VMX_TRY(B.gmax.reserve(8 * (size_t)(n + 1))); VMX_TRY(B.opc.reserve(8 * (size_t)(n + 1)));
+    const HostTables& T = host_tables();
+    {
+        if (prm->global_maxdiff > 62) { set_error("global_maxdiff > 62 unsupported"); return VM_ERR_UNSUPPORTED; }
+        std::vector<double> gap(64, 0.0);
+        for (int g = 1; g <= prm->global_maxdiff; ++g) gap[g] = (0.01 * ix.k * g + 0.5 * T.log2int[g]);
+        VMX_TRY(upload(B.gap, gap.data(), 64, c->stream));
+    }
+    const int caps[4] = {768, 1536, 3072, 4736};
+    std::vector<int32_t> lists[5];
+    for (int64_t r = 0; r < n; ++r) {
+        int64_t m = h_aoff[r + 1] - h_aoff[r]; const int64_t L = h_roff[r + 1] - h_roff[r];
+        if (m <= 2) continue;                                             // :23986 unmapped
+        if ((double)m / (double)L > 5.0) continue;                        // fast_enable (:23570): GC-fast not built yet -> gmax stays -1
+        int bk = 4; for (int q = 0; q < 4; ++q) if (m <= caps[q]) { bk = q; break; }
+        lists[bk].push_back((int32_t)r);
+    }
+    {
+        std::vector<int32_t> rl; int64_t rl_off[6];
+        for (int q = 0; q < 5; ++q) { rl_off[q] = (int64_t)rl.size(); rl.insert(rl.end(), lists[q].begin(), lists[q].end()); }
+        VMX_TRY(upload(B.rl, rl.data(), rl.size(), c->stream));
+        VMX_HIP(hipMemsetAsync(B.gmax.p, 0xff, 8 * (size_t)n, c->stream));
+        for (int q = 0; q < 5; ++q) {
+            int cnt = (int)lists[q].size(); if (!cnt) continue;
+            int cap = q < 4 ? caps[q] : 0; size_t shmem = (size_t)cap * VMX_GC_BYTES_PER_ANCHOR + 64;
+#ifndef VMX_EMU
+            if (shmem > 48 * 1024) VMX_HIP(hipFuncSetAttribute((const void*)k_chain_global, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+#endif
+            hipLaunchKernelGGL(k_chain_global, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 8)), dim3(64), shmem, c->stream, B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(),
+                               B.rl.as<int32_t>() + rl_off[q], cnt, cap, c->tables, B.gap.as<double>(), prm->global_skipcost, prm->global_maxdiff, 1000, B.S.as<double>(),
+                               B.P.as<int32_t>(), B.SA.as<int32_t>(), B.cov.as<uint8_t>(), B.gmax.as<int64_t>(), B.opc.as<int64_t>());
+        }
+    }
+    VMX_TRY(B.scr.reserve((size_t)stt + 64)); VMX_TRY(upload(B.soff, soff.data(), (size_t)n + 1, c->stream));
+    VMX_TRY(B.res.reserve(16 * (size_t)(n + 2) + 64));
+    double* d_gscore = B.res.as<double>(); int32_t* d_mapq = (int32_t*)(d_gscore + n + 1); int32_t* d_np = d_mapq + n + 1;
+    VMX_TRY(B.plen.reserve(4 * (size_t)(tot + 1))); VMX_TRY(B.prow.reserve(sizeof(vmx_anchor) * (size_t)(tot + 1)));
+    hipLaunchKernelGGL(k_chain_select, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(), B.lens.as<int64_t>(), (int)n,
+                       B.S.as<double>(), B.P.as<int32_t>(), B.SA.as<int32_t>(), B.gmax.as<int64_t>(), B.flip.as<int32_t>(), prm->mode, B.scr.as<char>(), B.soff.as<int64_t>(), d_mapq,
+                       d_gscore, d_np, B.plen.as<int32_t>(), B.prow.as<vmx_anchor>());
+    VMX_HIP(hipEventRecord(ev[nev++], c->stream));
+
+    // ---------------- orient + L1-L4 local stage
+    VMX_TRY(B.ocodes.reserve((size_t)total_bases + 64));
+    hipLaunchKernelGGL(k_orient, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, d_codes, d_roff, d_gscore, (int)n, B.ocodes.as<uint8_t>());
+    vmx_local_bufs& L = *vmx_ctx_local_bufs(c);
+    VMX_TRY(vmx_local_stage(c, ix, prm, n, B.ocodes.as<uint8_t>(), d_roff, h_roff, B.prow.as<vmx_anchor>(), B.plen.as<int32_t>(), d_np, B.aoff.as<int64_t>(), h_aoff, d_gscore, L));
+    for (int64_t r = 0; r < n; ++r) st.n_local_anchors += L.h_la_cnt[r];
+    VMX_HIP(hipEventRecord(ev[nev++], c->stream));
+
+    // ---------------- E1-E6 extend stage
+    // per-read pool geometry from the local anchor count (the chain is never longer than that)
+    std::vector<int64_t> coff3((size_t)n + 1), soff2((size_t)n + 1), bloboff((size_t)n + 1);
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t cl = L.h_la_cnt[r], len = h_roff[r + 1] - h_roff[r];
+        coff3[r + 1] = coff3[r] + (cl > 0 ? 3 * cl + 8 : 0); soff2[r + 1] = soff2[r] + (cl > 0 ? cl + 2 : 0);
+        bloboff[r + 1] = bloboff[r] + (cl > 0 ? ((3 * len + 64 * (cl / 2 + 2) + 63) & ~(int64_t)7) : 0);
+    }
+    const int64_t cA = coff3[n], cS = soff2[n], cB = bloboff[n];
+    VMX_TRY(B.er.reserve(sizeof(vmx_ext_read) * (size_t)(n + 1))); VMX_TRY(upload(B.coff3, coff3.data(), (size_t)n + 1, c->stream)); VMX_TRY(upload(B.soff2, soff2.data(), (size_t)n + 1, c->stream));
+    VMX_TRY(upload(B.bloboff, bloboff.data(), (size_t)n + 1, c->stream));
+    VMX_TRY(B.segA.reserve(sizeof(vmx_anchor) * (size_t)(cA + 1))); VMX_TRY(B.segA_s.reserve(sizeof(vmx_anchor) * (size_t)(cA + 1)));
+    VMX_TRY(B.st.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.en.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.st_s.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.en_s.reserve(4 * (size_t)(cS + 1)));
+    VMX_TRY(B.segprob.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.dup.reserve(4 * (size_t)(cS + 1)));
+    const int64_t round_cap = cS + 16;                       // one problem per anchor at most in any round
+    const int64_t pool_cap = 6 * total_bases + (1 << 20);
+    VMX_TRY(B.desc[0].reserve(sizeof(vmx_pair_desc) * (size_t)round_cap)); VMX_TRY(B.desc[1].reserve(sizeof(vmx_pair_desc) * (size_t)round_cap));
+    VMX_TRY(B.rcount.reserve(64)); VMX_TRY(B.oflow.reserve(64)); VMX_TRY(B.probread.reserve(4 * (size_t)round_cap));
+    VMX_TRY(B.tl.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.ql.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.toff.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.qoff.reserve(8 * (size_t)(round_cap + 1)));
+    VMX_TRY(B.tpool.reserve((size_t)pool_cap + 64)); VMX_TRY(B.qpool.reserve((size_t)pool_cap + 64));
+    VMX_TRY(B.edout.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.carry.reserve((size_t)pool_cap + 64)); VMX_TRY(B.ext3.reserve(12 * (size_t)(round_cap + 1)));
+    VMX_TRY(B.rec.reserve(sizeof(vm_record) * (size_t)(cS + 1))); VMX_TRY(B.blob.reserve((size_t)cB + 64)); VMX_TRY(B.reccoff.reserve(8 * (size_t)(cS + 1)));
+    VMX_TRY(B.recclen.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.dupd.reserve((size_t)cB + 64));
+    VMX_HIP(hipMemsetAsync(B.oflow.p, 0, 4, c->stream));
+    vmx_ext_args A; memset(&A, 0, sizeof A);
+    A.n_reads = (int)n; A.nseq = ix.nseq; A.local_maxdiff = prm->local_maxdiff; A.nodiscard = prm->nodiscard; A.hardclip = prm->hardclip; A.redo_only = 0; A.maxdivergence = prm->maxdivergence;
+    A.ocodes = B.ocodes.as<uint8_t>(); A.roff = d_roff; A.ref = ix.codes; A.coff = ix.coff;
+    A.chain = L.chain.as<vmx_anchor>(); A.chain_len = L.chain_len.as<int32_t>(); A.la_off = L.la_off.as<int64_t>(); A.lstatus = L.status.as<int32_t>();
+    A.gscore = d_gscore; A.mapq = d_mapq; A.er = B.er.as<vmx_ext_read>(); A.coff3 = B.coff3.as<int64_t>(); A.soff = B.soff2.as<int64_t>();
+    A.segA = B.segA.as<vmx_anchor>(); A.st = B.st.as<int32_t>(); A.en = B.en.as<int32_t>(); A.segA_snap = B.segA_s.as<vmx_anchor>(); A.st_snap = B.st_s.as<int32_t>(); A.en_snap = B.en_s.as<int32_t>();
+    A.seg_prob = B.segprob.as<int32_t>(); A.dup = B.dup.as<int32_t>(); A.round_count = B.rcount.as<int32_t>(); A.round_cap = round_cap; A.overflow = B.oflow.as<int32_t>();
+    A.ed_out = B.edout.as<int64_t>(); A.ext_te = B.ext3.as<int32_t>(); A.ext_qe = B.ext3.as<int32_t>() + round_cap;
+    A.rec = B.rec.as<vm_record>(); A.rec_blob = B.blob.as<char>(); A.blob_off = B.bloboff.as<int64_t>(); A.rec_coff = B.reccoff.as<int64_t>(); A.rec_clen = B.recclen.as<int32_t>();
+    A.dup_d = B.dupd.as<double>();
+    const unsigned gridR = (unsigned)((n + 63) / 64);
+    int cur = 0;
+    auto phase = [&](int ph) { A.desc = B.desc[cur].as<vmx_pair_desc>(); A.desc_prev = B.desc[cur ^ 1].as<vmx_pair_desc>();
+                               hipMemsetAsync(B.rcount.p, 0, 4, c->stream); hipLaunchKernelGGL(k_ext_phase, dim3(gridR), dim3(64), 0, c->stream, A, ph); };
+    auto ext_round = [&](int redo_only) -> int {   // x-drop extension of the problems of the current round
+        int cnt = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, redo_only, round_cap, pool_cap);
+        if (cnt < 0) return cnt;
+        st.n_ext_problems += cnt;
+        if (cnt) hipLaunchKernelGGL(k_extend, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.qpool.as<uint8_t>(),
+                                    B.qoff.as<int64_t>(), cnt, 2, -4, 4, 4, 100, 50, B.ext3.as<int32_t>(), B.ext3.as<int32_t>() + round_cap, B.ext3.as<int32_t>() + 2 * round_cap);
+        cur ^= 1;
+        return cnt;
+    };
+    std::vector<int64_t> dp_tot(5, 0);
+    auto gapfill = [&](int redo_only) -> int {
+        int cnt = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, redo_only, round_cap, pool_cap);
+        if (cnt < 0) return cnt;
+        for (int i = 0; i < 4; ++i) { VMX_TRY(B.dpsz[i].reserve(8 * (size_t)(cnt + 2))); VMX_TRY(B.dpoff[i].reserve(8 * (size_t)(cnt + 2))); }
+        VMX_TRY(B.dptab.reserve(sizeof(vmx_dp_prob) * (size_t)(cnt + 1))); VMX_TRY(B.ciglen.reserve(4 * (size_t)(cnt + 1))); VMX_TRY(B.dpscore.reserve(4 * (size_t)(cnt + 1)));
+        const int G = c->num_cu * 4;
+        hipLaunchKernelGGL(k_dp_sizes, dim3(G), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.dpsz[0].as<int64_t>(), B.dpsz[1].as<int64_t>(),
+                           B.dpsz[2].as<int64_t>(), B.dpsz[3].as<int64_t>());
+        for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, B.dpsz[i].as<int64_t>(), B.dpoff[i].as<int64_t>(), (int64_t)cnt, 0);
+        // sizing sync #3: total traceback / boundary / run / CIGAR bytes of the batch
+        int64_t totals[4];
+        for (int i = 0; i < 4; ++i) VMX_TRY(download(&totals[i], B.dpoff[i].as<int64_t>() + cnt, 1, c->stream));
+        int64_t tq[2]; VMX_TRY(download(&tq[0], B.toff.as<int64_t>() + cnt, 1, c->stream)); VMX_TRY(download(&tq[1], B.qoff.as<int64_t>() + cnt, 1, c->stream));
+        VMX_HIP(hipStreamSynchronize(c->stream));
+        VMX_TRY(B.tb.reserve((size_t)totals[0] + 64)); VMX_TRY(B.bnd.reserve(4 * (size_t)(totals[1] + 4))); VMX_TRY(B.run.reserve(4 * (size_t)(totals[2] + 4))); VMX_TRY(B.cig.reserve((size_t)totals[3] + 16));
+        st.n_dp_problems += cnt; st.dp_cells += totals[0];
+        hipLaunchKernelGGL(k_dp_table, dim3(G), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.dpoff[0].as<int64_t>(),
+                           B.dpoff[1].as<int64_t>(), B.dpoff[2].as<int64_t>(), B.dpoff[3].as<int64_t>(), B.dptab.as<vmx_dp_prob>());
+        if (cnt) {
+            hipLaunchKernelGGL(k_gapfill_fill, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>(), cnt,
+                               2, -4, 4, 2, 24, 1, B.tb.as<uint8_t>(), B.bnd.as<int32_t>(), B.dpscore.as<int32_t>());
+            hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>(), cnt, prm->eqx,
+                               B.tb.as<uint8_t>(), B.run.as<uint32_t>(), B.cig.as<char>(), B.ciglen.as<int32_t>());
+        }
+        A.redo_only = redo_only;
+        hipLaunchKernelGGL(k_ext_records, dim3(gridR), dim3(64), 0, c->stream, A, B.dptab.as<vmx_dp_prob>(), B.cig.as<char>(), B.ciglen.as<int32_t>());
+        cur ^= 1;
+        return cnt;
+    };
+    // pass 0
+    phase(0);
+    {   // divergence filter: edit distance of every segment (:19251)
+        int cnt = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, 0, round_cap, pool_cap);
+        if (cnt < 0) return cnt;
+        st.n_segments = cnt; st.n_ed_problems = cnt;
+        if (cnt) hipLaunchKernelGGL(k_edit_distance, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(),
+                                    B.toff.as<int64_t>(), B.carry.as<int8_t>(), B.toff.as<int64_t>(), cnt, B.edout.as<int64_t>());
+        cur ^= 1;
+    }
+    VMX_HIP(hipEventRecord(ev[nev++], c->stream));
+    phase(1); VMX_TRY(ext_round(0));
+    phase(2); VMX_TRY(ext_round(0));
+    phase(3); VMX_TRY(ext_round(0));
+    phase(4); VMX_TRY(ext_round(0));
+    VMX_HIP(hipEventRecord(ev[nev++], c->stream));
+    phase(5); VMX_TRY(gapfill(0));
+    VMX_HIP(hipEventRecord(ev[nev++], c->stream));
+    // pass 1: reads whose CIGARs carry paired indels are re-run with nofilter (:24079-24080)
+    A.redo_only = 1;
+    phase(3); phase(4); phase(5); VMX_TRY(gapfill(1));
+    A.redo_only = 0;
+    VMX_HIP(hipEventRecord(ev[nev++], c->stream));
+
+    // ---------------- results
+    std::vector<vmx_ext_read> er((size_t)n); std::vector<vm_record> hrec((size_t)cS + 1); std::vector<char> hblob((size_t)cB + 1);
+    int32_t oflow = 0;
+    VMX_TRY(download(er.data(), B.er.p, (size_t)n, c->stream)); VMX_TRY(download(hrec.data(), B.rec.p, (size_t)cS, c->stream));
+    VMX_TRY(download(hblob.data(), B.blob.p, (size_t)cB, c->stream)); VMX_TRY(download(&oflow, B.oflow.p, 1, c->stream));
+    std::vector<int32_t> lstat((size_t)n);
+    VMX_TRY(download(lstat.data(), L.status.p, (size_t)n, c->stream));
+    std::vector<int64_t> h_gmax((size_t)n);
+    VMX_TRY(download(h_gmax.data(), B.gmax.p, (size_t)n, c->stream));
+    VMX_HIP(hipEventRecord(ev[nev++], c->stream));
+    VMX_HIP(hipStreamSynchronize(c->stream));
+    VMX_HIP(hipGetLastError());
+    if (oflow) { set_error("extend stage: a per-batch work pool overflowed"); return VM_ERR_OOM; }
+    int64_t nr = 0, nb = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        int stt2 = er[r].status;
+        if (h_gmax[r] == -1 && (h_aoff[r + 1] - h_aoff[r]) > 2) stt2 = VM_READ_FASTPATH_DEV;   // needs GC-fast
+        if (status_per_read) status_per_read[r] = stt2;
+        if (stt2 != 0) { st.n_failed++; continue; }
+        if (er[r].nrec == 0) st.n_unmapped++;
+        for (int x = 0; x < er[r].nrec; ++x) { nr++; nb += hrec[soff2[r] + x].cigar_len + 1; }
+    }
+    *recs = (vm_record*)malloc(sizeof(vm_record) * (size_t)std::max<int64_t>(nr, 1)); *cigar_blob = (char*)malloc((size_t)std::max<int64_t>(nb, 1));
+    int64_t ri = 0, bo = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        int stt2 = er[r].status; if (h_gmax[r] == -1 && (h_aoff[r + 1] - h_aoff[r]) > 2) stt2 = VM_READ_FASTPATH_DEV;
+        if (stt2 != 0) continue;
+        for (int x = 0; x < er[r].nrec; ++x) {
+            vm_record rc = hrec[soff2[r] + x];
+            memcpy(*cigar_blob + bo, hblob.data() + bloboff[r] + rc.cigar_off, (size_t)rc.cigar_len); (*cigar_blob)[bo + rc.cigar_len] = 0;
+            rc.cigar_off = bo; bo += rc.cigar_len + 1;
+            st.aligned_bases += rc.q_en - rc.q_st; st.cigar_bytes += rc.cigar_len;
+            (*recs)[ri++] = rc;
+        }
+    }
+    *n_recs = nr; st.n_records = nr;
+    float ms = 0;
+    hipEventElapsedTime(&ms, ev[0], ev[nev - 1]); st.ms_total = ms;
+    for (int i = 1; i < nev && i < 16; ++i) { hipEventElapsedTime(&ms, ev[i - 1], ev[i]); st.ms_stage[i - 1] = ms; }
+    if (stats) *stats = st;
+    return VM_OK;
+}
+
+extern "C" {
+
+int vm_reads_upload(vm_ctx* c, int64_t n, const char* seqs, const int64_t* offsets, vm_reads** out) {
+    *out = nullptr;
+    if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
+    VMX_HIP(hipSetDevice(c->device));
+    vm_reads* R = new vm_reads(); R->ctx = c; R->n = n; R->h_off.assign(offsets, offsets + n + 1);
+    const int64_t tot = offsets[n];
+    int rc = 0;
+    if ((rc = upload(R->raw, seqs, (size_t)tot, c->stream)) < 0 || (rc = R->codes.reserve((size_t)tot + 64)) < 0 || (rc = upload(R->off, offsets, (size_t)n + 1, c->stream)) < 0) { delete R; return rc; }
+    if (tot) LAUNCH1D(k_encode, tot, R->raw.as<char>(), R->codes.as<uint8_t>(), tot);
+    VMX_HIP(hipStreamSynchronize(c->stream));
+    R->raw.release();
+    *out = R;
+    return VM_OK;
+}
+void vm_reads_free(vm_reads* R) { if (!R) return; R->raw.release(); R->codes.release(); R->off.release(); delete R; }
+
+int vm_align_resident(vm_ctx* c, const vm_index* mi, const vm_params* prm, const vm_reads* R, vm_record** recs, int64_t* n_recs, char** cigar_blob,
+                      int32_t* status_per_read, vm_batch_stats* stats) {
+    if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
+    VMX_HIP(hipSetDevice(c->device));
+    return align_device(c, mi, prm, R->n, R->codes.as<uint8_t>(), R->off.as<int64_t>(), R->h_off, recs, n_recs, cigar_blob, status_per_read, stats);
+}
+
+int vm_align_batch(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const char* seqs, const int64_t* offsets, vm_record** recs, int64_t* n_recs,
+                   char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats) {
+    if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
+    VMX_HIP(hipSetDevice(c->device));
+    vmx_batch_bufs& B = *batch_bufs(c);
+    const int64_t tot = offsets[n];
+    VMX_TRY(upload(B.raw, seqs, (size_t)tot, c->stream)); VMX_TRY(B.codes.reserve((size_t)tot + 64)); VMX_TRY(upload(B.off, offsets, (size_t)n + 1, c->stream));
+    if (tot) LAUNCH1D(k_encode, tot, B.raw.as<char>(), B.codes.as<uint8_t>(), tot);
+    std::vector<int64_t> h_off(offsets, offsets + n + 1);
+    return align_device(c, mi, prm, n, B.codes.as<uint8_t>(), B.off.as<int64_t>(), h_off, recs, n_recs, cigar_blob, status_per_read, stats);
+}
+
+}  // extern "C"

@@ -18,6 +18,9 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 }  // namespace vmx
 using namespace vmx;
 
+void vmx_ctx_free_local_bufs(vm_ctx* c);    // vmx_stage_local.hip
+void vmx_ctx_free_batch_bufs(vm_ctx* c);    // vmx_align.hip
+
 static inline int grid_for(const vm_ctx* c, int64_t n_items, int per_cu = 8) {
     int64_t g = std::min<int64_t>(n_items, (int64_t)c->num_cu * per_cu);
     return (int)std::max<int64_t>(g, 1);
@@ -83,6 +86,8 @@ void vm_ctx_destroy(vm_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < VMX_NBUF; ++i) c->b[i].release();
+    vmx_ctx_free_local_bufs(c);
+    vmx_ctx_free_batch_bufs(c);
     c->tab_buf.release();
     for (int i = 0; i < 24; ++i) (void)hipEventDestroy(c->ev[i]);
     (void)hipStreamDestroy(c->stream);

@@ -61,7 +61,30 @@ __device__ __forceinline__ int vmx_block_excl_scan(int v, int* scratch, int* tot
     return base + inc - v;
 }
 
-__device__ __forceinline__ uint8_t vmx_code(uint8_t c) {
+// block-wide bitonic sort of N (power of two) uint64 keys living in HBM at g; staged through `lds` (lds_cap keys) when they fit.
+// every thread of the workgroup must call it.
+__device__ inline void vmx_block_sort_u64_impl(uint64_t* g, int N, uint64_t* lds, int lds_cap) {
+    uint64_t* a = g;
+    const bool in_lds = N <= lds_cap;
+    if (in_lds) { for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) lds[i] = g[i]; a = lds; }
+    __syncthreads();
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    uint64_t x = a[i], y = a[ixj];
+                    bool asc = (i & k) == 0;
+                    if ((x > y) == asc) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (in_lds) { for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) g[i] = lds[i]; __syncthreads(); }
+}
+
+__host__ __device__ __forceinline__ uint8_t vmx_code(uint8_t c) {
     switch (c) {
         case 'A': case 'a': return 0;
         case 'C': case 'c': return 1;
