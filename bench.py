@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py — aligned Gbp/s of the seed -> non-linear chain -> extend path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads-per-step R] [--ref-mb M] [--cpu-sample S]
+    torchrun / python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...   (one rank per GPU)
+
+Workload (BASELINE.json configs[1], scaled by --steps): synthetic ONT-shape reads (Gamma lengths, mean 15 kb, 10 % error
+4:3:3 sub:del:ins) against a synthetic 100 Mb reference, -mode H -k 15 -w 10 -c 100. One "step" = one pass of the whole
+hot path (vm_align_resident: seed, global chain, local re-seed + chain, extend) over one batch of reads that is already
+resident in HBM; K timed steps use K different batches. value = aligned bases of all ranks / max-over-ranks time.
+Multi-GPU: the reference index is replicated per GPU (each rank builds the same seeded reference), reads are sharded
+across ranks, no data-path collective (weak scaling); torch.distributed (RCCL) provides the barrier and the reductions.
+"""
+import argparse, json, os, sys, time
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--reads-per-step', type=int, default=4096)
+    ap.add_argument('--ref-mb', type=float, default=100.0)
+    ap.add_argument('--mean-len', type=int, default=15000)
+    ap.add_argument('--err', type=float, default=0.10)
+    ap.add_argument('--cpu-sample', type=int, default=96, help='reads for the CPU baseline leg (rank 0, N=1 only); 0 disables')
+    ap.add_argument('--verify', type=int, default=8, help='reads of the first batch cross-checked against the oracle (0 disables)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1')); local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+
+    from vacmap_amd import synth
+    from vacmap_amd.lib import Context, Index, ResidentReads, load
+    ctx = Context(local_rank)                 # raises without the HIP library / a GPU: no fallback
+    lib = load()
+    prm = lib.params('H')
+
+    t0 = time.time()
+    ref_len = int(args.ref_mb * 1e6)
+    contigs = synth.make_reference([ref_len], seed=1)             # config 2: 1 contig x 100 Mb, seed 1
+    index = Index.from_seqs(ctx, ['chr1'], [contigs[0].tobytes()], k=15, w=10)
+    t_index = time.time() - t0
+
+    nsteps = args.warmup + args.steps
+    batches = []
+    for s in range(nsteps):
+        seed = 1000 + 7919 * (s * world + rank)                    # every (step, rank) draws its own reads
+        cat, off, truth = synth.sample_reads_concat(contigs, args.reads_per_step, mean_len=args.mean_len, err=args.err, seed=seed)
+        batches.append((cat, off))
+    resident = [ResidentReads(ctx, concat=c, offsets=o) for c, o in batches]   # inputs resident in HBM before timing
+    t_setup = time.time() - t0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # optional cross-check of the first batch against the oracle (checker only; outside the timed region)
+    verified = None
+    for s in range(args.warmup):
+        st, recs, stats = resident[s].align(index, prm, want_records=(s == 0 and args.verify > 0 and rank == 0))
+        if s == 0 and args.verify > 0 and rank == 0:
+            import oracle_lib as O
+            oi = O.Index.from_seqs(['chr1'], [contigs[0].tobytes()], k=15, w=10)
+            op = O.params('H')
+            cat, off = batches[0]
+            ok = 0
+            for i in range(min(args.verify, args.reads_per_step)):
+                rd = cat[off[i]:off[i + 1]].tobytes()
+                ost, orecs = O.align_read(oi, rd, op)
+                mine = [t[1:] for t in recs if t[0] == i]
+                ok += int((st[i] == 0) == (ost == 0) and mine == [t[1:] for t in orecs])
+            verified = '%d/%d' % (ok, min(args.verify, args.reads_per_step))
+            del oi
+
+    agg = {}
+    barrier()
+    t1 = time.time()
+    for s in range(args.warmup, nsteps):
+        st, _, stats = resident[s].align(index, prm, want_records=False)
+        for k, v in stats.items():
+            if k != 'ms_stage':
+                agg[k] = agg.get(k, 0) + v
+        agg['ms_stage'] = [a + b for a, b in zip(agg.get('ms_stage', [0.0] * 16), stats['ms_stage'])]
+    barrier()
+    dt = time.time() - t1
+
+    vals = torch.tensor([dt, float(agg['aligned_bases']), float(agg['n_reads']), float(agg['read_bases']), float(agg['n_failed'])], dtype=torch.float64, device='cuda')
+    if dist is not None:
+        tmax = vals[0:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        sums = vals[1:].clone(); dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        dt_all = float(tmax[0]); aligned, nreads, rbases, nfail = [float(x) for x in sums]
+    else:
+        dt_all = dt; aligned, nreads, rbases, nfail = [float(x) for x in vals[1:]]
+
+    if rank == 0:
+        K = args.steps
+        # roofline of the dominant kernel (k_gapfill_fill): algorithmic bytes per launch per SURVEY §8(d):
+        #   B(read) = L + 16 M + 8 n + (L + 14000)/4 + 40 R + C   with measured M (minimizers), n (anchors), R (records), C (CIGAR bytes)
+        nl = max(int(agg['n_gapfill_launches']), 1)
+        algo_bytes = (agg['read_bases'] + 16 * agg['n_minimizers'] + 8 * agg['n_anchors'] + (agg['read_bases'] + 14000 * agg['n_reads']) / 4.0 +
+                      40 * agg['n_records'] + agg['cigar_bytes'])
+        # one step launches the kernel twice (normal pass + nofilter redo); the redo launch covers a handful of reads, so the
+        # per-launch figures below are per STEP (both launches together)
+        fill_ms = agg['ms_gapfill_fill'] / K
+        achieved = (algo_bytes / K) / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
+        roofline = {'bound': 'hbm', 'kernel': 'k_gapfill_fill', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                    'traffic': None, 'avg_kernel_ms_per_step': fill_ms, 'algorithmic_bytes_per_step': algo_bytes / K,
+                    'dp_cells_per_s': (agg['dp_cells'] / K) / (fill_ms * 1e-3) if fill_ms > 0 else 0.0,
+                    'note': 'integer DP kernel: VALU-bound, not HBM-bound (DESIGN.md); traffic from rocprofv3 PMC passes is kept in profiles/'}
+        cpu = None
+        if args.cpu_sample > 0 and world == 1:
+            import oracle_lib as O
+            oi = O.Index.from_seqs(['chr1'], [contigs[0].tobytes()], k=15, w=10)
+            op = O.params('H')
+            cat, off = batches[args.warmup]
+            ns = min(args.cpu_sample, args.reads_per_step)
+            rds = [cat[off[i]:off[i + 1]].tobytes() for i in range(ns)]
+            cores = os.cpu_count() or 1
+            tc = time.time()
+            cst, crecs = O.align_batch(oi, rds, op, nthreads=cores)
+            tcpu = time.time() - tc
+            cal = sum(t[4] - t[3] for t in crecs)
+            cpu = {'value': cal / tcpu / 1e9, 'unit': 'Gbp/s', 'cores': cores, 'kind': 'port',
+                   'sample': '%d reads of the first timed batch (%d bases), oracle/liboracle.so with %d std::threads, index build excluded' % (ns, int(off[ns]), cores),
+                   'seconds': tcpu}
+        out = {
+            'metric': 'aligned Gbp/s (whole node) + reads/s, 15 kb ONT-shape reads vs synthetic ref', 'value': aligned / dt_all / 1e9, 'unit': 'Gbp/s',
+            'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': dt_all * 1e3 / K, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'int32+f64', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: synthetic ONT reads (Gamma mean %d bp, %.0f%% err) vs %.0f Mb synthetic ref, -mode H -k 15 -w 10 -c 100' % (
+                args.mean_len, args.err * 100, args.ref_mb), 'reads_per_step_per_gpu': args.reads_per_step, 'reads_timed': int(nreads),
+                'parallelism': 'reads sharded over %d GPU(s), index replicated' % world},
+            'reads_per_s': nreads / dt_all, 'input_Gbp_per_s': rbases / dt_all / 1e9, 'failed_reads': int(nfail), 'unmapped_reads': int(agg['n_unmapped']),
+            'device_ms_per_step': agg['ms_total'] / K, 'stage_ms_per_step': [x / K for x in agg['ms_stage'][:8]],
+            'stage_names': ['seed', 'global_chain', 'local', 'divergence_filter', 'edge_extension', 'gapfill+records', 'nofilter_redo', 'download'],
+            'gapfill_trace_ms_per_step': agg['ms_gapfill_trace'] / K,
+            'per_read': {'minimizers': agg['n_minimizers'] / max(agg['n_reads'], 1), 'anchors': agg['n_anchors'] / max(agg['n_reads'], 1),
+                         'local_anchors': agg['n_local_anchors'] / max(agg['n_reads'], 1), 'dp_problems': agg['n_dp_problems'] / max(agg['n_reads'], 1),
+                         'dp_cells': agg['dp_cells'] / max(agg['n_reads'], 1), 'records': agg['n_records'] / max(agg['n_reads'], 1)},
+            'oracle_crosscheck': verified, 'setup_s': t_setup, 'index_build_s': t_index,
+            'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -168,8 +168,13 @@ typedef struct vm_batch_stats {     /* measured on the device, for bench.py's ro
     int64_t n_reads, read_bases, n_minimizers, n_hits, n_anchors, n_local_hits, n_local_anchors;
     int64_t n_segments, n_ed_problems, ed_cells, n_ext_problems, ext_cells, n_dp_problems, dp_cells;
     int64_t n_records, cigar_bytes, aligned_bases, n_unmapped, n_failed;
+    int64_t dp_string_bytes;        /* target+query bases read by the gap-fill DP */
     double ms_total;                /* device time of the whole batch (HIP events on the ctx stream) */
-    double ms_stage[16];            /* per stage, same events */
+    double ms_stage[16];            /* 0 seed, 1 global chain, 2 local, 3 divergence filter, 4 edge extension, 5 gap fill + records,
+                                       6 nofilter redo, 7 result download */
+    double ms_gapfill_fill;         /* k_gapfill_fill launches only (HIP events on the stream the kernel runs on) */
+    double ms_gapfill_trace;        /* k_gapfill_trace launches only */
+    int64_t n_gapfill_launches;
 } vm_batch_stats;
 
 /* Align n reads (replaces get_readmap_DP_test per read). seqs concatenated, offsets[n+1].

@@ -22,7 +22,9 @@ __global__ void k_encode(const char* __restrict__ in, uint8_t* __restrict__ out,
 // Myers/Hyyro bit-vector, global distance. Pattern = query split into 64-row blocks; lane = block, step = anti-diagonal
 // (lane b works on text column step-b). Blocks beyond 64 are processed in passes; the horizontal deltas leaving block 63
 // of a pass are parked in `carry` (one int8 per text column) for the next pass.
-__global__ void __launch_bounds__(64) k_edit_distance(const uint8_t* __restrict__ qcodes, const int64_t* __restrict__ q_off,
+// (first version: one wavefront per problem, passes run back to back. Superseded by the pass-pipelined kernel in k_ed.hip;
+//  kept as the simple reference form of the same recurrence for A/B timing.)
+__global__ void __launch_bounds__(64) k_edit_distance_v1(const uint8_t* __restrict__ qcodes, const int64_t* __restrict__ q_off,
                                                       const uint8_t* __restrict__ tcodes, const int64_t* __restrict__ t_off,
                                                       int8_t* __restrict__ carry_pool, const int64_t* __restrict__ carry_off,
                                                       int n_prob, int64_t* __restrict__ out) {

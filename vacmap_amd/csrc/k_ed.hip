@@ -1,0 +1,123 @@
+// k_ed.hip — E2 divergence filter: global edit distance (edlib.align(task='distance'), /root/reference/src/vacmap/mammap_clrnano.py:19251).
+//
+// Myers/Hyyro bit-vector recurrence (spec VMX-ED; oracle/vmo_dp.cc). The pattern (query) is cut into 64-row blocks; a lane owns
+// one block and a step is one anti-diagonal (lane b works on text column step-b), so a wavefront sweeps 64 blocks x n columns
+// per PASS. A segment of a 15 kb read has ~235 blocks = 4 passes, a 100 kb read 25. Passes are PIPELINED over the waves of one
+// workgroup: wave w runs passes w, w+W, ...; pass p consumes the horizontal deltas leaving block 63 of pass p-1 ("carry", one
+// int8 per text column, ring of W arrays in HBM) 64 columns at a time, gated by a progress word in LDS. The critical path of a
+// problem is therefore ~n + 128*passes steps instead of passes*n. Text and carry are fetched 64 columns at a time (one
+// coalesced 64-byte load per wave) and handed to lane 0 with v_readlane; nothing on the per-step path touches memory.
+#include "vmx_device.h"
+#include "vmx_kernels.h"
+
+#ifdef VMX_EMU
+#define VMX_SPIN_PAUSE() hipemu::yield()
+#else
+#define VMX_SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)
+#endif
+
+__global__ void __launch_bounds__(64 * VMX_ED_WAVES) k_edit_distance(const uint8_t* __restrict__ qcodes, const int64_t* __restrict__ q_off,
+                                                                      const uint8_t* __restrict__ tcodes, const int64_t* __restrict__ t_off,
+                                                                      int8_t* __restrict__ carry_pool, const int64_t* __restrict__ carry_off,
+                                                                      int n_prob, int64_t* __restrict__ out) {
+    __shared__ volatile unsigned long long s_prog[VMX_ED_WAVES];   // (pass << 32) | columns whose carry is published
+    const int lane = vmx_lane();
+    const int w = (int)(threadIdx.x >> 6);
+    const int W = (int)(blockDim.x >> 6);
+    for (int p = blockIdx.x; p < n_prob; p += gridDim.x) {
+        const uint8_t* pat = qcodes + q_off[p];
+        const uint8_t* txt = tcodes + t_off[p];
+        const int m = (int)(q_off[p + 1] - q_off[p]);
+        const int n = (int)(t_off[p + 1] - t_off[p]);
+        int8_t* carry = carry_pool + (size_t)W * (size_t)carry_off[p];      // W arrays of n entries
+        if (m == 0 || n == 0) { if (threadIdx.x == 0) out[p] = m == 0 ? n : m; continue; }
+        if (lane == 0) s_prog[w] = 0ULL;
+        __syncthreads();
+        const int B = (m + 63) >> 6;
+        const int P = (B + 63) >> 6;
+        long long score = m;
+        for (int ps = w; ps < P; ps += W) {
+            const int b = ps * 64 + lane;
+            const bool active_b = b < B;
+            int nact = B - ps * 64; if (nact > 64) nact = 64;
+            unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0;
+            if (active_b) {
+                const int base = b << 6;
+                int lim = m - base; if (lim > 64) lim = 64;
+                for (int x = 0; x < lim; ++x) {
+                    const uint8_t c = pat[base + x];
+                    const unsigned long long bit = 1ULL << x;
+                    if (c == 0) p0 |= bit; else if (c == 1) p1 |= bit; else if (c == 2) p2 |= bit; else if (c == 3) p3 |= bit; else p4 |= bit;
+                }
+            }
+            unsigned long long Pv = ~0ULL, Mv = 0ULL;
+            const unsigned long long HIGH = (b == B - 1) ? (1ULL << ((m - 1) & 63)) : (1ULL << 63);
+            const bool last_pass = ps == P - 1;
+            const int8_t* cin_arr = carry + (size_t)((ps + W - 1) % W) * (size_t)n;
+            int8_t* cout_arr = carry + (size_t)(ps % W) * (size_t)n;
+            const unsigned long long need_hi = (unsigned long long)(ps - 1) << 32;
+            int hout_cur = 0, c_cur = 4;
+            int outc = 0;            // delta of column j (leaving block 63) parked in lane j & 63 until 64 of them are published
+            const int steps = n + nact - 1;
+            for (int t0 = 0; t0 < steps; t0 += 64) {
+                const int tch = (t0 + lane < n) ? (int)txt[t0 + lane] : 4;
+                int cin = 0;
+                if (ps > 0 && t0 < n) {
+                    int need = t0 + 64; if (need > n) need = n;
+                    while (s_prog[(ps - 1) % W] < (need_hi | (unsigned long long)need)) VMX_SPIN_PAUSE();
+                    __threadfence_block();
+                    cin = (t0 + lane < n) ? (int)cin_arr[t0 + lane] : 0;
+                }
+                int tend = steps - t0; if (tend > 64) tend = 64;
+                for (int tt = 0; tt < tend; ++tt) {
+                    const int t = t0 + tt;
+                    const int c_up = __shfl_up(c_cur, 1);
+                    const int h_up = __shfl_up(hout_cur, 1);
+                    const int c0 = __shfl(tch, tt);
+                    const int h0 = __shfl(cin, tt);
+                    int hin;
+                    if (lane == 0) { c_cur = t < n ? c0 : 4; hin = ps == 0 ? 1 : (t < n ? h0 : 0); }
+                    else { c_cur = c_up; hin = h_up; }
+                    const int j = t - lane;
+                    if (active_b && j >= 0 && j < n) {
+                        unsigned long long Eq = c_cur == 0 ? p0 : c_cur == 1 ? p1 : c_cur == 2 ? p2 : c_cur == 3 ? p3 : p4;
+                        const unsigned long long Xv = Eq | Mv;
+                        if (hin < 0) Eq |= 1ULL;
+                        const unsigned long long Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+                        unsigned long long Ph = Mv | ~(Xh | Pv);
+                        unsigned long long Mh = Pv & Xh;
+                        int hout = 0;
+                        if (Ph & HIGH) hout = 1;
+                        if (Mh & HIGH) hout = -1;
+                        Ph <<= 1; Mh <<= 1;
+                        if (hin < 0) Mh |= 1ULL; else if (hin > 0) Ph |= 1ULL;
+                        Pv = Mh | ~(Xv | Ph);
+                        Mv = Ph & Xv;
+                        hout_cur = hout;
+                        if (b == B - 1) score += hout;
+                    }
+                    if (!last_pass) {
+                        // park the delta leaving block 63 (column t-63) in lane (column & 63); publish 64 columns at a time
+                        const int h63 = __shfl(hout_cur, 63);
+                        const int j63 = t - 63;
+                        if (j63 >= 0 && j63 < n) {
+                            if (lane == (j63 & 63)) outc = h63;
+                            if ((j63 & 63) == 63 || j63 == n - 1) {
+                                const int base = j63 & ~63;
+                                if (base + lane <= j63) cout_arr[base + lane] = (int8_t)outc;
+                                __threadfence_block();
+                                if (lane == 0) s_prog[w] = ((unsigned long long)ps << 32) | (unsigned long long)(j63 + 1);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // the score lives in the lane that owns block B-1 (wave (P-1) % W)
+        if (w == (P - 1) % W) {
+            const long long s = __shfl(score, (B - 1) & 63);
+            if (lane == 0) out[p] = s;
+        }
+        __syncthreads();
+    }
+}

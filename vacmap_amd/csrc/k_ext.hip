@@ -132,19 +132,21 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
         int rc = vmx_fix_simple_inv(S, R, RD, L);
         if (rc < 0) { E.status = rc; return; }
         E.nseg = S.nseg;
-        // checkpoints -> gap-fill problems. capacity: at most one problem per anchor
+        // checkpoints -> gap-fill problems: count first, then allocate exactly that many slots
         int total = 0;
-        for (int s = 0; s < S.nseg; ++s) total += SEG_LEN(S, s);
+        for (int s = 0; s < S.nseg; ++s) {
+            int np = vmx_split_alignment(S, s, L, R, nullptr, 0);
+            if (np < 0) { E.status = np; return; }
+            segprob[s] = np; total += np;
+        }
         int b = vmx_alloc_probs(A, total);
         if (b < 0) { E.status = VM_READ_CAPACITY_DEV; return; }
         int k = 0;
         for (int s = 0; s < S.nseg; ++s) {
             int np = vmx_split_alignment(S, s, L, R, A.desc + b + k, total - k);
             if (np < 0) { E.status = np; return; }
-            segprob[s] = np; k += np;
+            k += np;
         }
-        // slots beyond k stay unused: mark them empty so the DP kernels skip them
-        for (int x = k; x < total; ++x) { vmx_pair_desc d; d.t.len = 0; d.q.len = 0; d.t.start = 0; d.q.start = 0; d.t.src = 1; d.q.src = 0; d.t.op = 0; d.q.op = 0; A.desc[b + x] = d; }
         E.dp_base = b; E.dp_n = k; E.prob_base = b; E.prob_n = total;
         return;
     }
@@ -212,6 +214,33 @@ __global__ void k_dp_table(const vmx_pair_desc* __restrict__ desc, const int32_t
         vmx_dp_prob p; p.t_off = t_off[i]; p.q_off = q_off[i]; p.tl = desc[i].t.len; p.ql = desc[i].q.len;
         p.tb_off = tb_off[i]; p.bnd_off = bnd_off[i]; p.run_off = run_off[i]; p.cig_off = cig_off[i];
         probs[i] = p;
+    }
+}
+
+// result compaction: per-read record counts / blob bytes -> (scan on the host side of the stream) -> packed arrays
+__global__ void k_res_sizes(const vmx_ext_read* __restrict__ er, const vm_record* __restrict__ rec, const int64_t* __restrict__ soff, int n_reads,
+                            int64_t* __restrict__ recn, int64_t* __restrict__ blobn) {
+    const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r >= n_reads) return;
+    const vmx_ext_read E = er[r];
+    long long nr = 0, nb = 0;
+    if (E.active && E.status == 0) { nr = E.nrec; for (int x = 0; x < E.nrec; ++x) nb += rec[soff[r] + x].cigar_len + 1; }
+    recn[r] = nr; blobn[r] = nb;
+}
+__global__ void k_res_pack(const vmx_ext_read* __restrict__ er, const vm_record* __restrict__ rec, const char* __restrict__ blob, const int64_t* __restrict__ soff,
+                           const int64_t* __restrict__ blob_off, int n_reads, const int64_t* __restrict__ rec_o, const int64_t* __restrict__ blob_o,
+                           vm_record* __restrict__ out_rec, char* __restrict__ out_blob) {
+    for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        const vmx_ext_read E = er[r];
+        if (!(E.active && E.status == 0)) continue;
+        long long bo = blob_o[r];
+        for (int x = 0; x < E.nrec; ++x) {
+            vm_record rc = rec[soff[r] + x];
+            const char* src = blob + blob_off[r] + rc.cigar_off;
+            for (long long i = threadIdx.x; i <= rc.cigar_len; i += blockDim.x) out_blob[bo + i] = i < rc.cigar_len ? src[i] : 0;
+            if (threadIdx.x == 0) { rc.cigar_off = bo; out_rec[rec_o[r] + x] = rc; }
+            bo += rc.cigar_len + 1;
+        }
     }
 }
 

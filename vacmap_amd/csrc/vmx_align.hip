@@ -22,6 +22,9 @@ __global__ void k_dp_sizes(const vmx_pair_desc* desc, const int32_t* n_prob, int
 __global__ void k_dp_table(const vmx_pair_desc* desc, const int32_t* n_prob, const int64_t* t_off, const int64_t* q_off, const int64_t* tb_off,
                            const int64_t* bnd_off, const int64_t* run_off, const int64_t* cig_off, vmx_dp_prob* probs);
 __global__ void k_ext_records(vmx_ext_args A, const vmx_dp_prob* probs, const char* cig_pool, const int32_t* cig_len);
+__global__ void k_res_sizes(const vmx_ext_read* er, const vm_record* rec, const int64_t* soff, int n_reads, int64_t* recn, int64_t* blobn);
+__global__ void k_res_pack(const vmx_ext_read* er, const vm_record* rec, const char* blob, const int64_t* soff, const int64_t* blob_off, int n_reads,
+                           const int64_t* rec_o, const int64_t* blob_o, vm_record* out_rec, char* out_blob);
 
 // ---- small utility kernels
 __global__ void k_compact_rows(const int64_t* __restrict__ rows, const int64_t* __restrict__ koff, const int64_t* __restrict__ aoff, int n_reads, int64_t* __restrict__ out) {
@@ -90,6 +93,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     std::vector<int64_t> h_koff, h_nhits;
     VMX_TRY(vmx_seed_stage(c, mi, prm->check_num, prm->mid_occ, n, d_codes, d_roff, total_bases, B.seed, h_koff, h_nhits));
     for (int64_t r = 0; r < n; ++r) st.n_hits += h_nhits[r];
+    st.n_minimizers = c->last_n_minimizers;
     // compact anchors: aoff = scan(n_anchors)
     VMX_TRY(B.nanc64.reserve(8 * (size_t)(n + 2))); VMX_TRY(B.aoff.reserve(8 * (size_t)(n + 2)));
     LAUNCH1D(k_i32_to_i64, n, B.seed[11].as<int32_t>(), B.nanc64.as<int64_t>(), n);
@@ -189,7 +193,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     VMX_TRY(B.rcount.reserve(64)); VMX_TRY(B.oflow.reserve(64)); VMX_TRY(B.probread.reserve(4 * (size_t)round_cap));
     VMX_TRY(B.tl.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.ql.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.toff.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.qoff.reserve(8 * (size_t)(round_cap + 1)));
     VMX_TRY(B.tpool.reserve((size_t)pool_cap + 64)); VMX_TRY(B.qpool.reserve((size_t)pool_cap + 64));
-    VMX_TRY(B.edout.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.carry.reserve((size_t)pool_cap + 64)); VMX_TRY(B.ext3.reserve(12 * (size_t)(round_cap + 1)));
+    VMX_TRY(B.edout.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.carry.reserve((size_t)VMX_ED_WAVES * (size_t)pool_cap + 64)); VMX_TRY(B.ext3.reserve(12 * (size_t)(round_cap + 1)));
     VMX_TRY(B.rec.reserve(sizeof(vm_record) * (size_t)(cS + 1))); VMX_TRY(B.blob.reserve((size_t)cB + 64)); VMX_TRY(B.reccoff.reserve(8 * (size_t)(cS + 1)));
     VMX_TRY(B.recclen.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.dupd.reserve((size_t)cB + 64));
     VMX_HIP(hipMemsetAsync(B.oflow.p, 0, 4, c->stream));
@@ -235,12 +239,15 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         st.n_dp_problems += cnt; st.dp_cells += totals[0];
         hipLaunchKernelGGL(k_dp_table, dim3(G), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.dpoff[0].as<int64_t>(),
                            B.dpoff[1].as<int64_t>(), B.dpoff[2].as<int64_t>(), B.dpoff[3].as<int64_t>(), B.dptab.as<vmx_dp_prob>());
-        if (cnt) {
-            hipLaunchKernelGGL(k_gapfill_fill, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>(), cnt,
-                               2, -4, 4, 2, 24, 1, B.tb.as<uint8_t>(), B.bnd.as<int32_t>(), B.dpscore.as<int32_t>());
-            hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>(), cnt, prm->eqx,
-                               B.tb.as<uint8_t>(), B.run.as<uint32_t>(), B.cig.as<char>(), B.ciglen.as<int32_t>());
-        }
+        st.dp_string_bytes += tq[0] + tq[1];
+        hipEvent_t* ke = c->ev + (redo_only ? 19 : 16);      // HIP events around the dominant kernel, on the stream it runs on
+        (void)hipEventRecord(ke[0], c->stream);
+        if (cnt) hipLaunchKernelGGL(k_gapfill_fill, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>(), cnt,
+                                    2, -4, 4, 2, 24, 1, B.tb.as<uint8_t>(), B.bnd.as<int32_t>(), B.dpscore.as<int32_t>());
+        (void)hipEventRecord(ke[1], c->stream);
+        if (cnt) hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>(), cnt, prm->eqx,
+                                    B.tb.as<uint8_t>(), B.run.as<uint32_t>(), B.cig.as<char>(), B.ciglen.as<int32_t>());
+        (void)hipEventRecord(ke[2], c->stream);
         A.redo_only = redo_only;
         hipLaunchKernelGGL(k_ext_records, dim3(gridR), dim3(64), 0, c->stream, A, B.dptab.as<vmx_dp_prob>(), B.cig.as<char>(), B.ciglen.as<int32_t>());
         cur ^= 1;
@@ -252,7 +259,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         int cnt = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, 0, round_cap, pool_cap);
         if (cnt < 0) return cnt;
         st.n_segments = cnt; st.n_ed_problems = cnt;
-        if (cnt) hipLaunchKernelGGL(k_edit_distance, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(),
+        if (cnt) hipLaunchKernelGGL(k_edit_distance, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 4)), dim3(64 * VMX_ED_WAVES), 0, c->stream, B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(),
                                     B.toff.as<int64_t>(), B.carry.as<int8_t>(), B.toff.as<int64_t>(), cnt, B.edout.as<int64_t>());
         cur ^= 1;
     }
@@ -271,44 +278,47 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));
 
     // ---------------- results
-    std::vector<vmx_ext_read> er((size_t)n); std::vector<vm_record> hrec((size_t)cS + 1); std::vector<char> hblob((size_t)cB + 1);
-    int32_t oflow = 0;
-    VMX_TRY(download(er.data(), B.er.p, (size_t)n, c->stream)); VMX_TRY(download(hrec.data(), B.rec.p, (size_t)cS, c->stream));
-    VMX_TRY(download(hblob.data(), B.blob.p, (size_t)cB, c->stream)); VMX_TRY(download(&oflow, B.oflow.p, 1, c->stream));
-    std::vector<int32_t> lstat((size_t)n);
-    VMX_TRY(download(lstat.data(), L.status.p, (size_t)n, c->stream));
+    // pack the records of the batch on the device, then copy exactly those bytes
+    VMX_TRY(B.dpsz[0].reserve(8 * (size_t)(n + 2))); VMX_TRY(B.dpsz[1].reserve(8 * (size_t)(n + 2))); VMX_TRY(B.dpoff[0].reserve(8 * (size_t)(n + 2))); VMX_TRY(B.dpoff[1].reserve(8 * (size_t)(n + 2)));
+    hipLaunchKernelGGL(k_res_sizes, dim3(gridR), dim3(64), 0, c->stream, B.er.as<vmx_ext_read>(), B.rec.as<vm_record>(), B.soff2.as<int64_t>(), (int)n, B.dpsz[0].as<int64_t>(), B.dpsz[1].as<int64_t>());
+    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, B.dpsz[0].as<int64_t>(), B.dpoff[0].as<int64_t>(), n, 0);
+    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, B.dpsz[1].as<int64_t>(), B.dpoff[1].as<int64_t>(), n, 0);
+    int64_t nr = 0, nb = 0; int32_t oflow = 0;
+    VMX_TRY(download(&nr, B.dpoff[0].as<int64_t>() + n, 1, c->stream)); VMX_TRY(download(&nb, B.dpoff[1].as<int64_t>() + n, 1, c->stream));
+    VMX_TRY(download(&oflow, B.oflow.p, 1, c->stream));
+    VMX_HIP(hipStreamSynchronize(c->stream));
+    if (oflow) { set_error("extend stage: a per-batch work pool overflowed"); return VM_ERR_OOM; }
+    VMX_TRY(B.totals.reserve(sizeof(vm_record) * (size_t)(nr + 1))); VMX_TRY(B.dupd.reserve((size_t)nb + 64));
+    hipLaunchKernelGGL(k_res_pack, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 8)), dim3(64), 0, c->stream, B.er.as<vmx_ext_read>(), B.rec.as<vm_record>(), B.blob.as<char>(),
+                       B.soff2.as<int64_t>(), B.bloboff.as<int64_t>(), (int)n, B.dpoff[0].as<int64_t>(), B.dpoff[1].as<int64_t>(), B.totals.as<vm_record>(), B.dupd.as<char>());
+    std::vector<vmx_ext_read> er((size_t)n);
+    *recs = (vm_record*)malloc(sizeof(vm_record) * (size_t)std::max<int64_t>(nr, 1)); *cigar_blob = (char*)malloc((size_t)std::max<int64_t>(nb, 1));
+    VMX_TRY(download(er.data(), B.er.p, (size_t)n, c->stream)); VMX_TRY(download(*recs, B.totals.p, (size_t)nr, c->stream));
+    VMX_TRY(download(*cigar_blob, B.dupd.p, (size_t)nb, c->stream));
     std::vector<int64_t> h_gmax((size_t)n);
     VMX_TRY(download(h_gmax.data(), B.gmax.p, (size_t)n, c->stream));
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));
     VMX_HIP(hipStreamSynchronize(c->stream));
     VMX_HIP(hipGetLastError());
-    if (oflow) { set_error("extend stage: a per-batch work pool overflowed"); return VM_ERR_OOM; }
-    int64_t nr = 0, nb = 0;
+    bool any_fast = false;
     for (int64_t r = 0; r < n; ++r) {
         int stt2 = er[r].status;
-        if (h_gmax[r] == -1 && (h_aoff[r + 1] - h_aoff[r]) > 2) stt2 = VM_READ_FASTPATH_DEV;   // needs GC-fast
+        if (h_gmax[r] == -1 && (h_aoff[r + 1] - h_aoff[r]) > 2) { stt2 = VM_READ_FASTPATH_DEV; any_fast = true; }   // needs GC-fast
         if (status_per_read) status_per_read[r] = stt2;
         if (stt2 != 0) { st.n_failed++; continue; }
         if (er[r].nrec == 0) st.n_unmapped++;
-        for (int x = 0; x < er[r].nrec; ++x) { nr++; nb += hrec[soff2[r] + x].cigar_len + 1; }
     }
-    *recs = (vm_record*)malloc(sizeof(vm_record) * (size_t)std::max<int64_t>(nr, 1)); *cigar_blob = (char*)malloc((size_t)std::max<int64_t>(nb, 1));
-    int64_t ri = 0, bo = 0;
-    for (int64_t r = 0; r < n; ++r) {
-        int stt2 = er[r].status; if (h_gmax[r] == -1 && (h_aoff[r + 1] - h_aoff[r]) > 2) stt2 = VM_READ_FASTPATH_DEV;
-        if (stt2 != 0) continue;
-        for (int x = 0; x < er[r].nrec; ++x) {
-            vm_record rc = hrec[soff2[r] + x];
-            memcpy(*cigar_blob + bo, hblob.data() + bloboff[r] + rc.cigar_off, (size_t)rc.cigar_len); (*cigar_blob)[bo + rc.cigar_len] = 0;
-            rc.cigar_off = bo; bo += rc.cigar_len + 1;
-            st.aligned_bases += rc.q_en - rc.q_st; st.cigar_bytes += rc.cigar_len;
-            (*recs)[ri++] = rc;
-        }
-    }
+    (void)any_fast;   // such reads never reach the local stage (their global score is 0), so they own no packed records
+    for (int64_t i = 0; i < nr; ++i) { st.aligned_bases += (*recs)[i].q_en - (*recs)[i].q_st; st.cigar_bytes += (*recs)[i].cigar_len; }
     *n_recs = nr; st.n_records = nr;
     float ms = 0;
     hipEventElapsedTime(&ms, ev[0], ev[nev - 1]); st.ms_total = ms;
     for (int i = 1; i < nev && i < 16; ++i) { hipEventElapsedTime(&ms, ev[i - 1], ev[i]); st.ms_stage[i - 1] = ms; }
+    for (int base = 16; base <= 19; base += 3) {
+        if (hipEventElapsedTime(&ms, ev[base], ev[base + 1]) == hipSuccess) st.ms_gapfill_fill += ms;
+        if (hipEventElapsedTime(&ms, ev[base + 1], ev[base + 2]) == hipSuccess) st.ms_gapfill_trace += ms;
+        st.n_gapfill_launches++;
+    }
     if (stats) *stats = st;
     return VM_OK;
 }

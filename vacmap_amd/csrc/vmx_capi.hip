@@ -132,9 +132,9 @@ int vm_edit_distance_batch(vm_ctx* c, int64_t n, const char* q, const int64_t* q
     VMX_HIP(hipSetDevice(c->device));
     VMX_TRY(upload_encode(c, q, q_off, n, c->b[0], c->b[1], c->b[2]));
     VMX_TRY(upload_encode(c, t, t_off, n, c->b[3], c->b[4], c->b[5]));
-    VMX_TRY(c->b[6].reserve((size_t)t_off[n] + 64));     // carry pool: one int8 per text column, same offsets as t
+    VMX_TRY(c->b[6].reserve((size_t)VMX_ED_WAVES * (size_t)t_off[n] + 64));     // carry ring: VMX_ED_WAVES x one int8 per text column
     VMX_TRY(c->b[7].reserve(sizeof(int64_t) * (size_t)(n + 1)));
-    if (n) hipLaunchKernelGGL(k_edit_distance, dim3(grid_for(c, n, 16)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[2].as<int64_t>(),
+    if (n) hipLaunchKernelGGL(k_edit_distance, dim3(grid_for(c, n, 4)), dim3(64 * VMX_ED_WAVES), 0, c->stream, c->b[1].as<uint8_t>(), c->b[2].as<int64_t>(),
                               c->b[4].as<uint8_t>(), c->b[5].as<int64_t>(), c->b[6].as<int8_t>(), c->b[5].as<int64_t>(), (int)n, c->b[7].as<int64_t>());
     *dist = host_alloc<int64_t>((size_t)n);
     VMX_TRY(download(*dist, c->b[7].p, (size_t)n, c->stream));

@@ -323,10 +323,12 @@ __host__ __device__ inline int vmx_fix_simple_inv(vmx_segs& S, const vmx_ref_vie
 
 // E5 checkpoints :21505-21617. Emits the DP problems of segment s (in the order the reference computes them) into out[];
 // converts the end anchors to zero length like the reference. returns the number of problems, or a negative status.
+// out == nullptr: count only (the end-anchor conversions are idempotent, so a counting call followed by an emitting call is safe)
 __host__ __device__ inline int vmx_split_alignment(vmx_segs& S, int s, long long L, const vmx_ref_view& R, vmx_pair_desc* out, int cap) {
     const long long min_gap_forcigar = 200;
     int np = 0;
     const int st = S.st[s], en = S.en[s];
+    vmx_pair_desc tmp;
     if (S.A[st].s == 1) {
         vmx_anchor& last = S.A[en - 1];
         if (last.l != 0) last = vmx_mk((long long)last.q + last.l, last.r + last.l, 1, 0);
@@ -336,9 +338,10 @@ __host__ __device__ inline int vmx_split_alignment(vmx_segs& S, int s, long long
             long long readgap = (long long)now.q - pre.q - pre.l, refgap = (long long)now.r - pre.r - pre.l;
             long long mn = readgap < refgap ? readgap : refgap;
             if ((now.l < 19 || mn < min_gap_forcigar) && i + 1 != en) continue;
-            if (np >= cap) return VM_READ_CAPACITY_DEV;
-            vmx_qt_for_cigar(pre, now, L, R, &out[np]);
-            if (out[np].t.len <= 0 || out[np].q.len <= 0) return VM_READ_RAISED_DEV;    // "Failed to compute CIGAR" :21562
+            if (out && np >= cap) return VM_READ_CAPACITY_DEV;
+            vmx_pair_desc* d = out ? &out[np] : &tmp;
+            vmx_qt_for_cigar(pre, now, L, R, d);
+            if (d->t.len <= 0 || d->q.len <= 0) return VM_READ_RAISED_DEV;    // "Failed to compute CIGAR" :21562
             ++np; pre = now;
         }
     } else {
@@ -350,9 +353,10 @@ __host__ __device__ inline int vmx_split_alignment(vmx_segs& S, int s, long long
             long long readgap = (long long)pre.q - now.q - now.l, refgap = (long long)now.r - pre.r - pre.l;
             long long mn = readgap < refgap ? readgap : refgap;
             if ((now.l < 19 || mn < min_gap_forcigar) && i != st) continue;
-            if (np >= cap) return VM_READ_CAPACITY_DEV;
-            vmx_qt_for_cigar(now, pre, L, R, &out[np]);
-            if (out[np].t.len <= 0 || out[np].q.len <= 0) return VM_READ_RAISED_DEV;
+            if (out && np >= cap) return VM_READ_CAPACITY_DEV;
+            vmx_pair_desc* d = out ? &out[np] : &tmp;
+            vmx_qt_for_cigar(now, pre, L, R, d);
+            if (d->t.len <= 0 || d->q.len <= 0) return VM_READ_RAISED_DEV;
             ++np; pre = now;
         }
     }

@@ -63,6 +63,7 @@ struct vm_ctx {
     vmx::DevBuf b[VMX_NBUF];     // scratch buffers reused by the entry points (grow-only)
     int num_cu = 256;
     hipEvent_t ev[24];
+    int64_t last_n_minimizers = 0;               // of the last seed stage (stats)
     struct vmx_local_bufs* lbufs = nullptr;      // vmx_stage.h
     struct vmx_extend_bufs* ebufs = nullptr;
     struct vmx_batch_bufs* bbufs = nullptr;

@@ -347,7 +347,10 @@ int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, in
     hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, nh.as<int64_t>(), koff.as<int64_t>(), n, 1);
     h_koff.resize((size_t)n + 1); h_nhits.resize((size_t)n);
     VMX_TRY(download(h_koff.data(), koff.p, (size_t)n + 1, c->stream)); VMX_TRY(download(h_nhits.data(), nh.p, (size_t)n, c->stream));
+    std::vector<int32_t> h_mzc((size_t)n);
+    VMX_TRY(download(h_mzc.data(), mzc.p, (size_t)n, c->stream));
     VMX_HIP(hipStreamSynchronize(c->stream));   // sizing sync #1: total (power-of-two padded) hits of the batch
+    c->last_n_minimizers = 0; for (int64_t r = 0; r < n; ++r) c->last_n_minimizers += h_mzc[r];
     const int64_t ktot = h_koff[n];
     VMX_TRY(keys.reserve(8 * (size_t)(ktot + 1))); VMX_TRY(ckeys.reserve(8 * (size_t)(ktot + 1))); VMX_TRY(rows.reserve(32 * (size_t)(ktot + 1)));
     hipLaunchKernelGGL(k_fill_hits, dim3(grid), dim3(256), 0, c->stream, mzp.as<uint32_t>(), d_roff, mzc.as<int32_t>(), (int)n, mst.as<uint32_t>(), mcn.as<uint32_t>(),

@@ -46,6 +46,7 @@ struct vmx_lseed_args {
     vmx_anchor* la_rows; uint64_t* la_ekey; vmx_anchor* la_sorted; const int64_t* la_off; int32_t* la_cnt; int32_t* status;
 };
 
+#define VMX_ED_WAVES 8               // waves per workgroup of k_edit_distance (passes pipelined across them)
 #define VMX_SORT_LDS 4096            // uint64 keys sorted in LDS by vmx_block_sort_u64 (larger sorts run in HBM)
 #define VM_READ_FASTPATH_DEV (-21)   // the reference would switch to a *_fast heuristic that is not built yet
 #define VMX_LC_BYTES_PER_ANCHOR 32   // q4 + r8 + ls4 + S8 + P4 + SA4

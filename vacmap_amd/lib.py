@@ -57,8 +57,10 @@ class Record(C.Structure):
 class BatchStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ('n_reads', 'read_bases', 'n_minimizers', 'n_hits', 'n_anchors', 'n_local_hits', 'n_local_anchors',
                                           'n_segments', 'n_ed_problems', 'ed_cells', 'n_ext_problems', 'ext_cells', 'n_dp_problems',
-                                          'dp_cells', 'n_records', 'cigar_bytes', 'aligned_bases', 'n_unmapped', 'n_failed')] + \
-               [('ms_total', C.c_double), ('ms_stage', C.c_double * 16)]
+                                          'dp_cells', 'n_records', 'cigar_bytes', 'aligned_bases', 'n_unmapped', 'n_failed',
+                                          'dp_string_bytes')] + \
+               [('ms_total', C.c_double), ('ms_stage', C.c_double * 16), ('ms_gapfill_fill', C.c_double), ('ms_gapfill_trace', C.c_double),
+                ('n_gapfill_launches', C.c_int64)]
 
 
 def _b(s):
@@ -304,9 +306,13 @@ def align_batch(ctx, index, prm, seqs):
 class ResidentReads:
     """reads uploaded once into HBM (bench: inputs resident when the timed region starts)"""
 
-    def __init__(self, ctx, seqs):
-        s, off = _cat(seqs)
-        self.ctx = ctx; self.n = len(seqs); self.bases = int(off[-1])
+    def __init__(self, ctx, seqs=None, concat=None, offsets=None):
+        if seqs is not None:
+            s, off = _cat(seqs)
+        else:
+            s = concat if isinstance(concat, (bytes, bytearray)) else np.ascontiguousarray(concat, dtype=np.uint8).tobytes()
+            off = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.ctx = ctx; self.n = len(off) - 1; self.bases = int(off[-1])
         h = C.c_void_p()
         ctx.lib.check(ctx.lib.L.vm_reads_upload(ctx.h, self.n, s, off.ctypes.data, C.byref(h)))
         self.h = h

@@ -108,3 +108,52 @@ def implant_svs(seq, ops):
 
 def tostr(a):
     return np.asarray(a, dtype=np.uint8).tobytes().decode()
+
+
+def sample_reads_concat(contigs, n, mean_len=15000, err=0.10, seed=2, shape='ont', min_len=1000, max_len=100000, sd=2000):
+    """Vectorised variant of sample_reads for large batches: returns (uint8 concatenation, int64 offsets[n+1], truth arrays).
+    Same read model (Gamma(2, mean/2) or Normal lengths, uniform start, 50/50 strand, i.i.d. errors 4:3:3) but all reads of
+    the batch are mutated in one pass over the concatenated fragments."""
+    rng = np.random.default_rng(seed)
+    lens_c = np.array([len(c) for c in contigs], dtype=np.int64)
+    cum = np.concatenate([[0], np.cumsum(lens_c)])
+    if shape == 'ont':
+        L = np.clip(rng.gamma(2.0, mean_len / 2.0, size=n), min_len, max_len).astype(np.int64)
+    else:
+        L = np.maximum(rng.normal(mean_len, sd, size=n), min_len).astype(np.int64)
+    ci = np.zeros(n, np.int64); st = np.zeros(n, np.int64)
+    for i in range(n):
+        while True:
+            g = int(rng.integers(0, cum[-1]))
+            c = int(np.searchsorted(cum, g, side='right') - 1)
+            s = g - int(cum[c])
+            if lens_c[c] < L[i]:
+                L[i] = lens_c[c]; s = 0
+            if s + L[i] <= lens_c[c]:
+                break
+        ci[i] = c; st[i] = s
+    strand = rng.integers(0, 2, size=n)
+    foff = np.concatenate([[0], np.cumsum(L)])
+    frag = np.empty(int(foff[-1]), np.uint8)
+    for i in range(n):
+        f = contigs[ci[i]][st[i]:st[i] + L[i]]
+        frag[foff[i]:foff[i + 1]] = revcomp(f) if strand[i] else f
+    tot = len(frag)
+    u = rng.random(tot)
+    ps, pd = err * 0.4, err * 0.3
+    is_sub = u < ps
+    is_del = (u >= ps) & (u < ps + pd)
+    is_ins = (u >= ps + pd) & (u < err)
+    idx = np.nonzero(is_sub)[0]
+    if len(idx):
+        code = np.searchsorted(_ACGT, frag[idx])
+        frag[idx] = _ACGT[(code + rng.integers(1, 4, size=len(idx))) % 4]
+    rep = (~is_del).astype(np.int64) + is_ins.astype(np.int64)
+    out = np.repeat(frag, rep)
+    ins_idx = np.nonzero(is_ins)[0]
+    if len(ins_idx):
+        starts = np.cumsum(rep) - rep
+        out[starts[ins_idx]] = _ACGT[rng.integers(0, 4, size=len(ins_idx))]
+    crep = np.concatenate([[0], np.cumsum(rep)])
+    off = crep[foff].astype(np.int64)
+    return out, off, {'contig': ci, 'start': st, 'len': L, 'strand': strand}
