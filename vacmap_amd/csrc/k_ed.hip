@@ -1,4 +1,5 @@
-// k_ed.hip — E2 divergence filter: global edit distance (edlib.align(task='distance'), /root/reference/src/vacmap/mammap_clrnano.py:19251).
+// k_ed.hip — E2 divergence filter: global edit distance (edlib.align(task='distance'), /root/reference/src/vacmap/mammap_clrnano.py:19251),
+// plus k_size_order, the longest-first work ordering shared by the DP kernels.
 //
 // Myers/Hyyro bit-vector recurrence (spec VMX-ED; oracle/vmo_dp.cc). The pattern (query) is cut into 64-row blocks; a lane owns
 // one block and a step is one anti-diagonal (lane b works on text column step-b), so a wavefront sweeps 64 blocks x n columns
@@ -6,30 +7,71 @@
 // workgroup: wave w runs passes w, w+W, ...; pass p consumes the horizontal deltas leaving block 63 of pass p-1 ("carry", one
 // int8 per text column, ring of W arrays in HBM) 64 columns at a time, gated by a progress word in LDS. The critical path of a
 // problem is therefore ~n + 128*passes steps instead of passes*n. Text and carry are fetched 64 columns at a time (one
-// coalesced 64-byte load per wave) and handed to lane 0 with v_readlane; nothing on the per-step path touches memory.
+// coalesced 64-byte load per wave) and handed to lane 0 with v_readlane; lane-to-lane hand-off is a DPP wave_shr:1 move.
+// Nothing on the per-step path touches memory. Problems are taken longest-first from a device-side queue (k_size_order);
+// long patterns (> 4 passes) run on 16-wave workgroups, the rest on 4-wave workgroups.
 #include "vmx_device.h"
 #include "vmx_kernels.h"
 
-#ifdef VMX_EMU
-#define VMX_SPIN_PAUSE() hipemu::yield()
-#else
-#define VMX_SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)
-#endif
+// order[] = problem indices sorted by floor(log2(size)) descending; range[0] = number of problems with size > thresh,
+// range[1] = n; counters[0..3] = 0 (work-queue heads of the consumers)
+__global__ void __launch_bounds__(1024) k_size_order(const int64_t* __restrict__ size, const int32_t* __restrict__ n_ptr, int64_t thresh,
+                                                     int32_t* __restrict__ order, int32_t* __restrict__ range, int32_t* __restrict__ counters) {
+    __shared__ int s_hist[64];
+    __shared__ int s_cur[64];
+    __shared__ int s_long;
+    const int n = *n_ptr;
+    if (threadIdx.x < 64) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_long = 0;
+    __syncthreads();
+    int nl = 0;
+    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
+        const long long s = size[i];
+        const int b = s > 0 ? 63 - __clzll(s) : 0;
+        atomicAdd(&s_hist[b], 1);
+        if (s > thresh) ++nl;
+    }
+    if (nl) atomicAdd(&s_long, nl);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 63; b >= 0; --b) { s_cur[b] = acc; acc += s_hist[b]; }
+        range[0] = s_long; range[1] = n;
+        counters[0] = 0; counters[1] = 0; counters[2] = 0; counters[3] = 0;
+    }
+    __syncthreads();
+    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
+        const long long s = size[i];
+        const int b = s > 0 ? 63 - __clzll(s) : 0;
+        order[atomicAdd(&s_cur[b], 1)] = i;
+    }
+}
 
+// which = 0: problems order[0 .. range[0]) (long), which = 1: order[range[0] .. range[1]). blockDim.x = 64 * W, W <= VMX_ED_WAVES.
 __global__ void __launch_bounds__(64 * VMX_ED_WAVES) k_edit_distance(const uint8_t* __restrict__ qcodes, const int64_t* __restrict__ q_off,
                                                                       const uint8_t* __restrict__ tcodes, const int64_t* __restrict__ t_off,
-                                                                      int8_t* __restrict__ carry_pool, const int64_t* __restrict__ carry_off,
-                                                                      int n_prob, int64_t* __restrict__ out) {
+                                                                      int8_t* __restrict__ carry_pool, const int32_t* __restrict__ order,
+                                                                      const int32_t* __restrict__ range, int32_t* __restrict__ counters, int which,
+                                                                      int64_t* __restrict__ out) {
     __shared__ volatile unsigned long long s_prog[VMX_ED_WAVES];   // (pass << 32) | columns whose carry is published
+    __shared__ int s_next;
     const int lane = vmx_lane();
     const int w = (int)(threadIdx.x >> 6);
     const int W = (int)(blockDim.x >> 6);
-    for (int p = blockIdx.x; p < n_prob; p += gridDim.x) {
+    const int lo = which == 0 ? 0 : range[0];
+    const int hi = which == 0 ? range[0] : range[1];
+    while (true) {
+        if (threadIdx.x == 0) s_next = lo + atomicAdd(&counters[which], 1);
+        __syncthreads();
+        const int qi = s_next;
+        __syncthreads();
+        if (qi >= hi) break;
+        const int p = order[qi];
         const uint8_t* pat = qcodes + q_off[p];
         const uint8_t* txt = tcodes + t_off[p];
         const int m = (int)(q_off[p + 1] - q_off[p]);
         const int n = (int)(t_off[p + 1] - t_off[p]);
-        int8_t* carry = carry_pool + (size_t)W * (size_t)carry_off[p];      // W arrays of n entries
+        int8_t* carry = carry_pool + (size_t)VMX_ED_WAVES * (size_t)t_off[p];   // ring of up to VMX_ED_WAVES arrays of n entries
         if (m == 0 || n == 0) { if (threadIdx.x == 0) out[p] = m == 0 ? n : m; continue; }
         if (lane == 0) s_prog[w] = 0ULL;
         __syncthreads();
@@ -71,10 +113,10 @@ __global__ void __launch_bounds__(64 * VMX_ED_WAVES) k_edit_distance(const uint8
                 int tend = steps - t0; if (tend > 64) tend = 64;
                 for (int tt = 0; tt < tend; ++tt) {
                     const int t = t0 + tt;
-                    const int c_up = __shfl_up(c_cur, 1);
-                    const int h_up = __shfl_up(hout_cur, 1);
-                    const int c0 = __shfl(tch, tt);
-                    const int h0 = __shfl(cin, tt);
+                    const int c_up = vmx_shr1(c_cur);
+                    const int h_up = vmx_shr1(hout_cur);
+                    const int c0 = vmx_readlane(tch, tt);
+                    const int h0 = vmx_readlane(cin, tt);
                     int hin;
                     if (lane == 0) { c_cur = t < n ? c0 : 4; hin = ps == 0 ? 1 : (t < n ? h0 : 0); }
                     else { c_cur = c_up; hin = h_up; }
@@ -98,7 +140,7 @@ __global__ void __launch_bounds__(64 * VMX_ED_WAVES) k_edit_distance(const uint8
                     }
                     if (!last_pass) {
                         // park the delta leaving block 63 (column t-63) in lane (column & 63); publish 64 columns at a time
-                        const int h63 = __shfl(hout_cur, 63);
+                        const int h63 = vmx_readlane(hout_cur, 63);
                         const int j63 = t - 63;
                         if (j63 >= 0 && j63 < n) {
                             if (lane == (j63 & 63)) outc = h63;

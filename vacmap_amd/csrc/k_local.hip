@@ -86,8 +86,10 @@ __global__ void __launch_bounds__(256) k_local_seed(vmx_lseed_args A) {
     __shared__ int s_niv;
     __shared__ int s_flag;
     __shared__ long long s_tot;
+    __shared__ unsigned long long s_min, s_max;
     const int k = A.k;
     const int nkey = 1 << (2 * k);
+    uint64_t* HKEY2 = A.hkey2_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;
     int32_t* CNT = A.cnt_pool + (size_t)blockIdx.x * (size_t)(nkey + 1);
     int32_t* CUR = A.cur_pool + (size_t)blockIdx.x * (size_t)nkey;
     int64_t* TPOS = A.tpos_pool + (size_t)blockIdx.x * (size_t)A.tpos_cap;
@@ -266,10 +268,21 @@ __global__ void __launch_bounds__(256) k_local_seed(vmx_lseed_args A) {
                     if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { long long point = -(rl + iloc); HKEY[w] = ((uint64_t)(point + (1LL << 36)) << 26) | (uint64_t)w; HVAL[w] = (rl << 1); HQ[w] = iloc; ++w; }
                 }
             }
-            for (long long i = H + threadIdx.x; i < NH; i += blockDim.x) HKEY[i] = ~0ULL;
             __syncthreads();
-            if (NH > 1) vmx_block_sort_u64(HKEY, (int)NH, s_sort);
-            __syncthreads();
+            // group the hits by diagonal, keeping stream order inside a diagonal: stable LSD radix sort on (point - min point)
+            {
+                unsigned long long mn = ~0ULL, mx = 0ULL;
+                for (long long i = threadIdx.x; i < H; i += blockDim.x) { const unsigned long long pk = HKEY[i] >> 26; mn = pk < mn ? pk : mn; mx = pk > mx ? pk : mx; }
+                for (int o = 32; o > 0; o >>= 1) { unsigned long long a = __shfl_xor(mn, o), b = __shfl_xor(mx, o); mn = a < mn ? a : mn; mx = b > mx ? b : mx; }
+                if (threadIdx.x == 0) { s_min = ~0ULL; s_max = 0ULL; }
+                __syncthreads();
+                if (vmx_lane() == 0) { atomicMin((unsigned long long*)&s_min, mn); atomicMax((unsigned long long*)&s_max, mx); }
+                __syncthreads();
+                int nbits = 0; { unsigned long long range = H > 0 ? s_max - s_min : 0; while (nbits < 40 && (range >> nbits)) ++nbits; }
+                uint64_t* res = vmx_block_radix_sort_u64(HKEY, HKEY2, (int)H, 26, (uint64_t)s_min, nbits, (int*)s_sort, s_scan);
+                if (res != HKEY) { for (long long i = threadIdx.x; i < H; i += blockDim.x) HKEY[i] = HKEY2[i]; }
+                __syncthreads();
+            }
             // --- run-merge per diagonal (:23232-23344): the lane whose index starts a key group walks that group.
             // pass 0 counts the anchors each group emits (-> offsets), pass 1 writes them with their emission key.
             for (int pass = 0; pass < 2 && status == 0; ++pass) {

@@ -49,13 +49,27 @@ struct vmx_batch_bufs {
     // extend stage
     DevBuf er, coff3, soff2, segA, st, en, segA_s, st_s, en_s, segprob, dup, desc[2], rcount, oflow, probread, tl, ql, toff, qoff, tpool, qpool;
     DevBuf edout, carry, ext3, dpsz[4], dpoff[4], dptab, tb, bnd, run, cig, ciglen, dpscore, rec, blob, bloboff, reccoff, recclen, dupd, totals;
-    DevBuf raw, codes, off;
+    DevBuf raw, codes, off, order, qrange, scanpart, scanoff;
     void release() { DevBuf* p = (DevBuf*)this; for (size_t i = 0; i < sizeof(*this) / sizeof(DevBuf); ++i) p[i].release(); }
 };
 static vmx_batch_bufs* batch_bufs(vm_ctx* c) { if (!c->bbufs) c->bbufs = new vmx_batch_bufs(); return c->bbufs; }
 void vmx_ctx_free_batch_bufs(vm_ctx* c) { if (c->bbufs) { c->bbufs->release(); delete c->bbufs; c->bbufs = nullptr; } }
 
 #define LAUNCH1D(kernel, n, ...) hipLaunchKernelGGL(kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(((n) + 255) / 256, 4096))), dim3(256), 0, c->stream, __VA_ARGS__)
+
+__global__ void k_scan_part(const int64_t* in, int64_t* part, int64_t n, int64_t chunk);
+__global__ void k_scan_apply(const int64_t* in, int64_t* out, const int64_t* part_off, int64_t n, int64_t chunk);
+
+// exclusive scan on the stream (out[n] = total): one workgroup for small n, three phases otherwise
+static int dev_scan(vm_ctx* c, vmx_batch_bufs& B, const int64_t* in, int64_t* out, int64_t n) {
+    if (n <= 16384) { hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, in, out, n, 0); return 0; }
+    int64_t chunk = (n + 511) / 512; const int64_t nb = (n + chunk - 1) / chunk;
+    VMX_TRY(B.scanpart.reserve(8 * (size_t)(nb + 2))); VMX_TRY(B.scanoff.reserve(8 * (size_t)(nb + 2)));
+    hipLaunchKernelGGL(k_scan_part, dim3((unsigned)nb), dim3(256), 0, c->stream, in, B.scanpart.as<int64_t>(), n, chunk);
+    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, B.scanpart.as<int64_t>(), B.scanoff.as<int64_t>(), nb, 0);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, c->stream, in, out, B.scanoff.as<int64_t>(), n, chunk);
+    return 0;
+}
 
 // one DP round of the extend stage: descriptors (count on device) -> offsets -> gathered pools. returns host copy of the count
 static int ext_gather_round(vm_ctx* c, vmx_batch_bufs& B, const vm_index_view& ix, int64_t n, const uint8_t* d_ocodes, const int64_t* d_roff, int cur, int redo_only,
@@ -68,8 +82,8 @@ static int ext_gather_round(vm_ctx* c, vmx_batch_bufs& B, const vm_index_view& i
     VMX_TRY(download(&cnt, B.rcount.p, 1, c->stream));
     VMX_HIP(hipStreamSynchronize(c->stream));
     if (cnt > round_cap) cnt = (int32_t)round_cap;
-    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, B.tl.as<int64_t>(), B.toff.as<int64_t>(), (int64_t)cnt, 0);
-    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, B.ql.as<int64_t>(), B.qoff.as<int64_t>(), (int64_t)cnt, 0);
+    VMX_TRY(dev_scan(c, B, B.tl.as<int64_t>(), B.toff.as<int64_t>(), (int64_t)cnt));
+    VMX_TRY(dev_scan(c, B, B.ql.as<int64_t>(), B.qoff.as<int64_t>(), (int64_t)cnt));
     if (cnt) hipLaunchKernelGGL(k_gather, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(),
                                 B.probread.as<int32_t>(), d_ocodes, d_roff, ix.codes, B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), pool_cap,
                                 B.oflow.as<int32_t>());
@@ -229,7 +243,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         const int G = c->num_cu * 4;
         hipLaunchKernelGGL(k_dp_sizes, dim3(G), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.dpsz[0].as<int64_t>(), B.dpsz[1].as<int64_t>(),
                            B.dpsz[2].as<int64_t>(), B.dpsz[3].as<int64_t>());
-        for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, B.dpsz[i].as<int64_t>(), B.dpoff[i].as<int64_t>(), (int64_t)cnt, 0);
+        for (int i = 0; i < 4; ++i) VMX_TRY(dev_scan(c, B, B.dpsz[i].as<int64_t>(), B.dpoff[i].as<int64_t>(), (int64_t)cnt));
         // sizing sync #3: total traceback / boundary / run / CIGAR bytes of the batch
         int64_t totals[4];
         for (int i = 0; i < 4; ++i) VMX_TRY(download(&totals[i], B.dpoff[i].as<int64_t>() + cnt, 1, c->stream));
@@ -259,8 +273,15 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         int cnt = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, 0, round_cap, pool_cap);
         if (cnt < 0) return cnt;
         st.n_segments = cnt; st.n_ed_problems = cnt;
-        if (cnt) hipLaunchKernelGGL(k_edit_distance, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 4)), dim3(64 * VMX_ED_WAVES), 0, c->stream, B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(),
-                                    B.toff.as<int64_t>(), B.carry.as<int8_t>(), B.toff.as<int64_t>(), cnt, B.edout.as<int64_t>());
+        if (cnt) {
+            VMX_TRY(B.order.reserve(4 * (size_t)(round_cap + 1))); VMX_TRY(B.qrange.reserve(64));
+            int32_t* d_range = B.qrange.as<int32_t>(); int32_t* d_cnt = d_range + 4;
+            hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.ql.as<int64_t>(), B.rcount.as<int32_t>(), (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt);
+            for (int which = 0; which < 2; ++which)
+                hipLaunchKernelGGL(k_edit_distance, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * (which == 0 ? 2 : 8))), dim3(which == 0 ? 64 * VMX_ED_WAVES : 256), 0, c->stream,
+                                   B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.carry.as<int8_t>(), B.order.as<int32_t>(), d_range, d_cnt, which,
+                                   B.edout.as<int64_t>());
+        }
         cur ^= 1;
     }
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));

@@ -134,8 +134,19 @@ int vm_edit_distance_batch(vm_ctx* c, int64_t n, const char* q, const int64_t* q
     VMX_TRY(upload_encode(c, t, t_off, n, c->b[3], c->b[4], c->b[5]));
     VMX_TRY(c->b[6].reserve((size_t)VMX_ED_WAVES * (size_t)t_off[n] + 64));     // carry ring: VMX_ED_WAVES x one int8 per text column
     VMX_TRY(c->b[7].reserve(sizeof(int64_t) * (size_t)(n + 1)));
-    if (n) hipLaunchKernelGGL(k_edit_distance, dim3(grid_for(c, n, 4)), dim3(64 * VMX_ED_WAVES), 0, c->stream, c->b[1].as<uint8_t>(), c->b[2].as<int64_t>(),
-                              c->b[4].as<uint8_t>(), c->b[5].as<int64_t>(), c->b[6].as<int8_t>(), c->b[5].as<int64_t>(), (int)n, c->b[7].as<int64_t>());
+    if (n) {
+        // longest-first device work queue; long patterns (> 4 passes) on 16-wave workgroups, the rest on 4-wave workgroups
+        std::vector<int64_t> sz((size_t)n); for (int64_t i = 0; i < n; ++i) sz[i] = q_off[i + 1] - q_off[i];
+        int32_t nn = (int32_t)n;
+        VMX_TRY(upload(c->b[8], sz.data(), (size_t)n, c->stream)); VMX_TRY(upload(c->b[9], &nn, 1, c->stream));
+        VMX_TRY(c->b[10].reserve(4 * (size_t)(n + 1))); VMX_TRY(c->b[11].reserve(64));
+        int32_t* d_range = c->b[11].as<int32_t>(); int32_t* d_cnt = d_range + 4;
+        hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, c->b[8].as<int64_t>(), c->b[9].as<int32_t>(), (int64_t)VMX_ED_LONG, c->b[10].as<int32_t>(), d_range, d_cnt);
+        for (int which = 0; which < 2; ++which)
+            hipLaunchKernelGGL(k_edit_distance, dim3(grid_for(c, n, which == 0 ? 2 : 8)), dim3(which == 0 ? 64 * VMX_ED_WAVES : 256), 0, c->stream, c->b[1].as<uint8_t>(),
+                               c->b[2].as<int64_t>(), c->b[4].as<uint8_t>(), c->b[5].as<int64_t>(), c->b[6].as<int8_t>(), c->b[10].as<int32_t>(), d_range, d_cnt, which,
+                               c->b[7].as<int64_t>());
+    }
     *dist = host_alloc<int64_t>((size_t)n);
     VMX_TRY(download(*dist, c->b[7].p, (size_t)n, c->stream));
     VMX_HIP(hipStreamSynchronize(c->stream));

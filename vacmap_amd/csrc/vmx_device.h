@@ -17,6 +17,28 @@
 
 __device__ __forceinline__ int vmx_lane() { return (int)(threadIdx.x & 63); }
 
+// lane i receives the value of lane i-1 (lane 0 keeps its own): one v_mov_b32_dpp wave_shr:1 on gfx950 instead of the
+// ds_bpermute that __shfl_up lowers to. vmx_readlane: value of a wave-uniform lane (v_readlane_b32).
+#ifdef VMX_EMU
+__device__ __forceinline__ int vmx_shr1(int v) { return __shfl_up(v, 1); }
+__device__ __forceinline__ int vmx_readlane(int v, int l) { return __shfl(v, l); }
+#define VMX_SPIN_PAUSE() hipemu::yield()
+#else
+__device__ __forceinline__ int vmx_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int vmx_readlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+#define VMX_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
+#endif
+__device__ __forceinline__ double vmx_shr1_f64(double v) {
+    union { double d; int i[2]; } u; u.d = v;
+    u.i[0] = vmx_shr1(u.i[0]); u.i[1] = vmx_shr1(u.i[1]);
+    return u.d;
+}
+__device__ __forceinline__ double vmx_readlane_f64(double v, int l) {
+    union { double d; int i[2]; } u; u.d = v;
+    u.i[0] = vmx_readlane(u.i[0], l); u.i[1] = vmx_readlane(u.i[1], l);
+    return u.d;
+}
+
 // wave-wide reductions / scans; every lane of the wave must call them (wave-uniform control flow)
 __device__ __forceinline__ int vmx_wave_max_i32(int v) {
     for (int o = 32; o > 0; o >>= 1) { int x = __shfl_xor(v, o); v = x > v ? x : v; }
@@ -82,6 +104,31 @@ __device__ inline void vmx_block_sort_u64_impl(uint64_t* g, int N, uint64_t* lds
         }
     }
     if (in_lds) { for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) g[i] = lds[i]; __syncthreads(); }
+}
+
+// block-wide STABLE LSD radix sort of n uint64 keys on the bit field [(key >> shift) - base] & (2^nbits - 1), 4 bits per pass,
+// ping-ponging between a and b (both in HBM). cnt: 16 * blockDim.x ints of LDS, scan: >= 17 ints. returns the buffer holding the result.
+// every thread of the workgroup must call it. blockDim.x <= 256.
+__device__ inline uint64_t* vmx_block_radix_sort_u64(uint64_t* a, uint64_t* b, int n, int shift, uint64_t base, int nbits, int* cnt, int* scan) {
+    const int T = (int)blockDim.x, tid = (int)threadIdx.x;
+    const int tile = (n + T - 1) / T;
+    const int lo = tid * tile < n ? tid * tile : n;
+    const int hi = lo + tile < n ? lo + tile : n;
+    for (int bit = 0; bit < nbits; bit += 4) {
+        for (int d = 0; d < 16; ++d) cnt[d * T + tid] = 0;
+        for (int i = lo; i < hi; ++i) { const int d = (int)((((a[i] >> shift) - base) >> bit) & 15); cnt[d * T + tid]++; }
+        __syncthreads();
+        // exclusive scan over the 16*T counters in (digit, thread) order: thread tid owns entries [16*tid, 16*tid+16)
+        int s = 0;
+        for (int e = 0; e < 16; ++e) s += cnt[16 * tid + e];
+        int tot; int ex = vmx_block_excl_scan(s, scan, &tot);
+        for (int e = 0; e < 16; ++e) { const int v = cnt[16 * tid + e]; cnt[16 * tid + e] = ex; ex += v; }
+        __syncthreads();
+        for (int i = lo; i < hi; ++i) { const uint64_t k = a[i]; const int d = (int)((((k >> shift) - base) >> bit) & 15); b[cnt[d * T + tid]++] = k; }
+        __syncthreads();
+        uint64_t* t = a; a = b; b = t;
+    }
+    return a;
 }
 
 __host__ __device__ __forceinline__ uint8_t vmx_code(uint8_t c) {

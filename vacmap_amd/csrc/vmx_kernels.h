@@ -40,13 +40,15 @@ struct vmx_lseed_args {
     int32_t n_reads, k, look_span, read_span;
     int32_t* cnt_pool; int32_t* cur_pool;                   // 4^k+1 / 4^k per slot
     int64_t* tpos_pool; int64_t tpos_cap;
+    uint64_t* hkey2_pool;
     uint64_t* hkey_pool; int64_t* hval_pool; int32_t* hq_pool; int32_t* goff_pool; int64_t hit_cap;
     int32_t* pcnt_pool; int64_t pcnt_cap;
     uint64_t* gkey_pool; int32_t* gq_pool; int64_t* gr_pool; int64_t gkey_cap;
     vmx_anchor* la_rows; uint64_t* la_ekey; vmx_anchor* la_sorted; const int64_t* la_off; int32_t* la_cnt; int32_t* status;
 };
 
-#define VMX_ED_WAVES 8               // waves per workgroup of k_edit_distance (passes pipelined across them)
+#define VMX_ED_WAVES 16              // max waves per workgroup of k_edit_distance (passes pipelined across them) = carry ring depth
+#define VMX_ED_LONG 16384            // patterns longer than this (> 4 passes) go to the 16-wave launch
 #define VMX_SORT_LDS 4096            // uint64 keys sorted in LDS by vmx_block_sort_u64 (larger sorts run in HBM)
 #define VM_READ_FASTPATH_DEV (-21)   // the reference would switch to a *_fast heuristic that is not built yet
 #define VMX_LC_BYTES_PER_ANCHOR 32   // q4 + r8 + ls4 + S8 + P4 + SA4

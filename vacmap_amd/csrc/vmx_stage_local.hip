@@ -55,6 +55,8 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     A.guide_rows = L.guide_rows.as<vmx_anchor>(); A.guide_len = L.guide_len.as<int32_t>(); A.n_guides_used = L.ng_used.as<int32_t>(); A.aoff = d_aoff;
     A.n_reads = (int)n; A.k = k; A.look_span = 7000; A.read_span = 7000;   // :23094, :23190
     A.cnt_pool = L.cnt.as<int32_t>(); A.cur_pool = L.cur.as<int32_t>(); A.tpos_pool = L.tpos.as<int64_t>(); A.tpos_cap = tpos_cap;
+    VMX_TRY(L.hkey2.reserve(8 * (size_t)G * (size_t)hit_cap));
+    A.hkey2_pool = L.hkey2.as<uint64_t>();
     A.hkey_pool = L.hkey.as<uint64_t>(); A.hval_pool = L.hval.as<int64_t>(); A.hq_pool = L.hq.as<int32_t>(); A.goff_pool = L.goff.as<int32_t>(); A.hit_cap = hit_cap;
     A.pcnt_pool = L.pcnt.as<int32_t>(); A.pcnt_cap = pcnt_cap; A.gkey_pool = L.gkey.as<uint64_t>(); A.gq_pool = L.gq.as<int32_t>(); A.gr_pool = L.gr.as<int64_t>();
     A.gkey_cap = gkey_cap;
