@@ -188,13 +188,14 @@ __global__ void __launch_bounds__(64) k_gapfill_fill(const uint8_t* __restrict__
         const uint8_t* T = tcodes + pr.t_off;
         const uint8_t* Q = qcodes + pr.q_off;
         const int tl = pr.tl, ql = pr.ql;
-        if (tl == 0 || ql == 0) { if (lane == 0) out_score[p] = (tl + ql) ? vmx_gap_open_row(tl + ql, o1, e1, o2, e2) : 0; continue; }
+        const bool trivial = tl == 0 || ql == 0;     // no barrier-skipping `continue`: an empty side just runs zero stripes
+        if (trivial && lane == 0) out_score[p] = (tl + ql) ? vmx_gap_open_row(tl + ql, o1, e1, o2, e2) : 0;
         uint8_t* tb = tb_pool + pr.tb_off;
         int32_t* bH = bnd_pool + pr.bnd_off;
         int32_t* bE1 = bH + (ql + 1);
         int32_t* bE2 = bE1 + (ql + 1);
         const int W = ql + 63;
-        const int nstr = (tl + 63) >> 6;
+        const int nstr = trivial ? 0 : (tl + 63) >> 6;
         for (int s = 0; s < nstr; ++s) {
             const int i = s * 64 + lane + 1;
             const bool row_active = i <= tl;

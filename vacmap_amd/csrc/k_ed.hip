@@ -63,20 +63,21 @@ __global__ void __launch_bounds__(64 * VMX_ED_WAVES) k_edit_distance(const uint8
     while (true) {
         if (threadIdx.x == 0) s_next = lo + atomicAdd(&counters[which], 1);
         __syncthreads();
-        const int qi = s_next;
+        const int qi = vmx_uniform_i32(s_next);       // tell the compiler the queue index (and everything derived from it) is wave-uniform
         __syncthreads();
         if (qi >= hi) break;
-        const int p = order[qi];
+        const int p = vmx_uniform_i32(order[qi]);
         const uint8_t* pat = qcodes + q_off[p];
         const uint8_t* txt = tcodes + t_off[p];
-        const int m = (int)(q_off[p + 1] - q_off[p]);
-        const int n = (int)(t_off[p + 1] - t_off[p]);
+        const int m = vmx_uniform_i32((int)(q_off[p + 1] - q_off[p]));
+        const int n = vmx_uniform_i32((int)(t_off[p + 1] - t_off[p]));
         int8_t* carry = carry_pool + (size_t)VMX_ED_WAVES * (size_t)t_off[p];   // ring of up to VMX_ED_WAVES arrays of n entries
-        if (m == 0 || n == 0) { if (threadIdx.x == 0) out[p] = m == 0 ? n : m; continue; }
+        // an empty side makes the distance trivial; such problems still walk through every barrier below (P = 0 passes)
+        const bool trivial = m == 0 || n == 0;
         if (lane == 0) s_prog[w] = 0ULL;
         __syncthreads();
         const int B = (m + 63) >> 6;
-        const int P = (B + 63) >> 6;
+        const int P = trivial ? 0 : (B + 63) >> 6;
         long long score = m;
         for (int ps = w; ps < P; ps += W) {
             const int b = ps * 64 + lane;
@@ -156,7 +157,8 @@ __global__ void __launch_bounds__(64 * VMX_ED_WAVES) k_edit_distance(const uint8
             }
         }
         // the score lives in the lane that owns block B-1 (wave (P-1) % W)
-        if (w == (P - 1) % W) {
+        if (trivial) { if (threadIdx.x == 0) out[p] = m == 0 ? n : m; }
+        else if (w == (P - 1) % W) {
             const long long s = __shfl(score, (B - 1) & 63);
             if (lane == 0) out[p] = s;
         }

@@ -141,7 +141,9 @@ int vm_edit_distance_batch(vm_ctx* c, int64_t n, const char* q, const int64_t* q
         VMX_TRY(upload(c->b[8], sz.data(), (size_t)n, c->stream)); VMX_TRY(upload(c->b[9], &nn, 1, c->stream));
         VMX_TRY(c->b[10].reserve(4 * (size_t)(n + 1))); VMX_TRY(c->b[11].reserve(64));
         int32_t* d_range = c->b[11].as<int32_t>(); int32_t* d_cnt = d_range + 4;
-        hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, c->b[8].as<int64_t>(), c->b[9].as<int32_t>(), (int64_t)VMX_ED_LONG, c->b[10].as<int32_t>(), d_range, d_cnt);
+        int64_t thresh = VMX_ED_LONG;
+        if (const char* e = getenv("VMX_ED_LONG")) thresh = atoll(e);      // test knob: exercise the 16-wave launch with short patterns
+        hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, c->b[8].as<int64_t>(), c->b[9].as<int32_t>(), thresh, c->b[10].as<int32_t>(), d_range, d_cnt);
         for (int which = 0; which < 2; ++which)
             hipLaunchKernelGGL(k_edit_distance, dim3(grid_for(c, n, which == 0 ? 2 : 8)), dim3(which == 0 ? 64 * VMX_ED_WAVES : 256), 0, c->stream, c->b[1].as<uint8_t>(),
                                c->b[2].as<int64_t>(), c->b[4].as<uint8_t>(), c->b[5].as<int64_t>(), c->b[6].as<int8_t>(), c->b[10].as<int32_t>(), d_range, d_cnt, which,

@@ -28,6 +28,12 @@ __device__ __forceinline__ int vmx_shr1(int v) { return __builtin_amdgcn_update_
 __device__ __forceinline__ int vmx_readlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 #define VMX_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
 #endif
+// value known to be identical in every lane: hand it to the compiler as a scalar (v_readfirstlane_b32)
+#ifdef VMX_EMU
+__device__ __forceinline__ int vmx_uniform_i32(int v) { return v; }
+#else
+__device__ __forceinline__ int vmx_uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
 __device__ __forceinline__ double vmx_shr1_f64(double v) {
     union { double d; int i[2]; } u; u.d = v;
     u.i[0] = vmx_shr1(u.i[0]); u.i[1] = vmx_shr1(u.i[1]);
