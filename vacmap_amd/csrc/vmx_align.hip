@@ -159,16 +159,18 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         for (int q = 0; q < 5; ++q) { rl_off[q] = (int64_t)rl.size(); rl.insert(rl.end(), lists[q].begin(), lists[q].end()); }
         VMX_TRY(upload(B.rl, rl.data(), rl.size(), c->stream));
         VMX_HIP(hipMemsetAsync(B.gmax.p, 0xff, 8 * (size_t)n, c->stream));
-        for (int q = 0; q < 5; ++q) {
+#ifndef VMX_EMU
+        VMX_HIP(hipFuncSetAttribute((const void*)k_chain_global, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)caps[3] * VMX_GC_BYTES_PER_ANCHOR + 64)));
+#endif
+        vmx_fork fk(c);                                               // the LDS buckets are independent: run them side by side
+        for (int q = 4; q >= 0; --q) {                                // slowest (largest reads) first
             int cnt = (int)lists[q].size(); if (!cnt) continue;
             int cap = q < 4 ? caps[q] : 0; size_t shmem = (size_t)cap * VMX_GC_BYTES_PER_ANCHOR + 64;
-#ifndef VMX_EMU
-            if (shmem > 48 * 1024) VMX_HIP(hipFuncSetAttribute((const void*)k_chain_global, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-#endif
-            hipLaunchKernelGGL(k_chain_global, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 8)), dim3(64), shmem, c->stream, B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(),
+            hipLaunchKernelGGL(k_chain_global, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 8)), dim3(64), shmem, fk.next(), B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(),
                                B.rl.as<int32_t>() + rl_off[q], cnt, cap, c->tables, B.gap.as<double>(), prm->global_skipcost, prm->global_maxdiff, 1000, B.S.as<double>(),
                                B.P.as<int32_t>(), B.SA.as<int32_t>(), B.cov.as<uint8_t>(), B.gmax.as<int64_t>(), B.opc.as<int64_t>());
         }
+        fk.join();
     }
     VMX_TRY(B.scr.reserve((size_t)stt + 64)); VMX_TRY(upload(B.soff, soff.data(), (size_t)n + 1, c->stream));
     VMX_TRY(B.res.reserve(16 * (size_t)(n + 2) + 64));

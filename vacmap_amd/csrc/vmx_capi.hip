@@ -61,6 +61,8 @@ int vm_ctx_create(int device_id, vm_ctx** out) {
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; set_error("hipStreamCreate failed"); return VM_ERR_HIP; }
     for (int i = 0; i < 24; ++i) (void)hipEventCreate(&c->ev[i]);
+    for (int i = 0; i < 4; ++i) { (void)hipStreamCreate(&c->aux[i]); (void)hipEventCreate(&c->join_ev[i]); }
+    (void)hipEventCreate(&c->fork_ev);
     // cost tables -> one device blob
     const HostTables& T = host_tables();
     size_t o_extra = 0, o_rh = o_extra + T.extra.size() * 4, o_rr = o_rh + 400, o_lr = o_rr + 400;
@@ -90,6 +92,8 @@ void vm_ctx_destroy(vm_ctx* c) {
     vmx_ctx_free_batch_bufs(c);
     c->tab_buf.release();
     for (int i = 0; i < 24; ++i) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 4; ++i) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); (void)hipEventDestroy(c->join_ev[i]); }
+    (void)hipEventDestroy(c->fork_ev);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -63,10 +63,29 @@ struct vm_ctx {
     vmx::DevBuf b[VMX_NBUF];     // scratch buffers reused by the entry points (grow-only)
     int num_cu = 256;
     hipEvent_t ev[24];
+    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams for independent launches (LDS-bucketed kernels)
+    hipEvent_t fork_ev = nullptr, join_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int64_t last_n_minimizers = 0;               // of the last seed stage (stats)
     struct vmx_local_bufs* lbufs = nullptr;      // vmx_stage.h
     struct vmx_extend_bufs* ebufs = nullptr;
     struct vmx_batch_bufs* bbufs = nullptr;
+};
+
+// fork/join of independent launches over the context's side streams (all ordered after / before the main stream)
+struct vmx_fork {
+    vm_ctx* c; int used = 0;
+    explicit vmx_fork(vm_ctx* ctx) : c(ctx) { (void)hipEventRecord(c->fork_ev, c->stream); }
+    hipStream_t next() {
+        hipStream_t s = c->aux[used & 3];
+        if (used < 4) (void)hipStreamWaitEvent(s, c->fork_ev, 0);
+        ++used;
+        return s;
+    }
+    void join() {
+        const int n = used < 4 ? used : 4;
+        for (int i = 0; i < n; ++i) { (void)hipEventRecord(c->join_ev[i], c->aux[i]); (void)hipStreamWaitEvent(c->stream, c->join_ev[i], 0); }
+        used = 0;
+    }
 };
 
 // ---- kernels (k_dp.hip, k_chain.hip, ...) ----

@@ -35,7 +35,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     hipLaunchKernelGGL(k_local_prep, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, d_path_rows, d_path_len, d_npaths, d_aoff, d_gscore, (int)n,
                        prm->mode, L.guide_rows.as<vmx_anchor>(), L.guide_len.as<int32_t>(), L.ng_used.as<int32_t>(), L.ng_total.as<int32_t>());
     // scratch per workgroup slot
-    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)c->num_cu * 2));
+    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)c->num_cu * 4));
     const int64_t nkey = (int64_t)1 << (2 * k);
     int64_t tpos_cap = 2 * Lmax + 5 * 14000 + 65536;
     int64_t hit_cap = 1; while (hit_cap < 4 * (Lmax + 14000)) hit_cap <<= 1;
@@ -93,19 +93,21 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     const int maxgap = prm->mode == VM_MODE_L ? 50 : 99;                                        // :24061 / mammap_ccs.py:24061
     const double skip_exact = prm->local_skipcost;
     const double skip_mm = prm->mode == VM_MODE_L ? std::min(prm->local_skipcost, 40.0) : prm->local_skipcost;   // mammap_ccs.py:28587
-    for (int q = 0; q < 5; ++q) {
+#ifndef VMX_EMU
+    VMX_HIP(hipFuncSetAttribute((const void*)k_chain_local, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)caps[3] * VMX_LC_BYTES_PER_ANCHOR + 64)));
+#endif
+    vmx_fork fk(c);                                                   // independent LDS buckets side by side, largest reads first
+    for (int q = 4; q >= 0; --q) {
         int cnt = (int)lists[q].size();
         if (!cnt) continue;
         int cap = q < 4 ? caps[q] : 0;
         size_t shmem = (size_t)cap * VMX_LC_BYTES_PER_ANCHOR + 64;
-#ifndef VMX_EMU
-        if (shmem > 48 * 1024) VMX_HIP(hipFuncSetAttribute((const void*)k_chain_local, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-#endif
-        hipLaunchKernelGGL(k_chain_local, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 8)), dim3(64), shmem, c->stream, L.la_sorted.as<vmx_anchor>(),
+        hipLaunchKernelGGL(k_chain_local, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 8)), dim3(64), shmem, fk.next(), L.la_sorted.as<vmx_anchor>(),
                            L.la_off.as<int64_t>(), L.la_cnt.as<int32_t>(), L.ng_total.as<int32_t>(), L.rlist.as<int32_t>() + rl_off[q], cnt, cap, c->tables,
                            L.gap.as<double>(), skip_exact, skip_mm, prm->local_maxdiff, maxgap, prm->mode, L.S.as<double>(), L.P.as<int32_t>(), L.SA.as<int32_t>(),
                            L.score.as<double>(), L.chain.as<vmx_anchor>(), L.chain_len.as<int32_t>(), L.variant.as<int32_t>(), L.status.as<int32_t>());
     }
+    fk.join();
     return 0;
 }
 
