@@ -30,7 +30,8 @@ typedef enum vm_status {
     VM_ERR_UNSUPPORTED = -7,
     /* per-read statuses (status_per_read of vm_align_batch); the reference skips such reads (:24116-24125) */
     VM_READ_RAISED = -10,       /* the reference's Python would have raised inside the per-read path */
-    VM_READ_CAPACITY = -20      /* a device work buffer overflowed for this read (reported, never silently truncated) */
+    VM_READ_CAPACITY = -20,     /* a device work buffer overflowed for this read (reported, never silently truncated) */
+    VM_READ_FASTPATH = -21      /* the reference would switch to a `_fast` chain heuristic (:23570, :24914, :27380) that is not built yet */
 } vm_status;
 
 enum { VM_MODE_H = 0, VM_MODE_L = 1, VM_MODE_S = 2, VM_MODE_R = 3 };   /* -mode (src/vacmap/vacmap:87) */
@@ -85,8 +86,8 @@ int vm_index_minimizers(const vm_index*, uint64_t** hashes, uint64_t** positions
 /* raw device pointers + sizes of the index blob pieces, for the multi-GPU broadcast (RCCL over xGMI) */
 int vm_index_blob_count(const vm_index*);
 int vm_index_blob(const vm_index*, int i, void** dev_ptr, int64_t* bytes);
-/* allocate an empty replica with the same geometry on another ctx (receiver side of the broadcast) */
-int vm_index_clone_geometry(vm_ctx*, const vm_index* src_host_meta, vm_index** out);
+/* metadata (k, w, contig names/lengths, table geometry) needed to allocate an empty replica on another GPU / process:
+ * sender: meta_size + meta_get; receiver: vm_index_from_meta, then the blobs are filled by the broadcast */
 int vm_index_meta_size(const vm_index*, int64_t* bytes);
 int vm_index_meta_get(const vm_index*, void* buf, int64_t bytes);
 int vm_index_from_meta(vm_ctx*, const void* buf, int64_t bytes, vm_index** out);
