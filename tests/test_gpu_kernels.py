@@ -46,3 +46,27 @@ def test_local_golden(ctx, oracle, golden):
 
 def test_align_golden(ctx, oracle, golden):
     KC.check_align_golden(ctx, oracle, golden)
+
+
+def test_align_random_vs_oracle(ctx, oracle):
+    """full-path parity on seeded random inputs at a size the oracle finishes in seconds: 2 contigs, SV donor, 160 ONT + 96 HiFi reads"""
+    import os
+    from vacmap_amd import synth
+    from vacmap_amd.lib import Index, align_batch
+    contigs = synth.make_reference([400000, 150000], seed=31)
+    L = 400000
+    ops = [('INV', L // 10, 3000), ('DEL', 2 * L // 10, 1500), ('INS', 3 * L // 10, 800, 5), ('DUP', 4 * L // 10, 2500, 2), ('INVDUP', 5 * L // 10, 2000),
+           ('INV', 6 * L // 10, 600), ('DEL', 7 * L // 10, 300), ('DUP', 8 * L // 10, 400, 3)]
+    d0 = synth.implant_svs(contigs[0], ops)
+    d0 = np.concatenate([d0[:9 * L // 10], contigs[1][1000:6000], d0[9 * L // 10:]])
+    names = ['chrA', 'chrB']
+    for mode, k, n, kw in (('H', 15, 160, dict(mean_len=9000, err=0.10, shape='ont')), ('L', 19, 96, dict(mean_len=10000, err=0.005, shape='hifi', min_len=4000))):
+        cat, off, _ = synth.sample_reads_concat([d0, contigs[1]], n, seed=33, **kw)
+        seqs = [cat[off[i]:off[i + 1]].tobytes().decode() for i in range(n)]
+        gi = Index.from_seqs(ctx, names, [synth.tostr(c) for c in contigs], k=k, w=10)
+        oi = oracle.Index.from_seqs(names, [synth.tostr(c) for c in contigs], k=k, w=10)
+        status, recs, stats = align_batch(ctx, gi, ctx.lib.params(mode), seqs)
+        ost, orecs = oracle.align_batch(oi, seqs, oracle.params(mode), nthreads=min(os.cpu_count() or 1, 32))
+        assert [(int(s) == 0) for s in status] == [(int(s) == 0) for s in ost]
+        assert recs == orecs, 'mode %s: records differ from the oracle' % mode
+        assert stats['n_records'] == len(orecs) and stats['n_records'] >= n
