@@ -1,0 +1,186 @@
+// k_chain_local.hip — local chain DP: LC-exact (get_optimal_chain_sortbyreadpos_forSV_inv_test_merged_fine_list,
+// /root/reference/src/vacmap/mammap_clrnano.py:27305-27528) and LC-mm (..._fine_list_mismatch, :28250-28476).
+// One wavefront per read; anchors (sorted by read END, :28585), S, P and the score-sorted index S_arg live in LDS (32 B per anchor)
+// when they fit, else in HBM. Same 64-wide descending-S candidate scan as k_chain_global with the LC rules: the loop breaks on
+// S[j] < max - l_i (strict) and `opcount` is bumped before that test (:27410-27415); overlapping predecessors with bonus <= 0 are
+// skipped; traceback trims overlaps (:27508-27526). Scores are IEEE double in the reference's evaluation order (-ffp-contract=off).
+#include "vmx_device.h"
+#include "vmx_kernels.h"
+#include "vmx_local.h"
+
+// ------------------------------------------------------------------------------------------------ L3 / L4 local chain DP
+// :13229-13265 literal
+__device__ __forceinline__ int vmx_smallorequal(const double* arr, double target, int n, const int* point) {
+    if (target < arr[point[0]]) return -1;
+    if (target >= arr[point[n - 1]]) return n - 1;
+    int i = 0, j = n, mid = 0;
+    while (i < j) {
+        mid = (i + j) >> 1;
+        double am = arr[point[mid]];
+        if (target == am) {
+            if (mid < n - 1) { if (arr[point[mid + 1]] > target) return mid; else i = mid + 1; }
+            else return mid;
+        } else if (target < am) {
+            if (mid > 0 && target >= arr[point[mid - 1]]) return mid - 1;
+            j = mid;
+        } else {
+            if (mid < n - 1 && target < arr[point[mid + 1]]) return mid;
+            i = mid + 1;
+        }
+    }
+    return mid;
+}
+
+__device__ __forceinline__ void vmx_sarg_insert_l(int* SA, int loc, int k, int lane) {
+    for (int hi = k; hi > loc; hi -= 64) {
+        int x = hi - lane; int v = 0;
+        if (x > loc) v = SA[x - 1];
+        __syncthreads();
+        if (x > loc) SA[x] = v;
+        __syncthreads();
+    }
+    if (lane == 0) SA[loc] = k;
+    __syncthreads();
+}
+
+
+__global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ la_off,
+                                                    const int32_t* __restrict__ la_cnt, const int32_t* __restrict__ n_guides_total,
+                                                    const int32_t* __restrict__ rlist, int nlist, int lds_cap, vmx_tables tab,
+                                                    const double* __restrict__ gapcost_list, double skip_exact, double skip_mm, int maxdiff,
+                                                    int maxgap, int mode, double* __restrict__ S_pool, int32_t* __restrict__ P_pool,
+                                                    int32_t* __restrict__ SA_pool, double* __restrict__ out_score,
+                                                    vmx_anchor* __restrict__ out_chain, int32_t* __restrict__ out_len, int32_t* __restrict__ out_variant,
+                                                    int32_t* __restrict__ status) {
+    VMX_DYN_SHARED(char, smem);
+    __shared__ double s_gapcost[64];
+    const int lane = vmx_lane();
+    for (int x = lane; x <= maxdiff && x < 64; x += 64) s_gapcost[x] = gapcost_list[x];
+    __syncthreads();
+    const long long extra_size = (long long)tab.extra_n - 1;
+    const long long l2c_size = (long long)tab.log2cache_n - 1;
+    for (int li_ = blockIdx.x; li_ < nlist; li_ += gridDim.x) {
+        const int rd = rlist[li_];
+        const int64_t a0 = la_off[rd];
+        const int n = la_cnt[rd];
+        if (n <= 0) { if (lane == 0) { out_len[rd] = 0; out_score[rd] = 0; status[rd] = VM_READ_RAISED_DEV; } continue; }   // np.array([]) indexing raises
+        const bool mm = n_guides_total[rd] > 1;
+        const double skipcost = mm ? skip_mm : skip_exact;
+        const float* rgc = mm ? tab.large_readgap : (mode == 3 ? tab.readgap_r : tab.readgap_h);
+        const vmx_anchor* A = anchors + a0;
+        double* S; int* P; int* SA; int* Q; long long* R; int* LS;
+        const bool in_lds = n <= lds_cap;
+        if (in_lds) { S = (double*)smem; R = (long long*)(S + lds_cap); Q = (int*)(R + lds_cap); LS = Q + lds_cap; P = LS + lds_cap; SA = P + lds_cap; }
+        else { S = S_pool + a0; P = P_pool + a0; SA = SA_pool + a0; Q = nullptr; R = nullptr; LS = nullptr; }
+        if (in_lds) for (int i = lane; i < n; i += 64) { vmx_anchor a = A[i]; Q[i] = a.q; R[i] = a.r; LS[i] = ((int)a.l & 0xffff) | ((int)a.s << 16); }
+        __syncthreads();
+#define AQ(i) (in_lds ? Q[i] : A[i].q)
+#define AR(i) (in_lds ? R[i] : (long long)A[i].r)
+#define AL(i) (in_lds ? (LS[i] & 0xffff) : (int)A[i].l)
+#define AS(i) (in_lds ? (LS[i] >> 16) : (int)A[i].s)
+        long long prereadloc = (long long)AQ(0) + AL(0);
+        int testspace_en = 1;
+        if (lane == 0) { SA[0] = 0; S[0] = (double)AL(0); P[0] = VMX_NOPRE; }
+        __syncthreads();
+        double g_max_scores = (double)AL(0); int g_max_index = 0;
+        long long opcount = 0;
+        bool need_fast = false;
+        for (int i = 1; i < n; ++i) {
+            const int qi = AQ(i); const long long ri = AR(i); const int li = AL(i); const int si = AS(i);
+            if (prereadloc < (long long)qi + li) {
+                if (opcount > 100000 && ((double)opcount / (double)prereadloc) > 1000.0) { need_fast = true; break; }   // :27380 -> *_fast
+                for (int k = testspace_en; k < i; ++k) {
+                    int loc = vmx_smallorequal(S, S[k], k, SA) + 1;
+                    vmx_sarg_insert_l(SA, loc, k, lane);
+                }
+                testspace_en = i;
+                prereadloc = (long long)qi + li;
+            }
+            const double dli = (double)li;
+            double max_scores = dli; int pre_index = VMX_NOPRE;
+            for (int base = testspace_en - 1; base >= 0; base -= 64) {
+                const int x = base - lane;
+                const bool valid = x >= 0;
+                int j = 0; double Sj = 0.0; double test = -1e300;
+                if (valid) {
+                    j = SA[x]; Sj = S[j];
+                    const int qj = AQ(j), lj = AL(j), sj = AS(j); const long long rj = AR(j);
+                    long long readgap = (long long)qi - qj - lj, refgap, bonus;
+                    bool skip = false;
+                    if (readgap < 0) {
+                        bonus = (long long)qi + li - qj - lj;
+                        if (bonus <= 0) skip = true;
+                        readgap = 0;
+                        long long overlap = (long long)qj + lj - qi;
+                        if (si == sj) { if (si == 1) refgap = ri + overlap - (rj + lj); else refgap = rj - (ri + bonus); }
+                        else { if (sj == -1) refgap = ri + overlap - rj + 1; else refgap = ri + bonus - 1 - (rj + lj); }
+                    } else {
+                        bonus = li;
+                        if (si == sj) { if (si == 1) refgap = ri - rj - lj; else refgap = rj - ri - li; }
+                        else { if (sj == -1) refgap = ri - rj + 1; else refgap = ri + li - 1 - rj - lj; }
+                    }
+                    if (!skip) {
+                        long long gapcost = readgap - refgap; if (gapcost < 0) gapcost = -gapcost;
+                        if (si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
+                            test = Sj + (double)bonus - s_gapcost[gapcost] - (double)rgc[readgap];
+                        } else if (!mm) {
+                            if (gapcost > extra_size) gapcost = extra_size;
+                            double pen;
+                            if (si != sj) pen = (skipcost < 50.0 ? skipcost : 50.0) + (double)tab.extra[gapcost];
+                            else pen = skipcost + (double)tab.extra[gapcost];
+                            test = Sj + (double)bonus - pen;
+                        } else {
+                            double pen = skipcost + tab.log2cache[gapcost < l2c_size ? gapcost : l2c_size];
+                            test = Sj + (double)bonus - pen;
+                        }
+                    }
+                }
+                const double m_before = vmx_wave_excl_max_f64(test, max_scores);
+                const bool brk = valid && (Sj < (m_before - dli));       // strict; opcount is bumped BEFORE this test (:27410-27415)
+                const unsigned long long bmask = __ballot(brk);
+                const unsigned long long vmask = __ballot(valid);
+                const int first = bmask ? (__ffsll((unsigned long long)bmask) - 1) : 64;
+                opcount += bmask ? (first + 1) : __popcll(vmask);
+                double best = (lane < first && valid) ? test : -1e300; int bl = lane;
+                for (int off = 32; off > 0; off >>= 1) {
+                    double ob = __shfl_xor(best, off); int ol = __shfl_xor(bl, off);
+                    if (ob > best || (ob == best && ol < bl)) { best = ob; bl = ol; }
+                }
+                const int jb = __shfl(j, bl);
+                if (best > max_scores) { max_scores = best; pre_index = jb; }
+                if (first < 64) break;
+            }
+            if (lane == 0) { S[i] = max_scores; P[i] = pre_index; }
+            if (max_scores > g_max_scores) { g_max_scores = max_scores; g_max_index = i; }
+            __syncthreads();
+        }
+        // traceback with overlap trimming :27508-27526 (serial, lane 0)
+        if (lane == 0) {
+            if (need_fast) { out_len[rd] = 0; out_score[rd] = 0; status[rd] = VM_READ_FASTPATH_DEV; }
+            else {
+                vmx_anchor* O = out_chain + a0;
+                int w = 0; int take = g_max_index;
+                vmx_anchor pre; pre.q = AQ(take); pre.r = AR(take); pre.l = (int16_t)AL(take); pre.s = (int16_t)AS(take);
+                O[w++] = pre;
+                while (P[take] != VMX_NOPRE) {
+                    take = P[take];
+                    vmx_anchor now; now.q = AQ(take); now.r = AR(take); now.l = (int16_t)AL(take); now.s = (int16_t)AS(take);
+                    if (pre.q < now.q + now.l) {
+                        int ov = now.q + now.l - pre.q;
+                        vmx_anchor t = pre; t.q = pre.q + ov; t.l = (int16_t)(pre.l - ov); if (pre.s == 1) t.r = pre.r + ov;
+                        O[w - 1] = t;
+                    }
+                    O[w++] = now;
+                    pre = now;
+                }
+                out_len[rd] = w; out_score[rd] = g_max_scores; status[rd] = 0;
+            }
+            out_variant[rd] = mm ? 1 : 0;
+        }
+        __syncthreads();
+#undef AQ
+#undef AR
+#undef AL
+#undef AS
+    }
+}

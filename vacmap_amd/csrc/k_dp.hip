@@ -1,13 +1,13 @@
-// k_dp.hip — hand-written gfx950 kernels for the three DP primitives of the extend stage.
+// k_dp.hip — hand-written gfx950 kernels for the banded edge extension and the gap-fill DP of the extend stage
+// (the divergence filter E2 lives in k_ed.hip).
 //
-//   k_edit_distance   E2  edlib.align(task='distance')   (/root/reference/src/vacmap/mammap_clrnano.py:19251)
-//   k_extend          E3  mp.k_cigar(.., 4,4,4,4, bw=100, zdropvalue=50)   (:2381, :2410, :2477, :2505)
+//   k_extend               E3  mp.k_cigar(.., 4,4,4,4, bw=100, zdropvalue=50)   (/root/reference/src/vacmap/mammap_clrnano.py:2381, :2410, :2477, :2505)
 //   k_gapfill_fill/_trace  E5  mp.k_cigar(.., 2,-4, 4,2, 24,1, bw=-1, zdropvalue=-1, eqx)   (:21554, :21598)
 //
-// The native libraries behind those calls (vacmap-index==0.0.3, edlib==1.3.9) are not in /root/reference; the kernels
-// implement the build's normative spec VMX-DP / VMX-ED and are parity-tested bit-for-bit against
-// oracle/vmo_dp.cc. All three are integer, wave64, anti-diagonal ("one lane = one row of a 64-row stripe") kernels:
-// no MFMA (nothing here is a contraction); one wavefront per problem, problems taken grid-stride.
+// The native library behind those calls (vacmap-index==0.0.3) is not in /root/reference; the kernels implement the build's
+// normative spec VMX-DP and are parity-tested bit-for-bit against oracle/vmo_dp.cc. Integer, wave64,
+// anti-diagonal kernels ("one lane = one row of a 64-row stripe"): no MFMA (nothing here is a contraction); one wavefront per
+// problem, problems taken longest-first from a device-side queue (k_size_order in k_ed.hip).
 #include "vmx_device.h"
 #include "vmx_kernels.h"
 
@@ -16,81 +16,6 @@ __global__ void k_encode(const char* __restrict__ in, uint8_t* __restrict__ out,
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) out[i] = vmx_code((uint8_t)in[i]);
-}
-
-// ------------------------------------------------------------------------------------------------ E2 edit distance
-// Myers/Hyyro bit-vector, global distance. Pattern = query split into 64-row blocks; lane = block, step = anti-diagonal
-// (lane b works on text column step-b). Blocks beyond 64 are processed in passes; the horizontal deltas leaving block 63
-// of a pass are parked in `carry` (one int8 per text column) for the next pass.
-// (first version: one wavefront per problem, passes run back to back. Superseded by the pass-pipelined kernel in k_ed.hip;
-//  kept as the simple reference form of the same recurrence for A/B timing.)
-__global__ void __launch_bounds__(64) k_edit_distance_v1(const uint8_t* __restrict__ qcodes, const int64_t* __restrict__ q_off,
-                                                      const uint8_t* __restrict__ tcodes, const int64_t* __restrict__ t_off,
-                                                      int8_t* __restrict__ carry_pool, const int64_t* __restrict__ carry_off,
-                                                      int n_prob, int64_t* __restrict__ out) {
-    const int lane = vmx_lane();
-    for (int p = blockIdx.x; p < n_prob; p += gridDim.x) {
-        const uint8_t* pat = qcodes + q_off[p];
-        const uint8_t* txt = tcodes + t_off[p];
-        const int m = (int)(q_off[p + 1] - q_off[p]);
-        const int n = (int)(t_off[p + 1] - t_off[p]);
-        int8_t* carry = carry_pool + carry_off[p];
-        if (m == 0 || n == 0) { if (lane == 0) out[p] = m == 0 ? n : m; continue; }
-        const int B = (m + 63) >> 6;
-        const int passes = (B + 63) >> 6;
-        long long score = m;
-        for (int ps = 0; ps < passes; ++ps) {
-            const int b = ps * 64 + lane;
-            const bool active_b = b < B;
-            int nact = B - ps * 64; if (nact > 64) nact = 64;
-            unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0;
-            if (active_b) {
-                int base = b << 6;
-                int lim = m - base; if (lim > 64) lim = 64;
-                for (int x = 0; x < lim; ++x) {
-                    uint8_t c = pat[base + x];
-                    unsigned long long bit = 1ULL << x;
-                    if (c == 0) p0 |= bit; else if (c == 1) p1 |= bit; else if (c == 2) p2 |= bit; else if (c == 3) p3 |= bit; else p4 |= bit;
-                }
-            }
-            unsigned long long Pv = ~0ULL, Mv = 0ULL;
-            const unsigned long long HIGH = (b == B - 1) ? (1ULL << ((m - 1) & 63)) : (1ULL << 63);
-            int hout_cur = 0; int c_cur = 0;
-            const int steps = n + nact - 1;
-            for (int t = 0; t < steps; ++t) {
-                int c_up = __shfl_up(c_cur, 1);
-                int h_up = __shfl_up(hout_cur, 1);
-                int hin;
-                if (lane == 0) {
-                    c_cur = t < n ? (int)txt[t] : 4;
-                    hin = ps == 0 ? 1 : (t < n ? (int)carry[t] : 0);
-                } else { c_cur = c_up; hin = h_up; }
-                const int j = t - lane;
-                if (active_b && j >= 0 && j < n) {
-                    unsigned long long Eq = c_cur == 0 ? p0 : c_cur == 1 ? p1 : c_cur == 2 ? p2 : c_cur == 3 ? p3 : p4;
-                    unsigned long long Xv = Eq | Mv;
-                    if (hin < 0) Eq |= 1ULL;
-                    unsigned long long Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-                    unsigned long long Ph = Mv | ~(Xh | Pv);
-                    unsigned long long Mh = Pv & Xh;
-                    int hout = 0;
-                    if (Ph & HIGH) hout = 1;
-                    if (Mh & HIGH) hout = -1;
-                    Ph <<= 1; Mh <<= 1;
-                    if (hin < 0) Mh |= 1ULL; else if (hin > 0) Ph |= 1ULL;
-                    Pv = Mh | ~(Xv | Ph);
-                    Mv = Ph & Xv;
-                    hout_cur = hout;
-                    if (b == B - 1) score += hout;
-                    else if (lane == 63) carry[j] = (int8_t)hout;
-                }
-            }
-            __syncthreads();   // carry[] of this pass visible to lane 0 of the next one
-        }
-        // the score lives in the lane that owns block B-1
-        long long s = __shfl(score, (B - 1) & 63);
-        if (lane == 0) out[p] = s;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------ E3 extension
@@ -171,23 +96,34 @@ __global__ void __launch_bounds__(64) k_extend(const uint8_t* __restrict__ tcode
 // ------------------------------------------------------------------------------------------------ E5 gap fill
 // VMX-DP-G: global dual-affine DP with a 7-bit traceback byte per cell (bits 0-2 source of H: 0 diag,1 E1,2 E2,3 F1,4 F2;
 // bit3 extE1, bit4 extE2, bit5 extF1, bit6 extF2). lane = target row inside a 64-row stripe, step = anti-diagonal of the
-// stripe; the row above a stripe comes from bnd[] (H, E1, E2 of the previous stripe's last row).
-// Traceback bytes are stored as tb[(stripe*(ql+63) + step)*64 + lane]: one coalesced 64-byte line per step.
+// stripe. Per step a lane needs H/E1/E2 of the cell above (the lane above, one step earlier: three DPP wave_shr:1 moves) and the
+// query base of its column (handed down the lanes the same way); lane 0 takes the row above the stripe from bnd[] (H, E1, E2 of
+// the previous stripe's last row) and its query base from a 64-column register chunk (v_readlane), refilled with one coalesced
+// load per 64 steps — nothing on the per-step path waits for memory. Traceback bytes are stored as
+// tb[(stripe*(ql+63) + step)*64 + lane]: one coalesced 64-byte line per step.
 __device__ __forceinline__ int vmx_gap_open_row(int i, int o1, int e1, int o2, int e2) {   // H(i,0) = H(0,i), i >= 1
     int a = -(o1 + i * e1), b = -(o2 + i * e2);
     return a > b ? a : b;
 }
 
+// order/counter: longest-first device work queue (order == nullptr: plain grid-stride over [0, n_prob))
 __global__ void __launch_bounds__(64) k_gapfill_fill(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
                                                      const vmx_dp_prob* __restrict__ probs, int n_prob, int match, int mismatch,
                                                      int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb_pool,
-                                                     int32_t* __restrict__ bnd_pool, int32_t* __restrict__ out_score) {
+                                                     int32_t* __restrict__ bnd_pool, int32_t* __restrict__ out_score,
+                                                     const int32_t* __restrict__ order, int32_t* __restrict__ counter) {
     const int lane = vmx_lane();
-    for (int p = blockIdx.x; p < n_prob; p += gridDim.x) {
+    int static_next = (int)blockIdx.x;
+    while (true) {
+        int qi;
+        if (order) { int v = 0; if (lane == 0) v = atomicAdd(counter, 1); qi = vmx_bcast0(v); }
+        else { qi = static_next; static_next += (int)gridDim.x; }
+        if (qi >= n_prob) break;
+        const int p = order ? vmx_uniform_i32(order[qi]) : qi;
         const vmx_dp_prob pr = probs[p];
         const uint8_t* T = tcodes + pr.t_off;
         const uint8_t* Q = qcodes + pr.q_off;
-        const int tl = pr.tl, ql = pr.ql;
+        const int tl = vmx_uniform_i32(pr.tl), ql = vmx_uniform_i32(pr.ql);
         const bool trivial = tl == 0 || ql == 0;     // no barrier-skipping `continue`: an empty side just runs zero stripes
         if (trivial && lane == 0) out_score[p] = (tl + ql) ? vmx_gap_open_row(tl + ql, o1, e1, o2, e2) : 0;
         uint8_t* tb = tb_pool + pr.tb_off;
@@ -204,41 +140,51 @@ __global__ void __launch_bounds__(64) k_gapfill_fill(const uint8_t* __restrict__
             int F1 = VMX_NEG, F2 = VMX_NEG;
             int Hdiag = (i - 1 == 0) ? 0 : vmx_gap_open_row(i - 1, o1, e1, o2, e2);
             int outH = 0, outE1 = VMX_NEG, outE2 = VMX_NEG;
+            int qc_cur = 4;
             uint8_t* tbs = tb + (size_t)s * (size_t)W * 64;
-            for (int t = 0; t < W; ++t) {
-                int upH = __shfl_up(outH, 1), upE1 = __shfl_up(outE1, 1), upE2 = __shfl_up(outE2, 1);
-                const int j = t - lane + 1;
-                if (lane == 0) {
-                    if (j <= ql) {
-                        if (s == 0) { upH = vmx_gap_open_row(j, o1, e1, o2, e2); upE1 = VMX_NEG; upE2 = VMX_NEG; }
-                        else { upH = bH[j]; upE1 = bE1[j]; upE2 = bE2[j]; }
+            for (int t0 = 0; t0 < W; t0 += 64) {
+                // 64-column chunks for lane 0: query bases Q[t0 .. t0+63] and the boundary row entries of columns j = t0+1 .. t0+64
+                const int jj = t0 + lane;
+                const int qchunk = jj < ql ? (int)Q[jj] : 4;
+                int cH = 0, cE1 = VMX_NEG, cE2 = VMX_NEG;
+                if (jj + 1 <= ql) {
+                    if (s == 0) cH = vmx_gap_open_row(jj + 1, o1, e1, o2, e2);
+                    else { cH = bH[jj + 1]; cE1 = bE1[jj + 1]; cE2 = bE2[jj + 1]; }
+                }
+                int tend = W - t0; if (tend > 64) tend = 64;
+                for (int tt = 0; tt < tend; ++tt) {
+                    const int t = t0 + tt;
+                    int upH = vmx_shr1(outH), upE1 = vmx_shr1(outE1), upE2 = vmx_shr1(outE2);
+                    const int q_up = vmx_shr1(qc_cur);
+                    const int q0 = vmx_readlane(qchunk, tt);
+                    const int h0 = vmx_readlane(cH, tt), e10 = vmx_readlane(cE1, tt), e20 = vmx_readlane(cE2, tt);
+                    if (lane == 0) { upH = h0; upE1 = e10; upE2 = e20; qc_cur = q0; } else qc_cur = q_up;
+                    const int j = t - lane + 1;
+                    if (row_active && j >= 1 && j <= ql) {
+                        int b = 0;
+                        const int a1 = upH - o1, a2 = upH - o2;
+                        if (upE1 > a1) b |= 8;
+                        if (upE2 > a2) b |= 16;
+                        const int e1v = (a1 > upE1 ? a1 : upE1) - e1, e2v = (a2 > upE2 ? a2 : upE2) - e2;
+                        const int c1 = Hleft - o1, c2 = Hleft - o2;
+                        if (F1 > c1) b |= 32;
+                        if (F2 > c2) b |= 64;
+                        F1 = (c1 > F1 ? c1 : F1) - e1; F2 = (c2 > F2 ? c2 : F2) - e2;
+                        int h = Hdiag + ((ti == qc_cur && ti < 4) ? match : mismatch);
+                        int src = 0;
+                        if (e1v > h) { h = e1v; src = 1; }
+                        if (e2v > h) { h = e2v; src = 2; }
+                        if (F1 > h) { h = F1; src = 3; }
+                        if (F2 > h) { h = F2; src = 4; }
+                        tbs[(size_t)t * 64 + lane] = (uint8_t)(b | src);
+                        Hdiag = upH; Hleft = h;
+                        outH = h; outE1 = e1v; outE2 = e2v;
+                        if (lane == 63) { bH[j] = h; bE1[j] = e1v; bE2[j] = e2v; }
+                        if (i == tl && j == ql) out_score[p] = h;
                     }
                 }
-                if (row_active && j >= 1 && j <= ql) {
-                    int b = 0;
-                    int a1 = upH - o1, a2 = upH - o2;
-                    if (upE1 > a1) b |= 8;
-                    if (upE2 > a2) b |= 16;
-                    int e1v = (a1 > upE1 ? a1 : upE1) - e1, e2v = (a2 > upE2 ? a2 : upE2) - e2;
-                    int c1 = Hleft - o1, c2 = Hleft - o2;
-                    if (F1 > c1) b |= 32;
-                    if (F2 > c2) b |= 64;
-                    F1 = (c1 > F1 ? c1 : F1) - e1; F2 = (c2 > F2 ? c2 : F2) - e2;
-                    int qc = (int)Q[j - 1];
-                    int h = Hdiag + ((ti == qc && ti < 4) ? match : mismatch);
-                    int src = 0;
-                    if (e1v > h) { h = e1v; src = 1; }
-                    if (e2v > h) { h = e2v; src = 2; }
-                    if (F1 > h) { h = F1; src = 3; }
-                    if (F2 > h) { h = F2; src = 4; }
-                    tbs[(size_t)t * 64 + lane] = (uint8_t)(b | src);
-                    Hdiag = upH; Hleft = h;
-                    outH = h; outE1 = e1v; outE2 = e2v;
-                    if (lane == 63) { bH[j] = h; bE1[j] = e1v; bE2[j] = e2v; }
-                    if (i == tl && j == ql) out_score[p] = h;
-                }
             }
-            __syncthreads();   // bnd[] written by lane 63 is read by lane 0 of the next stripe
+            __syncthreads();   // bnd[] written by lane 63 is read (in 64-column chunks) by the next stripe
         }
     }
 }

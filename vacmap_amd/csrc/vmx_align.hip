@@ -258,8 +258,14 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         st.dp_string_bytes += tq[0] + tq[1];
         hipEvent_t* ke = c->ev + (redo_only ? 19 : 16);      // HIP events around the dominant kernel, on the stream it runs on
         (void)hipEventRecord(ke[0], c->stream);
-        if (cnt) hipLaunchKernelGGL(k_gapfill_fill, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>(), cnt,
-                                    2, -4, 4, 2, 24, 1, B.tb.as<uint8_t>(), B.bnd.as<int32_t>(), B.dpscore.as<int32_t>());
+        if (cnt) {
+            VMX_TRY(B.order.reserve(4 * (size_t)(round_cap + 1))); VMX_TRY(B.qrange.reserve(64));
+            int32_t* d_range = B.qrange.as<int32_t>(); int32_t* d_cnt = d_range + 4;
+            hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), (int64_t)0, B.order.as<int32_t>(), d_range, d_cnt);
+            (void)hipEventRecord(ke[0], c->stream);
+            hipLaunchKernelGGL(k_gapfill_fill, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>(), cnt,
+                               2, -4, 4, 2, 24, 1, B.tb.as<uint8_t>(), B.bnd.as<int32_t>(), B.dpscore.as<int32_t>(), B.order.as<int32_t>(), d_cnt);
+        }
         (void)hipEventRecord(ke[1], c->stream);
         if (cnt) hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>(), cnt, prm->eqx,
                                     B.tb.as<uint8_t>(), B.run.as<uint32_t>(), B.cig.as<char>(), B.ciglen.as<int32_t>());

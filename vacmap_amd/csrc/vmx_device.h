@@ -23,16 +23,24 @@ __device__ __forceinline__ int vmx_lane() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ int vmx_shr1(int v) { return __shfl_up(v, 1); }
 __device__ __forceinline__ int vmx_readlane(int v, int l) { return __shfl(v, l); }
 #define VMX_SPIN_PAUSE() hipemu::yield()
+#define VMX_CLOCK() 0LL
 #else
 __device__ __forceinline__ int vmx_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int vmx_readlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 #define VMX_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
+#define VMX_CLOCK() ((long long)wall_clock64())
 #endif
 // value known to be identical in every lane: hand it to the compiler as a scalar (v_readfirstlane_b32)
 #ifdef VMX_EMU
 __device__ __forceinline__ int vmx_uniform_i32(int v) { return v; }
 #else
 __device__ __forceinline__ int vmx_uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+// broadcast lane 0's value to the wave
+#ifdef VMX_EMU
+__device__ __forceinline__ int vmx_bcast0(int v) { return __shfl(v, 0); }
+#else
+__device__ __forceinline__ int vmx_bcast0(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 __device__ __forceinline__ double vmx_shr1_f64(double v) {
     union { double d; int i[2]; } u; u.d = v;

@@ -38,8 +38,10 @@ struct vmx_lseed_args {
     const uint8_t* ref; const int64_t* coff; int32_t nseq;  // reference codes + contig offsets (nseq+1)
     const vmx_anchor* guide_rows; const int32_t* guide_len; const int32_t* n_guides_used; const int64_t* aoff;
     int32_t n_reads, k, look_span, read_span;
-    int32_t* cnt_pool; int32_t* cur_pool;                   // 4^k+1 / 4^k per slot
+    int32_t* head_pool; int32_t* next_pool;                 // HEAD[4^k] (all -1 between uses) / NEXT[tpos_cap] per slot
+    int32_t* sq_pool; int32_t* dst_pool;                    // hit_cap ints each
     int64_t* tpos_pool; int64_t tpos_cap;
+    unsigned long long* dbg;    // optional phase timers (VMX_DBG=1)
     uint64_t* hkey2_pool;
     uint64_t* hkey_pool; int64_t* hval_pool; int32_t* hq_pool; int32_t* goff_pool; int64_t hit_cap;
     int32_t* pcnt_pool; int64_t pcnt_cap;

@@ -5,6 +5,8 @@
 #include "vmx_stage.h"
 #include <algorithm>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 
 using namespace vmx;
 
@@ -41,7 +43,14 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     int64_t hit_cap = 1; while (hit_cap < 4 * (Lmax + 14000)) hit_cap <<= 1;
     int64_t pcnt_cap = Lmax + 16;
     int64_t gkey_cap = 1; { int64_t mx = 1; for (int64_t r = 0; r < n; ++r) mx = std::max(mx, h_aoff[r + 1] - h_aoff[r]); while (gkey_cap < mx) gkey_cap <<= 1; }
-    VMX_TRY(L.cnt.reserve(4 * (size_t)G * (size_t)(nkey + 1))); VMX_TRY(L.cur.reserve(4 * (size_t)G * (size_t)nkey));
+    {   // HEAD must be all -1 when the kernel starts; the kernel restores that itself, so only fresh memory needs the fill
+        const size_t need = 4 * (size_t)G * (size_t)nkey;
+        const void* before = L.cnt.p; const size_t cap_before = L.cnt.cap;
+        VMX_TRY(L.cnt.reserve(need));
+        if (L.cnt.p != before || L.cnt.cap != cap_before) VMX_HIP(hipMemsetAsync(L.cnt.p, 0xff, L.cnt.cap, c->stream));
+    }
+    VMX_TRY(L.cur.reserve(4 * (size_t)G * (size_t)tpos_cap));
+    VMX_TRY(L.sq.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.dst.reserve(4 * (size_t)G * (size_t)hit_cap));
     VMX_TRY(L.tpos.reserve(8 * (size_t)G * (size_t)tpos_cap)); VMX_TRY(L.hkey.reserve(8 * (size_t)G * (size_t)hit_cap));
     VMX_TRY(L.hval.reserve(8 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.hq.reserve(4 * (size_t)G * (size_t)hit_cap));
     VMX_TRY(L.goff.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.pcnt.reserve(4 * (size_t)G * (size_t)pcnt_cap));
@@ -54,7 +63,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     A.ocodes = d_ocodes; A.roff = d_roff; A.ref = ix.codes; A.coff = ix.coff; A.nseq = ix.nseq;
     A.guide_rows = L.guide_rows.as<vmx_anchor>(); A.guide_len = L.guide_len.as<int32_t>(); A.n_guides_used = L.ng_used.as<int32_t>(); A.aoff = d_aoff;
     A.n_reads = (int)n; A.k = k; A.look_span = 7000; A.read_span = 7000;   // :23094, :23190
-    A.cnt_pool = L.cnt.as<int32_t>(); A.cur_pool = L.cur.as<int32_t>(); A.tpos_pool = L.tpos.as<int64_t>(); A.tpos_cap = tpos_cap;
+    A.head_pool = L.cnt.as<int32_t>(); A.next_pool = L.cur.as<int32_t>(); A.sq_pool = L.sq.as<int32_t>(); A.dst_pool = L.dst.as<int32_t>(); A.tpos_pool = L.tpos.as<int64_t>(); A.tpos_cap = tpos_cap;
     VMX_TRY(L.hkey2.reserve(8 * (size_t)G * (size_t)hit_cap));
     A.hkey2_pool = L.hkey2.as<uint64_t>();
     A.hkey_pool = L.hkey.as<uint64_t>(); A.hval_pool = L.hval.as<int64_t>(); A.hq_pool = L.hq.as<int32_t>(); A.goff_pool = L.goff.as<int32_t>(); A.hit_cap = hit_cap;
@@ -62,7 +71,12 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     A.gkey_cap = gkey_cap;
     A.la_rows = L.la_rows.as<vmx_anchor>(); A.la_ekey = L.la_ekey.as<uint64_t>(); A.la_sorted = L.la_sorted.as<vmx_anchor>(); A.la_off = L.la_off.as<int64_t>();
     A.la_cnt = L.la_cnt.as<int32_t>(); A.status = L.status.as<int32_t>();
+    A.dbg = nullptr;
+    static const bool dbg_on = getenv("VMX_DBG") != nullptr;
+    if (dbg_on) { VMX_TRY(L.dbg.reserve(64)); VMX_HIP(hipMemsetAsync(L.dbg.p, 0, 64, c->stream)); A.dbg = L.dbg.as<unsigned long long>(); }
     hipLaunchKernelGGL(k_local_seed, dim3((unsigned)G), dim3(256), 0, c->stream, A);
+    if (dbg_on) { unsigned long long h[8]; VMX_TRY(download(h, L.dbg.p, 8, c->stream)); VMX_HIP(hipStreamSynchronize(c->stream));
+                  fprintf(stderr, "k_local_seed phase ticks (100MHz, summed over blocks): guide+windows %llu table %llu passA %llu passB+sort %llu merge %llu finalsort %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]); }
     // sizing sync #2: local anchor counts decide the LDS bucket of every read in the local chain DP
     L.h_la_cnt.resize((size_t)n);
     VMX_TRY(download(L.h_la_cnt.data(), L.la_cnt.p, (size_t)n, c->stream));
