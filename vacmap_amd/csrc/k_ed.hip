@@ -94,7 +94,8 @@ __global__ void __launch_bounds__(64 * VMX_ED_WAVES) k_edit_distance(const uint8
                 }
             }
             unsigned long long Pv = ~0ULL, Mv = 0ULL;
-            const unsigned long long HIGH = (b == B - 1) ? (1ULL << ((m - 1) & 63)) : (1ULL << 63);
+            const bool is_last_block = b == B - 1;
+            const int hbit = is_last_block ? ((m - 1) & 63) : 63;     // bit whose horizontal delta leaves the block
             const bool last_pass = ps == P - 1;
             const int8_t* cin_arr = carry + (size_t)((ps + W - 1) % W) * (size_t)n;
             int8_t* cout_arr = carry + (size_t)(ps % W) * (size_t)n;
@@ -123,21 +124,23 @@ __global__ void __launch_bounds__(64 * VMX_ED_WAVES) k_edit_distance(const uint8
                     else { c_cur = c_up; hin = h_up; }
                     const int j = t - lane;
                     if (active_b && j >= 0 && j < n) {
-                        unsigned long long Eq = c_cur == 0 ? p0 : c_cur == 1 ? p1 : c_cur == 2 ? p2 : c_cur == 3 ? p3 : p4;
+                        // branch-free body: 2-level select of the match vector, sign tricks for the carries
+                        const unsigned long long s01 = (c_cur & 1) ? p1 : p0, s23 = (c_cur & 1) ? p3 : p2;
+                        const unsigned long long s03 = (c_cur & 2) ? s23 : s01;
+                        unsigned long long Eq = (c_cur & 4) ? p4 : s03;
+                        const unsigned long long neg = (unsigned long long)((unsigned)hin >> 31);      // hin < 0
+                        const unsigned long long pos = (unsigned long long)((unsigned)(-hin) >> 31);   // hin > 0
                         const unsigned long long Xv = Eq | Mv;
-                        if (hin < 0) Eq |= 1ULL;
+                        Eq |= neg;
                         const unsigned long long Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
                         unsigned long long Ph = Mv | ~(Xh | Pv);
                         unsigned long long Mh = Pv & Xh;
-                        int hout = 0;
-                        if (Ph & HIGH) hout = 1;
-                        if (Mh & HIGH) hout = -1;
-                        Ph <<= 1; Mh <<= 1;
-                        if (hin < 0) Mh |= 1ULL; else if (hin > 0) Ph |= 1ULL;
+                        const int hout = (int)((Ph >> hbit) & 1ULL) - (int)((Mh >> hbit) & 1ULL);
+                        Ph = (Ph << 1) | pos; Mh = (Mh << 1) | neg;
                         Pv = Mh | ~(Xv | Ph);
                         Mv = Ph & Xv;
                         hout_cur = hout;
-                        if (b == B - 1) score += hout;
+                        score += is_last_block ? hout : 0;
                     }
                     if (!last_pass) {
                         // park the delta leaving block 63 (column t-63) in lane (column & 63); publish 64 columns at a time
