@@ -47,6 +47,46 @@ def check_edit_distance(ctx, O, n=32, maxlen=600, seed=1, minlen=0):
     assert got.tolist() == exp
 
 
+def check_edit_distance_bound(ctx, O, seed=5, lens=(1, 63, 64, 65, 700, 1600, 3000, 6500), big=True):
+    """banded upper bound of the divergence filter: exact on near-diagonal pairs, never below the exact distance,
+    -1 outside its eligibility window"""
+    rng = np.random.default_rng(seed)
+    qs, ts, kind = [], [], []
+    for L in lens:
+        for rate in (0.0, 0.1, 0.25):
+            a = rand_seq(rng, L)
+            b = mutate(rng, a, rate)
+            if abs(len(a) - len(b)) > 500 or not b:
+                continue
+            qs.append(a); ts.append(b); kind.append('exact')
+            qs.append(b); ts.append(a); kind.append('exact')
+    # an empty side, a one-sided length excess, unrelated sequences, and a path that leaves the band and comes back
+    qs.append(''); ts.append('ACGT'); kind.append('exact')
+    qs.append('ACGTN'); ts.append(''); kind.append('exact')
+    a = rand_seq(rng, 1200); qs.append(a); ts.append(a[:600]); kind.append('inelig')
+    qs.append(a[:500]); ts.append(a[:1100]); kind.append('inelig')
+    qs.append(rand_seq(rng, 900)); ts.append(rand_seq(rng, 1000)); kind.append('bound')
+    if big:
+        a = rand_seq(rng, 5000)
+        ins = rand_seq(rng, 1100)
+        b = a[:1000] + ins + a[1000:3000] + a[4000:]         # +1100 then -1000: the optimal path runs 1100 rows off the diagonal
+        qs.append(a); ts.append(b); kind.append('bound')
+        qs.append(b); ts.append(a); kind.append('bound')
+        a = rand_seq(rng, 4300); b = mutate(rng, a, 0.12)     # > 64 blocks: lanes are reused
+        if abs(len(a) - len(b)) <= 500:
+            qs.append(a); ts.append(b); kind.append('exact')
+    got = ctx.edit_distance_bound_batch(qs, ts).tolist()
+    for q, t, k, g in zip(qs, ts, kind, got):
+        e = O.edit_distance(q, t)
+        if k == 'exact':
+            assert g == e, (len(q), len(t), g, e)
+        elif k == 'inelig':
+            assert g == -1, (len(q), len(t), g)
+        else:
+            assert g >= e, (len(q), len(t), g, e)
+    return got
+
+
 def check_extend(ctx, O, n=64, seed=3, maxlen=700):
     rng = np.random.default_rng(seed)
     ts, qs = [], []

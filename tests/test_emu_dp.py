@@ -20,6 +20,10 @@ def test_emu_edit_distance(ctx, oracle):
     KC.check_edit_distance(ctx, oracle, n=2, maxlen=4500, seed=2, minlen=4200)   # > 64 blocks: multi-pass carry
 
 
+def test_emu_edit_distance_bound(ctx, oracle):
+    KC.check_edit_distance_bound(ctx, oracle, seed=5, lens=(1, 63, 64, 65, 700, 1700), big=True)
+
+
 def test_emu_extend(ctx, oracle):
     KC.check_extend(ctx, oracle, n=16, seed=3)
 

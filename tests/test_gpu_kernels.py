@@ -22,6 +22,11 @@ def test_edit_distance(ctx, oracle):
     KC.check_edit_distance(ctx, oracle, n=2, maxlen=17000, seed=13, minlen=15000)
 
 
+def test_edit_distance_bound(ctx, oracle):
+    KC.check_edit_distance_bound(ctx, oracle, seed=21)
+    KC.check_edit_distance_bound(ctx, oracle, seed=22, lens=(2, 100, 800, 2500, 9000, 20000))
+
+
 def test_extend(ctx, oracle):
     KC.check_extend(ctx, oracle, n=200, seed=14)
     KC.check_extend(ctx, oracle, n=8, seed=15, maxlen=6000)

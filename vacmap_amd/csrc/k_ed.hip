@@ -14,7 +14,7 @@
 #include "vmx_kernels.h"
 
 // order[] = problem indices sorted by floor(log2(size)) descending; range[0] = number of problems with size > thresh,
-// range[1] = n; counters[0..3] = 0 (work-queue heads of the consumers)
+// range[1] = number of problems queued (those with size >= 0); counters[0..3] = 0 (work-queue heads of the consumers)
 __global__ void __launch_bounds__(1024) k_size_order(const int64_t* __restrict__ size, const int32_t* __restrict__ n_ptr, int64_t thresh,
                                                      int32_t* __restrict__ order, int32_t* __restrict__ range, int32_t* __restrict__ counters) {
     __shared__ int s_hist[64];
@@ -27,6 +27,7 @@ __global__ void __launch_bounds__(1024) k_size_order(const int64_t* __restrict__
     int nl = 0;
     for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
         const long long s = size[i];
+        if (s < 0) continue;                       // negative size: problem already settled, not queued
         const int b = s > 0 ? 63 - __clzll(s) : 0;
         atomicAdd(&s_hist[b], 1);
         if (s > thresh) ++nl;
@@ -36,12 +37,13 @@ __global__ void __launch_bounds__(1024) k_size_order(const int64_t* __restrict__
     if (threadIdx.x == 0) {
         int acc = 0;
         for (int b = 63; b >= 0; --b) { s_cur[b] = acc; acc += s_hist[b]; }
-        range[0] = s_long; range[1] = n;
+        range[0] = s_long; range[1] = acc;
         counters[0] = 0; counters[1] = 0; counters[2] = 0; counters[3] = 0;
     }
     __syncthreads();
     for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
         const long long s = size[i];
+        if (s < 0) continue;
         const int b = s > 0 ? 63 - __clzll(s) : 0;
         order[atomicAdd(&s_cur[b], 1)] = i;
     }

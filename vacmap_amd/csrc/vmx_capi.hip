@@ -160,6 +160,30 @@ int vm_edit_distance_batch(vm_ctx* c, int64_t n, const char* q, const int64_t* q
     return VM_OK;
 }
 
+int vm_edit_distance_bound_batch(vm_ctx* c, int64_t n, const char* q, const int64_t* q_off, const char* t, const int64_t* t_off, int64_t** bound) {
+    if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
+    *bound = nullptr;
+    VMX_HIP(hipSetDevice(c->device));
+    VMX_TRY(upload_encode(c, q, q_off, n, c->b[0], c->b[1], c->b[2]));
+    VMX_TRY(upload_encode(c, t, t_off, n, c->b[3], c->b[4], c->b[5]));
+    VMX_TRY(c->b[7].reserve(sizeof(int64_t) * (size_t)(n + 1)));
+    if (n) {
+        std::vector<int64_t> sz((size_t)n); for (int64_t i = 0; i < n; ++i) sz[i] = q_off[i + 1] - q_off[i];
+        int32_t nn = (int32_t)n;
+        VMX_TRY(upload(c->b[8], sz.data(), (size_t)n, c->stream)); VMX_TRY(upload(c->b[9], &nn, 1, c->stream));
+        VMX_TRY(c->b[10].reserve(4 * (size_t)(n + 1))); VMX_TRY(c->b[11].reserve(64));
+        int32_t* d_range = c->b[11].as<int32_t>(); int32_t* d_cnt = d_range + 4;
+        hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, c->b[8].as<int64_t>(), c->b[9].as<int32_t>(), (int64_t)0, c->b[10].as<int32_t>(), d_range, d_cnt);
+        hipLaunchKernelGGL(k_ed_banded, dim3(grid_for(c, n, 16)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[2].as<int64_t>(), c->b[4].as<uint8_t>(), c->b[5].as<int64_t>(),
+                           c->b[10].as<int32_t>(), d_range, d_cnt, c->b[7].as<int64_t>());
+    }
+    *bound = host_alloc<int64_t>((size_t)n);
+    VMX_TRY(download(*bound, c->b[7].p, (size_t)n, c->stream));
+    VMX_HIP(hipStreamSynchronize(c->stream));
+    VMX_HIP(hipGetLastError());
+    return VM_OK;
+}
+
 int64_t vm_edit_distance(vm_ctx* c, const char* q, int64_t ql, const char* t, int64_t tl) {
     int64_t qo[2] = {0, ql}, to[2] = {0, tl};
     int64_t* d = nullptr;

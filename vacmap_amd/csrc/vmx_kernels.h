@@ -51,6 +51,8 @@ struct vmx_lseed_args {
 
 #define VMX_ED_WAVES 16              // max waves per workgroup of k_edit_distance (passes pipelined across them) = carry ring depth
 #define VMX_ED_LONG 16384            // patterns longer than this (> 4 passes) go to the 16-wave launch
+#define VMX_EDB_HW 768               // k_ed_banded: half width of the band in rows
+#define VMX_EDB_MAXD 512             // k_ed_banded: |m - n| above this is not eligible (goes to the unbanded kernel)
 #define VMX_SORT_LDS 4096            // uint64 keys sorted in LDS by vmx_block_sort_u64 (larger sorts run in HBM)
 #define VM_READ_FASTPATH_DEV (-21)   // the reference would switch to a *_fast heuristic that is not built yet
 #define VMX_LC_BYTES_PER_ANCHOR 32   // q4 + r8 + ls4 + S8 + P4 + SA4
