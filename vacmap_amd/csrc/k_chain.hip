@@ -95,18 +95,22 @@ __device__ __forceinline__ int vmx_insertpoint_score(const double* S, double tar
     return j;
 }
 
-// wave-cooperative S_arg[loc+1 : k+1] = S_arg[loc : k]; S_arg[loc] = k
-__device__ __forceinline__ void vmx_sarg_insert(int* SA, int loc, int k, int lane) {
-    for (int hi = k; hi > loc; hi -= 64) {
-        int x = hi - lane;
-        int v = 0;
-        if (x > loc) v = SA[x - 1];
-        __syncthreads();
-        if (x > loc) SA[x] = v;
-        __syncthreads();
+// The same insertion point without the dependent probe chain. On the sorted index the literal loop above only sees three outcomes
+// per probe: mid < a (score below target), mid >= b (above), a <= mid < b (equal: return mid + 1), with a = #scores < target and
+// b = #scores <= target. a and b come from two wave-cooperative 64-ary searches; the probe sequence is then replayed on (a, b)
+// in scalar registers, so ties land exactly where the reference's bisection puts them.
+__device__ __forceinline__ int vmx_insertpoint_score_wave(const double* S, double target, int k, const int* SA, int lane) {
+    const int a = vmx_sorted_count(S, SA, k, target, false, lane);
+    int b = a;
+    if (a < k && S[SA[a]] == target) b = vmx_sorted_count(S, SA, k, target, true, lane);
+    int i = 0, j = k;
+    while (i < j) {
+        const int mid = (i + j) >> 1;
+        if (mid < a) i = mid + 1;
+        else if (mid >= b) j = mid;
+        else return mid + 1;
     }
-    if (lane == 0) SA[loc] = k;
-    __syncthreads();
+    return j;
 }
 
 // shared gap geometry of GC and LC (:24953-24984, :27418-27456)
@@ -146,19 +150,25 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
         if (n <= 0) { if (lane == 0) { gmax_out[rd] = -2; opcount_out[rd] = 0; } continue; }
         const vmx_anchor* A = anchors + a0;
         // working arrays: LDS when the read fits, else straight in the HBM output arrays
-        double* S; int* P; int* SA; int* Q; long long* R; int* LS; uint8_t* COV;
-        const bool in_lds = n <= lds_cap;
+        // LDS layout (VMX_GC_BYTES_PER_ANCHOR = 25): S f64 | ref position relative to the smallest one u32 | q i32 | l,s packed i32 | S_arg i32 | cov u8.
+        // P (written once per anchor) goes straight to its HBM output array.
+        long long rmin = 0x7fffffffffffffffLL, rmax = -0x7fffffffffffffffLL;
+        for (int i = lane; i < n; i += 64) { const long long r = A[i].r; rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax; }
+        for (int o = 32; o > 0; o >>= 1) { const long long a = __shfl_xor(rmin, o), b = __shfl_xor(rmax, o); rmin = a < rmin ? a : rmin; rmax = b > rmax ? b : rmax; }
+        double* S; int* SA; int* Q; unsigned* R; int* LS; uint8_t* COV;
+        int* P = P_out + a0;
+        const bool in_lds = n <= lds_cap && (rmax - rmin) < 0xffffffffLL;
         if (in_lds) {
-            S = (double*)smem; R = (long long*)(S + lds_cap); Q = (int*)(R + lds_cap); LS = Q + lds_cap; P = LS + lds_cap;
-            SA = P + lds_cap; COV = (uint8_t*)(SA + lds_cap);
+            S = (double*)smem; R = (unsigned*)(S + lds_cap); Q = (int*)(R + lds_cap); LS = Q + lds_cap;
+            SA = LS + lds_cap; COV = (uint8_t*)(SA + lds_cap);
         } else {
-            S = S_out + a0; P = P_out + a0; SA = SA_out + a0; COV = cov_pool + a0;
+            S = S_out + a0; SA = SA_out + a0; COV = cov_pool + a0;
             Q = nullptr; R = nullptr; LS = nullptr;
         }
         // stage anchors + coverage (number of anchors sharing the read position, capped at 20: :24865-24868)
         for (int i = lane; i < n; i += 64) {
             vmx_anchor a = A[i];
-            if (in_lds) { Q[i] = a.q; R[i] = a.r; LS[i] = ((int)a.l & 0xffff) | ((int)a.s << 16); }
+            if (in_lds) { Q[i] = a.q; R[i] = (unsigned)(a.r - rmin); LS[i] = ((int)a.l & 0xffff) | ((int)a.s << 16); }
             int c = 1;
             for (int x = i - 1; x >= 0 && A[x].q == a.q && c < 20; --x) ++c;
             for (int x = i + 1; x < n && A[x].q == a.q && c < 20; ++x) ++c;
@@ -166,7 +176,7 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
         }
         __syncthreads();
 #define AQ(i) (in_lds ? Q[i] : A[i].q)
-#define AR(i) (in_lds ? R[i] : (long long)A[i].r)
+#define AR(i) (in_lds ? (rmin + (long long)R[i]) : (long long)A[i].r)
 #define AL(i) (in_lds ? (LS[i] & 0xffff) : (int)A[i].l)
 #define AS(i) (in_lds ? (LS[i] >> 16) : (int)A[i].s)
         int prereadloc = AQ(0);
@@ -183,8 +193,8 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
             if (prereadloc < qi) {
                 if (((double)opcount / (double)i) > 1000.0) { bailed = true; break; }   // :24914 max_factor
                 for (int k = testspace_en; k < i; ++k) {
-                    int loc = vmx_insertpoint_score(S, S[k], k, SA);
-                    vmx_sarg_insert(SA, loc, k, lane);
+                    const int loc = vmx_insertpoint_score_wave(S, S[k], k, SA, lane);
+                    vmx_sarg_insert4(SA, loc, k, lane);
                 }
                 testspace_en = i;
                 skipcost = oskipcost + (double)COV[i];
@@ -210,18 +220,21 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
                         test = Sj - skipcost + (double)bonus - (double)tab.extra[gapcost];
                     }
                 }
-                const double m_before = vmx_wave_excl_max_f64(test, max_scores);
+                const double incl = vmx_wave_incl_max_f64(test);                 // prefix max of the candidates' scores, in scan order
+                double m_before = vmx_wave_shr1_f64_fill(incl, VMX_F64_NEG);
+                m_before = m_before > max_scores ? m_before : max_scores;         // the running max the sequential loop holds at this candidate
                 const bool brk = !valid || !(Sj > (m_before - dli));
                 const unsigned long long mask = __ballot(brk);
                 const int first = mask ? (__ffsll((unsigned long long)mask) - 1) : 64;
                 opcount += first;
-                double best = lane < first ? test : -1e300; int bl = lane;
-                for (int off = 32; off > 0; off >>= 1) {
-                    double ob = __shfl_xor(best, off); int ol = __shfl_xor(bl, off);
-                    if (ob > best || (ob == best && ol < bl)) { best = ob; bl = ol; }
+                if (first > 0) {
+                    const double M = vmx_readlane_f64(incl, first - 1);          // best score among the candidates before the break
+                    if (M > max_scores) {                                        // strict >: the first (highest-S) candidate reaching M wins
+                        const unsigned long long em = __ballot(test == M) & (first >= 64 ? ~0ULL : ((1ULL << first) - 1ULL));
+                        pre_index = vmx_readlane(j, __ffsll((unsigned long long)em) - 1);
+                        max_scores = M;
+                    }
                 }
-                const int jb = __shfl(j, bl);
-                if (best > max_scores) { max_scores = best; pre_index = jb; }
                 if (first < 64) break;
             }
             if (lane == 0) { S[i] = max_scores; P[i] = pre_index; }
@@ -230,12 +243,12 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
         }
         if (!bailed) {
             for (int k = testspace_en; k < n; ++k) {
-                int loc = vmx_insertpoint_score(S, S[k], k, SA);
-                vmx_sarg_insert(SA, loc, k, lane);
+                const int loc = vmx_insertpoint_score_wave(S, S[k], k, SA, lane);
+                vmx_sarg_insert4(SA, loc, k, lane);
             }
         }
         if (in_lds) {
-            for (int i = lane; i < n; i += 64) { S_out[a0 + i] = S[i]; P_out[a0 + i] = P[i]; SA_out[a0 + i] = SA[i]; }
+            for (int i = lane; i < n; i += 64) { S_out[a0 + i] = S[i]; SA_out[a0 + i] = SA[i]; }
         }
         if (lane == 0) { gmax_out[rd] = bailed ? -1 : g_max_index; opcount_out[rd] = opcount; }
         __syncthreads();

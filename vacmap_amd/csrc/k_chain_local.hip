@@ -1,7 +1,8 @@
 // k_chain_local.hip — local chain DP: LC-exact (get_optimal_chain_sortbyreadpos_forSV_inv_test_merged_fine_list,
 // /root/reference/src/vacmap/mammap_clrnano.py:27305-27528) and LC-mm (..._fine_list_mismatch, :28250-28476).
-// One wavefront per read; anchors (sorted by read END, :28585), S, P and the score-sorted index S_arg live in LDS (32 B per anchor)
-// when they fit, else in HBM. Same 64-wide descending-S candidate scan as k_chain_global with the LC rules: the loop breaks on
+// One wavefront per read; anchors (sorted by read END, :28585), S and the score-sorted index S_arg live in LDS (24 B per anchor)
+// when they fit, else in HBM; reads are bucketed by anchor count so that a workgroup only claims the LDS its read needs.
+// Same 64-wide descending-S candidate scan as k_chain_global with the LC rules: the loop breaks on
 // S[j] < max - l_i (strict) and `opcount` is bumped before that test (:27410-27415); overlapping predecessors with bonus <= 0 are
 // skipped; traceback trims overlaps (:27508-27526). Scores are IEEE double in the reference's evaluation order (-ffp-contract=off).
 #include "vmx_device.h"
@@ -9,40 +10,8 @@
 #include "vmx_local.h"
 
 // ------------------------------------------------------------------------------------------------ L3 / L4 local chain DP
-// :13229-13265 literal
-__device__ __forceinline__ int vmx_smallorequal(const double* arr, double target, int n, const int* point) {
-    if (target < arr[point[0]]) return -1;
-    if (target >= arr[point[n - 1]]) return n - 1;
-    int i = 0, j = n, mid = 0;
-    while (i < j) {
-        mid = (i + j) >> 1;
-        double am = arr[point[mid]];
-        if (target == am) {
-            if (mid < n - 1) { if (arr[point[mid + 1]] > target) return mid; else i = mid + 1; }
-            else return mid;
-        } else if (target < am) {
-            if (mid > 0 && target >= arr[point[mid - 1]]) return mid - 1;
-            j = mid;
-        } else {
-            if (mid < n - 1 && target < arr[point[mid + 1]]) return mid;
-            i = mid + 1;
-        }
-    }
-    return mid;
-}
-
-__device__ __forceinline__ void vmx_sarg_insert_l(int* SA, int loc, int k, int lane) {
-    for (int hi = k; hi > loc; hi -= 64) {
-        int x = hi - lane; int v = 0;
-        if (x > loc) v = SA[x - 1];
-        __syncthreads();
-        if (x > loc) SA[x] = v;
-        __syncthreads();
-    }
-    if (lane == 0) SA[loc] = k;
-    __syncthreads();
-}
-
+// The reference's smallorequal (:13229-13265) returns, on the score-sorted index, the position of the last score <= target, whatever
+// its probe sequence; the kernel computes that count directly (vmx_sorted_count, vmx_device.h).
 
 __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ la_off,
                                                     const int32_t* __restrict__ la_cnt, const int32_t* __restrict__ n_guides_total,
@@ -54,6 +23,7 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
                                                     int32_t* __restrict__ status) {
     VMX_DYN_SHARED(char, smem);
     __shared__ double s_gapcost[64];
+    __shared__ float s_rgc[128];
     const int lane = vmx_lane();
     for (int x = lane; x <= maxdiff && x < 64; x += 64) s_gapcost[x] = gapcost_list[x];
     __syncthreads();
@@ -66,16 +36,24 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
         if (n <= 0) { if (lane == 0) { out_len[rd] = 0; out_score[rd] = 0; status[rd] = VM_READ_RAISED_DEV; } continue; }   // np.array([]) indexing raises
         const bool mm = n_guides_total[rd] > 1;
         const double skipcost = mm ? skip_mm : skip_exact;
-        const float* rgc = mm ? tab.large_readgap : (mode == 3 ? tab.readgap_r : tab.readgap_h);
+        const float* rgc_g = mm ? tab.large_readgap : (mode == 3 ? tab.readgap_r : tab.readgap_h);
+        for (int x = lane; x < 100; x += 64) s_rgc[x] = rgc_g[x];          // read-gap cost table of this read's variant (100 entries, maxgap <= 99)
+        const float* rgc = s_rgc;
         const vmx_anchor* A = anchors + a0;
-        double* S; int* P; int* SA; int* Q; long long* R; int* LS;
-        const bool in_lds = n <= lds_cap;
-        if (in_lds) { S = (double*)smem; R = (long long*)(S + lds_cap); Q = (int*)(R + lds_cap); LS = Q + lds_cap; P = LS + lds_cap; SA = P + lds_cap; }
-        else { S = S_pool + a0; P = P_pool + a0; SA = SA_pool + a0; Q = nullptr; R = nullptr; LS = nullptr; }
-        if (in_lds) for (int i = lane; i < n; i += 64) { vmx_anchor a = A[i]; Q[i] = a.q; R[i] = a.r; LS[i] = ((int)a.l & 0xffff) | ((int)a.s << 16); }
+        // LDS layout (VMX_LC_BYTES_PER_ANCHOR = 24): S f64 | ref position relative to the smallest one u32 | q i32 | l,s packed i32 | S_arg i32.
+        // P (written once per anchor, read by the traceback) stays in HBM.
+        long long rmin = 0x7fffffffffffffffLL, rmax = -0x7fffffffffffffffLL;
+        for (int i = lane; i < n; i += 64) { const long long r = A[i].r; rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax; }
+        for (int o = 32; o > 0; o >>= 1) { const long long a = __shfl_xor(rmin, o), b = __shfl_xor(rmax, o); rmin = a < rmin ? a : rmin; rmax = b > rmax ? b : rmax; }
+        double* S; int* SA; int* Q; unsigned* R; int* LS;
+        int* P = P_pool + a0;
+        const bool in_lds = n <= lds_cap && (rmax - rmin) < 0xffffffffLL;
+        if (in_lds) { S = (double*)smem; R = (unsigned*)(S + lds_cap); Q = (int*)(R + lds_cap); LS = Q + lds_cap; SA = LS + lds_cap; }
+        else { S = S_pool + a0; SA = SA_pool + a0; Q = nullptr; R = nullptr; LS = nullptr; }
+        if (in_lds) for (int i = lane; i < n; i += 64) { vmx_anchor a = A[i]; Q[i] = a.q; R[i] = (unsigned)(a.r - rmin); LS[i] = ((int)a.l & 0xffff) | ((int)a.s << 16); }
         __syncthreads();
 #define AQ(i) (in_lds ? Q[i] : A[i].q)
-#define AR(i) (in_lds ? R[i] : (long long)A[i].r)
+#define AR(i) (in_lds ? (rmin + (long long)R[i]) : (long long)A[i].r)
 #define AL(i) (in_lds ? (LS[i] & 0xffff) : (int)A[i].l)
 #define AS(i) (in_lds ? (LS[i] >> 16) : (int)A[i].s)
         long long prereadloc = (long long)AQ(0) + AL(0);
@@ -90,8 +68,9 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
             if (prereadloc < (long long)qi + li) {
                 if (opcount > 100000 && ((double)opcount / (double)prereadloc) > 1000.0) { need_fast = true; break; }   // :27380 -> *_fast
                 for (int k = testspace_en; k < i; ++k) {
-                    int loc = vmx_smallorequal(S, S[k], k, SA) + 1;
-                    vmx_sarg_insert_l(SA, loc, k, lane);
+                    // smallorequal(...) + 1 (:13229-13265) on a sorted array = number of scores <= S[k]
+                    const int loc = vmx_sorted_count(S, SA, k, S[k], true, lane);
+                    vmx_sarg_insert4(SA, loc, k, lane);
                 }
                 testspace_en = i;
                 prereadloc = (long long)qi + li;
@@ -135,19 +114,22 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
                         }
                     }
                 }
-                const double m_before = vmx_wave_excl_max_f64(test, max_scores);
+                const double incl = vmx_wave_incl_max_f64(test);                 // prefix max of the candidates' scores, in scan order
+                double m_before = vmx_wave_shr1_f64_fill(incl, VMX_F64_NEG);
+                m_before = m_before > max_scores ? m_before : max_scores;         // the running max the sequential loop holds at this candidate
                 const bool brk = valid && (Sj < (m_before - dli));       // strict; opcount is bumped BEFORE this test (:27410-27415)
                 const unsigned long long bmask = __ballot(brk);
                 const unsigned long long vmask = __ballot(valid);
                 const int first = bmask ? (__ffsll((unsigned long long)bmask) - 1) : 64;
                 opcount += bmask ? (first + 1) : __popcll(vmask);
-                double best = (lane < first && valid) ? test : -1e300; int bl = lane;
-                for (int off = 32; off > 0; off >>= 1) {
-                    double ob = __shfl_xor(best, off); int ol = __shfl_xor(bl, off);
-                    if (ob > best || (ob == best && ol < bl)) { best = ob; bl = ol; }
+                if (first > 0) {
+                    const double M = vmx_readlane_f64(incl, first - 1);          // best score among the candidates before the break
+                    if (M > max_scores) {                                        // strict >: the first (highest-S) candidate reaching M wins
+                        const unsigned long long em = __ballot(test == M) & (first >= 64 ? ~0ULL : ((1ULL << first) - 1ULL));
+                        pre_index = vmx_readlane(j, __ffsll((unsigned long long)em) - 1);
+                        max_scores = M;
+                    }
                 }
-                const int jb = __shfl(j, bl);
-                if (best > max_scores) { max_scores = best; pre_index = jb; }
                 if (first < 64) break;
             }
             if (lane == 0) { S[i] = max_scores; P[i] = pre_index; }

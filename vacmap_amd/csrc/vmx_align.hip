@@ -145,28 +145,33 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         for (int g = 1; g <= prm->global_maxdiff; ++g) gap[g] = (0.01 * ix.k * g + 0.5 * T.log2int[g]);
         VMX_TRY(upload(B.gap, gap.data(), 64, c->stream));
     }
-    const int caps[4] = {768, 1536, 3072, 4736};
-    std::vector<int32_t> lists[5];
+    // LDS buckets by anchor count (25 B per anchor), reads longest-first inside a bucket, one workgroup per read (see vmx_local_stage)
+    constexpr int NB = 10;
+    const int caps[NB] = {384, 512, 768, 1024, 1280, 1536, 2048, 3072, 4096, 6400};
+    std::vector<int32_t> lists[NB + 1];
     for (int64_t r = 0; r < n; ++r) {
         int64_t m = h_aoff[r + 1] - h_aoff[r]; const int64_t L = h_roff[r + 1] - h_roff[r];
         if (m <= 2) continue;                                             // :23986 unmapped
         if ((double)m / (double)L > 5.0) continue;                        // fast_enable (:23570): GC-fast not built yet -> gmax stays -1
-        int bk = 4; for (int q = 0; q < 4; ++q) if (m <= caps[q]) { bk = q; break; }
+        int bk = NB; for (int q = 0; q < NB; ++q) if (m <= caps[q]) { bk = q; break; }
         lists[bk].push_back((int32_t)r);
     }
     {
-        std::vector<int32_t> rl; int64_t rl_off[6];
-        for (int q = 0; q < 5; ++q) { rl_off[q] = (int64_t)rl.size(); rl.insert(rl.end(), lists[q].begin(), lists[q].end()); }
+        std::vector<int32_t> rl; int64_t rl_off[NB + 2];
+        for (int q = 0; q <= NB; ++q) {
+            std::stable_sort(lists[q].begin(), lists[q].end(), [&](int32_t a, int32_t b) { return h_aoff[a + 1] - h_aoff[a] > h_aoff[b + 1] - h_aoff[b]; });
+            rl_off[q] = (int64_t)rl.size(); rl.insert(rl.end(), lists[q].begin(), lists[q].end());
+        }
         VMX_TRY(upload(B.rl, rl.data(), rl.size(), c->stream));
         VMX_HIP(hipMemsetAsync(B.gmax.p, 0xff, 8 * (size_t)n, c->stream));
 #ifndef VMX_EMU
-        VMX_HIP(hipFuncSetAttribute((const void*)k_chain_global, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)caps[3] * VMX_GC_BYTES_PER_ANCHOR + 64)));
+        VMX_HIP(hipFuncSetAttribute((const void*)k_chain_global, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)caps[NB - 1] * VMX_GC_BYTES_PER_ANCHOR + 64)));
 #endif
         vmx_fork fk(c);                                               // the LDS buckets are independent: run them side by side
-        for (int q = 4; q >= 0; --q) {                                // slowest (largest reads) first
+        for (int q = NB; q >= 0; --q) {                               // slowest (largest reads) first
             int cnt = (int)lists[q].size(); if (!cnt) continue;
-            int cap = q < 4 ? caps[q] : 0; size_t shmem = (size_t)cap * VMX_GC_BYTES_PER_ANCHOR + 64;
-            hipLaunchKernelGGL(k_chain_global, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 8)), dim3(64), shmem, fk.next(), B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(),
+            int cap = q < NB ? caps[q] : 0; size_t shmem = (size_t)cap * VMX_GC_BYTES_PER_ANCHOR + 64;
+            hipLaunchKernelGGL(k_chain_global, dim3((unsigned)cnt), dim3(64), shmem, fk.next(), B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(),
                                B.rl.as<int32_t>() + rl_off[q], cnt, cap, c->tables, B.gap.as<double>(), prm->global_skipcost, prm->global_maxdiff, 1000, B.S.as<double>(),
                                B.P.as<int32_t>(), B.SA.as<int32_t>(), B.cov.as<uint8_t>(), B.gmax.as<int64_t>(), B.opc.as<int64_t>());
         }

@@ -319,7 +319,7 @@ int vm_chain_global_batch(vm_ctx* c, const vm_params* prm, int kmersize, int64_t
     for (int g = 1; g <= prm->global_maxdiff; ++g) gap[g] = (0.01 * kmersize * g + 0.5 * T.log2int[g]);
     VMX_TRY(upload(d_gap, gap.data(), 64, c->stream));
     // bucket the reads by anchor count so that each launch asks for no more LDS than it needs (160 KiB per CU on gfx950)
-    const int caps[4] = {768, 1536, 3072, 4736};
+    const int caps[4] = {768, 1536, 3072, 6400};
     std::vector<int32_t> lists[5];
     std::vector<char> fastflag((size_t)n, 0);
     for (int64_t r = 0; r < n; ++r) {

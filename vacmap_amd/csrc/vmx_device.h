@@ -82,6 +82,79 @@ __device__ __forceinline__ double vmx_wave_excl_max_f64(double v, double init) {
     return e;
 }
 
+// DPP forms of the prefix max used by the chain kernels' candidate scan: Kogge-Stone inside the 16-lane rows (row_shr:1/2/4/8),
+// then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3 — 12 v_mov_dpp + 6 max instead of 14 ds_bpermute round trips.
+#define VMX_F64_NEG (-__builtin_inf())
+#ifdef VMX_EMU
+__device__ __forceinline__ double vmx_wave_incl_max_f64(double v) {
+    int lane = vmx_lane();
+    for (int o = 1; o < 64; o <<= 1) { double x = __shfl_up(v, o); if (lane >= o) v = x > v ? x : v; }
+    return v;
+}
+__device__ __forceinline__ double vmx_wave_shr1_f64_fill(double v, double fill) {     // lane i <- lane i-1, lane 0 <- fill
+    double e = __shfl_up(v, 1);
+    return vmx_lane() == 0 ? fill : e;
+}
+#else
+template <int CTRL, int ROWMASK> __device__ __forceinline__ double vmx_dpp_f64(double old, double v) {
+    union { double d; int i[2]; } o, s, r; o.d = old; s.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(o.i[0], s.i[0], CTRL, ROWMASK, 0xf, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(o.i[1], s.i[1], CTRL, ROWMASK, 0xf, false);
+    return r.d;
+}
+__device__ __forceinline__ double vmx_wave_incl_max_f64(double v) {
+    double t;
+    t = vmx_dpp_f64<0x111, 0xf>(VMX_F64_NEG, v); v = t > v ? t : v;
+    t = vmx_dpp_f64<0x112, 0xf>(VMX_F64_NEG, v); v = t > v ? t : v;
+    t = vmx_dpp_f64<0x114, 0xf>(VMX_F64_NEG, v); v = t > v ? t : v;
+    t = vmx_dpp_f64<0x118, 0xf>(VMX_F64_NEG, v); v = t > v ? t : v;
+    t = vmx_dpp_f64<0x142, 0xa>(VMX_F64_NEG, v); v = t > v ? t : v;
+    t = vmx_dpp_f64<0x143, 0xc>(VMX_F64_NEG, v); v = t > v ? t : v;
+    return v;
+}
+__device__ __forceinline__ double vmx_wave_shr1_f64_fill(double v, double fill) { return vmx_dpp_f64<0x138, 0xf>(fill, v); }
+#endif
+
+// wave-cooperative count of the x in [0, k) with S[SA[x]] < target (le = false) or <= target (le = true), S ascending along SA:
+// 64-ary search, two rounds of (two dependent loads + ballot) up to k = 4096. Every lane of the wave must call it.
+__device__ __forceinline__ int vmx_sorted_count(const double* S, const int* SA, int k, double target, bool le, int lane) {
+    int lo = 0, hi = k;                   // elements [0, lo) qualify, elements [hi, k) do not
+    while (hi - lo > 64) {
+        const int stride = (hi - lo + 63) >> 6;
+        const int x = lo + (lane + 1) * stride - 1;
+        bool in = false;
+        if (x < hi) { const double v = S[SA[x]]; in = le ? v <= target : v < target; }
+        const int c = __popcll(__ballot(in));
+        const int nlo = lo + c * stride;
+        int nhi = nlo + stride - 1; if (nhi > hi) nhi = hi;
+        lo = nlo; hi = nhi;
+    }
+    const int x = lo + lane;
+    bool in = false;
+    if (x < hi) { const double v = S[SA[x]]; in = le ? v <= target : v < target; }
+    return lo + __popcll(__ballot(in));
+}
+
+// wave-cooperative SA[loc+1 : k+1] = SA[loc : k]; SA[loc] = k (256 elements per round)
+__device__ __forceinline__ void vmx_sarg_insert4(int* SA, int loc, int k, int lane) {
+    for (int hi = k; hi > loc; hi -= 256) {
+        const int x0 = hi - 4 * lane;
+        int v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        if (x0 > loc) v0 = SA[x0 - 1];
+        if (x0 - 1 > loc) v1 = SA[x0 - 2];
+        if (x0 - 2 > loc) v2 = SA[x0 - 3];
+        if (x0 - 3 > loc) v3 = SA[x0 - 4];
+        __syncthreads();
+        if (x0 > loc) SA[x0] = v0;
+        if (x0 - 1 > loc) SA[x0 - 1] = v1;
+        if (x0 - 2 > loc) SA[x0 - 2] = v2;
+        if (x0 - 3 > loc) SA[x0 - 3] = v3;
+        __syncthreads();
+    }
+    if (lane == 0) SA[loc] = k;
+    __syncthreads();
+}
+
 // block-wide exclusive scan of one int per thread (blockDim.x <= 1024, multiple of 64); returns exclusive prefix,
 // *total gets the block sum. scratch: >= 17 ints of shared memory.
 __device__ __forceinline__ int vmx_block_excl_scan(int v, int* scratch, int* total) {

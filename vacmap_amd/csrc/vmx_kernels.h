@@ -55,7 +55,7 @@ struct vmx_lseed_args {
 #define VMX_EDB_MAXD 512             // k_ed_banded: |m - n| above this is not eligible (goes to the unbanded kernel)
 #define VMX_SORT_LDS 4096            // uint64 keys sorted in LDS by vmx_block_sort_u64 (larger sorts run in HBM)
 #define VM_READ_FASTPATH_DEV (-21)   // the reference would switch to a *_fast heuristic that is not built yet
-#define VMX_LC_BYTES_PER_ANCHOR 32   // q4 + r8 + ls4 + S8 + P4 + SA4
-#define VMX_GC_BYTES_PER_ANCHOR 33   // q4 + r8 + ls4 + S8 + P4 + SA4 + cov1 (LDS bytes per anchor in k_chain_global)
+#define VMX_LC_BYTES_PER_ANCHOR 24   // S8 + r4 (relative) + q4 + ls4 + SA4 (LDS bytes per anchor in k_chain_local)
+#define VMX_GC_BYTES_PER_ANCHOR 25   // S8 + r4 (relative) + q4 + ls4 + SA4 + cov1 (LDS bytes per anchor in k_chain_global)
 
 #endif

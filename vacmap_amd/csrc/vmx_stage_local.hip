@@ -87,17 +87,24 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     std::vector<double> gap(64, 0.0);
     for (int g = 1; g <= prm->local_maxdiff; ++g) gap[g] = g <= 10 ? (0.01 * k * g + 0.5 * T.log2int[g]) : (0.01 * k * g + 2 * T.log2int[g]);   // :27317-27322
     VMX_TRY(upload(L.gap, gap.data(), 64, c->stream));
-    const int caps[4] = {768, 1536, 3072, 4864};
-    std::vector<int32_t> lists[5];
+    // LDS buckets by anchor count (24 B per anchor): a workgroup claims only what its read needs, so 4-12 reads share a CU.
+    // Inside a bucket the reads are ordered longest first and every read is its own workgroup: the dispatcher hands them out in
+    // that order, which is the longest-first dynamic schedule.
+    constexpr int NB = 10;
+    const int caps[NB] = {512, 768, 1024, 1280, 1536, 2048, 2560, 3072, 4096, 6656};
+    std::vector<int32_t> lists[NB + 1];
     for (int64_t r = 0; r < n; ++r) {
         int m = L.h_la_cnt[r];
         if (m <= 0) continue;   // no guide / capacity failure: nothing to chain (status already set by the seeding kernel or stays 0 for unmapped reads)
-        int bk = 4; for (int q = 0; q < 4; ++q) if (m <= caps[q]) { bk = q; break; }
+        int bk = NB; for (int q = 0; q < NB; ++q) if (m <= caps[q]) { bk = q; break; }
         lists[bk].push_back((int32_t)r);
     }
-    std::vector<int32_t> rl; int64_t rl_off[6];
-    for (int q = 0; q < 5; ++q) { rl_off[q] = (int64_t)rl.size(); rl.insert(rl.end(), lists[q].begin(), lists[q].end()); }
-    rl_off[5] = (int64_t)rl.size();
+    std::vector<int32_t> rl; int64_t rl_off[NB + 2];
+    for (int q = 0; q <= NB; ++q) {
+        std::stable_sort(lists[q].begin(), lists[q].end(), [&](int32_t a, int32_t b) { return L.h_la_cnt[a] > L.h_la_cnt[b]; });
+        rl_off[q] = (int64_t)rl.size(); rl.insert(rl.end(), lists[q].begin(), lists[q].end());
+    }
+    rl_off[NB + 1] = (int64_t)rl.size();
     VMX_TRY(upload(L.rlist, rl.data(), rl.size(), c->stream));
     VMX_TRY(L.S.reserve(8 * (size_t)(la_tot + 1))); VMX_TRY(L.P.reserve(4 * (size_t)(la_tot + 1))); VMX_TRY(L.SA.reserve(4 * (size_t)(la_tot + 1)));
     VMX_TRY(L.chain.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1)));
@@ -108,15 +115,15 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     const double skip_exact = prm->local_skipcost;
     const double skip_mm = prm->mode == VM_MODE_L ? std::min(prm->local_skipcost, 40.0) : prm->local_skipcost;   // mammap_ccs.py:28587
 #ifndef VMX_EMU
-    VMX_HIP(hipFuncSetAttribute((const void*)k_chain_local, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)caps[3] * VMX_LC_BYTES_PER_ANCHOR + 64)));
+    VMX_HIP(hipFuncSetAttribute((const void*)k_chain_local, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)caps[NB - 1] * VMX_LC_BYTES_PER_ANCHOR + 64)));
 #endif
     vmx_fork fk(c);                                                   // independent LDS buckets side by side, largest reads first
-    for (int q = 4; q >= 0; --q) {
+    for (int q = NB; q >= 0; --q) {
         int cnt = (int)lists[q].size();
         if (!cnt) continue;
-        int cap = q < 4 ? caps[q] : 0;
+        int cap = q < NB ? caps[q] : 0;
         size_t shmem = (size_t)cap * VMX_LC_BYTES_PER_ANCHOR + 64;
-        hipLaunchKernelGGL(k_chain_local, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 8)), dim3(64), shmem, fk.next(), L.la_sorted.as<vmx_anchor>(),
+        hipLaunchKernelGGL(k_chain_local, dim3((unsigned)cnt), dim3(64), shmem, fk.next(), L.la_sorted.as<vmx_anchor>(),
                            L.la_off.as<int64_t>(), L.la_cnt.as<int32_t>(), L.ng_total.as<int32_t>(), L.rlist.as<int32_t>() + rl_off[q], cnt, cap, c->tables,
                            L.gap.as<double>(), skip_exact, skip_mm, prm->local_maxdiff, maxgap, prm->mode, L.S.as<double>(), L.P.as<int32_t>(), L.SA.as<int32_t>(),
                            L.score.as<double>(), L.chain.as<vmx_anchor>(), L.chain_len.as<int32_t>(), L.variant.as<int32_t>(), L.status.as<int32_t>());
