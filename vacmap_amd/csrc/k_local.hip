@@ -90,7 +90,7 @@ __device__ __forceinline__ void vmx_isort_i64(int64_t* a, int n) {
     for (int i = 1; i < n; ++i) { int64_t v = a[i]; int j = i - 1; while (j >= 0 && a[j] > v) { a[j + 1] = a[j]; --j; } a[j + 1] = v; }
 }
 
-__global__ void __launch_bounds__(256) k_local_seed(vmx_lseed_args A) {
+__global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_args A) {
     __shared__ uint64_t s_sort[VMX_SORT_LDS];
     __shared__ int s_gq[VMX_GUIDE_LDS];
     __shared__ long long s_gr[VMX_GUIDE_LDS];
@@ -101,7 +101,9 @@ __global__ void __launch_bounds__(256) k_local_seed(vmx_lseed_args A) {
     __shared__ int s_flag;
     __shared__ long long s_tot;
     __shared__ unsigned long long s_min, s_max;
-    __shared__ int s_wmax[4];
+    __shared__ int s_wmax[16];
+    __shared__ int s_next;
+    const int nw = (int)(blockDim.x >> 6);
     const int k = A.k;
     const int nkey = 1 << (2 * k);
     int32_t* HEAD = A.head_pool + (size_t)blockIdx.x * (size_t)nkey;          // all -1 between uses
@@ -115,12 +117,21 @@ __global__ void __launch_bounds__(256) k_local_seed(vmx_lseed_args A) {
     int32_t* DST = A.dst_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;       // by sorted index: start of the diagonal group
     int32_t* GOFF = A.goff_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;
     int32_t* PCNT = A.pcnt_pool + (size_t)blockIdx.x * (size_t)A.pcnt_cap;
+    int32_t* PC2 = A.pc2_pool + (size_t)blockIdx.x * (size_t)A.pcnt_cap;             // per read position: accepted forward | reverse << 16
+    int64_t* STG = A.stg_pool + (size_t)blockIdx.x * 2 * (size_t)A.pcnt_cap;         // per read position: first accepted forward / reverse ref position
     uint64_t* GKEY = A.gkey_pool + (size_t)blockIdx.x * (size_t)A.gkey_cap;
     int32_t* GQg = A.gq_pool + (size_t)blockIdx.x * (size_t)A.gkey_cap;
     int64_t* GRg = A.gr_pool + (size_t)blockIdx.x * (size_t)A.gkey_cap;
     long long vt0 = VMX_CLOCK();
 #define VMX_T(ph) do { if (A.dbg && threadIdx.x == 0) { long long t1_ = VMX_CLOCK(); atomicAdd(&A.dbg[ph], (unsigned long long)(t1_ - vt0)); vt0 = t1_; } } while (0)
-    for (int r = blockIdx.x; r < A.n_reads; r += gridDim.x) {
+    while (true) {
+        // reads are taken longest first from a device-side queue; every thread sees the same queue index, so the exit is uniform
+        if (threadIdx.x == 0) s_next = atomicAdd(A.queue, 1);
+        __syncthreads();
+        const int qi = vmx_uniform_i32(s_next);
+        __syncthreads();
+        if (qi >= A.n_reads) break;
+        const int r = A.order[qi];
         const int ng = A.n_guides_used[r];
         const int64_t a0 = A.aoff[r];
         const uint8_t* RD = A.ocodes + A.roff[r];
@@ -231,44 +242,61 @@ __global__ void __launch_bounds__(256) k_local_seed(vmx_lseed_args A) {
             }
             int npos = (status == 0 && readend > readstart) ? readend - readstart : 0;
             if (npos > A.pcnt_cap) { status = VM_READ_CAPACITY_DEV; npos = 0; }
-            // pass A: accepted hits per read position (any order) -> exclusive offsets
-            long long run = 0;
-            for (int p0 = 0; p0 < npos; p0 += (int)blockDim.x) {
-                const int pi = p0 + (int)threadIdx.x;
-                int cnt = 0;
-                if (pi < npos) {
-                    const int iloc = readstart + pi;
-                    bool ok; const uint32_t fw = vmx_kmer_at(RD, iloc, k, ok);
-                    const uint32_t rv = vmx_kmer_rc(fw, k);
-                    if (ok && fw != rv) {
-                        int b0, b1, c0, c1; vmx_find_closest(GQ, mm, iloc, b0, b1, c0, c1);
-                        long long interval = (long long)b0 + b1 + 500; if (interval > 2000) interval = 2000;
-                        const long long ref1 = GR[c0], ref2 = GR[c1];
-                        long long rgap = (long long)iloc - GQ[c0]; if (rgap < 0) rgap = -rgap;
-                        for (int t = HEAD[fw]; t >= 0; t = NEXT[t]) if (vmx_local_accept(TPOS[t], ref1, ref2, interval, rgap)) ++cnt;
-                        if (iloc > 0) for (int t = HEAD[rv]; t >= 0; t = NEXT[t]) if (vmx_local_accept(TPOS[t], ref1, ref2, interval, rgap)) ++cnt;
-                    }
+            // pass A: accepted hits per read position and strand (any order), no barrier inside the loop so that the waves overlap their
+            // table walks. The first accepted hit of either strand is parked in STG: a position with at most one hit per strand (nearly all)
+            // needs no second walk in pass B.
+            for (int pi = (int)threadIdx.x; pi < npos; pi += (int)blockDim.x) {
+                const int iloc = readstart + pi;
+                int cf = 0, cr = 0; long long ff = 0, fr = 0;
+                bool ok; const uint32_t fw = vmx_kmer_at(RD, iloc, k, ok);
+                const uint32_t rv = vmx_kmer_rc(fw, k);
+                if (ok && fw != rv) {
+                    int b0, b1, c0, c1; vmx_find_closest(GQ, mm, iloc, b0, b1, c0, c1);
+                    long long interval = (long long)b0 + b1 + 500; if (interval > 2000) interval = 2000;
+                    const long long ref1 = GR[c0], ref2 = GR[c1];
+                    long long rgap = (long long)iloc - GQ[c0]; if (rgap < 0) rgap = -rgap;
+                    for (int t = HEAD[fw]; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cf == 0) ff = rl; ++cf; } }
+                    if (iloc > 0) for (int t = HEAD[rv]; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cr == 0) fr = rl; ++cr; } }
                 }
-                int tot; int ex = vmx_block_excl_scan(cnt, s_scan, &tot);
-                if (pi < npos) PCNT[pi] = (int)(run + ex);
-                run += tot;
+                PCNT[pi] = cf + cr;
+                PC2[pi] = (cf > 0xffff ? 0xffff : cf) | ((cr > 0x7fff ? 0x7fff : cr) << 16);
+                STG[2 * pi] = ff; STG[2 * pi + 1] = fr;
+            }
+            __syncthreads();
+            // exclusive offsets: every thread scans a contiguous slice of the per-position counts
+            long long H;
+            {
+                const int chunk = (npos + (int)blockDim.x - 1) / (int)blockDim.x;
+                const int lo = (int)threadIdx.x * chunk < npos ? (int)threadIdx.x * chunk : npos;
+                const int hi = lo + chunk < npos ? lo + chunk : npos;
+                int sum = 0;
+                for (int i = lo; i < hi; ++i) sum += PCNT[i];
+                int tot; int runx = vmx_block_excl_scan(sum, s_scan, &tot);
+                for (int i = lo; i < hi; ++i) { const int cc = PCNT[i]; PCNT[i] = runx; runx += cc; }
+                H = tot;
                 __syncthreads();
             }
             VMX_T(2);
-            long long H = run;
             if (H > A.hit_cap) { status = VM_READ_CAPACITY_DEV; H = 0; npos = 0; }
             // pass B: hits in stream order (read pos asc; forward before reverse; ref pos asc).
             // key = (point + 2^36) << 26 | stream index, point = r - q (forward) or -(r + q) (reverse): ONE key space, like pointdict (Q1)
             for (int pi = (int)threadIdx.x; pi < npos; pi += (int)blockDim.x) {
                 const int iloc = readstart + pi;
+                const int c2 = PC2[pi];
+                const int cf = c2 & 0xffff, cr = c2 >> 16;
+                if (c2 == 0) continue;
+                long long w = PCNT[pi];
+                if (cf <= 1 && cr <= 1) {
+                    if (cf) { const long long rl = STG[2 * pi]; HKEY[w] = ((uint64_t)((rl - iloc) + (1LL << 36)) << 26) | (uint64_t)w; HVAL[w] = (rl << 1) | 1; HQ[w] = iloc; ++w; }
+                    if (cr) { const long long rl = STG[2 * pi + 1]; HKEY[w] = ((uint64_t)(-(rl + iloc) + (1LL << 36)) << 26) | (uint64_t)w; HVAL[w] = (rl << 1); HQ[w] = iloc; }
+                    continue;
+                }
                 bool ok; const uint32_t fw = vmx_kmer_at(RD, iloc, k, ok);
                 const uint32_t rv = vmx_kmer_rc(fw, k);
-                if (!ok || fw == rv) continue;
                 int b0, b1, c0, c1; vmx_find_closest(GQ, mm, iloc, b0, b1, c0, c1);
                 long long interval = (long long)b0 + b1 + 500; if (interval > 2000) interval = 2000;
                 const long long ref1 = GR[c0], ref2 = GR[c1];
                 long long rgap = (long long)iloc - GQ[c0]; if (rgap < 0) rgap = -rgap;
-                long long w = PCNT[pi];
                 const long long wf = w;
                 for (int t = HEAD[fw]; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; }
                 const long long wr = w;
@@ -301,6 +329,7 @@ __global__ void __launch_bounds__(256) k_local_seed(vmx_lseed_args A) {
                 if (res != HKEY) { for (long long i = threadIdx.x; i < H; i += blockDim.x) HKEY[i] = HKEY2[i]; }
                 __syncthreads();
             }
+            int64_t* SV = (int64_t*)HKEY2;           // the sort's second buffer is free again: hit values (refloc << 1 | fwd) in sorted order
             // sorted-order copies of the read positions + start index of every diagonal group (block-wide running max)
             {
                 int carry = -1;
@@ -308,7 +337,9 @@ __global__ void __launch_bounds__(256) k_local_seed(vmx_lseed_args A) {
                     const long long i = i0 + threadIdx.x;
                     int v = -1;
                     if (i < H) {
-                        SQ[i] = HQ[HKEY[i] & ((1ULL << 26) - 1)];
+                        const uint64_t sidx = HKEY[i] & ((1ULL << 26) - 1);
+                        SQ[i] = HQ[sidx];
+                        SV[i] = HVAL[sidx];
                         if (i == 0 || (HKEY[i] >> 26) != (HKEY[i - 1] >> 26)) v = (int)i;
                     }
                     for (int o = 1; o < 64; o <<= 1) { int x = __shfl_up(v, o); if (vmx_lane() >= o) v = x > v ? x : v; }
@@ -318,67 +349,68 @@ __global__ void __launch_bounds__(256) k_local_seed(vmx_lseed_args A) {
                     for (int w2 = 0; w2 < (int)(threadIdx.x >> 6); ++w2) base = s_wmax[w2] > base ? s_wmax[w2] : base;
                     v = v > base ? v : base;
                     if (i < H) DST[i] = v;
-                    int tot = carry; for (int w2 = 0; w2 < 4; ++w2) tot = s_wmax[w2] > tot ? s_wmax[w2] : tot;
+                    int tot = carry; for (int w2 = 0; w2 < nw; ++w2) tot = s_wmax[w2] > tot ? s_wmax[w2] : tot;
                     carry = tot;
                     __syncthreads();
                 }
             }
             VMX_T(3);
-            // --- run-merge (:23232-23344). A RUN = hits of one diagonal whose read positions are <= k apart; the lane whose index starts a
-            // run walks it. pass 0 counts the anchors each run emits (-> offsets), pass 1 writes them with their emission key:
+            // --- run-merge (:23232-23344). A RUN = hits of one diagonal whose read positions are <= k apart. Every thread owns a contiguous
+            // slice of the sorted hits and walks the runs that START in it (to their end, which may lie in a later slice), so the work is
+            // balanced by hit count. pass 0 counts the anchors a thread emits (-> offsets), pass 1 writes them with their emission key:
             //   flush inside a run: key = stream index of the triggering hit; leftover of a run: stream index of the next hit on the same
             //   diagonal (it flushes the leftover, :23248) or, for the last run of a diagonal, 2^26 + stream index of the diagonal's first hit
             //   (appended after all flushes in first-appearance order, :23343).
-            for (int pass = 0; pass < 2; ++pass) {
-                long long base_run = 0;
-                const long long HH = status ? 0 : H;
-                for (long long i0 = 0; i0 < HH; i0 += blockDim.x) {
-                    const long long i = i0 + threadIdx.x;
-                    bool starts = false;
-                    if (i < HH) starts = (i == 0) || (HKEY[i] >> 26) != (HKEY[i - 1] >> 26) || (SQ[i] - SQ[i - 1] > k);
+            {
+                int mybase = 0;
+                for (int pass = 0; pass < 2; ++pass) {
+                    const long long HH = status ? 0 : H;
+                    const long long seg = (HH + blockDim.x - 1) / blockDim.x;
+                    const long long lo = (long long)threadIdx.x * seg < HH ? (long long)threadIdx.x * seg : HH;
+                    const long long hi = lo + seg < HH ? lo + seg : HH;
                     int wr = 0;
-                    if (starts) {
-                        const uint64_t pk = HKEY[i] >> 26;
-                        const int myoff = pass == 1 ? GOFF[i] : 0;
-                        long long cq = 0, cr = 0, cl = 0; int cs = 0;
-                        long long j = i;
-                        for (; j < HH; ++j) {
-                            if (j > i && ((HKEY[j] >> 26) != pk || SQ[j] - SQ[j - 1] > k)) break;
-                            const uint64_t sidx = HKEY[j] & ((1ULL << 26) - 1);
-                            const long long hv = HVAL[sidx];
+                    long long j = lo;
+                    while (j < hi) {
+                        const uint64_t kj = HKEY[j]; const uint64_t pk = kj >> 26;
+                        const int qj = SQ[j];
+                        const bool starts = (j == 0) || (HKEY[j - 1] >> 26) != pk || (qj - SQ[j - 1] > k);
+                        if (!starts) { ++j; continue; }
+                        const long long i = j;
+                        const long long hv0 = SV[j];
+                        long long cq = qj, cr = hv0 >> 1, cl = k; int cs = (hv0 & 1) ? 1 : -1;
+                        int prevq = qj;
+                        for (++j; j < HH; ++j) {
+                            const uint64_t k2 = HKEY[j]; const int q2 = SQ[j];
+                            if ((k2 >> 26) != pk || q2 - prevq > k) break;
+                            const uint64_t sidx = k2 & ((1ULL << 26) - 1);
+                            const long long hv = SV[j];
                             const long long refloc = hv >> 1; const int strand = (hv & 1) ? 1 : -1;
-                            const long long iloc = SQ[j];
-                            if (j == i) { cq = iloc; cr = refloc; cs = strand; cl = k; continue; }
-                            const long long bouns = iloc - (cq + cl) + k;          // > 0 inside a run
+                            const long long bouns = (long long)q2 - (cq + cl) + k;          // > 0 inside a run
                             if (cl + bouns < 20) { if (strand == 1) { cs = 1; cl += bouns; } else { cr = refloc; cs = -1; cl += bouns; } }
                             else {
-                                if (pass == 1) { OUT[n_out + myoff + wr] = vmx_mk_anchor(cq, cr, cs, cl); OKEY[n_out + myoff + wr] = ((uint64_t)g << 28) | sidx; }
+                                if (pass == 1) { OUT[n_out + mybase + wr] = vmx_mk_anchor(cq, cr, cs, cl); OKEY[n_out + mybase + wr] = ((uint64_t)g << 28) | sidx; }
                                 ++wr;
                                 const long long nq = cq + cl;
                                 if (strand == 1) { cr = cr + cl; cs = 1; } else { cr = refloc; cs = -1; }
                                 cq = nq; cl = bouns;
                             }
+                            prevq = q2;
                         }
                         if (pass == 1) {
                             uint64_t ek;
                             if (j < HH && (HKEY[j] >> 26) == pk) ek = ((uint64_t)g << 28) | (HKEY[j] & ((1ULL << 26) - 1));
                             else ek = ((uint64_t)g << 28) | (1ULL << 26) | (HKEY[DST[i]] & ((1ULL << 26) - 1));
-                            OUT[n_out + myoff + wr] = vmx_mk_anchor(cq, cr, cs, cl); OKEY[n_out + myoff + wr] = ek;
+                            OUT[n_out + mybase + wr] = vmx_mk_anchor(cq, cr, cs, cl); OKEY[n_out + mybase + wr] = ek;
                         }
                         ++wr;
                     }
                     if (pass == 0) {
-                        int tot; int ex = vmx_block_excl_scan(wr, s_scan, &tot);
-                        if (starts) GOFF[i] = (int)(base_run + ex);
-                        base_run += tot;
+                        int tot; mybase = vmx_block_excl_scan(wr, s_scan, &tot);
+                        if (threadIdx.x == 0) s_tot = tot;
+                        __syncthreads();
+                        if (n_out + s_tot > out_cap) status = VM_READ_CAPACITY_DEV;
                         __syncthreads();
                     }
-                }
-                if (pass == 0) {
-                    if (threadIdx.x == 0) s_tot = base_run;
-                    __syncthreads();
-                    if (n_out + s_tot > out_cap) status = VM_READ_CAPACITY_DEV;
-                    __syncthreads();
                 }
             }
             if (!status) n_out += (int)s_tot;

@@ -38,13 +38,14 @@ struct vmx_lseed_args {
     const uint8_t* ref; const int64_t* coff; int32_t nseq;  // reference codes + contig offsets (nseq+1)
     const vmx_anchor* guide_rows; const int32_t* guide_len; const int32_t* n_guides_used; const int64_t* aoff;
     int32_t n_reads, k, look_span, read_span;
+    const int32_t* order; int32_t* queue;                   // read indices longest first + the queue head (zero at launch)
     int32_t* head_pool; int32_t* next_pool;                 // HEAD[4^k] (all -1 between uses) / NEXT[tpos_cap] per slot
     int32_t* sq_pool; int32_t* dst_pool;                    // hit_cap ints each
     int64_t* tpos_pool; int64_t tpos_cap;
     unsigned long long* dbg;    // optional phase timers (VMX_DBG=1)
     uint64_t* hkey2_pool;
     uint64_t* hkey_pool; int64_t* hval_pool; int32_t* hq_pool; int32_t* goff_pool; int64_t hit_cap;
-    int32_t* pcnt_pool; int64_t pcnt_cap;
+    int32_t* pcnt_pool; int64_t pcnt_cap; int32_t* pc2_pool; int64_t* stg_pool;
     uint64_t* gkey_pool; int32_t* gq_pool; int64_t* gr_pool; int64_t gkey_cap;
     vmx_anchor* la_rows; uint64_t* la_ekey; vmx_anchor* la_sorted; const int64_t* la_off; int32_t* la_cnt; int32_t* status;
 };
@@ -53,7 +54,10 @@ struct vmx_lseed_args {
 #define VMX_ED_LONG 16384            // patterns longer than this (> 4 passes) go to the 16-wave launch
 #define VMX_EDB_HW 768               // k_ed_banded: half width of the band in rows
 #define VMX_EDB_MAXD 512             // k_ed_banded: |m - n| above this is not eligible (goes to the unbanded kernel)
-#define VMX_SORT_LDS 4096            // uint64 keys sorted in LDS by vmx_block_sort_u64 (larger sorts run in HBM)
+#ifndef VMX_LSEED_WAVES
+#define VMX_LSEED_WAVES 4            // k_local_seed: waves per SIMD the register allocation is held to (2 workgroups of 512 per CU)
+#endif
+#define VMX_SORT_LDS 4096           // uint64 keys sorted in LDS by vmx_block_sort_u64 (larger sorts run in HBM)
 #define VM_READ_FASTPATH_DEV (-21)   // the reference would switch to a *_fast heuristic that is not built yet
 #define VMX_LC_BYTES_PER_ANCHOR 24   // S8 + r4 (relative) + q4 + ls4 + SA4 (LDS bytes per anchor in k_chain_local)
 #define VMX_GC_BYTES_PER_ANCHOR 25   // S8 + r4 (relative) + q4 + ls4 + SA4 + cov1 (LDS bytes per anchor in k_chain_global)

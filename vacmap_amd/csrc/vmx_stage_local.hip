@@ -37,7 +37,21 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     hipLaunchKernelGGL(k_local_prep, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, d_path_rows, d_path_len, d_npaths, d_aoff, d_gscore, (int)n,
                        prm->mode, L.guide_rows.as<vmx_anchor>(), L.guide_len.as<int32_t>(), L.ng_used.as<int32_t>(), L.ng_total.as<int32_t>());
     // scratch per workgroup slot
-    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)c->num_cu * 4));
+    // exactly as many workgroups as the device keeps resident; they pull reads longest-first from a device-side queue
+    const int TPB = 512;
+    int occ = 1;
+#ifndef VMX_EMU
+    VMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_local_seed, TPB, 0));
+    if (occ < 1) occ = 1;
+#endif
+    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)c->num_cu * occ));
+    {
+        std::vector<int32_t> ord((size_t)n + 1);
+        for (int64_t r = 0; r < n; ++r) ord[(size_t)r + 1] = (int32_t)r;
+        std::stable_sort(ord.begin() + 1, ord.end(), [&](int32_t a, int32_t b) { return h_roff[a + 1] - h_roff[a] > h_roff[b + 1] - h_roff[b]; });
+        ord[0] = 0;                                               // [0] = queue head, [1..n] = read order
+        VMX_TRY(upload(L.rorder, ord.data(), ord.size(), c->stream));
+    }
     const int64_t nkey = (int64_t)1 << (2 * k);
     int64_t tpos_cap = 2 * Lmax + 5 * 14000 + 65536;
     int64_t hit_cap = 1; while (hit_cap < 4 * (Lmax + 14000)) hit_cap <<= 1;
@@ -63,10 +77,13 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     A.ocodes = d_ocodes; A.roff = d_roff; A.ref = ix.codes; A.coff = ix.coff; A.nseq = ix.nseq;
     A.guide_rows = L.guide_rows.as<vmx_anchor>(); A.guide_len = L.guide_len.as<int32_t>(); A.n_guides_used = L.ng_used.as<int32_t>(); A.aoff = d_aoff;
     A.n_reads = (int)n; A.k = k; A.look_span = 7000; A.read_span = 7000;   // :23094, :23190
+    A.queue = L.rorder.as<int32_t>(); A.order = L.rorder.as<int32_t>() + 1;
     A.head_pool = L.cnt.as<int32_t>(); A.next_pool = L.cur.as<int32_t>(); A.sq_pool = L.sq.as<int32_t>(); A.dst_pool = L.dst.as<int32_t>(); A.tpos_pool = L.tpos.as<int64_t>(); A.tpos_cap = tpos_cap;
     VMX_TRY(L.hkey2.reserve(8 * (size_t)G * (size_t)hit_cap));
     A.hkey2_pool = L.hkey2.as<uint64_t>();
     A.hkey_pool = L.hkey.as<uint64_t>(); A.hval_pool = L.hval.as<int64_t>(); A.hq_pool = L.hq.as<int32_t>(); A.goff_pool = L.goff.as<int32_t>(); A.hit_cap = hit_cap;
+    VMX_TRY(L.pc2.reserve(4 * (size_t)G * (size_t)pcnt_cap)); VMX_TRY(L.stg.reserve(16 * (size_t)G * (size_t)pcnt_cap));
+    A.pc2_pool = L.pc2.as<int32_t>(); A.stg_pool = L.stg.as<int64_t>();
     A.pcnt_pool = L.pcnt.as<int32_t>(); A.pcnt_cap = pcnt_cap; A.gkey_pool = L.gkey.as<uint64_t>(); A.gq_pool = L.gq.as<int32_t>(); A.gr_pool = L.gr.as<int64_t>();
     A.gkey_cap = gkey_cap;
     A.la_rows = L.la_rows.as<vmx_anchor>(); A.la_ekey = L.la_ekey.as<uint64_t>(); A.la_sorted = L.la_sorted.as<vmx_anchor>(); A.la_off = L.la_off.as<int64_t>();
@@ -74,7 +91,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     A.dbg = nullptr;
     static const bool dbg_on = getenv("VMX_DBG") != nullptr;
     if (dbg_on) { VMX_TRY(L.dbg.reserve(64)); VMX_HIP(hipMemsetAsync(L.dbg.p, 0, 64, c->stream)); A.dbg = L.dbg.as<unsigned long long>(); }
-    hipLaunchKernelGGL(k_local_seed, dim3((unsigned)G), dim3(256), 0, c->stream, A);
+    hipLaunchKernelGGL(k_local_seed, dim3((unsigned)G), dim3(TPB), 0, c->stream, A);
     if (dbg_on) { unsigned long long h[8]; VMX_TRY(download(h, L.dbg.p, 8, c->stream)); VMX_HIP(hipStreamSynchronize(c->stream));
                   fprintf(stderr, "k_local_seed phase ticks (100MHz, summed over blocks): guide+windows %llu table %llu passA %llu passB+sort %llu merge %llu finalsort %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]); }
     // sizing sync #2: local anchor counts decide the LDS bucket of every read in the local chain DP
