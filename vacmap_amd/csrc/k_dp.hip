@@ -98,9 +98,11 @@ __global__ void __launch_bounds__(64) k_extend(const uint8_t* __restrict__ tcode
 // bit3 extE1, bit4 extE2, bit5 extF1, bit6 extF2). lane = target row inside a 64-row stripe, step = anti-diagonal of the
 // stripe. Per step a lane needs H/E1/E2 of the cell above (the lane above, one step earlier: three DPP wave_shr:1 moves) and the
 // query base of its column (handed down the lanes the same way); lane 0 takes the row above the stripe from bnd[] (H, E1, E2 of
-// the previous stripe's last row) and its query base from a 64-column register chunk (v_readlane), refilled with one coalesced
-// load per 64 steps — nothing on the per-step path waits for memory. Traceback bytes are stored as
-// tb[(stripe*(ql+63) + step)*64 + lane]: one coalesced 64-byte line per step.
+// the previous stripe's last row) and its query base from 64-column chunk registers that rotate one lane per step (wave_rol:1), so
+// the value lane 0 needs rides into the wave_shr:1 move as its old operand; chunks are refilled with one coalesced load per 64
+// steps and lane 63's outputs leave through a rotating register FIFO flushed once per 64 columns — nothing on the per-step path
+// waits for memory. Chunks in which every lane is inside its row run without the per-step activity test.
+// Traceback bytes are stored as tb[(stripe*(ql+63) + step)*64 + lane]: one coalesced 64-byte line per step.
 __device__ __forceinline__ int vmx_gap_open_row(int i, int o1, int e1, int o2, int e2) {   // H(i,0) = H(0,i), i >= 1
     int a = -(o1 + i * e1), b = -(o2 + i * e2);
     return a > b ? a : b;
@@ -132,60 +134,75 @@ __global__ void __launch_bounds__(64) k_gapfill_fill(const uint8_t* __restrict__
         int32_t* bE2 = bE1 + (ql + 1);
         const int W = ql + 63;
         const int nstr = trivial ? 0 : (tl + 63) >> 6;
+        int outH = 0;
         for (int s = 0; s < nstr; ++s) {
             const int i = s * 64 + lane + 1;
-            const bool row_active = i <= tl;
-            const int ti = row_active ? (int)T[i - 1] : 4;
+            const int ti = i <= tl ? (int)T[i - 1] : 4;       // rows past tl (last stripe) compute unused cells into the stripe's padding
             int Hleft = vmx_gap_open_row(i, o1, e1, o2, e2);
             int F1 = VMX_NEG, F2 = VMX_NEG;
             int Hdiag = (i - 1 == 0) ? 0 : vmx_gap_open_row(i - 1, o1, e1, o2, e2);
-            int outH = 0, outE1 = VMX_NEG, outE2 = VMX_NEG;
+            int outE1 = VMX_NEG, outE2 = VMX_NEG;
+            outH = 0;
             int qc_cur = 4;
-            uint8_t* tbs = tb + (size_t)s * (size_t)W * 64;
+            int sH = 0, sE1 = 0, sE2 = 0;                    // lane 63's H/E1/E2 of the last 64 steps, newest in lane 0 (rotating register FIFO)
+            const bool store_bnd = s + 1 < nstr;              // the row below this stripe exists
+            uint8_t* tbs = tb + (size_t)s * (size_t)W * 64 + lane;
+            // one step of the stripe: hand-off from the lane above (lane 0: head of the rotating chunk registers), the cell, lane 63's FIFO
+#define VMX_GF_STEP(PRED)                                                                                             \
+            {                                                                                                         \
+                const int upH = vmx_shr1_in(outH, cH), upE1 = vmx_shr1_in(outE1, cE1), upE2 = vmx_shr1_in(outE2, cE2); \
+                qc_cur = vmx_shr1_in(qc_cur, qchunk);                                                                 \
+                cH = vmx_rol1(cH); cE1 = vmx_rol1(cE1); cE2 = vmx_rol1(cE2); qchunk = vmx_rol1(qchunk);               \
+                if (PRED) {                                                                                           \
+                    int b = 0;                                                                                        \
+                    const int a1 = upH - o1, a2 = upH - o2;                                                           \
+                    if (upE1 > a1) b |= 8;                                                                            \
+                    if (upE2 > a2) b |= 16;                                                                           \
+                    const int e1v = (a1 > upE1 ? a1 : upE1) - e1, e2v = (a2 > upE2 ? a2 : upE2) - e2;                 \
+                    const int c1 = Hleft - o1, c2 = Hleft - o2;                                                       \
+                    if (F1 > c1) b |= 32;                                                                             \
+                    if (F2 > c2) b |= 64;                                                                             \
+                    F1 = (c1 > F1 ? c1 : F1) - e1; F2 = (c2 > F2 ? c2 : F2) - e2;                                     \
+                    int h = Hdiag + ((ti == qc_cur && ti < 4) ? match : mismatch);                                    \
+                    int src = 0;                                                                                      \
+                    if (e1v > h) { h = e1v; src = 1; }                                                                \
+                    if (e2v > h) { h = e2v; src = 2; }                                                                \
+                    if (F1 > h) { h = F1; src = 3; }                                                                  \
+                    if (F2 > h) { h = F2; src = 4; }                                                                  \
+                    tbs[(size_t)t * 64] = (uint8_t)(b | src);                                                         \
+                    Hdiag = upH; Hleft = h;                                                                           \
+                    outH = h; outE1 = e1v; outE2 = e2v;                                                               \
+                }                                                                                                     \
+                if (store_bnd) {                                                                                      \
+                    sH = vmx_ror1(lane == 63 ? outH : sH); sE1 = vmx_ror1(lane == 63 ? outE1 : sE1); sE2 = vmx_ror1(lane == 63 ? outE2 : sE2); \
+                    const int j63 = t - 62;                   /* column lane 63 just finished */                      \
+                    if (j63 >= 1 && j63 <= ql && ((j63 & 63) == 0 || j63 == ql)) {                                    \
+                        const int col = j63 - lane;           /* lane k of the FIFO holds column j63 - k */           \
+                        if (col > ((j63 - 1) & ~63)) { bH[col] = sH; bE1[col] = sE1; bE2[col] = sE2; }                \
+                    }                                                                                                 \
+                }                                                                                                     \
+            }
             for (int t0 = 0; t0 < W; t0 += 64) {
                 // 64-column chunks for lane 0: query bases Q[t0 .. t0+63] and the boundary row entries of columns j = t0+1 .. t0+64
                 const int jj = t0 + lane;
-                const int qchunk = jj < ql ? (int)Q[jj] : 4;
+                int qchunk = jj < ql ? (int)Q[jj] : 4;
                 int cH = 0, cE1 = VMX_NEG, cE2 = VMX_NEG;
                 if (jj + 1 <= ql) {
                     if (s == 0) cH = vmx_gap_open_row(jj + 1, o1, e1, o2, e2);
                     else { cH = bH[jj + 1]; cE1 = bE1[jj + 1]; cE2 = bE2[jj + 1]; }
                 }
-                int tend = W - t0; if (tend > 64) tend = 64;
-                for (int tt = 0; tt < tend; ++tt) {
-                    const int t = t0 + tt;
-                    int upH = vmx_shr1(outH), upE1 = vmx_shr1(outE1), upE2 = vmx_shr1(outE2);
-                    const int q_up = vmx_shr1(qc_cur);
-                    const int q0 = vmx_readlane(qchunk, tt);
-                    const int h0 = vmx_readlane(cH, tt), e10 = vmx_readlane(cE1, tt), e20 = vmx_readlane(cE2, tt);
-                    if (lane == 0) { upH = h0; upE1 = e10; upE2 = e20; qc_cur = q0; } else qc_cur = q_up;
-                    const int j = t - lane + 1;
-                    if (row_active && j >= 1 && j <= ql) {
-                        int b = 0;
-                        const int a1 = upH - o1, a2 = upH - o2;
-                        if (upE1 > a1) b |= 8;
-                        if (upE2 > a2) b |= 16;
-                        const int e1v = (a1 > upE1 ? a1 : upE1) - e1, e2v = (a2 > upE2 ? a2 : upE2) - e2;
-                        const int c1 = Hleft - o1, c2 = Hleft - o2;
-                        if (F1 > c1) b |= 32;
-                        if (F2 > c2) b |= 64;
-                        F1 = (c1 > F1 ? c1 : F1) - e1; F2 = (c2 > F2 ? c2 : F2) - e2;
-                        int h = Hdiag + ((ti == qc_cur && ti < 4) ? match : mismatch);
-                        int src = 0;
-                        if (e1v > h) { h = e1v; src = 1; }
-                        if (e2v > h) { h = e2v; src = 2; }
-                        if (F1 > h) { h = F1; src = 3; }
-                        if (F2 > h) { h = F2; src = 4; }
-                        tbs[(size_t)t * 64 + lane] = (uint8_t)(b | src);
-                        Hdiag = upH; Hleft = h;
-                        outH = h; outE1 = e1v; outE2 = e2v;
-                        if (lane == 63) { bH[j] = h; bE1[j] = e1v; bE2[j] = e2v; }
-                        if (i == tl && j == ql) out_score[p] = h;
-                    }
+                if (t0 >= 64 && t0 + 64 <= ql) {
+                    // every lane is inside its row for the whole chunk: no per-step activity test
+                    for (int tt = 0; tt < 64; ++tt) { const int t = t0 + tt; VMX_GF_STEP(true) }
+                } else {
+                    int tend = W - t0; if (tend > 64) tend = 64;
+                    for (int tt = 0; tt < tend; ++tt) { const int t = t0 + tt; const int j = t - lane + 1; VMX_GF_STEP(j >= 1 && j <= ql) }
                 }
             }
-            __syncthreads();   // bnd[] written by lane 63 is read (in 64-column chunks) by the next stripe
+#undef VMX_GF_STEP
+            __syncthreads();   // bnd[] written by this stripe is read (in 64-column chunks) by the next one
         }
+        if (!trivial && lane == ((tl - 1) & 63)) out_score[p] = outH;     // H(tl, ql): the last cell that lane computed
     }
 }
 

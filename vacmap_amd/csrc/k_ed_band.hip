@@ -17,12 +17,6 @@
 #include "vmx_device.h"
 #include "vmx_kernels.h"
 
-#ifdef VMX_EMU
-__device__ __forceinline__ int vmx_ror1(int v) { return __shfl(v, (vmx_lane() + 63) & 63); }
-#else
-__device__ __forceinline__ int vmx_ror1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x13C, 0xf, 0xf, false); }   // wave_ror:1
-#endif
-
 __global__ void __launch_bounds__(64) k_ed_banded(const uint8_t* __restrict__ qcodes, const int64_t* __restrict__ q_off,
                                                   const uint8_t* __restrict__ tcodes, const int64_t* __restrict__ t_off,
                                                   const int32_t* __restrict__ order, const int32_t* __restrict__ range,

@@ -30,6 +30,18 @@ __device__ __forceinline__ int vmx_readlane(int v, int l) { return __builtin_amd
 #define VMX_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
 #define VMX_CLOCK() ((long long)wall_clock64())
 #endif
+// systolic hand-off used by the DP kernels: vmx_shr1_in(v, in): lane i <- lane i-1 of v, lane 0 <- its own `in` (wave_shr:1 leaves
+// lane 0's destination untouched, so `in` rides in as the old value: one v_mov_dpp, no select);
+// vmx_rol1: lane i <- lane i+1, lane 63 <- lane 0; vmx_ror1: lane i <- lane i-1, lane 0 <- lane 63
+#ifdef VMX_EMU
+__device__ __forceinline__ int vmx_shr1_in(int v, int in) { int e = __shfl_up(v, 1); return vmx_lane() == 0 ? in : e; }
+__device__ __forceinline__ int vmx_rol1(int v) { return __shfl(v, (vmx_lane() + 1) & 63); }
+__device__ __forceinline__ int vmx_ror1(int v) { return __shfl(v, (vmx_lane() + 63) & 63); }
+#else
+__device__ __forceinline__ int vmx_shr1_in(int v, int in) { return __builtin_amdgcn_update_dpp(in, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int vmx_rol1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x134, 0xf, 0xf, false); }
+__device__ __forceinline__ int vmx_ror1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x13C, 0xf, 0xf, false); }
+#endif
 // value known to be identical in every lane: hand it to the compiler as a scalar (v_readfirstlane_b32)
 #ifdef VMX_EMU
 __device__ __forceinline__ int vmx_uniform_i32(int v) { return v; }
