@@ -135,6 +135,8 @@ int vmo_align_batch(const vmo_index*, const vmo_params* p, int64_t n_reads, cons
 /* DP problem recorder: when enabled, every k_cigar_global / k_extend / edit distance call made
  * inside vmo_extend appends (kind, tl, ql) to a log (golden V5) */
 const char* vmo_last_error(void);
+/* how often GC-fast / LC-fast / LC-mm-fast ran in this process since the last reset (tests: which paths a case exercised) */
+void vmo_fast_counters(int64_t out[3], int reset);
 
 #ifdef __cplusplus
 }

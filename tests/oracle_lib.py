@@ -278,6 +278,13 @@ def table(which):
     return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ty)), shape=(n,)).copy()
 
 
+def fast_counters(reset=False):
+    """(GC-fast, LC-fast, LC-mm-fast) call counts of this process since the last reset"""
+    out = (C.c_int64 * 3)()
+    lib().vmo_fast_counters(out, 1 if reset else 0)
+    return tuple(out)
+
+
 def dplog(fn):
     """run fn() with DP-call logging on this thread; returns (fn result, [(kind, target, query)])"""
     L = lib()

@@ -32,6 +32,29 @@ def build_case(args):
         c1[5000:8000] = elem
         contigs = [c0, c1]
     src = contigs
+    if args.dense:
+        # repeat-dense case for the *_fast chain variants: a 6 kb element in 64 copies (1 % divergence) and a period-23 tandem array of
+        # 9.2 kb; reads are drawn from the copies / the array (+ flanks) only
+        rng = np.random.default_rng(args.seed + 400)
+        c0 = contigs[0].copy()
+        elem = synth.make_reference([6000], seed=args.seed + 401)[0]
+        starts = []
+        ncopy = 64
+        step = (len(c0) - 20000) // (ncopy + 1)
+        for t in range(ncopy):
+            p = 5000 + t * step
+            c0[p:p + 6000] = synth.mutate(elem, 0.01, rng, ratio=(1, 0, 0))[:6000]
+            starts.append(p)
+        unit = synth.make_reference([23], seed=args.seed + 402)[0]
+        tp = 5000 + ncopy * step + 2000
+        c0[tp:tp + 23 * 400] = np.tile(unit, 400)
+        # a diverged second copy of the array with its flanks on the other contig: reads through the array get a secondary chain,
+        # i.e. more than one guide (LC-mm) on top of the dense local anchors
+        c1 = contigs[1].copy()
+        seg = synth.mutate(c0[tp - 3000:tp + 9200 + 3000], 0.004, rng, ratio=(1, 0, 0))
+        c1[40000:40000 + len(seg)] = seg
+        contigs = [c0, c1]
+        src = [c0[p - 1500:p + 7500] for p in starts[:6]] + [c0[tp - 4000:tp + 9200 + 4000]] * 3
     if args.chimera:
         pass
     if args.sv:
@@ -51,6 +74,16 @@ def build_case(args):
     else:
         reads = synth.sample_reads(src, args.n, mean_len=args.mean or 15000, err=0.10, seed=args.seed + 1, shape='ont')
         k = 15
+    if args.dense:     # two-locus reads through the tandem array: more than one guide chain + dense local anchors (LC-mm and its _fast twin)
+        rng = np.random.default_rng(args.seed + 410)
+        err = 0.005 if args.mode == 'L' else 0.10
+        c0 = contigs[0]
+        eq = np.concatenate([[0], np.cumsum(c0[23:] == c0[:-23])])
+        tp = int(np.flatnonzero(eq[500:] - eq[:-500] == 500)[0])    # first position of the period-23 array
+        for i in range(3):
+            a = synth.mutate(c0[max(0, tp - 2500 - 500 * i):tp + 9200 + 2500], err, rng)
+            b = synth.mutate(contigs[1][20000 + 9000 * i:26000 + 9000 * i], err, rng)
+            reads.append(('twolocus%d' % i, np.concatenate([a, b] if i != 1 else [b, a]), {}))
     if args.chimera:   # join pairs of reads (translocation-like chimeras) and add pure-random reads (unmapped)
         rng = np.random.default_rng(args.seed + 200)
         out = []
@@ -83,7 +116,7 @@ def worker(job):
         ora_t = [(names[t[1]], t[2], t[3], t[4], t[5], t[6], t[7], t[8]) for t in recs]
         ok = (st == 0) == (st2 == 0) and ref_t == ora_t
         res.append((i, ok, st, st2, ref_t, ora_t, t1 - t0, repr(getattr(ctx, 'last_exc', None)) if st < 0 else ''))
-    return res
+    return res, O.fast_counters()
 
 
 if __name__ == '__main__':
@@ -92,13 +125,17 @@ if __name__ == '__main__':
     ap.add_argument('--reflen', type=int, default=300000); ap.add_argument('--sv', action='store_true')
     ap.add_argument('--procs', type=int, default=8); ap.add_argument('--mean', type=int, default=0)
     ap.add_argument('-v', action='store_true'); ap.add_argument('--repeats', action='store_true'); ap.add_argument('--chimera', action='store_true')
+    ap.add_argument('--dense', action='store_true')
     args = ap.parse_args()
     names, contigs, reads, k = build_case(args)
     import multiprocessing as mp
     chunks = np.linspace(0, len(reads), args.procs + 1).astype(int)
     jobs = [(args.mode, names, contigs, reads, k, int(chunks[i]), int(chunks[i + 1])) for i in range(args.procs) if chunks[i + 1] > chunks[i]]
     with mp.Pool(len(jobs)) as pool:
-        out = [r for rs in pool.map(worker, jobs) for r in rs]
+        got = pool.map(worker, jobs)
+    out = [r for rs, _ in got for r in rs]
+    fc = np.sum([c for _, c in got], axis=0)
+    print('oracle fast-path calls (GC-fast, LC-fast, LC-mm-fast):', fc.tolist())
     nok = sum(1 for r in out if r[1]); nrec = sum(len(r[4]) for r in out); nskip = sum(1 for r in out if r[2] < 0)
     nun = sum(1 for r in out if r[2] == 0 and not r[4])
     print('mode %s sv=%s reads=%d identical=%d ref_records=%d ref_raised=%d unmapped=%d ref_s/read=%.2f' % (

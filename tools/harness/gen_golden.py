@@ -56,6 +56,13 @@ def run_case(cid, mode, names, contigs, reads, k, arrays, meta):
             arrays[key + '_v2_S'] = np.asarray(S, dtype=np.float64)
             arrays[key + '_v2_P'] = np.asarray(P, dtype=np.int64)
             arrays[key + '_v2_Sarg'] = np.asarray(SA, dtype=np.int64)
+            if g == -1 or len(srt) / L > 5:      # the reference switches to GC-fast (:23570, :23577): keep its raw arrays too
+                gf, Sf, Pf, SAf = m.get_optimal_chain_sortbyreadpos_forSV_inv_test_merged_fine_list_d_fast_all(
+                    srt, kmersize=k, skipcost=ctx.option['golbal_skipcost'], maxdiff=ctx.option['golbal_maxdiff'], maxgap=1000)
+                rec['v2f_gmax'] = int(gf)
+                arrays[key + '_v2f_S'] = np.asarray(Sf, dtype=np.float64)
+                arrays[key + '_v2f_P'] = np.asarray(Pf, dtype=np.int64)
+                arrays[key + '_v2f_Sarg'] = np.asarray(SAf, dtype=np.int64)
         mapq, scores, path, factor, rpl = m.decode_hit(al, ctx.index2contig, seq, L, ctx.contig2start, k, ctx.contig2seq,
                                                      skipcost=(ctx.option['golbal_skipcost'],) * 2,
                                                      maxdiff=(ctx.option['golbal_maxdiff'],) * 2, maxgap=200, check_num=100,
@@ -75,16 +82,32 @@ def run_case(cid, mode, names, contigs, reads, k, arrays, meta):
             return f
         for n in names_lc:
             setattr(m, n, mk(n))
+        names_fast = [n + '_fast' for n in names_lc]
+        orig_fast = {n: getattr(m, n) for n in names_fast}
+
+        def mkf(n):
+            def f(one_mapinfo, **kw):
+                cap['fast'] = names_fast.index(n)
+                return orig_fast[n](one_mapinfo, **kw)
+            return f
+        for n in names_fast:
+            setattr(m, n, mkf(n))
         refrun.DPLOG = []
         st, one = ctx.align(rname, seq)
         dplog = refrun.DPLOG; refrun.DPLOG = None
         for n in names_lc:
             setattr(m, n, orig[n])
+        for n in names_fast:
+            setattr(m, n, orig_fast[n])
+        rec['v3_fast'] = cap.get('fast', -1)
         rec['v6_status'] = st
         rec['v6_records'] = [[t[1], t[2], int(t[3]), int(t[4]), int(t[5]), int(t[6]), int(t[7]), t[8]] for t in one]
         if 'raw' in cap:
             rec['v3_variant'] = cap['variant']; rec['v3_kw'] = cap['kw']
-            arrays[key + '_v3_raw'] = cap['raw'].astype(np.int64).reshape(-1, 4)
+            raw = cap['raw'].astype(np.int64).reshape(-1, 4)
+            rec['v3_raw_n'] = int(len(raw)); rec['v3_raw_crc'] = zlib.crc32(np.ascontiguousarray(raw).tobytes())
+            if len(raw) <= 20000:        # dense cases: only the count and a checksum of the raw local anchors travel
+                arrays[key + '_v3_raw'] = raw
             if scores != 0:
                 need_rev = scores < 0
                 rd = seq if not need_rev else synth.tostr(synth.revcomp(np.frombuffer(seq.encode(), np.uint8)))
@@ -137,6 +160,31 @@ def main():
     tandem = synth.mutate(c0[59000:63500], 0.08, rng)
     rD.append(('tandem0', tandem))
     run_case('D', 'H', ['chrA', 'chrB'], [synth.tostr(c0), synth.tostr(contigs[1])], [(n, synth.tostr(s)) for n, s in rD], 15, arrays, meta)
+    # cases E (mode L) and F (mode H): repeat-dense reads that drive the *_fast chain variants (G3, L5): a 2.5 kb element in 64 copies
+    # (GC-fast: more than 5 anchors per read base), a period-29 tandem array with a diverged second copy on the other contig
+    # (more than one guide chain + dense local anchors: LC-mm-fast) and a period-23 array without a copy (LC-fast)
+    rng = np.random.default_rng(120)
+    e0, e1 = synth.make_reference([420000, 60000], seed=121)
+    elem = synth.make_reference([2500], seed=122)[0]
+    step = (len(e0) - 40000) // 65
+    starts = []
+    for t in range(64):
+        p = 3000 + t * step
+        e0[p:p + 2500] = synth.mutate(elem, 0.01, rng, ratio=(1, 0, 0))[:2500]
+        starts.append(p)
+    t1 = len(e0) - 32000
+    e0[t1:t1 + 29 * 240] = np.tile(synth.make_reference([29], seed=123)[0], 240)
+    t2 = len(e0) - 16000
+    e0[t2:t2 + 23 * 400] = np.tile(synth.make_reference([23], seed=124)[0], 400)
+    seg = synth.mutate(e0[t1 - 2500:t1 + 6960 + 2500], 0.004, rng, ratio=(1, 0, 0))
+    e1[20000:20000 + len(seg)] = seg
+    cE = [synth.tostr(e0), synth.tostr(e1)]
+    rE = [('elem%d' % i, synth.mutate(e0[starts[7 * i + 3] - 300 + 100 * i:starts[7 * i + 3] + 2900], 0.005, rng)) for i in range(3)]
+    run_case('E', 'L', ['chrA', 'chrB'], cE, [(n, synth.tostr(x)) for n, x in rE], 19, arrays, meta)
+    rF = [('dupArray0', synth.mutate(e0[t1 - 1500:t1 + 6960 + 1500], 0.08, rng)),
+          ('dupArray1', synth.revcomp(synth.mutate(e0[t1 + 6960 - 2500:t1 + 6960 + 2500], 0.08, rng))),
+          ('soloArray0', synth.mutate(e0[t2 - 1500:t2 + 9200 + 1500], 0.08, rng))]
+    run_case('F', 'H', ['chrA', 'chrB'], cE, [(n, synth.tostr(x)) for n, x in rF], 15, arrays, meta)
     # V7: the reference's own known-answer tests for nm_from_cigar (tests/test_nm_from_cigar.py) — evaluate the inputs of each
     # test through the reference function and store (cigar, query, ref, expected NM)
     of = refrun.refload.load_output_functions()
