@@ -47,3 +47,7 @@ def test_emu_local(ctx, oracle, golden):
 def test_emu_align_end_to_end(ctx, oracle, golden):
     KC.check_align_golden(ctx, oracle, golden, cases=['B'], reads=[0, 1, 2])
     KC.check_align_golden(ctx, oracle, golden, cases=['D'])
+
+
+def test_emu_chain_global_fast(ctx, oracle):
+    KC.check_chain_global_fast_synth(ctx, oracle, seed=31, n_reads=2, L=140, per_pos=6)

@@ -75,3 +75,12 @@ def test_align_random_vs_oracle(ctx, oracle):
         assert [(int(s) == 0) for s in status] == [(int(s) == 0) for s in ost]
         assert recs == orecs, 'mode %s: records differ from the oracle' % mode
         assert stats['n_records'] == len(orecs) and stats['n_records'] >= n
+
+
+def test_chain_fast_variants(ctx, oracle, golden):
+    """G3 / L5: GC-fast on synthetic dense anchor sets and on golden case E; LC-fast and LC-mm-fast on golden case F"""
+    KC.check_chain_global_fast_synth(ctx, oracle, seed=41, n_reads=6, L=400, per_pos=8)
+    KC.check_chain_global_fast_synth(ctx, oracle, seed=42, n_reads=3, L=900, per_pos=6, mode='L')
+    KC.check_chain_global_golden(ctx, oracle, golden, cases=['E', 'F'])
+    KC.check_local_golden(ctx, oracle, golden, cases=['E', 'F'])
+    KC.check_align_golden(ctx, oracle, golden, cases=['E', 'F'])

@@ -49,7 +49,7 @@ struct vmx_batch_bufs {
     // extend stage
     DevBuf er, coff3, soff2, segA, st, en, segA_s, st_s, en_s, segprob, dup, desc[2], rcount, oflow, probread, tl, ql, toff, qoff, tpool, qpool;
     DevBuf edout, carry, ext3, dpsz[4], dpoff[4], dptab, tb, bnd, run, cig, ciglen, dpscore, rec, blob, bloboff, reccoff, recclen, dupd, totals;
-    DevBuf raw, codes, off, order, qrange, scanpart, scanoff;
+    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp;
     void release() { DevBuf* p = (DevBuf*)this; for (size_t i = 0; i < sizeof(*this) / sizeof(DevBuf); ++i) p[i].release(); }
 };
 static vmx_batch_bufs* batch_bufs(vm_ctx* c) { if (!c->bbufs) c->bbufs = new vmx_batch_bufs(); return c->bbufs; }
@@ -152,7 +152,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     for (int64_t r = 0; r < n; ++r) {
         int64_t m = h_aoff[r + 1] - h_aoff[r]; const int64_t L = h_roff[r + 1] - h_roff[r];
         if (m <= 2) continue;                                             // :23986 unmapped
-        if ((double)m / (double)L > 5.0) continue;                        // fast_enable (:23570): GC-fast not built yet -> gmax stays -1
+        if ((double)m / (double)L > 5.0) continue;                        // fast_enable (:23570): gmax stays -1 -> k_chain_global_fast below
         int bk = NB; for (int q = 0; q < NB; ++q) if (m <= caps[q]) { bk = q; break; }
         lists[bk].push_back((int32_t)r);
     }
@@ -176,6 +176,12 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
                                B.P.as<int32_t>(), B.SA.as<int32_t>(), B.cov.as<uint8_t>(), B.gmax.as<int64_t>(), B.opc.as<int64_t>());
         }
         fk.join();
+        // G3: reads left at gmax = -1 (more than 5 anchors per base, :23570, or GC-exact's opcount bail-out, :24914) take GC-fast.
+        // One wave per read; reads that do not need it return at once.
+        VMX_TRY(B.si.reserve(4 * (size_t)(tot + 1))); VMX_TRY(B.tg.reserve(8 * (size_t)(tot + 1))); VMX_TRY(B.cntp.reserve(4 * (size_t)(total_bases + 50 * n + 64)));
+        hipLaunchKernelGGL(k_chain_global_fast, dim3((unsigned)n), dim3(64), 0, c->stream, B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(), (int)n, d_roff, c->tables,
+                           B.gap.as<double>(), prm->global_skipcost, prm->global_maxdiff, 1000, B.S.as<double>(), B.P.as<int32_t>(), B.SA.as<int32_t>(), B.cov.as<uint8_t>(),
+                           B.si.as<int32_t>(), B.tg.as<int64_t>(), B.cntp.as<int32_t>(), B.gmax.as<int64_t>(), (int32_t*)nullptr);
     }
     VMX_TRY(B.scr.reserve((size_t)stt + 64)); VMX_TRY(upload(B.soff, soff.data(), (size_t)n + 1, c->stream));
     VMX_TRY(B.res.reserve(16 * (size_t)(n + 2) + 64));
@@ -345,15 +351,13 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));
     VMX_HIP(hipStreamSynchronize(c->stream));
     VMX_HIP(hipGetLastError());
-    bool any_fast = false;
     for (int64_t r = 0; r < n; ++r) {
         int stt2 = er[r].status;
-        if (h_gmax[r] == -1 && (h_aoff[r + 1] - h_aoff[r]) > 2) { stt2 = VM_READ_FASTPATH_DEV; any_fast = true; }   // needs GC-fast
+        if (h_gmax[r] == -2 && (h_aoff[r + 1] - h_aoff[r]) > 2) stt2 = VM_READ_RAISED;     // GC-fast: the reference raises on this read (k_chain_fast.hip)
         if (status_per_read) status_per_read[r] = stt2;
         if (stt2 != 0) { st.n_failed++; continue; }
         if (er[r].nrec == 0) st.n_unmapped++;
     }
-    (void)any_fast;   // such reads never reach the local stage (their global score is 0), so they own no packed records
     for (int64_t i = 0; i < nr; ++i) { st.aligned_bases += (*recs)[i].q_en - (*recs)[i].q_st; st.cigar_bytes += (*recs)[i].cigar_len; }
     *n_recs = nr; st.n_records = nr;
     float ms = 0;

@@ -345,7 +345,18 @@ int vm_chain_global_batch(vm_ctx* c, const vm_params* prm, int kmersize, int64_t
                            d_rl.as<int32_t>() + rl_off[k], cnt, cap, c->tables, d_gap.as<double>(), prm->global_skipcost, prm->global_maxdiff,
                            1000, d_S.as<double>(), d_P.as<int32_t>(), d_SA.as<int32_t>(), d_cov.as<uint8_t>(), d_gmax.as<int64_t>(), d_opc.as<int64_t>());
     }
-    // TODO(G3): reads with gmax == -1 (fast_enable or bail-out) go through GC-fast; until that kernel lands they are reported
+    // G3: reads left at gmax = -1 (fast_enable or the opcount bail-out) go through GC-fast (k_chain_fast.hip)
+    if (n) {
+        DevBuf &d_si = c->b[20], &d_tg = c->b[21], &d_cnt = c->b[22], &d_roff = c->b[23], &d_ran = c->b[24];
+        VMX_TRY(d_ran.reserve(4 * (size_t)(n + 1))); VMX_HIP(hipMemsetAsync(d_ran.p, 0, 4 * (size_t)n, c->stream));
+        std::vector<int64_t> roff((size_t)n + 1, 0);
+        for (int64_t r = 0; r < n; ++r) roff[(size_t)r + 1] = roff[(size_t)r] + readlens[r];
+        VMX_TRY(upload(d_roff, roff.data(), (size_t)n + 1, c->stream));
+        VMX_TRY(d_si.reserve(4 * (size_t)(tot + 1))); VMX_TRY(d_tg.reserve(8 * (size_t)(tot + 1))); VMX_TRY(d_cnt.reserve(4 * (size_t)(roff[(size_t)n] + 50 * n + 64)));
+        hipLaunchKernelGGL(k_chain_global_fast, dim3((unsigned)n), dim3(64), 0, c->stream, d_sorted.as<vmx_anchor>(), d_aoff.as<int64_t>(), (int)n, d_roff.as<int64_t>(),
+                           c->tables, d_gap.as<double>(), prm->global_skipcost, prm->global_maxdiff, 1000, d_S.as<double>(), d_P.as<int32_t>(), d_SA.as<int32_t>(),
+                           d_cov.as<uint8_t>(), d_si.as<int32_t>(), d_tg.as<int64_t>(), d_cnt.as<int32_t>(), d_gmax.as<int64_t>(), d_ran.as<int32_t>());
+    }
     VMX_TRY(d_scr.reserve((size_t)st + 64));
     VMX_TRY(upload(d_soff, soff.data(), (size_t)n + 1, c->stream));
     VMX_TRY(d_res.reserve((sizeof(double) + 2 * sizeof(int32_t)) * (size_t)(n + 1) + 64));
@@ -375,7 +386,8 @@ int vm_chain_global_batch(vm_ctx* c, const vm_params* prm, int kmersize, int64_t
     VMX_HIP(hipGetLastError());
     if (want_raw) for (int64_t i = 0; i < tot; ++i) { out->P[i] = hP[i]; out->S_arg[i] = hSA[i]; }
     int64_t npaths = 0, nrows = 0;
-    for (int64_t r = 0; r < n; ++r) { npaths += h_np[r]; for (int p = 0; p < h_np[r]; ++p) nrows += h_plen[aoff[r] + p]; out->fast_used[r] = fastflag[r] || out->gmax[r] == -1; }
+    for (int64_t r = 0; r < n; ++r) { npaths += h_np[r]; for (int p = 0; p < h_np[r]; ++p) nrows += h_plen[aoff[r] + p]; }
+    if (n) { VMX_TRY(download(out->fast_used, c->b[24].p, (size_t)n, c->stream)); VMX_HIP(hipStreamSynchronize(c->stream)); }
     out->read_path_off = host_alloc<int64_t>((size_t)n + 1); out->path_off = host_alloc<int64_t>((size_t)npaths + 1);
     out->path_anchors = host_alloc<int64_t>((size_t)nrows * 4);
     int64_t pi = 0, ro = 0;

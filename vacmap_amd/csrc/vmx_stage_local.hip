@@ -13,6 +13,10 @@ using namespace vmx;
 __global__ void k_local_prep(const vmx_anchor* path_rows, const int32_t* path_len, const int32_t* n_paths, const int64_t* aoff, const double* gscore,
                              int n_reads, int mode, vmx_anchor* guide_rows, int32_t* guide_len, int32_t* n_guides_used, int32_t* n_guides_total);
 __global__ void k_local_seed(vmx_lseed_args A);
+__global__ void k_chain_local_fast(const vmx_anchor* anchors, const int64_t* la_off, const int32_t* la_cnt, const int32_t* n_guides_total, int n_reads,
+                                   const int64_t* roff, vmx_tables tab, const double* gapcost_list, double skip_exact, double skip_mm, int maxdiff, int maxgap,
+                                   int mode, double* S_pool, int32_t* P_pool, int32_t* SA_pool, int32_t* si_pool, int64_t* t_pool, int32_t* cnt_pool,
+                                   double* out_score, vmx_anchor* out_chain, int32_t* out_len, int32_t* out_variant, int32_t* status);
 __global__ void k_chain_local(const vmx_anchor* anchors, const int64_t* la_off, const int32_t* la_cnt, const int32_t* n_guides_total,
                               const int32_t* rlist, int nlist, int lds_cap, vmx_tables tab, const double* gapcost_list, double skip_exact,
                               double skip_mm, int maxdiff, int maxgap, int mode, double* S_pool, int32_t* P_pool, int32_t* SA_pool, double* out_score,
@@ -31,7 +35,12 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     int64_t Lmax = 1;
     L.h_la_off.assign((size_t)n + 1, 0);
     for (int64_t r = 0; r < n; ++r) { int64_t len = h_roff[r + 1] - h_roff[r]; Lmax = std::max(Lmax, len); L.h_la_off[r + 1] = L.h_la_off[r] + 2 * len + 4096; }
-    const int64_t la_tot = L.h_la_off[n];
+    // the regular slot of a read holds 2*len + 4096 local anchors; reads that overflow it (tandem arrays: > 10 anchors per base) are
+    // re-run below with slots carved from an overflow area at the end of the pools
+    const int64_t la_regular = L.h_la_off[n];
+    const int64_t la_overflow = std::max<int64_t>((int64_t)4 << 20, 64 * Lmax);
+    const int64_t la_tot = la_regular + la_overflow;
+    L.la_pool_rows = la_tot;
     VMX_TRY(L.guide_rows.reserve(sizeof(vmx_anchor) * (size_t)(tot_anchors + 1))); VMX_TRY(L.guide_len.reserve(4 * (size_t)(tot_anchors + 1)));
     VMX_TRY(L.ng_used.reserve(4 * (size_t)(n + 1))); VMX_TRY(L.ng_total.reserve(4 * (size_t)(n + 1)));
     hipLaunchKernelGGL(k_local_prep, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, d_path_rows, d_path_len, d_npaths, d_aoff, d_gscore, (int)n,
@@ -57,48 +66,86 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     int64_t hit_cap = 1; while (hit_cap < 4 * (Lmax + 14000)) hit_cap <<= 1;
     int64_t pcnt_cap = Lmax + 16;
     int64_t gkey_cap = 1; { int64_t mx = 1; for (int64_t r = 0; r < n; ++r) mx = std::max(mx, h_aoff[r + 1] - h_aoff[r]); while (gkey_cap < mx) gkey_cap <<= 1; }
-    {   // HEAD must be all -1 when the kernel starts; the kernel restores that itself, so only fresh memory needs the fill
-        const size_t need = 4 * (size_t)G * (size_t)nkey;
-        const void* before = L.cnt.p; const size_t cap_before = L.cnt.cap;
-        VMX_TRY(L.cnt.reserve(need));
-        if (L.cnt.p != before || L.cnt.cap != cap_before) VMX_HIP(hipMemsetAsync(L.cnt.p, 0xff, L.cnt.cap, c->stream));
-    }
-    VMX_TRY(L.cur.reserve(4 * (size_t)G * (size_t)tpos_cap));
-    VMX_TRY(L.sq.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.dst.reserve(4 * (size_t)G * (size_t)hit_cap));
-    VMX_TRY(L.tpos.reserve(8 * (size_t)G * (size_t)tpos_cap)); VMX_TRY(L.hkey.reserve(8 * (size_t)G * (size_t)hit_cap));
-    VMX_TRY(L.hval.reserve(8 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.hq.reserve(4 * (size_t)G * (size_t)hit_cap));
-    VMX_TRY(L.goff.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.pcnt.reserve(4 * (size_t)G * (size_t)pcnt_cap));
-    VMX_TRY(L.gkey.reserve(8 * (size_t)G * (size_t)gkey_cap)); VMX_TRY(L.gq.reserve(4 * (size_t)G * (size_t)gkey_cap)); VMX_TRY(L.gr.reserve(8 * (size_t)G * (size_t)gkey_cap));
-    VMX_TRY(L.la_rows.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1))); VMX_TRY(L.la_ekey.reserve(8 * (size_t)(la_tot + 1)));
-    VMX_TRY(L.la_sorted.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1)));
-    VMX_TRY(upload(L.la_off, L.h_la_off.data(), (size_t)n + 1, c->stream));
-    VMX_TRY(L.la_cnt.reserve(4 * (size_t)(n + 1))); VMX_TRY(L.status.reserve(4 * (size_t)(n + 1)));
     vmx_lseed_args A;
-    A.ocodes = d_ocodes; A.roff = d_roff; A.ref = ix.codes; A.coff = ix.coff; A.nseq = ix.nseq;
-    A.guide_rows = L.guide_rows.as<vmx_anchor>(); A.guide_len = L.guide_len.as<int32_t>(); A.n_guides_used = L.ng_used.as<int32_t>(); A.aoff = d_aoff;
-    A.n_reads = (int)n; A.k = k; A.look_span = 7000; A.read_span = 7000;   // :23094, :23190
-    A.queue = L.rorder.as<int32_t>(); A.order = L.rorder.as<int32_t>() + 1;
-    A.head_pool = L.cnt.as<int32_t>(); A.next_pool = L.cur.as<int32_t>(); A.sq_pool = L.sq.as<int32_t>(); A.dst_pool = L.dst.as<int32_t>(); A.tpos_pool = L.tpos.as<int64_t>(); A.tpos_cap = tpos_cap;
-    VMX_TRY(L.hkey2.reserve(8 * (size_t)G * (size_t)hit_cap));
-    A.hkey2_pool = L.hkey2.as<uint64_t>();
-    A.hkey_pool = L.hkey.as<uint64_t>(); A.hval_pool = L.hval.as<int64_t>(); A.hq_pool = L.hq.as<int32_t>(); A.goff_pool = L.goff.as<int32_t>(); A.hit_cap = hit_cap;
-    VMX_TRY(L.pc2.reserve(4 * (size_t)G * (size_t)pcnt_cap)); VMX_TRY(L.stg.reserve(16 * (size_t)G * (size_t)pcnt_cap));
-    A.pc2_pool = L.pc2.as<int32_t>(); A.stg_pool = L.stg.as<int64_t>();
-    A.pcnt_pool = L.pcnt.as<int32_t>(); A.pcnt_cap = pcnt_cap; A.gkey_pool = L.gkey.as<uint64_t>(); A.gq_pool = L.gq.as<int32_t>(); A.gr_pool = L.gr.as<int64_t>();
-    A.gkey_cap = gkey_cap;
-    A.la_rows = L.la_rows.as<vmx_anchor>(); A.la_ekey = L.la_ekey.as<uint64_t>(); A.la_sorted = L.la_sorted.as<vmx_anchor>(); A.la_off = L.la_off.as<int64_t>();
-    A.la_cnt = L.la_cnt.as<int32_t>(); A.status = L.status.as<int32_t>();
-    A.dbg = nullptr;
     static const bool dbg_on = getenv("VMX_DBG") != nullptr;
-    if (dbg_on) { VMX_TRY(L.dbg.reserve(64)); VMX_HIP(hipMemsetAsync(L.dbg.p, 0, 64, c->stream)); A.dbg = L.dbg.as<unsigned long long>(); }
-    hipLaunchKernelGGL(k_local_seed, dim3((unsigned)G), dim3(TPB), 0, c->stream, A);
-    if (dbg_on) { unsigned long long h[8]; VMX_TRY(download(h, L.dbg.p, 8, c->stream)); VMX_HIP(hipStreamSynchronize(c->stream));
-                  fprintf(stderr, "k_local_seed phase ticks (100MHz, summed over blocks): guide+windows %llu table %llu passA %llu passB+sort %llu merge %llu finalsort %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]); }
+    // one launch over the reads listed in L.rorder[1 .. cnt] with `slots` workgroups and per-slot hit pools of `hcap` entries
+    auto run_seed = [&](int cnt, int slots, int64_t hcap) -> int {
+        const int64_t hit_cap = hcap;
+        const int G = slots;
+        {   // HEAD must be all -1 when the kernel starts; the kernel restores that itself, so only fresh memory needs the fill
+            const size_t need = 4 * (size_t)G * (size_t)nkey;
+            const void* before = L.cnt.p; const size_t cap_before = L.cnt.cap;
+            VMX_TRY(L.cnt.reserve(need));
+            if (L.cnt.p != before || L.cnt.cap != cap_before) VMX_HIP(hipMemsetAsync(L.cnt.p, 0xff, L.cnt.cap, c->stream));
+        }
+        VMX_TRY(L.cur.reserve(4 * (size_t)G * (size_t)tpos_cap));
+        VMX_TRY(L.sq.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.dst.reserve(4 * (size_t)G * (size_t)hit_cap));
+        VMX_TRY(L.tpos.reserve(8 * (size_t)G * (size_t)tpos_cap)); VMX_TRY(L.hkey.reserve(8 * (size_t)G * (size_t)hit_cap));
+        VMX_TRY(L.hval.reserve(8 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.hq.reserve(4 * (size_t)G * (size_t)hit_cap));
+        VMX_TRY(L.goff.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.pcnt.reserve(4 * (size_t)G * (size_t)pcnt_cap));
+        VMX_TRY(L.gkey.reserve(8 * (size_t)G * (size_t)gkey_cap)); VMX_TRY(L.gq.reserve(4 * (size_t)G * (size_t)gkey_cap)); VMX_TRY(L.gr.reserve(8 * (size_t)G * (size_t)gkey_cap));
+        VMX_TRY(L.la_rows.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1))); VMX_TRY(L.la_ekey.reserve(8 * (size_t)(la_tot + 1)));
+        VMX_TRY(L.la_sorted.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1)));
+        VMX_TRY(upload(L.la_off, L.h_la_off.data(), (size_t)n + 1, c->stream));
+        VMX_TRY(L.la_cnt.reserve(4 * (size_t)(n + 1))); VMX_TRY(L.status.reserve(4 * (size_t)(n + 1)));
+        A.ocodes = d_ocodes; A.roff = d_roff; A.ref = ix.codes; A.coff = ix.coff; A.nseq = ix.nseq;
+        A.guide_rows = L.guide_rows.as<vmx_anchor>(); A.guide_len = L.guide_len.as<int32_t>(); A.n_guides_used = L.ng_used.as<int32_t>(); A.aoff = d_aoff;
+        A.n_reads = cnt; A.k = k; A.look_span = 7000; A.read_span = 7000;   // :23094, :23190
+        A.queue = L.rorder.as<int32_t>(); A.order = L.rorder.as<int32_t>() + 1;
+        A.head_pool = L.cnt.as<int32_t>(); A.next_pool = L.cur.as<int32_t>(); A.sq_pool = L.sq.as<int32_t>(); A.dst_pool = L.dst.as<int32_t>(); A.tpos_pool = L.tpos.as<int64_t>(); A.tpos_cap = tpos_cap;
+        VMX_TRY(L.hkey2.reserve(8 * (size_t)G * (size_t)hit_cap));
+        A.hkey2_pool = L.hkey2.as<uint64_t>();
+        A.hkey_pool = L.hkey.as<uint64_t>(); A.hval_pool = L.hval.as<int64_t>(); A.hq_pool = L.hq.as<int32_t>(); A.goff_pool = L.goff.as<int32_t>(); A.hit_cap = hit_cap;
+        VMX_TRY(L.pc2.reserve(4 * (size_t)G * (size_t)pcnt_cap)); VMX_TRY(L.stg.reserve(16 * (size_t)G * (size_t)pcnt_cap));
+        A.pc2_pool = L.pc2.as<int32_t>(); A.stg_pool = L.stg.as<int64_t>();
+        A.pcnt_pool = L.pcnt.as<int32_t>(); A.pcnt_cap = pcnt_cap; A.gkey_pool = L.gkey.as<uint64_t>(); A.gq_pool = L.gq.as<int32_t>(); A.gr_pool = L.gr.as<int64_t>();
+        A.gkey_cap = gkey_cap;
+        A.la_rows = L.la_rows.as<vmx_anchor>(); A.la_ekey = L.la_ekey.as<uint64_t>(); A.la_sorted = L.la_sorted.as<vmx_anchor>(); A.la_off = L.la_off.as<int64_t>();
+        A.la_cnt = L.la_cnt.as<int32_t>(); A.status = L.status.as<int32_t>();
+        A.dbg = nullptr;
+        if (dbg_on) { VMX_TRY(L.dbg.reserve(64)); VMX_HIP(hipMemsetAsync(L.dbg.p, 0, 64, c->stream)); A.dbg = L.dbg.as<unsigned long long>(); }
+        hipLaunchKernelGGL(k_local_seed, dim3((unsigned)G), dim3(TPB), 0, c->stream, A);
+        if (dbg_on) { unsigned long long h[8]; VMX_TRY(download(h, L.dbg.p, 8, c->stream)); VMX_HIP(hipStreamSynchronize(c->stream));
+                      fprintf(stderr, "k_local_seed phase ticks (100MHz, summed over blocks): guide+windows %llu table %llu passA %llu passB+sort %llu merge %llu finalsort %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]); }
+        return 0;
+    };
+    A.la_slot_len = 1;
+    VMX_TRY(run_seed((int)n, G, hit_cap));
     // sizing sync #2: local anchor counts decide the LDS bucket of every read in the local chain DP
     L.h_la_cnt.resize((size_t)n);
     VMX_TRY(download(L.h_la_cnt.data(), L.la_cnt.p, (size_t)n, c->stream));
+    std::vector<int32_t> h_lstatus((size_t)n);
+    VMX_TRY(download(h_lstatus.data(), L.status.p, (size_t)n, c->stream));
     VMX_HIP(hipStreamSynchronize(c->stream));
     VMX_HIP(hipGetLastError());
+    {   // capacity retries: 8x, 64x, 512x the regular slot / hit pool, as long as the overflow area lasts
+        int64_t ovf_used = 0;
+        for (int round = 1; round <= 3; ++round) {
+            std::vector<int32_t> ord(1, 0);
+            const int64_t mult = (int64_t)1 << (3 * round);
+            int64_t lmax_f = 1;
+            for (int64_t r = 0; r < n; ++r) {
+                if (h_lstatus[r] != VM_READ_CAPACITY_DEV) continue;
+                const int64_t len = h_roff[r + 1] - h_roff[r];
+                const int64_t want = mult * (2 * len + 4096);
+                if (ovf_used + want > la_overflow) continue;                 // stays a capacity failure
+                L.h_la_off[r] = la_regular + ovf_used; ovf_used += want;
+                ord.push_back((int32_t)r); lmax_f = std::max(lmax_f, len);
+            }
+            const int cnt = (int)ord.size() - 1;
+            if (!cnt) break;
+            VMX_TRY(upload(L.rorder, ord.data(), ord.size(), c->stream));
+            VMX_TRY(upload(L.la_off, L.h_la_off.data(), (size_t)n + 1, c->stream));
+            int64_t hcap = 1; while (hcap < mult * 4 * (lmax_f + 14000)) hcap <<= 1;
+            if (hcap > ((int64_t)1 << 26)) hcap = (int64_t)1 << 26;          // stream indices are 26-bit
+            A.la_slot_len = mult;                                            // slot length = mult * (2*len + 4096) for the listed reads
+            VMX_TRY(run_seed(cnt, std::min(cnt, 8), hcap));
+            VMX_TRY(download(L.h_la_cnt.data(), L.la_cnt.p, (size_t)n, c->stream));
+            VMX_TRY(download(h_lstatus.data(), L.status.p, (size_t)n, c->stream));
+            VMX_HIP(hipStreamSynchronize(c->stream));
+            VMX_HIP(hipGetLastError());
+        }
+    }
     // LC DP
     const HostTables& T = host_tables();
     std::vector<double> gap(64, 0.0);
@@ -146,6 +193,13 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
                            L.score.as<double>(), L.chain.as<vmx_anchor>(), L.chain_len.as<int32_t>(), L.variant.as<int32_t>(), L.status.as<int32_t>());
     }
     fk.join();
+    // L5: reads whose LC launch hit the opcount switch (:27380 / :28333) take the *_fast twin. One wave per read; all other reads
+    // return at once.
+    VMX_TRY(L.si.reserve(4 * (size_t)(la_tot + 1))); VMX_TRY(L.tg.reserve(8 * (size_t)(la_tot + 1))); VMX_TRY(L.cntp.reserve(4 * (size_t)(h_roff[n] + 50 * n + 64)));
+    hipLaunchKernelGGL(k_chain_local_fast, dim3((unsigned)n), dim3(64), 0, c->stream, L.la_sorted.as<vmx_anchor>(), L.la_off.as<int64_t>(), L.la_cnt.as<int32_t>(),
+                       L.ng_total.as<int32_t>(), (int)n, d_roff, c->tables, L.gap.as<double>(), skip_exact, skip_mm, prm->local_maxdiff, maxgap, prm->mode,
+                       L.S.as<double>(), L.P.as<int32_t>(), L.SA.as<int32_t>(), L.si.as<int32_t>(), L.tg.as<int64_t>(), L.cntp.as<int32_t>(),
+                       L.score.as<double>(), L.chain.as<vmx_anchor>(), L.chain_len.as<int32_t>(), L.variant.as<int32_t>(), L.status.as<int32_t>());
     return 0;
 }
 
@@ -189,7 +243,7 @@ int vm_local_chain_batch(vm_ctx* c, const vm_index* mi, const vm_params* prm, in
     VMX_TRY(vmx_local_stage(c, ix, prm, n, codes.as<uint8_t>(), roff.as<int64_t>(), h_roff, d_rows.as<vmx_anchor>(), d_plen.as<int32_t>(), d_np.as<int32_t>(),
                             d_aoff.as<int64_t>(), h_aoff, d_gs.as<double>(), L));
     // download
-    const int64_t la_tot = L.h_la_off[n];
+    const int64_t la_tot = L.la_pool_rows;
     std::vector<int32_t> clen((size_t)n); std::vector<vmx_anchor> chain((size_t)la_tot), sorted((size_t)la_tot);
     out->status = (int32_t*)malloc(4 * (size_t)std::max<int64_t>(n, 1)); out->variant = (int32_t*)malloc(4 * (size_t)std::max<int64_t>(n, 1));
     out->score = (double*)malloc(8 * (size_t)std::max<int64_t>(n, 1));
