@@ -83,8 +83,10 @@ static inline void gap_geometry(const Anchor& ai, const Anchor& aj, int64_t& rea
 }
 
 // GC-exact :24828-25031. A sorted by q (stable). Returns g_max_index or -1 (bail-out, :24914).
+// rmode = true: the mode-R body (mammap_noprefercloser.py:22839-23057): no coverage terms; a non-co-linear step costs the fixed
+// skipcost, remembered in fixed_penatly / pre_penatly and refunded once the chain has continued co-linearly for more than skipcost bases.
 int64_t chain_global_exact(const std::vector<Anchor>& A, int kmersize, double oskipcost, int omaxdiff, int maxgap,
-                           std::vector<double>& S, std::vector<int64_t>& P, std::vector<int64_t>& S_arg, int64_t* opcount_out) {
+                           std::vector<double>& S, std::vector<int64_t>& P, std::vector<int64_t>& S_arg, int64_t* opcount_out, bool rmode) {
     const Tables& T = tables();
     const int64_t extra_size = (int64_t)T.extra.size() - 1;
     const int64_t repeat_weight = 20;
@@ -95,8 +97,9 @@ int64_t chain_global_exact(const std::vector<Anchor>& A, int kmersize, double os
     std::vector<int64_t> cov(A[n - 1].q + 1, 0);
     for (int64_t i = 0; i < n; ++i) cov[A[i].q] = std::min(cov[A[i].q] + 1, repeat_weight);
     int64_t prereadloc = A[0].q;
-    double skipcost = oskipcost + (double)cov[A[0].q];
-    int64_t maxdiff = std::max<int64_t>(omaxdiff - cov[A[0].q], 10);
+    double skipcost = rmode ? oskipcost : oskipcost + (double)cov[A[0].q];
+    int64_t maxdiff = rmode ? omaxdiff : std::max<int64_t>(omaxdiff - cov[A[0].q], 10);
+    std::vector<double> pre_pen(rmode ? n : 0, 0.0), fixed_pen(rmode ? n : 0, 0.0);
     int64_t testspace_en = 1;
     S_arg[0] = 0;
     S[0] = (double)A[0].l; P[0] = NOPRE;
@@ -112,8 +115,10 @@ int64_t chain_global_exact(const std::vector<Anchor>& A, int kmersize, double os
                 sarg_insert(S_arg.data(), loc, k);
             }
             testspace_en = i;
-            skipcost = oskipcost + (double)cov[A[i].q];
-            maxdiff = std::max<int64_t>(omaxdiff - cov[A[i].q], 10);
+            if (!rmode) {
+                skipcost = oskipcost + (double)cov[A[i].q];
+                maxdiff = std::max<int64_t>(omaxdiff - cov[A[i].q], 10);
+            }
             prereadloc = A[i].q;
         }
         const double li = (double)A[i].l;
@@ -125,6 +130,22 @@ int64_t chain_global_exact(const std::vector<Anchor>& A, int kmersize, double os
                 gap_geometry(A[i], A[j], readgap, refgap, bonus);
                 int64_t gapcost = std::llabs(readgap - refgap);
                 double test;
+                if (rmode) {                                            // mammap_noprefercloser.py:22973-23001
+                    if (A[i].s == A[j].s && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
+                        test = S[j] + (double)bonus - gapcost_list[gapcost];
+                        if (fixed_pen[j] < 0 && (fixed_pen[j] + (double)bonus) >= 0) test += pre_pen[j];
+                        if (test > max_scores) {
+                            max_scores = test; pre_index = j;
+                            if (fixed_pen[j] < 0 && (fixed_pen[j] + (double)bonus) < 0) { fixed_pen[i] = fixed_pen[j] + (double)bonus; pre_pen[i] = pre_pen[j]; }
+                            else { fixed_pen[i] = 0; pre_pen[i] = 0; }
+                        }
+                    } else {
+                        const double tmp_penalty = skipcost;
+                        test = S[j] + (double)bonus - tmp_penalty;
+                        if (test > max_scores) { max_scores = test; pre_index = j; fixed_pen[i] = -tmp_penalty + (double)bonus; pre_pen[i] = tmp_penalty; }
+                    }
+                    continue;
+                }
                 if (A[i].s == A[j].s && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
                     test = S[j] + (double)bonus - gapcost_list[gapcost];
                 } else {
@@ -146,13 +167,13 @@ int64_t chain_global_exact(const std::vector<Anchor>& A, int kmersize, double os
 }
 
 int64_t chain_global_fast(const std::vector<Anchor>& A, int kmersize, double oskipcost, int omaxdiff, int maxgap,
-                          std::vector<double>& S, std::vector<int64_t>& P, std::vector<int64_t>& S_arg);  // vmo_chain_fast.cc
+                          std::vector<double>& S, std::vector<int64_t>& P, std::vector<int64_t>& S_arg, bool rmode);  // vmo_chain_fast.cc
 
 // hit2work_1 :23491-23734 + decode_hit :23981-24020 (A = output of map(), unsorted)
 int decode_hit(std::vector<Anchor> A, int64_t readlen, int kmersize, const vmo_params& prm, ChainSet& out) {
     out = ChainSet();
     out.need_reverse = strand_flip(A, readlen);
-    if (A.size() <= 2) return 0;                                   // :23986
+    if (A.size() <= 2) return prm.mode == VMO_MODE_R ? -1 : 0;     // :23986; mode R returns an unbound `factor` here (mammap_noprefercloser.py:24417): the read raises
     const int mode = prm.mode;
     const double accept = (mode == VMO_MODE_H) ? 60.0 : 40.0;      // :23650 / mammap_ccs.py:23649
     const int64_t sec_min_span = (mode == VMO_MODE_R) ? 100 : 50;  // :23519 / mammap_noprefercloser.py:23949
@@ -163,10 +184,10 @@ int decode_hit(std::vector<Anchor> A, int64_t readlen, int kmersize, const vmo_p
     std::vector<double> S; std::vector<int64_t> P, S_arg;
     int64_t g_max_index = 0;
     if (!fast_enable)
-        g_max_index = chain_global_exact(A, kmersize, prm.global_skipcost, prm.global_maxdiff, 1000, S, P, S_arg, nullptr);
+        g_max_index = chain_global_exact(A, kmersize, prm.global_skipcost, prm.global_maxdiff, 1000, S, P, S_arg, nullptr, mode == VMO_MODE_R);
     if (fast_enable || g_max_index == -1) {
         fast_enable = true;
-        g_max_index = chain_global_fast(A, kmersize, prm.global_skipcost, prm.global_maxdiff, 1000, S, P, S_arg);
+        g_max_index = chain_global_fast(A, kmersize, prm.global_skipcost, prm.global_maxdiff, 1000, S, P, S_arg, mode == VMO_MODE_R);
         if (g_max_index < 0) return -2;
     }
     out.fast_used = fast_enable;
@@ -295,13 +316,12 @@ int vmo_strand_flip(int64_t* a, int64_t n, int64_t readlen) {
 
 int64_t vmo_chain_global_raw(const int64_t* a, int64_t n, int mode, int kmersize, double skipcost, int maxdiff, int maxgap,
                              int which, double* S, int64_t* P, int64_t* S_arg) {
-    (void)mode;
     std::vector<Anchor> v(n);
     for (int64_t i = 0; i < n; ++i) v[i] = Anchor{a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]};
     std::vector<double> s; std::vector<int64_t> p, sa;
     int64_t g;
-    if (which == 0) g = chain_global_exact(v, kmersize, skipcost, maxdiff, maxgap, s, p, sa, nullptr);
-    else g = chain_global_fast(v, kmersize, skipcost, maxdiff, maxgap, s, p, sa);
+    if (which == 0) g = chain_global_exact(v, kmersize, skipcost, maxdiff, maxgap, s, p, sa, nullptr, mode == VMO_MODE_R);
+    else g = chain_global_fast(v, kmersize, skipcost, maxdiff, maxgap, s, p, sa, mode == VMO_MODE_R);
     for (int64_t i = 0; i < n && i < (int64_t)s.size(); ++i) { S[i] = s[i]; P[i] = p[i]; S_arg[i] = sa[i]; }
     return g;
 }

@@ -85,7 +85,8 @@ static inline bool geometry(const Anchor& ai, const Anchor& aj, bool lc, int64_t
     return true;
 }
 
-// the shared skeleton. variant 0 = GC-fast, 1 = LC-fast, 2 = LC-mm-fast. Returns g_max_index, or < -1 on the two misbehaviours above.
+// the shared skeleton. variant 0 = GC-fast, 1 = LC-fast, 2 = LC-mm-fast, 3 = GC-fast of mode R (mammap_noprefercloser.py:23059-23417: no
+// coverage terms, fixed skipcost with refund). Returns g_max_index, or < -1 on the two misbehaviours above.
 static int64_t fast_dp(const std::vector<Anchor>& A, int variant, int kmersize, double oskipcost, int omaxdiff, int maxgap, int mode,
                        std::vector<double>& S, std::vector<int64_t>& P, std::vector<int64_t>& S_arg_i, double* g_max_out) {
     const Tables& T = tables();
@@ -94,8 +95,10 @@ static int64_t fast_dp(const std::vector<Anchor>& A, int variant, int kmersize, 
     const int64_t repeat_weight = 20;
     const int64_t fast_t = 5;
     const int64_t n = (int64_t)A.size();
-    const bool lc = variant != 0;
-    g_fast_calls[variant].fetch_add(1);
+    const bool lc = variant == 1 || variant == 2;
+    const bool gcr = variant == 3;
+    g_fast_calls[gcr ? 0 : variant].fetch_add(1);
+    std::vector<double> pre_pen(gcr ? A.size() : 0, 0.0), fixed_pen(gcr ? A.size() : 0, 0.0);
     std::vector<double> gapcost_list(omaxdiff + 1, 0.0);
     for (int g = 1; g <= omaxdiff; ++g) {
         if (!lc || g <= 10) gapcost_list[g] = (0.01 * kmersize * g + 0.5 * T.log2int[g]);     // :25052 / :26956
@@ -144,7 +147,7 @@ static int64_t fast_dp(const std::vector<Anchor>& A, int variant, int kmersize, 
         const int64_t pos_i = lc ? A[i].q + A[i].l : A[i].q;
         if (prereadloc < pos_i) {
             if (!insert_pending(i)) return -5;
-            if (!lc) {
+            if (!lc && !gcr) {
                 skipcost = oskipcost + (double)cov[A[i].q];                                     // :25151
                 maxdiff = std::max<int64_t>(omaxdiff - cov[A[i].q], 10);                        // :25152
             }
@@ -163,6 +166,22 @@ static int64_t fast_dp(const std::vector<Anchor>& A, int variant, int kmersize, 
                 if (!geometry(A[i], A[j], lc, readgap, refgap, bonus)) { hang = true; return; }
                 int64_t gapcost = std::llabs(readgap - refgap);
                 double test;
+                if (gcr) {
+                    if (A[i].s == A[j].s && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
+                        test = S[j] + (double)bonus - gapcost_list[gapcost];
+                        if (fixed_pen[j] < 0 && (fixed_pen[j] + (double)bonus) >= 0) test += pre_pen[j];
+                        if (test > max_scores) {
+                            max_scores = test; pre_index = j;
+                            if (fixed_pen[j] < 0 && (fixed_pen[j] + (double)bonus) < 0) { fixed_pen[i] = fixed_pen[j] + (double)bonus; pre_pen[i] = pre_pen[j]; }
+                            else { fixed_pen[i] = 0; pre_pen[i] = 0; }
+                        }
+                    } else {
+                        const double tmp_penalty = skipcost;
+                        test = S[j] + (double)bonus - tmp_penalty;
+                        if (test > max_scores) { max_scores = test; pre_index = j; fixed_pen[i] = -tmp_penalty + (double)bonus; pre_pen[i] = tmp_penalty; }
+                    }
+                    return;
+                }
                 if (A[i].s == A[j].s && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
                     if (!lc) test = S[j] + (double)bonus - gapcost_list[gapcost];
                     else test = S[j] + (double)bonus - gapcost_list[gapcost] - (double)readgapcost[readgap];
@@ -207,8 +226,8 @@ static int64_t fast_dp(const std::vector<Anchor>& A, int variant, int kmersize, 
 
 // G3 :25033-25339. A sorted by q (stable). S_arg comes back ordered by (int(S), diagonal key) — hit2work_1 peels in that order (:25339).
 int64_t chain_global_fast(const std::vector<Anchor>& A, int kmersize, double oskipcost, int omaxdiff, int maxgap,
-                          std::vector<double>& S, std::vector<int64_t>& P, std::vector<int64_t>& S_arg) {
-    const int64_t g = fast_dp(A, 0, kmersize, oskipcost, omaxdiff, maxgap, 0, S, P, S_arg, nullptr);
+                          std::vector<double>& S, std::vector<int64_t>& P, std::vector<int64_t>& S_arg, bool rmode) {
+    const int64_t g = fast_dp(A, rmode ? 3 : 0, kmersize, oskipcost, omaxdiff, maxgap, 0, S, P, S_arg, nullptr);
     if (g < 0) { set_error(g == -4 ? "GC-fast: reference does not terminate on this input" : "GC-fast: integer score outside S_i_count"); return -2; }
     return g;
 }

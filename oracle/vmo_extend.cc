@@ -254,7 +254,8 @@ static void merge_conjacent_alignment(const vmo_index* mi, std::vector<Seg>& al)
 }
 
 // :24226-24312. returns <0 where the reference raises (assert / IndexError on an emptied segment)
-static int fix_simple_inv(const vmo_index* mi, std::vector<Seg>& al, const std::string& read) {
+// rmode: mode R keeps an older body (mammap_noprefercloser.py:17155-17200) whose `refen_0 > refst_1` branch compares nothing and changes nothing
+static int fix_simple_inv(const vmo_index* mi, std::vector<Seg>& al, const std::string& read, bool rmode) {
     if (al.size() > 2) {
         int64_t iloc = 0;
         while (iloc + 2 < (int64_t)al.size()) {
@@ -274,6 +275,7 @@ static int fix_simple_inv(const vmo_index* mi, std::vector<Seg>& al, const std::
                     if (refst_2 - refen_0 == refen_1 - refst_1 && readst_1 - readen_0 + readst_2 - readen_1 == 0) {
                         if (refst_1 - refen_0 != 0 && refst_1 - refen_0 + refst_2 - refen_1 == 0) {
                             if (refen_0 > refst_1) {
+                                if (rmode) { iloc += 1; continue; }
                                 std::string tempref = revcomp(pyslice(cs, refen_1, refen_1 + refen_0 - refst_1));
                                 std::string tempquery = pyslice(read, readen_0 - refen_0 + refst_1, readen_0);
                                 if (tempref == tempquery) {
@@ -465,7 +467,7 @@ int extend_func(const vmo_index* mi, const std::string& read, const std::string&
     }
     if (al.size() < o_len) { filtered = true; extend_edge_test(mi, read, L, al); }
     merge_conjacent_alignment(mi, al);
-    rcode = fix_simple_inv(mi, al, read);
+    rcode = fix_simple_inv(mi, al, read, prm.mode == VMO_MODE_R);
     if (rcode < 0) return rcode;
     std::vector<Seg> nal; std::vector<std::vector<std::string>> cigarlist;
     for (const Seg& a : al) {

@@ -304,6 +304,89 @@ static int local_chain_dp(const std::vector<Anchor>& A, int kmersize, double ski
     return 0;
 }
 
+// mode R: get_optimal_chain_sortbyreadpos_forSV_inv_test_merged_fine_list_scar (mammap_noprefercloser.py:23419-23628). A sorted by read
+// START (stable); the candidate window still advances on read ENDS (:23484). Co-linear gap cost 0.5*log2 for every size (:23432), read-gap
+// cost from the R table (:16534), a non-co-linear step costs the fixed skipcost, refunded after skipcost co-linear bases (fixed_penatly /
+// pre_penatly). No opcount switch.
+static int local_chain_scar(const std::vector<Anchor>& A, int kmersize, double skipcost, int maxdiff, int maxgap, double* score, Path& path) {
+    const Tables& T = tables();
+    const int64_t n = (int64_t)A.size();
+    if (n == 0) return -1;
+    std::vector<double> gapcost_list(maxdiff + 1, 0.0);
+    for (int g = 1; g <= maxdiff; ++g) gapcost_list[g] = (0.01 * kmersize * g + 0.5 * T.log2int[g]);
+    const std::vector<float>& readgapcost = T.readgap_r;
+    std::vector<double> S(n), pre_pen(n, 0.0), fixed_pen(n, 0.0); std::vector<int64_t> P(n), S_arg(n);
+    int64_t prereadloc = A[0].q + A[0].l;
+    int64_t testspace_en = 1;
+    S_arg[0] = 0; S[0] = (double)A[0].l; P[0] = NOPRE;
+    double g_max_scores = (double)A[0].l; int64_t g_max_index = 0;
+    for (int64_t i = 1; i < n; ++i) {
+        double max_scores = (double)A[i].l;
+        int64_t pre_index = NOPRE;
+        if (prereadloc < A[i].q + A[i].l) {
+            for (int64_t k = testspace_en; k < i; ++k) {
+                int64_t loc = smallorequal2target_1d_point(S.data(), S[k], k, S_arg.data()) + 1;
+                memmove(S_arg.data() + loc + 1, S_arg.data() + loc, sizeof(int64_t) * (size_t)(k - loc));
+                S_arg[loc] = k;
+            }
+            testspace_en = i;
+            prereadloc = A[i].q + A[i].l;
+        }
+        const double li = (double)A[i].l;
+        for (int64_t x = testspace_en - 1; x >= 0; --x) {
+            const int64_t j = S_arg[x];
+            if (S[j] < (max_scores - li)) break;
+            const Anchor &ai = A[i], &aj = A[j];
+            int64_t readgap = ai.q - aj.q - aj.l, refgap, bonus;
+            if (readgap < 0) {
+                bonus = ai.q + ai.l - aj.q - aj.l;
+                if (bonus <= 0) continue;
+                readgap = 0;
+                int64_t overlap = aj.q + aj.l - ai.q;
+                if (ai.s == aj.s) { if (ai.s == 1) refgap = ai.r + overlap - (aj.r + aj.l); else refgap = aj.r - (ai.r + bonus); }
+                else { if (aj.s == -1) refgap = ai.r + overlap - aj.r + 1; else refgap = ai.r + bonus - 1 - (aj.r + aj.l); }
+            } else {
+                bonus = ai.l;
+                if (ai.s == aj.s) { if (ai.s == 1) refgap = ai.r - aj.r - aj.l; else refgap = aj.r - ai.r - ai.l; }
+                else { if (aj.s == -1) refgap = ai.r - aj.r + 1; else refgap = ai.r + ai.l - 1 - aj.r - aj.l; }
+            }
+            const int64_t gapcost = std::llabs(readgap - refgap);
+            if (ai.s == aj.s && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
+                double test = S[j] + (double)bonus - gapcost_list[gapcost] - (double)readgapcost[readgap];
+                if (fixed_pen[j] < 0 && (fixed_pen[j] + (double)bonus) >= 0) test += pre_pen[j];
+                if (test > max_scores) {
+                    max_scores = test; pre_index = j;
+                    if (fixed_pen[j] < 0 && (fixed_pen[j] + (double)bonus) < 0) { fixed_pen[i] = fixed_pen[j] + (double)bonus; pre_pen[i] = pre_pen[j]; }
+                    else { fixed_pen[i] = 0; pre_pen[i] = 0; }
+                }
+            } else {
+                const double tmp_penalty = skipcost;
+                const double test = S[j] + (double)bonus - tmp_penalty;
+                if (test > max_scores) { max_scores = test; pre_index = j; fixed_pen[i] = -tmp_penalty + (double)bonus; pre_pen[i] = tmp_penalty; }
+            }
+        }
+        S[i] = max_scores; P[i] = pre_index;
+        if (max_scores > g_max_scores) { g_max_scores = max_scores; g_max_index = i; }
+    }
+    path.clear();
+    int64_t take = g_max_index;
+    path.push_back(A[take]);
+    Anchor preitem = A[take];
+    while (P[take] != NOPRE) {
+        take = P[take];
+        const Anchor& now = A[take];
+        if (preitem.q < now.q + now.l) {
+            int64_t ov = now.q + now.l - preitem.q;
+            if (preitem.s == 1) path.back() = Anchor{preitem.q + ov, preitem.r + ov, preitem.s, preitem.l - ov};
+            else path.back() = Anchor{preitem.q + ov, preitem.r, preitem.s, preitem.l - ov};
+        }
+        path.push_back(now);
+        preitem = now;
+    }
+    *score = g_max_scores;
+    return 0;
+}
+
 // L1 :28479-28589
 int local_chain(const vmo_index* mi, const std::string& read, const std::string& rc, const std::vector<Path>& guides_in,
                 const vmo_params& prm, double* score, Path& chain_desc, std::vector<Anchor>* raw_out, int* variant) {
@@ -313,6 +396,16 @@ int local_chain(const vmo_index* mi, const std::string& read, const std::string&
     const int maxgap = (mode == VMO_MODE_L) ? 50 : 99;           // :24061 / mammap_ccs.py:24061
     const int max_chains = (mode == VMO_MODE_L) ? 3 : 5;         // :28581 / mammap_ccs.py:28581 (S: unlimited -> see below)
     if (guides_in.empty()) return -1;
+    if (mode == VMO_MODE_R) {
+        // mammap_noprefercloser.py:23902-23914: every chain is re-seeded in the order given (no merge / drop / cap), reference window
+        // +-2000, read window +-500 (:23631+); anchors sorted by read start; one DP variant
+        std::vector<Anchor> raw;
+        for (const Path& g : guides_in) local_seed_one(mi, read, g, k, 2000, 500, raw);
+        if (raw_out) *raw_out = raw;
+        std::stable_sort(raw.begin(), raw.end(), [](const Anchor& a, const Anchor& b) { return a.q < b.q; });
+        if (variant) *variant = 2;
+        return local_chain_scar(raw, k, prm.local_skipcost, prm.local_maxdiff, maxgap, score, chain_desc);
+    }
     // merge_chain :28529-28569
     std::vector<Path> chains(guides_in.begin() + 1, guides_in.end());
     std::stable_sort(chains.begin(), chains.end(), [](const Path& a, const Path& b) { return a.back().q < b.back().q; });

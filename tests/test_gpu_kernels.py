@@ -65,7 +65,8 @@ def test_align_random_vs_oracle(ctx, oracle):
     d0 = synth.implant_svs(contigs[0], ops)
     d0 = np.concatenate([d0[:9 * L // 10], contigs[1][1000:6000], d0[9 * L // 10:]])
     names = ['chrA', 'chrB']
-    for mode, k, n, kw in (('H', 15, 160, dict(mean_len=9000, err=0.10, shape='ont')), ('L', 19, 96, dict(mean_len=10000, err=0.005, shape='hifi', min_len=4000))):
+    for mode, k, n, kw in (('H', 15, 160, dict(mean_len=9000, err=0.10, shape='ont')), ('L', 19, 96, dict(mean_len=10000, err=0.005, shape='hifi', min_len=4000)),
+                           ('S', 15, 96, dict(mean_len=8000, err=0.12, shape='ont'))):      # S: skip 30/30, divergence 0.5, nodiscard, all guide chains
         cat, off, _ = synth.sample_reads_concat([d0, contigs[1]], n, seed=33, **kw)
         seqs = [cat[off[i]:off[i + 1]].tobytes().decode() for i in range(n)]
         gi = Index.from_seqs(ctx, names, [synth.tostr(c) for c in contigs], k=k, w=10)

@@ -72,11 +72,11 @@ def build_case(args):
         reads = synth.sample_reads(src, args.n, mean_len=args.mean or 18000, err=0.005, seed=args.seed + 1, shape='hifi', min_len=5000)
         k = 19
     else:
-        reads = synth.sample_reads(src, args.n, mean_len=args.mean or 15000, err=0.10, seed=args.seed + 1, shape='ont')
+        reads = synth.sample_reads(src, args.n, mean_len=args.mean or 15000, err=(args.err if args.err >= 0 else 0.10), seed=args.seed + 1, shape='ont')
         k = 15
     if args.dense:     # two-locus reads through the tandem array: more than one guide chain + dense local anchors (LC-mm and its _fast twin)
         rng = np.random.default_rng(args.seed + 410)
-        err = 0.005 if args.mode == 'L' else 0.10
+        err = args.err if args.err >= 0 else (0.005 if args.mode == 'L' else 0.10)
         c0 = contigs[0]
         eq = np.concatenate([[0], np.cumsum(c0[23:] == c0[:-23])])
         tp = int(np.flatnonzero(eq[500:] - eq[:-500] == 500)[0])    # first position of the period-23 array
@@ -125,7 +125,7 @@ if __name__ == '__main__':
     ap.add_argument('--reflen', type=int, default=300000); ap.add_argument('--sv', action='store_true')
     ap.add_argument('--procs', type=int, default=8); ap.add_argument('--mean', type=int, default=0)
     ap.add_argument('-v', action='store_true'); ap.add_argument('--repeats', action='store_true'); ap.add_argument('--chimera', action='store_true')
-    ap.add_argument('--dense', action='store_true')
+    ap.add_argument('--dense', action='store_true'); ap.add_argument('--err', type=float, default=-1.0)
     args = ap.parse_args()
     names, contigs, reads, k = build_case(args)
     import multiprocessing as mp
