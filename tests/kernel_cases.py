@@ -198,6 +198,28 @@ def check_chain_global_fast_synth(ctx, O, seed=31, n_reads=3, L=260, per_pos=7, 
         assert [p.tolist() for p in o['paths']] == [p.tolist() for p in g['paths']]
 
 
+def check_align_random(ctx, O, mode='R', n=8, seed=51, reflen=120000, mean_len=5000, err=0.10, nthreads=8):
+    """whole path on seeded reads from an SV donor (+ a short read that stays unmapped / raises) vs the oracle run on the same inputs"""
+    from vacmap_amd import synth
+    from vacmap_amd.lib import Index, align_batch
+    contigs = synth.make_reference([reflen, reflen // 3], seed=seed)
+    L = reflen
+    ops = [('INV', L // 10, 2500), ('DEL', 3 * L // 10, 1200), ('INS', 4 * L // 10, 600, 5), ('DUP', 6 * L // 10, 2000, 2), ('INVDUP', 8 * L // 10, 1500)]
+    d0 = synth.implant_svs(contigs[0], ops)
+    k = 19 if mode == 'L' else 15
+    cat, off, _ = synth.sample_reads_concat([d0, contigs[1]], n, seed=seed + 1, mean_len=mean_len, err=err, shape='hifi' if mode == 'L' else 'ont',
+                                            **({'min_len': 3000} if mode == 'L' else {}))
+    seqs = [cat[off[i]:off[i + 1]].tobytes().decode() for i in range(n)] + ['ACGTTGCAAC' * 3]
+    names = ['chrA', 'chrB']
+    gi = Index.from_seqs(ctx, names, [synth.tostr(c) for c in contigs], k=k, w=10)
+    oi = O.Index.from_seqs(names, [synth.tostr(c) for c in contigs], k=k, w=10)
+    status, recs, stats = align_batch(ctx, gi, ctx.lib.params(mode), seqs)
+    ost, orecs = O.align_batch(oi, seqs, O.params(mode), nthreads=nthreads)
+    assert [(int(s) == 0) for s in status] == [(int(s) == 0) for s in ost], (list(status), list(ost))
+    assert recs == orecs, 'mode %s: records differ from the oracle' % mode
+    return len(orecs)
+
+
 def _case_index(ctx, O, meta, arrays, cid):
     from vacmap_amd.lib import Index
     c = meta[cid]

@@ -51,3 +51,9 @@ def test_emu_align_end_to_end(ctx, oracle, golden):
 
 def test_emu_chain_global_fast(ctx, oracle):
     KC.check_chain_global_fast_synth(ctx, oracle, seed=31, n_reads=2, L=140, per_pos=6)
+
+
+def test_emu_mode_r(ctx, oracle):
+    """mode R (fixed-penalty chains with refund, all-chain re-seeding, _scar): GC-fast R on synthetic anchors, whole path on a few reads"""
+    KC.check_chain_global_fast_synth(ctx, oracle, seed=33, n_reads=1, L=120, per_pos=6, mode='R')
+    assert KC.check_align_random(ctx, oracle, mode='R', n=3, seed=51, reflen=60000, mean_len=2500) >= 3

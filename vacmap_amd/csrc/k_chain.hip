@@ -136,7 +136,8 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
                                                      const double* __restrict__ gapcost_list, double oskipcost, int omaxdiff,
                                                      int maxgap, double* __restrict__ S_out, int32_t* __restrict__ P_out,
                                                      int32_t* __restrict__ SA_out, uint8_t* __restrict__ cov_pool,
-                                                     int64_t* __restrict__ gmax_out, int64_t* __restrict__ opcount_out) {
+                                                     int64_t* __restrict__ gmax_out, int64_t* __restrict__ opcount_out, int rmode,
+                                                     double* __restrict__ FP_pool, double* __restrict__ PP_pool) {
     VMX_DYN_SHARED(char, smem);
     __shared__ double s_gapcost[64];
     const int lane = vmx_lane();
@@ -180,10 +181,13 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
 #define AL(i) (in_lds ? (LS[i] & 0xffff) : (int)A[i].l)
 #define AS(i) (in_lds ? (LS[i] >> 16) : (int)A[i].s)
         int prereadloc = AQ(0);
-        double skipcost = oskipcost + (double)COV[0];
-        int maxdiff = omaxdiff - (int)COV[0]; if (maxdiff < 10) maxdiff = 10;
+        // rmode: mode R's body (mammap_noprefercloser.py:22839-23057) has no coverage terms; a non-co-linear step costs the fixed skipcost,
+        // remembered per anchor in fixed_penatly / pre_penatly (FP / PP, in HBM) and refunded after skipcost co-linear bases
+        double* FP = rmode ? FP_pool + a0 : nullptr; double* PP = rmode ? PP_pool + a0 : nullptr;
+        double skipcost = rmode ? oskipcost : oskipcost + (double)COV[0];
+        int maxdiff = rmode ? omaxdiff : omaxdiff - (int)COV[0]; if (maxdiff < 10) maxdiff = 10;
         int testspace_en = 1;
-        if (lane == 0) { SA[0] = 0; S[0] = (double)AL(0); P[0] = VMX_NOPRE; }
+        if (lane == 0) { SA[0] = 0; S[0] = (double)AL(0); P[0] = VMX_NOPRE; if (rmode) { FP[0] = 0.0; PP[0] = 0.0; } }
         __syncthreads();
         double g_max_scores = (double)AL(0); int g_max_index = 0;
         long long opcount = 0;
@@ -197,23 +201,37 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
                     vmx_sarg_insert4(SA, loc, k, lane);
                 }
                 testspace_en = i;
-                skipcost = oskipcost + (double)COV[i];
-                maxdiff = omaxdiff - (int)COV[i]; if (maxdiff < 10) maxdiff = 10;
+                if (!rmode) {
+                    skipcost = oskipcost + (double)COV[i];
+                    maxdiff = omaxdiff - (int)COV[i]; if (maxdiff < 10) maxdiff = 10;
+                }
                 prereadloc = qi;
             }
             const double dli = (double)li;
             double max_scores = dli; int pre_index = VMX_NOPRE;
+            double fp_i = 0.0, pp_i = 0.0;                       // rmode: the winner's fixed_penatly / pre_penatly
             for (int base = testspace_en - 1; base >= 0; base -= 64) {
                 const int x = base - lane;
                 const bool valid = x >= 0;
                 int j = 0; double Sj = 0.0; double test = -1e300;
+                double nfp = 0.0, npp = 0.0;                     // rmode: what i inherits if this candidate wins
                 if (valid) {
                     j = SA[x]; Sj = S[j];
                     long long readgap, refgap, bonus;
                     const int sj = AS(j);
                     vmx_gap_geometry(qi, ri, si, li, AQ(j), AR(j), sj, AL(j), readgap, refgap, bonus);
                     long long gapcost = readgap - refgap; if (gapcost < 0) gapcost = -gapcost;
-                    if (si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
+                    if (rmode) {
+                        if (si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
+                            test = Sj + (double)bonus - s_gapcost[gapcost];
+                            const double fpj = FP[j], ppj = PP[j];
+                            if (fpj < 0 && (fpj + (double)bonus) >= 0) test += ppj;
+                            if (fpj < 0 && (fpj + (double)bonus) < 0) { nfp = fpj + (double)bonus; npp = ppj; }
+                        } else {
+                            test = Sj + (double)bonus - skipcost;
+                            nfp = -skipcost + (double)bonus; npp = skipcost;
+                        }
+                    } else if (si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
                         test = Sj + (double)bonus - s_gapcost[gapcost];
                     } else {
                         if (gapcost > extra_size) gapcost = extra_size;
@@ -231,13 +249,15 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
                     const double M = vmx_readlane_f64(incl, first - 1);          // best score among the candidates before the break
                     if (M > max_scores) {                                        // strict >: the first (highest-S) candidate reaching M wins
                         const unsigned long long em = __ballot(test == M) & (first >= 64 ? ~0ULL : ((1ULL << first) - 1ULL));
-                        pre_index = vmx_readlane(j, __ffsll((unsigned long long)em) - 1);
+                        const int wl = __ffsll((unsigned long long)em) - 1;
+                        pre_index = vmx_readlane(j, wl);
+                        if (rmode) { fp_i = vmx_readlane_f64(nfp, wl); pp_i = vmx_readlane_f64(npp, wl); }
                         max_scores = M;
                     }
                 }
                 if (first < 64) break;
             }
-            if (lane == 0) { S[i] = max_scores; P[i] = pre_index; }
+            if (lane == 0) { S[i] = max_scores; P[i] = pre_index; if (rmode) { FP[i] = fp_i; PP[i] = pp_i; } }
             if (max_scores > g_max_scores) { g_max_scores = max_scores; g_max_index = i; }
             __syncthreads();
         }

@@ -24,6 +24,7 @@ struct vmx_fast_io {
     int32_t* Si; int64_t* T;                        // int(S) and diagonal key per anchor
     int32_t* CNT; int cnt_n;                        // S_i_count (cnt_n = last read position + 50)
     uint8_t* COV;                                   // anchors sharing the read position, capped at 20 (GC-fast only)
+    double* FP; double* PP;                         // fixed_penatly / pre_penatly (mode R's GC-fast only)
 };
 
 // (Si, T) of entry x of the index vs (ts, td): -1 below, 0 equal, +1 above
@@ -107,15 +108,17 @@ struct vmx_fast_cost {
     const double* gapcost; const float* rgc; vmx_tables tab; double skipcost; int maxdiff, maxgap; long long extra_size, l2c_size;
 };
 
-// one candidate j for anchor i (:25191-25237 / :27098-27166). VARIANT 0 GC-fast, 1 LC-fast, 2 LC-mm-fast. returns false when LC's
-// `bonus <= 0` fires (the candidate is skipped)
+// one candidate j for anchor i (:25191-25237 / :27098-27166). VARIANT 0 GC-fast, 1 LC-fast, 2 LC-mm-fast, 3 GC-fast of mode R
+// (mammap_noprefercloser.py:23059-23417: fixed skipcost with refund; fpj / ppj = fixed_penatly[j] / pre_penatly[j], *nfp / *npp = what
+// i inherits if j wins). returns false when LC's `bonus <= 0` fires (the candidate is skipped)
 template <int VARIANT>
-__device__ __forceinline__ bool vmx_fast_eval(const vmx_anchor& ai, const vmx_anchor& aj, double Sj, const vmx_fast_cost& C, double* test) {
+__device__ __forceinline__ bool vmx_fast_eval(const vmx_anchor& ai, const vmx_anchor& aj, double Sj, const vmx_fast_cost& C, double* test,
+                                              double fpj = 0.0, double ppj = 0.0, double* nfp = nullptr, double* npp = nullptr) {
     const int qi = ai.q, li = ai.l, si = ai.s, qj = aj.q, lj = aj.l, sj = aj.s; const long long ri = ai.r, rj = aj.r;
     long long readgap = (long long)qi - qj - lj, refgap, bonus;
     if (readgap < 0) {
         bonus = (long long)qi + li - qj - lj;
-        if (VARIANT != 0 && bonus <= 0) return false;
+        if ((VARIANT == 1 || VARIANT == 2) && bonus <= 0) return false;
         readgap = 0;
         const long long overlap = (long long)qj + lj - qi;
         if (si == sj) { if (si == 1) refgap = ri + overlap - (rj + lj); else refgap = rj - (ri + bonus); }
@@ -126,6 +129,18 @@ __device__ __forceinline__ bool vmx_fast_eval(const vmx_anchor& ai, const vmx_an
         else { if (sj == -1) refgap = ri - rj + 1; else refgap = ri + li - 1 - rj - lj; }
     }
     long long gapcost = readgap - refgap; if (gapcost < 0) gapcost = -gapcost;
+    if (VARIANT == 3) {
+        if (si == sj && refgap >= 0 && readgap <= C.maxgap && gapcost <= C.maxdiff) {
+            double t = Sj + (double)bonus - C.gapcost[gapcost];
+            if (fpj < 0 && (fpj + (double)bonus) >= 0) t += ppj;
+            if (fpj < 0 && (fpj + (double)bonus) < 0) { *nfp = fpj + (double)bonus; *npp = ppj; } else { *nfp = 0.0; *npp = 0.0; }
+            *test = t;
+        } else {
+            *test = Sj + (double)bonus - C.skipcost;
+            *nfp = -C.skipcost + (double)bonus; *npp = C.skipcost;
+        }
+        return true;
+    }
     if (si == sj && refgap >= 0 && readgap <= C.maxgap && gapcost <= C.maxdiff) {
         if (VARIANT == 0) *test = Sj + (double)bonus - C.gapcost[gapcost];
         else *test = Sj + (double)bonus - C.gapcost[gapcost] - (double)C.rgc[readgap];
@@ -166,18 +181,19 @@ __device__ int vmx_fast_dp(const vmx_fast_io& io, vmx_fast_cost C, const double*
     }
     __syncthreads();
     const vmx_anchor a0 = A[0];
-    long long prereadloc = VARIANT == 0 ? (long long)a0.q : (long long)a0.q + a0.l;
+    constexpr bool GC = VARIANT == 0 || VARIANT == 3;
+    long long prereadloc = GC ? (long long)a0.q : (long long)a0.q + a0.l;
     C.gapcost = gapcost_list; C.skipcost = oskipcost; C.maxdiff = omaxdiff;
     int testspace_en_i = 1;
     if ((int)a0.l >= io.cnt_n) return -5;
-    if (lane == 0) { io.SA[0] = 0; io.S[0] = (double)a0.l; io.Si[0] = a0.l; io.P[0] = VMX_NOPRE; io.CNT[a0.l] = 1; }
+    if (lane == 0) { io.SA[0] = 0; io.S[0] = (double)a0.l; io.Si[0] = a0.l; io.P[0] = VMX_NOPRE; io.CNT[a0.l] = 1; if (VARIANT == 3) { io.FP[0] = 0.0; io.PP[0] = 0.0; } }
     __syncthreads();
     double g_max_scores = (double)a0.l; int g_max_index = 0;
     int max_score_i = 0;
     int err = 0;
     for (int i = 1; i < n && !err; ++i) {
         const vmx_anchor ai = A[i];
-        const long long pos_i = VARIANT == 0 ? (long long)ai.q : (long long)ai.q + ai.l;
+        const long long pos_i = GC ? (long long)ai.q : (long long)ai.q + ai.l;
         if (prereadloc < pos_i) {
             for (int k = testspace_en_i; k < i; ++k) {                         // :25132-25146
                 const int sk = io.Si[k];
@@ -198,6 +214,7 @@ __device__ int vmx_fast_dp(const vmx_fast_io& io, vmx_fast_cost C, const double*
             prereadloc = pos_i;
         }
         double max_scores = (double)ai.l; int pre_index = VMX_NOPRE;
+        double fp_i = 0.0, pp_i = 0.0;
         const double f = (double)(ai.l + 1);
         const long long ti = io.T[i];
         int en_top = testspace_en_i;                      // end of the bucket of the highest level of the current window
@@ -207,17 +224,20 @@ __device__ int vmx_fast_dp(const vmx_fast_io& io, vmx_fast_cost C, const double*
             const int incl_cnt = vmx_wave_incl_scan_i32(cnt);
             const int en_loc = en_top - (incl_cnt - cnt), st_loc = en_loc - cnt;
             double test = -1e300; int jbest = VMX_NOPRE; bool hang = false;
+            double nfp = 0.0, npp = 0.0;
             if (cnt > 0 && st_loc >= 0) {
                 if (cnt > 5) {
                     const int j = io.SA[vmx_fast_closest(io, ti, st_loc, en_loc)];
-                    double t;
-                    if (vmx_fast_eval<VARIANT>(ai, A[j], io.S[j], C, &t)) { test = t; jbest = j; }
+                    double t, a = 0.0, b = 0.0;
+                    const double fpj = VARIANT == 3 ? io.FP[j] : 0.0, ppj = VARIANT == 3 ? io.PP[j] : 0.0;
+                    if (vmx_fast_eval<VARIANT>(ai, A[j], io.S[j], C, &t, fpj, ppj, &a, &b)) { test = t; jbest = j; nfp = a; npp = b; }
                     else hang = true;                     // reference: `continue` with unchanged loop state
                 } else {
                     for (int x = en_loc - 1; x >= st_loc; --x) {
                         const int j = io.SA[x];
-                        double t;
-                        if (vmx_fast_eval<VARIANT>(ai, A[j], io.S[j], C, &t) && t > test) { test = t; jbest = j; }
+                        double t, a = 0.0, b = 0.0;
+                        const double fpj = VARIANT == 3 ? io.FP[j] : 0.0, ppj = VARIANT == 3 ? io.PP[j] : 0.0;
+                        if (vmx_fast_eval<VARIANT>(ai, A[j], io.S[j], C, &t, fpj, ppj, &a, &b) && t > test) { test = t; jbest = j; nfp = a; npp = b; }
                     }
                 }
             }
@@ -234,7 +254,9 @@ __device__ int vmx_fast_dp(const vmx_fast_io& io, vmx_fast_cost C, const double*
                 const double M = vmx_readlane_f64(incl, first - 1);
                 if (M > max_scores) {
                     const unsigned long long em = __ballot(test == M) & vis;
-                    pre_index = vmx_readlane(jbest, __ffsll((unsigned long long)em) - 1);
+                    const int wl = __ffsll((unsigned long long)em) - 1;
+                    pre_index = vmx_readlane(jbest, wl);
+                    if (VARIANT == 3) { fp_i = vmx_readlane_f64(nfp, wl); pp_i = vmx_readlane_f64(npp, wl); }
                     max_scores = M;
                 }
             }
@@ -242,12 +264,12 @@ __device__ int vmx_fast_dp(const vmx_fast_io& io, vmx_fast_cost C, const double*
             en_top -= vmx_readlane(incl_cnt, 63);
         }
         if (err) break;
-        if (lane == 0) { io.S[i] = max_scores; io.Si[i] = (int32_t)(long long)max_scores; io.P[i] = pre_index; }   // truncation toward zero (:25314)
+        if (lane == 0) { io.S[i] = max_scores; io.Si[i] = (int32_t)(long long)max_scores; io.P[i] = pre_index; if (VARIANT == 3) { io.FP[i] = fp_i; io.PP[i] = pp_i; } }   // truncation toward zero (:25314)
         if (max_scores > g_max_scores) { g_max_scores = max_scores; g_max_index = i; }
         __syncthreads();
     }
     if (err) return err;
-    if (VARIANT == 0) {                                                          // :25324-25336
+    if (GC) {                                                                    // :25324-25336
         for (int k = testspace_en_i; k < n; ++k) {
             const int sk = io.Si[k];
             if (sk < 0 || sk >= io.cnt_n) return -5;
@@ -267,7 +289,8 @@ __global__ void __launch_bounds__(64) k_chain_global_fast(const vmx_anchor* __re
                                                           double oskipcost, int omaxdiff, int maxgap, double* __restrict__ S_out,
                                                           int32_t* __restrict__ P_out, int32_t* __restrict__ SA_out, uint8_t* __restrict__ cov_pool,
                                                           int32_t* __restrict__ si_pool, int64_t* __restrict__ t_pool, int32_t* __restrict__ cnt_pool,
-                                                          int64_t* __restrict__ gmax_out, int32_t* __restrict__ ran) {
+                                                          int64_t* __restrict__ gmax_out, int32_t* __restrict__ ran, int rmode,
+                                                          double* __restrict__ FP_pool, double* __restrict__ PP_pool) {
     const int rd = (int)blockIdx.x;
     if (rd >= n_reads) return;
     const int64_t a0 = aoff[rd];
@@ -277,11 +300,11 @@ __global__ void __launch_bounds__(64) k_chain_global_fast(const vmx_anchor* __re
     vmx_fast_io io;
     io.A = anchors + a0; io.n = n; io.S = S_out + a0; io.P = P_out + a0; io.SA = SA_out + a0; io.Si = si_pool + a0; io.T = t_pool + a0;
     io.CNT = cnt_pool + roff[rd] + 50 * (int64_t)rd; io.cnt_n = io.A[n - 1].q + 50;
-    io.COV = cov_pool + a0;
+    io.COV = cov_pool + a0; io.FP = rmode ? FP_pool + a0 : nullptr; io.PP = rmode ? PP_pool + a0 : nullptr;
     vmx_fast_cost C; C.gapcost = gapcost_list; C.rgc = nullptr; C.tab = tab; C.skipcost = oskipcost; C.maxdiff = omaxdiff; C.maxgap = maxgap;
     C.extra_size = (long long)tab.extra_n - 1; C.l2c_size = (long long)tab.log2cache_n - 1;
     double gs = 0.0;
-    const int g = vmx_fast_dp<0>(io, C, gapcost_list, oskipcost, omaxdiff, &gs);
+    const int g = rmode ? vmx_fast_dp<3>(io, C, gapcost_list, oskipcost, omaxdiff, &gs) : vmx_fast_dp<0>(io, C, gapcost_list, oskipcost, omaxdiff, &gs);
     if (vmx_lane() == 0) gmax_out[rd] = g >= 0 ? g : -2;       // -2: the reference raises on this read (treated as unmapped)
 }
 
@@ -303,7 +326,7 @@ __global__ void __launch_bounds__(64) k_chain_local_fast(const vmx_anchor* __res
     vmx_fast_io io;
     io.A = anchors + a0; io.n = n; io.S = S_pool + a0; io.P = P_pool + a0; io.SA = SA_pool + a0; io.Si = si_pool + a0; io.T = t_pool + a0;
     io.CNT = cnt_pool + roff[rd] + 50 * (int64_t)rd; io.cnt_n = io.A[n - 1].q + 50;
-    io.COV = nullptr;
+    io.COV = nullptr; io.FP = nullptr; io.PP = nullptr;
     vmx_fast_cost C; C.gapcost = gapcost_list; C.tab = tab; C.maxdiff = maxdiff; C.maxgap = maxgap;
     C.rgc = mm ? tab.large_readgap : (mode == 3 ? tab.readgap_r : tab.readgap_h);
     C.extra_size = (long long)tab.extra_n - 1; C.l2c_size = (long long)tab.log2cache_n - 1;

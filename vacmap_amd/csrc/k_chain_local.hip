@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
                                                     int maxgap, int mode, double* __restrict__ S_pool, int32_t* __restrict__ P_pool,
                                                     int32_t* __restrict__ SA_pool, double* __restrict__ out_score,
                                                     vmx_anchor* __restrict__ out_chain, int32_t* __restrict__ out_len, int32_t* __restrict__ out_variant,
-                                                    int32_t* __restrict__ status) {
+                                                    int32_t* __restrict__ status, double* __restrict__ FP_pool, double* __restrict__ PP_pool) {
     VMX_DYN_SHARED(char, smem);
     __shared__ double s_gapcost[64];
     __shared__ float s_rgc[128];
@@ -34,7 +34,12 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
         const int64_t a0 = la_off[rd];
         const int n = la_cnt[rd];
         if (n <= 0) { if (lane == 0) { out_len[rd] = 0; out_score[rd] = 0; status[rd] = VM_READ_RAISED_DEV; } continue; }   // np.array([]) indexing raises
-        const bool mm = n_guides_total[rd] > 1;
+        // mode R runs one variant, `_scar` (mammap_noprefercloser.py:23419-23628): anchors sorted by read START, a non-co-linear step costs
+        // the fixed skipcost, remembered per anchor in fixed_penatly / pre_penatly (FP / PP, in HBM) and refunded once the chain has gone
+        // on co-linearly for skipcost bases; no opcount switch
+        const bool scar = mode == 3;
+        const bool mm = !scar && n_guides_total[rd] > 1;
+        double* FP = scar ? FP_pool + a0 : nullptr; double* PP = scar ? PP_pool + a0 : nullptr;
         const double skipcost = mm ? skip_mm : skip_exact;
         const float* rgc_g = mm ? tab.large_readgap : (mode == 3 ? tab.readgap_r : tab.readgap_h);
         for (int x = lane; x < 100; x += 64) s_rgc[x] = rgc_g[x];          // read-gap cost table of this read's variant (100 entries, maxgap <= 99)
@@ -58,7 +63,7 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
 #define AS(i) (in_lds ? (LS[i] >> 16) : (int)A[i].s)
         long long prereadloc = (long long)AQ(0) + AL(0);
         int testspace_en = 1;
-        if (lane == 0) { SA[0] = 0; S[0] = (double)AL(0); P[0] = VMX_NOPRE; }
+        if (lane == 0) { SA[0] = 0; S[0] = (double)AL(0); P[0] = VMX_NOPRE; if (scar) { FP[0] = 0.0; PP[0] = 0.0; } }
         __syncthreads();
         double g_max_scores = (double)AL(0); int g_max_index = 0;
         long long opcount = 0;
@@ -66,7 +71,7 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
         for (int i = 1; i < n; ++i) {
             const int qi = AQ(i); const long long ri = AR(i); const int li = AL(i); const int si = AS(i);
             if (prereadloc < (long long)qi + li) {
-                if (opcount > 100000 && ((double)opcount / (double)prereadloc) > 1000.0) { need_fast = true; break; }   // :27380 -> *_fast
+                if (!scar && opcount > 100000 && ((double)opcount / (double)prereadloc) > 1000.0) { need_fast = true; break; }   // :27380 -> *_fast
                 for (int k = testspace_en; k < i; ++k) {
                     // smallorequal(...) + 1 (:13229-13265) on a sorted array = number of scores <= S[k]
                     const int loc = vmx_sorted_count(S, SA, k, S[k], true, lane);
@@ -77,10 +82,12 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
             }
             const double dli = (double)li;
             double max_scores = dli; int pre_index = VMX_NOPRE;
+            double fp_i = 0.0, pp_i = 0.0;                       // scar: the winner's fixed_penatly / pre_penatly
             for (int base = testspace_en - 1; base >= 0; base -= 64) {
                 const int x = base - lane;
                 const bool valid = x >= 0;
                 int j = 0; double Sj = 0.0; double test = -1e300;
+                double nfp = 0.0, npp = 0.0;                     // scar: what i inherits if this candidate wins
                 if (valid) {
                     j = SA[x]; Sj = S[j];
                     const int qj = AQ(j), lj = AL(j), sj = AS(j); const long long rj = AR(j);
@@ -100,7 +107,17 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
                     }
                     if (!skip) {
                         long long gapcost = readgap - refgap; if (gapcost < 0) gapcost = -gapcost;
-                        if (si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
+                        if (scar) {
+                            if (si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
+                                test = Sj + (double)bonus - s_gapcost[gapcost] - (double)rgc[readgap];
+                                const double fpj = FP[j], ppj = PP[j];
+                                if (fpj < 0 && (fpj + (double)bonus) >= 0) test += ppj;                      // refund (:23557-23559)
+                                if (fpj < 0 && (fpj + (double)bonus) < 0) { nfp = fpj + (double)bonus; npp = ppj; }
+                            } else {
+                                test = Sj + (double)bonus - skipcost;                                          // :23577-23578
+                                nfp = -skipcost + (double)bonus; npp = skipcost;
+                            }
+                        } else if (si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
                             test = Sj + (double)bonus - s_gapcost[gapcost] - (double)rgc[readgap];
                         } else if (!mm) {
                             if (gapcost > extra_size) gapcost = extra_size;
@@ -126,13 +143,15 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
                     const double M = vmx_readlane_f64(incl, first - 1);          // best score among the candidates before the break
                     if (M > max_scores) {                                        // strict >: the first (highest-S) candidate reaching M wins
                         const unsigned long long em = __ballot(test == M) & (first >= 64 ? ~0ULL : ((1ULL << first) - 1ULL));
-                        pre_index = vmx_readlane(j, __ffsll((unsigned long long)em) - 1);
+                        const int wl = __ffsll((unsigned long long)em) - 1;
+                        pre_index = vmx_readlane(j, wl);
+                        if (scar) { fp_i = vmx_readlane_f64(nfp, wl); pp_i = vmx_readlane_f64(npp, wl); }
                         max_scores = M;
                     }
                 }
                 if (first < 64) break;
             }
-            if (lane == 0) { S[i] = max_scores; P[i] = pre_index; }
+            if (lane == 0) { S[i] = max_scores; P[i] = pre_index; if (scar) { FP[i] = fp_i; PP[i] = pp_i; } }
             if (max_scores > g_max_scores) { g_max_scores = max_scores; g_max_index = i; }
             __syncthreads();
         }
@@ -157,7 +176,7 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
                 }
                 out_len[rd] = w; out_score[rd] = g_max_scores; status[rd] = 0;
             }
-            out_variant[rd] = mm ? 1 : 0;
+            out_variant[rd] = scar ? 2 : (mm ? 1 : 0);
         }
         __syncthreads();
 #undef AQ

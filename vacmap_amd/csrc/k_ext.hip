@@ -129,7 +129,7 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
     }
     if (phase == 5) {
         vmx_merge_conjacent(S, R, A.dup + A.soff[r]);
-        int rc = vmx_fix_simple_inv(S, R, RD, L);
+        int rc = vmx_fix_simple_inv(S, R, RD, L, A.mode == 3);
         if (rc < 0) { E.status = rc; return; }
         E.nseg = S.nseg;
         // checkpoints -> gap-fill problems: count first, then allocate exactly that many slots

@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             __syncthreads();
             for (long long e = threadIdx.x; e < NP; e += blockDim.x) {
                 uint64_t kk = ~0ULL;
-                if (e < no) { const vmx_anchor a = OUT[GOFF[e]]; kk = ((uint64_t)(uint32_t)(a.q + a.l) << 32) | (uint64_t)e; }
+                if (e < no) { const vmx_anchor a = OUT[GOFF[e]]; kk = ((uint64_t)(uint32_t)(A.sort_by_start ? a.q : a.q + a.l) << 32) | (uint64_t)e; }   // :28585; mode R sorts by read start
                 HKEY[e] = kk;
             }
             __syncthreads();

@@ -49,7 +49,7 @@ struct vmx_batch_bufs {
     // extend stage
     DevBuf er, coff3, soff2, segA, st, en, segA_s, st_s, en_s, segprob, dup, desc[2], rcount, oflow, probread, tl, ql, toff, qoff, tpool, qpool;
     DevBuf edout, carry, ext3, dpsz[4], dpoff[4], dptab, tb, bnd, run, cig, ciglen, dpscore, rec, blob, bloboff, reccoff, recclen, dupd, totals;
-    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp;
+    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp;
     void release() { DevBuf* p = (DevBuf*)this; for (size_t i = 0; i < sizeof(*this) / sizeof(DevBuf); ++i) p[i].release(); }
 };
 static vmx_batch_bufs* batch_bufs(vm_ctx* c) { if (!c->bbufs) c->bbufs = new vmx_batch_bufs(); return c->bbufs; }
@@ -93,7 +93,6 @@ static int ext_gather_round(vm_ctx* c, vmx_batch_bufs& B, const vm_index_view& i
 static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
                         vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats) {
     *recs = nullptr; *n_recs = 0; *cigar_blob = nullptr;
-    if (prm->mode == VM_MODE_R) { set_error("mode R (fixed-penalty chain variants) not built yet"); return VM_ERR_UNSUPPORTED; }
     vmx_batch_bufs& B = *batch_bufs(c);
     vm_index_view ix; vmx_index_view(mi, &ix);
     const int64_t total_bases = h_roff[n];
@@ -145,6 +144,8 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         for (int g = 1; g <= prm->global_maxdiff; ++g) gap[g] = (0.01 * ix.k * g + 0.5 * T.log2int[g]);
         VMX_TRY(upload(B.gap, gap.data(), 64, c->stream));
     }
+    const int rmode = prm->mode == VM_MODE_R ? 1 : 0;
+    if (rmode) { VMX_TRY(B.fp.reserve(8 * (size_t)(tot + 1))); VMX_TRY(B.pp.reserve(8 * (size_t)(tot + 1))); }   // fixed_penatly / pre_penatly of mode R's chain
     // LDS buckets by anchor count (25 B per anchor), reads longest-first inside a bucket, one workgroup per read (see vmx_local_stage)
     constexpr int NB = 10;
     const int caps[NB] = {384, 512, 768, 1024, 1280, 1536, 2048, 3072, 4096, 6400};
@@ -173,7 +174,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
             int cap = q < NB ? caps[q] : 0; size_t shmem = (size_t)cap * VMX_GC_BYTES_PER_ANCHOR + 64;
             hipLaunchKernelGGL(k_chain_global, dim3((unsigned)cnt), dim3(64), shmem, fk.next(), B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(),
                                B.rl.as<int32_t>() + rl_off[q], cnt, cap, c->tables, B.gap.as<double>(), prm->global_skipcost, prm->global_maxdiff, 1000, B.S.as<double>(),
-                               B.P.as<int32_t>(), B.SA.as<int32_t>(), B.cov.as<uint8_t>(), B.gmax.as<int64_t>(), B.opc.as<int64_t>());
+                               B.P.as<int32_t>(), B.SA.as<int32_t>(), B.cov.as<uint8_t>(), B.gmax.as<int64_t>(), B.opc.as<int64_t>(), rmode, B.fp.as<double>(), B.pp.as<double>());
         }
         fk.join();
         // G3: reads left at gmax = -1 (more than 5 anchors per base, :23570, or GC-exact's opcount bail-out, :24914) take GC-fast.
@@ -181,7 +182,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         VMX_TRY(B.si.reserve(4 * (size_t)(tot + 1))); VMX_TRY(B.tg.reserve(8 * (size_t)(tot + 1))); VMX_TRY(B.cntp.reserve(4 * (size_t)(total_bases + 50 * n + 64)));
         hipLaunchKernelGGL(k_chain_global_fast, dim3((unsigned)n), dim3(64), 0, c->stream, B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(), (int)n, d_roff, c->tables,
                            B.gap.as<double>(), prm->global_skipcost, prm->global_maxdiff, 1000, B.S.as<double>(), B.P.as<int32_t>(), B.SA.as<int32_t>(), B.cov.as<uint8_t>(),
-                           B.si.as<int32_t>(), B.tg.as<int64_t>(), B.cntp.as<int32_t>(), B.gmax.as<int64_t>(), (int32_t*)nullptr);
+                           B.si.as<int32_t>(), B.tg.as<int64_t>(), B.cntp.as<int32_t>(), B.gmax.as<int64_t>(), (int32_t*)nullptr, rmode, B.fp.as<double>(), B.pp.as<double>());
     }
     VMX_TRY(B.scr.reserve((size_t)stt + 64)); VMX_TRY(upload(B.soff, soff.data(), (size_t)n + 1, c->stream));
     VMX_TRY(B.res.reserve(16 * (size_t)(n + 2) + 64));
@@ -225,7 +226,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     VMX_TRY(B.recclen.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.dupd.reserve((size_t)cB + 64));
     VMX_HIP(hipMemsetAsync(B.oflow.p, 0, 4, c->stream));
     vmx_ext_args A; memset(&A, 0, sizeof A);
-    A.n_reads = (int)n; A.nseq = ix.nseq; A.local_maxdiff = prm->local_maxdiff; A.nodiscard = prm->nodiscard; A.hardclip = prm->hardclip; A.redo_only = 0; A.maxdivergence = prm->maxdivergence;
+    A.n_reads = (int)n; A.nseq = ix.nseq; A.local_maxdiff = prm->local_maxdiff; A.nodiscard = prm->nodiscard; A.hardclip = prm->hardclip; A.redo_only = 0; A.mode = prm->mode; A.maxdivergence = prm->maxdivergence;
     A.ocodes = B.ocodes.as<uint8_t>(); A.roff = d_roff; A.ref = ix.codes; A.coff = ix.coff;
     A.chain = L.chain.as<vmx_anchor>(); A.chain_len = L.chain_len.as<int32_t>(); A.la_off = L.la_off.as<int64_t>(); A.lstatus = L.status.as<int32_t>();
     A.gscore = d_gscore; A.mapq = d_mapq; A.er = B.er.as<vmx_ext_read>(); A.coff3 = B.coff3.as<int64_t>(); A.soff = B.soff2.as<int64_t>();
@@ -354,6 +355,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     for (int64_t r = 0; r < n; ++r) {
         int stt2 = er[r].status;
         if (h_gmax[r] == -2 && (h_aoff[r + 1] - h_aoff[r]) > 2) stt2 = VM_READ_RAISED;     // GC-fast: the reference raises on this read (k_chain_fast.hip)
+        if (rmode && (h_aoff[r + 1] - h_aoff[r]) <= 2) stt2 = VM_READ_RAISED;              // mode R returns an unbound `factor` for <= 2 anchors (mammap_noprefercloser.py:24417)
         if (status_per_read) status_per_read[r] = stt2;
         if (stt2 != 0) { st.n_failed++; continue; }
         if (er[r].nrec == 0) st.n_unmapped++;

@@ -286,7 +286,6 @@ int vm_chain_global_batch(vm_ctx* c, const vm_params* prm, int kmersize, int64_t
                           const int64_t* readlens, int want_raw, vm_chains_out* out) {
     memset(out, 0, sizeof(*out));
     if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
-    if (prm->mode == VM_MODE_R) { set_error("mode R chain variant not built yet"); return VM_ERR_UNSUPPORTED; }
     if (prm->global_maxdiff > 62) { set_error("global_maxdiff > 62 unsupported"); return VM_ERR_UNSUPPORTED; }
     VMX_HIP(hipSetDevice(c->device));
     const int64_t tot = aoff[n];
@@ -318,6 +317,8 @@ int vm_chain_global_batch(vm_ctx* c, const vm_params* prm, int kmersize, int64_t
     std::vector<double> gap(64, 0.0);
     for (int g = 1; g <= prm->global_maxdiff; ++g) gap[g] = (0.01 * kmersize * g + 0.5 * T.log2int[g]);
     VMX_TRY(upload(d_gap, gap.data(), 64, c->stream));
+    const int rmode = prm->mode == VM_MODE_R ? 1 : 0;
+    if (rmode) { VMX_TRY(c->b[25].reserve(8 * (size_t)(tot + 1))); VMX_TRY(c->b[26].reserve(8 * (size_t)(tot + 1))); }   // mode R: fixed_penatly / pre_penatly
     // bucket the reads by anchor count so that each launch asks for no more LDS than it needs (160 KiB per CU on gfx950)
     const int caps[4] = {768, 1536, 3072, 6400};
     std::vector<int32_t> lists[5];
@@ -343,7 +344,8 @@ int vm_chain_global_batch(vm_ctx* c, const vm_params* prm, int kmersize, int64_t
 #endif
         hipLaunchKernelGGL(k_chain_global, dim3(grid_for(c, cnt, 8)), dim3(64), shmem, c->stream, d_sorted.as<vmx_anchor>(), d_aoff.as<int64_t>(),
                            d_rl.as<int32_t>() + rl_off[k], cnt, cap, c->tables, d_gap.as<double>(), prm->global_skipcost, prm->global_maxdiff,
-                           1000, d_S.as<double>(), d_P.as<int32_t>(), d_SA.as<int32_t>(), d_cov.as<uint8_t>(), d_gmax.as<int64_t>(), d_opc.as<int64_t>());
+                           1000, d_S.as<double>(), d_P.as<int32_t>(), d_SA.as<int32_t>(), d_cov.as<uint8_t>(), d_gmax.as<int64_t>(), d_opc.as<int64_t>(), rmode,
+                           c->b[25].as<double>(), c->b[26].as<double>());
     }
     // G3: reads left at gmax = -1 (fast_enable or the opcount bail-out) go through GC-fast (k_chain_fast.hip)
     if (n) {
@@ -355,7 +357,8 @@ int vm_chain_global_batch(vm_ctx* c, const vm_params* prm, int kmersize, int64_t
         VMX_TRY(d_si.reserve(4 * (size_t)(tot + 1))); VMX_TRY(d_tg.reserve(8 * (size_t)(tot + 1))); VMX_TRY(d_cnt.reserve(4 * (size_t)(roff[(size_t)n] + 50 * n + 64)));
         hipLaunchKernelGGL(k_chain_global_fast, dim3((unsigned)n), dim3(64), 0, c->stream, d_sorted.as<vmx_anchor>(), d_aoff.as<int64_t>(), (int)n, d_roff.as<int64_t>(),
                            c->tables, d_gap.as<double>(), prm->global_skipcost, prm->global_maxdiff, 1000, d_S.as<double>(), d_P.as<int32_t>(), d_SA.as<int32_t>(),
-                           d_cov.as<uint8_t>(), d_si.as<int32_t>(), d_tg.as<int64_t>(), d_cnt.as<int32_t>(), d_gmax.as<int64_t>(), d_ran.as<int32_t>());
+                           d_cov.as<uint8_t>(), d_si.as<int32_t>(), d_tg.as<int64_t>(), d_cnt.as<int32_t>(), d_gmax.as<int64_t>(), d_ran.as<int32_t>(), rmode,
+                           c->b[25].as<double>(), c->b[26].as<double>());
     }
     VMX_TRY(d_scr.reserve((size_t)st + 64));
     VMX_TRY(upload(d_soff, soff.data(), (size_t)n + 1, c->stream));

@@ -263,7 +263,8 @@ __host__ __device__ inline void vmx_merge_conjacent(vmx_segs& S, const vmx_ref_v
 __host__ __device__ inline uint8_t vmx_read_base(const uint8_t* rd, long long L, long long i) { return (i >= 0 && i < L) ? rd[i] : 4; }
 
 // :24226-24312. returns 0 or VM_READ_RAISED_DEV (assert / IndexError)
-__host__ __device__ inline int vmx_fix_simple_inv(vmx_segs& S, const vmx_ref_view& R, const uint8_t* rd, long long L) {
+// rmode: mode R keeps an older body (mammap_noprefercloser.py:17155-17200) whose `refen_0 > refst_1` branch changes nothing
+__host__ __device__ inline int vmx_fix_simple_inv(vmx_segs& S, const vmx_ref_view& R, const uint8_t* rd, long long L, bool rmode) {
     if (S.nseg <= 2) return 0;
     for (int iloc = 0; iloc + 2 < S.nseg; ++iloc) {
         if (!(SEG_FIRST(S, iloc).s == SEG_FIRST(S, iloc + 2).s && SEG_FIRST(S, iloc).s != SEG_FIRST(S, iloc + 1).s)) continue;
@@ -277,6 +278,7 @@ __host__ __device__ inline int vmx_fix_simple_inv(vmx_segs& S, const vmx_ref_vie
         if (!(refst_2 - refen_0 == refen_1 - refst_1 && readst_1 - readen_0 + readst_2 - readen_1 == 0)) continue;
         if (!(refst_1 - refen_0 != 0 && refst_1 - refen_0 + refst_2 - refen_1 == 0)) continue;
         if (refen_0 > refst_1) {
+            if (rmode) continue;
             // tempref = revcomp(ref[refen_1 : refen_1 + refen_0 - refst_1]) ; tempquery = read[readen_0 - refen_0 + refst_1 : readen_0]
             long long n = refen_0 - refst_1;
             long long ta = vmx_clampll(refen_1, 0, clen), tb = vmx_clampll(refen_1 + n, 0, clen);

@@ -108,10 +108,12 @@ __global__ void k_flip_sort(const int64_t* rows, const int64_t* aoff, const int6
                             const int64_t* key_off, vmx_anchor* sorted, int32_t* need_reverse);
 __global__ void k_chain_global(const vmx_anchor* anchors, const int64_t* aoff, const int32_t* rlist, int nlist, int lds_cap,
                                vmx_tables tab, const double* gapcost_list, double oskipcost, int omaxdiff, int maxgap,
-                               double* S_out, int32_t* P_out, int32_t* SA_out, uint8_t* cov_pool, int64_t* gmax_out, int64_t* opcount_out);
+                               double* S_out, int32_t* P_out, int32_t* SA_out, uint8_t* cov_pool, int64_t* gmax_out, int64_t* opcount_out, int rmode,
+                               double* FP_pool, double* PP_pool);
 __global__ void k_chain_global_fast(const vmx_anchor* anchors, const int64_t* aoff, int n_reads, const int64_t* roff, vmx_tables tab,
                                     const double* gapcost_list, double oskipcost, int omaxdiff, int maxgap, double* S_out, int32_t* P_out, int32_t* SA_out,
-                                    uint8_t* cov_pool, int32_t* si_pool, int64_t* t_pool, int32_t* cnt_pool, int64_t* gmax_out, int32_t* ran);
+                                    uint8_t* cov_pool, int32_t* si_pool, int64_t* t_pool, int32_t* cnt_pool, int64_t* gmax_out, int32_t* ran, int rmode,
+                                    double* FP_pool, double* PP_pool);
 __global__ void k_chain_select(const vmx_anchor* anchors, const int64_t* aoff, const int64_t* readlens, int n_reads, const double* S,
                                const int32_t* P, const int32_t* SA, const int64_t* gmax, const int32_t* need_reverse, int mode,
                                char* scratch, const int64_t* scratch_off, int32_t* out_mapq, double* out_score, int32_t* out_npaths,

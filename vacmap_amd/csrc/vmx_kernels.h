@@ -37,7 +37,7 @@ struct vmx_lseed_args {
     const uint8_t* ocodes; const int64_t* roff;            // oriented read codes
     const uint8_t* ref; const int64_t* coff; int32_t nseq;  // reference codes + contig offsets (nseq+1)
     const vmx_anchor* guide_rows; const int32_t* guide_len; const int32_t* n_guides_used; const int64_t* aoff;
-    int32_t n_reads, k, look_span, read_span;
+    int32_t n_reads, k, look_span, read_span, sort_by_start;
     const int32_t* order; int32_t* queue;                   // read indices longest first + the queue head (zero at launch)
     int64_t la_slot_len;                                    // local-anchor slot of a listed read = la_slot_len * (2 * len + 4096) rows at la_off[r]
     int32_t* head_pool; int32_t* next_pool;                 // HEAD[4^k] (all -1 between uses) / NEXT[tpos_cap] per slot

@@ -20,7 +20,7 @@ __global__ void k_chain_local_fast(const vmx_anchor* anchors, const int64_t* la_
 __global__ void k_chain_local(const vmx_anchor* anchors, const int64_t* la_off, const int32_t* la_cnt, const int32_t* n_guides_total,
                               const int32_t* rlist, int nlist, int lds_cap, vmx_tables tab, const double* gapcost_list, double skip_exact,
                               double skip_mm, int maxdiff, int maxgap, int mode, double* S_pool, int32_t* P_pool, int32_t* SA_pool, double* out_score,
-                              vmx_anchor* out_chain, int32_t* out_len, int32_t* out_variant, int32_t* status);
+                              vmx_anchor* out_chain, int32_t* out_len, int32_t* out_variant, int32_t* status, double* FP_pool, double* PP_pool);
 
 // Inputs on the device: oriented read codes + offsets; paths (rows at aoff[r], lengths at aoff[r]+p, n_paths[r]); gscore[r] (0 = unmapped).
 // h_roff / h_aoff are the host copies of the offsets. Leaves in L: la_off (device+host), chain rows / len / score / variant / status.
@@ -29,7 +29,6 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
                     const int64_t* d_aoff, const std::vector<int64_t>& h_aoff, const double* d_gscore, vmx_local_bufs& L) {
     const int k = prm->local_kmersize;
     if (k < 5 || k > 11) { set_error("local k-mer size must be in [5,11]"); return VM_ERR_UNSUPPORTED; }
-    if (prm->mode == VM_MODE_R) { set_error("mode R local stage (scar chain, +-2000/+-500 windows) not built yet"); return VM_ERR_UNSUPPORTED; }
     if (prm->local_maxdiff > 62) { set_error("local_maxdiff > 62 unsupported"); return VM_ERR_UNSUPPORTED; }
     const int64_t tot_anchors = h_aoff[n];
     int64_t Lmax = 1;
@@ -90,7 +89,9 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         VMX_TRY(L.la_cnt.reserve(4 * (size_t)(n + 1))); VMX_TRY(L.status.reserve(4 * (size_t)(n + 1)));
         A.ocodes = d_ocodes; A.roff = d_roff; A.ref = ix.codes; A.coff = ix.coff; A.nseq = ix.nseq;
         A.guide_rows = L.guide_rows.as<vmx_anchor>(); A.guide_len = L.guide_len.as<int32_t>(); A.n_guides_used = L.ng_used.as<int32_t>(); A.aoff = d_aoff;
-        A.n_reads = cnt; A.k = k; A.look_span = 7000; A.read_span = 7000;   // :23094, :23190
+        A.n_reads = cnt; A.k = k;
+        A.look_span = prm->mode == VM_MODE_R ? 2000 : 7000; A.read_span = prm->mode == VM_MODE_R ? 500 : 7000;   // :23094, :23190 / mammap_noprefercloser.py:23631+
+        A.sort_by_start = prm->mode == VM_MODE_R ? 1 : 0;
         A.queue = L.rorder.as<int32_t>(); A.order = L.rorder.as<int32_t>() + 1;
         A.head_pool = L.cnt.as<int32_t>(); A.next_pool = L.cur.as<int32_t>(); A.sq_pool = L.sq.as<int32_t>(); A.dst_pool = L.dst.as<int32_t>(); A.tpos_pool = L.tpos.as<int64_t>(); A.tpos_cap = tpos_cap;
         VMX_TRY(L.hkey2.reserve(8 * (size_t)G * (size_t)hit_cap));
@@ -149,7 +150,8 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     // LC DP
     const HostTables& T = host_tables();
     std::vector<double> gap(64, 0.0);
-    for (int g = 1; g <= prm->local_maxdiff; ++g) gap[g] = g <= 10 ? (0.01 * k * g + 0.5 * T.log2int[g]) : (0.01 * k * g + 2 * T.log2int[g]);   // :27317-27322
+    for (int g = 1; g <= prm->local_maxdiff; ++g)
+        gap[g] = (g <= 10 || prm->mode == VM_MODE_R) ? (0.01 * k * g + 0.5 * T.log2int[g]) : (0.01 * k * g + 2 * T.log2int[g]);   // :27317-27322; _scar: 0.5*log2 throughout (mammap_noprefercloser.py:23432)
     VMX_TRY(upload(L.gap, gap.data(), 64, c->stream));
     // LDS buckets by anchor count (24 B per anchor): a workgroup claims only what its read needs, so 4-12 reads share a CU.
     // Inside a bucket the reads are ordered longest first and every read is its own workgroup: the dispatcher hands them out in
@@ -181,6 +183,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
 #ifndef VMX_EMU
     VMX_HIP(hipFuncSetAttribute((const void*)k_chain_local, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)caps[NB - 1] * VMX_LC_BYTES_PER_ANCHOR + 64)));
 #endif
+    if (prm->mode == VM_MODE_R) { VMX_TRY(L.fp.reserve(8 * (size_t)(la_tot + 1))); VMX_TRY(L.pp.reserve(8 * (size_t)(la_tot + 1))); }   // _scar's fixed_penatly / pre_penatly
     vmx_fork fk(c);                                                   // independent LDS buckets side by side, largest reads first
     for (int q = NB; q >= 0; --q) {
         int cnt = (int)lists[q].size();
@@ -190,7 +193,8 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         hipLaunchKernelGGL(k_chain_local, dim3((unsigned)cnt), dim3(64), shmem, fk.next(), L.la_sorted.as<vmx_anchor>(),
                            L.la_off.as<int64_t>(), L.la_cnt.as<int32_t>(), L.ng_total.as<int32_t>(), L.rlist.as<int32_t>() + rl_off[q], cnt, cap, c->tables,
                            L.gap.as<double>(), skip_exact, skip_mm, prm->local_maxdiff, maxgap, prm->mode, L.S.as<double>(), L.P.as<int32_t>(), L.SA.as<int32_t>(),
-                           L.score.as<double>(), L.chain.as<vmx_anchor>(), L.chain_len.as<int32_t>(), L.variant.as<int32_t>(), L.status.as<int32_t>());
+                           L.score.as<double>(), L.chain.as<vmx_anchor>(), L.chain_len.as<int32_t>(), L.variant.as<int32_t>(), L.status.as<int32_t>(),
+                           L.fp.as<double>(), L.pp.as<double>());
     }
     fk.join();
     // L5: reads whose LC launch hit the opcount switch (:27380 / :28333) take the *_fast twin. One wave per read; all other reads
