@@ -290,7 +290,7 @@ def check_local_golden(ctx, O, golden, cases=('A', 'B', 'C', 'D')):
         for x, ri in enumerate(keys):
             r = c['reads'][ri]; key = '%s_r%d' % (cid, ri); g = res[x]
             o = O.local_chain(oi, seqs[x], paths[x], oprm)
-            oraw = o['raw'][np.argsort(o['raw'][:, 0] + o['raw'][:, 3], kind='stable')] if len(o['raw']) else o['raw']
+            oraw = o['raw'][np.argsort(o['raw'][:, 0] + (0 if c['mode'] == 'R' else o['raw'][:, 3]), kind='stable')] if len(o['raw']) else o['raw']
             assert g['status'] == 0, (key, g['status'])
             assert np.array_equal(g['raw'], oraw), key + ' raw local anchors differ from the oracle'
             assert g['variant'] == o['variant'] and g['score'] == o['score'] and np.array_equal(g['chain'], o['chain']), key + ' chain vs oracle'

@@ -87,9 +87,13 @@ def test_chain_fast_variants(ctx, oracle, golden):
     KC.check_align_golden(ctx, oracle, golden, cases=['E', 'F'])
 
 
-def test_mode_r_and_s(ctx, oracle):
+def test_mode_r_and_s(ctx, oracle, golden):
     """modes R (BASELINE config 5) and S through the whole path, and R's GC-fast on synthetic dense anchor sets"""
     KC.check_chain_global_fast_synth(ctx, oracle, seed=43, n_reads=4, L=500, per_pos=7, mode='R')
     assert KC.check_align_random(ctx, oracle, mode='R', n=160, seed=61, reflen=400000, mean_len=9000, nthreads=32) >= 160
     assert KC.check_align_random(ctx, oracle, mode='R', n=64, seed=62, reflen=300000, mean_len=7000, err=0.01, nthreads=32) >= 64
     assert KC.check_align_random(ctx, oracle, mode='S', n=96, seed=63, reflen=300000, mean_len=8000, err=0.12, nthreads=32) >= 96
+    # golden case G: records, local chains and global chains captured from mammap_noprefercloser.py
+    KC.check_chain_global_golden(ctx, oracle, golden, cases=['G'])
+    KC.check_local_golden(ctx, oracle, golden, cases=['G'])
+    KC.check_align_golden(ctx, oracle, golden, cases=['G'])

@@ -63,17 +63,24 @@ def run_case(cid, mode, names, contigs, reads, k, arrays, meta):
                 arrays[key + '_v2f_S'] = np.asarray(Sf, dtype=np.float64)
                 arrays[key + '_v2f_P'] = np.asarray(Pf, dtype=np.int64)
                 arrays[key + '_v2f_Sarg'] = np.asarray(SAf, dtype=np.int64)
-        mapq, scores, path, factor, rpl = m.decode_hit(al, ctx.index2contig, seq, L, ctx.contig2start, k, ctx.contig2seq,
-                                                     skipcost=(ctx.option['golbal_skipcost'],) * 2,
-                                                     maxdiff=(ctx.option['golbal_maxdiff'],) * 2, maxgap=200, check_num=100,
-                                                     c_bias=5000, bin_size=100, overlapprecentage=0.5, hastra=False, H=False, mid_occ=-1)
+        try:
+            mapq, scores, path, factor, rpl = m.decode_hit(al, ctx.index2contig, seq, L, ctx.contig2start, k, ctx.contig2seq,
+                                                         skipcost=(ctx.option['golbal_skipcost'],) * 2,
+                                                         maxdiff=(ctx.option['golbal_maxdiff'],) * 2, maxgap=200, check_num=100,
+                                                         c_bias=5000, bin_size=100, overlapprecentage=0.5, hastra=False, H=False, mid_occ=-1)
+        except UnboundLocalError:      # mode R: `factor` is unbound when <= 2 anchors survive (mammap_noprefercloser.py:24417)
+            mapq, scores, path, factor, rpl = 0, 0., [], 0, []
+            rec['v2_raised'] = True
         rec['v2_mapq'] = int(mapq); rec['v2_score'] = float(scores)
         rec['v2_paths'] = [rows(p) for p in rpl]
         # V3: capture the LC DP's input (raw local anchors, sorted by q+l) and its output
         cap = {}
         names_lc = ['get_optimal_chain_sortbyreadpos_forSV_inv_test_merged_fine_list',
-                    'get_optimal_chain_sortbyreadpos_forSV_inv_test_merged_fine_list_mismatch']
-        orig = {n: getattr(m, n) for n in names_lc}
+                    'get_optimal_chain_sortbyreadpos_forSV_inv_test_merged_fine_list_mismatch',
+                    'get_optimal_chain_sortbyreadpos_forSV_inv_test_merged_fine_list_scar']       # variant 0 / 1 / 2 (mode R)
+        if mode == 'R':
+            names_lc = [None, None, names_lc[2]]
+        orig = {n: getattr(m, n) for n in names_lc if n}
 
         def mk(n):
             def f(one_mapinfo, **kw):
@@ -81,8 +88,9 @@ def run_case(cid, mode, names, contigs, reads, k, arrays, meta):
                 return orig[n](one_mapinfo, **kw)
             return f
         for n in names_lc:
-            setattr(m, n, mk(n))
-        names_fast = [n + '_fast' for n in names_lc]
+            if n:
+                setattr(m, n, mk(n))
+        names_fast = [n + '_fast' for n in names_lc[:2] if n]
         orig_fast = {n: getattr(m, n) for n in names_fast}
 
         def mkf(n):
@@ -96,7 +104,8 @@ def run_case(cid, mode, names, contigs, reads, k, arrays, meta):
         st, one = ctx.align(rname, seq)
         dplog = refrun.DPLOG; refrun.DPLOG = None
         for n in names_lc:
-            setattr(m, n, orig[n])
+            if n:
+                setattr(m, n, orig[n])
         for n in names_fast:
             setattr(m, n, orig_fast[n])
         rec['v3_fast'] = cap.get('fast', -1)
@@ -185,6 +194,12 @@ def main():
           ('dupArray1', synth.revcomp(synth.mutate(e0[t1 + 6960 - 2500:t1 + 6960 + 2500], 0.08, rng))),
           ('soloArray0', synth.mutate(e0[t2 - 1500:t2 + 9200 + 1500], 0.08, rng))]
     run_case('F', 'H', ['chrA', 'chrB'], cE, [(n, synth.tostr(x)) for n, x in rF], 15, arrays, meta)
+    # case G: mode R (mammap_noprefercloser.py; BASELINE config 5 shape): reads from the SV donor of case B + a chimera + an unmappable read
+    rG = synth.sample_reads([d0, contigs[1]], 6, mean_len=7000, err=0.08, seed=130, shape='ont', min_len=2500, max_len=11000)
+    lG = [(n_, synth.tostr(s_)) for n_, s_, _ in rG]
+    lG.append(('chimR', synth.tostr(np.concatenate([rG[0][1][:2500], synth.revcomp(rG[1][1][:2500])]))))
+    lG.append(('randR', synth.tostr(synth.make_reference([2500], seed=131)[0])))
+    run_case('G', 'R', ['chrA', 'chrB'], [synth.tostr(c) for c in contigs], lG, 15, arrays, meta)
     # V7: the reference's own known-answer tests for nm_from_cigar (tests/test_nm_from_cigar.py) — evaluate the inputs of each
     # test through the reference function and store (cigar, query, ref, expected NM)
     of = refrun.refload.load_output_functions()
