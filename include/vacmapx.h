@@ -31,7 +31,7 @@ typedef enum vm_status {
     /* per-read statuses (status_per_read of vm_align_batch); the reference skips such reads (:24116-24125) */
     VM_READ_RAISED = -10,       /* the reference's Python would have raised inside the per-read path */
     VM_READ_CAPACITY = -20,     /* a device work buffer overflowed for this read (reported, never silently truncated) */
-    VM_READ_FASTPATH = -21      /* the reference would switch to a `_fast` chain heuristic (:23570, :24914, :27380) that is not built yet */
+    VM_READ_FASTPATH = -21      /* internal hand-off to the `_fast` chain kernels (:23570, :24914, :27380); never returned by vm_align_batch */
 } vm_status;
 
 enum { VM_MODE_H = 0, VM_MODE_L = 1, VM_MODE_S = 2, VM_MODE_R = 3 };   /* -mode (src/vacmap/vacmap:87) */
