@@ -32,6 +32,7 @@ def main():
     ap.add_argument('--err', type=float, default=0.10)
     ap.add_argument('--cpu-sample', type=int, default=96, help='minimum reads for the CPU baseline leg (rank 0, N=1 only); 0 disables')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='target wall time of the CPU baseline leg (the sample is sized by a pilot)')
+    ap.add_argument('--streams', type=int, default=2, help='batches in flight per GPU: one context (HIP stream set + work pools) and one host thread each')
     ap.add_argument('--verify', type=int, default=8, help='reads of the first batch cross-checked against the oracle (0 disables)')
     args = ap.parse_args()
 
@@ -93,32 +94,62 @@ def main():
     # optional cross-check of the first batch against the oracle (checker only; outside the timed region)
     verified = None
     oi = None
+    # S contexts per GPU (vm_ctx = HIP streams + work pools; "one per host thread per GPU", include/vacmapx.h): batches of different
+    # contexts overlap on the device, so the latency-bound chain / re-seeding kernels of one batch run under the VALU-bound DP of another
+    nstream = max(1, min(args.streams, nsteps))
+    ctxs = [ctx] + [Context(local_rank) for _ in range(nstream - 1)]
     for s in range(args.warmup):
-        st, recs, stats = resident[warm[s]].align(index, prm, want_records=(s == 0 and args.verify > 0 and rank == 0))
-        if s == 0 and args.verify > 0 and rank == 0:
-            import oracle_lib as O
-            oi = O.Index.from_seqs(['chr1'], [contigs[0].tobytes()], k=15, w=10)
-            op = O.params('H')
-            cat, off = batches[warm[0]]
-            ok = 0
-            for i in np.linspace(0, args.reads_per_step - 1, min(args.verify, args.reads_per_step)).astype(int):
-                rd = cat[off[i]:off[i + 1]].tobytes()
-                ost, orecs = O.align_read(oi, rd, op)
-                mine = [t[1:] for t in recs if t[0] == i]
-                ok += int((st[i] == 0) == (ost == 0) and mine == [t[1:] for t in orecs])
-            verified = '%d/%d' % (ok, min(args.verify, args.reads_per_step))
+        for ci, cx in enumerate(ctxs):      # every context is warmed on the same batches (sizes its pools)
+            st, recs, stats = resident[warm[s]].align(index, prm, want_records=(ci == 0 and s == 0 and args.verify > 0 and rank == 0), ctx=cx)
+            if ci == 0 and s == 0 and args.verify > 0 and rank == 0:
+                import oracle_lib as O
+                oi = O.Index.from_seqs(['chr1'], [contigs[0].tobytes()], k=15, w=10)
+                op = O.params('H')
+                cat, off = batches[warm[0]]
+                ok = 0
+                for i in np.linspace(0, args.reads_per_step - 1, min(args.verify, args.reads_per_step)).astype(int):
+                    rd = cat[off[i]:off[i + 1]].tobytes()
+                    ost, orecs = O.align_read(oi, rd, op)
+                    mine = [t[1:] for t in recs if t[0] == i]
+                    ok += int((st[i] == 0) == (ost == 0) and mine == [t[1:] for t in orecs])
+                verified = '%d/%d' % (ok, min(args.verify, args.reads_per_step))
 
+    import threading
     agg = {}
+    lock = threading.Lock()
+    nxt = [0]
+    errs = []
+
+    def worker(cx):
+        try:
+            while True:
+                with lock:
+                    s = nxt[0]; nxt[0] += 1
+                if s >= nsteps:
+                    return
+                st, _, stats = resident[s].align(index, prm, want_records=False, ctx=cx)     # ctypes releases the GIL for the call
+                with lock:
+                    for k, v in stats.items():
+                        if k != 'ms_stage':
+                            agg[k] = agg.get(k, 0) + v
+                    agg['ms_stage'] = [a + b for a, b in zip(agg.get('ms_stage', [0.0] * 16), stats['ms_stage'])]
+        except Exception as e:      # noqa: a failed batch must fail the bench, not hang it
+            errs.append(e)
+
     barrier()
     t1 = time.time()
-    for s in range(nsteps):
-        st, _, stats = resident[s].align(index, prm, want_records=False)
-        for k, v in stats.items():
-            if k != 'ms_stage':
-                agg[k] = agg.get(k, 0) + v
-        agg['ms_stage'] = [a + b for a, b in zip(agg.get('ms_stage', [0.0] * 16), stats['ms_stage'])]
+    if nstream == 1:
+        worker(ctxs[0])
+    else:
+        th = [threading.Thread(target=worker, args=(cx,)) for cx in ctxs]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
     barrier()
     dt = time.time() - t1
+    if errs:
+        raise errs[0]
 
     vals = torch.tensor([dt, float(agg['aligned_bases']), float(agg['n_reads']), float(agg['read_bases']), float(agg['n_failed'])], dtype=torch.float64, device='cuda')
     if dist is not None:
@@ -188,7 +219,7 @@ def main():
             'vs_baseline': None, 'dtype': 'int32+f64', 'data': 'synthetic',
             'config': {'workload': 'configs[1]: synthetic ONT reads (Gamma mean %d bp, %.0f%% err) vs %.0f Mb synthetic ref, -mode H -k 15 -w 10 -c 100' % (
                 args.mean_len, args.err * 100, args.ref_mb), 'reads_per_step_per_gpu': args.reads_per_step, 'reads_timed': int(nreads),
-                'parallelism': 'reads sharded over %d GPU(s), index replicated' % world},
+                'parallelism': 'reads sharded over %d GPU(s), index replicated, %d batches in flight per GPU' % (world, nstream)},
             'reads_per_s': nreads / dt_all, 'input_Gbp_per_s': rbases / dt_all / 1e9, 'failed_reads': int(nfail), 'unmapped_reads': int(agg['n_unmapped']),
             'device_ms_per_step': agg['ms_total'] / K, 'stage_ms_per_step': [x / K for x in agg['ms_stage'][:8]],
             'stage_names': ['seed', 'global_chain', 'local', 'divergence_filter', 'edge_extension', 'gapfill+records', 'nofilter_redo', 'download'],

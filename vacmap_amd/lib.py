@@ -324,10 +324,11 @@ class ResidentReads:
         ctx.lib.check(ctx.lib.L.vm_reads_upload(ctx.h, self.n, s, off.ctypes.data, C.byref(h)))
         self.h = h
 
-    def align(self, index, prm, want_records=True):
+    def align(self, index, prm, want_records=True, ctx=None):
+        """ctx: the context (streams + work pools) to run on; default = the one that uploaded the reads"""
         status = np.zeros(max(self.n, 1), np.int32)
         recs = C.POINTER(Record)(); nrec = C.c_int64(); blob = C.c_void_p(); stats = BatchStats()
-        self.ctx.lib.check(self.ctx.lib.L.vm_align_resident(self.ctx.h, index.h, C.byref(prm), self.h, C.byref(recs), C.byref(nrec), C.byref(blob),
+        self.ctx.lib.check(self.ctx.lib.L.vm_align_resident((ctx or self.ctx).h, index.h, C.byref(prm), self.h, C.byref(recs), C.byref(nrec), C.byref(blob),
                                                             status.ctypes.data, C.byref(stats)))
         if want_records:
             out, sd = _collect_records(self.ctx, recs, nrec.value, blob, stats)
