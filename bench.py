@@ -227,7 +227,7 @@ def main():
             'per_read': {'minimizers': agg['n_minimizers'] / max(agg['n_reads'], 1), 'anchors': agg['n_anchors'] / max(agg['n_reads'], 1),
                          'local_anchors': agg['n_local_anchors'] / max(agg['n_reads'], 1), 'dp_problems': agg['n_dp_problems'] / max(agg['n_reads'], 1),
                          'dp_cells': agg['dp_cells'] / max(agg['n_reads'], 1), 'records': agg['n_records'] / max(agg['n_reads'], 1)},
-            'ed_problems_per_step': agg['n_ed_problems'] / K, 'ed_unbanded_per_step': agg.get('n_ed_full', 0) / K,
+            'ed_problems_per_step': agg['n_ed_problems'] / K, 'ed_tier1_per_step': agg.get('n_ed_tier1', 0) / K, 'ed_tier2_per_step': agg.get('n_ed_tier2', 0) / K, 'ed_unbanded_per_step': agg.get('n_ed_full', 0) / K,
             'oracle_crosscheck': verified, 'setup_s': t_setup, 'index_build_s': t_index,
             'roofline': roofline, 'cpu_baseline': cpu,
         }

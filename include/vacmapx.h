@@ -152,10 +152,12 @@ int vm_k_cigar(vm_ctx*, const char* t, int64_t tl, const char* q, int64_t ql, co
 int vm_edit_distance_batch(vm_ctx*, int64_t n, const char* q, const int64_t* q_off, const char* t, const int64_t* t_off,
                            int64_t** dist);
 int64_t vm_edit_distance(vm_ctx*, const char* q, int64_t ql, const char* t, int64_t tl);
-/* banded form used by the divergence filter of vm_align_batch: bound[i] >= editDistance, equal to it when the optimal path
- * stays within 768 rows of the diagonal band; -1 when |len(q) - len(t)| > 512 (not eligible). The filter keeps a segment when
- * bound / min(len) <= maxdivergence and recomputes the exact distance otherwise, so its decisions equal the reference's. */
-int vm_edit_distance_bound_batch(vm_ctx*, int64_t n, const char* q, const int64_t* q_off, const char* t, const int64_t* t_off,
+/* banded forms used by the divergence filter of vm_align_batch: bound[i] >= editDistance, equal to it when the optimal path stays
+ * inside the band; -1 when |len(q) - len(t)| exceeds the tier's window (not eligible). tier 1: four problems per wavefront, band of
+ * +-320 rows, window 256; tier 2: one problem per wavefront, +-768 rows, window 512. The filter keeps a segment when
+ * bound / min(len) <= maxdivergence and passes it to the next tier (finally the exact kernel) otherwise, so its decisions equal the
+ * reference's. */
+int vm_edit_distance_bound_batch(vm_ctx*, int tier, int64_t n, const char* q, const int64_t* q_off, const char* t, const int64_t* t_off,
                                  int64_t** bound);
 
 /* ------------------------------------------------------------------ the batched path (the GPU entry) */
@@ -181,7 +183,9 @@ typedef struct vm_batch_stats {     /* measured on the device, for bench.py's ro
     double ms_gapfill_fill;         /* k_gapfill_fill launches only (HIP events on the stream the kernel runs on) */
     double ms_gapfill_trace;        /* k_gapfill_trace launches only */
     int64_t n_gapfill_launches;
-    int64_t n_ed_full;              /* divergence-filter problems the banded kernel could not settle (re-run unbanded) */
+    int64_t n_ed_full;              /* divergence-filter problems the banded kernels could not settle (re-run unbanded) */
+    int64_t n_ed_tier2;             /* problems the four-per-wave band could not settle (re-run in the wide band) */
+    int64_t n_ed_tier1;             /* problems the anchor bound could not settle (re-run in the four-per-wave band) */
 } vm_batch_stats;
 
 /* Align n reads (replaces get_readmap_DP_test per read). seqs concatenated, offsets[n+1].

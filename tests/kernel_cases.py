@@ -47,7 +47,7 @@ def check_edit_distance(ctx, O, n=32, maxlen=600, seed=1, minlen=0):
     assert got.tolist() == exp
 
 
-def check_edit_distance_bound(ctx, O, seed=5, lens=(1, 63, 64, 65, 700, 1600, 3000, 6500), big=True):
+def check_edit_distance_bound(ctx, O, seed=5, lens=(1, 63, 64, 65, 700, 1600, 3000, 6500), big=True, tier=2):
     """banded upper bound of the divergence filter: exact on near-diagonal pairs, never below the exact distance,
     -1 outside its eligibility window"""
     rng = np.random.default_rng(seed)
@@ -56,7 +56,7 @@ def check_edit_distance_bound(ctx, O, seed=5, lens=(1, 63, 64, 65, 700, 1600, 30
         for rate in (0.0, 0.1, 0.25):
             a = rand_seq(rng, L)
             b = mutate(rng, a, rate)
-            if abs(len(a) - len(b)) > 500 or not b:
+            if abs(len(a) - len(b)) > (500 if tier == 2 else 250) or not b:
                 continue
             qs.append(a); ts.append(b); kind.append('exact')
             qs.append(b); ts.append(a); kind.append('exact')
@@ -73,9 +73,9 @@ def check_edit_distance_bound(ctx, O, seed=5, lens=(1, 63, 64, 65, 700, 1600, 30
         qs.append(a); ts.append(b); kind.append('bound')
         qs.append(b); ts.append(a); kind.append('bound')
         a = rand_seq(rng, 4300); b = mutate(rng, a, 0.12)     # > 64 blocks: lanes are reused
-        if abs(len(a) - len(b)) <= 500:
+        if abs(len(a) - len(b)) <= (500 if tier == 2 else 250):
             qs.append(a); ts.append(b); kind.append('exact')
-    got = ctx.edit_distance_bound_batch(qs, ts).tolist()
+    got = ctx.edit_distance_bound_batch(qs, ts, tier=tier).tolist()
     for q, t, k, g in zip(qs, ts, kind, got):
         e = O.edit_distance(q, t)
         if k == 'exact':

@@ -22,6 +22,7 @@ def test_emu_edit_distance(ctx, oracle):
 
 def test_emu_edit_distance_bound(ctx, oracle):
     KC.check_edit_distance_bound(ctx, oracle, seed=5, lens=(1, 63, 64, 65, 700, 1700), big=True)
+    KC.check_edit_distance_bound(ctx, oracle, seed=6, lens=(1, 63, 64, 65, 700, 1300), big=True, tier=1)      # four problems per wave
 
 
 def test_emu_extend(ctx, oracle):

@@ -25,6 +25,8 @@ def test_edit_distance(ctx, oracle):
 def test_edit_distance_bound(ctx, oracle):
     KC.check_edit_distance_bound(ctx, oracle, seed=21)
     KC.check_edit_distance_bound(ctx, oracle, seed=22, lens=(2, 100, 800, 2500, 9000, 20000))
+    KC.check_edit_distance_bound(ctx, oracle, seed=23, tier=1)
+    KC.check_edit_distance_bound(ctx, oracle, seed=24, lens=(3, 17, 130, 900, 2500, 9000, 20000), tier=1)
 
 
 def test_extend(ctx, oracle):

@@ -306,3 +306,103 @@ __global__ void k_ext_records(vmx_ext_args A, const vmx_dp_prob* __restrict__ pr
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------ divergence filter, tier 0
+// An upper bound of the segment's edit distance from its own anchors: cutting the (query, target) pair of the problem at the start
+// corner of every anchor gives pieces of an anchor (an exact match: counted by direct comparison) plus the short gap behind it
+// (rebuild_chain_break keeps read gaps < 100, :23437-23484), and the sum of the pieces' costs is the cost of ONE valid alignment,
+// hence >= the edit distance whatever the anchors are. For a read at the divergence the filter tolerates this bound is already
+// below the threshold, which settles the segment without the 10^4-step serial bit-vector DP over the whole segment; the pieces
+// are independent, one lane each. A segment whose corners are not monotone in both strings, or with a gap longer than 256 rows,
+// gets -1 and goes to the banded tiers (k_ed_band.hip).
+__device__ inline int vmx_ed_small(const uint8_t* P, int m, const uint8_t* T, int n) {       // exact unit-cost distance, m <= 256
+    if (m == 0) return n;
+    if (n == 0) return m;
+    const int W = (m + 63) >> 6;
+    unsigned long long q0[4] = {0, 0, 0, 0}, q1[4] = {0, 0, 0, 0}, q2[4] = {0, 0, 0, 0}, q3[4] = {0, 0, 0, 0}, q4[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < W) {
+            int lim = m - (w << 6); if (lim > 64) lim = 64;
+            unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+            for (int x = 0; x < lim; ++x) {
+                const uint8_t c = P[(w << 6) + x]; const unsigned long long bit = 1ULL << x;
+                if (c == 0) a0 |= bit; else if (c == 1) a1 |= bit; else if (c == 2) a2 |= bit; else if (c == 3) a3 |= bit; else a4 |= bit;
+            }
+            q0[w] = a0; q1[w] = a1; q2[w] = a2; q3[w] = a3; q4[w] = a4;
+        }
+    }
+    unsigned long long Pv[4] = {~0ULL, ~0ULL, ~0ULL, ~0ULL}, Mv[4] = {0, 0, 0, 0};
+    int score = m;
+    const int lastbit = (m - 1) & 63;
+    for (int j = 0; j < n; ++j) {
+        const int c = T[j];
+        int hin = 1;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < W) {
+                unsigned long long Eq = c == 0 ? q0[w] : (c == 1 ? q1[w] : (c == 2 ? q2[w] : (c == 3 ? q3[w] : q4[w])));
+                const unsigned long long neg = (unsigned long long)((unsigned)hin >> 31), pos = (unsigned long long)((unsigned)(-hin) >> 31);
+                const unsigned long long Xv = Eq | Mv[w];
+                Eq |= neg;
+                const unsigned long long Xh = (((Eq & Pv[w]) + Pv[w]) ^ Pv[w]) | Eq;
+                unsigned long long Ph = Mv[w] | ~(Xh | Pv[w]);
+                unsigned long long Mh = Pv[w] & Xh;
+                const int hb = (w == W - 1) ? lastbit : 63;
+                const int hout = (int)((Ph >> hb) & 1ULL) - (int)((Mh >> hb) & 1ULL);
+                Ph = (Ph << 1) | pos; Mh = (Mh << 1) | neg;
+                Pv[w] = Mh | ~(Xv | Ph);
+                Mv[w] = Ph & Xv;
+                hin = hout;
+            }
+        }
+        score += hin;        // delta of the last row
+    }
+    return score;
+}
+
+__global__ void __launch_bounds__(64) k_ed_anchor_bound(vmx_ext_args A, const int32_t* __restrict__ probread, const uint8_t* __restrict__ qpool,
+                                                        const int64_t* __restrict__ qoff, const uint8_t* __restrict__ tpool,
+                                                        const int64_t* __restrict__ toff, int64_t* __restrict__ ub_out) {
+    const int lane = vmx_lane();
+    const int n_prob = *A.round_count;
+    for (int p = (int)blockIdx.x; p < n_prob; p += (int)gridDim.x) {
+        const int r = probread[p];
+        const vmx_ext_read E = A.er[r];
+        const int s = p - E.prob_base;
+        const vmx_segs S = vmx_read_segs(A, r, false);
+        const int st = S.st[s], en = S.en[s];
+        const vmx_anchor first = S.A[st], last = S.A[en - 1];
+        const uint8_t* Q = qpool + qoff[p]; const int ql = (int)(qoff[p + 1] - qoff[p]);
+        const uint8_t* T = tpool + toff[p]; const int tl = (int)(toff[p + 1] - toff[p]);
+        const int K = en - 1 - st;                      // anchors inside the strings (the last one only contributes its start)
+        const bool fwd = first.s == 1;
+        long long cost = 0; bool bad = false;
+        // corner k in string order: + strand anchors st .. en-2 ascending, - strand en-2 .. st (the query string is the reversed read)
+        for (int k = lane - 1; k < K; k += 64) {
+            int u0, v0, l0, u1, v1;
+            if (k < 0) { u0 = 0; v0 = 0; l0 = 0; }         // leading piece from the string start to the first corner (lane 0)
+            else {
+                const vmx_anchor a = fwd ? S.A[st + k] : S.A[en - 2 - k];
+                u0 = fwd ? a.q - first.q : last.q - (a.q + a.l);
+                v0 = fwd ? (int)(a.r - first.r) : (int)(a.r - (last.r + last.l));
+                l0 = a.l;
+            }
+            if (k + 1 < K) {
+                const vmx_anchor b = fwd ? S.A[st + k + 1] : S.A[en - 2 - (k + 1)];
+                u1 = fwd ? b.q - first.q : last.q - (b.q + b.l);
+                v1 = fwd ? (int)(b.r - first.r) : (int)(b.r - (last.r + last.l));
+            } else { u1 = ql; v1 = tl; }
+            if (u0 < 0 || v0 < 0 || u1 < u0 || v1 < v0 || u1 > ql || v1 > tl) { bad = true; continue; }
+            int lm = l0; if (lm > u1 - u0) lm = u1 - u0; if (lm > v1 - v0) lm = v1 - v0;       // matched part that fits before the next corner
+            int mism = 0;
+            for (int x = 0; x < lm; ++x) mism += Q[u0 + x] != T[v0 + x] ? 1 : 0;
+            const int gm = u1 - (u0 + lm), gn = v1 - (v0 + lm);
+            if (gm > 256) { bad = true; continue; }
+            cost += mism + vmx_ed_small(Q + u0 + lm, gm, T + v0 + lm, gn);
+        }
+        const long long tot = vmx_wave_sum_i64(cost);
+        const bool anybad = __any(bad) || K < 0;
+        if (lane == 0) ub_out[p] = anybad ? -1LL : tot;
+    }
+}

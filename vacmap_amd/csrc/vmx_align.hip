@@ -14,6 +14,8 @@ using namespace vmx;
 __global__ void k_orient(const uint8_t* codes, const int64_t* roff, const double* gscore, int n_reads, uint8_t* ocodes);
 __global__ void k_scan_i64(const int64_t* in, int64_t* out, int64_t n, int pow2_round);
 __global__ void k_ext_phase(vmx_ext_args A, int phase);
+__global__ void k_ed_anchor_bound(vmx_ext_args A, const int32_t* probread, const uint8_t* qpool, const int64_t* qoff, const uint8_t* tpool, const int64_t* toff,
+                                  int64_t* ub_out);
 __global__ void k_desc_lens(const vmx_pair_desc* desc, const int32_t* n_prob, int64_t* tl, int64_t* ql);
 __global__ void k_gather(const vmx_pair_desc* desc, const int32_t* n_prob, const int32_t* prob_read, const uint8_t* ocodes, const int64_t* roff,
                          const uint8_t* ref, const int64_t* t_off, const int64_t* q_off, uint8_t* tpool, uint8_t* qpool, int64_t pool_cap, int32_t* overflow);
@@ -297,13 +299,25 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
             VMX_TRY(B.order.reserve(4 * (size_t)(round_cap + 1))); VMX_TRY(B.qrange.reserve(64));
             int32_t* d_range = B.qrange.as<int32_t>(); int32_t* d_cnt = d_range + 4; int32_t* d_nfull = d_range + 8;
             VMX_TRY(B.dpsz[0].reserve(8 * (size_t)(cnt + 2))); VMX_TRY(B.dpsz[1].reserve(8 * (size_t)(cnt + 2)));
-            // banded upper bound first (k_ed_band.hip); only problems it cannot settle go to the unbanded kernel
-            hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.ql.as<int64_t>(), B.rcount.as<int32_t>(), (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt);
+            // tier 0 (k_ed_anchor_bound, k_ext.hip): the segment's own anchors cut the pair into independent short pieces whose summed cost
+            // bounds the edit distance from above; then (k_ed_band.hip) four problems per wave in a +-320-row band, one problem per wave in
+            // a +-768-row band, and the exact unbanded kernel, each only for the problems the tier before could not prove "keep" for
+            int32_t* d_n2 = d_range + 9; int32_t* d_n1 = d_range + 10;
+            (void)hipMemsetAsync(d_nfull, 0, 12, c->stream);
+            hipLaunchKernelGGL(k_ed_anchor_bound, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, A, B.probread.as<int32_t>(),
+                               B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.dpsz[1].as<int64_t>());
+            hipLaunchKernelGGL(k_ed_flag, dim3((unsigned)std::min<int64_t>((cnt + 255) / 256, 1024)), dim3(256), 0, c->stream, B.dpsz[1].as<int64_t>(), B.qoff.as<int64_t>(), B.toff.as<int64_t>(),
+                               B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_n1, 1);
+            hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt);
+            hipLaunchKernelGGL(k_ed_banded4, dim3((unsigned)std::min<int64_t>((cnt + 3) / 4, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(),
+                               B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.order.as<int32_t>(), d_range, d_cnt + 2, B.dpsz[1].as<int64_t>());
+            hipLaunchKernelGGL(k_ed_flag, dim3((unsigned)std::min<int64_t>((cnt + 255) / 256, 1024)), dim3(256), 0, c->stream, B.dpsz[1].as<int64_t>(), B.qoff.as<int64_t>(), B.toff.as<int64_t>(),
+                               B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_n2, 0);
+            hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt);
             hipLaunchKernelGGL(k_ed_banded, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(),
                                B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.order.as<int32_t>(), d_range, d_cnt + 2, B.dpsz[1].as<int64_t>());
-            (void)hipMemsetAsync(d_nfull, 0, 4, c->stream);
             hipLaunchKernelGGL(k_ed_flag, dim3((unsigned)std::min<int64_t>((cnt + 255) / 256, 1024)), dim3(256), 0, c->stream, B.dpsz[1].as<int64_t>(), B.qoff.as<int64_t>(), B.toff.as<int64_t>(),
-                               B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_nfull);
+                               B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_nfull, 0);
             hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt);
             for (int which = 0; which < 2; ++which)
                 hipLaunchKernelGGL(k_edit_distance, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * (which == 0 ? 2 : 8))), dim3(which == 0 ? 64 * VMX_ED_WAVES : 256), 0, c->stream,
@@ -335,10 +349,11 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     int64_t nr = 0, nb = 0; int32_t oflow = 0;
     VMX_TRY(download(&nr, B.dpoff[0].as<int64_t>() + n, 1, c->stream)); VMX_TRY(download(&nb, B.dpoff[1].as<int64_t>() + n, 1, c->stream));
     VMX_TRY(download(&oflow, B.oflow.p, 1, c->stream));
-    int32_t n_full = 0;
-    if (st.n_ed_problems) VMX_TRY(download(&n_full, B.qrange.as<int32_t>() + 8, 1, c->stream));
+    int32_t n_full = 0, n_t2 = 0, n_t1 = 0;
+    if (st.n_ed_problems) { VMX_TRY(download(&n_full, B.qrange.as<int32_t>() + 8, 1, c->stream)); VMX_TRY(download(&n_t2, B.qrange.as<int32_t>() + 9, 1, c->stream));
+                            VMX_TRY(download(&n_t1, B.qrange.as<int32_t>() + 10, 1, c->stream)); }
     VMX_HIP(hipStreamSynchronize(c->stream));
-    st.n_ed_full = n_full;
+    st.n_ed_full = n_full; st.n_ed_tier2 = n_t2; st.n_ed_tier1 = n_t1;
     if (oflow) { set_error("extend stage: a per-batch work pool overflowed"); return VM_ERR_OOM; }
     VMX_TRY(B.totals.reserve(sizeof(vm_record) * (size_t)(nr + 1))); VMX_TRY(B.dupd.reserve((size_t)nb + 64));
     hipLaunchKernelGGL(k_res_pack, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 8)), dim3(64), 0, c->stream, B.er.as<vmx_ext_read>(), B.rec.as<vm_record>(), B.blob.as<char>(),

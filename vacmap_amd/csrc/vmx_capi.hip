@@ -160,7 +160,7 @@ int vm_edit_distance_batch(vm_ctx* c, int64_t n, const char* q, const int64_t* q
     return VM_OK;
 }
 
-int vm_edit_distance_bound_batch(vm_ctx* c, int64_t n, const char* q, const int64_t* q_off, const char* t, const int64_t* t_off, int64_t** bound) {
+int vm_edit_distance_bound_batch(vm_ctx* c, int tier, int64_t n, const char* q, const int64_t* q_off, const char* t, const int64_t* t_off, int64_t** bound) {
     if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
     *bound = nullptr;
     VMX_HIP(hipSetDevice(c->device));
@@ -174,8 +174,12 @@ int vm_edit_distance_bound_batch(vm_ctx* c, int64_t n, const char* q, const int6
         VMX_TRY(c->b[10].reserve(4 * (size_t)(n + 1))); VMX_TRY(c->b[11].reserve(64));
         int32_t* d_range = c->b[11].as<int32_t>(); int32_t* d_cnt = d_range + 4;
         hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, c->b[8].as<int64_t>(), c->b[9].as<int32_t>(), (int64_t)0, c->b[10].as<int32_t>(), d_range, d_cnt);
-        hipLaunchKernelGGL(k_ed_banded, dim3(grid_for(c, n, 16)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[2].as<int64_t>(), c->b[4].as<uint8_t>(), c->b[5].as<int64_t>(),
-                           c->b[10].as<int32_t>(), d_range, d_cnt, c->b[7].as<int64_t>());
+        if (tier == 1)
+            hipLaunchKernelGGL(k_ed_banded4, dim3(grid_for(c, (n + 3) / 4, 16)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[2].as<int64_t>(), c->b[4].as<uint8_t>(),
+                               c->b[5].as<int64_t>(), c->b[10].as<int32_t>(), d_range, d_cnt, c->b[7].as<int64_t>());
+        else
+            hipLaunchKernelGGL(k_ed_banded, dim3(grid_for(c, n, 16)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[2].as<int64_t>(), c->b[4].as<uint8_t>(), c->b[5].as<int64_t>(),
+                               c->b[10].as<int32_t>(), d_range, d_cnt, c->b[7].as<int64_t>());
     }
     *bound = host_alloc<int64_t>((size_t)n);
     VMX_TRY(download(*bound, c->b[7].p, (size_t)n, c->stream));

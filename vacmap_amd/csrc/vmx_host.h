@@ -95,8 +95,11 @@ __global__ void k_edit_distance(const uint8_t* qcodes, const int64_t* q_off, con
 __global__ void k_size_order(const int64_t* size, const int32_t* n_ptr, int64_t thresh, int32_t* order, int32_t* range, int32_t* counters);
 __global__ void k_ed_banded(const uint8_t* qcodes, const int64_t* q_off, const uint8_t* tcodes, const int64_t* t_off, const int32_t* order,
                             const int32_t* range, int32_t* counter, int64_t* ub_out);
+struct vmx_ext_args;
+__global__ void k_ed_banded4(const uint8_t* qcodes, const int64_t* q_off, const uint8_t* tcodes, const int64_t* t_off, const int32_t* order,
+                             const int32_t* range, int32_t* counter, int64_t* ub_out);
 __global__ void k_ed_flag(const int64_t* ub, const int64_t* q_off, const int64_t* t_off, const int32_t* n_ptr, double maxdiv, int64_t* sizes,
-                          int64_t* ed_out, int32_t* n_flagged);
+                          int64_t* ed_out, int32_t* n_flagged, int first);
 __global__ void k_extend(const uint8_t* tcodes, const int64_t* t_off, const uint8_t* qcodes, const int64_t* q_off, int n_prob,
                          int match, int mismatch, int o, int e, int bw_in, int zdrop, int32_t* out_te, int32_t* out_qe, int32_t* out_sc);
 __global__ void k_gapfill_fill(const uint8_t* tcodes, const uint8_t* qcodes, const vmx_dp_prob* probs, int n_prob, int match,

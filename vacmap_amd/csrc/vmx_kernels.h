@@ -55,6 +55,8 @@ struct vmx_lseed_args {
 #define VMX_ED_LONG 16384            // patterns longer than this (> 4 passes) go to the 16-wave launch
 #define VMX_EDB_HW 768               // k_ed_banded: half width of the band in rows
 #define VMX_EDB_MAXD 512             // k_ed_banded: |m - n| above this is not eligible (goes to the unbanded kernel)
+#define VMX_EDB4_HW 320              // k_ed_banded4 (four problems per wave): half width of the band; 2*HW + MAXD + 64 <= 16 blocks
+#define VMX_EDB4_MAXD 256            // k_ed_banded4: |m - n| above this goes to k_ed_banded
 #ifndef VMX_LSEED_WAVES
 #define VMX_LSEED_WAVES 4            // k_local_seed: waves per SIMD the register allocation is held to (2 workgroups of 512 per CU)
 #endif

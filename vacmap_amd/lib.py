@@ -60,7 +60,7 @@ class BatchStats(C.Structure):
                                           'dp_cells', 'n_records', 'cigar_bytes', 'aligned_bases', 'n_unmapped', 'n_failed',
                                           'dp_string_bytes')] + \
                [('ms_total', C.c_double), ('ms_stage', C.c_double * 16), ('ms_gapfill_fill', C.c_double), ('ms_gapfill_trace', C.c_double),
-                ('n_gapfill_launches', C.c_int64), ('n_ed_full', C.c_int64)]
+                ('n_gapfill_launches', C.c_int64), ('n_ed_full', C.c_int64), ('n_ed_tier2', C.c_int64), ('n_ed_tier1', C.c_int64)]
 
 
 def _b(s):
@@ -92,7 +92,7 @@ class VmxLib:
         L.vm_ctx_destroy.argtypes = [vp]
         L.vm_table.argtypes = [vp, C.c_int, P(vp)]; L.vm_table.restype = i64
         L.vm_edit_distance_batch.argtypes = [vp, i64, cp, vp, cp, vp, P(P(i64))]
-        L.vm_edit_distance_bound_batch.argtypes = [vp, i64, cp, vp, cp, vp, P(P(i64))]
+        L.vm_edit_distance_bound_batch.argtypes = [vp, C.c_int, i64, cp, vp, cp, vp, P(P(i64))]
         L.vm_edit_distance.argtypes = [vp, cp, i64, cp, i64]; L.vm_edit_distance.restype = i64
         L.vm_k_extend_batch.argtypes = [vp] + [C.c_int] * 6 + [i64, cp, vp, cp, vp, P(P(i32)), P(P(i32)), P(P(i32))]
         L.vm_k_cigar_batch.argtypes = [vp, P(Score), C.c_int, i64, cp, vp, cp, vp, P(vp), P(P(i64)), P(P(i32))]
@@ -189,10 +189,10 @@ class Context:
         self.lib.check(self.lib.L.vm_edit_distance_batch(self.h, len(queries), q, qo.ctypes.data, t, to.ctypes.data, C.byref(out)))
         return self._take(out, len(queries), np.int64)
 
-    def edit_distance_bound_batch(self, queries, targets):
+    def edit_distance_bound_batch(self, queries, targets, tier=2):
         q, qo = _cat(queries); t, to = _cat(targets)
         out = C.POINTER(C.c_int64)()
-        self.lib.check(self.lib.L.vm_edit_distance_bound_batch(self.h, len(queries), q, qo.ctypes.data, t, to.ctypes.data, C.byref(out)))
+        self.lib.check(self.lib.L.vm_edit_distance_bound_batch(self.h, tier, len(queries), q, qo.ctypes.data, t, to.ctypes.data, C.byref(out)))
         return self._take(out, len(queries), np.int64)
 
     def edit_distance(self, q, t):
