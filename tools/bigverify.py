@@ -1,0 +1,25 @@
+import sys, time, os
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import numpy as np
+import oracle_lib as O
+from vacmap_amd import synth
+from vacmap_amd.lib import Context, Index, align_batch, load
+ctx = Context(0); lib = load()
+contigs = synth.make_reference([30_000_000], seed=1)
+names = ['chr1']
+for mode, k, n, kw in (('H', 15, 3000, dict(mean_len=15000, err=0.10)), ('L', 19, 1500, dict(mean_len=15000, err=0.005)), ('R', 15, 1500, dict(mean_len=12000, err=0.10)), ('S', 15, 1000, dict(mean_len=12000, err=0.13))):
+    cat, off, _ = synth.sample_reads_concat(contigs, n, seed=77, **kw)
+    seqs = [cat[off[i]:off[i + 1]].tobytes().decode() for i in range(n)]
+    gi = Index.from_seqs(ctx, names, [contigs[0].tobytes()], k=k, w=10)
+    oi = O.Index.from_seqs(names, [contigs[0].tobytes()], k=k, w=10)
+    t = time.time(); status, recs, stats = align_batch(ctx, gi, lib.params(mode), seqs); tg = time.time() - t
+    t = time.time(); ost, orecs = O.align_batch(oi, seqs, O.params(mode), nthreads=min(os.cpu_count(), 128)); tc = time.time() - t
+    same_st = [(int(s) == 0) for s in status] == [(int(s) == 0) for s in ost]
+    bad = 0
+    if recs != orecs:
+        a = {}; b = {}
+        for t_ in recs: a.setdefault(t_[0], []).append(t_[1:])
+        for t_ in orecs: b.setdefault(t_[0], []).append(t_[1:])
+        bad = sum(1 for i in range(n) if a.get(i) != b.get(i))
+    print('mode', mode, 'reads', n, 'records', len(orecs), 'status equal', same_st, 'reads with different records', bad, 'gpu %.2fs cpu %.2fs' % (tg, tc), 'failed', int(sum(1 for s in status if s != 0)), flush=True)
+    del gi, oi

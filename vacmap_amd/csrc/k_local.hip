@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
     __shared__ int s_niv;
     __shared__ int s_flag;
     __shared__ long long s_tot;
-    __shared__ unsigned long long s_min, s_max;
+    __shared__ unsigned long long s_min, s_max, s_min2, s_max2;
     __shared__ int s_wmax[16];
     __shared__ int s_next;
     const int nw = (int)(blockDim.x >> 6);
@@ -178,16 +178,18 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             const long long* GR = g_lds ? s_gr : (const long long*)GRg;
             // --- windows (serial, thread 0): :23105-23180
             if (threadIdx.x == 0) {
+                // the block sort leaves the sorted keys in its LDS staging buffer when they fit: walk them there, not in HBM
+                const uint64_t* GK = (NN > 1 && NN <= VMX_SORT_LDS) ? s_sort : GKEY;
                 int niv = 0; bool overflow = false;
                 for (int attempt = 0; attempt < 2 && mm > 0; ++attempt) {
                     const bool split = attempt == 1;
                     niv = 0; bool retry = false;
-                    long long ws = (long long)(GKEY[0] >> 24), we = ws;
+                    long long ws = (long long)(GK[0] >> 24), we = ws;
                     int cur = vmx_pos2contig(A.coff, A.nseq, ws);
                     for (int i = 1; i <= mm; ++i) {
                         bool close_it = true; long long rr = 0;
                         if (i < mm) {
-                            rr = (long long)(GKEY[i] >> 24);
+                            rr = (long long)(GK[i] >> 24);
                             bool same = (rr - we) < readgap;
                             if (split) same = same && (cur == vmx_pos2contig(A.coff, A.nseq, rr));
                             if (same) { we = rr; close_it = false; }
@@ -225,11 +227,17 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             // --- table: one atomic exchange per window position links it in front of its 9-mer's list
             for (int v = 0; v < niv; ++v) {
                 const long long lo = s_iv[v][0], hi = s_iv[v][1]; const int base = s_ivbase[v];
-                for (long long x = lo + threadIdx.x; x < hi; x += blockDim.x) {
-                    bool ok; const uint32_t km = vmx_kmer_at(A.ref, x, k, ok);
-                    const int idx = base + (int)(x - lo);
-                    TPOS[idx] = x;
-                    if (ok) { const int old = atomicExch(&HEAD[km], idx); NEXT[idx] = old; }
+                for (long long x = lo + threadIdx.x; x < hi; x += 2 * blockDim.x) {          // two positions per round: both exchanges in flight together
+                    const long long x2 = x + blockDim.x;
+                    bool ok, ok2 = false; const uint32_t km = vmx_kmer_at(A.ref, x, k, ok);
+                    uint32_t km2 = 0; if (x2 < hi) km2 = vmx_kmer_at(A.ref, x2, k, ok2);
+                    const int idx = base + (int)(x - lo), idx2 = base + (int)(x2 - lo);
+                    TPOS[idx] = x; if (x2 < hi) TPOS[idx2] = x2;
+                    int old = -1, old2 = -1;
+                    if (ok) old = atomicExch(&HEAD[km], idx);
+                    if (ok2) old2 = atomicExch(&HEAD[km2], idx2);
+                    if (ok) NEXT[idx] = old;
+                    if (ok2) NEXT[idx2] = old2;
                 }
             }
             __syncthreads();
@@ -255,8 +263,9 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                     long long interval = (long long)b0 + b1 + 500; if (interval > 2000) interval = 2000;
                     const long long ref1 = GR[c0], ref2 = GR[c1];
                     long long rgap = (long long)iloc - GQ[c0]; if (rgap < 0) rgap = -rgap;
-                    for (int t = HEAD[fw]; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cf == 0) ff = rl; ++cf; } }
-                    if (iloc > 0) for (int t = HEAD[rv]; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cr == 0) fr = rl; ++cr; } }
+                    const int hf = HEAD[fw], hr = iloc > 0 ? HEAD[rv] : -1;              // both list heads in flight together
+                    for (int t = hf; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cf == 0) ff = rl; ++cf; } }
+                    for (int t = hr; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cr == 0) fr = rl; ++cr; } }
                 }
                 PCNT[pi] = cf + cr;
                 PC2[pi] = (cf > 0xffff ? 0xffff : cf) | ((cr > 0x7fff ? 0x7fff : cr) << 16);
@@ -315,17 +324,38 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 const long long lo = s_iv[v][0], hi = s_iv[v][1];
                 for (long long x = lo + threadIdx.x; x < hi; x += blockDim.x) { bool ok; const uint32_t km = vmx_kmer_at(A.ref, x, k, ok); if (ok) HEAD[km] = -1; }
             }
-            // group the hits by diagonal, keeping stream order inside a diagonal: stable LSD radix sort on (point - min point)
+            // group the hits by diagonal, keeping stream order inside a diagonal: stable LSD radix sort. Only the grouping matters (the order of
+            // the groups is restored by the emission keys), so the points are first mapped injectively to a dense range: forward points
+            // (r - q > 0) and reverse points (-(r + q) < 0) form two clusters ~2r apart, each only as wide as the window
             {
-                unsigned long long mn = ~0ULL, mx = 0ULL;
-                for (long long i = threadIdx.x; i < H; i += blockDim.x) { const unsigned long long pk = HKEY[i] >> 26; mn = pk < mn ? pk : mn; mx = pk > mx ? pk : mx; }
-                for (int o = 32; o > 0; o >>= 1) { unsigned long long a = __shfl_xor(mn, o), b = __shfl_xor(mx, o); mn = a < mn ? a : mn; mx = b > mx ? b : mx; }
-                if (threadIdx.x == 0) { s_min = ~0ULL; s_max = 0ULL; }
+                const unsigned long long MID = 1ULL << 36;
+                unsigned long long mnL = ~0ULL, mxL = 0ULL, mnH = ~0ULL, mxH = 0ULL;
+                for (long long i = threadIdx.x; i < H; i += blockDim.x) {
+                    const unsigned long long pk = HKEY[i] >> 26;
+                    if (pk < MID) { mnL = pk < mnL ? pk : mnL; mxL = pk > mxL ? pk : mxL; } else { mnH = pk < mnH ? pk : mnH; mxH = pk > mxH ? pk : mxH; }
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    unsigned long long a1 = __shfl_xor(mnL, o), b1 = __shfl_xor(mxL, o), a2 = __shfl_xor(mnH, o), b2 = __shfl_xor(mxH, o);
+                    mnL = a1 < mnL ? a1 : mnL; mxL = b1 > mxL ? b1 : mxL; mnH = a2 < mnH ? a2 : mnH; mxH = b2 > mxH ? b2 : mxH;
+                }
+                if (threadIdx.x == 0) { s_min = ~0ULL; s_max = 0ULL; s_min2 = ~0ULL; s_max2 = 0ULL; }
                 __syncthreads();
-                if (vmx_lane() == 0) { atomicMin((unsigned long long*)&s_min, mn); atomicMax((unsigned long long*)&s_max, mx); }
+                if (vmx_lane() == 0) {
+                    atomicMin((unsigned long long*)&s_min, mnL); atomicMax((unsigned long long*)&s_max, mxL);
+                    atomicMin((unsigned long long*)&s_min2, mnH); atomicMax((unsigned long long*)&s_max2, mxH);
+                }
                 __syncthreads();
-                int nbits = 0; { unsigned long long range = H > 0 ? s_max - s_min : 0; while (nbits < 40 && (range >> nbits)) ++nbits; }
-                uint64_t* res = vmx_block_radix_sort_u64(HKEY, HKEY2, (int)H, 26, (uint64_t)s_min, nbits, (int*)s_sort, s_scan);
+                const bool hasL = s_min != ~0ULL, hasH = s_min2 != ~0ULL;
+                const unsigned long long baseL = hasL ? s_min : 0ULL, spanL = hasL ? s_max - s_min + 1 : 0ULL;
+                const unsigned long long baseH = hasH ? s_min2 : 0ULL, spanH = hasH ? s_max2 - s_min2 + 1 : 0ULL;
+                for (long long i = threadIdx.x; i < H; i += blockDim.x) {
+                    const unsigned long long kk = HKEY[i], pk = kk >> 26;
+                    const unsigned long long f = pk < MID ? pk - baseL : spanL + (pk - baseH);
+                    HKEY[i] = (f << 26) | (kk & ((1ULL << 26) - 1));
+                }
+                __syncthreads();
+                int nbits = 0; { unsigned long long range = H > 0 ? spanL + spanH : 0; while (nbits < 40 && (range >> nbits)) ++nbits; }
+                uint64_t* res = vmx_block_radix_sort_u64(HKEY, HKEY2, (int)H, 26, (uint64_t)0, nbits, (int*)s_sort, s_scan);
                 if (res != HKEY) { for (long long i = threadIdx.x; i < H; i += blockDim.x) HKEY[i] = HKEY2[i]; }
                 __syncthreads();
             }

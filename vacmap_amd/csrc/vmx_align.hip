@@ -190,7 +190,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     VMX_TRY(B.res.reserve(16 * (size_t)(n + 2) + 64));
     double* d_gscore = B.res.as<double>(); int32_t* d_mapq = (int32_t*)(d_gscore + n + 1); int32_t* d_np = d_mapq + n + 1;
     VMX_TRY(B.plen.reserve(4 * (size_t)(tot + 1))); VMX_TRY(B.prow.reserve(sizeof(vmx_anchor) * (size_t)(tot + 1)));
-    hipLaunchKernelGGL(k_chain_select, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(), B.lens.as<int64_t>(), (int)n,
+    hipLaunchKernelGGL(k_chain_select, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 12)), dim3(64), 0, c->stream, B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(), B.lens.as<int64_t>(), (int)n,
                        B.S.as<double>(), B.P.as<int32_t>(), B.SA.as<int32_t>(), B.gmax.as<int64_t>(), B.flip.as<int32_t>(), prm->mode, B.scr.as<char>(), B.soff.as<int64_t>(), d_mapq,
                        d_gscore, d_np, B.plen.as<int32_t>(), B.prow.as<vmx_anchor>());
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));

@@ -62,6 +62,7 @@ struct vmx_lseed_args {
 #endif
 #define VMX_SORT_LDS 4096           // uint64 keys sorted in LDS by vmx_block_sort_u64 (larger sorts run in HBM)
 #define VM_READ_FASTPATH_DEV (-21)   // the reference would switch to a *_fast heuristic that is not built yet
+#define VMX_SELECT_LDS 3072           // k_chain_select: anchors of a read whose S / P / S_arg / used flags are staged in LDS (17 B each)
 #define VMX_LC_BYTES_PER_ANCHOR 24   // S8 + r4 (relative) + q4 + ls4 + SA4 (LDS bytes per anchor in k_chain_local)
 #define VMX_GC_BYTES_PER_ANCHOR 25   // S8 + r4 (relative) + q4 + ls4 + SA4 + cov1 (LDS bytes per anchor in k_chain_global)
 

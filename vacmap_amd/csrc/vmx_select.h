@@ -29,7 +29,7 @@ __host__ __device__ inline int vmx_desc_intersect(const int* a, int na, const in
 
 __host__ __device__ inline void vmx_chain_select(const vmx_anchor* A, int n, int64_t L, const double* S, const int32_t* P,
                                                  const int32_t* SA, int gmax, int mode, char* scratch, int32_t* out_path_len,
-                                                 vmx_anchor* out_rows, vmx_select_out* o) {
+                                                 vmx_anchor* out_rows, vmx_select_out* o, unsigned char* used_buf = nullptr) {
     (void)L;
     double* cscore = (double*)scratch;
     int* cidx = (int*)(cscore + n);
@@ -39,8 +39,8 @@ __host__ __device__ inline void vmx_chain_select(const vmx_anchor* A, int n, int
     int* boff = bins + n;            // n+1
     int* prim = boff + n + 1;        // n
     int* sec = prim + n;             // n
-    unsigned char* used = (unsigned char*)(sec + n + 4);
-    for (int i = 0; i < n; ++i) used[i] = 0;
+    unsigned char* used = used_buf ? used_buf : (unsigned char*)(sec + n + 4);     // used_buf: caller-provided (LDS), already zeroed
+    if (!used_buf) for (int i = 0; i < n; ++i) used[i] = 0;
     const double accept = (mode == 0) ? 60.0 : 40.0;
     const int sec_min_span = (mode == 3) ? 100 : 50;
     int nch = 0, w = 0;
