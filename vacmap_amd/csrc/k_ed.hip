@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(64 * VMX_ED_WAVES) k_edit_distance(const uint8
                                                                       const uint8_t* __restrict__ tcodes, const int64_t* __restrict__ t_off,
                                                                       int8_t* __restrict__ carry_pool, const int32_t* __restrict__ order,
                                                                       const int32_t* __restrict__ range, int32_t* __restrict__ counters, int which,
-                                                                      int64_t* __restrict__ out) {
+                                                                      int64_t* __restrict__ out, int64_t carry_stride, int32_t* __restrict__ oflow) {
     __shared__ volatile unsigned long long s_prog[VMX_ED_WAVES];   // (pass << 32) | columns whose carry is published
     __shared__ int s_next;
     const int lane = vmx_lane();
@@ -73,9 +73,14 @@ __global__ void __launch_bounds__(64 * VMX_ED_WAVES) k_edit_distance(const uint8
         const uint8_t* txt = tcodes + t_off[p];
         const int m = vmx_uniform_i32((int)(q_off[p + 1] - q_off[p]));
         const int n = vmx_uniform_i32((int)(t_off[p + 1] - t_off[p]));
-        int8_t* carry = carry_pool + (size_t)VMX_ED_WAVES * (size_t)t_off[p];   // ring of up to VMX_ED_WAVES arrays of n entries
+        // ring of up to VMX_ED_WAVES arrays of n entries: per problem (carry_stride == 0: the pool holds VMX_ED_WAVES bytes per text base) or
+        // per workgroup (carry_stride = longest text the pool was sized for; a longer text raises the batch's overflow flag)
+        int8_t* carry = carry_stride > 0 ? carry_pool + (size_t)blockIdx.x * (size_t)VMX_ED_WAVES * (size_t)carry_stride
+                                         : carry_pool + (size_t)VMX_ED_WAVES * (size_t)t_off[p];
+        const bool too_long = carry_stride > 0 && n > carry_stride;
+        if (too_long && threadIdx.x == 0) { atomicExch(oflow, 1); out[p] = 0x7fffffffLL; }
         // an empty side makes the distance trivial; such problems still walk through every barrier below (P = 0 passes)
-        const bool trivial = m == 0 || n == 0;
+        const bool trivial = m == 0 || n == 0 || too_long;
         if (lane == 0) s_prog[w] = 0ULL;
         __syncthreads();
         const int B = (m + 63) >> 6;
@@ -162,7 +167,7 @@ __global__ void __launch_bounds__(64 * VMX_ED_WAVES) k_edit_distance(const uint8
             }
         }
         // the score lives in the lane that owns block B-1 (wave (P-1) % W)
-        if (trivial) { if (threadIdx.x == 0) out[p] = m == 0 ? n : m; }
+        if (trivial) { if (threadIdx.x == 0 && !too_long) out[p] = m == 0 ? n : m; }
         else if (w == (P - 1) % W) {
             const long long s = __shfl(score, (B - 1) & 63);
             if (lane == 0) out[p] = s;

@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
         vmx_anchor* OUT = A.la_rows + A.la_off[r];
         uint64_t* OKEY = A.la_ekey + A.la_off[r];
         vmx_anchor* SORTED = A.la_sorted + A.la_off[r];
-        const int out_cap = (int)(A.la_slot_len * (2 * (int64_t)L + 4096));     // slot of this read in the local-anchor pools
+        const int out_cap = (int)(A.la_slot_len * VMX_LA_SLOT((int64_t)L));     // slot of this read in the local-anchor pools
         int n_out = 0;
         int status = 0;
         int gbase = 0;

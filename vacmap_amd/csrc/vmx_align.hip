@@ -51,7 +51,7 @@ struct vmx_batch_bufs {
     // extend stage
     DevBuf er, coff3, soff2, segA, st, en, segA_s, st_s, en_s, segprob, dup, desc[2], rcount, oflow, probread, tl, ql, toff, qoff, tpool, qpool;
     DevBuf edout, carry, ext3, dpsz[4], dpoff[4], dptab, tb, bnd, run, cig, ciglen, dpscore, rec, blob, bloboff, reccoff, recclen, dupd, totals;
-    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp;
+    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp, chunkn;
     void release() { DevBuf* p = (DevBuf*)this; for (size_t i = 0; i < sizeof(*this) / sizeof(DevBuf); ++i) p[i].release(); }
 };
 static vmx_batch_bufs* batch_bufs(vm_ctx* c) { if (!c->bbufs) c->bbufs = new vmx_batch_bufs(); return c->bbufs; }
@@ -219,11 +219,13 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     VMX_TRY(B.segprob.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.dup.reserve(4 * (size_t)(cS + 1)));
     const int64_t round_cap = cS + 16;                       // one problem per anchor at most in any round
     const int64_t pool_cap = 6 * total_bases + (1 << 20);
+    int64_t Lmax_b = 1; for (int64_t r = 0; r < n; ++r) Lmax_b = std::max(Lmax_b, h_roff[r + 1] - h_roff[r]);
+    const int64_t carry_stride = 2 * Lmax_b + 32768;        // exact edit-distance kernel: one carry ring per workgroup (2 + 8 per CU), longest text it takes
     VMX_TRY(B.desc[0].reserve(sizeof(vmx_pair_desc) * (size_t)round_cap)); VMX_TRY(B.desc[1].reserve(sizeof(vmx_pair_desc) * (size_t)round_cap));
     VMX_TRY(B.rcount.reserve(64)); VMX_TRY(B.oflow.reserve(64)); VMX_TRY(B.probread.reserve(4 * (size_t)round_cap));
     VMX_TRY(B.tl.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.ql.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.toff.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.qoff.reserve(8 * (size_t)(round_cap + 1)));
     VMX_TRY(B.tpool.reserve((size_t)pool_cap + 64)); VMX_TRY(B.qpool.reserve((size_t)pool_cap + 64));
-    VMX_TRY(B.edout.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.carry.reserve((size_t)VMX_ED_WAVES * (size_t)pool_cap + 64)); VMX_TRY(B.ext3.reserve(12 * (size_t)(round_cap + 1)));
+    VMX_TRY(B.edout.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.carry.reserve((size_t)VMX_ED_WAVES * (size_t)carry_stride * (size_t)c->num_cu * 10 + 64)); VMX_TRY(B.ext3.reserve(12 * (size_t)(round_cap + 1)));
     VMX_TRY(B.rec.reserve(sizeof(vm_record) * (size_t)(cS + 1))); VMX_TRY(B.blob.reserve((size_t)cB + 64)); VMX_TRY(B.reccoff.reserve(8 * (size_t)(cS + 1)));
     VMX_TRY(B.recclen.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.dupd.reserve((size_t)cB + 64));
     VMX_HIP(hipMemsetAsync(B.oflow.p, 0, 4, c->stream));
@@ -260,30 +262,48 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         hipLaunchKernelGGL(k_dp_sizes, dim3(G), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.dpsz[0].as<int64_t>(), B.dpsz[1].as<int64_t>(),
                            B.dpsz[2].as<int64_t>(), B.dpsz[3].as<int64_t>());
         for (int i = 0; i < 4; ++i) VMX_TRY(dev_scan(c, B, B.dpsz[i].as<int64_t>(), B.dpoff[i].as<int64_t>(), (int64_t)cnt));
-        // sizing sync #3: total traceback / boundary / run / CIGAR bytes of the batch
+        // sizing sync #3: traceback offsets (to cut the problems into chunks of at most VMX_TB_CHUNK traceback bytes) and the totals of the
+        // boundary / run / CIGAR pools
+        std::vector<int64_t> h_tboff((size_t)cnt + 1);
+        VMX_TRY(download(h_tboff.data(), B.dpoff[0].as<int64_t>(), (size_t)cnt + 1, c->stream));
         int64_t totals[4];
         for (int i = 0; i < 4; ++i) VMX_TRY(download(&totals[i], B.dpoff[i].as<int64_t>() + cnt, 1, c->stream));
         int64_t tq[2]; VMX_TRY(download(&tq[0], B.toff.as<int64_t>() + cnt, 1, c->stream)); VMX_TRY(download(&tq[1], B.qoff.as<int64_t>() + cnt, 1, c->stream));
         VMX_HIP(hipStreamSynchronize(c->stream));
-        VMX_TRY(B.tb.reserve((size_t)totals[0] + 64)); VMX_TRY(B.bnd.reserve(4 * (size_t)(totals[1] + 4))); VMX_TRY(B.run.reserve(4 * (size_t)(totals[2] + 4))); VMX_TRY(B.cig.reserve((size_t)totals[3] + 16));
+        std::vector<int32_t> cuts(1, 0);                         // chunk c = problems [cuts[c], cuts[c+1])
+        {
+            int64_t base = 0;
+            for (int p = 0; p < cnt; ++p) if (h_tboff[(size_t)p + 1] - base > VMX_TB_CHUNK && p > cuts.back()) { cuts.push_back(p); base = h_tboff[(size_t)p]; }
+            cuts.push_back(cnt);
+        }
+        int64_t tbmax = 0;
+        for (size_t q = 0; q + 1 < cuts.size(); ++q) tbmax = std::max(tbmax, h_tboff[(size_t)cuts[q + 1]] - h_tboff[(size_t)cuts[q]]);
+        VMX_TRY(B.tb.reserve((size_t)tbmax + 64)); VMX_TRY(B.bnd.reserve(4 * (size_t)(totals[1] + 4))); VMX_TRY(B.run.reserve(4 * (size_t)(totals[2] + 4))); VMX_TRY(B.cig.reserve((size_t)totals[3] + 16));
         st.n_dp_problems += cnt; st.dp_cells += totals[0];
         hipLaunchKernelGGL(k_dp_table, dim3(G), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.dpoff[0].as<int64_t>(),
                            B.dpoff[1].as<int64_t>(), B.dpoff[2].as<int64_t>(), B.dpoff[3].as<int64_t>(), B.dptab.as<vmx_dp_prob>());
         st.dp_string_bytes += tq[0] + tq[1];
-        hipEvent_t* ke = c->ev + (redo_only ? 19 : 16);      // HIP events around the dominant kernel, on the stream it runs on
-        (void)hipEventRecord(ke[0], c->stream);
+        c->n_gev[redo_only ? 1 : 0] = 0;
         if (cnt) {
             VMX_TRY(B.order.reserve(4 * (size_t)(round_cap + 1))); VMX_TRY(B.qrange.reserve(64));
             int32_t* d_range = B.qrange.as<int32_t>(); int32_t* d_cnt = d_range + 4;
-            hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), (int64_t)0, B.order.as<int32_t>(), d_range, d_cnt);
-            (void)hipEventRecord(ke[0], c->stream);
-            hipLaunchKernelGGL(k_gapfill_fill, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>(), cnt,
-                               2, -4, 4, 2, 24, 1, B.tb.as<uint8_t>(), B.bnd.as<int32_t>(), B.dpscore.as<int32_t>(), B.order.as<int32_t>(), d_cnt);
+            std::vector<int32_t> csz; for (size_t q = 0; q + 1 < cuts.size(); ++q) csz.push_back(cuts[q + 1] - cuts[q]);
+            VMX_TRY(upload(B.chunkn, csz.data(), csz.size(), c->stream));
+            for (size_t q = 0; q + 1 < cuts.size(); ++q) {
+                const int p0 = cuts[q], pn = cuts[q + 1] - cuts[q];
+                // the problems' absolute traceback offsets index a buffer that holds this chunk only
+                uint8_t* tb_base = B.tb.as<uint8_t>() - h_tboff[(size_t)p0];
+                hipEvent_t* ke = q < 8 ? c->gev + (redo_only ? 24 : 0) + 3 * q : nullptr;      // HIP events around the dominant kernel, on the stream it runs on
+                hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>() + p0, B.chunkn.as<int32_t>() + q, (int64_t)0, B.order.as<int32_t>(), d_range, d_cnt);
+                if (ke) (void)hipEventRecord(ke[0], c->stream);
+                hipLaunchKernelGGL(k_gapfill_fill, dim3((unsigned)std::min<int64_t>(pn, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
+                                   B.dptab.as<vmx_dp_prob>() + p0, pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_cnt);
+                if (ke) (void)hipEventRecord(ke[1], c->stream);
+                hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)((pn + 63) / 64)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>() + p0, pn, prm->eqx,
+                                   tb_base, B.run.as<uint32_t>(), B.cig.as<char>(), B.ciglen.as<int32_t>() + p0);
+                if (ke) { (void)hipEventRecord(ke[2], c->stream); c->n_gev[redo_only ? 1 : 0] = (int)q + 1; }
+            }
         }
-        (void)hipEventRecord(ke[1], c->stream);
-        if (cnt) hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>(), cnt, prm->eqx,
-                                    B.tb.as<uint8_t>(), B.run.as<uint32_t>(), B.cig.as<char>(), B.ciglen.as<int32_t>());
-        (void)hipEventRecord(ke[2], c->stream);
         A.redo_only = redo_only;
         hipLaunchKernelGGL(k_ext_records, dim3(gridR), dim3(64), 0, c->stream, A, B.dptab.as<vmx_dp_prob>(), B.cig.as<char>(), B.ciglen.as<int32_t>());
         cur ^= 1;
@@ -321,8 +341,9 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
             hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt);
             for (int which = 0; which < 2; ++which)
                 hipLaunchKernelGGL(k_edit_distance, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * (which == 0 ? 2 : 8))), dim3(which == 0 ? 64 * VMX_ED_WAVES : 256), 0, c->stream,
-                                   B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.carry.as<int8_t>(), B.order.as<int32_t>(), d_range, d_cnt, which,
-                                   B.edout.as<int64_t>());
+                                   B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(), B.toff.as<int64_t>(),
+                                   B.carry.as<int8_t>() + (which ? (size_t)VMX_ED_WAVES * (size_t)carry_stride * (size_t)c->num_cu * 2 : 0), B.order.as<int32_t>(), d_range, d_cnt, which,
+                                   B.edout.as<int64_t>(), carry_stride, B.oflow.as<int32_t>());
         }
         cur ^= 1;
     }
@@ -380,11 +401,13 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     float ms = 0;
     hipEventElapsedTime(&ms, ev[0], ev[nev - 1]); st.ms_total = ms;
     for (int i = 1; i < nev && i < 16; ++i) { hipEventElapsedTime(&ms, ev[i - 1], ev[i]); st.ms_stage[i - 1] = ms; }
-    for (int base = 16; base <= 19; base += 3) {
-        if (hipEventElapsedTime(&ms, ev[base], ev[base + 1]) == hipSuccess) st.ms_gapfill_fill += ms;
-        if (hipEventElapsedTime(&ms, ev[base + 1], ev[base + 2]) == hipSuccess) st.ms_gapfill_trace += ms;
-        st.n_gapfill_launches++;
-    }
+    for (int pass = 0; pass < 2; ++pass)
+        for (int q = 0; q < c->n_gev[pass]; ++q) {
+            hipEvent_t* ke = c->gev + 24 * pass + 3 * q;
+            if (hipEventElapsedTime(&ms, ke[0], ke[1]) == hipSuccess) st.ms_gapfill_fill += ms;
+            if (hipEventElapsedTime(&ms, ke[1], ke[2]) == hipSuccess) st.ms_gapfill_trace += ms;
+            st.n_gapfill_launches++;
+        }
     if (stats) *stats = st;
     return VM_OK;
 }

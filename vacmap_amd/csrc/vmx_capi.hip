@@ -61,6 +61,7 @@ int vm_ctx_create(int device_id, vm_ctx** out) {
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; set_error("hipStreamCreate failed"); return VM_ERR_HIP; }
     for (int i = 0; i < 24; ++i) (void)hipEventCreate(&c->ev[i]);
+    for (int i = 0; i < 48; ++i) (void)hipEventCreate(&c->gev[i]);
     for (int i = 0; i < 4; ++i) { (void)hipStreamCreate(&c->aux[i]); (void)hipEventCreate(&c->join_ev[i]); }
     (void)hipEventCreate(&c->fork_ev);
     // cost tables -> one device blob
@@ -92,6 +93,7 @@ void vm_ctx_destroy(vm_ctx* c) {
     vmx_ctx_free_batch_bufs(c);
     c->tab_buf.release();
     for (int i = 0; i < 24; ++i) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 48; ++i) (void)hipEventDestroy(c->gev[i]);
     for (int i = 0; i < 4; ++i) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); (void)hipEventDestroy(c->join_ev[i]); }
     (void)hipEventDestroy(c->fork_ev);
     (void)hipStreamDestroy(c->stream);
@@ -151,7 +153,7 @@ int vm_edit_distance_batch(vm_ctx* c, int64_t n, const char* q, const int64_t* q
         for (int which = 0; which < 2; ++which)
             hipLaunchKernelGGL(k_edit_distance, dim3(grid_for(c, n, which == 0 ? 2 : 8)), dim3(which == 0 ? 64 * VMX_ED_WAVES : 256), 0, c->stream, c->b[1].as<uint8_t>(),
                                c->b[2].as<int64_t>(), c->b[4].as<uint8_t>(), c->b[5].as<int64_t>(), c->b[6].as<int8_t>(), c->b[10].as<int32_t>(), d_range, d_cnt, which,
-                               c->b[7].as<int64_t>());
+                               c->b[7].as<int64_t>(), (int64_t)0, (int32_t*)nullptr);
     }
     *dist = host_alloc<int64_t>((size_t)n);
     VMX_TRY(download(*dist, c->b[7].p, (size_t)n, c->stream));

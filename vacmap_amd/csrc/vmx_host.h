@@ -63,6 +63,8 @@ struct vm_ctx {
     vmx::DevBuf b[VMX_NBUF];     // scratch buffers reused by the entry points (grow-only)
     int num_cu = 256;
     hipEvent_t ev[24];
+    hipEvent_t gev[48];                          // gap-fill chunk events: [redo][chunk 0..7][before fill, after fill, after trace]
+    int n_gev[2] = {0, 0};                        // chunks recorded by the last batch per pass
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams for independent launches (LDS-bucketed kernels)
     hipEvent_t fork_ev = nullptr, join_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int64_t last_n_minimizers = 0;               // of the last seed stage (stats)
@@ -91,7 +93,8 @@ struct vmx_fork {
 // ---- kernels (k_dp.hip, k_chain.hip, ...) ----
 __global__ void k_encode(const char* in, uint8_t* out, int64_t n);
 __global__ void k_edit_distance(const uint8_t* qcodes, const int64_t* q_off, const uint8_t* tcodes, const int64_t* t_off,
-                                int8_t* carry_pool, const int32_t* order, const int32_t* range, int32_t* counters, int which, int64_t* out);
+                                int8_t* carry_pool, const int32_t* order, const int32_t* range, int32_t* counters, int which, int64_t* out,
+                                int64_t carry_stride, int32_t* oflow);
 __global__ void k_size_order(const int64_t* size, const int32_t* n_ptr, int64_t thresh, int32_t* order, int32_t* range, int32_t* counters);
 __global__ void k_ed_banded(const uint8_t* qcodes, const int64_t* q_off, const uint8_t* tcodes, const int64_t* t_off, const int32_t* order,
                             const int32_t* range, int32_t* counter, int64_t* ub_out);

@@ -39,7 +39,7 @@ struct vmx_lseed_args {
     const vmx_anchor* guide_rows; const int32_t* guide_len; const int32_t* n_guides_used; const int64_t* aoff;
     int32_t n_reads, k, look_span, read_span, sort_by_start;
     const int32_t* order; int32_t* queue;                   // read indices longest first + the queue head (zero at launch)
-    int64_t la_slot_len;                                    // local-anchor slot of a listed read = la_slot_len * (2 * len + 4096) rows at la_off[r]
+    int64_t la_slot_len;                                    // local-anchor slot of a listed read = la_slot_len * VMX_LA_SLOT(len) rows at la_off[r]
     int32_t* head_pool; int32_t* next_pool;                 // HEAD[4^k] (all -1 between uses) / NEXT[tpos_cap] per slot
     int32_t* sq_pool; int32_t* dst_pool;                    // hit_cap ints each
     int64_t* tpos_pool; int64_t tpos_cap;
@@ -62,6 +62,8 @@ struct vmx_lseed_args {
 #endif
 #define VMX_SORT_LDS 4096           // uint64 keys sorted in LDS by vmx_block_sort_u64 (larger sorts run in HBM)
 #define VM_READ_FASTPATH_DEV (-21)   // the reference would switch to a *_fast heuristic that is not built yet
+#define VMX_TB_CHUNK ((int64_t)24 << 30)   // gap fill: traceback bytes held at a time; a batch needing more runs fill + trace chunk by chunk
+#define VMX_LA_SLOT(len) ((len) / 2 + 4096)   // regular local-anchor slot of a read (rows); overflowing reads are re-run with 8x .. 4096x
 #define VMX_SELECT_LDS 3072           // k_chain_select: anchors of a read whose S / P / S_arg / used flags are staged in LDS (17 B each)
 #define VMX_LC_BYTES_PER_ANCHOR 24   // S8 + r4 (relative) + q4 + ls4 + SA4 (LDS bytes per anchor in k_chain_local)
 #define VMX_GC_BYTES_PER_ANCHOR 25   // S8 + r4 (relative) + q4 + ls4 + SA4 + cov1 (LDS bytes per anchor in k_chain_global)

@@ -33,8 +33,8 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     const int64_t tot_anchors = h_aoff[n];
     int64_t Lmax = 1;
     L.h_la_off.assign((size_t)n + 1, 0);
-    for (int64_t r = 0; r < n; ++r) { int64_t len = h_roff[r + 1] - h_roff[r]; Lmax = std::max(Lmax, len); L.h_la_off[r + 1] = L.h_la_off[r] + 2 * len + 4096; }
-    // the regular slot of a read holds 2*len + 4096 local anchors; reads that overflow it (tandem arrays: > 10 anchors per base) are
+    for (int64_t r = 0; r < n; ++r) { int64_t len = h_roff[r + 1] - h_roff[r]; Lmax = std::max(Lmax, len); L.h_la_off[r + 1] = L.h_la_off[r] + VMX_LA_SLOT(len); }
+    // the regular slot of a read holds len/2 + 4096 local anchors (a 10 % error read yields ~0.07 per base); reads that overflow it are
     // re-run below with slots carved from an overflow area at the end of the pools
     const int64_t la_regular = L.h_la_off[n];
     const int64_t la_overflow = std::max<int64_t>((int64_t)4 << 20, 64 * Lmax);
@@ -119,16 +119,16 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     VMX_TRY(download(h_lstatus.data(), L.status.p, (size_t)n, c->stream));
     VMX_HIP(hipStreamSynchronize(c->stream));
     VMX_HIP(hipGetLastError());
-    {   // capacity retries: 8x, 64x, 512x the regular slot / hit pool, as long as the overflow area lasts
+    {   // capacity retries: 8x, 64x, 512x, 4096x the regular slot / hit pool, as long as the overflow area lasts
         int64_t ovf_used = 0;
-        for (int round = 1; round <= 3; ++round) {
+        for (int round = 1; round <= 4; ++round) {
             std::vector<int32_t> ord(1, 0);
             const int64_t mult = (int64_t)1 << (3 * round);
             int64_t lmax_f = 1;
             for (int64_t r = 0; r < n; ++r) {
                 if (h_lstatus[r] != VM_READ_CAPACITY_DEV) continue;
                 const int64_t len = h_roff[r + 1] - h_roff[r];
-                const int64_t want = mult * (2 * len + 4096);
+                const int64_t want = mult * VMX_LA_SLOT(len);
                 if (ovf_used + want > la_overflow) continue;                 // stays a capacity failure
                 L.h_la_off[r] = la_regular + ovf_used; ovf_used += want;
                 ord.push_back((int32_t)r); lmax_f = std::max(lmax_f, len);
@@ -139,7 +139,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
             VMX_TRY(upload(L.la_off, L.h_la_off.data(), (size_t)n + 1, c->stream));
             int64_t hcap = 1; while (hcap < mult * 4 * (lmax_f + 14000)) hcap <<= 1;
             if (hcap > ((int64_t)1 << 26)) hcap = (int64_t)1 << 26;          // stream indices are 26-bit
-            A.la_slot_len = mult;                                            // slot length = mult * (2*len + 4096) for the listed reads
+            A.la_slot_len = mult;                                            // slot length = mult * VMX_LA_SLOT(len) for the listed reads
             VMX_TRY(run_seed(cnt, std::min(cnt, 8), hcap));
             VMX_TRY(download(L.h_la_cnt.data(), L.la_cnt.p, (size_t)n, c->stream));
             VMX_TRY(download(h_lstatus.data(), L.status.p, (size_t)n, c->stream));
