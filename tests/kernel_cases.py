@@ -107,11 +107,11 @@ def check_extend(ctx, O, n=64, seed=3, maxlen=700):
         assert (int(sc[i]), int(te[i]), int(qe[i])) == e, (i, len(ts[i]), len(qs[i]))
 
 
-def check_gapfill(ctx, O, n=64, maxlen=500, seed=4):
+def check_gapfill(ctx, O, n=64, maxlen=500, seed=4, minlen=1):
     rng = np.random.default_rng(seed)
     ts, qs = [], []
     for i in range(n):
-        L = int(rng.integers(1, maxlen))
+        L = int(rng.integers(minlen, maxlen))
         a = rand_seq(rng, L)
         b = mutate(rng, a, float(rng.choice([0.0, 0.1, 0.3])))
         if i % 7 == 3 and len(b) > 40:   # long gap -> second affine piece

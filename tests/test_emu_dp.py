@@ -31,6 +31,7 @@ def test_emu_extend(ctx, oracle):
 
 def test_emu_gapfill(ctx, oracle):
     KC.check_gapfill(ctx, oracle, n=10, maxlen=150, seed=4)
+    KC.check_gapfill(ctx, oracle, n=6, maxlen=330, seed=5)       # several 128-row stripes of the packed layout; beyond 420 cells of perimeter: int32 layout
 
 
 def test_emu_chain_global(ctx, oracle, golden):

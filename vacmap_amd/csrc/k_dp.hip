@@ -108,6 +108,93 @@ __device__ __forceinline__ int vmx_gap_open_row(int i, int o1, int e1, int o2, i
     return a > b ? a : b;
 }
 
+// Packed form for problems with tl + ql <= VMX_DP16_MAX (every score fits int16): a lane owns TWO consecutive rows of a 128-row stripe,
+// row 2l+1 in the low half and row 2l+2 in the high half of each register, the high row one column behind the low one, so both cells
+// of a step only need values of the step before: up(lo) = the lane above's high half, up(hi) = the own low half — one DPP move and one
+// v_alignbit per quantity. The recurrence runs on v_pk_add/sub/max_i16; comparison results are sign masks (v_pk_ashrrev_i16 15) merged
+// with v_bfi. Traceback bytes: tb[((stripe*(ql+127) + step)*64 + lane)*2 + half]. NEG16 stands for -infinity: a real score never gets
+// within reach of it, and it is never the larger operand of a max whose result is used.
+#define VMX_NEG16 (-20000)
+__device__ __forceinline__ void vmx_gapfill_fill16(const uint8_t* __restrict__ T, const uint8_t* __restrict__ Q, int tl, int ql, int match, int mismatch,
+                                                   int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb, int32_t* __restrict__ bH,
+                                                   int32_t* __restrict__ score_out, int lane) {
+    int32_t* bE1 = bH + (ql + 1);
+    int32_t* bE2 = bE1 + (ql + 1);
+    const int W = ql + 127;
+    const int nstr = (tl + 127) >> 7;
+    const unsigned O1 = vmx_pk(o1, o1), O2 = vmx_pk(o2, o2), E1C = vmx_pk(e1, e1), E2C = vmx_pk(e2, e2);
+    const unsigned MATCH = vmx_pk(match, match), MISM = vmx_pk(mismatch, mismatch), ONE = vmx_pk(1, 1);
+    const int rf = (tl - 1) & 127;                              // row tl inside the last stripe: lane rf / 2, half rf & 1
+    const int t_fin = ql - 1 + rf;                              // step at which that lane computes column ql
+    unsigned fin = 0;
+    for (int s = 0; s < nstr; ++s) {
+        const int i0 = s * 128 + 2 * lane + 1;                  // low-half row; the high half is row i0 + 1
+        const unsigned ti2 = vmx_pk(i0 <= tl ? (int)T[i0 - 1] : 5, i0 + 1 <= tl ? (int)T[i0] : 5);     // 5 never equals a query code (rows past tl)
+        unsigned Hleft = vmx_pk(vmx_gap_open_row(i0, o1, e1, o2, e2), vmx_gap_open_row(i0 + 1, o1, e1, o2, e2));
+        unsigned F1 = vmx_pk(VMX_NEG16, VMX_NEG16), F2 = F1;
+        unsigned Hdiag = vmx_pk(i0 - 1 == 0 ? 0 : vmx_gap_open_row(i0 - 1, o1, e1, o2, e2), vmx_gap_open_row(i0, o1, e1, o2, e2));
+        unsigned outH = 0, outE1 = F1, outE2 = F1, qc = vmx_pk(4, 4);
+        int sH = 0, sE1 = 0, sE2 = 0;                           // lane 63's high-half outputs of the last 64 steps (register FIFO, newest in lane 0)
+        const bool store_bnd = s + 1 < nstr;
+        uint8_t* tbs = tb + (size_t)s * (size_t)W * 128 + 2 * lane;
+        for (int t0 = 0; t0 < W; t0 += 64) {
+            // 64-column chunks for lane 0's low row, pre-shifted into the high half (the hand-off shifts them down): query bases Q[t0 ..] and
+            // the row above the stripe for columns t0+1 ..
+            const int jj = t0 + lane;
+            unsigned qchunk = (unsigned)(jj < ql ? (int)Q[jj] : 4) << 16;
+            unsigned cH = 0, cE1 = (unsigned)VMX_NEG16 << 16, cE2 = cE1;
+            if (jj + 1 <= ql) {
+                if (s == 0) cH = (unsigned)vmx_gap_open_row(jj + 1, o1, e1, o2, e2) << 16;
+                else { cH = (unsigned)bH[jj + 1] << 16; cE1 = (unsigned)bE1[jj + 1] << 16; cE2 = (unsigned)bE2[jj + 1] << 16; }
+            }
+            int tend = W - t0; if (tend > 64) tend = 64;
+            const bool ramp_up = t0 < 128;                      // some half has not reached its column 1 yet: its state must not move
+            for (int tt = 0; tt < tend; ++tt) {
+                const int t = t0 + tt;
+                const unsigned upH = vmx_alignbit16(outH, (unsigned)vmx_shr1_in((int)outH, (int)cH));
+                const unsigned upE1 = vmx_alignbit16(outE1, (unsigned)vmx_shr1_in((int)outE1, (int)cE1));
+                const unsigned upE2 = vmx_alignbit16(outE2, (unsigned)vmx_shr1_in((int)outE2, (int)cE2));
+                qc = vmx_alignbit16(qc, (unsigned)vmx_shr1_in((int)qc, (int)qchunk));
+                cH = (unsigned)vmx_rol1((int)cH); cE1 = (unsigned)vmx_rol1((int)cE1); cE2 = (unsigned)vmx_rol1((int)cE2); qchunk = (unsigned)vmx_rol1((int)qchunk);
+                const unsigned a1 = vmx_pk_sub(upH, O1), a2 = vmx_pk_sub(upH, O2);
+                unsigned b = vmx_pk_neg(vmx_pk_sub(a1, upE1)) & 0x00080008u;                       // upE1 > a1
+                b |= vmx_pk_neg(vmx_pk_sub(a2, upE2)) & 0x00100010u;
+                const unsigned e1v = vmx_pk_sub(vmx_pk_max(a1, upE1), E1C), e2v = vmx_pk_sub(vmx_pk_max(a2, upE2), E2C);
+                const unsigned c1 = vmx_pk_sub(Hleft, O1), c2 = vmx_pk_sub(Hleft, O2);
+                b |= vmx_pk_neg(vmx_pk_sub(c1, F1)) & 0x00200020u;                                  // F1 > c1
+                b |= vmx_pk_neg(vmx_pk_sub(c2, F2)) & 0x00400040u;
+                const unsigned nF1 = vmx_pk_sub(vmx_pk_max(c1, F1), E1C), nF2 = vmx_pk_sub(vmx_pk_max(c2, F2), E2C);
+                const unsigned eqm = vmx_pk_neg(vmx_pk_sub(ti2 ^ qc, ONE));                         // codes are 0..5: x - 1 < 0 iff x == 0
+                unsigned h = vmx_pk_add(Hdiag, vmx_bfi(eqm, MATCH, MISM));
+                unsigned src = 0, m;
+                m = vmx_pk_neg(vmx_pk_sub(h, e1v)); src = vmx_bfi(m, 0x00010001u, src); h = vmx_pk_max(h, e1v);
+                m = vmx_pk_neg(vmx_pk_sub(h, e2v)); src = vmx_bfi(m, 0x00020002u, src); h = vmx_pk_max(h, e2v);
+                m = vmx_pk_neg(vmx_pk_sub(h, nF1)); src = vmx_bfi(m, 0x00030003u, src); h = vmx_pk_max(h, nF1);
+                m = vmx_pk_neg(vmx_pk_sub(h, nF2)); src = vmx_bfi(m, 0x00040004u, src); h = vmx_pk_max(h, nF2);
+                b |= src;
+                *(uint16_t*)(tbs + (size_t)t * 128) = (uint16_t)((b & 0xffu) | ((b >> 8) & 0xff00u));
+                if (ramp_up) {
+                    // low half active from step 2*lane, high half from step 2*lane + 1
+                    const unsigned pm = (t >= 2 * lane ? 0xffffu : 0u) | (t >= 2 * lane + 1 ? 0xffff0000u : 0u);
+                    Hdiag = vmx_bfi(pm, upH, Hdiag); Hleft = vmx_bfi(pm, h, Hleft); F1 = vmx_bfi(pm, nF1, F1); F2 = vmx_bfi(pm, nF2, F2);
+                } else { Hdiag = upH; Hleft = h; F1 = nF1; F2 = nF2; }
+                outH = h; outE1 = e1v; outE2 = e2v;
+                fin = (t == t_fin) ? outH : fin;
+                if (store_bnd) {
+                    sH = vmx_ror1(lane == 63 ? vmx_pk_hi(outH) : sH); sE1 = vmx_ror1(lane == 63 ? vmx_pk_hi(outE1) : sE1); sE2 = vmx_ror1(lane == 63 ? vmx_pk_hi(outE2) : sE2);
+                    const int j63 = t - 126;                  // column the last row of the stripe (lane 63, high half) just finished
+                    if (j63 >= 1 && j63 <= ql && ((j63 & 63) == 0 || j63 == ql)) {
+                        const int col = j63 - lane;
+                        if (col > ((j63 - 1) & ~63)) { bH[col] = sH; bE1[col] = sE1; bE2[col] = sE2; }
+                    }
+                }
+            }
+        }
+        __syncthreads();   // bnd[] written by this stripe is read (in 64-column chunks) by the next one
+    }
+    if (lane == (rf >> 1)) *score_out = (rf & 1) ? vmx_pk_hi(fin) : vmx_pk_lo(fin);
+}
+
 // order/counter: longest-first device work queue (order == nullptr: plain grid-stride over [0, n_prob))
 __global__ void __launch_bounds__(64) k_gapfill_fill(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
                                                      const vmx_dp_prob* __restrict__ probs, int n_prob, int match, int mismatch,
@@ -132,8 +219,9 @@ __global__ void __launch_bounds__(64) k_gapfill_fill(const uint8_t* __restrict__
         int32_t* bH = bnd_pool + pr.bnd_off;
         int32_t* bE1 = bH + (ql + 1);
         int32_t* bE2 = bE1 + (ql + 1);
+        const bool pk = !trivial && VMX_DP16_OK(tl, ql);      // two rows per lane in packed int16 (below); larger problems keep int32
         const int W = ql + 63;
-        const int nstr = trivial ? 0 : (tl + 63) >> 6;
+        const int nstr = (trivial || pk) ? 0 : (tl + 63) >> 6;
         int outH = 0;
         for (int s = 0; s < nstr; ++s) {
             const int i = s * 64 + lane + 1;
@@ -202,7 +290,8 @@ __global__ void __launch_bounds__(64) k_gapfill_fill(const uint8_t* __restrict__
 #undef VMX_GF_STEP
             __syncthreads();   // bnd[] written by this stripe is read (in 64-column chunks) by the next one
         }
-        if (!trivial && lane == ((tl - 1) & 63)) out_score[p] = outH;     // H(tl, ql): the last cell that lane computed
+        if (!trivial && !pk && lane == ((tl - 1) & 63)) out_score[p] = outH;     // H(tl, ql): the last cell that lane computed
+        if (pk) vmx_gapfill_fill16(T, Q, tl, ql, match, mismatch, o1, e1, o2, e2, tb, bH, &out_score[p], lane);
     }
 }
 
@@ -219,7 +308,8 @@ __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_
     const uint8_t* tb = tb_pool + pr.tb_off;
     uint32_t* runs = run_pool + pr.run_off;
     char* cig = cig_pool + pr.cig_off;
-    const int W = ql + 63;
+    const bool pk = tl > 0 && ql > 0 && VMX_DP16_OK(tl, ql);     // packed layout of vmx_gapfill_fill16
+    const int W = ql + (pk ? 127 : 63);
     int nruns = 0; int cur_op = -1; uint32_t cur_len = 0;
 #define VMX_EMIT(op)                                                                   \
     do {                                                                               \
@@ -228,8 +318,9 @@ __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_
     } while (0)
     int i = tl, j = ql, state = 0;
     while (i > 0 && j > 0) {
-        const int s = (i - 1) >> 6, l = (i - 1) & 63, t = (j - 1) + l;
-        const int b = tb[((size_t)s * (size_t)W + (size_t)t) * 64 + l];
+        int b;
+        if (pk) { const int s = (i - 1) >> 7, r = (i - 1) & 127, t = (j - 1) + r; b = tb[(((size_t)s * (size_t)W + (size_t)t) * 64 + (r >> 1)) * 2 + (r & 1)]; }
+        else { const int s = (i - 1) >> 6, l = (i - 1) & 63, t = (j - 1) + l; b = tb[((size_t)s * (size_t)W + (size_t)t) * 64 + l]; }
         if (state == 0) {
             int src = b & 7;
             if (src == 0) {

@@ -230,7 +230,7 @@ int vm_k_cigar_batch(vm_ctx* c, const vm_score* sc, int eqx, int64_t n, const ch
         vmx_dp_prob& p = probs[i];
         p.t_off = t_off[i]; p.q_off = q_off[i]; p.tl = (int32_t)(t_off[i + 1] - t_off[i]); p.ql = (int32_t)(q_off[i + 1] - q_off[i]);
         p.tb_off = tb; p.bnd_off = bnd; p.run_off = run; p.cig_off = cig;
-        tb += (int64_t)((p.tl + 63) / 64) * (p.ql + 63) * 64;
+        tb += VMX_TB_BYTES((int64_t)p.tl, (int64_t)p.ql);
         bnd += 3 * (int64_t)(p.ql + 1); run += (int64_t)p.tl + p.ql + 2; cig += 2 * ((int64_t)p.tl + p.ql) + 16;
     }
     VMX_TRY(upload(c->b[6], probs.data(), (size_t)n, c->stream));

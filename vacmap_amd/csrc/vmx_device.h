@@ -42,6 +42,33 @@ __device__ __forceinline__ int vmx_shr1_in(int v, int in) { return __builtin_amd
 __device__ __forceinline__ int vmx_rol1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x134, 0xf, 0xf, false); }
 __device__ __forceinline__ int vmx_ror1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x13C, 0xf, 0xf, false); }
 #endif
+// packed int16 pairs in one 32-bit register (v_pk_add_i16 / v_pk_sub_i16 / v_pk_max_i16 / v_pk_ashrrev_i16 on gfx950): the gap-fill
+// DP keeps two rows per lane. vmx_pk_neg(a) = 0xffff in every half whose int16 is negative.
+#ifdef VMX_EMU
+__device__ __forceinline__ unsigned vmx_pk(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
+__device__ __forceinline__ int vmx_pk_lo(unsigned a) { return (int)(short)(a & 0xffffu); }
+__device__ __forceinline__ int vmx_pk_hi(unsigned a) { return (int)(short)(a >> 16); }
+__device__ __forceinline__ unsigned vmx_pk_add(unsigned a, unsigned b) { return vmx_pk(vmx_pk_lo(a) + vmx_pk_lo(b), vmx_pk_hi(a) + vmx_pk_hi(b)); }
+__device__ __forceinline__ unsigned vmx_pk_sub(unsigned a, unsigned b) { return vmx_pk(vmx_pk_lo(a) - vmx_pk_lo(b), vmx_pk_hi(a) - vmx_pk_hi(b)); }
+__device__ __forceinline__ unsigned vmx_pk_max(unsigned a, unsigned b) {
+    const int l = vmx_pk_lo(a) > vmx_pk_lo(b) ? vmx_pk_lo(a) : vmx_pk_lo(b), h = vmx_pk_hi(a) > vmx_pk_hi(b) ? vmx_pk_hi(a) : vmx_pk_hi(b);
+    return vmx_pk(l, h);
+}
+__device__ __forceinline__ unsigned vmx_pk_neg(unsigned a) { return (vmx_pk_lo(a) < 0 ? 0xffffu : 0u) | (vmx_pk_hi(a) < 0 ? 0xffff0000u : 0u); }
+__device__ __forceinline__ unsigned vmx_alignbit16(unsigned hi, unsigned lo) { return (hi << 16) | (lo >> 16); }
+#else
+typedef short vmx_v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned vmx_pk(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
+__device__ __forceinline__ int vmx_pk_lo(unsigned a) { return (int)(short)(a & 0xffffu); }
+__device__ __forceinline__ int vmx_pk_hi(unsigned a) { return (int)(short)(a >> 16); }
+__device__ __forceinline__ unsigned vmx_pk_add(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (vmx_v2s)(__builtin_bit_cast(vmx_v2s, a) + __builtin_bit_cast(vmx_v2s, b))); }
+__device__ __forceinline__ unsigned vmx_pk_sub(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (vmx_v2s)(__builtin_bit_cast(vmx_v2s, a) - __builtin_bit_cast(vmx_v2s, b))); }
+__device__ __forceinline__ unsigned vmx_pk_max(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(vmx_v2s, a), __builtin_bit_cast(vmx_v2s, b))); }
+// opaque on purpose: given the plain shift the compiler turns every use of the mask back into per-half compares and selects
+__device__ __forceinline__ unsigned vmx_pk_neg(unsigned a) { unsigned r; asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }
+__device__ __forceinline__ unsigned vmx_alignbit16(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
+#endif
+__device__ __forceinline__ unsigned vmx_bfi(unsigned m, unsigned a, unsigned b) { return (m & a) | (~m & b); }     // v_bfi_b32
 // value known to be identical in every lane: hand it to the compiler as a scalar (v_readfirstlane_b32)
 #ifdef VMX_EMU
 __device__ __forceinline__ int vmx_uniform_i32(int v) { return v; }

@@ -62,6 +62,13 @@ struct vmx_lseed_args {
 #endif
 #define VMX_SORT_LDS 4096           // uint64 keys sorted in LDS by vmx_block_sort_u64 (larger sorts run in HBM)
 #define VM_READ_FASTPATH_DEV (-21)   // the reference would switch to a *_fast heuristic that is not built yet
+#ifdef VMX_EMU
+#define VMX_DP16_MAX 420              // emulator build: small switch point so that the CPU tests cover both layouts with small problems
+#else
+#define VMX_DP16_MAX 6000             // gap fill: problems with tl + ql <= this run two rows per lane in packed int16
+#endif
+#define VMX_DP16_OK(tl, ql) ((tl) + (ql) <= VMX_DP16_MAX)
+#define VMX_TB_BYTES(tl, ql) (((tl) > 0 && (ql) > 0) ? (VMX_DP16_OK(tl, ql) ? (int64_t)(((tl) + 127) / 128) * ((ql) + 127) * 128 : (int64_t)(((tl) + 63) / 64) * ((ql) + 63) * 64) : 0)
 #define VMX_TB_CHUNK ((int64_t)24 << 30)   // gap fill: traceback bytes held at a time; a batch needing more runs fill + trace chunk by chunk
 #define VMX_LA_SLOT(len) ((len) / 2 + 4096)   // regular local-anchor slot of a read (rows); overflowing reads are re-run with 8x .. 4096x
 #define VMX_SELECT_LDS 3072           // k_chain_select: anchors of a read whose S / P / S_arg / used flags are staged in LDS (17 B each)
