@@ -58,7 +58,7 @@ struct vmx_lseed_args {
 #define VMX_EDB4_HW 320              // k_ed_banded4 (four problems per wave): half width of the band; 2*HW + MAXD + 64 <= 16 blocks
 #define VMX_EDB4_MAXD 256            // k_ed_banded4: |m - n| above this goes to k_ed_banded
 #ifndef VMX_LSEED_WAVES
-#define VMX_LSEED_WAVES 4            // k_local_seed: waves per SIMD the register allocation is held to (2 workgroups of 512 per CU)
+#define VMX_LSEED_WAVES 6            // k_local_seed: waves per SIMD the register allocation is held to (80 VGPRs: 3 workgroups of 512 per CU)
 #endif
 #define VMX_SORT_LDS 4096           // uint64 keys sorted in LDS by vmx_block_sort_u64 (larger sorts run in HBM)
 #define VM_READ_FASTPATH_DEV (-21)   // the reference would switch to a *_fast heuristic that is not built yet
