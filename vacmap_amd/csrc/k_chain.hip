@@ -287,24 +287,27 @@ __global__ void __launch_bounds__(64) k_chain_select(const vmx_anchor* __restric
                                int32_t* __restrict__ out_mapq, double* __restrict__ out_score, int32_t* __restrict__ out_npaths,
                                int32_t* __restrict__ out_path_len, vmx_anchor* __restrict__ out_path_anchors) {
     // one wavefront per read: the wave stages S / P / S_arg and the `used` flags of the read in LDS (17 B per anchor), then lane 0 runs the
-    // serial peel on them — its dependent walks (S_arg -> used -> P -> ...) cost LDS latency instead of HBM latency
-    __shared__ double s_S[VMX_SELECT_LDS];
-    __shared__ int32_t s_P[VMX_SELECT_LDS];
-    __shared__ int32_t s_SA[VMX_SELECT_LDS];
-    __shared__ unsigned char s_used[VMX_SELECT_LDS];
+    // serial peel on them — its dependent walks (S_arg -> used -> P -> ...) cost LDS latency instead of HBM latency. Reads of up to
+    // VMX_SELECT_LDS_FULL anchors also keep the function's scratch (chain lists, read bins: 37 B per anchor) in LDS.
+    __shared__ __attribute__((aligned(16))) char s_buf[VMX_SELECT_LDS * 17 + 64];
     const int lane = vmx_lane();
     for (int r = (int)blockIdx.x; r < n_reads; r += (int)gridDim.x) {
         const int64_t a0 = aoff[r];
         const int n = (int)(aoff[r + 1] - a0);
         const bool run = n > 2 && gmax[r] >= 0;
         const bool in_lds = run && n <= VMX_SELECT_LDS;
-        if (in_lds) for (int i = lane; i < n; i += 64) { s_S[i] = S[a0 + i]; s_P[i] = P[a0 + i]; s_SA[i] = SA[a0 + i]; s_used[i] = 0; }
+        const bool full = run && n <= VMX_SELECT_LDS_FULL;
+        double* s_S = (double*)s_buf; int32_t* s_P = (int32_t*)(s_S + n); int32_t* s_SA = s_P + n;
+        char* s_scr = (char*)(s_SA + n);                                  // full tier: scratch (8-byte aligned: n * 16 bytes precede it)
+        unsigned char* s_used = full ? (unsigned char*)nullptr : (unsigned char*)(s_SA + n);
+        if (in_lds) for (int i = lane; i < n; i += 64) { s_S[i] = S[a0 + i]; s_P[i] = P[a0 + i]; s_SA[i] = SA[a0 + i]; if (!full) s_used[i] = 0; }
         __syncthreads();
         if (lane == 0) {
             vmx_select_out o;
             o.mapq = 0; o.score = 0.0; o.n_paths = 0;
             if (run) {
-                if (in_lds) vmx_chain_select(anchors + a0, n, readlens[r], s_S, s_P, s_SA, (int)gmax[r], mode, scratch + scratch_off[r], out_path_len + a0, out_path_anchors + a0, &o, s_used);
+                if (full) vmx_chain_select(anchors + a0, n, readlens[r], s_S, s_P, s_SA, (int)gmax[r], mode, s_scr, out_path_len + a0, out_path_anchors + a0, &o);
+                else if (in_lds) vmx_chain_select(anchors + a0, n, readlens[r], s_S, s_P, s_SA, (int)gmax[r], mode, scratch + scratch_off[r], out_path_len + a0, out_path_anchors + a0, &o, s_used);
                 else vmx_chain_select(anchors + a0, n, readlens[r], S + a0, P + a0, SA + a0, (int)gmax[r], mode, scratch + scratch_off[r], out_path_len + a0, out_path_anchors + a0, &o);
             }
             out_mapq[r] = o.mapq;

@@ -21,16 +21,26 @@ __global__ void __launch_bounds__(1024) k_size_order(const int64_t* __restrict__
     __shared__ int s_cur[64];
     __shared__ int s_long;
     const int n = *n_ptr;
+    const int lane = vmx_lane();
     if (threadIdx.x < 64) s_hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_long = 0;
     __syncthreads();
+    // nearly all problems of a launch share two or three size classes: the lanes of a wave that hit the same class are counted with
+    // one ballot and ONE LDS atomic (a plain per-lane atomicAdd serialises 10^5 updates on the same word)
     int nl = 0;
-    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
-        const long long s = size[i];
-        if (s < 0) continue;                       // negative size: problem already settled, not queued
-        const int b = s > 0 ? 63 - __clzll(s) : 0;
-        atomicAdd(&s_hist[b], 1);
+    for (int i0 = 0; i0 < n; i0 += (int)blockDim.x) {
+        const int i = i0 + (int)threadIdx.x;
+        const long long s = i < n ? size[i] : -1;
+        int b = s < 0 ? -1 : (s > 0 ? 63 - __clzll(s) : 0);        // negative size: problem already settled, not queued
         if (s > thresh) ++nl;
+        unsigned long long todo = __ballot(b >= 0);
+        while (todo) {
+            const int leader = __ffsll((unsigned long long)todo) - 1;
+            const int b0 = vmx_readlane(b, leader);
+            const unsigned long long same = __ballot(b == b0);
+            if (lane == leader) atomicAdd(&s_hist[b0], __popcll(same));
+            todo &= ~same;
+        }
     }
     if (nl) atomicAdd(&s_long, nl);
     __syncthreads();
@@ -41,11 +51,21 @@ __global__ void __launch_bounds__(1024) k_size_order(const int64_t* __restrict__
         counters[0] = 0; counters[1] = 0; counters[2] = 0; counters[3] = 0;
     }
     __syncthreads();
-    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
-        const long long s = size[i];
-        if (s < 0) continue;
-        const int b = s > 0 ? 63 - __clzll(s) : 0;
-        order[atomicAdd(&s_cur[b], 1)] = i;
+    for (int i0 = 0; i0 < n; i0 += (int)blockDim.x) {
+        const int i = i0 + (int)threadIdx.x;
+        const long long s = i < n ? size[i] : -1;
+        int b = s < 0 ? -1 : (s > 0 ? 63 - __clzll(s) : 0);
+        unsigned long long todo = __ballot(b >= 0);
+        while (todo) {
+            const int leader = __ffsll((unsigned long long)todo) - 1;
+            const int b0 = vmx_readlane(b, leader);
+            const unsigned long long same = __ballot(b == b0);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&s_cur[b0], __popcll(same));
+            base = vmx_readlane(base, leader);
+            if (b == b0) order[base + __popcll(same & ((1ULL << lane) - 1ULL))] = i;
+            todo &= ~same;
+        }
     }
 }
 
