@@ -175,7 +175,7 @@ def main():
         traffic, traffic_src = None, None
         try:
             pj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_g_pmc_hbm_traffic.json')))
-            traffic = pj['kernels']['k_gapfill_fill']['hbm_bytes_per_launch']; traffic_src = 'profiles/r01_g_pmc_hbm_traffic.json'
+            traffic = pj['kernels']['k_gapfill_fill']['hbm_bytes_per_step']        # per step, like achieved (a step = 1-2 chunk launches); traffic_src = 'profiles/r01_g_pmc_hbm_traffic.json'
         except Exception:
             pass
         # what the kernel itself must move: one traceback byte per DP cell (the reference's k_cigar materialises the same matrix) + its strings
