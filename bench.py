@@ -192,7 +192,13 @@ def main():
             if oi is None:
                 oi = O.Index.from_seqs(['chr1'], [contigs[0].tobytes()], k=15, w=10)
             op = O.params('H')
-            cores = os.cpu_count() or 1
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+            try:        # a container's CPU quota (cgroup v2 cpu.max) is what the leg can actually use; more threads only get throttled
+                q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+                if q != 'max':
+                    cores = max(1, min(cores, int(round(int(q) / int(per)))))
+            except Exception:
+                pass
 
             def cpu_leg(ns):       # ns reads evenly spaced over the length-sorted timed pool (same length mix as the timed workload)
                 pick = order[np.linspace(0, nsteps * args.reads_per_step - 1, ns).astype(np.int64)]
@@ -202,7 +208,7 @@ def main():
                 tcpu = time.time() - tc
                 return sum(t[4] - t[3] for t in crecs), sum(len(r) for r in rds), tcpu
             # a pilot sizes the sample to about --cpu-seconds of wall time on this host
-            pilot = min(max(args.cpu_sample, 2 * cores), nsteps * args.reads_per_step)
+            pilot = min(max(args.cpu_sample, 4 * cores), nsteps * args.reads_per_step)
             cal, cb, tcpu = cpu_leg(pilot)
             ns = int(min(nsteps * args.reads_per_step, max(pilot, pilot * args.cpu_seconds / max(tcpu, 1e-3))))
             if ns > pilot:

@@ -12,6 +12,7 @@
 // A Python exception inside the per-read path makes the reference skip the read (:24116-24125); here every such
 // site returns a negative status instead (documented next to each `return -...`).
 #include "vmo_internal.h"
+#include <malloc.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -562,6 +563,9 @@ int vmo_align_read(const vmo_index* mi, const char* read, int64_t readlen, const
 
 int vmo_align_batch(const vmo_index* mi, const vmo_params* p, int64_t n_reads, const char* seqs, const int64_t* offsets, int nthreads,
                     vmo_record** recs, int64_t* n_recs, char** blob, int32_t* status) {
+    // many threads: keep the per-read megabyte-sized scratch vectors (9-mer tables, DP matrices) inside the malloc arenas — with the
+    // default 128 KiB mmap threshold every one of them is an mmap/munmap pair and the threads queue on the process's address-space lock
+    if (nthreads > 1 && !getenv("VMO_NO_MALLOPT")) { mallopt(M_MMAP_THRESHOLD, 256 << 20); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_TOP_PAD, 64 << 20); }
     std::vector<std::vector<Record>> pr((size_t)n_reads);
     std::atomic<int64_t> next(0);
     auto work = [&]() {
