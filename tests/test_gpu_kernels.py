@@ -100,3 +100,35 @@ def test_mode_r_and_s(ctx, oracle, golden):
     KC.check_chain_global_golden(ctx, oracle, golden, cases=['G'])
     KC.check_local_golden(ctx, oracle, golden, cases=['G'])
     KC.check_align_golden(ctx, oracle, golden, cases=['G'])
+
+
+def test_driver_sam_end_to_end(ctx, golden, tmp_path):
+    """§8(f) rank 1: FASTA + FASTQ in, SAM out through the command-line driver; body lines equal the reference's get_bam_dict_str
+    output for the testdata pair (golden case A: three alignments +, -, +) and the SV-donor reads of case B"""
+    import json, os
+    import sam_cases as SC
+    from vacmap_amd import driver
+    meta, arrays = golden
+    entries = [e for e in json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'sam.json')))
+               if e['opt'] == {'md': False, 'shortcs': True, 'cigar2cg': False, 'markunbalancetra': True, 'H': False, 'fakecigar': False}]
+    for cid in ('A', 'B'):
+        c = meta[cid]
+        ref = tmp_path / ('ref%s.fa' % cid); fq = tmp_path / ('reads%s.fq' % cid); out = tmp_path / ('out%s.sam' % cid)
+        with open(ref, 'w') as f:
+            for i, n in enumerate(c['names']):
+                s = arrays['%s_contig%d' % (cid, i)].tobytes().decode()
+                f.write('>%s\n' % n)
+                for x in range(0, len(s), 80):
+                    f.write(s[x:x + 80] + '\n')
+        expect = []
+        with open(fq, 'w') as f:
+            for ri, r in enumerate(c['reads']):
+                q = arrays['%s_r%d_seq' % (cid, ri)].tobytes().decode()
+                f.write('@%s\n%s\n+\n%s\n' % (r['name'], q, ''.join(chr(33 + (7 * i) % 40) for i in range(len(q)))))
+                expect += [d for e in entries if e['case'] == cid and e['read'] == ri for d in e['digest']]
+        assert driver.main(['-ref', str(ref), '-read', str(fq), '-mode', c['mode'], '-k', str(c['k']), '-o', str(out), '-t', '2', '--nowriteindex']) == 0
+        lines = open(out).read().split('\n')
+        hdr = [x for x in lines if x.startswith('@')]
+        body = [x for x in lines if x and not x.startswith('@')]
+        assert hdr[0] == '@HD\tVN:1.0' and len([x for x in hdr if x.startswith('@SQ')]) == len(c['names']) and hdr[-1].startswith('@PG\tID:VACmap')
+        assert [SC.digest(x) for x in body] == expect, cid
