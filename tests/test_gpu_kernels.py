@@ -132,3 +132,26 @@ def test_driver_sam_end_to_end(ctx, golden, tmp_path):
         body = [x for x in lines if x and not x.startswith('@')]
         assert hdr[0] == '@HD\tVN:1.0' and len([x for x in hdr if x.startswith('@SQ')]) == len(c['names']) and hdr[-1].startswith('@PG\tID:VACmap')
         assert [SC.digest(x) for x in body] == expect, cid
+
+
+def test_ragged_and_extreme_batches(ctx, oracle):
+    """edge inputs of the batched entry: empty batch, empty / tiny / all-N / lower-case reads, a 120 kb read next to 200 b reads"""
+    from vacmap_amd import synth
+    from vacmap_amd.lib import Index, align_batch
+    contigs = synth.make_reference([600000], seed=71)
+    names = ['chrA']
+    gi = Index.from_seqs(ctx, names, [synth.tostr(contigs[0])], k=15, w=10)
+    oi = oracle.Index.from_seqs(names, [synth.tostr(contigs[0])], k=15, w=10)
+    prm = ctx.lib.params('H'); oprm = oracle.params('H')
+    st, recs, stats = align_batch(ctx, gi, prm, [])
+    assert len(st) == 0 and recs == [] and stats['n_reads'] == 0
+    rng = np.random.default_rng(72)
+    long_read = synth.tostr(synth.mutate(contigs[0][100000:220000], 0.08, rng))
+    mid = synth.tostr(synth.mutate(contigs[0][300000:309000], 0.10, rng))
+    seqs = ['', 'ACGTA', 'N' * 3000, mid.lower(), long_read, synth.tostr(contigs[0][5000:5200]), mid[:3000] + 'N' * 50 + mid[3050:],
+            synth.tostr(synth.revcomp(contigs[0][400000:404000]))]
+    status, recs, stats = align_batch(ctx, gi, prm, seqs)
+    ost, orecs = oracle.align_batch(oi, [s.upper() for s in seqs], oprm, nthreads=8)
+    assert [(int(s) == 0) for s in status] == [(int(s) == 0) for s in ost], (list(status), list(ost))
+    assert recs == orecs
+    assert any(t[0] == 4 for t in recs) and any(t[0] == 7 and t[2] == '-' for t in recs)
