@@ -51,6 +51,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
 #ifndef VMX_EMU
     VMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_local_seed, TPB, 0));
     if (occ < 1) occ = 1;
+    if (const char* e = getenv("VMX_LSEED_WGS")) { int v = atoi(e); if (v >= 1 && v < occ) occ = v; }     // tuning knob: workgroups per CU
 #endif
     const int G = (int)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)c->num_cu * occ));
     {
