@@ -234,8 +234,7 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
                     } else if (si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
                         test = Sj + (double)bonus - s_gapcost[gapcost];
                     } else {
-                        if (gapcost > extra_size) gapcost = extra_size;
-                        test = Sj - skipcost + (double)bonus - (double)tab.extra[gapcost];
+                        test = Sj - skipcost + (double)bonus - vmx_extra_cost(tab, gapcost);
                     }
                 }
                 const double incl = vmx_wave_incl_max_f64(test);                 // prefix max of the candidates' scores, in scan order

@@ -145,13 +145,12 @@ __device__ __forceinline__ bool vmx_fast_eval(const vmx_anchor& ai, const vmx_an
         if (VARIANT == 0) *test = Sj + (double)bonus - C.gapcost[gapcost];
         else *test = Sj + (double)bonus - C.gapcost[gapcost] - (double)C.rgc[readgap];
     } else if (VARIANT == 0) {
-        if (gapcost > C.extra_size) gapcost = C.extra_size;
-        *test = Sj - C.skipcost + (double)bonus - (double)C.tab.extra[gapcost];
+        *test = Sj - C.skipcost + (double)bonus - vmx_extra_cost(C.tab, gapcost);
     } else if (VARIANT == 1) {
-        if (gapcost > C.extra_size) gapcost = C.extra_size;
+        const double ex = vmx_extra_cost(C.tab, gapcost);
         double pen;
-        if (si != sj) pen = (C.skipcost < 50.0 ? C.skipcost : 50.0) + (double)C.tab.extra[gapcost];
-        else pen = C.skipcost + (double)C.tab.extra[gapcost];
+        if (si != sj) pen = (C.skipcost < 50.0 ? C.skipcost : 50.0) + ex;
+        else pen = C.skipcost + ex;
         *test = Sj + (double)bonus - pen;
     } else {
         const double pen = C.skipcost + C.tab.log2cache[gapcost < C.l2c_size ? gapcost : C.l2c_size];

@@ -120,10 +120,10 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
                         } else if (si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
                             test = Sj + (double)bonus - s_gapcost[gapcost] - (double)rgc[readgap];
                         } else if (!mm) {
-                            if (gapcost > extra_size) gapcost = extra_size;
+                            const double ex = vmx_extra_cost(tab, gapcost);
                             double pen;
-                            if (si != sj) pen = (skipcost < 50.0 ? skipcost : 50.0) + (double)tab.extra[gapcost];
-                            else pen = skipcost + (double)tab.extra[gapcost];
+                            if (si != sj) pen = (skipcost < 50.0 ? skipcost : 50.0) + ex;
+                            else pen = skipcost + ex;
                             test = Sj + (double)bonus - pen;
                         } else {
                             double pen = skipcost + tab.log2cache[gapcost < l2c_size ? gapcost : l2c_size];

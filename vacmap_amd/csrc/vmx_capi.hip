@@ -80,6 +80,17 @@ int vm_ctx_create(int device_id, vm_ctx** out) {
     c->tables.large_readgap = (const float*)(base + o_lr);
     c->tables.log2cache = (const double*)(base + o_l2c); c->tables.log2cache_n = (int)T.log2cache.size();
     c->tables.log2int = (const double*)(base + o_l2i);
+    // closed-form prefix of `extra` (vmx_extra_cost, vmx_kernels.h): the same two multiplies the kernels do, compared entry by entry
+    {
+        int an = 0; const int lim = std::min<int>(20000, (int)T.extra.size() - 1);
+        for (; an < lim; ++an) {
+            const double dg = (double)an; const double a = dg * 0.01;
+            const float v = (float)((a < 10.0 ? a : 10.0) + dg * 0.001);
+            if (memcmp(&v, &T.extra[an], 4) != 0) break;
+        }
+        c->tables.extra_arith_n = an;
+        if (T.extra.back() != 36.0f) { delete c; set_error("cost table `extra` does not end at 36.0"); return VM_ERR_UNSUPPORTED; }
+    }
     *out = c;
     return VM_OK;
 }

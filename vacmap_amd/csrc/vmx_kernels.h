@@ -30,7 +30,21 @@ struct vmx_tables {
     const float* readgap_h; const float* readgap_r; const float* large_readgap;
     const double* log2cache; int32_t log2cache_n;
     const double* log2int;
+    int32_t extra_arith_n;   // extra[g] == (float)(min(10, g*0.01) + g*0.001) for every g below this (checked on the host, vmx_capi.hip)
 };
+
+// extra[min(g, extra_n-1)] as a double without touching HBM where the table has a closed form: below extra_arith_n the entry is the
+// linear part of :15371-15376 (two multiplies; identical to the table by the host's exhaustive check), at or above the last index it
+// is the table's final value 36.0; only the logarithmic stretch in between is loaded.
+__device__ __forceinline__ double vmx_extra_cost(const vmx_tables& tab, long long g) {
+    if (g >= (long long)tab.extra_n - 1) return 36.0;
+    if (g < (long long)tab.extra_arith_n) {
+        const double dg = (double)(int)g;
+        const double a = dg * 0.01;
+        return (double)(float)((a < 10.0 ? a : 10.0) + dg * 0.001);
+    }
+    return (double)tab.extra[g];
+}
 
 // arguments of k_local_seed (L2): inputs, per-workgroup-slot scratch pools, outputs
 struct vmx_lseed_args {
