@@ -131,35 +131,25 @@ __device__ __forceinline__ void vmx_gap_geometry(int qi, long long ri, int si, i
 }
 
 
-__global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ aoff,
-                                                     const int32_t* __restrict__ rlist, int nlist, int lds_cap, vmx_tables tab,
-                                                     const double* __restrict__ gapcost_list, double oskipcost, int omaxdiff,
-                                                     int maxgap, double* __restrict__ S_out, int32_t* __restrict__ P_out,
-                                                     int32_t* __restrict__ SA_out, uint8_t* __restrict__ cov_pool,
-                                                     int64_t* __restrict__ gmax_out, int64_t* __restrict__ opcount_out, int rmode,
-                                                     double* __restrict__ FP_pool, double* __restrict__ PP_pool) {
-    VMX_DYN_SHARED(char, smem);
-    __shared__ double s_gapcost[64];
+// One read. IN_LDS is a compile-time switch so that the working arrays are plain LDS pointers (ds_read / ds_write) in the instantiation the
+// buckets run and plain global pointers in the other; a run-time choice between the two would turn every access into a flat_load.
+template <bool IN_LDS>
+__device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restrict__ anchors, int rd, int64_t a0, int n, long long rmin, char* smem,
+                                                      const double* s_gapcost, int lds_cap, const vmx_tables& tab, double oskipcost, int omaxdiff,
+                                                      int maxgap, double* __restrict__ S_out, int32_t* __restrict__ P_out,
+                                                      int32_t* __restrict__ SA_out, uint8_t* __restrict__ cov_pool,
+                                                      int64_t* __restrict__ gmax_out, int64_t* __restrict__ opcount_out, int rmode,
+                                                      double* __restrict__ FP_pool, double* __restrict__ PP_pool) {
     const int lane = vmx_lane();
-    for (int x = lane; x <= omaxdiff && x < 64; x += 64) s_gapcost[x] = gapcost_list[x];
-    __syncthreads();
-    const long long extra_size = (long long)tab.extra_n - 1;
-    for (int li_ = blockIdx.x; li_ < nlist; li_ += gridDim.x) {
-        const int rd = rlist[li_];
-        const int64_t a0 = aoff[rd];
-        const int n = (int)(aoff[rd + 1] - a0);
-        if (n <= 0) { if (lane == 0) { gmax_out[rd] = -2; opcount_out[rd] = 0; } continue; }
+    constexpr bool in_lds = IN_LDS;
+    {
         const vmx_anchor* A = anchors + a0;
         // working arrays: LDS when the read fits, else straight in the HBM output arrays
         // LDS layout (VMX_GC_BYTES_PER_ANCHOR = 25): S f64 | ref position relative to the smallest one u32 | q i32 | l,s packed i32 | S_arg i32 | cov u8.
         // P (written once per anchor) goes straight to its HBM output array.
-        long long rmin = 0x7fffffffffffffffLL, rmax = -0x7fffffffffffffffLL;
-        for (int i = lane; i < n; i += 64) { const long long r = A[i].r; rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax; }
-        for (int o = 32; o > 0; o >>= 1) { const long long a = __shfl_xor(rmin, o), b = __shfl_xor(rmax, o); rmin = a < rmin ? a : rmin; rmax = b > rmax ? b : rmax; }
         double* S; int* SA; int* Q; unsigned* R; int* LS; uint8_t* COV;
         int* P = P_out + a0;
-        const bool in_lds = n <= lds_cap && (rmax - rmin) < 0xffffffffLL;
-        if (in_lds) {
+        if constexpr (IN_LDS) {
             S = (double*)smem; R = (unsigned*)(S + lds_cap); Q = (int*)(R + lds_cap); LS = Q + lds_cap;
             SA = LS + lds_cap; COV = (uint8_t*)(SA + lds_cap);
         } else {
@@ -169,7 +159,7 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
         // stage anchors + coverage (number of anchors sharing the read position, capped at 20: :24865-24868)
         for (int i = lane; i < n; i += 64) {
             vmx_anchor a = A[i];
-            if (in_lds) { Q[i] = a.q; R[i] = (unsigned)(a.r - rmin); LS[i] = ((int)a.l & 0xffff) | ((int)a.s << 16); }
+            if constexpr (IN_LDS) { Q[i] = a.q; R[i] = (unsigned)(a.r - rmin); LS[i] = ((int)a.l & 0xffff) | ((int)a.s << 16); }
             int c = 1;
             for (int x = i - 1; x >= 0 && A[x].q == a.q && c < 20; --x) ++c;
             for (int x = i + 1; x < n && A[x].q == a.q && c < 20; ++x) ++c;
@@ -266,7 +256,7 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
                 vmx_sarg_insert4(SA, loc, k, lane);
             }
         }
-        if (in_lds) {
+        if constexpr (IN_LDS) {
             for (int i = lane; i < n; i += 64) { S_out[a0 + i] = S[i]; SA_out[a0 + i] = SA[i]; }
         }
         if (lane == 0) { gmax_out[rd] = bailed ? -1 : g_max_index; opcount_out[rd] = opcount; }
@@ -275,6 +265,36 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
 #undef AR
 #undef AL
 #undef AS
+    }
+}
+
+__global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ aoff,
+                                                     const int32_t* __restrict__ rlist, int nlist, int lds_cap, vmx_tables tab,
+                                                     const double* __restrict__ gapcost_list, double oskipcost, int omaxdiff,
+                                                     int maxgap, double* __restrict__ S_out, int32_t* __restrict__ P_out,
+                                                     int32_t* __restrict__ SA_out, uint8_t* __restrict__ cov_pool,
+                                                     int64_t* __restrict__ gmax_out, int64_t* __restrict__ opcount_out, int rmode,
+                                                     double* __restrict__ FP_pool, double* __restrict__ PP_pool) {
+    VMX_DYN_SHARED(char, smem);
+    __shared__ double s_gapcost[64];
+    const int lane = vmx_lane();
+    for (int x = lane; x <= omaxdiff && x < 64; x += 64) s_gapcost[x] = gapcost_list[x];
+    __syncthreads();
+    for (int li_ = blockIdx.x; li_ < nlist; li_ += gridDim.x) {
+        const int rd = rlist[li_];
+        const int64_t a0 = aoff[rd];
+        const int n = (int)(aoff[rd + 1] - a0);
+        if (n <= 0) { if (lane == 0) { gmax_out[rd] = -2; opcount_out[rd] = 0; } continue; }
+        const vmx_anchor* A = anchors + a0;
+        long long rmin = 0x7fffffffffffffffLL, rmax = -0x7fffffffffffffffLL;
+        for (int i = lane; i < n; i += 64) { const long long r = A[i].r; rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax; }
+        for (int o = 32; o > 0; o >>= 1) { const long long a = __shfl_xor(rmin, o), b = __shfl_xor(rmax, o); rmin = a < rmin ? a : rmin; rmax = b > rmax ? b : rmax; }
+        if (n <= lds_cap && (rmax - rmin) < 0xffffffffLL)
+            vmx_chain_global_read<true>(anchors, rd, a0, n, rmin, smem, s_gapcost, lds_cap, tab, oskipcost, omaxdiff, maxgap, S_out, P_out, SA_out, cov_pool, gmax_out,
+                                        opcount_out, rmode, FP_pool, PP_pool);
+        else
+            vmx_chain_global_read<false>(anchors, rd, a0, n, rmin, smem, s_gapcost, lds_cap, tab, oskipcost, omaxdiff, maxgap, S_out, P_out, SA_out, cov_pool, gmax_out,
+                                         opcount_out, rmode, FP_pool, PP_pool);
     }
 }
 

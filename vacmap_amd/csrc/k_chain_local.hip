@@ -13,27 +13,19 @@
 // The reference's smallorequal (:13229-13265) returns, on the score-sorted index, the position of the last score <= target, whatever
 // its probe sequence; the kernel computes that count directly (vmx_sorted_count, vmx_device.h).
 
-__global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ la_off,
-                                                    const int32_t* __restrict__ la_cnt, const int32_t* __restrict__ n_guides_total,
-                                                    const int32_t* __restrict__ rlist, int nlist, int lds_cap, vmx_tables tab,
-                                                    const double* __restrict__ gapcost_list, double skip_exact, double skip_mm, int maxdiff,
-                                                    int maxgap, int mode, double* __restrict__ S_pool, int32_t* __restrict__ P_pool,
-                                                    int32_t* __restrict__ SA_pool, double* __restrict__ out_score,
-                                                    vmx_anchor* __restrict__ out_chain, int32_t* __restrict__ out_len, int32_t* __restrict__ out_variant,
-                                                    int32_t* __restrict__ status, double* __restrict__ FP_pool, double* __restrict__ PP_pool) {
-    VMX_DYN_SHARED(char, smem);
-    __shared__ double s_gapcost[64];
-    __shared__ float s_rgc[128];
+// One read. IN_LDS is a compile-time switch so that the working arrays are plain LDS pointers (ds_read / ds_write) in the instantiation the
+// buckets run, and plain global pointers in the other one; a run-time choice between the two would make every access a flat_load.
+template <bool IN_LDS>
+__device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restrict__ anchors, const int32_t* __restrict__ n_guides_total, int rd, int64_t a0, int n,
+                                                     long long rmin, char* smem, const double* s_gapcost, float* s_rgc, int lds_cap, const vmx_tables& tab,
+                                                     double skip_exact, double skip_mm, int maxdiff, int maxgap, int mode, double* __restrict__ S_pool,
+                                                     int32_t* __restrict__ P_pool, int32_t* __restrict__ SA_pool, double* __restrict__ out_score,
+                                                     vmx_anchor* __restrict__ out_chain, int32_t* __restrict__ out_len, int32_t* __restrict__ out_variant,
+                                                     int32_t* __restrict__ status, double* __restrict__ FP_pool, double* __restrict__ PP_pool) {
     const int lane = vmx_lane();
-    for (int x = lane; x <= maxdiff && x < 64; x += 64) s_gapcost[x] = gapcost_list[x];
-    __syncthreads();
-    const long long extra_size = (long long)tab.extra_n - 1;
     const long long l2c_size = (long long)tab.log2cache_n - 1;
-    for (int li_ = blockIdx.x; li_ < nlist; li_ += gridDim.x) {
-        const int rd = rlist[li_];
-        const int64_t a0 = la_off[rd];
-        const int n = la_cnt[rd];
-        if (n <= 0) { if (lane == 0) { out_len[rd] = 0; out_score[rd] = 0; status[rd] = VM_READ_RAISED_DEV; } continue; }   // np.array([]) indexing raises
+    constexpr bool in_lds = IN_LDS;
+    {
         // mode R runs one variant, `_scar` (mammap_noprefercloser.py:23419-23628): anchors sorted by read START, a non-co-linear step costs
         // the fixed skipcost, remembered per anchor in fixed_penatly / pre_penatly (FP / PP, in HBM) and refunded once the chain has gone
         // on co-linearly for skipcost bases; no opcount switch
@@ -47,15 +39,11 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
         const vmx_anchor* A = anchors + a0;
         // LDS layout (VMX_LC_BYTES_PER_ANCHOR = 24): S f64 | ref position relative to the smallest one u32 | q i32 | l,s packed i32 | S_arg i32.
         // P (written once per anchor, read by the traceback) stays in HBM.
-        long long rmin = 0x7fffffffffffffffLL, rmax = -0x7fffffffffffffffLL;
-        for (int i = lane; i < n; i += 64) { const long long r = A[i].r; rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax; }
-        for (int o = 32; o > 0; o >>= 1) { const long long a = __shfl_xor(rmin, o), b = __shfl_xor(rmax, o); rmin = a < rmin ? a : rmin; rmax = b > rmax ? b : rmax; }
         double* S; int* SA; int* Q; unsigned* R; int* LS;
         int* P = P_pool + a0;
-        const bool in_lds = n <= lds_cap && (rmax - rmin) < 0xffffffffLL;
-        if (in_lds) { S = (double*)smem; R = (unsigned*)(S + lds_cap); Q = (int*)(R + lds_cap); LS = Q + lds_cap; SA = LS + lds_cap; }
+        if constexpr (IN_LDS) { S = (double*)smem; R = (unsigned*)(S + lds_cap); Q = (int*)(R + lds_cap); LS = Q + lds_cap; SA = LS + lds_cap; }
         else { S = S_pool + a0; SA = SA_pool + a0; Q = nullptr; R = nullptr; LS = nullptr; }
-        if (in_lds) for (int i = lane; i < n; i += 64) { vmx_anchor a = A[i]; Q[i] = a.q; R[i] = (unsigned)(a.r - rmin); LS[i] = ((int)a.l & 0xffff) | ((int)a.s << 16); }
+        if constexpr (IN_LDS) for (int i = lane; i < n; i += 64) { vmx_anchor a = A[i]; Q[i] = a.q; R[i] = (unsigned)(a.r - rmin); LS[i] = ((int)a.l & 0xffff) | ((int)a.s << 16); }
         __syncthreads();
 #define AQ(i) (in_lds ? Q[i] : A[i].q)
 #define AR(i) (in_lds ? (rmin + (long long)R[i]) : (long long)A[i].r)
@@ -183,5 +171,37 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
 #undef AR
 #undef AL
 #undef AS
+    }
+}
+
+__global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ la_off,
+                                                    const int32_t* __restrict__ la_cnt, const int32_t* __restrict__ n_guides_total,
+                                                    const int32_t* __restrict__ rlist, int nlist, int lds_cap, vmx_tables tab,
+                                                    const double* __restrict__ gapcost_list, double skip_exact, double skip_mm, int maxdiff,
+                                                    int maxgap, int mode, double* __restrict__ S_pool, int32_t* __restrict__ P_pool,
+                                                    int32_t* __restrict__ SA_pool, double* __restrict__ out_score,
+                                                    vmx_anchor* __restrict__ out_chain, int32_t* __restrict__ out_len, int32_t* __restrict__ out_variant,
+                                                    int32_t* __restrict__ status, double* __restrict__ FP_pool, double* __restrict__ PP_pool) {
+    VMX_DYN_SHARED(char, smem);
+    __shared__ double s_gapcost[64];
+    __shared__ float s_rgc[128];
+    const int lane = vmx_lane();
+    for (int x = lane; x <= maxdiff && x < 64; x += 64) s_gapcost[x] = gapcost_list[x];
+    __syncthreads();
+    for (int li_ = blockIdx.x; li_ < nlist; li_ += gridDim.x) {
+        const int rd = rlist[li_];
+        const int64_t a0 = la_off[rd];
+        const int n = la_cnt[rd];
+        if (n <= 0) { if (lane == 0) { out_len[rd] = 0; out_score[rd] = 0; status[rd] = VM_READ_RAISED_DEV; } continue; }   // np.array([]) indexing raises
+        const vmx_anchor* A = anchors + a0;
+        long long rmin = 0x7fffffffffffffffLL, rmax = -0x7fffffffffffffffLL;
+        for (int i = lane; i < n; i += 64) { const long long r = A[i].r; rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax; }
+        for (int o = 32; o > 0; o >>= 1) { const long long a = __shfl_xor(rmin, o), b = __shfl_xor(rmax, o); rmin = a < rmin ? a : rmin; rmax = b > rmax ? b : rmax; }
+        if (n <= lds_cap && (rmax - rmin) < 0xffffffffLL)
+            vmx_chain_local_read<true>(anchors, n_guides_total, rd, a0, n, rmin, smem, s_gapcost, s_rgc, lds_cap, tab, skip_exact, skip_mm, maxdiff, maxgap, mode, S_pool, P_pool,
+                                       SA_pool, out_score, out_chain, out_len, out_variant, status, FP_pool, PP_pool);
+        else
+            vmx_chain_local_read<false>(anchors, n_guides_total, rd, a0, n, rmin, smem, s_gapcost, s_rgc, lds_cap, tab, skip_exact, skip_mm, maxdiff, maxgap, mode, S_pool, P_pool,
+                                        SA_pool, out_score, out_chain, out_len, out_variant, status, FP_pool, PP_pool);
     }
 }

@@ -177,17 +177,17 @@ __device__ __forceinline__ int vmx_sorted_count(const double* S, const int* SA, 
 // wave-cooperative SA[loc+1 : k+1] = SA[loc : k]; SA[loc] = k (256 elements per round)
 __device__ __forceinline__ void vmx_sarg_insert4(int* SA, int loc, int k, int lane) {
     for (int hi = k; hi > loc; hi -= 256) {
-        const int x0 = hi - 4 * lane;
+        const int x0 = hi - lane;             // consecutive lanes touch consecutive words: no LDS bank conflicts
         int v0 = 0, v1 = 0, v2 = 0, v3 = 0;
         if (x0 > loc) v0 = SA[x0 - 1];
-        if (x0 - 1 > loc) v1 = SA[x0 - 2];
-        if (x0 - 2 > loc) v2 = SA[x0 - 3];
-        if (x0 - 3 > loc) v3 = SA[x0 - 4];
+        if (x0 - 64 > loc) v1 = SA[x0 - 65];
+        if (x0 - 128 > loc) v2 = SA[x0 - 129];
+        if (x0 - 192 > loc) v3 = SA[x0 - 193];
         __syncthreads();
         if (x0 > loc) SA[x0] = v0;
-        if (x0 - 1 > loc) SA[x0 - 1] = v1;
-        if (x0 - 2 > loc) SA[x0 - 2] = v2;
-        if (x0 - 3 > loc) SA[x0 - 3] = v3;
+        if (x0 - 64 > loc) SA[x0 - 64] = v1;
+        if (x0 - 128 > loc) SA[x0 - 128] = v2;
+        if (x0 - 192 > loc) SA[x0 - 192] = v3;
         __syncthreads();
     }
     if (lane == 0) SA[loc] = k;
