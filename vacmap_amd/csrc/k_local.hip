@@ -253,6 +253,9 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             // pass A: accepted hits per read position and strand (any order), no barrier inside the loop so that the waves overlap their
             // table walks. The first accepted hit of either strand is parked in STG: a position with at most one hit per strand (nearly all)
             // needs no second walk in pass B.
+            // (instantiated for the LDS copy of the guide and for the HBM one: a pointer chosen at run time would turn the bisection's
+            // dependent loads into flat accesses)
+            auto pass_a = [&](const int* GQ, const long long* GR) __attribute__((always_inline)) {
             for (int pi = (int)threadIdx.x; pi < npos; pi += (int)blockDim.x) {
                 const int iloc = readstart + pi;
                 int cf = 0, cr = 0; long long ff = 0, fr = 0;
@@ -271,6 +274,8 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 PC2[pi] = (cf > 0xffff ? 0xffff : cf) | ((cr > 0x7fff ? 0x7fff : cr) << 16);
                 STG[2 * pi] = ff; STG[2 * pi + 1] = fr;
             }
+            };
+            if (g_lds) pass_a(s_gq, s_gr); else pass_a(GQg, (const long long*)GRg);
             __syncthreads();
             // exclusive offsets: every thread scans a contiguous slice of the per-position counts
             long long H;

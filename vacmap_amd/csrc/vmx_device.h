@@ -211,11 +211,7 @@ __device__ __forceinline__ int vmx_block_excl_scan(int v, int* scratch, int* tot
 
 // block-wide bitonic sort of N (power of two) uint64 keys living in HBM at g; staged through `lds` (lds_cap keys) when they fit.
 // every thread of the workgroup must call it.
-__device__ inline void vmx_block_sort_u64_impl(uint64_t* g, int N, uint64_t* lds, int lds_cap) {
-    uint64_t* a = g;
-    const bool in_lds = N <= lds_cap;
-    if (in_lds) { for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) lds[i] = g[i]; a = lds; }
-    __syncthreads();
+__device__ __forceinline__ void vmx_block_bitonic_passes(uint64_t* a, int N) {
     for (int k = 2; k <= N; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) {
@@ -229,7 +225,19 @@ __device__ inline void vmx_block_sort_u64_impl(uint64_t* g, int N, uint64_t* lds
             __syncthreads();
         }
     }
-    if (in_lds) { for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) g[i] = lds[i]; __syncthreads(); }
+}
+// (the passes are instantiated once on the LDS buffer and once on the HBM array: a pointer chosen at run time would make them flat accesses)
+__device__ inline void vmx_block_sort_u64_impl(uint64_t* g, int N, uint64_t* lds, int lds_cap) {
+    if (N <= lds_cap) {
+        for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) lds[i] = g[i];
+        __syncthreads();
+        vmx_block_bitonic_passes(lds, N);
+        for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) g[i] = lds[i];
+        __syncthreads();
+    } else {
+        __syncthreads();
+        vmx_block_bitonic_passes(g, N);
+    }
 }
 
 // block-wide STABLE LSD radix sort of n uint64 keys on the bit field [(key >> shift) - base] & (2^nbits - 1), 4 bits per pass,
