@@ -12,6 +12,11 @@ Multi-GPU: the reference index is replicated per GPU (each rank builds the same 
 across ranks, no data-path collective (weak scaling); torch.distributed (RCCL) provides the barrier and the reductions.
 """
 import argparse, json, os, sys, time
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4). Each batch in flight drives one
+# main stream and four side streams (the LDS buckets of the chain kernels run side by side), so with the default the batches in
+# flight serialise behind one another's queues; 8 queues measured best (3 batches in flight: 73.5 -> 65.5 ms per step). Must be set
+# before the runtime initialises, i.e. before torch / the library touch the GPU. See INTEGRATION.md.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -32,7 +37,7 @@ def main():
     ap.add_argument('--err', type=float, default=0.10)
     ap.add_argument('--cpu-sample', type=int, default=96, help='minimum reads for the CPU baseline leg (rank 0, N=1 only); 0 disables')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='target wall time of the CPU baseline leg (the sample is sized by a pilot)')
-    ap.add_argument('--streams', type=int, default=2, help='batches in flight per GPU: one context (HIP stream set + work pools) and one host thread each')
+    ap.add_argument('--streams', type=int, default=3, help='batches in flight per GPU: one context (HIP stream set + work pools) and one host thread each')
     ap.add_argument('--verify', type=int, default=8, help='reads of the first batch cross-checked against the oracle (0 disables)')
     args = ap.parse_args()
 

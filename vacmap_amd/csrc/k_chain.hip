@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(64) k_chain_select(const vmx_anchor* __restric
         const bool full = run && n <= VMX_SELECT_LDS_FULL;
         double* s_S = (double*)s_buf; int32_t* s_P = (int32_t*)(s_S + n); int32_t* s_SA = s_P + n;
         char* s_scr = (char*)(s_SA + n);                                  // full tier: scratch (8-byte aligned: n * 16 bytes precede it)
-        unsigned char* s_used = full ? (unsigned char*)nullptr : (unsigned char*)(s_SA + n);
+        unsigned char* s_used = (unsigned char*)(s_SA + n);               // mid tier only (the full tier keeps `used` inside its LDS scratch)
         if (in_lds) for (int i = lane; i < n; i += 64) { s_S[i] = S[a0 + i]; s_P[i] = P[a0 + i]; s_SA[i] = SA[a0 + i]; if (!full) s_used[i] = 0; }
         __syncthreads();
         if (lane == 0) {

@@ -56,14 +56,31 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
         double g_max_scores = (double)AL(0); int g_max_index = 0;
         long long opcount = 0;
         bool need_fast = false;
+        // candidate window (vmx_cwin): the testspace_en entries of S_arg, best first, the top 64 of them in registers
+        vmx_cwin win; win.j = 0; win.q = AQ(0); win.ls = AL(0) | (AS(0) << 16); win.S = (double)AL(0); win.r = AR(0);
+        int nq = 0, nl = 0, ns = 0; long long nr = 0;            // anchor i+1, loaded one step ahead
+        if (n > 1) { nq = AQ(1); nr = AR(1); nl = AL(1); ns = AS(1); }
+        int pq = win.q, pls = win.ls; long long pr = win.r; double pS = win.S;      // anchor i-1 and its score
         for (int i = 1; i < n; ++i) {
-            const int qi = AQ(i); const long long ri = AR(i); const int li = AL(i); const int si = AS(i);
+            const int qi = nq; const long long ri = nr; const int li = nl; const int si = ns;
+            if (i + 1 < n) { nq = AQ(i + 1); nr = AR(i + 1); nl = AL(i + 1); ns = AS(i + 1); }
             if (prereadloc < (long long)qi + li) {
                 if (!scar && opcount > 100000 && ((double)opcount / (double)prereadloc) > 1000.0) { need_fast = true; break; }   // :27380 -> *_fast
                 for (int k = testspace_en; k < i; ++k) {
-                    // smallorequal(...) + 1 (:13229-13265) on a sorted array = number of scores <= S[k]
-                    const int loc = vmx_sorted_count(S, SA, k, S[k], true, lane);
-                    vmx_sarg_insert4(SA, loc, k, lane);
+                    // smallorequal(...) + 1 (:13229-13265) on a sorted array = number of scores <= S[k]: the new entry goes above its equals
+                    double Sk; int qk, lsk; long long rk;
+                    if (k == i - 1) { Sk = pS; qk = pq; lsk = pls; rk = pr; }
+                    else { Sk = S[k]; qk = AQ(k); lsk = AL(k) | (AS(k) << 16); rk = AR(k); }
+                    const int W = k < 64 ? k : 64;               // k entries so far
+                    const int above = __popcll(__ballot(lane < W && win.S > Sk));
+                    if (above < 64 && (above < W || W == k)) {
+                        vmx_cwin_insert(win, above, k, Sk, qk, lsk, rk, lane);
+                        if (lane <= above) SA[k - lane] = win.j;
+                    } else {                                     // lands below the window: search + shift in the full index, then reload the window
+                        const int loc = vmx_sorted_count(S, SA, k, Sk, true, lane);
+                        vmx_sarg_insert4(SA, loc, k, lane);
+                        if (lane <= k) { const int j = SA[k - lane]; win.j = j; win.S = S[j]; win.q = AQ(j); win.ls = AL(j) | (AS(j) << 16); win.r = AR(j); }
+                    }
                 }
                 testspace_en = i;
                 prereadloc = (long long)qi + li;
@@ -77,8 +94,9 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
                 int j = 0; double Sj = 0.0; double test = -1e300;
                 double nfp = 0.0, npp = 0.0;                     // scar: what i inherits if this candidate wins
                 if (valid) {
-                    j = SA[x]; Sj = S[j];
-                    const int qj = AQ(j), lj = AL(j), sj = AS(j); const long long rj = AR(j);
+                    int qj, lj, sj; long long rj;
+                    if (base == testspace_en - 1) { j = win.j; Sj = win.S; qj = win.q; lj = win.ls & 0xffff; sj = win.ls >> 16; rj = win.r; }   // first 64: registers
+                    else { j = SA[x]; Sj = S[j]; qj = AQ(j); lj = AL(j); sj = AS(j); rj = AR(j); }
                     long long readgap = (long long)qi - qj - lj, refgap, bonus;
                     bool skip = false;
                     if (readgap < 0) {
@@ -141,6 +159,7 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
             }
             if (lane == 0) { S[i] = max_scores; P[i] = pre_index; if (scar) { FP[i] = fp_i; PP[i] = pp_i; } }
             if (max_scores > g_max_scores) { g_max_scores = max_scores; g_max_index = i; }
+            pS = max_scores; pq = qi; pls = li | (si << 16); pr = ri;
             __syncthreads();
         }
         // traceback with overlap trimming :27508-27526 (serial, lane 0)

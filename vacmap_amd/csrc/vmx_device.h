@@ -86,6 +86,22 @@ __device__ __forceinline__ double vmx_shr1_f64(double v) {
     u.i[0] = vmx_shr1(u.i[0]); u.i[1] = vmx_shr1(u.i[1]);
     return u.d;
 }
+__device__ __forceinline__ long long vmx_shr1_i64(long long v) {
+    union { long long d; int i[2]; } u; u.d = v;
+    u.i[0] = vmx_shr1(u.i[0]); u.i[1] = vmx_shr1(u.i[1]);
+    return u.d;
+}
+// The chain kernels' candidate window: lane t holds entry S_arg[m-1-t] of the score-sorted index (m entries so far), i.e. the 64 best
+// predecessors in scan order, with everything a candidate evaluation needs (anchor index, score, read position, length|strand<<16,
+// reference position). A new anchor whose score lands inside the window is inserted with one ballot and seven v_mov_dpp; no LDS read
+// sits on the per-anchor dependency chain.
+struct vmx_cwin { int j, q, ls; double S; long long r; };
+__device__ __forceinline__ void vmx_cwin_insert(vmx_cwin& w, int at, int k, double Sk, int qk, int lsk, long long rk, int lane) {
+    const int sj = vmx_shr1(w.j), sq = vmx_shr1(w.q), sls = vmx_shr1(w.ls);
+    const double sS = vmx_shr1_f64(w.S); const long long sr = vmx_shr1_i64(w.r);
+    if (lane > at) { w.j = sj; w.q = sq; w.ls = sls; w.S = sS; w.r = sr; }
+    else if (lane == at) { w.j = k; w.q = qk; w.ls = lsk; w.S = Sk; w.r = rk; }
+}
 __device__ __forceinline__ double vmx_readlane_f64(double v, int l) {
     union { double d; int i[2]; } u; u.d = v;
     u.i[0] = vmx_readlane(u.i[0], l); u.i[1] = vmx_readlane(u.i[1], l);

@@ -27,9 +27,17 @@ __host__ __device__ inline int vmx_desc_intersect(const int* a, int na, const in
     return c;
 }
 
-__host__ __device__ inline void vmx_chain_select(const vmx_anchor* A, int n, int64_t L, const double* S, const int32_t* P,
+// always inlined on the device: the kernel calls it on LDS-staged and on HBM arrays, and each inlined copy gets plain ds_ / global_
+// accesses where a shared out-of-line body would have to use flat ones
+#ifdef __HIPCC__
+#define VMX_SELECT_INLINE __attribute__((always_inline)) inline
+#else
+#define VMX_SELECT_INLINE inline
+#endif
+// `used` (n flags, all zero on entry) is either the caller's buffer or the tail of `scratch` (the overload below)
+__host__ __device__ VMX_SELECT_INLINE void vmx_chain_select(const vmx_anchor* A, int n, int64_t L, const double* S, const int32_t* P,
                                                  const int32_t* SA, int gmax, int mode, char* scratch, int32_t* out_path_len,
-                                                 vmx_anchor* out_rows, vmx_select_out* o, unsigned char* used_buf = nullptr) {
+                                                 vmx_anchor* out_rows, vmx_select_out* o, unsigned char* used) {
     (void)L;
     double* cscore = (double*)scratch;
     int* cidx = (int*)(cscore + n);
@@ -39,8 +47,6 @@ __host__ __device__ inline void vmx_chain_select(const vmx_anchor* A, int n, int
     int* boff = bins + n;            // n+1
     int* prim = boff + n + 1;        // n
     int* sec = prim + n;             // n
-    unsigned char* used = used_buf ? used_buf : (unsigned char*)(sec + n + 4);     // used_buf: caller-provided (LDS), already zeroed
-    if (!used_buf) for (int i = 0; i < n; ++i) used[i] = 0;
     const double accept = (mode == 0) ? 60.0 : 40.0;
     const int sec_min_span = (mode == 3) ? 100 : 50;
     int nch = 0, w = 0;
@@ -150,6 +156,14 @@ __host__ __device__ inline void vmx_chain_select(const vmx_anchor* A, int n, int
     }
     o->n_paths = nsec + 1;
     o->score = cscore[0];
+}
+
+__host__ __device__ VMX_SELECT_INLINE void vmx_chain_select(const vmx_anchor* A, int n, int64_t L, const double* S, const int32_t* P,
+                                                 const int32_t* SA, int gmax, int mode, char* scratch, int32_t* out_path_len,
+                                                 vmx_anchor* out_rows, vmx_select_out* o) {
+    unsigned char* used = (unsigned char*)((int*)((double*)scratch + n) + 7 * (size_t)n + 2 + 4);   // behind cscore and the seven int lists
+    for (int i = 0; i < n; ++i) used[i] = 0;
+    vmx_chain_select(A, n, L, S, P, SA, gmax, mode, scratch, out_path_len, out_rows, o, used);
 }
 
 #endif
