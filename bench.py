@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--steps', type=int, default=12, help='timed batches (default 12: half of the 24 batches of the 100k-read workload; enough for the 3 batches in flight to reach steady state)')
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--reads-per-step', type=int, default=4096)
     ap.add_argument('--ref-mb', type=float, default=100.0)

@@ -183,7 +183,8 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
         long long opcount = 0;
         bool bailed = false;
         for (int i = 1; i < n; ++i) {
-            const int qi = AQ(i); const long long ri = AR(i); const int li = AL(i); const int si = AS(i);
+            // the current anchor is the same in every lane: scalar registers, scalar branches on its strand
+            const int qi = vmx_uniform_i32(AQ(i)); const long long ri = vmx_uniform_i64(AR(i)); const int li = vmx_uniform_i32(AL(i)); const int si = vmx_uniform_i32(AS(i));
             if (prereadloc < qi) {
                 if (((double)opcount / (double)i) > 1000.0) { bailed = true; break; }   // :24914 max_factor
                 for (int k = testspace_en; k < i; ++k) {

@@ -15,7 +15,8 @@
 
 // One read. IN_LDS is a compile-time switch so that the working arrays are plain LDS pointers (ds_read / ds_write) in the instantiation the
 // buckets run, and plain global pointers in the other one; a run-time choice between the two would make every access a flat_load.
-template <bool IN_LDS>
+// VAR (0 LC-exact, 1 LC-mm, 2 `_scar`) is compile-time too: each instantiation carries one scoring rule.
+template <bool IN_LDS, int VAR>
 __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restrict__ anchors, const int32_t* __restrict__ n_guides_total, int rd, int64_t a0, int n,
                                                      long long rmin, char* smem, const double* s_gapcost, float* s_rgc, int lds_cap, const vmx_tables& tab,
                                                      double skip_exact, double skip_mm, int maxdiff, int maxgap, int mode, double* __restrict__ S_pool,
@@ -29,8 +30,8 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
         // mode R runs one variant, `_scar` (mammap_noprefercloser.py:23419-23628): anchors sorted by read START, a non-co-linear step costs
         // the fixed skipcost, remembered per anchor in fixed_penatly / pre_penatly (FP / PP, in HBM) and refunded once the chain has gone
         // on co-linearly for skipcost bases; no opcount switch
-        const bool scar = mode == 3;
-        const bool mm = !scar && n_guides_total[rd] > 1;
+        constexpr bool scar = VAR == 2;
+        constexpr bool mm = VAR == 1;
         double* FP = scar ? FP_pool + a0 : nullptr; double* PP = scar ? PP_pool + a0 : nullptr;
         const double skipcost = mm ? skip_mm : skip_exact;
         const float* rgc_g = mm ? tab.large_readgap : (mode == 3 ? tab.readgap_r : tab.readgap_h);
@@ -62,7 +63,8 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
         if (n > 1) { nq = AQ(1); nr = AR(1); nl = AL(1); ns = AS(1); }
         int pq = win.q, pls = win.ls; long long pr = win.r; double pS = win.S;      // anchor i-1 and its score
         for (int i = 1; i < n; ++i) {
-            const int qi = nq; const long long ri = nr; const int li = nl; const int si = ns;
+            // the current anchor is the same in every lane: scalar registers, scalar branches on its strand
+            const int qi = vmx_uniform_i32(nq); const long long ri = vmx_uniform_i64(nr); const int li = vmx_uniform_i32(nl); const int si = vmx_uniform_i32(ns);
             if (i + 1 < n) { nq = AQ(i + 1); nr = AR(i + 1); nl = AL(i + 1); ns = AS(i + 1); }
             if (prereadloc < (long long)qi + li) {
                 if (!scar && opcount > 100000 && ((double)opcount / (double)prereadloc) > 1000.0) { need_fast = true; break; }   // :27380 -> *_fast
@@ -216,11 +218,11 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
         long long rmin = 0x7fffffffffffffffLL, rmax = -0x7fffffffffffffffLL;
         for (int i = lane; i < n; i += 64) { const long long r = A[i].r; rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax; }
         for (int o = 32; o > 0; o >>= 1) { const long long a = __shfl_xor(rmin, o), b = __shfl_xor(rmax, o); rmin = a < rmin ? a : rmin; rmax = b > rmax ? b : rmax; }
-        if (n <= lds_cap && (rmax - rmin) < 0xffffffffLL)
-            vmx_chain_local_read<true>(anchors, n_guides_total, rd, a0, n, rmin, smem, s_gapcost, s_rgc, lds_cap, tab, skip_exact, skip_mm, maxdiff, maxgap, mode, S_pool, P_pool,
-                                       SA_pool, out_score, out_chain, out_len, out_variant, status, FP_pool, PP_pool);
-        else
-            vmx_chain_local_read<false>(anchors, n_guides_total, rd, a0, n, rmin, smem, s_gapcost, s_rgc, lds_cap, tab, skip_exact, skip_mm, maxdiff, maxgap, mode, S_pool, P_pool,
-                                        SA_pool, out_score, out_chain, out_len, out_variant, status, FP_pool, PP_pool);
+        const int var = mode == 3 ? 2 : (n_guides_total[rd] > 1 ? 1 : 0);
+#define VMX_LC_CALL(L, V) vmx_chain_local_read<L, V>(anchors, n_guides_total, rd, a0, n, rmin, smem, s_gapcost, s_rgc, lds_cap, tab, skip_exact, skip_mm, maxdiff, maxgap, \
+                                                      mode, S_pool, P_pool, SA_pool, out_score, out_chain, out_len, out_variant, status, FP_pool, PP_pool)
+        if (n <= lds_cap && (rmax - rmin) < 0xffffffffLL) { if (var == 0) VMX_LC_CALL(true, 0); else if (var == 1) VMX_LC_CALL(true, 1); else VMX_LC_CALL(true, 2); }
+        else { if (var == 0) VMX_LC_CALL(false, 0); else if (var == 1) VMX_LC_CALL(false, 1); else VMX_LC_CALL(false, 2); }
+#undef VMX_LC_CALL
     }
 }

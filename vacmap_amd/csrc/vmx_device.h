@@ -75,6 +75,11 @@ __device__ __forceinline__ int vmx_uniform_i32(int v) { return v; }
 #else
 __device__ __forceinline__ int vmx_uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
+__device__ __forceinline__ long long vmx_uniform_i64(long long v) {
+    union { long long d; int i[2]; } u; u.d = v;
+    u.i[0] = vmx_uniform_i32(u.i[0]); u.i[1] = vmx_uniform_i32(u.i[1]);
+    return u.d;
+}
 // broadcast lane 0's value to the wave
 #ifdef VMX_EMU
 __device__ __forceinline__ int vmx_bcast0(int v) { return __shfl(v, 0); }
