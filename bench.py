@@ -169,6 +169,7 @@ def main():
         # roofline of the dominant kernel (k_gapfill_fill): algorithmic bytes per launch per SURVEY §8(d):
         #   B(read) = L + 16 M + 8 n + (L + 14000)/4 + 40 R + C   with measured M (minimizers), n (anchors), R (records), C (CIGAR bytes)
         nl = max(int(agg['n_gapfill_launches']), 1)
+        _free, _tot = torch.cuda.mem_get_info(local_rank); hbm_used_gb = (_tot - _free) / 1e9      # index + reads + every context's work pools
         algo_bytes = (agg['read_bases'] + 16 * agg['n_minimizers'] + 8 * agg['n_anchors'] + (agg['read_bases'] + 14000 * agg['n_reads']) / 4.0 +
                       40 * agg['n_records'] + agg['cigar_bytes'])
         # one step launches the kernel twice (normal pass + nofilter redo); the redo launch covers a handful of reads, so the
@@ -239,7 +240,7 @@ def main():
                          'local_anchors': agg['n_local_anchors'] / max(agg['n_reads'], 1), 'dp_problems': agg['n_dp_problems'] / max(agg['n_reads'], 1),
                          'dp_cells': agg['dp_cells'] / max(agg['n_reads'], 1), 'records': agg['n_records'] / max(agg['n_reads'], 1)},
             'ed_problems_per_step': agg['n_ed_problems'] / K, 'ed_tier1_per_step': agg.get('n_ed_tier1', 0) / K, 'ed_tier2_per_step': agg.get('n_ed_tier2', 0) / K, 'ed_unbanded_per_step': agg.get('n_ed_full', 0) / K,
-            'oracle_crosscheck': verified, 'setup_s': t_setup, 'index_build_s': t_index,
+            'oracle_crosscheck': verified, 'setup_s': t_setup, 'index_build_s': t_index, 'hbm_used_gb': hbm_used_gb,
             'roofline': roofline, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))

@@ -133,15 +133,16 @@ __device__ __forceinline__ void vmx_gap_geometry(int qi, long long ri, int si, i
 
 // One read. IN_LDS is a compile-time switch so that the working arrays are plain LDS pointers (ds_read / ds_write) in the instantiation the
 // buckets run and plain global pointers in the other; a run-time choice between the two would turn every access into a flat_load.
-template <bool IN_LDS>
+template <bool IN_LDS, bool RMODE>
 __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restrict__ anchors, int rd, int64_t a0, int n, long long rmin, char* smem,
                                                       const double* s_gapcost, int lds_cap, const vmx_tables& tab, double oskipcost, int omaxdiff,
                                                       int maxgap, double* __restrict__ S_out, int32_t* __restrict__ P_out,
                                                       int32_t* __restrict__ SA_out, uint8_t* __restrict__ cov_pool,
-                                                      int64_t* __restrict__ gmax_out, int64_t* __restrict__ opcount_out, int rmode,
+                                                      int64_t* __restrict__ gmax_out, int64_t* __restrict__ opcount_out,
                                                       double* __restrict__ FP_pool, double* __restrict__ PP_pool) {
     const int lane = vmx_lane();
     constexpr bool in_lds = IN_LDS;
+    constexpr bool rmode = RMODE;
     {
         const vmx_anchor* A = anchors + a0;
         // working arrays: LDS when the read fits, else straight in the HBM output arrays
@@ -290,12 +291,11 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
         long long rmin = 0x7fffffffffffffffLL, rmax = -0x7fffffffffffffffLL;
         for (int i = lane; i < n; i += 64) { const long long r = A[i].r; rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax; }
         for (int o = 32; o > 0; o >>= 1) { const long long a = __shfl_xor(rmin, o), b = __shfl_xor(rmax, o); rmin = a < rmin ? a : rmin; rmax = b > rmax ? b : rmax; }
-        if (n <= lds_cap && (rmax - rmin) < 0xffffffffLL)
-            vmx_chain_global_read<true>(anchors, rd, a0, n, rmin, smem, s_gapcost, lds_cap, tab, oskipcost, omaxdiff, maxgap, S_out, P_out, SA_out, cov_pool, gmax_out,
-                                        opcount_out, rmode, FP_pool, PP_pool);
-        else
-            vmx_chain_global_read<false>(anchors, rd, a0, n, rmin, smem, s_gapcost, lds_cap, tab, oskipcost, omaxdiff, maxgap, S_out, P_out, SA_out, cov_pool, gmax_out,
-                                         opcount_out, rmode, FP_pool, PP_pool);
+#define VMX_GC_CALL(L, R) vmx_chain_global_read<L, R>(anchors, rd, a0, n, rmin, smem, s_gapcost, lds_cap, tab, oskipcost, omaxdiff, maxgap, S_out, P_out, SA_out, cov_pool, \
+                                                       gmax_out, opcount_out, FP_pool, PP_pool)
+        if (n <= lds_cap && (rmax - rmin) < 0xffffffffLL) { if (rmode) VMX_GC_CALL(true, true); else VMX_GC_CALL(true, false); }
+        else { if (rmode) VMX_GC_CALL(false, true); else VMX_GC_CALL(false, false); }
+#undef VMX_GC_CALL
     }
 }
 

@@ -223,6 +223,11 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             __syncthreads();
             if (s_flag) status = VM_READ_CAPACITY_DEV;
             const int niv = status ? 0 : s_niv;
+            // occupancy bitmap of the head table (one bit per k-mer, 32 KB for k = 9) in the sort buffer, which is idle until the radix sort:
+            // the windows fill about a tenth of the 4^k heads, so nine in ten look-ups of passes A and B are answered from LDS
+            unsigned* BM = (unsigned*)s_sort;
+            const bool use_bm = ((size_t)1 << (2 * k)) <= (size_t)VMX_SORT_LDS * 64;
+            if (use_bm) { for (int i = (int)threadIdx.x; i < (1 << (2 * k)) / 32; i += (int)blockDim.x) BM[i] = 0u; __syncthreads(); }
             VMX_T(0);
             // --- table: one atomic exchange per window position links it in front of its 9-mer's list
             for (int v = 0; v < niv; ++v) {
@@ -236,6 +241,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                     int old = -1, old2 = -1;
                     if (ok) old = atomicExch(&HEAD[km], idx);
                     if (ok2) old2 = atomicExch(&HEAD[km2], idx2);
+                    if (use_bm) { if (ok) atomicOr(&BM[km >> 5], 1u << (km & 31)); if (ok2) atomicOr(&BM[km2 >> 5], 1u << (km2 & 31)); }
                     if (ok) NEXT[idx] = old;
                     if (ok2) NEXT[idx2] = old2;
                 }
@@ -266,7 +272,8 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                     long long interval = (long long)b0 + b1 + 500; if (interval > 2000) interval = 2000;
                     const long long ref1 = GR[c0], ref2 = GR[c1];
                     long long rgap = (long long)iloc - GQ[c0]; if (rgap < 0) rgap = -rgap;
-                    const int hf = HEAD[fw], hr = iloc > 0 ? HEAD[rv] : -1;              // both list heads in flight together
+                    const bool pf = !use_bm || ((BM[fw >> 5] >> (fw & 31)) & 1u), pr = iloc > 0 && (!use_bm || ((BM[rv >> 5] >> (rv & 31)) & 1u));
+                    const int hf = pf ? HEAD[fw] : -1, hr = pr ? HEAD[rv] : -1;           // both list heads in flight together
                     for (int t = hf; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cf == 0) ff = rl; ++cf; } }
                     for (int t = hr; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cr == 0) fr = rl; ++cr; } }
                 }
@@ -312,9 +319,10 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 const long long ref1 = GR[c0], ref2 = GR[c1];
                 long long rgap = (long long)iloc - GQ[c0]; if (rgap < 0) rgap = -rgap;
                 const long long wf = w;
-                for (int t = HEAD[fw]; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; }
+                const bool pf = !use_bm || ((BM[fw >> 5] >> (fw & 31)) & 1u), pr = iloc > 0 && (!use_bm || ((BM[rv >> 5] >> (rv & 31)) & 1u));
+                for (int t = pf ? HEAD[fw] : -1; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; }
                 const long long wr = w;
-                if (iloc > 0) for (int t = HEAD[rv]; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; }
+                if (pr) for (int t = HEAD[rv]; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; }
                 if (wr - wf > 1) vmx_isort_i64(HVAL + wf, (int)(wr - wf));
                 if (w - wr > 1) vmx_isort_i64(HVAL + wr, (int)(w - wr));
                 for (long long x = wf; x < w; ++x) {

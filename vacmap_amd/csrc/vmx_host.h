@@ -4,6 +4,7 @@
 #include "vmx_device.h"
 #include "vmx_kernels.h"
 #include "../../include/vacmapx.h"
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -23,10 +24,11 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    // grows with 1/8 head-room (at most 1 GB of it) so that slightly larger batches do not reallocate
     int reserve(size_t bytes) {
         if (bytes <= cap && p) return 0;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 8 + 256;
+        size_t want = bytes + std::min<size_t>(bytes / 8, (size_t)1 << 30) + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
         cap = want;
