@@ -106,7 +106,12 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
     const int nw = (int)(blockDim.x >> 6);
     const int k = A.k;
     const int nkey = 1 << (2 * k);
-    int32_t* HEAD = A.head_pool + (size_t)blockIdx.x * (size_t)nkey;          // all -1 between uses
+    // head entries are (epoch << 23 | window index): an entry of another epoch is an empty list, so the table is never reset between
+    // uses (that was one random HBM write per window position); the slot's epoch lives in A.epoch_pool across launches, 511 = never used
+    int32_t* HEAD = A.head_pool + (size_t)blockIdx.x * (size_t)nkey;
+    unsigned ep = (unsigned)A.epoch_pool[blockIdx.x];
+    auto head_idx = [&](int h) { return (((unsigned)h) >> 23) == ep ? (int)(((unsigned)h) & 0x7fffffu) : -1; };
+#define VMX_HEAD_IDX(h) head_idx(h)
     int32_t* NEXT = A.next_pool + (size_t)blockIdx.x * (size_t)A.tpos_cap;
     int64_t* TPOS = A.tpos_pool + (size_t)blockIdx.x * (size_t)A.tpos_cap;
     uint64_t* HKEY = A.hkey_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;
@@ -217,7 +222,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 long long tot = 0;
                 for (int v = 0; v < niv; ++v) { s_ivbase[v] = (int)tot; tot += s_iv[v][1] - s_iv[v][0]; }
                 s_ivbase[niv] = (int)(tot < 0x7fffffff ? tot : 0x7fffffff);
-                if (tot > A.tpos_cap) overflow = true;
+                if (tot > A.tpos_cap || tot >= (1LL << 23)) overflow = true;
                 s_niv = niv; s_flag = overflow ? 1 : 0;
             }
             __syncthreads();
@@ -225,6 +230,8 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             const int niv = status ? 0 : s_niv;
             // occupancy bitmap of the head table (one bit per k-mer, 32 KB for k = 9) in the sort buffer, which is idle until the radix sort:
             // the windows fill about a tenth of the 4^k heads, so nine in ten look-ups of passes A and B are answered from LDS
+            ep = ep + 1;
+            if (ep >= 511u) { for (int i = (int)threadIdx.x; i < nkey; i += (int)blockDim.x) HEAD[i] = -1; ep = 0; __syncthreads(); }   // epochs used up: one real reset
             unsigned* BM = (unsigned*)s_sort;
             const bool use_bm = ((size_t)1 << (2 * k)) <= (size_t)VMX_SORT_LDS * 64;
             if (use_bm) { for (int i = (int)threadIdx.x; i < (1 << (2 * k)) / 32; i += (int)blockDim.x) BM[i] = 0u; __syncthreads(); }
@@ -239,8 +246,8 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                     const int idx = base + (int)(x - lo), idx2 = base + (int)(x2 - lo);
                     TPOS[idx] = x; if (x2 < hi) TPOS[idx2] = x2;
                     int old = -1, old2 = -1;
-                    if (ok) old = atomicExch(&HEAD[km], idx);
-                    if (ok2) old2 = atomicExch(&HEAD[km2], idx2);
+                    if (ok) old = VMX_HEAD_IDX(atomicExch(&HEAD[km], (int)((ep << 23) | (unsigned)idx)));
+                    if (ok2) old2 = VMX_HEAD_IDX(atomicExch(&HEAD[km2], (int)((ep << 23) | (unsigned)idx2)));
                     if (use_bm) { if (ok) atomicOr(&BM[km >> 5], 1u << (km & 31)); if (ok2) atomicOr(&BM[km2 >> 5], 1u << (km2 & 31)); }
                     if (ok) NEXT[idx] = old;
                     if (ok2) NEXT[idx2] = old2;
@@ -273,7 +280,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                     const long long ref1 = GR[c0], ref2 = GR[c1];
                     long long rgap = (long long)iloc - GQ[c0]; if (rgap < 0) rgap = -rgap;
                     const bool pf = !use_bm || ((BM[fw >> 5] >> (fw & 31)) & 1u), pr = iloc > 0 && (!use_bm || ((BM[rv >> 5] >> (rv & 31)) & 1u));
-                    const int hf = pf ? HEAD[fw] : -1, hr = pr ? HEAD[rv] : -1;           // both list heads in flight together
+                    const int hf = pf ? VMX_HEAD_IDX(HEAD[fw]) : -1, hr = pr ? VMX_HEAD_IDX(HEAD[rv]) : -1;   // both list heads in flight together
                     for (int t = hf; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cf == 0) ff = rl; ++cf; } }
                     for (int t = hr; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cr == 0) fr = rl; ++cr; } }
                 }
@@ -320,9 +327,9 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 long long rgap = (long long)iloc - GQ[c0]; if (rgap < 0) rgap = -rgap;
                 const long long wf = w;
                 const bool pf = !use_bm || ((BM[fw >> 5] >> (fw & 31)) & 1u), pr = iloc > 0 && (!use_bm || ((BM[rv >> 5] >> (rv & 31)) & 1u));
-                for (int t = pf ? HEAD[fw] : -1; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; }
+                for (int t = pf ? VMX_HEAD_IDX(HEAD[fw]) : -1; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; }
                 const long long wr = w;
-                if (pr) for (int t = HEAD[rv]; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; }
+                if (pr) for (int t = VMX_HEAD_IDX(HEAD[rv]); t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; }
                 if (wr - wf > 1) vmx_isort_i64(HVAL + wf, (int)(wr - wf));
                 if (w - wr > 1) vmx_isort_i64(HVAL + wr, (int)(w - wr));
                 for (long long x = wf; x < w; ++x) {
@@ -332,11 +339,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 }
             }
             __syncthreads();
-            // the table is no longer needed: reset the touched heads (HEAD is all -1 again for the next guide / read)
-            for (int v = 0; v < niv; ++v) {
-                const long long lo = s_iv[v][0], hi = s_iv[v][1];
-                for (long long x = lo + threadIdx.x; x < hi; x += blockDim.x) { bool ok; const uint32_t km = vmx_kmer_at(A.ref, x, k, ok); if (ok) HEAD[km] = -1; }
-            }
+            // the table is no longer needed; its entries die with the epoch
             // group the hits by diagonal, keeping stream order inside a diagonal: stable LSD radix sort. Only the grouping matters (the order of
             // the groups is restored by the emission keys), so the points are first mapped injectively to a dense range: forward points
             // (r - q > 0) and reverse points (-(r + q) < 0) form two clusters ~2r apart, each only as wide as the window
@@ -487,4 +490,6 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
         if (threadIdx.x == 0) { A.la_cnt[r] = status ? 0 : n_out; A.status[r] = status; }
         __syncthreads();
     }
+    if (threadIdx.x == 0) A.epoch_pool[blockIdx.x] = (int)ep;
+#undef VMX_HEAD_IDX
 }

@@ -72,11 +72,14 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     auto run_seed = [&](int cnt, int slots, int64_t hcap) -> int {
         const int64_t hit_cap = hcap;
         const int G = slots;
-        {   // HEAD must be all -1 when the kernel starts; the kernel restores that itself, so only fresh memory needs the fill
+        {   // head tables: entries are tagged with the slot's epoch (k_local_seed), so only fresh memory is filled (0xff = epoch 511, never current)
             const size_t need = 4 * (size_t)G * (size_t)nkey;
             const void* before = L.cnt.p; const size_t cap_before = L.cnt.cap;
-            VMX_TRY(L.cnt.reserve(need));
-            if (L.cnt.p != before || L.cnt.cap != cap_before) VMX_HIP(hipMemsetAsync(L.cnt.p, 0xff, L.cnt.cap, c->stream));
+            const void* ebefore = L.epoch.p;
+            VMX_TRY(L.cnt.reserve(need)); VMX_TRY(L.epoch.reserve(4 * (size_t)G + 64));
+            if (L.cnt.p != before || L.cnt.cap != cap_before || L.epoch.p != ebefore) {
+                VMX_HIP(hipMemsetAsync(L.cnt.p, 0xff, L.cnt.cap, c->stream)); VMX_HIP(hipMemsetAsync(L.epoch.p, 0, L.epoch.cap, c->stream));
+            }
         }
         VMX_TRY(L.cur.reserve(4 * (size_t)G * (size_t)tpos_cap));
         VMX_TRY(L.sq.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.dst.reserve(4 * (size_t)G * (size_t)hit_cap));
@@ -90,7 +93,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         VMX_TRY(L.la_cnt.reserve(4 * (size_t)(n + 1))); VMX_TRY(L.status.reserve(4 * (size_t)(n + 1)));
         A.ocodes = d_ocodes; A.roff = d_roff; A.ref = ix.codes; A.coff = ix.coff; A.nseq = ix.nseq;
         A.guide_rows = L.guide_rows.as<vmx_anchor>(); A.guide_len = L.guide_len.as<int32_t>(); A.n_guides_used = L.ng_used.as<int32_t>(); A.aoff = d_aoff;
-        A.n_reads = cnt; A.k = k;
+        A.n_reads = cnt; A.k = k; A.epoch_pool = L.epoch.as<int32_t>();
         A.look_span = prm->mode == VM_MODE_R ? 2000 : 7000; A.read_span = prm->mode == VM_MODE_R ? 500 : 7000;   // :23094, :23190 / mammap_noprefercloser.py:23631+
         A.sort_by_start = prm->mode == VM_MODE_R ? 1 : 0;
         A.queue = L.rorder.as<int32_t>(); A.order = L.rorder.as<int32_t>() + 1;
