@@ -113,7 +113,6 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
     auto head_idx = [&](int h) { return (((unsigned)h) >> 23) == ep ? (int)(((unsigned)h) & 0x7fffffu) : -1; };
 #define VMX_HEAD_IDX(h) head_idx(h)
     int32_t* NEXT = A.next_pool + (size_t)blockIdx.x * (size_t)A.tpos_cap;
-    int64_t* TPOS = A.tpos_pool + (size_t)blockIdx.x * (size_t)A.tpos_cap;
     uint64_t* HKEY = A.hkey_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;
     uint64_t* HKEY2 = A.hkey2_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;
     int64_t* HVAL = A.hval_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;     // by stream index: refloc << 1 | (strand == +1)
@@ -236,6 +235,8 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             const bool use_bm = ((size_t)1 << (2 * k)) <= (size_t)VMX_SORT_LDS * 64;
             if (use_bm) { for (int i = (int)threadIdx.x; i < (1 << (2 * k)) / 32; i += (int)blockDim.x) BM[i] = 0u; __syncthreads(); }
             VMX_T(0);
+            // the reference position of window index t is implied by the interval list (LDS): no position array in HBM
+            auto tpos_of = [&](int t) -> long long { int v = 0; while (v + 1 < niv && t >= s_ivbase[v + 1]) ++v; return s_iv[v][0] + (long long)(t - s_ivbase[v]); };
             // --- table: one atomic exchange per window position links it in front of its 9-mer's list
             for (int v = 0; v < niv; ++v) {
                 const long long lo = s_iv[v][0], hi = s_iv[v][1]; const int base = s_ivbase[v];
@@ -244,7 +245,6 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                     bool ok, ok2 = false; const uint32_t km = vmx_kmer_at(A.ref, x, k, ok);
                     uint32_t km2 = 0; if (x2 < hi) km2 = vmx_kmer_at(A.ref, x2, k, ok2);
                     const int idx = base + (int)(x - lo), idx2 = base + (int)(x2 - lo);
-                    TPOS[idx] = x; if (x2 < hi) TPOS[idx2] = x2;
                     int old = -1, old2 = -1;
                     if (ok) old = VMX_HEAD_IDX(atomicExch(&HEAD[km], (int)((ep << 23) | (unsigned)idx)));
                     if (ok2) old2 = VMX_HEAD_IDX(atomicExch(&HEAD[km2], (int)((ep << 23) | (unsigned)idx2)));
@@ -281,8 +281,8 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                     long long rgap = (long long)iloc - GQ[c0]; if (rgap < 0) rgap = -rgap;
                     const bool pf = !use_bm || ((BM[fw >> 5] >> (fw & 31)) & 1u), pr = iloc > 0 && (!use_bm || ((BM[rv >> 5] >> (rv & 31)) & 1u));
                     const int hf = pf ? VMX_HEAD_IDX(HEAD[fw]) : -1, hr = pr ? VMX_HEAD_IDX(HEAD[rv]) : -1;   // both list heads in flight together
-                    for (int t = hf; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cf == 0) ff = rl; ++cf; } }
-                    for (int t = hr; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cr == 0) fr = rl; ++cr; } }
+                    for (int t = hf; t >= 0; t = NEXT[t]) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cf == 0) ff = rl; ++cf; } }
+                    for (int t = hr; t >= 0; t = NEXT[t]) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cr == 0) fr = rl; ++cr; } }
                 }
                 PCNT[pi] = cf + cr;
                 PC2[pi] = (cf > 0xffff ? 0xffff : cf) | ((cr > 0x7fff ? 0x7fff : cr) << 16);
@@ -327,9 +327,9 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 long long rgap = (long long)iloc - GQ[c0]; if (rgap < 0) rgap = -rgap;
                 const long long wf = w;
                 const bool pf = !use_bm || ((BM[fw >> 5] >> (fw & 31)) & 1u), pr = iloc > 0 && (!use_bm || ((BM[rv >> 5] >> (rv & 31)) & 1u));
-                for (int t = pf ? VMX_HEAD_IDX(HEAD[fw]) : -1; t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; }
+                for (int t = pf ? VMX_HEAD_IDX(HEAD[fw]) : -1; t >= 0; t = NEXT[t]) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; }
                 const long long wr = w;
-                if (pr) for (int t = VMX_HEAD_IDX(HEAD[rv]); t >= 0; t = NEXT[t]) { const long long rl = TPOS[t]; if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; }
+                if (pr) for (int t = VMX_HEAD_IDX(HEAD[rv]); t >= 0; t = NEXT[t]) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; }
                 if (wr - wf > 1) vmx_isort_i64(HVAL + wf, (int)(wr - wf));
                 if (w - wr > 1) vmx_isort_i64(HVAL + wr, (int)(w - wr));
                 for (long long x = wf; x < w; ++x) {

@@ -83,7 +83,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         }
         VMX_TRY(L.cur.reserve(4 * (size_t)G * (size_t)tpos_cap));
         VMX_TRY(L.sq.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.dst.reserve(4 * (size_t)G * (size_t)hit_cap));
-        VMX_TRY(L.tpos.reserve(8 * (size_t)G * (size_t)tpos_cap)); VMX_TRY(L.hkey.reserve(8 * (size_t)G * (size_t)hit_cap));
+        VMX_TRY(L.hkey.reserve(8 * (size_t)G * (size_t)hit_cap));
         VMX_TRY(L.hval.reserve(8 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.hq.reserve(4 * (size_t)G * (size_t)hit_cap));
         VMX_TRY(L.goff.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.pcnt.reserve(4 * (size_t)G * (size_t)pcnt_cap));
         VMX_TRY(L.gkey.reserve(8 * (size_t)G * (size_t)gkey_cap)); VMX_TRY(L.gq.reserve(4 * (size_t)G * (size_t)gkey_cap)); VMX_TRY(L.gr.reserve(8 * (size_t)G * (size_t)gkey_cap));
@@ -97,7 +97,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         A.look_span = prm->mode == VM_MODE_R ? 2000 : 7000; A.read_span = prm->mode == VM_MODE_R ? 500 : 7000;   // :23094, :23190 / mammap_noprefercloser.py:23631+
         A.sort_by_start = prm->mode == VM_MODE_R ? 1 : 0;
         A.queue = L.rorder.as<int32_t>(); A.order = L.rorder.as<int32_t>() + 1;
-        A.head_pool = L.cnt.as<int32_t>(); A.next_pool = L.cur.as<int32_t>(); A.sq_pool = L.sq.as<int32_t>(); A.dst_pool = L.dst.as<int32_t>(); A.tpos_pool = L.tpos.as<int64_t>(); A.tpos_cap = tpos_cap;
+        A.head_pool = L.cnt.as<int32_t>(); A.next_pool = L.cur.as<int32_t>(); A.sq_pool = L.sq.as<int32_t>(); A.dst_pool = L.dst.as<int32_t>(); A.tpos_pool = nullptr; A.tpos_cap = tpos_cap;          // window positions are implied by the interval list (k_local_seed)
         VMX_TRY(L.hkey2.reserve(8 * (size_t)G * (size_t)hit_cap));
         A.hkey2_pool = L.hkey2.as<uint64_t>();
         A.hkey_pool = L.hkey.as<uint64_t>(); A.hval_pool = L.hval.as<int64_t>(); A.hq_pool = L.hq.as<int32_t>(); A.goff_pool = L.goff.as<int32_t>(); A.hit_cap = hit_cap;
