@@ -195,6 +195,143 @@ __device__ __forceinline__ void vmx_gapfill_fill16(const uint8_t* __restrict__ T
     if (lane == (rf >> 1)) *score_out = (rf & 1) ? vmx_pk_hi(fin) : vmx_pk_lo(fin);
 }
 
+
+// ---- four problems per wavefront (VMX_DP16X4_OK): the same packed recurrence, one problem per 16-lane DPP row. A lane owns rows 2l+1, 2l+2
+// of a 32-row stripe; hand-offs are row_shr:1 (lane 0 of every row keeps the old operand: its own chunk head), chunk registers rotate with
+// row_ror:15, the last row's FIFO with row_ror:1. A stripe is W = (ql + 31 rounded up to 16) steps wide, so every row starts its stripes
+// on a multiple of 16 steps and all four rows refill their 16-column chunks together although they are in different stripes and
+// columns. Small problems pad far less this way: rows to a multiple of 32 instead of 128, ramp 31 columns instead of 127.
+// Traceback bytes: tb[((stripe*W + step)*16 + l)*2 + half].
+#ifdef VMX_EMU
+__device__ __forceinline__ int vmx_r16_shr1_in(int v, int in) { const int l = vmx_lane(); const int e = __shfl(v, (l & 48) | ((l + 15) & 15)); return (l & 15) == 0 ? in : e; }
+__device__ __forceinline__ int vmx_r16_rol1(int v) { const int l = vmx_lane(); return __shfl(v, (l & 48) | ((l + 1) & 15)); }
+__device__ __forceinline__ int vmx_r16_ror1(int v) { const int l = vmx_lane(); return __shfl(v, (l & 48) | ((l + 15) & 15)); }
+#else
+__device__ __forceinline__ int vmx_r16_shr1_in(int v, int in) { return __builtin_amdgcn_update_dpp(in, v, 0x111, 0xf, 0xf, false); }   // row_shr:1
+__device__ __forceinline__ int vmx_r16_rol1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x12F, 0xf, 0xf, false); }             // row_ror:15
+__device__ __forceinline__ int vmx_r16_ror1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false); }             // row_ror:1
+#endif
+
+// T, Q, tl, ql, tb, bH, score_out describe the problem of this lane's 16-lane row (tl = 0: the row idles). Every lane of the wave calls it.
+// Control flow is wave-uniform (every lane runs every step, idle rows on dummy values with their memory accesses masked): the four rows
+// are in different stripes and columns, and the cross-lane moves must not sit in divergent code.
+__device__ __forceinline__ void vmx_gapfill_fill16x4(const uint8_t* __restrict__ T, const uint8_t* __restrict__ Q, int tl, int ql, int match, int mismatch,
+                                                     int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb, int32_t* __restrict__ bH,
+                                                     int32_t* __restrict__ score_out, int lane) {
+    const int l = lane & 15;
+    int32_t* bE1 = bH + (ql + 1);
+    int32_t* bE2 = bE1 + (ql + 1);
+    const int W = VMX_X4_W(ql);
+    const int nstr = (tl + 31) >> 5;
+    const unsigned O1 = vmx_pk(o1, o1), O2 = vmx_pk(o2, o2), E1C = vmx_pk(e1, e1), E2C = vmx_pk(e2, e2);
+    const unsigned MATCH = vmx_pk(match, match), MISM = vmx_pk(mismatch, mismatch), ONE = vmx_pk(1, 1);
+    const unsigned NEGP = vmx_pk(VMX_NEG16, VMX_NEG16);
+    const int rf = (tl - 1) & 31;                               // row tl inside the last stripe: lane rf / 2 of the row, half rf & 1
+    const int t_fin = ql - 1 + rf;
+    const int total = vmx_uniform_i32(vmx_wave_max_i32(nstr * W));   // steps of the longest of the four problems
+    unsigned fin = 0;
+    int s = 0, t = 0;                                           // this row's stripe and the step inside it (t is a multiple of 16 here)
+    unsigned ti2 = 0, Hleft = 0, F1 = NEGP, F2 = NEGP, Hdiag = 0, outH = 0, outE1 = NEGP, outE2 = NEGP, qc = vmx_pk(4, 4);
+    unsigned sHE = 0, sE2 = 0;                                  // lane 15's high-half outputs of the last 16 steps, newest in lane 0: H | E1 << 16, E2
+    bool store_bnd = false;
+    uint8_t* tbp = tb;                                          // traceback line of the block's first step
+    unsigned nq = 0, nH = 0, nE1 = 0, nE2 = 0;                  // chunk of the next block, loaded one block ahead
+    // chunk of the 16 columns starting at step t0 of stripe s0: query bases and the row above the stripe, pre-shifted into the high half
+    auto load_chunk = [&](bool on, int s0, int t0, unsigned& q, unsigned& h, unsigned& x1, unsigned& x2) {
+        const int jj = t0 + l;
+        q = (unsigned)(on && jj < ql ? (int)Q[jj] : 4) << 16;
+        h = 0; x1 = (unsigned)VMX_NEG16 << 16; x2 = x1;
+        if (on && jj + 1 <= ql) {
+            if (s0 == 0) h = (unsigned)vmx_gap_open_row(jj + 1, o1, e1, o2, e2) << 16;
+            else { h = (unsigned)bH[jj + 1] << 16; x1 = (unsigned)bE1[jj + 1] << 16; x2 = (unsigned)bE2[jj + 1] << 16; }
+        }
+    };
+    for (int g0 = 0; g0 < total; g0 += 16) {
+        const bool act = s < nstr;
+        if (__any(act && t == 0 && s > 0)) __syncthreads();    // a row is about to read the boundary rows its previous stripe stored
+        unsigned qchunk, cH, cE1, cE2;
+        if (act && t == 0) {
+            const int i0 = s * 32 + 2 * l + 1;
+            ti2 = vmx_pk(i0 <= tl ? (int)T[i0 - 1] : 5, i0 + 1 <= tl ? (int)T[i0] : 5);
+            Hleft = vmx_pk(vmx_gap_open_row(i0, o1, e1, o2, e2), vmx_gap_open_row(i0 + 1, o1, e1, o2, e2));
+            F1 = NEGP; F2 = NEGP;
+            Hdiag = vmx_pk(i0 - 1 == 0 ? 0 : vmx_gap_open_row(i0 - 1, o1, e1, o2, e2), vmx_gap_open_row(i0, o1, e1, o2, e2));
+            outH = 0; outE1 = NEGP; outE2 = NEGP; qc = vmx_pk(4, 4);
+            sHE = 0; sE2 = 0;
+            store_bnd = s + 1 < nstr;
+            tbp = tb + (size_t)s * (size_t)W * 32 + 2 * l;
+        }
+        // a stripe's first chunk is loaded here (the previous stripe has only just stored it); the others were prefetched a block ago
+        const bool first = __any(act && t == 0);
+        if (first) load_chunk(act && t == 0, s, 0, qchunk, cH, cE1, cE2);
+        if (!(act && t == 0)) { qchunk = nq; cH = nH; cE1 = nE1; cE2 = nE2; }
+        load_chunk(act && t + 16 < W, s, t + 16, nq, nH, nE1, nE2);
+        const bool any_bnd = __any(act && store_bnd);
+        const unsigned l15 = l == 15 ? 0xffffffffu : 0u;
+#define VMX_X4_STEP(RAMP, TT)                                                                                                      \
+            {                                                                                                                      \
+                const unsigned upH = vmx_alignbit16(outH, (unsigned)vmx_r16_shr1_in((int)outH, (int)cH));                          \
+                const unsigned upE1 = vmx_alignbit16(outE1, (unsigned)vmx_r16_shr1_in((int)outE1, (int)cE1));                      \
+                const unsigned upE2 = vmx_alignbit16(outE2, (unsigned)vmx_r16_shr1_in((int)outE2, (int)cE2));                      \
+                qc = vmx_alignbit16(qc, (unsigned)vmx_r16_shr1_in((int)qc, (int)qchunk));                                          \
+                cH = (unsigned)vmx_r16_rol1((int)cH); cE1 = (unsigned)vmx_r16_rol1((int)cE1); cE2 = (unsigned)vmx_r16_rol1((int)cE2); \
+                qchunk = (unsigned)vmx_r16_rol1((int)qchunk);                                                                      \
+                const unsigned a1 = vmx_pk_sub(upH, O1), a2 = vmx_pk_sub(upH, O2);                                                 \
+                unsigned b = vmx_pk_neg(vmx_pk_sub(a1, upE1)) & 0x00080008u;                                                       \
+                b |= vmx_pk_neg(vmx_pk_sub(a2, upE2)) & 0x00100010u;                                                               \
+                const unsigned e1v = vmx_pk_sub(vmx_pk_max(a1, upE1), E1C), e2v = vmx_pk_sub(vmx_pk_max(a2, upE2), E2C);           \
+                const unsigned c1 = vmx_pk_sub(Hleft, O1), c2 = vmx_pk_sub(Hleft, O2);                                             \
+                b |= vmx_pk_neg(vmx_pk_sub(c1, F1)) & 0x00200020u;                                                                 \
+                b |= vmx_pk_neg(vmx_pk_sub(c2, F2)) & 0x00400040u;                                                                 \
+                const unsigned nF1 = vmx_pk_sub(vmx_pk_max(c1, F1), E1C), nF2 = vmx_pk_sub(vmx_pk_max(c2, F2), E2C);               \
+                const unsigned eqm = vmx_pk_neg(vmx_pk_sub(ti2 ^ qc, ONE));                                                        \
+                unsigned h = vmx_pk_add(Hdiag, vmx_bfi(eqm, MATCH, MISM));                                                         \
+                unsigned src = 0, m;                                                                                               \
+                m = vmx_pk_neg(vmx_pk_sub(h, e1v)); src = vmx_bfi(m, 0x00010001u, src); h = vmx_pk_max(h, e1v);                    \
+                m = vmx_pk_neg(vmx_pk_sub(h, e2v)); src = vmx_bfi(m, 0x00020002u, src); h = vmx_pk_max(h, e2v);                    \
+                m = vmx_pk_neg(vmx_pk_sub(h, nF1)); src = vmx_bfi(m, 0x00030003u, src); h = vmx_pk_max(h, nF1);                    \
+                m = vmx_pk_neg(vmx_pk_sub(h, nF2)); src = vmx_bfi(m, 0x00040004u, src); h = vmx_pk_max(h, nF2);                    \
+                b |= src;                                                                                                          \
+                if (act) *(uint16_t*)(tbp + (TT) * 32) = (uint16_t)((b & 0xffu) | ((b >> 8) & 0xff00u));                           \
+                if (RAMP) {                                                                                                        \
+                    const int tc = t + (TT);                                                                                       \
+                    const unsigned pm = (tc >= 2 * l ? 0xffffu : 0u) | (tc >= 2 * l + 1 ? 0xffff0000u : 0u);                       \
+                    Hdiag = vmx_bfi(pm, upH, Hdiag); Hleft = vmx_bfi(pm, h, Hleft); F1 = vmx_bfi(pm, nF1, F1); F2 = vmx_bfi(pm, nF2, F2); \
+                } else { Hdiag = upH; Hleft = h; F1 = nF1; F2 = nF2; }                                                             \
+                outH = h; outE1 = e1v; outE2 = e2v;                                                                                \
+                fin = (tfin_rel == (TT)) ? outH : fin;                                                                             \
+                if (any_bnd) {                                                                                                     \
+                    sHE = (unsigned)vmx_r16_ror1((int)vmx_bfi(l15, (outH >> 16) | (outE1 & 0xffff0000u), sHE));                    \
+                    sE2 = (unsigned)vmx_r16_ror1((int)vmx_bfi(l15, outE2 >> 16, sE2));                                             \
+                    if ((TT) == 14) {      /* t is a multiple of 16: the last row finishes a column that is a multiple of 16 on steps = 14 mod 16 */ \
+                        const int col = t + 14 - 30 - l;      /* lane k of the FIFO holds column j15 - k */                        \
+                        if (store_bnd && act && col >= 1 && col <= ql) { bH[col] = (int)(short)(sHE & 0xffffu); bE1[col] = (int)sHE >> 16; bE2[col] = (int)(short)(sE2 & 0xffffu); } \
+                    }                                                                                                              \
+                }                                                                                                                  \
+            }
+        const int tfin_rel = act ? t_fin - t : -1;                 // a finished row keeps stepping on dummy values: never matches
+        // RAMP: some half of some row has not reached its column 1 yet (its state must not move); rows past their ramp get a full mask
+        if (__any(act && t < 32)) {
+            VMX_X4_STEP(true, 0) VMX_X4_STEP(true, 1) VMX_X4_STEP(true, 2) VMX_X4_STEP(true, 3) VMX_X4_STEP(true, 4) VMX_X4_STEP(true, 5) VMX_X4_STEP(true, 6) VMX_X4_STEP(true, 7)
+            VMX_X4_STEP(true, 8) VMX_X4_STEP(true, 9) VMX_X4_STEP(true, 10) VMX_X4_STEP(true, 11) VMX_X4_STEP(true, 12) VMX_X4_STEP(true, 13) VMX_X4_STEP(true, 14) VMX_X4_STEP(true, 15)
+        } else {
+            VMX_X4_STEP(false, 0) VMX_X4_STEP(false, 1) VMX_X4_STEP(false, 2) VMX_X4_STEP(false, 3) VMX_X4_STEP(false, 4) VMX_X4_STEP(false, 5) VMX_X4_STEP(false, 6) VMX_X4_STEP(false, 7)
+            VMX_X4_STEP(false, 8) VMX_X4_STEP(false, 9) VMX_X4_STEP(false, 10) VMX_X4_STEP(false, 11) VMX_X4_STEP(false, 12) VMX_X4_STEP(false, 13) VMX_X4_STEP(false, 14) VMX_X4_STEP(false, 15)
+        }
+#undef VMX_X4_STEP
+        if (act) {
+            t += 16; tbp += 16 * 32;
+            if (t == W) {
+                // the columns behind the last multiple of 16 are still in the FIFO (W - 31 >= ql): lane k holds column W - 31 - k
+                const int col = W - 31 - l;
+                if (store_bnd && col > ((W - 31) & ~15) && col <= ql) { bH[col] = (int)(short)(sHE & 0xffffu); bE1[col] = (int)sHE >> 16; bE2[col] = (int)(short)(sE2 & 0xffffu); }
+                t = 0; ++s;
+            }
+        }
+    }
+    if (nstr > 0 && l == (rf >> 1)) *score_out = (rf & 1) ? vmx_pk_hi(fin) : vmx_pk_lo(fin);
+}
+
 // order/counter: longest-first device work queue (order == nullptr: plain grid-stride over [0, n_prob))
 __global__ void __launch_bounds__(64) k_gapfill_fill(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
                                                      const vmx_dp_prob* __restrict__ probs, int n_prob, int match, int mismatch,
@@ -202,13 +339,28 @@ __global__ void __launch_bounds__(64) k_gapfill_fill(const uint8_t* __restrict__
                                                      int32_t* __restrict__ bnd_pool, int32_t* __restrict__ out_score,
                                                      const int32_t* __restrict__ order, int32_t* __restrict__ counter) {
     const int lane = vmx_lane();
-    int static_next = (int)blockIdx.x;
+    int static_next = 4 * (int)blockIdx.x;
     while (true) {
-        int qi;
-        if (order) { int v = 0; if (lane == 0) v = atomicAdd(counter, 1); qi = vmx_bcast0(v); }
-        else { qi = static_next; static_next += (int)gridDim.x; }
-        if (qi >= n_prob) break;
-        const int p = order ? vmx_uniform_i32(order[qi]) : qi;
+        // a wave takes four problems at a time: those of the small class run together, one per 16-lane row (vmx_gapfill_fill16x4); the
+        // others (the head of the longest-first queue) run one after the other on the whole wave
+        int q0;
+        if (order) { int v = 0; if (lane == 0) v = atomicAdd(counter, 4); q0 = vmx_bcast0(v); }
+        else { q0 = static_next; static_next += 4 * (int)gridDim.x; }
+        if (q0 >= n_prob) break;
+        const int qg = q0 + (lane >> 4);
+        const int pg = qg < n_prob ? (order ? order[qg] : qg) : -1;
+        bool x4 = false;
+        {
+            vmx_dp_prob pr; pr.tl = 0; pr.ql = 0; pr.t_off = 0; pr.q_off = 0; pr.tb_off = 0; pr.bnd_off = 0;
+            if (pg >= 0) pr = probs[pg];
+            x4 = pg >= 0 && pr.tl > 0 && pr.ql > 0 && VMX_DP16X4_OK(pr.tl, pr.ql);
+            if (__any(x4))
+                vmx_gapfill_fill16x4(tcodes + pr.t_off, qcodes + pr.q_off, x4 ? pr.tl : 0, x4 ? pr.ql : 0, match, mismatch, o1, e1, o2, e2, tb_pool + pr.tb_off,
+                                     bnd_pool + pr.bnd_off, &out_score[pg < 0 ? 0 : pg], lane);
+        }
+        for (int gk = 0; gk < 4; ++gk) {
+        const int p = vmx_readlane(pg, 16 * gk);
+        if (p < 0 || vmx_readlane((int)x4, 16 * gk)) continue;
         const vmx_dp_prob pr = probs[p];
         const uint8_t* T = tcodes + pr.t_off;
         const uint8_t* Q = qcodes + pr.q_off;
@@ -292,6 +444,7 @@ __global__ void __launch_bounds__(64) k_gapfill_fill(const uint8_t* __restrict__
         }
         if (!trivial && !pk && lane == ((tl - 1) & 63)) out_score[p] = outH;     // H(tl, ql): the last cell that lane computed
         if (pk) vmx_gapfill_fill16(T, Q, tl, ql, match, mismatch, o1, e1, o2, e2, tb, bH, &out_score[p], lane);
+        }
     }
 }
 
@@ -308,8 +461,9 @@ __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_
     const uint8_t* tb = tb_pool + pr.tb_off;
     uint32_t* runs = run_pool + pr.run_off;
     char* cig = cig_pool + pr.cig_off;
-    const bool pk = tl > 0 && ql > 0 && VMX_DP16_OK(tl, ql);     // packed layout of vmx_gapfill_fill16
-    const int W = ql + (pk ? 127 : 63);
+    const bool x4 = tl > 0 && ql > 0 && VMX_DP16X4_OK(tl, ql);   // layout of vmx_gapfill_fill16x4
+    const bool pk = !x4 && tl > 0 && ql > 0 && VMX_DP16_OK(tl, ql);     // packed layout of vmx_gapfill_fill16
+    const int W = x4 ? VMX_X4_W(ql) : ql + (pk ? 127 : 63);
     int nruns = 0; int cur_op = -1; uint32_t cur_len = 0;
 #define VMX_EMIT(op)                                                                   \
     do {                                                                               \
@@ -319,7 +473,8 @@ __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_
     int i = tl, j = ql, state = 0;
     while (i > 0 && j > 0) {
         int b;
-        if (pk) { const int s = (i - 1) >> 7, r = (i - 1) & 127, t = (j - 1) + r; b = tb[(((size_t)s * (size_t)W + (size_t)t) * 64 + (r >> 1)) * 2 + (r & 1)]; }
+        if (x4) { const int s = (i - 1) >> 5, r = (i - 1) & 31, t = (j - 1) + r; b = tb[(((size_t)s * (size_t)W + (size_t)t) * 16 + (r >> 1)) * 2 + (r & 1)]; }
+        else if (pk) { const int s = (i - 1) >> 7, r = (i - 1) & 127, t = (j - 1) + r; b = tb[(((size_t)s * (size_t)W + (size_t)t) * 64 + (r >> 1)) * 2 + (r & 1)]; }
         else { const int s = (i - 1) >> 6, l = (i - 1) & 63, t = (j - 1) + l; b = tb[((size_t)s * (size_t)W + (size_t)t) * 64 + l]; }
         if (state == 0) {
             int src = b & 7;

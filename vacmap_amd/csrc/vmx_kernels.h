@@ -83,7 +83,17 @@ struct vmx_lseed_args {
 #define VMX_DP16_MAX 6000             // gap fill: problems with tl + ql <= this run two rows per lane in packed int16
 #endif
 #define VMX_DP16_OK(tl, ql) ((tl) + (ql) <= VMX_DP16_MAX)
-#define VMX_TB_BYTES(tl, ql) (((tl) > 0 && (ql) > 0) ? (VMX_DP16_OK(tl, ql) ? (int64_t)(((tl) + 127) / 128) * ((ql) + 127) * 128 : (int64_t)(((tl) + 63) / 64) * ((ql) + 63) * 64) : 0)
+// gap fill, small problems: four problems per wavefront, one per 16-lane row, 32-row stripes (two rows per lane), stripe width padded to
+// a multiple of 16 steps so that the four rows refill their chunk registers on the same steps
+#ifdef VMX_EMU
+#define VMX_DP16X4_MAX 160
+#else
+#define VMX_DP16X4_MAX 1536
+#endif
+#define VMX_DP16X4_OK(tl, ql) ((tl) + (ql) <= VMX_DP16X4_MAX)
+#define VMX_X4_W(ql) ((((ql) + 31) + 15) & ~15)
+#define VMX_TB_BYTES(tl, ql) (((tl) > 0 && (ql) > 0) ? (VMX_DP16X4_OK(tl, ql) ? (int64_t)(((tl) + 31) / 32) * VMX_X4_W(ql) * 32 : \
+                              VMX_DP16_OK(tl, ql) ? (int64_t)(((tl) + 127) / 128) * ((ql) + 127) * 128 : (int64_t)(((tl) + 63) / 64) * ((ql) + 63) * 64) : 0)
 #define VMX_TB_CHUNK ((int64_t)12 << 30)   // gap fill: traceback bytes held at a time; a batch needing more runs fill + trace chunk by chunk (12 GB: lets 4+ batches in flight fit in 288 GB)
 #define VMX_LA_SLOT(len) ((len) / 2 + 4096)   // regular local-anchor slot of a read (rows); overflowing reads are re-run with 8x .. 4096x
 #define VMX_SELECT_LDS 3072           // k_chain_select: anchors of a read whose S / P / S_arg / used flags are staged in LDS (17 B each)
