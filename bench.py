@@ -180,8 +180,9 @@ def main():
         # in profiles/ (bench.py cannot collect counters on itself); null when the summary is absent
         traffic, traffic_src = None, None
         try:
-            pj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_g_pmc_hbm_traffic.json')))
-            traffic = pj['kernels']['k_gapfill_fill']['hbm_bytes_per_step']        # per step, like achieved (a step = 1-2 chunk launches); traffic_src = 'profiles/r01_g_pmc_hbm_traffic.json'
+            pj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_i_pmc_hbm_traffic.json')))
+            traffic = pj['kernels']['k_gapfill_fill']['hbm_bytes_per_step']        # per step, like achieved (a step = a few chunk launches)
+            traffic_src = 'profiles/r01_i_pmc_hbm_traffic.json'
         except Exception:
             pass
         # what the kernel itself must move: one traceback byte per DP cell (the reference's k_cigar materialises the same matrix) + its strings
@@ -190,8 +191,8 @@ def main():
                     'traffic': traffic, 'traffic_source': traffic_src, 'avg_kernel_ms_per_step': fill_ms, 'algorithmic_bytes_per_step': algo_bytes / K,
                     'kernel_bytes_per_step': kbytes, 'kernel_GBps': kbytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0,
                     'dp_cells_per_s': (agg['dp_cells'] / K) / (fill_ms * 1e-3) if fill_ms > 0 else 0.0,
-                    'note': 'achieved uses the path-level algorithmic bytes of SURVEY 8(d); the kernel is an integer DP bound by VALU issue (packed int16: ~85 VALU ops per '
-                            '128-cell step), its own stream is one traceback byte per cell incl. stripe padding (kernel_bytes_per_step); see DESIGN.md'}
+                    'note': 'achieved uses the path-level algorithmic bytes of SURVEY 8(d); the kernel is an integer DP bound by VALU issue (packed int16: ~75-85 VALU ops per '
+                            '128-cell step, 98 % VALU utilisation by SQ_INSTS_VALU / GRBM_GUI_ACTIVE), its own stream is one traceback byte per cell incl. stripe padding (kernel_bytes_per_step); see DESIGN.md'}
         cpu = None
         if args.cpu_sample > 0 and world == 1:
             import oracle_lib as O
