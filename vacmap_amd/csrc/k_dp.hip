@@ -172,7 +172,7 @@ __device__ __forceinline__ void vmx_gapfill_fill16(const uint8_t* __restrict__ T
                 m = vmx_pk_neg(vmx_pk_sub(h, nF1)); src = vmx_bfi(m, 0x00030003u, src); h = vmx_pk_max(h, nF1);
                 m = vmx_pk_neg(vmx_pk_sub(h, nF2)); src = vmx_bfi(m, 0x00040004u, src); h = vmx_pk_max(h, nF2);
                 b |= src;
-                *(uint16_t*)(tbs + (size_t)t * 128) = (uint16_t)((b & 0xffu) | ((b >> 8) & 0xff00u));
+                *(uint16_t*)(tbs + (size_t)t * 128) = (uint16_t)vmx_pk_bytes(b);
                 if (ramp_up) {
                     // low half active from step 2*lane, high half from step 2*lane + 1
                     const unsigned pm = (t >= 2 * lane ? 0xffffu : 0u) | (t >= 2 * lane + 1 ? 0xffff0000u : 0u);
@@ -215,6 +215,7 @@ __device__ __forceinline__ int vmx_r16_ror1(int v) { return __builtin_amdgcn_upd
 // T, Q, tl, ql, tb, bH, score_out describe the problem of this lane's 16-lane row (tl = 0: the row idles). Every lane of the wave calls it.
 // Control flow is wave-uniform (every lane runs every step, idle rows on dummy values with their memory accesses masked): the four rows
 // are in different stripes and columns, and the cross-lane moves must not sit in divergent code.
+template <bool SCORE>
 __device__ __forceinline__ void vmx_gapfill_fill16x4(const uint8_t* __restrict__ T, const uint8_t* __restrict__ Q, int tl, int ql, int match, int mismatch,
                                                      int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb, int32_t* __restrict__ bH,
                                                      int32_t* __restrict__ score_out, int lane) {
@@ -292,14 +293,14 @@ __device__ __forceinline__ void vmx_gapfill_fill16x4(const uint8_t* __restrict__
                 m = vmx_pk_neg(vmx_pk_sub(h, nF1)); src = vmx_bfi(m, 0x00030003u, src); h = vmx_pk_max(h, nF1);                    \
                 m = vmx_pk_neg(vmx_pk_sub(h, nF2)); src = vmx_bfi(m, 0x00040004u, src); h = vmx_pk_max(h, nF2);                    \
                 b |= src;                                                                                                          \
-                if (act) *(uint16_t*)(tbp + (TT) * 32) = (uint16_t)((b & 0xffu) | ((b >> 8) & 0xff00u));                           \
+                if (act) *(uint16_t*)(tbp + (TT) * 32) = (uint16_t)vmx_pk_bytes(b);                                                \
                 if (RAMP) {                                                                                                        \
                     const int tc = t + (TT);                                                                                       \
                     const unsigned pm = (tc >= 2 * l ? 0xffffu : 0u) | (tc >= 2 * l + 1 ? 0xffff0000u : 0u);                       \
                     Hdiag = vmx_bfi(pm, upH, Hdiag); Hleft = vmx_bfi(pm, h, Hleft); F1 = vmx_bfi(pm, nF1, F1); F2 = vmx_bfi(pm, nF2, F2); \
                 } else { Hdiag = upH; Hleft = h; F1 = nF1; F2 = nF2; }                                                             \
                 outH = h; outE1 = e1v; outE2 = e2v;                                                                                \
-                fin = (tfin_rel == (TT)) ? outH : fin;                                                                             \
+                if (SCORE) fin = (tfin_rel == (TT)) ? outH : fin;                                                                  \
                 if (any_bnd) {                                                                                                     \
                     sHE = (unsigned)vmx_r16_ror1((int)vmx_bfi(l15, (outH >> 16) | (outE1 & 0xffff0000u), sHE));                    \
                     sE2 = (unsigned)vmx_r16_ror1((int)vmx_bfi(l15, outE2 >> 16, sE2));                                             \
@@ -329,11 +330,13 @@ __device__ __forceinline__ void vmx_gapfill_fill16x4(const uint8_t* __restrict__
             }
         }
     }
-    if (nstr > 0 && l == (rf >> 1)) *score_out = (rf & 1) ? vmx_pk_hi(fin) : vmx_pk_lo(fin);
+    if (SCORE && nstr > 0 && l == (rf >> 1)) *score_out = (rf & 1) ? vmx_pk_hi(fin) : vmx_pk_lo(fin);
 }
 
 // order/counter: longest-first device work queue (order == nullptr: plain grid-stride over [0, n_prob))
-__global__ void __launch_bounds__(64) k_gapfill_fill(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
+// SCORE = false (k_gapfill_fill_ns): the batched path only consumes the traceback, so the small-problem form skips the score capture
+template <bool SCORE>
+__device__ __forceinline__ void vmx_gapfill_fill_body(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
                                                      const vmx_dp_prob* __restrict__ probs, int n_prob, int match, int mismatch,
                                                      int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb_pool,
                                                      int32_t* __restrict__ bnd_pool, int32_t* __restrict__ out_score,
@@ -355,7 +358,7 @@ __global__ void __launch_bounds__(64) k_gapfill_fill(const uint8_t* __restrict__
             if (pg >= 0) pr = probs[pg];
             x4 = pg >= 0 && pr.tl > 0 && pr.ql > 0 && VMX_DP16X4_OK(pr.tl, pr.ql);
             if (__any(x4))
-                vmx_gapfill_fill16x4(tcodes + pr.t_off, qcodes + pr.q_off, x4 ? pr.tl : 0, x4 ? pr.ql : 0, match, mismatch, o1, e1, o2, e2, tb_pool + pr.tb_off,
+                vmx_gapfill_fill16x4<SCORE>(tcodes + pr.t_off, qcodes + pr.q_off, x4 ? pr.tl : 0, x4 ? pr.ql : 0, match, mismatch, o1, e1, o2, e2, tb_pool + pr.tb_off,
                                      bnd_pool + pr.bnd_off, &out_score[pg < 0 ? 0 : pg], lane);
         }
         for (int gk = 0; gk < 4; ++gk) {
@@ -446,6 +449,21 @@ __global__ void __launch_bounds__(64) k_gapfill_fill(const uint8_t* __restrict__
         if (pk) vmx_gapfill_fill16(T, Q, tl, ql, match, mismatch, o1, e1, o2, e2, tb, bH, &out_score[p], lane);
         }
     }
+}
+
+__global__ void __launch_bounds__(64) k_gapfill_fill(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
+                                                     const vmx_dp_prob* __restrict__ probs, int n_prob, int match, int mismatch,
+                                                     int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb_pool,
+                                                     int32_t* __restrict__ bnd_pool, int32_t* __restrict__ out_score,
+                                                     const int32_t* __restrict__ order, int32_t* __restrict__ counter) {
+    vmx_gapfill_fill_body<true>(tcodes, qcodes, probs, n_prob, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, order, counter);
+}
+__global__ void __launch_bounds__(64) k_gapfill_fill_ns(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
+                                                        const vmx_dp_prob* __restrict__ probs, int n_prob, int match, int mismatch,
+                                                        int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb_pool,
+                                                        int32_t* __restrict__ bnd_pool, int32_t* __restrict__ out_score,
+                                                        const int32_t* __restrict__ order, int32_t* __restrict__ counter) {
+    vmx_gapfill_fill_body<false>(tcodes, qcodes, probs, n_prob, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, order, counter);
 }
 
 // serial traceback, one THREAD per problem (thousands of independent dependent-load chains hide each other's latency)

@@ -68,6 +68,12 @@ __device__ __forceinline__ unsigned vmx_pk_max(unsigned a, unsigned b) { return 
 __device__ __forceinline__ unsigned vmx_pk_neg(unsigned a) { unsigned r; asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }
 __device__ __forceinline__ unsigned vmx_alignbit16(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
 #endif
+// low bytes of the two halves of a packed register, side by side in the low 16 bits (one v_perm_b32)
+#ifdef VMX_EMU
+__device__ __forceinline__ unsigned vmx_pk_bytes(unsigned b) { return (b & 0xffu) | ((b >> 8) & 0xff00u); }
+#else
+__device__ __forceinline__ unsigned vmx_pk_bytes(unsigned b) { return __builtin_amdgcn_perm(b, b, 0x0c0c0200u); }
+#endif
 __device__ __forceinline__ unsigned vmx_bfi(unsigned m, unsigned a, unsigned b) { return (m & a) | (~m & b); }     // v_bfi_b32
 // value known to be identical in every lane: hand it to the compiler as a scalar (v_readfirstlane_b32)
 #ifdef VMX_EMU
