@@ -103,6 +103,8 @@ def main():
     # contexts overlap on the device, so the latency-bound chain / re-seeding kernels of one batch run under the VALU-bound DP of another
     nstream = max(1, min(args.streams, nsteps))
     ctxs = [ctx] + [Context(local_rank) for _ in range(nstream - 1)]
+    for cx in ctxs:
+        cx.set_inflight(nstream)            # contexts that share the GPU launch their latency-bound kernels narrower (vm_ctx_set_inflight)
     for s in range(args.warmup):
         for ci, cx in enumerate(ctxs):      # every context is warmed on the same batches (sizes its pools)
             st, recs, stats = resident[warm[s]].align(index, prm, want_records=(ci == 0 and s == 0 and args.verify > 0 and rank == 0), ctx=cx)

@@ -61,6 +61,10 @@ typedef struct vm_ctx vm_ctx;
 /* one context = one GPU (device_id) + its streams and work buffers; one per host thread per GPU */
 int vm_ctx_create(int device_id, vm_ctx** out);
 void vm_ctx_destroy(vm_ctx*);
+/* How many contexts share this GPU (batches in flight, one host thread each; default 1). A context that runs alone sizes its
+ * latency-bound kernels to fill the device; with several in flight they are launched narrower (the local seeding kernel at 3 / 2 / 1
+ * workgroups per CU for 1 / 2 / >= 3 contexts) so that another batch's VALU-bound gap-fill kernel can be resident beside them. */
+int vm_ctx_set_inflight(vm_ctx*, int n_contexts);
 int vm_device_count(void);
 
 /* build the minimizer index of a FASTA file / in-memory contigs ON THE GPU and keep it resident in HBM

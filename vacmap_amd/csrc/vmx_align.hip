@@ -289,6 +289,8 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
             int32_t* d_range = B.qrange.as<int32_t>(); int32_t* d_cnt = d_range + 4;
             std::vector<int32_t> csz; for (size_t q = 0; q + 1 < cuts.size(); ++q) csz.push_back(cuts[q + 1] - cuts[q]);
             VMX_TRY(upload(B.chunkn, csz.data(), csz.size(), c->stream));
+            int fill_waves = 16;                                  // waves per CU of the fill kernel (tuning knob: VMX_FILL_WAVES)
+            if (const char* e = getenv("VMX_FILL_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 32) fill_waves = v; }
             for (size_t q = 0; q + 1 < cuts.size(); ++q) {
                 const int p0 = cuts[q], pn = cuts[q + 1] - cuts[q];
                 // the problems' absolute traceback offsets index a buffer that holds this chunk only
@@ -296,7 +298,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
                 hipEvent_t* ke = q < 8 ? c->gev + (redo_only ? 24 : 0) + 3 * q : nullptr;      // HIP events around the dominant kernel, on the stream it runs on
                 hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>() + p0, B.chunkn.as<int32_t>() + q, (int64_t)0, B.order.as<int32_t>(), d_range, d_cnt);
                 if (ke) (void)hipEventRecord(ke[0], c->stream);
-                hipLaunchKernelGGL(k_gapfill_fill_ns, dim3((unsigned)std::min<int64_t>(pn, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
+                hipLaunchKernelGGL(k_gapfill_fill_ns, dim3((unsigned)std::min<int64_t>(pn, (int64_t)c->num_cu * fill_waves)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
                                    B.dptab.as<vmx_dp_prob>() + p0, pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_cnt);
                 if (ke) (void)hipEventRecord(ke[1], c->stream);
                 hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)((pn + 63) / 64)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>() + p0, pn, prm->eqx,

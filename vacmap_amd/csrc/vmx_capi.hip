@@ -111,6 +111,13 @@ void vm_ctx_destroy(vm_ctx* c) {
     delete c;
 }
 
+int vm_ctx_set_inflight(vm_ctx* c, int n_contexts) {
+    if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
+    if (n_contexts < 1) { set_error("n_contexts must be >= 1"); return VM_ERR_ARG; }
+    c->inflight = n_contexts;
+    return VM_OK;
+}
+
 int64_t vm_table(vm_ctx* c, int which, void** data) {
     if (!c) return VM_ERR_NO_CTX;
     const vmx_tables& t = c->tables;

@@ -64,6 +64,7 @@ struct vm_ctx {
     vmx::DevBuf tab_buf;
     vmx::DevBuf b[VMX_NBUF];     // scratch buffers reused by the entry points (grow-only)
     int num_cu = 256;
+    int inflight = 1;                            // contexts sharing the GPU (vm_ctx_set_inflight)
     hipEvent_t ev[24];
     hipEvent_t gev[48];                          // gap-fill chunk events: [redo][chunk 0..7][before fill, after fill, after trace]
     int n_gev[2] = {0, 0};                        // chunks recorded by the last batch per pass

@@ -90,6 +90,7 @@ class VmxLib:
         L.vm_params_default.argtypes = [P(Params), C.c_int]
         L.vm_ctx_create.argtypes = [C.c_int, P(vp)]
         L.vm_ctx_destroy.argtypes = [vp]
+        L.vm_ctx_set_inflight.argtypes = [vp, C.c_int]
         L.vm_table.argtypes = [vp, C.c_int, P(vp)]; L.vm_table.restype = i64
         L.vm_edit_distance_batch.argtypes = [vp, i64, cp, vp, cp, vp, P(P(i64))]
         L.vm_edit_distance_bound_batch.argtypes = [vp, C.c_int, i64, cp, vp, cp, vp, P(P(i64))]
@@ -156,6 +157,10 @@ class Context:
         h = C.c_void_p()
         self.lib.check(self.lib.L.vm_ctx_create(device, C.byref(h)))
         self.h = h
+
+    def set_inflight(self, n_contexts):
+        """tell the context how many contexts share its GPU (vm_ctx_set_inflight)"""
+        self.lib.check(self.lib.L.vm_ctx_set_inflight(self.h, int(n_contexts)))
 
     def close(self):
         if self.h:
