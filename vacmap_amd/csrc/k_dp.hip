@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(64) k_gapfill_fill(const uint8_t* __restrict__
                                                      const int32_t* __restrict__ order, int32_t* __restrict__ counter) {
     vmx_gapfill_fill_body<true>(tcodes, qcodes, probs, n_prob, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, order, counter);
 }
-__global__ void __launch_bounds__(64) k_gapfill_fill_ns(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
+__global__ void __launch_bounds__(64, 5) k_gapfill_fill_ns(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
                                                         const vmx_dp_prob* __restrict__ probs, int n_prob, int match, int mismatch,
                                                         int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb_pool,
                                                         int32_t* __restrict__ bnd_pool, int32_t* __restrict__ out_score,
