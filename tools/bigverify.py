@@ -7,7 +7,8 @@ from vacmap_amd.lib import Context, Index, align_batch, load
 ctx = Context(0); lib = load()
 contigs = synth.make_reference([30_000_000], seed=1)
 names = ['chr1']
-for mode, k, n, kw in (('H', 15, 3000, dict(mean_len=15000, err=0.10)), ('L', 19, 1500, dict(mean_len=15000, err=0.005)), ('R', 15, 1500, dict(mean_len=12000, err=0.10)), ('S', 15, 1000, dict(mean_len=12000, err=0.13))):
+for mode, k, n, kw in (('H', 15, 3000, dict(mean_len=15000, err=0.10)), ('L', 19, 1500, dict(mean_len=15000, err=0.005)), ('R', 15, 1500, dict(mean_len=12000, err=0.10)), ('S', 15, 1000, dict(mean_len=12000, err=0.13)),
+                        ('H', 15, 500, dict(mean_len=45000, err=0.10)), ('H', 15, 2000, dict(mean_len=2500, err=0.15))):   # long reads (large LDS buckets, many stripes); short reads (small DP problems)
     cat, off, _ = synth.sample_reads_concat(contigs, n, seed=77, **kw)
     seqs = [cat[off[i]:off[i + 1]].tobytes().decode() for i in range(n)]
     gi = Index.from_seqs(ctx, names, [contigs[0].tobytes()], k=k, w=10)
