@@ -180,17 +180,18 @@ def main():
         achieved = (algo_bytes / K) / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
         # HBM traffic of the kernel per launch: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs) of this same command, summarised
         # in profiles/ (bench.py cannot collect counters on itself); null when the summary is absent
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu_util = None, None, None
         try:
             pj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_j_pmc_hbm_traffic.json')))
             traffic = (pj['kernels'].get('k_gapfill_fill_ns') or pj['kernels']['k_gapfill_fill'])['hbm_bytes_per_step']        # per step, like achieved (a step = a few chunk launches)
             traffic_src = 'profiles/r01_j_pmc_hbm_traffic.json'
+            valu_util = (pj['kernels'].get('k_gapfill_fill_ns') or pj['kernels']['k_gapfill_fill']).get('valu_utilisation')
         except Exception:
             pass
         # what the kernel itself must move: one traceback byte per DP cell (the reference's k_cigar materialises the same matrix) + its strings
         kbytes = (agg['dp_cells'] + agg['dp_string_bytes']) / K
         roofline = {'bound': 'hbm', 'kernel': 'k_gapfill_fill_ns', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                    'traffic': traffic, 'traffic_source': traffic_src, 'avg_kernel_ms_per_step': fill_ms, 'algorithmic_bytes_per_step': algo_bytes / K,
+                    'traffic': traffic, 'traffic_source': traffic_src, 'valu_utilisation_pmc': valu_util, 'avg_kernel_ms_per_step': fill_ms, 'algorithmic_bytes_per_step': algo_bytes / K,
                     'kernel_bytes_per_step': kbytes, 'kernel_GBps': kbytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0,
                     'dp_cells_per_s': (agg['dp_cells'] / K) / (fill_ms * 1e-3) if fill_ms > 0 else 0.0,
                     'note': 'achieved uses the path-level algorithmic bytes of SURVEY 8(d); the kernel is an integer DP bound by VALU issue (packed int16: ~75-85 VALU ops per '
