@@ -38,18 +38,20 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
         for (int x = lane; x < 100; x += 64) s_rgc[x] = rgc_g[x];          // read-gap cost table of this read's variant (100 entries, maxgap <= 99)
         const float* rgc = s_rgc;
         const vmx_anchor* A = anchors + a0;
-        // LDS layout (VMX_LC_BYTES_PER_ANCHOR = 24): S f64 | ref position relative to the smallest one u32 | q i32 | l,s packed i32 | S_arg i32.
-        // P (written once per anchor, read by the traceback) stays in HBM.
-        double* S; int* SA; int* Q; unsigned* R; int* LS;
+        // LDS layout (VMX_LC_BYTES_PER_ANCHOR = 12): S f64 | S_arg i32 — only what the scan may touch at random. The anchors themselves stay in
+        // HBM: the loop takes them in order from 64-anchor register blocks (one coalesced load per 64 steps, a block ahead; the current anchor
+        // comes out by v_readlane), the candidates' fields live in the register window, and the rare paths (an insertion below the window, a
+        // scan past 64 candidates, the traceback) read A[j] directly. P (written once per anchor, read by the traceback) stays in HBM.
+        (void)rmin; (void)in_lds;
+        double* S; int* SA;
         int* P = P_pool + a0;
-        if constexpr (IN_LDS) { S = (double*)smem; R = (unsigned*)(S + lds_cap); Q = (int*)(R + lds_cap); LS = Q + lds_cap; SA = LS + lds_cap; }
-        else { S = S_pool + a0; SA = SA_pool + a0; Q = nullptr; R = nullptr; LS = nullptr; }
-        if constexpr (IN_LDS) for (int i = lane; i < n; i += 64) { vmx_anchor a = A[i]; Q[i] = a.q; R[i] = (unsigned)(a.r - rmin); LS[i] = ((int)a.l & 0xffff) | ((int)a.s << 16); }
+        if constexpr (IN_LDS) { S = (double*)smem; SA = (int*)(S + lds_cap); }
+        else { S = S_pool + a0; SA = SA_pool + a0; }
         __syncthreads();
-#define AQ(i) (in_lds ? Q[i] : A[i].q)
-#define AR(i) (in_lds ? (rmin + (long long)R[i]) : (long long)A[i].r)
-#define AL(i) (in_lds ? (LS[i] & 0xffff) : (int)A[i].l)
-#define AS(i) (in_lds ? (LS[i] >> 16) : (int)A[i].s)
+#define AQ(i) (A[i].q)
+#define AR(i) ((long long)A[i].r)
+#define AL(i) ((int)A[i].l & 0xffff)
+#define AS(i) ((int)A[i].s)
         long long prereadloc = (long long)AQ(0) + AL(0);
         int testspace_en = 1;
         if (lane == 0) { SA[0] = 0; S[0] = (double)AL(0); P[0] = VMX_NOPRE; if (scar) { FP[0] = 0.0; PP[0] = 0.0; } }
@@ -59,13 +61,20 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
         bool need_fast = false;
         // candidate window (vmx_cwin): the testspace_en entries of S_arg, best first, the top 64 of them in registers
         vmx_cwin win; win.j = 0; win.q = AQ(0); win.ls = AL(0) | (AS(0) << 16); win.S = (double)AL(0); win.r = AR(0);
-        int nq = 0, nl = 0, ns = 0; long long nr = 0;            // anchor i+1, loaded one step ahead
-        if (n > 1) { nq = AQ(1); nr = AR(1); nl = AL(1); ns = AS(1); }
+        // anchors [bb, bb + 64) in registers (lane t: anchor bb + t), the next block already on its way
+        int bq = 0, bls = 0; long long br = 0, nbr = 0; int nbq = 0, nbls = 0;
+        { const int x = lane < n ? lane : n - 1; const vmx_anchor a = A[x]; bq = a.q; bls = ((int)a.l & 0xffff) | ((int)a.s << 16); br = a.r; }
+        { const int x = 64 + lane < n ? 64 + lane : n - 1; const vmx_anchor a = A[x]; nbq = a.q; nbls = ((int)a.l & 0xffff) | ((int)a.s << 16); nbr = a.r; }
         int pq = win.q, pls = win.ls; long long pr = win.r; double pS = win.S;      // anchor i-1 and its score
         for (int i = 1; i < n; ++i) {
             // the current anchor is the same in every lane: scalar registers, scalar branches on its strand
-            const int qi = vmx_uniform_i32(nq); const long long ri = vmx_uniform_i64(nr); const int li = vmx_uniform_i32(nl); const int si = vmx_uniform_i32(ns);
-            if (i + 1 < n) { nq = AQ(i + 1); nr = AR(i + 1); nl = AL(i + 1); ns = AS(i + 1); }
+            if ((i & 63) == 0) {
+                bq = nbq; bls = nbls; br = nbr;
+                const int x = i + 64 + lane < n ? i + 64 + lane : n - 1; const vmx_anchor a = A[x]; nbq = a.q; nbls = ((int)a.l & 0xffff) | ((int)a.s << 16); nbr = a.r;
+            }
+            const int bl = i & 63;
+            const int qi = vmx_readlane(bq, bl); const int lsi = vmx_readlane(bls, bl); const int li = lsi & 0xffff, si = lsi >> 16;
+            long long ri; { union { long long d; int w[2]; } u; u.d = br; u.w[0] = vmx_readlane(u.w[0], bl); u.w[1] = vmx_readlane(u.w[1], bl); ri = u.d; }
             if (prereadloc < (long long)qi + li) {
                 if (!scar && opcount > 100000 && ((double)opcount / (double)prereadloc) > 1000.0) { need_fast = true; break; }   // :27380 -> *_fast
                 for (int k = testspace_en; k < i; ++k) {
@@ -215,13 +224,11 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
         const int n = la_cnt[rd];
         if (n <= 0) { if (lane == 0) { out_len[rd] = 0; out_score[rd] = 0; status[rd] = VM_READ_RAISED_DEV; } continue; }   // np.array([]) indexing raises
         const vmx_anchor* A = anchors + a0;
-        long long rmin = 0x7fffffffffffffffLL, rmax = -0x7fffffffffffffffLL;
-        for (int i = lane; i < n; i += 64) { const long long r = A[i].r; rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax; }
-        for (int o = 32; o > 0; o >>= 1) { const long long a = __shfl_xor(rmin, o), b = __shfl_xor(rmax, o); rmin = a < rmin ? a : rmin; rmax = b > rmax ? b : rmax; }
+        const long long rmin = 0;
         const int var = mode == 3 ? 2 : (n_guides_total[rd] > 1 ? 1 : 0);
 #define VMX_LC_CALL(L, V) vmx_chain_local_read<L, V>(anchors, n_guides_total, rd, a0, n, rmin, smem, s_gapcost, s_rgc, lds_cap, tab, skip_exact, skip_mm, maxdiff, maxgap, \
                                                       mode, S_pool, P_pool, SA_pool, out_score, out_chain, out_len, out_variant, status, FP_pool, PP_pool)
-        if (n <= lds_cap && (rmax - rmin) < 0xffffffffLL) { if (var == 0) VMX_LC_CALL(true, 0); else if (var == 1) VMX_LC_CALL(true, 1); else VMX_LC_CALL(true, 2); }
+        if (n <= lds_cap) { if (var == 0) VMX_LC_CALL(true, 0); else if (var == 1) VMX_LC_CALL(true, 1); else VMX_LC_CALL(true, 2); }
         else { if (var == 0) VMX_LC_CALL(false, 0); else if (var == 1) VMX_LC_CALL(false, 1); else VMX_LC_CALL(false, 2); }
 #undef VMX_LC_CALL
     }

@@ -164,7 +164,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     // Inside a bucket the reads are ordered longest first and every read is its own workgroup: the dispatcher hands them out in
     // that order, which is the longest-first dynamic schedule.
     constexpr int NB = 10;
-    const int caps[NB] = {512, 768, 1024, 1280, 1536, 2048, 2560, 3072, 4096, 6656};
+    const int caps[NB] = {512, 768, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 13056};
     std::vector<int32_t> lists[NB + 1];
     for (int64_t r = 0; r < n; ++r) {
         int m = L.h_la_cnt[r];
