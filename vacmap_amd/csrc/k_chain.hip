@@ -146,31 +146,28 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
     {
         const vmx_anchor* A = anchors + a0;
         // working arrays: LDS when the read fits, else straight in the HBM output arrays
-        // LDS layout (VMX_GC_BYTES_PER_ANCHOR = 25): S f64 | ref position relative to the smallest one u32 | q i32 | l,s packed i32 | S_arg i32 | cov u8.
-        // P (written once per anchor) goes straight to its HBM output array.
-        double* S; int* SA; int* Q; unsigned* R; int* LS; uint8_t* COV;
+        // LDS layout (VMX_GC_BYTES_PER_ANCHOR = 12): S f64 | S_arg i32 — only what the scan may touch at random. Anchors and coverage stay in
+        // HBM: the loop takes them in order from 64-anchor register blocks (one coalesced load per 64 steps, a block ahead; the current anchor
+        // comes out by v_readlane), the candidates' fields live in the register window (vmx_cwin), and the rare paths (an insertion below the
+        // window or among equal scores, a scan past 64 candidates) read A[j] directly. P (written once per anchor) goes to its HBM output array.
+        (void)rmin; (void)in_lds;
+        double* S; int* SA; uint8_t* COV = cov_pool + a0;
         int* P = P_out + a0;
-        if constexpr (IN_LDS) {
-            S = (double*)smem; R = (unsigned*)(S + lds_cap); Q = (int*)(R + lds_cap); LS = Q + lds_cap;
-            SA = LS + lds_cap; COV = (uint8_t*)(SA + lds_cap);
-        } else {
-            S = S_out + a0; SA = SA_out + a0; COV = cov_pool + a0;
-            Q = nullptr; R = nullptr; LS = nullptr;
-        }
-        // stage anchors + coverage (number of anchors sharing the read position, capped at 20: :24865-24868)
+        if constexpr (IN_LDS) { S = (double*)smem; SA = (int*)(S + lds_cap); }
+        else { S = S_out + a0; SA = SA_out + a0; }
+        // coverage (number of anchors sharing the read position, capped at 20: :24865-24868)
         for (int i = lane; i < n; i += 64) {
             vmx_anchor a = A[i];
-            if constexpr (IN_LDS) { Q[i] = a.q; R[i] = (unsigned)(a.r - rmin); LS[i] = ((int)a.l & 0xffff) | ((int)a.s << 16); }
             int c = 1;
             for (int x = i - 1; x >= 0 && A[x].q == a.q && c < 20; --x) ++c;
             for (int x = i + 1; x < n && A[x].q == a.q && c < 20; ++x) ++c;
             COV[i] = (uint8_t)c;
         }
         __syncthreads();
-#define AQ(i) (in_lds ? Q[i] : A[i].q)
-#define AR(i) (in_lds ? (rmin + (long long)R[i]) : (long long)A[i].r)
-#define AL(i) (in_lds ? (LS[i] & 0xffff) : (int)A[i].l)
-#define AS(i) (in_lds ? (LS[i] >> 16) : (int)A[i].s)
+#define AQ(i) (A[i].q)
+#define AR(i) ((long long)A[i].r)
+#define AL(i) ((int)A[i].l & 0xffff)
+#define AS(i) ((int)A[i].s)
         int prereadloc = AQ(0);
         // rmode: mode R's body (mammap_noprefercloser.py:22839-23057) has no coverage terms; a non-co-linear step costs the fixed skipcost,
         // remembered per anchor in fixed_penatly / pre_penatly (FP / PP, in HBM) and refunded after skipcost co-linear bases
@@ -183,19 +180,50 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
         double g_max_scores = (double)AL(0); int g_max_index = 0;
         long long opcount = 0;
         bool bailed = false;
+        // candidate window: the testspace_en entries of S_arg, best first, the top 64 of them in registers
+        vmx_cwin win; win.j = 0; win.q = AQ(0); win.ls = AL(0) | (AS(0) << 16); win.S = (double)AL(0); win.r = AR(0);
+        // anchors [bb, bb + 64) in registers (lane t: anchor bb + t), the next block already on its way
+        int bq = 0, bls = 0, bcov = 0, nbq = 0, nbls = 0, nbcov = 0; long long br = 0, nbr = 0;
+        { const int x = lane < n ? lane : n - 1; const vmx_anchor a = A[x]; bq = a.q; bls = ((int)a.l & 0xffff) | ((int)a.s << 16); br = a.r; bcov = COV[x]; }
+        { const int x = 64 + lane < n ? 64 + lane : n - 1; const vmx_anchor a = A[x]; nbq = a.q; nbls = ((int)a.l & 0xffff) | ((int)a.s << 16); nbr = a.r; nbcov = COV[x]; }
+        int pq = win.q, pls = win.ls; long long pr = win.r; double pS = win.S;      // anchor i-1 and its score
         for (int i = 1; i < n; ++i) {
+            if ((i & 63) == 0) {
+                bq = nbq; bls = nbls; br = nbr; bcov = nbcov;
+                const int x = i + 64 + lane < n ? i + 64 + lane : n - 1; const vmx_anchor a = A[x]; nbq = a.q; nbls = ((int)a.l & 0xffff) | ((int)a.s << 16); nbr = a.r; nbcov = COV[x];
+            }
             // the current anchor is the same in every lane: scalar registers, scalar branches on its strand
-            const int qi = vmx_uniform_i32(AQ(i)); const long long ri = vmx_uniform_i64(AR(i)); const int li = vmx_uniform_i32(AL(i)); const int si = vmx_uniform_i32(AS(i));
+            const int bl = i & 63, bb = i & ~63;
+            const int qi = vmx_readlane(bq, bl); const int lsi = vmx_readlane(bls, bl); const int li = lsi & 0xffff, si = lsi >> 16;
+            long long ri; { union { long long d; int w[2]; } u; u.d = br; u.w[0] = vmx_readlane(u.w[0], bl); u.w[1] = vmx_readlane(u.w[1], bl); ri = u.d; }
             if (prereadloc < qi) {
                 if (((double)opcount / (double)i) > 1000.0) { bailed = true; break; }   // :24914 max_factor
                 for (int k = testspace_en; k < i; ++k) {
-                    const int loc = vmx_insertpoint_score_wave(S, S[k], k, SA, lane);
-                    vmx_sarg_insert4(SA, loc, k, lane);
+                    double Sk; int qk, lsk; long long rk;
+                    if (k == i - 1) { Sk = pS; qk = pq; lsk = pls; rk = pr; }
+                    else if (k >= bb) {
+                        const int kl = k - bb; Sk = S[k]; qk = vmx_readlane(bq, kl); lsk = vmx_readlane(bls, kl);
+                        union { long long d; int w[2]; } u; u.d = br; u.w[0] = vmx_readlane(u.w[0], kl); u.w[1] = vmx_readlane(u.w[1], kl); rk = u.d;
+                    } else { Sk = S[k]; qk = AQ(k); lsk = AL(k) | (AS(k) << 16); rk = AR(k); }
+                    // the reference's bisection (:19369-19387) puts a score without an equal behind all smaller ones; among equals the place
+                    // depends on its probe sequence (vmx_insertpoint_score_wave): the window handles the first case
+                    const int W = k < 64 ? k : 64;               // k entries so far
+                    const unsigned long long gt = __ballot(lane < W && win.S > Sk), ge = __ballot(lane < W && win.S >= Sk);
+                    const int above = __popcll(gt);
+                    if (gt == ge && above < 64 && (above < W || W == k)) {
+                        vmx_cwin_insert(win, above, k, Sk, qk, lsk, rk, lane);
+                        if (lane <= above) SA[k - lane] = win.j;
+                    } else {
+                        const int loc = vmx_insertpoint_score_wave(S, Sk, k, SA, lane);
+                        vmx_sarg_insert4(SA, loc, k, lane);
+                        if (lane <= k) { const int j = SA[k - lane]; win.j = j; win.S = S[j]; win.q = AQ(j); win.ls = AL(j) | (AS(j) << 16); win.r = AR(j); }
+                    }
                 }
                 testspace_en = i;
                 if (!rmode) {
-                    skipcost = oskipcost + (double)COV[i];
-                    maxdiff = omaxdiff - (int)COV[i]; if (maxdiff < 10) maxdiff = 10;
+                    const int covi = vmx_readlane(bcov, bl);
+                    skipcost = oskipcost + (double)covi;
+                    maxdiff = omaxdiff - covi; if (maxdiff < 10) maxdiff = 10;
                 }
                 prereadloc = qi;
             }
@@ -208,10 +236,11 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
                 int j = 0; double Sj = 0.0; double test = -1e300;
                 double nfp = 0.0, npp = 0.0;                     // rmode: what i inherits if this candidate wins
                 if (valid) {
-                    j = SA[x]; Sj = S[j];
+                    int qj, lj, sj; long long rj;
+                    if (base == testspace_en - 1) { j = win.j; Sj = win.S; qj = win.q; lj = win.ls & 0xffff; sj = win.ls >> 16; rj = win.r; }   // first 64: registers
+                    else { j = SA[x]; Sj = S[j]; qj = AQ(j); lj = AL(j); sj = AS(j); rj = AR(j); }
                     long long readgap, refgap, bonus;
-                    const int sj = AS(j);
-                    vmx_gap_geometry(qi, ri, si, li, AQ(j), AR(j), sj, AL(j), readgap, refgap, bonus);
+                    vmx_gap_geometry(qi, ri, si, li, qj, rj, sj, lj, readgap, refgap, bonus);
                     long long gapcost = readgap - refgap; if (gapcost < 0) gapcost = -gapcost;
                     if (rmode) {
                         if (si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
@@ -250,6 +279,7 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
             }
             if (lane == 0) { S[i] = max_scores; P[i] = pre_index; if (rmode) { FP[i] = fp_i; PP[i] = pp_i; } }
             if (max_scores > g_max_scores) { g_max_scores = max_scores; g_max_index = i; }
+            pS = max_scores; pq = qi; pls = lsi; pr = ri;
             __syncthreads();
         }
         if (!bailed) {
@@ -288,12 +318,10 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
         const int n = (int)(aoff[rd + 1] - a0);
         if (n <= 0) { if (lane == 0) { gmax_out[rd] = -2; opcount_out[rd] = 0; } continue; }
         const vmx_anchor* A = anchors + a0;
-        long long rmin = 0x7fffffffffffffffLL, rmax = -0x7fffffffffffffffLL;
-        for (int i = lane; i < n; i += 64) { const long long r = A[i].r; rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax; }
-        for (int o = 32; o > 0; o >>= 1) { const long long a = __shfl_xor(rmin, o), b = __shfl_xor(rmax, o); rmin = a < rmin ? a : rmin; rmax = b > rmax ? b : rmax; }
+        const long long rmin = 0;
 #define VMX_GC_CALL(L, R) vmx_chain_global_read<L, R>(anchors, rd, a0, n, rmin, smem, s_gapcost, lds_cap, tab, oskipcost, omaxdiff, maxgap, S_out, P_out, SA_out, cov_pool, \
                                                        gmax_out, opcount_out, FP_pool, PP_pool)
-        if (n <= lds_cap && (rmax - rmin) < 0xffffffffLL) { if (rmode) VMX_GC_CALL(true, true); else VMX_GC_CALL(true, false); }
+        if (n <= lds_cap) { if (rmode) VMX_GC_CALL(true, true); else VMX_GC_CALL(true, false); }
         else { if (rmode) VMX_GC_CALL(false, true); else VMX_GC_CALL(false, false); }
 #undef VMX_GC_CALL
     }

@@ -150,7 +150,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     if (rmode) { VMX_TRY(B.fp.reserve(8 * (size_t)(tot + 1))); VMX_TRY(B.pp.reserve(8 * (size_t)(tot + 1))); }   // fixed_penatly / pre_penatly of mode R's chain
     // LDS buckets by anchor count (25 B per anchor), reads longest-first inside a bucket, one workgroup per read (see vmx_local_stage)
     constexpr int NB = 10;
-    const int caps[NB] = {384, 512, 768, 1024, 1280, 1536, 2048, 3072, 4096, 6400};
+    const int caps[NB] = {384, 512, 768, 1024, 1536, 2048, 3072, 4096, 8192, 13056};
     std::vector<int32_t> lists[NB + 1];
     for (int64_t r = 0; r < n; ++r) {
         int64_t m = h_aoff[r + 1] - h_aoff[r]; const int64_t L = h_roff[r + 1] - h_roff[r];

@@ -344,7 +344,7 @@ int vm_chain_global_batch(vm_ctx* c, const vm_params* prm, int kmersize, int64_t
     const int rmode = prm->mode == VM_MODE_R ? 1 : 0;
     if (rmode) { VMX_TRY(c->b[25].reserve(8 * (size_t)(tot + 1))); VMX_TRY(c->b[26].reserve(8 * (size_t)(tot + 1))); }   // mode R: fixed_penatly / pre_penatly
     // bucket the reads by anchor count so that each launch asks for no more LDS than it needs (160 KiB per CU on gfx950)
-    const int caps[4] = {768, 1536, 3072, 6400};
+    const int caps[4] = {768, 1536, 3072, 13056};
     std::vector<int32_t> lists[5];
     std::vector<char> fastflag((size_t)n, 0);
     for (int64_t r = 0; r < n; ++r) {
