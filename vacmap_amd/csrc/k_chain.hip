@@ -3,12 +3,13 @@
 //   k_flip_sort      S2 get_reversed_chain_numpy_rough (/root/reference/src/vacmap/mammap_clrnano.py:21202-21217)
 //                    + the stable argsort by read position of hit2work_1 (:23572)
 //   k_chain_global   G2 get_optimal_chain_sortbyreadpos_forSV_inv_test_merged_fine_list_d_all (:24828-25031), "GC-exact":
-//                    one wavefront per read; anchors, S, P and the score-sorted index S_arg live in LDS (32 B per
-//                    anchor) when they fit, else in HBM. The candidate scan visits 64 predecessors per wave step in
+//                    one wavefront per read; S and the score-sorted index S_arg live in LDS (12 B per anchor) when they
+//                    fit, else in HBM; anchors and coverage are streamed from HBM through 64-anchor register blocks, the
+//                    64 best predecessors sit in a register window. The candidate scan visits 64 predecessors per wave step in
 //                    descending-S order; an exclusive prefix-max recovers the exact sequential break index, `opcount`
 //                    and the strict-'>' winner.
 //   k_chain_select   G1 hit2work_1 peel / primary / MAPQ / secondaries (:23588-23707) + decode_hit (:23981-24020):
-//                    one thread per read (serial, tiny).
+//                    one wavefront per read: arrays staged in LDS, lane 0 runs the serial peel.
 // Scores are IEEE double in the reference's evaluation order; the library is compiled with -ffp-contract=off.
 #include "vmx_device.h"
 #include "vmx_kernels.h"

@@ -1,7 +1,8 @@
 // k_chain_local.hip — local chain DP: LC-exact (get_optimal_chain_sortbyreadpos_forSV_inv_test_merged_fine_list,
 // /root/reference/src/vacmap/mammap_clrnano.py:27305-27528) and LC-mm (..._fine_list_mismatch, :28250-28476).
-// One wavefront per read; anchors (sorted by read END, :28585), S and the score-sorted index S_arg live in LDS (24 B per anchor)
-// when they fit, else in HBM; reads are bucketed by anchor count so that a workgroup only claims the LDS its read needs.
+// One wavefront per read; S and the score-sorted index S_arg live in LDS (12 B per anchor) when they fit, else in HBM; the anchors
+// (sorted by read END, :28585) are streamed from HBM through 64-anchor register blocks and the 64 best predecessors are kept in a
+// register window; reads are bucketed by anchor count so that a workgroup only claims the LDS its read needs.
 // Same 64-wide descending-S candidate scan as k_chain_global with the LC rules: the loop breaks on
 // S[j] < max - l_i (strict) and `opcount` is bumped before that test (:27410-27415); overlapping predecessors with bonus <= 0 are
 // skipped; traceback trims overlaps (:27508-27526). Scores are IEEE double in the reference's evaluation order (-ffp-contract=off).

@@ -5,8 +5,10 @@
 //   k_local_prep    L1 merge_chain / drop_somechains / sort by 1/len (:28482-28574): one thread per read (vmx_local.h)
 //   k_local_seed    L2 get_localmap_multi_all_forDP_inv_guide_1 (:23069-23345): one workgroup per read.
 //                   Python's hash(str) tables are exact 9-mer identity, so the table is an 18-bit direct-address structure:
-//                   HEAD[4^9] + NEXT[] linked lists over the window positions (built with one atomic exchange per position,
-//                   torn down by resetting only the touched heads). Per read position: forward + reverse-complement
+//                   HEAD[4^9] + NEXT[] linked lists over the window positions (built with one atomic exchange per position;
+//                   head entries carry the slot's epoch, so the table is never torn down; an occupancy bitmap of it in LDS
+//                   answers the look-ups of empty lists; a position's reference coordinate is implied by the window
+//                   interval list). Per read position: forward + reverse-complement
 //                   lookups, proximity filter against the two closest guide anchors (findClosest_1 :17560; the guide lives
 //                   in LDS), accepted hits written in the reference's stream order (read pos asc, forward before reverse,
 //                   ref pos asc). The sequential "flush once a run reaches 20" merge (:23232-23344) only couples hits of
