@@ -373,8 +373,17 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 }
                 __syncthreads();
                 int nbits = 0; { unsigned long long range = H > 0 ? spanL + spanH : 0; while (nbits < 40 && (range >> nbits)) ++nbits; }
-                uint64_t* res = vmx_block_radix_sort_u64(HKEY, HKEY2, (int)H, 26, (uint64_t)0, nbits, (int*)s_sort, s_scan);
-                if (res != HKEY) { for (long long i = threadIdx.x; i < H; i += blockDim.x) HKEY[i] = HKEY2[i]; }
+                // the stream index sits in the low 26 bits, so sorting whole keys = the stable sort by diagonal: up to VMX_SORT_LDS hits (most
+                // reads) that is one bitonic sort in LDS instead of the radix passes through HBM
+                int NP2 = 1; while (NP2 < H) NP2 <<= 1;
+                if (H > 1 && NP2 <= VMX_SORT_LDS) {
+                    for (long long i = H + threadIdx.x; i < NP2; i += blockDim.x) HKEY[i] = ~0ULL;
+                    __syncthreads();
+                    vmx_block_sort_u64(HKEY, NP2, s_sort);
+                } else {
+                    uint64_t* res = vmx_block_radix_sort_u64(HKEY, HKEY2, (int)H, 26, (uint64_t)0, nbits, (int*)s_sort, s_scan);
+                    if (res != HKEY) { for (long long i = threadIdx.x; i < H; i += blockDim.x) HKEY[i] = HKEY2[i]; }
+                }
                 __syncthreads();
             }
             int64_t* SV = (int64_t*)HKEY2;           // the sort's second buffer is free again: hit values (refloc << 1 | fwd) in sorted order
