@@ -215,20 +215,23 @@ __device__ __forceinline__ int vmx_r16_ror1(int v) { return __builtin_amdgcn_upd
 // T, Q, tl, ql, tb, bH, score_out describe the problem of this lane's 16-lane row (tl = 0: the row idles). Every lane of the wave calls it.
 // Control flow is wave-uniform (every lane runs every step, idle rows on dummy values with their memory accesses masked): the four rows
 // are in different stripes and columns, and the cross-lane moves must not sit in divergent code.
-template <bool SCORE>
-__device__ __forceinline__ void vmx_gapfill_fill16x4(const uint8_t* __restrict__ T, const uint8_t* __restrict__ Q, int tl, int ql, int match, int mismatch,
-                                                     int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb, int32_t* __restrict__ bH,
-                                                     int32_t* __restrict__ score_out, int lane) {
+// BAND: stripe s only runs the columns [jlo_s, jlo_s + W - 32] around the main line (VMX_BAND_JLO); cells outside count as -infinity.
+// The caller keeps the result only if the returned score passes vmx_band_proven (below).
+template <bool SCORE, bool BAND>
+__device__ __forceinline__ int vmx_gapfill_fill16x4(const uint8_t* __restrict__ T, const uint8_t* __restrict__ Q, int tl, int ql, int match, int mismatch,
+                                                    int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb, int32_t* __restrict__ bH,
+                                                    int32_t* __restrict__ score_out, int lane) {
     const int l = lane & 15;
     int32_t* bE1 = bH + (ql + 1);
     int32_t* bE2 = bE1 + (ql + 1);
-    const int W = VMX_X4_W(ql);
+    const int W = BAND ? (tl > 0 ? VMX_BAND_STEPS(tl, ql) : 0) : VMX_X4_W(ql);
+    int jlo = 1, jplo = 1, jpend = 0;                           // first column of this stripe; computed column range of the stripe above
     const int nstr = (tl + 31) >> 5;
     const unsigned O1 = vmx_pk(o1, o1), O2 = vmx_pk(o2, o2), E1C = vmx_pk(e1, e1), E2C = vmx_pk(e2, e2);
     const unsigned MATCH = vmx_pk(match, match), MISM = vmx_pk(mismatch, mismatch), ONE = vmx_pk(1, 1);
     const unsigned NEGP = vmx_pk(VMX_NEG16, VMX_NEG16);
     const int rf = (tl - 1) & 31;                               // row tl inside the last stripe: lane rf / 2 of the row, half rf & 1
-    const int t_fin = ql - 1 + rf;
+    const int t_fin = ql - (BAND && tl > 0 ? VMX_BAND_JLO(tl, ql, nstr - 1) : 1) + rf;
     const int total = vmx_uniform_i32(vmx_wave_max_i32(nstr * W));   // steps of the longest of the four problems
     unsigned fin = 0;
     int s = 0, t = 0;                                           // this row's stripe and the step inside it (t is a multiple of 16 here)
@@ -238,13 +241,13 @@ __device__ __forceinline__ void vmx_gapfill_fill16x4(const uint8_t* __restrict__
     uint8_t* tbp = tb;                                          // traceback line of the block's first step
     unsigned nq = 0, nH = 0, nE1 = 0, nE2 = 0;                  // chunk of the next block, loaded one block ahead
     // chunk of the 16 columns starting at step t0 of stripe s0: query bases and the row above the stripe, pre-shifted into the high half
-    auto load_chunk = [&](bool on, int s0, int t0, unsigned& q, unsigned& h, unsigned& x1, unsigned& x2) {
-        const int jj = t0 + l;
+    auto load_chunk = [&](bool on, int s0, int t0, int j0, int plo, int pend, unsigned& q, unsigned& h, unsigned& x1, unsigned& x2) {
+        const int jj = j0 - 1 + t0 + l;                         // column jj + 1 (j0 = first column of the stripe)
         q = (unsigned)(on && jj < ql ? (int)Q[jj] : 4) << 16;
-        h = 0; x1 = (unsigned)VMX_NEG16 << 16; x2 = x1;
+        h = BAND ? (unsigned)VMX_NEG16 << 16 : 0u; x1 = (unsigned)VMX_NEG16 << 16; x2 = x1;
         if (on && jj + 1 <= ql) {
             if (s0 == 0) h = (unsigned)vmx_gap_open_row(jj + 1, o1, e1, o2, e2) << 16;
-            else { h = (unsigned)bH[jj + 1] << 16; x1 = (unsigned)bE1[jj + 1] << 16; x2 = (unsigned)bE2[jj + 1] << 16; }
+            else if (!BAND || (jj + 1 >= plo && jj + 1 <= pend)) { h = (unsigned)bH[jj + 1] << 16; x1 = (unsigned)bE1[jj + 1] << 16; x2 = (unsigned)bE2[jj + 1] << 16; }
         }
     };
     for (int g0 = 0; g0 < total; g0 += 16) {
@@ -254,9 +257,20 @@ __device__ __forceinline__ void vmx_gapfill_fill16x4(const uint8_t* __restrict__
         if (act && t == 0) {
             const int i0 = s * 32 + 2 * l + 1;
             ti2 = vmx_pk(i0 <= tl ? (int)T[i0 - 1] : 5, i0 + 1 <= tl ? (int)T[i0] : 5);
-            Hleft = vmx_pk(vmx_gap_open_row(i0, o1, e1, o2, e2), vmx_gap_open_row(i0 + 1, o1, e1, o2, e2));
+            if (BAND) {
+                jlo = VMX_BAND_JLO(tl, ql, s);
+                if (s > 0) { jplo = VMX_BAND_JLO(tl, ql, s - 1); jpend = jplo + (W - 31) - 1; if (jpend > ql) jpend = ql; }
+            }
+            if (!BAND || jlo == 1) {
+                Hleft = vmx_pk(vmx_gap_open_row(i0, o1, e1, o2, e2), vmx_gap_open_row(i0 + 1, o1, e1, o2, e2));
+                Hdiag = vmx_pk(i0 - 1 == 0 ? 0 : vmx_gap_open_row(i0 - 1, o1, e1, o2, e2), vmx_gap_open_row(i0, o1, e1, o2, e2));
+            } else {
+                // the cells left of the stripe's first column are outside the band; the stripe's first row takes H(i0 - 1, jlo - 1) from the row above
+                Hleft = NEGP; Hdiag = NEGP;
+                if (l == 0 && s == 0) Hdiag = vmx_pk(vmx_gap_open_row(jlo - 1, o1, e1, o2, e2), VMX_NEG16);     // row 0 is the matrix's boundary row
+                else if (l == 0 && jlo - 1 >= jplo && jlo - 1 <= jpend) Hdiag = vmx_pk(bH[jlo - 1], VMX_NEG16);
+            }
             F1 = NEGP; F2 = NEGP;
-            Hdiag = vmx_pk(i0 - 1 == 0 ? 0 : vmx_gap_open_row(i0 - 1, o1, e1, o2, e2), vmx_gap_open_row(i0, o1, e1, o2, e2));
             outH = 0; outE1 = NEGP; outE2 = NEGP; qc = vmx_pk(4, 4);
             sHE = 0; sE2 = 0;
             store_bnd = s + 1 < nstr;
@@ -264,9 +278,9 @@ __device__ __forceinline__ void vmx_gapfill_fill16x4(const uint8_t* __restrict__
         }
         // a stripe's first chunk is loaded here (the previous stripe has only just stored it); the others were prefetched a block ago
         const bool first = __any(act && t == 0);
-        if (first) load_chunk(act && t == 0, s, 0, qchunk, cH, cE1, cE2);
+        if (first) load_chunk(act && t == 0, s, 0, jlo, jplo, jpend, qchunk, cH, cE1, cE2);
         if (!(act && t == 0)) { qchunk = nq; cH = nH; cE1 = nE1; cE2 = nE2; }
-        load_chunk(act && t + 16 < W, s, t + 16, nq, nH, nE1, nE2);
+        load_chunk(act && t + 16 < W, s, t + 16, jlo, jplo, jpend, nq, nH, nE1, nE2);
         const bool any_bnd = __any(act && store_bnd);
         const unsigned l15 = l == 15 ? 0xffffffffu : 0u;
 #define VMX_X4_STEP(RAMP, TT)                                                                                                      \
@@ -300,13 +314,14 @@ __device__ __forceinline__ void vmx_gapfill_fill16x4(const uint8_t* __restrict__
                     Hdiag = vmx_bfi(pm, upH, Hdiag); Hleft = vmx_bfi(pm, h, Hleft); F1 = vmx_bfi(pm, nF1, F1); F2 = vmx_bfi(pm, nF2, F2); \
                 } else { Hdiag = upH; Hleft = h; F1 = nF1; F2 = nF2; }                                                             \
                 outH = h; outE1 = e1v; outE2 = e2v;                                                                                \
-                if (SCORE) fin = (tfin_rel == (TT)) ? outH : fin;                                                                  \
+                if (SCORE || BAND) fin = (tfin_rel == (TT)) ? outH : fin;                                                          \
                 if (any_bnd) {                                                                                                     \
                     sHE = (unsigned)vmx_r16_ror1((int)vmx_bfi(l15, (outH >> 16) | (outE1 & 0xffff0000u), sHE));                    \
                     sE2 = (unsigned)vmx_r16_ror1((int)vmx_bfi(l15, outE2 >> 16, sE2));                                             \
                     if ((TT) == 14) {      /* t is a multiple of 16: the last row finishes a column that is a multiple of 16 on steps = 14 mod 16 */ \
-                        const int col = t + 14 - 30 - l;      /* lane k of the FIFO holds column j15 - k */                        \
-                        if (store_bnd && act && col >= 1 && col <= ql) { bH[col] = (int)(short)(sHE & 0xffffu); bE1[col] = (int)sHE >> 16; bE2[col] = (int)(short)(sE2 & 0xffffu); } \
+                        const int colr = t + 14 - 30 - l;     /* lane k of the FIFO holds (stripe-relative) column j15 - k */      \
+                        const int col = jlo - 1 + colr;                                                                            \
+                        if (store_bnd && act && colr >= 1 && col <= ql) { bH[col] = (int)(short)(sHE & 0xffffu); bE1[col] = (int)sHE >> 16; bE2[col] = (int)(short)(sE2 & 0xffffu); } \
                     }                                                                                                              \
                 }                                                                                                                  \
             }
@@ -324,13 +339,29 @@ __device__ __forceinline__ void vmx_gapfill_fill16x4(const uint8_t* __restrict__
             t += 16; tbp += 16 * 32;
             if (t == W) {
                 // the columns behind the last multiple of 16 are still in the FIFO (W - 31 >= ql): lane k holds column W - 31 - k
-                const int col = W - 31 - l;
-                if (store_bnd && col > ((W - 31) & ~15) && col <= ql) { bH[col] = (int)(short)(sHE & 0xffffu); bE1[col] = (int)sHE >> 16; bE2[col] = (int)(short)(sE2 & 0xffffu); }
+                const int colr = W - 31 - l, col = jlo - 1 + colr;
+                if (store_bnd && colr > ((W - 31) & ~15) && col <= ql) { bH[col] = (int)(short)(sHE & 0xffffu); bE1[col] = (int)sHE >> 16; bE2[col] = (int)(short)(sE2 & 0xffffu); }
                 t = 0; ++s;
             }
         }
     }
-    if (SCORE && nstr > 0 && l == (rf >> 1)) *score_out = (rf & 1) ? vmx_pk_hi(fin) : vmx_pk_lo(fin);
+    const int sc = (rf & 1) ? vmx_pk_hi(fin) : vmx_pk_lo(fin);
+    if (SCORE && nstr > 0 && l == (rf >> 1)) *score_out = sc;
+    return sc;                                                  // meaningful in lane rf / 2 of the row
+}
+
+// Is the banded result the true optimum with the true traceback? Every path that leaves the computed band deviates from the matrix's
+// main line by more than VMX_BAND_W - 1 columns somewhere, so it holds at least g inserted and g deleted bases with
+// g = (VMX_BAND_W - 1 - |tl - ql|) * min / max, and cannot score more than match * (min(tl, ql) - g) minus two gaps of g. If the banded
+// score beats that bound, every optimal path lies inside the band, where all cells it touches and all comparisons the traceback reads
+// (they involve prefix-optimal values of cells on optimal paths only) are exact.
+__device__ __forceinline__ bool vmx_band_proven(int score, int tl, int ql, int match, int o1, int e1, int o2, int e2) {
+    const int mn = tl < ql ? tl : ql, mx = tl < ql ? ql : tl;
+    long long g = (long long)(VMX_BAND_W - 1 - (mx - mn)) * mn / mx;
+    if (g < 1) return false;
+    const long long c1 = o1 + g * e1, c2 = o2 + g * e2;
+    const long long U = (long long)match * (mn - g) - 2 * (c1 < c2 ? c1 : c2);
+    return (long long)score > U;
 }
 
 // order/counter: longest-first device work queue (order == nullptr: plain grid-stride over [0, n_prob))
@@ -357,9 +388,25 @@ __device__ __forceinline__ void vmx_gapfill_fill_body(const uint8_t* __restrict_
             vmx_dp_prob pr; pr.tl = 0; pr.ql = 0; pr.t_off = 0; pr.q_off = 0; pr.tb_off = 0; pr.bnd_off = 0;
             if (pg >= 0) pr = probs[pg];
             x4 = pg >= 0 && pr.tl > 0 && pr.ql > 0 && VMX_DP16X4_OK(pr.tl, pr.ql);
-            if (__any(x4))
-                vmx_gapfill_fill16x4<SCORE>(tcodes + pr.t_off, qcodes + pr.q_off, x4 ? pr.tl : 0, x4 ? pr.ql : 0, match, mismatch, o1, e1, o2, e2, tb_pool + pr.tb_off,
-                                     bnd_pool + pr.bnd_off, &out_score[pg < 0 ? 0 : pg], lane);
+            // SCORE = false (the batched path): first the banded form; out_score[p] then carries the layout flag the traceback kernel reads
+            // (1 = banded stripes); problems whose band is not proven run again in full
+            bool redo = x4;
+            if (!SCORE) {
+                const bool band = x4 && VMX_BAND_STEPS(pr.tl, pr.ql) > 0;
+                if (__any(band)) {
+                    const int sc = vmx_gapfill_fill16x4<false, true>(tcodes + pr.t_off, qcodes + pr.q_off, band ? pr.tl : 0, band ? pr.ql : 0, match, mismatch, o1, e1, o2, e2,
+                                                                     tb_pool + pr.tb_off, bnd_pool + pr.bnd_off, nullptr, lane);
+                    const int rfl = ((pr.tl - 1) & 31) >> 1;
+                    const int scr = __shfl(sc, (lane & 48) | (rfl & 15));      // the row's score lane
+                    const bool ok = band && vmx_band_proven(scr, pr.tl, pr.ql, match, o1, e1, o2, e2);
+                    redo = x4 && !ok;
+                    __syncthreads();                                           // (the full form reuses the problem's boundary rows)
+                }
+                if (x4 && (lane & 15) == 0) out_score[pg] = redo ? 0 : 1;
+            }
+            if (__any(redo))
+                vmx_gapfill_fill16x4<SCORE, false>(tcodes + pr.t_off, qcodes + pr.q_off, redo ? pr.tl : 0, redo ? pr.ql : 0, match, mismatch, o1, e1, o2, e2, tb_pool + pr.tb_off,
+                                                   bnd_pool + pr.bnd_off, &out_score[pg < 0 ? 0 : pg], lane);
         }
         for (int gk = 0; gk < 4; ++gk) {
         const int p = vmx_readlane(pg, 16 * gk);
@@ -370,6 +417,7 @@ __device__ __forceinline__ void vmx_gapfill_fill_body(const uint8_t* __restrict_
         const int tl = vmx_uniform_i32(pr.tl), ql = vmx_uniform_i32(pr.ql);
         const bool trivial = tl == 0 || ql == 0;     // no barrier-skipping `continue`: an empty side just runs zero stripes
         if (trivial && lane == 0) out_score[p] = (tl + ql) ? vmx_gap_open_row(tl + ql, o1, e1, o2, e2) : 0;
+        if (!SCORE && !trivial && lane == 0) out_score[p] = 0;     // layout flag: not banded
         uint8_t* tb = tb_pool + pr.tb_off;
         int32_t* bH = bnd_pool + pr.bnd_off;
         int32_t* bE1 = bH + (ql + 1);
@@ -469,7 +517,8 @@ __global__ void __launch_bounds__(64, 5) k_gapfill_fill_ns(const uint8_t* __rest
 // serial traceback, one THREAD per problem (thousands of independent dependent-load chains hide each other's latency)
 __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
                                 const vmx_dp_prob* __restrict__ probs, int n_prob, int eqx, const uint8_t* __restrict__ tb_pool,
-                                uint32_t* __restrict__ run_pool, char* __restrict__ cig_pool, int32_t* __restrict__ cig_len) {
+                                uint32_t* __restrict__ run_pool, char* __restrict__ cig_pool, int32_t* __restrict__ cig_len,
+                                const int32_t* __restrict__ band_flag) {
     int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (p >= n_prob) return;
     const vmx_dp_prob pr = probs[p];
@@ -481,7 +530,8 @@ __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_
     char* cig = cig_pool + pr.cig_off;
     const bool x4 = tl > 0 && ql > 0 && VMX_DP16X4_OK(tl, ql);   // layout of vmx_gapfill_fill16x4
     const bool pk = !x4 && tl > 0 && ql > 0 && VMX_DP16_OK(tl, ql);     // packed layout of vmx_gapfill_fill16
-    const int W = x4 ? VMX_X4_W(ql) : ql + (pk ? 127 : 63);
+    const bool band = x4 && band_flag != nullptr && band_flag[p] == 1;        // banded stripes (vmx_gapfill_fill16x4<.., true>)
+    const int W = band ? VMX_BAND_STEPS(tl, ql) : (x4 ? VMX_X4_W(ql) : ql + (pk ? 127 : 63));
     int nruns = 0; int cur_op = -1; uint32_t cur_len = 0;
 #define VMX_EMIT(op)                                                                   \
     do {                                                                               \
@@ -491,7 +541,7 @@ __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_
     int i = tl, j = ql, state = 0;
     while (i > 0 && j > 0) {
         int b;
-        if (x4) { const int s = (i - 1) >> 5, r = (i - 1) & 31, t = (j - 1) + r; b = tb[(((size_t)s * (size_t)W + (size_t)t) * 16 + (r >> 1)) * 2 + (r & 1)]; }
+        if (x4) { const int s = (i - 1) >> 5, r = (i - 1) & 31, t = (j - (band ? VMX_BAND_JLO(tl, ql, s) : 1)) + r; b = tb[(((size_t)s * (size_t)W + (size_t)t) * 16 + (r >> 1)) * 2 + (r & 1)]; }
         else if (pk) { const int s = (i - 1) >> 7, r = (i - 1) & 127, t = (j - 1) + r; b = tb[(((size_t)s * (size_t)W + (size_t)t) * 64 + (r >> 1)) * 2 + (r & 1)]; }
         else { const int s = (i - 1) >> 6, l = (i - 1) & 63, t = (j - 1) + l; b = tb[((size_t)s * (size_t)W + (size_t)t) * 64 + l]; }
         if (state == 0) {

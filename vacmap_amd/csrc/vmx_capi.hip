@@ -261,7 +261,7 @@ int vm_k_cigar_batch(vm_ctx* c, const vm_score* sc, int eqx, int64_t n, const ch
                            c->b[6].as<vmx_dp_prob>(), (int)n, sc->match, sc->mismatch, sc->o1, sc->e1, sc->o2, sc->e2, c->b[7].as<uint8_t>(),
                            c->b[8].as<int32_t>(), d_score, (const int32_t*)nullptr, (int32_t*)nullptr);
         hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[4].as<uint8_t>(),
-                           c->b[6].as<vmx_dp_prob>(), (int)n, eqx, c->b[7].as<uint8_t>(), c->b[9].as<uint32_t>(), c->b[10].as<char>(), d_len);
+                           c->b[6].as<vmx_dp_prob>(), (int)n, eqx, c->b[7].as<uint8_t>(), c->b[9].as<uint32_t>(), c->b[10].as<char>(), d_len, (const int32_t*)nullptr);
     }
     std::vector<char> hc((size_t)cig + 16); std::vector<int32_t> hl((size_t)n);
     *scores = host_alloc<int32_t>((size_t)n);
