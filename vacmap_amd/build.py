@@ -7,7 +7,7 @@ import glob, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libvacmapx.so')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math', '-Wno-unused-result']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math', '-Wno-unused-result'] + os.environ.get('VMX_EXTRA_FLAGS', '').split()   # e.g. -DVMX_BAND_W=48 for tuning runs
 
 
 def needs_build():

@@ -95,14 +95,16 @@ struct vmx_lseed_args {
 // banded form of the four-per-wave fill: a stripe of rows only runs the columns within VMX_BAND_W of the matrix's main line
 // (column ~ row * ql / tl); the result is kept only when every path that leaves the band is provably worse (k_dp.hip), else the problem
 // is filled again in full. Width of a banded stripe in steps (0: banding would not save a 16-step block, the problem runs in full):
+#ifndef VMX_BAND_W
 #ifdef VMX_EMU
 #define VMX_BAND_W 6
 #else
-#define VMX_BAND_W 56
+#define VMX_BAND_W 64      // measured fill kernel ms per batch for 40 / 48 / 56 / 64 / 72: 31.6 / 25.9 / 23.4 / 22.7 / 22.6 (narrow bands fail the proof more often)
+#endif
 #endif
 #define VMX_BAND_NC(tl, ql) (2 * VMX_BAND_W + 3 + (32 * (ql) + (tl) - 1) / (tl))          /* columns a banded stripe runs to the end */
 #define VMX_BAND_STEPS(tl, ql) ((((VMX_BAND_NC(tl, ql) + 31) + 15) & ~15) + 16 <= VMX_X4_W(ql) ? ((VMX_BAND_NC(tl, ql) + 31) + 15) & ~15 : 0)
-#define VMX_BAND_JLO(tl, ql, s) ((int)(((long long)((s) * 32 + 1) * (ql)) / (tl)) - VMX_BAND_W < 1 ? 1 : (int)(((long long)((s) * 32 + 1) * (ql)) / (tl)) - VMX_BAND_W)
+#define VMX_BAND_JLO(tl, ql, s) ((int)((unsigned)((s) * 32 + 1) * (unsigned)(ql) / (unsigned)(tl)) - VMX_BAND_W < 1 ? 1 : (int)((unsigned)((s) * 32 + 1) * (unsigned)(ql) / (unsigned)(tl)) - VMX_BAND_W)   /* tl + ql <= 1536: the product fits 32 bits */
 #define VMX_TB_BYTES(tl, ql) (((tl) > 0 && (ql) > 0) ? (VMX_DP16X4_OK(tl, ql) ? (int64_t)(((tl) + 31) / 32) * VMX_X4_W(ql) * 32 : \
                               VMX_DP16_OK(tl, ql) ? (int64_t)(((tl) + 127) / 128) * ((ql) + 127) * 128 : (int64_t)(((tl) + 63) / 64) * ((ql) + 63) * 64) : 0)
 #define VMX_TB_CHUNK ((int64_t)12 << 30)   // gap fill: traceback bytes held at a time; a batch needing more runs fill + trace chunk by chunk (12 GB: lets 4+ batches in flight fit in 288 GB)
