@@ -371,9 +371,14 @@ __device__ __forceinline__ void vmx_gapfill_fill_body(const uint8_t* __restrict_
                                                      const vmx_dp_prob* __restrict__ probs, int n_prob, int match, int mismatch,
                                                      int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb_pool,
                                                      int32_t* __restrict__ bnd_pool, int32_t* __restrict__ out_score,
-                                                     const int32_t* __restrict__ order, int32_t* __restrict__ counter) {
+                                                     const int32_t* __restrict__ order, int32_t* __restrict__ counter,
+                                                     int32_t* __restrict__ redo_list = nullptr, int32_t* __restrict__ redo_cnt = nullptr, int redo_pass = 0) {
+    // redo_list / redo_cnt (batched path): problems whose band is not proven are appended to the list instead of being filled in full on
+    // the spot (that would run a whole wave for one 16-lane row); a second launch (redo_pass = 1) takes them four per wave like any others.
+    // redo_cnt[0] = entries, redo_cnt[1] = the second launch's queue head.
     const int lane = vmx_lane();
     int static_next = 4 * (int)blockIdx.x;
+    if (redo_pass) { n_prob = redo_cnt[0]; order = redo_list; counter = redo_cnt + 1; }
     while (true) {
         // a wave takes four problems at a time: those of the small class run together, one per 16-lane row (vmx_gapfill_fill16x4); the
         // others (the head of the longest-first queue) run one after the other on the whole wave
@@ -390,19 +395,23 @@ __device__ __forceinline__ void vmx_gapfill_fill_body(const uint8_t* __restrict_
             x4 = pg >= 0 && pr.tl > 0 && pr.ql > 0 && VMX_DP16X4_OK(pr.tl, pr.ql);
             // SCORE = false (the batched path): first the banded form; out_score[p] then carries the layout flag the traceback kernel reads
             // (1 = banded stripes); problems whose band is not proven run again in full
-            bool redo = x4;
+            bool redo = x4, banded_ok = false;
             if (!SCORE) {
-                const bool band = x4 && VMX_BAND_STEPS(pr.tl, pr.ql) > 0;
+                const bool band = !redo_pass && x4 && VMX_BAND_STEPS(pr.tl, pr.ql) > 0;
                 if (__any(band)) {
                     const int sc = vmx_gapfill_fill16x4<false, true>(tcodes + pr.t_off, qcodes + pr.q_off, band ? pr.tl : 0, band ? pr.ql : 0, match, mismatch, o1, e1, o2, e2,
                                                                      tb_pool + pr.tb_off, bnd_pool + pr.bnd_off, nullptr, lane);
                     const int rfl = ((pr.tl - 1) & 31) >> 1;
                     const int scr = __shfl(sc, (lane & 48) | (rfl & 15));      // the row's score lane
-                    const bool ok = band && vmx_band_proven(scr, pr.tl, pr.ql, match, o1, e1, o2, e2);
-                    redo = x4 && !ok;
+                    banded_ok = band && vmx_band_proven(scr, pr.tl, pr.ql, match, o1, e1, o2, e2);
+                    redo = x4 && !banded_ok;
                     __syncthreads();                                           // (the full form reuses the problem's boundary rows)
+                    if (redo_list != nullptr) {
+                        if (band && !banded_ok && (lane & 15) == 0) redo_list[atomicAdd(redo_cnt, 1)] = pg;       // later, four per wave
+                        redo = x4 && !band;
+                    }
                 }
-                if (x4 && (lane & 15) == 0) out_score[pg] = redo ? 0 : 1;
+                if (x4 && (lane & 15) == 0) out_score[pg] = banded_ok ? 1 : 0;
             }
             if (__any(redo))
                 vmx_gapfill_fill16x4<SCORE, false>(tcodes + pr.t_off, qcodes + pr.q_off, redo ? pr.tl : 0, redo ? pr.ql : 0, match, mismatch, o1, e1, o2, e2, tb_pool + pr.tb_off,
@@ -510,8 +519,9 @@ __global__ void __launch_bounds__(64, 5) k_gapfill_fill_ns(const uint8_t* __rest
                                                         const vmx_dp_prob* __restrict__ probs, int n_prob, int match, int mismatch,
                                                         int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb_pool,
                                                         int32_t* __restrict__ bnd_pool, int32_t* __restrict__ out_score,
-                                                        const int32_t* __restrict__ order, int32_t* __restrict__ counter) {
-    vmx_gapfill_fill_body<false>(tcodes, qcodes, probs, n_prob, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, order, counter);
+                                                        const int32_t* __restrict__ order, int32_t* __restrict__ counter,
+                                                        int32_t* __restrict__ redo_list, int32_t* __restrict__ redo_cnt, int redo_pass) {
+    vmx_gapfill_fill_body<false>(tcodes, qcodes, probs, n_prob, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, order, counter, redo_list, redo_cnt, redo_pass);
 }
 
 // serial traceback, one THREAD per problem (thousands of independent dependent-load chains hide each other's latency)

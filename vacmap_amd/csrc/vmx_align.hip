@@ -285,8 +285,9 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         st.dp_string_bytes += tq[0] + tq[1];
         c->n_gev[redo_only ? 1 : 0] = 0;
         if (cnt) {
-            VMX_TRY(B.order.reserve(4 * (size_t)(round_cap + 1))); VMX_TRY(B.qrange.reserve(64));
+            VMX_TRY(B.order.reserve(4 * (size_t)(2 * round_cap + 64))); VMX_TRY(B.qrange.reserve(64));
             int32_t* d_range = B.qrange.as<int32_t>(); int32_t* d_cnt = d_range + 4;
+            int32_t* d_redo_list = B.order.as<int32_t>() + round_cap + 32; int32_t* d_redo_cnt = d_range + 12;     // problems whose band was not proven
             std::vector<int32_t> csz; for (size_t q = 0; q + 1 < cuts.size(); ++q) csz.push_back(cuts[q + 1] - cuts[q]);
             VMX_TRY(upload(B.chunkn, csz.data(), csz.size(), c->stream));
             int fill_waves = 16;                                  // waves per CU of the fill kernel (tuning knob: VMX_FILL_WAVES)
@@ -297,9 +298,15 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
                 uint8_t* tb_base = B.tb.as<uint8_t>() - h_tboff[(size_t)p0];
                 hipEvent_t* ke = q < 8 ? c->gev + (redo_only ? 24 : 0) + 3 * q : nullptr;      // HIP events around the dominant kernel, on the stream it runs on
                 hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>() + p0, B.chunkn.as<int32_t>() + q, (int64_t)0, B.order.as<int32_t>(), d_range, d_cnt);
+                (void)hipMemsetAsync(d_redo_cnt, 0, 8, c->stream);
                 if (ke) (void)hipEventRecord(ke[0], c->stream);
                 hipLaunchKernelGGL(k_gapfill_fill_ns, dim3((unsigned)std::min<int64_t>(pn, (int64_t)c->num_cu * fill_waves)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
-                                   B.dptab.as<vmx_dp_prob>() + p0, pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_cnt);
+                                   B.dptab.as<vmx_dp_prob>() + p0, pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_cnt,
+                                   d_redo_list, d_redo_cnt, 0);
+                // second launch: the problems whose band was not proven (a few per cent), in full, four per wave
+                hipLaunchKernelGGL(k_gapfill_fill_ns, dim3((unsigned)std::min<int64_t>((pn + 3) / 4, (int64_t)c->num_cu * 4)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
+                                   B.dptab.as<vmx_dp_prob>() + p0, pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_cnt,
+                                   d_redo_list, d_redo_cnt, 1);
                 if (ke) (void)hipEventRecord(ke[1], c->stream);
                 hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)((pn + 63) / 64)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>() + p0, pn, prm->eqx,
                                    tb_base, B.run.as<uint32_t>(), B.cig.as<char>(), B.ciglen.as<int32_t>() + p0, B.dpscore.as<int32_t>() + p0);

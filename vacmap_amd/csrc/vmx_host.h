@@ -113,7 +113,7 @@ __global__ void k_gapfill_fill(const uint8_t* tcodes, const uint8_t* qcodes, con
                                const int32_t* order, int32_t* counter);
 __global__ void k_gapfill_fill_ns(const uint8_t* tcodes, const uint8_t* qcodes, const vmx_dp_prob* probs, int n_prob, int match,
                                   int mismatch, int o1, int e1, int o2, int e2, uint8_t* tb_pool, int32_t* bnd_pool, int32_t* out_score,
-                                  const int32_t* order, int32_t* counter);
+                                  const int32_t* order, int32_t* counter, int32_t* redo_list, int32_t* redo_cnt, int redo_pass);
 __global__ void k_gapfill_trace(const uint8_t* tcodes, const uint8_t* qcodes, const vmx_dp_prob* probs, int n_prob, int eqx,
                                 const uint8_t* tb_pool, uint32_t* run_pool, char* cig_pool, int32_t* cig_len, const int32_t* band_flag);
 __global__ void k_flip_sort(const int64_t* rows, const int64_t* aoff, const int64_t* readlens, int n_reads, uint64_t* key_pool,

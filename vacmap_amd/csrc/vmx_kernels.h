@@ -99,7 +99,8 @@ struct vmx_lseed_args {
 #ifdef VMX_EMU
 #define VMX_BAND_W 6
 #else
-#define VMX_BAND_W 64      // measured fill kernel ms per batch for 40 / 48 / 56 / 64 / 72: 31.6 / 25.9 / 23.4 / 22.7 / 22.6 (narrow bands fail the proof more often)
+#define VMX_BAND_W 62      // 2 * 62 + 3 + 32 + 31 = 190 -> 192 steps per stripe for tl ~ ql. Fill kernel ms per batch measured for 40 / 48 / 56 / 64 / 72 (failed
+                           // problems then still re-run on the spot): 31.6 / 25.9 / 23.4 / 22.7 / 22.6 — narrow bands fail the proof more often (64: 2.8 % fail)
 #endif
 #endif
 #define VMX_BAND_NC(tl, ql) (2 * VMX_BAND_W + 3 + (32 * (ql) + (tl) - 1) / (tl))          /* columns a banded stripe runs to the end */
