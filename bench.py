@@ -182,9 +182,9 @@ def main():
         # in profiles/ (bench.py cannot collect counters on itself); null when the summary is absent
         traffic, traffic_src, valu_util = None, None, None
         try:
-            pj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_k_pmc_hbm_traffic.json')))
+            pj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_l_pmc_hbm_traffic.json')))
             traffic = (pj['kernels'].get('k_gapfill_fill_ns') or pj['kernels']['k_gapfill_fill'])['hbm_bytes_per_step']        # per step, like achieved (a step = a few chunk launches)
-            traffic_src = 'profiles/r01_k_pmc_hbm_traffic.json'
+            traffic_src = 'profiles/r01_l_pmc_hbm_traffic.json'
             valu_util = (pj['kernels'].get('k_gapfill_fill_ns') or pj['kernels']['k_gapfill_fill']).get('valu_utilisation')
         except Exception:
             pass
@@ -194,8 +194,8 @@ def main():
                     'traffic': traffic, 'traffic_source': traffic_src, 'valu_utilisation_pmc': valu_util, 'avg_kernel_ms_per_step': fill_ms, 'algorithmic_bytes_per_step': algo_bytes / K,
                     'kernel_bytes_per_step': kbytes, 'kernel_GBps': kbytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0,
                     'dp_cells_per_s': (agg['dp_cells'] / K) / (fill_ms * 1e-3) if fill_ms > 0 else 0.0,
-                    'note': 'achieved uses the path-level algorithmic bytes of SURVEY 8(d); the kernel is an integer DP bound by VALU issue (packed int16: ~75-85 VALU ops per '
-                            '128-cell step, 98 % VALU utilisation by SQ_INSTS_VALU / GRBM_GUI_ACTIVE), its own stream is one traceback byte per cell incl. stripe padding (kernel_bytes_per_step); see DESIGN.md'}
+                    'note': 'achieved uses the path-level algorithmic bytes of SURVEY 8(d); the kernel is an integer DP bound by VALU issue (packed int16, ~75 VALU ops per '
+                            '128-cell step, banded stripes with an optimality proof; 96-98 % VALU utilisation while the main launch runs), its own stream is one traceback byte per cell incl. stripe padding (kernel_bytes_per_step); see DESIGN.md'}
         cpu = None
         if args.cpu_sample > 0 and world == 1:
             import oracle_lib as O
