@@ -239,7 +239,48 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             VMX_T(0);
             // the reference position of window index t is implied by the interval list (LDS): no position array in HBM
             auto tpos_of = [&](int t) -> long long { int v = 0; while (v + 1 < niv && t >= s_ivbase[v + 1]) ++v; return s_iv[v][0] + (long long)(t - s_ivbase[v]); };
+            // --- read window :23183-23191
+            int readstart = 0, readend = 0;
+            if (mm > 0) {
+                readstart = GQ[0] - A.read_span; if (readstart < 0) readstart = 0;
+                readend = GQ[mm - 1] + A.read_span; if (readend > L - k + 1) readend = L - k + 1;
+            }
+            int npos = (status == 0 && readend > readstart) ? readend - readstart : 0;
+            if (npos > A.pcnt_cap) { status = VM_READ_CAPACITY_DEV; npos = 0; }
             // --- table: one atomic exchange per window position links it in front of its 9-mer's list
+            if (use_bm) {
+                // only the window positions whose 9-mer the read can ask for are linked (about one in nine: the read window holds ~30 k of the
+                // 4^9 k-mers): the bitmap first holds the READ's k-mers (forward and reverse complement), a coalesced sweep marks the matching
+                // window positions in NEXT, then the bitmap is rebuilt as the table's occupancy map while the marked positions are linked.
+                // Nine in ten of the random atomic exchanges on the 1 MB head table in HBM disappear; a list a look-up can reach is complete.
+                for (int pi = (int)threadIdx.x; pi < npos; pi += (int)blockDim.x) {
+                    bool ok; const uint32_t fw = vmx_kmer_at(RD, readstart + pi, k, ok);
+                    const uint32_t rv = vmx_kmer_rc(fw, k);
+                    if (ok && fw != rv) { atomicOr(&BM[fw >> 5], 1u << (fw & 31)); atomicOr(&BM[rv >> 5], 1u << (rv & 31)); }
+                }
+                __syncthreads();
+                for (int v = 0; v < niv; ++v) {
+                    const long long lo = s_iv[v][0], hi = s_iv[v][1]; const int base = s_ivbase[v];
+                    for (long long x = lo + threadIdx.x; x < hi; x += blockDim.x) {
+                        bool ok; const uint32_t km = vmx_kmer_at(A.ref, x, k, ok);
+                        NEXT[base + (int)(x - lo)] = (ok && ((BM[km >> 5] >> (km & 31)) & 1u)) ? -2 : -3;
+                    }
+                }
+                __syncthreads();
+                for (int i = (int)threadIdx.x; i < (1 << (2 * k)) / 32; i += (int)blockDim.x) BM[i] = 0u;
+                __syncthreads();
+                for (int v = 0; v < niv; ++v) {
+                    const long long lo = s_iv[v][0], hi = s_iv[v][1]; const int base = s_ivbase[v];
+                    for (long long x = lo + threadIdx.x; x < hi; x += blockDim.x) {
+                        const int idx = base + (int)(x - lo);
+                        if (NEXT[idx] != -2) continue;
+                        bool ok; const uint32_t km = vmx_kmer_at(A.ref, x, k, ok);
+                        const int old = VMX_HEAD_IDX(atomicExch(&HEAD[km], (int)((ep << 23) | (unsigned)idx)));
+                        atomicOr(&BM[km >> 5], 1u << (km & 31));
+                        NEXT[idx] = old;
+                    }
+                }
+            } else
             for (int v = 0; v < niv; ++v) {
                 const long long lo = s_iv[v][0], hi = s_iv[v][1]; const int base = s_ivbase[v];
                 for (long long x = lo + threadIdx.x; x < hi; x += 2 * blockDim.x) {          // two positions per round: both exchanges in flight together
@@ -250,21 +291,12 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                     int old = -1, old2 = -1;
                     if (ok) old = VMX_HEAD_IDX(atomicExch(&HEAD[km], (int)((ep << 23) | (unsigned)idx)));
                     if (ok2) old2 = VMX_HEAD_IDX(atomicExch(&HEAD[km2], (int)((ep << 23) | (unsigned)idx2)));
-                    if (use_bm) { if (ok) atomicOr(&BM[km >> 5], 1u << (km & 31)); if (ok2) atomicOr(&BM[km2 >> 5], 1u << (km2 & 31)); }
                     if (ok) NEXT[idx] = old;
                     if (ok2) NEXT[idx2] = old2;
                 }
             }
             __syncthreads();
             VMX_T(1);
-            // --- read window :23183-23191
-            int readstart = 0, readend = 0;
-            if (mm > 0) {
-                readstart = GQ[0] - A.read_span; if (readstart < 0) readstart = 0;
-                readend = GQ[mm - 1] + A.read_span; if (readend > L - k + 1) readend = L - k + 1;
-            }
-            int npos = (status == 0 && readend > readstart) ? readend - readstart : 0;
-            if (npos > A.pcnt_cap) { status = VM_READ_CAPACITY_DEV; npos = 0; }
             // pass A: accepted hits per read position and strand (any order), no barrier inside the loop so that the waves overlap their
             // table walks. The first accepted hit of either strand is parked in STG: a position with at most one hit per strand (nearly all)
             // needs no second walk in pass B.
