@@ -317,13 +317,14 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 int cf = 0, cr = 0; long long ff = 0, fr = 0;
                 bool ok; const uint32_t fw = vmx_kmer_at(RD, iloc, k, ok);
                 const uint32_t rv = vmx_kmer_rc(fw, k);
-                if (ok && fw != rv) {
+                const bool pf = ok && fw != rv && (!use_bm || ((BM[fw >> 5] >> (fw & 31)) & 1u));
+                const bool pr = ok && fw != rv && iloc > 0 && (!use_bm || ((BM[rv >> 5] >> (rv & 31)) & 1u));
+                if (pf || pr) {                                  // (the guide bisection only for the one position in five that can hit at all)
+                    const int hf = pf ? VMX_HEAD_IDX(HEAD[fw]) : -1, hr = pr ? VMX_HEAD_IDX(HEAD[rv]) : -1;   // both list heads in flight together
                     int b0, b1, c0, c1; vmx_find_closest(GQ, mm, iloc, b0, b1, c0, c1);
                     long long interval = (long long)b0 + b1 + 500; if (interval > 2000) interval = 2000;
                     const long long ref1 = GR[c0], ref2 = GR[c1];
                     long long rgap = (long long)iloc - GQ[c0]; if (rgap < 0) rgap = -rgap;
-                    const bool pf = !use_bm || ((BM[fw >> 5] >> (fw & 31)) & 1u), pr = iloc > 0 && (!use_bm || ((BM[rv >> 5] >> (rv & 31)) & 1u));
-                    const int hf = pf ? VMX_HEAD_IDX(HEAD[fw]) : -1, hr = pr ? VMX_HEAD_IDX(HEAD[rv]) : -1;   // both list heads in flight together
                     for (int t = hf; t >= 0; t = NEXT[t]) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cf == 0) ff = rl; ++cf; } }
                     for (int t = hr; t >= 0; t = NEXT[t]) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cr == 0) fr = rl; ++cr; } }
                 }
