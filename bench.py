@@ -182,9 +182,9 @@ def main():
         # in profiles/ (bench.py cannot collect counters on itself); null when the summary is absent
         traffic, traffic_src, valu_util = None, None, None
         try:
-            pj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_l_pmc_hbm_traffic.json')))
+            pj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_m_pmc_hbm_traffic.json')))
             traffic = (pj['kernels'].get('k_gapfill_fill_ns') or pj['kernels']['k_gapfill_fill'])['hbm_bytes_per_step']        # per step, like achieved (a step = a few chunk launches)
-            traffic_src = 'profiles/r01_l_pmc_hbm_traffic.json'
+            traffic_src = 'profiles/r01_m_pmc_hbm_traffic.json'
             valu_util = (pj['kernels'].get('k_gapfill_fill_ns') or pj['kernels']['k_gapfill_fill']).get('valu_utilisation')
         except Exception:
             pass

@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 }
                 PCNT[pi] = cf + cr;
                 PC2[pi] = (cf > 0xffff ? 0xffff : cf) | ((cr > 0x7fff ? 0x7fff : cr) << 16);
-                STG[2 * pi] = ff; STG[2 * pi + 1] = fr;
+                if (cf + cr) { STG[2 * pi] = ff; STG[2 * pi + 1] = fr; }      // (read back only where there are hits)
             }
             };
             if (g_lds) pass_a(s_gq, s_gr); else pass_a(GQg, (const long long*)GRg);
