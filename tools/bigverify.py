@@ -24,3 +24,26 @@ for mode, k, n, kw in (('H', 15, 3000, dict(mean_len=15000, err=0.10)), ('L', 19
         bad = sum(1 for i in range(n) if a.get(i) != b.get(i))
     print('mode', mode, 'reads', n, 'records', len(orecs), 'status equal', same_st, 'reads with different records', bad, 'gpu %.2fs cpu %.2fs' % (tg, tc), 'failed', int(sum(1 for s in status if s != 0)), flush=True)
     del gi, oi
+
+# reads from a donor with an insertion or deletion of 30-600 bp every ~2.5 kb: gap-fill problems far from square (the banded fill's proof
+# has to reject them or keep them for the right reason)
+rng = np.random.default_rng(5)
+ref = synth.make_reference([6_000_000], seed=3)
+ops = []
+for p_ in range(20_000, 5_900_000, 2500):
+    n_ = int(rng.integers(30, 600))
+    ops.append(('DEL', p_, n_) if rng.random() < 0.5 else ('INS', p_, n_, int(rng.integers(1 << 30))))
+donor = synth.implant_svs(ref[0], ops)
+for mode, n, kw in (('H', 1500, dict(mean_len=12000, err=0.08)), ('R', 800, dict(mean_len=9000, err=0.08))):
+    cat, off, _ = synth.sample_reads_concat([donor], n, seed=99, **kw)
+    seqs = [cat[off[i]:off[i + 1]].tobytes().decode() for i in range(n)]
+    gi = Index.from_seqs(ctx, names, [ref[0].tobytes()], k=15, w=10)
+    oi = O.Index.from_seqs(names, [ref[0].tobytes()], k=15, w=10)
+    status, recs, stats = align_batch(ctx, gi, lib.params(mode), seqs)
+    ost, orecs = O.align_batch(oi, seqs, O.params(mode), nthreads=min(os.cpu_count(), 128))
+    a = {}; b = {}
+    for t_ in recs: a.setdefault(t_[0], []).append(t_[1:])
+    for t_ in orecs: b.setdefault(t_[0], []).append(t_[1:])
+    bad = sum(1 for i in range(n) if a.get(i) != b.get(i))
+    print('indel donor, mode', mode, 'reads', n, 'records', len(orecs), 'status equal', [(int(x) == 0) for x in status] == [(int(x) == 0) for x in ost], 'reads with different records', bad, flush=True)
+    del gi, oi
