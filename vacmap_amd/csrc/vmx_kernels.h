@@ -88,7 +88,7 @@ struct vmx_lseed_args {
 #ifdef VMX_EMU
 #define VMX_DP16X4_MAX 160
 #else
-#define VMX_DP16X4_MAX 1536
+#define VMX_DP16X4_MAX 3072
 #endif
 #define VMX_DP16X4_OK(tl, ql) ((tl) + (ql) <= VMX_DP16X4_MAX)
 #define VMX_X4_W(ql) ((((ql) + 31) + 15) & ~15)
@@ -105,7 +105,7 @@ struct vmx_lseed_args {
 #endif
 #define VMX_BAND_NC(tl, ql) (2 * VMX_BAND_W + 3 + (32 * (ql) + (tl) - 1) / (tl))          /* columns a banded stripe runs to the end */
 #define VMX_BAND_STEPS(tl, ql) ((((VMX_BAND_NC(tl, ql) + 31) + 15) & ~15) + 16 <= VMX_X4_W(ql) ? ((VMX_BAND_NC(tl, ql) + 31) + 15) & ~15 : 0)
-#define VMX_BAND_JLO(tl, ql, s) ((int)((unsigned)((s) * 32 + 1) * (unsigned)(ql) / (unsigned)(tl)) - VMX_BAND_W < 1 ? 1 : (int)((unsigned)((s) * 32 + 1) * (unsigned)(ql) / (unsigned)(tl)) - VMX_BAND_W)   /* tl + ql <= 1536: the product fits 32 bits */
+#define VMX_BAND_JLO(tl, ql, s) ((int)((unsigned)((s) * 32 + 1) * (unsigned)(ql) / (unsigned)(tl)) - VMX_BAND_W < 1 ? 1 : (int)((unsigned)((s) * 32 + 1) * (unsigned)(ql) / (unsigned)(tl)) - VMX_BAND_W)   /* tl + ql <= 3072: the product fits 32 bits */
 #define VMX_TB_BYTES(tl, ql) (((tl) > 0 && (ql) > 0) ? (VMX_DP16X4_OK(tl, ql) ? (int64_t)(((tl) + 31) / 32) * VMX_X4_W(ql) * 32 : \
                               VMX_DP16_OK(tl, ql) ? (int64_t)(((tl) + 127) / 128) * ((ql) + 127) * 128 : (int64_t)(((tl) + 63) / 64) * ((ql) + 63) * 64) : 0)
 #define VMX_TB_CHUNK ((int64_t)12 << 30)   // gap fill: traceback bytes held at a time; a batch needing more runs fill + trace chunk by chunk (12 GB: lets 4+ batches in flight fit in 288 GB)
