@@ -37,7 +37,7 @@ def test_extend(ctx, oracle):
 def test_gapfill(ctx, oracle):
     KC.check_gapfill(ctx, oracle, n=200, maxlen=500, seed=16)
     KC.check_gapfill(ctx, oracle, n=6, maxlen=3000, seed=17)
-    KC.check_gapfill(ctx, oracle, n=37, maxlen=900, seed=19, minlen=600)       # around tl + ql = 1536: four-per-wave and one-per-wave problems in the same waves, idle rows
+    KC.check_gapfill(ctx, oracle, n=37, maxlen=1800, seed=19, minlen=1300)     # around tl + ql = 3072: four-per-wave and one-per-wave problems in the same waves, idle rows
     KC.check_gapfill(ctx, oracle, n=3, maxlen=3600, seed=18, minlen=3300)      # tl + ql > 6000: int32 layout
 
 
