@@ -464,16 +464,15 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 int mybase = 0;
                 for (int pass = 0; pass < 2; ++pass) {
                     const long long HH = status ? 0 : H;
-                    const long long seg = (HH + blockDim.x - 1) / blockDim.x;
-                    const long long lo = (long long)threadIdx.x * seg < HH ? (long long)threadIdx.x * seg : HH;
-                    const long long hi = lo + seg < HH ? lo + seg : HH;
                     int wr = 0;
-                    long long j = lo;
-                    while (j < hi) {
+                    // hits are dealt to the threads round-robin (neighbouring lanes test neighbouring hits: coalesced loads); a thread walks the runs
+                    // that START at its hits. The order in which anchors are emitted is free: the emission keys restore the reference's order.
+                    for (long long j0 = threadIdx.x; j0 < HH; j0 += blockDim.x) {
+                        long long j = j0;
                         const uint64_t kj = HKEY[j]; const uint64_t pk = kj >> 26;
                         const int qj = SQ[j];
                         const bool starts = (j == 0) || (HKEY[j - 1] >> 26) != pk || (qj - SQ[j - 1] > k);
-                        if (!starts) { ++j; continue; }
+                        if (!starts) continue;
                         const long long i = j;
                         const long long hv0 = SV[j];
                         long long cq = qj, cr = hv0 >> 1, cl = k; int cs = (hv0 & 1) ? 1 : -1;
