@@ -72,15 +72,24 @@ int vm_device_count(void);
 int vm_index_build_fasta(vm_ctx*, const char* fasta_path, int k, int w, vm_index** out);
 int vm_index_build_mem(vm_ctx*, int nseq, const char* const* names, const char* const* seqs, const int64_t* lens,
                        int k, int w, vm_index** out);
-/* own on-disk format `<ref>.w<w>_k<k>.vmx` (the reference's naming rule `<ref>.w<w>_k<k>.mmi`, vacmap:326) */
+/* own on-disk format `<ref>.w<w>_k<k>.vmx` (the reference's naming rule `<ref>.w<w>_k<k>.mmi`, vacmap:326): contig table, bases and the
+ * sorted position column; the loader recomputes the hashes on the GPU and rejects a file whose header, sizes, positions or order are
+ * inconsistent (VM_ERR_IO) before anything is used */
 int vm_index_save(const vm_index*, const char* path);
 int vm_index_load(vm_ctx*, const char* path, vm_index** out);
+/* minimap2 index files (`minimap2 -d`, on-disk format v3), the files the reference builds and reuses as `<ref>.w<w>_k<k>.mmi`
+ * (src/vacmap/vacmap:324-344, index.py:26). load: the file's minimizer set and 4-bit sequence become the HBM-resident index; every
+ * stored hash is re-derived from the sequence on the GPU and a mismatch rejects the file (VM_ERR_IO). Homopolymer-compressed,
+ * sequence-less and multi-part files are VM_ERR_UNSUPPORTED. save: writes the index in that format (bucket_bits < 0: minimap2's 14). */
+int vm_index_load_mmi(vm_ctx*, const char* path, vm_index** out);
+int vm_index_save_mmi(const vm_index*, const char* path, int bucket_bits);
 void vm_index_free(vm_index*);
 int vm_index_k(const vm_index*);                            /* Aligner.k      (:24024) */
 int vm_index_w(const vm_index*);
 int vm_index_nseq(const vm_index*);
 int vm_index_mid_occ(const vm_index*);
 int64_t vm_index_n_minimizers(const vm_index*);
+int64_t vm_index_n_distinct(const vm_index*);               /* distinct minimizer hashes (= occupied table slots) */
 /* Aligner.seq_offset (vacmap:358-361): name, length, global offset of contig i */
 int vm_index_seq_info(const vm_index*, int i, const char** name, int64_t* len, int64_t* offset);
 /* Aligner.seq(name)  (vacmap:363): copies upper-case bases [start,end) of contig i; returns the count */

@@ -12,7 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace vmo {
@@ -117,26 +119,82 @@ static thread_local std::string g_err;
 extern "C" const char* vmo_last_error(void) { return g_err.c_str(); }
 namespace vmo { void set_error(const std::string& s) { g_err = s; } }
 
+// threads the oracle may use for its one-off index build: the machine's cores, cut to the container's CPU quota (cgroup v2)
+static unsigned build_threads() {
+    unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64]; long long per = 0;
+        if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) { long long c = (atoll(q) + per - 1) / per; if (c >= 1 && (unsigned)c < nt) nt = (unsigned)c; }
+        fclose(f);
+    }
+    if (const char* e = getenv("VMO_THREADS")) { int v = atoi(e); if (v >= 1) nt = (unsigned)v; }
+    return nt > 64 ? 64 : nt;
+}
+template <class F> static void parallel_jobs(size_t njobs, unsigned nt, F fn) {
+    if (nt > njobs) nt = (unsigned)(njobs ? njobs : 1);
+    std::atomic<size_t> next(0);
+    auto work = [&]() { while (true) { size_t j = next.fetch_add(1); if (j >= njobs) break; fn(j); } };
+    if (nt <= 1) { work(); return; }
+    std::vector<std::thread> th; for (unsigned t = 0; t < nt; ++t) th.emplace_back(work); for (auto& t : th) t.join();
+}
+
+// Index = every contig's minimizers (sketch() per contig, windows never cross contigs) as (hash, gpos<<1|strand) pairs in ascending
+// order. Large references are sketched in chunks of k-mer starts by several threads: a chunk [st, en) is sketched together with
+// w - 1 starts of context on each side, which shows sketch() every window of the contig that contains one of the chunk's starts, so
+// the union over chunks equals sketch() of the whole contig; the pairs are then sorted by buckets of their leading hash bits.
 static void index_finish(vmo_index* mi) {
     const int k = mi->k, w = mi->w;
-    std::vector<std::pair<uint64_t, uint64_t>> all;
-    std::vector<Mz> mz;
+    typedef std::pair<uint64_t, uint64_t> HP;
+    struct Job { size_t contig; int64_t st, en; };
+    std::vector<Job> jobs;
     int64_t off = 0;
     mi->offsets.clear();
+    const int64_t CH = 4 << 20;
     for (size_t c = 0; c < mi->seqs.size(); ++c) {
         mi->offsets.push_back(off);
-        sketch(mi->seqs[c].data(), (int64_t)mi->seqs[c].size(), k, w, mz);
-        for (const Mz& m : mz) all.emplace_back(m.h, ((uint64_t)(off + m.pos) << 1) | (uint64_t)m.strand);
+        const int64_t P = (int64_t)mi->seqs[c].size() - k + 1;
+        for (int64_t s = 0; s < P; s += CH) jobs.push_back(Job{c, s, std::min<int64_t>(s + CH, P)});
         off += (int64_t)mi->seqs[c].size();
     }
-    std::sort(all.begin(), all.end());
+    const unsigned nt = build_threads();
+    const int NB = 256, hb = 2 * k >= 8 ? 2 * k - 8 : 0;           // bucket = leading 8 bits of the 2k-bit hash
+    std::vector<std::vector<HP>> parts(jobs.size());
+    std::vector<std::vector<size_t>> hist(jobs.size(), std::vector<size_t>(NB, 0));
+    parallel_jobs(jobs.size(), nt, [&](size_t j) {
+        const Job& jb = jobs[j];
+        const std::string& sq = mi->seqs[jb.contig];
+        const int64_t P = (int64_t)sq.size() - k + 1, goff = mi->offsets[jb.contig];
+        const int64_t lo = std::max<int64_t>(jb.st - (w - 1), 0), hi = std::min<int64_t>(jb.en + (w - 1), P);
+        std::vector<Mz> mz;
+        sketch(sq.data() + lo, (hi - lo) + k - 1, k, w, mz);
+        for (const Mz& m : mz) {
+            const int64_t p = lo + m.pos;
+            if (p < jb.st || p >= jb.en) continue;
+            parts[j].emplace_back(m.h, ((uint64_t)(goff + p) << 1) | (uint64_t)m.strand);
+            hist[j][(m.h >> hb) & (NB - 1)]++;
+        }
+    });
+    size_t total = 0; std::vector<size_t> bstart(NB + 1, 0);
+    for (int b = 0; b < NB; ++b) { bstart[b] = total; for (size_t j = 0; j < jobs.size(); ++j) { const size_t c = hist[j][b]; hist[j][b] = total; total += c; } }
+    bstart[NB] = total;
+    std::vector<HP> all(total);
+    parallel_jobs(jobs.size(), nt, [&](size_t j) {
+        for (const HP& e : parts[j]) all[hist[j][(e.first >> hb) & (NB - 1)]++] = e;
+        std::vector<HP>().swap(parts[j]);
+    });
+    parallel_jobs((size_t)NB, nt, [&](size_t b) { std::sort(all.begin() + bstart[b], all.begin() + bstart[b + 1]); });
     mi->hashes.resize(all.size());
     mi->positions.resize(all.size());
-    for (size_t i = 0; i < all.size(); ++i) { mi->hashes[i] = all[i].first; mi->positions[i] = all[i].second; }
+    parallel_jobs((all.size() + (1 << 22) - 1) >> 22, nt, [&](size_t c) {
+        const size_t e = std::min(all.size(), (c + 1) << 22);
+        for (size_t i = c << 22; i < e; ++i) { mi->hashes[i] = all[i].first; mi->positions[i] = all[i].second; }
+    });
+    std::vector<HP>().swap(all);
     mi->dkeys.clear(); mi->dstart.clear();
-    for (size_t i = 0; i < all.size(); ++i)
-        if (i == 0 || all[i].first != all[i - 1].first) { mi->dkeys.push_back(all[i].first); mi->dstart.push_back(i); }
-    mi->dstart.push_back(all.size());
+    const std::vector<uint64_t>& H = mi->hashes;
+    for (size_t i = 0; i < H.size(); ++i)
+        if (i == 0 || H[i] != H[i - 1]) { mi->dkeys.push_back(H[i]); mi->dstart.push_back(i); }
+    mi->dstart.push_back(H.size());
     // default occurrence cap: max(10, (count at the (1 - 2e-4) quantile of distinct minimizers) + 1)
     size_t nd = mi->dkeys.size();
     int occ = 10;

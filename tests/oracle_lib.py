@@ -118,9 +118,14 @@ class Index:
     def from_seqs(cls, names, seqs, k=15, w=10):
         n = len(names)
         na = (C.c_char_p * n)(*[_b(x) for x in names])
-        bs = [_b(x) for x in seqs]
-        sa = (C.c_char_p * n)(*bs)
-        la = (C.c_int64 * n)(*[len(x) for x in bs])
+        keep, ptrs, lens = [], [], []
+        for x in seqs:                      # uint8 NumPy arrays are handed over in place (hg38-size references)
+            if isinstance(x, np.ndarray):
+                a = np.ascontiguousarray(x, dtype=np.uint8); keep.append(a); ptrs.append(a.ctypes.data); lens.append(a.size)
+            else:
+                b = _b(x); keep.append(b); ptrs.append(C.cast(C.c_char_p(b), C.c_void_p).value); lens.append(len(b))
+        sa = C.cast((C.c_void_p * n)(*ptrs), C.POINTER(C.c_char_p))
+        la = (C.c_int64 * n)(*lens)
         return cls(lib().vmo_index_build_mem(n, na, sa, la, k, w))
 
     def seq(self, i, st=0, en=None):
@@ -129,6 +134,17 @@ class Index:
         buf = C.create_string_buffer(max(en - st, 1))
         n = lib().vmo_index_seq(self.h, i, st, en, buf)
         return buf.raw[:n].decode()
+
+    def n_minimizers(self):
+        return lib().vmo_index_n_minimizers(self.h)
+
+    def n_distinct(self):
+        return lib().vmo_index_n_distinct(self.h)
+
+    def positions_view(self):
+        """the position column without a copy (hg38-size comparisons)"""
+        n = lib().vmo_index_n_minimizers(self.h)
+        return np.ctypeslib.as_array(lib().vmo_index_positions(self.h), shape=(max(n, 1),))[:n]
 
     def minimizers(self):
         n = lib().vmo_index_n_minimizers(self.h)

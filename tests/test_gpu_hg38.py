@@ -1,0 +1,93 @@
+"""GPU parity at the metric's DEFINING SIZE (BASELINE configs[2]/[3], SURVEY §8(d) config 3/4 reference): the hg38-size synthetic
+reference (24 contigs with hg38's proportions, 3.1 Gb, seed 3) is indexed on the MI355X and by the oracle; the index columns, the
+`.map()` anchors and the full records of a stratified read sample must be identical — mode H k=15 (ONT shape) and mode L k=19
+(HiFi shape, config 3), including reads from the last contigs whose global offsets exceed 2^31 and reads at contig ends.
+Reference call sites: /root/reference/src/vacmap/vacmap:344-367 (index + contig table), mammap_clrnano.py:23985 (map)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from vacmap_amd.lib import Context
+    return Context(0)
+
+
+@pytest.fixture(scope='module')
+def hg38_ref():
+    from vacmap_amd import synth
+    return list(synth.HG38_NAMES), synth.make_reference_fast(synth.hg38_like_lengths(), seed=3)
+
+
+def stratified_reads(contigs, shape, seed):
+    """(reads, where): reads from the first / middle / last contigs, at contig starts and ends, both strands, plus one chimera that
+    joins the first and the last contig and one read with an inversion"""
+    from vacmap_amd import synth
+    rng = np.random.default_rng(seed)
+    err, mean, sd = (0.10, 15000, 0) if shape == 'ont' else (0.005, 18000, 2000)
+    spec = []
+    nc = len(contigs)
+    for c in (0, 1, nc // 2, nc - 3, nc - 2, nc - 1):            # chrX / chrY live above 2^31 on the global axis
+        L = len(contigs[c])
+        for st in (0, L // 3, L - 1):
+            ln = int(np.clip(rng.gamma(2.0, mean / 2.0), 3000, 40000)) if shape == 'ont' else int(max(rng.normal(mean, sd), 5000))
+            st = min(max(st, 0), L - ln)
+            spec.append((c, st, ln, int(rng.integers(0, 2))))
+    reads, where = [], []
+    for c, st, ln, strand in spec:
+        frag = contigs[c][st:st + ln]
+        if strand:
+            frag = synth.revcomp(frag)
+        reads.append(synth.mutate(frag, err, rng).tobytes()); where.append((c, st, ln, strand))
+    a = contigs[0][5_000_000:5_007_000]; b = contigs[nc - 1][1_000_000:1_008_000]
+    reads.append(synth.mutate(np.concatenate([a, synth.revcomp(b)]), err, rng).tobytes()); where.append(('chimera', 0, 15000, 0))
+    d = contigs[nc - 2][40_000_000:40_016_000].copy()
+    d[6000:9000] = synth.revcomp(d[6000:9000])
+    reads.append(synth.mutate(d, err, rng).tobytes()); where.append(('inv', 0, 16000, 0))
+    return reads, where
+
+
+@pytest.mark.parametrize('mode,k,shape', [('H', 15, 'ont'), ('L', 19, 'hifi')])
+def test_hg38_size_index_map_and_records(ctx, oracle, hg38_ref, mode, k, shape):
+    from vacmap_amd.lib import Index, align_batch
+    names, contigs = hg38_ref
+    gi = Index.from_seqs(ctx, names, contigs, k=k, w=10)
+    oi = oracle.Index.from_seqs(names, contigs, k=k, w=10)
+    assert gi.offsets == oi.offsets and gi.offsets[-1] > 2 ** 31 and sum(gi.lens) == 3_100_000_000
+    assert gi.n_minimizers() == oi.n_minimizers() > 500_000_000
+    assert gi.n_distinct() == oi.n_distinct() and gi.mid_occ == oi.mid_occ
+    gh, gp = gi.minimizers()                       # read back from the device: hashes recovered from the table, positions as stored
+    assert np.array_equal(gp, oi.positions_view())
+    oh = np.ctypeslib.as_array(oracle.lib().vmo_index_hashes(oi.h), shape=(len(gh),))
+    assert np.array_equal(gh, oh)
+    del gh, gp, oh
+    reads, where = stratified_reads(contigs, shape, seed=100 + k)
+    anchors = ctx.map_batch(gi, reads, check_num=100, mid_occ=-1)
+    n_hi = 0
+    for i, rd in enumerate(reads):
+        oa = oi.map(rd, 100, -1)
+        assert np.array_equal(anchors[i], oa), 'anchors of read %d %r differ' % (i, where[i])
+        n_hi += int((oa[:, 1] > 2 ** 31).sum()) if len(oa) else 0
+    assert n_hi > 1000                              # anchors beyond 2^31 were exercised
+    prm = ctx.lib.params(mode); op = oracle.params(mode)
+    status, recs, stats = align_batch(ctx, gi, prm, reads)
+    nrec = 0
+    for i, rd in enumerate(reads):
+        ost, orecs = oracle.align_read(oi, rd, op)
+        mine = [t[1:] for t in recs if t[0] == i]
+        assert (status[i] == 0) == (ost == 0) and mine == [t[1:] for t in orecs], 'records of read %d %r differ' % (i, where[i])
+        nrec += len(mine)
+    assert nrec >= len(reads) and stats['n_failed'] == 0
+    # a replica allocated from the metadata and filled from the builder's HBM pieces maps identically (the broadcast's receive side)
+    from vacmap_amd.dist import index_blobs
+    rep = Index.from_meta(ctx, gi.meta())
+    for dst, src in zip(index_blobs(rep, 'cuda:0'), index_blobs(gi, 'cuda:0')):
+        dst.copy_(src)
+    import torch
+    torch.cuda.synchronize()
+    ra = ctx.map_batch(rep, reads[:6], check_num=100, mid_occ=-1)
+    assert all(np.array_equal(x, y) for x, y in zip(ra, anchors[:6]))
+    assert rep.seq(len(names) - 1, 1000, 1060) == contigs[-1][1000:1060].tobytes().decode()
+    rep.close(); gi.close()

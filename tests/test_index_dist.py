@@ -1,0 +1,196 @@
+"""CPU tests (no GPU) of the index build / save / load / replication code and of the N > 1 path. The PRODUCT's own sources run here
+compiled against the test-only fiber emulator (tests/emu); multi-process cases use torch.distributed with the gloo backend, world 2."""
+import json, os, subprocess, sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    import emu_lib
+    return emu_lib.context()
+
+
+def _ref(seed=5, lens=(30000, 12000, 40)):
+    from vacmap_amd import synth
+    c = synth.make_reference(list(lens), seed=seed)
+    c[1][3000:3040] = ord('N')                      # an ambiguous stretch: no minimizer may touch it
+    return ['c%d' % i for i in range(len(lens))], c
+
+
+def test_index_build_matches_oracle_multi_contig(ctx, oracle):
+    """device build (sketch tiles -> radix sort -> run-length -> table) vs the oracle's index: both columns, cap, contig table"""
+    from vacmap_amd.lib import Index
+    names, c = _ref()
+    for k, w in ((15, 10), (19, 10), (9, 4), (5, 20)):
+        gi = Index.from_seqs(ctx, names, c, k=k, w=w)
+        oi = oracle.Index.from_seqs(names, c, k=k, w=w)
+        gh, gp = gi.minimizers(); oh, op = oi.minimizers()
+        assert np.array_equal(gh, oh) and np.array_equal(gp, op), (k, w)
+        assert gi.mid_occ == oi.mid_occ and gi.n_distinct() == oi.n_distinct() and gi.offsets == oi.offsets
+        assert gi.seq(1, 2990, 3050) == oi.seq(1, 2990, 3050)
+        gi.close()
+
+
+def test_index_save_load_roundtrip_and_rejects_corruption(ctx, oracle, tmp_path):
+    from vacmap_amd.lib import Index, VmxError
+    from vacmap_amd import synth
+    names, c = _ref(seed=6)
+    gi = Index.from_seqs(ctx, names, c, k=15, w=10)
+    p = str(tmp_path / 'ref.fa.w10_k15.vmx')
+    gi.save(p)
+    li = Index.load(ctx, p)
+    assert np.array_equal(li.minimizers()[0], gi.minimizers()[0]) and np.array_equal(li.minimizers()[1], gi.minimizers()[1])
+    assert (li.k, li.w, li.names, li.lens, li.mid_occ) == (gi.k, gi.w, gi.names, gi.lens, gi.mid_occ)
+    rd = synth.mutate(c[0][2000:9000], 0.08, np.random.default_rng(1)).tobytes()
+    assert np.array_equal(ctx.map_batch(li, [rd])[0], ctx.map_batch(gi, [rd])[0])
+    raw = bytearray(open(p, 'rb').read())
+    hdr = 8 + 48
+
+    def bad(mut, what):
+        b = bytearray(raw); mut(b)
+        q = str(tmp_path / 'bad.vmx'); open(q, 'wb').write(bytes(b))
+        with pytest.raises(VmxError) as e:
+            Index.load(ctx, q)
+        assert e.value.code == -5, what            # VM_ERR_IO, never a crash
+
+    def put(off, v):
+        return lambda b: b.__setitem__(slice(off, off + 8), int(v).to_bytes(8, 'little', signed=True))
+    bad(put(8, 99), 'k out of range'); bad(put(16, 0), 'w = 0'); bad(put(24, -3), 'negative contig count'); bad(put(32, 1 << 40), 'huge minimizer count')
+    bad(put(40, 1 << 50), 'huge total length'); bad(lambda b: b.__delitem__(slice(len(b) - 16, len(b))), 'truncated')
+    bad(lambda b: b.extend(b'\0' * 8), 'trailing bytes'); bad(lambda b: b.__setitem__(slice(0, 8), b'VMXIDX01'), 'old format')
+    npos = gi.n_minimizers(); pos0 = len(raw) - 8 * npos
+    bad(put(pos0 + 8 * 5, int.from_bytes(raw[pos0 + 8 * 5:pos0 + 8 * 5 + 8], 'little') ^ 1), 'strand bit flipped')
+    bad(put(pos0 + 8 * 7, (60000 << 1)), 'position crossing a contig end / in the N run')
+
+    def swap(b):
+        b[pos0:pos0 + 8], b[pos0 + 800:pos0 + 808] = b[pos0 + 800:pos0 + 808], b[pos0:pos0 + 8]
+    bad(swap, 'order broken')
+    assert hdr < pos0
+    # a replica made from the metadata has no host copy of the bases: seq() and save() decode them from the device pieces
+    from vacmap_amd.dist import index_blobs
+    rep = Index.from_meta(ctx, gi.meta())
+    for d, s in zip(index_blobs(rep, 'cpu'), index_blobs(gi, 'cpu')):
+        d.copy_(s)
+    assert rep.seq(1, 2990, 3050) == gi.seq(1, 2990, 3050).replace('N', 'N') and rep.n_minimizers() == gi.n_minimizers()
+    assert np.array_equal(ctx.map_batch(rep, [rd])[0], ctx.map_batch(gi, [rd])[0])
+    p2 = str(tmp_path / 'rep.vmx'); rep.save(p2)
+    assert np.array_equal(Index.load(ctx, p2).minimizers()[1], gi.minimizers()[1])
+    with pytest.raises(VmxError):
+        Index.from_meta(ctx, gi.meta()[:40])
+    with pytest.raises(VmxError):
+        Index.from_meta(ctx, b'\xff' * 80)
+
+
+def test_plan_batches_windows():
+    from vacmap_amd.pipeline import plan_batches
+    rng = np.random.default_rng(3)
+    lens = rng.integers(100, 50000, size=1000)
+    plan = plan_batches(lens, batch_reads=64, window_batches=4)
+    assert sorted(np.concatenate(plan).tolist()) == list(range(1000))            # every read exactly once
+    assert len(plan) == 16 and all(len(b) == 64 for b in plan[:15])
+    for w in range(0, 16, 4):                                                      # a window never mixes with the next one
+        ids = np.concatenate(plan[w:w + 4])
+        assert ids.min() >= w * 64 and ids.max() < min(1000, (w + 4) * 64)
+        tot = [lens[b].sum() for b in plan[w:w + 4]]
+        assert tot == sorted(tot, reverse=True)                                    # longest reads first inside a window
+        for b in plan[w:w + 4]:
+            assert (np.diff(lens[b]) >= 0).all()                                   # a batch holds reads of ascending length
+    flat = plan_batches(lens, 64, 4, sort=False)
+    assert np.array_equal(np.concatenate(flat), np.arange(1000))
+
+
+def test_pipeline_matches_single_context(ctx, oracle):
+    """the scheduler (3 contexts in flight, length-binned windows) returns exactly what one batch through one context returns"""
+    from vacmap_amd import synth, pipeline
+    from vacmap_amd.lib import Index, align_batch
+    contigs = synth.make_reference([60000], seed=21)
+    gi = Index.from_seqs(ctx, ['chr1'], contigs, k=15, w=10)
+    cat, off, _ = synth.sample_reads_concat(contigs, 10, mean_len=1500, err=0.08, seed=22, min_len=400, max_len=4000)
+    reads = [cat[off[i]:off[i + 1]].tobytes() for i in range(10)]
+    prm = ctx.lib.params('H')
+    st0, rec0, _ = align_batch(ctx, gi, prm, reads)
+    plan = pipeline.plan_batches(np.diff(off), batch_reads=3, window_batches=2)
+    pipe = pipeline.Pipeline(gi, prm, inflight=3, first_ctx=ctx)
+    got = {}
+
+    def on_result(i, res):
+        st, recs, _ = res
+        for j, r in enumerate(plan[i]):
+            got[int(r)] = (int(st[j]), [t[1:] for t in recs if t[0] == j])
+    res = pipeline.upload_batches(ctx, cat, off, plan)
+    pipe.run_resident(res, want_records=True, on_result=on_result)
+    for r in range(10):
+        assert got[r] == (int(st0[r]), [t[1:] for t in rec0 if t[0] == r])
+    got.clear()
+    pipe.run_host([[reads[int(r)] for r in b] for b in plan], on_result=on_result)
+    assert all(got[r] == (int(st0[r]), [t[1:] for t in rec0 if t[0] == r]) for r in range(10))
+    pipe.close()
+
+
+_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import numpy as np, torch, torch.distributed as dist
+dist.init_process_group(backend='gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
+import emu_lib                                   # TEST-ONLY: the product's sources on the CPU fiber emulator
+ctx = emu_lib.context()
+import vacmap_amd.lib as VL
+VL._default = ctx.lib                            # the driver below binds the same library
+from vacmap_amd import synth
+from vacmap_amd.dist import broadcast_index
+from vacmap_amd.lib import Index
+contigs = synth.make_reference([40000, 9000], seed=31)
+built = {'n': 0}
+_orig = Index.from_seqs.__func__
+def counting(cls, *a, **k):
+    built['n'] += 1
+    return _orig(cls, *a, **k)
+Index.from_seqs = classmethod(counting)
+index = Index.from_seqs(ctx, ['a', 'b'], contigs, k=15, w=10) if rank == 0 else None
+index, secs = broadcast_index(ctx, index, src=0, device=torch.device('cpu'), chunk_bytes=1 << 16)
+assert built['n'] == (1 if rank == 0 else 0)      # no rank other than 0 builds
+rd = synth.mutate(contigs[0][5000:11000], 0.08, np.random.default_rng(7)).tobytes()
+rows = ctx.map_batch(index, [rd])[0]
+allrows = [None] * world
+dist.all_gather_object(allrows, rows.tolist())
+assert allrows[0] == allrows[1] and len(allrows[0]) > 50
+assert index.seq(0, 100, 160) == contigs[0][100:160].tobytes().decode()
+# sharded driver run: every rank aligns its share of the batches, rank 0 gathers the SAM lines
+tmp = sys.argv[1]
+if rank == 0:
+    with open(os.path.join(tmp, 'ref.fa'), 'w') as f:
+        for n, c in zip(['a', 'b'], contigs):
+            f.write('>%%s\n%%s\n' %% (n, c.tobytes().decode()))
+    cat, off, _ = synth.sample_reads_concat(contigs, 7, mean_len=1500, err=0.06, seed=33, min_len=500, max_len=3000)
+    with open(os.path.join(tmp, 'reads.fa'), 'w') as f:
+        for i in range(7):
+            f.write('>r%%d\n%%s\n' %% (i, cat[off[i]:off[i + 1]].tobytes().decode()))
+dist.barrier()
+from vacmap_amd import driver
+rc = driver.main(['-ref', os.path.join(tmp, 'ref.fa'), '-read', os.path.join(tmp, 'reads.fa'), '-mode', 'H', '-o', os.path.join(tmp, 'out.sam'), '-t', '1',
+                  '--nowriteindex', '--batch-reads', '2', '--window-batches', '2', '--force'], comm=dist)
+assert rc == 0
+if rank == 0:
+    body = [l.split('\t')[0] for l in open(os.path.join(tmp, 'out.sam')) if not l.startswith('@')]
+    print(json.dumps({'names': body, 'secs': secs}))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_rank_index_broadcast_and_sharded_driver_gloo(tmp_path):
+    """world 2, gloo: rank 0 builds, rank 1 receives metadata + the four pieces and maps identically; then the driver runs sharded
+    (batch i -> rank i mod 2) and rank 0 writes every read's lines in input order"""
+    script = tmp_path / 'w.py'
+    script.write_text(_WORKER % (ROOT, ROOT))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29631')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', '29631', str(script), str(tmp_path)], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    names = d['names']
+    assert sorted(set(names), key=lambda s: int(s[1:])) == ['r%d' % i for i in range(7)]
+    assert names == sorted(names, key=lambda s: int(s[1:]))          # input order

@@ -75,6 +75,22 @@ def _cat(seqs):
     return b''.join(bs), off
 
 
+def _seq_ptrs(seqs):
+    """contig sequences as (keep-alive objects, char** argument, int64 lengths) without copying uint8 NumPy arrays (a 3.1 Gb
+    reference is handed over in place); str / bytes are accepted too"""
+    keep, ptrs, lens = [], [], []
+    for x in seqs:
+        if isinstance(x, np.ndarray):
+            a = np.ascontiguousarray(x, dtype=np.uint8)
+            keep.append(a); ptrs.append(a.ctypes.data); lens.append(a.size)
+        else:
+            b = C.create_string_buffer(_b(x), len(x)) if len(x) else C.create_string_buffer(1)
+            keep.append(b); ptrs.append(C.addressof(b)); lens.append(len(x))
+    n = len(ptrs)
+    arr = (C.c_void_p * max(n, 1))(*ptrs)
+    return keep, C.cast(arr, C.POINTER(C.c_char_p)), (C.c_int64 * max(n, 1))(*lens)
+
+
 class VmxLib:
     """Thin typed view of the C-ABI. `path` defaults to the in-tree libvacmapx.so."""
 
@@ -103,10 +119,12 @@ class VmxLib:
         L.vm_index_build_fasta.argtypes = [vp, cp, C.c_int, C.c_int, P(vp)]
         L.vm_index_build_mem.argtypes = [vp, C.c_int, P(cp), P(cp), P(i64), C.c_int, C.c_int, P(vp)]
         L.vm_index_save.argtypes = [vp, cp]; L.vm_index_load.argtypes = [vp, cp, P(vp)]
+        L.vm_index_save_mmi.argtypes = [vp, cp, C.c_int]; L.vm_index_load_mmi.argtypes = [vp, cp, P(vp)]
         L.vm_index_free.argtypes = [vp]
         for f in ('vm_index_k', 'vm_index_w', 'vm_index_nseq', 'vm_index_mid_occ', 'vm_index_blob_count'):
             getattr(L, f).argtypes = [vp]
         L.vm_index_n_minimizers.argtypes = [vp]; L.vm_index_n_minimizers.restype = i64
+        L.vm_index_n_distinct.argtypes = [vp]; L.vm_index_n_distinct.restype = i64
         L.vm_index_seq_info.argtypes = [vp, C.c_int, P(cp), P(i64), P(i64)]
         L.vm_index_seq.argtypes = [vp, C.c_int, i64, i64, vp]; L.vm_index_seq.restype = i64
         L.vm_index_minimizers.argtypes = [vp, P(P(C.c_uint64)), P(P(C.c_uint64)), P(i64)]
@@ -404,10 +422,11 @@ class Index:
     @classmethod
     def from_seqs(cls, ctx, names, seqs, k=15, w=10):
         n = len(names)
-        bs = [_b(s) for s in seqs]
-        na = (C.c_char_p * n)(*[_b(x) for x in names]); sa = (C.c_char_p * n)(*bs); la = (C.c_int64 * n)(*[len(b) for b in bs])
+        keep, sa, la = _seq_ptrs(seqs)
+        na = (C.c_char_p * max(n, 1))(*[_b(x) for x in names])
         h = C.c_void_p()
         ctx.lib.check(ctx.lib.L.vm_index_build_mem(ctx.h, n, na, sa, la, k, w, C.byref(h)))
+        del keep
         return cls(ctx, h)
 
     @classmethod
@@ -419,6 +438,41 @@ class Index:
     def save(self, path):
         self.ctx.lib.check(self.ctx.lib.L.vm_index_save(self.h, _b(path)))
 
+    @classmethod
+    def load_mmi(cls, ctx, path):
+        """a minimap2 index file (`minimap2 -d`, format v3; src/vacmap/vacmap:324-344)"""
+        h = C.c_void_p()
+        ctx.lib.check(ctx.lib.L.vm_index_load_mmi(ctx.h, _b(path), C.byref(h)))
+        return cls(ctx, h)
+
+    def save_mmi(self, path, bucket_bits=14):
+        self.ctx.lib.check(self.ctx.lib.L.vm_index_save_mmi(self.h, _b(path), bucket_bits))
+
+    # ---- multi-GPU replication (vacmap_amd/dist.py): metadata + the raw HBM pieces
+    def meta(self):
+        """bytes from which another process allocates an empty replica (vm_index_meta_get)"""
+        n = C.c_int64()
+        self.ctx.lib.check(self.ctx.lib.L.vm_index_meta_size(self.h, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        self.ctx.lib.check(self.ctx.lib.L.vm_index_meta_get(self.h, buf, n.value))
+        return buf.raw
+
+    @classmethod
+    def from_meta(cls, ctx, meta):
+        """empty replica on ctx's GPU with the geometry of `meta`; its blobs() are then filled by the broadcast"""
+        h = C.c_void_p()
+        ctx.lib.check(ctx.lib.L.vm_index_from_meta(ctx.h, meta, len(meta), C.byref(h)))
+        return cls(ctx, h)
+
+    def blobs(self):
+        """[(device pointer, bytes)] of codes, positions, hash table, contig offsets (vm_index_blob)"""
+        out = []
+        for i in range(self.ctx.lib.L.vm_index_blob_count(self.h)):
+            p = C.c_void_p(); n = C.c_int64()
+            self.ctx.lib.check(self.ctx.lib.L.vm_index_blob(self.h, i, C.byref(p), C.byref(n)))
+            out.append((p.value or 0, n.value))
+        return out
+
     def seq(self, i, st=0, en=None):
         en = self.lens[i] if en is None else en
         buf = C.create_string_buffer(max(en - st, 1))
@@ -427,6 +481,9 @@ class Index:
 
     def n_minimizers(self):
         return self.ctx.lib.L.vm_index_n_minimizers(self.h)
+
+    def n_distinct(self):
+        return self.ctx.lib.L.vm_index_n_distinct(self.h)
 
     def minimizers(self):
         hh = C.POINTER(C.c_uint64)(); pp = C.POINTER(C.c_uint64)(); n = C.c_int64()

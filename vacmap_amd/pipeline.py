@@ -1,0 +1,119 @@
+"""The product's batch schedule: length-binned batches inside a bounded window, several batches in flight per GPU.
+
+Counterpart of the reference's worker loop (`get_list_of_readmap_stdout`, mammap_clrnano.py:24086-24154: `t` processes each pull
+reads from a queue and push 2 MB of SAM text at a time; input order is not preserved across workers, :24147-24150). Here one process
+drives one GPU:
+
+  * reads are taken in arrival order in WINDOWS of `window_batches * batch_reads` reads; inside a window they are sorted by length
+    (stable) and cut into batches, so that the one-wavefront-per-read kernels of a batch finish together (`plan_batches`);
+  * `inflight` contexts (vm_ctx = HIP stream set + work pools), one host thread each, pull batches from the window, longest reads
+    first; their kernels overlap on the device — the latency-bound chain / re-seeding kernels of one batch run under the VALU-bound
+    gap fill of another — and every context is told how many share the GPU (`vm_ctx_set_inflight`);
+  * results are handed to the caller per batch as they complete (`on_result`), so SAM emission overlaps the next batches.
+
+`bench.py` times `Pipeline.run_resident` (reads already in HBM); `vacmap_amd/driver.py` feeds `Pipeline.run_host` from its FASTX /
+BAM reader. The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); a batch drives one main
+and four side streams, so the package asks for 8 before the runtime starts (vacmap_amd/__init__.py).
+"""
+import threading
+
+import numpy as np
+
+from .lib import Context, ResidentReads, align_batch
+
+DEFAULT_INFLIGHT = 3
+DEFAULT_BATCH_READS = 4096
+DEFAULT_WINDOW_BATCHES = 16
+
+
+def plan_batches(lengths, batch_reads=DEFAULT_BATCH_READS, window_batches=DEFAULT_WINDOW_BATCHES, sort=True):
+    """read lengths in arrival order -> list of int64 index arrays (one per batch), window by window; inside a window the batches
+    hold reads of ascending length and are listed LONGEST FIRST (the streams finish on the short ones). sort=False keeps arrival
+    order (the unsorted schedule, measured once for comparison)."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    n = len(lengths)
+    win = max(1, int(batch_reads) * max(1, int(window_batches)))
+    out = []
+    for w0 in range(0, n, win):
+        idx = np.arange(w0, min(n, w0 + win), dtype=np.int64)
+        if sort:
+            idx = idx[np.argsort(lengths[idx], kind='stable')]
+        if sort:            # cut from the long end: the longest reads fill whole batches, a short remainder holds the shortest
+            out.extend(idx[max(0, e - batch_reads):e] for e in range(len(idx), 0, -batch_reads))
+        else:
+            out.extend(idx[i:i + batch_reads] for i in range(0, len(idx), batch_reads))
+    return out
+
+
+class Pipeline:
+    def __init__(self, index, prm, device=0, inflight=DEFAULT_INFLIGHT, first_ctx=None):
+        self.index, self.prm = index, prm
+        self.inflight = max(1, int(inflight))
+        first = first_ctx or index.ctx
+        self.ctxs = [first] + [Context(device, lib=first.lib) for _ in range(self.inflight - 1)]
+        for cx in self.ctxs:
+            cx.set_inflight(self.inflight)
+
+    def close(self):
+        for cx in self.ctxs[1:]:
+            cx.close()
+        self.ctxs = self.ctxs[:1]
+
+    def _run(self, n_jobs, do_job, on_result):
+        """`inflight` threads pull job indices in order; do_job(i, ctx) -> result; on_result(i, result) is called under a lock"""
+        lock = threading.Lock()
+        nxt = [0]
+        errs = []
+
+        def worker(cx):
+            try:
+                while not errs:
+                    with lock:
+                        i = nxt[0]; nxt[0] += 1
+                    if i >= n_jobs:
+                        return
+                    res = do_job(i, cx)                   # ctypes releases the GIL for the library call
+                    if on_result is not None:
+                        with lock:
+                            on_result(i, res)
+            except BaseException as e:                    # a failed batch must fail the run, not hang it
+                errs.append(e)
+
+        if self.inflight == 1 or n_jobs <= 1:
+            worker(self.ctxs[0])
+        else:
+            th = [threading.Thread(target=worker, args=(cx,)) for cx in self.ctxs[:min(self.inflight, n_jobs)]]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        if errs:
+            raise errs[0]
+
+    def run_resident(self, resident, want_records=False, on_result=None):
+        """resident: list of ResidentReads in schedule order (plan_batches). on_result(i, (status, records or None, stats))"""
+        self._run(len(resident), lambda i, cx: resident[i].align(self.index, self.prm, want_records=want_records, ctx=cx), on_result)
+
+    def run_host(self, batches, on_result=None):
+        """batches: list of lists of read sequences (host memory; uploaded by vm_align_batch). on_result(i, (status, records, stats))"""
+        self._run(len(batches), lambda i, cx: align_batch(cx, self.index, self.prm, batches[i]), on_result)
+
+    def warm(self, resident):
+        """run every context once on `resident` (the largest batch): sizes the grow-only work pools so that no hipMalloc happens later"""
+        for cx in self.ctxs:
+            resident.align(self.index, self.prm, want_records=False, ctx=cx)
+
+
+def upload_batches(ctx, concat, offsets, plan):
+    """gather each planned batch from the concatenated pool (uint8, int64 offsets) and upload it: list of ResidentReads"""
+    concat = np.asarray(concat, dtype=np.uint8); offsets = np.asarray(offsets, dtype=np.int64)
+    lens = np.diff(offsets)
+    out = []
+    for idx in plan:
+        ln = lens[idx]
+        off = np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
+        cat = np.empty(int(off[-1]), np.uint8)
+        for j, i in enumerate(idx):
+            cat[off[j]:off[j + 1]] = concat[offsets[i]:offsets[i + 1]]
+        out.append(ResidentReads(ctx, concat=cat, offsets=off))
+    return out

@@ -25,6 +25,45 @@ def make_reference(lengths, seed=1):
     return [_ACGT[rng.integers(0, 4, size=int(n), dtype=np.uint8)] for n in lengths]
 
 
+# GRCh38 primary assembly, chr1..22, X, Y (bases): the proportions of the hg38-size synthetic reference
+HG38_LENGTHS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622,
+                133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468,
+                156040895, 57227415]
+HG38_NAMES = ['chr%d' % i for i in range(1, 23)] + ['chrX', 'chrY']
+
+
+def hg38_like_lengths(total=3_100_000_000):
+    """24 contig lengths with hg38's chromosome proportions, summing to `total`"""
+    tot = float(sum(HG38_LENGTHS))
+    ln = [int(round(x * total / tot)) for x in HG38_LENGTHS]
+    ln[0] += int(total) - sum(ln)
+    return ln
+
+
+_LUT4 = None
+
+
+def make_reference_fast(lengths, seed=3, threads=None):
+    """i.i.d. uniform ACGT contigs for LARGE references: one random byte yields four bases through a 256-entry table of packed
+    ASCII quadruples (seconds for 3.1 Gb instead of minutes). Contig i is a function of (seed, i) only."""
+    global _LUT4
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    if _LUT4 is None:
+        v = np.arange(256, dtype=np.uint32)
+        _LUT4 = (_ACGT[v & 3].astype(np.uint32) | (_ACGT[(v >> 2) & 3].astype(np.uint32) << 8) |
+                 (_ACGT[(v >> 4) & 3].astype(np.uint32) << 16) | (_ACGT[(v >> 6) & 3].astype(np.uint32) << 24))
+
+    def one(i):
+        n = int(lengths[i]); m = (n + 3) // 4
+        rng = np.random.default_rng([int(seed), i])
+        r = rng.integers(0, 1 << 32, size=(m + 3) // 4, dtype=np.uint32).view(np.uint8)[:m]
+        return _LUT4[r].view(np.uint8)[:n]
+    nt = threads or min(len(lengths), len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else 8, 16)
+    with ThreadPoolExecutor(max_workers=max(1, nt)) as ex:
+        return list(ex.map(one, range(len(lengths))))
+
+
 def mutate(seq, err, rng, ratio=(4, 3, 3)):
     """i.i.d. per-base errors split sub:del:ins = ratio; insertions add a random base before the position."""
     n = len(seq)
