@@ -154,6 +154,13 @@ void vm_local_out_free(vm_local_out*);
 typedef struct vm_score { int32_t match, mismatch, o1, e1, o2, e2; } vm_score;
 int vm_k_cigar_batch(vm_ctx*, const vm_score*, int eqx, int64_t n, const char* t, const int64_t* t_off, const char* q,
                      const int64_t* q_off, char** cigars, int64_t** cigar_off, int32_t** scores);
+/* The same problems through the schedule vm_align_batch uses for its gap fill (mammap_clrnano.py:21554, :21598 call sites): longest-first
+ * device queue, banded four-per-wavefront fill first, the problems whose band is not PROVEN optimal filled again in full by a second
+ * launch, per-problem layout flag for the traceback. CIGARs must equal vm_k_cigar_batch's. band_flag[n]: 1 = the banded result was
+ * proven and kept. stats[4] = {problems eligible for the band, proven, sent to the redo launch, not eligible (too large / band no
+ * narrower than the matrix)}. No scores (that form never captures them). */
+int vm_k_cigar_batch_banded(vm_ctx*, const vm_score*, int eqx, int64_t n, const char* t, const int64_t* t_off, const char* q,
+                            const int64_t* q_off, char** cigars, int64_t** cigar_off, int32_t** band_flag, int64_t* stats);
 /* `mp.k_cigar(..., 4,4,4,4, bw=100, zdropvalue=50)` (:2381): banded x-drop extension from (0,0); out t_e[n], q_e[n], score[n] */
 int vm_k_extend_batch(vm_ctx*, int match, int mismatch, int o, int e, int bw, int zdrop, int64_t n, const char* t,
                       const int64_t* t_off, const char* q, const int64_t* q_off, int32_t** t_e, int32_t** q_e, int32_t** score);

@@ -129,6 +129,101 @@ def check_gapfill(ctx, O, n=64, maxlen=500, seed=4, minlen=1):
             assert cg[i] == e_cg, (i, len(ts[i]), len(qs[i]))
 
 
+def band_steps(tl, ql, band_w):
+    """mirror of VMX_BAND_STEPS (vmx_kernels.h): width of a banded stripe in steps, 0 = the problem is not banded"""
+    if tl <= 0 or ql <= 0:
+        return 0
+    x4w = ((ql + 31) + 15) & ~15
+    nc = 2 * band_w + 3 + (32 * ql + tl - 1) // tl
+    st = ((nc + 31) + 15) & ~15
+    return st if st + 16 <= x4w else 0
+
+
+def gapfill_banded_cases(rng, band_w, x4_max, dp16_max, base_len, big=True):
+    """adversarial (target, query) pairs for the banded gap fill (k_gapfill_fill_ns): see check_gapfill_banded"""
+    ts, qs, tag = [], [], []
+
+    def add(t, q, what):
+        ts.append(t); qs.append(q if q else 'A'); tag.append(what)
+    L = base_len
+    # |tl - ql| from 0 to beyond the band: one deletion / insertion of d bases in the middle, light substitutions around it
+    for d in list(range(0, band_w + 9)):
+        a = rand_seq(rng, L)
+        add(a, mutate(rng, a[:L // 2] + a[L // 2 + d:], 0.02), 'del%d' % d)
+        add(a, mutate(rng, a[:L // 2] + rand_seq(rng, d) + a[L // 2:], 0.02), 'ins%d' % d)
+    # indels of about half the band .. just beyond it, at the start, the middle and the end
+    for d in sorted(set([max(1, band_w // 2), band_w - 3, band_w - 1, band_w, band_w + 1, band_w + 3])):
+        for pos in (2, L // 2, L - 2 - d):
+            a = rand_seq(rng, L)
+            add(a, a[:pos] + a[pos + d:], 'D%d@%d' % (d, pos))
+            add(a, a[:pos] + rand_seq(rng, d) + a[pos:], 'I%d@%d' % (d, pos))
+            add(a, mutate(rng, a[:pos] + a[pos + d:], 0.1), 'D%d@%d+err' % (d, pos))
+    # a gap long enough for the second affine piece (24 + g < 4 + 2 g for g > 20), and two opposite gaps (the path leaves and re-enters)
+    for g in (21, 22, 30):
+        a = rand_seq(rng, L)
+        add(a, a[:L // 3] + a[L // 3 + g:], 'piece2 del %d' % g)
+        add(a, a[:L // 3] + a[L // 3 + g:2 * L // 3] + rand_seq(rng, g) + a[2 * L // 3:], 'del+ins %d' % g)
+    # tandem repeats: many co-optimal paths far from the main line, the traceback's tie-breaks decide
+    for unit in (1, 2, 3, 7, 11):
+        u = rand_seq(rng, unit)
+        a = (u * (L // unit + 2))[:L]
+        add(a, a[unit * 2:] if len(a) > unit * 2 else a, 'tandem%d shift' % unit)
+        add(a, mutate(rng, a, 0.05), 'tandem%d err' % unit)
+    # unrelated sequences (every path is bad; the proof must fail or the result must still be the optimum)
+    for _ in range(4):
+        add(rand_seq(rng, L), rand_seq(rng, L + int(rng.integers(-5, 6))), 'unrelated')
+    # shapes around the switch where VMX_BAND_STEPS becomes 0 (banding would not save a 16-step block): sweep ql for tl ~ ql
+    lo = [q for q in range(8, 4 * band_w + 120) if band_steps(q, q, band_w) == 0]
+    hi = [q for q in range(8, 4 * band_w + 120) if band_steps(q, q, band_w) > 0]
+    edge = (max(lo) if lo else 8, min(hi) if hi else 8)
+    for q in range(max(1, edge[0] - 20), edge[1] + 21, 3):
+        a = rand_seq(rng, q + int(rng.integers(0, 4)))
+        add(a, mutate(rng, a, 0.08), 'flip%d' % q)
+    # very oblong problems (|tl - ql| large relative to min): g < 1, never proven
+    a = rand_seq(rng, L)
+    add(a, a[:L // 4], 'oblong'); add(a[:L // 4], a, 'oblong2')
+    # size-class boundaries of the three layouts: four per wave (tl + ql <= x4_max), packed int16 (<= dp16_max), int32 beyond
+    if big:
+        for tot in (x4_max - 1, x4_max, x4_max + 1, dp16_max - 1, dp16_max, dp16_max + 1):
+            tl = tot // 2; ql = tot - tl
+            a = rand_seq(rng, tl)
+            b = mutate(rng, a, 0.06)
+            while len(b) < ql:
+                b += rand_seq(rng, 1)
+            add(a, b[:ql], 'tot%d' % tot)
+    # empty / one-base sides
+    add('', 'ACGT', 'empty t'); add('ACGT', 'A', 'tiny q'); add('A', 'A', '1x1')
+    return ts, qs, tag
+
+
+def check_gapfill_banded(ctx, O, band_w, x4_max, dp16_max, base_len, seed=44, big=True, min_counts=(10, 10, 5)):
+    """E5 through the schedule of the batched path (vm_k_cigar_batch_banded -> k_gapfill_fill_ns: banded fill, optimality proof, redo
+    queue, per-problem layout flag read by k_gapfill_trace) vs the oracle's full DP (mammap_clrnano.py:21554, :21598 call sites):
+    identical CIGARs with eqx on and off, in shuffled order (waves mix proven, unproven, not-eligible and idle rows), and both branches
+    provably taken."""
+    rng = np.random.default_rng(seed)
+    ts, qs, tag = gapfill_banded_cases(rng, band_w, x4_max, dp16_max, base_len, big=big)
+    perm = rng.permutation(len(ts))
+    ts = [ts[i] for i in perm]; qs = [qs[i] for i in perm]; tag = [tag[i] for i in perm]
+    expect = {eqx: [O.k_cigar_global(t, q, eqx=eqx)[0] for t, q in zip(ts, qs)] for eqx in (False, True)}
+    for eqx in (False, True):
+        cg, flag, st = ctx.k_cigar_batch_banded(ts, qs, eqx=eqx)
+        for i in range(len(ts)):
+            assert cg[i] == expect[eqx][i], (tag[i], len(ts[i]), len(qs[i]), int(flag[i]), eqx)
+        elig = sum(1 for t, q in zip(ts, qs) if t and q and len(t) + len(q) <= x4_max and band_steps(len(t), len(q), band_w) > 0)
+        assert st['eligible'] == elig and st['not_eligible'] == len(ts) - elig
+        assert st['proven'] == int((flag == 1).sum()) and st['redo'] == elig - st['proven']
+        assert st['proven'] >= min_counts[0] and st['redo'] >= min_counts[1] and st['not_eligible'] >= min_counts[2], st      # both branches and the plain form ran
+        # the full-matrix entry agrees too (same problems, no band)
+        cg0, _ = ctx.k_cigar_batch(ts, qs, eqx=eqx)
+        assert cg0 == cg
+    # tiny batches: idle rows in the only wave
+    for n in (1, 2, 3, 5):
+        cg, flag, st = ctx.k_cigar_batch_banded(ts[:n], qs[:n])
+        assert cg == expect[False][:n]
+    return st
+
+
 def check_chain_global_golden(ctx, O, golden, cases=('A', 'B', 'C', 'D')):
     meta, arrays = golden
     for cid in cases:

@@ -34,6 +34,13 @@ def test_emu_gapfill(ctx, oracle):
     KC.check_gapfill(ctx, oracle, n=6, maxlen=330, seed=5)       # several 128-row stripes of the packed layout; beyond 420 cells of perimeter: int32 layout
 
 
+def test_emu_gapfill_banded(ctx, oracle):
+    """the batched path's gap-fill schedule (banded + proof + redo queue + layout flag) with the emulator build's small constants
+    (VMX_BAND_W 6, four-per-wave up to tl + ql = 160, packed int16 up to 420)"""
+    st = KC.check_gapfill_banded(ctx, oracle, band_w=6, x4_max=160, dp16_max=420, base_len=70, seed=44, min_counts=(10, 5, 5))
+    assert st['proven'] > 0 and st['redo'] > 0
+
+
 def test_emu_chain_global(ctx, oracle, golden):
     KC.check_chain_global_golden(ctx, oracle, golden, cases=['B', 'D'])
 

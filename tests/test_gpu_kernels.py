@@ -41,6 +41,16 @@ def test_gapfill(ctx, oracle):
     KC.check_gapfill(ctx, oracle, n=3, maxlen=3600, seed=18, minlen=3300)      # tl + ql > 6000: int32 layout
 
 
+def test_gapfill_banded_schedule(ctx, oracle):
+    """k_gapfill_fill_ns as vm_align_batch launches it (banded four-per-wave fill, optimality proof, redo queue, layout flag): CIGARs vs the
+    oracle on adversarial shapes — |tl - ql| 0..70, indels of 30-65 bp at the start / middle / end, second-piece gaps, tandem repeats, the
+    (tl, ql) where VMX_BAND_STEPS flips to 0, tl + ql in {3071..3073, 5999..6001}, mixed waves, eqx on and off"""
+    st = KC.check_gapfill_banded(ctx, oracle, band_w=62, x4_max=3072, dp16_max=6000, base_len=270, seed=44)
+    assert st['proven'] >= 10 and st['redo'] >= 10
+    KC.check_gapfill_banded(ctx, oracle, band_w=62, x4_max=3072, dp16_max=6000, base_len=420, seed=45, big=False)
+    KC.check_gapfill_banded(ctx, oracle, band_w=62, x4_max=3072, dp16_max=6000, base_len=1400, seed=46, big=False)
+
+
 def test_chain_global_golden(ctx, oracle, golden):
     KC.check_chain_global_golden(ctx, oracle, golden)
 

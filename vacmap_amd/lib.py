@@ -96,6 +96,10 @@ class VmxLib:
 
     def __init__(self, path=None):
         path = path or DEFAULT_SO
+        try:        # one HIP runtime per process: torch bundles its own libamdhip64, and whichever copy is loaded first serves both. Load
+            import torch  # noqa: F401   torch's before this library so that vacmap_amd.dist (RCCL broadcast of the HBM-resident index) works
+        except ImportError:               # whatever the import order of the caller; without torch there is simply no multi-GPU plumbing
+            pass
         if not os.path.exists(path):
             raise FileNotFoundError('%s not built: run `python -m vacmap_amd.build` (hipcc, gfx950). No fallback exists.' % path)
         L = self.L = C.CDLL(path)
@@ -114,6 +118,7 @@ class VmxLib:
         L.vm_k_extend_batch.argtypes = [vp] + [C.c_int] * 6 + [i64, cp, vp, cp, vp, P(P(i32)), P(P(i32)), P(P(i32))]
         L.vm_k_cigar_batch.argtypes = [vp, P(Score), C.c_int, i64, cp, vp, cp, vp, P(vp), P(P(i64)), P(P(i32))]
         L.vm_k_cigar.argtypes = [vp, cp, i64, cp, i64, P(Score), C.c_int, C.c_int, C.c_int, P(CigarOut)]
+        L.vm_k_cigar_batch_banded.argtypes = [vp, P(Score), C.c_int, i64, cp, vp, cp, vp, P(vp), P(P(i64)), P(P(i32)), vp]
         L.vm_chain_global_batch.argtypes = [vp, P(Params), C.c_int, i64, vp, vp, vp, C.c_int, P(ChainsOut)]
         L.vm_chains_out_free.argtypes = [P(ChainsOut)]
         L.vm_index_build_fasta.argtypes = [vp, cp, C.c_int, C.c_int, P(vp)]
@@ -242,6 +247,20 @@ class Context:
         self.lib.L.vm_free(cg)
         cigars = [blob[off[i]:off[i + 1] - 1].decode() for i in range(n)]
         return cigars, self._take(ss, n, np.int32)
+
+    def k_cigar_batch_banded(self, targets, queries, match=2, mismatch=-4, o1=4, e1=2, o2=24, e2=1, eqx=False):
+        """the gap-fill schedule of vm_align_batch (banded first, unproven problems redone in full): (cigars, band_flag, stats dict)"""
+        t, to = _cat(targets); q, qo = _cat(queries)
+        n = len(targets)
+        sc = Score(match, mismatch, o1, e1, o2, e2)
+        cg = C.c_void_p(); co = C.POINTER(C.c_int64)(); fl = C.POINTER(C.c_int32)(); st = (C.c_int64 * 4)()
+        self.lib.check(self.lib.L.vm_k_cigar_batch_banded(self.h, C.byref(sc), int(eqx), n, t, to.ctypes.data, q, qo.ctypes.data,
+                                                          C.byref(cg), C.byref(co), C.byref(fl), st))
+        off = self._take(co, n + 1, np.int64)
+        blob = C.string_at(cg.value, int(off[-1])) if off[-1] else b''
+        self.lib.L.vm_free(cg)
+        cigars = [blob[off[i]:off[i + 1] - 1].decode() for i in range(n)]
+        return cigars, self._take(fl, n, np.int32), {'eligible': st[0], 'proven': st[1], 'redo': st[2], 'not_eligible': st[3]}
 
     def k_cigar(self, target, query, match=2, mismatch=-4, gap_open_1=4, gap_extend_1=2, gap_open_2=24, gap_extend_2=1,
                 bw=-1, zdropvalue=-1, eqx=False):
