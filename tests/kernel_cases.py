@@ -219,7 +219,7 @@ def check_gapfill_banded(ctx, O, band_w, x4_max, dp16_max, base_len, seed=44, bi
         assert cg0 == cg
     # tiny batches: idle rows in the only wave
     for n in (1, 2, 3, 5):
-        cg, flag, st = ctx.k_cigar_batch_banded(ts[:n], qs[:n])
+        cg, _, _ = ctx.k_cigar_batch_banded(ts[:n], qs[:n])
         assert cg == expect[False][:n]
     return st
 
@@ -339,6 +339,39 @@ def check_seed_golden(ctx, O, golden, cases=('A', 'B', 'C', 'D')):
         for ri, a in enumerate(mp):
             assert np.array_equal(a, arrays['%s_r%d_anchors' % (cid, ri)].reshape(-1, 4)), (cid, ri, 'anchors differ')
         assert gi.seq(0, 5, 25) == oi.seq(0, 5, 25)
+
+
+def check_seed_many_hits(ctx, O, copies=30, unit=2500, read_len=4000, seed=61, min_hits=9000):
+    """`.map()` on reads whose hit count exceeds one and several LDS sort tiles of k_cluster (a diverged tandem array queried with a
+    raised occurrence cap): anchors equal the oracle's, cluster ranking and check_num cut included"""
+    from vacmap_amd import synth
+    from vacmap_amd.lib import Index
+    rng = np.random.default_rng(seed)
+    u = synth.make_reference([unit], seed=seed)[0]
+    parts = [synth.make_reference([20000], seed=seed + 1)[0]]
+    for c in range(copies):
+        parts.append(synth.mutate(u, 0.02, rng))
+        if c % 7 == 3:
+            parts.append(synth.make_reference([6000], seed=seed + 10 + c)[0])      # a gap > 5000 splits the array into several clusters
+    parts.append(synth.make_reference([20000], seed=seed + 2)[0])
+    ref = np.concatenate(parts)
+    gi = Index.from_seqs(ctx, ['rep'], [ref], k=15, w=10)
+    oi = O.Index.from_seqs(['rep'], [ref], k=15, w=10)
+    reads = []
+    for i in range(3):
+        body = np.concatenate([u, u])[i * 300:i * 300 + read_len]
+        reads.append(synth.mutate(body, 0.05, rng).tobytes())
+    reads.append(synth.mutate(ref[1000:1000 + read_len], 0.05, rng).tobytes())       # an ordinary read next to them (small class)
+    for check_num, occ in ((100, 4 * copies), (3, 4 * copies), (-1, 4 * copies), (100, -1)):
+        got = ctx.map_batch(gi, reads, check_num=check_num, mid_occ=occ)
+        tot = 0
+        for i, rd in enumerate(reads):
+            exp = oi.map(rd, check_num, occ)
+            assert np.array_equal(got[i], exp), (i, check_num, occ, len(got[i]), len(exp))
+            tot = max(tot, len(exp))
+        if check_num == -1:
+            assert tot >= min_hits, tot
+    gi.close()
 
 
 def check_align_golden(ctx, O, golden, cases=('A', 'B', 'C', 'D'), reads=None):

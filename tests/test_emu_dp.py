@@ -49,6 +49,10 @@ def test_emu_seed(ctx, oracle, golden):
     KC.check_seed_golden(ctx, oracle, golden, cases=['B', 'D'])
 
 
+def test_emu_seed_many_hits(ctx, oracle):
+    KC.check_seed_many_hits(ctx, oracle, copies=44, unit=2500, read_len=4500, seed=61, min_hits=9000)      # > one 8192-key tile of the emulator build
+
+
 def test_emu_local(ctx, oracle, golden):
     KC.check_local_golden(ctx, oracle, golden, cases=['B', 'D'])
 

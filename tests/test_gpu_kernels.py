@@ -34,6 +34,12 @@ def test_extend(ctx, oracle):
     KC.check_extend(ctx, oracle, n=8, seed=15, maxlen=6000)
 
 
+def test_seed_many_hits(ctx, oracle):
+    """k_cluster_big: reads with more hits than one / several 16384-key LDS tiles (tiled bitonic sort with its HBM steps)"""
+    KC.check_seed_many_hits(ctx, oracle, copies=30, unit=2500, read_len=4000, seed=61, min_hits=9000)
+    KC.check_seed_many_hits(ctx, oracle, copies=90, unit=3000, read_len=9000, seed=62, min_hits=70000)
+
+
 def test_gapfill(ctx, oracle):
     KC.check_gapfill(ctx, oracle, n=200, maxlen=500, seed=16)
     KC.check_gapfill(ctx, oracle, n=6, maxlen=3000, seed=17)
@@ -121,7 +127,7 @@ def test_driver_sam_end_to_end(ctx, golden, tmp_path):
     from vacmap_amd import driver
     meta, arrays = golden
     entries = [e for e in json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'sam.json')))
-               if e['opt'] == {'md': False, 'shortcs': True, 'cigar2cg': False, 'markunbalancetra': True, 'H': False, 'fakecigar': False}]
+               if e['opt'] == {'md': False, 'shortcs': True, 'cigar2cg': False, 'markunbalancetra': True, 'H': False, 'fakecigar': False, 'rg': '1'}]     # the driver's default read group
     for cid in ('A', 'B'):
         c = meta[cid]
         ref = tmp_path / ('ref%s.fa' % cid); fq = tmp_path / ('reads%s.fq' % cid); out = tmp_path / ('out%s.sam' % cid)
@@ -142,6 +148,7 @@ def test_driver_sam_end_to_end(ctx, golden, tmp_path):
         hdr = [x for x in lines if x.startswith('@')]
         body = [x for x in lines if x and not x.startswith('@')]
         assert hdr[0] == '@HD\tVN:1.0' and len([x for x in hdr if x.startswith('@SQ')]) == len(c['names']) and hdr[-1].startswith('@PG\tID:VACmap')
+        assert hdr[-2] == '@RG\tID:1\tSM:sample'                      # src/vacmap/vacmap:211-214
         assert [SC.digest(x) for x in body] == expect, cid
 
 

@@ -58,7 +58,11 @@ def main():
     optsets = [dict(md=False, shortcs=True, cigar2cg=False, markunbalancetra=True, H=False, fakecigar=False),
                dict(md=False, shortcs=True, cigar2cg=False, markunbalancetra=False, H=True, fakecigar=True, rg='grp1'),
                dict(md=True, shortcs=True, cigar2cg=True, markunbalancetra=True, H=False, fakecigar=False, eqx=True),
-               dict(md=True, shortcs=False, cigar2cg=False, markunbalancetra=True, H=True, fakecigar=True, eqx=True, comments='XC:Z:kept\\tNM:i:9\\tbad\\tYY:q:1')]
+               dict(md=True, shortcs=False, cigar2cg=False, markunbalancetra=True, H=True, fakecigar=True, eqx=True, comments='XC:Z:kept\\tNM:i:9\\tbad\\tYY:q:1'),
+               # the driver's default: no --rg-* option given -> read group {'ID': '1', 'SM': 'sample'}, rg-id '1' (src/vacmap/vacmap:211-214)
+               dict(md=False, shortcs=True, cigar2cg=False, markunbalancetra=True, H=False, fakecigar=False, rg='1'),
+               # --MD without --eqx: M CIGARs, empty MD / cs strings (vacmap:192, :19143)
+               dict(md=True, shortcs=True, cigar2cg=False, markunbalancetra=True, H=False, fakecigar=False, rg='1')]
     for cid in ('A', 'B', 'D', 'G'):
         c = meta[cid]
         contigs = {n: arrays['%s_contig%d' % (cid, i)].tobytes().decode() for i, n in enumerate(c['names'])}

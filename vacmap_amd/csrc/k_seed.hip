@@ -162,23 +162,27 @@ __global__ void __launch_bounds__(256) k_fill_hits(const uint32_t* __restrict__ 
     }
 }
 
-#define vmx_block_sort_u64(g, N, lds) vmx_block_sort_u64_impl((g), (N), (lds), VMX_SORT_LDS)
-
 // sort hits, cut clusters (ref gap > 5000), rank by (size desc, first ref asc), emit the first check_num clusters.
 // cl_keys: scratch with the same geometry as keys. rows out at key_off[r] (capacity nhits[r]).
-__global__ void __launch_bounds__(256) k_cluster(uint64_t* __restrict__ keys, uint64_t* __restrict__ cl_keys, const int64_t* __restrict__ key_off,
-                                                 const int64_t* __restrict__ nhits, int n_reads, int check_num, int kmer,
+// The reads of a launch come from `rlist` (one size class per launch): `tile` keys of dynamic LDS hold the sort — 4096 (32 KB, several
+// workgroups per CU) for reads with few hits, 16384 (128 KB, one workgroup of BLOCK threads per CU) for the others; a read with more
+// hits than a tile (a 15 kb read meets ~11 k hits in an hg38-size index, a 60 kb read 45 k) is sorted tile-wise with the few long-distance
+// steps through HBM (vmx_block_sort_u64_tiled).
+template <int BLOCK>
+__device__ __forceinline__ void vmx_cluster_body(uint64_t* __restrict__ keys, uint64_t* __restrict__ cl_keys, const int64_t* __restrict__ key_off,
+                                                 const int64_t* __restrict__ nhits, const int32_t* __restrict__ rlist, int nlist, int tile, int check_num, int kmer,
                                                  int64_t* __restrict__ rows, int32_t* __restrict__ n_anchors) {
-    __shared__ uint64_t s_sort[VMX_SORT_LDS];
+    VMX_DYN_SHARED(uint64_t, s_sort);
     __shared__ int s_scan[20];
     __shared__ int s_ncl;
-    for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
+    for (int x = blockIdx.x; x < nlist; x += gridDim.x) {
+        const int r = rlist[x];
         const int n = (int)nhits[r];
         if (n == 0) { if (threadIdx.x == 0) n_anchors[r] = 0; continue; }
         int N = 1; while (N < n) N <<= 1;
         uint64_t* K = keys + key_off[r];
         uint64_t* CK = cl_keys + key_off[r];
-        if (N > 1) vmx_block_sort_u64(K, N, s_sort);
+        if (N > 1) vmx_block_sort_u64_tiled(K, N, s_sort, tile);
         __syncthreads();
         // cluster starts, compacted in order: CK[c] = start index of cluster c (temporarily)
         int run = 0;
@@ -210,7 +214,7 @@ __global__ void __launch_bounds__(256) k_cluster(uint64_t* __restrict__ keys, ui
             if (c < NC) CK[c] = mykey[0];
             __syncthreads();
         }
-        if (NC > 1) vmx_block_sort_u64(CK, NC, s_sort);
+        if (NC > 1) vmx_block_sort_u64_tiled(CK, NC, s_sort, tile);
         __syncthreads();
         int keep = ncl; if (check_num > 0 && check_num < keep) keep = check_num;
         // emit: exclusive scan of kept cluster sizes gives the output offset of each cluster
@@ -233,6 +237,17 @@ __global__ void __launch_bounds__(256) k_cluster(uint64_t* __restrict__ keys, ui
         if (threadIdx.x == 0) n_anchors[r] = outbase;
         __syncthreads();
     }
+}
+
+__global__ void __launch_bounds__(256) k_cluster(uint64_t* __restrict__ keys, uint64_t* __restrict__ cl_keys, const int64_t* __restrict__ key_off,
+                                                 const int64_t* __restrict__ nhits, const int32_t* __restrict__ rlist, int nlist, int tile, int check_num, int kmer,
+                                                 int64_t* __restrict__ rows, int32_t* __restrict__ n_anchors) {
+    vmx_cluster_body<256>(keys, cl_keys, key_off, nhits, rlist, nlist, tile, check_num, kmer, rows, n_anchors);
+}
+__global__ void __launch_bounds__(1024) k_cluster_big(uint64_t* __restrict__ keys, uint64_t* __restrict__ cl_keys, const int64_t* __restrict__ key_off,
+                                                      const int64_t* __restrict__ nhits, const int32_t* __restrict__ rlist, int nlist, int tile, int check_num, int kmer,
+                                                      int64_t* __restrict__ rows, int32_t* __restrict__ n_anchors) {
+    vmx_cluster_body<1024>(keys, cl_keys, key_off, nhits, rlist, nlist, tile, check_num, kmer, rows, n_anchors);
 }
 
 // three-phase exclusive scan for large n: per-chunk sums -> k_scan_i64 over the sums -> per-chunk scan with its base

@@ -46,7 +46,7 @@ __global__ void k_readlens(const int64_t* __restrict__ roff, int64_t* __restrict
 struct vm_reads { vm_ctx* ctx; int64_t n; std::vector<int64_t> h_off; DevBuf raw, codes, off; };
 
 struct vmx_batch_bufs {
-    DevBuf seed[12];
+    DevBuf seed[13];
     DevBuf nanc64, aoff, rows, lens, keys, koff, sorted, flip, S, P, SA, cov, gmax, opc, rl, gap, scr, soff, res, plen, prow, ocodes;
     // extend stage
     DevBuf er, coff3, soff2, segA, st, en, segA_s, st_s, en_s, segprob, dup, desc[2], rcount, oflow, probread, tl, ql, toff, qoff, tpool, qpool;

@@ -267,6 +267,59 @@ __device__ inline void vmx_block_sort_u64_impl(uint64_t* g, int N, uint64_t* lds
     }
 }
 
+// The same sort for N beyond the LDS tile (`tile` keys, a power of two): every stage whose partner distance fits a tile runs in LDS (load
+// a tile, run the stages, store it), only the few steps with partner distance >= tile touch HBM (coalesced: thread i and thread i + 1
+// touch neighbouring keys). N = 4 tiles: 3 HBM steps and 3 LDS residencies per tile instead of 120 HBM passes.
+// every thread of the workgroup must call it.
+__device__ inline void vmx_block_sort_u64_tiled(uint64_t* g, int N, uint64_t* lds, int tile) {
+    const int T = (int)blockDim.x, tid = (int)threadIdx.x;
+    if (N <= tile) {
+        for (int i = tid; i < N; i += T) lds[i] = g[i];
+        __syncthreads();
+        vmx_block_bitonic_passes(lds, N);
+        for (int i = tid; i < N; i += T) g[i] = lds[i];
+        __syncthreads();
+        return;
+    }
+    for (int base = 0; base < N; base += tile) {                // all stages k <= tile, tile by tile (direction from the global index)
+        for (int i = tid; i < tile; i += T) lds[i] = g[base + i];
+        __syncthreads();
+        for (int k = 2; k <= tile; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < tile; i += T) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) { const uint64_t x = lds[i], y = lds[ixj]; const bool asc = ((base + i) & k) == 0; if ((x > y) == asc) { lds[i] = y; lds[ixj] = x; } }
+                }
+                __syncthreads();
+            }
+        for (int i = tid; i < tile; i += T) g[base + i] = lds[i];
+        __syncthreads();
+    }
+    for (int k = 2 * tile; k <= N; k <<= 1) {
+        for (int j = k >> 1; j >= tile; j >>= 1) {              // partner in another tile: through HBM
+            for (int i = tid; i < N; i += T) {
+                const int ixj = i ^ j;
+                if (ixj > i) { const uint64_t x = g[i], y = g[ixj]; const bool asc = (i & k) == 0; if ((x > y) == asc) { g[i] = y; g[ixj] = x; } }
+            }
+            __syncthreads();
+        }
+        for (int base = 0; base < N; base += tile) {            // the remaining steps of this stage stay inside a tile
+            for (int i = tid; i < tile; i += T) lds[i] = g[base + i];
+            __syncthreads();
+            const bool asc = (base & k) == 0;                   // k >= 2 * tile: one direction per tile
+            for (int j = tile >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < tile; i += T) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) { const uint64_t x = lds[i], y = lds[ixj]; if ((x > y) == asc) { lds[i] = y; lds[ixj] = x; } }
+                }
+                __syncthreads();
+            }
+            for (int i = tid; i < tile; i += T) g[base + i] = lds[i];
+            __syncthreads();
+        }
+    }
+}
+
 // block-wide STABLE LSD radix sort of n uint64 keys on the bit field [(key >> shift) - base] & (2^nbits - 1), 4 bits per pass,
 // ping-ponging between a and b (both in HBM). cnt: 16 * blockDim.x ints of LDS, scan: >= 17 ints. returns the buffer holding the result.
 // every thread of the workgroup must call it. blockDim.x <= 256.

@@ -32,8 +32,10 @@ __global__ void k_lookup(const uint64_t* mz_hash, const int64_t* mz_off, const i
 __global__ void k_fill_hits(const uint32_t* mz_ps, const int64_t* mz_off, const int32_t* mz_cnt, int n_reads, const uint32_t* m_start,
                             const uint32_t* m_cnt, const uint32_t* m_hoff, const uint64_t* idx_pos, uint64_t* keys, const int64_t* key_off,
                             const int64_t* nhits);
-__global__ void k_cluster(uint64_t* keys, uint64_t* cl_keys, const int64_t* key_off, const int64_t* nhits, int n_reads, int check_num, int kmer,
+__global__ void k_cluster(uint64_t* keys, uint64_t* cl_keys, const int64_t* key_off, const int64_t* nhits, const int32_t* rlist, int nlist, int tile, int check_num, int kmer,
                           int64_t* rows, int32_t* n_anchors);
+__global__ void k_cluster_big(uint64_t* keys, uint64_t* cl_keys, const int64_t* key_off, const int64_t* nhits, const int32_t* rlist, int nlist, int tile, int check_num, int kmer,
+                              int64_t* rows, int32_t* n_anchors);
 __global__ void k_scan_i64(const int64_t* in, int64_t* out, int64_t n, int pow2_round);
 
 // ------------------------------------------------------------------------------------------------ build kernels (spec VMX-S1)
@@ -609,7 +611,7 @@ int vm_sketch_batch(vm_ctx* c, int k, int w, int64_t n, const char* seqs, const 
 // device-side seed stage shared by vm_map_batch and vm_align_batch: codes/roff already on the device.
 // leaves rows (int64 x4) at key_off[r] with n_anchors[r] valid rows; returns host copies of key_off / nhits totals
 int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, int64_t total_bases,
-                   DevBuf* B /* >= 12 buffers */, std::vector<int64_t>& h_koff, std::vector<int64_t>& h_nhits) {
+                   DevBuf* B /* >= 13 buffers */, std::vector<int64_t>& h_koff, std::vector<int64_t>& h_nhits) {
     if (mid_occ <= 0) mid_occ = mi->mid_occ;
     DevBuf &mzh = B[0], &mzp = B[1], &mzc = B[2], &mst = B[3], &mcn = B[4], &mho = B[5], &nh = B[6], &koff = B[7], &keys = B[8], &ckeys = B[9], &rows = B[10], &nanc = B[11];
     VMX_TRY(mzh.reserve(8 * (size_t)(total_bases + 1))); VMX_TRY(mzp.reserve(4 * (size_t)(total_bases + 1))); VMX_TRY(mzc.reserve(4 * (size_t)(n + 1)));
@@ -630,8 +632,26 @@ int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, in
     VMX_TRY(keys.reserve(8 * (size_t)(ktot + 1))); VMX_TRY(ckeys.reserve(8 * (size_t)(ktot + 1))); VMX_TRY(rows.reserve(32 * (size_t)(ktot + 1)));
     hipLaunchKernelGGL(k_fill_hits, dim3(grid), dim3(256), 0, c->stream, mzp.as<uint32_t>(), d_roff, mzc.as<int32_t>(), (int)n, mst.as<uint32_t>(), mcn.as<uint32_t>(),
                        mho.as<uint32_t>(), mi->d_pos.as<uint64_t>(), keys.as<uint64_t>(), koff.as<int64_t>(), nh.as<int64_t>());
-    hipLaunchKernelGGL(k_cluster, dim3(grid), dim3(256), 0, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(), koff.as<int64_t>(), nh.as<int64_t>(), (int)n, check_num,
-                       mi->k, rows.as<int64_t>(), nanc.as<int32_t>());
+    // clustering, one launch per size class (the sort's LDS tile): reads with <= 4096 hits (32 KB of LDS, several workgroups per CU) and
+    // the others (16384-key tile = 128 KB, one 1024-thread workgroup per CU), longest first
+    {
+        std::vector<int32_t> small, big;
+        for (int64_t r = 0; r < n; ++r) (h_nhits[r] <= VMX_SORT_LDS ? small : big).push_back((int32_t)r);
+        std::stable_sort(big.begin(), big.end(), [&](int32_t a, int32_t b) { return h_nhits[a] > h_nhits[b]; });
+        std::vector<int32_t> rl(small); rl.insert(rl.end(), big.begin(), big.end());
+        VMX_TRY(upload(B[12], rl.data(), rl.size(), c->stream));
+        const int32_t* d_rl = B[12].as<int32_t>();
+        if (!big.empty()) {
+#ifndef VMX_EMU
+            VMX_HIP(hipFuncSetAttribute((const void*)k_cluster_big, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * VMX_SORT_LDS_BIG));
+#endif
+            hipLaunchKernelGGL(k_cluster_big, dim3((unsigned)std::min<int64_t>((int64_t)big.size(), c->num_cu)), dim3(1024), 8 * VMX_SORT_LDS_BIG, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(),
+                               koff.as<int64_t>(), nh.as<int64_t>(), d_rl + small.size(), (int)big.size(), VMX_SORT_LDS_BIG, check_num, mi->k, rows.as<int64_t>(), nanc.as<int32_t>());
+        }
+        if (!small.empty())
+            hipLaunchKernelGGL(k_cluster, dim3((unsigned)std::min<int64_t>((int64_t)small.size(), (int64_t)c->num_cu * 4)), dim3(256), 8 * VMX_SORT_LDS, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(),
+                               koff.as<int64_t>(), nh.as<int64_t>(), d_rl, (int)small.size(), VMX_SORT_LDS, check_num, mi->k, rows.as<int64_t>(), nanc.as<int32_t>());
+    }
     return 0;
 }
 

@@ -76,6 +76,11 @@ struct vmx_lseed_args {
 #define VMX_LSEED_WAVES 6            // k_local_seed: waves per SIMD the register allocation is held to (80 VGPRs: 3 workgroups of 512 per CU)
 #endif
 #define VMX_SORT_LDS 4096           // uint64 keys sorted in LDS by vmx_block_sort_u64 (larger sorts run in HBM)
+#ifdef VMX_EMU
+#define VMX_SORT_LDS_BIG 8192       // emulator build: a small tile so that the CPU tests reach the tiled (multi-tile) sort
+#else
+#define VMX_SORT_LDS_BIG 16384      // k_cluster_big: keys per LDS tile (128 KB of the 160 KB per CU)
+#endif
 #define VM_READ_FASTPATH_DEV (-21)   // the reference would switch to a *_fast heuristic that is not built yet
 #ifdef VMX_EMU
 #define VMX_DP16_MAX 420              // emulator build: small switch point so that the CPU tests cover both layouts with small problems
