@@ -36,7 +36,7 @@ def test_extend(ctx, oracle):
 
 def test_seed_many_hits(ctx, oracle):
     """k_cluster_big: reads with more hits than one / several 16384-key LDS tiles (tiled bitonic sort with its HBM steps)"""
-    KC.check_seed_many_hits(ctx, oracle, copies=30, unit=2500, read_len=4000, seed=61, min_hits=9000)
+    KC.check_seed_many_hits(ctx, oracle, copies=44, unit=2500, read_len=4500, seed=61, min_hits=9000)
     KC.check_seed_many_hits(ctx, oracle, copies=90, unit=3000, read_len=9000, seed=62, min_hits=70000)
 
 

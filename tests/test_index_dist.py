@@ -194,3 +194,116 @@ def test_two_rank_index_broadcast_and_sharded_driver_gloo(tmp_path):
     names = d['names']
     assert sorted(set(names), key=lambda s: int(s[1:])) == ['r%d' % i for i in range(7)]
     assert names == sorted(names, key=lambda s: int(s[1:]))          # input order
+
+
+# ---------------------------------------------------------------- minimap2 index files
+def _py_write_mmi(path, names, contigs, k, w, hashes, positions, offsets, b=6):
+    """an INDEPENDENT writer of minimap2's on-disk index (format v3, index.c mm_idx_dump) from sorted (hash, gpos<<1|strand) columns:
+    test-side restatement of the format, used to feed vm_index_load_mmi something the product did not write itself"""
+    import struct
+    out = [b'MMI\x02', struct.pack('<5I', w, k, b, len(names), 0)]
+    for n, c in zip(names, contigs):
+        out += [struct.pack('<B', len(n)), n.encode(), struct.pack('<I', len(c))]
+    offs = np.asarray(offsets, dtype=np.int64)
+    buckets = [[] for _ in range(1 << b)]
+    for h, p in zip(hashes.tolist(), positions.tolist()):
+        g = p >> 1
+        rid = int(np.searchsorted(offs, g, side='right') - 1)
+        y = (rid << 32) | ((g - int(offs[rid]) + k - 1) << 1) | (p & 1)
+        buckets[h & ((1 << b) - 1)].append((h >> b, y))
+    for bk in buckets:
+        bk.sort()
+        groups = {}
+        for key, y in bk:
+            groups.setdefault(key, []).append(y)
+        p, ent = [], []
+        for key in sorted(groups, reverse=True):           # any entry order is legal: the reader inserts them into a hash table
+            ys = groups[key]
+            if len(ys) == 1:
+                ent.append(((key << 1) | 1, ys[0]))
+            else:
+                ent.append((key << 1, (len(p) << 32) | len(ys))); p += ys
+        out.append(struct.pack('<i', len(p))); out.append(np.asarray(p, dtype=np.uint64).tobytes())
+        out.append(struct.pack('<I', len(ent))); out.append(np.asarray(ent, dtype=np.uint64).tobytes())
+    tot = sum(len(c) for c in contigs)
+    S = np.zeros((tot + 7) // 8, np.uint32)
+    code = np.full(256, 4, np.uint32); code[[65, 67, 71, 84]] = [0, 1, 2, 3]
+    cat = code[np.concatenate([np.asarray(c, dtype=np.uint8) for c in contigs])]
+    for i in range(8):
+        part = cat[i::8]
+        S[:len(part)] |= part << np.uint32(4 * i)
+    out.append(S.tobytes())
+    open(path, 'wb').write(b''.join(out))
+
+
+def _py_read_mmi(path):
+    """independent reader of the same format -> (w, k, names, lens, sorted (hash, gpos<<1|strand) pairs, bases)"""
+    import struct
+    d = open(path, 'rb').read()
+    assert d[:4] == b'MMI\x02'
+    w, k, b, nseq, flag = struct.unpack_from('<5I', d, 4); o = 24
+    names, lens = [], []
+    for _ in range(nseq):
+        l = d[o]; o += 1; names.append(d[o:o + l].decode()); o += l; lens.append(struct.unpack_from('<I', d, o)[0]); o += 4
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    pairs = []
+    for bi in range(1 << b):
+        n, = struct.unpack_from('<i', d, o); o += 4
+        p = np.frombuffer(d, np.uint64, n, o); o += 8 * n
+        size, = struct.unpack_from('<I', d, o); o += 4
+        ent = np.frombuffer(d, np.uint64, 2 * size, o).reshape(-1, 2); o += 16 * size
+        for key, val in ent.tolist():
+            h = ((key >> 1) << b) | bi
+            ys = [val] if key & 1 else p[val >> 32:(val >> 32) + (val & 0xffffffff)].tolist()
+            for y in ys:
+                rid, last, z = y >> 32, (y & 0xffffffff) >> 1, y & 1
+                pairs.append((h, ((int(offs[rid]) + last - (k - 1)) << 1) | z))
+    tot = int(offs[-1])
+    S = np.frombuffer(d, np.uint32, (tot + 7) // 8, o); o += 4 * ((tot + 7) // 8)
+    assert o == len(d)
+    codes = np.stack([(S >> np.uint32(4 * i)) & 15 for i in range(8)], axis=1).reshape(-1)[:tot]
+    bases = np.frombuffer(b'ACGTN', np.uint8)[np.minimum(codes, 4)]
+    return w, k, names, lens, sorted(pairs), bases
+
+
+def test_mmi_reader_writer(ctx, oracle, tmp_path):
+    from vacmap_amd.lib import Index, VmxError
+    from vacmap_amd import synth
+    names, c = _ref(seed=8, lens=(26000, 9000, 700))
+    oi = oracle.Index.from_seqs(names, c, k=15, w=10)
+    oh, op = oi.minimizers()
+    # (1) a file written by the independent test-side writer loads into the same index (hashes re-derived from the sequence agree)
+    p = str(tmp_path / 'ref.fa.w10_k15.mmi')
+    _py_write_mmi(p, names, c, 15, 10, oh, op, oi.offsets)
+    gi = Index.load_mmi(ctx, p)
+    gh, gp = gi.minimizers()
+    assert np.array_equal(gh, oh) and np.array_equal(gp, op) and gi.mid_occ == oi.mid_occ and (gi.k, gi.w, gi.names, gi.lens) == (15, 10, names, [len(x) for x in c])
+    assert gi.seq(1, 2990, 3050) == oi.seq(1, 2990, 3050)                    # the N run survives the 4-bit store
+    rd = synth.mutate(c[0][3000:9000], 0.08, np.random.default_rng(2)).tobytes()
+    assert np.array_equal(ctx.map_batch(gi, [rd])[0], oi.map(rd, 100, -1))
+    # (2) a file written by the product is read back by the independent reader with the same content, and by the product itself
+    q = str(tmp_path / 'out.mmi')
+    built = Index.from_seqs(ctx, names, c, k=15, w=10)
+    built.save_mmi(q)
+    w, k, n2, l2, pairs, bases = _py_read_mmi(q)
+    assert (w, k, n2, l2) == (10, 15, names, [len(x) for x in c])
+    assert pairs == sorted(zip(oh.tolist(), op.tolist()))
+    assert bases.tobytes() == np.concatenate(c).tobytes()
+    again = Index.load_mmi(ctx, q)
+    assert np.array_equal(again.minimizers()[1], op)
+    # (3) a subset of minimizers is a legal index (minimap2's own selection differs at sequence ends): it loads and maps with ITS set
+    keep = np.ones(len(oh), bool); keep[::7] = False
+    _py_write_mmi(p, names, c, 15, 10, oh[keep], op[keep], oi.offsets)
+    sub = Index.load_mmi(ctx, p)
+    assert sub.n_minimizers() == int(keep.sum())
+    # (4) rejected: a hash that is not hash64 of its k-mer, HPC / sequence-less flags, truncation, trailing part
+    bad = oh.copy(); bad[5] ^= 3
+    _py_write_mmi(p, names, c, 15, 10, bad, op, oi.offsets)
+    with pytest.raises(VmxError):
+        Index.load_mmi(ctx, p)
+    raw = bytearray(open(q, 'rb').read())
+    for mut in (lambda x: x.__setitem__(slice(20, 24), (1).to_bytes(4, 'little')), lambda x: x.__setitem__(slice(20, 24), (2).to_bytes(4, 'little')),
+                lambda x: x.__delitem__(slice(len(x) - 40, len(x))), lambda x: x.extend(b'MMI\x02' + b'\0' * 20), lambda x: x.__setitem__(slice(8, 12), (40).to_bytes(4, 'little'))):
+        y = bytearray(raw); mut(y); open(p, 'wb').write(bytes(y))
+        with pytest.raises(VmxError):
+            Index.load_mmi(ctx, p)

@@ -25,9 +25,15 @@ __device__ __forceinline__ vmx_segs vmx_read_segs(const vmx_ext_args& A, int r, 
 // allocate n contiguous problem slots of the current round
 __device__ __forceinline__ int vmx_alloc_probs(const vmx_ext_args& A, int n) {
     if (n <= 0) return 0;
-    int b = atomicAdd(A.round_count, n);
-    if ((long long)b + n > A.round_cap) { atomicExch(A.overflow, 1); return -1; }
-    return b;
+    // compare-and-swap: the published count never passes the capacity, so every later kernel that re-reads it (descriptor lengths, DP
+    // sizes, gather, queue order) stays inside the pools; the read that does not fit is reported (VM_READ_CAPACITY), the batch goes on
+    int old = *(volatile int*)A.round_count;
+    while (true) {
+        if ((long long)old + n > A.round_cap) return -1;
+        const int prev = atomicCAS(A.round_count, old, old + n);
+        if (prev == old) return old;
+        old = prev;
+    }
 }
 
 __global__ void k_ext_phase(vmx_ext_args A, int phase) {
