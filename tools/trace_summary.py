@@ -10,7 +10,7 @@ for b in range(len(idx) - 1):
     print('batch', b, 'span %.1f' % ((seg[-1][1] + seg[-1][2] - t0) / 1e6), ' '.join('%s=%.1f' % (k[2:], v / 1e6) for k, v in sorted(tot.items(), key=lambda x: -x[1])[:10]))
     if len(sys.argv) > 2 and b == int(sys.argv[2]):
         for r in seg:
-            if r[2] > 400000: print('   %-22s start %7.2f dur %6.2f ms grid=%s' % (r[0], (r[1] - t0) / 1e6, r[2] / 1e6, r[3]))
+            if r[2] > 400000 or r[0] in ('k_ext_phase', 'k_ext_records'): print('   %-22s start %7.2f dur %6.2f ms grid=%s' % (r[0], (r[1] - t0) / 1e6, r[2] / 1e6, r[3]))
 # timed batches only (skip the first: warm-up): per-kernel total over them, ms per batch
 tb = range(1, len(idx) - 1); tot = {}; span = 0.0
 for b in tb:
