@@ -134,9 +134,14 @@ int vmo_align_batch(const vmo_index*, const vmo_params* p, int64_t n_reads, cons
 
 /* DP problem recorder: when enabled, every k_cigar_global / k_extend / edit distance call made
  * inside vmo_extend appends (kind, tl, ql) to a log (golden V5) */
+/* golden V4 stage entry (segment surgery, mammap_clrnano.py:23437 / :726 / :16736 / :24226): see vmo_extend.cc */
+int vmo_stage_v4(const vmo_index*, int fn, const int64_t* rows_in, int64_t n_in, int64_t arg, const char* read, int64_t readlen,
+                 int64_t** rows_out, int64_t* n_out, int* ret);
 const char* vmo_last_error(void);
 /* how often GC-fast / LC-fast / LC-mm-fast ran in this process since the last reset (tests: which paths a case exercised) */
 void vmo_fast_counters(int64_t out[3], int reset);
+/* tests: how often the segment surgery took its rare branches: drop_misplaced removals, merges, fix_simple_inv shifts (both branches) */
+void vmo_surgery_counters(int64_t out[4], int reset);
 
 #ifdef __cplusplus
 }

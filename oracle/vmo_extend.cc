@@ -25,6 +25,7 @@
 namespace vmo {
 
 thread_local std::vector<DpCall>* g_dplog = nullptr;
+static std::atomic<int64_t> g_surgery[4];     // tests: drop_misplaced removals, merges, fix_simple_inv shifts (left / right branch)
 
 typedef std::vector<Anchor> Seg;
 
@@ -192,6 +193,7 @@ static bool drop_misplaced_alignment_test(std::vector<Seg>& al, int64_t iloc) {
                 int64_t gap_2 = std::llabs(readgap - refgap);
                 if (DEL == 1 && INS == 1 && (mid_size < 500 || ((double)std::max(gap_1, gap_2) / (double)mid_size) > 0.5)) {
                     al.erase(al.begin() + iloc + 1);
+                    g_surgery[0].fetch_add(1);
                     return true;
                 }
             }
@@ -247,6 +249,7 @@ static void merge_conjacent_alignment(const vmo_index* mi, std::vector<Seg>& al)
             if (pre.s == 1) refgap = now.r - pre.r - pre.l; else refgap = pre.r - now.r - now.l;
             if (refgap < 0) { iloc += 1; continue; }
             if (std::min(readgap, refgap) < 50 && std::llabs(readgap - refgap) < 10000) {
+                g_surgery[1].fetch_add(1);
                 al[iloc].insert(al[iloc].end(), al[iloc + 1].begin(), al[iloc + 1].end());   // List_merge :283
                 al.erase(al.begin() + iloc + 1);
             } else iloc += 1;
@@ -280,6 +283,7 @@ static int fix_simple_inv(const vmo_index* mi, std::vector<Seg>& al, const std::
                                 std::string tempref = revcomp(pyslice(cs, refen_1, refen_1 + refen_0 - refst_1));
                                 std::string tempquery = pyslice(read, readen_0 - refen_0 + refst_1, readen_0);
                                 if (tempref == tempquery) {
+                                    g_surgery[2].fetch_add(1);
                                     int64_t b = refen_0 - refst_1;
                                     al[iloc + 2][0] = Anchor{readst_2 - b, refst_2 - b + bias, 1, 0};
                                     Anchor ins{readst_2 - b, refen_0 + bias, -1, 0};
@@ -293,6 +297,7 @@ static int fix_simple_inv(const vmo_index* mi, std::vector<Seg>& al, const std::
                                 std::string tempref = pyslice(cs, refen_0, refen_0 - refen_0 + refst_1);
                                 std::string tempquery = pyslice(read, readen_0, readen_0 - refen_0 + refst_1);
                                 if (tempref == tempquery) {
+                                    g_surgery[3].fetch_add(1);
                                     al[iloc].back() = Anchor{readen_0 - refen_0 + refst_1, refen_0 - refen_0 + refst_1 + bias, 1, 0};
                                     Anchor ins{readen_0 - refen_0 + refst_1, refen_1 + refen_0 - refst_1 + bias, -1, 0};
                                     while (true) {
@@ -440,6 +445,41 @@ bool pairedindel(const std::vector<std::string>& cigars, double indelsize) {
     }
     return false;
 }
+
+}  // namespace vmo
+
+extern "C" void vmo_surgery_counters(int64_t out[4], int reset) {
+    for (int i = 0; i < 4; ++i) { out[i] = vmo::g_surgery[i].load(); if (reset) vmo::g_surgery[i].store(0); }
+}
+
+// Stage entry for golden vectors V4 (segment surgery): rows are (segment index, q, r, s, l).
+//   fn 0 rebuild_chain_break(raw chain; arg = large_cost)   fn 1 drop_misplaced_alignment_test(segments; arg = iloc) -> *ret = removed
+//   fn 2 merge_conjacent_alignment (getdupiloc inside)      fn 3 fix_simple_inv(segments, read; arg = 1 for mode R)
+// returns 0, or the negative code of the condition under which the reference raises
+extern "C" int vmo_stage_v4(const vmo_index* mi, int fn, const int64_t* rows_in, int64_t n_in, int64_t arg, const char* read, int64_t readlen,
+                            int64_t** rows_out, int64_t* n_out, int* ret) {
+    using namespace vmo;
+    std::vector<Seg> al;
+    for (int64_t i = 0; i < n_in; ++i) {
+        const int64_t* r = rows_in + 5 * i;
+        if ((int64_t)al.size() <= r[0]) al.resize((size_t)r[0] + 1);
+        al[(size_t)r[0]].push_back(Anchor{r[1], r[2], r[3], r[4]});
+    }
+    int rc = 0; *ret = 0;
+    if (fn == 0) { Path raw = al.empty() ? Path() : al[0]; std::vector<Seg> out; rc = raw.empty() ? -1 : rebuild_chain_break(mi, raw, arg, 50, out); al.swap(out); }
+    else if (fn == 1) *ret = drop_misplaced_alignment_test(al, arg) ? 1 : 0;
+    else if (fn == 2) merge_conjacent_alignment(mi, al);
+    else if (fn == 3) rc = fix_simple_inv(mi, al, std::string(read, (size_t)readlen), arg != 0);
+    else return -1;
+    size_t tot = 0; for (auto& sg : al) tot += sg.size();
+    int64_t* o = (int64_t*)malloc(sizeof(int64_t) * 5 * (tot ? tot : 1));
+    size_t x = 0;
+    for (size_t si = 0; si < al.size(); ++si) for (const Anchor& a : al[si]) { o[5 * x] = (int64_t)si; o[5 * x + 1] = a.q; o[5 * x + 2] = a.r; o[5 * x + 3] = a.s; o[5 * x + 4] = a.l; ++x; }
+    *rows_out = o; *n_out = (int64_t)tot;
+    return rc;
+}
+
+namespace vmo {
 
 // extend_func :19238-19303
 int extend_func(const vmo_index* mi, const std::string& read, const std::string& rc, Path chain_asc, int mapq,

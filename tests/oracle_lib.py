@@ -66,6 +66,7 @@ def lib():
     L.vmo_sketch.argtypes = [cp, i64, C.c_int, C.c_int, vp, vp, vp]; L.vmo_sketch.restype = i64
     L.vmo_map.argtypes = [vp, cp, i64, C.c_int, C.c_int, P(P(i64))]; L.vmo_map.restype = i64
     L.vmo_free.argtypes = [vp]
+    L.vmo_stage_v4.argtypes = [vp, C.c_int, vp, i64, i64, cp, i64, P(P(i64)), P(i64), P(C.c_int)]
     L.vmo_k_cigar_global.argtypes = [cp, i64, cp, i64] + [C.c_int] * 7 + [P(vp), P(i32)]
     L.vmo_k_extend.argtypes = [cp, i64, cp, i64] + [C.c_int] * 6 + [P(i32), P(i32)]
     L.vmo_edit_distance.argtypes = [cp, i64, cp, i64]; L.vmo_edit_distance.restype = i64
@@ -287,6 +288,17 @@ def align_batch(index, reads, prm, nthreads=1):
     return status, _take_records(recs, n.value, blob)
 
 
+def stage_v4(index, fn, rows, arg=0, read=b''):
+    """golden V4 stage entry: rows (n, 5) int64 = (segment, q, r, s, l); returns (rc, ret, rows out)"""
+    rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1, 5)
+    out = C.POINTER(C.c_int64)(); n = C.c_int64(); ret = C.c_int()
+    rd = _b(read)
+    rc = lib().vmo_stage_v4(index.h, fn, rows.ctypes.data, len(rows), int(arg), rd, len(rd), C.byref(out), C.byref(n), C.byref(ret))
+    a = np.ctypeslib.as_array(out, shape=(max(n.value, 1), 5))[:n.value].copy()
+    lib().vmo_free(out)
+    return rc, ret.value, a
+
+
 def table(which):
     ptr = C.c_void_p()
     n = lib().vmo_table(which, C.byref(ptr))
@@ -298,6 +310,13 @@ def fast_counters(reset=False):
     """(GC-fast, LC-fast, LC-mm-fast) call counts of this process since the last reset"""
     out = (C.c_int64 * 3)()
     lib().vmo_fast_counters(out, 1 if reset else 0)
+    return tuple(out)
+
+
+def surgery_counters(reset=False):
+    """(drop_misplaced removals, merges, fix_simple_inv shifts of the left / right breakpoint) of this process since the last reset"""
+    out = (C.c_int64 * 4)()
+    lib().vmo_surgery_counters(out, 1 if reset else 0)
     return tuple(out)
 
 

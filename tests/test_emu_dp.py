@@ -60,6 +60,8 @@ def test_emu_local(ctx, oracle, golden):
 def test_emu_align_end_to_end(ctx, oracle, golden):
     KC.check_align_golden(ctx, oracle, golden, cases=['B'], reads=[0, 1, 2])
     KC.check_align_golden(ctx, oracle, golden, cases=['D'])
+    KC.check_align_golden(ctx, oracle, golden, cases=['I'], reads=[0, 3])     # fix_simple_inv shift, drop_misplaced removal
+    KC.check_align_golden(ctx, oracle, golden, cases=['H'], reads=[3])        # nested SVs from the vacsim-grammar donor, mode R
 
 
 def test_emu_chain_global_fast(ctx, oracle):

@@ -4,7 +4,9 @@ import hashlib, json, os, zlib
 import numpy as np
 import pytest
 
-CASES = ['A', 'B', 'C', 'D', 'E', 'F', 'G']     # E, F: repeat-dense reads that take the *_fast chain variants (G3, L5); G: mode R
+CASES = ['A', 'B', 'C', 'D', 'E', 'F', 'G', 'H', 'I']     # E, F: repeat-dense reads that take the *_fast chain variants (G3, L5); G: mode R;
+                                                       # H: mode R on a donor made by the vacsim-grammar implanter (nested INV / DUP / TRA, BASELINE configs[4])
+                                                       # I: inputs that drive the rare branches of the segment surgery (V4)
 
 
 def _index(O, meta, arrays, cid):
@@ -122,6 +124,56 @@ def test_v5_v6_records_and_dp_problems(oracle, golden, cid):
         assert got == r['v6_records'], (cid, ri)
         dp = [[kd, len(t), len(q), zlib.crc32(t.encode()), zlib.crc32(q.encode())] for kd, t, q in calls]
         assert dp == r['v5'], (cid, ri)
+
+
+_V4_FN = {'rebuild_chain_break': 0, 'drop_misplaced_alignment_test': 1, 'merge_conjacent_alignment': 2, 'fix_simple_inv': 3}
+
+
+@pytest.mark.parametrize('cid', ['A', 'B', 'C', 'D', 'G', 'H', 'I'])
+def test_v4_segment_surgery(oracle, golden, cid):
+    """stage vectors V4: every call the reference made to rebuild_chain_break (:23437), drop_misplaced_alignment_test (:726),
+    merge_conjacent_alignment (:16736, getdupiloc_numba :16680 inside) and fix_simple_inv (:24226) while aligning the read — the oracle's
+    functions reproduce each output from the captured input, so a surgery bug is localised to its function"""
+    meta, arrays = golden
+    c = meta[cid]
+    ix = _index(oracle, meta, arrays, cid)
+    ncall = {k: 0 for k in _V4_FN}
+    for ri, r in enumerate(c['reads']):
+        seq = _seq(arrays, cid, ri)
+        need_rev = r.get('v2_score', 0) < 0
+        rd = seq if not need_rev else seq.encode().translate(bytes.maketrans(b'ACGTN', b'TGCAN'))[::-1].decode()
+        for e in r.get('v4', []):
+            if 'in' not in e:
+                continue
+            fn = _V4_FN[e['fn']]
+            arg = e.get('large_cost', 0) if fn == 0 else (e.get('iloc', 0) if fn == 1 else (1 if c['mode'] == 'R' else 0))
+            rc, ret, out = oracle.stage_v4(ix, fn, arrays[e['in']], arg=arg, read=rd)
+            assert rc == 0, (cid, ri, e['fn'])
+            assert np.array_equal(out, arrays[e['out']].reshape(-1, 5)), (cid, ri, e['fn'], e.get('iloc'))
+            if fn == 1:
+                assert bool(ret) == e['removed']
+            ncall[e['fn']] += 1
+    assert ncall['rebuild_chain_break'] >= len([r for r in c['reads'] if r['v6_records']]) and ncall['fix_simple_inv'] >= 1
+
+
+def test_v4_covers_every_branch(golden):
+    """the captured calls exercise what they are meant to pin: at least one drop_misplaced removal, one merge that merges, one
+    fix_simple_inv that moves a breakpoint"""
+    meta, arrays = golden
+    seen = {'drop': 0, 'merge': 0, 'fix': 0}
+    for cid in ('A', 'B', 'C', 'D', 'G', 'H', 'I'):
+        for r in meta[cid]['reads']:
+            for e in r.get('v4', []):
+                if 'in' not in e:
+                    continue
+                changed = not np.array_equal(arrays[e['in']], arrays[e['out']])
+                if e['fn'] == 'drop_misplaced_alignment_test' and e['removed']:
+                    seen['drop'] += 1
+                if e['fn'] == 'merge_conjacent_alignment' and changed:
+                    seen['merge'] += 1
+                if e['fn'] == 'fix_simple_inv' and changed:
+                    seen['fix'] += 1
+    assert seen['drop'] >= 3 and seen['merge'] >= 1 and seen['fix'] >= 3, seen
 
 
 def test_testdata_three_alignments(oracle, golden):

@@ -5,6 +5,8 @@ Vectors:
   V1 get_reversed_chain_numpy_rough      anchors -> (flag, anchors)
   V2 hit2work_1 / decode_hit             anchors -> paths, scores, mapq, secondaries; raw S, P, S_arg of GC-exact
   V3 ..._guide_list                      guide paths + read -> raw local anchors (argument of the LC DP), (score, path)
+  V4 segment surgery                     rebuild_chain_break :23437, drop_misplaced_alignment_test :726, merge_conjacent_alignment :16736 (+ getdupiloc_numba
+                                         :16680 inside it), fix_simple_inv :24226 — segment lists in / out of every call the read makes
   V5 DP problem list                     every k_cigar / edlib call the reference makes for the read (kind, |t|, |q|, crc)
   V6 get_readmap_DP_test                 read -> onemapinfolist 9-tuples (the record type of the path)
   V7 tests/test_nm_from_cigar.py         the reference's 9 known-answer triples for nm_from_cigar
@@ -24,11 +26,24 @@ from vacmap_amd import synth
 GOLD = os.path.join(_ROOT, 'tests', 'golden')
 
 
+VACSIM_TEXT_H = """Specified{INV:300:600,DUP:300:600:1:2,TRA:400:800:1;number=2}
+Specified{DEL:100:200,INS:100:400,INV:300:500,DUP:300:500:0:3,TRA:400:800:0;number=1}
+Specified{INV:400:800,NML:100:200,INV:400:800;number=1}
+Random{eventset=["DEL:100:200,INV:300:600","INS:100:300,NML:100:200","DUP:300:600","TRA:400:800"];eventcount=[2,6];number=2}
+"""
+
+
 def rows(x):
     return [[int(v) for v in r] for r in x]
 
 
-def run_case(cid, mode, names, contigs, reads, k, arrays, meta):
+def seg_rows(al):
+    """list of segments (lists of 4-tuples) -> int64 rows (segment index, q, r, s, l)"""
+    out = [[si, int(a[0]), int(a[1]), int(a[2]), int(a[3])] for si, seg in enumerate(al) for a in seg]
+    return np.array(out, dtype=np.int64).reshape(-1, 5)
+
+
+def run_case(cid, mode, names, contigs, reads, k, arrays, meta, v4=False):
     ix = O.Index.from_seqs(names, contigs, k=k, w=10)
     al = refrun.Aligner(oracle_index=ix)
     ctx = refrun.RefContext(mode, al)
@@ -100,9 +115,54 @@ def run_case(cid, mode, names, contigs, reads, k, arrays, meta):
             return f
         for n in names_fast:
             setattr(m, n, mkf(n))
+        # V4: every call of the segment-surgery functions during the read's extend_func run(s) (:19238; a second run follows with
+        # nofilter when pairedindel fires, :24079-24080): inputs and outputs as segment-row arrays
+        v4log = []
+        v4orig = {n: getattr(m, n) for n in ('rebuild_chain_break', 'drop_misplaced_alignment_test', 'merge_conjacent_alignment', 'fix_simple_inv')} if v4 else {}
+        if v4:
+            def put(tag, al):
+                kk = '%s_v4_%d_%s' % (key, len(v4log), tag)
+                arrays[kk] = seg_rows(al)
+                return kk
+
+            def w_rebuild(contig2start, raw, **kw):
+                e = {'fn': 'rebuild_chain_break', 'large_cost': int(kw.get('large_cost', 0))}
+                e['in'] = put('in', [list(raw)])
+                out = v4orig['rebuild_chain_break'](contig2start, raw, **kw)
+                e['out'] = put('out', out); v4log.append(e)
+                return out
+
+            def w_drop(al, iloc, **kw):
+                snap = [list(x) for x in al]
+                rem = v4orig['drop_misplaced_alignment_test'](al, iloc, **kw)
+                first = not any(x['fn'] == 'drop_misplaced_alignment_test' and x['run'] == sum(1 for y in v4log if y['fn'] == 'rebuild_chain_break') for x in v4log)
+                e = {'fn': 'drop_misplaced_alignment_test', 'iloc': int(iloc), 'removed': bool(rem), 'run': sum(1 for y in v4log if y['fn'] == 'rebuild_chain_break')}
+                if rem or first:         # snapshots only where something happens (and once per run, to pin the state the loop starts from)
+                    e['in'] = put('in', snap); e['out'] = put('out', al)
+                v4log.append(e)
+                return rem
+
+            def w_merge(al, contig2start):
+                e = {'fn': 'merge_conjacent_alignment'}
+                e['in'] = put('in', al)
+                v4orig['merge_conjacent_alignment'](al, contig2start)
+                e['out'] = put('out', al); v4log.append(e)
+
+            def w_fix(al, contig2start, contig2seq, testseq):
+                e = {'fn': 'fix_simple_inv'}
+                e['in'] = put('in', al)
+                v4orig['fix_simple_inv'](al, contig2start, contig2seq, testseq)
+                e['out'] = put('out', al); v4log.append(e)
+            m.rebuild_chain_break, m.drop_misplaced_alignment_test, m.merge_conjacent_alignment, m.fix_simple_inv = w_rebuild, w_drop, w_merge, w_fix
         refrun.DPLOG = []
-        st, one = ctx.align(rname, seq)
+        try:
+            st, one = ctx.align(rname, seq)
+        finally:
+            for n, f in v4orig.items():
+                setattr(m, n, f)
         dplog = refrun.DPLOG; refrun.DPLOG = None
+        if v4:
+            rec['v4'] = v4log
         for n in names_lc:
             if n:
                 setattr(m, n, orig[n])
@@ -140,7 +200,7 @@ def main():
     # case A: the reference's testdata (config 1)
     ref = refrun.read_fasta('/root/reference/testdata/reference.fasta')
     rds = refrun.read_fasta('/root/reference/testdata/read.fasta')
-    run_case('A', 'H', [n for n, _ in ref], [s.upper() for _, s in ref], [(n, s.upper()) for n, s in rds], 15, arrays, meta)
+    run_case('A', 'H', [n for n, _ in ref], [s.upper() for _, s in ref], [(n, s.upper()) for n, s in rds], 15, arrays, meta, v4=True)
     # case B: ONT-shape reads from an SV donor (mode H)
     L = 120000
     contigs = synth.make_reference([L, 40000], seed=101)
@@ -149,10 +209,10 @@ def main():
     d0 = synth.implant_svs(contigs[0], ops)
     d0 = np.concatenate([d0[:105000], contigs[1][2000:5000], d0[105000:]])
     rB = synth.sample_reads([d0, contigs[1]], 8, mean_len=7000, err=0.10, seed=102, shape='ont', min_len=2000, max_len=12000)
-    run_case('B', 'H', ['chrA', 'chrB'], [synth.tostr(c) for c in contigs], [(n, synth.tostr(s)) for n, s, _ in rB], 15, arrays, meta)
+    run_case('B', 'H', ['chrA', 'chrB'], [synth.tostr(c) for c in contigs], [(n, synth.tostr(s)) for n, s, _ in rB], 15, arrays, meta, v4=True)
     # case C: HiFi-shape reads (mode L, k=19)
     rC = synth.sample_reads([d0, contigs[1]], 5, mean_len=8000, err=0.005, seed=103, shape='hifi', min_len=4000, sd=1500)
-    run_case('C', 'L', ['chrA', 'chrB'], [synth.tostr(c) for c in contigs], [(n, synth.tostr(s)) for n, s, _ in rC], 19, arrays, meta)
+    run_case('C', 'L', ['chrA', 'chrB'], [synth.tostr(c) for c in contigs], [(n, synth.tostr(s)) for n, s, _ in rC], 19, arrays, meta, v4=True)
     # case D: chimeras, repeats, unmappable, short and N-bearing reads (mode H)
     rng = np.random.default_rng(104)
     c0 = contigs[0].copy()
@@ -168,7 +228,7 @@ def main():
     rD.append(('withN', wn))
     tandem = synth.mutate(c0[59000:63500], 0.08, rng)
     rD.append(('tandem0', tandem))
-    run_case('D', 'H', ['chrA', 'chrB'], [synth.tostr(c0), synth.tostr(contigs[1])], [(n, synth.tostr(s)) for n, s in rD], 15, arrays, meta)
+    run_case('D', 'H', ['chrA', 'chrB'], [synth.tostr(c0), synth.tostr(contigs[1])], [(n, synth.tostr(s)) for n, s in rD], 15, arrays, meta, v4=True)
     # cases E (mode L) and F (mode H): repeat-dense reads that drive the *_fast chain variants (G3, L5): a 2.5 kb element in 64 copies
     # (GC-fast: more than 5 anchors per read base), a period-29 tandem array with a diverged second copy on the other contig
     # (more than one guide chain + dense local anchors: LC-mm-fast) and a period-23 array without a copy (LC-fast)
@@ -199,7 +259,43 @@ def main():
     lG = [(n_, synth.tostr(s_)) for n_, s_, _ in rG]
     lG.append(('chimR', synth.tostr(np.concatenate([rG[0][1][:2500], synth.revcomp(rG[1][1][:2500])]))))
     lG.append(('randR', synth.tostr(synth.make_reference([2500], seed=131)[0])))
-    run_case('G', 'R', ['chrA', 'chrB'], [synth.tostr(c) for c in contigs], lG, 15, arrays, meta)
+    run_case('G', 'R', ['chrA', 'chrB'], [synth.tostr(c) for c in contigs], lG, 15, arrays, meta, v4=True)
+    # case H: BASELINE configs[4] shape — a donor made by the vacsim-GRAMMAR implanter (vacmap_amd/vacsim.py: Specified{} / Random{} lines with nested
+    # INV, DUP:..:rev:times, TRA between the two contigs, NML spacers), reads across the implanted complex SVs on both strands, mode R
+    from vacmap_amd import vacsim
+    hc = synth.make_reference([150000, 90000], seed=141)
+    donorH, piecesH, eventsH = vacsim.implant(hc, VACSIM_TEXT_H, seed=7)
+    rngH = np.random.default_rng(142)
+    lH = []
+    for ei in range(0, len(eventsH), max(1, len(eventsH) // 7)):
+        ev = eventsH[ei]; ci = ev['contig']
+        dpos = [ds + ev['start'] - ss for ds, de, sc, ss, se, stx in piecesH[ci] if sc == ci and stx > 0 and ss <= ev['start'] <= se]
+        if not dpos:
+            continue
+        a = max(0, dpos[0] - 3500); b = min(len(donorH[ci]), dpos[0] + 4500)
+        frag = donorH[ci][a:b]
+        if len(lH) % 2:
+            frag = synth.revcomp(frag)
+        lH.append(('sv%d_%s' % (ev['sv'], ev['type']), synth.tostr(synth.mutate(frag, 0.06, rngH))))
+    run_case('H', 'R', ['chrA', 'chrB'], [synth.tostr(c) for c in hc], lH, 15, arrays, meta, v4=True)
+    meta['H']['vacsim_text'] = VACSIM_TEXT_H; meta['H']['vacsim_seed'] = 7; meta['H']['ref_seed'] = 141
+    # case I: inputs built to drive the rare branches of the segment surgery (V4): inversions whose breakpoints carry a 6 / 9 / 12 bp
+    # inverted repeat (fix_simple_inv :24226 shifts the breakpoints across the micro-homology) and small segments copied from 1.5-4 kb
+    # downstream between paired DEL / INS (drop_misplaced_alignment_test :726 removes them)
+    ri_ = synth.make_reference([200000], seed=151)[0]
+    rngI = np.random.default_rng(152)
+    sites = [(60000 + 7000 * b, 3000, b) for b in (6, 9, 12)]
+    for p_, ml_, b_ in sites:
+        ri_[p_ + ml_ - b_:p_ + ml_] = synth.revcomp(ri_[p_:p_ + b_])
+    lI = []
+    for p_, ml_, b_ in sites:
+        don = np.concatenate([ri_[:p_], synth.revcomp(ri_[p_:p_ + ml_]), ri_[p_ + ml_:]])
+        lI.append(('inv_ir%d' % b_, synth.tostr(synth.mutate(don[p_ - 4000:p_ + ml_ + 4000], 0.005, rngI))))
+    for sz_, sh_ in ((300, 2500), (450, 4000), (700, 1500)):
+        p_ = 30000
+        don = np.concatenate([ri_[:p_], ri_[p_ + sh_:p_ + sh_ + sz_], ri_[p_ + 400:]])
+        lI.append(('misplaced%d' % sz_, synth.tostr(synth.mutate(don[p_ - 5000:p_ + sz_ + 5000], 0.03, rngI))))
+    run_case('I', 'H', ['chrA'], [synth.tostr(ri_)], lI, 15, arrays, meta, v4=True)
     # V7: the reference's own known-answer tests for nm_from_cigar (tests/test_nm_from_cigar.py) — evaluate the inputs of each
     # test through the reference function and store (cigar, query, ref, expected NM)
     of = refrun.refload.load_output_functions()

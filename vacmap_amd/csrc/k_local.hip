@@ -56,9 +56,9 @@ __global__ void k_local_prep(const vmx_anchor* __restrict__ path_rows, const int
 
 // ------------------------------------------------------------------------------------------------ L2 seeding
 __device__ __forceinline__ int vmx_pos2contig(const int64_t* __restrict__ coff, int nseq, long long pos) {   // :51-59
-    int pre = 0;
-    for (int c = 0; c < nseq; ++c) { if (pos < coff[c]) break; pre = c; }
-    return pre;
+    int lo = 0, hi = nseq;                        // bisection: same index as the reference's linear scan of the contig starts
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (coff[mid] <= pos) lo = mid; else hi = mid; }
+    return lo;
 }
 
 // findClosest_1 :17560-17582 on the guide sorted by read position (gq ascending)

@@ -220,12 +220,34 @@ __device__ __forceinline__ void vmx_cluster_body(uint64_t* __restrict__ keys, ui
         // emit: exclusive scan of kept cluster sizes gives the output offset of each cluster
         int64_t* out = rows + 4 * key_off[r];
         int outbase = 0;
+        if (keep <= tile) {
+            // (offset, start) of every kept cluster parked in LDS (the sort tile is idle now), then ALL threads copy hits: element e belongs
+            // to the last cluster whose offset is <= e. One thread per cluster would leave the true locus (hundreds of hits) to a single lane.
+            for (int c0 = 0; c0 < keep; c0 += (int)blockDim.x) {
+                int c = c0 + (int)threadIdx.x;
+                int sz = 0, st = 0;
+                if (c < keep) { uint64_t kk = CK[c]; sz = (int)(0xffffffffu - (uint32_t)(kk >> 32)); st = (int)(kk & 0xffffffffu); }
+                int tot; int ex = vmx_block_excl_scan(sz, s_scan, &tot);
+                if (c < keep) s_sort[c] = ((uint64_t)(uint32_t)(outbase + ex) << 32) | (uint32_t)st;
+                outbase += tot;
+                __syncthreads();
+            }
+            for (int e = (int)threadIdx.x; e < outbase; e += (int)blockDim.x) {
+                int lo = 0, hi = keep;
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)(s_sort[mid] >> 32) <= e) lo = mid; else hi = mid; }
+                const uint64_t ce = s_sort[lo];
+                const uint64_t hk = K[(int)(ce & 0xffffffffu) + (e - (int)(ce >> 32))];
+                int64_t* o = out + 4 * (int64_t)e;
+                o[0] = (int64_t)((hk >> 1) & 0x7ffffffULL); o[1] = (int64_t)(hk >> 28); o[2] = (hk & 1) ? 1 : -1; o[3] = kmer;
+            }
+            __syncthreads();
+        } else
         for (int c0 = 0; c0 < keep; c0 += (int)blockDim.x) {
             int c = c0 + (int)threadIdx.x;
             int sz = 0, st = 0;
             if (c < keep) { uint64_t kk = CK[c]; sz = (int)(0xffffffffu - (uint32_t)(kk >> 32)); st = (int)(kk & 0xffffffffu); }
             int tot; int ex = vmx_block_excl_scan(sz, s_scan, &tot);
-            // each thread copies its own cluster (clusters are few and mostly small; the big one is the true locus)
+            // each thread copies its own cluster
             for (int e = 0; e < sz; ++e) {
                 uint64_t hk = K[st + e];
                 int64_t* o = out + 4 * (int64_t)(outbase + ex + e);

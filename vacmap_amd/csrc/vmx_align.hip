@@ -7,6 +7,8 @@
 #include "vmx_select.h"
 #include "vmx_ext_state.h"
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 using namespace vmx;
@@ -417,6 +419,15 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
             if (hipEventElapsedTime(&ms, ke[1], ke[2]) == hipSuccess) st.ms_gapfill_trace += ms;
             st.n_gapfill_launches++;
         }
+    if (stats) *stats = st;
+    if (getenv("VMX_DBG_POOLS")) {      // tuning aid: which grow-only pools hold the context's HBM (index in declaration order of vmx_batch_bufs / vmx_local_bufs)
+        const DevBuf* bb = (const DevBuf*)&B; size_t tot = 0;
+        for (size_t i = 0; i < sizeof(B) / sizeof(DevBuf); ++i) { tot += bb[i].cap; if (bb[i].cap > ((size_t)128 << 20)) fprintf(stderr, "[pools] batch[%zu] %.2f GB\n", i, bb[i].cap / 1e9); }
+        fprintf(stderr, "[pools] batch bufs total %.2f GB\n", tot / 1e9);
+        const DevBuf* lb = (const DevBuf*)&L; size_t lt = 0; const size_t nl = (size_t)((const char*)&L.la_pool_rows - (const char*)&L) / sizeof(DevBuf);
+        for (size_t i = 0; i < nl; ++i) { lt += lb[i].cap; if (lb[i].cap > ((size_t)128 << 20)) fprintf(stderr, "[pools] local[%zu] %.2f GB\n", i, lb[i].cap / 1e9); }
+        fprintf(stderr, "[pools] local bufs total %.2f GB\n", lt / 1e9);
+    }
     if (stats) *stats = st;
     return VM_OK;
 }

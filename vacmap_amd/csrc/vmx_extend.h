@@ -25,10 +25,12 @@ struct vmx_ref_view { const uint8_t* codes; const int64_t* coff; int nseq; };
 // per-read segment list: segment s = A[st[s] .. en[s]) ; every segment keeps one spare slot before and after it
 struct vmx_segs { vmx_anchor* A; int32_t* st; int32_t* en; int32_t nseg; int32_t capA; int32_t capS; };
 
+// pos2contig (:51-59): the last contig whose start is <= pos (0 when pos lies before the first). The reference scans the contig
+// starts linearly; a bisection gives the same index with 5 instead of 24 dependent loads on an hg38-size contig table.
 __host__ __device__ inline int vmx_p2c(const vmx_ref_view& R, long long pos) {
-    int pre = 0;
-    for (int c = 0; c < R.nseq; ++c) { if (pos < R.coff[c]) break; pre = c; }
-    return pre;
+    int lo = 0, hi = R.nseq;                      // invariant: coff[lo] <= pos (or lo == 0), coff[hi] > pos (or hi == nseq)
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (R.coff[mid] <= pos) lo = mid; else hi = mid; }
+    return lo;
 }
 __host__ __device__ inline long long vmx_clampll(long long v, long long lo, long long hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __host__ __device__ inline vmx_anchor vmx_mk(long long q, long long r, int s, int l) { vmx_anchor a; a.q = (int32_t)q; a.r = r; a.s = (int16_t)s; a.l = (int16_t)l; return a; }
