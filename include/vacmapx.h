@@ -221,6 +221,15 @@ void vm_reads_free(vm_reads*);
 int vm_align_resident(vm_ctx*, const vm_index*, const vm_params*, const vm_reads*, vm_record** recs, int64_t* n_recs,
                       char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats);
 
+/* Diagnostic for the stage tests of the extend phase (E1 / E3 / E4): runs vm_align_batch's path and returns every read's segment lists
+ * as they stand, in the first (filtering) run of extend_func (:19238), after
+ *   stage 0  rebuild_chain_break (:23437)
+ *   stage 3  divergence filter, both rounds of extend_edge_test (:2302) and the drop_misplaced_alignment_test loop (:726)
+ *   stage 5  merge_conjacent_alignment (:16736) and fix_simple_inv (:24226)
+ * rows: int64 (segment index, q, r, s, l) concatenated over the reads, row_off[n + 1] (both vm_free). Reads without a local chain have none. */
+int vm_align_trace(vm_ctx*, const vm_index*, const vm_params*, int64_t n_reads, const char* seqs, const int64_t* offsets, int stage,
+                   int64_t** rows, int64_t** row_off);
+
 /* cost tables C0 as uploaded to the device (tests): which = 0 extra,1 readgap_h,2 readgap_r,3 large_readgap (f32),
  * 4 log2cache, 5 log2int (f64). returns length, *data = host copy read back FROM THE DEVICE (vm_free) */
 int64_t vm_table(vm_ctx*, int which, void** data);

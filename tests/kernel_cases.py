@@ -430,3 +430,58 @@ def check_local_golden(ctx, O, golden, cases=('A', 'B', 'C', 'D')):
                     assert len(g['raw']) == r['v3_raw_n'] and zlib.crc32(np.ascontiguousarray(g['raw'].astype(np.int64)).tobytes()) == r['v3_raw_crc'], key + ' raw vs golden'
                 assert g['variant'] == r['v3_variant'] and g['score'] == r['v3_score'], key
                 assert np.array_equal(g['chain'], arrays[key + '_v3_path'].reshape(-1, 4)), key + ' chain vs golden'
+
+
+def _end_markers(rows):
+    """segment lists with the first and last anchor of every segment written as zero-length end markers — (q, r or r + l on the '-'
+    strand, s, 0) and (q + l, r + l or r on the '-' strand, s, 0): the form split_alignment_test (:21530-21547) gives the last anchor and
+    the kernel of stage 5 gives both ends in place. Same end points, comparable lists."""
+    rows = np.array(rows, dtype=np.int64).reshape(-1, 5).copy()
+    for sg in np.unique(rows[:, 0]):
+        ix = np.nonzero(rows[:, 0] == sg)[0]
+        a, b = ix[0], ix[-1]
+        _, q, r, st, ln = rows[b]
+        rows[b] = (sg, q + ln, r + ln if st == 1 else r, st, 0)
+        if a != b:
+            _, q, r, st, ln = rows[a]
+            rows[a] = (sg, q, r if st == 1 else r + ln, st, 0)
+    return rows
+
+
+def check_stage_trace_golden(ctx, O, golden, cases=('A', 'B', 'I'), reads=None):
+    """E1 / E3 / E4 stage by stage (golden V4): the product's segment lists after rebuild_chain_break, after the extension rounds + the
+    drop_misplaced loop, and after merge_conjacent + fix_simple_inv (vm_align_trace) equal what the REFERENCE held at those points"""
+    from vacmap_amd.lib import align_trace
+    meta, arrays = golden
+    checked = {0: 0, 3: 0, 5: 0}
+    for cid in cases:
+        c = meta[cid]
+        gi, _ = _case_index(ctx, O, meta, arrays, cid)
+        prm = ctx.lib.params(c['mode'])
+        sel = [ri for ri in range(len(c['reads'])) if reads is None or ri in reads]
+        seqs = [arrays['%s_r%d_seq' % (cid, ri)].tobytes().decode() for ri in sel]
+        got = {st: align_trace(ctx, gi, prm, seqs, st) for st in (0, 3, 5)}
+        for x, ri in enumerate(sel):
+            v4 = c['reads'][ri].get('v4', [])
+            if not v4:
+                assert all(len(got[st][x]) == 0 for st in (0, 3, 5)), (cid, ri)
+                continue
+            run0 = []
+            for e in v4:                                     # the first extend_func run = everything before a second rebuild_chain_break
+                if e['fn'] == 'rebuild_chain_break' and run0:
+                    break
+                run0.append(e)
+            exp0 = arrays[run0[0]['out']].reshape(-1, 5)
+            assert np.array_equal(got[0][x], exp0), (cid, ri, 'rebuild_chain_break')
+            checked[0] += 1
+            merge = [e for e in run0 if e['fn'] == 'merge_conjacent_alignment']
+            fix = [e for e in run0 if e['fn'] == 'fix_simple_inv']
+            drops = [e for e in run0 if e['fn'] == 'drop_misplaced_alignment_test' and e['removed']]
+            if drops or merge:
+                exp3 = arrays[(drops[-1]['out'] if drops else merge[0]['in'])].reshape(-1, 5)
+                assert np.array_equal(got[3][x], exp3), (cid, ri, 'extension + drop_misplaced')
+                checked[3] += 1
+            if fix:
+                assert np.array_equal(_end_markers(got[5][x]), _end_markers(arrays[fix[0]['out']])), (cid, ri, 'merge_conjacent + fix_simple_inv')
+                checked[5] += 1
+    return checked

@@ -64,6 +64,13 @@ def test_emu_align_end_to_end(ctx, oracle, golden):
     KC.check_align_golden(ctx, oracle, golden, cases=['H'], reads=[3])        # nested SVs from the vacsim-grammar donor, mode R
 
 
+def test_emu_stage_trace(ctx, oracle, golden):
+    """E1 / E3 / E4 stage by stage against the reference's captured segment lists (golden V4)"""
+    n = KC.check_stage_trace_golden(ctx, oracle, golden, cases=['I'], reads=[0, 3])
+    assert n[0] == 2 and n[3] == 2 and n[5] == 2
+    KC.check_stage_trace_golden(ctx, oracle, golden, cases=['B'], reads=[0, 1])
+
+
 def test_emu_chain_global_fast(ctx, oracle):
     KC.check_chain_global_fast_synth(ctx, oracle, seed=31, n_reads=2, L=140, per_pos=6)
 

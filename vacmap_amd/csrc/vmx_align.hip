@@ -94,8 +94,12 @@ static int ext_gather_round(vm_ctx* c, vmx_batch_bufs& B, const vm_index_view& i
     return cnt;
 }
 
+// diagnostic capture for the stage tests (vm_align_trace): the segment lists of every read as they stand after one phase of the
+// extend stage in the first (filtering) pass: rows (segment, q, r, s, l), off[n + 1]
+struct vmx_seg_trace { int stage; std::vector<int64_t> rows, off; };
+
 static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
-                        vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats) {
+                        vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats, vmx_seg_trace* trace = nullptr) {
     *recs = nullptr; *n_recs = 0; *cigar_blob = nullptr;
     vmx_batch_bufs& B = *batch_bufs(c);
     vm_index_view ix; vmx_index_view(mi, &ix);
@@ -244,7 +248,25 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     const unsigned gridR = (unsigned)((n + 63) / 64);
     int cur = 0;
     auto phase = [&](int ph) { A.desc = B.desc[cur].as<vmx_pair_desc>(); A.desc_prev = B.desc[cur ^ 1].as<vmx_pair_desc>();
-                               hipMemsetAsync(B.rcount.p, 0, 4, c->stream); hipLaunchKernelGGL(k_ext_phase, dim3(gridR), dim3(64), 0, c->stream, A, ph); };
+                               (void)hipMemsetAsync(B.rcount.p, 0, 4, c->stream); hipLaunchKernelGGL(k_ext_phase, dim3(gridR), dim3(64), 0, c->stream, A, ph);
+                               if (trace && trace->stage == ph && !A.redo_only && trace->off.empty()) {
+                                   std::vector<vmx_ext_read> er((size_t)n); std::vector<vmx_anchor> sa((size_t)cA + 1); std::vector<int32_t> st_((size_t)cS + 1), en_((size_t)cS + 1);
+                                   (void)hipMemcpyAsync(er.data(), B.er.p, sizeof(vmx_ext_read) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+                                   (void)hipMemcpyAsync(sa.data(), B.segA.p, sizeof(vmx_anchor) * (size_t)cA, hipMemcpyDeviceToHost, c->stream);
+                                   (void)hipMemcpyAsync(st_.data(), B.st.p, 4 * (size_t)cS, hipMemcpyDeviceToHost, c->stream);
+                                   (void)hipMemcpyAsync(en_.data(), B.en.p, 4 * (size_t)cS, hipMemcpyDeviceToHost, c->stream);
+                                   (void)hipStreamSynchronize(c->stream);
+                                   trace->off.assign(1, 0);
+                                   for (int64_t r = 0; r < n; ++r) {
+                                       if (er[(size_t)r].active && er[(size_t)r].status == 0)
+                                           for (int sg = 0; sg < er[(size_t)r].nseg; ++sg)
+                                               for (int t = st_[(size_t)(soff2[r] + sg)]; t < en_[(size_t)(soff2[r] + sg)]; ++t) {
+                                                   const vmx_anchor& a = sa[(size_t)(coff3[r] + t)];
+                                                   const int64_t row[5] = {sg, a.q, a.r, a.s, a.l}; trace->rows.insert(trace->rows.end(), row, row + 5);
+                                               }
+                                       trace->off.push_back((int64_t)trace->rows.size() / 5);
+                                   }
+                               } };
     auto ext_round = [&](int redo_only) -> int {   // x-drop extension of the problems of the current round
         int cnt = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, redo_only, round_cap, pool_cap);
         if (cnt < 0) return cnt;
@@ -455,6 +477,28 @@ int vm_align_resident(vm_ctx* c, const vm_index* mi, const vm_params* prm, const
     if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
     VMX_HIP(hipSetDevice(c->device));
     return align_device(c, mi, prm, R->n, R->codes.as<uint8_t>(), R->off.as<int64_t>(), R->h_off, recs, n_recs, cigar_blob, status_per_read, stats);
+}
+
+int vm_align_trace(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const char* seqs, const int64_t* offsets, int stage, int64_t** rows, int64_t** row_off) {
+    *rows = nullptr; *row_off = nullptr;
+    if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
+    if (stage != 0 && stage != 3 && stage != 5) { set_error("vm_align_trace: stage must be 0, 3 or 5"); return VM_ERR_ARG; }
+    VMX_HIP(hipSetDevice(c->device));
+    vmx_batch_bufs& B = *batch_bufs(c);
+    const int64_t tot = offsets[n];
+    VMX_TRY(upload(B.raw, seqs, (size_t)tot, c->stream)); VMX_TRY(B.codes.reserve((size_t)tot + 64)); VMX_TRY(upload(B.off, offsets, (size_t)n + 1, c->stream));
+    if (tot) LAUNCH1D(k_encode, tot, B.raw.as<char>(), B.codes.as<uint8_t>(), tot);
+    std::vector<int64_t> h_off(offsets, offsets + n + 1);
+    vmx_seg_trace tr; tr.stage = stage;
+    vm_record* recs = nullptr; int64_t nrec = 0; char* blob = nullptr;
+    std::vector<int32_t> status((size_t)n + 1);
+    const int rc = align_device(c, mi, prm, n, B.codes.as<uint8_t>(), B.off.as<int64_t>(), h_off, &recs, &nrec, &blob, status.data(), nullptr, &tr);
+    free(recs); free(blob);
+    if (rc < 0) return rc;
+    if (tr.off.empty()) tr.off.assign((size_t)n + 1, 0);
+    *rows = (int64_t*)malloc(8 * std::max<size_t>(tr.rows.size(), 1)); *row_off = (int64_t*)malloc(8 * tr.off.size());
+    memcpy(*rows, tr.rows.data(), 8 * tr.rows.size()); memcpy(*row_off, tr.off.data(), 8 * tr.off.size());
+    return VM_OK;
 }
 
 int vm_align_batch(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const char* seqs, const int64_t* offsets, vm_record** recs, int64_t* n_recs,

@@ -93,7 +93,8 @@ struct vmx_lseed_args {
 #ifdef VMX_EMU
 #define VMX_DP16X4_MAX 160
 #else
-#define VMX_DP16X4_MAX 3072
+#define VMX_DP16X4_MAX 1024       // larger problems run one per wavefront: a 700 x 700 problem almost never passes the band proof (its score falls ~0.8 per base
+                                  // behind the all-match bound) and its full fill on one 16-lane row was a 5-10 ms tail of the second launch (3072 before)
 #endif
 #define VMX_DP16X4_OK(tl, ql) ((tl) + (ql) <= VMX_DP16X4_MAX)
 #define VMX_X4_W(ql) ((((ql) + 31) + 15) & ~15)

@@ -142,6 +142,7 @@ class VmxLib:
         L.vm_local_chain_batch.argtypes = [vp, vp, P(Params), i64, cp, vp, vp, vp, vp, P(LocalOut)]
         L.vm_local_out_free.argtypes = [P(LocalOut)]
         L.vm_align_batch.argtypes = [vp, vp, P(Params), i64, cp, vp, P(P(Record)), P(i64), P(vp), vp, P(BatchStats)]
+        L.vm_align_trace.argtypes = [vp, vp, P(Params), i64, cp, vp, C.c_int, P(P(i64)), P(P(i64))]
         L.vm_reads_upload.argtypes = [vp, i64, cp, vp, P(vp)]
         L.vm_reads_free.argtypes = [vp]
         L.vm_align_resident.argtypes = [vp, vp, P(Params), vp, P(P(Record)), P(i64), P(vp), vp, P(BatchStats)]
@@ -350,6 +351,19 @@ def align_batch(ctx, index, prm, seqs):
                                            status.ctypes.data, C.byref(stats)))
     out, sd = _collect_records(ctx, recs, nrec.value, blob, stats)
     return status[:n], out, sd
+
+
+def align_trace(ctx, index, prm, seqs, stage):
+    """segment lists of every read after stage 0 / 3 / 5 of the extend phase (vm_align_trace): list of (n_i, 5) int64 arrays"""
+    s, off = _cat(seqs)
+    n = len(seqs)
+    rows = C.POINTER(C.c_int64)(); ro = C.POINTER(C.c_int64)()
+    ctx.lib.check(ctx.lib.L.vm_align_trace(ctx.h, index.h, C.byref(prm), n, s, off.ctypes.data, int(stage), C.byref(rows), C.byref(ro)))
+    o = ctx._take(ro, n + 1, np.int64)
+    tot = int(o[-1])
+    a = np.ctypeslib.as_array(rows, shape=(max(tot, 1), 5))[:tot].copy()
+    ctx.lib.L.vm_free(rows)
+    return [a[o[i]:o[i + 1]] for i in range(n)]
 
 
 class ResidentReads:
