@@ -56,7 +56,7 @@ def test_gapfill_banded_schedule(ctx, oracle):
     st = KC.check_gapfill_banded(ctx, oracle, band_w=62, x4_max=1024, dp16_max=6000, base_len=270, seed=44)
     assert st['proven'] >= 10 and st['redo'] >= 10
     KC.check_gapfill_banded(ctx, oracle, band_w=62, x4_max=1024, dp16_max=6000, base_len=420, seed=45, big=False)
-    KC.check_gapfill_banded(ctx, oracle, band_w=62, x4_max=1024, dp16_max=6000, base_len=1400, seed=46, big=False)
+    KC.check_gapfill_banded(ctx, oracle, band_w=62, x4_max=1024, dp16_max=6000, base_len=1400, seed=46, big=False, min_counts=(0, 0, 100))     # one problem per wavefront (packed int16), the same shapes
 
 
 def test_chain_global_golden(ctx, oracle, golden):

@@ -8,7 +8,6 @@ MD / cs (need --eqx CIGARs), hard clipping, approximate SA CIGARs, CG tag for > 
 """
 import re
 
-_CIGAR_RE = re.compile(r'(\d+)([MIDNSHP=X])')
 _COMP = bytes.maketrans(b'ACGTNacgtn', b'TGCANtgcan')
 
 
@@ -38,27 +37,36 @@ def merge_cigar(cigar):
 
 
 def nm_from_cigar(cigar, query, ref):
-    """output_functions.py:300 — mismatches of M ops + I + D + X lengths; S advances the query, N the reference"""
-    nm = q = r = 0
-    for m in _CIGAR_RE.finditer(cigar):
-        n, op = int(m.group(1)), m.group(2)
-        if op == 'M':
-            for i in range(n):
-                if query[q + i].upper() != ref[r + i].upper():
-                    nm += 1
-            q += n; r += n
-        elif op == 'I':
-            nm += n; q += n
-        elif op == 'D':
-            nm += n; r += n
-        elif op == 'N':
-            r += n
-        elif op == 'S':
-            q += n
-        elif op == '=':
-            q += n; r += n
-        elif op == 'X':
-            nm += n; q += n; r += n
+    """NM of a SAM record from its CIGAR (the reference's `nm_from_cigar`, output_functions.py:300, pinned by its nine known-answer
+    tests): inserted + deleted + X-run bases, plus the mismatching columns of M runs (compared case-insensitively). S / I consume the
+    query, D / N the reference, = / X / M both; H and P consume nothing. An M run that leaves either sequence raises IndexError, like
+    the reference's per-base indexing does."""
+    nm = qpos = rpos = run = 0
+    for ch in cigar:
+        d = ord(ch) - 48
+        if 0 <= d <= 9:
+            run = run * 10 + d
+            continue
+        n, run = run, 0
+        if ch == 'M':
+            qs, rs = query[qpos:qpos + n], ref[rpos:rpos + n]
+            if len(qs) < n or len(rs) < n:
+                raise IndexError('M run beyond the sequence')
+            if qs != rs:
+                nm += sum(1 for x, y in zip(qs.upper(), rs.upper()) if x != y)
+            qpos += n; rpos += n
+        elif ch == '=':
+            qpos += n; rpos += n
+        elif ch == 'X':
+            nm += n; qpos += n; rpos += n
+        elif ch == 'I':
+            nm += n; qpos += n
+        elif ch == 'D':
+            nm += n; rpos += n
+        elif ch == 'S':
+            qpos += n
+        elif ch == 'N':
+            rpos += n
     return nm
 
 
