@@ -200,6 +200,58 @@ __device__ __forceinline__ void vmx_cluster_body(uint64_t* __restrict__ keys, ui
         const int ncl = s_ncl;
         // rank key = (0xffffffff - size) << 32 | start  (ascending = size desc, start asc = first ref pos asc)
         int NC = 1; while (NC < ncl) NC <<= 1;
+        const bool topk = check_num > 0 && check_num < ncl && check_num <= 1024;
+        if (topk) {
+            // Only the check_num best-ranked clusters are emitted, and a read's ~10^4 clusters in an hg38-size index are almost all
+            // single random hits: instead of sorting every rank key, find the size s* of the check_num-th cluster from a size histogram,
+            // take every cluster larger than s* and the first of size s* in reference order (CK is in that order), and sort those few keys.
+            int* hist = (int*)s_sort;                                 // sizes 1..1022, bin 1023 = larger (all of them are taken)
+            for (int i = (int)threadIdx.x; i < 1024; i += (int)blockDim.x) hist[i] = 0;
+            __syncthreads();
+            for (int c = (int)threadIdx.x; c < ncl; c += (int)blockDim.x) {
+                const uint64_t st = CK[c], en = (c + 1 < ncl) ? CK[c + 1] : (uint64_t)n;
+                const int sz = (int)(en - st);
+                atomicAdd(&hist[sz < 1023 ? sz : 1023], 1);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int acc = 0, sstar = 0, above = 0;
+                for (int b = 1023; b >= 1; --b) { if (acc + hist[b] >= check_num) { sstar = b; above = acc; break; } acc += hist[b]; }
+                s_ncl = sstar; s_scan[18] = above;                    // clusters strictly larger than s*, and s* (1023: the overflow bin holds the cut)
+            }
+            __syncthreads();
+            const int sstar = s_ncl, above = s_scan[18];
+            __syncthreads();
+            if (sstar >= 1023 || sstar == 0) {
+                // the cut falls among clusters of 1023 hits or more (or nothing was found): keep the general path
+            } else {
+                const int need = check_num - above;                   // clusters of size exactly s* to take, first in reference order
+                uint64_t* sel = s_sort + 512;                         // selected rank keys (<= check_num <= 1024), behind the histogram
+                int nsel = 0, neq = 0;
+                for (int c0 = 0; c0 < ncl; c0 += (int)blockDim.x) {
+                    const int c = c0 + (int)threadIdx.x;
+                    int sz = 0; uint64_t st = 0;
+                    if (c < ncl) { st = CK[c]; const uint64_t en = (c + 1 < ncl) ? CK[c + 1] : (uint64_t)n; sz = (int)(en - st); }
+                    const int eq = sz == sstar;
+                    int toteq; const int exeq = vmx_block_excl_scan(eq, s_scan, &toteq);
+                    const int take = sz > sstar || (eq && neq + exeq < need);
+                    __syncthreads();
+                    int tott; const int ext = vmx_block_excl_scan(take, s_scan, &tott);
+                    if (take) sel[nsel + ext] = ((uint64_t)(0xffffffffu - (uint32_t)sz) << 32) | st;
+                    nsel += tott; neq += toteq;
+                    __syncthreads();
+                }
+                int NS = 1; while (NS < nsel) NS <<= 1;
+                for (int i = nsel + (int)threadIdx.x; i < NS; i += (int)blockDim.x) sel[i] = VMX_INF64;
+                __syncthreads();
+                if (NS > 1) vmx_block_bitonic_passes(sel, NS);
+                __syncthreads();
+                for (int i = (int)threadIdx.x; i < nsel; i += (int)blockDim.x) CK[i] = sel[i];
+                __syncthreads();
+                NC = 0;                                               // CK[0 .. check_num) is ranked: skip the full sort
+            }
+        }
+        if (NC > 0) {
         // sizes need the next start: read all first, then overwrite
         uint64_t mykey[1];
         for (int c0 = 0; c0 < NC; c0 += (int)blockDim.x) {
@@ -216,6 +268,7 @@ __device__ __forceinline__ void vmx_cluster_body(uint64_t* __restrict__ keys, ui
         }
         if (NC > 1) vmx_block_sort_u64_tiled(CK, NC, s_sort, tile);
         __syncthreads();
+        }
         int keep = ncl; if (check_num > 0 && check_num < keep) keep = check_num;
         // emit: exclusive scan of kept cluster sizes gives the output offset of each cluster
         int64_t* out = rows + 4 * key_off[r];

@@ -34,6 +34,7 @@ __host__ __device__ inline int vmx_p2c(const vmx_ref_view& R, long long pos) {
 }
 __host__ __device__ inline long long vmx_clampll(long long v, long long lo, long long hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __host__ __device__ inline vmx_anchor vmx_mk(long long q, long long r, int s, int l) { vmx_anchor a; a.q = (int32_t)q; a.r = r; a.s = (int16_t)s; a.l = (int16_t)l; return a; }
+#define VMX_PF 8                 // anchors fetched ahead by the serial segment walks
 #define SEG_FIRST(S, s) ((S).A[(S).st[s]])
 #define SEG_LAST(S, s) ((S).A[(S).en[s] - 1])
 #define SEG_LEN(S, s) ((S).en[s] - (S).st[s])
@@ -51,8 +52,16 @@ __host__ __device__ inline int vmx_rebuild_chain_break(const vmx_anchor* chain_d
     vmx_anchor pre = chain_desc[n - 1];
     if (S.capS < 1 || S.capA < 4) return VM_READ_CAPACITY_DEV;
     S.st[0] = w; S.A[w++] = pre; S.en[0] = w; S.nseg = 1;
-    for (int x = 1; x < n; ++x) {
-        const vmx_anchor now = chain_desc[n - 1 - x];
+    // the chain is walked serially (every step depends on the anchor kept before it), but the LOADS do not: VMX_PF anchors are fetched
+    // ahead so that their HBM latencies overlap instead of adding up (one lane per read: nothing else hides them)
+    for (int x0 = 1; x0 < n; x0 += VMX_PF) {
+      vmx_anchor pf[VMX_PF];
+#pragma unroll
+      for (int j = 0; j < VMX_PF; ++j) pf[j] = chain_desc[x0 + j < n ? n - 1 - (x0 + j) : 0];
+#pragma unroll
+      for (int j = 0; j < VMX_PF; ++j) {
+        if (x0 + j >= n) break;
+        const vmx_anchor now = pf[j];
         if (pre.s == now.s) {
             long long readgap = (long long)now.q - pre.q - pre.l, refgap;
             if (pre.s == 1) refgap = (long long)now.r - pre.r - pre.l; else refgap = (long long)pre.r - now.r - now.l;
@@ -74,6 +83,7 @@ __host__ __device__ inline int vmx_rebuild_chain_break(const vmx_anchor* chain_d
         if (S.nseg + 1 > S.capS || w + 2 > S.capA) return VM_READ_CAPACITY_DEV;
         S.st[S.nseg] = w; S.A[w++] = now; S.en[S.nseg] = w; ++S.nseg;
         pre = now;
+      }
     }
     if (SEG_LEN(S, S.nseg - 1) == 1) --S.nseg;
     if (S.nseg == 0) return VM_READ_RAISED_DEV;
@@ -337,8 +347,15 @@ __host__ __device__ inline int vmx_split_alignment(vmx_segs& S, int s, long long
         vmx_anchor& last = S.A[en - 1];
         if (last.l != 0) last = vmx_mk((long long)last.q + last.l, last.r + last.l, 1, 0);
         vmx_anchor pre = S.A[st];
-        for (int i = st + 1; i < en; ++i) {
-            const vmx_anchor now = S.A[i];
+        for (int i0 = st + 1; i0 < en; i0 += VMX_PF) {
+          vmx_anchor pf[VMX_PF];                             // loads fetched ahead of the serial walk (see vmx_rebuild_chain_break)
+#pragma unroll
+          for (int j = 0; j < VMX_PF; ++j) pf[j] = S.A[i0 + j < en ? i0 + j : en - 1];
+#pragma unroll
+          for (int j = 0; j < VMX_PF; ++j) {
+            const int i = i0 + j;
+            if (i >= en) break;
+            const vmx_anchor now = pf[j];
             long long readgap = (long long)now.q - pre.q - pre.l, refgap = (long long)now.r - pre.r - pre.l;
             long long mn = readgap < refgap ? readgap : refgap;
             if ((now.l < 19 || mn < min_gap_forcigar) && i + 1 != en) continue;
@@ -347,13 +364,21 @@ __host__ __device__ inline int vmx_split_alignment(vmx_segs& S, int s, long long
             vmx_qt_for_cigar(pre, now, L, R, d);
             if (d->t.len <= 0 || d->q.len <= 0) return VM_READ_RAISED_DEV;    // "Failed to compute CIGAR" :21562
             ++np; pre = now;
+          }
         }
     } else {
         if (S.A[st].l != 0) S.A[st] = vmx_mk(S.A[st].q, S.A[st].r + S.A[st].l, -1, 0);
         if (S.A[en - 1].l != 0) S.A[en - 1] = vmx_mk((long long)S.A[en - 1].q + S.A[en - 1].l, S.A[en - 1].r, -1, 0);
         vmx_anchor pre = S.A[en - 1];                      // alignment[::-1]
-        for (int i = en - 2; i >= st; --i) {
-            const vmx_anchor now = S.A[i];
+        for (int i0 = en - 2; i0 >= st; i0 -= VMX_PF) {
+          vmx_anchor pf[VMX_PF];
+#pragma unroll
+          for (int j = 0; j < VMX_PF; ++j) pf[j] = S.A[i0 - j >= st ? i0 - j : st];
+#pragma unroll
+          for (int j = 0; j < VMX_PF; ++j) {
+            const int i = i0 - j;
+            if (i < st) break;
+            const vmx_anchor now = pf[j];
             long long readgap = (long long)pre.q - now.q - now.l, refgap = (long long)now.r - pre.r - pre.l;
             long long mn = readgap < refgap ? readgap : refgap;
             if ((now.l < 19 || mn < min_gap_forcigar) && i != st) continue;
@@ -362,6 +387,7 @@ __host__ __device__ inline int vmx_split_alignment(vmx_segs& S, int s, long long
             vmx_qt_for_cigar(now, pre, L, R, d);
             if (d->t.len <= 0 || d->q.len <= 0) return VM_READ_RAISED_DEV;
             ++np; pre = now;
+          }
         }
     }
     if (np == 0) return VM_READ_RAISED_DEV;                // cigarlist[-1] == [] :21566
