@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""End-to-end throughput of the command-line driver (vacmap_amd/driver.py: FASTQ in, SAM out) next to the bench's number for the same
+reads — VERDICT r1 item 4: the schedule bench.py times must be the one a user runs.
+
+    python tools/driver_bench.py [--ref-mb 100] [--reads 20480] [--t 16] [--out gpurun_out/driver_bench.json]
+
+Writes a synthetic reference FASTA (BASELINE configs[1] shape: one contig, seed 1) and ONT-shape reads as FASTQ under /tmp, runs
+`driver.main` on them (index built on the GPU, `.vmx` cache off), and reports wall time split into index build and the read loop
+(parse + align + SAM emission + write), reads/s and aligned Gbp/s of the read loop. Then the same reads go through
+`Pipeline.run_resident` (what bench.py times) for the comparison figure."""
+import argparse, json, os, sys, time
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--ref-mb', type=float, default=100.0); ap.add_argument('--reads', type=int, default=20480)
+    ap.add_argument('--t', type=int, default=16); ap.add_argument('--out', default=None); ap.add_argument('--tmp', default='/tmp/vmx_driver_bench')
+    args = ap.parse_args()
+    from vacmap_amd import synth, driver, pipeline
+    os.makedirs(args.tmp, exist_ok=True)
+    ref = synth.make_reference([int(args.ref_mb * 1e6)], seed=1)[0]
+    fa = os.path.join(args.tmp, 'ref.fa'); fq = os.path.join(args.tmp, 'reads.fq'); sam_path = os.path.join(args.tmp, 'out.sam')
+    with open(fa, 'wb') as f:
+        f.write(b'>chr1\n'); f.write(ref.tobytes()); f.write(b'\n')
+    cat, off = [], [0]
+    for s in range(0, args.reads, 4096):
+        c, o, _ = synth.sample_reads_concat([ref], min(4096, args.reads - s), mean_len=15000, err=0.10, seed=1000 + 7919 * (s // 4096))
+        cat.append(c); off.extend((o[1:] + off[-1]).tolist())
+    cat = np.concatenate(cat); off = np.asarray(off, dtype=np.int64)
+    n = len(off) - 1
+    with open(fq, 'wb') as f:
+        for i in range(n):
+            L = int(off[i + 1] - off[i])
+            f.write(b'@r%d\n' % i); f.write(cat[off[i]:off[i + 1]].tobytes()); f.write(b'\n+\n'); f.write(b'I' * L); f.write(b'\n')
+    fq_bytes = os.path.getsize(fq)
+    # index build alone (so that the read loop can be separated from it)
+    from vacmap_amd.lib import Context, Index, load
+    ctx = Context(0)
+    t0 = time.time(); idx = Index.from_fasta(ctx, fa, k=15, w=10); t_index = time.time() - t0
+    prm = load().params('H')
+    # the bench's figure for these reads (inputs resident, no SAM): the product's scheduler on length-binned batches
+    plan = pipeline.plan_batches(np.diff(off), 4096, 16)
+    res = pipeline.upload_batches(ctx, cat, off, plan)
+    pipe = pipeline.Pipeline(idx, prm, inflight=3, first_ctx=ctx)
+    pipe.warm(res[0])
+    agg = {'aligned': 0}
+
+    def on(i, r):
+        agg['aligned'] += r[2]['aligned_bases']
+    t0 = time.time(); pipe.run_resident(res, on_result=on); t_res = time.time() - t0
+    del res
+    pipe.close(); idx.close(); ctx.close()
+    # the driver, end to end
+    t0 = time.time()
+    rc = driver.main(['-ref', fa, '-read', fq, '-mode', 'H', '-o', sam_path, '-t', str(args.t), '--nowriteindex', '--force'])
+    t_driver = time.time() - t0
+    lines = sum(1 for ln in open(sam_path, 'rb') if not ln.startswith(b'@'))
+    out = {'reads': n, 'read_bases': int(off[-1]), 'fastq_bytes': fq_bytes, 'sam_lines': lines, 'driver_rc': rc, 'emit_processes': args.t,
+           'driver_wall_s': t_driver, 'index_build_s': t_index, 'driver_read_loop_s': t_driver - t_index,
+           'driver_reads_per_s': n / max(t_driver - t_index, 1e-9), 'driver_input_Gbp_per_s': float(off[-1]) / max(t_driver - t_index, 1e-9) / 1e9,
+           'resident_pipeline_s': t_res, 'resident_reads_per_s': n / t_res, 'resident_aligned_Gbp_per_s': agg['aligned'] / t_res / 1e9,
+           'driver_over_resident': (n / max(t_driver - t_index, 1e-9)) / (n / t_res)}
+    print(json.dumps(out))
+    if args.out:
+        json.dump(out, open(args.out, 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()
