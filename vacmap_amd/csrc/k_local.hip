@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
     __shared__ int s_niv;
     __shared__ int s_flag;
     __shared__ long long s_tot;
+    __shared__ int s_emit;
     __shared__ unsigned long long s_min, s_max, s_min2, s_max2;
     __shared__ int s_wmax[16];
     __shared__ int s_next;
@@ -110,10 +111,19 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
     const int nkey = 1 << (2 * k);
     // head entries are (epoch << 23 | window index): an entry of another epoch is an empty list, so the table is never reset between
     // uses (that was one random HBM write per window position); the slot's epoch lives in A.epoch_pool across launches, 511 = never used
-    int32_t* HEAD = A.head_pool + (size_t)blockIdx.x * (size_t)nkey;
+    // k = 9 (the only local k-mer size the reference uses, vacmap:255): the 4^9 heads are folded into 2^14 BUCKETS (the k-mer's low 14
+    // bits); a list entry carries the k-mer's remaining 4 bits next to its 23-bit link, and a walk skips entries of another k-mer. The
+    // slot's table shrinks from 1 MB to 64 KB — 768 resident slots fit the L2 / Infinity Cache instead of spraying an 800 MB region with
+    // random atomics — while the exact per-k-mer occupancy bitmap in LDS still answers nine in ten look-ups without touching it.
+    const bool bucketed = 2 * k > 14 && ((size_t)1 << (2 * k)) <= (size_t)VMX_SORT_LDS * 64;
+    const int nhead = bucketed ? (1 << 14) : nkey;
+    int32_t* HEAD = A.head_pool + (size_t)blockIdx.x * (size_t)A.head_stride;
     unsigned ep = (unsigned)A.epoch_pool[blockIdx.x];
     auto head_idx = [&](int h) { return (((unsigned)h) >> 23) == ep ? (int)(((unsigned)h) & 0x7fffffu) : -1; };
 #define VMX_HEAD_IDX(h) head_idx(h)
+#define VMX_HB(km) (bucketed ? ((km) & 0x3fffu) : (km))                                     /* head slot of a k-mer */
+#define VMX_ENT_OK(e, km) (!bucketed || ((unsigned)(e) >> 23) == ((km) >> 14))              /* list entry belongs to this k-mer */
+#define VMX_ENT_NEXT(e) (bucketed ? (((e) & 0x7fffff) == 0x7fffff ? -1 : ((e) & 0x7fffff)) : (e))
     int32_t* NEXT = A.next_pool + (size_t)blockIdx.x * (size_t)A.tpos_cap;
     uint64_t* HKEY = A.hkey_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;
     uint64_t* HKEY2 = A.hkey2_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;
@@ -223,7 +233,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 long long tot = 0;
                 for (int v = 0; v < niv; ++v) { s_ivbase[v] = (int)tot; tot += s_iv[v][1] - s_iv[v][0]; }
                 s_ivbase[niv] = (int)(tot < 0x7fffffff ? tot : 0x7fffffff);
-                if (tot > A.tpos_cap || tot >= (1LL << 23)) overflow = true;
+                if (tot > A.tpos_cap || tot >= (1LL << 23) - 1) overflow = true;     // 0x7fffff is the end-of-list mark of bucketed entries
                 s_niv = niv; s_flag = overflow ? 1 : 0;
             }
             __syncthreads();
@@ -232,7 +242,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             // occupancy bitmap of the head table (one bit per k-mer, 32 KB for k = 9) in the sort buffer, which is idle until the radix sort:
             // the windows fill about a tenth of the 4^k heads, so nine in ten look-ups of passes A and B are answered from LDS
             ep = ep + 1;
-            if (ep >= 511u) { for (int i = (int)threadIdx.x; i < nkey; i += (int)blockDim.x) HEAD[i] = -1; ep = 0; __syncthreads(); }   // epochs used up: one real reset
+            if (ep >= 511u) { for (int i = (int)threadIdx.x; i < nhead; i += (int)blockDim.x) HEAD[i] = -1; ep = 0; __syncthreads(); }   // epochs used up: one real reset
             unsigned* BM = (unsigned*)s_sort;
             const bool use_bm = ((size_t)1 << (2 * k)) <= (size_t)VMX_SORT_LDS * 64;
             if (use_bm) { for (int i = (int)threadIdx.x; i < (1 << (2 * k)) / 32; i += (int)blockDim.x) BM[i] = 0u; __syncthreads(); }
@@ -250,8 +260,8 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             // --- table: one atomic exchange per window position links it in front of its 9-mer's list
             if (use_bm) {
                 // only the window positions whose 9-mer the read can ask for are linked (about one in nine: the read window holds ~30 k of the
-                // 4^9 k-mers): the bitmap first holds the READ's k-mers (forward and reverse complement), a coalesced sweep marks the matching
-                // window positions in NEXT, then the bitmap is rebuilt as the table's occupancy map while the marked positions are linked.
+                // 4^9 k-mers): the bitmap first holds the READ's k-mers (forward and reverse complement), a coalesced sweep lists the matching
+                // window positions, then the bitmap is rebuilt as the table's occupancy map while the marked positions are linked.
                 // Nine in ten of the random atomic exchanges on the 1 MB head table in HBM disappear; a list a look-up can reach is complete.
                 // (both sweeps roll the k-mer over runs of 8 consecutive positions per thread: 2 byte loads per position instead of k)
                 const uint32_t KMASK = (1u << (2 * k)) - 1u;
@@ -263,7 +273,10 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                         if (nval >= k) { const uint32_t rv = vmx_kmer_rc(fw, k); if (fw != rv) { atomicOr(&BM[fw >> 5], 1u << (fw & 31)); atomicOr(&BM[rv >> 5], 1u << (rv & 31)); } }
                     }
                 }
+                if (threadIdx.x == 0) s_next = 0;
                 __syncthreads();
+                // the window positions whose k-mer the read holds are appended to a compact list (the hit pool SQ, idle until the sort):
+                // ~3 k indices instead of a mark per window position written to and read back from HBM
                 for (int v = 0; v < niv; ++v) {
                     const long long lo = s_iv[v][0], hi = s_iv[v][1]; const int base = s_ivbase[v];
                     for (long long x0 = lo + 8 * (long long)threadIdx.x; x0 < hi; x0 += 8 * (long long)blockDim.x) {
@@ -271,23 +284,22 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                         for (int i = 0; i < k - 1; ++i) { const uint8_t c = A.ref[x0 + i]; nval = c > 3 ? 0 : nval + 1; km = (km << 2) | (uint32_t)(c & 3); }
                         for (int j = 0; j < 8 && x0 + j < hi; ++j) {
                             const uint8_t c = A.ref[x0 + j + k - 1]; nval = c > 3 ? 0 : nval + 1; km = ((km << 2) | (uint32_t)(c & 3)) & KMASK;
-                            NEXT[base + (int)(x0 + j - lo)] = (nval >= k && ((BM[km >> 5] >> (km & 31)) & 1u)) ? -2 : -3;
+                            if (nval >= k && ((BM[km >> 5] >> (km & 31)) & 1u)) { const int p = atomicAdd(&s_next, 1); if (p < A.hit_cap) SQ[p] = base + (int)(x0 + j - lo); }
                         }
                     }
                 }
                 __syncthreads();
+                int nmark = s_next;
+                __syncthreads();
+                if (nmark > A.hit_cap) { status = VM_READ_CAPACITY_DEV; nmark = 0; npos = 0; }      // re-run with larger pools (vmx_stage_local.hip)
                 for (int i = (int)threadIdx.x; i < (1 << (2 * k)) / 32; i += (int)blockDim.x) BM[i] = 0u;
                 __syncthreads();
-                for (int v = 0; v < niv; ++v) {
-                    const long long lo = s_iv[v][0], hi = s_iv[v][1]; const int base = s_ivbase[v];
-                    for (long long x = lo + threadIdx.x; x < hi; x += blockDim.x) {
-                        const int idx = base + (int)(x - lo);
-                        if (NEXT[idx] != -2) continue;
-                        bool ok; const uint32_t km = vmx_kmer_at(A.ref, x, k, ok);
-                        const int old = VMX_HEAD_IDX(atomicExch(&HEAD[km], (int)((ep << 23) | (unsigned)idx)));
-                        atomicOr(&BM[km >> 5], 1u << (km & 31));
-                        NEXT[idx] = old;
-                    }
+                for (int e = (int)threadIdx.x; e < nmark; e += (int)blockDim.x) {
+                    const int idx = SQ[e];
+                    bool ok; const uint32_t km = vmx_kmer_at(A.ref, tpos_of(idx), k, ok);
+                    const int old = VMX_HEAD_IDX(atomicExch(&HEAD[VMX_HB(km)], (int)((ep << 23) | (unsigned)idx)));
+                    atomicOr(&BM[km >> 5], 1u << (km & 31));
+                    NEXT[idx] = bucketed ? (int)(((km >> 14) << 23) | (unsigned)(old < 0 ? 0x7fffff : old)) : old;
                 }
             } else
             for (int v = 0; v < niv; ++v) {
@@ -320,13 +332,13 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 const bool pf = ok && fw != rv && (!use_bm || ((BM[fw >> 5] >> (fw & 31)) & 1u));
                 const bool pr = ok && fw != rv && iloc > 0 && (!use_bm || ((BM[rv >> 5] >> (rv & 31)) & 1u));
                 if (pf || pr) {                                  // (the guide bisection only for the one position in five that can hit at all)
-                    const int hf = pf ? VMX_HEAD_IDX(HEAD[fw]) : -1, hr = pr ? VMX_HEAD_IDX(HEAD[rv]) : -1;   // both list heads in flight together
+                    const int hf = pf ? VMX_HEAD_IDX(HEAD[VMX_HB(fw)]) : -1, hr = pr ? VMX_HEAD_IDX(HEAD[VMX_HB(rv)]) : -1;   // both list heads in flight together
                     int b0, b1, c0, c1; vmx_find_closest(GQ, mm, iloc, b0, b1, c0, c1);
                     long long interval = (long long)b0 + b1 + 500; if (interval > 2000) interval = 2000;
                     const long long ref1 = GR[c0], ref2 = GR[c1];
                     long long rgap = (long long)iloc - GQ[c0]; if (rgap < 0) rgap = -rgap;
-                    for (int t = hf; t >= 0; t = NEXT[t]) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cf == 0) ff = rl; ++cf; } }
-                    for (int t = hr; t >= 0; t = NEXT[t]) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cr == 0) fr = rl; ++cr; } }
+                    for (int t = hf; t >= 0;) { const int e = NEXT[t]; if (VMX_ENT_OK(e, fw)) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cf == 0) ff = rl; ++cf; } } t = VMX_ENT_NEXT(e); }
+                    for (int t = hr; t >= 0;) { const int e = NEXT[t]; if (VMX_ENT_OK(e, rv)) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cr == 0) fr = rl; ++cr; } } t = VMX_ENT_NEXT(e); }
                 }
                 PCNT[pi] = cf + cr;
                 PC2[pi] = (cf > 0xffff ? 0xffff : cf) | ((cr > 0x7fff ? 0x7fff : cr) << 16);
@@ -371,9 +383,9 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 long long rgap = (long long)iloc - GQ[c0]; if (rgap < 0) rgap = -rgap;
                 const long long wf = w;
                 const bool pf = !use_bm || ((BM[fw >> 5] >> (fw & 31)) & 1u), pr = iloc > 0 && (!use_bm || ((BM[rv >> 5] >> (rv & 31)) & 1u));
-                for (int t = pf ? VMX_HEAD_IDX(HEAD[fw]) : -1; t >= 0; t = NEXT[t]) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; }
+                for (int t = pf ? VMX_HEAD_IDX(HEAD[VMX_HB(fw)]) : -1; t >= 0;) { const int e = NEXT[t]; if (VMX_ENT_OK(e, fw)) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; } t = VMX_ENT_NEXT(e); }
                 const long long wr = w;
-                if (pr) for (int t = VMX_HEAD_IDX(HEAD[rv]); t >= 0; t = NEXT[t]) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; }
+                if (pr) for (int t = VMX_HEAD_IDX(HEAD[VMX_HB(rv)]); t >= 0;) { const int e = NEXT[t]; if (VMX_ENT_OK(e, rv)) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; } t = VMX_ENT_NEXT(e); }
                 if (wr - wf > 1) vmx_isort_i64(HVAL + wf, (int)(wr - wf));
                 if (w - wr > 1) vmx_isort_i64(HVAL + wr, (int)(w - wr));
                 for (long long x = wf; x < w; ++x) {
@@ -461,10 +473,12 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             //   diagonal (it flushes the leftover, :23248) or, for the last run of a diagonal, 2^26 + stream index of the diagonal's first hit
             //   (appended after all flushes in first-appearance order, :23343).
             {
-                int mybase = 0;
-                for (int pass = 0; pass < 2; ++pass) {
+                // one walk: output slots are claimed with an LDS counter as anchors are emitted (their order in OUT is free, see above), so
+                // the runs are not walked a second time to learn the offsets
+                if (threadIdx.x == 0) s_emit = 0;
+                __syncthreads();
+                {
                     const long long HH = status ? 0 : H;
-                    int wr = 0;
                     // hits are dealt to the threads round-robin (neighbouring lanes test neighbouring hits: coalesced loads); a thread walks the runs
                     // that START at its hits. The order in which anchors are emitted is free: the emission keys restore the reference's order.
                     for (long long j0 = threadIdx.x; j0 < HH; j0 += blockDim.x) {
@@ -486,29 +500,27 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                             const long long bouns = (long long)q2 - (cq + cl) + k;          // > 0 inside a run
                             if (cl + bouns < 20) { if (strand == 1) { cs = 1; cl += bouns; } else { cr = refloc; cs = -1; cl += bouns; } }
                             else {
-                                if (pass == 1) { OUT[n_out + mybase + wr] = vmx_mk_anchor(cq, cr, cs, cl); OKEY[n_out + mybase + wr] = ((uint64_t)g << 28) | sidx; }
-                                ++wr;
+                                const int o = n_out + atomicAdd(&s_emit, 1);
+                                if (o < out_cap) { OUT[o] = vmx_mk_anchor(cq, cr, cs, cl); OKEY[o] = ((uint64_t)g << 28) | sidx; }
                                 const long long nq = cq + cl;
                                 if (strand == 1) { cr = cr + cl; cs = 1; } else { cr = refloc; cs = -1; }
                                 cq = nq; cl = bouns;
                             }
                             prevq = q2;
                         }
-                        if (pass == 1) {
+                        {
                             uint64_t ek;
                             if (j < HH && (HKEY[j] >> 26) == pk) ek = ((uint64_t)g << 28) | (HKEY[j] & ((1ULL << 26) - 1));
                             else ek = ((uint64_t)g << 28) | (1ULL << 26) | (HKEY[DST[i]] & ((1ULL << 26) - 1));
-                            OUT[n_out + mybase + wr] = vmx_mk_anchor(cq, cr, cs, cl); OKEY[n_out + mybase + wr] = ek;
+                            const int o = n_out + atomicAdd(&s_emit, 1);
+                            if (o < out_cap) { OUT[o] = vmx_mk_anchor(cq, cr, cs, cl); OKEY[o] = ek; }
                         }
-                        ++wr;
                     }
-                    if (pass == 0) {
-                        int tot; mybase = vmx_block_excl_scan(wr, s_scan, &tot);
-                        if (threadIdx.x == 0) s_tot = tot;
-                        __syncthreads();
-                        if (n_out + s_tot > out_cap) status = VM_READ_CAPACITY_DEV;
-                        __syncthreads();
-                    }
+                    __syncthreads();
+                    if (threadIdx.x == 0) s_tot = s_emit;
+                    __syncthreads();
+                    if (n_out + s_tot > out_cap) status = VM_READ_CAPACITY_DEV;
+                    __syncthreads();
                 }
             }
             if (!status) n_out += (int)s_tot;
@@ -544,4 +556,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
     }
     if (threadIdx.x == 0) A.epoch_pool[blockIdx.x] = (int)ep;
 #undef VMX_HEAD_IDX
+#undef VMX_HB
+#undef VMX_ENT_OK
+#undef VMX_ENT_NEXT
 }

@@ -54,7 +54,8 @@ struct vmx_lseed_args {
     int32_t n_reads, k, look_span, read_span, sort_by_start;
     const int32_t* order; int32_t* queue;                   // read indices longest first + the queue head (zero at launch)
     int64_t la_slot_len;                                    // local-anchor slot of a listed read = la_slot_len * VMX_LA_SLOT(len) rows at la_off[r]
-    int32_t* head_pool; int32_t* next_pool;                 // HEAD[4^k] (epoch-tagged entries) / NEXT[tpos_cap] per slot
+    int32_t* head_pool; int32_t* next_pool;                 // HEAD[head_stride] (epoch-tagged entries) / NEXT[tpos_cap] per slot
+    int64_t head_stride;                                    // heads per slot: 4^k, or 2^14 buckets when 14 < 2k <= 18 (k_local_seed)
     int32_t* epoch_pool;                                    // current epoch of every slot's head table (persists across launches)
     int32_t* sq_pool; int32_t* dst_pool;                    // hit_cap ints each
     int64_t* tpos_pool; int64_t tpos_cap;

@@ -65,6 +65,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         VMX_TRY(upload(L.rorder, ord.data(), ord.size(), c->stream));
     }
     const int64_t nkey = (int64_t)1 << (2 * k);
+    const int64_t head_stride = (2 * k > 14 && nkey <= (int64_t)VMX_SORT_LDS * 64) ? ((int64_t)1 << 14) : nkey;     // bucketed heads (k_local_seed)
     int64_t tpos_cap = 2 * Lmax + 5 * 14000 + 65536;
     int64_t hit_cap = 1; while (hit_cap < 4 * (Lmax + 14000)) hit_cap <<= 1;
     int64_t pcnt_cap = Lmax + 16;
@@ -76,7 +77,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         const int64_t hit_cap = hcap;
         const int G = slots;
         {   // head tables: entries are tagged with the slot's epoch (k_local_seed), so only fresh memory is filled (0xff = epoch 511, never current)
-            const size_t need = 4 * (size_t)G * (size_t)nkey;
+            const size_t need = 4 * (size_t)G * (size_t)head_stride;
             const void* before = L.cnt.p; const size_t cap_before = L.cnt.cap;
             const void* ebefore = L.epoch.p;
             VMX_TRY(L.cnt.reserve(need)); VMX_TRY(L.epoch.reserve(4 * (size_t)G + 64));
@@ -100,7 +101,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         A.look_span = prm->mode == VM_MODE_R ? 2000 : 7000; A.read_span = prm->mode == VM_MODE_R ? 500 : 7000;   // :23094, :23190 / mammap_noprefercloser.py:23631+
         A.sort_by_start = prm->mode == VM_MODE_R ? 1 : 0;
         A.queue = L.rorder.as<int32_t>(); A.order = L.rorder.as<int32_t>() + 1;
-        A.head_pool = L.cnt.as<int32_t>(); A.next_pool = L.cur.as<int32_t>(); A.sq_pool = L.sq.as<int32_t>(); A.dst_pool = L.dst.as<int32_t>(); A.tpos_pool = nullptr; A.tpos_cap = tpos_cap;          // window positions are implied by the interval list (k_local_seed)
+        A.head_stride = head_stride; A.head_pool = L.cnt.as<int32_t>(); A.next_pool = L.cur.as<int32_t>(); A.sq_pool = L.sq.as<int32_t>(); A.dst_pool = L.dst.as<int32_t>(); A.tpos_pool = nullptr; A.tpos_cap = tpos_cap;          // window positions are implied by the interval list (k_local_seed)
         VMX_TRY(L.hkey2.reserve(8 * (size_t)G * (size_t)hit_cap));
         A.hkey2_pool = L.hkey2.as<uint64_t>();
         A.hkey_pool = L.hkey.as<uint64_t>(); A.hval_pool = L.hval.as<int64_t>(); A.hq_pool = L.hq.as<int32_t>(); A.goff_pool = L.goff.as<int32_t>(); A.hit_cap = hit_cap;
