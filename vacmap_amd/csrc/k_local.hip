@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             const int NN = status ? 0 : N;
             for (int i = (int)threadIdx.x; i < NN; i += (int)blockDim.x) GKEY[i] = i < m ? (((uint64_t)G[i].r << 24) | (uint64_t)i) : ~0ULL;
             __syncthreads();
-            if (NN > 1) vmx_block_sort_u64(GKEY, NN, s_sort);
+            if (NN > 1) vmx_block_sort_u64_tiled(GKEY, NN, s_sort, VMX_SORT_LDS);
             // guide in ascending read order (:23183) = reverse of the stored descending order; read positions are distinct
             const bool g_lds = mm <= VMX_GUIDE_LDS;
             for (int i = (int)threadIdx.x; i < mm; i += (int)blockDim.x) {
@@ -430,10 +430,11 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 // the stream index sits in the low 26 bits, so sorting whole keys = the stable sort by diagonal: up to VMX_SORT_LDS hits (most
                 // reads) that is one bitonic sort in LDS instead of the radix passes through HBM
                 int NP2 = 1; while (NP2 < H) NP2 <<= 1;
-                if (H > 1 && NP2 <= VMX_SORT_LDS) {
+                if (H > 1 && NP2 <= A.hit_cap) {
+                    // (beyond one LDS tile: tile-wise bitonic sort, only the few long-distance steps through HBM — vmx_block_sort_u64_tiled)
                     for (long long i = H + threadIdx.x; i < NP2; i += blockDim.x) HKEY[i] = ~0ULL;
                     __syncthreads();
-                    vmx_block_sort_u64(HKEY, NP2, s_sort);
+                    vmx_block_sort_u64_tiled(HKEY, NP2, s_sort, VMX_SORT_LDS);
                 } else {
                     uint64_t* res = vmx_block_radix_sort_u64(HKEY, HKEY2, (int)H, 26, (uint64_t)0, nbits, (int*)s_sort, s_scan);
                     if (res != HKEY) { for (long long i = threadIdx.x; i < H; i += blockDim.x) HKEY[i] = HKEY2[i]; }
@@ -535,7 +536,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             const long long NP = no > 0 ? NO : 0;
             for (long long i = threadIdx.x; i < NP; i += blockDim.x) HKEY[i] = i < no ? ((OKEY[i] << 32) | (uint64_t)i) : ~0ULL;
             __syncthreads();
-            if (NP > 1) vmx_block_sort_u64(HKEY, (int)NP, s_sort);
+            if (NP > 1) vmx_block_sort_u64_tiled(HKEY, (int)NP, s_sort, VMX_SORT_LDS);
             __syncthreads();
             for (long long e = threadIdx.x; e < no; e += blockDim.x) GOFF[e] = (int)(HKEY[e] & 0xffffffffu);   // rank e -> anchor index
             __syncthreads();
@@ -545,7 +546,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 HKEY[e] = kk;
             }
             __syncthreads();
-            if (NP > 1) vmx_block_sort_u64(HKEY, (int)NP, s_sort);
+            if (NP > 1) vmx_block_sort_u64_tiled(HKEY, (int)NP, s_sort, VMX_SORT_LDS);
             __syncthreads();
             for (long long x = threadIdx.x; x < no; x += blockDim.x) SORTED[x] = OUT[GOFF[(int)(HKEY[x] & 0xffffffffu)]];
             __syncthreads();

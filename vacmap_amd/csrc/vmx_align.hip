@@ -158,11 +158,12 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     constexpr int NB = 10;
     const int caps[NB] = {384, 512, 768, 1024, 1536, 2048, 3072, 4096, 8192, 13056};
     std::vector<int32_t> lists[NB + 1];
+    static const int gc_lds_max = [] { const char* e = getenv("VMX_GC_LDS_MAX"); return e ? atoi(e) : VMX_GC_LDS_MAX_DEFAULT; }();     // see vmx_stage_local.hip
     for (int64_t r = 0; r < n; ++r) {
         int64_t m = h_aoff[r + 1] - h_aoff[r]; const int64_t L = h_roff[r + 1] - h_roff[r];
         if (m <= 2) continue;                                             // :23986 unmapped
         if ((double)m / (double)L > 5.0) continue;                        // fast_enable (:23570): gmax stays -1 -> k_chain_global_fast below
-        int bk = NB; for (int q = 0; q < NB; ++q) if (m <= caps[q]) { bk = q; break; }
+        int bk = NB; for (int q = 0; q < NB; ++q) if (m <= caps[q] && caps[q] <= gc_lds_max) { bk = q; break; }
         lists[bk].push_back((int32_t)r);
     }
     {

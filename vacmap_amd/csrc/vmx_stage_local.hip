@@ -167,10 +167,13 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     constexpr int NB = 10;
     const int caps[NB] = {512, 768, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 13056};
     std::vector<int32_t> lists[NB + 1];
+    // reads above lds_max anchors keep their working arrays in HBM (cap 0): a 100 KB LDS claim leaves one wavefront per CU, and a batch
+    // of long reads then runs 256 reads at a time (tuning knob VMX_LC_LDS_MAX)
+    static const int lds_max = [] { const char* e = getenv("VMX_LC_LDS_MAX"); return e ? atoi(e) : VMX_LC_LDS_MAX_DEFAULT; }();
     for (int64_t r = 0; r < n; ++r) {
         int m = L.h_la_cnt[r];
         if (m <= 0) continue;   // no guide / capacity failure: nothing to chain (status already set by the seeding kernel or stays 0 for unmapped reads)
-        int bk = NB; for (int q = 0; q < NB; ++q) if (m <= caps[q]) { bk = q; break; }
+        int bk = NB; for (int q = 0; q < NB; ++q) if (m <= caps[q] && caps[q] <= lds_max) { bk = q; break; }
         lists[bk].push_back((int32_t)r);
     }
     std::vector<int32_t> rl; int64_t rl_off[NB + 2];
