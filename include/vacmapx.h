@@ -230,6 +230,33 @@ int vm_align_resident(vm_ctx*, const vm_index*, const vm_params*, const vm_reads
 int vm_align_trace(vm_ctx*, const vm_index*, const vm_params*, int64_t n_reads, const char* seqs, const int64_t* offsets, int stage,
                    int64_t** rows, int64_t** row_off);
 
+/* ------------------------------------------------------------------ native I/O around the batched path (host threads, no GPU work)
+ * SAM text for the records of one batch — the consumer of the path, get_bam_dict_str / _comments (mammap_clrnano.py:20841, :21022) with
+ * reassign_mapq (:11661), merged CIGARs (:4773), NM (output_functions.py:300), optional MD / cs (:19012 / :19062), SA tag, S / H clipping,
+ * approximate SA CIGARs, CG tag switch, comment copying (:20686). Options mirror the driver's `pdict` keys of those functions. */
+typedef struct vm_sam_opts {
+    int32_t md, shortcs, cigar2cg, markunbalancetra, hardclip, fakecigar;
+    const char* rg_id;           /* RG:Z: value on every line; NULL = none (the reference's driver always sets one, vacmap:211-214) */
+} vm_sam_opts;
+/* reads as blobs with offsets[n + 1] (quals / comments and their offsets may be NULL; a read whose quality string is empty or of another
+ * length than its sequence gets '*'); recs / cigar_blob / status as returned by vm_align_batch for these reads. text: the lines
+ * ('\n'-terminated) of all reads in read order, text_off[n + 1] delimits every read's lines (both vm_free). A read whose emission raises in
+ * the reference (index past a sequence end) or whose status is not 0 emits nothing and counts in n_skipped, like the worker's except
+ * (:24127-24134). */
+int vm_sam_emit(const vm_index*, const vm_sam_opts*, int64_t n_reads, const char* names, const int64_t* name_off, const char* seqs, const int64_t* seq_off,
+                const char* quals, const int64_t* qual_off, const char* comments, const int64_t* com_off, const vm_record* recs, int64_t n_recs,
+                const char* cigar_blob, const int32_t* status, int nthreads, char** text, int64_t** text_off, int64_t* n_lines, int64_t* n_skipped);
+/* `mp.fastx_read(path, read_comment=)` (vacmap:445): FASTA / FASTQ, plain or gzip. vm_fastx_read returns up to max_reads records (stopping
+ * early once max_bases bases are held) as blobs: names, UPPER-CASED sequences (vacmap:476), qualities (empty for FASTA), comments (header
+ * text after the first blank, else tab). Returns the record count, 0 at the end of the input, or a negative vm_status. */
+/* entries idx[0..n) of a blob copied back to back (out may be NULL to size it): returns the byte count, out_off[n + 1] */
+int64_t vm_blob_gather(const char* blob, const int64_t* off, const int64_t* idx, int64_t n, char* out, int64_t* out_off);
+typedef struct vm_fastx vm_fastx;
+int vm_fastx_open(const char* path, vm_fastx** out);
+void vm_fastx_close(vm_fastx*);
+int64_t vm_fastx_read(vm_fastx*, int64_t max_reads, int64_t max_bases, char** names, int64_t** name_off, char** seqs, int64_t** seq_off, char** quals,
+                      int64_t** qual_off, char** comments, int64_t** com_off);
+
 /* cost tables C0 as uploaded to the device (tests): which = 0 extra,1 readgap_h,2 readgap_r,3 large_readgap (f32),
  * 4 log2cache, 5 log2int (f64). returns length, *data = host copy read back FROM THE DEVICE (vm_free) */
 int64_t vm_table(vm_ctx*, int which, void** data);

@@ -30,7 +30,7 @@ def build(force=False):
             sys.stderr.write('emu build failed on %s\n%s\n' % (s, out)); bad = True
     if bad:
         raise RuntimeError('emu build failed')
-    subprocess.check_call(['g++', '-shared', '-pthread', '-o', OUT] + objs)
+    subprocess.check_call(['g++', '-shared', '-pthread', '-o', OUT] + objs + ['-lz'])
     return OUT
 
 

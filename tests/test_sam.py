@@ -41,3 +41,84 @@ def test_header_and_format():
     h = sam.header_lines([('chr1', 1000), ('chr2', 50)], 'vacmap -ref r.fa', rg={'ID': 'g', 'SM': 's'})
     assert h[0] == '@HD\tVN:1.0' and h[1] == '@SQ\tSN:chr1\tLN:1000' and h[3] == '@RG\tID:g\tSM:s' and h[4].startswith('@PG\tID:VACmap\tPN:VACmap\tVN:1.0.2\tCL:')
     assert sam.format_line({'QNAME': 'r', 'FLAG': '0', 'NM': 3, 'XX': 1.5}) == 'r\t0\t*\t0\t255\t*\t*\t0\t0\t*\t*\tNM:i:3\tXX:f:1.5'
+
+
+def _raw_from_tuples(VL, recs, names):
+    """a RawBatch-shaped object holding the 9-tuples of one read as vm_record structs + CIGAR blob"""
+    import ctypes as C
+    import numpy as np
+    R = (VL.Record * max(len(recs), 1))(); blob = b''
+    for i, r in enumerate(recs):
+        cg = r[8].encode()
+        R[i].read_idx = 0; R[i].contig = names.index(r[1]); R[i].strand = 1 if r[2] == '+' else -1; R[i].mapq = r[7]
+        R[i].q_st, R[i].q_en, R[i].r_st, R[i].r_en = r[3], r[4], r[5], r[6]; R[i].cigar_off = len(blob); R[i].cigar_len = len(cg); blob += cg + b'\0'
+
+    class Raw:
+        pass
+    raw = Raw(); raw.recs = R; raw.nrec = len(recs); raw.blob = C.c_char_p(blob); raw.status = np.zeros(1, np.int32); raw._keep = blob
+    return raw
+
+
+def test_native_sam_emitter_matches_reference(golden, oracle):
+    """vm_sam_emit (the C++ emitter the driver uses at GPU rates) against the same reference lines as sam.py: all option sets, raises included"""
+    import numpy as np
+    import emu_lib, kernel_cases as KC
+    from vacmap_amd import lib as VL
+    ctx = emu_lib.context()
+    meta, arrays = golden
+    entries = json.load(open(os.path.join(GOLD, 'sam.json')))
+    idx = {}
+    nlines = nraised = 0
+    for e in entries:
+        cid = e['case']
+        if cid not in idx:
+            idx[cid] = KC._case_index(ctx, oracle, meta, arrays, cid)[0]
+        recs, query, qual, contigs = SC.inputs(e, meta, arrays)
+        o = e['opt']
+        raw = _raw_from_tuples(VL, recs, meta[cid]['names'])
+        opts = VL.SamOpts(int(o['md']), int(o['shortcs']), int(o['cigar2cg']), int(o['markunbalancetra']), int(o['H']), int(o['fakecigar']), o['rg'].encode() if 'rg' in o else None)
+        nm = recs[0][0].encode()
+        com = o['comments'].replace('\\t', '\t').encode() if 'comments' in o else None
+        buf, off, nl, ns = VL.sam_emit(ctx.lib, idx[cid], opts, np.frombuffer(nm, np.uint8), [0, len(nm)], np.frombuffer(query.encode(), np.uint8), [0, len(query)], raw,
+                                       quals=np.frombuffer(qual.encode(), np.uint8) if qual else None, qual_off=[0, len(qual)] if qual else None,
+                                       comments=np.frombuffer(com, np.uint8) if com else None, com_off=[0, len(com)] if com else None, nthreads=2)
+        lines = buf.tobytes().decode().split('\n')[:-1] if len(buf) else []
+        if e['raised']:
+            assert ns == 1 and not lines, (cid, e['read'], o)
+            nraised += 1
+            continue
+        assert [SC.head(x) for x in lines] == e['head'], (cid, e['read'], o)
+        assert [SC.digest(x) for x in lines] == e['digest'], (cid, e['read'], o)
+        assert nl == len(lines) and off[-1] == len(buf)
+        nlines += len(lines)
+    assert nlines >= 150 and nraised >= 10
+
+
+def test_native_fastx_reader(tmp_path):
+    """vm_fastx_read: FASTA (multi-line, lower case, blank lines), FASTQ, gzip, comments after blank / tab, chunked reads, CRLF"""
+    import gzip
+    import emu_lib
+    from vacmap_amd import lib as VL
+    from vacmap_amd import driver
+    emu_lib.context()
+    L = emu_lib.context().lib
+    fa = tmp_path / 'a.fa'
+    fa.write_text('>r1 first comment\nACGTacgt\nNNAC\n\n>r2\tXC:Z:tab\nGG\n>r3\n\n>r4 x\r\nAC\r\nGT\r\n')
+    fq = tmp_path / 'b.fq.gz'
+    with gzip.open(fq, 'wt') as f:
+        for i in range(70):
+            f.write('@q%d c%d\n%s\n+\n%s\n' % (i, i, 'acgtn' * (i + 1), 'I' * (5 * (i + 1))))
+    for path in (str(fa), str(fq)):
+        exp = list(driver.read_fastx(path, want_comment=True))
+        got = []
+        rd = VL.Fastx(path, lib=L)
+        while True:
+            ch = rd.read(max_reads=16)
+            if ch is None:
+                break
+            for i in range(len(ch['seqs_off']) - 1):
+                f = lambda k: ch[k][ch[k + '_off'][i]:ch[k + '_off'][i + 1]].tobytes().decode()
+                got.append((f('names'), f('seqs'), f('quals') or None, f('comments') or None))
+        rd.close()
+        assert got == [(n, s.upper(), q, c) for n, s, q, c in exp], path
+    assert len(got) == 70

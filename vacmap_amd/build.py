@@ -42,7 +42,7 @@ def build(force=False, verbose=False):
             print(out)
     if fail:
         raise RuntimeError('libvacmapx build failed')
-    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs)
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs + ['-lz'])      # zlib: gzip FASTQ input (vmx_sam.hip)
     return OUT
 
 

@@ -158,7 +158,8 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     constexpr int NB = 10;
     const int caps[NB] = {384, 512, 768, 1024, 1536, 2048, 3072, 4096, 8192, 13056};
     std::vector<int32_t> lists[NB + 1];
-    static const int gc_lds_max = [] { const char* e = getenv("VMX_GC_LDS_MAX"); return e ? atoi(e) : VMX_GC_LDS_MAX_DEFAULT; }();     // see vmx_stage_local.hip
+    static const int gc_lds_env = [] { const char* e = getenv("VMX_GC_LDS_MAX"); return e ? atoi(e) : -1; }();     // see vmx_stage_local.hip
+    const int gc_lds_max = gc_lds_env >= 0 ? gc_lds_env : (c->inflight >= 2 ? VMX_CHAIN_LDS_MAX_SHARED : VMX_GC_LDS_MAX_DEFAULT);
     for (int64_t r = 0; r < n; ++r) {
         int64_t m = h_aoff[r + 1] - h_aoff[r]; const int64_t L = h_roff[r + 1] - h_roff[r];
         if (m <= 2) continue;                                             // :23986 unmapped
@@ -227,12 +228,14 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     const int64_t round_cap = cS + 16;                       // one problem per anchor at most in any round
     const int64_t pool_cap = 6 * total_bases + (1 << 20);
     int64_t Lmax_b = 1; for (int64_t r = 0; r < n; ++r) Lmax_b = std::max(Lmax_b, h_roff[r + 1] - h_roff[r]);
-    const int64_t carry_stride = 2 * Lmax_b + 32768;        // exact edit-distance kernel: one carry ring per workgroup (1 + 2 per CU), longest text it takes
+    const int64_t carry_stride = 2 * Lmax_b + 32768;
+    const int64_t ed_wgs = std::min<int64_t>(c->num_cu, 64);   // workgroups of the exact kernel (x1 long, x2 short patterns): the last tier of the filter, hardly ever
+                                                               // reached (0 problems per step on the bench workload), so its carry rings are kept small (0.8 instead of 3.2 GB)        // exact edit-distance kernel: one carry ring per workgroup (1 + 2 per CU), longest text it takes
     VMX_TRY(B.desc[0].reserve(sizeof(vmx_pair_desc) * (size_t)round_cap)); VMX_TRY(B.desc[1].reserve(sizeof(vmx_pair_desc) * (size_t)round_cap));
     VMX_TRY(B.rcount.reserve(64)); VMX_TRY(B.oflow.reserve(64)); VMX_TRY(B.probread.reserve(4 * (size_t)round_cap));
     VMX_TRY(B.tl.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.ql.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.toff.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.qoff.reserve(8 * (size_t)(round_cap + 1)));
     VMX_TRY(B.tpool.reserve((size_t)pool_cap + 64)); VMX_TRY(B.qpool.reserve((size_t)pool_cap + 64));
-    VMX_TRY(B.edout.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.carry.reserve((size_t)VMX_ED_WAVES * (size_t)carry_stride * (size_t)c->num_cu * 3 + 64)); VMX_TRY(B.ext3.reserve(12 * (size_t)(round_cap + 1)));
+    VMX_TRY(B.edout.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.carry.reserve((size_t)VMX_ED_WAVES * (size_t)carry_stride * (size_t)ed_wgs * 3 + 64)); VMX_TRY(B.ext3.reserve(12 * (size_t)(round_cap + 1)));
     VMX_TRY(B.rec.reserve(sizeof(vm_record) * (size_t)(cS + 1))); VMX_TRY(B.blob.reserve((size_t)cB + 64)); VMX_TRY(B.reccoff.reserve(8 * (size_t)(cS + 1)));
     VMX_TRY(B.recclen.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.dupd.reserve((size_t)cB + 64));
     VMX_HIP(hipMemsetAsync(B.oflow.p, 0, 4, c->stream));
@@ -374,9 +377,9 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
                                B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_nfull, 0);
             hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt);
             for (int which = 0; which < 2; ++which)
-                hipLaunchKernelGGL(k_edit_distance, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * (which == 0 ? 1 : 2))), dim3(which == 0 ? 64 * VMX_ED_WAVES : 256), 0, c->stream,
+                hipLaunchKernelGGL(k_edit_distance, dim3((unsigned)std::min<int64_t>(cnt, ed_wgs * (which == 0 ? 1 : 2))), dim3(which == 0 ? 64 * VMX_ED_WAVES : 256), 0, c->stream,
                                    B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(), B.toff.as<int64_t>(),
-                                   B.carry.as<int8_t>() + (which ? (size_t)VMX_ED_WAVES * (size_t)carry_stride * (size_t)c->num_cu : 0), B.order.as<int32_t>(), d_range, d_cnt, which,
+                                   B.carry.as<int8_t>() + (which ? (size_t)VMX_ED_WAVES * (size_t)carry_stride * (size_t)ed_wgs : 0), B.order.as<int32_t>(), d_range, d_cnt, which,
                                    B.edout.as<int64_t>(), carry_stride, B.oflow.as<int32_t>());
         }
         cur ^= 1;

@@ -121,6 +121,8 @@ struct vmx_lseed_args {
 #define VMX_SELECT_LDS_FULL 960       // ... and whose scratch (37 B + 64) fits next to them: 960 * 53 + 64 <= 3072 * 17
 #define VMX_LC_LDS_MAX_DEFAULT 13056   // reads with more local anchors than this run the chain DP on HBM-resident arrays (VMX_LC_LDS_MAX)
 #define VMX_GC_LDS_MAX_DEFAULT 13056
+#define VMX_CHAIN_LDS_MAX_SHARED 512   // ... and this when several batches are in flight on the GPU (vm_ctx_set_inflight >= 2): a large LDS claim per
+                                      // wavefront starves the other batches' kernels of CUs
 #define VMX_LC_BYTES_PER_ANCHOR 12   // S8 + SA4 (LDS bytes per anchor in k_chain_local; the anchors themselves are read from HBM in register blocks)
 #define VMX_GC_BYTES_PER_ANCHOR 12   // S8 + SA4 (LDS bytes per anchor in k_chain_global; anchors and coverage are read from HBM in register blocks)
 

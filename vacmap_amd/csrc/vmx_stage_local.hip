@@ -169,7 +169,10 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     std::vector<int32_t> lists[NB + 1];
     // reads above lds_max anchors keep their working arrays in HBM (cap 0): a 100 KB LDS claim leaves one wavefront per CU, and a batch
     // of long reads then runs 256 reads at a time (tuning knob VMX_LC_LDS_MAX)
-    static const int lds_max = [] { const char* e = getenv("VMX_LC_LDS_MAX"); return e ? atoi(e) : VMX_LC_LDS_MAX_DEFAULT; }();
+    // Measured on the hg38-size workload, ms per step with 3 batches in flight for limits 13056 / 4096 / 2048 / 1024 / 512 / 0:
+    // 46.3 / 46.1 / 44.9 / 43.9 / 44.0 / 43.4 — LDS residency pays for a context that runs alone, not when batches share the GPU.
+    static const int lds_env = [] { const char* e = getenv("VMX_LC_LDS_MAX"); return e ? atoi(e) : -1; }();
+    const int lds_max = lds_env >= 0 ? lds_env : (c->inflight >= 2 ? VMX_CHAIN_LDS_MAX_SHARED : VMX_LC_LDS_MAX_DEFAULT);
     for (int64_t r = 0; r < n; ++r) {
         int m = L.h_la_cnt[r];
         if (m <= 0) continue;   // no guide / capacity failure: nothing to chain (status already set by the seeding kernel or stays 0 for unmapped reads)

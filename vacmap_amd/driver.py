@@ -6,15 +6,16 @@ src/vacmap/output_functions.py:172-235) around the MI355X library (SURVEY §8(f)
     python -m torch.distributed.run --nproc-per-node N -m vacmap_amd.driver ...        (one rank per GPU)
 
 One process drives one GPU. The index is built on the GPU (or loaded from `<ref>.w<w>_k<k>.vmx`, the reference's `.mmi` naming rule,
-vacmap:326; a minimap2 `.mmi` of that name is read too) and kept in HBM. Reads flow through `vacmap_amd.pipeline`: windows of
-`--window-batches` x `--batch-reads` reads, length-binned batches, several batches in flight; finished batches are turned into SAM
-lines (vacmap_amd/sam.py) by `-t` worker processes while the next batches align, and every window is written in input order. Like the
-reference's worker (:24116-24134) a read whose path or whose emission raises is skipped, and a read without records produces no line.
+vacmap:326; a minimap2 `.mmi` of that name is read too) and kept in HBM. Reads never become Python objects: the library's FASTX
+reader (vm_fastx_read) fills blobs, `vacmap_amd.pipeline` cuts windows of `--window-batches` x `--batch-reads` reads into length-binned
+batches, several batches are in flight, each worker thread aligns its batch on the GPU (vm_align_batch) and turns the records into SAM
+text with `-t` host threads (vm_sam_emit, the C++ twin of vacmap_amd/sam.py) while the other batches align; every window is written
+in input order. Like the reference's worker (:24116-24134) a read whose path or whose emission raises is skipped, and a read without
+records produces no line.
 With N ranks, rank 0 builds the index and broadcasts it over RCCL (vacmap_amd/dist.py), batch i of a window goes to rank i mod N, and
 rank 0 gathers and writes the lines. `-mode asm` is not provided.
 """
 import argparse, gzip, os, shutil, struct, subprocess, sys, threading, queue
-from multiprocessing import Pool
 
 from . import sam
 
@@ -84,20 +85,25 @@ def read_bam(path):
             yield name, seq, qual, None
 
 
-_G = {}
+def _bam_chunks(path, n_max):
+    """BAM records as the blob chunks the FASTX reader yields (names, upper-cased sequences, qualities, no comments)"""
+    import numpy as np
+    cur = []
 
-
-def _emit_init(contigs, kw):
-    _G['contigs'] = contigs; _G['kw'] = kw
-
-
-def _emit(job):
-    name, seq, qual, comments, recs = job
-    try:
-        c = _G['contigs']
-        return sam.sam_lines(recs, seq, qual, lambda n, a, b: c[n][a:b], comments=comments, **_G['kw'])
-    except Exception:          # the reference's worker skips reads whose emission raises (:24127-24134)
-        return None
+    def pack(rows):
+        out = {}
+        for key, col in (('names', 0), ('seqs', 1), ('quals', 2)):
+            bs = [(r[col] or '').encode() for r in rows]
+            out[key] = np.frombuffer(b''.join(bs), dtype=np.uint8)
+            out[key + '_off'] = np.concatenate([[0], np.cumsum([len(b) for b in bs])]).astype(np.int64)
+        out['comments'] = np.zeros(0, np.uint8); out['comments_off'] = np.zeros(len(rows) + 1, np.int64)
+        return out
+    for name, seq, qual, _ in read_bam(path):
+        cur.append((name, seq.upper(), qual))
+        if len(cur) >= n_max:
+            yield pack(cur); cur = []
+    if cur:
+        yield pack(cur)
 
 
 RG_ARGS = (('rg-id', 'ID'), ('rg-sm', 'SM'), ('rg-lb', 'LB'), ('rg-pl', 'PL'), ('rg-ds', 'DS'), ('rg-dt', 'DT'), ('rg-pu', 'PU'), ('rg-pi', 'PI'),
@@ -128,13 +134,13 @@ def build_parser():
 def _open_output(path):
     """'-' / .sam: text; .bam / .sorted.bam: a `samtools view -b` / `samtools sort --write-index` pipe (output_functions.py:200-208)"""
     if path == '-':
-        return sys.stdout, None
+        return sys.stdout.buffer, None
     if path.endswith('.sam'):
-        return open(path, 'w'), None
+        return open(path, 'wb'), None
     if not shutil.which('samtools'):
         sys.exit('writing %s needs the samtools binary on PATH (the reference pipes SAM text into it too); write .sam instead' % path)
     cmd = ['samtools', 'sort', '-@', '8', '--write-index', '-o', path, '-'] if path.endswith('sorted.bam') else ['samtools', 'view', '-b', '-@', '8', '-o', path, '-']
-    proc = subprocess.Popen(cmd, stdin=subprocess.PIPE, encoding='utf-8', bufsize=64 * 1024)
+    proc = subprocess.Popen(cmd, stdin=subprocess.PIPE, bufsize=1 << 20)
     return proc.stdin, proc
 
 
@@ -179,7 +185,6 @@ def main(argv=None, comm=None):
     if args.globalpenalty is not None: prm.global_skipcost = args.globalpenalty
     if args.localpenalty is not None: prm.local_skipcost = args.localpenalty
     names = index.names
-    contigs = {n: index.seq(i).upper() for i, n in enumerate(names)}
     # read group: always present, like the reference (vacmap:186-218) — {'ID': '1', 'SM': 'sample'} unless --rg-* options are given
     rg = {}
     for a, tag in RG_ARGS:
@@ -191,34 +196,49 @@ def main(argv=None, comm=None):
     if not rg:
         rg = {'ID': '1', 'SM': 'sample'}
     mark = args.markunbalancetra or args.mode in ('H', 'L')          # mode defaults of vacmap:286-296
-    kw = dict(md=bool(args.MD), shortcs=(args.cs != 'long'), cigar2cg=args.L, markunbalancetra=mark, hardclip=args.H, fakecigar=args.fakecigar, rg_id=rg['ID'])
+    from .lib import SamOpts, Fastx, align_batch_raw, sam_emit, blob_gather
+    opts = SamOpts(int(bool(args.MD)), int(args.cs != 'long'), int(bool(args.L)), int(bool(mark)), int(bool(args.H)), int(bool(args.fakecigar)), rg['ID'].encode())
     out, proc = (None, None)
     if rank == 0:
         out, proc = _open_output(args.o)
-        for ln in sam.header_lines([(n, len(contigs[n])) for n in names], ' '.join(sys.argv if argv is None else ['vacmapx'] + list(argv)), rg):
-            out.write(ln + '\n')
-    pool = Pool(max(1, args.t), initializer=_emit_init, initargs=(contigs, kw)) if args.t > 1 else None
-    if pool is None:
-        _emit_init(contigs, kw)
+        for ln in sam.header_lines([(n, ln_) for n, ln_ in zip(names, index.lens)], ' '.join(sys.argv if argv is None else ['vacmapx'] + list(argv)), rg):
+            out.write(ln.encode() + b'\n')
     pipe = pipeline.Pipeline(index, prm, device=device, inflight=args.inflight, first_ctx=ctx)
+    emit_threads = max(1, args.t // max(1, pipe.inflight))            # -t host threads in all, shared by the batches in flight
     counts = {'reads': 0, 'lines': 0, 'skipped': 0}
     win_reads = max(1, args.batch_reads * args.window_batches)
+    import numpy as np
 
     def windows():
-        """input records in arrival order, upper-cased, de-duplicated by name (vacmap:457,475,487), cut into windows"""
-        seen = set(); cur = []
+        """input records in arrival order as blobs (names, upper-cased sequences, qualities, comments), de-duplicated by name
+        (vacmap:457,475,487), one window of at most win_reads reads at a time"""
+        seen = set()
         for group in args.read:
             for path in group:
-                it = read_bam(path) if path.endswith('.bam') else read_fastx(path, want_comment=args.copycomments)
-                for name, seq, qual, com in it:
-                    if name in seen:
-                        continue
-                    seen.add(name)
-                    cur.append((name, seq.upper(), None if args.Q else qual, com))
-                    if len(cur) >= win_reads:
-                        yield cur; cur = []
-        if cur:
-            yield cur
+                if path.endswith('.bam'):
+                    chunks = _bam_chunks(path, win_reads)
+                else:
+                    rd = Fastx(path, lib=lib)
+                    chunks = iter(lambda rd=rd: rd.read(win_reads), None)
+                for ch in chunks:
+                    n = len(ch['seqs_off']) - 1
+                    nb, no = ch['names'].tobytes(), ch['names_off']
+                    keep = []
+                    for i in range(n):
+                        nm = nb[no[i]:no[i + 1]]
+                        if nm in seen:
+                            continue
+                        seen.add(nm); keep.append(i)
+                    if len(keep) < n:
+                        ix = np.asarray(keep, dtype=np.int64)
+                        for key in ('names', 'seqs', 'quals', 'comments'):
+                            ch[key], ch[key + '_off'] = blob_gather(lib, ch[key], ch[key + '_off'], ix)
+                    if args.Q:
+                        ch['quals_off'] = np.zeros(len(ch['seqs_off']), np.int64)
+                    if not args.copycomments:
+                        ch['comments_off'] = np.zeros(len(ch['seqs_off']), np.int64)
+                    if len(ch['seqs_off']) > 1:
+                        yield ch
 
     wq = queue.Queue(maxsize=2)
 
@@ -231,81 +251,49 @@ def main(argv=None, comm=None):
             wq.put(e)
 
     threading.Thread(target=reader, daemon=True).start()
-    outq = queue.Queue(maxsize=2)
-    werr = []
-
-    def writer():
-        """collects a window's emission results, gathers the ranks' lines on rank 0 and writes them in input order"""
-        try:
-            while True:
-                item = outq.get()
-                if item is None:
-                    return
-                pending = item                               # [(read index in window, AsyncResult or list)]
-                mine = {}
-                for ids, res in pending:
-                    lines = res.get() if hasattr(res, 'get') else res
-                    for ridx, ls in zip(ids, lines):
-                        if ls is None:
-                            counts['skipped'] += 1
-                        else:
-                            mine[ridx] = ls
-                if world > 1:
-                    from .dist import gather_lines
-                    parts = gather_lines(mine, dst=0)
-                    if rank != 0:
-                        continue
-                    mine = {}
-                    for d in parts:
-                        mine.update(d)
-                for ridx in sorted(mine):
-                    for ln in mine[ridx]:
-                        out.write(ln + '\n'); counts['lines'] += 1
-        except BaseException as e:
-            werr.append(e)
-
-    wt = threading.Thread(target=writer)
-    wt.start()
-    import numpy as np
     while True:
         wnd = wq.get()
         if wnd is None:
             break
         if isinstance(wnd, BaseException):
-            outq.put(None); wt.join()
             raise wnd
-        counts['reads'] += len(wnd)
-        plan = pipeline.plan_batches(np.fromiter((len(r[1]) for r in wnd), dtype=np.int64, count=len(wnd)), args.batch_reads, args.window_batches)
+        n = len(wnd['seqs_off']) - 1
+        counts['reads'] += n
+        plan = pipeline.plan_batches(np.diff(wnd['seqs_off']), args.batch_reads, args.window_batches)
         plan = [plan[i] for i in range(rank, len(plan), world)]        # static sharding: batch i -> rank i mod N
-        pending = []
+        has_q = bool(wnd['quals_off'][-1]); has_c = bool(wnd['comments_off'][-1])
 
-        def on_result(i, res, plan=plan, wnd=wnd, pending=pending):
-            status, recs, _ = res
-            per = {}
-            for t in recs:
-                per.setdefault(t[0], []).append(t)
-            jobs, ids = [], []
-            for j, ridx in enumerate(plan[i]):
-                if status[j] != 0:
-                    counts['skipped'] += 1
-                    continue
-                rr = per.get(j)
-                if not rr:
-                    continue
-                name, seq, qual, com = wnd[int(ridx)]
-                jobs.append((name, seq, qual, com, [(name, names[t[1]], t[2], t[3], t[4], t[5], t[6], t[7], t[8]) for t in rr]))
-                ids.append(int(ridx))
-            pending.append((ids, pool.map_async(_emit, jobs, chunksize=16) if pool else [_emit(jb) for jb in jobs]))
+        def job(i, cx, plan=plan, wnd=wnd):
+            """one batch: gather its reads from the window, align (GPU), emit SAM text (host threads); everything below releases the GIL"""
+            ix = plan[i]
+            sb, so = blob_gather(lib, wnd['seqs'], wnd['seqs_off'], ix)
+            raw = align_batch_raw(cx, index, prm, sb, so)
+            nb, no = blob_gather(lib, wnd['names'], wnd['names_off'], ix)
+            qb, qo = blob_gather(lib, wnd['quals'], wnd['quals_off'], ix) if has_q else (None, None)
+            cb, co = blob_gather(lib, wnd['comments'], wnd['comments_off'], ix) if has_c else (None, None)
+            text, toff, nl, ns = sam_emit(lib, index, opts, nb, no, sb, so, raw, quals=qb, qual_off=qo, comments=cb, com_off=co, nthreads=emit_threads)
+            raw.close()
+            return ix, text, toff, nl, ns
 
-        pipe.run_host([[wnd[int(r)][1] for r in b] for b in plan], on_result=on_result)
-        outq.put(pending)
-        if werr:
-            break
-    outq.put(None); wt.join()
-    if werr:
-        raise werr[0]
-    if pool:
-        pool.close(); pool.join()
+        done = []
+        pipe._run(len(plan), job, lambda i, res: done.append(res))
+        parts = [(ix, text, toff) for ix, text, toff, _, _ in done]
+        counts['lines'] += sum(r[3] for r in done); counts['skipped'] += sum(r[4] for r in done)
+        if world > 1:
+            from .dist import gather_lines
+            allp = gather_lines(parts, dst=0)
+            if rank != 0:
+                continue
+            parts = [p for rp in allp for p in rp]
+        # the window's lines in input order: one more gather over the concatenated batch texts
+        if parts:
+            ridx = np.concatenate([p[0] for p in parts])
+            big = np.concatenate([p[1] for p in parts]) if len(parts) > 1 else parts[0][1]
+            lens = np.concatenate([np.diff(p[2]) for p in parts])
+            boff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            order = np.argsort(ridx, kind='stable')
+            txt, _ = blob_gather(lib, big, boff, order)
+            out.write(memoryview(txt))
     pipe.close()
     if rank == 0:
         if proc is not None:
@@ -313,8 +301,10 @@ def main(argv=None, comm=None):
             rc = proc.wait()
             if rc != 0:
                 sys.stderr.write('Error: samtools exited with code %d\n' % rc)
-        elif out is not sys.stdout:
+        elif args.o != '-':
             out.close()
+        else:
+            out.flush()
         sys.stderr.write('vacmapx: %d reads, %d SAM lines, %d reads skipped\n' % (counts['reads'], counts['lines'], counts['skipped']))
     if own_group:
         comm.barrier(); comm.destroy_process_group()

@@ -54,6 +54,11 @@ class Record(C.Structure):
                 ('cigar_off', C.c_int64), ('cigar_len', C.c_int64)]
 
 
+class SamOpts(C.Structure):
+    _fields_ = [('md', C.c_int32), ('shortcs', C.c_int32), ('cigar2cg', C.c_int32), ('markunbalancetra', C.c_int32), ('hardclip', C.c_int32),
+                ('fakecigar', C.c_int32), ('rg_id', C.c_char_p)]
+
+
 class BatchStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ('n_reads', 'read_bases', 'n_minimizers', 'n_hits', 'n_anchors', 'n_local_hits', 'n_local_anchors',
                                           'n_segments', 'n_ed_problems', 'ed_cells', 'n_ext_problems', 'ext_cells', 'n_dp_problems',
@@ -143,6 +148,10 @@ class VmxLib:
         L.vm_local_out_free.argtypes = [P(LocalOut)]
         L.vm_align_batch.argtypes = [vp, vp, P(Params), i64, cp, vp, P(P(Record)), P(i64), P(vp), vp, P(BatchStats)]
         L.vm_align_trace.argtypes = [vp, vp, P(Params), i64, cp, vp, C.c_int, P(P(i64)), P(P(i64))]
+        L.vm_sam_emit.argtypes = [vp, P(SamOpts), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, C.c_int, P(vp), P(P(i64)), P(i64), P(i64)]
+        L.vm_blob_gather.argtypes = [vp, vp, vp, i64, vp, vp]; L.vm_blob_gather.restype = i64
+        L.vm_fastx_open.argtypes = [cp, P(vp)]; L.vm_fastx_close.argtypes = [vp]
+        L.vm_fastx_read.argtypes = [vp, i64, i64] + [P(vp), P(P(i64))] * 4; L.vm_fastx_read.restype = i64
         L.vm_reads_upload.argtypes = [vp, i64, cp, vp, P(vp)]
         L.vm_reads_free.argtypes = [vp]
         L.vm_align_resident.argtypes = [vp, vp, P(Params), vp, P(P(Record)), P(i64), P(vp), vp, P(BatchStats)]
@@ -364,6 +373,112 @@ def align_trace(ctx, index, prm, seqs, stage):
     a = np.ctypeslib.as_array(rows, shape=(max(tot, 1), 5))[:tot].copy()
     ctx.lib.L.vm_free(rows)
     return [a[o[i]:o[i + 1]] for i in range(n)]
+
+
+class RawBatch:
+    """result of vm_align_batch kept in library memory (no per-record Python objects): what the native SAM emitter consumes"""
+
+    def __init__(self, ctx, status, recs, nrec, blob, stats):
+        self.ctx, self.status, self.recs, self.nrec, self.blob = ctx, status, recs, nrec, blob
+        self.stats = {k: getattr(stats, k) for k, _ in BatchStats._fields_ if k != 'ms_stage'}
+        self.stats['ms_stage'] = list(stats.ms_stage)
+
+    def close(self):
+        if self.recs is not None:
+            self.ctx.lib.L.vm_free(self.recs); self.ctx.lib.L.vm_free(self.blob)
+            self.recs = self.blob = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def align_batch_raw(ctx, index, prm, seq_blob, seq_off):
+    """vm_align_batch on a read blob (uint8 array + int64 offsets[n + 1]); the records stay in library memory (RawBatch)"""
+    seq_blob = _u8(seq_blob); seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
+    n = len(seq_off) - 1
+    status = np.zeros(max(n, 1), np.int32)
+    recs = C.POINTER(Record)(); nrec = C.c_int64(); blob = C.c_void_p(); stats = BatchStats()
+    ctx.lib.check(ctx.lib.L.vm_align_batch(ctx.h, index.h, C.byref(prm), n, seq_blob.ctypes.data_as(C.c_char_p), seq_off.ctypes.data, C.byref(recs), C.byref(nrec),
+                                           C.byref(blob), status.ctypes.data, C.byref(stats)))
+    return RawBatch(ctx, status[:n], recs, nrec.value, blob, stats)
+
+
+def sam_emit(lib, index, opts, names, name_off, seqs, seq_off, raw, quals=None, qual_off=None, comments=None, com_off=None, nthreads=8):
+    """SAM lines of a batch (vm_sam_emit): returns (text as a uint8 array, text_off[n + 1], n_lines, n_skipped). Blobs are uint8 arrays,
+    offsets int64; quals / comments may be None."""
+    names = _u8(names); seqs = _u8(seqs)
+    name_off = np.ascontiguousarray(name_off, dtype=np.int64); seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
+    n = len(seq_off) - 1
+    q = _u8(quals) if quals is not None else None; qo = np.ascontiguousarray(qual_off, dtype=np.int64) if quals is not None else None
+    cm = _u8(comments) if comments is not None else None; co = np.ascontiguousarray(com_off, dtype=np.int64) if comments is not None else None
+    text = C.c_void_p(); toff = C.POINTER(C.c_int64)(); nl = C.c_int64(); ns = C.c_int64()
+    lib.check(lib.L.vm_sam_emit(index.h, C.byref(opts), n, names.ctypes.data, name_off.ctypes.data, seqs.ctypes.data, seq_off.ctypes.data,
+                                q.ctypes.data if q is not None else None, qo.ctypes.data if qo is not None else None,
+                                cm.ctypes.data if cm is not None else None, co.ctypes.data if co is not None else None,
+                                C.cast(raw.recs, C.c_void_p), raw.nrec, raw.blob, raw.status.ctypes.data if len(raw.status) else None, int(nthreads),
+                                C.byref(text), C.byref(toff), C.byref(nl), C.byref(ns)))
+    off = np.ctypeslib.as_array(toff, shape=(n + 1,)).copy()
+    lib.L.vm_free(toff)
+    tot = int(off[-1])
+    buf = np.ctypeslib.as_array(C.cast(text, C.POINTER(C.c_uint8)), shape=(max(tot, 1),))[:tot].copy()
+    lib.L.vm_free(text)
+    return buf, off, nl.value, ns.value
+
+
+def blob_gather(lib, blob, off, idx):
+    """entries idx of (blob, off) back to back: (uint8 array, int64 offsets) — one memcpy loop in the library (vm_blob_gather)"""
+    blob = _u8(blob); off = np.ascontiguousarray(off, dtype=np.int64); idx = np.ascontiguousarray(idx, dtype=np.int64)
+    n = len(idx)
+    oo = np.empty(n + 1, np.int64)
+    tot = int((off[idx + 1] - off[idx]).sum()) if n else 0
+    out = np.empty(max(tot, 1), np.uint8)
+    lib.L.vm_blob_gather(blob.ctypes.data, off.ctypes.data, idx.ctypes.data, n, out.ctypes.data, oo.ctypes.data)
+    return out[:tot], oo
+
+
+class Fastx:
+    """FASTA / FASTQ(.gz) reader into blobs (vm_fastx_*): the native counterpart of mp.fastx_read (vacmap:445)"""
+
+    def __init__(self, path, lib=None):
+        self.lib = lib or load()
+        h = C.c_void_p()
+        self.lib.check(self.lib.L.vm_fastx_open(_b(path), C.byref(h)))
+        self.h = h
+
+    def read(self, max_reads, max_bases=1 << 62):
+        """next chunk: dict of uint8 blobs and int64 offsets (names, seqs, quals, comments), or None at the end of the input"""
+        ptrs = [C.c_void_p() for _ in range(4)]; offs = [C.POINTER(C.c_int64)() for _ in range(4)]
+        args = []
+        for p, o in zip(ptrs, offs):
+            args += [C.byref(p), C.byref(o)]
+        n = self.lib.L.vm_fastx_read(self.h, int(max_reads), int(max_bases), *args)
+        if n < 0:
+            raise VmxError(int(n), self.lib.err())
+        out = {}
+        for key, p, o in zip(('names', 'seqs', 'quals', 'comments'), ptrs, offs):
+            oo = np.ctypeslib.as_array(o, shape=(n + 1,)).copy(); self.lib.L.vm_free(o)
+            tot = int(oo[-1])
+            out[key] = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(tot, 1),))[:tot].copy()
+            out[key + '_off'] = oo
+            self.lib.L.vm_free(p)
+        return out if n > 0 else None
+
+    def close(self):
+        if self.h:
+            self.lib.L.vm_fastx_close(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ResidentReads:
