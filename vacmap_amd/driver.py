@@ -15,7 +15,7 @@ records produces no line.
 With N ranks, rank 0 builds the index and broadcasts it over RCCL (vacmap_amd/dist.py), batch i of a window goes to rank i mod N, and
 rank 0 gathers and writes the lines. `-mode asm` is not provided.
 """
-import argparse, gzip, os, shutil, struct, subprocess, sys, threading, queue
+import argparse, gzip, os, shutil, struct, subprocess, sys, threading, time, queue
 
 from . import sam
 
@@ -251,11 +251,45 @@ def main(argv=None, comm=None):
             wq.put(e)
 
     threading.Thread(target=reader, daemon=True).start()
-    while True:
+    oq = queue.Queue(maxsize=2)
+    werr = []
+    tm = {'wait_input': 0.0, 'align_emit': 0.0, 'assemble_write': 0.0}
+
+    def writer():
+        """a window's lines in input order (one more gather over the concatenated batch texts) while the next window aligns"""
+        try:
+            while True:
+                parts = oq.get()
+                if parts is None:
+                    return
+                t0 = time.time()
+                if world > 1:
+                    from .dist import gather_lines
+                    allp = gather_lines(parts, dst=0)
+                    if rank != 0:
+                        continue
+                    parts = [p for rp in allp for p in rp]
+                if parts:
+                    ridx = np.concatenate([p[0] for p in parts])
+                    big = np.concatenate([p[1] for p in parts]) if len(parts) > 1 else parts[0][1]
+                    lens = np.concatenate([np.diff(p[2]) for p in parts])
+                    boff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+                    txt, _ = blob_gather(lib, big, boff, np.argsort(ridx, kind='stable'))
+                    out.write(memoryview(txt))
+                tm['assemble_write'] += time.time() - t0
+        except BaseException as e:
+            werr.append(e)
+
+    wt = threading.Thread(target=writer)
+    wt.start()
+    while not werr:
+        t0 = time.time()
         wnd = wq.get()
+        tm['wait_input'] += time.time() - t0
         if wnd is None:
             break
         if isinstance(wnd, BaseException):
+            oq.put(None); wt.join()
             raise wnd
         n = len(wnd['seqs_off']) - 1
         counts['reads'] += n
@@ -263,7 +297,7 @@ def main(argv=None, comm=None):
         plan = [plan[i] for i in range(rank, len(plan), world)]        # static sharding: batch i -> rank i mod N
         has_q = bool(wnd['quals_off'][-1]); has_c = bool(wnd['comments_off'][-1])
 
-        def job(i, cx, plan=plan, wnd=wnd):
+        def job(i, cx, plan=plan, wnd=wnd, has_q=has_q, has_c=has_c):
             """one batch: gather its reads from the window, align (GPU), emit SAM text (host threads); everything below releases the GIL"""
             ix = plan[i]
             sb, so = blob_gather(lib, wnd['seqs'], wnd['seqs_off'], ix)
@@ -276,24 +310,16 @@ def main(argv=None, comm=None):
             return ix, text, toff, nl, ns
 
         done = []
+        t0 = time.time()
         pipe._run(len(plan), job, lambda i, res: done.append(res))
-        parts = [(ix, text, toff) for ix, text, toff, _, _ in done]
+        tm['align_emit'] += time.time() - t0
         counts['lines'] += sum(r[3] for r in done); counts['skipped'] += sum(r[4] for r in done)
-        if world > 1:
-            from .dist import gather_lines
-            allp = gather_lines(parts, dst=0)
-            if rank != 0:
-                continue
-            parts = [p for rp in allp for p in rp]
-        # the window's lines in input order: one more gather over the concatenated batch texts
-        if parts:
-            ridx = np.concatenate([p[0] for p in parts])
-            big = np.concatenate([p[1] for p in parts]) if len(parts) > 1 else parts[0][1]
-            lens = np.concatenate([np.diff(p[2]) for p in parts])
-            boff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-            order = np.argsort(ridx, kind='stable')
-            txt, _ = blob_gather(lib, big, boff, order)
-            out.write(memoryview(txt))
+        oq.put([(ix, text, toff) for ix, text, toff, _, _ in done])
+    oq.put(None); wt.join()
+    if werr:
+        raise werr[0]
+    if os.environ.get('VMX_DRIVER_TIMING'):
+        sys.stderr.write('vacmapx timing (s): %s\n' % ' '.join('%s=%.2f' % kv for kv in tm.items()))
     pipe.close()
     if rank == 0:
         if proc is not None:
