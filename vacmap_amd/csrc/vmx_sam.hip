@@ -60,7 +60,7 @@ static int64_t nm_from_cigar(const Ops& o, const char* q, int64_t ql, const char
     for (size_t i = 0; i < o.op.size(); ++i) {
         const int64_t n = o.n[i];
         switch (o.op[i]) {
-            case 'M': if (qp + n > ql || rp + n > tl) throw Raise(); for (int64_t x = 0; x < n; ++x) nm += up(q[qp + x]) != up(t[rp + x]); qp += n; rp += n; break;
+            case 'M': if (qp + n > ql || rp + n > tl) throw Raise(); { const char* a = q + qp; const char* b = t + rp; int64_t d = 0; for (int64_t x = 0; x < n; ++x) d += ((a[x] ^ b[x]) & 0xDF) != 0; nm += d; } qp += n; rp += n; break;   /* letters compared case-insensitively */
             case '=': qp += n; rp += n; break;
             case 'X': nm += n; qp += n; rp += n; break;
             case 'I': nm += n; qp += n; break;
@@ -281,6 +281,7 @@ int vm_sam_emit(const vm_index* mi, const vm_sam_opts* o, int64_t n_reads, const
             while (true) {
                 const int64_t c = next.fetch_add(1); if (c >= nch) break;
                 std::string& out = part[(size_t)c];
+                { int64_t est = 0; for (int64_t r = c * CH; r < std::min(n_reads, (c + 1) * CH); ++r) est += 2 * (seq_off[r + 1] - seq_off[r]) + (seq_off[r + 1] - seq_off[r]) / 2 + 512; out.reserve((size_t)est); }
                 for (int64_t r = c * CH; r < std::min(n_reads, (c + 1) * CH); ++r) {
                     const size_t before = out.size();
                     if (status && status[r] != 0) { skipped.fetch_add(1); continue; }
@@ -298,10 +299,16 @@ int vm_sam_emit(const vm_index* mi, const vm_sam_opts* o, int64_t n_reads, const
         };
         if (nthreads == 1 || nch <= 1) work();
         else { std::vector<std::thread> th; for (int t = 0; t < nthreads && t < nch; ++t) th.emplace_back(work); for (auto& t : th) t.join(); }
-        size_t tot = 0; for (auto& p : part) tot += p.size();
+        size_t tot = 0; std::vector<size_t> pstart(part.size() + 1, 0);
+        for (size_t i = 0; i < part.size(); ++i) { pstart[i] = tot; tot += part[i].size(); }
         *text = (char*)malloc(tot + 1); *text_off = (int64_t*)malloc(8 * ((size_t)n_reads + 1));
         if (!*text || !*text_off) { free(*text); free(*text_off); *text = nullptr; *text_off = nullptr; set_error("out of host memory"); return VM_ERR_OOM; }
-        size_t w = 0; for (auto& p : part) { memcpy(*text + w, p.data(), p.size()); w += p.size(); }
+        {   // the parts are copied into place by the same number of threads (a batch's text is ~150 MB)
+            std::atomic<size_t> nx(0);
+            auto cp = [&]() { while (true) { const size_t i = nx.fetch_add(1); if (i >= part.size()) break; memcpy(*text + pstart[i], part[i].data(), part[i].size()); std::string().swap(part[i]); } };
+            if (nthreads == 1 || part.size() <= 1) cp();
+            else { std::vector<std::thread> th; for (int t = 0; t < nthreads && (size_t)t < part.size(); ++t) th.emplace_back(cp); for (auto& t : th) t.join(); }
+        }
         (*text)[tot] = 0;
         int64_t acc = 0; for (int64_t r = 0; r < n_reads; ++r) { (*text_off)[r] = acc; acc += rlen[(size_t)r]; }
         (*text_off)[n_reads] = acc;
@@ -322,27 +329,37 @@ int64_t vm_blob_gather(const char* blob, const int64_t* off, const int64_t* idx,
 }
 
 // ------------------------------------------------------------------------------------------------ FASTA / FASTQ(.gz) reader
-struct vm_fastx { gzFile f; std::string buf; size_t pos = 0; bool eof = false; std::string line, pending; bool have_pending = false; };
+struct vm_fastx { gzFile f; std::string buf; size_t pos = 0; bool eof = false; };
 
 static bool fx_fill(vm_fastx* x) {
     if (x->eof) return false;
     if (x->pos > 0) { x->buf.erase(0, x->pos); x->pos = 0; }
-    const size_t old = x->buf.size(), want = (size_t)4 << 20;
+    const size_t old = x->buf.size(), want = (size_t)8 << 20;
     x->buf.resize(old + want);
     const int n = gzread(x->f, &x->buf[old], (unsigned)want);
     x->buf.resize(old + (n > 0 ? (size_t)n : 0));
     if (n <= 0) x->eof = true;
     return n > 0;
 }
-// next line without its terminator; false at end of input
-static bool fx_line(vm_fastx* x, std::string& out) {
-    if (x->have_pending) { out.swap(x->pending); x->have_pending = false; return true; }
+// next line as a VIEW into the read buffer (valid until the next call), without its terminator; false at end of input.
+// peek = true leaves the line unconsumed.
+static bool fx_line(vm_fastx* x, const char*& p, size_t& len, bool peek = false) {
     while (true) {
         const char* b = x->buf.data() + x->pos; const size_t n = x->buf.size() - x->pos;
         const char* nl = n ? (const char*)memchr(b, '\n', n) : nullptr;
-        if (nl) { size_t len = (size_t)(nl - b); out.assign(b, len); x->pos += len + 1; if (!out.empty() && out.back() == '\r') out.pop_back(); return true; }
-        if (!fx_fill(x)) { if (n == 0) return false; out.assign(b, n); x->pos += n; if (!out.empty() && out.back() == '\r') out.pop_back(); return true; }
+        size_t l, adv;
+        if (nl) { l = (size_t)(nl - b); adv = l + 1; }
+        else { if (fx_fill(x)) continue; if (n == 0) return false; l = n; adv = n; }
+        if (l && b[l - 1] == '\r') --l;
+        p = b; len = l;
+        if (!peek) x->pos += adv;
+        return true;
     }
+}
+static inline void fx_append_upper(std::string& dst, const char* p, size_t n) {
+    const size_t o = dst.size(); dst.resize(o + n);
+    char* d = &dst[o];
+    for (size_t i = 0; i < n; ++i) { const char c = p[i]; d[i] = (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
 }
 
 int vm_fastx_open(const char* path, vm_fastx** out) {
@@ -363,30 +380,29 @@ int64_t vm_fastx_read(vm_fastx* x, int64_t max_reads, int64_t max_bases, char** 
                       char** comments, int64_t** com_off) {
     try {
         std::string nb, sb, qb, cb; std::vector<int64_t> no(1, 0), so(1, 0), qo(1, 0), co(1, 0);
-        int64_t n = 0; std::string ln, s2;
+        int64_t n = 0; const char* p; size_t len;
         while (n < max_reads && (int64_t)sb.size() < max_bases) {
-            if (!fx_line(x, ln)) break;
-            if (ln.empty()) continue;
-            if (ln[0] != '>' && ln[0] != '@') { set_error("not FASTA/FASTQ: " + ln.substr(0, 40)); return VM_ERR_IO; }
-            const bool fq = ln[0] == '@';
-            size_t sp = ln.find(' ', 1);                         // name | comment: at the first blank, else at the first tab (driver.read_fastx)
-            if (sp == std::string::npos || sp + 1 == ln.size()) { const size_t tb = ln.find('\t', 1); if (sp == std::string::npos) sp = tb; else if (tb != std::string::npos && tb < sp) sp = tb; }
-            nb.append(ln, 1, sp == std::string::npos ? std::string::npos : sp - 1);
-            if (sp != std::string::npos) cb.append(ln, sp + 1, std::string::npos);
+            if (!fx_line(x, p, len)) break;
+            if (len == 0) continue;
+            if (p[0] != '>' && p[0] != '@') { set_error("not FASTA/FASTQ: " + std::string(p, len < 40 ? len : 40)); return VM_ERR_IO; }
+            const bool fq = p[0] == '@';
+            {   // name | comment: at the first blank, else at the first tab (driver.read_fastx)
+                const char* sp = (const char*)memchr(p + 1, ' ', len - 1);
+                if (!sp || sp + 1 == p + len) { const char* tb = (const char*)memchr(p + 1, '\t', len - 1); if (!sp) sp = tb; else if (tb && tb < sp) sp = tb; }
+                if (sp) { nb.append(p + 1, (size_t)(sp - p - 1)); cb.append(sp + 1, (size_t)(p + len - sp - 1)); } else nb.append(p + 1, len - 1);
+            }
             if (fq) {
-                if (!fx_line(x, s2)) { set_error("truncated FASTQ record"); return VM_ERR_IO; }
-                const size_t s0 = sb.size(); sb.append(s2);
-                for (size_t i = s0; i < sb.size(); ++i) sb[i] = up(sb[i]);
-                if (!fx_line(x, s2) || !fx_line(x, s2)) { set_error("truncated FASTQ record"); return VM_ERR_IO; }
-                qb.append(s2);
+                if (!fx_line(x, p, len)) { set_error("truncated FASTQ record"); return VM_ERR_IO; }
+                fx_append_upper(sb, p, len);
+                if (!fx_line(x, p, len) || !fx_line(x, p, len)) { set_error("truncated FASTQ record"); return VM_ERR_IO; }
+                qb.append(p, len);
             } else {
-                const size_t s0 = sb.size();
-                while (fx_line(x, s2)) {
-                    if (!s2.empty() && s2[0] == '>') { x->pending.swap(s2); x->have_pending = true; break; }
-                    size_t a = 0, b = s2.size(); while (a < b && (s2[a] == ' ' || s2[a] == '\t')) ++a; while (b > a && (s2[b - 1] == ' ' || s2[b - 1] == '\t')) --b;
-                    sb.append(s2, a, b - a);
+                while (fx_line(x, p, len, true)) {
+                    if (len && p[0] == '>') break;
+                    fx_line(x, p, len);
+                    size_t a = 0, b = len; while (a < b && (p[a] == ' ' || p[a] == '\t')) ++a; while (b > a && (p[b - 1] == ' ' || p[b - 1] == '\t')) --b;
+                    fx_append_upper(sb, p + a, b - a);
                 }
-                for (size_t i = s0; i < sb.size(); ++i) sb[i] = up(sb[i]);
             }
             no.push_back((int64_t)nb.size()); so.push_back((int64_t)sb.size()); qo.push_back((int64_t)qb.size()); co.push_back((int64_t)cb.size());
             ++n;

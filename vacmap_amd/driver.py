@@ -300,13 +300,19 @@ def main(argv=None, comm=None):
         def job(i, cx, plan=plan, wnd=wnd, has_q=has_q, has_c=has_c):
             """one batch: gather its reads from the window, align (GPU), emit SAM text (host threads); everything below releases the GIL"""
             ix = plan[i]
+            t0 = time.time()
             sb, so = blob_gather(lib, wnd['seqs'], wnd['seqs_off'], ix)
+            t1 = time.time()
             raw = align_batch_raw(cx, index, prm, sb, so)
+            t2 = time.time()
             nb, no = blob_gather(lib, wnd['names'], wnd['names_off'], ix)
             qb, qo = blob_gather(lib, wnd['quals'], wnd['quals_off'], ix) if has_q else (None, None)
             cb, co = blob_gather(lib, wnd['comments'], wnd['comments_off'], ix) if has_c else (None, None)
+            t3 = time.time()
             text, toff, nl, ns = sam_emit(lib, index, opts, nb, no, sb, so, raw, quals=qb, qual_off=qo, comments=cb, com_off=co, nthreads=emit_threads)
             raw.close()
+            t4 = time.time()
+            tm['job_gather'] = tm.get('job_gather', 0.0) + (t1 - t0) + (t3 - t2); tm['job_align'] = tm.get('job_align', 0.0) + (t2 - t1); tm['job_emit'] = tm.get('job_emit', 0.0) + (t4 - t3)
             return ix, text, toff, nl, ns
 
         done = []

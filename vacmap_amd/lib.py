@@ -427,9 +427,21 @@ def sam_emit(lib, index, opts, names, name_off, seqs, seq_off, raw, quals=None, 
     off = np.ctypeslib.as_array(toff, shape=(n + 1,)).copy()
     lib.L.vm_free(toff)
     tot = int(off[-1])
-    buf = np.ctypeslib.as_array(C.cast(text, C.POINTER(C.c_uint8)), shape=(max(tot, 1),))[:tot].copy()
-    lib.L.vm_free(text)
-    return buf, off, nl.value, ns.value
+    buf = _OwnedText(lib, text, tot)          # a view of the library's buffer (no copy of ~150 MB per batch); freed with the object
+    return buf.array, off, nl.value, ns.value
+
+
+class _OwnedText:
+    """uint8 view of a library-allocated buffer; the memory lives as long as any array derived from `.array` does"""
+
+    def __init__(self, lib, ptr, n):
+        self.lib, self.ptr = lib, ptr
+        self.array = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n]
+        import weakref
+        base = self.array
+        while isinstance(getattr(base, 'base', None), np.ndarray):
+            base = base.base
+        weakref.finalize(base, lib.L.vm_free, ptr)
 
 
 def blob_gather(lib, blob, off, idx):
