@@ -122,6 +122,33 @@ def test_mode_r_and_s(ctx, oracle, golden):
     KC.check_align_golden(ctx, oracle, golden, cases=['I'])      # rare branches of the segment surgery (mode H)
 
 
+def test_n_runs_in_read_and_reference(ctx, oracle):
+    """ambiguous bases on both sides (DESIGN.md deviation D6: one code for every non-ACGT base): runs of N in the reference, N and IUPAC
+    letters in the reads, lower case — the GPU path and the oracle agree read by read, and `seq()` returns N like minimap2's 4-bit store"""
+    from vacmap_amd import synth
+    from vacmap_amd.lib import Index, align_batch
+    rng = np.random.default_rng(81)
+    ref = synth.make_reference([400000], seed=82)[0]
+    for p0, ln in ((50000, 40), (120000, 300), (120400, 7), (250000, 2500)):
+        ref[p0:p0 + ln] = ord('N')
+    names = ['chrN']
+    gi = Index.from_seqs(ctx, names, [ref], k=15, w=10)
+    oi = oracle.Index.from_seqs(names, [ref], k=15, w=10)
+    assert gi.seq(0, 49990, 50050) == oi.seq(0, 49990, 50050) and 'N' * 40 in gi.seq(0, 49990, 50050)
+    reads = []
+    for st in (46000, 116000, 246000, 300000):
+        rd = synth.mutate(ref[st:st + 9000], 0.06, rng)
+        rd[1000:1012] = ord('N'); rd[4000] = ord('R'); rd[4001] = ord('Y')
+        reads.append(rd.tobytes())
+        reads.append(synth.revcomp(rd).tobytes().lower())
+    prm = ctx.lib.params('H'); op = oracle.params('H')
+    status, recs, _ = align_batch(ctx, gi, prm, [r.upper() for r in reads])
+    for i, rd in enumerate(reads):
+        ost, orecs = oracle.align_read(oi, rd.upper(), op)
+        assert (status[i] == 0) == (ost == 0) and [t[1:] for t in recs if t[0] == i] == [t[1:] for t in orecs], i
+    assert len(recs) >= len(reads)
+
+
 def test_extend_stage_trace(ctx, oracle, golden):
     """E1 / E3 / E4 stage by stage (golden V4): the segment lists the GPU path holds after rebuild_chain_break, after the extension
     rounds + drop_misplaced loop and after merge_conjacent + fix_simple_inv equal the lists the reference held at those points — all
