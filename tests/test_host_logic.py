@@ -109,3 +109,37 @@ def test_two_rank_sharding_gloo(tmp_path):
     line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
     d = json.loads(line)
     assert d['reads'] == 16.0 and d['tmax'] == 1.5 and d['bases'] > 16 * 1000
+
+
+def _write_bam(path, records):
+    """minimal BAM writer for the reader test: records = (name, seq, qual or None, flag); BGZF = a series of gzip members"""
+    import gzip, struct
+    code = {c: i for i, c in enumerate('=ACMGRSVTWYHKDBN')}
+    body = b'BAM\x01' + struct.pack('<i', 0) + struct.pack('<i', 0)
+    blocks = [body]
+    for name, seq, qual, flag in records:
+        nm = name.encode() + b'\0'
+        packed = bytearray((len(seq) + 1) // 2)
+        for i, ch in enumerate(seq):
+            packed[i // 2] |= code[ch] << (4 if i % 2 == 0 else 0)
+        q = bytes([0xff] * len(seq)) if qual is None else bytes(ord(c) - 33 for c in qual)
+        rec = struct.pack('<iiBBHHHiiii', -1, -1, len(nm), 0, 4680, 0, flag, len(seq), -1, -1, 0) + nm + bytes(packed) + q
+        blocks.append(struct.pack('<i', len(rec)) + rec)
+    with open(path, 'wb') as f:
+        for i in range(0, len(blocks), 3):                       # several gzip members, like BGZF blocks
+            f.write(gzip.compress(b''.join(blocks[i:i + 3])))
+
+
+def test_bam_reader_and_blob_chunks(tmp_path):
+    """driver.read_bam (vacmap:455-471): names, sequences, qualities; a reverse-strand record comes back in the read's own orientation;
+    missing qualities (0xff) and empty sequences are handled like the reference's pysam loop"""
+    from vacmap_amd import driver
+    recs = [('r1', 'ACGTNACGTA', 'IIIIIHHHHH', 0), ('r2', 'AACCGGTTA', 'ABCDEFGHI', 16), ('r3', 'GATTACA', None, 4), ('r4', '', None, 4), ('r5', 'ACGRYK', '!!!!!!', 0)]
+    p = str(tmp_path / 'x.bam')
+    _write_bam(p, recs)
+    got = list(driver.read_bam(p))
+    assert got == [('r1', 'ACGTNACGTA', 'IIIIIHHHHH', None), ('r2', 'TAACCGGTT', 'IHGFEDCBA', None), ('r3', 'GATTACA', None, None), ('r5', 'ACGRYK', '!!!!!!', None)]
+    chunks = list(driver._bam_chunks(p, 3))
+    assert [len(c['seqs_off']) - 1 for c in chunks] == [3, 1]
+    c0 = chunks[0]
+    assert c0['seqs'].tobytes() == b'ACGTNACGTATAACCGGTTGATTACA' and c0['quals_off'].tolist() == [0, 10, 19, 19] and c0['names'].tobytes() == b'r1r2r3'

@@ -307,3 +307,46 @@ def test_mmi_reader_writer(ctx, oracle, tmp_path):
         y = bytearray(raw); mut(y); open(p, 'wb').write(bytes(y))
         with pytest.raises(VmxError):
             Index.load_mmi(ctx, p)
+
+
+def test_driver_native_path_matches_python_emitter(ctx, oracle, tmp_path, monkeypatch):
+    """the command-line driver on the CPU emulator build: gzip FASTQ + BAM input, a repeated read name, --eqx --MD --copycomments; every
+    line equals what vacmap_amd/sam.py (the Python statement of the reference's emitter) makes of the same records, in input order"""
+    import gzip
+    from vacmap_amd import synth, driver, sam
+    import vacmap_amd.lib as VL
+    from test_host_logic import _write_bam
+    monkeypatch.setattr(VL, '_default', ctx.lib)
+    contigs = synth.make_reference([50000, 20000], seed=41)
+    names = ['cA', 'cB']
+    fa = tmp_path / 'ref.fa'
+    fa.write_text(''.join('>%s\n%s\n' % (n, c.tobytes().decode()) for n, c in zip(names, contigs)))
+    cat, off, _ = synth.sample_reads_concat(contigs, 6, mean_len=1500, err=0.05, seed=42, min_len=600, max_len=2500)
+    reads = [cat[off[i]:off[i + 1]].tobytes().decode() for i in range(6)]
+    quals = [''.join(chr(33 + (3 * j) % 40) for j in range(len(r))) for r in reads]
+    fq = tmp_path / 'r.fq.gz'
+    with gzip.open(fq, 'wt') as f:
+        for i in range(4):
+            f.write('@q%d XC:Z:c%d\n%s\n+\n%s\n' % (i, i, reads[i].lower() if i == 1 else reads[i], quals[i]))
+        f.write('@q0 XC:Z:dup\n%s\n+\n%s\n' % (reads[4], quals[4]))             # a repeated name: dropped (vacmap:457)
+    bam = tmp_path / 'more.bam'
+    _write_bam(str(bam), [('b4', reads[4], quals[4], 0), ('b5', synth.tostr(synth.revcomp(np.frombuffer(reads[5].encode(), np.uint8))), quals[5][::-1], 16)])
+    out = tmp_path / 'o.sam'
+    assert driver.main(['-ref', str(fa), '-read', str(fq), str(bam), '-mode', 'H', '-o', str(out), '-t', '2', '--nowriteindex', '--eqx', '--MD', '--copycomments',
+                        '--batch-reads', '2', '--window-batches', '2', '--inflight', '2']) == 0
+    lines = open(out).read().split('\n')
+    hdr = [x for x in lines if x.startswith('@')]; body = [x for x in lines if x and not x.startswith('@')]
+    assert hdr[1:3] == ['@SQ\tSN:cA\tLN:50000', '@SQ\tSN:cB\tLN:20000'] and hdr[3] == '@RG\tID:1\tSM:sample'
+    from vacmap_amd.lib import Index, align_batch
+    gi = Index.from_seqs(ctx, names, contigs, k=15, w=10)
+    prm = ctx.lib.params('H'); prm.eqx = 1
+    order = [('q0', reads[0], quals[0], 'XC:Z:c0'), ('q1', reads[1], quals[1], 'XC:Z:c1'), ('q2', reads[2], quals[2], 'XC:Z:c2'), ('q3', reads[3], quals[3], 'XC:Z:c3'),
+             ('b4', reads[4], quals[4], None), ('b5', reads[5], quals[5], None)]
+    status, recs, _ = align_batch(ctx, gi, prm, [r[1] for r in order])
+    expect = []
+    cs = {n: c.tobytes().decode() for n, c in zip(names, contigs)}
+    for i, (nm, sq, ql, com) in enumerate(order):
+        rr = [(nm, names[t[1]], t[2], t[3], t[4], t[5], t[6], t[7], t[8]) for t in recs if t[0] == i]
+        if status[i] == 0 and rr:
+            expect += sam.sam_lines(rr, sq, ql, lambda n, a, b: cs[n][a:b], md=True, shortcs=True, markunbalancetra=True, rg_id='1', comments=com)
+    assert body == expect and len(body) >= 6
