@@ -191,6 +191,13 @@ def gapfill_banded_cases(rng, band_w, x4_max, dp16_max, base_len, big=True):
             while len(b) < ql:
                 b += rand_seq(rng, 1)
             add(a, b[:ql], 'tot%d' % tot)
+    # ambiguous bases on both sides: an N never matches, not even an N in the same column (all three layouts must agree)
+    for Ln in (L, L // 2, 3 * L):
+        a = list(rand_seq(rng, Ln))
+        for p0 in (3, Ln // 2, Ln - 6):
+            a[p0:p0 + 3] = 'NNN'
+        a = ''.join(a)
+        add(a, a, 'N both %d' % Ln); add(a, mutate(rng, a, 0.05), 'N both err %d' % Ln); add(a.replace('N', 'A'), a, 'N query %d' % Ln)
     # empty / one-base sides
     add('', 'ACGT', 'empty t'); add('ACGT', 'A', 'tiny q'); add('A', 'A', '1x1')
     return ts, qs, tag

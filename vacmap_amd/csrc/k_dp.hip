@@ -11,6 +11,12 @@
 #include "vmx_device.h"
 #include "vmx_kernels.h"
 
+// target code as the packed forms compare it: an ambiguous target base (code 4) becomes 6, which equals no query code — an N never
+// matches, not even another N (VMX-DP-G; the int32 form tests `ti == qc && ti < 4`). Costs nothing per DP step: the row's code is loaded
+// once per stripe.
+__device__ __forceinline__ int vmx_tcode(uint8_t c) { return c < 4 ? (int)c : 6; }
+
+
 // ------------------------------------------------------------------------------------------------ encode
 __global__ void k_encode(const char* __restrict__ in, uint8_t* __restrict__ out, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,7 +135,7 @@ __device__ __forceinline__ void vmx_gapfill_fill16(const uint8_t* __restrict__ T
     unsigned fin = 0;
     for (int s = 0; s < nstr; ++s) {
         const int i0 = s * 128 + 2 * lane + 1;                  // low-half row; the high half is row i0 + 1
-        const unsigned ti2 = vmx_pk(i0 <= tl ? (int)T[i0 - 1] : 5, i0 + 1 <= tl ? (int)T[i0] : 5);     // 5 never equals a query code (rows past tl)
+        const unsigned ti2 = vmx_pk(i0 <= tl ? vmx_tcode(T[i0 - 1]) : 5, i0 + 1 <= tl ? vmx_tcode(T[i0]) : 5);     // 5 never equals a query code (rows past tl)
         unsigned Hleft = vmx_pk(vmx_gap_open_row(i0, o1, e1, o2, e2), vmx_gap_open_row(i0 + 1, o1, e1, o2, e2));
         unsigned F1 = vmx_pk(VMX_NEG16, VMX_NEG16), F2 = F1;
         unsigned Hdiag = vmx_pk(i0 - 1 == 0 ? 0 : vmx_gap_open_row(i0 - 1, o1, e1, o2, e2), vmx_gap_open_row(i0, o1, e1, o2, e2));
@@ -256,7 +262,7 @@ __device__ __forceinline__ int vmx_gapfill_fill16x4(const uint8_t* __restrict__ 
         unsigned qchunk, cH, cE1, cE2;
         if (act && t == 0) {
             const int i0 = s * 32 + 2 * l + 1;
-            ti2 = vmx_pk(i0 <= tl ? (int)T[i0 - 1] : 5, i0 + 1 <= tl ? (int)T[i0] : 5);
+            ti2 = vmx_pk(i0 <= tl ? vmx_tcode(T[i0 - 1]) : 5, i0 + 1 <= tl ? vmx_tcode(T[i0]) : 5);
             if (BAND) {
                 jlo = VMX_BAND_JLO(tl, ql, s);
                 if (s > 0) { jplo = VMX_BAND_JLO(tl, ql, s - 1); jpend = jplo + (W - 31) - 1; if (jpend > ql) jpend = ql; }
