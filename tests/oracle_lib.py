@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(_ROOT, 'oracle', 'liboracle.so')
+_SO = os.environ.get('VMO_LIB') or os.path.join(_ROOT, 'oracle', 'liboracle.so')     # VMO_LIB: e.g. the sanitizer build (oracle/Makefile `asan`)
 
 
 class Params(C.Structure):

@@ -9,7 +9,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
+#include <string>
 
 using namespace vmx;
 
@@ -505,16 +507,55 @@ int vm_align_trace(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t 
     return VM_OK;
 }
 
+static int align_batch_one(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const char* seqs, const int64_t* offsets, vm_record** recs, int64_t* n_recs,
+                           char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats) {
+    vmx_batch_bufs& B = *batch_bufs(c);
+    const int64_t base = offsets[0], tot = offsets[n] - base;
+    std::vector<int64_t> h_off((size_t)n + 1);
+    for (int64_t i = 0; i <= n; ++i) h_off[(size_t)i] = offsets[i] - base;
+    VMX_TRY(upload(B.raw, seqs + base, (size_t)tot, c->stream)); VMX_TRY(B.codes.reserve((size_t)tot + 64)); VMX_TRY(upload(B.off, h_off.data(), (size_t)n + 1, c->stream));
+    if (tot) LAUNCH1D(k_encode, tot, B.raw.as<char>(), B.codes.as<uint8_t>(), tot);
+    return align_device(c, mi, prm, n, B.codes.as<uint8_t>(), B.off.as<int64_t>(), h_off, recs, n_recs, cigar_blob, status_per_read, stats);
+}
+
+// The work pools of a context grow with the batch (≈ 0.85 KB per read base at hg38 size) and never shrink, so one oversized call —
+// 100 k long reads in one batch — could exhaust HBM next to the index and the other contexts. A call above VMX_MAX_BATCH_BASES bases or
+// VMX_MAX_BATCH_READS reads is therefore processed as consecutive sub-batches of the same context and its results are concatenated;
+// callers that size their batches like vacmap_amd.pipeline (4096 reads, ~60 Mbases) never notice.
 int vm_align_batch(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const char* seqs, const int64_t* offsets, vm_record** recs, int64_t* n_recs,
                    char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats) {
     if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
     VMX_HIP(hipSetDevice(c->device));
-    vmx_batch_bufs& B = *batch_bufs(c);
-    const int64_t tot = offsets[n];
-    VMX_TRY(upload(B.raw, seqs, (size_t)tot, c->stream)); VMX_TRY(B.codes.reserve((size_t)tot + 64)); VMX_TRY(upload(B.off, offsets, (size_t)n + 1, c->stream));
-    if (tot) LAUNCH1D(k_encode, tot, B.raw.as<char>(), B.codes.as<uint8_t>(), tot);
-    std::vector<int64_t> h_off(offsets, offsets + n + 1);
-    return align_device(c, mi, prm, n, B.codes.as<uint8_t>(), B.off.as<int64_t>(), h_off, recs, n_recs, cigar_blob, status_per_read, stats);
+    static const int64_t max_bases = [] { const char* e = getenv("VMX_MAX_BATCH_BASES"); const long long v = e ? atoll(e) : 0; return v > 0 ? (int64_t)v : (int64_t)VMX_MAX_BATCH_BASES; }();
+    if (n <= VMX_MAX_BATCH_READS && offsets[n] - offsets[0] <= max_bases) return align_batch_one(c, mi, prm, n, seqs, offsets, recs, n_recs, cigar_blob, status_per_read, stats);
+    *recs = nullptr; *n_recs = 0; *cigar_blob = nullptr;
+    std::vector<vm_record> all; std::string blob;
+    vm_batch_stats tot; memset(&tot, 0, sizeof tot);
+    for (int64_t a = 0; a < n;) {
+        int64_t b = a + 1;                                       // at least one read per sub-batch, whatever its length
+        while (b < n && b - a < VMX_MAX_BATCH_READS && offsets[b + 1] - offsets[a] <= max_bases) ++b;
+        vm_record* r = nullptr; int64_t nr = 0; char* cb = nullptr; vm_batch_stats st;
+        const int rc = align_batch_one(c, mi, prm, b - a, seqs, offsets + a, &r, &nr, &cb, status_per_read ? status_per_read + a : nullptr, &st);
+        if (rc < 0) { free(r); free(cb); return rc; }
+        int64_t bl = 0; for (int64_t i = 0; i < nr; ++i) bl = std::max(bl, r[i].cigar_off + r[i].cigar_len);
+        for (int64_t i = 0; i < nr; ++i) { vm_record x = r[i]; x.read_idx += (int32_t)a; x.cigar_off += (int64_t)blob.size(); all.push_back(x); }
+        blob.append(cb, (size_t)bl); blob.push_back('\0');
+        free(r); free(cb);
+        {   // counters and times add up; sizes are per call
+            int64_t* d = (int64_t*)&tot; const int64_t* s2 = (const int64_t*)&st;
+            for (size_t i = 0; i < offsetof(vm_batch_stats, ms_total) / 8; ++i) d[i] += s2[i];
+            tot.ms_total += st.ms_total; for (int i = 0; i < 16; ++i) tot.ms_stage[i] += st.ms_stage[i];
+            tot.ms_gapfill_fill += st.ms_gapfill_fill; tot.ms_gapfill_trace += st.ms_gapfill_trace; tot.n_gapfill_launches += st.n_gapfill_launches;
+            tot.n_ed_full += st.n_ed_full; tot.n_ed_tier2 += st.n_ed_tier2; tot.n_ed_tier1 += st.n_ed_tier1;
+        }
+        a = b;
+    }
+    *recs = (vm_record*)malloc(sizeof(vm_record) * std::max<size_t>(all.size(), 1)); *cigar_blob = (char*)malloc(std::max<size_t>(blob.size(), 1));
+    if (!*recs || !*cigar_blob) { free(*recs); free(*cigar_blob); *recs = nullptr; *cigar_blob = nullptr; set_error("out of host memory"); return VM_ERR_OOM; }
+    memcpy(*recs, all.data(), sizeof(vm_record) * all.size()); memcpy(*cigar_blob, blob.data(), blob.size());
+    *n_recs = (int64_t)all.size();
+    if (stats) *stats = tot;
+    return VM_OK;
 }
 
 }  // extern "C"

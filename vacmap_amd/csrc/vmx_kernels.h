@@ -116,6 +116,13 @@ struct vmx_lseed_args {
 #define VMX_TB_BYTES(tl, ql) (((tl) > 0 && (ql) > 0) ? (VMX_DP16X4_OK(tl, ql) ? (int64_t)(((tl) + 31) / 32) * VMX_X4_W(ql) * 32 : \
                               VMX_DP16_OK(tl, ql) ? (int64_t)(((tl) + 127) / 128) * ((ql) + 127) * 128 : (int64_t)(((tl) + 63) / 64) * ((ql) + 63) * 64) : 0)
 #define VMX_TB_CHUNK ((int64_t)12 << 30)   // gap fill: traceback bytes held at a time; a batch needing more runs fill + trace chunk by chunk (12 GB: lets 4+ batches in flight fit in 288 GB)
+#ifdef VMX_EMU
+#define VMX_MAX_BATCH_BASES 20000          // emulator build: small limits so that the CPU tests split a batch
+#define VMX_MAX_BATCH_READS 6
+#else
+#define VMX_MAX_BATCH_BASES ((int64_t)160 << 20)     // bases per internal sub-batch of vm_align_batch (a pipeline batch is ~60 M)
+#define VMX_MAX_BATCH_READS 16384
+#endif
 #define VMX_LA_SLOT(len) ((len) / 2 + 4096)   // regular local-anchor slot of a read (rows); overflowing reads are re-run with 8x .. 4096x
 #define VMX_SELECT_LDS 3072           // k_chain_select: anchors of a read whose S / P / S_arg / used flags are staged in LDS (17 B each)
 #define VMX_SELECT_LDS_FULL 960       // ... and whose scratch (37 B + 64) fits next to them: 960 * 53 + 64 <= 3072 * 17
