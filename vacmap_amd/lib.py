@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_SO = os.path.join(_HERE, 'libvacmapx.so')
+DEFAULT_SO = os.environ.get('VACMAPX_LIB') or os.path.join(_HERE, 'libvacmapx.so')     # VACMAPX_LIB: another build of the same library (tuning variants)
 
 VM_ERR_NO_DEVICE = -2
 MODES = {'H': 0, 'L': 1, 'S': 2, 'R': 3}
