@@ -155,10 +155,11 @@ typedef struct vm_score { int32_t match, mismatch, o1, e1, o2, e2; } vm_score;
 int vm_k_cigar_batch(vm_ctx*, const vm_score*, int eqx, int64_t n, const char* t, const int64_t* t_off, const char* q,
                      const int64_t* q_off, char** cigars, int64_t** cigar_off, int32_t** scores);
 /* The same problems through the schedule vm_align_batch uses for its gap fill (mammap_clrnano.py:21554, :21598 call sites): longest-first
- * device queue, banded four-per-wavefront fill first, the problems whose band is not PROVEN optimal filled again in full by a second
- * launch, per-problem layout flag for the traceback. CIGARs must equal vm_k_cigar_batch's. band_flag[n]: 1 = the banded result was
- * proven and kept. stats[4] = {problems eligible for the band, proven, sent to the redo launch, not eligible (too large / band no
- * narrower than the matrix)}. No scores (that form never captures them). */
+ * device queue, banded eight-per-wavefront fill first (anti-diagonal form on a fixed band of 32 * ns diagonals), the problems whose band
+ * is not PROVEN optimal filled again in full by a second launch, per-problem layout flag for the traceback. CIGARs must equal
+ * vm_k_cigar_batch's. band_flag[n]: 16 + ns = the band's result was proven and kept, 0 = full matrix. stats[4] = {small problems tried
+ * in a band, proven, sent to the second launch (not proven, or small but never tried), problems outside the small class}. No scores
+ * (that form never captures them). */
 int vm_k_cigar_batch_banded(vm_ctx*, const vm_score*, int eqx, int64_t n, const char* t, const int64_t* t_off, const char* q,
                             const int64_t* q_off, char** cigars, int64_t** cigar_off, int32_t** band_flag, int64_t* stats);
 /* `mp.k_cigar(..., 4,4,4,4, bw=100, zdropvalue=50)` (:2381): banded x-drop extension from (0,0); out t_e[n], q_e[n], score[n] */
@@ -206,6 +207,8 @@ typedef struct vm_batch_stats {     /* measured on the device, for bench.py's ro
     int64_t n_ed_full;              /* divergence-filter problems the banded kernels could not settle (re-run unbanded) */
     int64_t n_ed_tier2;             /* problems the four-per-wave band could not settle (re-run in the wide band) */
     int64_t n_ed_tier1;             /* problems the anchor bound could not settle (re-run in the four-per-wave band) */
+    int64_t n_dp_redo;              /* gap-fill problems whose band was not proven optimal (or that were too large to try one): filled again in full */
+    int64_t dp_redo_tb_bytes;       /* traceback bytes of those (second pool); dp_cells counts all traceback bytes written */
 } vm_batch_stats;
 
 /* Align n reads (replaces get_readmap_DP_test per read). seqs concatenated, offsets[n+1].

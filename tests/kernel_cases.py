@@ -129,40 +129,77 @@ def check_gapfill(ctx, O, n=64, maxlen=500, seed=4, minlen=1):
             assert cg[i] == e_cg, (i, len(ts[i]), len(qs[i]))
 
 
-def band_steps(tl, ql, band_w):
-    """mirror of VMX_BAND_STEPS (vmx_kernels.h): width of a banded stripe in steps, 0 = the problem is not banded"""
+AD_NS_MAX = 4       # mirrors of vmx_kernels.h: vmx_ad_geom / vmx_ad_margin / vmx_ad_ns (anti-diagonal band form of the gap fill)
+
+
+def ad_geom(tl, ql, ns):
+    """(g, dlo): a path leaving the band of 32 * ns diagonals holds >= g inserted and g deleted bases; g = 0: the band cannot hold the problem"""
+    dl = ql - tl; lo = min(0, dl); hi = max(0, dl)
+    slack = 32 * ns - (hi - lo + 1)
+    if slack < 0:
+        return 0, 0
+    mb = slack // 2; dlo = lo - mb
+    if dlo & 1:
+        if mb + 1 <= slack:
+            mb += 1; dlo -= 1
+        elif mb >= 1:
+            mb -= 1; dlo += 1
+        else:
+            return 0, 0
+    return min(mb, slack - mb) + 1, dlo
+
+
+def ad_margin(g, match=2, o1=4, e1=2, o2=24, e2=1):
+    return match * g + 2 * min(o1 + g * e1, o2 + g * e2)
+
+
+def ad_ns(tl, ql, pct=100, pct_min=65):
     if tl <= 0 or ql <= 0:
         return 0
-    x4w = ((ql + 31) + 15) & ~15
-    nc = 2 * band_w + 3 + (32 * ql + tl - 1) // tl
-    st = ((nc + 31) + 15) & ~15
-    return st if st + 16 <= x4w else 0
+    mn = min(tl, ql); g = 0
+    for ns in range(1, AD_NS_MAX + 1):
+        g, _ = ad_geom(tl, ql, ns)
+        if g >= 1 and (g > mn or ad_margin(g) * 100 >= pct * mn):
+            return ns
+    return AD_NS_MAX if (g >= 1 and ad_margin(g) * 100 >= pct_min * mn) else 0
 
 
-def gapfill_banded_cases(rng, band_w, x4_max, dp16_max, base_len, big=True):
+def gapfill_banded_cases(rng, x4_max, dp16_max, base_len, big=True, pct=100, pct_min=65):
     """adversarial (target, query) pairs for the banded gap fill (k_gapfill_fill_ns): see check_gapfill_banded"""
     ts, qs, tag = [], [], []
 
     def add(t, q, what):
         ts.append(t); qs.append(q if q else 'A'); tag.append(what)
     L = base_len
-    # |tl - ql| from 0 to beyond the band: one deletion / insertion of d bases in the middle, light substitutions around it
-    for d in list(range(0, band_w + 9)):
-        a = rand_seq(rng, L)
+    ns0 = max(1, ad_ns(L, L, pct, pct_min))
+    g0 = ad_geom(L, L, ns0)[0]                       # margin of the band a square problem of this size gets
+    # |tl - ql| from 0 to beyond the widest band: one deletion / insertion of d bases in the middle, light substitutions around it
+    for d in list(range(0, 24)) + list(range(24, 32 * AD_NS_MAX + 12, 3)):
+        a = rand_seq(rng, L + (d if d > L // 2 else 0))
         add(a, mutate(rng, a[:L // 2] + a[L // 2 + d:], 0.02), 'del%d' % d)
         add(a, mutate(rng, a[:L // 2] + rand_seq(rng, d) + a[L // 2:], 0.02), 'ins%d' % d)
-    # indels of about half the band .. just beyond it, at the start, the middle and the end
-    for d in sorted(set([max(1, band_w // 2), band_w - 3, band_w - 1, band_w, band_w + 1, band_w + 3])):
+    # indels around the band's margin — just inside, on it, just beyond — at the start, the middle and the end
+    for d in sorted(set([max(1, g0 // 2), g0 - 3, g0 - 2, g0 - 1, g0, g0 + 1, g0 + 3, 2 * g0 - 2, 2 * g0 - 1, 2 * g0, 2 * g0 + 1])):
+        if d < 1 or d + 4 >= L:
+            continue
         for pos in (2, L // 2, L - 2 - d):
             a = rand_seq(rng, L)
             add(a, a[:pos] + a[pos + d:], 'D%d@%d' % (d, pos))
             add(a, a[:pos] + rand_seq(rng, d) + a[pos:], 'I%d@%d' % (d, pos))
             add(a, mutate(rng, a[:pos] + a[pos + d:], 0.1), 'D%d@%d+err' % (d, pos))
-    # a gap long enough for the second affine piece (24 + g < 4 + 2 g for g > 20), and two opposite gaps (the path leaves and re-enters)
-    for g in (21, 22, 30):
+    # two opposite gaps: the optimal path leaves the main line by g bases and comes back (tl == ql: the band's margin decides whether it
+    # stays inside); sizes around every band width's margin, incl. the second affine piece (24 + g < 4 + 2 g for g > 20)
+    gs = set([21, 22, 30])
+    for ns in range(1, AD_NS_MAX + 1):
+        g = ad_geom(L, L, ns)[0]
+        gs.update([g - 2, g - 1, g, g + 1])
+    for g in sorted(gs):
+        if g < 1 or 3 * g + 6 >= L:
+            continue
         a = rand_seq(rng, L)
         add(a, a[:L // 3] + a[L // 3 + g:], 'piece2 del %d' % g)
         add(a, a[:L // 3] + a[L // 3 + g:2 * L // 3] + rand_seq(rng, g) + a[2 * L // 3:], 'del+ins %d' % g)
+        add(a, a[:L // 3] + rand_seq(rng, g) + a[L // 3:2 * L // 3] + a[2 * L // 3 + g:], 'ins+del %d' % g)
     # tandem repeats: many co-optimal paths far from the main line, the traceback's tie-breaks decide
     for unit in (1, 2, 3, 7, 11):
         u = rand_seq(rng, unit)
@@ -172,17 +209,17 @@ def gapfill_banded_cases(rng, band_w, x4_max, dp16_max, base_len, big=True):
     # unrelated sequences (every path is bad; the proof must fail or the result must still be the optimum)
     for _ in range(4):
         add(rand_seq(rng, L), rand_seq(rng, L + int(rng.integers(-5, 6))), 'unrelated')
-    # shapes around the switch where VMX_BAND_STEPS becomes 0 (banding would not save a 16-step block): sweep ql for tl ~ ql
-    lo = [q for q in range(8, 4 * band_w + 120) if band_steps(q, q, band_w) == 0]
-    hi = [q for q in range(8, 4 * band_w + 120) if band_steps(q, q, band_w) > 0]
-    edge = (max(lo) if lo else 8, min(hi) if hi else 8)
-    for q in range(max(1, edge[0] - 20), edge[1] + 21, 3):
-        a = rand_seq(rng, q + int(rng.integers(0, 4)))
-        add(a, mutate(rng, a, 0.08), 'flip%d' % q)
-    # very oblong problems (|tl - ql| large relative to min): g < 1, never proven
+    # sizes around the switches of the band-width rule (ns 1 -> 2 -> 3 -> 4 -> tried anyway -> not tried)
+    sw = [q for q in range(8, x4_max // 2 + 2) if ad_ns(q, q, pct, pct_min) != ad_ns(q + 1, q + 1, pct, pct_min)]
+    for q0 in sw:
+        for q in (q0 - 1, q0, q0 + 1, q0 + 2):
+            a = rand_seq(rng, q)
+            add(a, mutate(rng, a, 0.08), 'switch%d' % q)
+            add(a, mutate(rng, a, 0.01), 'switch%d clean' % q)
+    # very oblong problems: the band cannot hold both corners, or g exceeds the short side (nothing can leave the band: proven outright)
     a = rand_seq(rng, L)
-    add(a, a[:L // 4], 'oblong'); add(a[:L // 4], a, 'oblong2')
-    # size-class boundaries of the three layouts: four per wave (tl + ql <= x4_max), packed int16 (<= dp16_max), int32 beyond
+    add(a, a[:L // 4], 'oblong'); add(a[:L // 4], a, 'oblong2'); add(a[:3], a[:40], 'oblong3'); add(a[:50], a[:2], 'oblong4')
+    # size-class boundaries of the three layouts: small class (tl + ql <= x4_max), packed int16 (<= dp16_max), int32 beyond
     if big:
         for tot in (x4_max - 1, x4_max, x4_max + 1, dp16_max - 1, dp16_max, dp16_max + 1):
             tl = tot // 2; ql = tot - tl
@@ -191,7 +228,7 @@ def gapfill_banded_cases(rng, band_w, x4_max, dp16_max, base_len, big=True):
             while len(b) < ql:
                 b += rand_seq(rng, 1)
             add(a, b[:ql], 'tot%d' % tot)
-    # ambiguous bases on both sides: an N never matches, not even an N in the same column (all three layouts must agree)
+    # ambiguous bases on both sides: an N never matches, not even an N in the same column (all layouts must agree)
     for Ln in (L, L // 2, 3 * L):
         a = list(rand_seq(rng, Ln))
         for p0 in (3, Ln // 2, Ln - 6):
@@ -199,35 +236,42 @@ def gapfill_banded_cases(rng, band_w, x4_max, dp16_max, base_len, big=True):
         a = ''.join(a)
         add(a, a, 'N both %d' % Ln); add(a, mutate(rng, a, 0.05), 'N both err %d' % Ln); add(a.replace('N', 'A'), a, 'N query %d' % Ln)
     # empty / one-base sides
-    add('', 'ACGT', 'empty t'); add('ACGT', 'A', 'tiny q'); add('A', 'A', '1x1')
+    add('', 'ACGT', 'empty t'); add('ACGT', 'A', 'tiny q'); add('A', 'A', '1x1'); add('A', 'C', '1x1 mismatch'); add('AC', 'A', '2x1')
     return ts, qs, tag
 
 
-def check_gapfill_banded(ctx, O, band_w, x4_max, dp16_max, base_len, seed=44, big=True, min_counts=(10, 10, 5)):
-    """E5 through the schedule of the batched path (vm_k_cigar_batch_banded -> k_gapfill_fill_ns: banded fill, optimality proof, redo
-    queue, per-problem layout flag read by k_gapfill_trace) vs the oracle's full DP (mammap_clrnano.py:21554, :21598 call sites):
-    identical CIGARs with eqx on and off, in shuffled order (waves mix proven, unproven, not-eligible and idle rows), and both branches
-    provably taken."""
+def check_gapfill_banded(ctx, O, x4_max, dp16_max, base_len, seed=44, big=True, min_counts=(10, 10, 5), pct=100, pct_min=65, redo_pk_min=640):
+    """E5 through the schedule of the batched path (vm_k_cigar_batch_banded -> k_gapfill_fill_ns: anti-diagonal band fill of eight problems
+    per wave, optimality proof, redo queue, per-problem layout flag read by k_gapfill_trace) vs the oracle's full DP (mammap_clrnano.py:21554,
+    :21598 call sites): identical CIGARs with eqx on and off, in shuffled order (waves mix proven, unproven, never-tried and idle rows and
+    band widths), and both branches provably taken. pct / pct_min: the band-width rule the library is running with (VMX_AD_PCT, VMX_AD_PCT_MIN)."""
     rng = np.random.default_rng(seed)
-    ts, qs, tag = gapfill_banded_cases(rng, band_w, x4_max, dp16_max, base_len, big=big)
+    ts, qs, tag = gapfill_banded_cases(rng, x4_max, dp16_max, base_len, big=big, pct=pct, pct_min=pct_min)
     perm = rng.permutation(len(ts))
     ts = [ts[i] for i in perm]; qs = [qs[i] for i in perm]; tag = [tag[i] for i in perm]
     expect = {eqx: [O.k_cigar_global(t, q, eqx=eqx)[0] for t, q in zip(ts, qs)] for eqx in (False, True)}
+    small = [bool(t) and bool(q) and len(t) + len(q) <= x4_max for t, q in zip(ts, qs)]
+    want_ns = [ad_ns(len(t), len(q), pct, pct_min) if sm else 0 for t, q, sm in zip(ts, qs, small)]
     for eqx in (False, True):
         cg, flag, st = ctx.k_cigar_batch_banded(ts, qs, eqx=eqx)
         for i in range(len(ts)):
             assert cg[i] == expect[eqx][i], (tag[i], len(ts[i]), len(qs[i]), int(flag[i]), eqx)
-        elig = sum(1 for t, q in zip(ts, qs) if t and q and len(t) + len(q) <= x4_max and band_steps(len(t), len(q), band_w) > 0)
-        assert st['eligible'] == elig and st['not_eligible'] == len(ts) - elig
-        assert st['proven'] == int((flag == 1).sum()) and st['redo'] == elig - st['proven']
-        assert st['proven'] >= min_counts[0] and st['redo'] >= min_counts[1] and st['not_eligible'] >= min_counts[2], st      # both branches and the plain form ran
+            # layout flags: 0 striped four-per-wave, 1 whole-wave packed (the second launch's larger problems), 16 + ns anti-diagonal band
+            assert int(flag[i]) == 0 or (want_ns[i] > 0 and 16 + want_ns[i] <= int(flag[i]) <= 16 + AD_NS_MAX) or \
+                (int(flag[i]) == 1 and small[i] and len(ts[i]) + len(qs[i]) >= redo_pk_min), (tag[i], int(flag[i]), want_ns[i])
+        elig = sum(1 for w in want_ns if w > 0)
+        assert st['eligible'] == elig and st['not_eligible'] == len(ts) - sum(small), (st, elig, sum(small))
+        assert st['proven'] == int((flag > 16).sum()) and st['redo'] == sum(small) - st['proven'], st
+        assert st['proven'] >= min_counts[0] and st['redo'] >= min_counts[1] and st['not_eligible'] >= min_counts[2], st      # both branches and the plain forms ran
         # the full-matrix entry agrees too (same problems, no band)
         cg0, _ = ctx.k_cigar_batch(ts, qs, eqx=eqx)
         assert cg0 == cg
     # tiny batches: idle rows in the only wave
-    for n in (1, 2, 3, 5):
+    for n in (1, 2, 3, 5, 9):
         cg, _, _ = ctx.k_cigar_batch_banded(ts[:n], qs[:n])
         assert cg == expect[False][:n]
+    st['ns_kept'] = sorted(set(int(f) - 16 for f in flag if f > 16))
+    st['redo_packed'] = int((flag == 1).sum())
     return st
 
 

@@ -34,11 +34,18 @@ def test_emu_gapfill(ctx, oracle):
     KC.check_gapfill(ctx, oracle, n=6, maxlen=330, seed=5)       # several 128-row stripes of the packed layout; beyond 420 cells of perimeter: int32 layout
 
 
-def test_emu_gapfill_banded(ctx, oracle):
-    """the batched path's gap-fill schedule (banded + proof + redo queue + layout flag) with the emulator build's small constants
-    (VMX_BAND_W 6, four-per-wave up to tl + ql = 160, packed int16 up to 420)"""
-    st = KC.check_gapfill_banded(ctx, oracle, band_w=6, x4_max=160, dp16_max=420, base_len=70, seed=44, min_counts=(10, 5, 5))
-    assert st['proven'] > 0 and st['redo'] > 0
+def test_emu_gapfill_banded(ctx, oracle, monkeypatch):
+    """the batched path's gap-fill schedule (anti-diagonal band + proof + redo queue + layout flag) with the emulator build's small
+    constants (small class up to tl + ql = 160, packed int16 up to 420). The band-width rule is pushed through all four widths with
+    VMX_AD_PCT (at its default every problem this small gets the narrowest band)."""
+    seen = set()
+    for pct, seed in ((100, 44), (250, 45), (330, 46), (400, 47)):
+        monkeypatch.setenv('VMX_AD_PCT', str(pct))
+        # (the wide bands hold every path of problems this small: g > min(tl, ql), nothing is left to redo)
+        st = KC.check_gapfill_banded(ctx, oracle, x4_max=160, dp16_max=420, base_len=70, seed=seed, min_counts=(10, 5 if pct == 100 else 0, 5), pct=pct, redo_pk_min=120)
+        assert st['proven'] > 0 and (pct != 100 or st['redo_packed'] > 0)
+        seen.update(st['ns_kept'])
+    assert seen == {1, 2, 3, 4}, seen
 
 
 def test_emu_chain_global(ctx, oracle, golden):

@@ -50,13 +50,17 @@ def test_gapfill(ctx, oracle):
 
 
 def test_gapfill_banded_schedule(ctx, oracle):
-    """k_gapfill_fill_ns as vm_align_batch launches it (banded four-per-wave fill, optimality proof, redo queue, layout flag): CIGARs vs the
-    oracle on adversarial shapes — |tl - ql| 0..70, indels of 30-65 bp at the start / middle / end, second-piece gaps, tandem repeats, the
-    (tl, ql) where VMX_BAND_STEPS flips to 0, tl + ql in {1023..1025, 5999..6001}, mixed waves, eqx on and off"""
-    st = KC.check_gapfill_banded(ctx, oracle, band_w=62, x4_max=1024, dp16_max=6000, base_len=270, seed=44)
-    assert st['proven'] >= 10 and st['redo'] >= 10
-    KC.check_gapfill_banded(ctx, oracle, band_w=62, x4_max=1024, dp16_max=6000, base_len=420, seed=45, big=False)
-    KC.check_gapfill_banded(ctx, oracle, band_w=62, x4_max=1024, dp16_max=6000, base_len=1400, seed=46, big=False, min_counts=(0, 0, 100))     # one problem per wavefront (packed int16), the same shapes
+    """k_gapfill_fill_ns as vm_align_batch launches it (anti-diagonal band fill, eight problems per wave, optimality proof, redo queue, layout
+    flag): CIGARs vs the oracle on adversarial shapes — |tl - ql| from 0 to beyond the widest band, indels and opposite gap pairs just
+    inside / on / beyond every band width's margin at the start, middle and end, second-piece gaps, tandem repeats, the sizes where the
+    band-width rule switches, tl + ql in {1023..1025, 5999..6001}, N runs, mixed waves, eqx on and off"""
+    seen = set()
+    for base_len, seed in ((60, 41), (130, 42), (200, 43), (270, 44), (420, 45)):
+        st = KC.check_gapfill_banded(ctx, oracle, x4_max=1024, dp16_max=6000, base_len=base_len, seed=seed, big=(base_len == 270),
+                                     min_counts=(10, 10, 2 if base_len == 270 else 0))
+        seen.update(st['ns_kept'])
+    assert seen == {1, 2, 3, 4}, seen
+    KC.check_gapfill_banded(ctx, oracle, x4_max=1024, dp16_max=6000, base_len=1400, seed=46, big=False, min_counts=(0, 0, 100))     # one problem per wavefront (packed int16), the same shapes
 
 
 def test_chain_global_golden(ctx, oracle, golden):

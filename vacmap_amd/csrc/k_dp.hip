@@ -109,6 +109,7 @@ __global__ void __launch_bounds__(64) k_extend(const uint8_t* __restrict__ tcode
 // steps and lane 63's outputs leave through a rotating register FIFO flushed once per 64 columns — nothing on the per-step path
 // waits for memory. Chunks in which every lane is inside its row run without the per-step activity test.
 // Traceback bytes are stored as tb[(stripe*(ql+63) + step)*64 + lane]: one coalesced 64-byte line per step.
+// (The batched path runs its small problems — nearly all of them — in the anti-diagonal band form of vmx_dp_ad.h first.)
 __device__ __forceinline__ int vmx_gap_open_row(int i, int o1, int e1, int o2, int e2) {   // H(i,0) = H(0,i), i >= 1
     int a = -(o1 + i * e1), b = -(o2 + i * e2);
     return a > b ? a : b;
@@ -221,23 +222,20 @@ __device__ __forceinline__ int vmx_r16_ror1(int v) { return __builtin_amdgcn_upd
 // T, Q, tl, ql, tb, bH, score_out describe the problem of this lane's 16-lane row (tl = 0: the row idles). Every lane of the wave calls it.
 // Control flow is wave-uniform (every lane runs every step, idle rows on dummy values with their memory accesses masked): the four rows
 // are in different stripes and columns, and the cross-lane moves must not sit in divergent code.
-// BAND: stripe s only runs the columns [jlo_s, jlo_s + W - 32] around the main line (VMX_BAND_JLO); cells outside count as -infinity.
-// The caller keeps the result only if the returned score passes vmx_band_proven (below).
-template <bool SCORE, bool BAND>
+template <bool SCORE>
 __device__ __forceinline__ int vmx_gapfill_fill16x4(const uint8_t* __restrict__ T, const uint8_t* __restrict__ Q, int tl, int ql, int match, int mismatch,
                                                     int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb, int32_t* __restrict__ bH,
                                                     int32_t* __restrict__ score_out, int lane) {
     const int l = lane & 15;
     int32_t* bE1 = bH + (ql + 1);
     int32_t* bE2 = bE1 + (ql + 1);
-    const int W = BAND ? (tl > 0 ? VMX_BAND_STEPS(tl, ql) : 0) : VMX_X4_W(ql);
-    int jlo = 1, jplo = 1, jpend = 0;                           // first column of this stripe; computed column range of the stripe above
+    const int W = VMX_X4_W(ql);
     const int nstr = (tl + 31) >> 5;
     const unsigned O1 = vmx_pk(o1, o1), O2 = vmx_pk(o2, o2), E1C = vmx_pk(e1, e1), E2C = vmx_pk(e2, e2);
     const unsigned MATCH = vmx_pk(match, match), MISM = vmx_pk(mismatch, mismatch), ONE = vmx_pk(1, 1);
     const unsigned NEGP = vmx_pk(VMX_NEG16, VMX_NEG16);
     const int rf = (tl - 1) & 31;                               // row tl inside the last stripe: lane rf / 2 of the row, half rf & 1
-    const int t_fin = ql - (BAND && tl > 0 ? VMX_BAND_JLO(tl, ql, nstr - 1) : 1) + rf;
+    const int t_fin = ql - 1 + rf;
     const int total = vmx_uniform_i32(vmx_wave_max_i32(nstr * W));   // steps of the longest of the four problems
     unsigned fin = 0;
     int s = 0, t = 0;                                           // this row's stripe and the step inside it (t is a multiple of 16 here)
@@ -247,13 +245,13 @@ __device__ __forceinline__ int vmx_gapfill_fill16x4(const uint8_t* __restrict__ 
     uint8_t* tbp = tb;                                          // traceback line of the block's first step
     unsigned nq = 0, nH = 0, nE1 = 0, nE2 = 0;                  // chunk of the next block, loaded one block ahead
     // chunk of the 16 columns starting at step t0 of stripe s0: query bases and the row above the stripe, pre-shifted into the high half
-    auto load_chunk = [&](bool on, int s0, int t0, int j0, int plo, int pend, unsigned& q, unsigned& h, unsigned& x1, unsigned& x2) {
-        const int jj = j0 - 1 + t0 + l;                         // column jj + 1 (j0 = first column of the stripe)
+    auto load_chunk = [&](bool on, int s0, int t0, unsigned& q, unsigned& h, unsigned& x1, unsigned& x2) {
+        const int jj = t0 + l;                                  // column jj + 1
         q = (unsigned)(on && jj < ql ? (int)Q[jj] : 4) << 16;
-        h = BAND ? (unsigned)VMX_NEG16 << 16 : 0u; x1 = (unsigned)VMX_NEG16 << 16; x2 = x1;
+        h = 0u; x1 = (unsigned)VMX_NEG16 << 16; x2 = x1;
         if (on && jj + 1 <= ql) {
             if (s0 == 0) h = (unsigned)vmx_gap_open_row(jj + 1, o1, e1, o2, e2) << 16;
-            else if (!BAND || (jj + 1 >= plo && jj + 1 <= pend)) { h = (unsigned)bH[jj + 1] << 16; x1 = (unsigned)bE1[jj + 1] << 16; x2 = (unsigned)bE2[jj + 1] << 16; }
+            else { h = (unsigned)bH[jj + 1] << 16; x1 = (unsigned)bE1[jj + 1] << 16; x2 = (unsigned)bE2[jj + 1] << 16; }
         }
     };
     for (int g0 = 0; g0 < total; g0 += 16) {
@@ -263,19 +261,8 @@ __device__ __forceinline__ int vmx_gapfill_fill16x4(const uint8_t* __restrict__ 
         if (act && t == 0) {
             const int i0 = s * 32 + 2 * l + 1;
             ti2 = vmx_pk(i0 <= tl ? vmx_tcode(T[i0 - 1]) : 5, i0 + 1 <= tl ? vmx_tcode(T[i0]) : 5);
-            if (BAND) {
-                jlo = VMX_BAND_JLO(tl, ql, s);
-                if (s > 0) { jplo = VMX_BAND_JLO(tl, ql, s - 1); jpend = jplo + (W - 31) - 1; if (jpend > ql) jpend = ql; }
-            }
-            if (!BAND || jlo == 1) {
-                Hleft = vmx_pk(vmx_gap_open_row(i0, o1, e1, o2, e2), vmx_gap_open_row(i0 + 1, o1, e1, o2, e2));
-                Hdiag = vmx_pk(i0 - 1 == 0 ? 0 : vmx_gap_open_row(i0 - 1, o1, e1, o2, e2), vmx_gap_open_row(i0, o1, e1, o2, e2));
-            } else {
-                // the cells left of the stripe's first column are outside the band; the stripe's first row takes H(i0 - 1, jlo - 1) from the row above
-                Hleft = NEGP; Hdiag = NEGP;
-                if (l == 0 && s == 0) Hdiag = vmx_pk(vmx_gap_open_row(jlo - 1, o1, e1, o2, e2), VMX_NEG16);     // row 0 is the matrix's boundary row
-                else if (l == 0 && jlo - 1 >= jplo && jlo - 1 <= jpend) Hdiag = vmx_pk(bH[jlo - 1], VMX_NEG16);
-            }
+            Hleft = vmx_pk(vmx_gap_open_row(i0, o1, e1, o2, e2), vmx_gap_open_row(i0 + 1, o1, e1, o2, e2));
+            Hdiag = vmx_pk(i0 - 1 == 0 ? 0 : vmx_gap_open_row(i0 - 1, o1, e1, o2, e2), vmx_gap_open_row(i0, o1, e1, o2, e2));
             F1 = NEGP; F2 = NEGP;
             outH = 0; outE1 = NEGP; outE2 = NEGP; qc = vmx_pk(4, 4);
             sHE = 0; sE2 = 0;
@@ -284,9 +271,9 @@ __device__ __forceinline__ int vmx_gapfill_fill16x4(const uint8_t* __restrict__ 
         }
         // a stripe's first chunk is loaded here (the previous stripe has only just stored it); the others were prefetched a block ago
         const bool first = __any(act && t == 0);
-        if (first) load_chunk(act && t == 0, s, 0, jlo, jplo, jpend, qchunk, cH, cE1, cE2);
+        if (first) load_chunk(act && t == 0, s, 0, qchunk, cH, cE1, cE2);
         if (!(act && t == 0)) { qchunk = nq; cH = nH; cE1 = nE1; cE2 = nE2; }
-        load_chunk(act && t + 16 < W, s, t + 16, jlo, jplo, jpend, nq, nH, nE1, nE2);
+        load_chunk(act && t + 16 < W, s, t + 16, nq, nH, nE1, nE2);
         const bool any_bnd = __any(act && store_bnd);
         const unsigned l15 = l == 15 ? 0xffffffffu : 0u;
 #define VMX_X4_STEP(RAMP, TT)                                                                                                      \
@@ -320,13 +307,13 @@ __device__ __forceinline__ int vmx_gapfill_fill16x4(const uint8_t* __restrict__ 
                     Hdiag = vmx_bfi(pm, upH, Hdiag); Hleft = vmx_bfi(pm, h, Hleft); F1 = vmx_bfi(pm, nF1, F1); F2 = vmx_bfi(pm, nF2, F2); \
                 } else { Hdiag = upH; Hleft = h; F1 = nF1; F2 = nF2; }                                                             \
                 outH = h; outE1 = e1v; outE2 = e2v;                                                                                \
-                if (SCORE || BAND) fin = (tfin_rel == (TT)) ? outH : fin;                                                          \
+                if (SCORE) fin = (tfin_rel == (TT)) ? outH : fin;                                                                  \
                 if (any_bnd) {                                                                                                     \
                     sHE = (unsigned)vmx_r16_ror1((int)vmx_bfi(l15, (outH >> 16) | (outE1 & 0xffff0000u), sHE));                    \
                     sE2 = (unsigned)vmx_r16_ror1((int)vmx_bfi(l15, outE2 >> 16, sE2));                                             \
                     if ((TT) == 14) {      /* t is a multiple of 16: the last row finishes a column that is a multiple of 16 on steps = 14 mod 16 */ \
                         const int colr = t + 14 - 30 - l;     /* lane k of the FIFO holds (stripe-relative) column j15 - k */      \
-                        const int col = jlo - 1 + colr;                                                                            \
+                        const int col = colr;                                                                                      \
                         if (store_bnd && act && colr >= 1 && col <= ql) { bH[col] = (int)(short)(sHE & 0xffffu); bE1[col] = (int)sHE >> 16; bE2[col] = (int)(short)(sE2 & 0xffffu); } \
                     }                                                                                                              \
                 }                                                                                                                  \
@@ -345,7 +332,7 @@ __device__ __forceinline__ int vmx_gapfill_fill16x4(const uint8_t* __restrict__ 
             t += 16; tbp += 16 * 32;
             if (t == W) {
                 // the columns behind the last multiple of 16 are still in the FIFO (W - 31 >= ql): lane k holds column W - 31 - k
-                const int colr = W - 31 - l, col = jlo - 1 + colr;
+                const int colr = W - 31 - l, col = colr;
                 if (store_bnd && colr > ((W - 31) & ~15) && col <= ql) { bH[col] = (int)(short)(sHE & 0xffffu); bE1[col] = (int)sHE >> 16; bE2[col] = (int)(short)(sE2 & 0xffffu); }
                 t = 0; ++s;
             }
@@ -356,84 +343,21 @@ __device__ __forceinline__ int vmx_gapfill_fill16x4(const uint8_t* __restrict__ 
     return sc;                                                  // meaningful in lane rf / 2 of the row
 }
 
-// Is the banded result the true optimum with the true traceback? Every path that leaves the computed band deviates from the matrix's
-// main line by more than VMX_BAND_W - 1 columns somewhere, so it holds at least g inserted and g deleted bases with
-// g = (VMX_BAND_W - 1 - |tl - ql|) * min / max, and cannot score more than match * (min(tl, ql) - g) minus two gaps of g. If the banded
-// score beats that bound, every optimal path lies inside the band, where all cells it touches and all comparisons the traceback reads
-// (they involve prefix-optimal values of cells on optimal paths only) are exact.
-__device__ __forceinline__ bool vmx_band_proven(int score, int tl, int ql, int match, int o1, int e1, int o2, int e2) {
-    const int mn = tl < ql ? tl : ql, mx = tl < ql ? ql : tl;
-    long long g = (long long)(VMX_BAND_W - 1 - (mx - mn)) * mn / mx;
-    if (g < 1) return false;
-    const long long c1 = o1 + g * e1, c2 = o2 + g * e2;
-    const long long U = (long long)match * (mn - g) - 2 * (c1 < c2 ? c1 : c2);
-    return (long long)score > U;
-}
+#include "vmx_dp_ad.h"
 
-// order/counter: longest-first device work queue (order == nullptr: plain grid-stride over [0, n_prob))
-// SCORE = false (k_gapfill_fill_ns): the batched path only consumes the traceback, so the small-problem form skips the score capture
+// one problem on the whole wavefront (p is wave-uniform): int32 cells, one row per lane, or packed int16, two rows per lane
 template <bool SCORE>
-__device__ __forceinline__ void vmx_gapfill_fill_body(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
-                                                     const vmx_dp_prob* __restrict__ probs, int n_prob, int match, int mismatch,
-                                                     int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb_pool,
-                                                     int32_t* __restrict__ bnd_pool, int32_t* __restrict__ out_score,
-                                                     const int32_t* __restrict__ order, int32_t* __restrict__ counter,
-                                                     int32_t* __restrict__ redo_list = nullptr, int32_t* __restrict__ redo_cnt = nullptr, int redo_pass = 0) {
-    // redo_list / redo_cnt (batched path): problems whose band is not proven are appended to the list instead of being filled in full on
-    // the spot (that would run a whole wave for one 16-lane row); a second launch (redo_pass = 1) takes them four per wave like any others.
-    // redo_cnt[0] = entries, redo_cnt[1] = the second launch's queue head.
-    const int lane = vmx_lane();
-    int static_next = 4 * (int)blockIdx.x;
-    if (redo_pass) { n_prob = redo_cnt[0]; order = redo_list; counter = redo_cnt + 1; }
-    while (true) {
-        // a wave takes four problems at a time: those of the small class run together, one per 16-lane row (vmx_gapfill_fill16x4); the
-        // others (the head of the longest-first queue) run one after the other on the whole wave
-        int q0;
-        if (order) { int v = 0; if (lane == 0) v = atomicAdd(counter, 4); q0 = vmx_bcast0(v); }
-        else { q0 = static_next; static_next += 4 * (int)gridDim.x; }
-        if (q0 >= n_prob) break;
-        const int qg = q0 + (lane >> 4);
-        const int pg = qg < n_prob ? (order ? order[qg] : qg) : -1;
-        bool x4 = false;
-        {
-            vmx_dp_prob pr; pr.tl = 0; pr.ql = 0; pr.t_off = 0; pr.q_off = 0; pr.tb_off = 0; pr.bnd_off = 0;
-            if (pg >= 0) pr = probs[pg];
-            x4 = pg >= 0 && pr.tl > 0 && pr.ql > 0 && VMX_DP16X4_OK(pr.tl, pr.ql);
-            // SCORE = false (the batched path): first the banded form; out_score[p] then carries the layout flag the traceback kernel reads
-            // (1 = banded stripes); problems whose band is not proven run again in full
-            bool redo = x4, banded_ok = false;
-            if (!SCORE) {
-                const bool band = !redo_pass && x4 && VMX_BAND_STEPS(pr.tl, pr.ql) > 0;
-                if (__any(band)) {
-                    const int sc = vmx_gapfill_fill16x4<false, true>(tcodes + pr.t_off, qcodes + pr.q_off, band ? pr.tl : 0, band ? pr.ql : 0, match, mismatch, o1, e1, o2, e2,
-                                                                     tb_pool + pr.tb_off, bnd_pool + pr.bnd_off, nullptr, lane);
-                    const int rfl = ((pr.tl - 1) & 31) >> 1;
-                    const int scr = __shfl(sc, (lane & 48) | (rfl & 15));      // the row's score lane
-                    banded_ok = band && vmx_band_proven(scr, pr.tl, pr.ql, match, o1, e1, o2, e2);
-                    redo = x4 && !banded_ok;
-                    __syncthreads();                                           // (the full form reuses the problem's boundary rows)
-                    if (redo_list != nullptr) {
-                        if (band && !banded_ok && (lane & 15) == 0) redo_list[atomicAdd(redo_cnt, 1)] = pg;       // later, four per wave
-                        redo = x4 && !band;
-                    }
-                }
-                if (x4 && (lane & 15) == 0) out_score[pg] = banded_ok ? 1 : 0;
-            }
-            if (__any(redo))
-                vmx_gapfill_fill16x4<SCORE, false>(tcodes + pr.t_off, qcodes + pr.q_off, redo ? pr.tl : 0, redo ? pr.ql : 0, match, mismatch, o1, e1, o2, e2, tb_pool + pr.tb_off,
-                                                   bnd_pool + pr.bnd_off, &out_score[pg < 0 ? 0 : pg], lane);
-        }
-        for (int gk = 0; gk < 4; ++gk) {
-        const int p = vmx_readlane(pg, 16 * gk);
-        if (p < 0 || vmx_readlane((int)x4, 16 * gk)) continue;
+__device__ __forceinline__ void vmx_gapfill_fill_one(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes, const vmx_dp_prob* __restrict__ probs, int p,
+                                                    int match, int mismatch, int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb_pool,
+                                                    int32_t* __restrict__ bnd_pool, int32_t* __restrict__ out_score, int lane, int flag_value = 0, uint8_t* __restrict__ redo_pool = nullptr) {
         const vmx_dp_prob pr = probs[p];
         const uint8_t* T = tcodes + pr.t_off;
         const uint8_t* Q = qcodes + pr.q_off;
         const int tl = vmx_uniform_i32(pr.tl), ql = vmx_uniform_i32(pr.ql);
         const bool trivial = tl == 0 || ql == 0;     // no barrier-skipping `continue`: an empty side just runs zero stripes
         if (trivial && lane == 0) out_score[p] = (tl + ql) ? vmx_gap_open_row(tl + ql, o1, e1, o2, e2) : 0;
-        if (!SCORE && !trivial && lane == 0) out_score[p] = 0;     // layout flag: not banded
-        uint8_t* tb = tb_pool + pr.tb_off;
+        if (!SCORE && !trivial && lane == 0) out_score[p] = flag_value;     // layout flag (0: the layout of the problem's size class)
+        uint8_t* tb = vmx_tb_ptr(tb_pool, redo_pool, pr.tb_off);
         int32_t* bH = bnd_pool + pr.bnd_off;
         int32_t* bE1 = bH + (ql + 1);
         int32_t* bE2 = bE1 + (ql + 1);
@@ -509,7 +433,126 @@ __device__ __forceinline__ void vmx_gapfill_fill_body(const uint8_t* __restrict_
             __syncthreads();   // bnd[] written by this stripe is read (in 64-column chunks) by the next one
         }
         if (!trivial && !pk && lane == ((tl - 1) & 63)) out_score[p] = outH;     // H(tl, ql): the last cell that lane computed
-        if (pk) vmx_gapfill_fill16(T, Q, tl, ql, match, mismatch, o1, e1, o2, e2, tb, bH, &out_score[p], lane);
+        int32_t sink = 0;
+        if (pk) vmx_gapfill_fill16(T, Q, tl, ql, match, mismatch, o1, e1, o2, e2, tb, bH, SCORE ? &out_score[p] : &sink, lane);
+}
+
+// order/counter: longest-first device work queue (order == nullptr: plain grid-stride over [0, n_prob))
+// SCORE = false: the batched path only consumes the traceback, so the small-problem form skips the score capture; out_score[p] then carries
+// the layout flag the traceback kernel reads (0: striped). redo_pass: the queue is the list the first launch of the batched path left
+// behind (redo_cnt[0] = entries, redo_cnt[1] = this launch's queue head).
+template <bool SCORE>
+__device__ __forceinline__ void vmx_gapfill_fill_body(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
+                                                     const vmx_dp_prob* __restrict__ probs, int n_prob, int match, int mismatch,
+                                                     int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb_pool,
+                                                     int32_t* __restrict__ bnd_pool, int32_t* __restrict__ out_score,
+                                                     const int32_t* __restrict__ order, int32_t* __restrict__ counter,
+                                                     int32_t* __restrict__ redo_list = nullptr, int32_t* __restrict__ redo_cnt = nullptr, int redo_pass = 0,
+                                                     uint8_t* __restrict__ redo_pool = nullptr) {
+    const int lane = vmx_lane();
+    int static_next = 4 * (int)blockIdx.x;
+    if (redo_pass) {
+        n_prob = redo_cnt[0]; order = redo_list; counter = redo_cnt + 1;
+        // the larger problems of the list first, one per task on the whole wave in the packed two-rows-per-lane layout (flag VMX_PK_FLAG): on a
+        // single 16-lane row a 500 x 500 matrix is a millisecond-long serial chain that the rest of the launch would wait for
+        while (true) {
+            int q; { int v = 0; if (lane == 0) v = atomicAdd(redo_cnt + 2, 1); q = vmx_bcast0(v); }
+            if (q >= n_prob) break;
+            const int p = order[q];
+            const int tl = probs[p].tl, ql = probs[p].ql;
+            if (VMX_REDO_PK(tl, ql)) vmx_gapfill_fill_one<SCORE>(tcodes, qcodes, probs, p, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, lane, VMX_PK_FLAG, redo_pool);
+        }
+    }
+    while (true) {
+        // a wave takes four problems at a time: those of the small class run together, one per 16-lane row (vmx_gapfill_fill16x4); the
+        // others (the head of the longest-first queue) run one after the other on the whole wave
+        int q0;
+        if (order) { int v = 0; if (lane == 0) v = atomicAdd(counter, 4); q0 = vmx_bcast0(v); }
+        else { q0 = static_next; static_next += 4 * (int)gridDim.x; }
+        if (q0 >= n_prob) break;
+        const int qg = q0 + (lane >> 4);
+        const int pg = qg < n_prob ? (order ? order[qg] : qg) : -1;
+        bool x4 = false, skip = false;
+        {
+            vmx_dp_prob pr; pr.tl = 0; pr.ql = 0; pr.t_off = 0; pr.q_off = 0; pr.tb_off = 0; pr.bnd_off = 0;
+            if (pg >= 0) pr = probs[pg];
+            skip = redo_pass && pg >= 0 && VMX_REDO_PK(pr.tl, pr.ql);          // done above
+            x4 = pg >= 0 && !skip && pr.tl > 0 && pr.ql > 0 && VMX_DP16X4_OK(pr.tl, pr.ql);
+            if (!SCORE && x4 && (lane & 15) == 0) out_score[pg] = 0;
+            if (__any(x4))
+                vmx_gapfill_fill16x4<SCORE>(tcodes + pr.t_off, qcodes + pr.q_off, x4 ? pr.tl : 0, x4 ? pr.ql : 0, match, mismatch, o1, e1, o2, e2, vmx_tb_ptr(tb_pool, redo_pool, pr.tb_off),
+                                            bnd_pool + pr.bnd_off, &out_score[pg < 0 ? 0 : pg], lane);
+        }
+        for (int gk = 0; gk < 4; ++gk) {
+            const int p = vmx_readlane(pg, 16 * gk);
+            if (p < 0 || vmx_readlane((int)(x4 || skip), 16 * gk)) continue;
+            vmx_gapfill_fill_one<SCORE>(tcodes, qcodes, probs, p, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, lane, 0, redo_pool);
+        }
+    }
+}
+
+// first launch of the batched path: EIGHT problems at a time. Those of the small class whose shape a band can hold (vmx_ad_ns) run together
+// in the anti-diagonal form (vmx_dp_ad.h), all with the widest band any of the eight asks for; a problem whose result is proven keeps it
+// (layout flag VMX_AD_FLAG + ns), the others — not proven, or small but not worth a band — are appended to redo_list for the second launch
+// (vmx_gapfill_fill_body with redo_pass = 1: full matrix, four per wave). Larger problems run one after the other on the whole wave.
+__device__ __forceinline__ void vmx_gapfill_ad_pass(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes, vmx_dp_prob* __restrict__ probs, int n_prob,
+                                                   int match, int mismatch, int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb_pool, int32_t* __restrict__ bnd_pool,
+                                                   int32_t* __restrict__ out_score, const int32_t* __restrict__ order, const int32_t* __restrict__ range, int32_t* __restrict__ counter,
+                                                   int32_t* __restrict__ redo_list, int32_t* __restrict__ redo_cnt, int ad_pct, unsigned long long* __restrict__ redo_bytes) {
+    const int lane = vmx_lane();
+    const int pct = ad_pct & 0xffff, pct_min = (ad_pct >> 16) & 0xffff;
+    // the head of the longest-first queue (range[0] entries: the size classes above the small one) goes one problem per task: eight of them in
+    // a row on one wave would be a multi-millisecond serial chain at the start of the launch; then eight at a time
+    const int n_head = range[0] < n_prob ? range[0] : n_prob;
+    bool head = n_head > 0;
+    while (true) {
+        int pX = -1, pY = -1;                                  // this lane's row's two problems (-1: none)
+        if (head) {
+            int q; { int v = 0; if (lane == 0) v = atomicAdd(counter + 1, 1); q = vmx_bcast0(v); }
+            if (q >= n_head) { head = false; continue; }
+            if (lane < 16) pX = order[q];
+        } else {
+            int q0; { int v = 0; if (lane == 0) v = atomicAdd(counter, 8); q0 = n_head + vmx_bcast0(v); }
+            if (q0 >= n_prob) break;
+            const int qX = q0 + 2 * (lane >> 4), qY = qX + 1;
+            if (qX < n_prob) pX = order[qX];
+            if (qY < n_prob) pY = order[qY];
+        }
+        vmx_dp_prob prX, prY;
+        prX.tl = 0; prX.ql = 0; prX.t_off = 0; prX.q_off = 0; prX.tb_off = 0; prY = prX;
+        if (pX >= 0) prX = probs[pX];
+        if (pY >= 0) prY = probs[pY];
+        const bool x4X = pX >= 0 && prX.tl > 0 && prX.ql > 0 && VMX_DP16X4_OK(prX.tl, prX.ql), x4Y = pY >= 0 && prY.tl > 0 && prY.ql > 0 && VMX_DP16X4_OK(prY.tl, prY.ql);
+        const int nsX = x4X ? vmx_ad_ns(prX.tl, prX.ql, match, o1, e1, o2, e2, pct, pct_min) : 0, nsY = x4Y ? vmx_ad_ns(prY.tl, prY.ql, match, o1, e1, o2, e2, pct, pct_min) : 0;
+        const int ns = vmx_uniform_i32(vmx_wave_max_i32(nsX > nsY ? nsX : nsY));
+        bool keepX = false, keepY = false;
+        if (ns > 0) {
+            int dloX = 0, dloY = 0;
+            const int gX = nsX > 0 ? vmx_ad_geom(prX.tl, prX.ql, ns, &dloX) : 0, gY = nsY > 0 ? vmx_ad_geom(prY.tl, prY.ql, ns, &dloY) : 0;
+            const int tlX = gX > 0 ? prX.tl : 0, qlX = gX > 0 ? prX.ql : 0, tlY = gY > 0 ? prY.tl : 0, qlY = gY > 0 ? prY.ql : 0;
+            int scX = 0, scY = 0;
+#define VMX_AD_RUN(NSV) vmx_gapfill_fill_ad<NSV>(tcodes + prX.t_off, qcodes + prX.q_off, tlX, qlX, dloX, tb_pool + prX.tb_off, tcodes + prY.t_off, qcodes + prY.q_off, tlY, qlY, dloY, \
+                                                 tb_pool + prY.tb_off, match, mismatch, o1, e1, o2, e2, lane, scX, scY)
+            if (ns == 1) VMX_AD_RUN(1); else if (ns == 2) VMX_AD_RUN(2); else if (ns == 3) VMX_AD_RUN(3); else VMX_AD_RUN(4);
+#undef VMX_AD_RUN
+            keepX = gX > 0 && vmx_ad_proven(scX, prX.tl, prX.ql, gX, match, o1, e1, o2, e2);
+            keepY = gY > 0 && vmx_ad_proven(scY, prY.tl, prY.ql, gY, match, o1, e1, o2, e2);
+        }
+        if ((lane & 15) == 0) {
+            // a problem for the second launch takes its full-matrix traceback space out of the second pool
+            if (x4X) {
+                out_score[pX] = keepX ? VMX_AD_FLAG + ns : 0;
+                if (!keepX) { probs[pX].tb_off = -(int64_t)atomicAdd(redo_bytes, (unsigned long long)VMX_REDO_TB_BYTES(prX.tl, prX.ql)) - 1; redo_list[atomicAdd(redo_cnt, 1)] = pX; }
+            }
+            if (x4Y) {
+                out_score[pY] = keepY ? VMX_AD_FLAG + ns : 0;
+                if (!keepY) { probs[pY].tb_off = -(int64_t)atomicAdd(redo_bytes, (unsigned long long)VMX_REDO_TB_BYTES(prY.tl, prY.ql)) - 1; redo_list[atomicAdd(redo_cnt, 1)] = pY; }
+            }
+        }
+        for (int gk = 0; gk < 8; ++gk) {
+            const int p = vmx_readlane((gk & 1) ? pY : pX, 16 * (gk >> 1));
+            if (p < 0 || vmx_readlane((int)((gk & 1) ? x4Y : x4X), 16 * (gk >> 1))) continue;
+            vmx_gapfill_fill_one<false>(tcodes, qcodes, probs, p, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, lane);
         }
     }
 }
@@ -521,33 +564,39 @@ __global__ void __launch_bounds__(64) k_gapfill_fill(const uint8_t* __restrict__
                                                      const int32_t* __restrict__ order, int32_t* __restrict__ counter) {
     vmx_gapfill_fill_body<true>(tcodes, qcodes, probs, n_prob, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, order, counter);
 }
-__global__ void __launch_bounds__(64, 5) k_gapfill_fill_ns(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
-                                                        const vmx_dp_prob* __restrict__ probs, int n_prob, int match, int mismatch,
+__global__ void __launch_bounds__(64, 4) k_gapfill_fill_ns(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
+                                                        vmx_dp_prob* __restrict__ probs, int n_prob, int match, int mismatch,
                                                         int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb_pool,
                                                         int32_t* __restrict__ bnd_pool, int32_t* __restrict__ out_score,
-                                                        const int32_t* __restrict__ order, int32_t* __restrict__ counter,
-                                                        int32_t* __restrict__ redo_list, int32_t* __restrict__ redo_cnt, int redo_pass) {
-    vmx_gapfill_fill_body<false>(tcodes, qcodes, probs, n_prob, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, order, counter, redo_list, redo_cnt, redo_pass);
+                                                        const int32_t* __restrict__ order, const int32_t* __restrict__ range, int32_t* __restrict__ counter,
+                                                        int32_t* __restrict__ redo_list, int32_t* __restrict__ redo_cnt, int redo_pass, int ad_pct,
+                                                        uint8_t* __restrict__ redo_pool, unsigned long long* __restrict__ redo_bytes) {
+    if (redo_pass) vmx_gapfill_fill_body<false>(tcodes, qcodes, probs, n_prob, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, order, counter, redo_list, redo_cnt, 1, redo_pool);
+    else vmx_gapfill_ad_pass(tcodes, qcodes, probs, n_prob, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, order, range, counter, redo_list, redo_cnt, ad_pct, redo_bytes);
 }
 
 // serial traceback, one THREAD per problem (thousands of independent dependent-load chains hide each other's latency)
 __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
                                 const vmx_dp_prob* __restrict__ probs, int n_prob, int eqx, const uint8_t* __restrict__ tb_pool,
                                 uint32_t* __restrict__ run_pool, char* __restrict__ cig_pool, int32_t* __restrict__ cig_len,
-                                const int32_t* __restrict__ band_flag) {
+                                const int32_t* __restrict__ band_flag, const uint8_t* __restrict__ redo_pool) {
     int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (p >= n_prob) return;
     const vmx_dp_prob pr = probs[p];
     const uint8_t* T = tcodes + pr.t_off;
     const uint8_t* Q = qcodes + pr.q_off;
     const int tl = pr.tl, ql = pr.ql;
-    const uint8_t* tb = tb_pool + pr.tb_off;
+    const uint8_t* tb = vmx_tb_ptr(tb_pool, redo_pool, pr.tb_off);
     uint32_t* runs = run_pool + pr.run_off;
     char* cig = cig_pool + pr.cig_off;
-    const bool x4 = tl > 0 && ql > 0 && VMX_DP16X4_OK(tl, ql);   // layout of vmx_gapfill_fill16x4
-    const bool pk = !x4 && tl > 0 && ql > 0 && VMX_DP16_OK(tl, ql);     // packed layout of vmx_gapfill_fill16
-    const bool band = x4 && band_flag != nullptr && band_flag[p] == 1;        // banded stripes (vmx_gapfill_fill16x4<.., true>)
-    const int W = band ? VMX_BAND_STEPS(tl, ql) : (x4 ? VMX_X4_W(ql) : ql + (pk ? 127 : 63));
+    bool x4 = tl > 0 && ql > 0 && VMX_DP16X4_OK(tl, ql);         // layout of vmx_gapfill_fill16x4
+    bool pk = !x4 && tl > 0 && ql > 0 && VMX_DP16_OK(tl, ql);           // packed layout of vmx_gapfill_fill16
+    const int flag = (x4 && band_flag != nullptr) ? band_flag[p] : 0;
+    const int ns = flag > VMX_AD_FLAG ? flag - VMX_AD_FLAG : 0;          // anti-diagonal layout (vmx_dp_ad.h) with 2 * ns diagonals per lane
+    if (flag == VMX_PK_FLAG) { x4 = false; pk = true; }                  // a small-class problem the second launch ran on the whole wave
+    int dlo = 0;
+    if (ns) vmx_ad_geom(tl, ql, ns, &dlo);
+    const int W = x4 ? VMX_X4_W(ql) : ql + (pk ? 127 : 63);
     int nruns = 0; int cur_op = -1; uint32_t cur_len = 0;
 #define VMX_EMIT(op)                                                                   \
     do {                                                                               \
@@ -557,7 +606,8 @@ __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_
     int i = tl, j = ql, state = 0;
     while (i > 0 && j > 0) {
         int b;
-        if (x4) { const int s = (i - 1) >> 5, r = (i - 1) & 31, t = (j - (band ? VMX_BAND_JLO(tl, ql, s) : 1)) + r; b = tb[(((size_t)s * (size_t)W + (size_t)t) * 16 + (r >> 1)) * 2 + (r & 1)]; }
+        if (ns) { const int x = (j - i) - dlo, l = x / (2 * ns), k = (x - 2 * ns * l) >> 1; b = tb[(size_t)(i + j - 1) * 64 + (size_t)(4 * l + k)]; }
+        else if (x4) { const int s = (i - 1) >> 5, r = (i - 1) & 31, t = (j - 1) + r; b = tb[(((size_t)s * (size_t)W + (size_t)t) * 16 + (r >> 1)) * 2 + (r & 1)]; }
         else if (pk) { const int s = (i - 1) >> 7, r = (i - 1) & 127, t = (j - 1) + r; b = tb[(((size_t)s * (size_t)W + (size_t)t) * 64 + (r >> 1)) * 2 + (r & 1)]; }
         else { const int s = (i - 1) >> 6, l = (i - 1) & 63, t = (j - 1) + l; b = tb[((size_t)s * (size_t)W + (size_t)t) * 64 + l]; }
         if (state == 0) {

@@ -13,16 +13,24 @@
 #include "vmx_device.h"
 #include "vmx_kernels.h"
 
-// order[] = problem indices sorted by floor(log2(size)) descending; range[0] = number of problems with size > thresh,
+// order[] = problem indices sorted by size class descending (quarter octaves: floor(log2(size)) and the two bits below the leading one);
+// range[0] = number of problems with size > thresh (the head of the order when thresh + 1 is a power of two),
 // range[1] = number of problems queued (those with size >= 0); counters[0..3] = 0 (work-queue heads of the consumers)
+__device__ __forceinline__ int vmx_size_class(long long s) {
+    if (s < 0) return -1;
+    if (s == 0) return 0;
+    const int e = 63 - __clzll(s);
+    const int m = (int)((e >= 2 ? s >> (e - 2) : s << (2 - e)) & 3);
+    return (e << 2) | m;
+}
 __global__ void __launch_bounds__(1024) k_size_order(const int64_t* __restrict__ size, const int32_t* __restrict__ n_ptr, int64_t thresh,
                                                      int32_t* __restrict__ order, int32_t* __restrict__ range, int32_t* __restrict__ counters) {
-    __shared__ int s_hist[64];
-    __shared__ int s_cur[64];
+    __shared__ int s_hist[256];
+    __shared__ int s_cur[256];
     __shared__ int s_long;
     const int n = *n_ptr;
     const int lane = vmx_lane();
-    if (threadIdx.x < 64) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_long = 0;
     __syncthreads();
     // nearly all problems of a launch share two or three size classes: the lanes of a wave that hit the same class are counted with
@@ -31,7 +39,7 @@ __global__ void __launch_bounds__(1024) k_size_order(const int64_t* __restrict__
     for (int i0 = 0; i0 < n; i0 += (int)blockDim.x) {
         const int i = i0 + (int)threadIdx.x;
         const long long s = i < n ? size[i] : -1;
-        int b = s < 0 ? -1 : (s > 0 ? 63 - __clzll(s) : 0);        // negative size: problem already settled, not queued
+        int b = vmx_size_class(s);                                  // negative size: problem already settled, not queued
         if (s > thresh) ++nl;
         unsigned long long todo = __ballot(b >= 0);
         while (todo) {
@@ -46,7 +54,7 @@ __global__ void __launch_bounds__(1024) k_size_order(const int64_t* __restrict__
     __syncthreads();
     if (threadIdx.x == 0) {
         int acc = 0;
-        for (int b = 63; b >= 0; --b) { s_cur[b] = acc; acc += s_hist[b]; }
+        for (int b = 255; b >= 0; --b) { s_cur[b] = acc; acc += s_hist[b]; }
         range[0] = s_long; range[1] = acc;
         counters[0] = 0; counters[1] = 0; counters[2] = 0; counters[3] = 0;
     }
@@ -54,7 +62,7 @@ __global__ void __launch_bounds__(1024) k_size_order(const int64_t* __restrict__
     for (int i0 = 0; i0 < n; i0 += (int)blockDim.x) {
         const int i = i0 + (int)threadIdx.x;
         const long long s = i < n ? size[i] : -1;
-        int b = s < 0 ? -1 : (s > 0 ? 63 - __clzll(s) : 0);
+        int b = vmx_size_class(s);
         unsigned long long todo = __ballot(b >= 0);
         while (todo) {
             const int leader = __ffsll((unsigned long long)todo) - 1;

@@ -206,7 +206,7 @@ __global__ void k_dp_sizes(const vmx_pair_desc* __restrict__ desc, const int32_t
     const int n = *n_prob;
     for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x)) {
         const long long tl = desc[i].t.len, ql = desc[i].q.len;
-        tb_sz[i] = VMX_TB_BYTES(tl, ql);
+        tb_sz[i] = VMX_TB_BYTES_NS(tl, ql);
         bnd_sz[i] = 3 * (ql + 1); run_sz[i] = tl + ql + 2; cig_sz[i] = 2 * (tl + ql) + 16;
     }
 }

@@ -54,7 +54,7 @@ struct vmx_batch_bufs {
     DevBuf nanc64, aoff, rows, lens, keys, koff, sorted, flip, S, P, SA, cov, gmax, opc, rl, gap, scr, soff, res, plen, prow, ocodes;
     // extend stage
     DevBuf er, coff3, soff2, segA, st, en, segA_s, st_s, en_s, segprob, dup, desc[2], rcount, oflow, probread, tl, ql, toff, qoff, tpool, qpool;
-    DevBuf edout, carry, ext3, dpsz[4], dpoff[4], dptab, tb, bnd, run, cig, ciglen, dpscore, rec, blob, bloboff, reccoff, recclen, dupd, totals;
+    DevBuf edout, carry, ext3, dpsz[4], dpoff[4], dptab, tb, tbredo, bnd, run, cig, ciglen, dpscore, rec, blob, bloboff, reccoff, recclen, dupd, totals;
     DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp, chunkn;
     void release() { DevBuf* p = (DevBuf*)this; for (size_t i = 0; i < sizeof(*this) / sizeof(DevBuf); ++i) p[i].release(); }
 };
@@ -315,11 +315,13 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         st.dp_string_bytes += tq[0] + tq[1];
         c->n_gev[redo_only ? 1 : 0] = 0;
         if (cnt) {
-            VMX_TRY(B.order.reserve(4 * (size_t)(2 * round_cap + 64))); VMX_TRY(B.qrange.reserve(64));
+            VMX_TRY(B.order.reserve(4 * (size_t)(2 * round_cap + 64))); VMX_TRY(B.qrange.reserve(128));
             int32_t* d_range = B.qrange.as<int32_t>(); int32_t* d_cnt = d_range + 4;
+            unsigned long long* d_redo_bytes = (unsigned long long*)(d_range + 16);
             int32_t* d_redo_list = B.order.as<int32_t>() + round_cap + 32; int32_t* d_redo_cnt = d_range + 12;     // problems whose band was not proven
             std::vector<int32_t> csz; for (size_t q = 0; q + 1 < cuts.size(); ++q) csz.push_back(cuts[q + 1] - cuts[q]);
             VMX_TRY(upload(B.chunkn, csz.data(), csz.size(), c->stream));
+            const int ad_pct = vmx_ad_pct_env();
             int fill_waves = 16;                                  // waves per CU of the fill kernel (tuning knob: VMX_FILL_WAVES)
             if (const char* e = getenv("VMX_FILL_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 32) fill_waves = v; }
             for (size_t q = 0; q + 1 < cuts.size(); ++q) {
@@ -327,19 +329,25 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
                 // the problems' absolute traceback offsets index a buffer that holds this chunk only
                 uint8_t* tb_base = B.tb.as<uint8_t>() - h_tboff[(size_t)p0];
                 hipEvent_t* ke = q < 8 ? c->gev + (redo_only ? 24 : 0) + 3 * q : nullptr;      // HIP events around the dominant kernel, on the stream it runs on
-                hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>() + p0, B.chunkn.as<int32_t>() + q, (int64_t)0, B.order.as<int32_t>(), d_range, d_cnt);
-                (void)hipMemsetAsync(d_redo_cnt, 0, 8, c->stream);
+                hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>() + p0, B.chunkn.as<int32_t>() + q, (int64_t)VMX_HEAD_THRESH, B.order.as<int32_t>(), d_range, d_cnt);
+                (void)hipMemsetAsync(d_redo_cnt, 0, 16, c->stream); (void)hipMemsetAsync(d_redo_bytes, 0, 8, c->stream);
                 if (ke) (void)hipEventRecord(ke[0], c->stream);
                 hipLaunchKernelGGL(k_gapfill_fill_ns, dim3((unsigned)std::min<int64_t>(pn, (int64_t)c->num_cu * fill_waves)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
-                                   B.dptab.as<vmx_dp_prob>() + p0, pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_cnt,
-                                   d_redo_list, d_redo_cnt, 0);
-                // second launch: the problems whose band was not proven (a few per cent), in full, four per wave
+                                   B.dptab.as<vmx_dp_prob>() + p0, pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_range, d_cnt,
+                                   d_redo_list, d_redo_cnt, 0, ad_pct, (uint8_t*)nullptr, d_redo_bytes);
+                // sizing sync #4: full-matrix traceback space of the problems the first launch queued for the second one (a few per cent of them)
+                unsigned long long redo_bytes = 0; int32_t n_redo = 0;
+                VMX_TRY(download(&redo_bytes, d_redo_bytes, 1, c->stream)); VMX_TRY(download(&n_redo, d_redo_cnt, 1, c->stream));
+                VMX_HIP(hipStreamSynchronize(c->stream));
+                VMX_TRY(B.tbredo.reserve((size_t)redo_bytes + 64));
+                st.dp_redo_tb_bytes += (int64_t)redo_bytes; st.n_dp_redo += n_redo; st.dp_cells += (int64_t)redo_bytes;
+                // second launch: the problems whose band was not proven (a few per cent), in full: the larger ones on a whole wave, the others four per wave
                 hipLaunchKernelGGL(k_gapfill_fill_ns, dim3((unsigned)std::min<int64_t>((pn + 3) / 4, (int64_t)c->num_cu * 4)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
-                                   B.dptab.as<vmx_dp_prob>() + p0, pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_cnt,
-                                   d_redo_list, d_redo_cnt, 1);
+                                   B.dptab.as<vmx_dp_prob>() + p0, pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_range, d_cnt,
+                                   d_redo_list, d_redo_cnt, 1, ad_pct, B.tbredo.as<uint8_t>(), d_redo_bytes);
                 if (ke) (void)hipEventRecord(ke[1], c->stream);
                 hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)((pn + 63) / 64)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>() + p0, pn, prm->eqx,
-                                   tb_base, B.run.as<uint32_t>(), B.cig.as<char>(), B.ciglen.as<int32_t>() + p0, B.dpscore.as<int32_t>() + p0);
+                                   tb_base, B.run.as<uint32_t>(), B.cig.as<char>(), B.ciglen.as<int32_t>() + p0, B.dpscore.as<int32_t>() + p0, B.tbredo.as<uint8_t>());
                 if (ke) { (void)hipEventRecord(ke[2], c->stream); c->n_gev[redo_only ? 1 : 0] = (int)q + 1; }
             }
         }
@@ -547,6 +555,7 @@ int vm_align_batch(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t 
             tot.ms_total += st.ms_total; for (int i = 0; i < 16; ++i) tot.ms_stage[i] += st.ms_stage[i];
             tot.ms_gapfill_fill += st.ms_gapfill_fill; tot.ms_gapfill_trace += st.ms_gapfill_trace; tot.n_gapfill_launches += st.n_gapfill_launches;
             tot.n_ed_full += st.n_ed_full; tot.n_ed_tier2 += st.n_ed_tier2; tot.n_ed_tier1 += st.n_ed_tier1;
+            tot.n_dp_redo += st.n_dp_redo; tot.dp_redo_tb_bytes += st.dp_redo_tb_bytes;
         }
         a = b;
     }

@@ -237,8 +237,10 @@ int vm_k_extend_batch(vm_ctx* c, int match, int mismatch, int o, int e, int bw, 
 }
 
 // schedule = 0: k_gapfill_fill (full matrix, scores captured). schedule = 1: exactly what vm_align_batch launches for its gap-fill
-// problems (vmx_align.hip): longest-first device queue, k_gapfill_fill_ns with the BANDED four-per-wave form first, the problems whose
-// band is not proven queued and filled in full by the second launch, the per-problem layout flag handed to k_gapfill_trace.
+// problems (vmx_align.hip): longest-first device queue, k_gapfill_fill_ns with the anti-diagonal BAND form first (eight small problems per
+// wave), the problems whose band is not proven (or that are not worth a band) queued and filled in full by the second launch, the
+// per-problem layout flag handed to k_gapfill_trace. stats: small problems tried in a band, kept (proven), queued for the second launch
+// (incl. the small ones never tried), problems outside the small class.
 static int k_cigar_batch_impl(vm_ctx* c, const vm_score* sc, int eqx, int schedule, int64_t n, const char* t, const int64_t* t_off, const char* q,
                               const int64_t* q_off, char** cigars, int64_t** cigar_off, int32_t** scores, int32_t** band_flag, int64_t* stats) {
     if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
@@ -253,7 +255,7 @@ static int k_cigar_batch_impl(vm_ctx* c, const vm_score* sc, int eqx, int schedu
         vmx_dp_prob& p = probs[i];
         p.t_off = t_off[i]; p.q_off = q_off[i]; p.tl = (int32_t)(t_off[i + 1] - t_off[i]); p.ql = (int32_t)(q_off[i + 1] - q_off[i]);
         p.tb_off = tb; p.bnd_off = bnd; p.run_off = run; p.cig_off = cig;
-        tbsz[i] = VMX_TB_BYTES((int64_t)p.tl, (int64_t)p.ql);
+        tbsz[i] = schedule == 0 ? VMX_TB_BYTES((int64_t)p.tl, (int64_t)p.ql) : VMX_TB_BYTES_NS((int64_t)p.tl, (int64_t)p.ql);
         tb += tbsz[i];
         bnd += 3 * (int64_t)(p.ql + 1); run += (int64_t)p.tl + p.ql + 2; cig += 2 * ((int64_t)p.tl + p.ql) + 16;
     }
@@ -263,27 +265,35 @@ static int k_cigar_batch_impl(vm_ctx* c, const vm_score* sc, int eqx, int schedu
     VMX_TRY(c->b[11].reserve(sizeof(int32_t) * 2 * (size_t)(n + 1)));
     int32_t* d_score = c->b[11].as<int32_t>(); int32_t* d_len = d_score + n;
     int32_t redo[2] = {0, 0};
+    const int ad_pct = vmx_ad_pct_env();
     if (n && schedule == 0) {
         hipLaunchKernelGGL(k_gapfill_fill, dim3(grid_for(c, n, 16)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[4].as<uint8_t>(),
                            c->b[6].as<vmx_dp_prob>(), (int)n, sc->match, sc->mismatch, sc->o1, sc->e1, sc->o2, sc->e2, c->b[7].as<uint8_t>(),
                            c->b[8].as<int32_t>(), d_score, (const int32_t*)nullptr, (int32_t*)nullptr);
         hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[4].as<uint8_t>(),
-                           c->b[6].as<vmx_dp_prob>(), (int)n, eqx, c->b[7].as<uint8_t>(), c->b[9].as<uint32_t>(), c->b[10].as<char>(), d_len, (const int32_t*)nullptr);
+                           c->b[6].as<vmx_dp_prob>(), (int)n, eqx, c->b[7].as<uint8_t>(), c->b[9].as<uint32_t>(), c->b[10].as<char>(), d_len, (const int32_t*)nullptr, (const uint8_t*)nullptr);
     } else if (n) {
         const int32_t nn = (int32_t)n;
         VMX_TRY(upload(c->b[12], tbsz.data(), (size_t)n, c->stream)); VMX_TRY(upload(c->b[13], &nn, 1, c->stream));
-        VMX_TRY(c->b[14].reserve(4 * (size_t)(2 * n + 64))); VMX_TRY(c->b[15].reserve(64));
+        VMX_TRY(c->b[14].reserve(4 * (size_t)(2 * n + 64))); VMX_TRY(c->b[15].reserve(128));
         int32_t* d_range = c->b[15].as<int32_t>(); int32_t* d_cnt = d_range + 4; int32_t* d_redo_cnt = d_range + 12;
+        unsigned long long* d_redo_bytes = (unsigned long long*)(d_range + 16);
         int32_t* d_order = c->b[14].as<int32_t>(); int32_t* d_redo_list = d_order + n + 32;
-        hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, c->b[12].as<int64_t>(), c->b[13].as<int32_t>(), (int64_t)0, d_order, d_range, d_cnt);
-        VMX_HIP(hipMemsetAsync(d_redo_cnt, 0, 8, c->stream));
+        hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, c->b[12].as<int64_t>(), c->b[13].as<int32_t>(), (int64_t)VMX_HEAD_THRESH, d_order, d_range, d_cnt);
+        VMX_HIP(hipMemsetAsync(d_redo_cnt, 0, 16, c->stream)); VMX_HIP(hipMemsetAsync(d_redo_bytes, 0, 8, c->stream));
         hipLaunchKernelGGL(k_gapfill_fill_ns, dim3(grid_for(c, n, 16)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[4].as<uint8_t>(), c->b[6].as<vmx_dp_prob>(), (int)n,
-                           sc->match, sc->mismatch, sc->o1, sc->e1, sc->o2, sc->e2, c->b[7].as<uint8_t>(), c->b[8].as<int32_t>(), d_score, d_order, d_cnt, d_redo_list, d_redo_cnt, 0);
-        VMX_TRY(download(redo, d_redo_cnt, 1, c->stream));          // entries queued by the first launch (read before the second launch moves its head)
+                           sc->match, sc->mismatch, sc->o1, sc->e1, sc->o2, sc->e2, c->b[7].as<uint8_t>(), c->b[8].as<int32_t>(), d_score, d_order, d_range, d_cnt, d_redo_list, d_redo_cnt, 0, ad_pct,
+                           (uint8_t*)nullptr, d_redo_bytes);
+        unsigned long long redo_bytes = 0;
+        VMX_TRY(download(redo, d_redo_cnt, 1, c->stream));          // entries queued by the first launch and the full-matrix traceback space they need
+        VMX_TRY(download(&redo_bytes, d_redo_bytes, 1, c->stream));
+        VMX_HIP(hipStreamSynchronize(c->stream));
+        VMX_TRY(c->b[16].reserve((size_t)redo_bytes + 64));
         hipLaunchKernelGGL(k_gapfill_fill_ns, dim3(grid_for(c, (n + 3) / 4, 4)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[4].as<uint8_t>(), c->b[6].as<vmx_dp_prob>(), (int)n,
-                           sc->match, sc->mismatch, sc->o1, sc->e1, sc->o2, sc->e2, c->b[7].as<uint8_t>(), c->b[8].as<int32_t>(), d_score, d_order, d_cnt, d_redo_list, d_redo_cnt, 1);
+                           sc->match, sc->mismatch, sc->o1, sc->e1, sc->o2, sc->e2, c->b[7].as<uint8_t>(), c->b[8].as<int32_t>(), d_score, d_order, d_range, d_cnt, d_redo_list, d_redo_cnt, 1, ad_pct,
+                           c->b[16].as<uint8_t>(), d_redo_bytes);
         hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[4].as<uint8_t>(),
-                           c->b[6].as<vmx_dp_prob>(), (int)n, eqx, c->b[7].as<uint8_t>(), c->b[9].as<uint32_t>(), c->b[10].as<char>(), d_len, d_score);
+                           c->b[6].as<vmx_dp_prob>(), (int)n, eqx, c->b[7].as<uint8_t>(), c->b[9].as<uint32_t>(), c->b[10].as<char>(), d_len, d_score, c->b[16].as<uint8_t>());
     }
     std::vector<char> hc((size_t)cig + 16); std::vector<int32_t> hl((size_t)n);
     *scores = host_alloc<int32_t>((size_t)n);
@@ -296,11 +306,18 @@ static int k_cigar_batch_impl(vm_ctx* c, const vm_score* sc, int eqx, int schedu
         if (band_flag) { *band_flag = host_alloc<int32_t>((size_t)n); memcpy(*band_flag, *scores, sizeof(int32_t) * (size_t)n); }
         int64_t nb = 0, eligible = 0;
         for (int64_t i = 0; i < n; ++i) {
-            nb += (*scores)[i] == 1;
-            eligible += probs[i].tl > 0 && probs[i].ql > 0 && VMX_DP16X4_OK(probs[i].tl, probs[i].ql) && VMX_BAND_STEPS(probs[i].tl, probs[i].ql) > 0;
+            const bool small = probs[i].tl > 0 && probs[i].ql > 0 && VMX_DP16X4_OK(probs[i].tl, probs[i].ql);
+            if (!small && band_flag) (*band_flag)[i] = 0;         // (the larger forms leave their score there)
+            nb += small && (*scores)[i] > VMX_AD_FLAG;
+            eligible += probs[i].tl > 0 && probs[i].ql > 0 && VMX_DP16X4_OK(probs[i].tl, probs[i].ql) &&
+                        vmx_ad_ns(probs[i].tl, probs[i].ql, sc->match, sc->o1, sc->e1, sc->o2, sc->e2, ad_pct & 0xffff, (ad_pct >> 16) & 0xffff) > 0;
             (*scores)[i] = 0;
         }
-        if (stats) { stats[0] = eligible; stats[1] = nb; stats[2] = redo[0]; stats[3] = n - eligible; }
+        if (stats) {
+            int64_t small = 0;
+            for (int64_t i = 0; i < n; ++i) small += probs[i].tl > 0 && probs[i].ql > 0 && VMX_DP16X4_OK(probs[i].tl, probs[i].ql);
+            stats[0] = eligible; stats[1] = nb; stats[2] = redo[0]; stats[3] = n - small;
+        }
     } else if (band_flag) *band_flag = nullptr;
     *cigar_off = host_alloc<int64_t>((size_t)n + 1);
     int64_t tot = 0;

@@ -111,11 +111,19 @@ __global__ void k_extend(const uint8_t* tcodes, const int64_t* t_off, const uint
 __global__ void k_gapfill_fill(const uint8_t* tcodes, const uint8_t* qcodes, const vmx_dp_prob* probs, int n_prob, int match,
                                int mismatch, int o1, int e1, int o2, int e2, uint8_t* tb_pool, int32_t* bnd_pool, int32_t* out_score,
                                const int32_t* order, int32_t* counter);
-__global__ void k_gapfill_fill_ns(const uint8_t* tcodes, const uint8_t* qcodes, const vmx_dp_prob* probs, int n_prob, int match,
+__global__ void k_gapfill_fill_ns(const uint8_t* tcodes, const uint8_t* qcodes, vmx_dp_prob* probs, int n_prob, int match,
                                   int mismatch, int o1, int e1, int o2, int e2, uint8_t* tb_pool, int32_t* bnd_pool, int32_t* out_score,
-                                  const int32_t* order, int32_t* counter, int32_t* redo_list, int32_t* redo_cnt, int redo_pass);
+                                  const int32_t* order, const int32_t* range, int32_t* counter, int32_t* redo_list, int32_t* redo_cnt, int redo_pass, int ad_pct,
+                                  uint8_t* redo_pool, unsigned long long* redo_bytes);
+// band-width rule of the anti-diagonal gap fill (vmx_ad_ns): pct | pct_min << 16; tuning knobs VMX_AD_PCT / VMX_AD_PCT_MIN
+static inline int vmx_ad_pct_env() {
+    int pct = VMX_AD_PCT_DEFAULT, pmin = VMX_AD_PCT_MIN_DEFAULT;
+    if (const char* e = getenv("VMX_AD_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 60000) pct = v; }
+    if (const char* e = getenv("VMX_AD_PCT_MIN")) { const int v = atoi(e); if (v >= 0 && v <= 60000) pmin = v; }
+    return pct | (pmin << 16);
+}
 __global__ void k_gapfill_trace(const uint8_t* tcodes, const uint8_t* qcodes, const vmx_dp_prob* probs, int n_prob, int eqx,
-                                const uint8_t* tb_pool, uint32_t* run_pool, char* cig_pool, int32_t* cig_len, const int32_t* band_flag);
+                                const uint8_t* tb_pool, uint32_t* run_pool, char* cig_pool, int32_t* cig_len, const int32_t* band_flag, const uint8_t* redo_pool);
 __global__ void k_flip_sort(const int64_t* rows, const int64_t* aoff, const int64_t* readlens, int n_reads, uint64_t* key_pool,
                             const int64_t* key_off, vmx_anchor* sorted, int32_t* need_reverse);
 __global__ void k_chain_global(const vmx_anchor* anchors, const int64_t* aoff, const int32_t* rlist, int nlist, int lds_cap,

@@ -99,22 +99,69 @@ struct vmx_lseed_args {
 #endif
 #define VMX_DP16X4_OK(tl, ql) ((tl) + (ql) <= VMX_DP16X4_MAX)
 #define VMX_X4_W(ql) ((((ql) + 31) + 15) & ~15)
-// banded form of the four-per-wave fill: a stripe of rows only runs the columns within VMX_BAND_W of the matrix's main line
-// (column ~ row * ql / tl); the result is kept only when every path that leaves the band is provably worse (k_dp.hip), else the problem
-// is filled again in full. Width of a banded stripe in steps (0: banding would not save a 16-step block, the problem runs in full):
-#ifndef VMX_BAND_W
+// anti-diagonal band form of the small-problem fill (vmx_dp_ad.h): EIGHT problems per wavefront, one per 16-lane DPP row and 16-bit register
+// half, each on a fixed band of 32 * ns diagonals d = j - i in [dlo, dlo + 32 ns) (ns = 1 .. VMX_AD_NS_MAX diagonal pairs per lane). dlo is
+// even, so that all problems of a wave compute the same diagonal parity on the same step, and the band's margins below min(0, ql - tl) and
+// above max(0, ql - tl) are as equal as that allows. vmx_ad_geom returns g: a path that leaves the band holds at least g inserted AND g deleted
+// bases (0: the band cannot hold both corners). The result is kept only when vmx_ad_proven (vmx_dp_ad.h) shows every such path is worse.
+#define VMX_AD_NS_MAX 4
+__host__ __device__ static inline int vmx_ad_geom(int tl, int ql, int ns, int* dlo_out) {
+    const int dl = ql - tl, lo = dl < 0 ? dl : 0, hi = dl > 0 ? dl : 0;
+    const int slack = 32 * ns - (hi - lo + 1);
+    if (slack < 0) return 0;
+    int mb = slack / 2, dlo = lo - mb;
+    if (dlo & 1) {
+        if (mb + 1 <= slack) { ++mb; --dlo; }
+        else if (mb >= 1) { --mb; ++dlo; }
+        else return 0;
+    }
+    *dlo_out = dlo;
+    const int ma = slack - mb;
+    return (mb < ma ? mb : ma) + 1;
+}
+// what a path pays at least for leaving a band of margin g: g matches fewer and two gaps of g bases
+__host__ __device__ static inline long long vmx_ad_margin(int g, int match, int o1, int e1, int o2, int e2) {
+    const long long c1 = o1 + (long long)g * e1, c2 = o2 + (long long)g * e2;
+    return (long long)match * g + 2 * (c1 < c2 ? c1 : c2);
+}
+// band width (diagonal pairs per lane) a problem is tried with: the narrowest whose margin is at least pct % of min(tl, ql) (a 10 %-error
+// read loses ~0.7 per base against the all-match bound), the widest one if that still reaches pct_min %, 0 = not worth trying / impossible
+__host__ __device__ static inline int vmx_ad_ns(int tl, int ql, int match, int o1, int e1, int o2, int e2, int pct, int pct_min) {
+    if (tl <= 0 || ql <= 0) return 0;
+    const int mn = tl < ql ? tl : ql;
+    int dlo, g = 0;
+    for (int ns = 1; ns <= VMX_AD_NS_MAX; ++ns) {
+        g = vmx_ad_geom(tl, ql, ns, &dlo);
+        if (g >= 1 && (g > mn || vmx_ad_margin(g, match, o1, e1, o2, e2) * 100 >= (long long)pct * mn)) return ns;
+    }
+    return (g >= 1 && vmx_ad_margin(g, match, o1, e1, o2, e2) * 100 >= (long long)pct_min * mn) ? VMX_AD_NS_MAX : 0;
+}
+#define VMX_AD_PCT_DEFAULT 100
+#define VMX_AD_PCT_MIN_DEFAULT 65
+#define VMX_AD_FLAG 16                 /* layout flag of a problem kept in the anti-diagonal layout: VMX_AD_FLAG + ns */
+#define VMX_PK_FLAG 1                  /* layout flag of a small-class problem the second launch ran on the whole wave (packed two-rows-per-lane layout) */
 #ifdef VMX_EMU
-#define VMX_BAND_W 6
+#define VMX_REDO_PK(tl, ql) ((tl) > 0 && (ql) > 0 && VMX_DP16X4_OK(tl, ql) && (tl) + (ql) >= 120)
 #else
-#define VMX_BAND_W 62      // 2 * 62 + 3 + 32 + 31 = 190 -> 192 steps per stripe for tl ~ ql. Fill kernel ms per batch measured for 40 / 48 / 56 / 64 / 72 (failed
-                           // problems then still re-run on the spot): 31.6 / 25.9 / 23.4 / 22.7 / 22.6 — narrow bands fail the proof more often (64: 2.8 % fail)
+#define VMX_REDO_PK(tl, ql) ((tl) > 0 && (ql) > 0 && VMX_DP16X4_OK(tl, ql) && (tl) + (ql) >= 640)
 #endif
-#endif
-#define VMX_BAND_NC(tl, ql) (2 * VMX_BAND_W + 3 + (32 * (ql) + (tl) - 1) / (tl))          /* columns a banded stripe runs to the end */
-#define VMX_BAND_STEPS(tl, ql) ((((VMX_BAND_NC(tl, ql) + 31) + 15) & ~15) + 16 <= VMX_X4_W(ql) ? ((VMX_BAND_NC(tl, ql) + 31) + 15) & ~15 : 0)
-#define VMX_BAND_JLO(tl, ql, s) ((int)((unsigned)((s) * 32 + 1) * (unsigned)(ql) / (unsigned)(tl)) - VMX_BAND_W < 1 ? 1 : (int)((unsigned)((s) * 32 + 1) * (unsigned)(ql) / (unsigned)(tl)) - VMX_BAND_W)   /* tl + ql <= 3072: the product fits 32 bits */
-#define VMX_TB_BYTES(tl, ql) (((tl) > 0 && (ql) > 0) ? (VMX_DP16X4_OK(tl, ql) ? (int64_t)(((tl) + 31) / 32) * VMX_X4_W(ql) * 32 : \
-                              VMX_DP16_OK(tl, ql) ? (int64_t)(((tl) + 127) / 128) * ((ql) + 127) * 128 : (int64_t)(((tl) + 63) / 64) * ((ql) + 63) * 64) : 0)
+#define VMX_PK_TB_BYTES(tl, ql) ((int64_t)(((tl) + 127) / 128) * ((ql) + 127) * 128)
+#define VMX_AD_TB_BYTES(tl, ql) ((int64_t)((tl) + (ql)) * 64)      /* one 4-byte slot per lane and anti-diagonal */
+#define VMX_X4_TB_BYTES(tl, ql) ((int64_t)(((tl) + 31) / 32) * VMX_X4_W(ql) * 32)
+// traceback bytes of a problem. VMX_TB_BYTES: the full-matrix forms (k_gapfill_fill). VMX_TB_BYTES_NS: the batched path (k_gapfill_fill_ns), whose
+// small problems get the anti-diagonal layout's (tl + ql) * 64 bytes only; the few that have to be filled again in full take
+// VMX_REDO_TB_BYTES from a second pool, handed out with an atomic counter when the first launch queues them (vmx_dp_prob.tb_off < 0:
+// offset -tb_off - 1 into that pool).
+#define VMX_TB_BYTES(tl, ql) (((tl) > 0 && (ql) > 0) ? (VMX_DP16X4_OK(tl, ql) ? VMX_X4_TB_BYTES(tl, ql) : \
+                              VMX_DP16_OK(tl, ql) ? VMX_PK_TB_BYTES(tl, ql) : (int64_t)(((tl) + 63) / 64) * ((ql) + 63) * 64) : 0)
+#define VMX_TB_BYTES_NS(tl, ql) (((tl) > 0 && (ql) > 0 && VMX_DP16X4_OK(tl, ql)) ? VMX_AD_TB_BYTES(tl, ql) : VMX_TB_BYTES(tl, ql))
+#define VMX_REDO_TB_BYTES(tl, ql) (VMX_REDO_PK(tl, ql) ? VMX_PK_TB_BYTES(tl, ql) : VMX_X4_TB_BYTES(tl, ql))
+// (integer arithmetic: a select between the two pool pointers crashes this compiler's optimizer)
+__device__ __forceinline__ uint8_t* vmx_tb_ptr(const uint8_t* tb_pool, const uint8_t* redo_pool, int64_t off) {
+    const unsigned long long base = off >= 0 ? (unsigned long long)tb_pool : (unsigned long long)redo_pool;
+    return (uint8_t*)(base + (unsigned long long)(off >= 0 ? off : -off - 1));
+}
+#define VMX_HEAD_THRESH (((int64_t)1 << 18) - 1)   /* traceback bytes above which a gap-fill problem is taken from the queue alone (k_size_order thresh): ~450 x 450 and up */
 #define VMX_TB_CHUNK ((int64_t)12 << 30)   // gap fill: traceback bytes held at a time; a batch needing more runs fill + trace chunk by chunk (12 GB: lets 4+ batches in flight fit in 288 GB)
 #ifdef VMX_EMU
 #define VMX_MAX_BATCH_BASES 20000          // emulator build: small limits so that the CPU tests split a batch
