@@ -65,6 +65,9 @@ void vm_ctx_destroy(vm_ctx*);
  * latency-bound kernels to fill the device; with several in flight they are launched narrower (the local seeding kernel at 3 / 2 / 1
  * workgroups per CU for 1 / 2 / >= 3 contexts) so that another batch's VALU-bound gap-fill kernel can be resident beside them. */
 int vm_ctx_set_inflight(vm_ctx*, int n_contexts);
+/* on != 0: the context's host thread sleeps while it waits for the GPU inside vm_align_batch instead of spinning (default: spin, lowest
+ * latency). For processes whose other threads need the cores — vacmap_amd.driver's SAM emitters under a CPU quota. */
+int vm_ctx_set_blocking_sync(vm_ctx*, int on);
 int vm_device_count(void);
 
 /* build the minimizer index of a FASTA file / in-memory contigs ON THE GPU and keep it resident in HBM
@@ -254,6 +257,8 @@ int vm_sam_emit(const vm_index*, const vm_sam_opts*, int64_t n_reads, const char
  * text after the first blank, else tab). Returns the record count, 0 at the end of the input, or a negative vm_status. */
 /* entries idx[0..n) of a blob copied back to back (out may be NULL to size it): returns the byte count, out_off[n + 1] */
 int64_t vm_blob_gather(const char* blob, const int64_t* off, const int64_t* idx, int64_t n, char* out, int64_t* out_off);
+/* the same over several blobs: output entry j = entry idx[j] of blob part[j]; returns the bytes written (out must hold them) */
+int64_t vm_blob_gather_parts(const char* const* blobs, const int64_t* const* offs, const int32_t* part, const int64_t* idx, int64_t n, char* out);
 typedef struct vm_fastx vm_fastx;
 int vm_fastx_open(const char* path, vm_fastx** out);
 void vm_fastx_close(vm_fastx*);

@@ -281,8 +281,9 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
             if (lane == 0) { S[i] = max_scores; P[i] = pre_index; if (rmode) { FP[i] = fp_i; PP[i] = pp_i; } }
             if (max_scores > g_max_scores) { g_max_scores = max_scores; g_max_index = i; }
             pS = max_scores; pq = qi; pls = lsi; pr = ri;
-            __syncthreads();
+            if constexpr (IN_LDS && !RMODE) vmx_wave_lds_fence(); else __syncthreads();     // (mode R: FP / PP go through HBM)
         }
+        __syncthreads();
         if (!bailed) {
             for (int k = testspace_en; k < n; ++k) {
                 const int loc = vmx_insertpoint_score_wave(S, S[k], k, SA, lane);

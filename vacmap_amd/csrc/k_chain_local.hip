@@ -172,8 +172,9 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
             if (lane == 0) { S[i] = max_scores; P[i] = pre_index; if (scar) { FP[i] = fp_i; PP[i] = pp_i; } }
             if (max_scores > g_max_scores) { g_max_scores = max_scores; g_max_index = i; }
             pS = max_scores; pq = qi; pls = li | (si << 16); pr = ri;
-            __syncthreads();
+            if constexpr (IN_LDS && VAR != 2) vmx_wave_lds_fence(); else __syncthreads();     // (scar: FP / PP go through HBM)
         }
+        __syncthreads();       // (P, written through the loop without waiting, is read back by the traceback)
         // traceback with overlap trimming :27508-27526 (serial, lane 0)
         if (lane == 0) {
             if (need_fast) { out_len[rd] = 0; out_score[rd] = 0; status[rd] = VM_READ_FASTPATH_DEV; }

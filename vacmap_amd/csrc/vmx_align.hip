@@ -86,7 +86,7 @@ static int ext_gather_round(vm_ctx* c, vmx_batch_bufs& B, const vm_index_view& i
     // scans over the full capacity would be wasteful: the count lives on the device, so read it (4 bytes) — also needed to size the DP launches
     int32_t cnt = 0;
     VMX_TRY(download(&cnt, B.rcount.p, 1, c->stream));
-    VMX_HIP(hipStreamSynchronize(c->stream));
+    VMX_HIP(vmx_stream_sync(c));
     if (cnt > round_cap) cnt = (int32_t)round_cap;
     VMX_TRY(dev_scan(c, B, B.tl.as<int64_t>(), B.toff.as<int64_t>(), (int64_t)cnt));
     VMX_TRY(dev_scan(c, B, B.ql.as<int64_t>(), B.qoff.as<int64_t>(), (int64_t)cnt));
@@ -123,7 +123,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, B.nanc64.as<int64_t>(), B.aoff.as<int64_t>(), n, 0);
     std::vector<int64_t> h_aoff((size_t)n + 1);
     VMX_TRY(download(h_aoff.data(), B.aoff.p, (size_t)n + 1, c->stream));
-    VMX_HIP(hipStreamSynchronize(c->stream));
+    VMX_HIP(vmx_stream_sync(c));
     const int64_t tot = h_aoff[n];
     st.n_anchors = tot;
     VMX_TRY(B.rows.reserve(32 * (size_t)(tot + 1)));
@@ -261,7 +261,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
                                    (void)hipMemcpyAsync(sa.data(), B.segA.p, sizeof(vmx_anchor) * (size_t)cA, hipMemcpyDeviceToHost, c->stream);
                                    (void)hipMemcpyAsync(st_.data(), B.st.p, 4 * (size_t)cS, hipMemcpyDeviceToHost, c->stream);
                                    (void)hipMemcpyAsync(en_.data(), B.en.p, 4 * (size_t)cS, hipMemcpyDeviceToHost, c->stream);
-                                   (void)hipStreamSynchronize(c->stream);
+                                   (void)vmx_stream_sync(c);
                                    trace->off.assign(1, 0);
                                    for (int64_t r = 0; r < n; ++r) {
                                        if (er[(size_t)r].active && er[(size_t)r].status == 0)
@@ -299,7 +299,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         int64_t totals[4];
         for (int i = 0; i < 4; ++i) VMX_TRY(download(&totals[i], B.dpoff[i].as<int64_t>() + cnt, 1, c->stream));
         int64_t tq[2]; VMX_TRY(download(&tq[0], B.toff.as<int64_t>() + cnt, 1, c->stream)); VMX_TRY(download(&tq[1], B.qoff.as<int64_t>() + cnt, 1, c->stream));
-        VMX_HIP(hipStreamSynchronize(c->stream));
+        VMX_HIP(vmx_stream_sync(c));
         std::vector<int32_t> cuts(1, 0);                         // chunk c = problems [cuts[c], cuts[c+1])
         {
             int64_t base = 0;
@@ -338,7 +338,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
                 // sizing sync #4: full-matrix traceback space of the problems the first launch queued for the second one (a few per cent of them)
                 unsigned long long redo_bytes = 0; int32_t n_redo = 0;
                 VMX_TRY(download(&redo_bytes, d_redo_bytes, 1, c->stream)); VMX_TRY(download(&n_redo, d_redo_cnt, 1, c->stream));
-                VMX_HIP(hipStreamSynchronize(c->stream));
+                VMX_HIP(vmx_stream_sync(c));
                 VMX_TRY(B.tbredo.reserve((size_t)redo_bytes + 64));
                 st.dp_redo_tb_bytes += (int64_t)redo_bytes; st.n_dp_redo += n_redo; st.dp_cells += (int64_t)redo_bytes;
                 // second launch: the problems whose band was not proven (a few per cent), in full: the larger ones on a whole wave, the others four per wave
@@ -420,7 +420,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     int32_t n_full = 0, n_t2 = 0, n_t1 = 0;
     if (st.n_ed_problems) { VMX_TRY(download(&n_full, B.qrange.as<int32_t>() + 8, 1, c->stream)); VMX_TRY(download(&n_t2, B.qrange.as<int32_t>() + 9, 1, c->stream));
                             VMX_TRY(download(&n_t1, B.qrange.as<int32_t>() + 10, 1, c->stream)); }
-    VMX_HIP(hipStreamSynchronize(c->stream));
+    VMX_HIP(vmx_stream_sync(c));
     st.n_ed_full = n_full; st.n_ed_tier2 = n_t2; st.n_ed_tier1 = n_t1;
     if (oflow) { set_error("extend stage: a per-batch work pool overflowed"); return VM_ERR_OOM; }
     VMX_TRY(B.totals.reserve(sizeof(vm_record) * (size_t)(nr + 1))); VMX_TRY(B.dupd.reserve((size_t)nb + 64));
@@ -433,7 +433,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     std::vector<int64_t> h_gmax((size_t)n);
     VMX_TRY(download(h_gmax.data(), B.gmax.p, (size_t)n, c->stream));
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));
-    VMX_HIP(hipStreamSynchronize(c->stream));
+    VMX_HIP(vmx_stream_sync(c));
     VMX_HIP(hipGetLastError());
     for (int64_t r = 0; r < n; ++r) {
         int stt2 = er[r].status;
@@ -479,7 +479,7 @@ int vm_reads_upload(vm_ctx* c, int64_t n, const char* seqs, const int64_t* offse
     int rc = 0;
     if ((rc = upload(R->raw, seqs, (size_t)tot, c->stream)) < 0 || (rc = R->codes.reserve((size_t)tot + 64)) < 0 || (rc = upload(R->off, offsets, (size_t)n + 1, c->stream)) < 0) { delete R; return rc; }
     if (tot) LAUNCH1D(k_encode, tot, R->raw.as<char>(), R->codes.as<uint8_t>(), tot);
-    VMX_HIP(hipStreamSynchronize(c->stream));
+    VMX_HIP(vmx_stream_sync(c));
     R->raw.release();
     *out = R;
     return VM_OK;

@@ -107,6 +107,7 @@ void vm_ctx_destroy(vm_ctx* c) {
     for (int i = 0; i < 48; ++i) (void)hipEventDestroy(c->gev[i]);
     for (int i = 0; i < 4; ++i) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); (void)hipEventDestroy(c->join_ev[i]); }
     (void)hipEventDestroy(c->fork_ev);
+    if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -115,6 +116,18 @@ int vm_ctx_set_inflight(vm_ctx* c, int n_contexts) {
     if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
     if (n_contexts < 1) { set_error("n_contexts must be >= 1"); return VM_ERR_ARG; }
     c->inflight = n_contexts;
+    return VM_OK;
+}
+
+int vm_ctx_set_blocking_sync(vm_ctx* c, int on) {
+    if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
+#ifndef VMX_EMU
+    VMX_HIP(hipSetDevice(c->device));
+    if (on && !c->sync_ev) VMX_HIP(hipEventCreateWithFlags(&c->sync_ev, hipEventBlockingSync | hipEventDisableTiming));
+    if (!on && c->sync_ev) { (void)hipEventDestroy(c->sync_ev); c->sync_ev = nullptr; }
+#else
+    (void)on;
+#endif
     return VM_OK;
 }
 

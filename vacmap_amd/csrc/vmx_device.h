@@ -74,6 +74,14 @@ __device__ __forceinline__ unsigned vmx_pk_bytes(unsigned b) { return (b & 0xffu
 #else
 __device__ __forceinline__ unsigned vmx_pk_bytes(unsigned b) { return __builtin_amdgcn_perm(b, b, 0x0c0c0200u); }
 #endif
+// single-wavefront workgroups: LDS operations of one wave execute in order, so a value one lane stores is visible to the other lanes' later
+// loads without a barrier; what is needed is only that the compiler keeps the order. (A __syncthreads() here also drains the wave's
+// outstanding global stores — an HBM write acknowledgement per anchor in the chain kernels.) The emulator's lanes are fibers: keep the rendezvous.
+#ifdef VMX_EMU
+__device__ __forceinline__ void vmx_wave_lds_fence() { __syncthreads(); }
+#else
+__device__ __forceinline__ void vmx_wave_lds_fence() { asm volatile("" ::: "memory"); }
+#endif
 __device__ __forceinline__ unsigned vmx_bfi(unsigned m, unsigned a, unsigned b) { return (m & a) | (~m & b); }     // v_bfi_b32
 // value known to be identical in every lane: hand it to the compiler as a scalar (v_readfirstlane_b32)
 #ifdef VMX_EMU

@@ -65,6 +65,7 @@ struct vm_ctx {
     vmx::DevBuf b[VMX_NBUF];     // scratch buffers reused by the entry points (grow-only)
     int num_cu = 256;
     int inflight = 1;                            // contexts sharing the GPU (vm_ctx_set_inflight)
+    hipEvent_t sync_ev = nullptr;                // blocking-sync event (vm_ctx_set_blocking_sync): the host thread sleeps in its waits instead of spinning
     hipEvent_t ev[24];
     hipEvent_t gev[48];                          // gap-fill chunk events: [redo][chunk 0..7][before fill, after fill, after trace]
     int n_gev[2] = {0, 0};                        // chunks recorded by the last batch per pass
@@ -75,6 +76,16 @@ struct vm_ctx {
     struct vmx_extend_bufs* ebufs = nullptr;
     struct vmx_batch_bufs* bbufs = nullptr;
 };
+
+// wait for the context's main stream. Default: hipStreamSynchronize (the runtime spins: lowest latency, one busy core per waiting thread).
+// With vm_ctx_set_blocking_sync the thread sleeps on an interrupt instead — for callers whose other threads need the cores (the driver's
+// SAM emitters under a CPU quota: spinning waiters push the process over its quota and the whole process, aligners included, is throttled).
+static inline hipError_t vmx_stream_sync(vm_ctx* c) {
+#ifndef VMX_EMU
+    if (c->sync_ev) { const hipError_t e = hipEventRecord(c->sync_ev, c->stream); if (e != hipSuccess) return e; return hipEventSynchronize(c->sync_ev); }
+#endif
+    return hipStreamSynchronize(c->stream);
+}
 
 // fork/join of independent launches over the context's side streams (all ordered after / before the main stream)
 struct vmx_fork {

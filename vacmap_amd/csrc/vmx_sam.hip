@@ -16,6 +16,9 @@
 #include <thread>
 #include <vector>
 #include <zlib.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <errno.h>
 
 using namespace vmx;
 
@@ -34,7 +37,7 @@ namespace {
 
 struct Raise {};        // what is an IndexError in the Python counterpart
 
-struct Rec { int contig; char strand; int mapq; int64_t q_st, q_en, r_st, r_en; std::string cigar; };
+struct Rec { int contig; char strand; int mapq; int64_t q_st, q_en, r_st, r_en; const char* cigar; int64_t cigar_len; };     // cigar: a view into the batch's blob
 
 struct Ops { std::vector<int64_t> n; std::string op; };     // merged CIGAR: run lengths and operators
 
@@ -49,7 +52,13 @@ static void merge_cigar(const char* c, int64_t len, Ops& o) {
         num = 0;
     }
 }
-static void put_int(std::string& s, int64_t v) { char b[24]; int n = snprintf(b, sizeof b, "%lld", (long long)v); s.append(b, (size_t)n); }
+static inline void put_int(std::string& s, int64_t v) {      // (a CIGAR holds thousands of numbers: no snprintf)
+    char b[24]; int n = 24;
+    unsigned long long u = v < 0 ? 0ULL - (unsigned long long)v : (unsigned long long)v;
+    do { b[--n] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) b[--n] = '-';
+    s.append(b + n, (size_t)(24 - n));
+}
 static void join_ops(const Ops& o, std::string& s) { s.clear(); for (size_t i = 0; i < o.op.size(); ++i) { put_int(s, o.n[i]); s.push_back(o.op[i]); } }
 static inline char up(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
 static inline char lo(char c) { return (c >= 'A' && c <= 'Z') ? (char)(c + 32) : c; }
@@ -159,7 +168,7 @@ static int emit_read(const vm_index* mi, const std::string& bases, const vm_sam_
         for (int64_t i = 0; i < nr; ++i) {
             Rec& r = S.recs[(size_t)i];
             r.contig = rr[i].contig; r.strand = rr[i].strand == 1 ? '+' : '-'; r.mapq = rr[i].mapq; r.q_st = rr[i].q_st; r.q_en = rr[i].q_en; r.r_st = rr[i].r_st; r.r_en = rr[i].r_en;
-            r.cigar.assign(blob + rr[i].cigar_off, (size_t)rr[i].cigar_len);
+            r.cigar = blob + rr[i].cigar_off; r.cigar_len = rr[i].cigar_len;
         }
         if (o->markunbalancetra) reassign_mapq(S.recs);
         // sort by query span ascending (stable), then reverse: longest first, later ones first among equals (:20855-20856)
@@ -179,7 +188,7 @@ static int emit_read(const vm_index* mi, const std::string& bases, const vm_sam_
             int64_t ta = r.r_st < 0 ? 0 : (r.r_st > clen ? clen : r.r_st), tb = r.r_en < 0 ? 0 : (r.r_en > clen ? clen : r.r_en);     // Python slice semantics of contig[a:b]
             if (tb < ta) tb = ta;
             const char* t = bases.data() + mi->offsets[(size_t)r.contig] + ta; const int64_t tl = tb - ta;
-            merge_cigar(r.cigar.data(), (int64_t)r.cigar.size(), S.ops[i]);
+            merge_cigar(r.cigar, r.cigar_len, S.ops[i]);
             join_ops(S.ops[i], S.cig[i]);
             if (!o->md) S.nm[i] = nm_from_cigar(S.ops[i], qs, qlen, t, tl);
             else {
@@ -328,24 +337,59 @@ int64_t vm_blob_gather(const char* blob, const int64_t* off, const int64_t* idx,
     return w;
 }
 
+// the same over several blobs: entry j of the output is entry idx[j] of blob part[j] (the writer's batch texts -> input order, without
+// concatenating the batches first). out must hold the sum of the lengths; returns that sum.
+int64_t vm_blob_gather_parts(const char* const* blobs, const int64_t* const* offs, const int32_t* part, const int64_t* idx, int64_t n, char* out) {
+    int64_t w = 0;
+    for (int64_t j = 0; j < n; ++j) {
+        const int64_t* off = offs[part[j]];
+        const int64_t a = off[idx[j]], b = off[idx[j] + 1];
+        if (b > a) memcpy(out + w, blobs[part[j]] + a, (size_t)(b - a));
+        w += b - a;
+    }
+    return w;
+}
+
 // ------------------------------------------------------------------------------------------------ FASTA / FASTQ(.gz) reader
-struct vm_fastx { gzFile f; std::string buf; size_t pos = 0; bool eof = false; };
+// Plain files are read with read(2) straight into the line buffer (gzread's transparent mode costs a copy); gzip members go through zlib.
+// The output blobs grow by realloc (large blocks move by remapping, not by copying) and are handed to the caller as they are.
+struct vm_fastx { gzFile f = nullptr; int fd = -1; char* buf = nullptr; size_t cap = 0, len = 0, pos = 0; bool eof = false; size_t hint = 0; };
+
+struct Blob {
+    char* p = nullptr; size_t n = 0, cap = 0;
+    void need(size_t extra) {
+        if (n + extra + 1 <= cap) return;
+        size_t c = cap ? cap : (size_t)1 << 16;
+        while (c < n + extra + 1) c += c / 2 + 4096;
+        char* q = (char*)realloc(p, c);
+        if (!q) throw std::bad_alloc();
+        p = q; cap = c;
+    }
+    void append(const char* s, size_t k) { need(k); memcpy(p + n, s, k); n += k; }
+    char* release() { need(0); p[n] = 0; char* r = p; p = nullptr; n = cap = 0; return r; }
+    ~Blob() { free(p); }
+};
 
 static bool fx_fill(vm_fastx* x) {
     if (x->eof) return false;
-    if (x->pos > 0) { x->buf.erase(0, x->pos); x->pos = 0; }
-    const size_t old = x->buf.size(), want = (size_t)8 << 20;
-    x->buf.resize(old + want);
-    const int n = gzread(x->f, &x->buf[old], (unsigned)want);
-    x->buf.resize(old + (n > 0 ? (size_t)n : 0));
-    if (n <= 0) x->eof = true;
+    if (x->pos > 0) { memmove(x->buf, x->buf + x->pos, x->len - x->pos); x->len -= x->pos; x->pos = 0; }
+    const size_t want = (size_t)8 << 20;
+    if (x->len + want > x->cap) {
+        size_t c = x->cap ? x->cap : 2 * want; while (c < x->len + want) c *= 2;
+        char* q = (char*)realloc(x->buf, c); if (!q) throw std::bad_alloc();
+        x->buf = q; x->cap = c;
+    }
+    long n;
+    if (x->f) n = gzread(x->f, x->buf + x->len, (unsigned)want);
+    else { do { n = (long)read(x->fd, x->buf + x->len, want); } while (n < 0 && errno == EINTR); }
+    if (n > 0) x->len += (size_t)n; else x->eof = true;
     return n > 0;
 }
 // next line as a VIEW into the read buffer (valid until the next call), without its terminator; false at end of input.
 // peek = true leaves the line unconsumed.
 static bool fx_line(vm_fastx* x, const char*& p, size_t& len, bool peek = false) {
     while (true) {
-        const char* b = x->buf.data() + x->pos; const size_t n = x->buf.size() - x->pos;
+        const char* b = x->buf + x->pos; const size_t n = x->len - x->pos;
         const char* nl = n ? (const char*)memchr(b, '\n', n) : nullptr;
         size_t l, adv;
         if (nl) { l = (size_t)(nl - b); adv = l + 1; }
@@ -356,22 +400,29 @@ static bool fx_line(vm_fastx* x, const char*& p, size_t& len, bool peek = false)
         return true;
     }
 }
-static inline void fx_append_upper(std::string& dst, const char* p, size_t n) {
-    const size_t o = dst.size(); dst.resize(o + n);
-    char* d = &dst[o];
-    for (size_t i = 0; i < n; ++i) { const char c = p[i]; d[i] = (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
+static inline void fx_append_upper(Blob& dst, const char* p, size_t n) {
+    dst.need(n);
+    char* d = dst.p + dst.n;
+    for (size_t i = 0; i < n; ++i) { const unsigned char c = (unsigned char)p[i]; d[i] = (char)(c - (((unsigned)(c - 'a') < 26u) << 5)); }      // (branch-free: vectorises)
+    dst.n += n;
 }
 
 int vm_fastx_open(const char* path, vm_fastx** out) {
     *out = nullptr;
-    gzFile f = gzopen(path, "rb");                       // reads plain files too
-    if (!f) { set_error(std::string("cannot open ") + path); return VM_ERR_IO; }
-    gzbuffer(f, 1 << 20);
-    vm_fastx* x = new vm_fastx(); x->f = f;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { set_error(std::string("cannot open ") + path); return VM_ERR_IO; }
+    unsigned char magic[2] = {0, 0};
+    const long got = (long)pread(fd, magic, 2, 0);
+    vm_fastx* x = new vm_fastx();
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        x->f = gzdopen(fd, "rb");
+        if (!x->f) { close(fd); delete x; set_error(std::string("cannot open ") + path); return VM_ERR_IO; }
+        gzbuffer(x->f, 1 << 20);
+    } else x->fd = fd;
     *out = x;
     return VM_OK;
 }
-void vm_fastx_close(vm_fastx* x) { if (!x) return; gzclose(x->f); delete x; }
+void vm_fastx_close(vm_fastx* x) { if (!x) return; if (x->f) gzclose(x->f); else if (x->fd >= 0) close(x->fd); free(x->buf); delete x; }
 
 // up to max_reads records (and at most max_bases bases) appended as blobs: names, upper-cased sequences, qualities (empty for FASTA),
 // comments (the header text after the first blank or tab). Returns the number of records read (0 at end of input) or a negative status.
@@ -379,9 +430,10 @@ void vm_fastx_close(vm_fastx* x) { if (!x) return; gzclose(x->f); delete x; }
 int64_t vm_fastx_read(vm_fastx* x, int64_t max_reads, int64_t max_bases, char** names, int64_t** name_off, char** seqs, int64_t** seq_off, char** quals, int64_t** qual_off,
                       char** comments, int64_t** com_off) {
     try {
-        std::string nb, sb, qb, cb; std::vector<int64_t> no(1, 0), so(1, 0), qo(1, 0), co(1, 0);
+        Blob nb, sb, qb, cb; std::vector<int64_t> no(1, 0), so(1, 0), qo(1, 0), co(1, 0);
+        if (x->hint) { sb.need(x->hint); qb.need(x->hint); }          // the previous call's size: one allocation instead of a growth series
         int64_t n = 0; const char* p; size_t len;
-        while (n < max_reads && (int64_t)sb.size() < max_bases) {
+        while (n < max_reads && (int64_t)sb.n < max_bases) {
             if (!fx_line(x, p, len)) break;
             if (len == 0) continue;
             if (p[0] != '>' && p[0] != '@') { set_error("not FASTA/FASTQ: " + std::string(p, len < 40 ? len : 40)); return VM_ERR_IO; }
@@ -404,12 +456,13 @@ int64_t vm_fastx_read(vm_fastx* x, int64_t max_reads, int64_t max_bases, char** 
                     fx_append_upper(sb, p + a, b - a);
                 }
             }
-            no.push_back((int64_t)nb.size()); so.push_back((int64_t)sb.size()); qo.push_back((int64_t)qb.size()); co.push_back((int64_t)cb.size());
+            no.push_back((int64_t)nb.n); so.push_back((int64_t)sb.n); qo.push_back((int64_t)qb.n); co.push_back((int64_t)cb.n);
             ++n;
         }
-        auto give = [](const std::string& s, char** p) { *p = (char*)malloc(s.size() + 1); memcpy(*p, s.data(), s.size()); (*p)[s.size()] = 0; };
+        if (sb.n > x->hint) x->hint = sb.n + sb.n / 16;
         auto giveo = [](const std::vector<int64_t>& v, int64_t** p) { *p = (int64_t*)malloc(8 * v.size()); memcpy(*p, v.data(), 8 * v.size()); };
-        give(nb, names); give(sb, seqs); give(qb, quals); give(cb, comments); giveo(no, name_off); giveo(so, seq_off); giveo(qo, qual_off); giveo(co, com_off);
+        *names = nb.release(); *seqs = sb.release(); *quals = qb.release(); *comments = cb.release();
+        giveo(no, name_off); giveo(so, seq_off); giveo(qo, qual_off); giveo(co, com_off);
         return n;
     }
     catch (const std::bad_alloc&) { set_error("vm_fastx_read: out of host memory"); return VM_ERR_OOM; }

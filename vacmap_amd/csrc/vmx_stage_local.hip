@@ -114,7 +114,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         A.dbg = nullptr;
         if (dbg_on) { VMX_TRY(L.dbg.reserve(64)); VMX_HIP(hipMemsetAsync(L.dbg.p, 0, 64, c->stream)); A.dbg = L.dbg.as<unsigned long long>(); }
         hipLaunchKernelGGL(k_local_seed, dim3((unsigned)G), dim3(TPB), 0, c->stream, A);
-        if (dbg_on) { unsigned long long h[8]; VMX_TRY(download(h, L.dbg.p, 8, c->stream)); VMX_HIP(hipStreamSynchronize(c->stream));
+        if (dbg_on) { unsigned long long h[8]; VMX_TRY(download(h, L.dbg.p, 8, c->stream)); VMX_HIP(vmx_stream_sync(c));
                       fprintf(stderr, "k_local_seed phase ticks (100MHz, summed over blocks): guide+windows %llu table %llu passA %llu passB+sort %llu merge %llu finalsort %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]); }
         return 0;
     };
@@ -125,7 +125,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     VMX_TRY(download(L.h_la_cnt.data(), L.la_cnt.p, (size_t)n, c->stream));
     std::vector<int32_t> h_lstatus((size_t)n);
     VMX_TRY(download(h_lstatus.data(), L.status.p, (size_t)n, c->stream));
-    VMX_HIP(hipStreamSynchronize(c->stream));
+    VMX_HIP(vmx_stream_sync(c));
     VMX_HIP(hipGetLastError());
     {   // capacity retries: 8x, 64x, 512x, 4096x the regular slot / hit pool, as long as the overflow area lasts
         int64_t ovf_used = 0;
@@ -151,7 +151,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
             VMX_TRY(run_seed(cnt, std::min(cnt, 8), hcap));
             VMX_TRY(download(L.h_la_cnt.data(), L.la_cnt.p, (size_t)n, c->stream));
             VMX_TRY(download(h_lstatus.data(), L.status.p, (size_t)n, c->stream));
-            VMX_HIP(hipStreamSynchronize(c->stream));
+            VMX_HIP(vmx_stream_sync(c));
             VMX_HIP(hipGetLastError());
         }
     }
@@ -268,7 +268,7 @@ int vm_local_chain_batch(vm_ctx* c, const vm_index* mi, const vm_params* prm, in
     VMX_TRY(download(out->status, L.status.p, (size_t)n, c->stream)); VMX_TRY(download(out->variant, L.variant.p, (size_t)n, c->stream));
     VMX_TRY(download(out->score, L.score.p, (size_t)n, c->stream)); VMX_TRY(download(clen.data(), L.chain_len.p, (size_t)n, c->stream));
     VMX_TRY(download(chain.data(), L.chain.p, (size_t)la_tot, c->stream)); VMX_TRY(download(sorted.data(), L.la_sorted.p, (size_t)la_tot, c->stream));
-    VMX_HIP(hipStreamSynchronize(c->stream)); VMX_HIP(hipGetLastError());
+    VMX_HIP(vmx_stream_sync(c)); VMX_HIP(hipGetLastError());
     int64_t tc = 0, tr = 0;
     for (int64_t r = 0; r < n; ++r) { tc += clen[r]; tr += L.h_la_cnt[r]; }
     out->chain_off = (int64_t*)malloc(8 * (size_t)(n + 1)); out->raw_off = (int64_t*)malloc(8 * (size_t)(n + 1));

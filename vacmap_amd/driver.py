@@ -196,7 +196,7 @@ def main(argv=None, comm=None):
     if not rg:
         rg = {'ID': '1', 'SM': 'sample'}
     mark = args.markunbalancetra or args.mode in ('H', 'L')          # mode defaults of vacmap:286-296
-    from .lib import SamOpts, Fastx, align_batch_raw, sam_emit, blob_gather
+    from .lib import SamOpts, Fastx, align_batch_raw, sam_emit, blob_gather, blob_gather_parts
     opts = SamOpts(int(bool(args.MD)), int(args.cs != 'long'), int(bool(args.L)), int(bool(mark)), int(bool(args.H)), int(bool(args.fakecigar)), rg['ID'].encode())
     out, proc = (None, None)
     if rank == 0:
@@ -204,10 +204,18 @@ def main(argv=None, comm=None):
         for ln in sam.header_lines([(n, ln_) for n, ln_ in zip(names, index.lens)], ' '.join(sys.argv if argv is None else ['vacmapx'] + list(argv)), rg):
             out.write(ln.encode() + b'\n')
     pipe = pipeline.Pipeline(index, prm, device=device, inflight=args.inflight, first_ctx=ctx)
-    emit_threads = max(1, args.t // max(1, pipe.inflight))            # -t host threads in all, shared by the batches in flight
+    if os.environ.get('VMX_SPIN_SYNC') != '1':
+        for cx in pipe.ctxs:
+            cx.set_blocking_sync(True)                    # the emitters need the cores the waiting aligner threads would spin on
+    # host threads (-t in all): `inflight` of them feed the GPU (gather a batch's reads, vm_align_batch) and mostly wait for it; the SAM
+    # text of finished batches is produced by a pool of emit_jobs concurrent vm_sam_emit calls of emit_threads threads each, so that the
+    # GPU never waits for text and the text never waits for the GPU
+    emit_jobs = max(1, min(4, args.t // 4))
+    emit_threads = max(1, args.t // emit_jobs)
     counts = {'reads': 0, 'lines': 0, 'skipped': 0}
     win_reads = max(1, args.batch_reads * args.window_batches)
     import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
 
     def windows():
         """input records in arrival order as blobs (names, upper-cased sequences, qualities, comments), de-duplicated by name
@@ -240,9 +248,106 @@ def main(argv=None, comm=None):
                     if len(ch['seqs_off']) > 1:
                         yield ch
 
+    tm = {'wait_input': 0.0, 'assemble_write': 0.0, 'job_gather': 0.0, 'job_align': 0.0, 'job_emit': 0.0}
+    tml = threading.Lock()
+    errs = []
+    slots = threading.Semaphore(3)                      # windows in memory at a time (input blobs + SAM text)
+    oq = queue.Queue()                                  # windows in input order -> writer
+    emit_pool = ThreadPoolExecutor(max_workers=emit_jobs)
+
+    class Window:
+        def __init__(self, wnd, plan):
+            self.wnd, self.plan = wnd, plan
+            self.has_q = bool(wnd['quals_off'][-1]); self.has_c = bool(wnd['comments_off'][-1])
+            self.futs = [None] * len(plan)
+            self.left = len(plan)
+            self.ready = threading.Event()              # every batch of the window has been aligned and handed to the emit pool
+            if not plan:
+                self.ready.set()
+
+    def job_source():
+        """(window, batch index) in schedule order; a window is planned when the first worker reaches it"""
+        while not errs:
+            slots.acquire()
+            t0 = time.time()
+            wnd = wq.get()
+            with tml:
+                tm['wait_input'] += time.time() - t0
+            if isinstance(wnd, BaseException):
+                errs.append(wnd); wnd = None
+            if wnd is None:
+                slots.release()
+                break
+            counts['reads'] += len(wnd['seqs_off']) - 1
+            plan = pipeline.plan_batches(np.diff(wnd['seqs_off']), args.batch_reads, args.window_batches)
+            plan = [plan[i] for i in range(rank, len(plan), world)]        # static sharding: batch i -> rank i mod N
+            w = Window(wnd, plan)
+            oq.put(w)
+            for i in range(len(plan)):
+                yield w, i
+        oq.put(None)
+
+    def emit(w, i, ix, sb, so, raw):
+        t0 = time.time()
+        wnd = w.wnd
+        nb, no = blob_gather(lib, wnd['names'], wnd['names_off'], ix)
+        qb, qo = blob_gather(lib, wnd['quals'], wnd['quals_off'], ix) if w.has_q else (None, None)
+        cb, co = blob_gather(lib, wnd['comments'], wnd['comments_off'], ix) if w.has_c else (None, None)
+        text, toff, nl, ns = sam_emit(lib, index, opts, nb, no, sb, so, raw, quals=qb, qual_off=qo, comments=cb, com_off=co, nthreads=emit_threads)
+        raw.close()
+        with tml:
+            tm['job_emit'] += time.time() - t0
+        return ix, text, toff, nl, ns
+
+    def align(job, cx):
+        """one batch: gather its reads from the window, align (GPU), hand the records to the emit pool; the library calls release the GIL"""
+        w, i = job
+        ix = w.plan[i]
+        t0 = time.time()
+        sb, so = blob_gather(lib, w.wnd['seqs'], w.wnd['seqs_off'], ix)
+        t1 = time.time()
+        raw = align_batch_raw(cx, index, prm, sb, so)
+        t2 = time.time()
+        w.futs[i] = emit_pool.submit(emit, w, i, ix, sb, so, raw)
+        with tml:
+            tm['job_gather'] += t1 - t0; tm['job_align'] += t2 - t1; tm['device_s'] = tm.get('device_s', 0.0) + raw.stats['ms_total'] * 1e-3
+            w.left -= 1
+            if w.left == 0:
+                w.ready.set()
+
+    def writer():
+        """a window's lines in input order (one more gather over the concatenated batch texts) while later windows align and emit"""
+        try:
+            while True:
+                w = oq.get()
+                if w is None:
+                    return
+                while not w.ready.wait(0.2):
+                    if errs:
+                        return
+                done = [f.result() for f in w.futs]
+                counts['lines'] += sum(r[3] for r in done); counts['skipped'] += sum(r[4] for r in done)
+                parts = [(ix, text, toff) for ix, text, toff, _, _ in done]
+                t0 = time.time()
+                if world > 1:
+                    from .dist import gather_lines
+                    allp = gather_lines(parts, dst=0)
+                    parts = [p for rp in allp for p in rp] if rank == 0 else []
+                if parts:
+                    txt = blob_gather_parts(lib, [p[1] for p in parts], [p[2] for p in parts], [p[0] for p in parts])
+                    out.write(memoryview(txt))
+                w.wnd = None; w.futs = None
+                slots.release()
+                with tml:
+                    tm['assemble_write'] += time.time() - t0
+        except BaseException as e:
+            errs.append(e)
+            slots.release()
+
     wq = queue.Queue(maxsize=2)
 
     def reader():
+        """input parsing runs ahead of the aligners (the FASTX reader releases the GIL)"""
         try:
             for wnd in windows():
                 wq.put(wnd)
@@ -251,79 +356,17 @@ def main(argv=None, comm=None):
             wq.put(e)
 
     threading.Thread(target=reader, daemon=True).start()
-    oq = queue.Queue(maxsize=2)
-    werr = []
-    tm = {'wait_input': 0.0, 'align_emit': 0.0, 'assemble_write': 0.0}
-
-    def writer():
-        """a window's lines in input order (one more gather over the concatenated batch texts) while the next window aligns"""
-        try:
-            while True:
-                parts = oq.get()
-                if parts is None:
-                    return
-                t0 = time.time()
-                if world > 1:
-                    from .dist import gather_lines
-                    allp = gather_lines(parts, dst=0)
-                    if rank != 0:
-                        continue
-                    parts = [p for rp in allp for p in rp]
-                if parts:
-                    ridx = np.concatenate([p[0] for p in parts])
-                    big = np.concatenate([p[1] for p in parts]) if len(parts) > 1 else parts[0][1]
-                    lens = np.concatenate([np.diff(p[2]) for p in parts])
-                    boff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-                    txt, _ = blob_gather(lib, big, boff, np.argsort(ridx, kind='stable'))
-                    out.write(memoryview(txt))
-                tm['assemble_write'] += time.time() - t0
-        except BaseException as e:
-            werr.append(e)
-
     wt = threading.Thread(target=writer)
     wt.start()
-    while not werr:
-        t0 = time.time()
-        wnd = wq.get()
-        tm['wait_input'] += time.time() - t0
-        if wnd is None:
-            break
-        if isinstance(wnd, BaseException):
-            oq.put(None); wt.join()
-            raise wnd
-        n = len(wnd['seqs_off']) - 1
-        counts['reads'] += n
-        plan = pipeline.plan_batches(np.diff(wnd['seqs_off']), args.batch_reads, args.window_batches)
-        plan = [plan[i] for i in range(rank, len(plan), world)]        # static sharding: batch i -> rank i mod N
-        has_q = bool(wnd['quals_off'][-1]); has_c = bool(wnd['comments_off'][-1])
-
-        def job(i, cx, plan=plan, wnd=wnd, has_q=has_q, has_c=has_c):
-            """one batch: gather its reads from the window, align (GPU), emit SAM text (host threads); everything below releases the GIL"""
-            ix = plan[i]
-            t0 = time.time()
-            sb, so = blob_gather(lib, wnd['seqs'], wnd['seqs_off'], ix)
-            t1 = time.time()
-            raw = align_batch_raw(cx, index, prm, sb, so)
-            t2 = time.time()
-            nb, no = blob_gather(lib, wnd['names'], wnd['names_off'], ix)
-            qb, qo = blob_gather(lib, wnd['quals'], wnd['quals_off'], ix) if has_q else (None, None)
-            cb, co = blob_gather(lib, wnd['comments'], wnd['comments_off'], ix) if has_c else (None, None)
-            t3 = time.time()
-            text, toff, nl, ns = sam_emit(lib, index, opts, nb, no, sb, so, raw, quals=qb, qual_off=qo, comments=cb, com_off=co, nthreads=emit_threads)
-            raw.close()
-            t4 = time.time()
-            tm['job_gather'] = tm.get('job_gather', 0.0) + (t1 - t0) + (t3 - t2); tm['job_align'] = tm.get('job_align', 0.0) + (t2 - t1); tm['job_emit'] = tm.get('job_emit', 0.0) + (t4 - t3)
-            return ix, text, toff, nl, ns
-
-        done = []
-        t0 = time.time()
-        pipe._run(len(plan), job, lambda i, res: done.append(res))
-        tm['align_emit'] += time.time() - t0
-        counts['lines'] += sum(r[3] for r in done); counts['skipped'] += sum(r[4] for r in done)
-        oq.put([(ix, text, toff) for ix, text, toff, _, _ in done])
-    oq.put(None); wt.join()
-    if werr:
-        raise werr[0]
+    try:
+        pipe.run_stream(job_source(), align, errs)
+    finally:
+        if errs:
+            oq.put(None)
+        wt.join()
+        emit_pool.shutdown(wait=True)
+    if errs:
+        raise errs[0]
     if os.environ.get('VMX_DRIVER_TIMING'):
         sys.stderr.write('vacmapx timing (s): %s\n' % ' '.join('%s=%.2f' % kv for kv in tm.items()))
     pipe.close()

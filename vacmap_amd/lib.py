@@ -117,6 +117,7 @@ class VmxLib:
         L.vm_ctx_create.argtypes = [C.c_int, P(vp)]
         L.vm_ctx_destroy.argtypes = [vp]
         L.vm_ctx_set_inflight.argtypes = [vp, C.c_int]
+        L.vm_ctx_set_blocking_sync.argtypes = [vp, C.c_int]
         L.vm_table.argtypes = [vp, C.c_int, P(vp)]; L.vm_table.restype = i64
         L.vm_edit_distance_batch.argtypes = [vp, i64, cp, vp, cp, vp, P(P(i64))]
         L.vm_edit_distance_bound_batch.argtypes = [vp, C.c_int, i64, cp, vp, cp, vp, P(P(i64))]
@@ -151,6 +152,7 @@ class VmxLib:
         L.vm_align_trace.argtypes = [vp, vp, P(Params), i64, cp, vp, C.c_int, P(P(i64)), P(P(i64))]
         L.vm_sam_emit.argtypes = [vp, P(SamOpts), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, C.c_int, P(vp), P(P(i64)), P(i64), P(i64)]
         L.vm_blob_gather.argtypes = [vp, vp, vp, i64, vp, vp]; L.vm_blob_gather.restype = i64
+        L.vm_blob_gather_parts.argtypes = [vp, vp, vp, vp, i64, vp]; L.vm_blob_gather_parts.restype = i64
         L.vm_fastx_open.argtypes = [cp, P(vp)]; L.vm_fastx_close.argtypes = [vp]
         L.vm_fastx_read.argtypes = [vp, i64, i64] + [P(vp), P(P(i64))] * 4; L.vm_fastx_read.restype = i64
         L.vm_reads_upload.argtypes = [vp, i64, cp, vp, P(vp)]
@@ -195,6 +197,10 @@ class Context:
     def set_inflight(self, n_contexts):
         """tell the context how many contexts share its GPU (vm_ctx_set_inflight)"""
         self.lib.check(self.lib.L.vm_ctx_set_inflight(self.h, int(n_contexts)))
+
+    def set_blocking_sync(self, on=True):
+        """sleep instead of spinning while waiting for the GPU (vm_ctx_set_blocking_sync)"""
+        self.lib.check(self.lib.L.vm_ctx_set_blocking_sync(self.h, int(bool(on))))
 
     def close(self):
         if self.h:
@@ -456,6 +462,22 @@ def blob_gather(lib, blob, off, idx):
     return out[:tot], oo
 
 
+def blob_gather_parts(lib, blobs, offs, order_keys):
+    """several (blob, off) pairs merged into one blob whose entries follow ascending order_keys (one int64 key array per pair, e.g. the
+    reads' indices in the input window): one memcpy loop in the library, no concatenation of the parts first"""
+    blobs = [_u8(b) for b in blobs]; offs = [np.ascontiguousarray(o, dtype=np.int64) for o in offs]
+    keys = np.concatenate([np.asarray(k, dtype=np.int64) for k in order_keys]) if blobs else np.zeros(0, np.int64)
+    part = np.concatenate([np.full(len(k), i, np.int32) for i, k in enumerate(order_keys)]) if blobs else np.zeros(0, np.int32)
+    local = np.concatenate([np.arange(len(k), dtype=np.int64) for k in order_keys]) if blobs else np.zeros(0, np.int64)
+    order = np.argsort(keys, kind='stable')
+    part = np.ascontiguousarray(part[order]); local = np.ascontiguousarray(local[order])
+    tot = int(sum(int(o[-1]) for o in offs))
+    out = np.empty(max(tot, 1), np.uint8)
+    bp = (C.c_void_p * len(blobs))(*[b.ctypes.data for b in blobs]); op = (C.c_void_p * len(offs))(*[o.ctypes.data for o in offs])
+    w = lib.L.vm_blob_gather_parts(bp, op, part.ctypes.data, local.ctypes.data, len(local), out.ctypes.data)
+    return out[:w]
+
+
 class Fastx:
     """FASTA / FASTQ(.gz) reader into blobs (vm_fastx_*): the native counterpart of mp.fastx_read (vacmap:445)"""
 
@@ -478,9 +500,8 @@ class Fastx:
         for key, p, o in zip(('names', 'seqs', 'quals', 'comments'), ptrs, offs):
             oo = np.ctypeslib.as_array(o, shape=(n + 1,)).copy(); self.lib.L.vm_free(o)
             tot = int(oo[-1])
-            out[key] = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(tot, 1),))[:tot].copy()
+            out[key] = _OwnedText(self.lib, p, tot).array          # a view of the library's buffer (a window is ~1 GB: no copy)
             out[key + '_off'] = oo
-            self.lib.L.vm_free(p)
         return out if n > 0 else None
 
     def close(self):

@@ -90,6 +90,33 @@ class Pipeline:
         if errs:
             raise errs[0]
 
+    def run_stream(self, jobs, do_job, errs=None):
+        """`inflight` threads pull jobs from the iterator `jobs` (one at a time, under a lock) and run do_job(job, ctx) until it is
+        exhausted: no barrier between groups of jobs, the contexts stay busy across the caller's windows. An exception in any thread is
+        appended to `errs` (shared with the caller's other threads), stops the others and is re-raised."""
+        lock = threading.Lock()
+        errs = [] if errs is None else errs
+        it = iter(jobs)
+
+        def worker(cx):
+            try:
+                while not errs:
+                    with lock:
+                        job = next(it, None)
+                    if job is None:
+                        return
+                    do_job(job, cx)
+            except BaseException as e:
+                errs.append(e)
+
+        th = [threading.Thread(target=worker, args=(cx,)) for cx in self.ctxs[:self.inflight]]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+
     def run_resident(self, resident, want_records=False, on_result=None):
         """resident: list of ResidentReads in schedule order (plan_batches). on_result(i, (status, records or None, stats))"""
         self._run(len(resident), lambda i, cx: resident[i].align(self.index, self.prm, want_records=want_records, ctx=cx), on_result)
