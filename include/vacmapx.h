@@ -62,8 +62,8 @@ typedef struct vm_ctx vm_ctx;
 int vm_ctx_create(int device_id, vm_ctx** out);
 void vm_ctx_destroy(vm_ctx*);
 /* How many contexts share this GPU (batches in flight, one host thread each; default 1). A context that runs alone sizes its
- * latency-bound kernels to fill the device; with several in flight they are launched narrower (the local seeding kernel at 3 / 2 / 1
- * workgroups per CU for 1 / 2 / >= 3 contexts) so that another batch's VALU-bound gap-fill kernel can be resident beside them. */
+ * latency-bound kernels to fill the device; with several in flight they are launched narrower (the local seeding kernel at 3 / 2
+ * workgroups per CU for 1 / >= 2 contexts) so that another batch's VALU-bound gap-fill kernel can be resident beside them. */
 int vm_ctx_set_inflight(vm_ctx*, int n_contexts);
 /* on != 0: the context's host thread sleeps while it waits for the GPU inside vm_align_batch instead of spinning (default: spin, lowest
  * latency). For processes whose other threads need the cores — vacmap_amd.driver's SAM emitters under a CPU quota. */

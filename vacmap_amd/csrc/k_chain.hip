@@ -309,6 +309,7 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
                                                      int32_t* __restrict__ SA_out, uint8_t* __restrict__ cov_pool,
                                                      int64_t* __restrict__ gmax_out, int64_t* __restrict__ opcount_out, int rmode,
                                                      double* __restrict__ FP_pool, double* __restrict__ PP_pool) {
+    VMX_SETPRIO(3);
     VMX_DYN_SHARED(char, smem);
     __shared__ double s_gapcost[64];
     const int lane = vmx_lane();
@@ -336,6 +337,7 @@ __global__ void __launch_bounds__(64) k_chain_select(const vmx_anchor* __restric
                                char* __restrict__ scratch, const int64_t* __restrict__ scratch_off,
                                int32_t* __restrict__ out_mapq, double* __restrict__ out_score, int32_t* __restrict__ out_npaths,
                                int32_t* __restrict__ out_path_len, vmx_anchor* __restrict__ out_path_anchors) {
+    VMX_SETPRIO(3);
     // one wavefront per read: the wave stages S / P / S_arg and the `used` flags of the read in LDS (17 B per anchor), then lane 0 runs the
     // serial peel on them — its dependent walks (S_arg -> used -> P -> ...) cost LDS latency instead of HBM latency. Reads of up to
     // VMX_SELECT_LDS_FULL anchors also keep the function's scratch (chain lists, read bins: 37 B per anchor) in LDS.

@@ -214,6 +214,7 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
                                                     int32_t* __restrict__ SA_pool, double* __restrict__ out_score,
                                                     vmx_anchor* __restrict__ out_chain, int32_t* __restrict__ out_len, int32_t* __restrict__ out_variant,
                                                     int32_t* __restrict__ status, double* __restrict__ FP_pool, double* __restrict__ PP_pool) {
+    VMX_SETPRIO(3);
     VMX_DYN_SHARED(char, smem);
     __shared__ double s_gapcost[64];
     __shared__ float s_rgc[128];

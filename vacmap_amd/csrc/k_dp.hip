@@ -580,6 +580,7 @@ __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_
                                 const vmx_dp_prob* __restrict__ probs, int n_prob, int eqx, const uint8_t* __restrict__ tb_pool,
                                 uint32_t* __restrict__ run_pool, char* __restrict__ cig_pool, int32_t* __restrict__ cig_len,
                                 const int32_t* __restrict__ band_flag, const uint8_t* __restrict__ redo_pool) {
+    VMX_SETPRIO(3);
     int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (p >= n_prob) return;
     const vmx_dp_prob pr = probs[p];

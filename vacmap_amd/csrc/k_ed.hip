@@ -25,6 +25,7 @@ __device__ __forceinline__ int vmx_size_class(long long s) {
 }
 __global__ void __launch_bounds__(1024) k_size_order(const int64_t* __restrict__ size, const int32_t* __restrict__ n_ptr, int64_t thresh,
                                                      int32_t* __restrict__ order, int32_t* __restrict__ range, int32_t* __restrict__ counters) {
+    VMX_SETPRIO(3);
     __shared__ int s_hist[256];
     __shared__ int s_cur[256];
     __shared__ int s_long;

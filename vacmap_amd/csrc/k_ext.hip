@@ -35,6 +35,7 @@ __device__ __forceinline__ int vmx_alloc_probs(const vmx_ext_args& A, int n) {
 }
 
 __global__ void k_ext_phase(vmx_ext_args A, int phase) {
+    VMX_SETPRIO(3);
     const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (r >= A.n_reads) return;
     vmx_ext_read& E = A.er[r];
@@ -250,6 +251,7 @@ __global__ void k_res_pack(const vmx_ext_read* __restrict__ er, const vm_record*
 
 // E6 records (:20731-20838) + pairedindel (:5604). one thread per read.
 __global__ void k_ext_records(vmx_ext_args A, const vmx_dp_prob* __restrict__ probs, const char* __restrict__ cig_pool, const int32_t* __restrict__ cig_len) {
+    VMX_SETPRIO(3);
     const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (r >= A.n_reads) return;
     vmx_ext_read& E = A.er[r];

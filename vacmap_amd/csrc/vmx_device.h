@@ -74,6 +74,14 @@ __device__ __forceinline__ unsigned vmx_pk_bytes(unsigned b) { return (b & 0xffu
 #else
 __device__ __forceinline__ unsigned vmx_pk_bytes(unsigned b) { return __builtin_amdgcn_perm(b, b, 0x0c0c0200u); }
 #endif
+// issue priority of the calling wave (s_setprio, 0 .. 3). The serial, latency-bound kernels (one lane or one wave per read walking
+// dependent loads) raise it: they issue a handful of instructions per microsecond, and when another batch's VALU-bound kernel shares the
+// SIMD every one of those waits behind a queue of packed-int16 arithmetic; getting them through first costs the arithmetic nothing.
+#if defined(VMX_EMU) || defined(VMX_NOPRIO)
+#define VMX_SETPRIO(p) ((void)0)
+#else
+#define VMX_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+#endif
 // single-wavefront workgroups: LDS operations of one wave execute in order, so a value one lane stores is visible to the other lanes' later
 // loads without a barrier; what is needed is only that the compiler keeps the order. (A __syncthreads() here also drains the wave's
 // outstanding global stores — an HBM write acknowledgement per anchor in the chain kernels.) The emulator's lanes are fibers: keep the rendezvous.

@@ -51,9 +51,10 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
 #ifndef VMX_EMU
     VMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_local_seed, TPB, 0));
     if (occ < 1) occ = 1;
-    // a context that shares the GPU with others (batches in flight) leaves room for their kernels: measured with 3 in flight,
-    // 3 / 2 / 1 workgroups per CU give 56.4 / 53.5 / 52.5 ms per batch, while alone 3 is best (77 vs 79 / 82 ms)
-    { const int want = c->inflight >= 3 ? 1 : (c->inflight == 2 ? 2 : 3); if (want < occ) occ = want; }
+    // a context that shares the GPU with others (batches in flight) leaves room for their kernels: measured with 3 in flight and the
+    // anti-diagonal gap fill, 1 / 2 / 3 workgroups per CU give 34.8 / 33.0 / 35.2 ms per batch (with the slower striped fill one was
+    // best: 52.5 / 53.5 / 56.4), while alone 3 is best
+    { const int want = c->inflight >= 2 ? 2 : 3; if (want < occ) occ = want; }
     if (const char* e = getenv("VMX_LSEED_WGS")) { int v = atoi(e); if (v >= 1) occ = v; }                  // tuning knob: workgroups per CU
 #endif
     const int G = (int)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)c->num_cu * occ));
