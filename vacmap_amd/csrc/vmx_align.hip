@@ -463,6 +463,8 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         const DevBuf* lb = (const DevBuf*)&L; size_t lt = 0; const size_t nl = (size_t)((const char*)&L.la_pool_rows - (const char*)&L) / sizeof(DevBuf);
         for (size_t i = 0; i < nl; ++i) { lt += lb[i].cap; if (lb[i].cap > ((size_t)128 << 20)) fprintf(stderr, "[pools] local[%zu] %.2f GB\n", i, lb[i].cap / 1e9); }
         fprintf(stderr, "[pools] local bufs total %.2f GB\n", lt / 1e9);
+        fprintf(stderr, "[pools] process so far: %lld first allocations, %lld re-allocations, %.3f s in hipFree + hipMalloc\n", (long long)vmx::devbuf_stats().first.load(),
+                (long long)vmx::devbuf_stats().grows.load(), vmx::devbuf_stats().ns.load() * 1e-9);
     }
     if (stats) *stats = st;
     return VM_OK;

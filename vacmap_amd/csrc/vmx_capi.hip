@@ -103,6 +103,7 @@ void vm_ctx_destroy(vm_ctx* c) {
     vmx_ctx_free_local_bufs(c);
     vmx_ctx_free_batch_bufs(c);
     c->tab_buf.release();
+    vmx::devbuf_retired().flush();
     for (int i = 0; i < 24; ++i) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 48; ++i) (void)hipEventDestroy(c->gev[i]);
     for (int i = 0; i < 4; ++i) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); (void)hipEventDestroy(c->join_ev[i]); }

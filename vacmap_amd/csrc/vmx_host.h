@@ -7,6 +7,9 @@
 #include <algorithm>
 #include <string>
 #include <vector>
+#include <chrono>
+#include <atomic>
+#include <mutex>
 
 namespace vmx {
 
@@ -21,17 +24,48 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 #define VMX_TRY(expr) do { int _rc = (expr); if (_rc < 0) return _rc; } while (0)
 
 // grow-only device buffer
+// growth statistics of the grow-only pools (tuning aid, printed with VMX_DBG_POOLS): a growth is a hipFree — which waits for the whole
+// device, every other context's batch included — plus a hipMalloc
+struct DevBufStats { std::atomic<long long> grows{0}, first{0}, ns{0}; };
+inline DevBufStats& devbuf_stats() { static DevBufStats s; return s; }
+
+// A buffer that has to grow is not freed on the spot: hipFree waits for the WHOLE device — every other context's batch in flight — and a
+// run's first windows grow a few hundred buffers (each new longest read resizes the per-slot pools). The outgrown allocations are parked
+// here and freed together once they add up to VMX_RETIRE_BYTES (one device-wide wait instead of hundreds), when an allocation fails, or
+// when a context is destroyed.
+struct DevBufRetired {
+    std::mutex m; std::vector<void*> v; size_t bytes = 0;
+    void flush_locked() { for (void* q : v) (void)hipFree(q); v.clear(); bytes = 0; }
+    void flush() { std::lock_guard<std::mutex> g(m); flush_locked(); }
+    void park(void* q, size_t cap) {
+        std::lock_guard<std::mutex> g(m);
+        v.push_back(q); bytes += cap;
+        if (bytes > ((size_t)6 << 30) || v.size() >= 512) flush_locked();
+    }
+};
+inline DevBufRetired& devbuf_retired() { static DevBufRetired r; return r; }
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    // grows with 1/8 head-room (at most 1 GB of it) so that slightly larger batches do not reallocate
+    // grows with head-room so that slightly larger batches do not reallocate: 1/8 on the first allocation, 1/2 (at most 2 GB) when the
+    // buffer has to grow again — the input has shown that it varies
     int reserve(size_t bytes) {
         if (bytes <= cap && p) return 0;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + std::min<size_t>(bytes / 8, (size_t)1 << 30) + 256;
+        const auto t0 = std::chrono::steady_clock::now();
+        const bool regrow = p != nullptr;
+        if (p) { devbuf_retired().park(p, cap); p = nullptr; cap = 0; }
+        size_t want = bytes + (regrow ? std::min<size_t>(bytes / 2, (size_t)2 << 30) : std::min<size_t>(bytes / 8, (size_t)1 << 30)) + 256;
         hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { (void)hipGetLastError(); devbuf_retired().flush(); e = hipMalloc(&p, want); }                // give the parked memory back first
+        if (e != hipSuccess && regrow) { (void)hipGetLastError(); want = bytes + 256; e = hipMalloc(&p, want); }          // no room for the head-room: exact size
         if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
         cap = want;
+        DevBufStats& st = devbuf_stats(); (regrow ? st.grows : st.first)++;
+        const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        st.ns += ns;
+        static const bool verbose = getenv("VMX_DBG_POOLS") && atoi(getenv("VMX_DBG_POOLS")) >= 2;
+        if (verbose && ns > 2000000) fprintf(stderr, "[pools] %s of %.3f GB took %.1f ms\n", regrow ? "re-allocation" : "allocation", want / 1e9, ns * 1e-6);
         return 0;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }

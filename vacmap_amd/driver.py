@@ -144,8 +144,12 @@ def _open_output(path):
     return proc.stdin, proc
 
 
+last_timing = {}          # wall seconds of the last main() call by phase (tools/driver_bench.py reads it)
+
+
 def main(argv=None, comm=None):
     """comm: an initialised torch.distributed module (tests); under torchrun (WORLD_SIZE > 1) the process group is created here"""
+    t_start = time.time()
     args, _unknown = build_parser().parse_known_args(argv)          # unknown flags are ignored like the reference's parse_known_args (vacmap:152)
     if args.o != '-' and not (args.o.endswith('.sam') or args.o.endswith('.bam')):
         sys.exit("Output path must end with .sam, .bam, .sorted.bam, or be '-' for stdout.")
@@ -210,8 +214,9 @@ def main(argv=None, comm=None):
     # host threads (-t in all): `inflight` of them feed the GPU (gather a batch's reads, vm_align_batch) and mostly wait for it; the SAM
     # text of finished batches is produced by a pool of emit_jobs concurrent vm_sam_emit calls of emit_threads threads each, so that the
     # GPU never waits for text and the text never waits for the GPU
-    emit_jobs = max(1, min(4, args.t // 4))
-    emit_threads = max(1, args.t // emit_jobs)
+    emit_total = int(os.environ.get('VMX_EMIT_THREADS', '0')) or args.t
+    emit_jobs = max(1, min(4, emit_total // 4))
+    emit_threads = max(1, emit_total // emit_jobs)
     counts = {'reads': 0, 'lines': 0, 'skipped': 0}
     win_reads = max(1, args.batch_reads * args.window_batches)
     import numpy as np
@@ -248,7 +253,7 @@ def main(argv=None, comm=None):
                     if len(ch['seqs_off']) > 1:
                         yield ch
 
-    tm = {'wait_input': 0.0, 'assemble_write': 0.0, 'job_gather': 0.0, 'job_align': 0.0, 'job_emit': 0.0}
+    tm = {'setup': time.time() - t_start, 'wait_input': 0.0, 'assemble_write': 0.0, 'job_gather': 0.0, 'job_align': 0.0, 'job_emit': 0.0}
     tml = threading.Lock()
     errs = []
     slots = threading.Semaphore(3)                      # windows in memory at a time (input blobs + SAM text)
@@ -289,6 +294,9 @@ def main(argv=None, comm=None):
 
     def emit(w, i, ix, sb, so, raw):
         t0 = time.time()
+        if os.environ.get('VMX_SKIP_EMIT') == '1':          # diagnostic: aligners alone
+            raw.close()
+            return ix, np.zeros(0, np.uint8), np.zeros(len(ix) + 1, np.int64), 0, 0
         wnd = w.wnd
         nb, no = blob_gather(lib, wnd['names'], wnd['names_off'], ix)
         qb, qo = blob_gather(lib, wnd['quals'], wnd['quals_off'], ix) if w.has_q else (None, None)
@@ -311,6 +319,8 @@ def main(argv=None, comm=None):
         w.futs[i] = emit_pool.submit(emit, w, i, ix, sb, so, raw)
         with tml:
             tm['job_gather'] += t1 - t0; tm['job_align'] += t2 - t1; tm['device_s'] = tm.get('device_s', 0.0) + raw.stats['ms_total'] * 1e-3
+            if os.environ.get('VMX_DRIVER_TIMING') == '2':
+                sys.stderr.write('batch t=%.3f reads %d bases %d align %.3f device %.3f\n' % (t1 - t_loop, len(ix), int(so[-1]), t2 - t1, raw.stats['ms_total'] * 1e-3))
             w.left -= 1
             if w.left == 0:
                 w.ready.set()
@@ -358,8 +368,10 @@ def main(argv=None, comm=None):
     threading.Thread(target=reader, daemon=True).start()
     wt = threading.Thread(target=writer)
     wt.start()
+    t_loop = time.time()
     try:
         pipe.run_stream(job_source(), align, errs)
+        tm['aligners_done'] = time.time() - t_loop
     finally:
         if errs:
             oq.put(None)
@@ -367,6 +379,8 @@ def main(argv=None, comm=None):
         emit_pool.shutdown(wait=True)
     if errs:
         raise errs[0]
+    tm['loop'] = time.time() - t_loop
+    last_timing.clear(); last_timing.update(tm); last_timing['reads'] = counts['reads']
     if os.environ.get('VMX_DRIVER_TIMING'):
         sys.stderr.write('vacmapx timing (s): %s\n' % ' '.join('%s=%.2f' % kv for kv in tm.items()))
     pipe.close()
