@@ -161,7 +161,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     const int caps[NB] = {384, 512, 768, 1024, 1536, 2048, 3072, 4096, 8192, 13056};
     std::vector<int32_t> lists[NB + 1];
     static const int gc_lds_env = [] { const char* e = getenv("VMX_GC_LDS_MAX"); return e ? atoi(e) : -1; }();     // see vmx_stage_local.hip
-    const int gc_lds_max = gc_lds_env >= 0 ? gc_lds_env : (c->inflight >= 2 ? VMX_CHAIN_LDS_MAX_SHARED : VMX_GC_LDS_MAX_DEFAULT);
+    const int gc_lds_max = gc_lds_env >= 0 ? gc_lds_env : VMX_CHAIN_LDS_MAX_SHARED;
     for (int64_t r = 0; r < n; ++r) {
         int64_t m = h_aoff[r + 1] - h_aoff[r]; const int64_t L = h_roff[r + 1] - h_roff[r];
         if (m <= 2) continue;                                             // :23986 unmapped

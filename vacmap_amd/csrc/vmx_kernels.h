@@ -175,8 +175,9 @@ __device__ __forceinline__ uint8_t* vmx_tb_ptr(const uint8_t* tb_pool, const uin
 #define VMX_SELECT_LDS_FULL 960       // ... and whose scratch (37 B + 64) fits next to them: 960 * 53 + 64 <= 3072 * 17
 #define VMX_LC_LDS_MAX_DEFAULT 13056   // reads with more local anchors than this run the chain DP on HBM-resident arrays (VMX_LC_LDS_MAX)
 #define VMX_GC_LDS_MAX_DEFAULT 13056
-#define VMX_CHAIN_LDS_MAX_SHARED 512   // ... and this when several batches are in flight on the GPU (vm_ctx_set_inflight >= 2): a large LDS claim per
-                                      // wavefront starves the other batches' kernels of CUs
+#define VMX_CHAIN_LDS_MAX_SHARED 512   // ... what the chain kernels actually use (VMX_LC_LDS_MAX / VMX_GC_LDS_MAX override it): above it S / S_arg stay in HBM, where
+                                      // one wave per read leaves room for eight waves per SIMD instead of one — a large LDS claim per wavefront starves the
+                                      // kernel itself (alone: 52.5 -> 49.1 ms per batch) and the other batches' kernels of CUs (three in flight: 46.3 -> 42.5)
 #define VMX_LC_BYTES_PER_ANCHOR 12   // S8 + SA4 (LDS bytes per anchor in k_chain_local; the anchors themselves are read from HBM in register blocks)
 #define VMX_GC_BYTES_PER_ANCHOR 12   // S8 + SA4 (LDS bytes per anchor in k_chain_global; anchors and coverage are read from HBM in register blocks)
 

@@ -173,7 +173,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     // Measured on the hg38-size workload, ms per step with 3 batches in flight for limits 13056 / 4096 / 2048 / 1024 / 512 / 0:
     // 46.3 / 46.1 / 44.9 / 43.9 / 44.0 / 43.4 — LDS residency pays for a context that runs alone, not when batches share the GPU.
     static const int lds_env = [] { const char* e = getenv("VMX_LC_LDS_MAX"); return e ? atoi(e) : -1; }();
-    const int lds_max = lds_env >= 0 ? lds_env : (c->inflight >= 2 ? VMX_CHAIN_LDS_MAX_SHARED : VMX_LC_LDS_MAX_DEFAULT);
+    const int lds_max = lds_env >= 0 ? lds_env : VMX_CHAIN_LDS_MAX_SHARED;
     for (int64_t r = 0; r < n; ++r) {
         int m = L.h_la_cnt[r];
         if (m <= 0) continue;   // no guide / capacity failure: nothing to chain (status already set by the seeding kernel or stays 0 for unmapped reads)
