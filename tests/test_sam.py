@@ -122,3 +122,25 @@ def test_native_fastx_reader(tmp_path):
         rd.close()
         assert got == [(n, s.upper(), q, c) for n, s, q, c in exp], path
     assert len(got) == 70
+
+
+def test_blob_gather_parts_restores_input_order():
+    """vm_blob_gather_parts (the driver's writer): entries of several (blob, offsets) parts merged in ascending key order, empty entries and
+    empty parts included"""
+    import numpy as np
+    import emu_lib
+    from vacmap_amd import lib as VL
+    L = emu_lib.context().lib
+    rng = np.random.default_rng(3)
+    n = 500
+    texts = [bytes(rng.integers(65, 91, int(rng.integers(0, 40)), dtype=np.uint8)) for _ in range(n)]
+    perm = rng.permutation(n)
+    cuts = [0, 120, 120, 333, n]                                   # four parts, one of them empty
+    blobs, offs, keys = [], [], []
+    for a, b in zip(cuts, cuts[1:]):
+        idx = np.sort(perm[a:b])                                   # a batch holds its reads in window order
+        blobs.append(np.frombuffer(b''.join(texts[i] for i in idx), dtype=np.uint8))
+        offs.append(np.concatenate([[0], np.cumsum([len(texts[i]) for i in idx])]).astype(np.int64))
+        keys.append(idx.astype(np.int64))
+    out = VL.blob_gather_parts(L, blobs, offs, keys)
+    assert out.tobytes() == b''.join(texts)
