@@ -579,9 +579,12 @@ __global__ void __launch_bounds__(64, 4) k_gapfill_fill_ns(const uint8_t* __rest
 __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
                                 const vmx_dp_prob* __restrict__ probs, int n_prob, int eqx, const uint8_t* __restrict__ tb_pool,
                                 uint32_t* __restrict__ run_pool, char* __restrict__ cig_pool, int32_t* __restrict__ cig_len,
-                                const int32_t* __restrict__ band_flag, const uint8_t* __restrict__ redo_pool) {
+                                const int32_t* __restrict__ band_flag, const uint8_t* __restrict__ redo_pool, int spread) {
     VMX_SETPRIO(3);
-    int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    // one lane in `spread` works (like k_ext_phase: the walks of the 64 problems of a full wave diverge at every step)
+    const int gt = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (spread > 1 && gt % spread) return;
+    int p = spread > 1 ? gt / spread : gt;
     if (p >= n_prob) return;
     const vmx_dp_prob pr = probs[p];
     const uint8_t* T = tcodes + pr.t_off;

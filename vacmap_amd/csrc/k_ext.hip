@@ -36,7 +36,12 @@ __device__ __forceinline__ int vmx_alloc_probs(const vmx_ext_args& A, int n) {
 
 __global__ void k_ext_phase(vmx_ext_args A, int phase) {
     VMX_SETPRIO(3);
-    const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    // one lane per read, every A.spread-th lane of the grid: a read's walk is a chain of dependent loads and data-dependent branches, and the
+    // 64 reads of a full wave execute the union of their branches in lock step
+    const int sp = A.spread > 1 ? A.spread : 1;
+    const int gt = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (gt % sp) return;
+    const int r = gt / sp;
     if (r >= A.n_reads) return;
     vmx_ext_read& E = A.er[r];
     if (phase == 0) { E.status = A.lstatus[r]; E.nseg = 0; E.nseg_snap = 0; E.filtered = 0; E.redo = 0; E.prob_base = 0; E.prob_n = 0; E.dp_base = 0; E.dp_n = 0; E.nrec = 0; E.active = 0; E.pass = 0; E.skip_ext = 0; }
@@ -252,7 +257,10 @@ __global__ void k_res_pack(const vmx_ext_read* __restrict__ er, const vm_record*
 // E6 records (:20731-20838) + pairedindel (:5604). one thread per read.
 __global__ void k_ext_records(vmx_ext_args A, const vmx_dp_prob* __restrict__ probs, const char* __restrict__ cig_pool, const int32_t* __restrict__ cig_len) {
     VMX_SETPRIO(3);
-    const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int sp = A.spread > 1 ? A.spread : 1;
+    const int gt = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (gt % sp) return;
+    const int r = gt / sp;
     if (r >= A.n_reads) return;
     vmx_ext_read& E = A.er[r];
     if (!E.active || E.status != 0) return;

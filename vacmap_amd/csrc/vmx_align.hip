@@ -252,9 +252,16 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     A.rec = B.rec.as<vm_record>(); A.rec_blob = B.blob.as<char>(); A.blob_off = B.bloboff.as<int64_t>(); A.rec_coff = B.reccoff.as<int64_t>(); A.rec_clen = B.recclen.as<int32_t>();
     A.dup_d = B.dupd.as<double>();
     const unsigned gridR = (unsigned)((n + 63) / 64);
+    // k_ext_phase / k_ext_records: one lane in `spread` works. Alone, spreading the reads over more waves shortens the batch (a batch of
+    // 40-100 kb reads, 1 / 4 / 16 / 64 lanes per read: phases 19.7 / 16.5 / 13.9 / 14.4 ms, records 8.7 / 7.6 / 8.6 / 15.6 ms; batch 130 -> 123 ms);
+    // with three batches in flight it does not raise the throughput (34.3 vs 33.7 ms per step), so a shared context keeps one lane per read
+    static const int ext_env = [] { const char* e = getenv("VMX_EXT_SPREAD"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 0; }();
+    static const int rec_env = [] { const char* e = getenv("VMX_REC_SPREAD"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 0; }();
+    const int ext_spread = ext_env ? ext_env : (c->inflight >= 2 ? 1 : 16), rec_spread = rec_env ? rec_env : (c->inflight >= 2 ? 1 : 4);
+    const unsigned gridX = (unsigned)((n * ext_spread + 63) / 64), gridXR = (unsigned)((n * rec_spread + 63) / 64);
     int cur = 0;
     auto phase = [&](int ph) { A.desc = B.desc[cur].as<vmx_pair_desc>(); A.desc_prev = B.desc[cur ^ 1].as<vmx_pair_desc>();
-                               (void)hipMemsetAsync(B.rcount.p, 0, 4, c->stream); hipLaunchKernelGGL(k_ext_phase, dim3(gridR), dim3(64), 0, c->stream, A, ph);
+                               (void)hipMemsetAsync(B.rcount.p, 0, 4, c->stream); A.spread = ext_spread; hipLaunchKernelGGL(k_ext_phase, dim3(gridX), dim3(64), 0, c->stream, A, ph);
                                if (trace && trace->stage == ph && !A.redo_only && trace->off.empty()) {
                                    std::vector<vmx_ext_read> er((size_t)n); std::vector<vmx_anchor> sa((size_t)cA + 1); std::vector<int32_t> st_((size_t)cS + 1), en_((size_t)cS + 1);
                                    (void)hipMemcpyAsync(er.data(), B.er.p, sizeof(vmx_ext_read) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
@@ -346,13 +353,15 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
                                    B.dptab.as<vmx_dp_prob>() + p0, pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_range, d_cnt,
                                    d_redo_list, d_redo_cnt, 1, ad_pct, B.tbredo.as<uint8_t>(), d_redo_bytes);
                 if (ke) (void)hipEventRecord(ke[1], c->stream);
-                hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)((pn + 63) / 64)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>() + p0, pn, prm->eqx,
-                                   tb_base, B.run.as<uint32_t>(), B.cig.as<char>(), B.ciglen.as<int32_t>() + p0, B.dpscore.as<int32_t>() + p0, B.tbredo.as<uint8_t>());
+                static const int tr_spread = [] { const char* e = getenv("VMX_TRACE_SPREAD"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 64 ? v : 1; }();
+                hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)(((int64_t)pn * tr_spread + 63) / 64)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>() + p0, pn, prm->eqx,
+                                   tb_base, B.run.as<uint32_t>(), B.cig.as<char>(), B.ciglen.as<int32_t>() + p0, B.dpscore.as<int32_t>() + p0, B.tbredo.as<uint8_t>(), tr_spread);
                 if (ke) { (void)hipEventRecord(ke[2], c->stream); c->n_gev[redo_only ? 1 : 0] = (int)q + 1; }
             }
         }
         A.redo_only = redo_only;
-        hipLaunchKernelGGL(k_ext_records, dim3(gridR), dim3(64), 0, c->stream, A, B.dptab.as<vmx_dp_prob>(), B.cig.as<char>(), B.ciglen.as<int32_t>());
+        A.spread = rec_spread;
+        hipLaunchKernelGGL(k_ext_records, dim3(gridXR), dim3(64), 0, c->stream, A, B.dptab.as<vmx_dp_prob>(), B.cig.as<char>(), B.ciglen.as<int32_t>());
         cur ^= 1;
         return cnt;
     };
