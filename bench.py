@@ -14,7 +14,7 @@ max-over-ranks time. Multi-GPU: rank 0 builds the index on its GPU and broadcast
 (vacmap_amd.dist.broadcast_index, timed separately); reads are sharded across ranks; no data-path collective (weak scaling).
 """
 import argparse, glob, json, os, sys, time
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')     # see vacmap_amd/__init__.py: must be set before the HIP runtime starts
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')     # see vacmap_amd/__init__.py: must be set before the HIP runtime starts
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -9,7 +9,7 @@ Writes a synthetic reference FASTA (BASELINE configs[1] shape: one contig, seed 
 (parse + align + SAM emission + write), reads/s and aligned Gbp/s of the read loop. Then the same reads go through
 `Pipeline.run_resident` (what bench.py times) for the comparison figure."""
 import argparse, json, os, sys, time
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
