@@ -5,12 +5,13 @@ import oracle_lib as O
 from vacmap_amd import synth
 from vacmap_amd.lib import Context, Index, align_batch, load
 ctx = Context(0); lib = load()
-print('bigverify: GPU path (vm_align_batch) vs the oracle, whole records per read', flush=True)
+SO = int(os.environ.get('BIGVERIFY_SEED_OFFSET', '0'))      # a second, independent sample of reads: BIGVERIFY_SEED_OFFSET=1000
+print('bigverify: GPU path (vm_align_batch) vs the oracle, whole records per read (read seed offset %d)' % SO, flush=True)
 if '--no-hg38' not in sys.argv:
     # the metric's defining size: hg38-size reference (24 contigs, 3.1 Gb), ONT shape in mode H k=15 and HiFi shape in mode L k=19 (config 3)
     names38 = list(synth.HG38_NAMES); c38 = synth.make_reference_fast(synth.hg38_like_lengths(), seed=3)
     for mode, k, n, kw in (('H', 15, 3000, dict(mean_len=15000, err=0.10)), ('L', 19, 1500, dict(mean_len=18000, err=0.005, shape='hifi'))):
-        cat, off, _ = synth.sample_reads_concat(c38, n, seed=177, **kw)
+        cat, off, _ = synth.sample_reads_concat(c38, n, seed=177 + SO, **kw)
         seqs = [cat[off[i]:off[i + 1]].tobytes().decode() for i in range(n)]
         gi = Index.from_seqs(ctx, names38, c38, k=k, w=10)
         t = time.time(); oi = O.Index.from_seqs(names38, c38, k=k, w=10); ti = time.time() - t
@@ -28,7 +29,7 @@ contigs = synth.make_reference([30_000_000], seed=1)
 names = ['chr1']
 for mode, k, n, kw in (('H', 15, 3000, dict(mean_len=15000, err=0.10)), ('L', 19, 1500, dict(mean_len=15000, err=0.005)), ('R', 15, 1500, dict(mean_len=12000, err=0.10)), ('S', 15, 1000, dict(mean_len=12000, err=0.13)),
                         ('H', 15, 500, dict(mean_len=45000, err=0.10)), ('H', 15, 2000, dict(mean_len=2500, err=0.15))):   # long reads (large LDS buckets, many stripes); short reads (small DP problems)
-    cat, off, _ = synth.sample_reads_concat(contigs, n, seed=77, **kw)
+    cat, off, _ = synth.sample_reads_concat(contigs, n, seed=77 + SO, **kw)
     seqs = [cat[off[i]:off[i + 1]].tobytes().decode() for i in range(n)]
     gi = Index.from_seqs(ctx, names, [contigs[0].tobytes()], k=k, w=10)
     oi = O.Index.from_seqs(names, [contigs[0].tobytes()], k=k, w=10)
@@ -54,7 +55,7 @@ for p_ in range(20_000, 5_900_000, 2500):
     ops.append(('DEL', p_, n_) if rng.random() < 0.5 else ('INS', p_, n_, int(rng.integers(1 << 30))))
 donor = synth.implant_svs(ref[0], ops)
 for mode, n, kw in (('H', 1500, dict(mean_len=12000, err=0.08)), ('R', 800, dict(mean_len=9000, err=0.08))):
-    cat, off, _ = synth.sample_reads_concat([donor], n, seed=99, **kw)
+    cat, off, _ = synth.sample_reads_concat([donor], n, seed=99 + SO, **kw)
     seqs = [cat[off[i]:off[i + 1]].tobytes().decode() for i in range(n)]
     gi = Index.from_seqs(ctx, names, [ref[0].tobytes()], k=15, w=10)
     oi = O.Index.from_seqs(names, [ref[0].tobytes()], k=15, w=10)
