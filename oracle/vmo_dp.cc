@@ -87,8 +87,8 @@ int k_cigar_global(const char* t, int64_t tl, const char* q, int64_t ql, int mat
             int32_t d = Hp[j - 1] + ((ti == qc[j - 1] && ti < 4) ? match : mismatch);
             int32_t h = d; uint8_t src = 0;
             if (e1v > h) { h = e1v; src = 1; }
-            if (e2v > h) { h = e2v; src = 2; }
             if (F1 > h) { h = F1; src = 3; }
+            if (e2v > h) { h = e2v; src = 2; }
             if (F2 > h) { h = F2; src = 4; }
             Hc[j] = h; tr[j] = b | src;
         }

@@ -129,6 +129,92 @@ def check_gapfill(ctx, O, n=64, maxlen=500, seed=4, minlen=1):
             assert cg[i] == e_cg, (i, len(ts[i]), len(qs[i]))
 
 
+def ksw2_order_cigar(t, q, match=2, mis=-4, o1=4, e1=2, o2=24, e2=1):
+    """independent pure-Python restatement of VMX-DP-G with the PUBLISHED ksw2 (ksw_extd2, left-aligned) priorities: the source of H is
+    the first of diagonal > E1 (deletion, short piece) > F1 (insertion, short piece) > E2 > F2 that is strictly larger than the ones
+    before it; a gap state continues iff its extension is strictly better than a new opening. Small inputs only."""
+    NEG = -10 ** 9
+    tl, ql = len(t), len(q)
+    mk = lambda: [[NEG] * (ql + 1) for _ in range(tl + 1)]
+    H, E1, E2, F1, F2 = mk(), mk(), mk(), mk(), mk()
+    src, x1, x2, y1, y2 = mk(), mk(), mk(), mk(), mk()
+    H[0][0] = 0
+    for i in range(tl + 1):
+        for j in range(ql + 1):
+            if i == 0 and j == 0:
+                continue
+            if i > 0:
+                a1, a2 = H[i - 1][j] - o1, H[i - 1][j] - o2
+                x1[i][j] = E1[i - 1][j] > a1; x2[i][j] = E2[i - 1][j] > a2
+                E1[i][j] = max(a1, E1[i - 1][j]) - e1; E2[i][j] = max(a2, E2[i - 1][j]) - e2
+            if j > 0:
+                c1, c2 = H[i][j - 1] - o1, H[i][j - 1] - o2
+                y1[i][j] = F1[i][j - 1] > c1; y2[i][j] = F2[i][j - 1] > c2
+                F1[i][j] = max(c1, F1[i][j - 1]) - e1; F2[i][j] = max(c2, F2[i][j - 1]) - e2
+            d = NEG
+            if i > 0 and j > 0:
+                d = H[i - 1][j - 1] + (match if (t[i - 1] == q[j - 1] and t[i - 1] in 'ACGT') else mis)
+            h, sr = d, 0
+            for kk, v in ((1, E1[i][j]), (3, F1[i][j]), (2, E2[i][j]), (4, F2[i][j])):       # state codes: 1 E1, 2 E2, 3 F1, 4 F2
+                if v > h:
+                    h, sr = v, kk
+            H[i][j] = h; src[i][j] = sr
+    ops = []; i, j, st = tl, ql, 0
+    while i > 0 or j > 0:
+        if st == 0:
+            sr = src[i][j]
+            if sr == 0:
+                ops.append('M'); i -= 1; j -= 1
+            else:
+                st = sr
+        elif st in (1, 2):
+            ext = x1[i][j] if st == 1 else x2[i][j]
+            ops.append('D'); i -= 1
+            if not ext:
+                st = 0
+        else:
+            ext = y1[i][j] if st == 3 else y2[i][j]
+            ops.append('I'); j -= 1
+            if not ext:
+                st = 0
+    ops.reverse()
+    out = []; a = 0
+    while a < len(ops):
+        b = a
+        while b < len(ops) and ops[b] == ops[a]:
+            b += 1
+        out.append('%d%s' % (b - a, ops[a])); a = b
+    return ''.join(out), H[tl][ql]
+
+
+def gapfill_tie_cases(seed=7):
+    """problems with an EXACT tie between a long-piece deletion (E2) and a short-piece insertion (F1) at the same cell: a deletion of
+    Ld >= 21 bases next to an insertion of Li <= 12 bases of an alphabet the deleted bases do not share ("delete then insert" and "insert
+    then delete" cost the same). Published ksw2 resolves it as F1 before E2, i.e. the CIGAR reads ..D..I..."""
+    import random
+    rng = random.Random(seed)
+    out = []
+    for Ld, Li in ((40, 10), (45, 6), (60, 12), (33, 8), (30, 7), (80, 11)):
+        for rep in range(3):
+            P = ''.join(rng.choice('ACGT') for _ in range(20 + 7 * rep)); S = ''.join(rng.choice('ACGT') for _ in range(25 + 5 * rep))
+            X = ''.join(rng.choice('AC') for _ in range(Ld)); Y = ''.join(rng.choice('GT') for _ in range(Li))
+            out.append((P + X + S, P + Y + S))
+            out.append((P + Y + S, P + X + S))           # the mirrored problem: a long insertion (F2) against a short deletion (E1)
+    return out
+
+
+def check_gapfill_ties(ctx, O):
+    """E5 tie order on the device: identical to the oracle on the constructed E2 = F1 ties, through both schedules"""
+    cases = gapfill_tie_cases()
+    ts = [t for t, _ in cases]; qs = [q for _, q in cases]
+    exp = [O.k_cigar_global(t, q)[0] for t, q in cases]
+    assert sum(1 for e in exp if 'D' in e and 'I' in e and e.index('D') < e.index('I')) >= len(cases) // 2 - 2
+    cg, _ = ctx.k_cigar_batch(ts, qs)
+    assert cg == exp
+    cg2, _, _ = ctx.k_cigar_batch_banded(ts, qs)
+    assert cg2 == exp
+
+
 AD_NS_MAX = 4       # mirrors of vmx_kernels.h: vmx_ad_geom / vmx_ad_margin / vmx_ad_ns (anti-diagonal band form of the gap fill)
 
 

@@ -34,6 +34,10 @@ def test_emu_gapfill(ctx, oracle):
     KC.check_gapfill(ctx, oracle, n=6, maxlen=330, seed=5)       # several 128-row stripes of the packed layout; beyond 420 cells of perimeter: int32 layout
 
 
+def test_emu_gapfill_tie_order(ctx, oracle):
+    KC.check_gapfill_ties(ctx, oracle)
+
+
 def test_emu_gapfill_banded(ctx, oracle, monkeypatch):
     """the batched path's gap-fill schedule (anti-diagonal band + proof + redo queue + layout flag) with the emulator build's small
     constants (small class up to tl + ql = 160, packed int16 up to 420). The band-width rule is pushed through all four widths with

@@ -49,6 +49,11 @@ def test_gapfill(ctx, oracle):
     KC.check_gapfill(ctx, oracle, n=3, maxlen=3600, seed=18, minlen=3300)      # tl + ql > 6000: int32 layout
 
 
+def test_gapfill_tie_order(ctx, oracle):
+    """exact E2 = F1 / E1 = F2 ties: the device follows the published ksw2 priority (diagonal > E1 > F1 > E2 > F2) like the oracle"""
+    KC.check_gapfill_ties(ctx, oracle)
+
+
 def test_gapfill_banded_schedule(ctx, oracle):
     """k_gapfill_fill_ns as vm_align_batch launches it (anti-diagonal band fill, eight problems per wave, optimality proof, redo queue, layout
     flag): CIGARs vs the oracle on adversarial shapes — |tl - ql| from 0 to beyond the widest band, indels and opposite gap pairs just

@@ -171,7 +171,7 @@ if rank == 0:
             f.write('>r%%d\n%%s\n' %% (i, cat[off[i]:off[i + 1]].tobytes().decode()))
 dist.barrier()
 from vacmap_amd import driver
-rc = driver.main(['-ref', os.path.join(tmp, 'ref.fa'), '-read', os.path.join(tmp, 'reads.fa'), '-mode', 'H', '-o', os.path.join(tmp, 'out.sam'), '-t', '1',
+rc = driver.main(['-ref', os.path.join(tmp, 'ref.fa'), '-read', os.path.join(tmp, 'reads.fa'), '-mode', 'H', '-o', os.path.join(tmp, 'out.sam'), '-t', '8',     # 2 concurrent emit jobs: the replica's host copy of the bases is decoded once, under call_once
                   '--nowriteindex', '--batch-reads', '2', '--window-batches', '2', '--force'], comm=dist)
 assert rc == 0
 if rank == 0:

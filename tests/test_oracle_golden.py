@@ -216,3 +216,24 @@ def test_primitives_properties(oracle):
     assert (sc, te, qe) == (20, 10, 10)
     sc, te, qe = oracle.k_extend('', 'ACGT')
     assert (sc, te, qe) == (0, 0, 0)
+
+
+def test_gapfill_tie_break_is_published_ksw2_order(oracle):
+    """VMX-DP-G's choice among co-optimal alignments follows minimap2's ksw_extd2 (left-aligned): diagonal > E1 > F1 > E2 > F2.
+    The oracle must equal an independent Python DP written to that order on constructed exact ties (a long-piece deletion next to a
+    short-piece insertion), and the ties must resolve as 'deletion, then insertion' in the CIGAR."""
+    import kernel_cases as KC
+    n_di = 0
+    for t, q in KC.gapfill_tie_cases():
+        exp, sc = KC.ksw2_order_cigar(t, q)
+        got, gsc = oracle.k_cigar_global(t, q)
+        assert (got, gsc) == (exp, sc), (t, q)
+        if len(t) > len(q):
+            assert 'D' in got and 'I' in got and got.index('D') < got.index('I'), got
+            n_di += 1
+    assert n_di >= 15
+    rng = np.random.default_rng(77)                      # and on ordinary small problems
+    for _ in range(40):
+        a = KC.rand_seq(rng, int(rng.integers(1, 60)))
+        b = KC.mutate(rng, a, 0.25) or 'A'
+        assert oracle.k_cigar_global(a, b) == KC.ksw2_order_cigar(a, b)

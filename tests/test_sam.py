@@ -103,7 +103,7 @@ def test_native_fastx_reader(tmp_path):
     emu_lib.context()
     L = emu_lib.context().lib
     fa = tmp_path / 'a.fa'
-    fa.write_text('>r1 first comment\nACGTacgt\nNNAC\n\n>r2\tXC:Z:tab\nGG\n>r3\n\n>r4 x\r\nAC\r\nGT\r\n')
+    fa.write_text('>r1 first comment\nACGTacgt\nNNAC\n\n>r2\tXC:Z:tab\nGG\n>r3\n\n>r4 x\r\nAC\r\nGT\r\n>r5\tRG:Z:a b\nAC\n>r6 c\td\nTT\n')
     fq = tmp_path / 'b.fq.gz'
     with gzip.open(fq, 'wt') as f:
         for i in range(70):
@@ -122,6 +122,21 @@ def test_native_fastx_reader(tmp_path):
         rd.close()
         assert got == [(n, s.upper(), q, c) for n, s, q, c in exp], path
     assert len(got) == 70
+    # the name ends at the FIRST blank or tab (kseq, what mp.fastx_read does): a tab before a blank must not leak into QNAME
+    rd = VL.Fastx(str(fa), lib=L); ch = rd.read(max_reads=16); rd.close()
+    names = [ch['names'][ch['names_off'][i]:ch['names_off'][i + 1]].tobytes().decode() for i in range(6)]
+    coms = [ch['comments'][ch['comments_off'][i]:ch['comments_off'][i + 1]].tobytes().decode() for i in range(6)]
+    assert names == ['r1', 'r2', 'r3', 'r4', 'r5', 'r6'] and coms[4] == 'RG:Z:a b' and coms[5] == 'c\td'
+    # a truncated .gz is an I/O error, not a clean end of input (the driver must not write a partial SAM and exit 0)
+    import pytest
+    raw = open(fq, 'rb').read()
+    bad = tmp_path / 'trunc.fq.gz'
+    bad.write_bytes(raw[:len(raw) // 2])
+    rd = VL.Fastx(str(bad), lib=L)
+    with pytest.raises(VL.VmxError):
+        while rd.read(max_reads=16) is not None:
+            pass
+    rd.close()
 
 
 def test_blob_gather_parts_restores_input_order():

@@ -33,11 +33,9 @@ class Aligner:
             self.index = _lib.Index.load(self.ctx, fn_idx_in)
         else:
             # the reference names its cached index <ref>.w<w>_k<k>.mmi (vacmap:326); ours is <ref>.w<w>_k<k>.vmx
-            cached = '%s.w%d_k%d.vmx' % (fn_idx_in, w, k)
-            if os.path.exists(cached):
-                self.index = _lib.Index.load(self.ctx, cached)
-            else:
-                self.index = _lib.Index.from_fasta(self.ctx, fn_idx_in, k=k, w=w)
+            # (indexfile.find_index: a cached file older than the FASTA, or one the loader rejects, is rebuilt, never trusted)
+            from .indexfile import find_index
+            self.index = find_index(self.ctx, fn_idx_in, k, w, write=False)
         self.k = self.index.k
         self.w = self.index.w
         self.seq_offset = [(n.encode(), ln, off) for n, ln, off in zip(self.index.names, self.index.lens, self.index.offsets)]

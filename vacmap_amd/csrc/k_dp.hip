@@ -175,8 +175,8 @@ __device__ __forceinline__ void vmx_gapfill_fill16(const uint8_t* __restrict__ T
                 unsigned h = vmx_pk_add(Hdiag, vmx_bfi(eqm, MATCH, MISM));
                 unsigned src = 0, m;
                 m = vmx_pk_neg(vmx_pk_sub(h, e1v)); src = vmx_bfi(m, 0x00010001u, src); h = vmx_pk_max(h, e1v);
-                m = vmx_pk_neg(vmx_pk_sub(h, e2v)); src = vmx_bfi(m, 0x00020002u, src); h = vmx_pk_max(h, e2v);
                 m = vmx_pk_neg(vmx_pk_sub(h, nF1)); src = vmx_bfi(m, 0x00030003u, src); h = vmx_pk_max(h, nF1);
+                m = vmx_pk_neg(vmx_pk_sub(h, e2v)); src = vmx_bfi(m, 0x00020002u, src); h = vmx_pk_max(h, e2v);
                 m = vmx_pk_neg(vmx_pk_sub(h, nF2)); src = vmx_bfi(m, 0x00040004u, src); h = vmx_pk_max(h, nF2);
                 b |= src;
                 *(uint16_t*)(tbs + (size_t)t * 128) = (uint16_t)vmx_pk_bytes(b);
@@ -296,8 +296,8 @@ __device__ __forceinline__ int vmx_gapfill_fill16x4(const uint8_t* __restrict__ 
                 unsigned h = vmx_pk_add(Hdiag, vmx_bfi(eqm, MATCH, MISM));                                                         \
                 unsigned src = 0, m;                                                                                               \
                 m = vmx_pk_neg(vmx_pk_sub(h, e1v)); src = vmx_bfi(m, 0x00010001u, src); h = vmx_pk_max(h, e1v);                    \
-                m = vmx_pk_neg(vmx_pk_sub(h, e2v)); src = vmx_bfi(m, 0x00020002u, src); h = vmx_pk_max(h, e2v);                    \
                 m = vmx_pk_neg(vmx_pk_sub(h, nF1)); src = vmx_bfi(m, 0x00030003u, src); h = vmx_pk_max(h, nF1);                    \
+                m = vmx_pk_neg(vmx_pk_sub(h, e2v)); src = vmx_bfi(m, 0x00020002u, src); h = vmx_pk_max(h, e2v);                    \
                 m = vmx_pk_neg(vmx_pk_sub(h, nF2)); src = vmx_bfi(m, 0x00040004u, src); h = vmx_pk_max(h, nF2);                    \
                 b |= src;                                                                                                          \
                 if (act) *(uint16_t*)(tbp + (TT) * 32) = (uint16_t)vmx_pk_bytes(b);                                                \
@@ -396,8 +396,8 @@ __device__ __forceinline__ void vmx_gapfill_fill_one(const uint8_t* __restrict__
                     int h = Hdiag + ((ti == qc_cur && ti < 4) ? match : mismatch);                                    \
                     int src = 0;                                                                                      \
                     if (e1v > h) { h = e1v; src = 1; }                                                                \
-                    if (e2v > h) { h = e2v; src = 2; }                                                                \
                     if (F1 > h) { h = F1; src = 3; }                                                                  \
+                    if (e2v > h) { h = e2v; src = 2; }                                                                \
                     if (F2 > h) { h = F2; src = 4; }                                                                  \
                     tbs[(size_t)t * 64] = (uint8_t)(b | src);                                                         \
                     Hdiag = upH; Hleft = h;                                                                           \

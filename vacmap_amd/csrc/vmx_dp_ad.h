@@ -53,8 +53,8 @@ __device__ __forceinline__ unsigned vmx_ad_cell(const vmx_ad_consts& K, unsigned
     unsigned h = vmx_pk_add(H, vmx_bfi(eqm, K.MATCH, K.MISM));
     unsigned src = 0, m;
     m = vmx_pk_neg(vmx_pk_sub(h, e1v)); src = vmx_bfi(m, 0x00010001u, src); h = vmx_pk_max(h, e1v);
+    m = vmx_pk_neg(vmx_pk_sub(h, f1v)); src = vmx_bfi(m, 0x00030003u, src); h = vmx_pk_max(h, f1v);     // ksw2's order: diagonal > E1 > F1 > E2 > F2
     m = vmx_pk_neg(vmx_pk_sub(h, e2v)); src = vmx_bfi(m, 0x00020002u, src); h = vmx_pk_max(h, e2v);
-    m = vmx_pk_neg(vmx_pk_sub(h, f1v)); src = vmx_bfi(m, 0x00030003u, src); h = vmx_pk_max(h, f1v);
     m = vmx_pk_neg(vmx_pk_sub(h, f2v)); src = vmx_bfi(m, 0x00040004u, src); h = vmx_pk_max(h, f2v);
     H = h; E1 = e1v; E2 = e2v; F1 = f1v; F2 = f2v;
     return b | src;

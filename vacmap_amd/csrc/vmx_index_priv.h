@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 
+#include <mutex>
 struct vm_index {
     vm_ctx* ctx = nullptr;
     int k = 0, w = 0, mid_occ = 10, table_bits = 0;
@@ -15,6 +16,7 @@ struct vm_index {
     int64_t n_min = 0, n_distinct = 0;
     vmx::DevBuf d_codes, d_pos, d_table, d_off;
     bool has_host_seq = true;
+    std::once_flag host_seq_once;           // replicas decode their host copy of the bases from HBM once, whichever emitter thread asks first (vmx_sam.hip)
 };
 
 static inline unsigned grid1d(int64_t n, int64_t cap = 65536) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, cap)); }

@@ -25,11 +25,15 @@ using namespace vmx;
 // ------------------------------------------------------------------------------------------------ reference bases on the host
 // upper-case bases of the whole reference: the index's host copy, or (replicas made by vm_index_from_meta) decoded once from HBM
 static const std::string& host_bases(const vm_index* mi) {
-    if (mi->has_host_seq || mi->bases.size() == (size_t)mi->offsets.back()) return mi->bases;
+    if (mi->has_host_seq) return mi->bases;
     vm_index* m = const_cast<vm_index*>(mi);
-    std::string dec((size_t)mi->offsets.back(), 'N');
-    for (size_t i = 0; i < mi->names.size(); ++i) if (mi->lens[i] > 0) vm_index_seq(mi, (int)i, 0, mi->lens[i], &dec[(size_t)mi->offsets[i]]);
-    m->bases.swap(dec);
+    // concurrent vm_sam_emit jobs share the index: exactly one of them decodes, the others wait for it (call_once), and nobody
+    // swaps the buffer under a reader afterwards
+    std::call_once(m->host_seq_once, [m] {
+        std::string dec((size_t)m->offsets.back(), 'N');
+        for (size_t i = 0; i < m->names.size(); ++i) if (m->lens[i] > 0) vm_index_seq(m, (int)i, 0, m->lens[i], &dec[(size_t)m->offsets[i]]);
+        m->bases.swap(dec);
+    });
     return mi->bases;
 }
 
@@ -353,7 +357,7 @@ int64_t vm_blob_gather_parts(const char* const* blobs, const int64_t* const* off
 // ------------------------------------------------------------------------------------------------ FASTA / FASTQ(.gz) reader
 // Plain files are read with read(2) straight into the line buffer (gzread's transparent mode costs a copy); gzip members go through zlib.
 // The output blobs grow by realloc (large blocks move by remapping, not by copying) and are handed to the caller as they are.
-struct vm_fastx { gzFile f = nullptr; int fd = -1; char* buf = nullptr; size_t cap = 0, len = 0, pos = 0; bool eof = false; size_t hint = 0; };
+struct vm_fastx { gzFile f = nullptr; int fd = -1; char* buf = nullptr; size_t cap = 0, len = 0, pos = 0; bool eof = false, io_error = false; size_t hint = 0; };
 
 struct Blob {
     char* p = nullptr; size_t n = 0, cap = 0;
@@ -383,6 +387,8 @@ static bool fx_fill(vm_fastx* x) {
     if (x->f) n = gzread(x->f, x->buf + x->len, (unsigned)want);
     else { do { n = (long)read(x->fd, x->buf + x->len, want); } while (n < 0 && errno == EINTR); }
     if (n > 0) x->len += (size_t)n; else x->eof = true;
+    if (n < 0) x->io_error = true;                       // a truncated or corrupt .gz (or a read error) is not a clean end of input
+    else if (n == 0 && x->f) { int ze = Z_OK; (void)gzerror(x->f, &ze); if (ze != Z_OK && ze != Z_STREAM_END) x->io_error = true; }
     return n > 0;
 }
 // next line as a VIEW into the read buffer (valid until the next call), without its terminator; false at end of input.
@@ -438,9 +444,9 @@ int64_t vm_fastx_read(vm_fastx* x, int64_t max_reads, int64_t max_bases, char** 
             if (len == 0) continue;
             if (p[0] != '>' && p[0] != '@') { set_error("not FASTA/FASTQ: " + std::string(p, len < 40 ? len : 40)); return VM_ERR_IO; }
             const bool fq = p[0] == '@';
-            {   // name | comment: at the first blank, else at the first tab (driver.read_fastx)
-                const char* sp = (const char*)memchr(p + 1, ' ', len - 1);
-                if (!sp || sp + 1 == p + len) { const char* tb = (const char*)memchr(p + 1, '\t', len - 1); if (!sp) sp = tb; else if (tb && tb < sp) sp = tb; }
+            {   // name | comment: at the first blank or tab, whichever comes first (kseq's rule, which mp.fastx_read follows, vacmap:445)
+                const char* sp = nullptr;
+                for (size_t i = 1; i < len; ++i) if (p[i] == ' ' || p[i] == '\t') { sp = p + i; break; }
                 if (sp) { nb.append(p + 1, (size_t)(sp - p - 1)); cb.append(sp + 1, (size_t)(p + len - sp - 1)); } else nb.append(p + 1, len - 1);
             }
             if (fq) {
@@ -459,6 +465,7 @@ int64_t vm_fastx_read(vm_fastx* x, int64_t max_reads, int64_t max_bases, char** 
             no.push_back((int64_t)nb.n); so.push_back((int64_t)sb.n); qo.push_back((int64_t)qb.n); co.push_back((int64_t)cb.n);
             ++n;
         }
+        if (x->io_error) { set_error("read error or truncated / corrupt compressed input"); return VM_ERR_IO; }
         if (sb.n > x->hint) x->hint = sb.n + sb.n / 16;
         auto giveo = [](const std::vector<int64_t>& v, int64_t** p) { *p = (int64_t*)malloc(8 * v.size()); memcpy(*p, v.data(), 8 * v.size()); };
         *names = nb.release(); *seqs = sb.release(); *quals = qb.release(); *comments = cb.release();

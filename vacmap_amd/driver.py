@@ -34,20 +34,24 @@ def read_fastx(path, want_comment=False):
                 line = f.readline()
                 while line and line[0] != '>':
                     seqs.append(line.strip()); line = f.readline()
-                name, _, com = head.partition(' ')
-                if not com and '\t' in name:
-                    name, _, com = head.partition('\t')
+                name, com = _split_header(head)
                 yield name, ''.join(seqs), None, (com if want_comment and com else None)
             elif line[0] == '@':
                 head = line[1:]
                 seq = f.readline().strip(); f.readline(); qual = f.readline().strip()
-                name, _, com = head.partition(' ')
-                if not com and '\t' in name:
-                    name, _, com = head.partition('\t')
+                name, com = _split_header(head)
                 yield name, seq, qual, (com if want_comment and com else None)
                 line = f.readline()
             else:
                 raise ValueError('not FASTA/FASTQ: %r' % line[:40])
+
+
+def _split_header(head):
+    """name | comment at the first blank or tab (kseq's rule)"""
+    for i, ch in enumerate(head):
+        if ch == ' ' or ch == '\t':
+            return head[:i], head[i + 1:]
+    return head, ''
 
 
 _BAM_NT16 = '=ACMGRSVTWYHKDBN'
@@ -162,6 +166,13 @@ def main(argv=None, comm=None):
         torch.cuda.set_device(local_rank)
         comm.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
         own_group = True
+    text_group = None
+    if own_group:
+        # SAM text is host data gathered from a writer THREAD: a gloo (CPU) group suits it — an object gather over the nccl group would
+        # stage its byte tensors on the calling thread's current device (cuda:0 in a new thread), not the rank's — and its timeout turns
+        # a peer that died into an error instead of a hang
+        import datetime
+        text_group = comm.new_group(backend='gloo', timeout=datetime.timedelta(seconds=int(os.environ.get('VMX_GATHER_TIMEOUT', '1800'))))
     if comm is not None:
         world, rank = comm.get_world_size(), comm.get_rank()
     if rank == 0 and args.o != '-' and os.path.exists(args.o) and not args.force:
@@ -253,6 +264,19 @@ def main(argv=None, comm=None):
                     if len(ch['seqs_off']) > 1:
                         yield ch
 
+    prog = {'t0': time.time(), 't': time.time(), 'n': 0, 'next': 100000}
+
+    def progress(count):
+        """the reference's progress line, every 100 000 sequences (vacmap:498-514)"""
+        if rank != 0 or count < prog['next']:
+            return
+        now = time.time()
+        dt, tt = max(now - prog['t'], 0.001), max(now - prog['t0'], 0.001)
+        sys.stderr.write('%d / sec in the last %d minutes, %d / sec AVG. %d sequences processed.\n'
+                         % (round((count - prog['n']) / dt), max(round(dt / 60), 1), round(count / tt), count))
+        prog['t'], prog['n'] = now, count
+        prog['next'] = (count // 100000 + 1) * 100000
+
     tm = {'setup': time.time() - t_start, 'wait_input': 0.0, 'assemble_write': 0.0, 'job_gather': 0.0, 'job_align': 0.0, 'job_emit': 0.0}
     tml = threading.Lock()
     errs = []
@@ -273,7 +297,10 @@ def main(argv=None, comm=None):
     def job_source():
         """(window, batch index) in schedule order; a window is planned when the first worker reaches it"""
         while not errs:
-            slots.acquire()
+            while not slots.acquire(timeout=0.2):       # (never parked for good: a failure elsewhere must end the run, not hang it)
+                if errs:
+                    oq.put(None)
+                    return
             t0 = time.time()
             wnd = wq.get()
             with tml:
@@ -284,6 +311,7 @@ def main(argv=None, comm=None):
                 slots.release()
                 break
             counts['reads'] += len(wnd['seqs_off']) - 1
+            progress(counts['reads'])
             plan = pipeline.plan_batches(np.diff(wnd['seqs_off']), args.batch_reads, args.window_batches)
             plan = [plan[i] for i in range(rank, len(plan), world)]        # static sharding: batch i -> rank i mod N
             w = Window(wnd, plan)
@@ -336,13 +364,17 @@ def main(argv=None, comm=None):
                     if errs:
                         return
                 done = [f.result() for f in w.futs]
-                counts['lines'] += sum(r[3] for r in done); counts['skipped'] += sum(r[4] for r in done)
+                nl, ns = sum(r[3] for r in done), sum(r[4] for r in done)
                 parts = [(ix, text, toff) for ix, text, toff, _, _ in done]
                 t0 = time.time()
                 if world > 1:
                     from .dist import gather_lines
-                    allp = gather_lines(parts, dst=0)
-                    parts = [p for rp in allp for p in rp] if rank == 0 else []
+                    allp = gather_lines((parts, nl, ns), dst=0, group=text_group)
+                    if rank == 0:
+                        parts = [p for rp in allp for p in rp[0]]; nl = sum(rp[1] for rp in allp); ns = sum(rp[2] for rp in allp)
+                    else:
+                        parts = []
+                counts['lines'] += nl; counts['skipped'] += ns
                 if parts:
                     txt = blob_gather_parts(lib, [p[1] for p in parts], [p[2] for p in parts], [p[0] for p in parts])
                     out.write(memoryview(txt))
@@ -352,7 +384,9 @@ def main(argv=None, comm=None):
                     tm['assemble_write'] += time.time() - t0
         except BaseException as e:
             errs.append(e)
-            slots.release()
+        finally:
+            for _ in range(3):                          # whatever ended the writer, nobody stays parked on a window slot
+                slots.release()
 
     wq = queue.Queue(maxsize=2)
 
@@ -394,6 +428,8 @@ def main(argv=None, comm=None):
             out.close()
         else:
             out.flush()
+        tt = max(time.time() - prog['t0'], 0.001)     # vacmap:535-541
+        sys.stderr.write('User time (h:m:s): %d:%d:%d %d / sec AVG. %d sequences processed.\n' % (tt // 3600, (tt % 3600) // 60, tt % 60, round(counts['reads'] / tt), counts['reads']))
         sys.stderr.write('vacmapx: %d reads, %d SAM lines, %d reads skipped\n' % (counts['reads'], counts['lines'], counts['skipped']))
     if own_group:
         comm.barrier(); comm.destroy_process_group()

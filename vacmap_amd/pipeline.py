@@ -13,7 +13,7 @@ drives one GPU:
 
 `bench.py` times `Pipeline.run_resident` (reads already in HBM); `vacmap_amd/driver.py` feeds `Pipeline.run_host` from its FASTX /
 BAM reader. The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); a batch drives one main
-and four side streams, so the package asks for 8 before the runtime starts (vacmap_amd/__init__.py).
+and four side streams, so the package asks for 16 before the runtime starts (vacmap_amd/__init__.py).
 """
 import threading
 
