@@ -1,5 +1,6 @@
 """Shared parity checks: the HIP path (real library on a GPU, or its emulator build in CPU tests) against the oracle.
 `ctx` is a vacmap_amd.lib.Context; `O` is tests/oracle_lib."""
+import re
 import numpy as np
 
 
@@ -622,3 +623,57 @@ def check_stage_trace_golden(ctx, O, golden, cases=('A', 'B', 'I'), reads=None):
                 assert np.array_equal(_end_markers(got[5][x]), _end_markers(arrays[fix[0]['out']])), (cid, ri, 'merge_conjacent + fix_simple_inv')
                 checked[5] += 1
     return checked
+
+
+def check_reference_call_shapes(ctx, O, golden, small=False):
+    """The three exports that carry the reference's own call shape, and the `vacmap_index`-shaped shim on top of them (vacmap_amd/aligner.py),
+    against the oracle and against their batched siblings:
+      index_object.map(seq, check_num=, mid_occ=)                         mammap_clrnano.py:23985   -> vm_map
+      mp.k_cigar(t, q, 2, -4, 4, 2, 24, 1, bw=-1, zdropvalue=-1, eqx=)     :21554, :21598           -> vm_k_cigar (global, traceback)
+      mp.k_cigar(t, q, 2, -4, 4, 4, 4, 4, bw=100, zdropvalue=50)           :2381, :2410, :2477, :2505 -> vm_k_cigar (z-drop extension: q_e, t_e)
+      edlib.align(query=, target=, task='distance')['editDistance']       :19251                   -> vm_edit_distance"""
+    from vacmap_amd import aligner as AL
+    meta, arrays = golden
+    gi, oi = _case_index(ctx, O, meta, arrays, 'A')
+    AL.use_context(ctx)
+    al = AL.Aligner(index=gi, ctx=ctx)
+    # the Aligner surface the reference reads (vacmap:344-363, :24024)
+    assert bool(al) and al.k == 15 and al.w == 10
+    assert [(n.decode(), ln, off) for n, ln, off in al.seq_offset] == list(zip(gi.names, gi.lens, gi.offsets))
+    c0 = arrays['A_contig0'].tobytes().decode()
+    assert al.seq(gi.names[0]) == c0 and al.seq(gi.names[0], 100, 260) == c0[100:260]
+    rng = np.random.default_rng(91)
+    read = arrays['A_r0_seq'].tobytes().decode()
+    pieces = [read[:3000], read[7000:7000 + (1500 if small else 6000)], mutate(rng, c0[2000:4000], 0.1), 'ACGT' * 5, 'A']
+    for sq in pieces:
+        for cn, mo in ((100, -1), (-1, -1), (3, 50)):
+            rows = al.map(sq, check_num=cn, mid_occ=mo)
+            exp = [tuple(int(v) for v in r) for r in oi.map(sq, check_num=cn, mid_occ=mo)]
+            assert rows == exp, (len(sq), cn, mo, len(rows), len(exp))
+            assert rows == [tuple(int(v) for v in r) for r in ctx.map_batch(gi, [sq], check_num=cn, mid_occ=mo)[0]]
+    # k_cigar, global parameterisation
+    ts, qs = [], []
+    for i in range(6 if small else 24):
+        a = rand_seq(rng, int(rng.integers(1, 120 if small else 420)))
+        b = mutate(rng, a, float(rng.choice([0.0, 0.1, 0.25]))) or 'C'
+        ts.append(a); qs.append(b)
+    ts += [t for t, _ in gapfill_tie_cases()[:4]]; qs += [q for _, q in gapfill_tie_cases()[:4]]
+    for eqx in (False, True):
+        batch, bsc = ctx.k_cigar_batch(ts, qs, eqx=eqx)
+        for i, (t, q) in enumerate(zip(ts, qs)):
+            cg, zc, q_e, t_e, nd, ni = AL.k_cigar(t, q, match=2, mismatch=-4, gap_open_1=4, gap_extend_1=2, gap_open_2=24, gap_extend_2=1, bw=-1, zdropvalue=-1, eqx=eqx)
+            assert cg == O.k_cigar_global(t, q, eqx=eqx)[0] == batch[i], (i, eqx)
+            assert (q_e, t_e) == (len(q), len(t))
+            ql = sum(int(n) for n, op in re.findall(r'(\d+)([MIDX=])', cg) if op in 'MIX=')
+            assert ql == len(q)                                  # what the reference asserts on the merged CIGAR (:20779-20781)
+    # k_cigar, z-drop extension parameterisation: the reference uses q_e / t_e only
+    es, et, eq = ctx.k_extend_batch(ts, qs, 2, -4, 4, 4, 100, 50)
+    for i, (t, q) in enumerate(zip(ts, qs)):
+        cg, zc, q_e, t_e, nd, ni = AL.k_cigar(t, q, 2, -4, 4, 4, 4, 4, bw=100, zdropvalue=50)
+        osc, ote, oqe = O.k_extend(t, q, 2, -4, 4, 4, 100, 50)
+        assert (t_e, q_e) == (ote, oqe) == (int(et[i]), int(eq[i])), i
+    # edlib.align(...)['editDistance']
+    eb = ctx.edit_distance_batch(qs, ts)
+    for i, (t, q) in enumerate(zip(ts, qs)):
+        d = AL.edlib_align(query=q, target=t, task='distance')['editDistance']
+        assert d == O.edit_distance(q, t) == int(eb[i]), i

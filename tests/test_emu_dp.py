@@ -34,6 +34,10 @@ def test_emu_gapfill(ctx, oracle):
     KC.check_gapfill(ctx, oracle, n=6, maxlen=330, seed=5)       # several 128-row stripes of the packed layout; beyond 420 cells of perimeter: int32 layout
 
 
+def test_emu_reference_call_shapes(ctx, oracle, golden):
+    KC.check_reference_call_shapes(ctx, oracle, golden, small=True)
+
+
 def test_emu_gapfill_tie_order(ctx, oracle):
     KC.check_gapfill_ties(ctx, oracle)
 

@@ -34,6 +34,12 @@ def test_extend(ctx, oracle):
     KC.check_extend(ctx, oracle, n=8, seed=15, maxlen=6000)
 
 
+def test_reference_call_shapes(ctx, oracle, golden):
+    """vm_map, vm_k_cigar (both live parameterisations) and vm_edit_distance — the entries a maintainer keeping the reference's Python
+    would bind — through vacmap_amd/aligner.py, vs the oracle and vs the batched entries"""
+    KC.check_reference_call_shapes(ctx, oracle, golden)
+
+
 def test_seed_many_hits(ctx, oracle):
     """k_cluster_big: reads with more hits than one / several 16384-key LDS tiles (tiled bitonic sort with its HBM steps)"""
     KC.check_seed_many_hits(ctx, oracle, copies=44, unit=2500, read_len=4500, seed=61, min_hits=9000)

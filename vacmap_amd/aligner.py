@@ -24,6 +24,12 @@ def context(device=0):
     return _ctx
 
 
+def use_context(ctx):
+    """bind the module-level calls (k_cigar, edlib_align) to an existing context"""
+    global _ctx
+    _ctx = ctx
+
+
 class Aligner:
     def __init__(self, fn_idx_in=None, w=10, k=15, device=0, ctx=None, index=None, **kw):
         self.ctx = ctx or context(device)
@@ -48,7 +54,7 @@ class Aligner:
         return self.index.seq(self._name2i[name], start, end)
 
     def map(self, seq, check_num=100, mid_occ=-1):
-        rows = self.ctx.map_batch(self.index, [seq], check_num=check_num, mid_occ=mid_occ)[0]
+        rows = self.ctx.map(self.index, seq, check_num=check_num, mid_occ=mid_occ)            # vm_map, the reference's call shape
         return [tuple(int(v) for v in r) for r in rows]
 
     def save(self, path):

@@ -182,7 +182,8 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             const int NN = status ? 0 : N;
             for (int i = (int)threadIdx.x; i < NN; i += (int)blockDim.x) GKEY[i] = i < m ? (((uint64_t)G[i].r << 24) | (uint64_t)i) : ~0ULL;
             __syncthreads();
-            if (NN > 1) vmx_block_sort_u64_tiled(GKEY, NN, s_sort, VMX_SORT_LDS);
+            int gk_lds = 0;                                       // does the sort leave the sorted guide keys in its LDS tile, and in which order
+            if (NN > 1) gk_lds = vmx_block_sort_u64_tiled(GKEY, NN, s_sort, VMX_SORT_LDS);
             // guide in ascending read order (:23183) = reverse of the stored descending order; read positions are distinct
             const bool g_lds = mm <= VMX_GUIDE_LDS;
             for (int i = (int)threadIdx.x; i < mm; i += (int)blockDim.x) {
@@ -195,17 +196,17 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             // --- windows (serial, thread 0): :23105-23180
             if (threadIdx.x == 0) {
                 // the block sort leaves the sorted keys in its LDS staging buffer when they fit: walk them there, not in HBM
-                const uint64_t* GK = (NN > 1 && NN <= VMX_SORT_LDS) ? s_sort : GKEY;
+                auto GK = [&](int i) -> uint64_t { return gk_lds == 2 ? s_sort[vmx_sw(i)] : (gk_lds == 1 ? s_sort[i] : GKEY[i]); };
                 int niv = 0; bool overflow = false;
                 for (int attempt = 0; attempt < 2 && mm > 0; ++attempt) {
                     const bool split = attempt == 1;
                     niv = 0; bool retry = false;
-                    long long ws = (long long)(GK[0] >> 24), we = ws;
+                    long long ws = (long long)(GK(0) >> 24), we = ws;
                     int cur = vmx_pos2contig(A.coff, A.nseq, ws);
                     for (int i = 1; i <= mm; ++i) {
                         bool close_it = true; long long rr = 0;
                         if (i < mm) {
-                            rr = (long long)(GK[i] >> 24);
+                            rr = (long long)(GK(i) >> 24);
                             bool same = (rr - we) < readgap;
                             if (split) same = same && (cur == vmx_pos2contig(A.coff, A.nseq, rr));
                             if (same) { we = rr; close_it = false; }

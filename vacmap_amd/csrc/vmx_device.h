@@ -269,9 +269,85 @@ __device__ __forceinline__ void vmx_block_bitonic_passes(uint64_t* a, int N) {
         }
     }
 }
+// ---- register-blocked bitonic sort of an LDS tile -------------------------------------------------------------------------------
+// The plain passes above make one LDS round trip and one barrier per (k, j) stage — 105 of them for 16384 keys — with half of the
+// threads idle. Here a thread takes SIXTEEN keys whose indices differ in four consecutive bits [b, b + 4) into registers and runs up to
+// four stages (j = 2^(b+3) .. 2^b) on them before they go back: 29 round trips for 16384 keys, every thread busy, the compare-exchange
+// network fully unrolled. The first round trip sorts every run of 16 consecutive keys outright (phases k = 2 .. 16, ten stages).
+// Keys live in LDS in a swizzled order, slot(i) = i ^ ((i >> 4) & 15): whatever four bits a round trip spreads over the registers, the
+// sixteen lanes that issue together touch sixteen different 8-byte bank pairs (a linear layout would put the 128-byte strides of the
+// low-bit round trips on one bank). vmx_sw() maps an index to its slot for callers that read the sorted tile in place.
+__device__ __forceinline__ int vmx_sw(int i) { return i ^ ((i >> 4) & 15); }
+__device__ __forceinline__ void vmx_ce_u64(uint64_t& x, uint64_t& y, bool asc) {
+    const bool sw = (x > y) == asc;
+    const uint64_t lo = sw ? y : x, hi = sw ? x : y;
+    x = lo; y = hi;
+}
+// one round trip: stages j = 2^(b + nst - 1) .. 2^b of phase k (k > 2^(b+3): one direction per thread), or with first = true the whole
+// of phases 2 .. 16 on runs of 16 consecutive keys (b = 0). gbase: global index of lds[0] (tiled sorts), fixed_dir >= 0 forces the direction.
+__device__ __forceinline__ void vmx_bitonic_roundtrip(uint64_t* lds, int N, int gbase, int k, int b, int nst, bool first) {
+    const int T = (int)blockDim.x;
+    for (int g = (int)threadIdx.x; g < (N >> 4); g += T) {
+        const int base = ((g >> b) << (b + 4)) | (g & ((1 << b) - 1));
+        uint64_t r[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) r[m] = lds[vmx_sw(base | (m << b))];
+        if (first) {
+            const bool asc16 = ((gbase + base) & 16) == 0;
+#pragma unroll
+            for (int kk = 2; kk <= 16; kk <<= 1)
+#pragma unroll
+                for (int jj = kk >> 1; jj > 0; jj >>= 1)
+#pragma unroll
+                    for (int m = 0; m < 16; ++m)
+                        if ((m ^ jj) > m) vmx_ce_u64(r[m], r[m ^ jj], kk == 16 ? asc16 : ((m & kk) == 0));
+        } else {
+            const bool asc = ((gbase + base) & k) == 0;
+            if (nst >= 4) {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) if (!(m & 8)) vmx_ce_u64(r[m], r[m | 8], asc);
+            }
+            if (nst >= 3) {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) if (!(m & 4)) vmx_ce_u64(r[m], r[m | 4], asc);
+            }
+            if (nst >= 2) {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) if (!(m & 2)) vmx_ce_u64(r[m], r[m | 2], asc);
+            }
+#pragma unroll
+            for (int m = 0; m < 16; ++m) if (!(m & 1)) vmx_ce_u64(r[m], r[m | 1], asc);
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) lds[vmx_sw(base | (m << b))] = r[m];
+    }
+    __syncthreads();
+}
+// stages j = 2^e .. 1 of phase k on the swizzled tile (e < log2 N; k > 2^e)
+__device__ __forceinline__ void vmx_bitonic_phase_tail(uint64_t* lds, int N, int gbase, int k, int e) {
+    while (e >= 0) {
+        const int b = e >= 3 ? e - 3 : 0;
+        vmx_bitonic_roundtrip(lds, N, gbase, k, b, e - b + 1, false);
+        e = b - 1;
+    }
+}
+// all phases k = 2 .. kmax of a swizzled tile of N >= 16 keys (N a power of two). every thread of the workgroup must call it.
+__device__ __forceinline__ void vmx_bitonic_tile_sw(uint64_t* lds, int N, int gbase, int kmax) {
+    vmx_bitonic_roundtrip(lds, N, gbase, 16, 0, 4, true);
+    for (int k = 32, p = 5; k <= kmax; k <<= 1, ++p) vmx_bitonic_phase_tail(lds, N, gbase, k, p - 1);
+}
+// is the register-blocked form worth it? it needs 16 keys per working thread; below a quarter of the workgroup the plain passes win
+__device__ __forceinline__ bool vmx_bitonic_fast_ok(int N) { return N >= 64 && (N >> 4) >= ((int)blockDim.x >> 2); }
+
 // (the passes are instantiated once on the LDS buffer and once on the HBM array: a pointer chosen at run time would make them flat accesses)
 __device__ inline void vmx_block_sort_u64_impl(uint64_t* g, int N, uint64_t* lds, int lds_cap) {
-    if (N <= lds_cap) {
+    if (N <= lds_cap && vmx_bitonic_fast_ok(N)) {
+        for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) lds[vmx_sw(i)] = g[i];
+        __syncthreads();
+        vmx_bitonic_tile_sw(lds, N, 0, N);
+        for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) g[i] = lds[vmx_sw(i)];
+        __syncthreads();
+    } else if (N <= lds_cap) {
         for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) lds[i] = g[i];
         __syncthreads();
         vmx_block_bitonic_passes(lds, N);
@@ -287,17 +363,37 @@ __device__ inline void vmx_block_sort_u64_impl(uint64_t* g, int N, uint64_t* lds
 // a tile, run the stages, store it), only the few steps with partner distance >= tile touch HBM (coalesced: thread i and thread i + 1
 // touch neighbouring keys). N = 4 tiles: 3 HBM steps and 3 LDS residencies per tile instead of 120 HBM passes.
 // every thread of the workgroup must call it.
-__device__ inline void vmx_block_sort_u64_tiled(uint64_t* g, int N, uint64_t* lds, int tile) {
+// Returns 0 when the LDS buffer holds nothing the caller may use, 1 when it holds the N sorted keys in plain order, 2 when it holds them
+// in swizzled order (key i at lds[vmx_sw(i)]).
+__device__ inline int vmx_block_sort_u64_tiled(uint64_t* g, int N, uint64_t* lds, int tile) {
     const int T = (int)blockDim.x, tid = (int)threadIdx.x;
     if (N <= tile) {
+        if (vmx_bitonic_fast_ok(N)) {
+            for (int i = tid; i < N; i += T) lds[vmx_sw(i)] = g[i];
+            __syncthreads();
+            vmx_bitonic_tile_sw(lds, N, 0, N);
+            for (int i = tid; i < N; i += T) g[i] = lds[vmx_sw(i)];
+            __syncthreads();
+            return 2;
+        }
         for (int i = tid; i < N; i += T) lds[i] = g[i];
         __syncthreads();
         vmx_block_bitonic_passes(lds, N);
         for (int i = tid; i < N; i += T) g[i] = lds[i];
         __syncthreads();
-        return;
+        return 1;
     }
+    const bool fast = vmx_bitonic_fast_ok(tile);
+    int ltile = 0; while ((1 << ltile) < tile) ++ltile;
     for (int base = 0; base < N; base += tile) {                // all stages k <= tile, tile by tile (direction from the global index)
+        if (fast) {
+            for (int i = tid; i < tile; i += T) lds[vmx_sw(i)] = g[base + i];
+            __syncthreads();
+            vmx_bitonic_tile_sw(lds, tile, base, tile);
+            for (int i = tid; i < tile; i += T) g[base + i] = lds[vmx_sw(i)];
+            __syncthreads();
+            continue;
+        }
         for (int i = tid; i < tile; i += T) lds[i] = g[base + i];
         __syncthreads();
         for (int k = 2; k <= tile; k <<= 1)
@@ -320,6 +416,14 @@ __device__ inline void vmx_block_sort_u64_tiled(uint64_t* g, int N, uint64_t* ld
             __syncthreads();
         }
         for (int base = 0; base < N; base += tile) {            // the remaining steps of this stage stay inside a tile
+            if (fast) {
+                for (int i = tid; i < tile; i += T) lds[vmx_sw(i)] = g[base + i];
+                __syncthreads();
+                vmx_bitonic_phase_tail(lds, tile, base, k, ltile - 1);
+                for (int i = tid; i < tile; i += T) g[base + i] = lds[vmx_sw(i)];
+                __syncthreads();
+                continue;
+            }
             for (int i = tid; i < tile; i += T) lds[i] = g[base + i];
             __syncthreads();
             const bool asc = (base & k) == 0;                   // k >= 2 * tile: one direction per tile
@@ -334,6 +438,7 @@ __device__ inline void vmx_block_sort_u64_tiled(uint64_t* g, int N, uint64_t* ld
             __syncthreads();
         }
     }
+    return 0;
 }
 
 // block-wide STABLE LSD radix sort of n uint64 keys on the bit field [(key >> shift) - base] & (2^nbits - 1), 4 bits per pass,

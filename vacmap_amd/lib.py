@@ -332,6 +332,15 @@ class Context:
         H = self._take(h, m, np.uint64); Pp = self._take(p, m, np.int32); Z = self._take(z, m, np.int8)
         return [(H[o[i]:o[i + 1]], Pp[o[i]:o[i + 1]], Z[o[i]:o[i + 1]]) for i in range(n)]
 
+    def map(self, index, seq, check_num=100, mid_occ=-1):
+        """vm_map: the reference's per-read call `index_object.map(seq, check_num=, mid_occ=)` (mammap_clrnano.py:23985) -> (n, 4) int64 rows"""
+        sq = _b(seq)
+        a = C.POINTER(C.c_int64)(); n = C.c_int64(0)
+        self.lib.check(self.lib.L.vm_map(self.h, index.h, sq, len(sq), int(check_num), int(mid_occ), C.byref(a), C.byref(n)))
+        rows = np.ctypeslib.as_array(a, shape=(max(n.value, 1), 4))[:n.value].copy()
+        self.lib.L.vm_free(a)
+        return rows
+
     def map_batch(self, index, seqs, check_num=100, mid_occ=-1):
         s, off = _cat(seqs)
         n = len(seqs)
