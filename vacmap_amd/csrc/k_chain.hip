@@ -331,40 +331,86 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ G1 select
+// One wavefront per read. `rlist` (nlist reads, nullptr = reads 0 .. nlist-1) is one size class: `lds_cap` anchors fit the dynamic LDS
+// (17 B each: S, P, S_arg and the `used` flags of the serial peel; lds_cap = 0: everything stays in HBM). After the peel the same LDS
+// holds the small arrays of the ranking step. Phases:
+//   1 wave   stage S / P / S_arg, clear `used`
+//   2 lane 0 the peel (dependent walks S_arg -> used -> P at LDS latency); chain lists go to the read's scratch in HBM (stores only)
+//   3 wave   read positions of the chain nodes (cq[t] = A[cidx[t]].q: the loads lane 0 used to make one after the other at HBM latency)
+//   4 lane 0 order / read bins / primaries / MAPQ / secondaries on LDS arrays
+//   5 wave   copy of the selected paths (decode_hit :23981-24020)
 __global__ void __launch_bounds__(64) k_chain_select(const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ aoff, const int64_t* __restrict__ readlens,
-                               int n_reads, const double* __restrict__ S, const int32_t* __restrict__ P, const int32_t* __restrict__ SA,
+                               const int32_t* __restrict__ rlist, int nlist, int lds_cap, const double* __restrict__ S, const int32_t* __restrict__ P, const int32_t* __restrict__ SA,
                                const int64_t* __restrict__ gmax, const int32_t* __restrict__ need_reverse, int mode,
                                char* __restrict__ scratch, const int64_t* __restrict__ scratch_off,
                                int32_t* __restrict__ out_mapq, double* __restrict__ out_score, int32_t* __restrict__ out_npaths,
                                int32_t* __restrict__ out_path_len, vmx_anchor* __restrict__ out_path_anchors) {
     VMX_SETPRIO(3);
-    // one wavefront per read: the wave stages S / P / S_arg and the `used` flags of the read in LDS (17 B per anchor), then lane 0 runs the
-    // serial peel on them — its dependent walks (S_arg -> used -> P -> ...) cost LDS latency instead of HBM latency. Reads of up to
-    // VMX_SELECT_LDS_FULL anchors also keep the function's scratch (chain lists, read bins: 37 B per anchor) in LDS.
-    __shared__ __attribute__((aligned(16))) char s_buf[VMX_SELECT_LDS * 17 + 64];
+    VMX_DYN_SHARED(char, s_buf);
+    __shared__ int s_hdr[4];
     const int lane = vmx_lane();
-    for (int r = (int)blockIdx.x; r < n_reads; r += (int)gridDim.x) {
+    const int lds_bytes = lds_cap * 17 + 64;
+    (void)readlens;
+    for (int x = (int)blockIdx.x; x < nlist; x += (int)gridDim.x) {
+        const int r = rlist ? rlist[x] : x;
         const int64_t a0 = aoff[r];
         const int n = (int)(aoff[r + 1] - a0);
         const bool run = n > 2 && gmax[r] >= 0;
-        const bool in_lds = run && n <= VMX_SELECT_LDS;
-        const bool full = run && n <= VMX_SELECT_LDS_FULL;
-        double* s_S = (double*)s_buf; int32_t* s_P = (int32_t*)(s_S + n); int32_t* s_SA = s_P + n;
-        char* s_scr = (char*)(s_SA + n);                                  // full tier: scratch (8-byte aligned: n * 16 bytes precede it)
-        unsigned char* s_used = (unsigned char*)(s_SA + n);               // mid tier only (the full tier keeps `used` inside its LDS scratch)
-        if (in_lds) for (int i = lane; i < n; i += 64) { s_S[i] = S[a0 + i]; s_P[i] = P[a0 + i]; s_SA[i] = SA[a0 + i]; if (!full) s_used[i] = 0; }
+        if (!run) {
+            if (lane == 0) { out_mapq[r] = 0; out_score[r] = need_reverse[r] ? -0.0 : 0.0; out_npaths[r] = 0; }
+            continue;
+        }
+        const vmx_anchor* A = anchors + a0;
+        const bool in_lds = n <= lds_cap;
+        vmx_select_scr W = vmx_select_scratch(scratch + scratch_off[r], n);
+        double* s_S = (double*)s_buf; int32_t* s_P = (int32_t*)(s_S + n); int32_t* s_SA = s_P + n; unsigned char* s_used = (unsigned char*)(s_SA + n);
+        if (in_lds) { for (int i = lane; i < n; i += 64) { s_S[i] = S[a0 + i]; s_P[i] = P[a0 + i]; s_SA[i] = SA[a0 + i]; s_used[i] = 0; } }
+        else { for (int i = lane; i < n; i += 64) W.used[i] = 0; }
         __syncthreads();
         if (lane == 0) {
-            vmx_select_out o;
-            o.mapq = 0; o.score = 0.0; o.n_paths = 0;
-            if (run) {
-                if (full) vmx_chain_select(anchors + a0, n, readlens[r], s_S, s_P, s_SA, (int)gmax[r], mode, s_scr, out_path_len + a0, out_path_anchors + a0, &o);
-                else if (in_lds) vmx_chain_select(anchors + a0, n, readlens[r], s_S, s_P, s_SA, (int)gmax[r], mode, scratch + scratch_off[r], out_path_len + a0, out_path_anchors + a0, &o, s_used);
-                else vmx_chain_select(anchors + a0, n, readlens[r], S + a0, P + a0, SA + a0, (int)gmax[r], mode, scratch + scratch_off[r], out_path_len + a0, out_path_anchors + a0, &o);
-            }
-            out_mapq[r] = o.mapq;
-            out_score[r] = need_reverse[r] ? -o.score : o.score;
-            out_npaths[r] = o.n_paths;
+            int nch;
+            if (in_lds) nch = vmx_select_peel(n, s_S, s_P, s_SA, (int)gmax[r], mode, s_used, W.cscore, W.coff, W.cidx);
+            else nch = vmx_select_peel(n, S + a0, P + a0, SA + a0, (int)gmax[r], mode, W.used, W.cscore, W.coff, W.cidx);
+            s_hdr[0] = nch; s_hdr[1] = nch > 0 ? W.coff[nch] : 0;
+        }
+        __syncthreads();
+        const int nch = s_hdr[0], w = s_hdr[1];
+        __syncthreads();
+        if (nch <= 0) {
+            if (lane == 0) { out_mapq[r] = 0; out_score[r] = need_reverse[r] ? -0.0 : 0.0; out_npaths[r] = 0; }
+            continue;
+        }
+        // the ranking step's arrays: in LDS (over the peel's, which are done with) when they fit, else in the read's HBM scratch
+        const int need = 8 * nch + 4 * (5 * nch + 4) + 8 * w + 32;
+        const bool fit = need <= lds_bytes && lds_cap > 0;
+        double* l_cscore = (double*)s_buf; int* l_coff = (int*)(l_cscore + nch); int* l_order = l_coff + nch + 1; int* l_prim = l_order + nch; int* l_sec = l_prim + nch;
+        int* l_boff = l_sec + nch; int* l_cq = l_boff + nch + 1; int* l_bins = l_cq + w;
+        if (fit) {
+            for (int c = lane; c < nch; c += 64) l_cscore[c] = W.cscore[c];
+            for (int c = lane; c <= nch; c += 64) l_coff[c] = W.coff[c];
+            for (int t = lane; t < w; t += 64) l_cq[t] = A[W.cidx[t]].q;
+        } else {
+            for (int t = lane; t < w; t += 64) W.cq[t] = A[W.cidx[t]].q;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            int mapq = 0, nsec;
+            if (fit) nsec = vmx_select_rank(nch, mode, l_cscore, l_coff, l_cq, S + a0, W.cidx, l_order, l_bins, l_boff, l_prim, l_sec, &mapq);
+            else nsec = vmx_select_rank(nch, mode, W.cscore, W.coff, W.cq, S + a0, W.cidx, W.order, W.bins, W.boff, W.prim, W.sec, &mapq);
+            const double sc = fit ? l_cscore[0] : W.cscore[0];
+            out_mapq[r] = mapq; out_score[r] = need_reverse[r] ? -sc : sc; out_npaths[r] = nsec + 1;
+            s_hdr[2] = nsec;
+        }
+        __syncthreads();
+        const int nsec = s_hdr[2];
+        // decode_hit: return_path_list = [best path] + secondaries
+        int wr = 0;
+        for (int pi = 0; pi <= nsec; ++pi) {
+            const int c = pi == 0 ? 0 : (fit ? l_sec[pi - 1] : W.sec[pi - 1]);
+            const int t0 = fit ? l_coff[c] : W.coff[c], t1 = fit ? l_coff[c + 1] : W.coff[c + 1];
+            if (lane == 0) out_path_len[a0 + pi] = t1 - t0;
+            for (int t = t0 + lane; t < t1; t += 64) out_path_anchors[a0 + wr + (t - t0)] = A[W.cidx[t]];
+            wr += t1 - t0;
         }
         __syncthreads();
     }

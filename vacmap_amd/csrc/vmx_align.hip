@@ -55,11 +55,42 @@ struct vmx_batch_bufs {
     // extend stage
     DevBuf er, coff3, soff2, segA, st, en, segA_s, st_s, en_s, segprob, dup, desc[2], rcount, oflow, probread, tl, ql, toff, qoff, tpool, qpool;
     DevBuf edout, carry, ext3, dpsz[4], dpoff[4], dptab, tb, tbredo, bnd, run, cig, ciglen, dpscore, rec, blob, bloboff, reccoff, recclen, dupd, totals;
-    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp, chunkn;
+    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp, chunkn, sellist;
     void release() { DevBuf* p = (DevBuf*)this; for (size_t i = 0; i < sizeof(*this) / sizeof(DevBuf); ++i) p[i].release(); }
 };
 static vmx_batch_bufs* batch_bufs(vm_ctx* c) { if (!c->bbufs) c->bbufs = new vmx_batch_bufs(); return c->bbufs; }
 void vmx_ctx_free_batch_bufs(vm_ctx* c) { if (c->bbufs) { c->bbufs->release(); delete c->bbufs; c->bbufs = nullptr; } }
+
+// k_chain_select by LDS size class: a read claims 17 B of LDS per anchor for its serial peel, so a launch whose reads have at most `cap`
+// anchors asks for exactly that (a fixed 52 KB claim kept three waves on a CU — and next to another batch's kernels often none);
+// reads beyond the largest class keep everything in HBM. Inside a class the reads with most anchors go first.
+int vmx_launch_chain_select(vm_ctx* c, int64_t n, const int64_t* h_aoff, DevBuf& d_list, const vmx_anchor* sorted, const int64_t* d_aoff, const int64_t* d_lens,
+                            const double* S, const int32_t* P, const int32_t* SA, const int64_t* gmax, const int32_t* flip, int mode, char* scr, const int64_t* soff,
+                            int32_t* d_mapq, double* d_score, int32_t* d_np, int32_t* plen, vmx_anchor* prow) {
+    if (n <= 0) return 0;
+    constexpr int NC = 6;
+    const int caps[NC] = {192, 384, 768, 1536, 3072, 0};
+    std::vector<int32_t> lists[NC];
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t m = h_aoff[r + 1] - h_aoff[r];
+        int q = NC - 1; for (int i = 0; i < NC - 1; ++i) if (m <= caps[i]) { q = i; break; }
+        lists[q].push_back((int32_t)r);
+    }
+    std::vector<int32_t> rl; size_t off[NC + 1];
+    for (int q = 0; q < NC; ++q) {
+        std::stable_sort(lists[q].begin(), lists[q].end(), [&](int32_t a, int32_t b) { return h_aoff[a + 1] - h_aoff[a] > h_aoff[b + 1] - h_aoff[b]; });
+        off[q] = rl.size(); rl.insert(rl.end(), lists[q].begin(), lists[q].end());
+    }
+    VMX_TRY(upload(d_list, rl.data(), rl.size(), c->stream));
+    vmx_fork fk(c);
+    for (int q = NC - 1; q >= 0; --q) {                          // the classes with the longest walks first
+        const int cnt = (int)lists[q].size(); if (!cnt) continue;
+        hipLaunchKernelGGL(k_chain_select, dim3((unsigned)cnt), dim3(64), (size_t)caps[q] * 17 + 64, fk.next(), sorted, d_aoff, d_lens, d_list.as<int32_t>() + off[q], cnt, caps[q],
+                           S, P, SA, gmax, flip, mode, scr, soff, d_mapq, d_score, d_np, plen, prow);
+    }
+    fk.join();
+    return 0;
+}
 
 #define LAUNCH1D(kernel, n, ...) hipLaunchKernelGGL(kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(((n) + 255) / 256, 4096))), dim3(256), 0, c->stream, __VA_ARGS__)
 
@@ -200,9 +231,8 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     VMX_TRY(B.res.reserve(16 * (size_t)(n + 2) + 64));
     double* d_gscore = B.res.as<double>(); int32_t* d_mapq = (int32_t*)(d_gscore + n + 1); int32_t* d_np = d_mapq + n + 1;
     VMX_TRY(B.plen.reserve(4 * (size_t)(tot + 1))); VMX_TRY(B.prow.reserve(sizeof(vmx_anchor) * (size_t)(tot + 1)));
-    hipLaunchKernelGGL(k_chain_select, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 12)), dim3(64), 0, c->stream, B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(), B.lens.as<int64_t>(), (int)n,
-                       B.S.as<double>(), B.P.as<int32_t>(), B.SA.as<int32_t>(), B.gmax.as<int64_t>(), B.flip.as<int32_t>(), prm->mode, B.scr.as<char>(), B.soff.as<int64_t>(), d_mapq,
-                       d_gscore, d_np, B.plen.as<int32_t>(), B.prow.as<vmx_anchor>());
+    VMX_TRY(vmx_launch_chain_select(c, n, h_aoff.data(), B.sellist, B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(), B.lens.as<int64_t>(), B.S.as<double>(), B.P.as<int32_t>(), B.SA.as<int32_t>(),
+                                    B.gmax.as<int64_t>(), B.flip.as<int32_t>(), prm->mode, B.scr.as<char>(), B.soff.as<int64_t>(), d_mapq, d_gscore, d_np, B.plen.as<int32_t>(), B.prow.as<vmx_anchor>()));
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));
 
     // ---------------- orient + L1-L4 local stage

@@ -2,6 +2,7 @@
 // Everything that computes runs the HIP kernels of this directory on the context's stream; there is no CPU path.
 #include "vmx_host.h"
 #include "vmx_select.h"
+#include "vmx_stage.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -465,10 +466,9 @@ int vm_chain_global_batch(vm_ctx* c, const vm_params* prm, int kmersize, int64_t
     VMX_TRY(d_res.reserve((sizeof(double) + 2 * sizeof(int32_t)) * (size_t)(n + 1) + 64));
     double* d_score = d_res.as<double>(); int32_t* d_mapq = (int32_t*)(d_score + n + 1); int32_t* d_np = d_mapq + n + 1;
     VMX_TRY(d_plen.reserve(sizeof(int32_t) * (size_t)(tot + 1))); VMX_TRY(d_prow.reserve(sizeof(vmx_anchor) * (size_t)(tot + 1)));
-    if (n) hipLaunchKernelGGL(k_chain_select, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 12)), dim3(64), 0, c->stream, d_sorted.as<vmx_anchor>(), d_aoff.as<int64_t>(),
-                              d_len.as<int64_t>(), (int)n, d_S.as<double>(), d_P.as<int32_t>(), d_SA.as<int32_t>(), d_gmax.as<int64_t>(),
-                              d_flip.as<int32_t>(), prm->mode, d_scr.as<char>(), d_soff.as<int64_t>(), d_mapq, d_score, d_np,
-                              d_plen.as<int32_t>(), d_prow.as<vmx_anchor>());
+    std::vector<int64_t> h_ao(aoff, aoff + n + 1);
+    VMX_TRY(vmx_launch_chain_select(c, n, h_ao.data(), c->b[27], d_sorted.as<vmx_anchor>(), d_aoff.as<int64_t>(), d_len.as<int64_t>(), d_S.as<double>(), d_P.as<int32_t>(), d_SA.as<int32_t>(),
+                                    d_gmax.as<int64_t>(), d_flip.as<int32_t>(), prm->mode, d_scr.as<char>(), d_soff.as<int64_t>(), d_mapq, d_score, d_np, d_plen.as<int32_t>(), d_prow.as<vmx_anchor>()));
     // download
     std::vector<int32_t> h_np((size_t)n), h_plen((size_t)tot);
     std::vector<vmx_anchor> h_prow((size_t)tot);

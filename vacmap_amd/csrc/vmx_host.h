@@ -179,8 +179,8 @@ __global__ void k_chain_global_fast(const vmx_anchor* anchors, const int64_t* ao
                                     const double* gapcost_list, double oskipcost, int omaxdiff, int maxgap, double* S_out, int32_t* P_out, int32_t* SA_out,
                                     uint8_t* cov_pool, int32_t* si_pool, int64_t* t_pool, int32_t* cnt_pool, int64_t* gmax_out, int32_t* ran, int rmode,
                                     double* FP_pool, double* PP_pool);
-__global__ void k_chain_select(const vmx_anchor* anchors, const int64_t* aoff, const int64_t* readlens, int n_reads, const double* S,
-                               const int32_t* P, const int32_t* SA, const int64_t* gmax, const int32_t* need_reverse, int mode,
+__global__ void k_chain_select(const vmx_anchor* anchors, const int64_t* aoff, const int64_t* readlens, const int32_t* rlist, int nlist, int lds_cap,
+                               const double* S, const int32_t* P, const int32_t* SA, const int64_t* gmax, const int32_t* need_reverse, int mode,
                                char* scratch, const int64_t* scratch_off, int32_t* out_mapq, double* out_score, int32_t* out_npaths,
                                int32_t* out_path_len, vmx_anchor* out_path_anchors);
 

@@ -171,8 +171,7 @@ __device__ __forceinline__ uint8_t* vmx_tb_ptr(const uint8_t* tb_pool, const uin
 #define VMX_MAX_BATCH_READS 16384
 #endif
 #define VMX_LA_SLOT(len) ((len) / 2 + 4096)   // regular local-anchor slot of a read (rows); overflowing reads are re-run with 8x .. 4096x
-#define VMX_SELECT_LDS 3072           // k_chain_select: anchors of a read whose S / P / S_arg / used flags are staged in LDS (17 B each)
-#define VMX_SELECT_LDS_FULL 960       // ... and whose scratch (37 B + 64) fits next to them: 960 * 53 + 64 <= 3072 * 17
+#define VMX_SELECT_LDS 3072           // k_chain_select: largest LDS size class (17 B per anchor: S, P, S_arg, used flags); see vmx_launch_chain_select
 #define VMX_LC_LDS_MAX_DEFAULT 13056   // reads with more local anchors than this run the chain DP on HBM-resident arrays (VMX_LC_LDS_MAX)
 #define VMX_GC_LDS_MAX_DEFAULT 13056
 #define VMX_CHAIN_LDS_MAX_SHARED 512   // ... what the chain kernels actually use (VMX_LC_LDS_MAX / VMX_GC_LDS_MAX override it): above it S / S_arg stay in HBM, where

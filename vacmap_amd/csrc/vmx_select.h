@@ -14,7 +14,7 @@
 
 struct vmx_select_out { int mapq; double score; int n_paths; };
 
-__host__ __device__ inline int64_t vmx_select_scratch_bytes(int64_t n) { return 8 * n + 4 * (7 * n + 8) + n + 64; }
+__host__ __device__ inline int64_t vmx_select_scratch_bytes(int64_t n) { return 8 * n + 4 * (8 * n + 12) + n + 64; }
 
 // |A ∩ B| of two strictly descending int lists
 __host__ __device__ inline int vmx_desc_intersect(const int* a, int na, const int* b, int nb) {
@@ -34,21 +34,24 @@ __host__ __device__ inline int vmx_desc_intersect(const int* a, int na, const in
 #else
 #define VMX_SELECT_INLINE inline
 #endif
-// `used` (n flags, all zero on entry) is either the caller's buffer or the tail of `scratch` (the overload below)
-__host__ __device__ VMX_SELECT_INLINE void vmx_chain_select(const vmx_anchor* A, int n, int64_t L, const double* S, const int32_t* P,
-                                                 const int32_t* SA, int gmax, int mode, char* scratch, int32_t* out_path_len,
-                                                 vmx_anchor* out_rows, vmx_select_out* o, unsigned char* used) {
-    (void)L;
-    double* cscore = (double*)scratch;
-    int* cidx = (int*)(cscore + n);
-    int* coff = cidx + n;            // n+1
-    int* order = coff + n + 1;       // n
-    int* bins = order + n;           // n
-    int* boff = bins + n;            // n+1
-    int* prim = boff + n + 1;        // n
-    int* sec = prim + n;             // n
+// The function is cut into the pieces k_chain_select (k_chain.hip) runs: the serial peel on lane 0 over LDS-staged S / P / S_arg / used,
+// a wave-parallel gather of the chain nodes' read positions, the serial ranking (order, read bins, primaries, MAPQ, secondaries) on
+// small arrays, and a wave-parallel copy of the selected paths. Scratch of a read in HBM (vmx_select_scratch_bytes):
+// cscore[n] f64 | cidx[n] | coff[n+1] | order[n] | bins[n] | boff[n+1] | prim[n] | sec[n] | cq[n] (+ used[n] bytes for the HBM tier).
+struct vmx_select_scr { double* cscore; int *cidx, *coff, *order, *bins, *boff, *prim, *sec, *cq; unsigned char* used; };
+__host__ __device__ inline vmx_select_scr vmx_select_scratch(char* scratch, int n) {
+    vmx_select_scr r;
+    r.cscore = (double*)scratch; r.cidx = (int*)(r.cscore + n); r.coff = r.cidx + n; r.order = r.coff + n + 1; r.bins = r.order + n;
+    r.boff = r.bins + n; r.prim = r.boff + n + 1; r.sec = r.prim + n; r.cq = r.sec + n; r.used = (unsigned char*)(r.cq + n + 2);
+    return r;
+}
+
+// hit2work_1 :23588-23640: best chain first, then every other chain end in descending-S order (S_arg), a walk stops at the first anchor
+// an earlier chain used and its score is S[end] - S[that anchor]; chains scoring <= 40 are dropped. Returns the number of chains kept,
+// or -1 when the read is unmapped (best chain <= 40, or not above the mode's accept threshold :23650). `used`: n zeroed flags.
+__host__ __device__ VMX_SELECT_INLINE int vmx_select_peel(int n, const double* S, const int32_t* P, const int32_t* SA, int gmax, int mode, unsigned char* used,
+                                                          double* cscore, int* coff, int* cidx) {
     const double accept = (mode == 0) ? 60.0 : 40.0;
-    const int sec_min_span = (mode == 3) ? 100 : 50;
     int nch = 0, w = 0;
     bool hit = false;
     const double scores = S[gmax];
@@ -58,7 +61,7 @@ __host__ __device__ VMX_SELECT_INLINE void vmx_chain_select(const vmx_anchor* A,
         if (score > 40) { hit = true; cscore[nch] = score; coff[nch] = start; ++nch; } else w = start;
     }
     const double max_scores = scores > 0 ? scores : 0;
-    if (!hit) { o->mapq = 0; o->score = 0; o->n_paths = 0; return; }   // hit == False -> unmapped whatever follows
+    if (!hit) return -1;                                 // hit == False -> unmapped whatever follows
     for (int x = n - 1; x >= 0; --x) {
         int take = SA[x];
         if (used[take]) continue;
@@ -73,7 +76,15 @@ __host__ __device__ VMX_SELECT_INLINE void vmx_chain_select(const vmx_anchor* A,
         if (score > 40) { cscore[nch] = score; coff[nch] = start; ++nch; } else w = start;
     }
     coff[nch] = w;
-    if (!(max_scores > accept)) { o->mapq = 0; o->score = 0; o->n_paths = 0; return; }
+    if (!(max_scores > accept)) return -1;
+    return nch;
+}
+
+// :23650-23707 + select_secondary_alignment :23505-23538 on the kept chains: cq[t] = read position of chain node t (A[cidx[t]].q).
+// Sg / cidx: S and the chain node list in HBM (read a few times by the secondary test). Returns the number of secondaries (sec[]).
+__host__ __device__ VMX_SELECT_INLINE int vmx_select_rank(int nch, int mode, const double* cscore, const int* coff, const int* cq, const double* Sg, const int* cidx,
+                                                          int* order, int* bins, int* boff, int* prim, int* sec, int* out_mapq) {
+    const int sec_min_span = (mode == 3) ? 100 : 50;
     // order = argsort(scores)[::-1] (stable): descending score, equal scores in descending index
     for (int c = 0; c < nch; ++c) {
         int pos = 0;
@@ -87,7 +98,7 @@ __host__ __device__ VMX_SELECT_INLINE void vmx_chain_select(const vmx_anchor* A,
         int bw = 0;
         for (int c = 0; c < nch; ++c) {
             boff[c] = bw; int last = -1;
-            for (int t = coff[c]; t < coff[c + 1]; ++t) { int b = A[cidx[t]].q / 100; if (b != last) { bins[bw++] = b; last = b; } }
+            for (int t = coff[c]; t < coff[c + 1]; ++t) { int b = cq[t] / 100; if (b != last) { bins[bw++] = b; last = b; } }
         }
         boff[nch] = bw;
     }
@@ -113,22 +124,21 @@ __host__ __device__ VMX_SELECT_INLINE void vmx_chain_select(const vmx_anchor* A,
         v = v * mm;
         v = v * log(f1);
         long long iv = (long long)v;
-        o->mapq = (int)(iv < 60 ? iv : 60);
+        *out_mapq = (int)(iv < 60 ? iv : 60);
     }
-    // select_secondary_alignment
     int nsec = 0;
     if (nch > 1) {
         const int b0 = coff[0], b1 = coff[1];   // best path, descending q
         for (int oi = 1; oi < nch; ++oi) {
             int c = order[oi];
-            int en = A[cidx[coff[c]]].q, st = A[cidx[coff[c + 1] - 1]].q;
+            int en = cq[coff[c]], st = cq[coff[c + 1] - 1];
             if (en - st < sec_min_span) continue;
             double v_en = 0.0, v_st = 0.0;
             for (int pass = 0; pass < 2; ++pass) {   // loc2score[x] = S of the best-path anchor with the largest q <= x (0 if none)
                 int x = pass == 0 ? en : st;
                 int lo = b0, hi = b1;   // first t in [b0,b1) with q <= x (q descending)
-                while (lo < hi) { int mid = (lo + hi) >> 1; if (A[cidx[mid]].q <= x) hi = mid; else lo = mid + 1; }
-                double v = lo < b1 ? S[cidx[lo]] : 0.0;
+                while (lo < hi) { int mid = (lo + hi) >> 1; if (cq[mid] <= x) hi = mid; else lo = mid + 1; }
+                double v = lo < b1 ? Sg[cidx[lo]] : 0.0;
                 if (pass == 0) v_en = v; else v_st = v;
             }
             double f1s = v_en - v_st; if (f1s < 1.0) f1s = 1.0;
@@ -138,7 +148,7 @@ __host__ __device__ VMX_SELECT_INLINE void vmx_chain_select(const vmx_anchor* A,
                 bool skip = false;
                 for (int s2 = 0; s2 < nsec; ++s2) {
                     int pc = sec[s2];
-                    int pen = A[cidx[coff[pc]]].q, pst = A[cidx[coff[pc + 1] - 1]].q;
+                    int pen = cq[coff[pc]], pst = cq[coff[pc + 1] - 1];
                     int lo = pst > st ? pst : st, hi = en < pen ? en : pen;
                     int ov = hi - lo; if (ov < 0) ov = 0;
                     if (((double)ov / (double)(en - st)) > 0.5) { skip = true; break; }
@@ -147,23 +157,7 @@ __host__ __device__ VMX_SELECT_INLINE void vmx_chain_select(const vmx_anchor* A,
             }
         }
     }
-    // decode_hit: return_path_list = [best path] + secondaries
-    int wr = 0;
-    for (int pi = 0; pi <= nsec; ++pi) {
-        int c = pi == 0 ? 0 : sec[pi - 1];
-        out_path_len[pi] = coff[c + 1] - coff[c];
-        for (int t = coff[c]; t < coff[c + 1]; ++t) out_rows[wr++] = A[cidx[t]];
-    }
-    o->n_paths = nsec + 1;
-    o->score = cscore[0];
-}
-
-__host__ __device__ VMX_SELECT_INLINE void vmx_chain_select(const vmx_anchor* A, int n, int64_t L, const double* S, const int32_t* P,
-                                                 const int32_t* SA, int gmax, int mode, char* scratch, int32_t* out_path_len,
-                                                 vmx_anchor* out_rows, vmx_select_out* o) {
-    unsigned char* used = (unsigned char*)((int*)((double*)scratch + n) + 7 * (size_t)n + 2 + 4);   // behind cscore and the seven int lists
-    for (int i = 0; i < n; ++i) used[i] = 0;
-    vmx_chain_select(A, n, L, S, P, SA, gmax, mode, scratch, out_path_len, out_rows, o, used);
+    return nsec;
 }
 
 #endif
