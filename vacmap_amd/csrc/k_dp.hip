@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(64, 4) k_gapfill_fill_ns(const uint8_t* __rest
 __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
                                 const vmx_dp_prob* __restrict__ probs, int n_prob, int eqx, const uint8_t* __restrict__ tb_pool,
                                 uint32_t* __restrict__ run_pool, char* __restrict__ cig_pool, int32_t* __restrict__ cig_len,
-                                const int32_t* __restrict__ band_flag, const uint8_t* __restrict__ redo_pool, int spread) {
+                                const int32_t* __restrict__ band_flag, const uint8_t* __restrict__ redo_pool, int spread, int32_t* __restrict__ cig_q) {
     VMX_SETPRIO(3);
     // one lane in `spread` works (like k_ext_phase: the walks of the 64 problems of a full wave diverge at every step)
     const int gt = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -610,6 +610,29 @@ __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_
     int i = tl, j = ql, state = 0;
     while (i > 0 && j > 0) {
         int b;
+        if (ns && state == 0) {
+            // Anti-diagonal layout, H state: nine steps in ten are diagonal moves (a 10 % error read), and a diagonal move keeps the diagonal
+            // x and goes back two anti-diagonals, i.e. 128 bytes. The bytes (and, for =/X, the codes) of the next eight cells down the
+            // diagonal are loaded TOGETHER and consumed as long as the path stays on it: one memory latency per eight steps instead
+            // of one per step (the walk is a chain of dependent loads, this kernel's whole cost).
+            const int x = (j - i) - dlo, l = x / (2 * ns), k = (x - 2 * ns * l) >> 1;
+            const uint8_t* cell = tb + (size_t)(i + j - 1) * 64 + (size_t)(4 * l + k);
+            int m = i < j ? i : j; if (m > 8) m = 8;
+            uint8_t bb[8], ta[8], qa[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (u < m) { bb[u] = cell[-(ptrdiff_t)128 * u]; if (eqx) { ta[u] = T[i - 1 - u]; qa[u] = Q[j - 1 - u]; } }
+            int u = 0;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                if (v == u && v < m) {
+                    const int src = bb[v] & 7;
+                    if (src == 0) { int op = 'M'; if (eqx) op = (ta[v] == qa[v] && ta[v] < 4) ? '=' : 'X'; VMX_EMIT(op); --i; --j; ++u; }
+                    else state = src;
+                }
+            }
+            if (state == 0) continue;                 // the whole batch was diagonal (or the matrix edge was reached)
+            // a gap starts at cell (i, j): the generic step below re-reads its byte in the gap state
+        }
         if (ns) { const int x = (j - i) - dlo, l = x / (2 * ns), k = (x - 2 * ns * l) >> 1; b = tb[(size_t)(i + j - 1) * 64 + (size_t)(4 * l + k)]; }
         else if (x4) { const int s = (i - 1) >> 5, r = (i - 1) & 31, t = (j - 1) + r; b = tb[(((size_t)s * (size_t)W + (size_t)t) * 16 + (r >> 1)) * 2 + (r & 1)]; }
         else if (pk) { const int s = (i - 1) >> 7, r = (i - 1) & 127, t = (j - 1) + r; b = tb[(((size_t)s * (size_t)W + (size_t)t) * 64 + (r >> 1)) * 2 + (r & 1)]; }
@@ -636,9 +659,10 @@ __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_
     if (cur_op >= 0) runs[nruns++] = (cur_len << 8) | (uint32_t)cur_op;
 #undef VMX_EMIT
     // runs were produced end-to-start: print them in reverse
-    int w = 0;
+    int w = 0; long long qsum = 0;
     for (int r = nruns - 1; r >= 0; --r) {
         uint32_t len = runs[r] >> 8; char op = (char)(runs[r] & 0xff);
+        if (op != 'D') qsum += len;                           // query bases the CIGAR consumes (M, =, X, I)
         char tmp[12]; int nd = 0;
         do { tmp[nd++] = (char)('0' + len % 10); len /= 10; } while (len);
         while (nd) cig[w++] = tmp[--nd];
@@ -646,4 +670,5 @@ __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_
     }
     cig[w] = 0;
     cig_len[p] = w;
+    if (cig_q) cig_q[p] = (int32_t)qsum;
 }

@@ -254,13 +254,15 @@ __global__ void k_res_pack(const vmx_ext_read* __restrict__ er, const vm_record*
     }
 }
 
-// E6 records (:20731-20838) + pairedindel (:5604). one thread per read.
-__global__ void k_ext_records(vmx_ext_args A, const vmx_dp_prob* __restrict__ probs, const char* __restrict__ cig_pool, const int32_t* __restrict__ cig_len) {
+// E6 records (:20731-20838) + pairedindel (:5604). One WAVEFRONT per read: every lane follows the same (uniform) record logic on the same
+// data, the bytes of the problems' CIGARs — 8 KB per 15 kb read, which one lane used to move a byte at a time — are copied by the 64 lanes
+// together, and lane 0 stores the records. The reference's check that the concatenated CIGAR consumes the whole read (:20779-20786) uses the
+// per-problem query lengths the trace kernel counted from the operators it emitted (cig_q) instead of parsing the text again.
+__global__ void __launch_bounds__(64) k_ext_records(vmx_ext_args A, const vmx_dp_prob* __restrict__ probs, const char* __restrict__ cig_pool, const int32_t* __restrict__ cig_len,
+                                                    const int32_t* __restrict__ cig_q) {
     VMX_SETPRIO(3);
-    const int sp = A.spread > 1 ? A.spread : 1;
-    const int gt = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (gt % sp) return;
-    const int r = gt / sp;
+    const int lane = vmx_lane();
+    const int r = (int)blockIdx.x;
     if (r >= A.n_reads) return;
     vmx_ext_read& E = A.er[r];
     if (!E.active || E.status != 0) return;
@@ -275,8 +277,10 @@ __global__ void k_ext_records(vmx_ext_args A, const vmx_dp_prob* __restrict__ pr
     int64_t* roffs = A.rec_coff + A.soff[r]; int32_t* rlens = A.rec_clen + A.soff[r];
     const bool need_reverse = A.gscore[r] < 0.0;
     const char clip = A.hardclip ? 'H' : 'S';
+    const int dp_base = E.dp_base, pass = E.pass, filtered = E.filtered, nseg_snap = E.nseg_snap;
     long long w = 0; int k = 0;
-    for (int s = 0; s < S.nseg; ++s) {
+    int fail = 0;
+    for (int s = 0; s < S.nseg && !fail; ++s) {
         const vmx_anchor a0 = S.A[S.st[s]].s == 1 ? S.A[S.st[s]] : S.A[S.en[s] - 1];     // new_alignment[0]
         const vmx_anchor a1 = S.A[S.st[s]].s == 1 ? S.A[S.en[s] - 1] : S.A[S.st[s]];     // new_alignment[-1]
         const int c = vmx_p2c(R, a0.r); const long long bias = R.coff[c];
@@ -285,38 +289,47 @@ __global__ void k_ext_records(vmx_ext_args A, const vmx_dp_prob* __restrict__ pr
         if (a0.s == 1) { q_st = a0.q; q_en = (long long)a1.q + a1.l; rec.strand = need_reverse ? -1 : 1; }
         else { q_st = L - a0.q - a0.l; q_en = L - a1.q; rec.strand = need_reverse ? 1 : -1; }
         rec.q_st = q_st; rec.q_en = q_en; rec.r_st = a0.r - bias; rec.r_en = a1.r + a1.l - bias;
-        // worst-case length check before writing
-        long long need = 48; for (int x = 0; x < segprob[s]; ++x) need += cig_len[E.dp_base + k + x];
-        if (w + need > blob_cap) { E.status = VM_READ_CAPACITY_DEV; return; }
+        const int np = segprob[s];
+        // worst-case length check before writing; the problems' CIGAR lengths and query lengths summed across the lanes
+        long long need = 0, qsum = 0;
+        for (int x = lane; x < np; x += 64) { need += cig_len[dp_base + k + x]; qsum += cig_q[dp_base + k + x]; }
+        need = vmx_wave_sum_i64(need) + 48; qsum = vmx_wave_sum_i64(qsum);
+        if (w + need > blob_cap) { fail = VM_READ_CAPACITY_DEV; break; }
         const long long st = w;
-        if (q_st > 0) { w += vmx_put_int(BLOB + w, q_st); BLOB[w++] = clip; }
-        for (int x = 0; x < segprob[s]; ++x) {
-            const int p = E.dp_base + k + x; const char* src = cig_pool + probs[p].cig_off; const int n = cig_len[p];
-            for (int i = 0; i < n; ++i) BLOB[w++] = src[i];
+        char tmp[24];
+        if (q_st > 0) { const int nd = vmx_put_int(tmp, q_st); if (lane == 0) { for (int i = 0; i < nd; ++i) BLOB[w + i] = tmp[i]; BLOB[w + nd] = clip; } w += nd + 1; }
+        for (int x = 0; x < np; ++x) {
+            const int p = dp_base + k + x; const char* src = cig_pool + probs[p].cig_off; const int n = cig_len[p];
+            for (int i = lane; i < n; i += 64) BLOB[w + i] = src[i];
+            w += n;
         }
-        k += segprob[s];
-        if (a0.s == 1 && a1.l > 0) { w += vmx_put_int(BLOB + w, a1.l); BLOB[w++] = 'M'; }
-        if (L - q_en > 0) { w += vmx_put_int(BLOB + w, L - q_en); BLOB[w++] = clip; }
-        BLOB[w] = 0;
+        k += np;
+        long long ql = qsum;
+        if (a0.s == 1 && a1.l > 0) { const int nd = vmx_put_int(tmp, a1.l); if (lane == 0) { for (int i = 0; i < nd; ++i) BLOB[w + i] = tmp[i]; BLOB[w + nd] = 'M'; } w += nd + 1; ql += a1.l; }
+        if (L - q_en > 0) { const int nd = vmx_put_int(tmp, L - q_en); if (lane == 0) { for (int i = 0; i < nd; ++i) BLOB[w + i] = tmp[i]; BLOB[w + nd] = clip; } w += nd + 1; if (!A.hardclip) ql += L - q_en; }
+        if (q_st > 0 && !A.hardclip) ql += q_st;
+        if (lane == 0) BLOB[w] = 0;
         rec.cigar_off = st; rec.cigar_len = w - st;
-        roffs[s] = st; rlens[s] = (int32_t)(w - st);
+        if (lane == 0) { roffs[s] = st; rlens[s] = (int32_t)(w - st); }
         ++w;
-        // :20779-20786
-        const long long ql = vmx_cigar_qlen(BLOB + st, (int)(w - 1 - st));
-        if (!A.hardclip) { if (L != ql) { E.status = VM_READ_RAISED_DEV; return; } }
-        else { if ((q_en - q_st) != ql) { E.status = VM_READ_RAISED_DEV; return; } }
-        REC[s] = rec;
+        // :20779-20786 len(Cigar(cigarstring)) against the read (soft clips count, hard clips do not)
+        if (!A.hardclip) { if (L != ql) { fail = VM_READ_RAISED_DEV; break; } }
+        else { if ((q_en - q_st) != ql) { fail = VM_READ_RAISED_DEV; break; } }
+        if (lane == 0) REC[s] = rec;
     }
+    if (fail) { if (lane == 0) E.status = fail; return; }
+    __syncthreads();                                          // the records and the text are complete before lane 0 reads them back
+    if (lane != 0) return;
     E.nrec = S.nseg;
     if (need_reverse) { for (int a = 0, b = S.nseg - 1; a < b; ++a, --b) { vm_record t = REC[a]; REC[a] = REC[b]; REC[b] = t; } }
     // redo with nofilter (:24079-24080)
-    if (E.pass == 0 && !A.nodiscard && E.filtered && S.nseg > 0) {
+    if (pass == 0 && !A.nodiscard && filtered && S.nseg > 0) {
         if (vmx_pairedindel(BLOB, roffs, rlens, S.nseg, 30.0, (double*)(A.dup_d + A.blob_off[r] / 8), (int)(blob_cap / 8 - 1))) {
             E.redo = 1; E.pass = 1; E.nrec = 0;
             // restore the state saved after the first extension round
             vmx_segs P = vmx_read_segs(A, r, true);
-            for (int s = 0; s < E.nseg_snap; ++s) { S.st[s] = P.st[s]; S.en[s] = P.en[s]; for (int t = P.st[s] - 1; t <= P.en[s]; ++t) S.A[t] = P.A[t]; }
-            E.nseg = E.nseg_snap; E.filtered = 0; E.skip_ext = 1;
+            for (int s = 0; s < nseg_snap; ++s) { S.st[s] = P.st[s]; S.en[s] = P.en[s]; for (int t = P.st[s] - 1; t <= P.en[s]; ++t) S.A[t] = P.A[t]; }
+            E.nseg = nseg_snap; E.filtered = 0; E.skip_ext = 1;
         }
     }
 }

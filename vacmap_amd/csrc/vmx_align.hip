@@ -27,7 +27,7 @@ __global__ void k_prob_owner(const vmx_ext_read* er, int n_reads, int use_dp, in
 __global__ void k_dp_sizes(const vmx_pair_desc* desc, const int32_t* n_prob, int64_t* tb_sz, int64_t* bnd_sz, int64_t* run_sz, int64_t* cig_sz);
 __global__ void k_dp_table(const vmx_pair_desc* desc, const int32_t* n_prob, const int64_t* t_off, const int64_t* q_off, const int64_t* tb_off,
                            const int64_t* bnd_off, const int64_t* run_off, const int64_t* cig_off, vmx_dp_prob* probs);
-__global__ void k_ext_records(vmx_ext_args A, const vmx_dp_prob* probs, const char* cig_pool, const int32_t* cig_len);
+__global__ void k_ext_records(vmx_ext_args A, const vmx_dp_prob* probs, const char* cig_pool, const int32_t* cig_len, const int32_t* cig_q);
 __global__ void k_res_sizes(const vmx_ext_read* er, const vm_record* rec, const int64_t* soff, int n_reads, int64_t* recn, int64_t* blobn);
 __global__ void k_res_pack(const vmx_ext_read* er, const vm_record* rec, const char* blob, const int64_t* soff, const int64_t* blob_off, int n_reads,
                            const int64_t* rec_o, const int64_t* blob_o, vm_record* out_rec, char* out_blob);
@@ -55,7 +55,7 @@ struct vmx_batch_bufs {
     // extend stage
     DevBuf er, coff3, soff2, segA, st, en, segA_s, st_s, en_s, segprob, dup, desc[2], rcount, oflow, probread, tl, ql, toff, qoff, tpool, qpool;
     DevBuf edout, carry, ext3, dpsz[4], dpoff[4], dptab, tb, tbredo, bnd, run, cig, ciglen, dpscore, rec, blob, bloboff, reccoff, recclen, dupd, totals;
-    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp, chunkn, sellist;
+    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp, chunkn, sellist, cigq;
     void release() { DevBuf* p = (DevBuf*)this; for (size_t i = 0; i < sizeof(*this) / sizeof(DevBuf); ++i) p[i].release(); }
 };
 static vmx_batch_bufs* batch_bufs(vm_ctx* c) { if (!c->bbufs) c->bbufs = new vmx_batch_bufs(); return c->bbufs; }
@@ -324,7 +324,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         int cnt = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, redo_only, round_cap, pool_cap);
         if (cnt < 0) return cnt;
         for (int i = 0; i < 4; ++i) { VMX_TRY(B.dpsz[i].reserve(8 * (size_t)(cnt + 2))); VMX_TRY(B.dpoff[i].reserve(8 * (size_t)(cnt + 2))); }
-        VMX_TRY(B.dptab.reserve(sizeof(vmx_dp_prob) * (size_t)(cnt + 1))); VMX_TRY(B.ciglen.reserve(4 * (size_t)(cnt + 1))); VMX_TRY(B.dpscore.reserve(4 * (size_t)(cnt + 1)));
+        VMX_TRY(B.dptab.reserve(sizeof(vmx_dp_prob) * (size_t)(cnt + 1))); VMX_TRY(B.ciglen.reserve(4 * (size_t)(cnt + 1))); VMX_TRY(B.cigq.reserve(4 * (size_t)(cnt + 1))); VMX_TRY(B.dpscore.reserve(4 * (size_t)(cnt + 1)));
         const int G = c->num_cu * 4;
         hipLaunchKernelGGL(k_dp_sizes, dim3(G), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.dpsz[0].as<int64_t>(), B.dpsz[1].as<int64_t>(),
                            B.dpsz[2].as<int64_t>(), B.dpsz[3].as<int64_t>());
@@ -385,13 +385,13 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
                 if (ke) (void)hipEventRecord(ke[1], c->stream);
                 static const int tr_spread = [] { const char* e = getenv("VMX_TRACE_SPREAD"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 64 ? v : 1; }();
                 hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)(((int64_t)pn * tr_spread + 63) / 64)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>() + p0, pn, prm->eqx,
-                                   tb_base, B.run.as<uint32_t>(), B.cig.as<char>(), B.ciglen.as<int32_t>() + p0, B.dpscore.as<int32_t>() + p0, B.tbredo.as<uint8_t>(), tr_spread);
+                                   tb_base, B.run.as<uint32_t>(), B.cig.as<char>(), B.ciglen.as<int32_t>() + p0, B.dpscore.as<int32_t>() + p0, B.tbredo.as<uint8_t>(), tr_spread, B.cigq.as<int32_t>() + p0);
                 if (ke) { (void)hipEventRecord(ke[2], c->stream); c->n_gev[redo_only ? 1 : 0] = (int)q + 1; }
             }
         }
         A.redo_only = redo_only;
         A.spread = rec_spread;
-        hipLaunchKernelGGL(k_ext_records, dim3(gridXR), dim3(64), 0, c->stream, A, B.dptab.as<vmx_dp_prob>(), B.cig.as<char>(), B.ciglen.as<int32_t>());
+        hipLaunchKernelGGL(k_ext_records, dim3((unsigned)n), dim3(64), 0, c->stream, A, B.dptab.as<vmx_dp_prob>(), B.cig.as<char>(), B.ciglen.as<int32_t>(), B.cigq.as<int32_t>());     // one wavefront per read
         cur ^= 1;
         return cnt;
     };

@@ -286,7 +286,7 @@ static int k_cigar_batch_impl(vm_ctx* c, const vm_score* sc, int eqx, int schedu
                            c->b[6].as<vmx_dp_prob>(), (int)n, sc->match, sc->mismatch, sc->o1, sc->e1, sc->o2, sc->e2, c->b[7].as<uint8_t>(),
                            c->b[8].as<int32_t>(), d_score, (const int32_t*)nullptr, (int32_t*)nullptr);
         hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[4].as<uint8_t>(),
-                           c->b[6].as<vmx_dp_prob>(), (int)n, eqx, c->b[7].as<uint8_t>(), c->b[9].as<uint32_t>(), c->b[10].as<char>(), d_len, (const int32_t*)nullptr, (const uint8_t*)nullptr, 1);
+                           c->b[6].as<vmx_dp_prob>(), (int)n, eqx, c->b[7].as<uint8_t>(), c->b[9].as<uint32_t>(), c->b[10].as<char>(), d_len, (const int32_t*)nullptr, (const uint8_t*)nullptr, 1, (int32_t*)nullptr);
     } else if (n) {
         const int32_t nn = (int32_t)n;
         VMX_TRY(upload(c->b[12], tbsz.data(), (size_t)n, c->stream)); VMX_TRY(upload(c->b[13], &nn, 1, c->stream));
@@ -308,7 +308,7 @@ static int k_cigar_batch_impl(vm_ctx* c, const vm_score* sc, int eqx, int schedu
                            sc->match, sc->mismatch, sc->o1, sc->e1, sc->o2, sc->e2, c->b[7].as<uint8_t>(), c->b[8].as<int32_t>(), d_score, d_order, d_range, d_cnt, d_redo_list, d_redo_cnt, 1, ad_pct,
                            c->b[16].as<uint8_t>(), d_redo_bytes);
         hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[4].as<uint8_t>(),
-                           c->b[6].as<vmx_dp_prob>(), (int)n, eqx, c->b[7].as<uint8_t>(), c->b[9].as<uint32_t>(), c->b[10].as<char>(), d_len, d_score, c->b[16].as<uint8_t>(), 1);
+                           c->b[6].as<vmx_dp_prob>(), (int)n, eqx, c->b[7].as<uint8_t>(), c->b[9].as<uint32_t>(), c->b[10].as<char>(), d_len, d_score, c->b[16].as<uint8_t>(), 1, (int32_t*)nullptr);
     }
     std::vector<char> hc((size_t)cig + 16); std::vector<int32_t> hl((size_t)n);
     *scores = host_alloc<int32_t>((size_t)n);

@@ -168,7 +168,7 @@ static inline int vmx_ad_pct_env() {
     return pct | (pmin << 16);
 }
 __global__ void k_gapfill_trace(const uint8_t* tcodes, const uint8_t* qcodes, const vmx_dp_prob* probs, int n_prob, int eqx,
-                                const uint8_t* tb_pool, uint32_t* run_pool, char* cig_pool, int32_t* cig_len, const int32_t* band_flag, const uint8_t* redo_pool, int spread);
+                                const uint8_t* tb_pool, uint32_t* run_pool, char* cig_pool, int32_t* cig_len, const int32_t* band_flag, const uint8_t* redo_pool, int spread, int32_t* cig_q);
 __global__ void k_flip_sort(const int64_t* rows, const int64_t* aoff, const int64_t* readlens, int n_reads, uint64_t* key_pool,
                             const int64_t* key_off, vmx_anchor* sorted, int32_t* need_reverse);
 __global__ void k_chain_global(const vmx_anchor* anchors, const int64_t* aoff, const int32_t* rlist, int nlist, int lds_cap,
