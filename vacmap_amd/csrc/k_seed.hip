@@ -49,6 +49,80 @@ __global__ void __launch_bounds__(256) k_sketch(const uint8_t* __restrict__ code
         if (P <= 0) { if (threadIdx.x == 0) mz_cnt[r] = 0; continue; }
         const int nwin = P >= w ? P - w + 1 : 1;
         const int wl = P >= w ? w : P;
+        if (w == 10 && P >= 10 && blockDim.x == 256) {
+            // The common geometry (w = 10, every mode's default): each thread owns EIGHT consecutive positions of the tile.
+            //  * k-mers are rolled (two shifts per base instead of a k-base loop per position);
+            //  * the window minima of its 8 starts come from 17 hashes held in registers, by doubling (pairs, fours, eights; 10 = 8 + 2);
+            //  * a position is a minimizer iff its hash equals the minimum of SOME window that holds it; every such window's minimum is <= the
+            //    hash, so that is the same as: the MAXIMUM of the minima of the windows holding it equals the hash — again a width-10
+            //    sliding reduction by doubling (windows outside [0, nwin) count as 0, below every hash that could match);
+            //  * one block scan per tile places the tile's minimizers in order.
+            for (int t0 = 0; t0 < P; t0 += VMX_SK_TILE) {
+                const int lo = t0 - 9 > 0 ? t0 - 9 : 0;
+                int hi = t0 + VMX_SK_TILE + 9; if (hi > P) hi = P;
+                const int npos = hi - lo;
+                for (int x = (int)threadIdx.x; x < npos + k - 1; x += 256) s_codes[x] = C[lo + x];
+                __syncthreads();
+                for (int x0 = 8 * (int)threadIdx.x; x0 < npos; x0 += 8 * 256) {
+                    uint64_t fwd = 0, rc = 0; int nval = 0;
+                    for (int i = 0; i < k - 1; ++i) { const uint8_t c = s_codes[x0 + i]; nval = c > 3 ? 0 : nval + 1; fwd = (fwd << 2) | (uint64_t)(c & 3); rc = (rc >> 2) | ((uint64_t)(3 - (c & 3)) << shift); }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (x0 + j < npos) {
+                            const uint8_t c = s_codes[x0 + j + k - 1]; nval = c > 3 ? 0 : nval + 1;
+                            fwd = ((fwd << 2) | (uint64_t)(c & 3)) & mask; rc = (rc >> 2) | ((uint64_t)(3 - (c & 3)) << shift);
+                            uint64_t h = VMX_INF64; uint8_t z = 0;
+                            if (nval >= k && fwd != rc) { z = rc < fwd ? 1 : 0; h = vmx_hash64(fwd < rc ? fwd : rc, mask); }
+                            s_h[x0 + j] = h; s_z[x0 + j] = z;
+                        }
+                    }
+                }
+                __syncthreads();
+                for (int x0 = 8 * (int)threadIdx.x; x0 < npos; x0 += 8 * 256) {
+                    uint64_t v[17], m2[16], m4[14], m8[8];
+#pragma unroll
+                    for (int i = 0; i < 17; ++i) v[i] = x0 + i < npos ? s_h[x0 + i] : VMX_INF64;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) m2[i] = v[i] < v[i + 1] ? v[i] : v[i + 1];
+#pragma unroll
+                    for (int i = 0; i < 14; ++i) m4[i] = m2[i] < m2[i + 2] ? m2[i] : m2[i + 2];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { m8[i] = m4[i] < m4[i + 4] ? m4[i] : m4[i + 4]; const uint64_t m = m8[i] < m2[i + 8] ? m8[i] : m2[i + 8]; if (x0 + i < npos) s_wmin[x0 + i] = (lo + x0 + i < nwin) ? m : 0ULL; }
+                }
+                __syncthreads();
+                int pend = t0 + VMX_SK_TILE; if (pend > P) pend = P;
+                const int p0 = t0 + 8 * (int)threadIdx.x;               // this thread's positions p0 .. p0 + 7
+                unsigned selmask = 0; uint64_t hs[8];
+                if (p0 < pend) {
+                    const int xa = p0 - 9 - lo;                          // LDS index of window start p0 - 9 (negative: before the sequence)
+                    uint64_t v[17], m2[16], m4[14];
+#pragma unroll
+                    for (int i = 0; i < 17; ++i) v[i] = (xa + i >= 0 && xa + i < npos) ? s_wmin[xa + i] : 0ULL;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) m2[i] = v[i] > v[i + 1] ? v[i] : v[i + 1];
+#pragma unroll
+                    for (int i = 0; i < 14; ++i) m4[i] = m2[i] > m2[i + 2] ? m2[i] : m2[i + 2];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint64_t m8 = m4[j] > m4[j + 4] ? m4[j] : m4[j + 4];
+                        const uint64_t mx = m8 > m2[j + 8] ? m8 : m2[j + 8];          // windows p - 9 .. p
+                        const uint64_t h = p0 + j < pend ? s_h[p0 + j - lo] : VMX_INF64;
+                        hs[j] = h;
+                        if (h != VMX_INF64 && mx == h) selmask |= 1u << j;
+                    }
+                }
+                int tot; const int ex = vmx_block_excl_scan(__popc(selmask), s_scan, &tot);
+                if (selmask) {
+                    int o = written + ex;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if ((selmask >> j) & 1u) { oh[o] = hs[j]; op[o] = ((uint32_t)(p0 + j) << 1) | s_z[p0 + j - lo]; ++o; }
+                }
+                written += tot;
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) mz_cnt[r] = written;
+            continue;
+        }
         for (int t0 = 0; t0 < P; t0 += VMX_SK_TILE) {
             // positions [t0 - (w-1), t0 + TILE + (w-1)) clipped to [0, P) are needed for the window minima
             const int lo = t0 - (w - 1) > 0 ? t0 - (w - 1) : 0;

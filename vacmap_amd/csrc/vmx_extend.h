@@ -20,7 +20,12 @@
 struct vmx_sdesc { int64_t start; int32_t len; int8_t src; int8_t op; int16_t pad; };
 struct vmx_pair_desc { vmx_sdesc t, q; };
 
-struct vmx_ref_view { const uint8_t* codes; const int64_t* coff; int nseq; };
+struct vmx_ref_view {
+    const uint8_t* codes; const int64_t* coff; int nseq;
+    // the contig of the last look-up: consecutive anchors of a read sit on one contig, so nearly every vmx_p2c is answered by two compares
+    // on registers instead of a five-step bisection of dependent loads (the segment walks make two look-ups per anchor)
+    mutable int cc = -1; mutable long long clo = 1, chi = 0;
+};
 
 // per-read segment list: segment s = A[st[s] .. en[s]) ; every segment keeps one spare slot before and after it
 struct vmx_segs { vmx_anchor* A; int32_t* st; int32_t* en; int32_t nseg; int32_t capA; int32_t capS; };
@@ -28,8 +33,11 @@ struct vmx_segs { vmx_anchor* A; int32_t* st; int32_t* en; int32_t nseg; int32_t
 // pos2contig (:51-59): the last contig whose start is <= pos (0 when pos lies before the first). The reference scans the contig
 // starts linearly; a bisection gives the same index with 5 instead of 24 dependent loads on an hg38-size contig table.
 __host__ __device__ inline int vmx_p2c(const vmx_ref_view& R, long long pos) {
+    if (pos >= R.clo && pos < R.chi) return R.cc;
     int lo = 0, hi = R.nseq;                      // invariant: coff[lo] <= pos (or lo == 0), coff[hi] > pos (or hi == nseq)
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (R.coff[mid] <= pos) lo = mid; else hi = mid; }
+    // remember the interval on which this answer holds: [coff[lo], coff[lo + 1]) — for lo = 0 everything below coff[1], for the last contig everything above
+    R.cc = lo; R.clo = lo == 0 ? -(1LL << 62) : R.coff[lo]; R.chi = lo + 1 >= R.nseq ? (1LL << 62) : R.coff[lo + 1];
     return lo;
 }
 __host__ __device__ inline long long vmx_clampll(long long v, long long lo, long long hi) { return v < lo ? lo : (v > hi ? hi : v); }
