@@ -63,7 +63,7 @@ def main():
     ap.add_argument('--streams', type=int, default=3, help='batches in flight per GPU (vacmap_amd.pipeline)')
     ap.add_argument('--window-batches', type=int, default=16, help='length binning window of the scheduler, in batches')
     ap.add_argument('--arrival-order', action='store_true', help='no length binning: batches in arrival order (measured once for comparison)')
-    ap.add_argument('--verify', type=int, default=8, help='reads of the first batch cross-checked against the oracle (0 disables)')
+    ap.add_argument('--verify', type=int, default=64, help='reads of the first batch cross-checked against the oracle (0 disables)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1')); local_rank = int(os.environ.get('LOCAL_RANK', '0'))

@@ -212,6 +212,9 @@ typedef struct vm_batch_stats {     /* measured on the device, for bench.py's ro
     int64_t n_ed_tier1;             /* problems the anchor bound could not settle (re-run in the four-per-wave band) */
     int64_t n_dp_redo;              /* gap-fill problems whose band was not proven optimal (or that were too large to try one): filled again in full */
     int64_t dp_redo_tb_bytes;       /* traceback bytes of those (second pool); dp_cells counts all traceback bytes written */
+    double ms_local_seed;           /* k_local_seed, the batch's main launch (HIP events on the stream it runs on) */
+    double ms_cluster;              /* k_cluster_big + k_cluster (hit clustering of the seed stage) */
+    int64_t n_host_syncs;           /* host waits for the device inside this batch (sizing read-backs + result download) */
 } vm_batch_stats;
 
 /* Align n reads (replaces get_readmap_DP_test per read). seqs concatenated, offsets[n+1].

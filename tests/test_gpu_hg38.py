@@ -80,6 +80,17 @@ def test_hg38_size_index_map_and_records(ctx, oracle, hg38_ref, mode, k, shape):
         assert (status[i] == 0) == (ost == 0) and mine == [t[1:] for t in orecs], 'records of read %d %r differ' % (i, where[i])
         nrec += len(mine)
     assert nrec >= len(reads) and stats['n_failed'] == 0
+    # the bulk sample: 208 more reads of the configuration's own read model, whole path, records vs the oracle
+    import os
+    from vacmap_amd import synth
+    cat, off, _ = synth.sample_reads_concat(contigs, 208, mean_len=15000 if shape == 'ont' else 18000, err=0.10 if shape == 'ont' else 0.005, seed=900 + k,
+                                            shape=shape, **({'min_len': 5000} if shape == 'hifi' else {}))
+    bulk = [cat[off[i]:off[i + 1]].tobytes() for i in range(208)]
+    bst, brecs, bstats = align_batch(ctx, gi, prm, bulk)
+    ost, orecs = oracle.align_batch(oi, bulk, op, nthreads=min(os.cpu_count() or 1, 32))
+    assert [(int(x) == 0) for x in bst] == [(int(x) == 0) for x in ost]
+    assert brecs == orecs, 'bulk sample: records differ from the oracle'
+    assert len(orecs) >= 200
     # a replica allocated from the metadata and filled from the builder's HBM pieces maps identically (the broadcast's receive side)
     from vacmap_amd.dist import index_blobs
     rep = Index.from_meta(ctx, gi.meta())

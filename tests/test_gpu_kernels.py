@@ -137,6 +137,46 @@ def test_mode_r_and_s(ctx, oracle, golden):
     KC.check_align_golden(ctx, oracle, golden, cases=['I'])      # rare branches of the segment surgery (mode H)
 
 
+def test_round3_goldens(ctx, oracle, golden):
+    """the wider reference pin of round 3 on the device: mode S (J), 24 more mode-L reads at k 19 (K), reads of 40-52 kb in modes H and L (M, M2),
+    the `refen_0 < refst_1` branch of fix_simple_inv (N), 30 more mode-H reads (O), 20 more mode-R reads (P): anchors, local anchors + chains
+    and records identical to the imported reference's and to the oracle's"""
+    cases = ['J', 'K', 'M', 'M2', 'N', 'O', 'P']
+    KC.check_seed_golden(ctx, oracle, golden, cases=cases)
+    KC.check_local_golden(ctx, oracle, golden, cases=cases)
+    KC.check_align_golden(ctx, oracle, golden, cases=cases)
+    n = KC.check_stage_trace_golden(ctx, oracle, golden, cases=['N'])
+    assert n >= 1
+
+
+def test_mmi_roundtrip_on_device(ctx, oracle, golden, tmp_path):
+    """minimap2 index files on the GPU (vacmap:324-344, index.py:26): vm_index_save_mmi -> vm_index_load_mmi re-derives every stored hash
+    from the sequence ON THE DEVICE; the loaded index holds the same columns and gives the same vm_map_batch anchors; so does the own
+    .vmx format; a corrupted .mmi is rejected"""
+    from vacmap_amd.lib import Index, VmxError
+    meta, arrays = golden
+    gi, oi = KC._case_index(ctx, oracle, meta, arrays, 'B')
+    seqs = [arrays['B_r%d_seq' % ri].tobytes().decode() for ri in range(len(meta['B']['reads']))]
+    want = ctx.map_batch(gi, seqs)
+    gh, gp = gi.minimizers()
+    for ext, save, load in (('mmi', gi.save_mmi, Index.load_mmi), ('vmx', gi.save, Index.load)):
+        path = str(tmp_path / ('ref.w10_k15.' + ext))
+        save(path)
+        li = load(ctx, path)
+        assert (li.k, li.w, li.names, li.lens, li.mid_occ) == (gi.k, gi.w, gi.names, gi.lens, gi.mid_occ)
+        lh, lp = li.minimizers()
+        assert np.array_equal(lh, gh) and np.array_equal(lp, gp), ext
+        got = ctx.map_batch(li, seqs)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want)), ext
+        assert li.seq(0, 100, 180) == gi.seq(0, 100, 180)
+        li.close()
+    raw = bytearray(open(str(tmp_path / 'ref.w10_k15.mmi'), 'rb').read())
+    raw[8:12] = (40).to_bytes(4, 'little')                      # k = 40: no such index
+    bad = str(tmp_path / 'bad.mmi'); open(bad, 'wb').write(bytes(raw))
+    with pytest.raises(VmxError):
+        Index.load_mmi(ctx, bad)
+
+
 def test_n_runs_in_read_and_reference(ctx, oracle):
     """ambiguous bases on both sides (DESIGN.md deviation D6: one code for every non-ACGT base): runs of N in the reference, N and IUPAC
     letters in the reads, lower case — the GPU path and the oracle agree read by read, and `seq()` returns N like minimap2's 4-bit store"""

@@ -4,7 +4,7 @@ import hashlib, json, os, zlib
 import numpy as np
 import pytest
 
-CASES = ['A', 'B', 'C', 'D', 'E', 'F', 'G', 'H', 'I']     # E, F: repeat-dense reads that take the *_fast chain variants (G3, L5); G: mode R;
+CASES = ['A', 'B', 'C', 'D', 'E', 'F', 'G', 'H', 'I', 'J', 'K', 'M', 'M2', 'N', 'O', 'P']     # J-P (round 3): mode S, more L / H / R reads, reads of 40-52 kb, the last fix_simple_inv branch; E, F: repeat-dense reads that take the *_fast chain variants (G3, L5); G: mode R;
                                                        # H: mode R on a donor made by the vacsim-grammar implanter (nested INV / DUP / TRA, BASELINE configs[4])
                                                        # I: inputs that drive the rare branches of the segment surgery (V4)
 
@@ -129,7 +129,7 @@ def test_v5_v6_records_and_dp_problems(oracle, golden, cid):
 _V4_FN = {'rebuild_chain_break': 0, 'drop_misplaced_alignment_test': 1, 'merge_conjacent_alignment': 2, 'fix_simple_inv': 3}
 
 
-@pytest.mark.parametrize('cid', ['A', 'B', 'C', 'D', 'G', 'H', 'I'])
+@pytest.mark.parametrize('cid', ['A', 'B', 'C', 'D', 'G', 'H', 'I', 'N'])
 def test_v4_segment_surgery(oracle, golden, cid):
     """stage vectors V4: every call the reference made to rebuild_chain_break (:23437), drop_misplaced_alignment_test (:726),
     merge_conjacent_alignment (:16736, getdupiloc_numba :16680 inside) and fix_simple_inv (:24226) while aligning the read — the oracle's
@@ -160,8 +160,8 @@ def test_v4_covers_every_branch(golden):
     """the captured calls exercise what they are meant to pin: at least one drop_misplaced removal, one merge that merges, one
     fix_simple_inv that moves a breakpoint"""
     meta, arrays = golden
-    seen = {'drop': 0, 'merge': 0, 'fix': 0}
-    for cid in ('A', 'B', 'C', 'D', 'G', 'H', 'I'):
+    seen = {'drop': 0, 'merge': 0, 'fix': 0, 'fix_left_flank': 0}
+    for cid in ('A', 'B', 'C', 'D', 'G', 'H', 'I', 'N'):
         for r in meta[cid]['reads']:
             for e in r.get('v4', []):
                 if 'in' not in e:
@@ -173,7 +173,25 @@ def test_v4_covers_every_branch(golden):
                     seen['merge'] += 1
                 if e['fn'] == 'fix_simple_inv' and changed:
                     seen['fix'] += 1
-    assert seen['drop'] >= 3 and seen['merge'] >= 1 and seen['fix'] >= 3, seen
+                    # the `refen_0 < refst_1` branch (:24297-24310) moves the LAST (zero-length) anchor of the left flank forward
+                    # (the other branch rewrites the first anchor of the right flank)
+                    i_, o_ = arrays[e['in']].reshape(-1, 5), arrays[e['out']].reshape(-1, 5)
+                    for sg in np.unique(o_[:, 0]):
+                        li, lo = i_[i_[:, 0] == sg], o_[o_[:, 0] == sg]
+                        if len(li) and len(lo) and lo[-1, 3] == 1 and lo[-1, 4] == 0 and lo[-1, 1] > li[-1, 1] and sg + 2 <= o_[:, 0].max():
+                            seen['fix_left_flank'] += 1
+    assert seen['drop'] >= 3 and seen['merge'] >= 1 and seen['fix'] >= 4 and seen['fix_left_flank'] >= 1, seen
+
+
+def test_golden_pin_is_wide(golden):
+    """at least 150 reads from the imported reference, every mode, reads of 40 kb and more"""
+    meta, arrays = golden
+    cases = {k: v for k, v in meta.items() if isinstance(v, dict)}
+    assert sum(len(c['reads']) for c in cases.values()) >= 150
+    assert {c['mode'] for c in cases.values()} == {'H', 'L', 'S', 'R'}
+    assert sum(len(c['reads']) for c in cases.values() if c['mode'] == 'S') >= 20
+    assert sum(len(c['reads']) for c in cases.values() if c['mode'] == 'L' and c['k'] == 19) >= 30
+    assert sum(1 for c in cases.values() for r in c['reads'] if r['len'] >= 40000) >= 3
 
 
 def test_testdata_three_alignments(oracle, golden):

@@ -43,7 +43,9 @@ def seg_rows(al):
     return np.array(out, dtype=np.int64).reshape(-1, 5)
 
 
-def run_case(cid, mode, names, contigs, reads, k, arrays, meta, v4=False):
+def run_case(cid, mode, names, contigs, reads, k, arrays, meta, v4=False, light=False):
+    """light: bulk cases keep the per-read outputs (V1, V2 paths / score / MAPQ, V3 score + chain + checksum of the raw local anchors, V5, V6) but not
+    the raw S / P / S_arg arrays and raw local-anchor rows, so that the fixture stays small"""
     ix = O.Index.from_seqs(names, contigs, k=k, w=10)
     al = refrun.Aligner(oracle_index=ix)
     ctx = refrun.RefContext(mode, al)
@@ -63,7 +65,7 @@ def run_case(cid, mode, names, contigs, reads, k, arrays, meta, v4=False):
         rec['v1_flag'] = bool(flag)
         arrays[key + '_v1'] = np.ascontiguousarray(flipped)
         # V2 raw GC-exact on the q-sorted flipped anchors + hit2work_1
-        if len(flipped) > 2:
+        if len(flipped) > 2 and not light:
             srt = np.ascontiguousarray(flipped)[np.argsort(np.ascontiguousarray(flipped)[:, 0])]
             g, S, P, SA, fac = m.get_optimal_chain_sortbyreadpos_forSV_inv_test_merged_fine_list_d_all(
                 srt, kmersize=k, skipcost=ctx.option['golbal_skipcost'], maxdiff=ctx.option['golbal_maxdiff'], maxgap=1000)
@@ -175,7 +177,7 @@ def run_case(cid, mode, names, contigs, reads, k, arrays, meta, v4=False):
             rec['v3_variant'] = cap['variant']; rec['v3_kw'] = cap['kw']
             raw = cap['raw'].astype(np.int64).reshape(-1, 4)
             rec['v3_raw_n'] = int(len(raw)); rec['v3_raw_crc'] = zlib.crc32(np.ascontiguousarray(raw).tobytes())
-            if len(raw) <= 20000:        # dense cases: only the count and a checksum of the raw local anchors travel
+            if len(raw) <= 20000 and not light:        # dense and bulk cases: only the count and a checksum of the raw local anchors travel
                 arrays[key + '_v3_raw'] = raw
             if scores != 0:
                 need_rev = scores < 0
@@ -296,6 +298,45 @@ def main():
         don = np.concatenate([ri_[:p_], ri_[p_ + sh_:p_ + sh_ + sz_], ri_[p_ + 400:]])
         lI.append(('misplaced%d' % sz_, synth.tostr(synth.mutate(don[p_ - 5000:p_ + sz_ + 5000], 0.03, rngI))))
     run_case('I', 'H', ['chrA'], [synth.tostr(ri_)], lI, 15, arrays, meta, v4=True)
+    # ---- round 3: a wider pin
+    # case J: mode S (mammap_sensitive.py): ONT reads at 10-13 % error from the SV donor of case B, a chimera and an unmappable read
+    rJ = synth.sample_reads([d0, contigs[1]], 18, mean_len=5000, err=0.12, seed=160, shape='ont', min_len=1500, max_len=9000)
+    lJ = [(n_, synth.tostr(s_)) for n_, s_, _ in rJ]
+    lJ.append(('chimS', synth.tostr(np.concatenate([rJ[0][1][:2000], synth.revcomp(rJ[1][1][:2500])]))))
+    lJ.append(('randS', synth.tostr(synth.make_reference([2500], seed=161)[0])))
+    run_case('J', 'S', ['chrA', 'chrB'], [synth.tostr(c) for c in contigs], lJ, 15, arrays, meta, light=True)
+    # case K: mode L at k = 19, 24 more HiFi-shape reads (0.5 % and 1 % error) over the SV donor, both strands
+    rK = synth.sample_reads([d0, contigs[1]], 16, mean_len=7000, err=0.005, seed=170, shape='hifi', min_len=3000, sd=2000)
+    rK += synth.sample_reads([d0, contigs[1]], 8, mean_len=5000, err=0.01, seed=171, shape='hifi', min_len=2500, sd=1500)
+    run_case('K', 'L', ['chrA', 'chrB'], [synth.tostr(c) for c in contigs], [('k%d_%s' % (i, n_), synth.tostr(s_)) for i, (n_, s_, _) in enumerate(rK)], 19, arrays, meta, light=True)
+    # case M: reads of 40 kb and more (several gap-fill chunks, long chains): two ONT reads (mode H) and one HiFi read (mode L, case M2)
+    bigc = synth.make_reference([260000], seed=180)[0]
+    bigd = synth.implant_svs(bigc, [('INV', 60000, 3000), ('DEL', 110000, 1200), ('DUP', 150000, 2500, 2), ('INS', 200000, 700, 9)])
+    rngM = np.random.default_rng(181)
+    lM = [('long45k', synth.tostr(synth.mutate(bigd[30000:75000], 0.10, rngM))), ('long52k_rc', synth.tostr(synth.revcomp(synth.mutate(bigd[95000:147000], 0.09, rngM))))]
+    run_case('M', 'H', ['chrL'], [synth.tostr(bigc)], lM, 15, arrays, meta, light=True)
+    lM2 = [('hifi41k', synth.tostr(synth.mutate(bigd[140000:181000], 0.005, rngM)))]
+    run_case('M2', 'L', ['chrL'], [synth.tostr(bigc)], lM2, 19, arrays, meta, light=True)
+    # case N: the remaining branch of fix_simple_inv (:24226-24312, `refen_0 < refst_1`: the left flank ends BEFORE the inverted segment's
+    # reference start and the right flank starts as many bases early). Found by tools/harness/find_inv_branch.py (seed 547): an inversion whose
+    # two breakpoints carry 25-bp inverted-repeat arms, 1 % error
+    rngN = np.random.default_rng(547)
+    rN = synth.make_reference([200000], seed=151)[0]
+    pN = 60000 + int(rngN.integers(0, 50000)); mlN = int(rngN.integers(900, 3000)); bN = int(rngN.integers(5, 30))
+    kindN = int(rngN.integers(0, 4))
+    assert kindN == 2, kindN
+    rN[pN - bN:pN] = synth.revcomp(rN[pN + mlN - bN:pN + mlN]); rN[pN + mlN:pN + mlN + bN] = synth.revcomp(rN[pN:pN + bN])
+    donN = np.concatenate([rN[:pN], synth.revcomp(rN[pN:pN + mlN]), rN[pN + mlN:]])
+    errN = float(rngN.choice([0.0, 0.003, 0.01]))
+    lN = [('inv_under_extended', synth.tostr(synth.mutate(donN[pN - 3500:pN + mlN + 3500], errN, rngN)))]
+    run_case('N', 'H', ['chrA'], [synth.tostr(rN)], lN, 15, arrays, meta, v4=True)
+    # case O: 30 more ONT reads (mode H) over a second SV donor on two contigs; case P: 20 more mode-R reads over the vacsim-grammar donor of case H
+    oc = synth.make_reference([180000, 70000], seed=190)
+    od = synth.implant_svs(oc[0], [('DEL', 20000, 400), ('INV', 45000, 1800), ('DUP', 80000, 1200, 3), ('INS', 110000, 350, 11), ('INVDUP', 140000, 1000)])
+    rO = synth.sample_reads([od, oc[1]], 30, mean_len=6000, err=0.10, seed=191, shape='ont', min_len=1500, max_len=14000)
+    run_case('O', 'H', ['chrA', 'chrB'], [synth.tostr(c) for c in oc], [(n_, synth.tostr(s_)) for n_, s_, _ in rO], 15, arrays, meta, light=True)
+    rP = synth.sample_reads([donorH[0], donorH[1]], 20, mean_len=6000, err=0.07, seed=195, shape='ont', min_len=2000, max_len=12000)
+    run_case('P', 'R', ['chrA', 'chrB'], [synth.tostr(c) for c in hc], [(n_, synth.tostr(s_)) for n_, s_, _ in rP], 15, arrays, meta, light=True)
     # V7: the reference's own known-answer tests for nm_from_cigar (tests/test_nm_from_cigar.py) — evaluate the inputs of each
     # test through the reference function and store (cigar, query, ref, expected NM)
     of = refrun.refload.load_output_functions()

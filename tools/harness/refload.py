@@ -52,7 +52,28 @@ def load(mode='H', vacmap_index_module=None):
     logging.disable(logging.CRITICAL)
     import matplotlib
     matplotlib.use('Agg')
-    return importlib.import_module('vacmap.' + MODE_MODULE[mode])
+    m = importlib.import_module('vacmap.' + MODE_MODULE[mode])
+    _numba_minmax(m)
+    return m
+
+
+def _numba_minmax(m):
+    """numba types `min(50, skipcost)` (mammap_ccs.py:27475, :28587 ...) as float64 when any argument is a float; plain CPython returns the
+    Python int / float it picked, which NumPy (NEP 50) then treats as a WEAK scalar: `50 + np.float32(x)` is computed in float32. Round 3's
+    wider mode-L goldens showed the difference (one float32 ulp in the strand-switch penalty, local_skipcost = 59 > 50). The reference
+    modules therefore get min / max that return np.float64 whenever a float took part, as the compiled code does."""
+    import builtins
+    import numpy as np
+
+    def wrap(f):
+        def g(*a, **kw):
+            r = f(*a, **kw)
+            if len(a) > 1 and not isinstance(r, np.generic) and isinstance(r, (int, float)) and not isinstance(r, bool) \
+                    and any(isinstance(x, (float, np.floating)) for x in a):
+                return np.float64(r)
+            return r
+        return g
+    m.min = wrap(builtins.min); m.max = wrap(builtins.max)
 
 
 def load_output_functions():

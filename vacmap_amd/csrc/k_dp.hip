@@ -31,7 +31,8 @@ __global__ void k_encode(const char* __restrict__ in, uint8_t* __restrict__ out,
 __global__ void __launch_bounds__(64) k_extend(const uint8_t* __restrict__ tcodes, const int64_t* __restrict__ t_off,
                                                const uint8_t* __restrict__ qcodes, const int64_t* __restrict__ q_off, int n_prob,
                                                int match, int mismatch, int o, int e, int bw_in, int zdrop,
-                                               int32_t* __restrict__ out_te, int32_t* __restrict__ out_qe, int32_t* __restrict__ out_sc) {
+                                               int32_t* __restrict__ out_te, int32_t* __restrict__ out_qe, int32_t* __restrict__ out_sc, const int32_t* __restrict__ n_ptr) {
+    if (n_ptr) n_prob = *n_ptr;                  // the batched path keeps the round's problem count on the device
     __shared__ int sH[3][VMX_EXT_RING];
     __shared__ int sE[2][VMX_EXT_RING];
     __shared__ int sF[2][VMX_EXT_RING];

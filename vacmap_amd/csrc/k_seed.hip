@@ -434,6 +434,45 @@ __global__ void __launch_bounds__(256) k_scan_apply(const int64_t* __restrict__ 
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = s_base;
 }
 
+// the same two phases with the element count read from the device (no host round trip to learn it): gridDim.x chunks of ceil(n / gridDim.x)
+// elements; the middle phase is k_scan_i64 over the gridDim.x partial sums, whose total (part_off[gridDim.x]) becomes out[n]
+__global__ void __launch_bounds__(256) k_scan_part_dev(const int64_t* __restrict__ in, int64_t* __restrict__ part, const int32_t* __restrict__ n_ptr) {
+    __shared__ long long s_w[4];
+    const int64_t n = *n_ptr, chunk = (n + gridDim.x - 1) / gridDim.x;
+    int64_t lo = (int64_t)blockIdx.x * chunk; if (lo > n) lo = n;
+    const int64_t hi = lo + chunk < n ? lo + chunk : n;
+    long long s = 0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) s += in[i];
+    s = vmx_wave_sum_i64(s);
+    if (vmx_lane() == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ void __launch_bounds__(256) k_scan_apply_dev(const int64_t* __restrict__ in, int64_t* __restrict__ out, const int64_t* __restrict__ part_off, const int32_t* __restrict__ n_ptr) {
+    __shared__ long long s_part[256];
+    __shared__ long long s_base;
+    const int64_t n = *n_ptr, chunk = (n + gridDim.x - 1) / gridDim.x;
+    int64_t lo = (int64_t)blockIdx.x * chunk; if (lo > n) lo = n;
+    const int64_t hi = lo + chunk < n ? lo + chunk : n;
+    if (threadIdx.x == 0) s_base = part_off[blockIdx.x];
+    __syncthreads();
+    for (int64_t i0 = lo; i0 < hi; i0 += 256) {
+        const int64_t i = i0 + threadIdx.x;
+        long long v = i < hi ? in[i] : 0;
+        long long inc = v;
+        for (int o = 1; o < 64; o <<= 1) { long long x = __shfl_up(inc, o); if (vmx_lane() >= o) inc += x; }
+        if (vmx_lane() == 63) s_part[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        long long wb = 0; for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wb += s_part[w];
+        const long long tot = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (i < hi) out[i] = s_base + wb + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += tot;
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = part_off[gridDim.x];
+}
+
 // exclusive scan of n int64 values (single workgroup, n up to a few million): out[n] = total
 __global__ void __launch_bounds__(256) k_scan_i64(const int64_t* __restrict__ in, int64_t* __restrict__ out, int64_t n, int pow2_round) {
     __shared__ long long s_part[256];

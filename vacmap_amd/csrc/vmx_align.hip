@@ -47,6 +47,17 @@ __global__ void k_readlens(const int64_t* __restrict__ roff, int64_t* __restrict
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) lens[i] = roff[i + 1] - roff[i];
 }
 
+// scalars the host wants are gathered by one-thread kernels into one block and read back with ONE copy (a hipMemcpyAsync per scalar is a
+// runtime copy kernel each: ~100 of them per batch before)
+__global__ void k_stat_put(const int32_t* __restrict__ src, int32_t* __restrict__ dst) { *dst = *src; }
+__global__ void k_pick6_i64(const int64_t* a0, const int64_t* a1, const int64_t* a2, const int64_t* a3, const int64_t* a4, const int64_t* a5, int64_t* __restrict__ out) {
+    out[0] = *a0; out[1] = *a1; out[2] = *a2; out[3] = *a3; out[4] = *a4; out[5] = *a5;
+}
+__global__ void k_final_scalars(const int64_t* nr, const int64_t* nb, const int32_t* oflow, const int32_t* edc, const int32_t* rounds, int64_t* __restrict__ out) {
+    out[0] = *nr; out[1] = *nb; out[2] = *oflow; out[3] = edc[0]; out[4] = edc[1]; out[5] = edc[2];
+    for (int i = 0; i < 8; ++i) out[6 + i] = rounds[i];
+}
+
 struct vm_reads { vm_ctx* ctx; int64_t n; std::vector<int64_t> h_off; DevBuf raw, codes, off; };
 
 struct vmx_batch_bufs {
@@ -55,7 +66,7 @@ struct vmx_batch_bufs {
     // extend stage
     DevBuf er, coff3, soff2, segA, st, en, segA_s, st_s, en_s, segprob, dup, desc[2], rcount, oflow, probread, tl, ql, toff, qoff, tpool, qpool;
     DevBuf edout, carry, ext3, dpsz[4], dpoff[4], dptab, tb, tbredo, bnd, run, cig, ciglen, dpscore, rec, blob, bloboff, reccoff, recclen, dupd, totals;
-    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp, chunkn, sellist, cigq;
+    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp, chunkn, sellist, cigq, statblk;
     void release() { DevBuf* p = (DevBuf*)this; for (size_t i = 0; i < sizeof(*this) / sizeof(DevBuf); ++i) p[i].release(); }
 };
 static vmx_batch_bufs* batch_bufs(vm_ctx* c) { if (!c->bbufs) c->bbufs = new vmx_batch_bufs(); return c->bbufs; }
@@ -94,6 +105,8 @@ int vmx_launch_chain_select(vm_ctx* c, int64_t n, const int64_t* h_aoff, DevBuf&
 
 #define LAUNCH1D(kernel, n, ...) hipLaunchKernelGGL(kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(((n) + 255) / 256, 4096))), dim3(256), 0, c->stream, __VA_ARGS__)
 
+__global__ void k_scan_part_dev(const int64_t* in, int64_t* part, const int32_t* n_ptr);
+__global__ void k_scan_apply_dev(const int64_t* in, int64_t* out, const int64_t* part_off, const int32_t* n_ptr);
 __global__ void k_scan_part(const int64_t* in, int64_t* part, int64_t n, int64_t chunk);
 __global__ void k_scan_apply(const int64_t* in, int64_t* out, const int64_t* part_off, int64_t n, int64_t chunk);
 
@@ -108,22 +121,34 @@ static int dev_scan(vm_ctx* c, vmx_batch_bufs& B, const int64_t* in, int64_t* ou
     return 0;
 }
 
-// one DP round of the extend stage: descriptors (count on device) -> offsets -> gathered pools. returns host copy of the count
+// the same with the element count on the device (*n_ptr <= cap): no host read-back; out[n] = total
+static int dev_scan_dev(vm_ctx* c, vmx_batch_bufs& B, const int64_t* in, int64_t* out, const int32_t* n_ptr) {
+    const int nb = 512;
+    VMX_TRY(B.scanpart.reserve(8 * (size_t)(nb + 2))); VMX_TRY(B.scanoff.reserve(8 * (size_t)(nb + 2)));
+    hipLaunchKernelGGL(k_scan_part_dev, dim3(nb), dim3(256), 0, c->stream, in, B.scanpart.as<int64_t>(), n_ptr);
+    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, B.scanpart.as<int64_t>(), B.scanoff.as<int64_t>(), (int64_t)nb, 0);
+    hipLaunchKernelGGL(k_scan_apply_dev, dim3(nb), dim3(256), 0, c->stream, in, out, B.scanoff.as<int64_t>(), n_ptr);
+    return 0;
+}
+
+// one DP round of the extend stage: descriptors (count on device) -> offsets -> gathered pools. The round's problem count stays on the
+// device (B.rcount; every consumer reads it there and launches a grid sized for the hardware, not for the count); it is copied into
+// slot `stat_slot` of the batch's counter block, which the host reads once at the end. want_cnt: also return a host copy (one wait) —
+// only the gap-fill rounds, whose pools are sized by it, ask for that.
 static int ext_gather_round(vm_ctx* c, vmx_batch_bufs& B, const vm_index_view& ix, int64_t n, const uint8_t* d_ocodes, const int64_t* d_roff, int cur, int redo_only,
-                            int64_t round_cap, int64_t pool_cap) {
+                            int64_t round_cap, int64_t pool_cap, int stat_slot, bool want_cnt) {
     const int G = c->num_cu * 4;
     hipLaunchKernelGGL(k_prob_owner, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, B.er.as<vmx_ext_read>(), (int)n, redo_only, B.probread.as<int32_t>());
     hipLaunchKernelGGL(k_desc_lens, dim3(G), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.tl.as<int64_t>(), B.ql.as<int64_t>());
-    // scans over the full capacity would be wasteful: the count lives on the device, so read it (4 bytes) — also needed to size the DP launches
+    (void)round_cap;                              // vmx_alloc_probs never lets the published count pass the capacity
+    hipLaunchKernelGGL(k_stat_put, dim3(1), dim3(1), 0, c->stream, B.rcount.as<int32_t>(), B.statblk.as<int32_t>() + stat_slot);
     int32_t cnt = 0;
-    VMX_TRY(download(&cnt, B.rcount.p, 1, c->stream));
-    VMX_HIP(vmx_stream_sync(c));
-    if (cnt > round_cap) cnt = (int32_t)round_cap;
-    VMX_TRY(dev_scan(c, B, B.tl.as<int64_t>(), B.toff.as<int64_t>(), (int64_t)cnt));
-    VMX_TRY(dev_scan(c, B, B.ql.as<int64_t>(), B.qoff.as<int64_t>(), (int64_t)cnt));
-    if (cnt) hipLaunchKernelGGL(k_gather, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(),
-                                B.probread.as<int32_t>(), d_ocodes, d_roff, ix.codes, B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), pool_cap,
-                                B.oflow.as<int32_t>());
+    if (want_cnt) { VMX_TRY(download(&cnt, B.rcount.p, 1, c->stream)); VMX_HIP(vmx_stream_sync(c)); }
+    VMX_TRY(dev_scan_dev(c, B, B.tl.as<int64_t>(), B.toff.as<int64_t>(), B.rcount.as<int32_t>()));
+    VMX_TRY(dev_scan_dev(c, B, B.ql.as<int64_t>(), B.qoff.as<int64_t>(), B.rcount.as<int32_t>()));
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)((int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(),
+                       B.probread.as<int32_t>(), d_ocodes, d_roff, ix.codes, B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), pool_cap,
+                       B.oflow.as<int32_t>());
     return cnt;
 }
 
@@ -140,6 +165,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     vm_batch_stats st; memset(&st, 0, sizeof st);
     st.n_reads = n; st.read_bases = total_bases;
     hipEvent_t* ev = c->ev; int nev = 0;
+    c->n_syncs = 0; c->kev_set = 0;
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));
     if (n == 0) { *recs = (vm_record*)malloc(sizeof(vm_record)); *cigar_blob = (char*)malloc(1); if (stats) *stats = st; return VM_OK; }
 
@@ -271,6 +297,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     VMX_TRY(B.rec.reserve(sizeof(vm_record) * (size_t)(cS + 1))); VMX_TRY(B.blob.reserve((size_t)cB + 64)); VMX_TRY(B.reccoff.reserve(8 * (size_t)(cS + 1)));
     VMX_TRY(B.recclen.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.dupd.reserve((size_t)cB + 64));
     VMX_HIP(hipMemsetAsync(B.oflow.p, 0, 4, c->stream));
+    VMX_TRY(B.statblk.reserve(512)); VMX_HIP(hipMemsetAsync(B.statblk.p, 0, 512, c->stream));     // [0..7] i32 round counts | i64 [16..21] gap-fill totals | i64 [32..45] final scalars
     vmx_ext_args A; memset(&A, 0, sizeof A);
     A.n_reads = (int)n; A.nseq = ix.nseq; A.local_maxdiff = prm->local_maxdiff; A.nodiscard = prm->nodiscard; A.hardclip = prm->hardclip; A.redo_only = 0; A.mode = prm->mode; A.maxdivergence = prm->maxdivergence;
     A.ocodes = B.ocodes.as<uint8_t>(); A.roff = d_roff; A.ref = ix.codes; A.coff = ix.coff;
@@ -310,18 +337,18 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
                                        trace->off.push_back((int64_t)trace->rows.size() / 5);
                                    }
                                } };
-    auto ext_round = [&](int redo_only) -> int {   // x-drop extension of the problems of the current round
-        int cnt = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, redo_only, round_cap, pool_cap);
-        if (cnt < 0) return cnt;
-        st.n_ext_problems += cnt;
-        if (cnt) hipLaunchKernelGGL(k_extend, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.qpool.as<uint8_t>(),
-                                    B.qoff.as<int64_t>(), cnt, 2, -4, 4, 4, 100, 50, B.ext3.as<int32_t>(), B.ext3.as<int32_t>() + round_cap, B.ext3.as<int32_t>() + 2 * round_cap);
+    int ext_rounds = 0;
+    auto ext_round = [&](int redo_only) -> int {   // x-drop extension of the problems of the current round (their count stays on the device)
+        int rc = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, redo_only, round_cap, pool_cap, 1 + ext_rounds++, false);
+        if (rc < 0) return rc;
+        hipLaunchKernelGGL(k_extend, dim3((unsigned)((int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.qpool.as<uint8_t>(),
+                           B.qoff.as<int64_t>(), 0, 2, -4, 4, 4, 100, 50, B.ext3.as<int32_t>(), B.ext3.as<int32_t>() + round_cap, B.ext3.as<int32_t>() + 2 * round_cap, B.rcount.as<int32_t>());
         cur ^= 1;
-        return cnt;
+        return 0;
     };
     std::vector<int64_t> dp_tot(5, 0);
     auto gapfill = [&](int redo_only) -> int {
-        int cnt = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, redo_only, round_cap, pool_cap);
+        int cnt = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, redo_only, round_cap, pool_cap, 6 + redo_only, true);
         if (cnt < 0) return cnt;
         for (int i = 0; i < 4; ++i) { VMX_TRY(B.dpsz[i].reserve(8 * (size_t)(cnt + 2))); VMX_TRY(B.dpoff[i].reserve(8 * (size_t)(cnt + 2))); }
         VMX_TRY(B.dptab.reserve(sizeof(vmx_dp_prob) * (size_t)(cnt + 1))); VMX_TRY(B.ciglen.reserve(4 * (size_t)(cnt + 1))); VMX_TRY(B.cigq.reserve(4 * (size_t)(cnt + 1))); VMX_TRY(B.dpscore.reserve(4 * (size_t)(cnt + 1)));
@@ -333,10 +360,13 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         // boundary / run / CIGAR pools
         std::vector<int64_t> h_tboff((size_t)cnt + 1);
         VMX_TRY(download(h_tboff.data(), B.dpoff[0].as<int64_t>(), (size_t)cnt + 1, c->stream));
-        int64_t totals[4];
-        for (int i = 0; i < 4; ++i) VMX_TRY(download(&totals[i], B.dpoff[i].as<int64_t>() + cnt, 1, c->stream));
-        int64_t tq[2]; VMX_TRY(download(&tq[0], B.toff.as<int64_t>() + cnt, 1, c->stream)); VMX_TRY(download(&tq[1], B.qoff.as<int64_t>() + cnt, 1, c->stream));
+        int64_t totals[4], tq[2], six[6];
+        hipLaunchKernelGGL(k_pick6_i64, dim3(1), dim3(1), 0, c->stream, B.dpoff[0].as<int64_t>() + cnt, B.dpoff[1].as<int64_t>() + cnt, B.dpoff[2].as<int64_t>() + cnt, B.dpoff[3].as<int64_t>() + cnt,
+                           B.toff.as<int64_t>() + cnt, B.qoff.as<int64_t>() + cnt, B.statblk.as<int64_t>() + 16);
+        VMX_TRY(download(six, B.statblk.as<int64_t>() + 16, 6, c->stream));
         VMX_HIP(vmx_stream_sync(c));
+        for (int i = 0; i < 4; ++i) totals[i] = six[i];
+        tq[0] = six[4]; tq[1] = six[5];
         std::vector<int32_t> cuts(1, 0);                         // chunk c = problems [cuts[c], cuts[c+1])
         {
             int64_t base = 0;
@@ -374,8 +404,10 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
                                    d_redo_list, d_redo_cnt, 0, ad_pct, (uint8_t*)nullptr, d_redo_bytes);
                 // sizing sync #4: full-matrix traceback space of the problems the first launch queued for the second one (a few per cent of them)
                 unsigned long long redo_bytes = 0; int32_t n_redo = 0;
-                VMX_TRY(download(&redo_bytes, d_redo_bytes, 1, c->stream)); VMX_TRY(download(&n_redo, d_redo_cnt, 1, c->stream));
+                int32_t qr[20];                                   // the queue block holds both numbers: one copy
+                VMX_TRY(download(qr, d_range, 20, c->stream));
                 VMX_HIP(vmx_stream_sync(c));
+                n_redo = qr[12]; memcpy(&redo_bytes, &qr[16], 8);
                 VMX_TRY(B.tbredo.reserve((size_t)redo_bytes + 64));
                 st.dp_redo_tb_bytes += (int64_t)redo_bytes; st.n_dp_redo += n_redo; st.dp_cells += (int64_t)redo_bytes;
                 // second launch: the problems whose band was not proven (a few per cent), in full: the larger ones on a whole wave, the others four per wave
@@ -398,13 +430,13 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     // pass 0
     phase(0);
     {   // divergence filter: edit distance of every segment (:19251)
-        int cnt = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, 0, round_cap, pool_cap);
-        if (cnt < 0) return cnt;
-        st.n_segments = cnt; st.n_ed_problems = cnt;
-        if (cnt) {
-            VMX_TRY(B.order.reserve(4 * (size_t)(round_cap + 1))); VMX_TRY(B.qrange.reserve(64));
+        int rc0 = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, 0, round_cap, pool_cap, 0, false);
+        if (rc0 < 0) return rc0;
+        const int64_t cnt = round_cap;                           // launch widths only: every kernel below reads the real count on the device
+        {
+            VMX_TRY(B.order.reserve(4 * (size_t)(2 * round_cap + 64))); VMX_TRY(B.qrange.reserve(128));
             int32_t* d_range = B.qrange.as<int32_t>(); int32_t* d_cnt = d_range + 4; int32_t* d_nfull = d_range + 8;
-            VMX_TRY(B.dpsz[0].reserve(8 * (size_t)(cnt + 2))); VMX_TRY(B.dpsz[1].reserve(8 * (size_t)(cnt + 2)));
+            VMX_TRY(B.dpsz[0].reserve(8 * (size_t)(round_cap + 2))); VMX_TRY(B.dpsz[1].reserve(8 * (size_t)(round_cap + 2)));
             // tier 0 (k_ed_anchor_bound, k_ext.hip): the segment's own anchors cut the pair into independent short pieces whose summed cost
             // bounds the edit distance from above; then (k_ed_band.hip) four problems per wave in a +-320-row band, one problem per wave in
             // a +-768-row band, and the exact unbanded kernel, each only for the problems the tier before could not prove "keep" for
@@ -454,12 +486,15 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, B.dpsz[0].as<int64_t>(), B.dpoff[0].as<int64_t>(), n, 0);
     hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, B.dpsz[1].as<int64_t>(), B.dpoff[1].as<int64_t>(), n, 0);
     int64_t nr = 0, nb = 0; int32_t oflow = 0;
-    VMX_TRY(download(&nr, B.dpoff[0].as<int64_t>() + n, 1, c->stream)); VMX_TRY(download(&nb, B.dpoff[1].as<int64_t>() + n, 1, c->stream));
-    VMX_TRY(download(&oflow, B.oflow.p, 1, c->stream));
     int32_t n_full = 0, n_t2 = 0, n_t1 = 0;
-    if (st.n_ed_problems) { VMX_TRY(download(&n_full, B.qrange.as<int32_t>() + 8, 1, c->stream)); VMX_TRY(download(&n_t2, B.qrange.as<int32_t>() + 9, 1, c->stream));
-                            VMX_TRY(download(&n_t1, B.qrange.as<int32_t>() + 10, 1, c->stream)); }
+    int64_t fin[14]; int64_t hstat[8];
+    hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(1), 0, c->stream, B.dpoff[0].as<int64_t>() + n, B.dpoff[1].as<int64_t>() + n, B.oflow.as<int32_t>(), B.qrange.as<int32_t>() + 8,
+                       B.statblk.as<int32_t>(), B.statblk.as<int64_t>() + 32);
+    VMX_TRY(download(fin, B.statblk.as<int64_t>() + 32, 14, c->stream));          // record / blob totals, overflow flag, tier counters, per-round problem counts: one copy
     VMX_HIP(vmx_stream_sync(c));
+    nr = fin[0]; nb = fin[1]; oflow = (int32_t)fin[2]; n_full = (int32_t)fin[3]; n_t2 = (int32_t)fin[4]; n_t1 = (int32_t)fin[5];
+    for (int i = 0; i < 8; ++i) hstat[i] = fin[6 + i];
+    st.n_segments = hstat[0]; st.n_ed_problems = hstat[0]; st.n_ext_problems = (int64_t)hstat[1] + hstat[2] + hstat[3] + hstat[4];
     st.n_ed_full = n_full; st.n_ed_tier2 = n_t2; st.n_ed_tier1 = n_t1;
     if (oflow) { set_error("extend stage: a per-batch work pool overflowed"); return VM_ERR_OOM; }
     VMX_TRY(B.totals.reserve(sizeof(vm_record) * (size_t)(nr + 1))); VMX_TRY(B.dupd.reserve((size_t)nb + 64));
@@ -487,6 +522,9 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     float ms = 0;
     hipEventElapsedTime(&ms, ev[0], ev[nev - 1]); st.ms_total = ms;
     for (int i = 1; i < nev && i < 16; ++i) { hipEventElapsedTime(&ms, ev[i - 1], ev[i]); st.ms_stage[i - 1] = ms; }
+    if ((c->kev_set & 1) && hipEventElapsedTime(&ms, c->kev[0], c->kev[1]) == hipSuccess) st.ms_local_seed = ms;
+    if ((c->kev_set & 2) && hipEventElapsedTime(&ms, c->kev[2], c->kev[3]) == hipSuccess) st.ms_cluster = ms;
+    st.n_host_syncs = c->n_syncs;
     for (int pass = 0; pass < 2; ++pass)
         for (int q = 0; q < c->n_gev[pass]; ++q) {
             hipEvent_t* ke = c->gev + 24 * pass + 3 * q;
@@ -596,7 +634,7 @@ int vm_align_batch(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t 
             tot.ms_total += st.ms_total; for (int i = 0; i < 16; ++i) tot.ms_stage[i] += st.ms_stage[i];
             tot.ms_gapfill_fill += st.ms_gapfill_fill; tot.ms_gapfill_trace += st.ms_gapfill_trace; tot.n_gapfill_launches += st.n_gapfill_launches;
             tot.n_ed_full += st.n_ed_full; tot.n_ed_tier2 += st.n_ed_tier2; tot.n_ed_tier1 += st.n_ed_tier1;
-            tot.n_dp_redo += st.n_dp_redo; tot.dp_redo_tb_bytes += st.dp_redo_tb_bytes;
+            tot.n_dp_redo += st.n_dp_redo; tot.dp_redo_tb_bytes += st.dp_redo_tb_bytes; tot.ms_local_seed += st.ms_local_seed; tot.ms_cluster += st.ms_cluster; tot.n_host_syncs += st.n_host_syncs;
         }
         a = b;
     }

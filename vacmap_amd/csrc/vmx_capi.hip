@@ -63,6 +63,7 @@ int vm_ctx_create(int device_id, vm_ctx** out) {
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; set_error("hipStreamCreate failed"); return VM_ERR_HIP; }
     for (int i = 0; i < 24; ++i) (void)hipEventCreate(&c->ev[i]);
     for (int i = 0; i < 48; ++i) (void)hipEventCreate(&c->gev[i]);
+    for (int i = 0; i < 4; ++i) (void)hipEventCreate(&c->kev[i]);
     for (int i = 0; i < 4; ++i) { (void)hipStreamCreate(&c->aux[i]); (void)hipEventCreate(&c->join_ev[i]); }
     (void)hipEventCreate(&c->fork_ev);
     // cost tables -> one device blob
@@ -107,6 +108,7 @@ void vm_ctx_destroy(vm_ctx* c) {
     vmx::devbuf_retired().flush();
     for (int i = 0; i < 24; ++i) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 48; ++i) (void)hipEventDestroy(c->gev[i]);
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(c->kev[i]);
     for (int i = 0; i < 4; ++i) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); (void)hipEventDestroy(c->join_ev[i]); }
     (void)hipEventDestroy(c->fork_ev);
     if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
@@ -242,7 +244,7 @@ int vm_k_extend_batch(vm_ctx* c, int match, int mismatch, int o, int e, int bw, 
     VMX_TRY(c->b[6].reserve(sizeof(int32_t) * 3 * (size_t)(n + 1)));
     int32_t* d_te = c->b[6].as<int32_t>(); int32_t* d_qe = d_te + n; int32_t* d_sc = d_qe + n;
     if (n) hipLaunchKernelGGL(k_extend, dim3(grid_for(c, n, 16)), dim3(64), 0, c->stream, c->b[1].as<uint8_t>(), c->b[2].as<int64_t>(),
-                              c->b[4].as<uint8_t>(), c->b[5].as<int64_t>(), (int)n, match, mismatch, o, e, bw, zdrop, d_te, d_qe, d_sc);
+                              c->b[4].as<uint8_t>(), c->b[5].as<int64_t>(), (int)n, match, mismatch, o, e, bw, zdrop, d_te, d_qe, d_sc, (const int32_t*)nullptr);
     *t_e = host_alloc<int32_t>((size_t)n); *q_e = host_alloc<int32_t>((size_t)n); *score = host_alloc<int32_t>((size_t)n);
     VMX_TRY(download(*t_e, d_te, (size_t)n, c->stream)); VMX_TRY(download(*q_e, d_qe, (size_t)n, c->stream));
     VMX_TRY(download(*score, d_sc, (size_t)n, c->stream));

@@ -103,6 +103,9 @@ struct vm_ctx {
     hipEvent_t ev[24];
     hipEvent_t gev[48];                          // gap-fill chunk events: [redo][chunk 0..7][before fill, after fill, after trace]
     int n_gev[2] = {0, 0};                        // chunks recorded by the last batch per pass
+    hipEvent_t kev[4] = {nullptr, nullptr, nullptr, nullptr};   // around k_local_seed's main launch [0,1] and the clustering kernels [2,3] of the last batch
+    int kev_set = 0;                              // bit 0: [0,1] recorded, bit 1: [2,3] recorded
+    int64_t n_syncs = 0;                          // host waits on this context's stream (reset per batch)
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams for independent launches (LDS-bucketed kernels)
     hipEvent_t fork_ev = nullptr, join_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int64_t last_n_minimizers = 0;               // of the last seed stage (stats)
@@ -115,6 +118,7 @@ struct vm_ctx {
 // With vm_ctx_set_blocking_sync the thread sleeps on an interrupt instead — for callers whose other threads need the cores (the driver's
 // SAM emitters under a CPU quota: spinning waiters push the process over its quota and the whole process, aligners included, is throttled).
 static inline hipError_t vmx_stream_sync(vm_ctx* c) {
+    ++c->n_syncs;
 #ifndef VMX_EMU
     if (c->sync_ev) { const hipError_t e = hipEventRecord(c->sync_ev, c->stream); if (e != hipSuccess) return e; return hipEventSynchronize(c->sync_ev); }
 #endif
@@ -152,7 +156,7 @@ __global__ void k_ed_banded4(const uint8_t* qcodes, const int64_t* q_off, const 
 __global__ void k_ed_flag(const int64_t* ub, const int64_t* q_off, const int64_t* t_off, const int32_t* n_ptr, double maxdiv, int64_t* sizes,
                           int64_t* ed_out, int32_t* n_flagged, int first);
 __global__ void k_extend(const uint8_t* tcodes, const int64_t* t_off, const uint8_t* qcodes, const int64_t* q_off, int n_prob,
-                         int match, int mismatch, int o, int e, int bw_in, int zdrop, int32_t* out_te, int32_t* out_qe, int32_t* out_sc);
+                         int match, int mismatch, int o, int e, int bw_in, int zdrop, int32_t* out_te, int32_t* out_qe, int32_t* out_sc, const int32_t* n_ptr);
 __global__ void k_gapfill_fill(const uint8_t* tcodes, const uint8_t* qcodes, const vmx_dp_prob* probs, int n_prob, int match,
                                int mismatch, int o1, int e1, int o2, int e2, uint8_t* tb_pool, int32_t* bnd_pool, int32_t* out_score,
                                const int32_t* order, int32_t* counter);

@@ -626,7 +626,7 @@ int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, in
     VMX_TRY(download(h_koff.data(), koff.p, (size_t)n + 1, c->stream)); VMX_TRY(download(h_nhits.data(), nh.p, (size_t)n, c->stream));
     std::vector<int32_t> h_mzc((size_t)n);
     VMX_TRY(download(h_mzc.data(), mzc.p, (size_t)n, c->stream));
-    VMX_HIP(hipStreamSynchronize(c->stream));   // sizing sync #1: total (power-of-two padded) hits of the batch
+    VMX_HIP(vmx_stream_sync(c));   // sizing sync #1: total (power-of-two padded) hits of the batch
     c->last_n_minimizers = 0; for (int64_t r = 0; r < n; ++r) c->last_n_minimizers += h_mzc[r];
     const int64_t ktot = h_koff[n];
     VMX_TRY(keys.reserve(8 * (size_t)(ktot + 1))); VMX_TRY(ckeys.reserve(8 * (size_t)(ktot + 1))); VMX_TRY(rows.reserve(32 * (size_t)(ktot + 1)));
@@ -644,6 +644,7 @@ int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, in
         std::vector<int32_t> rl(small); rl.insert(rl.end(), big.begin(), big.end());
         VMX_TRY(upload(B[12], rl.data(), rl.size(), c->stream));
         const int32_t* d_rl = B[12].as<int32_t>();
+        (void)hipEventRecord(c->kev[2], c->stream);
         if (!big.empty()) {
 #ifndef VMX_EMU
             VMX_HIP(hipFuncSetAttribute((const void*)k_cluster_big, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * VMX_SORT_LDS_BIG));
@@ -654,6 +655,7 @@ int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, in
         if (!small.empty())
             hipLaunchKernelGGL(k_cluster, dim3((unsigned)std::min<int64_t>((int64_t)small.size(), (int64_t)c->num_cu * 4)), dim3(256), 8 * VMX_SORT_LDS, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(),
                                koff.as<int64_t>(), nh.as<int64_t>(), d_rl, (int)small.size(), VMX_SORT_LDS, check_num, mi->k, rows.as<int64_t>(), nanc.as<int32_t>());
+        (void)hipEventRecord(c->kev[3], c->stream); c->kev_set |= 2;
     }
     return 0;
 }

@@ -120,7 +120,9 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         return 0;
     };
     A.la_slot_len = 1;
+    (void)hipEventRecord(c->kev[0], c->stream);
     VMX_TRY(run_seed((int)n, G, hit_cap));
+    (void)hipEventRecord(c->kev[1], c->stream); c->kev_set |= 1;
     // sizing sync #2: local anchor counts decide the LDS bucket of every read in the local chain DP
     L.h_la_cnt.resize((size_t)n);
     VMX_TRY(download(L.h_la_cnt.data(), L.la_cnt.p, (size_t)n, c->stream));
