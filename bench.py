@@ -133,9 +133,10 @@ def main():
     # long-running mapper reaches that state after its first large batch). The first pass is cross-checked against the oracle.
     longest = int(np.argmax([lens[p].sum() for p in plan]))
     verified = None; oi = None; t_oracle_index = None
+    warm_runs = 0
     for s in range(args.warmup):
         if s == 0 and args.verify > 0 and rank == 0:
-            st, recs, _ = resident[longest].align(index, prm, want_records=True, ctx=ctx)
+            st, recs, _ = resident[longest].align(index, prm, want_records=True, ctx=ctx); warm_runs += 1
             import oracle_lib as O
             tq = time.time()
             oi = O.Index.from_seqs(names, contigs, k=k, w=10)
@@ -149,7 +150,7 @@ def main():
                 mine = [t[1:] for t in recs if t[0] == j]
                 ok += int((st[j] == 0) == (ost == 0) and mine == [t[1:] for t in orecs])
             verified = '%d/%d' % (ok, nv)
-        pipe.warm(resident[longest])
+        pipe.warm(resident[longest]); warm_runs += pipe.inflight
 
     agg = {}
 
@@ -176,26 +177,47 @@ def main():
 
     if rank == 0:
         K = args.steps
-        # roofline of the dominant kernel (k_gapfill_fill_ns): algorithmic bytes per launch per SURVEY §8(d):
+        # roofline of the DOMINANT kernel of this run: the three heaviest kernels of the path are bracketed by HIP events on the stream
+        # they run on (vm_batch_stats: gap-fill fill, local re-seeding, hit clustering); the one with the largest time per step in THIS
+        # run is reported. achieved = SURVEY 8(d)'s path-level algorithmic bytes per step / that kernel's time per step:
         #   B(read) = L + 16 M + 8 n + (L + 14000)/4 + 40 R + C   with measured M (minimizers), n (anchors), R (records), C (CIGAR bytes)
         _free, _tot = torch.cuda.mem_get_info(local_rank); hbm_used_gb = (_tot - _free) / 1e9      # index + reads + every context's work pools
         algo_bytes = (agg['read_bases'] + 16 * agg['n_minimizers'] + 8 * agg['n_anchors'] + (agg['read_bases'] + 14000 * agg['n_reads']) / 4.0 +
                       40 * agg['n_records'] + agg['cigar_bytes'])
-        # one step launches the kernel for the normal pass and for the nofilter redo (a handful of reads); per-launch figures are per STEP
-        fill_ms = agg['ms_gapfill_fill'] / K
-        achieved = (algo_bytes / K) / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
-        traffic, traffic_src, valu = None, None, None
+        kms = {'k_gapfill_fill_ns': agg['ms_gapfill_fill'] / K, 'k_local_seed': agg.get('ms_local_seed', 0.0) / K, 'k_cluster_big': agg.get('ms_cluster', 0.0) / K}
+        # what each of them must move at the least (its own algorithmic bytes per step): fill = the DP strings + one traceback byte per band
+        # cell; local re-seeding = the read (1 B/base) + the 2-bit reference window (SURVEY 8(d)'s (L + 14000)/4); clustering = 8 B per hit in, 32 B per anchor out
+        kalgo = {'k_gapfill_fill_ns': (agg['dp_cells'] + agg['dp_string_bytes']) / K,
+                 'k_local_seed': (agg['read_bases'] + (agg['read_bases'] + 14000 * agg['n_reads']) / 4.0) / K,
+                 'k_cluster_big': (8 * agg['n_hits'] + 32 * agg['n_anchors']) / K}
+        dom = max(kms, key=lambda k_: kms[k_])
+        dom_ms = kms[dom]
+        achieved = (algo_bytes / K) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         pj, src = latest_pmc(workload_id)
-        if pj is not None:
-            kk = pj['kernels'].get('k_gapfill_fill_ns') or {}
-            traffic = kk.get('hbm_bytes_per_step'); traffic_src = src; valu = kk.get('valu')
-        kbytes = (agg['dp_cells'] + agg['dp_string_bytes']) / K
-        roofline = {'bound': 'hbm', 'kernel': 'k_gapfill_fill_ns', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                    'traffic': traffic, 'traffic_source': traffic_src, 'valu': valu, 'avg_kernel_ms_per_step': fill_ms, 'algorithmic_bytes_per_step': algo_bytes / K,
-                    'kernel_bytes_per_step': kbytes, 'kernel_GBps': kbytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0,
-                    'dp_cells_per_s': (agg['dp_cells'] / K) / (fill_ms * 1e-3) if fill_ms > 0 else 0.0,
-                    'note': 'achieved = path-level algorithmic bytes of SURVEY 8(d) / kernel time; the kernel is an integer DP bound by VALU issue, not by HBM (see `valu` '
-                            'and profiles/r02_valu_calibration.md); see DESIGN.md §4'}
+        per_kernel = {}
+        for kn in kms:
+            e = {'ms_per_step': kms[kn], 'kernel_algorithmic_bytes_per_step': kalgo[kn], 'traffic': None, 'traffic_over_algorithmic': None, 'valu': None}
+            pk = ((pj or {}).get('kernels') or {}).get(kn if kn != 'k_cluster_big' or 'k_cluster_big' in ((pj or {}).get('kernels') or {}) else 'k_cluster')
+            if pk:
+                e['traffic'] = pk.get('hbm_bytes_per_step'); e['valu'] = pk.get('valu')
+                if e['traffic'] and kalgo[kn] > 0:
+                    e['traffic_over_algorithmic'] = e['traffic'] / kalgo[kn]
+            e['kernel_GBps'] = (e['traffic'] or kalgo[kn]) / (kms[kn] * 1e-3) / 1e9 if kms[kn] > 0 else 0.0
+            per_kernel[kn] = e
+        pipeline_valu = None
+        if pj is not None and pj.get('valu_wave_insts_per_step'):
+            floor_ms = pj['valu_wave_insts_per_step'] / pj['valu_peak_wave_insts_per_s'] * 1e3
+            pipeline_valu = {'wave_insts_per_step': pj['valu_wave_insts_per_step'], 'floor_ms_per_step': floor_ms, 'ms_per_step_over_floor': (dt_all * 1e3 / K) / floor_ms,
+                             'note': 'all kernels of a step: SQ_INSTS_VALU / calibrated issue peak (profiles/r02_valu_calibration.md) against the measured step'}
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                    'traffic': per_kernel[dom]['traffic'], 'traffic_source': src, 'traffic_over_kernel_algorithmic': per_kernel[dom]['traffic_over_algorithmic'],
+                    'avg_kernel_ms_per_step': dom_ms, 'algorithmic_bytes_per_step': algo_bytes / K,
+                    'kernels': per_kernel, 'valu': per_kernel['k_gapfill_fill_ns']['valu'], 'pipeline_valu': pipeline_valu,
+                    'dp_cells_per_s': (agg['dp_cells'] / K) / (kms['k_gapfill_fill_ns'] * 1e-3) if kms['k_gapfill_fill_ns'] > 0 else 0.0,
+                    'note': 'kernel = the one with the largest HIP-event time per step in this run (batches share the GPU, so the time includes what the other '
+                            'batches\' kernels cost it); achieved = path-level algorithmic bytes of SURVEY 8(d) / that time. The path is not HBM-bound (SURVEY 8(d)): '
+                            '`kernels` gives every instrumented kernel its own algorithmic bytes, its PMC traffic (FETCH_SIZE + WRITE_SIZE) and their ratio, '
+                            '`valu` the VALU issue fraction of the gap fill, `pipeline_valu` the step against the VALU floor of all its kernels; DESIGN.md §4'}
         cpu = None
         if args.cpu_sample > 0 and world == 1:
             import oracle_lib as O
@@ -233,10 +255,11 @@ def main():
                        'schedule': 'vacmap_amd.pipeline: %s, %d batches in flight per GPU' % (
                            'arrival-order batches' if args.arrival_order else 'length-binned batches inside windows of %d batches' % args.window_batches, pipe.inflight),
                        'parallelism': 'reads sharded over %d GPU(s), index built by rank 0 and broadcast over RCCL' % world if world > 1 else 'one GPU'},
+            'timed_bases': int(rbases), 'warmup_batches': warm_runs, 'warmup_bases': int(warm_runs * lens[plan[longest]].sum()),
             'reads_per_s': nreads / dt_all, 'input_Gbp_per_s': rbases / dt_all / 1e9, 'failed_reads': int(nfail), 'unmapped_reads': int(agg['n_unmapped']),
             'device_ms_per_step': agg['ms_total'] / K, 'stage_ms_per_step': [x / K for x in agg['ms_stage'][:8]],
             'stage_names': ['seed', 'global_chain', 'local', 'divergence_filter', 'edge_extension', 'gapfill+records', 'nofilter_redo', 'download'],
-            'gapfill_trace_ms_per_step': agg['ms_gapfill_trace'] / K,
+            'gapfill_trace_ms_per_step': agg['ms_gapfill_trace'] / K, 'host_syncs_per_step': agg.get('n_host_syncs', 0) / K,
             'per_read': {'minimizers': agg['n_minimizers'] / max(agg['n_reads'], 1), 'hits': agg['n_hits'] / max(agg['n_reads'], 1), 'anchors': agg['n_anchors'] / max(agg['n_reads'], 1),
                          'local_anchors': agg['n_local_anchors'] / max(agg['n_reads'], 1), 'dp_problems': agg['n_dp_problems'] / max(agg['n_reads'], 1),
                          'dp_cells': agg['dp_cells'] / max(agg['n_reads'], 1), 'records': agg['n_records'] / max(agg['n_reads'], 1)},

@@ -94,3 +94,19 @@ def test_emu_mode_r(ctx, oracle):
     """mode R (fixed-penalty chains with refund, all-chain re-seeding, _scar): GC-fast R on synthetic anchors, whole path on a few reads"""
     KC.check_chain_global_fast_synth(ctx, oracle, seed=33, n_reads=1, L=120, per_pos=6, mode='R')
     assert KC.check_align_random(ctx, oracle, mode='R', n=3, seed=51, reflen=60000, mean_len=2500) >= 3
+
+
+def test_emu_oom_degrades_to_sub_batches(ctx, oracle, golden, monkeypatch):
+    """a batch the device has no memory for is cut in two and tried again (down to single reads) instead of failing with VM_ERR_OOM:
+    same records, same order, same per-read status (test hook VMX_TEST_OOM_ABOVE_BASES stands in for a failed hipMalloc)"""
+    from vacmap_amd.lib import align_batch
+    meta, arrays = golden
+    gi, oi = KC._case_index(ctx, oracle, meta, arrays, 'D')
+    seqs = [arrays['D_r%d_seq' % ri].tobytes().decode() for ri in (2, 4, 5, 3)]       # incl. the 12-base read that stays unmapped
+    st0, rec0, _ = align_batch(ctx, gi, ctx.lib.params('H'), seqs)
+    monkeypatch.setenv('VMX_TEST_OOM_ABOVE_BASES', str(max(len(s) for s in seqs) + 10))
+    st1, rec1, stats = align_batch(ctx, gi, ctx.lib.params('H'), seqs)
+    assert list(st0) == list(st1) and rec0 == rec1 and stats['n_reads'] == len(seqs)
+    monkeypatch.setenv('VMX_TEST_OOM_ABOVE_BASES', '5')                                # not even one read fits: the error surfaces
+    with pytest.raises(Exception):
+        align_batch(ctx, gi, ctx.lib.params('H'), seqs)

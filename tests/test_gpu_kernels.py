@@ -146,7 +146,7 @@ def test_round3_goldens(ctx, oracle, golden):
     KC.check_local_golden(ctx, oracle, golden, cases=cases)
     KC.check_align_golden(ctx, oracle, golden, cases=cases)
     n = KC.check_stage_trace_golden(ctx, oracle, golden, cases=['N'])
-    assert n >= 1
+    assert n[0] >= 1 and n[5] >= 1                      # rebuild_chain_break and fix_simple_inv (its left-flank branch) seen on the device
 
 
 def test_mmi_roundtrip_on_device(ctx, oracle, golden, tmp_path):

@@ -457,6 +457,11 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
             hipLaunchKernelGGL(k_ed_flag, dim3((unsigned)std::min<int64_t>((cnt + 255) / 256, 1024)), dim3(256), 0, c->stream, B.dpsz[1].as<int64_t>(), B.qoff.as<int64_t>(), B.toff.as<int64_t>(),
                                B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_nfull, 0);
             hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt);
+            // the exact tier is hardly ever needed (0 problems per step on the bench workload), and its wide workgroups wait for room on a
+            // GPU the other batches keep full — an empty launch cost more than this 4-byte read-back does: launch only when something is left
+            int32_t h_nfull = 0;
+            VMX_TRY(download(&h_nfull, d_nfull, 1, c->stream)); VMX_HIP(vmx_stream_sync(c));
+            if (h_nfull > 0)
             for (int which = 0; which < 2; ++which)
                 hipLaunchKernelGGL(k_edit_distance, dim3((unsigned)std::min<int64_t>(cnt, ed_wgs * (which == 0 ? 1 : 2))), dim3(which == 0 ? 64 * VMX_ED_WAVES : 256), 0, c->stream,
                                    B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(), B.toff.as<int64_t>(),
@@ -614,15 +619,40 @@ int vm_align_batch(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t 
     if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
     VMX_HIP(hipSetDevice(c->device));
     static const int64_t max_bases = [] { const char* e = getenv("VMX_MAX_BATCH_BASES"); const long long v = e ? atoll(e) : 0; return v > 0 ? (int64_t)v : (int64_t)VMX_MAX_BATCH_BASES; }();
-    if (n <= VMX_MAX_BATCH_READS && offsets[n] - offsets[0] <= max_bases) return align_batch_one(c, mi, prm, n, seqs, offsets, recs, n_recs, cigar_blob, status_per_read, stats);
+    // test hook: pretend the device is out of memory for any sub-batch above this many bases (exercises the degradation below)
+    const char* oom_env = getenv("VMX_TEST_OOM_ABOVE_BASES");
+    const int64_t fake_oom = oom_env ? atoll(oom_env) : 0;
+    auto run_one = [&](int64_t a, int64_t b, vm_record** r, int64_t* nr, char** cb, vm_batch_stats* st) -> int {
+        if (fake_oom > 0 && offsets[b] - offsets[a] > fake_oom) { *r = nullptr; *nr = 0; *cb = nullptr; set_error("out of device memory (test hook)"); return VM_ERR_OOM; }
+        return align_batch_one(c, mi, prm, b - a, seqs, offsets + a, r, nr, cb, status_per_read ? status_per_read + a : nullptr, st);
+    };
+    if (n <= VMX_MAX_BATCH_READS && offsets[n] - offsets[0] <= max_bases) {
+        const int rc = run_one(0, n, recs, n_recs, cigar_blob, stats);
+        if (rc != VM_ERR_OOM || n <= 1) return rc;
+        free(*recs); free(*cigar_blob);                          // fall through: the batch is cut into pieces that fit
+    }
     *recs = nullptr; *n_recs = 0; *cigar_blob = nullptr;
     std::vector<vm_record> all; std::string blob;
     vm_batch_stats tot; memset(&tot, 0, sizeof tot);
+    // work list of read ranges in order; a range the device has no memory for (the grow-only pools of this and the other contexts, the
+    // index and the reads share the HBM) is cut in two and tried again instead of failing the whole call with VM_ERR_OOM — down to single reads
+    std::vector<std::pair<int64_t, int64_t>> work;
     for (int64_t a = 0; a < n;) {
         int64_t b = a + 1;                                       // at least one read per sub-batch, whatever its length
         while (b < n && b - a < VMX_MAX_BATCH_READS && offsets[b + 1] - offsets[a] <= max_bases) ++b;
+        work.emplace_back(a, b); a = b;
+    }
+    for (size_t wi = 0; wi < work.size(); ++wi) {
+        const int64_t a = work[wi].first, b = work[wi].second;
         vm_record* r = nullptr; int64_t nr = 0; char* cb = nullptr; vm_batch_stats st;
-        const int rc = align_batch_one(c, mi, prm, b - a, seqs, offsets + a, &r, &nr, &cb, status_per_read ? status_per_read + a : nullptr, &st);
+        const int rc = run_one(a, b, &r, &nr, &cb, &st);
+        if (rc == VM_ERR_OOM && b - a > 1) {
+            free(r); free(cb);
+            vmx::devbuf_retired().flush();                       // parked (outgrown) allocations go back to the device first
+            const int64_t mid = a + (b - a) / 2;
+            work[wi] = std::make_pair(a, mid); work.insert(work.begin() + (std::ptrdiff_t)wi + 1, std::make_pair(mid, b));
+            --wi; continue;
+        }
         if (rc < 0) { free(r); free(cb); return rc; }
         int64_t bl = 0; for (int64_t i = 0; i < nr; ++i) bl = std::max(bl, r[i].cigar_off + r[i].cigar_len);
         for (int64_t i = 0; i < nr; ++i) { vm_record x = r[i]; x.read_idx += (int32_t)a; x.cigar_off += (int64_t)blob.size(); all.push_back(x); }
@@ -636,7 +666,6 @@ int vm_align_batch(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t 
             tot.n_ed_full += st.n_ed_full; tot.n_ed_tier2 += st.n_ed_tier2; tot.n_ed_tier1 += st.n_ed_tier1;
             tot.n_dp_redo += st.n_dp_redo; tot.dp_redo_tb_bytes += st.dp_redo_tb_bytes; tot.ms_local_seed += st.ms_local_seed; tot.ms_cluster += st.ms_cluster; tot.n_host_syncs += st.n_host_syncs;
         }
-        a = b;
     }
     *recs = (vm_record*)malloc(sizeof(vm_record) * std::max<size_t>(all.size(), 1)); *cigar_blob = (char*)malloc(std::max<size_t>(blob.size(), 1));
     if (!*recs || !*cigar_blob) { free(*recs); free(*cigar_blob); *recs = nullptr; *cigar_blob = nullptr; set_error("out of host memory"); return VM_ERR_OOM; }
