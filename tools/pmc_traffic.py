@@ -37,7 +37,11 @@ steps = bench['steps']
 timed_bases = bench['timed_bases']; warm_bases = bench['warmup_bases']
 scale = timed_bases / float(timed_bases + warm_bases) / steps            # total over the run -> per timed step
 VALU_PEAK_PER_US_PER_SIMD = 574.0      # profiles/r02_valu_calibration.md: packed-int16 / DPP / v_max wave-instructions per microsecond per SIMD (4.18 cycles each at 2.4 GHz)
-tot_valu = sum(v.get('SQ_INSTS_VALU', 0.0) for v in va.values()) if va else 0.0
+def once(k):      # kernels of the index build and the read upload: they run once per process, not per step
+    return k.startswith('k_ref_sketch') or k.startswith('k_idx_') or 'rocprim' in k or k.startswith('k_encode')
+
+
+tot_valu = sum(v.get('SQ_INSTS_VALU', 0.0) for k, v in va.items() if not once(k)) if va else 0.0
 res = {'workload_id': bench['config']['workload_id'], 'steps': steps, 'warmup_batches': bench.get('warmup_batches'), 'per_step_scale': scale,
        'valu_wave_insts_per_step': (tot_valu * scale) if tot_valu else None, 'valu_peak_wave_insts_per_s': VALU_PEAK_PER_US_PER_SIMD * 1e6 * 1024,
        'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE (separate passes, --kernel-trace only) of the default '
@@ -56,8 +60,11 @@ for k in sorted(fa, key=lambda k: -(fa[k]['FETCH_SIZE'] + wa.get(k, {}).get('WRI
                      'utilisation_4cycle_model': util, 'frac_of_calibrated_peak': util / 0.96,
                      'peak_wave_insts_per_s': VALU_PEAK_PER_US_PER_SIMD * 1e6 * 1024, 'cycles_per_wave_inst': 4.18,
                      'note': 'time-weighted over every launch of the kernel incl. the low-occupancy redo launches; calibration in profiles/r02_valu_calibration.md'}
+    if once(k):
+        res.setdefault('once_per_process', {})[k.split('<')[0][:60]] = {'launches': ln, 'hbm_bytes_total': f + w}
+        continue
     if (f + w) * scale > 16e6 or k in ('k_gapfill_fill_ns', 'k_local_seed', 'k_cluster_big', 'k_cluster'):
         res['kernels'][k] = e
-res['total_hbm_bytes_per_step'] = sum((fa[k]['FETCH_SIZE'] + wa.get(k, {}).get('WRITE_SIZE', 0)) for k in fa) * 1024 * scale
+res['total_hbm_bytes_per_step'] = sum((fa[k]['FETCH_SIZE'] + wa.get(k, {}).get('WRITE_SIZE', 0)) for k in fa if not once(k)) * 1024 * scale
 json.dump(res, open(out, 'w'), indent=1)
 print(out, {k: round(v['hbm_bytes_per_step'] / 1e9, 2) for k, v in list(res['kernels'].items())[:8]})
