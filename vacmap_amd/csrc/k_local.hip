@@ -106,7 +106,6 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
     __shared__ unsigned long long s_min, s_max, s_min2, s_max2;
     __shared__ int s_wmax[16];
     __shared__ int s_next;
-    __shared__ uint32_t s_bk[VMX_LSEED_BUCKETS + 2];     // sorted-mark table: first mark of every k-mer bucket (k-mer >> bshift)
     const int nw = (int)(blockDim.x >> 6);
     const int k = A.k;
     const int nkey = 1 << (2 * k);
@@ -259,9 +258,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             }
             int npos = (status == 0 && readend > readstart) ? readend - readstart : 0;
             if (npos > A.pcnt_cap) { status = VM_READ_CAPACITY_DEV; npos = 0; }
-            // --- table of the window's k-mers
-            int nmk = 0, mk_lds = 0;                              // sorted-mark table (use_bm): number of marks, where they live (vmx_block_sort_u64_tiled's code)
-            const int bshift = 2 * k > VMX_LSEED_BUCKET_BITS ? 2 * k - VMX_LSEED_BUCKET_BITS : 0;
+            // --- table: one atomic exchange per window position links it in front of its 9-mer's list
             if (use_bm) {
                 // only the window positions whose 9-mer the read can ask for are linked (about one in nine: the read window holds ~30 k of the
                 // 4^9 k-mers): the bitmap first holds the READ's k-mers (forward and reverse complement), a coalesced sweep lists the matching
@@ -288,7 +285,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                         for (int i = 0; i < k - 1; ++i) { const uint8_t c = A.ref[x0 + i]; nval = c > 3 ? 0 : nval + 1; km = (km << 2) | (uint32_t)(c & 3); }
                         for (int j = 0; j < 8 && x0 + j < hi; ++j) {
                             const uint8_t c = A.ref[x0 + j + k - 1]; nval = c > 3 ? 0 : nval + 1; km = ((km << 2) | (uint32_t)(c & 3)) & KMASK;
-                            if (nval >= k && ((BM[km >> 5] >> (km & 31)) & 1u)) { const int p = atomicAdd(&s_next, 1); if (p < A.hit_cap) HKEY2[p] = ((uint64_t)km << 23) | (uint64_t)(base + (int)(x0 + j - lo)); }
+                            if (nval >= k && ((BM[km >> 5] >> (km & 31)) & 1u)) { const int p = atomicAdd(&s_next, 1); if (p < A.hit_cap) SQ[p] = base + (int)(x0 + j - lo); }
                         }
                     }
                 }
@@ -296,21 +293,14 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 int nmark = s_next;
                 __syncthreads();
                 if (nmark > A.hit_cap) { status = VM_READ_CAPACITY_DEV; nmark = 0; npos = 0; }      // re-run with larger pools (vmx_stage_local.hip)
-                // The marks ARE the table: sorted by (k-mer, window index) — in LDS when they fit the sort tile (a 15 kb read marks ~3 k window
-                // positions), tile-wise through HBM otherwise — with the first mark of every k-mer bucket in s_bk. A look-up reads two bucket
-                // bounds and scans the bucket's one or two marks; the matches come out in ascending reference order. No head table in HBM, no
-                // atomic exchanges, no linked lists: building and probing them was half of this kernel's 4 MB of traffic per read.
-                nmk = nmark;
-                int NPM = 1; while (NPM < nmark) NPM <<= 1;
-                for (int i = nmark + (int)threadIdx.x; i < NPM; i += (int)blockDim.x) HKEY2[i] = ~0ULL;
+                for (int i = (int)threadIdx.x; i < (1 << (2 * k)) / 32; i += (int)blockDim.x) BM[i] = 0u;
                 __syncthreads();
-                mk_lds = 0;
-                if (nmark > 1) mk_lds = vmx_block_sort_u64_tiled(HKEY2, NPM, s_sort, VMX_SORT_LDS);
-                else if (nmark == 1) { if (threadIdx.x == 0) s_sort[0] = HKEY2[0]; mk_lds = 1; __syncthreads(); }
-                for (int i = (int)threadIdx.x; i <= nmark; i += (int)blockDim.x) {
-                    const int kb = i < nmark ? (int)((mk_lds == 2 ? s_sort[vmx_sw(i)] : (mk_lds == 1 ? s_sort[i] : HKEY2[i])) >> (23 + bshift)) : VMX_LSEED_BUCKETS;
-                    const int kp = i > 0 ? (int)((mk_lds == 2 ? s_sort[vmx_sw(i - 1)] : (mk_lds == 1 ? s_sort[i - 1] : HKEY2[i - 1])) >> (23 + bshift)) : -1;
-                    for (int bb = kp + 1; bb <= kb; ++bb) s_bk[bb] = (uint32_t)i;
+                for (int e = (int)threadIdx.x; e < nmark; e += (int)blockDim.x) {
+                    const int idx = SQ[e];
+                    bool ok; const uint32_t km = vmx_kmer_at(A.ref, tpos_of(idx), k, ok);
+                    const int old = VMX_HEAD_IDX(atomicExch(&HEAD[VMX_HB(km)], (int)((ep << 23) | (unsigned)idx)));
+                    atomicOr(&BM[km >> 5], 1u << (km & 31));
+                    NEXT[idx] = bucketed ? (int)(((km >> 14) << 23) | (unsigned)(old < 0 ? 0x7fffff : old)) : old;
                 }
             } else
             for (int v = 0; v < niv; ++v) {
@@ -340,20 +330,9 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 int cf = 0, cr = 0; long long ff = 0, fr = 0;
                 bool ok; const uint32_t fw = vmx_kmer_at(RD, iloc, k, ok);
                 const uint32_t rv = vmx_kmer_rc(fw, k);
-                const bool pf = ok && fw != rv, pr = ok && fw != rv && iloc > 0;
-                if (use_bm) {
-                    // sorted marks: the matches of a k-mer are the marks of its bucket that carry it; the guide bisection only runs for a
-                    // position that has a match at all (one in five)
-                    bool have = false; long long interval = 0, ref1 = 0, ref2 = 0, rgap = 0;
-#define VMX_MARK_AT(i) (mk_lds == 2 ? s_sort[vmx_sw(i)] : (mk_lds == 1 ? s_sort[i] : HKEY2[i]))
-#define VMX_CLOSEST() do { if (!have) { int b0, b1, c0, c1; vmx_find_closest(GQ, mm, iloc, b0, b1, c0, c1); interval = (long long)b0 + b1 + 500; if (interval > 2000) interval = 2000; \
-                                        ref1 = GR[c0]; ref2 = GR[c1]; rgap = (long long)iloc - GQ[c0]; if (rgap < 0) rgap = -rgap; have = true; } } while (0)
-                    if (pf) { const int e1 = (int)s_bk[(fw >> bshift) + 1]; for (int i = (int)s_bk[fw >> bshift]; i < e1; ++i) { const uint64_t key = VMX_MARK_AT(i); const uint32_t kk = (uint32_t)(key >> 23); if (kk < fw) continue; if (kk > fw) break;
-                                  VMX_CLOSEST(); const long long rl = tpos_of((int)(key & 0x7fffff)); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cf == 0) ff = rl; ++cf; } } }
-                    if (pr) { const int e1 = (int)s_bk[(rv >> bshift) + 1]; for (int i = (int)s_bk[rv >> bshift]; i < e1; ++i) { const uint64_t key = VMX_MARK_AT(i); const uint32_t kk = (uint32_t)(key >> 23); if (kk < rv) continue; if (kk > rv) break;
-                                  VMX_CLOSEST(); const long long rl = tpos_of((int)(key & 0x7fffff)); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cr == 0) fr = rl; ++cr; } } }
-                } else
-                if (pf || pr) {
+                const bool pf = ok && fw != rv && (!use_bm || ((BM[fw >> 5] >> (fw & 31)) & 1u));
+                const bool pr = ok && fw != rv && iloc > 0 && (!use_bm || ((BM[rv >> 5] >> (rv & 31)) & 1u));
+                if (pf || pr) {                                  // (the guide bisection only for the one position in five that can hit at all)
                     const int hf = pf ? VMX_HEAD_IDX(HEAD[VMX_HB(fw)]) : -1, hr = pr ? VMX_HEAD_IDX(HEAD[VMX_HB(rv)]) : -1;   // both list heads in flight together
                     int b0, b1, c0, c1; vmx_find_closest(GQ, mm, iloc, b0, b1, c0, c1);
                     long long interval = (long long)b0 + b1 + 500; if (interval > 2000) interval = 2000;
@@ -404,18 +383,10 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 const long long ref1 = GR[c0], ref2 = GR[c1];
                 long long rgap = (long long)iloc - GQ[c0]; if (rgap < 0) rgap = -rgap;
                 const long long wf = w;
-                long long wr;
-                if (use_bm) {
-                    { const int e1 = (int)s_bk[(fw >> bshift) + 1]; for (int i = (int)s_bk[fw >> bshift]; i < e1; ++i) { const uint64_t key = VMX_MARK_AT(i); const uint32_t kk = (uint32_t)(key >> 23); if (kk < fw) continue; if (kk > fw) break;
-                          const long long rl = tpos_of((int)(key & 0x7fffff)); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; } }
-                    wr = w;
-                    if (iloc > 0) { const int e1 = (int)s_bk[(rv >> bshift) + 1]; for (int i = (int)s_bk[rv >> bshift]; i < e1; ++i) { const uint64_t key = VMX_MARK_AT(i); const uint32_t kk = (uint32_t)(key >> 23); if (kk < rv) continue; if (kk > rv) break;
-                          const long long rl = tpos_of((int)(key & 0x7fffff)); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; } }
-                } else {
-                    for (int t = VMX_HEAD_IDX(HEAD[VMX_HB(fw)]); t >= 0;) { const int e = NEXT[t]; if (VMX_ENT_OK(e, fw)) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; } t = VMX_ENT_NEXT(e); }
-                    wr = w;
-                    if (iloc > 0) for (int t = VMX_HEAD_IDX(HEAD[VMX_HB(rv)]); t >= 0;) { const int e = NEXT[t]; if (VMX_ENT_OK(e, rv)) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; } t = VMX_ENT_NEXT(e); }
-                }
+                const bool pf = !use_bm || ((BM[fw >> 5] >> (fw & 31)) & 1u), pr = iloc > 0 && (!use_bm || ((BM[rv >> 5] >> (rv & 31)) & 1u));
+                for (int t = pf ? VMX_HEAD_IDX(HEAD[VMX_HB(fw)]) : -1; t >= 0;) { const int e = NEXT[t]; if (VMX_ENT_OK(e, fw)) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; } t = VMX_ENT_NEXT(e); }
+                const long long wr = w;
+                if (pr) for (int t = VMX_HEAD_IDX(HEAD[VMX_HB(rv)]); t >= 0;) { const int e = NEXT[t]; if (VMX_ENT_OK(e, rv)) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; } t = VMX_ENT_NEXT(e); }
                 if (wr - wf > 1) vmx_isort_i64(HVAL + wf, (int)(wr - wf));
                 if (w - wr > 1) vmx_isort_i64(HVAL + wr, (int)(w - wr));
                 for (long long x = wf; x < w; ++x) {
@@ -590,6 +561,4 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
 #undef VMX_HB
 #undef VMX_ENT_OK
 #undef VMX_ENT_NEXT
-#undef VMX_MARK_AT
-#undef VMX_CLOSEST
 }

@@ -76,8 +76,6 @@ struct vmx_lseed_args {
 #ifndef VMX_LSEED_WAVES
 #define VMX_LSEED_WAVES 6            // k_local_seed: waves per SIMD the register allocation is held to (80 VGPRs: 3 workgroups of 512 per CU)
 #endif
-#define VMX_LSEED_BUCKET_BITS 11     // k_local_seed: k-mer buckets of the sorted-mark table (first mark per bucket in LDS: 8 KB)
-#define VMX_LSEED_BUCKETS (1 << VMX_LSEED_BUCKET_BITS)
 #define VMX_SORT_LDS 4096           // uint64 keys sorted in LDS by vmx_block_sort_u64 (larger sorts run in HBM)
 #ifdef VMX_EMU
 #define VMX_SORT_LDS_BIG 8192       // emulator build: a small tile so that the CPU tests reach the tiled (multi-tile) sort
