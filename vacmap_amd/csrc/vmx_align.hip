@@ -53,6 +53,31 @@ __global__ void k_stat_put(const int32_t* __restrict__ src, int32_t* __restrict_
 __global__ void k_pick6_i64(const int64_t* a0, const int64_t* a1, const int64_t* a2, const int64_t* a3, const int64_t* a4, const int64_t* a5, int64_t* __restrict__ out) {
     out[0] = *a0; out[1] = *a1; out[2] = *a2; out[3] = *a3; out[4] = *a4; out[5] = *a5;
 }
+// gap-fill sizing on the device: the totals of the four per-problem pools and of the string pools, and the cut of the problems into chunks
+// of at most `limit` traceback bytes (a chunk ends before the first problem that would pass the limit; a single larger problem is a chunk
+// of its own) — found by bisection on the offsets. out: [0] n, [1..4] pool totals, [5] target bytes, [6] query bytes, [7] number of chunks m,
+// [8 .. 8 + VMX_MAX_CHUNKS] first problem of every chunk (m + 1 entries), then the traceback offsets at those problems (m + 1 entries);
+// m = -1 when more than VMX_MAX_CHUNKS chunks would be needed.
+#define VMX_MAX_CHUNKS 24
+__global__ void k_tb_plan(const int64_t* __restrict__ tboff, const int64_t* bnd, const int64_t* run, const int64_t* cig, const int64_t* toff, const int64_t* qoff,
+                          const int32_t* __restrict__ n_ptr, int64_t limit, int64_t* __restrict__ out) {
+    const int n = *n_ptr;
+    out[0] = n; out[1] = tboff[n]; out[2] = bnd[n]; out[3] = run[n]; out[4] = cig[n]; out[5] = toff[n]; out[6] = qoff[n];
+    int64_t* cuts = out + 8; int64_t* offs = out + 8 + VMX_MAX_CHUNKS + 1;
+    int m = 0, p = 0;
+    cuts[0] = 0; offs[0] = 0;
+    while (p < n) {
+        const int64_t base = tboff[p];
+        // the largest e in (p, n] with tboff[e] - base <= limit; at least one problem per chunk
+        int lo = p + 1, hi = n;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tboff[mid] - base <= limit) lo = mid; else hi = mid - 1; }
+        p = lo; ++m;
+        if (m > VMX_MAX_CHUNKS) { m = -1; break; }
+        cuts[m] = p; offs[m] = tboff[p];
+    }
+    out[7] = m;
+}
+
 __global__ void k_final_scalars(const int64_t* nr, const int64_t* nb, const int32_t* oflow, const int32_t* edc, const int32_t* rounds, int64_t* __restrict__ out) {
     out[0] = *nr; out[1] = *nb; out[2] = *oflow; out[3] = edc[0]; out[4] = edc[1]; out[5] = edc[2];
     for (int i = 0; i < 8; ++i) out[6 + i] = rounds[i];
@@ -297,7 +322,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     VMX_TRY(B.rec.reserve(sizeof(vm_record) * (size_t)(cS + 1))); VMX_TRY(B.blob.reserve((size_t)cB + 64)); VMX_TRY(B.reccoff.reserve(8 * (size_t)(cS + 1)));
     VMX_TRY(B.recclen.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.dupd.reserve((size_t)cB + 64));
     VMX_HIP(hipMemsetAsync(B.oflow.p, 0, 4, c->stream));
-    VMX_TRY(B.statblk.reserve(512)); VMX_HIP(hipMemsetAsync(B.statblk.p, 0, 512, c->stream));     // [0..7] i32 round counts | i64 [16..21] gap-fill totals | i64 [32..45] final scalars
+    VMX_TRY(B.statblk.reserve(1024)); VMX_HIP(hipMemsetAsync(B.statblk.p, 0, 1024, c->stream));     // [0..7] i32 round counts | i64 [16..21] gap-fill totals | i64 [32..45] final scalars
     vmx_ext_args A; memset(&A, 0, sizeof A);
     A.n_reads = (int)n; A.nseq = ix.nseq; A.local_maxdiff = prm->local_maxdiff; A.nodiscard = prm->nodiscard; A.hardclip = prm->hardclip; A.redo_only = 0; A.mode = prm->mode; A.maxdivergence = prm->maxdivergence;
     A.ocodes = B.ocodes.as<uint8_t>(); A.roff = d_roff; A.ref = ix.codes; A.coff = ix.coff;
@@ -348,33 +373,29 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     };
     std::vector<int64_t> dp_tot(5, 0);
     auto gapfill = [&](int redo_only) -> int {
-        int cnt = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, redo_only, round_cap, pool_cap, 6 + redo_only, true);
-        if (cnt < 0) return cnt;
-        for (int i = 0; i < 4; ++i) { VMX_TRY(B.dpsz[i].reserve(8 * (size_t)(cnt + 2))); VMX_TRY(B.dpoff[i].reserve(8 * (size_t)(cnt + 2))); }
-        VMX_TRY(B.dptab.reserve(sizeof(vmx_dp_prob) * (size_t)(cnt + 1))); VMX_TRY(B.ciglen.reserve(4 * (size_t)(cnt + 1))); VMX_TRY(B.cigq.reserve(4 * (size_t)(cnt + 1))); VMX_TRY(B.dpscore.reserve(4 * (size_t)(cnt + 1)));
+        int rcg = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, redo_only, round_cap, pool_cap, 6 + redo_only, false);
+        if (rcg < 0) return rcg;
+        // per-problem tables are sized for the round's capacity; the count, the pool totals and the chunk cuts come back in ONE read
+        for (int i = 0; i < 4; ++i) { VMX_TRY(B.dpsz[i].reserve(8 * (size_t)(round_cap + 2))); VMX_TRY(B.dpoff[i].reserve(8 * (size_t)(round_cap + 2))); }
+        VMX_TRY(B.dptab.reserve(sizeof(vmx_dp_prob) * (size_t)(round_cap + 1))); VMX_TRY(B.ciglen.reserve(4 * (size_t)(round_cap + 1))); VMX_TRY(B.cigq.reserve(4 * (size_t)(round_cap + 1))); VMX_TRY(B.dpscore.reserve(4 * (size_t)(round_cap + 1)));
         const int G = c->num_cu * 4;
         hipLaunchKernelGGL(k_dp_sizes, dim3(G), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.dpsz[0].as<int64_t>(), B.dpsz[1].as<int64_t>(),
                            B.dpsz[2].as<int64_t>(), B.dpsz[3].as<int64_t>());
-        for (int i = 0; i < 4; ++i) VMX_TRY(dev_scan(c, B, B.dpsz[i].as<int64_t>(), B.dpoff[i].as<int64_t>(), (int64_t)cnt));
-        // sizing sync #3: traceback offsets (to cut the problems into chunks of at most VMX_TB_CHUNK traceback bytes) and the totals of the
-        // boundary / run / CIGAR pools
-        std::vector<int64_t> h_tboff((size_t)cnt + 1);
-        VMX_TRY(download(h_tboff.data(), B.dpoff[0].as<int64_t>(), (size_t)cnt + 1, c->stream));
-        int64_t totals[4], tq[2], six[6];
-        hipLaunchKernelGGL(k_pick6_i64, dim3(1), dim3(1), 0, c->stream, B.dpoff[0].as<int64_t>() + cnt, B.dpoff[1].as<int64_t>() + cnt, B.dpoff[2].as<int64_t>() + cnt, B.dpoff[3].as<int64_t>() + cnt,
-                           B.toff.as<int64_t>() + cnt, B.qoff.as<int64_t>() + cnt, B.statblk.as<int64_t>() + 16);
-        VMX_TRY(download(six, B.statblk.as<int64_t>() + 16, 6, c->stream));
+        for (int i = 0; i < 4; ++i) VMX_TRY(dev_scan_dev(c, B, B.dpsz[i].as<int64_t>(), B.dpoff[i].as<int64_t>(), B.rcount.as<int32_t>()));
+        // sizing sync #3 (the only one of the round): problem count, pool totals, chunk cuts (at most VMX_TB_CHUNK traceback bytes per chunk)
+        int64_t plan[8 + 2 * (VMX_MAX_CHUNKS + 1)];
+        hipLaunchKernelGGL(k_tb_plan, dim3(1), dim3(1), 0, c->stream, B.dpoff[0].as<int64_t>(), B.dpoff[1].as<int64_t>(), B.dpoff[2].as<int64_t>(), B.dpoff[3].as<int64_t>(),
+                           B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.rcount.as<int32_t>(), (int64_t)VMX_TB_CHUNK, B.statblk.as<int64_t>() + 64);
+        VMX_TRY(download(plan, B.statblk.as<int64_t>() + 64, sizeof(plan) / 8, c->stream));
         VMX_HIP(vmx_stream_sync(c));
-        for (int i = 0; i < 4; ++i) totals[i] = six[i];
-        tq[0] = six[4]; tq[1] = six[5];
-        std::vector<int32_t> cuts(1, 0);                         // chunk c = problems [cuts[c], cuts[c+1])
-        {
-            int64_t base = 0;
-            for (int p = 0; p < cnt; ++p) if (h_tboff[(size_t)p + 1] - base > VMX_TB_CHUNK && p > cuts.back()) { cuts.push_back(p); base = h_tboff[(size_t)p]; }
-            cuts.push_back(cnt);
-        }
+        const int cnt = (int)plan[0];
+        int64_t totals[4] = {plan[1], plan[2], plan[3], plan[4]}, tq[2] = {plan[5], plan[6]};
+        if (plan[7] < 0) { set_error("gap fill: more traceback chunks than VMX_MAX_CHUNKS"); return VM_ERR_OOM; }
+        std::vector<int32_t> cuts; std::vector<int64_t> h_tboff_at;            // chunk q = problems [cuts[q], cuts[q+1]); traceback offset at every cut
+        for (int q = 0; q <= (int)plan[7]; ++q) { cuts.push_back((int32_t)plan[8 + q]); h_tboff_at.push_back(plan[8 + VMX_MAX_CHUNKS + 1 + q]); }
+        if (cuts.size() < 2) { cuts.assign(2, 0); h_tboff_at.assign(2, 0); }
         int64_t tbmax = 0;
-        for (size_t q = 0; q + 1 < cuts.size(); ++q) tbmax = std::max(tbmax, h_tboff[(size_t)cuts[q + 1]] - h_tboff[(size_t)cuts[q]]);
+        for (size_t q = 0; q + 1 < cuts.size(); ++q) tbmax = std::max(tbmax, h_tboff_at[q + 1] - h_tboff_at[q]);
         VMX_TRY(B.tb.reserve((size_t)tbmax + 64)); VMX_TRY(B.bnd.reserve(4 * (size_t)(totals[1] + 4))); VMX_TRY(B.run.reserve(4 * (size_t)(totals[2] + 4))); VMX_TRY(B.cig.reserve((size_t)totals[3] + 16));
         st.n_dp_problems += cnt; st.dp_cells += totals[0];
         hipLaunchKernelGGL(k_dp_table, dim3(G), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.dpoff[0].as<int64_t>(),
@@ -394,7 +415,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
             for (size_t q = 0; q + 1 < cuts.size(); ++q) {
                 const int p0 = cuts[q], pn = cuts[q + 1] - cuts[q];
                 // the problems' absolute traceback offsets index a buffer that holds this chunk only
-                uint8_t* tb_base = B.tb.as<uint8_t>() - h_tboff[(size_t)p0];
+                uint8_t* tb_base = B.tb.as<uint8_t>() - h_tboff_at[q];
                 hipEvent_t* ke = q < 8 ? c->gev + (redo_only ? 24 : 0) + 3 * q : nullptr;      // HIP events around the dominant kernel, on the stream it runs on
                 hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>() + p0, B.chunkn.as<int32_t>() + q, (int64_t)VMX_HEAD_THRESH, B.order.as<int32_t>(), d_range, d_cnt);
                 (void)hipMemsetAsync(d_redo_cnt, 0, 16, c->stream); (void)hipMemsetAsync(d_redo_bytes, 0, 8, c->stream);
