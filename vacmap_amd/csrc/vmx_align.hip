@@ -50,9 +50,6 @@ __global__ void k_readlens(const int64_t* __restrict__ roff, int64_t* __restrict
 // scalars the host wants are gathered by one-thread kernels into one block and read back with ONE copy (a hipMemcpyAsync per scalar is a
 // runtime copy kernel each: ~100 of them per batch before)
 __global__ void k_stat_put(const int32_t* __restrict__ src, int32_t* __restrict__ dst) { *dst = *src; }
-__global__ void k_pick6_i64(const int64_t* a0, const int64_t* a1, const int64_t* a2, const int64_t* a3, const int64_t* a4, const int64_t* a5, int64_t* __restrict__ out) {
-    out[0] = *a0; out[1] = *a1; out[2] = *a2; out[3] = *a3; out[4] = *a4; out[5] = *a5;
-}
 // gap-fill sizing on the device: the totals of the four per-problem pools and of the string pools, and the cut of the problems into chunks
 // of at most `limit` traceback bytes (a chunk ends before the first problem that would pass the limit; a single larger problem is a chunk
 // of its own) — found by bisection on the offsets. out: [0] n, [1..4] pool totals, [5] target bytes, [6] query bytes, [7] number of chunks m,
