@@ -258,19 +258,15 @@ __device__ __forceinline__ void vmx_cluster_body(uint64_t* __restrict__ keys, ui
         uint64_t* CK = cl_keys + key_off[r];
         if (N > 1) vmx_block_sort_u64_tiled(K, N, s_sort, tile);
         __syncthreads();
-        // cluster starts, compacted in order: CK[c] = start index of cluster c (temporarily). Every thread owns a contiguous slice of the sorted
-        // hits: it counts its starts, ONE block scan places the slices (a scan per 1024 hits cost a dozen barrier rounds per read)
+        // cluster starts, compacted in order: CK[c] = start index of cluster c (temporarily)
         int run = 0;
-        {
-            const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x;
-            const int lo = (int)threadIdx.x * per < n ? (int)threadIdx.x * per : n, hi = lo + per < n ? lo + per : n;
-            int cnt = 0;
-            uint64_t prev = lo > 0 && lo < n ? K[lo - 1] : 0;
-            for (int i = lo; i < hi; ++i) { const uint64_t cur = K[i]; cnt += (i == 0) || ((long long)(cur >> 28) - (long long)(prev >> 28) > 5000); prev = cur; }
-            int tot; int ex = vmx_block_excl_scan(cnt, s_scan, &tot);
-            prev = lo > 0 && lo < n ? K[lo - 1] : 0;
-            for (int i = lo; i < hi; ++i) { const uint64_t cur = K[i]; if ((i == 0) || ((long long)(cur >> 28) - (long long)(prev >> 28) > 5000)) CK[ex++] = (uint64_t)i; prev = cur; }
-            run = tot;
+        for (int i0 = 0; i0 < n; i0 += (int)blockDim.x) {
+            int i = i0 + (int)threadIdx.x;
+            int f = 0;
+            if (i < n) f = (i == 0) || ((long long)(K[i] >> 28) - (long long)(K[i - 1] >> 28) > 5000);
+            int tot; int ex = vmx_block_excl_scan(f, s_scan, &tot);
+            if (f) CK[run + ex] = (uint64_t)i;
+            run += tot;
             __syncthreads();
         }
         if (threadIdx.x == 0) s_ncl = run;
@@ -305,25 +301,18 @@ __device__ __forceinline__ void vmx_cluster_body(uint64_t* __restrict__ keys, ui
             } else {
                 const int need = check_num - above;                   // clusters of size exactly s* to take, first in reference order
                 uint64_t* sel = s_sort + 512;                         // selected rank keys (<= check_num <= 1024), behind the histogram
-                int nsel = 0;
-                {   // every thread owns a contiguous slice of the clusters (reference order): clusters larger than s* are taken, and the first
-                    // `need` of size s*; two block scans in all (equal-sized before the slice, taken before the slice)
-                    const int per = (ncl + (int)blockDim.x - 1) / (int)blockDim.x;
-                    const int lo = (int)threadIdx.x * per < ncl ? (int)threadIdx.x * per : ncl, hi = lo + per < ncl ? lo + per : ncl;
-                    int eqc = 0, bigc = 0;
-                    for (int c = lo; c < hi; ++c) { const uint64_t st = CK[c], en = (c + 1 < ncl) ? CK[c + 1] : (uint64_t)n; const int sz = (int)(en - st); eqc += sz == sstar; bigc += sz > sstar; }
-                    int toteq; const int exeq = vmx_block_excl_scan(eqc, s_scan, &toteq);
-                    int takeeq = need - exeq; if (takeeq < 0) takeeq = 0; if (takeeq > eqc) takeeq = eqc;       // how many of this slice's equal-sized clusters are taken
+                int nsel = 0, neq = 0;
+                for (int c0 = 0; c0 < ncl; c0 += (int)blockDim.x) {
+                    const int c = c0 + (int)threadIdx.x;
+                    int sz = 0; uint64_t st = 0;
+                    if (c < ncl) { st = CK[c]; const uint64_t en = (c + 1 < ncl) ? CK[c + 1] : (uint64_t)n; sz = (int)(en - st); }
+                    const int eq = sz == sstar;
+                    int toteq; const int exeq = vmx_block_excl_scan(eq, s_scan, &toteq);
+                    const int take = sz > sstar || (eq && neq + exeq < need);
                     __syncthreads();
-                    int tott; int ext = vmx_block_excl_scan(bigc + takeeq, s_scan, &tott);
-                    int eqseen = 0;
-                    for (int c = lo; c < hi; ++c) {
-                        const uint64_t st = CK[c], en = (c + 1 < ncl) ? CK[c + 1] : (uint64_t)n; const int sz = (int)(en - st);
-                        bool take = sz > sstar;
-                        if (sz == sstar) { take = eqseen < takeeq; ++eqseen; }
-                        if (take) sel[ext++] = ((uint64_t)(0xffffffffu - (uint32_t)sz) << 32) | st;
-                    }
-                    nsel = tott;
+                    int tott; const int ext = vmx_block_excl_scan(take, s_scan, &tott);
+                    if (take) sel[nsel + ext] = ((uint64_t)(0xffffffffu - (uint32_t)sz) << 32) | st;
+                    nsel += tott; neq += toteq;
                     __syncthreads();
                 }
                 int NS = 1; while (NS < nsel) NS <<= 1;
