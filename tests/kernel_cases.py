@@ -453,6 +453,42 @@ def check_align_random(ctx, O, mode='R', n=8, seed=51, reflen=120000, mean_len=5
     return len(orecs)
 
 
+def check_seed_sparse_noise(ctx, O, ref_mb=10, read_len=4000, seed=71, min_hits=900):
+    """`.map()` in the regime of an hg38-size index: one true locus plus a thousand-odd ISOLATED stray hits (22-mers of the read planted every
+    7 kb of a random reference, some in pairs 3 kb apart = small clusters, some 6 kb apart = neighbours that are not a cluster) — the
+    filtered form of k_cluster_big (isolated hits are never sorted; the missing clusters come from a radix select). Anchors equal the
+    oracle's for check_num below, at and above the number of multi-hit clusters, and beyond the filtered form's limit (general path)."""
+    from vacmap_amd import synth
+    from vacmap_amd.lib import Index
+    rng = np.random.default_rng(seed)
+    ref = synth.make_reference([int(ref_mb * 1e6)], seed=seed)[0]
+    p0 = len(ref) // 3
+    src = ref[p0:p0 + read_len].copy()
+    pos = 50000; j = 0
+    while pos + 7000 < len(ref):
+        if not (p0 - 20000 < pos < p0 + read_len + 20000):
+            a = int(rng.integers(0, read_len - 30)); ln = int(rng.integers(18, 26))
+            ref[pos:pos + ln] = src[a:a + ln]
+            if j % 9 == 4:                      # a second stray hit 3 kb on: one cluster of two across bins
+                b = int(rng.integers(0, read_len - 30)); ref[pos + 3000:pos + 3000 + 22] = src[b:b + 22]
+            if j % 11 == 7:                     # a neighbour 6 kb on: adjacent bin, but its own cluster
+                b = int(rng.integers(0, read_len - 30)); ref[pos + 6000:pos + 6000 + 22] = src[b:b + 22]
+            j += 1
+        pos += 7000 + int(rng.integers(0, 2000))
+    gi = Index.from_seqs(ctx, ['noise'], [ref], k=15, w=10)
+    oi = O.Index.from_seqs(['noise'], [ref], k=15, w=10)
+    reads = [synth.mutate(src, 0.03, rng).tobytes(), synth.revcomp(synth.mutate(src[500:3500], 0.02, rng)).tobytes(), src[:700].tobytes()]
+    most = 0
+    for check_num in (100, 3, 1, 700, 1024, 3000, -1):
+        got = ctx.map_batch(gi, reads, check_num=check_num, mid_occ=200)
+        for i, rd in enumerate(reads):
+            exp = oi.map(rd, check_num, 200)
+            assert np.array_equal(got[i], exp), (i, check_num, len(got[i]), len(exp))
+            most = max(most, len(exp))
+    assert most >= min_hits, most
+    gi.close()
+
+
 def _case_index(ctx, O, meta, arrays, cid):
     from vacmap_amd.lib import Index
     c = meta[cid]

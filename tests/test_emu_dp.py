@@ -68,6 +68,15 @@ def test_emu_seed_many_hits(ctx, oracle):
     KC.check_seed_many_hits(ctx, oracle, copies=44, unit=2500, read_len=4500, seed=61, min_hits=9000)      # > one 8192-key tile of the emulator build
 
 
+def test_emu_seed_sparse_noise(ctx, oracle, monkeypatch):
+    monkeypatch.setenv('VMX_CLUSTER_SMALL_MAX', '256')          # route these reads to k_cluster_big, whose filtered form is under test
+    import ctypes
+    f = ctx.lib.L.vmx_emu_cf_count; f.argtypes = [ctypes.c_int]
+    t0, d0 = f(0), f(1)
+    KC.check_seed_sparse_noise(ctx, oracle, ref_mb=10, read_len=4000, seed=71, min_hits=900)
+    assert f(0) - t0 >= 8 and f(1) - d0 <= 6, (f(0) - t0, f(1) - d0)     # the filtered form answered (it declines check_num > 1024 and -1)
+
+
 def test_emu_local(ctx, oracle, golden):
     KC.check_local_golden(ctx, oracle, golden, cases=['B', 'D'])
 

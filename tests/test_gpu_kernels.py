@@ -40,6 +40,14 @@ def test_reference_call_shapes(ctx, oracle, golden):
     KC.check_reference_call_shapes(ctx, oracle, golden)
 
 
+def test_seed_sparse_noise(ctx, oracle, monkeypatch):
+    """k_cluster_big's filtered form: a true locus plus thousands of isolated stray hits (the hg38-size regime), every check_num branch"""
+    monkeypatch.setenv('VMX_CLUSTER_SMALL_MAX', '256')
+    KC.check_seed_sparse_noise(ctx, oracle, ref_mb=40, read_len=9000, seed=72, min_hits=4200)
+    monkeypatch.delenv('VMX_CLUSTER_SMALL_MAX')
+    KC.check_seed_sparse_noise(ctx, oracle, ref_mb=60, read_len=12000, seed=73, min_hits=6000)
+
+
 def test_seed_many_hits(ctx, oracle):
     """k_cluster_big: reads with more hits than one / several 16384-key LDS tiles (tiled bitonic sort with its HBM steps)"""
     KC.check_seed_many_hits(ctx, oracle, copies=44, unit=2500, read_len=4500, seed=61, min_hits=9000)

@@ -242,6 +242,220 @@ __global__ void __launch_bounds__(256) k_fill_hits(const uint32_t* __restrict__ 
 // workgroups per CU) for reads with few hits, 16384 (128 KB, one workgroup of BLOCK threads per CU) for the others; a read with more
 // hits than a tile (a 15 kb read meets ~11 k hits in an hg38-size index, a 60 kb read 45 k) is sorted tile-wise with the few long-distance
 // steps through HBM (vmx_block_sort_u64_tiled).
+// ---- k_cluster_big, filtered form ------------------------------------------------------------------------------------------------
+// A 15 kb read meets ~11 k hits in an hg38-size index, of which ~10 k are isolated random hits: no other hit within 5000 bp, so each can
+// only ever be a cluster of one, and only the first few by reference position can reach the output (they rank behind every larger
+// cluster). Sorting them is wasted work. Here a 2-bit-per-slot filter over 8192-bp reference bins (2^18 slots in LDS: "one hit" / "two or
+// more") finds the hits that have a neighbour in their own or an adjacent bin — a superset of every hit with another hit within 5000 bp, so
+// every cluster of two or more lies wholly inside it — and only those CANDIDATES (~1.5-2 k) are sorted and cut into clusters, in LDS. If fewer
+// than check_num clusters of two or more exist, the missing ones are the singletons with the smallest reference positions (candidate
+// clusters of one and isolated hits alike): their cut-off comes from a three-pass radix select, no sort. The result is VMX-S1's, hit for hit.
+// Returns false (nothing written) when the read does not fit the scheme; the caller then takes the general path.
+#ifdef VMX_EMU
+#define VMX_CF_SLOT_BITS 15                 // emulator build: a layout that fits its 8192-key tile, so that the CPU tests run this path
+#define VMX_CF_CAND 2048
+#else
+#define VMX_CF_SLOT_BITS 18
+#define VMX_CF_CAND 4096
+#endif
+#define VMX_CF_F_U64 (1 << (VMX_CF_SLOT_BITS - 5))                       /* filter: 2 bits per slot */
+#define VMX_CF_CS_U64 ((VMX_CF_CAND + 512) / 4)                          /* cluster starts, uint16 each */
+#define VMX_CF_TOTAL_U64 (VMX_CF_F_U64 + VMX_CF_CAND + VMX_CF_CS_U64 + 1024 + 1024)
+__device__ __forceinline__ bool vmx_cf_is_cand(const uint32_t* F, uint64_t key) {
+    const unsigned slot = (unsigned)((key >> 28) >> 13) & ((1u << VMX_CF_SLOT_BITS) - 1u);
+    const unsigned lo = (slot - 1u) & ((1u << VMX_CF_SLOT_BITS) - 1u), hi = (slot + 1u) & ((1u << VMX_CF_SLOT_BITS) - 1u);
+    return ((F[slot >> 4] >> (2 * (slot & 15))) & 2u) || ((F[lo >> 4] >> (2 * (lo & 15))) & 1u) || ((F[hi >> 4] >> (2 * (hi & 15))) & 1u);
+}
+#ifdef VMX_EMU
+// emulator-only test hook: how many reads the filtered form answered / handed back to the general path
+static int g_vmx_cf_taken = 0, g_vmx_cf_declined = 0;
+extern "C" int vmx_emu_cf_count(int which) { return which ? g_vmx_cf_declined : g_vmx_cf_taken; }
+#endif
+template <int BLOCK>
+__device__ __forceinline__ bool vmx_cluster_filtered(const uint64_t* __restrict__ K, int n, int check_num, int kmer, uint64_t* s_sort, int* s_scan,
+                                                     int64_t* __restrict__ out, int32_t* __restrict__ n_anchors_r) {
+    __shared__ int s_cf[8];
+    uint32_t* F = (uint32_t*)s_sort;                              // 64 KB: 2 bits per slot
+    uint64_t* CAND = s_sort + VMX_CF_F_U64;                       // 32 KB: candidate keys, sorted in place
+    uint16_t* CS = (uint16_t*)(CAND + VMX_CF_CAND);               // 9 KB: first hit of every candidate cluster (+ end); later the output offsets
+    uint32_t* HIST = (uint32_t*)(CAND + VMX_CF_CAND + VMX_CF_CS_U64);     // 8 KB: radix-select / size histogram; later the isolated keys that were selected
+    uint64_t* ISO = (uint64_t*)HIST;
+    uint64_t* SEL = CAND + VMX_CF_CAND + VMX_CF_CS_U64 + 1024;    // 8 KB: rank keys of the selected clusters
+    const int tid = (int)threadIdx.x;
+    if (n > 0x3fff) return false;                                 // cluster sizes travel in 14 bits of the rank key
+    for (int i = tid; i < (1 << VMX_CF_SLOT_BITS) / 16; i += BLOCK) F[i] = 0u;
+    if (tid == 0) { s_cf[0] = 0; s_cf[3] = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += BLOCK) {
+        const unsigned slot = (unsigned)((K[i] >> 28) >> 13) & ((1u << VMX_CF_SLOT_BITS) - 1u);
+        const unsigned sh = 2 * (slot & 15);
+        const unsigned old = atomicOr(&F[slot >> 4], 1u << sh);
+        if ((old >> sh) & 1u) atomicOr(&F[slot >> 4], 2u << sh);
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += BLOCK) {
+        const uint64_t key = K[i];
+        if (vmx_cf_is_cand(F, key)) { const int p = atomicAdd(&s_cf[0], 1); if (p < VMX_CF_CAND) CAND[p] = key; }
+    }
+    __syncthreads();
+    const int ncand = s_cf[0];
+    __syncthreads();
+    if (ncand > VMX_CF_CAND) return false;
+    int NC = 1; while (NC < ncand) NC <<= 1;
+    for (int i = ncand + tid; i < NC; i += BLOCK) CAND[i] = VMX_INF64;
+    __syncthreads();
+    const bool fast = NC > 1 && vmx_bitonic_fast_ok(NC);
+    if (fast) {
+        for (int i = tid; i < NC; i += BLOCK) { const int j = vmx_sw(i); if (j > i) { const uint64_t a = CAND[i]; CAND[i] = CAND[j]; CAND[j] = a; } }   // linear -> swizzled (an involution)
+        __syncthreads();
+        vmx_bitonic_tile_sw(CAND, NC, 0, NC);
+    } else if (NC > 1) vmx_block_bitonic_passes(CAND, NC);
+#define VMX_CF_C(i) (CAND[fast ? vmx_sw(i) : (i)])
+    // candidate clusters: starts in order (CS), then sizes by difference
+    int ncl = 0;
+    for (int i0 = 0; i0 < ncand; i0 += BLOCK) {
+        const int i = i0 + tid;
+        int f = 0;
+        if (i < ncand) f = (i == 0) || ((long long)(VMX_CF_C(i) >> 28) - (long long)(VMX_CF_C(i - 1) >> 28) > 5000);
+        int tot; const int ex = vmx_block_excl_scan(f, s_scan, &tot);
+        if (f) CS[ncl + ex] = (uint16_t)i;
+        ncl += tot;
+        __syncthreads();
+    }
+    if (tid == 0) CS[ncl] = (uint16_t)ncand;
+    for (int i = tid; i < 2048; i += BLOCK) HIST[i] = 0u;
+    __syncthreads();
+    // clusters of two or more: how many, and the histogram of their sizes (bin 1023 = larger)
+    int m2 = 0;
+    for (int c = tid; c < ncl; c += BLOCK) { const int sz = (int)CS[c + 1] - (int)CS[c]; if (sz >= 2) { ++m2; atomicAdd(&HIST[sz < 1023 ? sz : 1023], 1u); } }
+    { int tot; (void)vmx_block_excl_scan(m2, s_scan, &tot); m2 = tot; }
+    __syncthreads();
+    const int niso = n - ncand;                                   // isolated hits: singletons by construction
+    const int nsingle = (ncl - m2) + niso;
+    int nsel = 0;
+    if (m2 >= check_num) {
+        // the cut falls among the clusters of two or more: size s* of the check_num-th, everything larger, and the first of size s* in reference order
+        if (tid == 0) {
+            int acc = 0, sstar = 0, above = 0;
+            for (int b = 1023; b >= 2; --b) { if (acc + (int)HIST[b] >= check_num) { sstar = b; above = acc; break; } acc += (int)HIST[b]; }
+            s_cf[1] = sstar; s_cf[2] = above;
+        }
+        __syncthreads();
+        const int sstar = s_cf[1], need = check_num - s_cf[2];
+        __syncthreads();
+        if (sstar >= 1023 || sstar < 2) return false;
+        int neq = 0;
+        for (int c0 = 0; c0 < ncl; c0 += BLOCK) {
+            const int c = c0 + tid;
+            int sz = 0, st = 0;
+            if (c < ncl) { st = CS[c]; sz = (int)CS[c + 1] - st; }
+            const int eq = sz == sstar;
+            int toteq; const int exeq = vmx_block_excl_scan(eq, s_scan, &toteq);
+            const int take = sz > sstar || (eq && neq + exeq < need);
+            __syncthreads();
+            int tott; const int ext = vmx_block_excl_scan(take, s_scan, &tott);
+            if (take) SEL[nsel + ext] = ((uint64_t)(0x3fffu - (unsigned)sz) << 50) | ((VMX_CF_C(st) >> 28) << 14) | (uint64_t)st;
+            nsel += tott; neq += toteq;
+            __syncthreads();
+        }
+    } else {
+        // every cluster of two or more is taken; the rest are the R singletons with the smallest reference positions
+        for (int c0 = 0; c0 < ncl; c0 += BLOCK) {
+            const int c = c0 + tid;
+            int sz = 0, st = 0;
+            if (c < ncl) { st = CS[c]; sz = (int)CS[c + 1] - st; }
+            if (sz > 0x3fff) s_cf[3] = 1;
+            const int take = sz >= 2;
+            int tott; const int ext = vmx_block_excl_scan(take, s_scan, &tott);
+            if (take) SEL[nsel + ext] = ((uint64_t)(0x3fffu - (unsigned)sz) << 50) | ((VMX_CF_C(st) >> 28) << 14) | (uint64_t)st;
+            nsel += tott;
+            __syncthreads();
+        }
+        int R = check_num - m2; if (R > nsingle) R = nsingle;
+        uint64_t T = ~0ULL;                                       // singletons with reference position <= T are taken
+        if (R < nsingle) {
+            // radix select of the R-th smallest position: 12 bits per pass, most significant first; positions of singletons are distinct
+            uint64_t prefix = 0; int rem = R;
+            for (int shift = 24; shift >= 0; shift -= 12) {
+                for (int i = tid; i < 2048; i += BLOCK) HIST[i] = 0u;         // 4096 16-bit counters (n <= 16384)
+                __syncthreads();
+                const uint64_t himask = shift == 24 ? 0ULL : (~0ULL << (shift + 12));
+                for (int c = tid; c < ncl; c += BLOCK) if ((int)CS[c + 1] - (int)CS[c] == 1) {
+                    const uint64_t v = VMX_CF_C(CS[c]) >> 28;
+                    if ((v & himask) == prefix) { const unsigned b = (unsigned)(v >> shift) & 0xfffu; atomicAdd(&HIST[b >> 1], 1u << (16 * (b & 1))); }
+                }
+                for (int i = tid; i < n; i += BLOCK) {
+                    const uint64_t key = K[i];
+                    if (!vmx_cf_is_cand(F, key)) { const uint64_t v = key >> 28; if ((v & himask) == prefix) { const unsigned b = (unsigned)(v >> shift) & 0xfffu; atomicAdd(&HIST[b >> 1], 1u << (16 * (b & 1))); } }
+                }
+                __syncthreads();
+                // bins 4 tid .. 4 tid + 3 per thread; the bin where the running count reaches `rem`
+                int cnt[4]; int sum = 0;
+                for (int j = 0; j < 4; ++j) { const unsigned b = 4u * (unsigned)tid + (unsigned)j; cnt[j] = b < 4096u ? (int)((HIST[b >> 1] >> (16 * (b & 1))) & 0xffffu) : 0; sum += cnt[j]; }
+                int tot; int ex = vmx_block_excl_scan(sum, s_scan, &tot);
+                for (int j = 0; j < 4; ++j) { if (ex < rem && rem <= ex + cnt[j]) { s_cf[4] = 4 * tid + j; s_cf[5] = ex; } ex += cnt[j]; }
+                __syncthreads();
+                prefix |= (uint64_t)(unsigned)s_cf[4] << shift; rem -= s_cf[5];
+                __syncthreads();
+            }
+            T = prefix;
+        }
+        // collect the singletons at or below T: candidate clusters of one (handle = start in CAND) and isolated hits (handle = slot in ISO)
+        if (tid == 0) s_cf[6] = 0;
+        __syncthreads();
+        for (int c0 = 0; c0 < ncl; c0 += BLOCK) {
+            const int c = c0 + tid;
+            int take = 0, st = 0;
+            if (c < ncl && (int)CS[c + 1] - (int)CS[c] == 1) { st = CS[c]; take = (VMX_CF_C(st) >> 28) <= T; }
+            int tott; const int ext = vmx_block_excl_scan(take, s_scan, &tott);
+            if (take) SEL[nsel + ext] = ((uint64_t)(0x3fffu - 1u) << 50) | ((VMX_CF_C(st) >> 28) << 14) | (uint64_t)st;
+            nsel += tott;
+            __syncthreads();
+        }
+        for (int i = tid; i < n; i += BLOCK) {
+            const uint64_t key = K[i];
+            if (!vmx_cf_is_cand(F, key) && (key >> 28) <= T) {
+                const int q = atomicAdd(&s_cf[6], 1);
+                if (nsel + q < 1024) { ISO[q] = key; SEL[nsel + q] = ((uint64_t)(0x3fffu - 1u) << 50) | ((key >> 28) << 14) | (uint64_t)(0x2000 | q); }
+            }
+        }
+        __syncthreads();
+        nsel += s_cf[6];
+        __syncthreads();
+        if (nsel > 1024 || s_cf[3]) return false;
+    }
+    if (nsel > check_num) return false;                           // (cannot happen; the general path is the safe answer to a broken invariant)
+    int NS = 1; while (NS < nsel) NS <<= 1;
+    for (int i = nsel + tid; i < NS; i += BLOCK) SEL[i] = VMX_INF64;
+    __syncthreads();
+    if (NS > 1) vmx_block_bitonic_passes(SEL, NS);
+    __syncthreads();
+    // emit cluster by cluster in rank order: output offsets (over CS, which is done with), then every thread copies hits
+    uint32_t* OFF = (uint32_t*)CS;
+    int total = 0;
+    for (int c0 = 0; c0 < nsel; c0 += BLOCK) {
+        const int c = c0 + tid;
+        int sz = 0;
+        if (c < nsel) sz = 0x3fff - (int)(SEL[c] >> 50);
+        int tot; const int ex = vmx_block_excl_scan(sz, s_scan, &tot);
+        if (c < nsel) OFF[c] = (uint32_t)(total + ex);
+        total += tot;
+        __syncthreads();
+    }
+    for (int e = tid; e < total; e += BLOCK) {
+        int lo = 0, hi = nsel;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)OFF[mid] <= e) lo = mid; else hi = mid; }
+        const uint64_t sk = SEL[lo]; const int h = (int)(sk & 0x3fffu);
+        const uint64_t hk = (h & 0x2000) ? ISO[h & 0x1fff] : VMX_CF_C(h + (e - (int)OFF[lo]));
+        int64_t* o = out + 4 * (int64_t)e;
+        o[0] = (int64_t)((hk >> 1) & 0x7ffffffULL); o[1] = (int64_t)(hk >> 28); o[2] = (hk & 1) ? 1 : -1; o[3] = kmer;
+    }
+    if (tid == 0) *n_anchors_r = total;
+    __syncthreads();
+    return true;
+#undef VMX_CF_C
+}
+
 template <int BLOCK>
 __device__ __forceinline__ void vmx_cluster_body(uint64_t* __restrict__ keys, uint64_t* __restrict__ cl_keys, const int64_t* __restrict__ key_off,
                                                  const int64_t* __restrict__ nhits, const int32_t* __restrict__ rlist, int nlist, int tile, int check_num, int kmer,
@@ -256,6 +470,15 @@ __device__ __forceinline__ void vmx_cluster_body(uint64_t* __restrict__ keys, ui
         int N = 1; while (N < n) N <<= 1;
         uint64_t* K = keys + key_off[r];
         uint64_t* CK = cl_keys + key_off[r];
+        if (BLOCK == 1024 && tile >= VMX_CF_TOTAL_U64 && n <= tile && check_num > 0 && check_num <= 1024) {
+            // (uniform: every thread sees the same n and gets the same answer)
+            const bool cf_done = vmx_cluster_filtered<BLOCK>(K, n, check_num, kmer, s_sort, s_scan, rows + 4 * key_off[r], &n_anchors[r]);
+#ifdef VMX_EMU
+            if (threadIdx.x == 0) ++(cf_done ? g_vmx_cf_taken : g_vmx_cf_declined);
+#endif
+            if (cf_done) continue;
+            __syncthreads();
+        }
         if (N > 1) vmx_block_sort_u64_tiled(K, N, s_sort, tile);
         __syncthreads();
         // cluster starts, compacted in order: CK[c] = start index of cluster c (temporarily)

@@ -638,7 +638,9 @@ int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, in
         std::vector<int32_t> small, big;
         static const int big_env = [] { const char* e = getenv("VMX_CLUSTER_BIG"); return e ? atoi(e) : -1; }();     // tuning knob: 0 = every read through the 32 KB kernel
         const bool use_big = big_env >= 0 ? big_env != 0 : true;
-        for (int64_t r = 0; r < n; ++r) ((h_nhits[r] <= VMX_SORT_LDS || !use_big) ? small : big).push_back((int32_t)r);
+        int64_t small_max = VMX_SORT_LDS;                            // test knob: reads with more hits than this take the 1024-thread kernel
+        if (const char* e = getenv("VMX_CLUSTER_SMALL_MAX")) { const long long v = atoll(e); if (v >= 0 && v <= VMX_SORT_LDS) small_max = v; }
+        for (int64_t r = 0; r < n; ++r) ((h_nhits[r] <= small_max || !use_big) ? small : big).push_back((int32_t)r);
         if (!use_big) std::stable_sort(small.begin(), small.end(), [&](int32_t a, int32_t b) { return h_nhits[a] > h_nhits[b]; });
         std::stable_sort(big.begin(), big.end(), [&](int32_t a, int32_t b) { return h_nhits[a] > h_nhits[b]; });
         std::vector<int32_t> rl(small); rl.insert(rl.end(), big.begin(), big.end());
