@@ -21,6 +21,32 @@ import numpy as np
 
 from .lib import Context, ResidentReads, align_batch
 
+class _Roctx:
+    """optional roctx ranges around every batch (VMX_ROCTX=1): `rocprofv3 --marker-trace` then shows which batch a kernel belongs to"""
+
+    def __init__(self):
+        import ctypes, os
+        self.lib = None
+        if os.environ.get('VMX_ROCTX') == '1':
+            for name in ('libroctx64.so', 'librocprofiler-sdk-roctx.so'):
+                try:
+                    self.lib = ctypes.CDLL(name); break
+                except OSError:
+                    continue
+            if self.lib is not None:
+                self.lib.roctxRangePushA.argtypes = [ctypes.c_char_p]
+
+    def push(self, text):
+        if self.lib is not None:
+            self.lib.roctxRangePushA(text.encode())
+
+    def pop(self):
+        if self.lib is not None:
+            self.lib.roctxRangePop()
+
+
+_roctx = _Roctx()
+
 DEFAULT_INFLIGHT = 3
 DEFAULT_BATCH_READS = 4096
 DEFAULT_WINDOW_BATCHES = 16
@@ -72,7 +98,11 @@ class Pipeline:
                         i = nxt[0]; nxt[0] += 1
                     if i >= n_jobs:
                         return
-                    res = do_job(i, cx)                   # ctypes releases the GIL for the library call
+                    _roctx.push('vacmapx batch %d' % i)
+                    try:
+                        res = do_job(i, cx)               # ctypes releases the GIL for the library call
+                    finally:
+                        _roctx.pop()
                     if on_result is not None:
                         with lock:
                             on_result(i, res)
@@ -105,7 +135,11 @@ class Pipeline:
                         job = next(it, None)
                     if job is None:
                         return
-                    do_job(job, cx)
+                    _roctx.push('vacmapx batch')
+                    try:
+                        do_job(job, cx)
+                    finally:
+                        _roctx.pop()
             except BaseException as e:
                 errs.append(e)
 
