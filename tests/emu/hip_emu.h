@@ -43,6 +43,7 @@ namespace hipemu {
 struct Block;
 struct Lane {
     ucontext_t ctx;
+    void* sp = nullptr;             // saved stack pointer of the fiber (x86-64 fast switch, hip_emu.cpp)
     char* stack = nullptr;
     Block* blk = nullptr;
     unsigned tid = 0;
@@ -56,6 +57,7 @@ struct Block {
     unsigned nthreads = 0;
     std::vector<Lane> lanes;
     ucontext_t sched;
+    void* sched_sp = nullptr;
     unsigned cur = 0;
     std::vector<uint64_t> slots;          // one exchange slot per lane
     std::vector<uint64_t> slots2;

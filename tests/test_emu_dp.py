@@ -47,13 +47,13 @@ def test_emu_gapfill_banded(ctx, oracle, monkeypatch):
     constants (small class up to tl + ql = 160, packed int16 up to 420). The band-width rule is pushed through all four widths with
     VMX_AD_PCT (at its default every problem this small gets the narrowest band)."""
     seen = set()
-    for pct, seed in ((100, 44), (250, 45), (400, 47)):
+    for pct, seed in ((100, 44), (250, 45), (330, 46), (400, 47)):
         monkeypatch.setenv('VMX_AD_PCT', str(pct))
         # (the wide bands hold every path of problems this small: g > min(tl, ql), nothing is left to redo)
         st = KC.check_gapfill_banded(ctx, oracle, x4_max=160, dp16_max=420, base_len=70, seed=seed, min_counts=(10, 5 if pct == 100 else 0, 5), pct=pct, redo_pk_min=120)
         assert st['proven'] > 0 and (pct != 100 or st['redo_packed'] > 0)
         seen.update(st['ns_kept'])
-    assert seen >= {1, 2, 4}, seen                    # (all four widths: the GPU test)
+    assert seen == {1, 2, 3, 4}, seen
 
 
 def test_emu_chain_global(ctx, oracle, golden):
@@ -79,12 +79,16 @@ def test_emu_seed_sparse_noise(ctx, oracle, monkeypatch):
 
 def test_emu_local(ctx, oracle, golden):
     KC.check_local_golden(ctx, oracle, golden, cases=['B', 'D'])
+    KC.check_local_golden(ctx, oracle, golden, cases=['P'])                  # mode R (_scar chains), 20 reads
 
 
 def test_emu_align_end_to_end(ctx, oracle, golden):
-    KC.check_align_golden(ctx, oracle, golden, cases=['B'], reads=[0, 2])
-    KC.check_align_golden(ctx, oracle, golden, cases=['D'], reads=[0, 2, 4, 5, 6])      # chimera, repeat, short, 12-base and N-bearing reads
-    KC.check_align_golden(ctx, oracle, golden, cases=['I'], reads=[3])        # drop_misplaced removal (the fix_simple_inv shift: stage trace below)
+    KC.check_align_golden(ctx, oracle, golden, cases=['B'], reads=[0, 1, 2])
+    KC.check_align_golden(ctx, oracle, golden, cases=['D'])                   # chimeras, repeat, unmappable, short, 12-base and N-bearing reads
+    KC.check_align_golden(ctx, oracle, golden, cases=['I'], reads=[0, 3])     # fix_simple_inv shift, drop_misplaced removal
+    KC.check_align_golden(ctx, oracle, golden, cases=['N'])                   # fix_simple_inv's left-flank branch
+    KC.check_align_golden(ctx, oracle, golden, cases=['J'], reads=[0, 5, 18]) # mode S (incl. the chimera)
+    KC.check_align_golden(ctx, oracle, golden, cases=['K'], reads=[5, 7])     # mode L at k 19 (reads with a strand switch)
     KC.check_align_golden(ctx, oracle, golden, cases=['H'], reads=[3])        # nested SVs from the vacsim-grammar donor, mode R
 
 
@@ -93,6 +97,7 @@ def test_emu_stage_trace(ctx, oracle, golden):
     n = KC.check_stage_trace_golden(ctx, oracle, golden, cases=['I'], reads=[0, 3])
     assert n[0] == 2 and n[3] == 2 and n[5] == 2
     KC.check_stage_trace_golden(ctx, oracle, golden, cases=['N'])               # fix_simple_inv's left-flank branch
+    KC.check_stage_trace_golden(ctx, oracle, golden, cases=['B'], reads=[0, 1])
 
 
 def test_emu_chain_global_fast(ctx, oracle):

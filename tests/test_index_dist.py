@@ -108,8 +108,8 @@ def test_pipeline_matches_single_context(ctx, oracle):
     from vacmap_amd.lib import Index, align_batch
     contigs = synth.make_reference([60000], seed=21)
     gi = Index.from_seqs(ctx, ['chr1'], contigs, k=15, w=10)
-    cat, off, _ = synth.sample_reads_concat(contigs, 7, mean_len=1200, err=0.08, seed=22, min_len=400, max_len=3000)
-    reads = [cat[off[i]:off[i + 1]].tobytes() for i in range(7)]
+    cat, off, _ = synth.sample_reads_concat(contigs, 10, mean_len=1500, err=0.08, seed=22, min_len=400, max_len=4000)
+    reads = [cat[off[i]:off[i + 1]].tobytes() for i in range(10)]
     prm = ctx.lib.params('H')
     st0, rec0, _ = align_batch(ctx, gi, prm, reads)
     plan = pipeline.plan_batches(np.diff(off), batch_reads=3, window_batches=2)
@@ -122,11 +122,11 @@ def test_pipeline_matches_single_context(ctx, oracle):
             got[int(r)] = (int(st[j]), [t[1:] for t in recs if t[0] == j])
     res = pipeline.upload_batches(ctx, cat, off, plan)
     pipe.run_resident(res, want_records=True, on_result=on_result)
-    for r in range(7):
+    for r in range(10):
         assert got[r] == (int(st0[r]), [t[1:] for t in rec0 if t[0] == r])
     got.clear()
     pipe.run_host([[reads[int(r)] for r in b] for b in plan], on_result=on_result)
-    assert all(got[r] == (int(st0[r]), [t[1:] for t in rec0 if t[0] == r]) for r in range(7))
+    assert all(got[r] == (int(st0[r]), [t[1:] for t in rec0 if t[0] == r]) for r in range(10))
     pipe.close()
 
 
