@@ -63,13 +63,25 @@ def main():
     del res
     pipe.close(); idx.close(); ctx.close()
     # the driver, end to end: a quarter of the reads, then all of them
-    t0 = time.time()
-    driver.main(['-ref', fa, '-read', fq4, '-mode', 'H', '-o', sam_path, '-t', str(args.t), '--nowriteindex', '--force'])
-    t_quarter = time.time() - t0
-    t0 = time.time()
-    rc = driver.main(['-ref', fa, '-read', fq, '-mode', 'H', '-o', sam_path, '-t', str(args.t), '--nowriteindex', '--force'])
-    t_driver = time.time() - t0
-    tm_full = dict(driver.last_timing)
+    # each run in a FRESH process, as the command line is used: in this process the resident pipeline above has just freed ~190 GB of
+    # pools, and allocating after such a free costs ~33 ms per GB here (5 s for the three contexts) against 0.6 s in a fresh process
+    import subprocess
+
+    def run_driver(reads):
+        env = dict(os.environ, VMX_DRIVER_TIMING='1', PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+        t0_ = time.time()
+        pr = subprocess.run([sys.executable, '-m', 'vacmap_amd.driver', '-ref', fa, '-read', reads, '-mode', 'H', '-o', sam_path, '-t', str(args.t), '--nowriteindex', '--force'],
+                            env=env, stderr=subprocess.PIPE, text=True)
+        dt_ = time.time() - t0_
+        tm_ = {}
+        for ln in pr.stderr.splitlines():
+            if ln.startswith('vacmapx timing (s):'):
+                tm_ = {kv.split('=')[0]: float(kv.split('=')[1]) for kv in ln.split(':', 1)[1].split()}
+        sys.stderr.write(pr.stderr[-2000:])
+        return pr.returncode, dt_, tm_
+    _, t_quarter, _ = run_driver(fq4)
+    rc, t_driver, tm_full = run_driver(fq)
+    t_index = tm_full.get('setup', t_index)                 # the driver's own set-up (context, FASTA parse, index build on the GPU)
     lines = sum(1 for ln in open(sam_path, 'rb') if not ln.startswith(b'@'))
     out = {'reads': n, 'read_bases': int(off[-1]), 'fastq_bytes': fq_bytes, 'sam_lines': lines, 'driver_rc': rc, 'emit_processes': args.t,
            'driver_wall_s': t_driver, 'index_build_s': t_index, 'driver_read_loop_s': t_driver - t_index,

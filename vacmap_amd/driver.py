@@ -294,6 +294,8 @@ def main(argv=None, comm=None):
             if not plan:
                 self.ready.set()
 
+    pending = []                                        # windows taken from the reader ahead of the workers (the warm-up below)
+
     def job_source():
         """(window, batch index) in schedule order; a window is planned when the first worker reaches it"""
         while not errs:
@@ -302,7 +304,7 @@ def main(argv=None, comm=None):
                     oq.put(None)
                     return
             t0 = time.time()
-            wnd = wq.get()
+            wnd = pending.pop(0) if pending else wq.get()
             with tml:
                 tm['wait_input'] += time.time() - t0
             if isinstance(wnd, BaseException):
@@ -403,6 +405,31 @@ def main(argv=None, comm=None):
     wt = threading.Thread(target=writer)
     wt.start()
     t_loop = time.time()
+    # Size every context's grow-only work pools ONCE, before the stream starts: each context aligns the longest batch of the first window
+    # (its result is dropped). Without this a context meets its first long-read batch windows later, outgrows the pools its earlier,
+    # shorter batches sized, and pays for ~50 GB of re-allocation next to two other contexts' pools — seconds with the GPU idle
+    # (rocprofv3 trace of a 131 k-read run: no kernel resident 73 % of the time, 2 s batches; `profiles/r03_l_*`).
+    if os.environ.get('VMX_NO_WARM') != '1':
+        first = wq.get()
+        pending.append(first)
+        if first is not None and not isinstance(first, BaseException):
+            plan0 = pipeline.plan_batches(np.diff(first['seqs_off']), args.batch_reads, args.window_batches)
+            plan0 = [plan0[i] for i in range(rank, len(plan0), world)]
+            if plan0:
+                ix0 = max(plan0, key=lambda ix: int(np.diff(first['seqs_off'])[ix].sum()))
+                sb0, so0 = blob_gather(lib, first['seqs'], first['seqs_off'], ix0)
+
+                def warm(cx):
+                    try:
+                        align_batch_raw(cx, index, prm, sb0, so0).close()
+                    except BaseException as e:
+                        errs.append(e)
+                wth = [threading.Thread(target=warm, args=(cx,)) for cx in pipe.ctxs]
+                for t_ in wth:
+                    t_.start()
+                for t_ in wth:
+                    t_.join()
+        tm['warm'] = time.time() - t_loop
     try:
         pipe.run_stream(job_source(), align, errs)
         tm['aligners_done'] = time.time() - t_loop
