@@ -45,26 +45,7 @@ def main():
         for i in range(nq):
             L = int(off[i + 1] - off[i])
             f.write(b'@r%d\n' % i); f.write(cat[off[i]:off[i + 1]].tobytes()); f.write(b'\n+\n'); f.write(b'I' * L); f.write(b'\n')
-    # index build alone (so that the read loop can be separated from it)
-    from vacmap_amd.lib import Context, Index, load
-    ctx = Context(0)
-    t0 = time.time(); idx = Index.from_fasta(ctx, fa, k=15, w=10); t_index = time.time() - t0
-    prm = load().params('H')
-    # the bench's figure for these reads (inputs resident, no SAM): the product's scheduler on length-binned batches
-    plan = pipeline.plan_batches(np.diff(off), 4096, 16)
-    res = pipeline.upload_batches(ctx, cat, off, plan)
-    pipe = pipeline.Pipeline(idx, prm, inflight=3, first_ctx=ctx)
-    pipe.warm(res[0])
-    agg = {'aligned': 0}
-
-    def on(i, r):
-        agg['aligned'] += r[2]['aligned_bases']
-    t0 = time.time(); pipe.run_resident(res, on_result=on); t_res = time.time() - t0
-    del res
-    pipe.close(); idx.close(); ctx.close()
-    # the driver, end to end: a quarter of the reads, then all of them
-    # each run in a FRESH process, as the command line is used: in this process the resident pipeline above has just freed ~190 GB of
-    # pools, and allocating after such a free costs ~33 ms per GB here (5 s for the three contexts) against 0.6 s in a fresh process
+    # each run in a FRESH process, as the command line is used
     import subprocess
 
     def run_driver(reads):
@@ -79,9 +60,31 @@ def main():
                 tm_ = {kv.split('=')[0]: float(kv.split('=')[1]) for kv in ln.split(':', 1)[1].split()}
         sys.stderr.write(pr.stderr[-2000:])
         return pr.returncode, dt_, tm_
+    # (the device scrubs memory a process has freed before it hands it out again, ~33 ms per GB: a run that starts right after another one's
+    # 190 GB were freed waits for that, which a command-line run on an idle GPU never does; hence the pauses)
     _, t_quarter, _ = run_driver(fq4)
+    time.sleep(12)
     rc, t_driver, tm_full = run_driver(fq)
-    t_index = tm_full.get('setup', t_index)                 # the driver's own set-up (context, FASTA parse, index build on the GPU)
+    time.sleep(12)
+    t_index = tm_full.get('setup', 0.0)                  # the driver's own set-up (context, FASTA parse, index build on the GPU)
+    # the bench's figure for the same reads comes AFTER the driver runs, in this process
+    from vacmap_amd.lib import Context, Index, load
+    ctx = Context(0)
+    idx = Index.from_fasta(ctx, fa, k=15, w=10)
+    prm = load().params('H')
+    # the bench's figure for these reads (inputs resident, no SAM): the product's scheduler on length-binned batches
+    plan = pipeline.plan_batches(np.diff(off), 4096, 16)
+    res = pipeline.upload_batches(ctx, cat, off, plan)
+    pipe = pipeline.Pipeline(idx, prm, inflight=3, first_ctx=ctx)
+    pipe.warm(res[0])
+    agg = {'aligned': 0}
+
+    def on(i, r):
+        agg['aligned'] += r[2]['aligned_bases']
+    t0 = time.time(); pipe.run_resident(res, on_result=on); t_res = time.time() - t0
+    del res
+    pipe.close(); idx.close(); ctx.close()
+    # the driver, end to end: a quarter of the reads, then all of them
     lines = sum(1 for ln in open(sam_path, 'rb') if not ln.startswith(b'@'))
     out = {'reads': n, 'read_bases': int(off[-1]), 'fastq_bytes': fq_bytes, 'sam_lines': lines, 'driver_rc': rc, 'emit_processes': args.t,
            'driver_wall_s': t_driver, 'index_build_s': t_index, 'driver_read_loop_s': t_driver - t_index,
