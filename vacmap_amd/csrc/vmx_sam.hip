@@ -67,6 +67,40 @@ static void join_ops(const Ops& o, std::string& s) { s.clear(); for (size_t i = 
 static inline char up(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
 static inline char lo(char c) { return (c >= 'A' && c <= 'Z') ? (char)(c + 32) : c; }
 
+// mergecigar_ (:4773) + nm_from_cigar (output_functions.py:300) in ONE pass over the text (the path without MD / cs): adjacent runs of the
+// same operator are merged straight into the output string (only the joins between gap-fill pieces ever merge), NM is accumulated run by
+// run, and the number of merged operators is returned for the CG-tag test. Same results as merge_cigar -> join_ops -> nm_from_cigar.
+static int64_t merge_cigar_nm(const char* c, int64_t len, const char* q, int64_t ql, const char* t, int64_t tl, std::string& cig, int64_t* n_ops) {
+    cig.clear();
+    int64_t nm = 0, qp = 0, rp = 0, nops = 0;
+    int64_t cur_n = 0; char cur_op = 0;
+    auto flush = [&]() {
+        if (!cur_op) return;
+        put_int(cig, cur_n); cig.push_back(cur_op); ++nops;
+        const int64_t n = cur_n;
+        switch (cur_op) {
+            case 'M': if (qp + n > ql || rp + n > tl) throw Raise(); { const char* a = q + qp; const char* b = t + rp; int64_t d = 0; for (int64_t x = 0; x < n; ++x) d += ((a[x] ^ b[x]) & 0xDF) != 0; nm += d; } qp += n; rp += n; break;
+            case '=': qp += n; rp += n; break;
+            case 'X': nm += n; qp += n; rp += n; break;
+            case 'I': nm += n; qp += n; break;
+            case 'D': nm += n; rp += n; break;
+            case 'S': qp += n; break;
+            case 'N': rp += n; break;
+            default: break;
+        }
+    };
+    int64_t num = 0;
+    for (int64_t i = 0; i < len; ++i) {
+        const char ch = c[i];
+        if (ch >= '0' && ch <= '9') { num = num * 10 + (ch - '0'); continue; }
+        if (ch == cur_op) cur_n += num; else { flush(); cur_op = ch; cur_n = num; }
+        num = 0;
+    }
+    flush();
+    *n_ops = nops;
+    return nm;
+}
+
 // nm_from_cigar (output_functions.py:300): q / t are the sequences the CIGAR walks from their position 0
 static int64_t nm_from_cigar(const Ops& o, const char* q, int64_t ql, const char* t, int64_t tl) {
     int64_t nm = 0, qp = 0, rp = 0;
@@ -153,15 +187,11 @@ static void reassign_mapq(std::vector<Rec>& recs) {
 
 static void revcomp_into(const char* s, int64_t n, std::string& out) {
     out.resize((size_t)n);
-    for (int64_t i = 0; i < n; ++i) {
-        char c = s[n - 1 - i], o;
-        switch (c) { case 'A': o = 'T'; break; case 'C': o = 'G'; break; case 'G': o = 'C'; break; case 'T': o = 'A'; break; case 'N': o = 'N'; break;
-                     case 'a': o = 't'; break; case 'c': o = 'g'; break; case 'g': o = 'c'; break; case 't': o = 'a'; break; case 'n': o = 'n'; break; default: o = c; }
-        out[(size_t)i] = o;
-    }
+    static const struct Tab { unsigned char v[256]; Tab() { for (int i = 0; i < 256; ++i) v[i] = (unsigned char)i; v['A'] = 'T'; v['C'] = 'G'; v['G'] = 'C'; v['T'] = 'A'; v['a'] = 't'; v['c'] = 'g'; v['g'] = 'c'; v['t'] = 'a'; } } tab;
+    for (int64_t i = 0; i < n; ++i) out[(size_t)i] = (char)tab.v[(unsigned char)s[n - 1 - i]];
 }
 
-struct Scratch { std::vector<Rec> recs; std::vector<Ops> ops; std::vector<std::string> cig, md, cs, fake; std::vector<int64_t> nm; std::string rcq, rcqual; };
+struct Scratch { std::vector<Rec> recs; std::vector<Ops> ops; std::vector<std::string> cig, md, cs, fake; std::vector<int64_t> nm, nops; std::string rcq, rcqual; };
 
 // SAM lines of one read appended to `out`; returns the number of lines, or -1 when the reference's emitter would raise
 static int emit_read(const vm_index* mi, const std::string& bases, const vm_sam_opts* o, const char* name, int64_t name_len, const char* query, int64_t qlen, const char* qual,
@@ -183,7 +213,7 @@ static int emit_read(const vm_index* mi, const std::string& bases, const vm_sam_
         const bool has_qual = qual != nullptr && qual_len == qlen;
         if (need_rc && has_qual) { S.rcqual.assign(qual, (size_t)qlen); std::reverse(S.rcqual.begin(), S.rcqual.end()); }
         const size_t n = S.recs.size();
-        S.ops.resize(n); S.cig.resize(n); S.md.resize(n); S.cs.resize(n); S.fake.resize(n); S.nm.resize(n);
+        S.ops.resize(n); S.cig.resize(n); S.md.resize(n); S.cs.resize(n); S.fake.resize(n); S.nm.resize(n); S.nops.resize(n);
         const char clip = o->hardclip ? 'H' : 'S';
         for (size_t i = 0; i < n; ++i) {
             Rec& r = S.recs[i];
@@ -192,10 +222,11 @@ static int emit_read(const vm_index* mi, const std::string& bases, const vm_sam_
             int64_t ta = r.r_st < 0 ? 0 : (r.r_st > clen ? clen : r.r_st), tb = r.r_en < 0 ? 0 : (r.r_en > clen ? clen : r.r_en);     // Python slice semantics of contig[a:b]
             if (tb < ta) tb = ta;
             const char* t = bases.data() + mi->offsets[(size_t)r.contig] + ta; const int64_t tl = tb - ta;
-            merge_cigar(r.cigar, r.cigar_len, S.ops[i]);
-            join_ops(S.ops[i], S.cig[i]);
-            if (!o->md) S.nm[i] = nm_from_cigar(S.ops[i], qs, qlen, t, tl);
+            if (!o->md) S.nm[i] = merge_cigar_nm(r.cigar, r.cigar_len, qs, qlen, t, tl, S.cig[i], &S.nops[i]);      // one pass: merged text + NM
             else {
+                merge_cigar(r.cigar, r.cigar_len, S.ops[i]);
+                join_ops(S.ops[i], S.cig[i]);
+                S.nops[i] = (int64_t)S.ops[i].op.size();
                 int64_t qa = r.q_st < 0 ? 0 : (r.q_st > qlen ? qlen : r.q_st), qb = r.q_en < 0 ? 0 : (r.q_en > qlen ? qlen : r.q_en); if (qb < qa) qb = qa;
                 md_cs(S.ops[i], t, tl, qs + qa, qb - qa, o->shortcs != 0, S.md[i], S.cs[i]);
                 S.nm[i] = nm_from_cigar(S.ops[i], qs + qa, qb - qa, t, tl);
@@ -205,7 +236,7 @@ static int emit_read(const vm_index* mi, const std::string& bases, const vm_sam_
         int lines = 0;
         for (size_t i = 0; i < n; ++i) {
             const Rec& r = S.recs[i];
-            const bool cg = (int64_t)(2 * S.ops[i].op.size()) > 65535 && o->cigar2cg;          // Q4: the reference counts two list entries per operator
+            const bool cg = 2 * S.nops[i] > 65535 && o->cigar2cg;          // Q4: the reference counts two list entries per operator
             out.append(name, (size_t)name_len); out.push_back('\t');
             put_int(out, (i == 0 ? 0 : 2048) + (r.strand == '+' ? 0 : 16)); out.push_back('\t');
             out.append(mi->names[(size_t)r.contig]); out.push_back('\t');
@@ -344,13 +375,31 @@ int64_t vm_blob_gather(const char* blob, const int64_t* off, const int64_t* idx,
 // the same over several blobs: entry j of the output is entry idx[j] of blob part[j] (the writer's batch texts -> input order, without
 // concatenating the batches first). out must hold the sum of the lengths; returns that sum.
 int64_t vm_blob_gather_parts(const char* const* blobs, const int64_t* const* offs, const int32_t* part, const int64_t* idx, int64_t n, char* out) {
+    // a window's SAM text is gigabytes: the output offsets come from one pass over the lengths, the copies run on a few threads
+    // (one thread moves ~5 GB/s; the writer thread of the driver was the longest stage of its loop)
+    std::vector<int64_t> at((size_t)n + 1);
     int64_t w = 0;
-    for (int64_t j = 0; j < n; ++j) {
-        const int64_t* off = offs[part[j]];
-        const int64_t a = off[idx[j]], b = off[idx[j] + 1];
-        if (b > a) memcpy(out + w, blobs[part[j]] + a, (size_t)(b - a));
-        w += b - a;
+    for (int64_t j = 0; j < n; ++j) { const int64_t* off = offs[part[j]]; at[(size_t)j] = w; w += off[idx[j] + 1] - off[idx[j]]; }
+    at[(size_t)n] = w;
+    auto copy = [&](int64_t j0, int64_t j1) {
+        for (int64_t j = j0; j < j1; ++j) {
+            const int64_t* off = offs[part[j]];
+            const int64_t a = off[idx[j]], b = off[idx[j] + 1];
+            if (b > a) memcpy(out + at[(size_t)j], blobs[part[j]] + a, (size_t)(b - a));
+        }
+    };
+    const int T = (w > ((int64_t)64 << 20) && n >= 64) ? 4 : 1;
+    if (T == 1) { copy(0, n); return w; }
+    std::vector<std::thread> th;
+    int64_t j0 = 0;
+    for (int t = 0; t < T; ++t) {                                // cut by bytes, not by entries
+        const int64_t target = w * (t + 1) / T;
+        int64_t j1 = t + 1 == T ? n : (int64_t)(std::lower_bound(at.begin() + j0, at.begin() + n, target) - at.begin());
+        if (j1 < j0) j1 = j0;
+        th.emplace_back(copy, j0, j1);
+        j0 = j1;
     }
+    for (auto& t : th) t.join();
     return w;
 }
 
