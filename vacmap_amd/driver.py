@@ -355,40 +355,6 @@ def main(argv=None, comm=None):
             if w.left == 0:
                 w.ready.set()
 
-    wstate = {'pos': None}
-
-    def write_text(mv):
-        """a window's text (gigabytes): to a regular file in four concurrent pwrite()s at known offsets (one thread copies ~3 GB/s into the
-        page cache, and the writer was the longest stage of the loop); to a pipe or stdout in order"""
-        n = len(mv)
-        if proc is None and args.o != '-' and n > (64 << 20):
-            if wstate['pos'] is None:
-                out.flush(); wstate['pos'] = out.tell()
-            fd, base = out.fileno(), wstate['pos']
-            cuts = [n * i // 4 for i in range(5)]
-
-            werr = []
-
-            def put(i):
-                try:
-                    a, b = cuts[i], cuts[i + 1]
-                    while a < b:
-                        a += os.pwrite(fd, mv[a:b], base + a)
-                except BaseException as e:
-                    werr.append(e)
-            ths = [threading.Thread(target=put, args=(i,)) for i in range(4)]
-            for t_ in ths:
-                t_.start()
-            for t_ in ths:
-                t_.join()
-            if werr:
-                raise werr[0]
-            wstate['pos'] = base + n
-        else:
-            if wstate['pos'] is not None:
-                out.seek(wstate['pos']); wstate['pos'] = None
-            out.write(mv)
-
     def writer():
         """a window's lines in input order (one more gather over the concatenated batch texts) while later windows align and emit"""
         try:
@@ -413,7 +379,7 @@ def main(argv=None, comm=None):
                 counts['lines'] += nl; counts['skipped'] += ns
                 if parts:
                     txt = blob_gather_parts(lib, [p[1] for p in parts], [p[2] for p in parts], [p[0] for p in parts])
-                    write_text(memoryview(txt))
+                    out.write(memoryview(txt))
                 w.wnd = None; w.futs = None
                 slots.release()
                 with tml:
@@ -486,8 +452,6 @@ def main(argv=None, comm=None):
             if rc != 0:
                 sys.stderr.write('Error: samtools exited with code %d\n' % rc)
         elif args.o != '-':
-            if wstate['pos'] is not None:
-                out.seek(wstate['pos'])
             out.close()
         else:
             out.flush()
