@@ -327,7 +327,7 @@ def gapfill_banded_cases(rng, x4_max, dp16_max, base_len, big=True, pct=100, pct
     return ts, qs, tag
 
 
-def check_gapfill_banded(ctx, O, x4_max, dp16_max, base_len, seed=44, big=True, min_counts=(10, 10, 5), pct=100, pct_min=65, redo_pk_min=640):
+def check_gapfill_banded(ctx, O, x4_max, dp16_max, base_len, seed=44, big=True, min_counts=(10, 10, 5), pct=100, pct_min=65, redo_pk_min=384):
     """E5 through the schedule of the batched path (vm_k_cigar_batch_banded -> k_gapfill_fill_ns: anti-diagonal band fill of eight problems
     per wave, optimality proof, redo queue, per-problem layout flag read by k_gapfill_trace) vs the oracle's full DP (mammap_clrnano.py:21554,
     :21598 call sites): identical CIGARs with eqx on and off, in shuffled order (waves mix proven, unproven, never-tried and idle rows and

@@ -429,7 +429,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
                 VMX_TRY(B.tbredo.reserve((size_t)redo_bytes + 64));
                 st.dp_redo_tb_bytes += (int64_t)redo_bytes; st.n_dp_redo += n_redo; st.dp_cells += (int64_t)redo_bytes;
                 // second launch: the problems whose band was not proven (a few per cent), in full: the larger ones on a whole wave, the others four per wave
-                hipLaunchKernelGGL(k_gapfill_fill_ns, dim3((unsigned)std::min<int64_t>((pn + 3) / 4, (int64_t)c->num_cu * 4)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
+                hipLaunchKernelGGL(k_gapfill_fill_ns, dim3((unsigned)std::min<int64_t>(std::max<int64_t>(n_redo, 1), (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
                                    B.dptab.as<vmx_dp_prob>() + p0, pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_range, d_cnt,
                                    d_redo_list, d_redo_cnt, 1, ad_pct, B.tbredo.as<uint8_t>(), d_redo_bytes);
                 if (ke) (void)hipEventRecord(ke[1], c->stream);

@@ -143,7 +143,11 @@ __host__ __device__ static inline int vmx_ad_ns(int tl, int ql, int match, int o
 #ifdef VMX_EMU
 #define VMX_REDO_PK(tl, ql) ((tl) > 0 && (ql) > 0 && VMX_DP16X4_OK(tl, ql) && (tl) + (ql) >= 120)
 #else
-#define VMX_REDO_PK(tl, ql) ((tl) > 0 && (ql) > 0 && VMX_DP16X4_OK(tl, ql) && (tl) + (ql) >= 640)
+#ifndef VMX_REDO_PK_MIN
+#define VMX_REDO_PK_MIN 384            /* redone problems of at least this perimeter take a whole wavefront each (the typical 270 x 270 problem included: the second
+                                          launch holds ~3.5 k problems per batch, a quarter of the machine's wave slots — four per wave left it waiting 2.75 ms for 900 waves) */
+#endif
+#define VMX_REDO_PK(tl, ql) ((tl) > 0 && (ql) > 0 && VMX_DP16X4_OK(tl, ql) && (tl) + (ql) >= VMX_REDO_PK_MIN)
 #endif
 #define VMX_PK_TB_BYTES(tl, ql) ((int64_t)(((tl) + 127) / 128) * ((ql) + 127) * 128)
 #define VMX_AD_TB_BYTES(tl, ql) ((int64_t)((tl) + (ql)) * 64)      /* one 4-byte slot per lane and anti-diagonal */
