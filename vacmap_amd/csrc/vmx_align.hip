@@ -513,25 +513,38 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     int64_t fin[14]; int64_t hstat[8];
     hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(1), 0, c->stream, B.dpoff[0].as<int64_t>() + n, B.dpoff[1].as<int64_t>() + n, B.oflow.as<int32_t>(), B.qrange.as<int32_t>() + 8,
                        B.statblk.as<int32_t>(), B.statblk.as<int64_t>() + 32);
+    // ONE wait for the results: the packed buffers on the device have room for the worst case (cS records, cB CIGAR bytes), so the pack
+    // kernel runs before the totals are known on the host, and the host copies as many records / bytes as the context's history
+    // suggests for a batch of this size (records per read, CIGAR bytes per base, + 15 %). Only when a batch exceeds the guess — the
+    // first batch of a context always does — the missing tail costs a second copy and wait.
+    VMX_TRY(B.totals.reserve(sizeof(vm_record) * (size_t)(cS + 1))); VMX_TRY(B.dupd.reserve((size_t)cB + 64));
+    hipLaunchKernelGGL(k_res_pack, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 8)), dim3(64), 0, c->stream, B.er.as<vmx_ext_read>(), B.rec.as<vm_record>(), B.blob.as<char>(),
+                       B.soff2.as<int64_t>(), B.bloboff.as<int64_t>(), (int)n, B.dpoff[0].as<int64_t>(), B.dpoff[1].as<int64_t>(), B.totals.as<vm_record>(), B.dupd.as<char>());
+    int64_t g_nr = std::min<int64_t>(cS, (int64_t)(c->res_rec_per_read * 1.15 * (double)n) + 64), g_nb = std::min<int64_t>(cB, (int64_t)(c->res_blob_per_base * 1.15 * (double)total_bases) + 4096);
+    if (c->res_rec_per_read <= 0.0) { g_nr = 0; g_nb = 0; }
+    std::vector<vmx_ext_read> er((size_t)n);
+    std::vector<int64_t> h_gmax((size_t)n);
+    *recs = (vm_record*)malloc(sizeof(vm_record) * (size_t)std::max<int64_t>(g_nr, 1)); *cigar_blob = (char*)malloc((size_t)std::max<int64_t>(g_nb, 1));
+    if (!*recs || !*cigar_blob) { set_error("out of host memory"); return VM_ERR_OOM; }
     VMX_TRY(download(fin, B.statblk.as<int64_t>() + 32, 14, c->stream));          // record / blob totals, overflow flag, tier counters, per-round problem counts: one copy
+    VMX_TRY(download(er.data(), B.er.p, (size_t)n, c->stream)); VMX_TRY(download(h_gmax.data(), B.gmax.p, (size_t)n, c->stream));
+    VMX_TRY(download(*recs, B.totals.p, (size_t)g_nr, c->stream)); VMX_TRY(download(*cigar_blob, B.dupd.p, (size_t)g_nb, c->stream));
+    VMX_HIP(hipEventRecord(ev[nev++], c->stream));
     VMX_HIP(vmx_stream_sync(c));
+    VMX_HIP(hipGetLastError());
     nr = fin[0]; nb = fin[1]; oflow = (int32_t)fin[2]; n_full = (int32_t)fin[3]; n_t2 = (int32_t)fin[4]; n_t1 = (int32_t)fin[5];
     for (int i = 0; i < 8; ++i) hstat[i] = fin[6 + i];
     st.n_segments = hstat[0]; st.n_ed_problems = hstat[0]; st.n_ext_problems = (int64_t)hstat[1] + hstat[2] + hstat[3] + hstat[4];
     st.n_ed_full = n_full; st.n_ed_tier2 = n_t2; st.n_ed_tier1 = n_t1;
     if (oflow) { set_error("extend stage: a per-batch work pool overflowed"); return VM_ERR_OOM; }
-    VMX_TRY(B.totals.reserve(sizeof(vm_record) * (size_t)(nr + 1))); VMX_TRY(B.dupd.reserve((size_t)nb + 64));
-    hipLaunchKernelGGL(k_res_pack, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 8)), dim3(64), 0, c->stream, B.er.as<vmx_ext_read>(), B.rec.as<vm_record>(), B.blob.as<char>(),
-                       B.soff2.as<int64_t>(), B.bloboff.as<int64_t>(), (int)n, B.dpoff[0].as<int64_t>(), B.dpoff[1].as<int64_t>(), B.totals.as<vm_record>(), B.dupd.as<char>());
-    std::vector<vmx_ext_read> er((size_t)n);
-    *recs = (vm_record*)malloc(sizeof(vm_record) * (size_t)std::max<int64_t>(nr, 1)); *cigar_blob = (char*)malloc((size_t)std::max<int64_t>(nb, 1));
-    VMX_TRY(download(er.data(), B.er.p, (size_t)n, c->stream)); VMX_TRY(download(*recs, B.totals.p, (size_t)nr, c->stream));
-    VMX_TRY(download(*cigar_blob, B.dupd.p, (size_t)nb, c->stream));
-    std::vector<int64_t> h_gmax((size_t)n);
-    VMX_TRY(download(h_gmax.data(), B.gmax.p, (size_t)n, c->stream));
-    VMX_HIP(hipEventRecord(ev[nev++], c->stream));
-    VMX_HIP(vmx_stream_sync(c));
-    VMX_HIP(hipGetLastError());
+    if (nr > g_nr || nb > g_nb) {                                 // the guess was short: fetch the tails
+        if (nr > g_nr) { vm_record* p2 = (vm_record*)realloc(*recs, sizeof(vm_record) * (size_t)nr); if (!p2) { set_error("out of host memory"); return VM_ERR_OOM; } *recs = p2;
+                         VMX_TRY(download(*recs + g_nr, B.totals.as<vm_record>() + g_nr, (size_t)(nr - g_nr), c->stream)); }
+        if (nb > g_nb) { char* p2 = (char*)realloc(*cigar_blob, (size_t)nb); if (!p2) { set_error("out of host memory"); return VM_ERR_OOM; } *cigar_blob = p2;
+                         VMX_TRY(download(*cigar_blob + g_nb, B.dupd.as<char>() + g_nb, (size_t)(nb - g_nb), c->stream)); }
+        VMX_HIP(vmx_stream_sync(c));
+    }
+    if (n > 0 && total_bases > 0) { c->res_rec_per_read = std::max(c->res_rec_per_read, (double)nr / (double)n); c->res_blob_per_base = std::max(c->res_blob_per_base, (double)nb / (double)total_bases); }
     for (int64_t r = 0; r < n; ++r) {
         int stt2 = er[r].status;
         if (h_gmax[r] == -2 && (h_aoff[r + 1] - h_aoff[r]) > 2) stt2 = VM_READ_RAISED;     // GC-fast: the reference raises on this read (k_chain_fast.hip)

@@ -106,6 +106,7 @@ struct vm_ctx {
     hipEvent_t kev[4] = {nullptr, nullptr, nullptr, nullptr};   // around k_local_seed's main launch [0,1] and the clustering kernels [2,3] of the last batch
     int kev_set = 0;                              // bit 0: [0,1] recorded, bit 1: [2,3] recorded
     int64_t n_syncs = 0;                          // host waits on this context's stream (reset per batch)
+    double res_rec_per_read = 0.0, res_blob_per_base = 0.0;   // largest records per read / CIGAR bytes per base a batch of this context produced (result copy size guess)
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams for independent launches (LDS-bucketed kernels)
     hipEvent_t fork_ev = nullptr, join_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int64_t last_n_minimizers = 0;               // of the last seed stage (stats)
