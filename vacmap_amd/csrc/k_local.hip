@@ -16,6 +16,7 @@
 //                   RUN is walked by its own lane; the reference's append order and its stable argsort by q+l (:28585)
 //                   are restored by two key sorts on the emission key.
 // Deviation D1: a 9-mer holding a non-ACGT base never matches.
+#define VMX_SORT_LOGR 3          // eight keys per thread in the block sorts: this kernel is held to 80 VGPRs (three 512-thread workgroups per CU)
 #include "vmx_device.h"
 #include "vmx_kernels.h"
 #include "vmx_local.h"

@@ -283,61 +283,60 @@ __device__ __forceinline__ void vmx_ce_u64(uint64_t& x, uint64_t& y, bool asc) {
     const uint64_t lo = sw ? y : x, hi = sw ? x : y;
     x = lo; y = hi;
 }
-// one round trip: stages j = 2^(b + nst - 1) .. 2^b of phase k (k > 2^(b+3): one direction per thread), or with first = true the whole
-// of phases 2 .. 16 on runs of 16 consecutive keys (b = 0). gbase: global index of lds[0] (tiled sorts), fixed_dir >= 0 forces the direction.
+// one round trip: stages j = 2^(b + nst - 1) .. 2^b of phase k (k > 2^(b + LR - 1): one direction per thread), or with first = true the
+// whole of phases 2 .. R on runs of R consecutive keys (b = 0). gbase: global index of lds[0] (tiled sorts).
+// R = 2^VMX_SORT_LOGR keys per thread: 16 by default; a kernel held to few registers defines VMX_SORT_LOGR 3 before including this
+// header (k_local_seed: at its 80-VGPR budget the 16-key form lived in scratch memory).
+#ifndef VMX_SORT_LOGR
+#define VMX_SORT_LOGR 4
+#endif
+#define VMX_SORT_R (1 << VMX_SORT_LOGR)
 __device__ __forceinline__ void vmx_bitonic_roundtrip(uint64_t* lds, int N, int gbase, int k, int b, int nst, bool first) {
     const int T = (int)blockDim.x;
-    for (int g = (int)threadIdx.x; g < (N >> 4); g += T) {
-        const int base = ((g >> b) << (b + 4)) | (g & ((1 << b) - 1));
-        uint64_t r[16];
+    for (int g = (int)threadIdx.x; g < (N >> VMX_SORT_LOGR); g += T) {
+        const int base = ((g >> b) << (b + VMX_SORT_LOGR)) | (g & ((1 << b) - 1));
+        uint64_t r[VMX_SORT_R];
 #pragma unroll
-        for (int m = 0; m < 16; ++m) r[m] = lds[vmx_sw(base | (m << b))];
+        for (int m = 0; m < VMX_SORT_R; ++m) r[m] = lds[vmx_sw(base | (m << b))];
         if (first) {
-            const bool asc16 = ((gbase + base) & 16) == 0;
+            const bool ascR = ((gbase + base) & VMX_SORT_R) == 0;
 #pragma unroll
-            for (int kk = 2; kk <= 16; kk <<= 1)
+            for (int kk = 2; kk <= VMX_SORT_R; kk <<= 1)
 #pragma unroll
                 for (int jj = kk >> 1; jj > 0; jj >>= 1)
 #pragma unroll
-                    for (int m = 0; m < 16; ++m)
-                        if ((m ^ jj) > m) vmx_ce_u64(r[m], r[m ^ jj], kk == 16 ? asc16 : ((m & kk) == 0));
+                    for (int m = 0; m < VMX_SORT_R; ++m)
+                        if ((m ^ jj) > m) vmx_ce_u64(r[m], r[m ^ jj], kk == VMX_SORT_R ? ascR : ((m & kk) == 0));
         } else {
             const bool asc = ((gbase + base) & k) == 0;
-            if (nst >= 4) {
 #pragma unroll
-                for (int m = 0; m < 16; ++m) if (!(m & 8)) vmx_ce_u64(r[m], r[m | 8], asc);
+            for (int s = VMX_SORT_LOGR - 1; s >= 0; --s) {
+                if (nst > s) {
+#pragma unroll
+                    for (int m = 0; m < VMX_SORT_R; ++m) if (!(m & (1 << s))) vmx_ce_u64(r[m], r[m | (1 << s)], asc);
+                }
             }
-            if (nst >= 3) {
-#pragma unroll
-                for (int m = 0; m < 16; ++m) if (!(m & 4)) vmx_ce_u64(r[m], r[m | 4], asc);
-            }
-            if (nst >= 2) {
-#pragma unroll
-                for (int m = 0; m < 16; ++m) if (!(m & 2)) vmx_ce_u64(r[m], r[m | 2], asc);
-            }
-#pragma unroll
-            for (int m = 0; m < 16; ++m) if (!(m & 1)) vmx_ce_u64(r[m], r[m | 1], asc);
         }
 #pragma unroll
-        for (int m = 0; m < 16; ++m) lds[vmx_sw(base | (m << b))] = r[m];
+        for (int m = 0; m < VMX_SORT_R; ++m) lds[vmx_sw(base | (m << b))] = r[m];
     }
     __syncthreads();
 }
 // stages j = 2^e .. 1 of phase k on the swizzled tile (e < log2 N; k > 2^e)
 __device__ __forceinline__ void vmx_bitonic_phase_tail(uint64_t* lds, int N, int gbase, int k, int e) {
     while (e >= 0) {
-        const int b = e >= 3 ? e - 3 : 0;
+        const int b = e >= VMX_SORT_LOGR - 1 ? e - (VMX_SORT_LOGR - 1) : 0;
         vmx_bitonic_roundtrip(lds, N, gbase, k, b, e - b + 1, false);
         e = b - 1;
     }
 }
-// all phases k = 2 .. kmax of a swizzled tile of N >= 16 keys (N a power of two). every thread of the workgroup must call it.
+// all phases k = 2 .. kmax of a swizzled tile of N >= R keys (N a power of two). every thread of the workgroup must call it.
 __device__ __forceinline__ void vmx_bitonic_tile_sw(uint64_t* lds, int N, int gbase, int kmax) {
-    vmx_bitonic_roundtrip(lds, N, gbase, 16, 0, 4, true);
-    for (int k = 32, p = 5; k <= kmax; k <<= 1, ++p) vmx_bitonic_phase_tail(lds, N, gbase, k, p - 1);
+    vmx_bitonic_roundtrip(lds, N, gbase, VMX_SORT_R, 0, VMX_SORT_LOGR, true);
+    for (int k = 2 * VMX_SORT_R, p = VMX_SORT_LOGR + 1; k <= kmax; k <<= 1, ++p) vmx_bitonic_phase_tail(lds, N, gbase, k, p - 1);
 }
-// is the register-blocked form worth it? it needs 16 keys per working thread; below a quarter of the workgroup the plain passes win
-__device__ __forceinline__ bool vmx_bitonic_fast_ok(int N) { return N >= 64 && (N >> 4) >= ((int)blockDim.x >> 2); }
+// is the register-blocked form worth it? it needs R keys per working thread; below a quarter of the workgroup the plain passes win
+__device__ __forceinline__ bool vmx_bitonic_fast_ok(int N) { return N >= 4 * VMX_SORT_R && (N >> VMX_SORT_LOGR) >= ((int)blockDim.x >> 2); }
 
 // (the passes are instantiated once on the LDS buffer and once on the HBM array: a pointer chosen at run time would make them flat accesses)
 __device__ inline void vmx_block_sort_u64_impl(uint64_t* g, int N, uint64_t* lds, int lds_cap) {
