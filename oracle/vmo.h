@@ -22,7 +22,8 @@ extern "C" {
 typedef struct vmo_index vmo_index;
 
 /* mode constants */
-enum { VMO_MODE_H = 0, VMO_MODE_L = 1, VMO_MODE_S = 2, VMO_MODE_R = 3 };
+enum { VMO_MODE_H = 0, VMO_MODE_L = 1, VMO_MODE_S = 2, VMO_MODE_R = 3,
+       VMO_MODE_ASM = 4 /* -mode asm: mammap_asm.py, an older fork of the path (vmo_asm.cc) */ };
 
 typedef struct vmo_params {
     int32_t mode;            /* VMO_MODE_* */
@@ -131,6 +132,19 @@ int vmo_align_read(const vmo_index*, const char* read, int64_t readlen, const vm
 int vmo_align_batch(const vmo_index*, const vmo_params* p, int64_t n_reads, const char* seqs,
                     const int64_t* offsets, int nthreads, vmo_record** recs, int64_t* n_recs,
                     char** cigar_blob, int32_t* status);
+
+/* -mode asm (mammap_asm.py): one assembly contig. Contigs below 500 000 bases take the module's own get_readmap_DP_test (:19681) with
+ * check_num = -1; longer ones assembly_get_readmap_DP_test (:23204): 100 kb seeding windows, chain DPs LINKED across batches of more than
+ * 500 000 anchors, a second linked pass over 9-mer anchors, ass_extend_func. p->mode must be VMO_MODE_ASM. split_len / batch_anchors /
+ * window <= 0 take the reference's 500000 / 500000 / 100000 (tests shrink them to reach the linked path on small inputs — the reference
+ * run that made the goldens was patched to the same numbers). status as vmo_align_read. */
+int vmo_align_asm(const vmo_index*, const char* contig, int64_t len, const vmo_params* p, int64_t split_len, int64_t batch_anchors,
+                  int64_t window, vmo_record** recs, int64_t* n_recs, char** cigar_blob);
+/* stage entry of the linked chain DPs (:21686 GC-exact, :21871 GC-fast, :21504 LC): which = 0 / 1 / 2. anchors sorted by q (rows of the
+ * carried anchors first); pre_S / pre_P: carried state (n_pre may be 0). Outputs S, P, S_arg [n]; returns g_max_index (-1: exact bailed out) */
+int64_t vmo_chain_linked_raw(const int64_t* anchors, int64_t n, int which, int kmersize, double skipcost, int maxdiff, int maxgap,
+                             double g_max_scores, int64_t g_max_index, const double* pre_S, const int64_t* pre_P, int64_t n_pre,
+                             int64_t prereadloc, double* S, int64_t* P, int64_t* S_arg);
 
 /* DP problem recorder: when enabled, every k_cigar_global / k_extend / edit distance call made
  * inside vmo_extend appends (kind, tl, ql) to a log (golden V5) */

@@ -166,6 +166,69 @@ int64_t chain_global_exact(const std::vector<Anchor>& A, int kmersize, double os
     return g_max_index;
 }
 
+// -mode asm: GC-exact of the older fork, mammap_asm.py:20551-20737 (no coverage terms, gap_geometry_asm), its LINKED form :21686-21870
+// (link != nullptr with n_pre > 0: S / P of the first n_pre rows are the carried state, the loop starts behind them, g_max_* and prereadloc come
+// from the caller) and the linked LC :21504-21685 (lc: co-linear steps also pay readgapcost_list[readgap] :16536 = the mode-R table; no
+// bail-out). A sorted by q (stable) behind the carried rows. Returns g_max_index, or -1 (bail-out :20623 / :21757).
+int64_t chain_exact_asm(const std::vector<Anchor>& A, int kmersize, double skipcost, int maxdiff, int maxgap, bool lc, const LinkState* link,
+                        std::vector<double>& S, std::vector<int64_t>& P, std::vector<int64_t>& S_arg) {
+    const Tables& T = tables();
+    const int64_t extra_size = (int64_t)T.extra.size() - 1;
+    const int64_t n = (int64_t)A.size();
+    S.assign(n, 0.0); P.assign(n, 0); S_arg.assign(n, 0);
+    std::vector<double> gapcost_list(maxdiff + 1, 0.0);
+    for (int g = 1; g <= maxdiff; ++g) gapcost_list[g] = (0.01 * kmersize * g + 0.5 * T.log2int[g]);
+    double g_max_scores; int64_t g_max_index, prereadloc, pre_size, testspace_en = 1;
+    S_arg[0] = 0;
+    if (link && link->n_pre > 0) {
+        for (int64_t i = 0; i < link->n_pre; ++i) { S[i] = link->pre_S[i]; P[i] = link->pre_P[i]; }
+        pre_size = link->n_pre; g_max_scores = link->g_max_scores; g_max_index = link->g_max_index; prereadloc = link->prereadloc;
+    } else {
+        S[0] = (double)A[0].l; P[0] = NOPRE;
+        g_max_scores = (double)A[0].l; g_max_index = 0; prereadloc = A[0].q; pre_size = 1;
+    }
+    int64_t opcount = 0;
+    for (int64_t i = pre_size; i < n; ++i) {
+        double max_scores = (double)A[i].l;
+        int64_t pre_index = NOPRE;
+        if (prereadloc < A[i].q) {
+            if (!lc && ((double)opcount / (double)i) > 1000.0) return -1;
+            for (int64_t k = testspace_en; k < i; ++k) {
+                const int64_t loc = insertpoint_score(S.data(), S[k], k, S_arg.data());
+                sarg_insert(S_arg.data(), loc, k);
+            }
+            testspace_en = i;
+            prereadloc = A[i].q;
+        }
+        const double li = (double)A[i].l;
+        for (int64_t x = testspace_en - 1; x >= 0; --x) {
+            const int64_t j = S_arg[x];
+            if (S[j] > (max_scores - li)) {
+                ++opcount;
+                int64_t readgap, refgap, bonus;
+                gap_geometry_asm(A[i], A[j], readgap, refgap, bonus);
+                int64_t gapcost = std::llabs(readgap - refgap);
+                double test;
+                if (A[i].s == A[j].s && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
+                    test = S[j] + (double)bonus - gapcost_list[gapcost];
+                    if (lc) test = test - (double)T.readgap_r[readgap];
+                } else {
+                    if (gapcost > extra_size) gapcost = extra_size;
+                    test = S[j] - skipcost + (double)bonus - (double)T.extra[gapcost];
+                }
+                if (test > max_scores) { max_scores = test; pre_index = j; }
+            } else break;
+        }
+        S[i] = max_scores; P[i] = pre_index;
+        if (max_scores > g_max_scores) { g_max_scores = max_scores; g_max_index = i; }
+    }
+    for (int64_t k = testspace_en; k < n; ++k) {
+        const int64_t loc = insertpoint_score(S.data(), S[k], k, S_arg.data());
+        sarg_insert(S_arg.data(), loc, k);
+    }
+    return g_max_index;
+}
+
 int64_t chain_global_fast(const std::vector<Anchor>& A, int kmersize, double oskipcost, int omaxdiff, int maxgap,
                           std::vector<double>& S, std::vector<int64_t>& P, std::vector<int64_t>& S_arg, bool rmode);  // vmo_chain_fast.cc
 

@@ -87,8 +87,11 @@ static inline bool geometry(const Anchor& ai, const Anchor& aj, bool lc, int64_t
 
 // the shared skeleton. variant 0 = GC-fast, 1 = LC-fast, 2 = LC-mm-fast, 3 = GC-fast of mode R (mammap_noprefercloser.py:23059-23417: no
 // coverage terms, fixed skipcost with refund). Returns g_max_index, or < -1 on the two misbehaviours above.
+// variant 4 = GC-fast of the -mode asm fork (mammap_asm.py:20738-21037: no coverage terms, gap_geometry_asm, plain skipcost + extra) and, with
+// link->n_pre > 0, its LINKED form (:21871-22158: the first n_pre rows carry S / P from the previous batch, S_i = int(pre_S), the bucket index
+// starts with row 0 only, max_score_i = S_i[0]).
 static int64_t fast_dp(const std::vector<Anchor>& A, int variant, int kmersize, double oskipcost, int omaxdiff, int maxgap, int mode,
-                       std::vector<double>& S, std::vector<int64_t>& P, std::vector<int64_t>& S_arg_i, double* g_max_out) {
+                       std::vector<double>& S, std::vector<int64_t>& P, std::vector<int64_t>& S_arg_i, double* g_max_out, const LinkState* link = nullptr) {
     const Tables& T = tables();
     const int64_t extra_size = (int64_t)T.extra.size() - 1;
     const int64_t log2cache_size = (int64_t)T.log2cache.size() - 1;
@@ -97,7 +100,8 @@ static int64_t fast_dp(const std::vector<Anchor>& A, int variant, int kmersize, 
     const int64_t n = (int64_t)A.size();
     const bool lc = variant == 1 || variant == 2;
     const bool gcr = variant == 3;
-    g_fast_calls[gcr ? 0 : variant].fetch_add(1);
+    const bool asmv = variant == 4;
+    g_fast_calls[(gcr || asmv) ? 0 : variant].fetch_add(1);
     std::vector<double> pre_pen(gcr ? A.size() : 0, 0.0), fixed_pen(gcr ? A.size() : 0, 0.0);
     std::vector<double> gapcost_list(omaxdiff + 1, 0.0);
     for (int g = 1; g <= omaxdiff; ++g) {
@@ -117,6 +121,7 @@ static int64_t fast_dp(const std::vector<Anchor>& A, int variant, int kmersize, 
         else target_arr[i] = -(A[i].r + A[i].q + readlength);
     }
     int64_t prereadloc = lc ? A[0].q + A[0].l : A[0].q;
+    int64_t pre_size = 1;
     double skipcost = oskipcost;                      // GC-fast: updated with the coverage on every position advance; LC-fast: never
     int64_t maxdiff = omaxdiff;
     int64_t testspace_en_i = 1;
@@ -127,6 +132,14 @@ static int64_t fast_dp(const std::vector<Anchor>& A, int variant, int kmersize, 
     if (A[0].l < 0 || A[0].l >= (int64_t)S_i_count.size()) return -5;
     S_i_count[A[0].l] = 1;
     int64_t max_score_i = 0;
+    if (link && link->n_pre > 0) {                   // :21893-21901
+        S_i_count[A[0].l] = 0;
+        for (int64_t i = 0; i < link->n_pre; ++i) { S[i] = link->pre_S[i]; S_i[i] = (int64_t)link->pre_S[i]; P[i] = link->pre_P[i]; }
+        pre_size = link->n_pre; g_max_scores = link->g_max_scores; g_max_index = link->g_max_index; prereadloc = link->prereadloc;
+        if (S_i[0] < 0 || S_i[0] >= (int64_t)S_i_count.size()) return -5;
+        S_i_count[S_i[0]] = 1;
+        max_score_i = S_i[0];
+    }
     auto insert_pending = [&](int64_t upto) -> bool {
         int64_t k = testspace_en_i;
         while (k < upto) {
@@ -141,13 +154,13 @@ static int64_t fast_dp(const std::vector<Anchor>& A, int variant, int kmersize, 
         testspace_en_i = k;
         return true;
     };
-    for (int64_t i = 1; i < n; ++i) {
+    for (int64_t i = pre_size; i < n; ++i) {
         double max_scores = (double)A[i].l;
         int64_t pre_index = NOPRE;
         const int64_t pos_i = lc ? A[i].q + A[i].l : A[i].q;
         if (prereadloc < pos_i) {
             if (!insert_pending(i)) return -5;
-            if (!lc && !gcr) {
+            if (!lc && !gcr && !asmv) {
                 skipcost = oskipcost + (double)cov[A[i].q];                                     // :25151
                 maxdiff = std::max<int64_t>(omaxdiff - cov[A[i].q], 10);                        // :25152
             }
@@ -163,7 +176,8 @@ static int64_t fast_dp(const std::vector<Anchor>& A, int variant, int kmersize, 
             if (st_loc < 0) return -5;
             auto eval = [&](int64_t j, bool& hang) {
                 int64_t readgap, refgap, bonus;
-                if (!geometry(A[i], A[j], lc, readgap, refgap, bonus)) { hang = true; return; }
+                if (asmv) gap_geometry_asm(A[i], A[j], readgap, refgap, bonus);
+                else if (!geometry(A[i], A[j], lc, readgap, refgap, bonus)) { hang = true; return; }
                 int64_t gapcost = std::llabs(readgap - refgap);
                 double test;
                 if (gcr) {
@@ -185,7 +199,7 @@ static int64_t fast_dp(const std::vector<Anchor>& A, int variant, int kmersize, 
                 if (A[i].s == A[j].s && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
                     if (!lc) test = S[j] + (double)bonus - gapcost_list[gapcost];
                     else test = S[j] + (double)bonus - gapcost_list[gapcost] - (double)readgapcost[readgap];
-                } else if (variant == 0) {
+                } else if (variant == 0 || asmv) {
                     if (gapcost > extra_size) gapcost = extra_size;
                     test = S[j] - skipcost + (double)bonus - (double)T.extra[gapcost];
                 } else if (variant == 1) {
@@ -229,6 +243,13 @@ int64_t chain_global_fast(const std::vector<Anchor>& A, int kmersize, double osk
                           std::vector<double>& S, std::vector<int64_t>& P, std::vector<int64_t>& S_arg, bool rmode) {
     const int64_t g = fast_dp(A, rmode ? 3 : 0, kmersize, oskipcost, omaxdiff, maxgap, 0, S, P, S_arg, nullptr);
     if (g < 0) { set_error(g == -4 ? "GC-fast: reference does not terminate on this input" : "GC-fast: integer score outside S_i_count"); return -2; }
+    return g;
+}
+
+int64_t chain_global_fast_asm(const std::vector<Anchor>& A, int kmersize, double skipcost, int maxdiff, int maxgap, const LinkState* link,
+                              std::vector<double>& S, std::vector<int64_t>& P, std::vector<int64_t>& S_arg) {
+    const int64_t g = fast_dp(A, 4, kmersize, skipcost, maxdiff, maxgap, 0, S, P, S_arg, nullptr, link);
+    if (g < 0) { set_error(g == -4 ? "GC-fast (asm): reference does not terminate on this input" : "GC-fast (asm): integer score outside S_i_count"); return -2; }
     return g;
 }
 

@@ -42,7 +42,8 @@ static std::string reversed(std::string s) { std::reverse(s.begin(), s.end()); r
 static bool same_contig(const vmo_index* mi, int64_t a, int64_t b) { return pos2contig(mi, a) == pos2contig(mi, b); }
 
 // E1 :23437-23484. returns <0 where the reference raises IndexError (alignment_list[-1] on an empty list)
-static int rebuild_chain_break(const vmo_index* mi, const Path& raw, int64_t large_cost, int64_t small_alignment, std::vector<Seg>& al) {
+// asmv: the -mode asm fork (mammap_asm.py:13256-13295) joins only when refgap >= 0 (no tolerance for a 20-base back-step)
+static int rebuild_chain_break(const vmo_index* mi, const Path& raw, int64_t large_cost, int64_t small_alignment, std::vector<Seg>& al, bool asmv = false) {
     al.clear();
     Anchor pre = raw[0];
     al.push_back(Seg{pre});
@@ -51,7 +52,9 @@ static int rebuild_chain_break(const vmo_index* mi, const Path& raw, int64_t lar
         if (pre.s == now.s) {
             int64_t readgap = now.q - pre.q - pre.l, refgap;
             if (pre.s == 1) refgap = now.r - pre.r - pre.l; else refgap = pre.r - now.r - now.l;
-            if (std::llabs(readgap - refgap) <= large_cost && refgap >= -20 && readgap < 100) {
+            if (asmv) {
+                if (std::llabs(readgap - refgap) <= large_cost && refgap >= 0 && readgap < 100 && same_contig(mi, pre.r, now.r)) { al.back().push_back(now); pre = now; continue; }
+            } else if (std::llabs(readgap - refgap) <= large_cost && refgap >= -20 && readgap < 100) {
                 if (same_contig(mi, pre.r, now.r)) {
                     if (refgap >= 0) { al.back().push_back(now); pre = now; continue; }
                     else { if (readgap <= 20) continue; al.back().push_back(now); pre = now; continue; }
@@ -76,7 +79,7 @@ static int rebuild_chain_break(const vmo_index* mi, const Path& raw, int64_t lar
 }
 
 // :5802-5818
-static void get_query_target_for_cigar(const vmo_index* mi, const Anchor& pre, const Anchor& now, const std::string& read,
+void get_query_target_for_cigar(const vmo_index* mi, const Anchor& pre, const Anchor& now, const std::string& read,
                                        const std::string& rc, int64_t L, std::string& target, std::string& query) {
     if (pre.s == 1) {
         int c = pos2contig(mi, pre.r); int64_t bias = index_offset(mi, c);
@@ -324,9 +327,44 @@ static int gap_fill(const std::string& target, const std::string& query, int eqx
 }
 
 // E5 :21505-21617. out_alignment = new_alignment[0], cigars = cigarlist[0]
+// link_cigar :22365-22410 (mode asm): joins two CIGAR strings, adding the counts when the last operator of the first equals the first of the second
+static std::string link_cigar(const std::string& c1, const std::string& c2) {
+    int64_t iloc = (int64_t)c1.size() - 1;
+    const char last = c1[iloc];
+    int64_t num_1 = 0, factor = 1;
+    while (iloc > 0) {
+        iloc -= 1;
+        if (c1[iloc] >= '0' && c1[iloc] <= '9') { num_1 = num_1 + (c1[iloc] - '0') * factor; factor *= 10; continue; }
+        else break;
+    }
+    char first = 0; int64_t jloc = 0, num_2 = 0;
+    while (jloc < (int64_t)c2.size()) {
+        first = c2[jloc];
+        if (c2[jloc] >= '0' && c2[jloc] <= '9') { num_2 = num_2 * 10 + (c2[jloc] - '0'); jloc += 1; continue; }
+        else break;
+    }
+    if (last == first) {
+        const std::string mid = std::to_string(num_1 + num_2) + last;
+        const bool whole1 = iloc == 0, whole2 = (jloc + 1) == (int64_t)c2.size();
+        if (whole1 && whole2) return mid;
+        if (whole1) return mid + c2.substr((size_t)jloc + 1);
+        if (whole2) return c1.substr(0, (size_t)iloc + 1) + mid;
+        return c1.substr(0, (size_t)iloc + 1) + mid + c2.substr((size_t)jloc + 1);
+    }
+    return c1 + c2;
+}
+
+// asmv (mammap_asm.py:22197-22316): the short-anchor / short-gap skip applies only while max(readgap, refgap) < 2000; an empty CIGAR raises; the
+// CIGAR pieces of a segment are joined with link_cigar into ONE string
 static int split_alignment_test(const vmo_index* mi, Seg alignment, const std::string& read, const std::string& rc, int64_t L,
-                                int eqx, Seg& out_alignment, std::vector<std::string>& cigars) {
+                                int eqx, Seg& out_alignment, std::vector<std::string>& cigars, bool asmv = false) {
     const int64_t min_gap_forcigar = 200;
+    auto add_cigar = [&](const std::string& cg) -> int {
+        if (!asmv) { cigars.push_back(cg); return 0; }
+        if (cg.empty()) return -13;                                   // :22244
+        if (!cigars.empty()) cigars[0] = link_cigar(cigars[0], cg); else cigars.push_back(cg);
+        return 0;
+    };
     out_alignment.clear(); cigars.clear();
     if (alignment[0].s == 1) {
         Anchor& last = alignment.back();
@@ -337,14 +375,14 @@ static int split_alignment_test(const vmo_index* mi, Seg alignment, const std::s
         while (iloc < alignment.size()) {
             const Anchor now = alignment[iloc];
             int64_t readgap = now.q - pre.q - pre.l, refgap = now.r - pre.r - pre.l;
-            if (now.l < 19 || std::min(readgap, refgap) < min_gap_forcigar) {
+            if ((!asmv || std::max(readgap, refgap) < 2000) && (now.l < 19 || std::min(readgap, refgap) < min_gap_forcigar)) {
                 if (iloc + 1 != alignment.size()) { iloc += 1; continue; }
             }
             std::string target, query;
             get_query_target_for_cigar(mi, pre, now, read, rc, L, target, query);
             if (target.size() > 0 && query.size() > 0) {
                 std::string cg; gap_fill(target, query, eqx, cg);
-                out_alignment.push_back(now); cigars.push_back(cg);
+                out_alignment.push_back(now); if (add_cigar(cg) < 0) return -13;
             } else return -13;   // raise Exception("ERROR: Failed to compute CIGAR") :21562
             pre = now; iloc += 1;
         }
@@ -360,14 +398,14 @@ static int split_alignment_test(const vmo_index* mi, Seg alignment, const std::s
         while (iloc < alignment.size()) {
             const Anchor now = alignment[iloc];
             int64_t readgap = pre.q - now.q - now.l, refgap = now.r - pre.r - pre.l;
-            if (now.l < 19 || std::min(readgap, refgap) < min_gap_forcigar) {
+            if ((!asmv || std::max(readgap, refgap) < 2000) && (now.l < 19 || std::min(readgap, refgap) < min_gap_forcigar)) {
                 if (iloc + 1 != alignment.size()) { iloc += 1; continue; }
             }
             std::string target, query;
             get_query_target_for_cigar(mi, now, pre, read, rc, L, target, query);
             if (target.size() > 0 && query.size() > 0) {
                 std::string cg; gap_fill(target, query, eqx, cg);
-                out_alignment.push_back(now); cigars.push_back(cg);
+                out_alignment.push_back(now); if (add_cigar(cg) < 0) return -13;
             } else return -13;
             pre = now; iloc += 1;
         }
@@ -487,7 +525,8 @@ int extend_func(const vmo_index* mi, const std::string& read, const std::string&
     const int64_t L = (int64_t)read.size();
     recs.clear();
     std::vector<Seg> al;
-    int rcode = rebuild_chain_break(mi, chain_asc, prm.local_maxdiff, 50, al);
+    const bool asmv = prm.mode == VMO_MODE_ASM;      // mammap_asm.py:22317-22363: small_alignment 40, no drop_misplaced pass, filtered = False
+    int rcode = rebuild_chain_break(mi, chain_asc, prm.local_maxdiff, asmv ? 40 : 50, al, asmv);
     if (rcode < 0) return rcode;
     // divergence filter :19246-19254
     for (int64_t t = 0; t < (int64_t)al.size(); ++t) {
@@ -502,18 +541,18 @@ int extend_func(const vmo_index* mi, const std::string& read, const std::string&
     extend_edge_test(mi, read, L, al);
     size_t o_len = al.size();
     bool filtered = false;
-    if (al.size() > 2 && !nofilter) {
+    if (al.size() > 2 && !nofilter && !asmv) {
         int64_t iloc = 0;
         while (iloc < (int64_t)al.size() - 2) { if (drop_misplaced_alignment_test(al, iloc)) continue; else iloc += 1; }
     }
     if (al.size() < o_len) { filtered = true; extend_edge_test(mi, read, L, al); }
     merge_conjacent_alignment(mi, al);
-    rcode = fix_simple_inv(mi, al, read, prm.mode == VMO_MODE_R);
+    rcode = fix_simple_inv(mi, al, read, prm.mode == VMO_MODE_R || asmv);      // mammap_asm.py:17158-17207 = the mode-R body
     if (rcode < 0) return rcode;
     std::vector<Seg> nal; std::vector<std::vector<std::string>> cigarlist;
     for (const Seg& a : al) {
         Seg oa; std::vector<std::string> cg;
-        rcode = split_alignment_test(mi, a, read, rc, L, prm.eqx, oa, cg);
+        rcode = split_alignment_test(mi, a, read, rc, L, prm.eqx, oa, cg, asmv);
         if (rcode < 0) return rcode;
         nal.push_back(oa); cigarlist.push_back(cg);
     }
@@ -523,9 +562,33 @@ int extend_func(const vmo_index* mi, const std::string& read, const std::string&
     return 0;
 }
 
+// ass_extend_func mammap_asm.py:23423-23460: large_cost 50, small_alignment 30, no divergence filter, MAPQ 60, forward orientation
+int ass_extend_func(const vmo_index* mi, const std::string& read, const std::string& rc, Path chain_asc, const vmo_params& prm, std::vector<Record>& recs) {
+    const int64_t L = (int64_t)read.size();
+    recs.clear();
+    std::vector<Seg> al;
+    int rcode = rebuild_chain_break(mi, chain_asc, 50, 30, al, true);
+    if (rcode < 0) return rcode;
+    extend_edge_test(mi, read, L, al);
+    merge_conjacent_alignment(mi, al);
+    rcode = fix_simple_inv(mi, al, read, true);
+    if (rcode < 0) return rcode;
+    std::vector<Seg> nal; std::vector<std::vector<std::string>> cigarlist;
+    for (const Seg& a : al) {
+        Seg oa; std::vector<std::string> cg;
+        rcode = split_alignment_test(mi, a, read, rc, L, prm.eqx, oa, cg, true);
+        if (rcode < 0) return rcode;
+        nal.push_back(oa); cigarlist.push_back(cg);
+    }
+    rcode = get_onemapinfolist(mi, nal, cigarlist, 60, L, false, prm.hardclip != 0, recs);
+    if (rcode < 0) { recs.clear(); return rcode; }
+    return 0;
+}
+
 // get_readmap_DP_test :24023-24084
 int align_read(const vmo_index* mi, const std::string& read_in, const vmo_params& prm, std::vector<Record>& recs) {
     recs.clear();
+    if (prm.mode == VMO_MODE_ASM) return align_asm(mi, read_in, prm, 0, 0, 0, recs);
     std::string read = read_in;
     for (char& c : read) if (c >= 'a' && c <= 'z') c -= 32;   // driver upper-cases reads (src/vacmap/vacmap:449)
     const int64_t L = (int64_t)read.size();

@@ -10,6 +10,8 @@ namespace vmo {
 
 struct Anchor { int64_t q, r, s, l; };   // (read pos, global ref pos, strand +-1, length) — SURVEY §8 row T
 struct Mz { uint64_t h; int32_t pos; int8_t strand; };
+typedef std::vector<Anchor> Path;
+struct Record;
 
 struct Nt4Table { uint8_t t[256]; Nt4Table(); };
 extern const Nt4Table NT4T;
@@ -36,7 +38,6 @@ const Tables& tables();
 
 std::string revcomp(const std::string& s);
 
-typedef std::vector<Anchor> Path;
 
 struct ChainSet {                      // result of decode_hit (:23981-24020)
     bool need_reverse = false;
@@ -47,6 +48,45 @@ struct ChainSet {                      // result of decode_hit (:23981-24020)
     bool fast_used = false;
 };
 bool strand_flip(std::vector<Anchor>& a, int64_t readlen);
+
+// gap geometry of the -mode asm fork (mammap_asm.py:20660-20688; the same lines in its GC-fast :20866+, LC :16641+ and linked DPs):
+// the overlap case is written with non_overlap_size = q_i - q_j and the opposite-strand cases carry no +-1
+static inline void gap_geometry_asm(const Anchor& ai, const Anchor& aj, int64_t& readgap, int64_t& refgap, int64_t& bonus) {
+    readgap = ai.q - aj.q - aj.l;
+    if (readgap < 0) {
+        bonus = ai.q + ai.l - aj.q - aj.l;
+        readgap = 0;
+        const int64_t nov = ai.q - aj.q;
+        if (ai.s == aj.s) { if (ai.s == 1) refgap = ai.r - aj.r - nov; else refgap = aj.r + aj.l - nov - ai.r - ai.l; }
+        else { if (aj.s == -1) refgap = ai.r + aj.l - nov - aj.r; else refgap = ai.r + ai.l - aj.r - nov; }
+    } else {
+        bonus = ai.l;
+        if (ai.s == aj.s) { if (ai.s == 1) refgap = ai.r - aj.r - aj.l; else refgap = aj.r - ai.r - ai.l; }
+        else { if (aj.s == -1) refgap = ai.r - aj.r; else refgap = ai.r + ai.l - aj.r - aj.l; }
+    }
+}
+
+// carried state of a LINKED chain DP (mammap_asm.py:21686 / :21871 / :21504): scores / negated predecessors of the anchors kept from the
+// previous batch (they are the first rows of A), the running maximum and the largest read position among them
+struct LinkState { const double* pre_S = nullptr; const int64_t* pre_P = nullptr; int64_t n_pre = 0; double g_max_scores = 0.; int64_t g_max_index = 0; int64_t prereadloc = 0; };
+// the asm fork's exact DPs (vmo_asm.cc). lc = false: GC-exact (:20551; linked :21686); lc = true: the linked LC (:21504). Returns g_max_index, -1 = bail-out
+int64_t chain_exact_asm(const std::vector<Anchor>& A, int kmersize, double skipcost, int maxdiff, int maxgap, bool lc, const LinkState* link,
+                        std::vector<double>& S, std::vector<int64_t>& P, std::vector<int64_t>& S_arg);
+// GC-fast of the asm fork (:20738; linked :21871) — vmo_chain_fast.cc
+int64_t chain_global_fast_asm(const std::vector<Anchor>& A, int kmersize, double skipcost, int maxdiff, int maxgap, const LinkState* link,
+                              std::vector<double>& S, std::vector<int64_t>& P, std::vector<int64_t>& S_arg);
+// the asm fork's local chain DP (:16540) on anchors sorted by read start — vmo_asm.cc
+int local_chain_asm(const std::vector<Anchor>& A, int kmersize, double skipcost, int maxdiff, int maxgap, double* score, Path& path);
+// local re-seeding around one guide chain (vmo_local.cc; get_localmap_..._guide_1 :23069 = mammap_asm.py:17960 / :22477). r_st < 0: the read
+// window follows the guide (+- read_span); otherwise positions [r_st, r_en) are looked up (collect_second_round_anchors)
+void local_seed_one(const vmo_index* mi, const std::string& read, Path guide, int k, int64_t look_span, int64_t read_span, std::vector<Anchor>& out,
+                    int64_t r_st = -1, int64_t r_en = -1);
+void get_query_target_for_cigar(const vmo_index* mi, const Anchor& pre, const Anchor& now, const std::string& read,
+                                const std::string& rc, int64_t L, std::string& target, std::string& query);
+// ass_extend_func (mammap_asm.py:23423) — vmo_extend.cc
+int ass_extend_func(const vmo_index* mi, const std::string& read, const std::string& rc, Path chain_asc, const vmo_params& prm, std::vector<Record>& recs);
+int align_asm(const vmo_index* mi, const std::string& contig, const vmo_params& prm, int64_t split_len, int64_t batch_anchors, int64_t window,
+              std::vector<Record>& recs);
 int decode_hit(std::vector<Anchor> A, int64_t readlen, int kmersize, const vmo_params& prm, ChainSet& out);
 
 // contig helpers (pos2contig :51-59 — last contig whose start <= pos)

@@ -51,8 +51,10 @@ static void findClosest_1(const std::vector<int64_t>& arr, int64_t target, int64
 struct PointEntry { int64_t q, r, s, l; };
 
 // L2 :23069-23345. `guide` = one guide chain (any order). Appends run-merged local anchors to out.
-static void local_seed_one(const vmo_index* mi, const std::string& read, Path guide, int k, int64_t look_span,
-                           int64_t read_span, std::vector<Anchor>& out) {
+// r_st >= 0: collect_second_round_anchors (mammap_asm.py:22477-22756) — the same body, but the read positions looked up are [r_st, r_en - k)
+// (:22580, :22589-22593) instead of the guide's span
+void local_seed_one(const vmo_index* mi, const std::string& read, Path guide, int k, int64_t look_span,
+                    int64_t read_span, std::vector<Anchor>& out, int64_t r_st, int64_t r_en) {
     const int64_t L = (int64_t)read.size();
     // :23095-23102
     int64_t readgap = 0;
@@ -125,6 +127,7 @@ static void local_seed_one(const vmo_index* mi, const std::string& read, Path gu
     std::stable_sort(guide.begin(), guide.end(), [](const Anchor& a, const Anchor& b) { return a.q < b.q; });
     int64_t readstart = std::max<int64_t>(0, guide.front().q - read_span);
     int64_t readend = std::min<int64_t>(L - k + 1, guide.back().q + read_span);
+    if (r_st >= 0) { readstart = r_st; readend = r_en - k; }
     std::vector<int64_t> readpos(guide.size());
     for (size_t i = 0; i < guide.size(); ++i) readpos[i] = guide[i].q;
     std::unordered_map<int64_t, PointEntry> pointdict;
@@ -304,6 +307,69 @@ static int local_chain_dp(const std::vector<Anchor>& A, int kmersize, double ski
     return 0;
 }
 
+// -mode asm: the older LC DP, mammap_asm.py:16540-16730. A sorted by read START (stable, :18237); the candidate window advances on read starts;
+// `break` on S[j] < max - l is tested before anything else; no `bonus <= 0` skip; gap_geometry_asm; co-linear gap cost 0.5*log2 for every size;
+// read-gap cost 0.1*log2(r) (:16536 = the mode-R table); a non-co-linear step costs skipcost + extra[gapcost]; no opcount switch. The traceback
+// trims the EARLIER anchor's end where two chained anchors overlap on the read (:16720-16726).
+int local_chain_asm(const std::vector<Anchor>& A, int kmersize, double skipcost, int maxdiff, int maxgap, double* score, Path& path) {
+    const Tables& T = tables();
+    const int64_t extra_size = (int64_t)T.extra.size() - 1;
+    const int64_t n = (int64_t)A.size();
+    if (n == 0) return -1;
+    std::vector<double> gapcost_list(maxdiff + 1, 0.0);
+    for (int g = 1; g <= maxdiff; ++g) gapcost_list[g] = (0.01 * kmersize * g + 0.5 * T.log2int[g]);
+    std::vector<double> S(n); std::vector<int64_t> P(n), S_arg(n);
+    int64_t prereadloc = A[0].q;
+    int64_t testspace_en = 1;
+    S_arg[0] = 0; S[0] = (double)A[0].l; P[0] = NOPRE;
+    double g_max_scores = (double)A[0].l; int64_t g_max_index = 0;
+    for (int64_t i = 1; i < n; ++i) {
+        double max_scores = (double)A[i].l;
+        int64_t pre_index = NOPRE;
+        if (prereadloc < A[i].q) {
+            for (int64_t k = testspace_en; k < i; ++k) {
+                int64_t loc = smallorequal2target_1d_point(S.data(), S[k], k, S_arg.data()) + 1;
+                memmove(S_arg.data() + loc + 1, S_arg.data() + loc, sizeof(int64_t) * (size_t)(k - loc));
+                S_arg[loc] = k;
+            }
+            testspace_en = i;
+            prereadloc = A[i].q;
+        }
+        const double li = (double)A[i].l;
+        for (int64_t x = testspace_en - 1; x >= 0; --x) {
+            const int64_t j = S_arg[x];
+            if (S[j] < (max_scores - li)) break;
+            int64_t readgap, refgap, bonus;
+            gap_geometry_asm(A[i], A[j], readgap, refgap, bonus);
+            int64_t gapcost = std::llabs(readgap - refgap);
+            double test;
+            if (A[i].s == A[j].s && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
+                test = S[j] + (double)bonus - gapcost_list[gapcost] - (double)T.readgap_r[readgap];
+            } else {
+                if (gapcost > extra_size) gapcost = extra_size;
+                test = S[j] - skipcost + (double)bonus - (double)T.extra[gapcost];
+            }
+            if (test > max_scores) { max_scores = test; pre_index = j; }
+        }
+        S[i] = max_scores; P[i] = pre_index;
+        if (max_scores > g_max_scores) { g_max_scores = max_scores; g_max_index = i; }
+    }
+    path.clear();
+    int64_t take = g_max_index;
+    path.push_back(A[take]);
+    Anchor preitem = A[take];
+    while (P[take] != NOPRE) {
+        take = P[take];
+        const Anchor& now = A[take];
+        if (preitem.q >= now.q + now.l) path.push_back(now);
+        else if (now.s == 1) path.push_back(Anchor{now.q, now.r, now.s, preitem.q - now.q});
+        else path.push_back(Anchor{now.q, now.r + now.l - preitem.q + now.q, now.s, preitem.q - now.q});
+        preitem = now;
+    }
+    *score = g_max_scores;
+    return 0;
+}
+
 // mode R: get_optimal_chain_sortbyreadpos_forSV_inv_test_merged_fine_list_scar (mammap_noprefercloser.py:23419-23628). A sorted by read
 // START (stable); the candidate window still advances on read ENDS (:23484). Co-linear gap cost 0.5*log2 for every size (:23432), read-gap
 // cost from the R table (:16534), a non-co-linear step costs the fixed skipcost, refunded after skipcost co-linear bases (fixed_penatly /
@@ -396,6 +462,17 @@ int local_chain(const vmo_index* mi, const std::string& read, const std::string&
     const int maxgap = (mode == VMO_MODE_L) ? 50 : 99;           // :24061 / mammap_ccs.py:24061
     const int max_chains = (mode == VMO_MODE_L) ? 3 : 5;         // :28581 / mammap_ccs.py:28581 (S: unlimited -> see below)
     if (guides_in.empty()) return -1;
+    if (mode == VMO_MODE_ASM) {
+        // mammap_asm.py:19714-19719 -> get_localmap_multi_all_forDP_inv_guide :17960-18238: the primary path only, reference window +-2000, read
+        // window +-500, anchors sorted by read start (:18237), the older LC DP
+        std::vector<Anchor> raw;
+        local_seed_one(mi, read, guides_in[0], k, 2000, 500, raw);
+        if (raw_out) *raw_out = raw;
+        if (raw.empty()) return -16;       // np.array([])[:, 0] raises IndexError (:18237)
+        std::stable_sort(raw.begin(), raw.end(), [](const Anchor& a, const Anchor& b) { return a.q < b.q; });
+        if (variant) *variant = 3;
+        return local_chain_asm(raw, k, prm.local_skipcost, prm.local_maxdiff, 99, score, chain_desc);
+    }
     if (mode == VMO_MODE_R) {
         // mammap_noprefercloser.py:23902-23914: every chain is re-seeded in the order given (no merge / drop / cap), reference window
         // +-2000, read window +-500 (:23631+); anchors sorted by read start; one DP variant

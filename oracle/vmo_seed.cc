@@ -223,6 +223,8 @@ void vmo_params_default(vmo_params* p, int mode) {
     else if (mode == VMO_MODE_H) { p->local_skipcost = 40.; p->global_skipcost = 40.; p->maxdivergence = 0.2; }
     else { p->local_skipcost = 30.; p->global_skipcost = 30.; p->maxdivergence = 0.5; }
     p->nodiscard = !(mode == VMO_MODE_L || mode == VMO_MODE_H);
+    // -mode asm: --eqx forced (vacmap:246), maxdivergence forced to 1 by the worker (mammap_asm.py:23483), check_num = -1 (:23206, :22419)
+    if (mode == VMO_MODE_ASM) { p->eqx = 1; p->maxdivergence = 1.0; p->check_num = -1; }
 }
 
 vmo_index* vmo_index_build_mem(int nseq, const char* const* names, const char* const* seqs, const int64_t* lens,

@@ -31,7 +31,7 @@ class Chains(C.Structure):
                 ('n_all', C.c_int32), ('all_scores', C.POINTER(C.c_double))]
 
 
-MODES = {'H': 0, 'L': 1, 'S': 2, 'R': 3}
+MODES = {'H': 0, 'L': 1, 'S': 2, 'R': 3, 'asm': 4}
 _lib = None
 
 
@@ -79,6 +79,9 @@ def lib():
     L.vmo_extend.argtypes = [vp, cp, i64, vp, i64, C.c_int, C.c_int, C.c_int, P(Params), P(P(Record)), P(i64), P(vp), P(i32)]
     L.vmo_align_read.argtypes = [vp, cp, i64, P(Params), P(P(Record)), P(i64), P(vp)]
     L.vmo_align_batch.argtypes = [vp, P(Params), i64, cp, vp, C.c_int, P(P(Record)), P(i64), P(vp), vp]
+    L.vmo_align_asm.argtypes = [vp, cp, i64, P(Params), i64, i64, i64, P(P(Record)), P(i64), P(vp)]
+    L.vmo_chain_linked_raw.argtypes = [vp, i64, C.c_int, C.c_int, dbl, C.c_int, C.c_int, dbl, i64, vp, vp, i64, i64, vp, vp, vp]
+    L.vmo_chain_linked_raw.restype = i64
     L.vmo_table.argtypes = [C.c_int, P(vp)]; L.vmo_table.restype = i64
     L.vmo_dplog_begin.argtypes = []; L.vmo_dplog_end.restype = i64
     L.vmo_dplog_get.argtypes = [i64, P(i32), P(vp), P(i64), P(vp), P(i64)]
@@ -273,6 +276,26 @@ def align_read(index, read, prm):
     recs = C.POINTER(Record)(); n = C.c_int64(); blob = C.c_void_p()
     rc = lib().vmo_align_read(index.h, rd, len(rd), C.byref(prm), C.byref(recs), C.byref(n), C.byref(blob))
     return rc, _take_records(recs, n.value, blob)
+
+
+def align_asm(index, contig, prm, split_len=0, batch_anchors=0, window=0):
+    """-mode asm on one assembly contig (mammap_asm.py:23204); the three sizes default to the reference's 500000 / 500000 / 100000"""
+    rd = _b(contig)
+    recs = C.POINTER(Record)(); n = C.c_int64(); blob = C.c_void_p()
+    rc = lib().vmo_align_asm(index.h, rd, len(rd), C.byref(prm), split_len, batch_anchors, window, C.byref(recs), C.byref(n), C.byref(blob))
+    return rc, _take_records(recs, n.value, blob)
+
+
+def chain_linked_raw(anchors, which, kmersize, skipcost, maxdiff, maxgap, g_max_scores=0., g_max_index=0, pre_S=None, pre_P=None, prereadloc=0):
+    """linked chain DPs of -mode asm (which: 0 GC-exact :21686, 1 GC-fast :21871, 2 LC :21504) -> (g_max_index, S, P, S_arg)"""
+    a = np.ascontiguousarray(anchors, dtype=np.int64).reshape(-1, 4)
+    n = len(a)
+    ps = np.ascontiguousarray(pre_S if pre_S is not None else [], dtype=np.float64)
+    pp = np.ascontiguousarray(pre_P if pre_P is not None else [], dtype=np.int64)
+    S = np.zeros(n, np.float64); P = np.zeros(n, np.int64); SA = np.zeros(n, np.int64)
+    g = lib().vmo_chain_linked_raw(a.ctypes.data, n, which, kmersize, float(skipcost), int(maxdiff), int(maxgap), float(g_max_scores), int(g_max_index),
+                                   ps.ctypes.data, pp.ctypes.data, len(ps), int(prereadloc), S.ctypes.data, P.ctypes.data, SA.ctypes.data)
+    return g, S, P, SA
 
 
 def align_batch(index, reads, prm, nthreads=1):
