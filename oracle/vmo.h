@@ -140,6 +140,8 @@ int vmo_align_batch(const vmo_index*, const vmo_params* p, int64_t n_reads, cons
  * run that made the goldens was patched to the same numbers). status as vmo_align_read. */
 int vmo_align_asm(const vmo_index*, const char* contig, int64_t len, const vmo_params* p, int64_t split_len, int64_t batch_anchors,
                   int64_t window, vmo_record** recs, int64_t* n_recs, char** cigar_blob);
+/* decode_hit of the fork (:21280; seeds the contig itself with p->check_num): MAPQ, signed score, the primary path */
+int vmo_decode_hit_asm(const vmo_index*, const char* contig, int64_t len, const vmo_params* p, vmo_chains* out);
 /* stage entry of the linked chain DPs (:21686 GC-exact, :21871 GC-fast, :21504 LC): which = 0 / 1 / 2. anchors sorted by q (rows of the
  * carried anchors first); pre_S / pre_P: carried state (n_pre may be 0). Outputs S, P, S_arg [n]; returns g_max_index (-1: exact bailed out) */
 int64_t vmo_chain_linked_raw(const int64_t* anchors, int64_t n, int which, int kmersize, double skipcost, int maxdiff, int maxgap,

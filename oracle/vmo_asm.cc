@@ -386,6 +386,32 @@ int vmo_align_asm(const vmo_index* mi, const char* contig, int64_t len, const vm
     return rc;
 }
 
+int vmo_decode_hit_asm(const vmo_index* mi, const char* contig, int64_t len, const vmo_params* prm, vmo_chains* out) {
+    std::string seq(contig, (size_t)len);
+    for (char& c : seq) if (c >= 'a' && c <= 'z') c -= 32;
+    std::vector<Anchor> A;
+    map_read(mi, seq.data(), len, prm->check_num, prm->mid_occ, A);
+    ChainSet cs;
+    const int rc = decode_hit_asm(mi, seq, revcomp(seq), A, vmo_index_k(mi), *prm, cs);
+    memset(out, 0, sizeof(*out));
+    if (rc < 0) return rc;
+    out->need_reverse = cs.need_reverse; out->mapq = cs.mapq; out->score = cs.score; out->fast_used = cs.fast_used;
+    out->n_paths = (int32_t)cs.paths.size();
+    size_t tot = 0; for (auto& p : cs.paths) tot += p.size();
+    out->path_off = (int64_t*)malloc(sizeof(int64_t) * (cs.paths.size() + 1));
+    out->path_anchors = (int64_t*)malloc(sizeof(int64_t) * 4 * (tot ? tot : 1));
+    size_t o = 0;
+    for (size_t i = 0; i < cs.paths.size(); ++i) {
+        out->path_off[i] = (int64_t)o;
+        for (const Anchor& x : cs.paths[i]) { int64_t* r = out->path_anchors + 4 * o; r[0] = x.q; r[1] = x.r; r[2] = x.s; r[3] = x.l; ++o; }
+    }
+    out->path_off[cs.paths.size()] = (int64_t)o;
+    out->n_all = (int32_t)cs.all_scores.size();
+    out->all_scores = (double*)malloc(sizeof(double) * (cs.all_scores.size() ? cs.all_scores.size() : 1));
+    for (size_t i = 0; i < cs.all_scores.size(); ++i) out->all_scores[i] = cs.all_scores[i];
+    return 0;
+}
+
 int64_t vmo_chain_linked_raw(const int64_t* a, int64_t n, int which, int kmersize, double skipcost, int maxdiff, int maxgap,
                              double g_max_scores, int64_t g_max_index, const double* pre_S, const int64_t* pre_P, int64_t n_pre,
                              int64_t prereadloc, double* S, int64_t* P, int64_t* S_arg) {

@@ -80,6 +80,7 @@ def lib():
     L.vmo_align_read.argtypes = [vp, cp, i64, P(Params), P(P(Record)), P(i64), P(vp)]
     L.vmo_align_batch.argtypes = [vp, P(Params), i64, cp, vp, C.c_int, P(P(Record)), P(i64), P(vp), vp]
     L.vmo_align_asm.argtypes = [vp, cp, i64, P(Params), i64, i64, i64, P(P(Record)), P(i64), P(vp)]
+    L.vmo_decode_hit_asm.argtypes = [vp, cp, i64, P(Params), P(Chains)]
     L.vmo_chain_linked_raw.argtypes = [vp, i64, C.c_int, C.c_int, dbl, C.c_int, C.c_int, dbl, i64, vp, vp, i64, i64, vp, vp, vp]
     L.vmo_chain_linked_raw.restype = i64
     L.vmo_table.argtypes = [C.c_int, P(vp)]; L.vmo_table.restype = i64
@@ -284,6 +285,20 @@ def align_asm(index, contig, prm, split_len=0, batch_anchors=0, window=0):
     recs = C.POINTER(Record)(); n = C.c_int64(); blob = C.c_void_p()
     rc = lib().vmo_align_asm(index.h, rd, len(rd), C.byref(prm), split_len, batch_anchors, window, C.byref(recs), C.byref(n), C.byref(blob))
     return rc, _take_records(recs, n.value, blob)
+
+
+def decode_hit_asm(index, contig, prm):
+    """decode_hit of the -mode asm fork (mammap_asm.py:21280) -> dict(rc, need_reverse, mapq, score, paths)"""
+    rd = _b(contig)
+    ch = Chains()
+    rc = lib().vmo_decode_hit_asm(index.h, rd, len(rd), C.byref(prm), C.byref(ch))
+    res = {'rc': rc, 'need_reverse': bool(ch.need_reverse), 'mapq': ch.mapq, 'score': ch.score, 'fast_used': bool(ch.fast_used), 'paths': []}
+    if rc == 0 and ch.n_paths > 0:
+        off = [ch.path_off[i] for i in range(ch.n_paths + 1)]
+        pa = np.ctypeslib.as_array(ch.path_anchors, shape=(max(off[-1], 1), 4))[:off[-1]].copy()
+        res['paths'] = [pa[off[i]:off[i + 1]] for i in range(ch.n_paths)]
+    lib().vmo_chains_free(C.byref(ch))
+    return res
 
 
 def chain_linked_raw(anchors, which, kmersize, skipcost, maxdiff, maxgap, g_max_scores=0., g_max_index=0, pre_S=None, pre_P=None, prereadloc=0):

@@ -15,7 +15,7 @@ REF = '/root/reference'
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _pkgroot = None
 
-MODE_MODULE = {'H': 'mammap_clrnano', 'L': 'mammap_ccs', 'S': 'mammap_sensitive', 'R': 'mammap_noprefercloser'}
+MODE_MODULE = {'H': 'mammap_clrnano', 'L': 'mammap_ccs', 'S': 'mammap_sensitive', 'R': 'mammap_noprefercloser', 'asm': 'mammap_asm'}
 
 
 def _setup():
