@@ -31,10 +31,17 @@ typedef enum vm_status {
     /* per-read statuses (status_per_read of vm_align_batch); the reference skips such reads (:24116-24125) */
     VM_READ_RAISED = -10,       /* the reference's Python would have raised inside the per-read path */
     VM_READ_CAPACITY = -20,     /* a device work buffer overflowed for this read (reported, never silently truncated) */
-    VM_READ_FASTPATH = -21      /* internal hand-off to the `_fast` chain kernels (:23570, :24914, :27380); never returned by vm_align_batch */
+    VM_READ_FASTPATH = -21,     /* internal hand-off to the `_fast` chain kernels (:23570, :24914, :27380); never returned by vm_align_batch */
+    VM_READ_UNSUPPORTED = -22   /* -mode asm only: a contig of 500 000 bases or more, or one whose equal-score chains need the edlib tie-break of
+                                   mammap_asm.py:21302-21326 (MAPQ 0): reported, not approximated */
 } vm_status;
 
-enum { VM_MODE_H = 0, VM_MODE_L = 1, VM_MODE_S = 2, VM_MODE_R = 3 };   /* -mode (src/vacmap/vacmap:87) */
+enum { VM_MODE_H = 0, VM_MODE_L = 1, VM_MODE_S = 2, VM_MODE_R = 3,   /* -mode (src/vacmap/vacmap:87) */
+       /* -mode asm runs src/vacmap/mammap_asm.py, an older fork of the path. Through vm_align_batch every "read" is an assembly contig and takes
+        * that module's per-read function (get_readmap_DP_test :19681, check_num = -1) — the reference's route for contigs below 500 000 bases
+        * (assembly_get_readmap_DP_test :23205). Longer contigs (the batch-linked chain DPs, :23208-23422) are not built on the device yet:
+        * they come back as VM_READ_UNSUPPORTED, never through another route. */
+       VM_MODE_ASM = 4 };
 
 /* option dict `pdict` of the reference driver (src/vacmap/vacmap:177-296) as one POD */
 typedef struct vm_params {

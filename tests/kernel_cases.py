@@ -713,3 +713,70 @@ def check_reference_call_shapes(ctx, O, golden, small=False):
     for i, (t, q) in enumerate(zip(ts, qs)):
         d = AL.edlib_align(query=q, target=t, task='distance')['editDistance']
         assert d == O.edit_distance(q, t) == int(eb[i]), i
+
+
+# ------------------------------------------------------------------------------------------------ -mode asm (mammap_asm.py)
+def asm_golden():
+    import json, os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    return json.load(open(os.path.join(g, 'asm.json'))), np.load(os.path.join(g, 'asm.npz'))
+
+
+def _asm_index(ctx, O, meta, arr, cid):
+    from vacmap_amd.lib import Index
+    c = meta[cid]
+    contigs = [arr['%s_ref%d' % (cid, i)].tobytes().decode() for i in range(len(c['names']))]
+    return Index.from_seqs(ctx, c['names'], contigs, k=c['k'], w=c['w']), O.Index.from_seqs(c['names'], contigs, k=c['k'], w=c['w'])
+
+
+def check_asm_golden(ctx, O, cases=('AS1',), contigs=None, want_unsupported=(), vs_golden=True):
+    """vm_align_batch in VM_MODE_ASM: every assembly contig below 500 kb takes the fork's per-read function (mammap_asm.py:19681). Records must
+    equal the reference's (golden V6a) and the oracle's run live; contigs named in want_unsupported must come back as VM_READ_UNSUPPORTED (-22)
+    with no records (500 kb and more: the linked path is not on the device)"""
+    import zlib
+    from vacmap_amd.lib import align_batch
+    meta, arr = asm_golden()
+    n_ok = 0
+    for cid in cases:
+        c = meta[cid]
+        gi, oi = _asm_index(ctx, O, meta, arr, cid)
+        prm = ctx.lib.params('asm'); oprm = O.params('asm')
+        assert prm.eqx == 1 and prm.check_num == -1 and prm.maxdivergence == 1.0
+        idx = list(range(len(c['contigs']))) if contigs is None else [i for i in contigs if i < len(c['contigs'])]
+        seqs = [arr['%s_c%d_seq' % (cid, ci)].tobytes().decode() for ci in idx]
+        status, recs, stats = align_batch(ctx, gi, prm, seqs)
+        for x, ci in enumerate(idx):
+            g = c['contigs'][ci]
+            mine = [t for t in recs if t[0] == x]
+            if g['name'] in want_unsupported:
+                assert status[x] == -22 and not mine, (cid, g['name'], int(status[x]))
+                continue
+            ost, orecs = O.align_asm(oi, seqs[x], oprm)
+            assert (status[x] == 0) == (ost == 0), (cid, g['name'], int(status[x]), ost)
+            assert [t[1:] for t in mine] == [t[1:] for t in orecs], (cid, g['name'], 'records differ from the oracle')
+            got = [[c['names'][t[1]], t[2], t[3], t[4], t[5], t[6], t[7], len(t[8]), zlib.crc32(t[8].encode())] + ([t[8]] if len(t[8]) <= 4096 else []) for t in mine]
+            if vs_golden:        # (AS3's goldens were made with shrunk size constants: there only the live oracle, at the reference's sizes, applies)
+                assert (status[x] == 0) == (g['status'] == 0) and got == g['records'], (cid, g['name'], 'records differ from the reference golden')
+            n_ok += 1
+    return n_ok
+
+
+def check_asm_decode_hit(ctx, O, cases=('AS1', 'AS4')):
+    """stage entry vm_chain_global_batch in VM_MODE_ASM (GC-exact / GC-fast of the fork + its hit2work_1 / decode_hit) vs golden V2a"""
+    meta, arr = asm_golden()
+    n = 0
+    for cid in cases:
+        c = meta[cid]
+        gi, oi = _asm_index(ctx, O, meta, arr, cid)
+        prm = ctx.lib.params('asm')
+        seqs = [arr['%s_c%d_seq' % (cid, ci)].tobytes().decode() for ci in range(len(c['contigs']))]
+        anchors = ctx.map_batch(gi, seqs, check_num=-1)
+        res = ctx.chain_global_batch(prm, c['k'], anchors, [len(s) for s in seqs])
+        for ci, g in enumerate(c['contigs']):
+            r = res[ci]
+            assert r['mapq'] == g['v2_mapq'] and r['score'] == g['v2_score'], (cid, g['name'], r['mapq'], r['score'], g['v2_mapq'], g['v2_score'])
+            if g['v2_score'] != 0:
+                assert len(r['paths']) == 1 and np.array_equal(r['paths'][0], arr['%s_c%d_v2_path' % (cid, ci)]), (cid, g['name'])
+                assert bool(r['fast_used']) == (cid == 'AS4'), (cid, g['name'])
+                n += 1
+    return n

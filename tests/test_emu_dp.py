@@ -124,3 +124,8 @@ def test_emu_oom_degrades_to_sub_batches(ctx, oracle, golden, monkeypatch):
     monkeypatch.setenv('VMX_TEST_OOM_ABOVE_BASES', '5')                                # not even one read fits: the error surfaces
     with pytest.raises(Exception):
         align_batch(ctx, gi, ctx.lib.params('H'), seqs)
+
+
+def test_emu_mode_asm(ctx, oracle):
+    """-mode asm, contigs below 500 kb (the fork's per-read function): records = the reference's goldens = the oracle's"""
+    assert KC.check_asm_golden(ctx, oracle, cases=['AS1'], contigs=[3, 8, 9]) == 3       # 30 kb contig with an SV, unmappable, 900-base contig

@@ -319,3 +319,13 @@ def test_ragged_and_extreme_batches(ctx, oracle):
     assert [(int(s) == 0) for s in status] == [(int(s) == 0) for s in ost], (list(status), list(ost))
     assert recs == orecs
     assert any(t[0] == 4 for t in recs) and any(t[0] == 7 and t[2] == '-' for t in recs)
+
+
+def test_mode_asm(ctx, oracle):
+    """-mode asm (mammap_asm.py) through vm_align_batch: assembly contigs below 500 kb take the fork's per-read function on the device —
+    records = the reference's goldens (AS1: SVs, both strands, a chimera, an unmappable and a 900-base contig; AS4: repeat-dense contigs through
+    the fork's GC-fast) = the oracle's; 120 - 250 kb contigs (AS3) against the oracle run live; the 600 kb contig (AS2) is refused loudly"""
+    assert KC.check_asm_decode_hit(ctx, oracle) >= 12
+    assert KC.check_asm_golden(ctx, oracle, cases=['AS1', 'AS4']) == 13
+    assert KC.check_asm_golden(ctx, oracle, cases=['AS3'], vs_golden=False) == 3
+    assert KC.check_asm_golden(ctx, oracle, cases=['AS2'], want_unsupported=('ctg600k',)) == 0

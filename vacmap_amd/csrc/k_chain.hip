@@ -132,9 +132,28 @@ __device__ __forceinline__ void vmx_gap_geometry(int qi, long long ri, int si, i
 }
 
 
+// the -mode asm fork's geometry (mammap_asm.py:20660-20688, the same lines in its GC-fast, LC and linked DPs): the overlap case is written
+// with non_overlap_size = q_i - q_j and the opposite-strand cases carry no +-1
+__device__ __forceinline__ void vmx_gap_geometry_asm(int qi, long long ri, int si, int li, int qj, long long rj, int sj, int lj,
+                                                     long long& readgap, long long& refgap, long long& bonus) {
+    readgap = (long long)qi - qj - lj;
+    if (readgap < 0) {
+        bonus = (long long)qi + li - qj - lj;
+        readgap = 0;
+        const long long nov = (long long)qi - qj;
+        if (si == sj) { if (si == 1) refgap = ri - rj - nov; else refgap = rj + lj - nov - ri - li; }
+        else { if (sj == -1) refgap = ri + lj - nov - rj; else refgap = ri + li - rj - nov; }
+    } else {
+        bonus = li;
+        if (si == sj) { if (si == 1) refgap = ri - rj - lj; else refgap = rj - ri - li; }
+        else { if (sj == -1) refgap = ri - rj; else refgap = ri + li - rj - lj; }
+    }
+}
+
 // One read. IN_LDS is a compile-time switch so that the working arrays are plain LDS pointers (ds_read / ds_write) in the instantiation the
 // buckets run and plain global pointers in the other; a run-time choice between the two would turn every access into a flat_load.
-template <bool IN_LDS, bool RMODE>
+// VAR: 0 = modes H / L / S, 1 = mode R, 2 = -mode asm (mammap_asm.py:20551-20737: no coverage terms, vmx_gap_geometry_asm, H's scoring)
+template <bool IN_LDS, int VAR>
 __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restrict__ anchors, int rd, int64_t a0, int n, long long rmin, char* smem,
                                                       const double* s_gapcost, int lds_cap, const vmx_tables& tab, double oskipcost, int omaxdiff,
                                                       int maxgap, double* __restrict__ S_out, int32_t* __restrict__ P_out,
@@ -143,7 +162,8 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
                                                       double* __restrict__ FP_pool, double* __restrict__ PP_pool) {
     const int lane = vmx_lane();
     constexpr bool in_lds = IN_LDS;
-    constexpr bool rmode = RMODE;
+    constexpr bool rmode = VAR == 1;
+    constexpr bool nocov = VAR != 0;
     {
         const vmx_anchor* A = anchors + a0;
         // working arrays: LDS when the read fits, else straight in the HBM output arrays
@@ -173,8 +193,8 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
         // rmode: mode R's body (mammap_noprefercloser.py:22839-23057) has no coverage terms; a non-co-linear step costs the fixed skipcost,
         // remembered per anchor in fixed_penatly / pre_penatly (FP / PP, in HBM) and refunded after skipcost co-linear bases
         double* FP = rmode ? FP_pool + a0 : nullptr; double* PP = rmode ? PP_pool + a0 : nullptr;
-        double skipcost = rmode ? oskipcost : oskipcost + (double)COV[0];
-        int maxdiff = rmode ? omaxdiff : omaxdiff - (int)COV[0]; if (maxdiff < 10) maxdiff = 10;
+        double skipcost = nocov ? oskipcost : oskipcost + (double)COV[0];
+        int maxdiff = nocov ? omaxdiff : omaxdiff - (int)COV[0]; if (maxdiff < 10) maxdiff = 10;
         int testspace_en = 1;
         if (lane == 0) { SA[0] = 0; S[0] = (double)AL(0); P[0] = VMX_NOPRE; if (rmode) { FP[0] = 0.0; PP[0] = 0.0; } }
         __syncthreads();
@@ -221,7 +241,7 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
                     }
                 }
                 testspace_en = i;
-                if (!rmode) {
+                if (!nocov) {
                     const int covi = vmx_readlane(bcov, bl);
                     skipcost = oskipcost + (double)covi;
                     maxdiff = omaxdiff - covi; if (maxdiff < 10) maxdiff = 10;
@@ -241,7 +261,8 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
                     if (base == testspace_en - 1) { j = win.j; Sj = win.S; qj = win.q; lj = win.ls & 0xffff; sj = win.ls >> 16; rj = win.r; }   // first 64: registers
                     else { j = SA[x]; Sj = S[j]; qj = AQ(j); lj = AL(j); sj = AS(j); rj = AR(j); }
                     long long readgap, refgap, bonus;
-                    vmx_gap_geometry(qi, ri, si, li, qj, rj, sj, lj, readgap, refgap, bonus);
+                    if constexpr (VAR == 2) vmx_gap_geometry_asm(qi, ri, si, li, qj, rj, sj, lj, readgap, refgap, bonus);
+                    else vmx_gap_geometry(qi, ri, si, li, qj, rj, sj, lj, readgap, refgap, bonus);
                     long long gapcost = readgap - refgap; if (gapcost < 0) gapcost = -gapcost;
                     if (rmode) {
                         if (si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
@@ -281,7 +302,7 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
             if (lane == 0) { S[i] = max_scores; P[i] = pre_index; if (rmode) { FP[i] = fp_i; PP[i] = pp_i; } }
             if (max_scores > g_max_scores) { g_max_scores = max_scores; g_max_index = i; }
             pS = max_scores; pq = qi; pls = lsi; pr = ri;
-            if constexpr (IN_LDS && !RMODE) vmx_wave_lds_fence(); else __syncthreads();     // (mode R: FP / PP go through HBM)
+            if constexpr (IN_LDS && VAR != 1) vmx_wave_lds_fence(); else __syncthreads();     // (mode R: FP / PP go through HBM)
         }
         __syncthreads();
         if (!bailed) {
@@ -324,8 +345,9 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
         const long long rmin = 0;
 #define VMX_GC_CALL(L, R) vmx_chain_global_read<L, R>(anchors, rd, a0, n, rmin, smem, s_gapcost, lds_cap, tab, oskipcost, omaxdiff, maxgap, S_out, P_out, SA_out, cov_pool, \
                                                        gmax_out, opcount_out, FP_pool, PP_pool)
-        if (n <= lds_cap) { if (rmode) VMX_GC_CALL(true, true); else VMX_GC_CALL(true, false); }
-        else { if (rmode) VMX_GC_CALL(false, true); else VMX_GC_CALL(false, false); }
+        // rmode: 0 / 1 / 2 = the VAR above
+        if (n <= lds_cap) { if (rmode == 1) VMX_GC_CALL(true, 1); else if (rmode == 2) VMX_GC_CALL(true, 2); else VMX_GC_CALL(true, 0); }
+        else { if (rmode == 1) VMX_GC_CALL(false, 1); else if (rmode == 2) VMX_GC_CALL(false, 2); else VMX_GC_CALL(false, 0); }
 #undef VMX_GC_CALL
     }
 }
@@ -394,19 +416,23 @@ __global__ void __launch_bounds__(64) k_chain_select(const vmx_anchor* __restric
         }
         __syncthreads();
         if (lane == 0) {
-            int mapq = 0, nsec;
-            if (fit) nsec = vmx_select_rank(nch, mode, l_cscore, l_coff, l_cq, S + a0, W.cidx, l_order, l_bins, l_boff, l_prim, l_sec, &mapq);
-            else nsec = vmx_select_rank(nch, mode, W.cscore, W.coff, W.cq, S + a0, W.cidx, W.order, W.bins, W.boff, W.prim, W.sec, &mapq);
-            const double sc = fit ? l_cscore[0] : W.cscore[0];
-            out_mapq[r] = mapq; out_score[r] = need_reverse[r] ? -sc : sc; out_npaths[r] = nsec + 1;
-            s_hdr[2] = nsec;
+            int mapq = 0, nsec, pidx = 0;
+            if (fit) nsec = vmx_select_rank(nch, mode, l_cscore, l_coff, l_cq, S + a0, W.cidx, l_order, l_bins, l_boff, l_prim, l_sec, &mapq, &pidx);
+            else nsec = vmx_select_rank(nch, mode, W.cscore, W.coff, W.cq, S + a0, W.cidx, W.order, W.bins, W.boff, W.prim, W.sec, &mapq, &pidx);
+            const double sc = fit ? l_cscore[pidx] : W.cscore[pidx];
+            if (nsec == -2) {                          // -mode asm: the edlib tie-break among equal chains is not built (vmx_select.h)
+                out_mapq[r] = 0; out_score[r] = need_reverse[r] ? -0.0 : 0.0; out_npaths[r] = 0;
+                const_cast<int64_t*>(gmax)[r] = -3;
+            } else { out_mapq[r] = mapq; out_score[r] = need_reverse[r] ? -sc : sc; out_npaths[r] = nsec + 1; }
+            s_hdr[2] = nsec; s_hdr[3] = pidx;
         }
         __syncthreads();
-        const int nsec = s_hdr[2];
+        const int nsec = s_hdr[2], pidx = s_hdr[3];
+        if (nsec < 0) continue;
         // decode_hit: return_path_list = [best path] + secondaries
         int wr = 0;
         for (int pi = 0; pi <= nsec; ++pi) {
-            const int c = pi == 0 ? 0 : (fit ? l_sec[pi - 1] : W.sec[pi - 1]);
+            const int c = pi == 0 ? pidx : (fit ? l_sec[pi - 1] : W.sec[pi - 1]);
             const int t0 = fit ? l_coff[c] : W.coff[c], t1 = fit ? l_coff[c + 1] : W.coff[c + 1];
             if (lane == 0) out_path_len[a0 + pi] = t1 - t0;
             for (int t = t0 + lane; t < t1; t += 64) out_path_anchors[a0 + wr + (t - t0)] = A[W.cidx[t]];

@@ -116,7 +116,19 @@ __device__ __forceinline__ bool vmx_fast_eval(const vmx_anchor& ai, const vmx_an
                                               double fpj = 0.0, double ppj = 0.0, double* nfp = nullptr, double* npp = nullptr) {
     const int qi = ai.q, li = ai.l, si = ai.s, qj = aj.q, lj = aj.l, sj = aj.s; const long long ri = ai.r, rj = aj.r;
     long long readgap = (long long)qi - qj - lj, refgap, bonus;
-    if (readgap < 0) {
+    if (VARIANT == 4) {                                   // -mode asm: mammap_asm.py:20866-20895 (non_overlap_size form, no +-1)
+        if (readgap < 0) {
+            bonus = (long long)qi + li - qj - lj;
+            readgap = 0;
+            const long long nov = (long long)qi - qj;
+            if (si == sj) { if (si == 1) refgap = ri - rj - nov; else refgap = rj + lj - nov - ri - li; }
+            else { if (sj == -1) refgap = ri + lj - nov - rj; else refgap = ri + li - rj - nov; }
+        } else {
+            bonus = li;
+            if (si == sj) { if (si == 1) refgap = ri - rj - lj; else refgap = rj - ri - li; }
+            else { if (sj == -1) refgap = ri - rj; else refgap = ri + li - rj - lj; }
+        }
+    } else if (readgap < 0) {
         bonus = (long long)qi + li - qj - lj;
         if ((VARIANT == 1 || VARIANT == 2) && bonus <= 0) return false;
         readgap = 0;
@@ -142,9 +154,9 @@ __device__ __forceinline__ bool vmx_fast_eval(const vmx_anchor& ai, const vmx_an
         return true;
     }
     if (si == sj && refgap >= 0 && readgap <= C.maxgap && gapcost <= C.maxdiff) {
-        if (VARIANT == 0) *test = Sj + (double)bonus - C.gapcost[gapcost];
+        if (VARIANT == 0 || VARIANT == 4) *test = Sj + (double)bonus - C.gapcost[gapcost];
         else *test = Sj + (double)bonus - C.gapcost[gapcost] - (double)C.rgc[readgap];
-    } else if (VARIANT == 0) {
+    } else if (VARIANT == 0 || VARIANT == 4) {
         *test = Sj - C.skipcost + (double)bonus - vmx_extra_cost(C.tab, gapcost);
     } else if (VARIANT == 1) {
         const double ex = vmx_extra_cost(C.tab, gapcost);
@@ -180,7 +192,7 @@ __device__ int vmx_fast_dp(const vmx_fast_io& io, vmx_fast_cost C, const double*
     }
     __syncthreads();
     const vmx_anchor a0 = A[0];
-    constexpr bool GC = VARIANT == 0 || VARIANT == 3;
+    constexpr bool GC = VARIANT == 0 || VARIANT == 3 || VARIANT == 4;     // 4: GC-fast of the -mode asm fork (mammap_asm.py:20738-21037), no coverage terms
     long long prereadloc = GC ? (long long)a0.q : (long long)a0.q + a0.l;
     C.gapcost = gapcost_list; C.skipcost = oskipcost; C.maxdiff = omaxdiff;
     int testspace_en_i = 1;
@@ -299,11 +311,11 @@ __global__ void __launch_bounds__(64) k_chain_global_fast(const vmx_anchor* __re
     vmx_fast_io io;
     io.A = anchors + a0; io.n = n; io.S = S_out + a0; io.P = P_out + a0; io.SA = SA_out + a0; io.Si = si_pool + a0; io.T = t_pool + a0;
     io.CNT = cnt_pool + roff[rd] + 50 * (int64_t)rd; io.cnt_n = io.A[n - 1].q + 50;
-    io.COV = cov_pool + a0; io.FP = rmode ? FP_pool + a0 : nullptr; io.PP = rmode ? PP_pool + a0 : nullptr;
+    io.COV = cov_pool + a0; io.FP = rmode == 1 ? FP_pool + a0 : nullptr; io.PP = rmode == 1 ? PP_pool + a0 : nullptr;
     vmx_fast_cost C; C.gapcost = gapcost_list; C.rgc = nullptr; C.tab = tab; C.skipcost = oskipcost; C.maxdiff = omaxdiff; C.maxgap = maxgap;
     C.extra_size = (long long)tab.extra_n - 1; C.l2c_size = (long long)tab.log2cache_n - 1;
     double gs = 0.0;
-    const int g = rmode ? vmx_fast_dp<3>(io, C, gapcost_list, oskipcost, omaxdiff, &gs) : vmx_fast_dp<0>(io, C, gapcost_list, oskipcost, omaxdiff, &gs);
+    const int g = rmode == 1 ? vmx_fast_dp<3>(io, C, gapcost_list, oskipcost, omaxdiff, &gs) : (rmode == 2 ? vmx_fast_dp<4>(io, C, gapcost_list, oskipcost, omaxdiff, &gs) : vmx_fast_dp<0>(io, C, gapcost_list, oskipcost, omaxdiff, &gs));
     if (vmx_lane() == 0) gmax_out[rd] = g >= 0 ? g : -2;       // -2: the reference raises on this read (treated as unmapped)
 }
 

@@ -16,7 +16,11 @@
 
 // One read. IN_LDS is a compile-time switch so that the working arrays are plain LDS pointers (ds_read / ds_write) in the instantiation the
 // buckets run, and plain global pointers in the other one; a run-time choice between the two would make every access a flat_load.
-// VAR (0 LC-exact, 1 LC-mm, 2 `_scar`) is compile-time too: each instantiation carries one scoring rule.
+// VAR (0 LC-exact, 1 LC-mm, 2 `_scar`, 3 the -mode asm fork's LC) is compile-time too: each instantiation carries one scoring rule.
+// VAR 3 = mammap_asm.py:16540-16730: anchors sorted by read START and the candidate window advances on read starts (:16609), no opcount
+// switch, no `bonus <= 0` skip, the fork's gap geometry (:16641-16669), co-linear steps pay 0.5*log2 + 0.1*log2(readgap) (:16555, :16536),
+// a non-co-linear step costs skipcost + extra[gapcost] evaluated as ((S_j - skipcost) + bonus) - extra (:16686), and the traceback trims the
+// EARLIER anchor's end where two chained anchors overlap on the read (:16720-16726).
 template <bool IN_LDS, int VAR>
 __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restrict__ anchors, const int32_t* __restrict__ n_guides_total, int rd, int64_t a0, int n,
                                                      long long rmin, char* smem, const double* s_gapcost, float* s_rgc, int lds_cap, const vmx_tables& tab,
@@ -33,9 +37,10 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
         // on co-linearly for skipcost bases; no opcount switch
         constexpr bool scar = VAR == 2;
         constexpr bool mm = VAR == 1;
+        constexpr bool asmv = VAR == 3;
         double* FP = scar ? FP_pool + a0 : nullptr; double* PP = scar ? PP_pool + a0 : nullptr;
         const double skipcost = mm ? skip_mm : skip_exact;
-        const float* rgc_g = mm ? tab.large_readgap : (mode == 3 ? tab.readgap_r : tab.readgap_h);
+        const float* rgc_g = mm ? tab.large_readgap : ((mode == 3 || asmv) ? tab.readgap_r : tab.readgap_h);
         for (int x = lane; x < 100; x += 64) s_rgc[x] = rgc_g[x];          // read-gap cost table of this read's variant (100 entries, maxgap <= 99)
         const float* rgc = s_rgc;
         const vmx_anchor* A = anchors + a0;
@@ -53,7 +58,7 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
 #define AR(i) ((long long)A[i].r)
 #define AL(i) ((int)A[i].l & 0xffff)
 #define AS(i) ((int)A[i].s)
-        long long prereadloc = (long long)AQ(0) + AL(0);
+        long long prereadloc = asmv ? (long long)AQ(0) : (long long)AQ(0) + AL(0);
         int testspace_en = 1;
         if (lane == 0) { SA[0] = 0; S[0] = (double)AL(0); P[0] = VMX_NOPRE; if (scar) { FP[0] = 0.0; PP[0] = 0.0; } }
         __syncthreads();
@@ -76,8 +81,8 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
             const int bl = i & 63;
             const int qi = vmx_readlane(bq, bl); const int lsi = vmx_readlane(bls, bl); const int li = lsi & 0xffff, si = lsi >> 16;
             long long ri; { union { long long d; int w[2]; } u; u.d = br; u.w[0] = vmx_readlane(u.w[0], bl); u.w[1] = vmx_readlane(u.w[1], bl); ri = u.d; }
-            if (prereadloc < (long long)qi + li) {
-                if (!scar && opcount > 100000 && ((double)opcount / (double)prereadloc) > 1000.0) { need_fast = true; break; }   // :27380 -> *_fast
+            if (prereadloc < (asmv ? (long long)qi : (long long)qi + li)) {
+                if (!scar && !asmv && opcount > 100000 && ((double)opcount / (double)prereadloc) > 1000.0) { need_fast = true; break; }   // :27380 -> *_fast
                 for (int k = testspace_en; k < i; ++k) {
                     // smallorequal(...) + 1 (:13229-13265) on a sorted array = number of scores <= S[k]: the new entry goes above its equals
                     double Sk; int qk, lsk; long long rk;
@@ -95,7 +100,7 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
                     }
                 }
                 testspace_en = i;
-                prereadloc = (long long)qi + li;
+                prereadloc = asmv ? (long long)qi : (long long)qi + li;
             }
             const double dli = (double)li;
             double max_scores = dli; int pre_index = VMX_NOPRE;
@@ -111,7 +116,19 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
                     else { j = SA[x]; Sj = S[j]; qj = AQ(j); lj = AL(j); sj = AS(j); rj = AR(j); }
                     long long readgap = (long long)qi - qj - lj, refgap, bonus;
                     bool skip = false;
-                    if (readgap < 0) {
+                    if (asmv) {
+                        if (readgap < 0) {
+                            bonus = (long long)qi + li - qj - lj;
+                            readgap = 0;
+                            const long long nov = (long long)qi - qj;
+                            if (si == sj) { if (si == 1) refgap = ri - rj - nov; else refgap = rj + lj - nov - ri - li; }
+                            else { if (sj == -1) refgap = ri + lj - nov - rj; else refgap = ri + li - rj - nov; }
+                        } else {
+                            bonus = li;
+                            if (si == sj) { if (si == 1) refgap = ri - rj - lj; else refgap = rj - ri - li; }
+                            else { if (sj == -1) refgap = ri - rj; else refgap = ri + li - rj - lj; }
+                        }
+                    } else if (readgap < 0) {
                         bonus = (long long)qi + li - qj - lj;
                         if (bonus <= 0) skip = true;
                         readgap = 0;
@@ -137,6 +154,8 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
                             }
                         } else if (si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
                             test = Sj + (double)bonus - s_gapcost[gapcost] - (double)rgc[readgap];
+                        } else if (asmv) {
+                            test = Sj - skipcost + (double)bonus - vmx_extra_cost(tab, gapcost);
                         } else if (!mm) {
                             const double ex = vmx_extra_cost(tab, gapcost);
                             double pen;
@@ -186,6 +205,13 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
                 while (P[take] != VMX_NOPRE) {
                     take = P[take];
                     vmx_anchor now; now.q = AQ(take); now.r = AR(take); now.l = (int16_t)AL(take); now.s = (int16_t)AS(take);
+                    if (asmv) {
+                        vmx_anchor t = now;
+                        if (!(pre.q >= now.q + now.l)) { t.l = (int16_t)(pre.q - now.q); if (now.s != 1) t.r = now.r + now.l - pre.q + now.q; }
+                        O[w++] = t;
+                        pre = now;
+                        continue;
+                    }
                     if (pre.q < now.q + now.l) {
                         int ov = now.q + now.l - pre.q;
                         vmx_anchor t = pre; t.q = pre.q + ov; t.l = (int16_t)(pre.l - ov); if (pre.s == 1) t.r = pre.r + ov;
@@ -196,7 +222,7 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
                 }
                 out_len[rd] = w; out_score[rd] = g_max_scores; status[rd] = 0;
             }
-            out_variant[rd] = scar ? 2 : (mm ? 1 : 0);
+            out_variant[rd] = asmv ? 3 : (scar ? 2 : (mm ? 1 : 0));
         }
         __syncthreads();
 #undef AQ
@@ -228,11 +254,11 @@ __global__ void __launch_bounds__(64) k_chain_local(const vmx_anchor* __restrict
         if (n <= 0) { if (lane == 0) { out_len[rd] = 0; out_score[rd] = 0; status[rd] = VM_READ_RAISED_DEV; } continue; }   // np.array([]) indexing raises
         const vmx_anchor* A = anchors + a0;
         const long long rmin = 0;
-        const int var = mode == 3 ? 2 : (n_guides_total[rd] > 1 ? 1 : 0);
+        const int var = mode == 4 ? 3 : (mode == 3 ? 2 : (n_guides_total[rd] > 1 ? 1 : 0));
 #define VMX_LC_CALL(L, V) vmx_chain_local_read<L, V>(anchors, n_guides_total, rd, a0, n, rmin, smem, s_gapcost, s_rgc, lds_cap, tab, skip_exact, skip_mm, maxdiff, maxgap, \
                                                       mode, S_pool, P_pool, SA_pool, out_score, out_chain, out_len, out_variant, status, FP_pool, PP_pool)
-        if (n <= lds_cap) { if (var == 0) VMX_LC_CALL(true, 0); else if (var == 1) VMX_LC_CALL(true, 1); else VMX_LC_CALL(true, 2); }
-        else { if (var == 0) VMX_LC_CALL(false, 0); else if (var == 1) VMX_LC_CALL(false, 1); else VMX_LC_CALL(false, 2); }
+        if (n <= lds_cap) { if (var == 0) VMX_LC_CALL(true, 0); else if (var == 1) VMX_LC_CALL(true, 1); else if (var == 2) VMX_LC_CALL(true, 2); else VMX_LC_CALL(true, 3); }
+        else { if (var == 0) VMX_LC_CALL(false, 0); else if (var == 1) VMX_LC_CALL(false, 1); else if (var == 2) VMX_LC_CALL(false, 2); else VMX_LC_CALL(false, 3); }
 #undef VMX_LC_CALL
     }
 }

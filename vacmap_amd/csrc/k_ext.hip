@@ -57,7 +57,7 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
     int32_t* segprob = A.seg_prob + A.soff[r];
     const bool nofilter = A.nodiscard || E.pass == 1;
     if (phase == 0) {
-        int rc = vmx_rebuild_chain_break(A.chain + A.la_off[r], cl, R, A.local_maxdiff, 50, S);
+        int rc = vmx_rebuild_chain_break(A.chain + A.la_off[r], cl, R, A.local_maxdiff, A.mode == 4 ? 40 : 50, S, A.mode == 4);     // small_alignment 40 in the asm fork (mammap_asm.py:22321)
         if (rc < 0) { E.status = rc; return; }
         E.nseg = S.nseg;
         int b = vmx_alloc_probs(A, S.nseg);
@@ -99,7 +99,7 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
             E.nseg_snap = S.nseg;
         }
         const int o_len = S.nseg;
-        if (S.nseg > 2 && !nofilter) { int iloc = 0; while (iloc < S.nseg - 2) { if (vmx_drop_misplaced(S, iloc)) continue; else iloc += 1; } }
+        if (S.nseg > 2 && !nofilter && A.mode != 4) { int iloc = 0; while (iloc < S.nseg - 2) { if (vmx_drop_misplaced(S, iloc)) continue; else iloc += 1; } }
         E.nseg = S.nseg;
         E.skip_ext = 1;
         if (S.nseg < o_len) { E.filtered = 1; E.skip_ext = 0; }
@@ -139,13 +139,13 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
     }
     if (phase == 5) {
         vmx_merge_conjacent(S, R, A.dup + A.soff[r]);
-        int rc = vmx_fix_simple_inv(S, R, RD, L, A.mode == 3);
+        int rc = vmx_fix_simple_inv(S, R, RD, L, A.mode == 3 || A.mode == 4);      // the asm fork keeps mode R's body (mammap_asm.py:17158-17207)
         if (rc < 0) { E.status = rc; return; }
         E.nseg = S.nseg;
         // checkpoints -> gap-fill problems: count first, then allocate exactly that many slots
         int total = 0;
         for (int s = 0; s < S.nseg; ++s) {
-            int np = vmx_split_alignment(S, s, L, R, nullptr, 0);
+            int np = vmx_split_alignment(S, s, L, R, nullptr, 0, A.mode == 4);
             if (np < 0) { E.status = np; return; }
             segprob[s] = np; total += np;
         }
@@ -153,7 +153,7 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
         if (b < 0) { E.status = VM_READ_CAPACITY_DEV; return; }
         int k = 0;
         for (int s = 0; s < S.nseg; ++s) {
-            int np = vmx_split_alignment(S, s, L, R, A.desc + b + k, total - k);
+            int np = vmx_split_alignment(S, s, L, R, A.desc + b + k, total - k, A.mode == 4);
             if (np < 0) { E.status = np; return; }
             k += np;
         }
@@ -298,10 +298,30 @@ __global__ void __launch_bounds__(64) k_ext_records(vmx_ext_args A, const vmx_dp
         const long long st = w;
         char tmp[24];
         if (q_st > 0) { const int nd = vmx_put_int(tmp, q_st); if (lane == 0) { for (int i = 0; i < nd; ++i) BLOB[w + i] = tmp[i]; BLOB[w + nd] = clip; } w += nd + 1; }
+        const long long wc0 = w;                      // start of the segment's CIGAR body (behind the leading clip)
         for (int x = 0; x < np; ++x) {
             const int p = dp_base + k + x; const char* src = cig_pool + probs[p].cig_off; const int n = cig_len[p];
-            for (int i = lane; i < n; i += 64) BLOB[w + i] = src[i];
-            w += n;
+            int from = 0;
+            if (A.mode == 4 && x > 0 && n > 0 && w > wc0) {
+                // link_cigar (mammap_asm.py:22365-22410): the asm fork joins the pieces into ONE string, adding the counts when the last operator
+                // written equals the first operator of the next piece. Every lane reads the same few bytes; lane 0 writes the joined count.
+                __syncthreads();
+                const char last = BLOB[w - 1];
+                int j = 0; long long num2 = 0;
+                while (j < n && src[j] >= '0' && src[j] <= '9') { num2 = num2 * 10 + (src[j] - '0'); ++j; }
+                if (j < n && src[j] == last) {
+                    long long i = w - 1, num1 = 0, factor = 1; bool brk = false;
+                    while (i > wc0) { --i; const char ch = BLOB[i]; if (ch >= '0' && ch <= '9') { num1 += (long long)(ch - '0') * factor; factor *= 10; } else { brk = true; break; } }
+                    w = brk ? i + 1 : wc0;
+                    __syncthreads();              // every lane has parsed the old count before lane 0 overwrites it
+                    const int nd = vmx_put_int(tmp, num1 + num2);
+                    if (lane == 0) { for (int t = 0; t < nd; ++t) BLOB[w + t] = tmp[t]; BLOB[w + nd] = last; }
+                    w += nd + 1;
+                    from = j + 1;
+                }
+            }
+            for (int i = from + lane; i < n; i += 64) BLOB[w + (i - from)] = src[i];
+            w += n - from;
         }
         k += np;
         long long ql = qsum;

@@ -233,17 +233,19 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         for (int g = 1; g <= prm->global_maxdiff; ++g) gap[g] = (0.01 * ix.k * g + 0.5 * T.log2int[g]);
         VMX_TRY(upload(B.gap, gap.data(), 64, c->stream));
     }
-    const int rmode = prm->mode == VM_MODE_R ? 1 : 0;
-    if (rmode) { VMX_TRY(B.fp.reserve(8 * (size_t)(tot + 1))); VMX_TRY(B.pp.reserve(8 * (size_t)(tot + 1))); }   // fixed_penatly / pre_penatly of mode R's chain
+    const int rmode = prm->mode == VM_MODE_R ? 1 : (prm->mode == VM_MODE_ASM ? 2 : 0);      // the GC kernels' variant: H / L / S, R, the asm fork
+    if (rmode == 1) { VMX_TRY(B.fp.reserve(8 * (size_t)(tot + 1))); VMX_TRY(B.pp.reserve(8 * (size_t)(tot + 1))); }   // fixed_penatly / pre_penatly of mode R's chain
     // LDS buckets by anchor count (25 B per anchor), reads longest-first inside a bucket, one workgroup per read (see vmx_local_stage)
     constexpr int NB = 10;
     const int caps[NB] = {384, 512, 768, 1024, 1536, 2048, 3072, 4096, 8192, 13056};
     std::vector<int32_t> lists[NB + 1];
+    std::vector<int64_t> asm_long;
     static const int gc_lds_env = [] { const char* e = getenv("VMX_GC_LDS_MAX"); return e ? atoi(e) : -1; }();     // see vmx_stage_local.hip
     const int gc_lds_max = gc_lds_env >= 0 ? gc_lds_env : VMX_CHAIN_LDS_MAX_SHARED;
     for (int64_t r = 0; r < n; ++r) {
         int64_t m = h_aoff[r + 1] - h_aoff[r]; const int64_t L = h_roff[r + 1] - h_roff[r];
         if (m <= 2) continue;                                             // :23986 unmapped
+        if (prm->mode == VM_MODE_ASM && L >= 500000) { asm_long.push_back(r); continue; }      // mammap_asm.py:23205: the linked path, not built on the device
         if ((double)m / (double)L > 5.0) continue;                        // fast_enable (:23570): gmax stays -1 -> k_chain_global_fast below
         int bk = NB; for (int q = 0; q < NB; ++q) if (m <= caps[q] && caps[q] <= gc_lds_max) { bk = q; break; }
         lists[bk].push_back((int32_t)r);
@@ -256,6 +258,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         }
         VMX_TRY(upload(B.rl, rl.data(), rl.size(), c->stream));
         VMX_HIP(hipMemsetAsync(B.gmax.p, 0xff, 8 * (size_t)n, c->stream));
+        { static const int64_t kUnsupported = -4; for (int64_t r : asm_long) VMX_HIP(hipMemcpyAsync(B.gmax.as<int64_t>() + r, &kUnsupported, 8, hipMemcpyHostToDevice, c->stream)); }
 #ifndef VMX_EMU
         VMX_HIP(hipFuncSetAttribute((const void*)k_chain_global, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)caps[NB - 1] * VMX_GC_BYTES_PER_ANCHOR + 64)));
 #endif
@@ -548,7 +551,8 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     for (int64_t r = 0; r < n; ++r) {
         int stt2 = er[r].status;
         if (h_gmax[r] == -2 && (h_aoff[r + 1] - h_aoff[r]) > 2) stt2 = VM_READ_RAISED;     // GC-fast: the reference raises on this read (k_chain_fast.hip)
-        if (rmode && (h_aoff[r + 1] - h_aoff[r]) <= 2) stt2 = VM_READ_RAISED;              // mode R returns an unbound `factor` for <= 2 anchors (mammap_noprefercloser.py:24417)
+        if (h_gmax[r] == -3 || h_gmax[r] == -4) stt2 = VM_READ_UNSUPPORTED;                // -mode asm: edlib tie-break among equal chains / contig of 500 kb or more (vacmapx.h)
+        if (rmode == 1 && (h_aoff[r + 1] - h_aoff[r]) <= 2) stt2 = VM_READ_RAISED;              // mode R returns an unbound `factor` for <= 2 anchors (mammap_noprefercloser.py:24417)
         if (status_per_read) status_per_read[r] = stt2;
         if (stt2 != 0) { st.n_failed++; continue; }
         if (er[r].nrec == 0) st.n_unmapped++;

@@ -42,6 +42,8 @@ void vm_params_default(vm_params* p, int mode) {
     else if (mode == VM_MODE_H) { p->local_skipcost = 40.; p->global_skipcost = 40.; p->maxdivergence = 0.2; }
     else { p->local_skipcost = 30.; p->global_skipcost = 30.; p->maxdivergence = 0.5; }
     p->nodiscard = !(mode == VM_MODE_L || mode == VM_MODE_H);
+    // -mode asm: --eqx forced (src/vacmap/vacmap:246), maxdivergence forced to 1 by the worker (mammap_asm.py:23483), check_num = -1 (:23206)
+    if (mode == VM_MODE_ASM) { p->eqx = 1; p->maxdivergence = 1.0; p->check_num = -1; }
 }
 
 int vm_device_count(void) {
@@ -420,8 +422,8 @@ int vm_chain_global_batch(vm_ctx* c, const vm_params* prm, int kmersize, int64_t
     std::vector<double> gap(64, 0.0);
     for (int g = 1; g <= prm->global_maxdiff; ++g) gap[g] = (0.01 * kmersize * g + 0.5 * T.log2int[g]);
     VMX_TRY(upload(d_gap, gap.data(), 64, c->stream));
-    const int rmode = prm->mode == VM_MODE_R ? 1 : 0;
-    if (rmode) { VMX_TRY(c->b[25].reserve(8 * (size_t)(tot + 1))); VMX_TRY(c->b[26].reserve(8 * (size_t)(tot + 1))); }   // mode R: fixed_penatly / pre_penatly
+    const int rmode = prm->mode == VM_MODE_R ? 1 : (prm->mode == VM_MODE_ASM ? 2 : 0);
+    if (rmode == 1) { VMX_TRY(c->b[25].reserve(8 * (size_t)(tot + 1))); VMX_TRY(c->b[26].reserve(8 * (size_t)(tot + 1))); }   // mode R: fixed_penatly / pre_penatly
     // bucket the reads by anchor count so that each launch asks for no more LDS than it needs (160 KiB per CU on gfx950)
     const int caps[4] = {768, 1536, 3072, 13056};
     std::vector<int32_t> lists[5];

@@ -54,7 +54,8 @@ __host__ __device__ inline void vmx_seg_erase(vmx_segs& S, int s) {
 }
 
 // E1 :23437-23484. chain in ASCENDING read order. returns 0, VM_READ_RAISED_DEV (IndexError at :23480) or VM_READ_CAPACITY_DEV
-__host__ __device__ inline int vmx_rebuild_chain_break(const vmx_anchor* chain_desc, int n, const vmx_ref_view& R, int large_cost, int small_alignment, vmx_segs& S) {
+// asmv: the -mode asm fork (mammap_asm.py:13256-13295) joins only when refgap >= 0 (no tolerance for a 20-base back-step)
+__host__ __device__ inline int vmx_rebuild_chain_break(const vmx_anchor* chain_desc, int n, const vmx_ref_view& R, int large_cost, int small_alignment, vmx_segs& S, bool asmv = false) {
     S.nseg = 0;
     int w = 1;                                   // write cursor in A (slot 0 = spare before the first segment)
     vmx_anchor pre = chain_desc[n - 1];
@@ -74,7 +75,7 @@ __host__ __device__ inline int vmx_rebuild_chain_break(const vmx_anchor* chain_d
             long long readgap = (long long)now.q - pre.q - pre.l, refgap;
             if (pre.s == 1) refgap = (long long)now.r - pre.r - pre.l; else refgap = (long long)pre.r - now.r - now.l;
             long long d = readgap - refgap; if (d < 0) d = -d;
-            if (d <= large_cost && refgap >= -20 && readgap < 100) {
+            if (d <= large_cost && refgap >= (asmv ? 0 : -20) && readgap < 100) {
                 if (vmx_p2c(R, pre.r) == vmx_p2c(R, now.r)) {
                     if (refgap >= 0) { if (w + 2 > S.capA) return VM_READ_CAPACITY_DEV; S.A[w++] = now; S.en[S.nseg - 1] = w; pre = now; continue; }
                     else { if (readgap <= 20) continue; if (w + 2 > S.capA) return VM_READ_CAPACITY_DEV; S.A[w++] = now; S.en[S.nseg - 1] = w; pre = now; continue; }
@@ -346,7 +347,8 @@ __host__ __device__ inline int vmx_fix_simple_inv(vmx_segs& S, const vmx_ref_vie
 // E5 checkpoints :21505-21617. Emits the DP problems of segment s (in the order the reference computes them) into out[];
 // converts the end anchors to zero length like the reference. returns the number of problems, or a negative status.
 // out == nullptr: count only (the end-anchor conversions are idempotent, so a counting call followed by an emitting call is safe)
-__host__ __device__ inline int vmx_split_alignment(vmx_segs& S, int s, long long L, const vmx_ref_view& R, vmx_pair_desc* out, int cap) {
+// asmv: mammap_asm.py:22197-22316 — the short-anchor / short-gap skip applies only while max(readgap, refgap) < 2000
+__host__ __device__ inline int vmx_split_alignment(vmx_segs& S, int s, long long L, const vmx_ref_view& R, vmx_pair_desc* out, int cap, bool asmv = false) {
     const long long min_gap_forcigar = 200;
     int np = 0;
     const int st = S.st[s], en = S.en[s];
@@ -366,7 +368,8 @@ __host__ __device__ inline int vmx_split_alignment(vmx_segs& S, int s, long long
             const vmx_anchor now = pf[j];
             long long readgap = (long long)now.q - pre.q - pre.l, refgap = (long long)now.r - pre.r - pre.l;
             long long mn = readgap < refgap ? readgap : refgap;
-            if ((now.l < 19 || mn < min_gap_forcigar) && i + 1 != en) continue;
+            const long long mx = readgap < refgap ? refgap : readgap;
+            if ((!asmv || mx < 2000) && (now.l < 19 || mn < min_gap_forcigar) && i + 1 != en) continue;
             if (out && np >= cap) return VM_READ_CAPACITY_DEV;
             vmx_pair_desc* d = out ? &out[np] : &tmp;
             vmx_qt_for_cigar(pre, now, L, R, d);
@@ -389,7 +392,8 @@ __host__ __device__ inline int vmx_split_alignment(vmx_segs& S, int s, long long
             const vmx_anchor now = pf[j];
             long long readgap = (long long)pre.q - now.q - now.l, refgap = (long long)now.r - pre.r - pre.l;
             long long mn = readgap < refgap ? readgap : refgap;
-            if ((now.l < 19 || mn < min_gap_forcigar) && i != st) continue;
+            const long long mx = readgap < refgap ? refgap : readgap;
+            if ((!asmv || mx < 2000) && (now.l < 19 || mn < min_gap_forcigar) && i != st) continue;
             if (out && np >= cap) return VM_READ_CAPACITY_DEV;
             vmx_pair_desc* d = out ? &out[np] : &tmp;
             vmx_qt_for_cigar(now, pre, L, R, d);

@@ -26,8 +26,9 @@ __host__ __device__ inline bool vmx_local_accept(long long refloc, long long ref
 __host__ __device__ inline void vmx_local_prep(const vmx_anchor* rows, const int32_t* len, int np, int mode, vmx_anchor* out_rows,
                                                int32_t* out_len, int32_t* n_used, int32_t* n_total) {
     if (np > VMX_MAX_PATHS) np = VMX_MAX_PATHS;
-    if (mode == 3) {
+    if (mode == 3 || mode == 4) {
         // mode R (mammap_noprefercloser.py:23902-23914): every chain is re-seeded, in the order given, no merge / drop / cap
+        // (-mode asm, mammap_asm.py:19714-19719: decode_hit returns the primary path only, and that one is re-seeded)
         int w = 0;
         for (int p = 0; p < np; ++p) { for (int t = 0; t < len[p]; ++t) { out_rows[w] = rows[w]; ++w; } out_len[p] = len[p]; }
         *n_used = np; *n_total = np;

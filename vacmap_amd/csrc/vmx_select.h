@@ -82,9 +82,14 @@ __host__ __device__ VMX_SELECT_INLINE int vmx_select_peel(int n, const double* S
 
 // :23650-23707 + select_secondary_alignment :23505-23538 on the kept chains: cq[t] = read position of chain node t (A[cidx[t]].q).
 // Sg / cidx: S and the chain node list in HBM (read a few times by the secondary test). Returns the number of secondaries (sec[]).
+// mode 4 (-mode asm, mammap_asm.py:18551-18602 + decode_hit :21280-21348): the chains keep their score order (no "best chain first" swap), the
+// primary is order[0] (*out_prim), there are no secondaries; when MAPQ is 0 and the primary's group holds a second chain within 0.1 % of its
+// score the reference picks the least divergent of them with edlib (:21302-21326) — that choice is not made here: returns -2 and the caller
+// reports the contig as VM_READ_UNSUPPORTED instead of guessing.
 __host__ __device__ VMX_SELECT_INLINE int vmx_select_rank(int nch, int mode, const double* cscore, const int* coff, const int* cq, const double* Sg, const int* cidx,
-                                                          int* order, int* bins, int* boff, int* prim, int* sec, int* out_mapq) {
+                                                          int* order, int* bins, int* boff, int* prim, int* sec, int* out_mapq, int* out_prim) {
     const int sec_min_span = (mode == 3) ? 100 : 50;
+    const bool asmv = mode == 4;
     // order = argsort(scores)[::-1] (stable): descending score, equal scores in descending index
     for (int c = 0; c < nch; ++c) {
         int pos = 0;
@@ -92,7 +97,9 @@ __host__ __device__ VMX_SELECT_INLINE int vmx_select_rank(int nch, int mode, con
         for (int t = c; t > pos; --t) order[t] = order[t - 1];
         order[pos] = c;
     }
-    if (order[0] != 0) { for (int i = 0; i < nch; ++i) if (order[i] == 0) { order[i] = order[0]; order[0] = 0; break; } }
+    if (!asmv && order[0] != 0) { for (int i = 0; i < nch; ++i) if (order[i] == 0) { order[i] = order[0]; order[0] = 0; break; } }
+    const int pc0 = order[0];
+    *out_prim = pc0;
     // read-position bins (//100) per chain, unique, descending
     {
         int bw = 0;
@@ -117,14 +124,15 @@ __host__ __device__ VMX_SELECT_INLINE int vmx_select_rank(int nch, int mode, con
         else if (prefer == 0) { f2 = cscore[c]; break; }   // = primary_scores_List[0][1]; later members never matter
     }
     {
-        const double f1 = cscore[0];
-        const double mlen = (double)(coff[1] - coff[0]);
+        const double f1 = cscore[pc0];
+        const double mlen = (double)(coff[pc0 + 1] - coff[pc0]);
         double v = 40 * (1 - f2 / f1);
         double mm = mlen / 10; if (mm > 1.0) mm = 1.0;
         v = v * mm;
         v = v * log(f1);
         long long iv = (long long)v;
         *out_mapq = (int)(iv < 60 ? iv : 60);
+        if (asmv) return (*out_mapq == 0 && f2 != 0.0 && !(f2 / f1 < 0.999)) ? -2 : 0;
     }
     int nsec = 0;
     if (nch > 1) {

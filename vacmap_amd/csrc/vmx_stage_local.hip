@@ -99,8 +99,9 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         A.ocodes = d_ocodes; A.roff = d_roff; A.ref = ix.codes; A.coff = ix.coff; A.nseq = ix.nseq;
         A.guide_rows = L.guide_rows.as<vmx_anchor>(); A.guide_len = L.guide_len.as<int32_t>(); A.n_guides_used = L.ng_used.as<int32_t>(); A.aoff = d_aoff;
         A.n_reads = cnt; A.k = k; A.epoch_pool = L.epoch.as<int32_t>();
-        A.look_span = prm->mode == VM_MODE_R ? 2000 : 7000; A.read_span = prm->mode == VM_MODE_R ? 500 : 7000;   // :23094, :23190 / mammap_noprefercloser.py:23631+
-        A.sort_by_start = prm->mode == VM_MODE_R ? 1 : 0;
+        const bool narrow = prm->mode == VM_MODE_R || prm->mode == VM_MODE_ASM;                   // mammap_noprefercloser.py:23631+ / mammap_asm.py:18012, :18059-18060, :18237
+        A.look_span = narrow ? 2000 : 7000; A.read_span = narrow ? 500 : 7000;   // :23094, :23190
+        A.sort_by_start = narrow ? 1 : 0;
         A.queue = L.rorder.as<int32_t>(); A.order = L.rorder.as<int32_t>() + 1;
         A.head_stride = head_stride; A.head_pool = L.cnt.as<int32_t>(); A.next_pool = L.cur.as<int32_t>(); A.sq_pool = L.sq.as<int32_t>(); A.dst_pool = L.dst.as<int32_t>(); A.tpos_pool = nullptr; A.tpos_cap = tpos_cap;          // window positions are implied by the interval list (k_local_seed)
         VMX_TRY(L.hkey2.reserve(8 * (size_t)G * (size_t)hit_cap));
@@ -162,7 +163,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     const HostTables& T = host_tables();
     std::vector<double> gap(64, 0.0);
     for (int g = 1; g <= prm->local_maxdiff; ++g)
-        gap[g] = (g <= 10 || prm->mode == VM_MODE_R) ? (0.01 * k * g + 0.5 * T.log2int[g]) : (0.01 * k * g + 2 * T.log2int[g]);   // :27317-27322; _scar: 0.5*log2 throughout (mammap_noprefercloser.py:23432)
+        gap[g] = (g <= 10 || prm->mode == VM_MODE_R || prm->mode == VM_MODE_ASM) ? (0.01 * k * g + 0.5 * T.log2int[g]) : (0.01 * k * g + 2 * T.log2int[g]);   // :27317-27322; _scar: 0.5*log2 throughout (mammap_noprefercloser.py:23432)
     VMX_TRY(upload(L.gap, gap.data(), 64, c->stream));
     // LDS buckets by anchor count (24 B per anchor): a workgroup claims only what its read needs, so 4-12 reads share a CU.
     // Inside a bucket the reads are ordered longest first and every read is its own workgroup: the dispatcher hands them out in

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_SO = os.environ.get('VACMAPX_LIB') or os.path.join(_HERE, 'libvacmapx.so')     # VACMAPX_LIB: another build of the same library (tuning variants)
 
 VM_ERR_NO_DEVICE = -2
-MODES = {'H': 0, 'L': 1, 'S': 2, 'R': 3}
+MODES = {'H': 0, 'L': 1, 'S': 2, 'R': 3, 'asm': 4}
 
 
 class VmxError(RuntimeError):
