@@ -158,6 +158,22 @@ int vm_local_chain_batch(vm_ctx*, const vm_index*, const vm_params*, int64_t n, 
                          const int64_t* read_path_off, const int64_t* path_off, const int64_t* path_anchors, vm_local_out* out);
 void vm_local_out_free(vm_local_out*);
 
+/* One batch of -mode asm's LINKED chain DPs on the device (contigs of 500 kb and more, src/vacmap/mammap_asm.py:23228-23275 / :23328-23373):
+ * which = 0 linked GC-exact (:21686), 2 linked LC (:21504). rows: n x 4 int64, the n_pre anchors carried from the previous batch first, the
+ * new ones sorted by read position behind them; pre_S / pre_P, g_max_scores, g_max_index, prereadloc: the carried state (n_pre may be 0).
+ * out: S[n], P[n]; the HOT part of the score-sorted index S_arg (its last n_hot entries in the reference's order — the n_cold entries below can
+ * never be visited, k_chain_linked.hip); gmax (-1: GC-exact's bail-out); and what :23250-23272 carries into the next batch: carry_status 0
+ * with saved = 0 (`continue`: best chain ends in a carried or fresh anchor) or saved = 1 and carry_S / carry_P / carry_rows [n_carry], or
+ * a negative status when the device refuses (slice reaches the cold entries, bail-out) or the reference raises. */
+typedef struct vm_linked_out {
+    int64_t gmax, n_hot, n_cold, opcount; double cold_max;
+    double* S; int64_t* P; int64_t* S_arg_hot;
+    int32_t carry_status, saved; int64_t n_carry; double* carry_S; int64_t* carry_P; int64_t* carry_rows; double carry_g_max_scores; int64_t carry_prereadloc;
+} vm_linked_out;
+int vm_chain_linked(vm_ctx*, int which, int kmersize, double skipcost, int maxdiff, int maxgap, int64_t n, const int64_t* rows, int64_t n_pre,
+                    const double* pre_S, const int64_t* pre_P, double g_max_scores, int64_t g_max_index, int64_t prereadloc, vm_linked_out* out);
+void vm_linked_out_free(vm_linked_out*);
+
 /* `mp.k_cigar(target, query, match, mismatch, o1, e1, o2, e2, bw=-1, zdropvalue=-1, eqx)` (:21554): global dual-affine
  * alignment with traceback, n problems. t/q concatenated with offsets [n+1]. out: CIGAR strings concatenated
  * (NUL-separated) with cigar_off[n+1], scores[n] */

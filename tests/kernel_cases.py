@@ -780,3 +780,77 @@ def check_asm_decode_hit(ctx, O, cases=('AS1', 'AS4')):
                 assert bool(r['fast_used']) == (cid == 'AS4'), (cid, g['name'])
                 n += 1
     return n
+
+
+def check_asm_linked_golden(ctx, O, cases=('AS2', 'AS3'), max_calls=None):
+    """vm_chain_linked (k_chain_linked.hip) on the carried states the REFERENCE built (golden VL): S and P of every anchor bit-equal, the hot
+    part of the score index = the tail of the reference's S_arg, g_max_index equal; and the state the device carries into the next batch
+    (k_link_carry, mammap_asm.py:23250-23272) = the pre_S / pre_P / rows the reference fed to its NEXT linked call"""
+    meta, arr = asm_golden()
+    n_full = {0: 0, 2: 0}; n_carry = 0; n_cold = 0
+    for cid in cases:
+        for c in meta[cid]['contigs']:
+            calls = c['linked_calls']
+            for ei, e in enumerate(calls):
+                if 'key' not in e:
+                    continue
+                if max_calls is not None and n_full[e['which']] >= max_calls:
+                    continue
+                kk = e['key']
+                r = ctx.chain_linked(arr[kk + '_rows'], e['which'], int(e['kw']['kmersize']), e['kw']['skipcost'], int(e['kw']['maxdiff']), int(e['kw']['maxgap']),
+                                     e['g_max_scores'], e['g_max_index'], arr[kk + '_preS'], arr[kk + '_preP'], e['prereadloc'])
+                assert r['gmax'] == e['g'], (kk, r['gmax'], e['g'])
+                assert np.array_equal(r['S'].view(np.uint64), arr[kk + '_S'].view(np.uint64)), kk
+                assert np.array_equal(r['P'], arr[kk + '_P']), kk
+                sa = arr[kk + '_Sarg']
+                assert r['n_hot'] + r['n_cold'] == len(sa) and np.array_equal(r['S_arg_hot'], sa[len(sa) - r['n_hot']:]), (kk, 'hot index differs from the tail of S_arg')
+                n_full[e['which']] += 1; n_cold += r['n_cold']
+                # the next linked call of the same round was fed what the reference carried out of this one
+                nxt = calls[ei + 1] if ei + 1 < len(calls) and calls[ei + 1]['which'] == e['which'] else None
+                if nxt is not None and nxt['n_pre'] > 0 and 'key' in nxt:
+                    k2 = nxt['key']
+                    assert r['carry_status'] == 0 and r['saved'] == 1 and r['n_carry'] == nxt['n_pre'], (kk, r['carry_status'], r['saved'], r['n_carry'], nxt['n_pre'])
+                    assert np.array_equal(r['carry_S'].view(np.uint64), arr[k2 + '_preS'].view(np.uint64)) and np.array_equal(r['carry_P'], arr[k2 + '_preP'])
+                    assert np.array_equal(r['carry_rows'], arr[k2 + '_rows'][:nxt['n_pre']])
+                    assert r['carry_g_max_scores'] == nxt['g_max_scores'] and r['carry_prereadloc'] == nxt['prereadloc'] and r['n_carry'] - 1 == nxt['g_max_index']
+                    n_carry += 1
+    return n_full, n_carry, n_cold
+
+
+def check_asm_linked_noise(ctx, O, seed=5, noise_per_anchor=8, which=0, cid='AS3', contig=1):
+    """k_chain_linked on a linked batch of the goldens with `noise_per_anchor` isolated random anchors mixed in per true anchor (what
+    check_num = -1 gives on a human-size reference: every noise anchor hangs itself onto the best chain at the skip penalty). S / P of every
+    anchor, g_max_index, the stored tail of S_arg and the carried state must equal the oracle's (which keeps the whole index like the reference)"""
+    meta, arr = asm_golden()
+    c = meta[cid]['contigs'][contig]
+    e = [x for x in c['linked_calls'] if 'key' in x and x['which'] == which][0]
+    kk = e['key']
+    rows = arr[kk + '_rows']; n_pre = e['n_pre']
+    rng = np.random.default_rng(seed)
+    new = rows[n_pre:]
+    m = noise_per_anchor * len(new)
+    q = rng.integers(new[:, 0].min(), new[:, 0].max() + 1, m)
+    noise = np.stack([q, rng.integers(0, 3_000_000_000, m), rng.choice([-1, 1], m), np.full(m, 15 if which == 0 else 9)], axis=1).astype(np.int64)
+    allnew = np.concatenate([new, noise])
+    allnew = allnew[np.argsort(allnew[:, 0], kind='stable')]
+    linked = np.ascontiguousarray(np.concatenate([rows[:n_pre], allnew]))
+    kw = e['kw']
+    args = (int(kw['kmersize']), kw['skipcost'], int(kw['maxdiff']), int(kw['maxgap']), e['g_max_scores'], e['g_max_index'], arr[kk + '_preS'], arr[kk + '_preP'], e['prereadloc'])
+    g, S, P, SA = O.chain_linked_raw(linked, which, *args)
+    r = ctx.chain_linked(linked, which, *args)
+    assert r['gmax'] == g and np.array_equal(r['S'].view(np.uint64), S.view(np.uint64)) and np.array_equal(r['P'], P)
+    assert r['n_hot'] + r['n_cold'] == len(SA) and np.array_equal(r['S_arg_hot'], SA[len(SA) - r['n_hot']:])
+    # mammap_asm.py:23250-23272 on the oracle's arrays
+    if P[g] < 0:
+        assert r['carry_status'] == 0 and r['saved'] == 0
+    else:
+        low = S[SA[-1]] - kw['skipcost'] - 36 - 20
+        sl = len(S) - 1
+        while low < S[SA[sl]]:
+            sl -= 1
+            if sl == 0:
+                break
+        assert r['carry_status'] == 0 and r['saved'] == 1 and r['n_carry'] == len(S) - sl
+        assert np.array_equal(r['carry_S'].view(np.uint64), (S[SA[sl:]] - S[SA[sl]] + 1000).view(np.uint64)) and np.array_equal(r['carry_P'], -P[SA[sl:]])
+        assert np.array_equal(r['carry_rows'], linked[SA[sl:]]) and r['carry_prereadloc'] == linked[SA[sl:], 0].max()
+    return r['n_cold'], r['n_hot']

@@ -129,3 +129,10 @@ def test_emu_oom_degrades_to_sub_batches(ctx, oracle, golden, monkeypatch):
 def test_emu_mode_asm(ctx, oracle):
     """-mode asm, contigs below 500 kb (the fork's per-read function): records = the reference's goldens = the oracle's"""
     assert KC.check_asm_golden(ctx, oracle, cases=['AS1'], contigs=[3, 8, 9]) == 3       # 30 kb contig with an SV, unmappable, 900-base contig
+
+
+def test_emu_asm_linked(ctx, oracle):
+    """-mode asm's batch-linked chain DPs (k_chain_linked / k_link_carry): the reference's own carried states, then a batch with noise anchors"""
+    n_full, n_carry, _ = KC.check_asm_linked_golden(ctx, oracle, cases=['AS3'], max_calls=2)
+    assert n_full[0] == 2 and n_full[2] == 2 and n_carry >= 2
+    KC.check_asm_linked_noise(ctx, oracle, seed=5, noise_per_anchor=2, which=0)

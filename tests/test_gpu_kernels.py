@@ -329,3 +329,17 @@ def test_mode_asm(ctx, oracle):
     assert KC.check_asm_golden(ctx, oracle, cases=['AS1', 'AS4']) == 13
     assert KC.check_asm_golden(ctx, oracle, cases=['AS3'], vs_golden=False) == 3
     assert KC.check_asm_golden(ctx, oracle, cases=['AS2'], want_unsupported=('ctg600k',)) == 0
+
+
+def test_mode_asm_linked_dp(ctx, oracle):
+    """the batch-linked chain DPs of -mode asm on the device (contigs of 500 kb and more, mammap_asm.py:21686 / :21504 / :23250-23272): every
+    linked call the reference made in the goldens (600 kb contig with the reference's sizes, three contigs with shrunk sizes), the state carried
+    from one call into the next, and batches with 8 noise anchors per true anchor against the oracle"""
+    import time
+    n_full, n_carry, _ = KC.check_asm_linked_golden(ctx, oracle)
+    assert n_full[0] >= 4 and n_full[2] >= 6 and n_carry >= 5
+    t0 = time.time()
+    nc, nh = KC.check_asm_linked_noise(ctx, oracle, seed=5, noise_per_anchor=8, which=0)
+    print('linked GC-exact, %d anchors: %.2f s incl. the oracle' % (nc + nh, time.time() - t0))
+    KC.check_asm_linked_noise(ctx, oracle, seed=6, noise_per_anchor=3, which=2)
+    KC.check_asm_linked_noise(ctx, oracle, seed=7, noise_per_anchor=8, which=0, contig=0)

@@ -42,6 +42,13 @@ class ChainsOut(C.Structure):
                 ('S_arg', C.POINTER(C.c_int64)), ('gmax', C.POINTER(C.c_int64)), ('opcount', C.POINTER(C.c_int64))]
 
 
+class LinkedOut(C.Structure):
+    _fields_ = [('gmax', C.c_int64), ('n_hot', C.c_int64), ('n_cold', C.c_int64), ('opcount', C.c_int64), ('cold_max', C.c_double),
+                ('S', C.POINTER(C.c_double)), ('P', C.POINTER(C.c_int64)), ('S_arg_hot', C.POINTER(C.c_int64)),
+                ('carry_status', C.c_int32), ('saved', C.c_int32), ('n_carry', C.c_int64), ('carry_S', C.POINTER(C.c_double)),
+                ('carry_P', C.POINTER(C.c_int64)), ('carry_rows', C.POINTER(C.c_int64)), ('carry_g_max_scores', C.c_double), ('carry_prereadloc', C.c_int64)]
+
+
 class LocalOut(C.Structure):
     _fields_ = [('status', C.POINTER(C.c_int32)), ('variant', C.POINTER(C.c_int32)), ('score', C.POINTER(C.c_double)),
                 ('chain_off', C.POINTER(C.c_int64)), ('chain', C.POINTER(C.c_int64)), ('raw_off', C.POINTER(C.c_int64)),
@@ -127,6 +134,8 @@ class VmxLib:
         L.vm_k_cigar.argtypes = [vp, cp, i64, cp, i64, P(Score), C.c_int, C.c_int, C.c_int, P(CigarOut)]
         L.vm_k_cigar_batch_banded.argtypes = [vp, P(Score), C.c_int, i64, cp, vp, cp, vp, P(vp), P(P(i64)), P(P(i32)), vp]
         L.vm_chain_global_batch.argtypes = [vp, P(Params), C.c_int, i64, vp, vp, vp, C.c_int, P(ChainsOut)]
+        L.vm_chain_linked.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, i64, vp, i64, vp, vp, C.c_double, i64, i64, P(LinkedOut)]
+        L.vm_linked_out_free.argtypes = [P(LinkedOut)]
         L.vm_chains_out_free.argtypes = [P(ChainsOut)]
         L.vm_index_build_fasta.argtypes = [vp, cp, C.c_int, C.c_int, P(vp)]
         L.vm_index_build_mem.argtypes = [vp, C.c_int, P(cp), P(cp), P(i64), C.c_int, C.c_int, P(vp)]
@@ -340,6 +349,27 @@ class Context:
         rows = np.ctypeslib.as_array(a, shape=(max(n.value, 1), 4))[:n.value].copy()
         self.lib.L.vm_free(a)
         return rows
+
+    def chain_linked(self, rows, which, kmersize, skipcost, maxdiff, maxgap, g_max_scores=0., g_max_index=0, pre_S=None, pre_P=None, prereadloc=0):
+        """one batch of -mode asm's linked chain DPs (vm_chain_linked): dict(gmax, S, P, S_arg_hot, n_cold, cold_max, opcount, carry...)"""
+        a = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1, 4)
+        ps = np.ascontiguousarray(pre_S if pre_S is not None else [], dtype=np.float64)
+        pp = np.ascontiguousarray(pre_P if pre_P is not None else [], dtype=np.int64)
+        out = LinkedOut()
+        self.lib.check(self.lib.L.vm_chain_linked(self.h, which, kmersize, float(skipcost), int(maxdiff), int(maxgap), len(a), a.ctypes.data, len(ps), ps.ctypes.data,
+                                                  pp.ctypes.data, float(g_max_scores), int(g_max_index), int(prereadloc), C.byref(out)))
+        n = len(a)
+        r = {'gmax': out.gmax, 'n_hot': out.n_hot, 'n_cold': out.n_cold, 'cold_max': out.cold_max, 'opcount': out.opcount,
+             'S': np.ctypeslib.as_array(out.S, shape=(n,)).copy(), 'P': np.ctypeslib.as_array(out.P, shape=(n,)).copy(),
+             'S_arg_hot': np.ctypeslib.as_array(out.S_arg_hot, shape=(max(out.n_hot, 1),))[:out.n_hot].copy(),
+             'carry_status': out.carry_status, 'saved': out.saved, 'n_carry': out.n_carry}
+        if out.carry_status == 0 and out.saved:
+            m = out.n_carry
+            r.update(carry_S=np.ctypeslib.as_array(out.carry_S, shape=(m,)).copy(), carry_P=np.ctypeslib.as_array(out.carry_P, shape=(m,)).copy(),
+                     carry_rows=np.ctypeslib.as_array(out.carry_rows, shape=(m, 4)).copy(), carry_g_max_scores=out.carry_g_max_scores,
+                     carry_prereadloc=out.carry_prereadloc)
+        self.lib.L.vm_linked_out_free(C.byref(out))
+        return r
 
     def map_batch(self, index, seqs, check_num=100, mid_occ=-1):
         s, off = _cat(seqs)
