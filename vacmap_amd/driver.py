@@ -13,7 +13,8 @@ text with `-t` host threads (vm_sam_emit, the C++ twin of vacmap_amd/sam.py) whi
 in input order. Like the reference's worker (:24116-24134) a read whose path or whose emission raises is skipped, and a read without
 records produces no line.
 With N ranks, rank 0 builds the index and broadcasts it over RCCL (vacmap_amd/dist.py), batch i of a window goes to rank i mod N, and
-rank 0 gathers and writes the lines. `-mode asm` is not provided.
+rank 0 gathers and writes the lines. `-mode asm` is not provided by this driver (its SAM emitters are a fork of their own,
+mammap_asm.py:22757; the mode itself is reachable through the C-ABI: VM_MODE_ASM, include/vacmapx.h).
 """
 import argparse, gzip, os, shutil, struct, subprocess, sys, threading, time, queue
 
