@@ -32,15 +32,14 @@ typedef enum vm_status {
     VM_READ_RAISED = -10,       /* the reference's Python would have raised inside the per-read path */
     VM_READ_CAPACITY = -20,     /* a device work buffer overflowed for this read (reported, never silently truncated) */
     VM_READ_FASTPATH = -21,     /* internal hand-off to the `_fast` chain kernels (:23570, :24914, :27380); never returned by vm_align_batch */
-    VM_READ_UNSUPPORTED = -22   /* -mode asm only: a contig of 500 000 bases or more, or one whose equal-score chains need the edlib tie-break of
-                                   mammap_asm.py:21302-21326 (MAPQ 0): reported, not approximated */
+    VM_READ_UNSUPPORTED = -22   /* -mode asm only: a contig whose equal-score chains need the edlib tie-break of mammap_asm.py:21302-21326 (MAPQ 0),
+                                   or a long contig whose GC-exact bails out into the fork's linked GC-fast (:23246): reported, not approximated */
 } vm_status;
 
 enum { VM_MODE_H = 0, VM_MODE_L = 1, VM_MODE_S = 2, VM_MODE_R = 3,   /* -mode (src/vacmap/vacmap:87) */
-       /* -mode asm runs src/vacmap/mammap_asm.py, an older fork of the path. Through vm_align_batch every "read" is an assembly contig and takes
-        * that module's per-read function (get_readmap_DP_test :19681, check_num = -1) — the reference's route for contigs below 500 000 bases
-        * (assembly_get_readmap_DP_test :23205). Longer contigs (the batch-linked chain DPs, :23208-23422) are not built on the device yet:
-        * they come back as VM_READ_UNSUPPORTED, never through another route. */
+       /* -mode asm runs src/vacmap/mammap_asm.py, an older fork of the path. Every "read" of vm_align_batch is then an assembly contig and takes
+        * the route of assembly_get_readmap_DP_test (:23204): below 500 000 bases that module's per-read function (:19681, check_num = -1), in one
+        * batch with the others; from 500 000 bases on the batch-linked path, contig by contig (vm_align_asm). */
        VM_MODE_ASM = 4 };
 
 /* option dict `pdict` of the reference driver (src/vacmap/vacmap:177-296) as one POD */
@@ -252,6 +251,16 @@ int vm_reads_upload(vm_ctx*, int64_t n_reads, const char* seqs, const int64_t* o
 void vm_reads_free(vm_reads*);
 int vm_align_resident(vm_ctx*, const vm_index*, const vm_params*, const vm_reads*, vm_record** recs, int64_t* n_recs,
                       char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats);
+
+/* -mode asm on ONE assembly contig, the route of assembly_get_readmap_DP_test (mammap_asm.py:23204): below split_len bases the fork's per-read
+ * function (= vm_align_batch with VM_MODE_ASM), otherwise 100 kb seeding windows, chain DPs linked across batches of more than batch_anchors
+ * anchors, the second linked round over 9-mer anchors, ass_extend_func. split_len / batch_anchors / window <= 0: the reference's 500000 / 500000 /
+ * 100000 (tests shrink them to reach the linked path on small inputs; split_len may only be lowered). p->mode must be VM_MODE_ASM. *status: 0,
+ * VM_READ_RAISED, VM_READ_CAPACITY or VM_READ_UNSUPPORTED (GC-exact's bail-out into the linked GC-fast, a carried slice outside the stored
+ * index; include/vacmapx.h VM_MODE_ASM). The host runs the reference's loop (batch assembly, tracebacks, cut points); seeding, chain DPs,
+ * re-seeding and extension run on the device. */
+int vm_align_asm(vm_ctx*, const vm_index*, const vm_params* p, const char* contig, int64_t len, int64_t split_len, int64_t batch_anchors, int64_t window,
+                 vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status);
 
 /* Diagnostic for the stage tests of the extend phase (E1 / E3 / E4): runs vm_align_batch's path and returns every read's segment lists
  * as they stand, in the first (filtering) run of extend_func (:19238), after

@@ -140,6 +140,10 @@ int vmo_align_batch(const vmo_index*, const vmo_params* p, int64_t n_reads, cons
  * run that made the goldens was patched to the same numbers). status as vmo_align_read. */
 int vmo_align_asm(const vmo_index*, const char* contig, int64_t len, const vmo_params* p, int64_t split_len, int64_t batch_anchors,
                   int64_t window, vmo_record** recs, int64_t* n_recs, char** cigar_blob);
+/* stages of the long-contig path for the tests of the device's loop: which = 1 first-round path (descending read order), 2 the chain handed to
+ * ass_extend_func (ascending, read overlaps trimmed), 3 the second-round anchor batches (rows concatenated, off[n_off] batch ends) */
+int vmo_asm_trace(const vmo_index*, const char* contig, int64_t len, const vmo_params* p, int64_t split_len, int64_t batch_anchors, int64_t window,
+                  int which, int64_t** rows, int64_t* n_rows, int64_t** off, int64_t* n_off);
 /* decode_hit of the fork (:21280; seeds the contig itself with p->check_num): MAPQ, signed score, the primary path */
 int vmo_decode_hit_asm(const vmo_index*, const char* contig, int64_t len, const vmo_params* p, vmo_chains* out);
 /* stage entry of the linked chain DPs (:21686 GC-exact, :21871 GC-fast, :21504 LC): which = 0 / 1 / 2. anchors sorted by q (rows of the

@@ -185,6 +185,12 @@ static int align_small(const vmo_index* mi, std::string read, const vmo_params& 
     return 0;
 }
 
+// stage capture for the tests of the device's long-contig loop: 1 = first-round path (descending read order), 2 = the chain handed to
+// ass_extend_func (ascending, overlaps trimmed), 3 = the second-round anchor batches (rows, batch after batch)
+thread_local int g_trace_which = 0;
+thread_local std::vector<Anchor>* g_trace_rows = nullptr;
+thread_local std::vector<int64_t>* g_trace_off = nullptr;
+
 struct SavedBatch { std::vector<Anchor> rows; std::vector<int64_t> P; };
 
 // the body shared by the two rounds of assembly_get_readmap_DP_test (:23228-23275 / :23328-23373): link, chain, carry, "save"
@@ -302,6 +308,7 @@ int align_asm(const vmo_index* mi, const std::string& contig_in, const vmo_param
     Path path;
     int rcode = r1.traceback(r1.pre_g_max_index, path);
     if (rcode < 0) return rcode;
+    if (g_trace_which == 1 && g_trace_rows) *g_trace_rows = path;
     if (path.size() <= 1) return 0;
     // ---- second round :23309-23396
     const int k2 = prm.local_kmersize;
@@ -316,6 +323,7 @@ int align_asm(const vmo_index* mi, const std::string& contig_in, const vmo_param
             local_seed_one(mi, seq, guide, k2, 2000, 500, out, st_read, en_read);
             if (out.empty()) return -16;                               // np.array([])[:, 0] (:22755)
             std::stable_sort(out.begin(), out.end(), [](const Anchor& a, const Anchor& b) { return a.q < b.q; });
+            if (g_trace_which == 3 && g_trace_rows) { g_trace_rows->insert(g_trace_rows->end(), out.begin(), out.end()); g_trace_off->push_back((int64_t)g_trace_rows->size()); }
             return r2.feed(out);
         };
         // yield_second_mapinfo :22444-22476
@@ -355,6 +363,7 @@ int align_asm(const vmo_index* mi, const std::string& contig_in, const vmo_param
         }
     }
     Path asc(path2.rbegin(), path2.rend());
+    if (g_trace_which == 2 && g_trace_rows) *g_trace_rows = asc;
     rcode = ass_extend_func(mi, seq, rc, asc, prm, recs);
     if (rcode < 0) { recs.clear(); return rcode; }
     return 0;
@@ -383,6 +392,22 @@ int vmo_align_asm(const vmo_index* mi, const char* contig, int64_t len, const vm
         memcpy(*blob + bo, r[i].cigar.c_str(), r[i].cigar.size() + 1); bo += r[i].cigar.size() + 1;
     }
     *n_recs = (int64_t)r.size();
+    return rc;
+}
+
+int vmo_asm_trace(const vmo_index* mi, const char* contig, int64_t len, const vmo_params* p, int64_t split_len, int64_t batch_anchors, int64_t window,
+                  int which, int64_t** rows, int64_t* n_rows, int64_t** off, int64_t* n_off) {
+    std::vector<Anchor> tr; std::vector<int64_t> to(1, 0);
+    g_trace_which = which; g_trace_rows = &tr; g_trace_off = &to;
+    std::vector<Record> r;
+    const int rc = align_asm(mi, std::string(contig, (size_t)len), *p, split_len, batch_anchors, window, r);
+    g_trace_which = 0; g_trace_rows = nullptr; g_trace_off = nullptr;
+    *rows = (int64_t*)malloc(32 * (tr.size() ? tr.size() : 1));
+    for (size_t i = 0; i < tr.size(); ++i) { (*rows)[4 * i] = tr[i].q; (*rows)[4 * i + 1] = tr[i].r; (*rows)[4 * i + 2] = tr[i].s; (*rows)[4 * i + 3] = tr[i].l; }
+    *n_rows = (int64_t)tr.size();
+    *off = (int64_t*)malloc(8 * to.size());
+    for (size_t i = 0; i < to.size(); ++i) (*off)[i] = to[i];
+    *n_off = (int64_t)to.size();
     return rc;
 }
 

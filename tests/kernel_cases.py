@@ -854,3 +854,29 @@ def check_asm_linked_noise(ctx, O, seed=5, noise_per_anchor=8, which=0, cid='AS3
         assert np.array_equal(r['carry_S'].view(np.uint64), (S[SA[sl:]] - S[SA[sl]] + 1000).view(np.uint64)) and np.array_equal(r['carry_P'], -P[SA[sl:]])
         assert np.array_equal(r['carry_rows'], linked[SA[sl:]]) and r['carry_prereadloc'] == linked[SA[sl:], 0].max()
     return r['n_cold'], r['n_hot']
+
+
+def check_asm_long_golden(ctx, O, cid='AS3', contigs=None, vs_golden=True):
+    """vm_align_asm on contigs that take the LINKED path (assembly_get_readmap_DP_test :23208-23422) with the sizes the goldens were made with:
+    records = the reference's (golden V6a) = the oracle's run live"""
+    import zlib
+    from vacmap_amd.lib import align_asm
+    meta, arr = asm_golden()
+    c = meta[cid]
+    gi, oi = _asm_index(ctx, O, meta, arr, cid)
+    prm = ctx.lib.params('asm'); oprm = O.params('asm')
+    sizes = c['sizes']
+    n_ok = 0
+    for ci, g in enumerate(c['contigs']):
+        if contigs is not None and ci not in contigs:
+            continue
+        seq = arr['%s_c%d_seq' % (cid, ci)].tobytes().decode()
+        st, recs = align_asm(ctx, gi, prm, seq, *sizes)
+        ost, orecs = O.align_asm(oi, seq, oprm, *sizes)
+        assert (st == 0) == (ost == 0), (cid, g['name'], st, ost)
+        assert [t[1:] for t in recs] == [t[1:] for t in orecs], (cid, g['name'], 'records differ from the oracle')
+        if vs_golden:
+            got = [[c['names'][t[1]], t[2], t[3], t[4], t[5], t[6], t[7], len(t[8]), zlib.crc32(t[8].encode())] + ([t[8]] if len(t[8]) <= 4096 else []) for t in recs]
+            assert (st == 0) == (g['status'] == 0) and got == g['records'], (cid, g['name'], 'records differ from the reference golden')
+        n_ok += 1
+    return n_ok

@@ -80,6 +80,7 @@ def lib():
     L.vmo_align_read.argtypes = [vp, cp, i64, P(Params), P(P(Record)), P(i64), P(vp)]
     L.vmo_align_batch.argtypes = [vp, P(Params), i64, cp, vp, C.c_int, P(P(Record)), P(i64), P(vp), vp]
     L.vmo_align_asm.argtypes = [vp, cp, i64, P(Params), i64, i64, i64, P(P(Record)), P(i64), P(vp)]
+    L.vmo_asm_trace.argtypes = [vp, cp, i64, P(Params), i64, i64, i64, C.c_int, P(P(i64)), P(i64), P(P(i64)), P(i64)]
     L.vmo_decode_hit_asm.argtypes = [vp, cp, i64, P(Params), P(Chains)]
     L.vmo_chain_linked_raw.argtypes = [vp, i64, C.c_int, C.c_int, dbl, C.c_int, C.c_int, dbl, i64, vp, vp, i64, i64, vp, vp, vp]
     L.vmo_chain_linked_raw.restype = i64
@@ -285,6 +286,17 @@ def align_asm(index, contig, prm, split_len=0, batch_anchors=0, window=0):
     recs = C.POINTER(Record)(); n = C.c_int64(); blob = C.c_void_p()
     rc = lib().vmo_align_asm(index.h, rd, len(rd), C.byref(prm), split_len, batch_anchors, window, C.byref(recs), C.byref(n), C.byref(blob))
     return rc, _take_records(recs, n.value, blob)
+
+
+def asm_trace(index, contig, prm, which, split_len=0, batch_anchors=0, window=0):
+    """stages of the long-contig asm path (vmo_asm_trace): (rc, rows (n,4), batch ends)"""
+    rd = _b(contig)
+    rows = C.POINTER(C.c_int64)(); n = C.c_int64(); off = C.POINTER(C.c_int64)(); no = C.c_int64()
+    rc = lib().vmo_asm_trace(index.h, rd, len(rd), C.byref(prm), split_len, batch_anchors, window, which, C.byref(rows), C.byref(n), C.byref(off), C.byref(no))
+    a = np.ctypeslib.as_array(rows, shape=(max(n.value, 1), 4))[:n.value].copy()
+    o = np.ctypeslib.as_array(off, shape=(no.value,)).copy()
+    lib().vmo_free(rows); lib().vmo_free(off)
+    return rc, a, o
 
 
 def decode_hit_asm(index, contig, prm):

@@ -136,3 +136,8 @@ def test_emu_asm_linked(ctx, oracle):
     n_full, n_carry, _ = KC.check_asm_linked_golden(ctx, oracle, cases=['AS3'], max_calls=2)
     assert n_full[0] == 2 and n_full[2] == 2 and n_carry >= 2
     KC.check_asm_linked_noise(ctx, oracle, seed=5, noise_per_anchor=2, which=0)
+
+
+def test_emu_mode_asm_long_contig(ctx, oracle):
+    """the long-contig loop of -mode asm (vm_align_asm) with shrunk sizes: linked first round, re-seeded second round, ass_extend_func"""
+    assert KC.check_asm_long_golden(ctx, oracle, 'AS3', contigs=[2]) == 1

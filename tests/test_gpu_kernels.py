@@ -324,11 +324,19 @@ def test_ragged_and_extreme_batches(ctx, oracle):
 def test_mode_asm(ctx, oracle):
     """-mode asm (mammap_asm.py) through vm_align_batch: assembly contigs below 500 kb take the fork's per-read function on the device —
     records = the reference's goldens (AS1: SVs, both strands, a chimera, an unmappable and a 900-base contig; AS4: repeat-dense contigs through
-    the fork's GC-fast) = the oracle's; 120 - 250 kb contigs (AS3) against the oracle run live; the 600 kb contig (AS2) is refused loudly"""
+    the fork's GC-fast) = the oracle's; 120 - 250 kb contigs (AS3) against the oracle run live; the 600 kb contig (AS2) takes the batch-linked path"""
     assert KC.check_asm_decode_hit(ctx, oracle) >= 12
     assert KC.check_asm_golden(ctx, oracle, cases=['AS1', 'AS4']) == 13
     assert KC.check_asm_golden(ctx, oracle, cases=['AS3'], vs_golden=False) == 3
-    assert KC.check_asm_golden(ctx, oracle, cases=['AS2'], want_unsupported=('ctg600k',)) == 0
+    assert KC.check_asm_golden(ctx, oracle, cases=['AS2']) == 1       # the 600 kb contig: vm_align_batch hands it to the batch-linked path
+
+
+def test_mode_asm_long_contigs(ctx, oracle):
+    """contigs of 500 kb and more (assembly_get_readmap_DP_test, mammap_asm.py:23208-23422: seeding windows, linked chain DPs, traceback, second
+    linked round over re-seeded 9-mer anchors, ass_extend_func) through vm_align_asm: the 600 kb contig with the reference's sizes and three
+    contigs with the shrunk sizes their goldens were made with (5-7 linked first-round batches each) — records = reference goldens = oracle"""
+    assert KC.check_asm_long_golden(ctx, oracle, 'AS3') == 3
+    assert KC.check_asm_long_golden(ctx, oracle, 'AS2') == 1
 
 
 def test_mode_asm_linked_dp(ctx, oracle):

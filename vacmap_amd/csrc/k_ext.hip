@@ -57,9 +57,10 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
     int32_t* segprob = A.seg_prob + A.soff[r];
     const bool nofilter = A.nodiscard || E.pass == 1;
     if (phase == 0) {
-        int rc = vmx_rebuild_chain_break(A.chain + A.la_off[r], cl, R, A.local_maxdiff, A.mode == 4 ? 40 : 50, S, A.mode == 4);     // small_alignment 40 in the asm fork (mammap_asm.py:22321)
+        int rc = vmx_rebuild_chain_break(A.chain + A.la_off[r], cl, R, A.local_maxdiff, A.asm_long ? 30 : (A.mode == 4 ? 40 : 50), S, A.mode == 4);     // small_alignment 40 in the asm fork (mammap_asm.py:22321), 30 in ass_extend_func (:23426)
         if (rc < 0) { E.status = rc; return; }
         E.nseg = S.nseg;
+        if (A.asm_long) { E.prob_base = 0; E.prob_n = 0; return; }                  // ass_extend_func has no divergence filter
         int b = vmx_alloc_probs(A, S.nseg);
         if (b < 0) { E.status = VM_READ_CAPACITY_DEV; return; }
         E.prob_base = b; E.prob_n = S.nseg;
@@ -69,7 +70,7 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
         }
         return;
     }
-    if (phase == 1) {
+    if (phase == 1 && !A.asm_long) {
         // divergence filter :19246-19254
         int b = E.prob_base; int w = 0;
         const int n0 = S.nseg;
@@ -309,6 +310,9 @@ __global__ void __launch_bounds__(64) k_ext_records(vmx_ext_args A, const vmx_dp
                 const char last = BLOB[w - 1];
                 int j = 0; long long num2 = 0;
                 while (j < n && src[j] >= '0' && src[j] <= '9') { num2 = num2 * 10 + (src[j] - '0'); ++j; }
+#ifdef VMX_EMU
+                if (getenv("VMX_DBG_LINK") && lane == 0) fprintf(stderr, "[link] seg %d piece %d/%d n %d last %c first %c num2 %lld\n", s, x, np, n, last, j < n ? src[j] : '?', num2);
+#endif
                 if (j < n && src[j] == last) {
                     long long i = w - 1, num1 = 0, factor = 1; bool brk = false;
                     while (i > wc0) { --i; const char ch = BLOB[i]; if (ch >= '0' && ch <= '9') { num1 += (long long)(ch - '0') * factor; factor *= 10; } else { brk = true; break; } }

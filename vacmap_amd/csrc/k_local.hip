@@ -151,12 +151,12 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
         const int r = A.order[qi];
         const int ng = A.n_guides_used[r];
         const int64_t a0 = A.aoff[r];
-        const uint8_t* RD = A.ocodes + A.roff[r];
-        const int L = (int)(A.roff[r + 1] - A.roff[r]);
+        const uint8_t* RD = A.ocodes + (A.rd_off ? A.rd_off[r] : A.roff[r]);
+        const int L = A.rd_off ? (int)A.rd_len[r] : (int)(A.roff[r + 1] - A.roff[r]);
         vmx_anchor* OUT = A.la_rows + A.la_off[r];
         uint64_t* OKEY = A.la_ekey + A.la_off[r];
         vmx_anchor* SORTED = A.la_sorted + A.la_off[r];
-        const int out_cap = (int)(A.la_slot_len * VMX_LA_SLOT((int64_t)L));     // slot of this read in the local-anchor pools
+        const int out_cap = A.rd_off ? (int)(A.la_off[r + 1] - A.la_off[r]) : (int)(A.la_slot_len * VMX_LA_SLOT((int64_t)L));     // slot of this read in the local-anchor pools
         int n_out = 0;
         int status = 0;
         int gbase = 0;
@@ -256,6 +256,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             if (mm > 0) {
                 readstart = GQ[0] - A.read_span; if (readstart < 0) readstart = 0;
                 readend = GQ[mm - 1] + A.read_span; if (readend > L - k + 1) readend = L - k + 1;
+                if (A.r_st) { readstart = A.r_st[r]; readend = A.r_en[r] - k; }          // :22580, :22589
             }
             int npos = (status == 0 && readend > readstart) ? readend - readstart : 0;
             if (npos > A.pcnt_cap) { status = VM_READ_CAPACITY_DEV; npos = 0; }

@@ -177,9 +177,13 @@ static int ext_gather_round(vm_ctx* c, vmx_batch_bufs& B, const vm_index_view& i
 // diagnostic capture for the stage tests (vm_align_trace): the segment lists of every read as they stand after one phase of the
 // extend stage in the first (filtering) pass: rows (segment, q, r, s, l), off[n + 1]
 struct vmx_seg_trace { int stage; std::vector<int64_t> rows, off; };
+int vmx_align_batch_asm_mixed(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const char* seqs, const int64_t* offsets, vm_record** recs, int64_t* n_recs,
+                              char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats);
+int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
+                 vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats, vmx_seg_trace* trace = nullptr, const vmx_preset* preset = nullptr);
 
-static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
-                        vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats, vmx_seg_trace* trace = nullptr) {
+int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
+                        vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats, vmx_seg_trace* trace, const vmx_preset* preset) {
     *recs = nullptr; *n_recs = 0; *cigar_blob = nullptr;
     vmx_batch_bufs& B = *batch_bufs(c);
     vm_index_view ix; vmx_index_view(mi, &ix);
@@ -191,6 +195,12 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));
     if (n == 0) { *recs = (vm_record*)malloc(sizeof(vm_record)); *cigar_blob = (char*)malloc(1); if (stats) *stats = st; return VM_OK; }
 
+    std::vector<int64_t> h_aoff((size_t)n + 1, 0);
+    const int rmode = prm->mode == VM_MODE_R ? 1 : (prm->mode == VM_MODE_ASM ? 2 : 0);      // the GC kernels' variant: H / L / S, R, the asm fork
+    double* d_gscore = nullptr; int32_t* d_mapq = nullptr; int32_t* d_np = nullptr;
+    vmx_local_bufs& L = *vmx_ctx_local_bufs(c);
+    // the stages in front of the extension: seed, global chain, local chain
+    auto front = [&]() -> int {
     // ---------------- S1 seed
     std::vector<int64_t> h_koff, h_nhits;
     VMX_TRY(vmx_seed_stage(c, mi, prm->check_num, prm->mid_occ, n, d_codes, d_roff, total_bases, B.seed, h_koff, h_nhits));
@@ -200,7 +210,6 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     VMX_TRY(B.nanc64.reserve(8 * (size_t)(n + 2))); VMX_TRY(B.aoff.reserve(8 * (size_t)(n + 2)));
     LAUNCH1D(k_i32_to_i64, n, B.seed[11].as<int32_t>(), B.nanc64.as<int64_t>(), n);
     hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, B.nanc64.as<int64_t>(), B.aoff.as<int64_t>(), n, 0);
-    std::vector<int64_t> h_aoff((size_t)n + 1);
     VMX_TRY(download(h_aoff.data(), B.aoff.p, (size_t)n + 1, c->stream));
     VMX_HIP(vmx_stream_sync(c));
     const int64_t tot = h_aoff[n];
@@ -233,7 +242,6 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
         for (int g = 1; g <= prm->global_maxdiff; ++g) gap[g] = (0.01 * ix.k * g + 0.5 * T.log2int[g]);
         VMX_TRY(upload(B.gap, gap.data(), 64, c->stream));
     }
-    const int rmode = prm->mode == VM_MODE_R ? 1 : (prm->mode == VM_MODE_ASM ? 2 : 0);      // the GC kernels' variant: H / L / S, R, the asm fork
     if (rmode == 1) { VMX_TRY(B.fp.reserve(8 * (size_t)(tot + 1))); VMX_TRY(B.pp.reserve(8 * (size_t)(tot + 1))); }   // fixed_penatly / pre_penatly of mode R's chain
     // LDS buckets by anchor count (25 B per anchor), reads longest-first inside a bucket, one workgroup per read (see vmx_local_stage)
     constexpr int NB = 10;
@@ -280,7 +288,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     }
     VMX_TRY(B.scr.reserve((size_t)stt + 64)); VMX_TRY(upload(B.soff, soff.data(), (size_t)n + 1, c->stream));
     VMX_TRY(B.res.reserve(16 * (size_t)(n + 2) + 64));
-    double* d_gscore = B.res.as<double>(); int32_t* d_mapq = (int32_t*)(d_gscore + n + 1); int32_t* d_np = d_mapq + n + 1;
+    d_gscore = B.res.as<double>(); d_mapq = (int32_t*)(d_gscore + n + 1); d_np = d_mapq + n + 1;
     VMX_TRY(B.plen.reserve(4 * (size_t)(tot + 1))); VMX_TRY(B.prow.reserve(sizeof(vmx_anchor) * (size_t)(tot + 1)));
     VMX_TRY(vmx_launch_chain_select(c, n, h_aoff.data(), B.sellist, B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(), B.lens.as<int64_t>(), B.S.as<double>(), B.P.as<int32_t>(), B.SA.as<int32_t>(),
                                     B.gmax.as<int64_t>(), B.flip.as<int32_t>(), prm->mode, B.scr.as<char>(), B.soff.as<int64_t>(), d_mapq, d_gscore, d_np, B.plen.as<int32_t>(), B.prow.as<vmx_anchor>()));
@@ -289,10 +297,35 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     // ---------------- orient + L1-L4 local stage
     VMX_TRY(B.ocodes.reserve((size_t)total_bases + 64));
     hipLaunchKernelGGL(k_orient, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, d_codes, d_roff, d_gscore, (int)n, B.ocodes.as<uint8_t>());
-    vmx_local_bufs& L = *vmx_ctx_local_bufs(c);
     VMX_TRY(vmx_local_stage(c, ix, prm, n, B.ocodes.as<uint8_t>(), d_roff, h_roff, B.prow.as<vmx_anchor>(), B.plen.as<int32_t>(), d_np, B.aoff.as<int64_t>(), h_aoff, d_gscore, L));
     for (int64_t r = 0; r < n; ++r) st.n_local_anchors += L.h_la_cnt[r];
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));
+
+    return 0;
+    };
+    // -mode asm, contig of 500 kb and more (vmx_asm.hip): the chain comes from the linked DPs; the extend stage below runs on it as
+    // ass_extend_func does (mammap_asm.py:23423-23460): forward orientation, MAPQ 60
+    auto front_preset = [&]() -> int {
+        if (n != 1 || preset->len < 2) { set_error("preset chain: one contig with a chain of two anchors or more"); return VM_ERR_ARG; }
+        VMX_TRY(B.ocodes.reserve((size_t)total_bases + 64));
+        VMX_HIP(hipMemcpyAsync(B.ocodes.p, d_codes, (size_t)total_bases, hipMemcpyDeviceToDevice, c->stream));
+        VMX_TRY(B.res.reserve(16 * (size_t)(n + 2) + 64));
+        d_gscore = B.res.as<double>(); d_mapq = (int32_t*)(d_gscore + n + 1); d_np = d_mapq + n + 1;
+        const double gs = 1.0; const int32_t mq = 60, one = 1, zero = 0, len32 = (int32_t)preset->len;
+        VMX_HIP(hipMemcpyAsync(d_gscore, &gs, 8, hipMemcpyHostToDevice, c->stream)); VMX_HIP(hipMemcpyAsync(d_mapq, &mq, 4, hipMemcpyHostToDevice, c->stream));
+        VMX_HIP(hipMemcpyAsync(d_np, &one, 4, hipMemcpyHostToDevice, c->stream));
+        VMX_TRY(B.gmax.reserve(8 * (size_t)(n + 1))); VMX_HIP(hipMemsetAsync(B.gmax.p, 0, 8 * (size_t)n, c->stream));
+        h_aoff[0] = 0; h_aoff[1] = 3;
+        L.h_la_off.assign(2, 0); L.h_la_off[1] = preset->len; L.h_la_cnt.assign(1, len32);
+        VMX_TRY(upload(L.la_off, L.h_la_off.data(), 2, c->stream));
+        VMX_TRY(upload(L.chain, preset->chain_desc, (size_t)preset->len, c->stream));
+        VMX_TRY(L.chain_len.reserve(8)); VMX_HIP(hipMemcpyAsync(L.chain_len.p, &len32, 4, hipMemcpyHostToDevice, c->stream));
+        VMX_TRY(L.status.reserve(8)); VMX_HIP(hipMemcpyAsync(L.status.p, &zero, 4, hipMemcpyHostToDevice, c->stream));
+        VMX_HIP(vmx_stream_sync(c));                              // the small host values above are on their way
+        for (int e = 0; e < 3; ++e) VMX_HIP(hipEventRecord(ev[nev++], c->stream));
+        return 0;
+    };
+    { const int rcf = preset ? front_preset() : front(); if (rcf < 0) return rcf; }
 
     // ---------------- E1-E6 extend stage
     // per-read pool geometry from the local anchor count (the chain is never longer than that)
@@ -324,7 +357,7 @@ static int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int
     VMX_HIP(hipMemsetAsync(B.oflow.p, 0, 4, c->stream));
     VMX_TRY(B.statblk.reserve(1024)); VMX_HIP(hipMemsetAsync(B.statblk.p, 0, 1024, c->stream));     // [0..7] i32 round counts | i64 [16..21] gap-fill totals | i64 [32..45] final scalars
     vmx_ext_args A; memset(&A, 0, sizeof A);
-    A.n_reads = (int)n; A.nseq = ix.nseq; A.local_maxdiff = prm->local_maxdiff; A.nodiscard = prm->nodiscard; A.hardclip = prm->hardclip; A.redo_only = 0; A.mode = prm->mode; A.maxdivergence = prm->maxdivergence;
+    A.n_reads = (int)n; A.nseq = ix.nseq; A.local_maxdiff = preset ? 50 : prm->local_maxdiff /* ass_extend_func: large_cost 50, mammap_asm.py:23426 */; A.asm_long = preset ? 1 : 0; A.nodiscard = prm->nodiscard; A.hardclip = prm->hardclip; A.redo_only = 0; A.mode = prm->mode; A.maxdivergence = prm->maxdivergence;
     A.ocodes = B.ocodes.as<uint8_t>(); A.roff = d_roff; A.ref = ix.codes; A.coff = ix.coff;
     A.chain = L.chain.as<vmx_anchor>(); A.chain_len = L.chain_len.as<int32_t>(); A.la_off = L.la_off.as<int64_t>(); A.lstatus = L.status.as<int32_t>();
     A.gscore = d_gscore; A.mapq = d_mapq; A.er = B.er.as<vmx_ext_read>(); A.coff3 = B.coff3.as<int64_t>(); A.soff = B.soff2.as<int64_t>();
@@ -653,6 +686,9 @@ int vm_align_batch(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t 
                    char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats) {
     if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
     VMX_HIP(hipSetDevice(c->device));
+    if (prm->mode == VM_MODE_ASM)        // contigs of 500 kb and more take the linked path (vmx_asm.hip), one by one
+        for (int64_t r = 0; r < n; ++r)
+            if (offsets[r + 1] - offsets[r] >= 500000) return vmx_align_batch_asm_mixed(c, mi, prm, n, seqs, offsets, recs, n_recs, cigar_blob, status_per_read, stats);
     static const int64_t max_bases = [] { const char* e = getenv("VMX_MAX_BATCH_BASES"); const long long v = e ? atoll(e) : 0; return v > 0 ? (int64_t)v : (int64_t)VMX_MAX_BATCH_BASES; }();
     // test hook: pretend the device is out of memory for any sub-batch above this many bases (exercises the degradation below)
     const char* oom_env = getenv("VMX_TEST_OOM_ABOVE_BASES");

@@ -90,3 +90,378 @@ extern "C" int vm_chain_linked(vm_ctx* c, int which, int kmersize, double skipco
     }
     return VM_OK;
 }
+
+// ================================================================================================ contigs of 500 kb and more
+// assembly_get_readmap_DP_test (mammap_asm.py:23204-23422). The host runs the reference's LOOP — which windows form a batch (yield_mapinfo
+// :22411), the traceback over the saved batches (:23277-23292), where the second round is cut (yield_second_mapinfo :22444), the overlap trim
+// (:23400-23412) — and the device does the work inside it: seeding of the 100 kb windows (vm_map_batch, check_num = -1), the linked chain DPs
+// and the state carried between batches (k_chain_linked / k_link_carry), the second-round 9-mer re-seeding (k_local_seed over a given read
+// range = collect_second_round_anchors :22477), and ass_extend_func through the extend stage of vm_align_batch on the resulting chain.
+// The reference spills every batch's (anchors, P) to <workdir>/<n>.npz; here they are kept in host memory.
+#include "vmx_stage.h"
+#include "vmx_local.h"
+
+__global__ void k_local_seed(vmx_lseed_args A);
+struct vmx_seg_trace;
+int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
+                 vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats, vmx_seg_trace* trace, const vmx_preset* preset);
+
+namespace {
+
+struct LinkRound {
+    vm_ctx* c = nullptr; int lc = 0, kmersize = 15, maxdiff = 50, maxgap = 1000, cap_pre = 4096; double skipcost = 30., margin_base = 0.;
+    DevBuf st, preS, preP, preR, rows, S, P, SA, job, gap;
+    std::vector<std::vector<vmx_anchor>> saved_rows; std::vector<std::vector<int32_t>> saved_P;
+    int64_t pre_g_max_index = 0; bool have = false; int cur_n_pre = 0;
+    LinkRound() = default; LinkRound(const LinkRound&) = delete;
+    ~LinkRound() { for (DevBuf* b : {&st, &preS, &preP, &preR, &rows, &S, &P, &SA, &job, &gap}) b->release(); }
+    int init(vm_ctx* ctx, int lc_, int k, double skip, int md, int mg) {
+        c = ctx; lc = lc_; kmersize = k; skipcost = skip; maxdiff = md; maxgap = mg;
+        if (md > 62) { set_error("maxdiff > 62 unsupported"); return VM_ERR_UNSUPPORTED; }
+        const HostTables& T = host_tables();
+        std::vector<double> g(64, 0.0); double gapmax = 0.0;
+        for (int x = 1; x <= md; ++x) { g[x] = (0.01 * k * x + 0.5 * T.log2int[x]); gapmax = std::max(gapmax, g[x]); }
+        double rgcmax = 0.0; if (lc) for (int r = 0; r < 100; ++r) rgcmax = std::max(rgcmax, (double)T.readgap_r[r]);
+        margin_base = std::max(skip + 36.0, gapmax + rgcmax);
+        VMX_TRY(upload(gap, g.data(), 64, c->stream));
+        VMX_TRY(preS.reserve(8 * (size_t)cap_pre)); VMX_TRY(preP.reserve(4 * (size_t)cap_pre)); VMX_TRY(preR.reserve(sizeof(vmx_anchor) * (size_t)cap_pre));
+        vmx_link_state hs; memset(&hs, 0, sizeof hs);
+        hs.cap_pre = cap_pre; hs.pre_S = preS.as<double>(); hs.pre_P = preP.as<int32_t>(); hs.pre_rows = preR.as<vmx_anchor>();
+        VMX_TRY(upload(st, &hs, 1, c->stream));
+        VMX_HIP(vmx_stream_sync(c));
+        return 0;
+    }
+    // one batch (:23230-23275 / :23329-23373). rows_new: sorted by read position (stable)
+    int feed(const std::vector<vmx_anchor>& rows_new) {
+        const int64_t n_new = (int64_t)rows_new.size();
+        if (n_new == 0) return 0;
+        const size_t tot = (size_t)cap_pre + (size_t)n_new;
+        VMX_TRY(rows.reserve(sizeof(vmx_anchor) * tot)); VMX_TRY(S.reserve(8 * tot)); VMX_TRY(P.reserve(4 * tot)); VMX_TRY(SA.reserve(4 * tot));
+        VMX_HIP(hipMemcpyAsync(rows.as<vmx_anchor>() + cap_pre, rows_new.data(), sizeof(vmx_anchor) * (size_t)n_new, hipMemcpyHostToDevice, c->stream));
+        vmx_link_job hj; memset(&hj, 0, sizeof hj);
+        hj.state = st.as<vmx_link_state>(); hj.rows = rows.as<vmx_anchor>(); hj.S = S.as<double>(); hj.P = P.as<int32_t>(); hj.SA = SA.as<int32_t>();
+        hj.cap_pre = cap_pre; hj.n_new = (int32_t)n_new;
+        VMX_TRY(upload(job, &hj, 1, c->stream));
+        vmx_link_job* d_job = job.as<vmx_link_job>(); const double* d_gap = gap.as<double>(); const vmx_tables tabs = c->tables; hipStream_t stq = c->stream;
+        const double sk = skipcost, mb = margin_base; const int md = maxdiff, mg = maxgap, l = lc;
+        hipLaunchKernelGGL(k_link_place, dim3(1), dim3(256), 0, stq, d_job, 1);
+        hipLaunchKernelGGL(k_chain_linked, dim3(1), dim3(64), 0, stq, d_job, 1, tabs, d_gap, sk, md, mg, l, mb);
+        hipLaunchKernelGGL(k_link_carry, dim3(1), dim3(64), 0, stq, d_job, 1, sk);
+        vmx_link_state hs;
+        VMX_TRY(download(&hj, job.p, 1, c->stream)); VMX_TRY(download(&hs, st.p, 1, c->stream));
+        VMX_HIP(vmx_stream_sync(c));
+        VMX_HIP(hipGetLastError());
+        if (hs.status == VM_LINK_RAISED) { set_error("asm: the reference raises on this contig (linked chain)"); return VM_READ_RAISED; }
+        if (hs.status != 0) { set_error(hs.status == VM_LINK_BAILED ? "asm: GC-exact bailed out; the fork's linked GC-fast is not on the device" : "asm: carried slice outside the stored index / staging area"); return VM_READ_UNSUPPORTED; }
+        if (!hj.ran) { set_error("asm: a linked batch did not run"); return VM_ERR_HIP; }
+        have = true; pre_g_max_index = hs.pre_g_max_index;
+        if (hj.saved) {
+            const int n_pre = cur_n_pre, base = cap_pre - n_pre, n = hj.n;
+            std::vector<vmx_anchor> lr((size_t)n); std::vector<int32_t> lp((size_t)n);
+            VMX_TRY(download(lr.data(), rows.as<vmx_anchor>() + base, (size_t)n_pre, c->stream));
+            VMX_TRY(download(lp.data(), P.as<int32_t>() + base, (size_t)n, c->stream));
+            VMX_HIP(vmx_stream_sync(c));
+            std::copy(rows_new.begin(), rows_new.end(), lr.begin() + n_pre);
+            saved_rows.push_back(std::move(lr)); saved_P.push_back(std::move(lp));
+            cur_n_pre = hs.n_pre;
+        }
+        return 0;
+    }
+    // :23277-23292 / :23379-23396
+    int traceback(int64_t start, std::vector<vmx_anchor>& path) const {
+        path.clear();
+        int64_t gi = start;
+        for (int64_t d = (int64_t)saved_rows.size() - 1; d >= 0; --d) {
+            const std::vector<vmx_anchor>& R = saved_rows[(size_t)d]; const std::vector<int32_t>& Pp = saved_P[(size_t)d];
+            const int64_t n = (int64_t)R.size();
+            int64_t take = gi;
+            if (take < 0 || take >= n) return VM_READ_RAISED;     // IndexError
+            path.push_back(R[(size_t)take]);
+            while (true) {
+                if (Pp[(size_t)take] < 0) break;
+                take = Pp[(size_t)take];
+                if (take >= n) return VM_READ_RAISED;
+                path.push_back(R[(size_t)take]);
+            }
+            gi = std::llabs((long long)Pp[(size_t)take]);
+        }
+        return 0;
+    }
+};
+
+struct SeedBufs {
+    DevBuf guide, glen, ngu, aoff, order, head, epoch, next, sq, dst, hkey, hkey2, hval, hq, goff, pcnt, pc2, stg, gkey, gq, gr, la_rows, la_ekey, la_sorted, la_off, la_cnt, status, rdoff, rdlen, rst, ren;
+    SeedBufs() = default; SeedBufs(const SeedBufs&) = delete;
+    ~SeedBufs() { for (DevBuf* b : {&guide, &glen, &ngu, &aoff, &order, &head, &epoch, &next, &sq, &dst, &hkey, &hkey2, &hval, &hq, &goff, &pcnt, &pc2, &stg, &gkey, &gq, &gr, &la_rows, &la_ekey, &la_sorted, &la_off, &la_cnt, &status, &rdoff, &rdlen, &rst, &ren}) b->release(); }
+};
+
+struct Tuple { int64_t st_read, en_read, lo, hi; };
+
+// development aid (VMX_ASM_DUMP=<dir>): the stages of the long-contig loop as int64 rows (q, r, s, l), for comparison with the oracle's vmo_asm_trace
+void dump_rows(const char* name, const std::vector<vmx_anchor>& v, bool append = false) {
+    const char* d = getenv("VMX_ASM_DUMP"); if (!d) return;
+    const std::string fn = std::string(d) + "/" + name;
+    FILE* f = fopen(fn.c_str(), append ? "ab" : "wb"); if (!f) return;
+    for (const vmx_anchor& a : v) { const int64_t row[4] = {a.q, a.r, a.s, (int)a.l & 0xffff}; fwrite(row, 8, 4, f); }
+    fclose(f);
+}
+
+// collect_second_round_anchors (:22477-22756) for every second-round batch at once: one k_local_seed launch, one unit per batch
+int second_round_seed(vm_ctx* c, const vm_index_view& ix, int k, const uint8_t* d_codes, int64_t L, const std::vector<vmx_anchor>& raw_asc, const std::vector<Tuple>& tuples,
+                      std::vector<std::vector<vmx_anchor>>& out) {
+    const int64_t nt = (int64_t)tuples.size();
+    out.assign((size_t)nt, {});
+    if (!nt) return 0;
+    if (k < 5 || k > 11) { set_error("local k-mer size must be in [5,11]"); return VM_ERR_UNSUPPORTED; }
+    SeedBufs B;
+    std::vector<vmx_anchor> guide; std::vector<int32_t> glen; std::vector<int64_t> aoff((size_t)nt + 1, 0), la_off((size_t)nt + 1, 0), rdoff((size_t)nt, 0), rdlen((size_t)nt, L);
+    std::vector<int32_t> ngu((size_t)nt, 1), rst((size_t)nt), ren((size_t)nt), order((size_t)nt + 1, 0);
+    int64_t span_max = 1, glen_max = 1;
+    for (int64_t t = 0; t < nt; ++t) {
+        const Tuple& u = tuples[(size_t)t];
+        if (u.hi <= u.lo) { set_error("asm: the reference raises on this contig (empty second-round guide)"); return VM_READ_RAISED; }
+        aoff[(size_t)t] = (int64_t)guide.size();
+        for (int64_t i = u.hi - 1; i >= u.lo; --i) guide.push_back(raw_asc[(size_t)i]);          // descending read order, like a stored path
+        rst[(size_t)t] = (int32_t)u.st_read; ren[(size_t)t] = (int32_t)u.en_read;
+        const int64_t span = u.en_read - u.st_read;
+        span_max = std::max(span_max, span); glen_max = std::max(glen_max, u.hi - u.lo);
+        la_off[(size_t)t + 1] = la_off[(size_t)t] + 8 * VMX_LA_SLOT(span);
+        order[(size_t)t + 1] = (int32_t)t;
+    }
+    aoff[(size_t)nt] = (int64_t)guide.size();
+    glen.assign(guide.size() + 1, 0);
+    for (int64_t t = 0; t < nt; ++t) glen[(size_t)aoff[(size_t)t]] = (int32_t)(tuples[(size_t)t].hi - tuples[(size_t)t].lo);
+    std::stable_sort(order.begin() + 1, order.end(), [&](int32_t a, int32_t b) { return tuples[(size_t)a].en_read - tuples[(size_t)a].st_read > tuples[(size_t)b].en_read - tuples[(size_t)b].st_read; });
+    const int TPB = 512;
+    int occ = 1;
+#ifndef VMX_EMU
+    VMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_local_seed, TPB, 0));
+    if (occ < 1) occ = 1;
+    if (occ > 2) occ = 2;
+#endif
+    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(nt, std::min<int64_t>(64, (int64_t)c->num_cu * occ)));
+    const int64_t nkey = (int64_t)1 << (2 * k);
+    const int64_t head_stride = (2 * k > 14 && nkey <= (int64_t)VMX_SORT_LDS * 64) ? ((int64_t)1 << 14) : nkey;
+    // the guide of a batch spans about its read range on the reference (+ 2000 on either side of every window, :22526-22530)
+    const int64_t tpos_cap = std::min<int64_t>(4 * span_max + 64 * 4000 + 65536, ((int64_t)1 << 23) - 2);
+    int64_t hit_cap = 1; while (hit_cap < 4 * (span_max + 14000)) hit_cap <<= 1;
+    if (hit_cap > ((int64_t)1 << 26)) hit_cap = (int64_t)1 << 26;
+    const int64_t pcnt_cap = span_max + 16;
+    int64_t gkey_cap = 1; while (gkey_cap < glen_max) gkey_cap <<= 1;
+    const int64_t la_tot = la_off[(size_t)nt];
+    VMX_TRY(upload(B.guide, guide.data(), guide.size(), c->stream)); VMX_TRY(upload(B.glen, glen.data(), glen.size(), c->stream)); VMX_TRY(upload(B.ngu, ngu.data(), ngu.size(), c->stream));
+    VMX_TRY(upload(B.aoff, aoff.data(), aoff.size(), c->stream)); VMX_TRY(upload(B.order, order.data(), order.size(), c->stream));
+    VMX_TRY(upload(B.la_off, la_off.data(), la_off.size(), c->stream)); VMX_TRY(upload(B.rdoff, rdoff.data(), rdoff.size(), c->stream)); VMX_TRY(upload(B.rdlen, rdlen.data(), rdlen.size(), c->stream));
+    VMX_TRY(upload(B.rst, rst.data(), rst.size(), c->stream)); VMX_TRY(upload(B.ren, ren.data(), ren.size(), c->stream));
+    VMX_TRY(B.head.reserve(4 * (size_t)G * (size_t)head_stride)); VMX_TRY(B.epoch.reserve(4 * (size_t)G + 64));
+    VMX_HIP(hipMemsetAsync(B.head.p, 0xff, B.head.cap, c->stream)); VMX_HIP(hipMemsetAsync(B.epoch.p, 0, B.epoch.cap, c->stream));
+    VMX_TRY(B.next.reserve(4 * (size_t)G * (size_t)tpos_cap));
+    VMX_TRY(B.sq.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(B.dst.reserve(4 * (size_t)G * (size_t)hit_cap));
+    VMX_TRY(B.hkey.reserve(8 * (size_t)G * (size_t)hit_cap)); VMX_TRY(B.hkey2.reserve(8 * (size_t)G * (size_t)hit_cap)); VMX_TRY(B.hval.reserve(8 * (size_t)G * (size_t)hit_cap));
+    VMX_TRY(B.hq.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(B.goff.reserve(4 * (size_t)G * (size_t)hit_cap));
+    VMX_TRY(B.pcnt.reserve(4 * (size_t)G * (size_t)pcnt_cap)); VMX_TRY(B.pc2.reserve(4 * (size_t)G * (size_t)pcnt_cap)); VMX_TRY(B.stg.reserve(16 * (size_t)G * (size_t)pcnt_cap));
+    VMX_TRY(B.gkey.reserve(8 * (size_t)G * (size_t)gkey_cap)); VMX_TRY(B.gq.reserve(4 * (size_t)G * (size_t)gkey_cap)); VMX_TRY(B.gr.reserve(8 * (size_t)G * (size_t)gkey_cap));
+    VMX_TRY(B.la_rows.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1))); VMX_TRY(B.la_ekey.reserve(8 * (size_t)(la_tot + 1))); VMX_TRY(B.la_sorted.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1)));
+    VMX_TRY(B.la_cnt.reserve(4 * (size_t)(nt + 1))); VMX_TRY(B.status.reserve(4 * (size_t)(nt + 1)));
+    vmx_lseed_args A; memset(&A, 0, sizeof A);
+    A.ocodes = d_codes; A.roff = nullptr; A.ref = ix.codes; A.coff = ix.coff; A.nseq = ix.nseq;
+    A.guide_rows = B.guide.as<vmx_anchor>(); A.guide_len = B.glen.as<int32_t>(); A.n_guides_used = B.ngu.as<int32_t>(); A.aoff = B.aoff.as<int64_t>();
+    A.n_reads = (int)nt; A.k = k; A.look_span = 2000; A.read_span = 500; A.sort_by_start = 1;          // :22526-22530, :22755
+    A.queue = B.order.as<int32_t>(); A.order = B.order.as<int32_t>() + 1; A.la_slot_len = 1;
+    A.head_pool = B.head.as<int32_t>(); A.next_pool = B.next.as<int32_t>(); A.head_stride = head_stride; A.epoch_pool = B.epoch.as<int32_t>();
+    A.sq_pool = B.sq.as<int32_t>(); A.dst_pool = B.dst.as<int32_t>(); A.tpos_pool = nullptr; A.tpos_cap = tpos_cap; A.dbg = nullptr;
+    A.hkey2_pool = B.hkey2.as<uint64_t>(); A.hkey_pool = B.hkey.as<uint64_t>(); A.hval_pool = B.hval.as<int64_t>(); A.hq_pool = B.hq.as<int32_t>(); A.goff_pool = B.goff.as<int32_t>(); A.hit_cap = hit_cap;
+    A.pcnt_pool = B.pcnt.as<int32_t>(); A.pcnt_cap = pcnt_cap; A.pc2_pool = B.pc2.as<int32_t>(); A.stg_pool = B.stg.as<int64_t>();
+    A.gkey_pool = B.gkey.as<uint64_t>(); A.gq_pool = B.gq.as<int32_t>(); A.gr_pool = B.gr.as<int64_t>(); A.gkey_cap = gkey_cap;
+    A.la_rows = B.la_rows.as<vmx_anchor>(); A.la_ekey = B.la_ekey.as<uint64_t>(); A.la_sorted = B.la_sorted.as<vmx_anchor>(); A.la_off = B.la_off.as<int64_t>();
+    A.la_cnt = B.la_cnt.as<int32_t>(); A.status = B.status.as<int32_t>();
+    A.rd_off = B.rdoff.as<int64_t>(); A.rd_len = B.rdlen.as<int64_t>(); A.r_st = B.rst.as<int32_t>(); A.r_en = B.ren.as<int32_t>();
+    hipStream_t stq = c->stream;
+    hipLaunchKernelGGL(k_local_seed, dim3((unsigned)G), dim3(TPB), 0, stq, A);
+    std::vector<int32_t> cnt((size_t)nt), stt((size_t)nt);
+    VMX_TRY(download(cnt.data(), B.la_cnt.p, (size_t)nt, c->stream)); VMX_TRY(download(stt.data(), B.status.p, (size_t)nt, c->stream));
+    VMX_HIP(vmx_stream_sync(c));
+    VMX_HIP(hipGetLastError());
+    for (int64_t t = 0; t < nt; ++t) {
+        if (stt[(size_t)t] != 0) { set_error("asm: a second-round re-seeding batch overflowed its device pools"); return VM_READ_CAPACITY; }
+        out[(size_t)t].resize((size_t)cnt[(size_t)t]);
+        VMX_TRY(download(out[(size_t)t].data(), B.la_sorted.as<vmx_anchor>() + la_off[(size_t)t], (size_t)cnt[(size_t)t], c->stream));
+    }
+    VMX_HIP(vmx_stream_sync(c));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int vm_align_asm(vm_ctx* c, const vm_index* mi, const vm_params* prm_in, const char* contig, int64_t len, int64_t split_len, int64_t batch_anchors, int64_t window,
+                            vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status) {
+    if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
+    if (!prm_in || prm_in->mode != VM_MODE_ASM || !contig || len <= 0 || !recs || !n_recs || !cigar_blob || !status) { set_error("vm_align_asm: bad arguments"); return VM_ERR_ARG; }
+    if (len >= ((int64_t)1 << 31) - 64) { set_error("vm_align_asm: contig of 2^31 bases or more"); return VM_ERR_UNSUPPORTED; }
+    if (split_len <= 0) split_len = 500000;
+    if (batch_anchors <= 0) batch_anchors = 500000;
+    if (window <= 0) window = 100000;
+    *recs = nullptr; *n_recs = 0; *cigar_blob = nullptr; *status = 0;
+    VMX_HIP(hipSetDevice(c->device));
+    auto finish_empty = [&](int st) { *recs = (vm_record*)malloc(sizeof(vm_record)); *cigar_blob = (char*)malloc(1); *n_recs = 0; *status = st; return VM_OK; };
+    auto per_contig = [&](int rc) -> int {                       // a per-contig outcome (raised / unsupported / capacity) is a status, not a failed call
+        if (rc == VM_READ_RAISED || rc == VM_READ_UNSUPPORTED || rc == VM_READ_CAPACITY) return finish_empty(rc);
+        return rc;
+    };
+    const int64_t off1[2] = {0, len};
+    if (len < split_len) {                                       // :23205: the fork's per-read function
+        vm_params p = *prm_in;
+        if (len >= 500000) { set_error("vm_align_asm: split_len above the reference's 500000"); return VM_ERR_ARG; }
+        return vm_align_batch(c, mi, &p, 1, contig, off1, recs, n_recs, cigar_blob, status, nullptr);
+    }
+    std::string seq(contig, (size_t)len);
+    for (char& ch : seq) if (ch >= 'a' && ch <= 'z') ch -= 32;
+    vm_index_view ix; vmx_index_view(mi, &ix);
+    // ---- first round :23214-23292
+    LinkRound r1;
+    VMX_TRY(r1.init(c, 0, ix.k, prm_in->global_skipcost, prm_in->global_maxdiff, 1000));
+    {
+        std::vector<std::vector<vmx_anchor>> cache; int64_t cache_size = 0;
+        std::vector<vmx_anchor> one;
+        auto flush = [&](std::vector<vmx_anchor>& batch) -> int {
+            std::stable_sort(batch.begin(), batch.end(), [](const vmx_anchor& a, const vmx_anchor& b) { return a.q < b.q; });
+            return r1.feed(batch);
+        };
+        const int64_t n_win = (len + window - 1) / window;
+        const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(256, ((int64_t)32 << 20) / window));
+        for (int64_t w0 = 0; w0 < n_win; w0 += chunk) {
+            const int64_t w1 = std::min(n_win, w0 + chunk);
+            std::vector<int64_t> woff((size_t)(w1 - w0) + 1);
+            for (int64_t w = w0; w <= w1; ++w) woff[(size_t)(w - w0)] = std::min(w * window, len) - w0 * window;
+            int64_t* anchors = nullptr; int64_t* aoff = nullptr;
+            VMX_TRY(vm_map_batch(c, mi, -1, -1, w1 - w0, seq.data() + w0 * window, woff.data(), &anchors, &aoff));      // :22419
+            for (int64_t w = w0; w < w1; ++w) {
+                const int64_t st = w * window;
+                one.clear();
+                for (int64_t i = aoff[w - w0]; i < aoff[w - w0 + 1]; ++i) { vmx_anchor a; a.q = (int32_t)(anchors[4 * i] + st); a.r = anchors[4 * i + 1]; a.s = (int16_t)anchors[4 * i + 2]; a.l = (int16_t)anchors[4 * i + 3]; one.push_back(a); }
+                // yield_mapinfo :22423-22438
+                if ((int64_t)one.size() + cache_size > batch_anchors) {
+                    if (cache_size > 0) {
+                        if (!one.empty()) cache.push_back(one);
+                        std::vector<vmx_anchor> all; for (auto& cc : cache) all.insert(all.end(), cc.begin(), cc.end());
+                        one.swap(all); cache_size = 0; cache.clear();
+                    }
+                    std::vector<vmx_anchor> batch = one;
+                    const int rc = flush(batch);
+                    if (rc < 0) { free(anchors); free(aoff); return per_contig(rc); }
+                } else if (!one.empty()) { cache.push_back(one); cache_size += (int64_t)one.size(); }
+            }
+            free(anchors); free(aoff);
+        }
+        if (cache_size > 0) {                                    // :22439-22443, including the second copy of the last window's anchors
+            if (!one.empty()) cache.push_back(one);
+            std::vector<vmx_anchor> all; for (auto& cc : cache) all.insert(all.end(), cc.begin(), cc.end());
+            const int rc = flush(all);
+            if (rc < 0) return per_contig(rc);
+        }
+    }
+    if (!r1.have) return finish_empty(VM_READ_RAISED);          // NameError: pre_g_max_index (:23278)
+    std::vector<vmx_anchor> path;
+    { const int rc = r1.traceback(r1.pre_g_max_index, path); if (rc < 0) return per_contig(rc); }
+    dump_rows("path1.bin", path);
+    if (path.size() <= 1) return finish_empty(0);
+    // ---- second round :23309-23396
+    const int k2 = prm_in->local_kmersize;
+    LinkRound r2;
+    VMX_TRY(r2.init(c, 1, k2, prm_in->local_skipcost, prm_in->local_maxdiff, 99));
+    DevBuf d_raw, d_codes;
+    struct Rel { DevBuf* a; DevBuf* b; ~Rel() { a->release(); b->release(); } } rel{&d_raw, &d_codes};
+    VMX_TRY(upload(d_raw, seq.data(), (size_t)len, c->stream)); VMX_TRY(d_codes.reserve((size_t)len + 64));
+    { const char* dr = d_raw.as<char>(); uint8_t* dc = d_codes.as<uint8_t>(); const int64_t nn = len; hipStream_t stq = c->stream;
+      hipLaunchKernelGGL(k_encode, dim3((unsigned)std::min<int64_t>((nn + 255) / 256, 65535)), dim3(256), 0, stq, dr, dc, nn); }
+    {
+        const std::vector<vmx_anchor> raw(path.rbegin(), path.rend());
+        const int64_t np_ = (int64_t)raw.size();
+        std::vector<Tuple> tuples;
+        int64_t st_read = 0, st_path = 0, iloc_path = 0;         // yield_second_mapinfo :22444-22476
+        for (int64_t x = 1; x < np_; ++x) {
+            const vmx_anchor& now = raw[(size_t)x];
+            iloc_path += 1;
+            if (iloc_path == np_ - 1 || (iloc_path < np_ - 1 && raw[(size_t)iloc_path + 1].q > raw[(size_t)iloc_path].q)) {
+                if (((int64_t)now.q + ((int)now.l & 0xffff)) > (st_read + window) && (iloc_path - st_path) > 300) {
+                    const int64_t en_read = raw[(size_t)iloc_path].q;
+                    tuples.push_back(Tuple{st_read, en_read, std::max<int64_t>(0, st_path - 20), std::min<int64_t>(iloc_path + 20, np_)});
+                    st_path = iloc_path + 1;
+                    st_read = en_read;
+                }
+            }
+        }
+        if (st_read < len) tuples.push_back(Tuple{st_read, len, std::max<int64_t>(0, st_path - 20), std::min<int64_t>(iloc_path + 20, np_)});
+        std::vector<std::vector<vmx_anchor>> second;
+        { const int rc = second_round_seed(c, ix, k2, d_codes.as<uint8_t>(), len, raw, tuples, second); if (rc < 0) return per_contig(rc); }
+        for (size_t t = 0; t < second.size(); ++t) {
+            dump_rows("second.bin", second[t], t > 0);
+            if (second[t].empty()) return finish_empty(VM_READ_RAISED);     // np.array([])[:, 0] (:22755)
+            const int rc = r2.feed(second[t]);
+            if (rc < 0) return per_contig(rc);
+        }
+    }
+    std::vector<vmx_anchor> path2;
+    { const int rc = r2.traceback(r2.have ? r2.pre_g_max_index : r1.pre_g_max_index, path2); if (rc < 0) return per_contig(rc); }
+    if (path2.size() <= 1) return finish_empty(0);
+    {   // :23400-23412 trim read overlaps against the UNtrimmed neighbour
+        vmx_anchor pre = path2[0];
+        for (size_t x = 1; x < path2.size(); ++x) {
+            const vmx_anchor now = path2[x];
+            const int nl = (int)now.l & 0xffff;
+            if (!(pre.q >= now.q + nl)) {
+                vmx_anchor t = now; t.l = (int16_t)(pre.q - now.q);
+                if (now.s != 1) t.r = now.r + nl - pre.q + now.q;
+                path2[x] = t;
+            }
+            pre = now;
+        }
+    }
+    dump_rows("path2.bin", path2);
+    // ---- ass_extend_func :23414 on the chain (descending read order, as the extend stage takes a local chain)
+    DevBuf d_off; struct Rel1 { DevBuf* a; ~Rel1() { a->release(); } } rel1{&d_off};
+    VMX_TRY(upload(d_off, off1, 2, c->stream));
+    std::vector<int64_t> h_off(off1, off1 + 2);
+    vmx_preset ps; ps.chain_desc = path2.data(); ps.len = (int64_t)path2.size();
+    const int rc = align_device(c, mi, prm_in, 1, d_codes.as<uint8_t>(), d_off.as<int64_t>(), h_off, recs, n_recs, cigar_blob, status, nullptr, nullptr, &ps);
+    return rc;
+}
+
+// vm_align_batch in VM_MODE_ASM with contigs of 500 kb and more in the batch: the shorter ones go through the batched path together, every long
+// one through vm_align_asm; records come back in contig order like any other batch
+int vmx_align_batch_asm_mixed(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const char* seqs, const int64_t* offsets, vm_record** recs, int64_t* n_recs,
+                              char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats) {
+    *recs = nullptr; *n_recs = 0; *cigar_blob = nullptr;
+    std::vector<int64_t> shorts, longs;
+    for (int64_t r = 0; r < n; ++r) ((offsets[r + 1] - offsets[r] >= 500000) ? longs : shorts).push_back(r);
+    std::vector<std::vector<vm_record>> per((size_t)n); std::vector<std::string> pblob((size_t)n);
+    std::vector<int32_t> st((size_t)n, 0);
+    vm_batch_stats tot; memset(&tot, 0, sizeof tot);
+    if (!shorts.empty()) {
+        std::string cat; std::vector<int64_t> off(1, 0);
+        for (int64_t r : shorts) { cat.append(seqs + offsets[r], (size_t)(offsets[r + 1] - offsets[r])); off.push_back((int64_t)cat.size()); }
+        vm_record* r0 = nullptr; int64_t nr = 0; char* cb = nullptr; std::vector<int32_t> s0(shorts.size());
+        const int rc = vm_align_batch(c, mi, prm, (int64_t)shorts.size(), cat.data(), off.data(), &r0, &nr, &cb, s0.data(), &tot);
+        if (rc < 0) { free(r0); free(cb); return rc; }
+        for (int64_t i = 0; i < nr; ++i) { const int64_t r = shorts[(size_t)r0[i].read_idx]; vm_record x = r0[i]; x.cigar_off = (int64_t)pblob[(size_t)r].size(); pblob[(size_t)r].append(cb + r0[i].cigar_off, (size_t)r0[i].cigar_len); pblob[(size_t)r].push_back('\0'); per[(size_t)r].push_back(x); }
+        for (size_t i = 0; i < shorts.size(); ++i) st[(size_t)shorts[i]] = s0[i];
+        free(r0); free(cb);
+    }
+    for (int64_t r : longs) {
+        vm_record* r0 = nullptr; int64_t nr = 0; char* cb = nullptr; int32_t s1 = 0;
+        const int rc = vm_align_asm(c, mi, prm, seqs + offsets[r], offsets[r + 1] - offsets[r], 0, 0, 0, &r0, &nr, &cb, &s1);
+        if (rc < 0) { free(r0); free(cb); return rc; }
+        for (int64_t i = 0; i < nr; ++i) { vm_record x = r0[i]; x.cigar_off = (int64_t)pblob[(size_t)r].size(); pblob[(size_t)r].append(cb + r0[i].cigar_off, (size_t)r0[i].cigar_len); pblob[(size_t)r].push_back('\0'); per[(size_t)r].push_back(x); }
+        st[(size_t)r] = s1; tot.n_reads += 1; tot.read_bases += offsets[r + 1] - offsets[r]; tot.n_records += nr; if (s1 != 0) tot.n_failed += 1;
+        free(r0); free(cb);
+    }
+    std::vector<vm_record> all; std::string blob;
+    for (int64_t r = 0; r < n; ++r) for (vm_record x : per[(size_t)r]) { x.read_idx = (int32_t)r; const int64_t o = x.cigar_off; x.cigar_off = (int64_t)blob.size(); blob.append(pblob[(size_t)r].data() + o, (size_t)x.cigar_len); blob.push_back('\0'); all.push_back(x); }
+    *recs = (vm_record*)malloc(sizeof(vm_record) * std::max<size_t>(all.size(), 1)); *cigar_blob = (char*)malloc(std::max<size_t>(blob.size(), 1));
+    if (!*recs || !*cigar_blob) { free(*recs); free(*cigar_blob); *recs = nullptr; *cigar_blob = nullptr; set_error("out of host memory"); return VM_ERR_OOM; }
+    memcpy(*recs, all.data(), sizeof(vm_record) * all.size()); memcpy(*cigar_blob, blob.data(), blob.size());
+    *n_recs = (int64_t)all.size();
+    if (status_per_read) for (int64_t r = 0; r < n; ++r) status_per_read[r] = st[(size_t)r];
+    if (stats) *stats = tot;
+    return VM_OK;
+}

@@ -20,6 +20,7 @@ struct vmx_ext_read {
 
 struct vmx_ext_args {
     int32_t n_reads, nseq, local_maxdiff, nodiscard, hardclip, redo_only, mode, spread;     // spread: lanes of the grid per read in k_ext_phase / k_ext_records
+    int32_t asm_long, pad_;       // -mode asm, contig of 500 kb and more: ass_extend_func (mammap_asm.py:23423) — small_alignment 30, no divergence filter
     double maxdivergence;
     const uint8_t* ocodes; const int64_t* roff; const uint8_t* ref; const int64_t* coff;
     const vmx_anchor* chain; const int32_t* chain_len; const int64_t* la_off; const int32_t* lstatus;

@@ -65,6 +65,9 @@ struct vmx_lseed_args {
     int32_t* pcnt_pool; int64_t pcnt_cap; int32_t* pc2_pool; int64_t* stg_pool;
     uint64_t* gkey_pool; int32_t* gq_pool; int64_t* gr_pool; int64_t gkey_cap;
     vmx_anchor* la_rows; uint64_t* la_ekey; vmx_anchor* la_sorted; const int64_t* la_off; int32_t* la_cnt; int32_t* status;
+    // collect_second_round_anchors (mammap_asm.py:22477-22756; null otherwise): unit r looks up the read positions [r_st[r], r_en[r] - k) of the
+    // sequence at ocodes + rd_off[r] (length rd_len[r]: every unit of a contig shares it) and owns la_off[r + 1] - la_off[r] anchor rows
+    const int64_t* rd_off; const int64_t* rd_len; const int32_t* r_st; const int32_t* r_en;
 };
 
 #define VMX_ED_WAVES 16              // max waves per workgroup of k_edit_distance (passes pipelined across them) = carry ring depth

@@ -9,6 +9,9 @@ struct vm_index_view {
 };
 void vmx_index_view(const vm_index* mi, vm_index_view* v);
 
+// a chain handed to the extend stage instead of the seed / chain stages (host rows, DESCENDING read order like a local chain)
+struct vmx_preset { const vmx_anchor* chain_desc; int64_t len; };
+
 struct vmx_local_bufs {
     vmx::DevBuf sq, dst, rorder, pc2, stg, si, tg, cntp, fp, pp;
     vmx::DevBuf guide_rows, guide_len, ng_used, ng_total, cnt, cur, tpos, hkey, hkey2, dbg, hval, hq, goff, pcnt, gkey, gq, gr, epoch;

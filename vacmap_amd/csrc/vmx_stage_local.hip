@@ -72,6 +72,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     int64_t pcnt_cap = Lmax + 16;
     int64_t gkey_cap = 1; { int64_t mx = 1; for (int64_t r = 0; r < n; ++r) mx = std::max(mx, h_aoff[r + 1] - h_aoff[r]); while (gkey_cap < mx) gkey_cap <<= 1; }
     vmx_lseed_args A;
+    A.rd_off = nullptr; A.rd_len = nullptr; A.r_st = nullptr; A.r_en = nullptr;
     static const bool dbg_on = getenv("VMX_DBG") != nullptr;
     // one launch over the reads listed in L.rorder[1 .. cnt] with `slots` workgroups and per-slot hit pools of `hcap` entries
     auto run_seed = [&](int cnt, int slots, int64_t hcap) -> int {

@@ -136,6 +136,7 @@ class VmxLib:
         L.vm_chain_global_batch.argtypes = [vp, P(Params), C.c_int, i64, vp, vp, vp, C.c_int, P(ChainsOut)]
         L.vm_chain_linked.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, i64, vp, i64, vp, vp, C.c_double, i64, i64, P(LinkedOut)]
         L.vm_linked_out_free.argtypes = [P(LinkedOut)]
+        L.vm_align_asm.argtypes = [vp, vp, P(Params), C.c_char_p, i64, i64, i64, i64, P(P(Record)), P(i64), P(vp), P(C.c_int32)]
         L.vm_chains_out_free.argtypes = [P(ChainsOut)]
         L.vm_index_build_fasta.argtypes = [vp, cp, C.c_int, C.c_int, P(vp)]
         L.vm_index_build_mem.argtypes = [vp, C.c_int, P(cp), P(cp), P(i64), C.c_int, C.c_int, P(vp)]
@@ -406,6 +407,15 @@ def align_batch(ctx, index, prm, seqs):
                                            status.ctypes.data, C.byref(stats)))
     out, sd = _collect_records(ctx, recs, nrec.value, blob, stats)
     return status[:n], out, sd
+
+
+def align_asm(ctx, index, prm, contig, split_len=0, batch_anchors=0, window=0):
+    """-mode asm on one assembly contig (vm_align_asm): (status, records as 9-tuples)"""
+    s = contig if isinstance(contig, bytes) else contig.encode()
+    recs = C.POINTER(Record)(); nrec = C.c_int64(); blob = C.c_void_p(); st = C.c_int32()
+    ctx.lib.check(ctx.lib.L.vm_align_asm(ctx.h, index.h, C.byref(prm), s, len(s), split_len, batch_anchors, window, C.byref(recs), C.byref(nrec), C.byref(blob), C.byref(st)))
+    out, _ = _collect_records(ctx, recs, nrec.value, blob, BatchStats())
+    return st.value, out
 
 
 def align_trace(ctx, index, prm, seqs, stage):
