@@ -100,6 +100,7 @@ extern "C" int vm_chain_linked(vm_ctx* c, int which, int kmersize, double skipco
 // The reference spills every batch's (anchors, P) to <workdir>/<n>.npz; here they are kept in host memory.
 #include "vmx_stage.h"
 #include "vmx_local.h"
+#include <memory>
 
 __global__ void k_local_seed(vmx_lseed_args A);
 struct vmx_seg_trace;
@@ -131,26 +132,19 @@ struct LinkRound {
         VMX_HIP(vmx_stream_sync(c));
         return 0;
     }
-    // one batch (:23230-23275 / :23329-23373). rows_new: sorted by read position (stable)
-    int feed(const std::vector<vmx_anchor>& rows_new) {
+    // one batch (:23230-23275 / :23329-23373), in two halves so that the batches of several contigs run in ONE launch (run_jobs below).
+    // rows_new: sorted by read position (stable)
+    int stage(const std::vector<vmx_anchor>& rows_new, vmx_link_job& hj) {
         const int64_t n_new = (int64_t)rows_new.size();
-        if (n_new == 0) return 0;
         const size_t tot = (size_t)cap_pre + (size_t)n_new;
         VMX_TRY(rows.reserve(sizeof(vmx_anchor) * tot)); VMX_TRY(S.reserve(8 * tot)); VMX_TRY(P.reserve(4 * tot)); VMX_TRY(SA.reserve(4 * tot));
         VMX_HIP(hipMemcpyAsync(rows.as<vmx_anchor>() + cap_pre, rows_new.data(), sizeof(vmx_anchor) * (size_t)n_new, hipMemcpyHostToDevice, c->stream));
-        vmx_link_job hj; memset(&hj, 0, sizeof hj);
+        memset(&hj, 0, sizeof hj);
         hj.state = st.as<vmx_link_state>(); hj.rows = rows.as<vmx_anchor>(); hj.S = S.as<double>(); hj.P = P.as<int32_t>(); hj.SA = SA.as<int32_t>();
         hj.cap_pre = cap_pre; hj.n_new = (int32_t)n_new;
-        VMX_TRY(upload(job, &hj, 1, c->stream));
-        vmx_link_job* d_job = job.as<vmx_link_job>(); const double* d_gap = gap.as<double>(); const vmx_tables tabs = c->tables; hipStream_t stq = c->stream;
-        const double sk = skipcost, mb = margin_base; const int md = maxdiff, mg = maxgap, l = lc;
-        hipLaunchKernelGGL(k_link_place, dim3(1), dim3(256), 0, stq, d_job, 1);
-        hipLaunchKernelGGL(k_chain_linked, dim3(1), dim3(64), 0, stq, d_job, 1, tabs, d_gap, sk, md, mg, l, mb);
-        hipLaunchKernelGGL(k_link_carry, dim3(1), dim3(64), 0, stq, d_job, 1, sk);
-        vmx_link_state hs;
-        VMX_TRY(download(&hj, job.p, 1, c->stream)); VMX_TRY(download(&hs, st.p, 1, c->stream));
-        VMX_HIP(vmx_stream_sync(c));
-        VMX_HIP(hipGetLastError());
+        return 0;
+    }
+    int finish(const vmx_link_job& hj, const vmx_link_state& hs, const std::vector<vmx_anchor>& rows_new) {
         if (hs.status == VM_LINK_RAISED) { set_error("asm: the reference raises on this contig (linked chain)"); return VM_READ_RAISED; }
         if (hs.status != 0) { set_error(hs.status == VM_LINK_BAILED ? "asm: GC-exact bailed out; the fork's linked GC-fast is not on the device" : "asm: carried slice outside the stored index / staging area"); return VM_READ_UNSUPPORTED; }
         if (!hj.ran) { set_error("asm: a linked batch did not run"); return VM_ERR_HIP; }
@@ -188,6 +182,32 @@ struct LinkRound {
         return 0;
     }
 };
+
+// the current batch of every listed contig in one launch (one wavefront per contig): rc[i] = 0 or that contig's negative status; a negative
+// return value is a failed call. All rounds share the DP's parameters (same round of the same run).
+int run_jobs(vm_ctx* c, DevBuf& d_jobs, const std::vector<LinkRound*>& rounds, const std::vector<const std::vector<vmx_anchor>*>& news, std::vector<int>& rc) {
+    const size_t nj = rounds.size();
+    rc.assign(nj, 0);
+    if (!nj) return 0;
+    std::vector<vmx_link_job> hj(nj); std::vector<vmx_link_state> hs(nj);
+    for (size_t i = 0; i < nj; ++i) VMX_TRY(rounds[i]->stage(*news[i], hj[i]));
+    VMX_TRY(upload(d_jobs, hj.data(), nj, c->stream));
+    const LinkRound& R0 = *rounds[0];
+    vmx_link_job* dj = d_jobs.as<vmx_link_job>(); const double* d_gap = R0.gap.as<double>(); const vmx_tables tabs = c->tables; hipStream_t stq = c->stream;
+    const double sk = R0.skipcost, mb = R0.margin_base; const int md = R0.maxdiff, mg = R0.maxgap, l = R0.lc, n_jobs = (int)nj;
+    hipLaunchKernelGGL(k_link_place, dim3((unsigned)nj), dim3(256), 0, stq, dj, n_jobs);
+    hipLaunchKernelGGL(k_chain_linked, dim3((unsigned)nj), dim3(64), 0, stq, dj, n_jobs, tabs, d_gap, sk, md, mg, l, mb);
+    hipLaunchKernelGGL(k_link_carry, dim3((unsigned)nj), dim3(64), 0, stq, dj, n_jobs, sk);
+    VMX_TRY(download(hj.data(), d_jobs.p, nj, c->stream));
+    for (size_t i = 0; i < nj; ++i) VMX_TRY(download(&hs[i], rounds[i]->st.p, 1, c->stream));
+    VMX_HIP(vmx_stream_sync(c));
+    VMX_HIP(hipGetLastError());
+    for (size_t i = 0; i < nj; ++i) {
+        const int r = rounds[i]->finish(hj[i], hs[i], *news[i]);
+        if (r == VM_READ_RAISED || r == VM_READ_UNSUPPORTED || r == VM_READ_CAPACITY) rc[i] = r; else if (r < 0) return r;
+    }
+    return 0;
+}
 
 struct SeedBufs {
     DevBuf guide, glen, ngu, aoff, order, head, epoch, next, sq, dst, hkey, hkey2, hval, hq, goff, pcnt, pc2, stg, gkey, gq, gr, la_rows, la_ekey, la_sorted, la_off, la_cnt, status, rdoff, rdlen, rst, ren;
@@ -293,6 +313,180 @@ int second_round_seed(vm_ctx* c, const vm_index_view& ix, int k, const uint8_t* 
 
 }  // namespace
 
+namespace {
+
+struct LongContig {
+    const char* src = nullptr; int64_t len = 0;
+    std::string seq; int status = 0; bool done = false;           // done: finished (records or a status), nothing more to run
+    LinkRound r1, r2;
+    std::vector<std::vector<vmx_anchor>> batches;                 // first-round batches (yield_mapinfo), then the second round's
+    std::vector<vmx_anchor> path, raw, path2;
+    std::vector<Tuple> tuples;
+    DevBuf d_codes;
+    vm_record* recs = nullptr; int64_t n_recs = 0; char* blob = nullptr;
+    LongContig() = default; LongContig(const LongContig&) = delete;
+    ~LongContig() { d_codes.release(); }
+    void fail(int st) { status = st; done = true; }
+};
+
+// assembly_get_readmap_DP_test (:23208-23422) for a group of contigs side by side: whatever is serial inside a contig — the linked chain DPs,
+// batch after batch — runs for all of them in one launch per batch index
+int asm_long_group(vm_ctx* c, const vm_index* mi, const vm_params* prm, std::vector<LongContig*>& G, int64_t batch_anchors, int64_t window) {
+    vm_index_view ix; vmx_index_view(mi, &ix);
+    static const bool timing = getenv("VMX_ASM_TIME") != nullptr;
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now_s(), t_seed = 0, t_dp1 = 0, t_seed2 = 0, t_dp2 = 0, t_ext = 0; int64_t n_a1 = 0, n_a2 = 0, bases = 0;
+    auto lap = [&](double& acc) { const double t = now_s(); acc += t - t_mark; t_mark = t; };
+    DevBuf d_jobs; struct RelJ { DevBuf* a; ~RelJ() { a->release(); } } relj{&d_jobs};
+    // ---- first round :23214-23292: the batches of every contig (yield_mapinfo :22411-22443)
+    for (LongContig* Cn : G) {
+        LongContig& C = *Cn;
+        C.seq.assign(C.src, (size_t)C.len);
+        for (char& ch : C.seq) if (ch >= 'a' && ch <= 'z') ch -= 32;
+        bases += C.len;
+        VMX_TRY(C.r1.init(c, 0, ix.k, prm->global_skipcost, prm->global_maxdiff, 1000));
+        std::vector<std::vector<vmx_anchor>> cache; int64_t cache_size = 0;
+        std::vector<vmx_anchor> one;
+        auto emit = [&](std::vector<vmx_anchor>& batch) {
+            std::stable_sort(batch.begin(), batch.end(), [](const vmx_anchor& a, const vmx_anchor& b) { return a.q < b.q; });
+            n_a1 += (int64_t)batch.size();
+            if (!batch.empty()) C.batches.push_back(batch);        // :23231 an empty pack is skipped
+        };
+        const int64_t n_win = (C.len + window - 1) / window;
+        const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(256, ((int64_t)32 << 20) / window));
+        for (int64_t w0 = 0; w0 < n_win; w0 += chunk) {
+            const int64_t w1 = std::min(n_win, w0 + chunk);
+            std::vector<int64_t> woff((size_t)(w1 - w0) + 1);
+            for (int64_t w = w0; w <= w1; ++w) woff[(size_t)(w - w0)] = std::min(w * window, C.len) - w0 * window;
+            int64_t* anchors = nullptr; int64_t* aoff = nullptr;
+            VMX_TRY(vm_map_batch(c, mi, -1, -1, w1 - w0, C.seq.data() + w0 * window, woff.data(), &anchors, &aoff));      // :22419
+            for (int64_t w = w0; w < w1; ++w) {
+                const int64_t st = w * window;
+                one.clear();
+                for (int64_t i = aoff[w - w0]; i < aoff[w - w0 + 1]; ++i) { vmx_anchor a; a.q = (int32_t)(anchors[4 * i] + st); a.r = anchors[4 * i + 1]; a.s = (int16_t)anchors[4 * i + 2]; a.l = (int16_t)anchors[4 * i + 3]; one.push_back(a); }
+                if ((int64_t)one.size() + cache_size > batch_anchors) {          // :22423-22438
+                    if (cache_size > 0) {
+                        if (!one.empty()) cache.push_back(one);
+                        std::vector<vmx_anchor> all; for (auto& cc : cache) all.insert(all.end(), cc.begin(), cc.end());
+                        one.swap(all); cache_size = 0; cache.clear();
+                    }
+                    std::vector<vmx_anchor> batch = one;
+                    emit(batch);
+                } else if (!one.empty()) { cache.push_back(one); cache_size += (int64_t)one.size(); }
+            }
+            free(anchors); free(aoff);
+        }
+        if (cache_size > 0) {                                    // :22439-22443, including the second copy of the last window's anchors
+            if (!one.empty()) cache.push_back(one);
+            std::vector<vmx_anchor> all; for (auto& cc : cache) all.insert(all.end(), cc.begin(), cc.end());
+            emit(all);
+        }
+    }
+    lap(t_seed);
+    auto run_round = [&](bool second) -> int {                   // batch b of every contig that has one, b = 0, 1, ...
+        for (size_t b = 0;; ++b) {
+            std::vector<LinkRound*> rounds; std::vector<const std::vector<vmx_anchor>*> news; std::vector<LongContig*> who;
+            for (LongContig* Cn : G) if (!Cn->done && b < Cn->batches.size()) { rounds.push_back(second ? &Cn->r2 : &Cn->r1); news.push_back(&Cn->batches[b]); who.push_back(Cn); }
+            if (rounds.empty()) break;
+            std::vector<int> rc;
+            VMX_TRY(run_jobs(c, d_jobs, rounds, news, rc));
+            for (size_t i = 0; i < who.size(); ++i) if (rc[i] < 0) who[i]->fail(rc[i]);
+        }
+        return 0;
+    };
+    VMX_TRY(run_round(false));
+    for (LongContig* Cn : G) {
+        LongContig& C = *Cn;
+        if (C.done) continue;
+        C.batches.clear(); C.batches.shrink_to_fit();
+        if (!C.r1.have) { C.fail(VM_READ_RAISED); continue; }     // NameError: pre_g_max_index (:23278)
+        const int rc = C.r1.traceback(C.r1.pre_g_max_index, C.path);
+        if (rc < 0) { C.fail(rc); continue; }
+        dump_rows("path1.bin", C.path);
+        if (C.path.size() <= 1) { C.done = true; continue; }
+        C.r1.saved_rows.clear(); C.r1.saved_rows.shrink_to_fit(); C.r1.saved_P.clear(); C.r1.saved_P.shrink_to_fit();
+    }
+    lap(t_dp1);
+    // ---- second round :23309-23396
+    const int k2 = prm->local_kmersize;
+    for (LongContig* Cn : G) {
+        LongContig& C = *Cn;
+        if (C.done) continue;
+        VMX_TRY(C.r2.init(c, 1, k2, prm->local_skipcost, prm->local_maxdiff, 99));
+        {
+            DevBuf d_raw; struct Rel { DevBuf* a; ~Rel() { a->release(); } } rel{&d_raw};
+            VMX_TRY(upload(d_raw, C.seq.data(), (size_t)C.len, c->stream)); VMX_TRY(C.d_codes.reserve((size_t)C.len + 64));
+            const char* dr = d_raw.as<char>(); uint8_t* dc = C.d_codes.as<uint8_t>(); const int64_t nn = C.len; hipStream_t stq = c->stream;
+            hipLaunchKernelGGL(k_encode, dim3((unsigned)std::min<int64_t>((nn + 255) / 256, 65535)), dim3(256), 0, stq, dr, dc, nn);
+            VMX_HIP(vmx_stream_sync(c));
+        }
+        C.raw.assign(C.path.rbegin(), C.path.rend());
+        const std::vector<vmx_anchor>& raw = C.raw;
+        const int64_t np_ = (int64_t)raw.size();
+        int64_t st_read = 0, st_path = 0, iloc_path = 0;         // yield_second_mapinfo :22444-22476
+        for (int64_t x = 1; x < np_; ++x) {
+            const vmx_anchor& now = raw[(size_t)x];
+            iloc_path += 1;
+            if (iloc_path == np_ - 1 || (iloc_path < np_ - 1 && raw[(size_t)iloc_path + 1].q > raw[(size_t)iloc_path].q)) {
+                if (((int64_t)now.q + ((int)now.l & 0xffff)) > (st_read + window) && (iloc_path - st_path) > 300) {
+                    const int64_t en_read = raw[(size_t)iloc_path].q;
+                    C.tuples.push_back(Tuple{st_read, en_read, std::max<int64_t>(0, st_path - 20), std::min<int64_t>(iloc_path + 20, np_)});
+                    st_path = iloc_path + 1;
+                    st_read = en_read;
+                }
+            }
+        }
+        if (st_read < C.len) C.tuples.push_back(Tuple{st_read, C.len, std::max<int64_t>(0, st_path - 20), std::min<int64_t>(iloc_path + 20, np_)});
+        const int rc = second_round_seed(c, ix, k2, C.d_codes.as<uint8_t>(), C.len, raw, C.tuples, C.batches);
+        if (rc == VM_READ_RAISED || rc == VM_READ_UNSUPPORTED || rc == VM_READ_CAPACITY) { C.fail(rc); continue; }
+        if (rc < 0) return rc;
+        for (size_t t = 0; t < C.batches.size(); ++t) {
+            dump_rows("second.bin", C.batches[t], t > 0);
+            n_a2 += (int64_t)C.batches[t].size();
+            if (C.batches[t].empty()) { C.fail(VM_READ_RAISED); break; }        // np.array([])[:, 0] (:22755)
+        }
+    }
+    lap(t_seed2);
+    VMX_TRY(run_round(true));
+    lap(t_dp2);
+    // ---- traceback, overlap trim (:23400-23412), ass_extend_func (:23414)
+    for (LongContig* Cn : G) {
+        LongContig& C = *Cn;
+        if (C.done) continue;
+        const int rc = C.r2.traceback(C.r2.have ? C.r2.pre_g_max_index : C.r1.pre_g_max_index, C.path2);
+        if (rc < 0) { C.fail(rc); continue; }
+        if (C.path2.size() <= 1) { C.done = true; continue; }
+        vmx_anchor pre = C.path2[0];
+        for (size_t x = 1; x < C.path2.size(); ++x) {            // against the UNtrimmed neighbour
+            const vmx_anchor now = C.path2[x];
+            const int nl = (int)now.l & 0xffff;
+            if (!(pre.q >= now.q + nl)) {
+                vmx_anchor t = now; t.l = (int16_t)(pre.q - now.q);
+                if (now.s != 1) t.r = now.r + nl - pre.q + now.q;
+                C.path2[x] = t;
+            }
+            pre = now;
+        }
+        dump_rows("path2.bin", C.path2);
+        const int64_t off1[2] = {0, C.len};
+        DevBuf d_off; struct Rel1 { DevBuf* a; ~Rel1() { a->release(); } } rel1{&d_off};
+        VMX_TRY(upload(d_off, off1, 2, c->stream));
+        std::vector<int64_t> h_off(off1, off1 + 2);
+        vmx_preset ps; ps.chain_desc = C.path2.data(); ps.len = (int64_t)C.path2.size();     // descending read order, as the extend stage takes a local chain
+        int32_t st1 = 0;
+        const int rce = align_device(c, mi, prm, 1, C.d_codes.as<uint8_t>(), d_off.as<int64_t>(), h_off, &C.recs, &C.n_recs, &C.blob, &st1, nullptr, nullptr, &ps);
+        if (rce < 0) return rce;
+        C.status = st1; C.done = true;
+        C.d_codes.release();
+    }
+    lap(t_ext);
+    if (timing) fprintf(stderr, "[asm] %zu contigs, %lld bases: windows+seed %.2f s, linked GC %.2f s (%lld anchors), re-seed %.2f s, linked LC %.2f s (%lld anchors), traceback+extend %.2f s\n",
+                        G.size(), (long long)bases, t_seed, t_dp1, (long long)n_a1, t_seed2, t_dp2, (long long)n_a2, t_ext);
+    return 0;
+}
+
+}  // namespace
+
 extern "C" int vm_align_asm(vm_ctx* c, const vm_index* mi, const vm_params* prm_in, const char* contig, int64_t len, int64_t split_len, int64_t batch_anchors, int64_t window,
                             vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status) {
     if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
@@ -303,128 +497,18 @@ extern "C" int vm_align_asm(vm_ctx* c, const vm_index* mi, const vm_params* prm_
     if (window <= 0) window = 100000;
     *recs = nullptr; *n_recs = 0; *cigar_blob = nullptr; *status = 0;
     VMX_HIP(hipSetDevice(c->device));
-    auto finish_empty = [&](int st) { *recs = (vm_record*)malloc(sizeof(vm_record)); *cigar_blob = (char*)malloc(1); *n_recs = 0; *status = st; return VM_OK; };
-    auto per_contig = [&](int rc) -> int {                       // a per-contig outcome (raised / unsupported / capacity) is a status, not a failed call
-        if (rc == VM_READ_RAISED || rc == VM_READ_UNSUPPORTED || rc == VM_READ_CAPACITY) return finish_empty(rc);
-        return rc;
-    };
-    const int64_t off1[2] = {0, len};
     if (len < split_len) {                                       // :23205: the fork's per-read function
-        vm_params p = *prm_in;
         if (len >= 500000) { set_error("vm_align_asm: split_len above the reference's 500000"); return VM_ERR_ARG; }
-        return vm_align_batch(c, mi, &p, 1, contig, off1, recs, n_recs, cigar_blob, status, nullptr);
+        const int64_t off1[2] = {0, len};
+        return vm_align_batch(c, mi, prm_in, 1, contig, off1, recs, n_recs, cigar_blob, status, nullptr);
     }
-    std::string seq(contig, (size_t)len);
-    for (char& ch : seq) if (ch >= 'a' && ch <= 'z') ch -= 32;
-    vm_index_view ix; vmx_index_view(mi, &ix);
-    // ---- first round :23214-23292
-    LinkRound r1;
-    VMX_TRY(r1.init(c, 0, ix.k, prm_in->global_skipcost, prm_in->global_maxdiff, 1000));
-    {
-        std::vector<std::vector<vmx_anchor>> cache; int64_t cache_size = 0;
-        std::vector<vmx_anchor> one;
-        auto flush = [&](std::vector<vmx_anchor>& batch) -> int {
-            std::stable_sort(batch.begin(), batch.end(), [](const vmx_anchor& a, const vmx_anchor& b) { return a.q < b.q; });
-            return r1.feed(batch);
-        };
-        const int64_t n_win = (len + window - 1) / window;
-        const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(256, ((int64_t)32 << 20) / window));
-        for (int64_t w0 = 0; w0 < n_win; w0 += chunk) {
-            const int64_t w1 = std::min(n_win, w0 + chunk);
-            std::vector<int64_t> woff((size_t)(w1 - w0) + 1);
-            for (int64_t w = w0; w <= w1; ++w) woff[(size_t)(w - w0)] = std::min(w * window, len) - w0 * window;
-            int64_t* anchors = nullptr; int64_t* aoff = nullptr;
-            VMX_TRY(vm_map_batch(c, mi, -1, -1, w1 - w0, seq.data() + w0 * window, woff.data(), &anchors, &aoff));      // :22419
-            for (int64_t w = w0; w < w1; ++w) {
-                const int64_t st = w * window;
-                one.clear();
-                for (int64_t i = aoff[w - w0]; i < aoff[w - w0 + 1]; ++i) { vmx_anchor a; a.q = (int32_t)(anchors[4 * i] + st); a.r = anchors[4 * i + 1]; a.s = (int16_t)anchors[4 * i + 2]; a.l = (int16_t)anchors[4 * i + 3]; one.push_back(a); }
-                // yield_mapinfo :22423-22438
-                if ((int64_t)one.size() + cache_size > batch_anchors) {
-                    if (cache_size > 0) {
-                        if (!one.empty()) cache.push_back(one);
-                        std::vector<vmx_anchor> all; for (auto& cc : cache) all.insert(all.end(), cc.begin(), cc.end());
-                        one.swap(all); cache_size = 0; cache.clear();
-                    }
-                    std::vector<vmx_anchor> batch = one;
-                    const int rc = flush(batch);
-                    if (rc < 0) { free(anchors); free(aoff); return per_contig(rc); }
-                } else if (!one.empty()) { cache.push_back(one); cache_size += (int64_t)one.size(); }
-            }
-            free(anchors); free(aoff);
-        }
-        if (cache_size > 0) {                                    // :22439-22443, including the second copy of the last window's anchors
-            if (!one.empty()) cache.push_back(one);
-            std::vector<vmx_anchor> all; for (auto& cc : cache) all.insert(all.end(), cc.begin(), cc.end());
-            const int rc = flush(all);
-            if (rc < 0) return per_contig(rc);
-        }
-    }
-    if (!r1.have) return finish_empty(VM_READ_RAISED);          // NameError: pre_g_max_index (:23278)
-    std::vector<vmx_anchor> path;
-    { const int rc = r1.traceback(r1.pre_g_max_index, path); if (rc < 0) return per_contig(rc); }
-    dump_rows("path1.bin", path);
-    if (path.size() <= 1) return finish_empty(0);
-    // ---- second round :23309-23396
-    const int k2 = prm_in->local_kmersize;
-    LinkRound r2;
-    VMX_TRY(r2.init(c, 1, k2, prm_in->local_skipcost, prm_in->local_maxdiff, 99));
-    DevBuf d_raw, d_codes;
-    struct Rel { DevBuf* a; DevBuf* b; ~Rel() { a->release(); b->release(); } } rel{&d_raw, &d_codes};
-    VMX_TRY(upload(d_raw, seq.data(), (size_t)len, c->stream)); VMX_TRY(d_codes.reserve((size_t)len + 64));
-    { const char* dr = d_raw.as<char>(); uint8_t* dc = d_codes.as<uint8_t>(); const int64_t nn = len; hipStream_t stq = c->stream;
-      hipLaunchKernelGGL(k_encode, dim3((unsigned)std::min<int64_t>((nn + 255) / 256, 65535)), dim3(256), 0, stq, dr, dc, nn); }
-    {
-        const std::vector<vmx_anchor> raw(path.rbegin(), path.rend());
-        const int64_t np_ = (int64_t)raw.size();
-        std::vector<Tuple> tuples;
-        int64_t st_read = 0, st_path = 0, iloc_path = 0;         // yield_second_mapinfo :22444-22476
-        for (int64_t x = 1; x < np_; ++x) {
-            const vmx_anchor& now = raw[(size_t)x];
-            iloc_path += 1;
-            if (iloc_path == np_ - 1 || (iloc_path < np_ - 1 && raw[(size_t)iloc_path + 1].q > raw[(size_t)iloc_path].q)) {
-                if (((int64_t)now.q + ((int)now.l & 0xffff)) > (st_read + window) && (iloc_path - st_path) > 300) {
-                    const int64_t en_read = raw[(size_t)iloc_path].q;
-                    tuples.push_back(Tuple{st_read, en_read, std::max<int64_t>(0, st_path - 20), std::min<int64_t>(iloc_path + 20, np_)});
-                    st_path = iloc_path + 1;
-                    st_read = en_read;
-                }
-            }
-        }
-        if (st_read < len) tuples.push_back(Tuple{st_read, len, std::max<int64_t>(0, st_path - 20), std::min<int64_t>(iloc_path + 20, np_)});
-        std::vector<std::vector<vmx_anchor>> second;
-        { const int rc = second_round_seed(c, ix, k2, d_codes.as<uint8_t>(), len, raw, tuples, second); if (rc < 0) return per_contig(rc); }
-        for (size_t t = 0; t < second.size(); ++t) {
-            dump_rows("second.bin", second[t], t > 0);
-            if (second[t].empty()) return finish_empty(VM_READ_RAISED);     // np.array([])[:, 0] (:22755)
-            const int rc = r2.feed(second[t]);
-            if (rc < 0) return per_contig(rc);
-        }
-    }
-    std::vector<vmx_anchor> path2;
-    { const int rc = r2.traceback(r2.have ? r2.pre_g_max_index : r1.pre_g_max_index, path2); if (rc < 0) return per_contig(rc); }
-    if (path2.size() <= 1) return finish_empty(0);
-    {   // :23400-23412 trim read overlaps against the UNtrimmed neighbour
-        vmx_anchor pre = path2[0];
-        for (size_t x = 1; x < path2.size(); ++x) {
-            const vmx_anchor now = path2[x];
-            const int nl = (int)now.l & 0xffff;
-            if (!(pre.q >= now.q + nl)) {
-                vmx_anchor t = now; t.l = (int16_t)(pre.q - now.q);
-                if (now.s != 1) t.r = now.r + nl - pre.q + now.q;
-                path2[x] = t;
-            }
-            pre = now;
-        }
-    }
-    dump_rows("path2.bin", path2);
-    // ---- ass_extend_func :23414 on the chain (descending read order, as the extend stage takes a local chain)
-    DevBuf d_off; struct Rel1 { DevBuf* a; ~Rel1() { a->release(); } } rel1{&d_off};
-    VMX_TRY(upload(d_off, off1, 2, c->stream));
-    std::vector<int64_t> h_off(off1, off1 + 2);
-    vmx_preset ps; ps.chain_desc = path2.data(); ps.len = (int64_t)path2.size();
-    const int rc = align_device(c, mi, prm_in, 1, d_codes.as<uint8_t>(), d_off.as<int64_t>(), h_off, recs, n_recs, cigar_blob, status, nullptr, nullptr, &ps);
-    return rc;
+    LongContig C; C.src = contig; C.len = len;
+    std::vector<LongContig*> G(1, &C);
+    VMX_TRY(asm_long_group(c, mi, prm_in, G, batch_anchors, window));
+    if (C.recs) { *recs = C.recs; *n_recs = C.n_recs; *cigar_blob = C.blob; }
+    else { *recs = (vm_record*)malloc(sizeof(vm_record)); *cigar_blob = (char*)malloc(1); *n_recs = 0; }
+    *status = C.status;
+    return VM_OK;
 }
 
 // vm_align_batch in VM_MODE_ASM with contigs of 500 kb and more in the batch: the shorter ones go through the batched path together, every long
@@ -447,13 +531,27 @@ int vmx_align_batch_asm_mixed(vm_ctx* c, const vm_index* mi, const vm_params* pr
         for (size_t i = 0; i < shorts.size(); ++i) st[(size_t)shorts[i]] = s0[i];
         free(r0); free(cb);
     }
-    for (int64_t r : longs) {
-        vm_record* r0 = nullptr; int64_t nr = 0; char* cb = nullptr; int32_t s1 = 0;
-        const int rc = vm_align_asm(c, mi, prm, seqs + offsets[r], offsets[r + 1] - offsets[r], 0, 0, 0, &r0, &nr, &cb, &s1);
-        if (rc < 0) { free(r0); free(cb); return rc; }
-        for (int64_t i = 0; i < nr; ++i) { vm_record x = r0[i]; x.cigar_off = (int64_t)pblob[(size_t)r].size(); pblob[(size_t)r].append(cb + r0[i].cigar_off, (size_t)r0[i].cigar_len); pblob[(size_t)r].push_back('\0'); per[(size_t)r].push_back(x); }
-        st[(size_t)r] = s1; tot.n_reads += 1; tot.read_bases += offsets[r + 1] - offsets[r]; tot.n_records += nr; if (s1 != 0) tot.n_failed += 1;
-        free(r0); free(cb);
+    // the long contigs side by side, in groups of at most 400 Mbases (their anchors wait in host memory between the rounds)
+    for (size_t g0 = 0; g0 < longs.size();) {
+        size_t g1 = g0; int64_t gb = 0;
+        while (g1 < longs.size() && (g1 == g0 || gb + (offsets[longs[g1] + 1] - offsets[longs[g1]]) <= (int64_t)400000000)) { gb += offsets[longs[g1] + 1] - offsets[longs[g1]]; ++g1; }
+        std::vector<std::unique_ptr<LongContig>> own; std::vector<LongContig*> G;
+        for (size_t i = g0; i < g1; ++i) {
+            const int64_t r = longs[i];
+            if (offsets[r + 1] - offsets[r] >= ((int64_t)1 << 31) - 64) { set_error("asm: contig of 2^31 bases or more"); return VM_ERR_UNSUPPORTED; }
+            own.emplace_back(new LongContig()); own.back()->src = seqs + offsets[r]; own.back()->len = offsets[r + 1] - offsets[r]; G.push_back(own.back().get());
+        }
+        const int rc = asm_long_group(c, mi, prm, G, 500000, 100000);
+        for (size_t i = g0; i < g1; ++i) {
+            const int64_t r = longs[i]; LongContig& C = *G[i - g0];
+            if (rc >= 0) {
+                for (int64_t x = 0; x < C.n_recs; ++x) { vm_record y = C.recs[x]; y.cigar_off = (int64_t)pblob[(size_t)r].size(); pblob[(size_t)r].append(C.blob + C.recs[x].cigar_off, (size_t)C.recs[x].cigar_len); pblob[(size_t)r].push_back('\0'); per[(size_t)r].push_back(y); }
+                st[(size_t)r] = C.status; tot.n_reads += 1; tot.read_bases += C.len; tot.n_records += C.n_recs; if (C.status != 0) tot.n_failed += 1;
+            }
+            free(C.recs); free(C.blob);
+        }
+        if (rc < 0) return rc;
+        g0 = g1;
     }
     std::vector<vm_record> all; std::string blob;
     for (int64_t r = 0; r < n; ++r) for (vm_record x : per[(size_t)r]) { x.read_idx = (int32_t)r; const int64_t o = x.cigar_off; x.cigar_off = (int64_t)blob.size(); blob.append(pblob[(size_t)r].data() + o, (size_t)x.cigar_len); blob.push_back('\0'); all.push_back(x); }
