@@ -32,8 +32,8 @@ typedef enum vm_status {
     VM_READ_RAISED = -10,       /* the reference's Python would have raised inside the per-read path */
     VM_READ_CAPACITY = -20,     /* a device work buffer overflowed for this read (reported, never silently truncated) */
     VM_READ_FASTPATH = -21,     /* internal hand-off to the `_fast` chain kernels (:23570, :24914, :27380); never returned by vm_align_batch */
-    VM_READ_UNSUPPORTED = -22   /* -mode asm only: a contig whose equal-score chains need the edlib tie-break of mammap_asm.py:21302-21326 (MAPQ 0),
-                                   or a long contig whose GC-exact bails out into the fork's linked GC-fast (:23246): reported, not approximated */
+    VM_READ_UNSUPPORTED = -22   /* -mode asm only: a contig whose equal-score chains need the edlib tie-break of mammap_asm.py:21302-21326 (MAPQ 0), or a
+                                   long contig whose carried slice leaves the stored part of the score index (k_chain_linked.hip): reported, not approximated */
 } vm_status;
 
 enum { VM_MODE_H = 0, VM_MODE_L = 1, VM_MODE_S = 2, VM_MODE_R = 3,   /* -mode (src/vacmap/vacmap:87) */
@@ -256,8 +256,7 @@ int vm_align_resident(vm_ctx*, const vm_index*, const vm_params*, const vm_reads
  * function (= vm_align_batch with VM_MODE_ASM), otherwise 100 kb seeding windows, chain DPs linked across batches of more than batch_anchors
  * anchors, the second linked round over 9-mer anchors, ass_extend_func. split_len / batch_anchors / window <= 0: the reference's 500000 / 500000 /
  * 100000 (tests shrink them to reach the linked path on small inputs; split_len may only be lowered). p->mode must be VM_MODE_ASM. *status: 0,
- * VM_READ_RAISED, VM_READ_CAPACITY or VM_READ_UNSUPPORTED (GC-exact's bail-out into the linked GC-fast, a carried slice outside the stored
- * index; include/vacmapx.h VM_MODE_ASM). The host runs the reference's loop (batch assembly, tracebacks, cut points); seeding, chain DPs,
+ * VM_READ_RAISED, VM_READ_CAPACITY or VM_READ_UNSUPPORTED (see that status). The host runs the reference's loop (batch assembly, tracebacks, cut points); seeding, chain DPs,
  * re-seeding and extension run on the device. */
 int vm_align_asm(vm_ctx*, const vm_index*, const vm_params* p, const char* contig, int64_t len, int64_t split_len, int64_t batch_anchors, int64_t window,
                  vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status);

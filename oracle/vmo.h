@@ -144,6 +144,9 @@ int vmo_align_asm(const vmo_index*, const char* contig, int64_t len, const vmo_p
  * ass_extend_func (ascending, read overlaps trimmed), 3 the second-round anchor batches (rows concatenated, off[n_off] batch ends) */
 int vmo_asm_trace(const vmo_index*, const char* contig, int64_t len, const vmo_params* p, int64_t split_len, int64_t batch_anchors, int64_t window,
                   int which, int64_t** rows, int64_t* n_rows, int64_t** off, int64_t* n_off);
+/* test hook: the bail-out factor of the asm fork's GC-exact (max_factor = 1000, mammap_asm.py:20623 / :21757); lowered by tests that need the
+ * linked path to take its GC-fast (:23246-23247) on inputs where the real factor is never reached */
+void vmo_test_asm_max_factor(double f);
 /* decode_hit of the fork (:21280; seeds the contig itself with p->check_num): MAPQ, signed score, the primary path */
 int vmo_decode_hit_asm(const vmo_index*, const char* contig, int64_t len, const vmo_params* p, vmo_chains* out);
 /* stage entry of the linked chain DPs (:21686 GC-exact, :21871 GC-fast, :21504 LC): which = 0 / 1 / 2. anchors sorted by q (rows of the

@@ -170,6 +170,7 @@ int64_t chain_global_exact(const std::vector<Anchor>& A, int kmersize, double os
 // (link != nullptr with n_pre > 0: S / P of the first n_pre rows are the carried state, the loop starts behind them, g_max_* and prereadloc come
 // from the caller) and the linked LC :21504-21685 (lc: co-linear steps also pay readgapcost_list[readgap] :16536 = the mode-R table; no
 // bail-out). A sorted by q (stable) behind the carried rows. Returns g_max_index, or -1 (bail-out :20623 / :21757).
+double g_asm_max_factor = 1000.0;     // max_factor (:20623); tests lower it to drive the linked path into its GC-fast (vmo_test_asm_max_factor)
 int64_t chain_exact_asm(const std::vector<Anchor>& A, int kmersize, double skipcost, int maxdiff, int maxgap, bool lc, const LinkState* link,
                         std::vector<double>& S, std::vector<int64_t>& P, std::vector<int64_t>& S_arg) {
     const Tables& T = tables();
@@ -192,7 +193,7 @@ int64_t chain_exact_asm(const std::vector<Anchor>& A, int kmersize, double skipc
         double max_scores = (double)A[i].l;
         int64_t pre_index = NOPRE;
         if (prereadloc < A[i].q) {
-            if (!lc && ((double)opcount / (double)i) > 1000.0) return -1;
+            if (!lc && ((double)opcount / (double)i) > g_asm_max_factor) return -1;
             for (int64_t k = testspace_en; k < i; ++k) {
                 const int64_t loc = insertpoint_score(S.data(), S[k], k, S_arg.data());
                 sarg_insert(S_arg.data(), loc, k);
@@ -412,6 +413,8 @@ int vmo_decode_hit(const int64_t* a, int64_t n, int64_t readlen, int kmersize, c
     for (size_t i = 0; i < cs.all_scores.size(); ++i) out->all_scores[i] = cs.all_scores[i];
     return 0;
 }
+
+void vmo_test_asm_max_factor(double f) { vmo::g_asm_max_factor = f; }
 
 void vmo_chains_free(vmo_chains* c) { free(c->path_off); free(c->path_anchors); free(c->all_scores); memset(c, 0, sizeof(*c)); }
 

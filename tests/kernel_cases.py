@@ -880,3 +880,44 @@ def check_asm_long_golden(ctx, O, cid='AS3', contigs=None, vs_golden=True):
             assert (st == 0) == (g['status'] == 0) and got == g['records'], (cid, g['name'], 'records differ from the reference golden')
         n_ok += 1
     return n_ok
+
+
+def check_asm_linked_fast_golden(ctx, O):
+    """the fork's GC-fast and its LINKED form on the device (k_chain_linked_fast, mammap_asm.py:20738 / :21871) against the direct calls of the
+    reference kept in golden AS4: S, P, the (int(S), diagonal)-ordered index, g_max_index; the carried state against the one the generator built"""
+    meta, arr = asm_golden()
+    d = meta['AS4']['direct']
+    r1 = ctx.chain_linked(arr['AS4_direct_first'], 1, 15, 30., 50, 1000)
+    assert r1['gmax'] == d['g1'] and np.array_equal(r1['S'].view(np.uint64), arr['AS4_direct_S1'].view(np.uint64))
+    assert np.array_equal(r1['P'], arr['AS4_direct_P1']) and np.array_equal(r1['S_arg_hot'], arr['AS4_direct_SA1'])
+    pre_S = arr['AS4_direct_preS']
+    assert r1['carry_status'] == 0 and r1['saved'] == 1 and r1['n_carry'] == d['n_pre']
+    assert np.array_equal(r1['carry_S'].view(np.uint64), pre_S.view(np.uint64)) and np.array_equal(r1['carry_P'], arr['AS4_direct_preP'])
+    assert np.array_equal(r1['carry_rows'], arr['AS4_direct_linked'][:d['n_pre']]) and r1['carry_prereadloc'] == d['prereadloc']
+    r2 = ctx.chain_linked(arr['AS4_direct_linked'], 1, 15, 30., 50, 1000, pre_S[-1], len(pre_S) - 1, pre_S, arr['AS4_direct_preP'], d['prereadloc'])
+    assert r2['gmax'] == d['g2'] and np.array_equal(r2['S'].view(np.uint64), arr['AS4_direct_S2'].view(np.uint64))
+    assert np.array_equal(r2['P'], arr['AS4_direct_P2']) and np.array_equal(r2['S_arg_hot'], arr['AS4_direct_SA2'])
+    return d['n_first'], d['n_linked']
+
+
+def check_asm_long_forced_fast(ctx, O, monkeypatch, cid='AS3', contig=2, factor=0.5):
+    """the bail-out route of the long-contig loop (mammap_asm.py:23246-23247): with max_factor lowered in the oracle and in the library (test hooks)
+    every first-round batch leaves GC-exact for the fork's linked GC-fast; records must equal the oracle's"""
+    from vacmap_amd.lib import align_asm
+    meta, arr = asm_golden()
+    c = meta[cid]
+    gi, oi = _asm_index(ctx, O, meta, arr, cid)
+    prm = ctx.lib.params('asm'); oprm = O.params('asm')
+    seq = arr['%s_c%d_seq' % (cid, contig)].tobytes().decode()
+    monkeypatch.setenv('VMX_TEST_ASM_MAX_FACTOR', str(factor))
+    O.lib().vmo_test_asm_max_factor(factor)
+    try:
+        O.fast_counters(reset=True)
+        ost, orecs = O.align_asm(oi, seq, oprm, *c['sizes'])
+        nfast = O.fast_counters()[0]
+        st, recs = align_asm(ctx, gi, prm, seq, *c['sizes'])
+    finally:
+        O.lib().vmo_test_asm_max_factor(1000.0)
+    assert nfast >= 2, nfast
+    assert (st == 0) == (ost == 0) and [t[1:] for t in recs] == [t[1:] for t in orecs], 'records differ from the oracle'
+    return nfast, len(recs)

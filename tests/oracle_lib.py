@@ -80,6 +80,7 @@ def lib():
     L.vmo_align_read.argtypes = [vp, cp, i64, P(Params), P(P(Record)), P(i64), P(vp)]
     L.vmo_align_batch.argtypes = [vp, P(Params), i64, cp, vp, C.c_int, P(P(Record)), P(i64), P(vp), vp]
     L.vmo_align_asm.argtypes = [vp, cp, i64, P(Params), i64, i64, i64, P(P(Record)), P(i64), P(vp)]
+    L.vmo_test_asm_max_factor.argtypes = [dbl]
     L.vmo_asm_trace.argtypes = [vp, cp, i64, P(Params), i64, i64, i64, C.c_int, P(P(i64)), P(i64), P(P(i64)), P(i64)]
     L.vmo_decode_hit_asm.argtypes = [vp, cp, i64, P(Params), P(Chains)]
     L.vmo_chain_linked_raw.argtypes = [vp, i64, C.c_int, C.c_int, dbl, C.c_int, C.c_int, dbl, i64, vp, vp, i64, i64, vp, vp, vp]

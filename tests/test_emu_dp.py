@@ -129,6 +129,7 @@ def test_emu_oom_degrades_to_sub_batches(ctx, oracle, golden, monkeypatch):
 def test_emu_mode_asm(ctx, oracle):
     """-mode asm, contigs below 500 kb (the fork's per-read function): records = the reference's goldens = the oracle's"""
     assert KC.check_asm_golden(ctx, oracle, cases=['AS1'], contigs=[3, 8, 9]) == 3       # 30 kb contig with an SV, unmappable, 900-base contig
+    assert KC.check_asm_golden(ctx, oracle, cases=['AS5'], contigs=[1]) == 1             # decode_hit's edlib tie-break between two near-identical copies
 
 
 def test_emu_asm_linked(ctx, oracle):
@@ -136,8 +137,14 @@ def test_emu_asm_linked(ctx, oracle):
     n_full, n_carry, _ = KC.check_asm_linked_golden(ctx, oracle, cases=['AS3'], max_calls=2)
     assert n_full[0] == 2 and n_full[2] == 2 and n_carry >= 2
     KC.check_asm_linked_noise(ctx, oracle, seed=5, noise_per_anchor=2, which=0)
+    KC.check_asm_linked_fast_golden(ctx, oracle)                 # the fork's GC-fast, plain and linked, against the reference's direct calls
 
 
 def test_emu_mode_asm_long_contig(ctx, oracle):
     """the long-contig loop of -mode asm (vm_align_asm) with shrunk sizes: linked first round, re-seeded second round, ass_extend_func"""
     assert KC.check_asm_long_golden(ctx, oracle, 'AS3', contigs=[2]) == 1
+
+
+def test_emu_mode_asm_long_contig_bail_out(ctx, oracle, monkeypatch):
+    """GC-exact's bail-out into the linked GC-fast inside the long-contig loop (mammap_asm.py:23246-23247), forced by the max_factor test hooks"""
+    KC.check_asm_long_forced_fast(ctx, oracle, monkeypatch)

@@ -327,6 +327,7 @@ def test_mode_asm(ctx, oracle):
     the fork's GC-fast) = the oracle's; 120 - 250 kb contigs (AS3) against the oracle run live; the 600 kb contig (AS2) takes the batch-linked path"""
     assert KC.check_asm_decode_hit(ctx, oracle) >= 12
     assert KC.check_asm_golden(ctx, oracle, cases=['AS1', 'AS4']) == 13
+    assert KC.check_asm_golden(ctx, oracle, cases=['AS5']) == 4       # MAPQ 0 between two near-identical copies: decode_hit's edlib tie-break (mammap_asm.py:21302-21326)
     assert KC.check_asm_golden(ctx, oracle, cases=['AS3'], vs_golden=False) == 3
     assert KC.check_asm_golden(ctx, oracle, cases=['AS2']) == 1       # the 600 kb contig: vm_align_batch hands it to the batch-linked path
 
@@ -337,6 +338,13 @@ def test_mode_asm_long_contigs(ctx, oracle):
     contigs with the shrunk sizes their goldens were made with (5-7 linked first-round batches each) — records = reference goldens = oracle"""
     assert KC.check_asm_long_golden(ctx, oracle, 'AS3') == 3
     assert KC.check_asm_long_golden(ctx, oracle, 'AS2') == 1
+
+
+def test_mode_asm_long_contig_bail_out(ctx, oracle, monkeypatch):
+    """GC-exact's bail-out into the fork's linked GC-fast inside the long-contig loop (mammap_asm.py:23246-23247; the real max_factor of 1000 is out of
+    reach under the index's occurrence cap, so the test hooks of oracle and library lower it): records = the oracle's"""
+    for ci in (0, 1, 2):
+        KC.check_asm_long_forced_fast(ctx, oracle, monkeypatch, contig=ci)
 
 
 def test_mode_asm_linked_dp(ctx, oracle):
@@ -351,3 +359,4 @@ def test_mode_asm_linked_dp(ctx, oracle):
     print('linked GC-exact, %d anchors: %.2f s incl. the oracle' % (nc + nh, time.time() - t0))
     KC.check_asm_linked_noise(ctx, oracle, seed=6, noise_per_anchor=3, which=2)
     KC.check_asm_linked_noise(ctx, oracle, seed=7, noise_per_anchor=8, which=0, contig=0)
+    KC.check_asm_linked_fast_golden(ctx, oracle)                 # the fork's GC-fast, plain and linked (k_chain_linked_fast), against the reference's direct calls

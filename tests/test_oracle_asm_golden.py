@@ -23,7 +23,7 @@ def check_records(ix, recs, want, tag):
     assert got == want, '%s: records differ from the reference' % tag
 
 
-@pytest.mark.parametrize('cid', ['AS1', 'AS2', 'AS3', 'AS4'])
+@pytest.mark.parametrize('cid', ['AS1', 'AS2', 'AS3', 'AS4', 'AS5'])
 def test_asm_records(gold, cid):
     """V6a: the 9-tuples of assembly_get_readmap_DP_test (mammap_asm.py:23204), per-read function and linked path, reference sizes and shrunk ones"""
     meta, arr = gold
@@ -43,7 +43,7 @@ def test_asm_records(gold, cid):
 def test_asm_decode_hit(gold):
     """V2a: decode_hit of the fork (:21280): MAPQ, signed score, primary path; AS4 goes through its GC-fast (:20738)"""
     meta, arr = gold
-    for cid in ('AS1', 'AS4'):
+    for cid in ('AS1', 'AS4', 'AS5'):
         ix = case_index(meta, arr, cid)
         prm = O.params('asm')
         O.fast_counters(reset=True)

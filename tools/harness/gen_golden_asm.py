@@ -9,7 +9,8 @@ tests/golden/asm.npz + asm.json. Per case: the reference contigs, the assembly c
 Cases: AS1 contigs below 500 kb (the module's get_readmap_DP_test, check_num = -1); AS2 a 600 kb contig with the reference's constants (one
 first-round batch, six linked second-round batches); AS3 the same function with its three size constants shrunk IN MEMORY (split 100000, batch
 6000 anchors, window 20000: many linked first-round batches, the final-flush duplicate of yield_mapinfo :22439-22443); AS4 a repeat-dense
-contig (GC-fast of the fork :20738) and a direct call of the linked GC-fast (:21871) on a carried state built the way :23254-23272 builds it.
+contig (GC-fast of the fork :20738) and a direct call of the linked GC-fast (:21871) on a carried state built the way :23254-23272 builds it;
+AS5 contigs that fit two near-identical copies of a segment equally well (MAPQ 0: decode_hit's edlib tie-break :21302-21326).
 """
 import inspect, json, os, re, shutil, sys, tempfile, zlib
 import numpy as np
@@ -191,6 +192,22 @@ def main():
     arrays['AS4_direct_linked'] = linked; arrays['AS4_direct_preS'] = np.asarray(pre_S, np.float64); arrays['AS4_direct_preP'] = np.asarray(pre_P, np.int64)
     arrays['AS4_direct_S2'] = np.asarray(S2, np.float64); arrays['AS4_direct_P2'] = np.asarray(P2, np.int64); arrays['AS4_direct_SA2'] = np.asarray(SA2, np.int64)
     meta['AS4']['direct'] = {'g1': int(g1), 'g2': int(g2), 'prereadloc': prl, 'n_first': int(len(first)), 'n_linked': int(len(linked)), 'n_pre': int(len(pre_S))}
+    # ---- AS5: decode_hit's edlib tie-break (:21302-21326): a 40 kb segment and a copy of it with 1 - 3 substitutions; contigs cut from inside
+    # either copy (0.3 % errors, both strands) score within 0.1 % on both placements -> MAPQ 0 -> the least divergent placement wins
+    l5 = []
+    r5 = synth.make_reference([400000], seed=400)[0]
+    seg = r5[50000:90000].copy()
+    rng = np.random.default_rng(401)
+    cp = seg.copy()
+    for p_ in rng.integers(1000, 39000, 3):
+        cp[p_] = ord('ACGT'[(b'ACGT'.index(bytes([cp[p_]])) + 1) % 4])
+    r5[250000:290000] = cp
+    for i, (a_, b_, rcflag) in enumerate([(50500, 89500, 0), (250800, 289000, 0), (52000, 88000, 1), (251500, 289500, 1)]):
+        sq = synth.mutate(r5[a_:b_], 0.003, rng)
+        if rcflag:
+            sq = synth.revcomp(sq)
+        l5.append(('dup%d' % i, synth.tostr(sq)))
+    run_case('AS5', ['chrD'], [synth.tostr(r5)], l5, arrays, meta)
     np.savez_compressed(os.path.join(GOLD, 'asm.npz'), **arrays)
     json.dump(meta, open(os.path.join(GOLD, 'asm.json'), 'w'), indent=0, sort_keys=True)
     print('asm goldens:', {k: len(v['contigs']) for k, v in meta.items()}, 'npz bytes', os.path.getsize(os.path.join(GOLD, 'asm.npz')),

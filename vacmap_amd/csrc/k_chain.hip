@@ -420,9 +420,8 @@ __global__ void __launch_bounds__(64) k_chain_select(const vmx_anchor* __restric
             if (fit) nsec = vmx_select_rank(nch, mode, l_cscore, l_coff, l_cq, S + a0, W.cidx, l_order, l_bins, l_boff, l_prim, l_sec, &mapq, &pidx);
             else nsec = vmx_select_rank(nch, mode, W.cscore, W.coff, W.cq, S + a0, W.cidx, W.order, W.bins, W.boff, W.prim, W.sec, &mapq, &pidx);
             const double sc = fit ? l_cscore[pidx] : W.cscore[pidx];
-            if (nsec == -2) {                          // -mode asm: the edlib tie-break among equal chains is not built (vmx_select.h)
-                out_mapq[r] = 0; out_score[r] = need_reverse[r] ? -0.0 : 0.0; out_npaths[r] = 0;
-                const_cast<int64_t*>(gmax)[r] = -3;
+            if (nsec == -2) {                          // -mode asm: decode_hit's edlib tie-break among equal chains is made by the host (vmx_asm_resolve_ties)
+                out_mapq[r] = 0; out_score[r] = need_reverse[r] ? -0.0 : 0.0; out_npaths[r] = -7;
             } else { out_mapq[r] = mapq; out_score[r] = need_reverse[r] ? -sc : sc; out_npaths[r] = nsec + 1; }
             s_hdr[2] = nsec; s_hdr[3] = pidx;
         }

@@ -17,6 +17,7 @@
 #include "vmx_device.h"
 #include "vmx_kernels.h"
 #include "vmx_local.h"
+#include "vmx_link.h"
 
 struct vmx_fast_io {
     const vmx_anchor* A; int n;
@@ -173,8 +174,11 @@ __device__ __forceinline__ bool vmx_fast_eval(const vmx_anchor& ai, const vmx_an
 
 // the DP. returns g_max_index (>= 0), -4 (the reference would not terminate: LC-fast's `continue` in the large-bucket branch,
 // :27103-27104) or -5 (an integer score outside S_i_count: IndexError in the reference). *gmax_score gets the best score.
+// lk (VARIANT 4 only): the LINKED form, mammap_asm.py:21871-22158 — S / P of the first lk->n_pre rows are the carried state (already in io.S /
+// io.P), S_i = int(pre_S), the bucket index starts with row 0 alone and max_score_i = S_i[0] (:21893-21901), the loop starts behind the carried rows
+struct vmx_fast_link { int n_pre; double g_max_scores; int g_max_index; long long prereadloc; };
 template <int VARIANT>
-__device__ int vmx_fast_dp(const vmx_fast_io& io, vmx_fast_cost C, const double* gapcost_list, double oskipcost, int omaxdiff, double* gmax_score) {
+__device__ int vmx_fast_dp(const vmx_fast_io& io, vmx_fast_cost C, const double* gapcost_list, double oskipcost, int omaxdiff, double* gmax_score, const vmx_fast_link* lk = nullptr) {
     const int lane = vmx_lane();
     const int n = io.n;
     const vmx_anchor* A = io.A;
@@ -197,12 +201,23 @@ __device__ int vmx_fast_dp(const vmx_fast_io& io, vmx_fast_cost C, const double*
     C.gapcost = gapcost_list; C.skipcost = oskipcost; C.maxdiff = omaxdiff;
     int testspace_en_i = 1;
     if ((int)a0.l >= io.cnt_n) return -5;
-    if (lane == 0) { io.SA[0] = 0; io.S[0] = (double)a0.l; io.Si[0] = a0.l; io.P[0] = VMX_NOPRE; io.CNT[a0.l] = 1; if (VARIANT == 3) { io.FP[0] = 0.0; io.PP[0] = 0.0; } }
+    const bool linked = VARIANT == 4 && lk && lk->n_pre > 0;
+    if (lane == 0) { io.SA[0] = 0; if (!linked) { io.S[0] = (double)a0.l; io.P[0] = VMX_NOPRE; } io.Si[0] = a0.l; io.CNT[a0.l] = 1; if (VARIANT == 3) { io.FP[0] = 0.0; io.PP[0] = 0.0; } }
     __syncthreads();
     double g_max_scores = (double)a0.l; int g_max_index = 0;
     int max_score_i = 0;
     int err = 0;
-    for (int i = 1; i < n && !err; ++i) {
+    int pre_size = 1;
+    if (VARIANT == 4 && lk && lk->n_pre > 0) {
+        for (int i = lane; i < lk->n_pre; i += 64) io.Si[i] = (int32_t)(long long)io.S[i];
+        __syncthreads();
+        const int s0 = io.Si[0];
+        if (s0 < 0 || s0 >= io.cnt_n) return -5;
+        if (lane == 0) { io.CNT[a0.l] = 0; io.CNT[s0] = 1; }
+        __syncthreads();
+        pre_size = lk->n_pre; g_max_scores = lk->g_max_scores; g_max_index = lk->g_max_index; prereadloc = lk->prereadloc; max_score_i = s0;
+    }
+    for (int i = pre_size; i < n && !err; ++i) {
         const vmx_anchor ai = A[i];
         const long long pos_i = GC ? (long long)ai.q : (long long)ai.q + ai.l;
         if (prereadloc < pos_i) {
@@ -368,5 +383,31 @@ __global__ void __launch_bounds__(64) k_chain_local_fast(const vmx_anchor* __res
             out_len[rd] = w; out_score[rd] = gs; status[rd] = 0;
         }
         out_variant[rd] = mm ? 1 : 0;
+    }
+}
+
+
+// -mode asm, contigs of 500 kb and more: the batches whose linked GC-exact bailed out (k_chain_linked left gmax = -1, mammap_asm.py:23246-23247)
+// are chained again with the fork's linked GC-fast (:21871-22158). One wavefront per job; jobs that did not bail out return at once.
+__global__ void __launch_bounds__(64) k_chain_linked_fast(vmx_link_job* __restrict__ jobs, int n_jobs, vmx_tables tab, const double* __restrict__ gapcost_list,
+                                                         double skipcost, int maxdiff, int maxgap) {
+    const int lane = vmx_lane();
+    for (int jb = (int)blockIdx.x; jb < n_jobs; jb += (int)gridDim.x) {
+        vmx_link_job& J = jobs[jb];
+        vmx_link_state& ST = *J.state;
+        if (!J.ran || J.gmax != -1 || ST.status != 0 || !J.Si) continue;
+        const int n_pre = ST.n_pre, base = J.cap_pre - n_pre, n = n_pre + J.n_new;
+        vmx_fast_io io;
+        io.A = J.rows + base; io.n = n; io.S = J.S + base; io.P = J.P + base; io.SA = J.SA; io.Si = J.Si; io.T = J.T; io.CNT = J.CNT; io.cnt_n = io.A[n - 1].q + 50;
+        io.COV = nullptr; io.FP = nullptr; io.PP = nullptr;
+        for (int i = lane; i < n_pre; i += 64) { io.S[i] = ST.pre_S[i]; io.P[i] = ST.pre_P[i]; }
+        __syncthreads();
+        vmx_fast_cost C; C.gapcost = gapcost_list; C.rgc = nullptr; C.tab = tab; C.skipcost = skipcost; C.maxdiff = maxdiff; C.maxgap = maxgap;
+        C.extra_size = (long long)tab.extra_n - 1; C.l2c_size = (long long)tab.log2cache_n - 1;
+        vmx_fast_link lk; lk.n_pre = n_pre; lk.g_max_scores = ST.g_max_scores; lk.g_max_index = ST.g_max_index; lk.prereadloc = ST.prereadloc;
+        double gs = 0.0;
+        const int g = vmx_fast_dp<4>(io, C, gapcost_list, skipcost, maxdiff, &gs, &lk);
+        if (lane == 0) { J.gmax = g >= 0 ? g : -2; J.n = n; J.hot = n; J.n_cold = 0; J.cold_max = -1e300; }      // -2: the reference raises (an integer score outside S_i_count)
+        __syncthreads();
     }
 }

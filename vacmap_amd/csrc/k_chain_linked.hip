@@ -64,7 +64,7 @@ __device__ __forceinline__ void vmx_link_sa_insert(int32_t* SA, int loc, int cnt
 
 // one batch of one contig per workgroup (one wavefront)
 __global__ void __launch_bounds__(64) k_chain_linked(vmx_link_job* __restrict__ jobs, int n_jobs, vmx_tables tab, const double* __restrict__ gapcost_list,
-                                                    double skipcost, int maxdiff, int maxgap, int lc, double margin_base) {
+                                                    double skipcost, int maxdiff, int maxgap, int lc, double margin_base, double max_factor) {
     __shared__ double s_gapcost[64];
     const int lane = vmx_lane();
     for (int x = lane; x <= maxdiff && x < 64; x += 64) s_gapcost[x] = gapcost_list[x];
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(64) k_chain_linked(vmx_link_job* __restrict__ 
             const vmx_anchor ai = A[i];
             const int qi = ai.q, li = (int)ai.l & 0xffff, si = (int)ai.s; const long long ri = ai.r;
             if (prereadloc < (long long)qi) {
-                if (!lc && ((double)opcount / (double)i) > 1000.0) { bailed = true; break; }     // :21757 max_factor
+                if (!lc && ((double)opcount / (double)i) > max_factor) { bailed = true; break; }     // :21757 max_factor (1000; a test hook lowers it)
                 for (int k = testspace_en; k < i; ++k) index_anchor(k);
                 testspace_en = i;
                 prereadloc = qi;
@@ -186,17 +186,24 @@ __global__ void __launch_bounds__(64) k_link_carry(vmx_link_job* __restrict__ jo
         const vmx_anchor* A = J.rows + base;
         const double* S = J.S + base; const int32_t* P = J.P + base; const int32_t* SA = J.SA;
         const int n = J.n, hot = J.hot;
-        if (J.gmax < 0) { if (lane == 0) ST.status = VM_LINK_BAILED; continue; }         // GC-exact bailed out: the fork's linked GC-fast is not on the device
+        if (J.gmax == -2) { if (lane == 0) ST.status = VM_LINK_RAISED; continue; }        // the linked GC-fast ran into the reference's IndexError
+        if (J.gmax < 0) { if (lane == 0) ST.status = VM_LINK_BAILED; continue; }         // GC-exact bailed out: the host re-runs the batch with k_chain_linked_fast
         if (lane == 0) { ST.pre_g_max_index = (int)J.gmax; ST.have = 1; ST.last_base = base; ST.last_n = n; }
         if (P[J.gmax] < 0) { if (lane == 0) J.saved = 0; continue; }                        // :23250 `continue`: nothing carried, nothing saved
         if (n - 1 <= 0) { if (lane == 0) ST.status = VM_LINK_RAISED; continue; }            // raise Exception("ERROR: ") :23266
         const double top = S[SA[hot - 1]];
         const double lowest = top - skipcost - 36 - 20;
-        // sliceiloc: walk down from the top while lowestscores < S[S_arg[sliceiloc]] (stops at index 0 of the FULL index)
-        const int cnt = vmx_sorted_count(S, SA, hot, lowest, true, lane);        // hot entries with S <= lowest
-        int slice;                                                                // hot position of S_arg[sliceiloc]
+        // sliceiloc: walk down from the top while lowestscores < S[S_arg[sliceiloc]]; it stops at the first entry at or below that score, or at
+        // index 0 of the FULL index. A literal walk, 64 entries per step (after the linked GC-fast the index is ordered by (int(S), diagonal), not by S)
+        int slice = -1;
+        for (int bs = hot - 1; bs >= 0 && slice < 0; bs -= 64) {
+            const int x = bs - lane;
+            const bool stop = x >= 0 && !(lowest < S[SA[x]]);
+            const unsigned long long m = __ballot(stop);
+            if (m) slice = bs - (__ffsll((unsigned long long)m) - 1);
+        }
         bool ok = true;
-        if (cnt > 0) { slice = cnt - 1; if (J.n_cold > 0 && !(S[SA[slice]] > J.cold_max)) ok = false; }
+        if (slice >= 0) { if (J.n_cold > 0 && !(S[SA[slice]] > J.cold_max)) ok = false; }
         else { if (J.n_cold > 0) ok = false; slice = 0; }                          // the walk would run into the cold entries / stops at index 0
         const int n_carry = hot - slice;
         if (!ok || n_carry > ST.cap_pre) { if (lane == 0) ST.status = VM_LINK_UNSUPPORTED; continue; }

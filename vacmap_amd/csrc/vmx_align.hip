@@ -177,6 +177,9 @@ static int ext_gather_round(vm_ctx* c, vmx_batch_bufs& B, const vm_index_view& i
 // diagnostic capture for the stage tests (vm_align_trace): the segment lists of every read as they stand after one phase of the
 // extend stage in the first (filtering) pass: rows (segment, q, r, s, l), off[n + 1]
 struct vmx_seg_trace { int stage; std::vector<int64_t> rows, off; };
+int vmx_asm_resolve_ties(vm_ctx* c, const vm_index* mi, int64_t n, const std::vector<int64_t>& h_roff, const std::vector<int64_t>& h_aoff, const uint8_t* d_codes,
+                         const vmx_anchor* d_sorted, const double* d_S, const int32_t* d_P, const int32_t* d_SA, const int64_t* d_gmax, const int32_t* d_flip,
+                         int32_t* d_mapq, double* d_gscore, int32_t* d_np, int32_t* d_plen, vmx_anchor* d_prow, std::vector<int32_t>& status_override);
 int vmx_align_batch_asm_mixed(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const char* seqs, const int64_t* offsets, vm_record** recs, int64_t* n_recs,
                               char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats);
 int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
@@ -196,6 +199,7 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     if (n == 0) { *recs = (vm_record*)malloc(sizeof(vm_record)); *cigar_blob = (char*)malloc(1); if (stats) *stats = st; return VM_OK; }
 
     std::vector<int64_t> h_aoff((size_t)n + 1, 0);
+    std::vector<int32_t> asm_override;                           // -mode asm: per-contig status set by the tie-break step
     const int rmode = prm->mode == VM_MODE_R ? 1 : (prm->mode == VM_MODE_ASM ? 2 : 0);      // the GC kernels' variant: H / L / S, R, the asm fork
     double* d_gscore = nullptr; int32_t* d_mapq = nullptr; int32_t* d_np = nullptr;
     vmx_local_bufs& L = *vmx_ctx_local_bufs(c);
@@ -292,6 +296,9 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     VMX_TRY(B.plen.reserve(4 * (size_t)(tot + 1))); VMX_TRY(B.prow.reserve(sizeof(vmx_anchor) * (size_t)(tot + 1)));
     VMX_TRY(vmx_launch_chain_select(c, n, h_aoff.data(), B.sellist, B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(), B.lens.as<int64_t>(), B.S.as<double>(), B.P.as<int32_t>(), B.SA.as<int32_t>(),
                                     B.gmax.as<int64_t>(), B.flip.as<int32_t>(), prm->mode, B.scr.as<char>(), B.soff.as<int64_t>(), d_mapq, d_gscore, d_np, B.plen.as<int32_t>(), B.prow.as<vmx_anchor>()));
+    if (prm->mode == VM_MODE_ASM)        // decode_hit's edlib tie-break among equal chains (mammap_asm.py:21302-21326): marked contigs are settled here
+        VMX_TRY(vmx_asm_resolve_ties(c, mi, n, h_roff, h_aoff, d_codes, B.sorted.as<vmx_anchor>(), B.S.as<double>(), B.P.as<int32_t>(), B.SA.as<int32_t>(), B.gmax.as<int64_t>(),
+                                     B.flip.as<int32_t>(), d_mapq, d_gscore, d_np, B.plen.as<int32_t>(), B.prow.as<vmx_anchor>(), asm_override));
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));
 
     // ---------------- orient + L1-L4 local stage
@@ -584,7 +591,8 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     for (int64_t r = 0; r < n; ++r) {
         int stt2 = er[r].status;
         if (h_gmax[r] == -2 && (h_aoff[r + 1] - h_aoff[r]) > 2) stt2 = VM_READ_RAISED;     // GC-fast: the reference raises on this read (k_chain_fast.hip)
-        if (h_gmax[r] == -3 || h_gmax[r] == -4) stt2 = VM_READ_UNSUPPORTED;                // -mode asm: edlib tie-break among equal chains / contig of 500 kb or more (vacmapx.h)
+        if (h_gmax[r] == -4) stt2 = VM_READ_UNSUPPORTED;                                    // -mode asm: a contig of 500 kb or more inside align_device (vm_align_batch routes those to vmx_asm.hip)
+        if (!asm_override.empty() && asm_override[(size_t)r] != 0) stt2 = asm_override[(size_t)r];
         if (rmode == 1 && (h_aoff[r + 1] - h_aoff[r]) <= 2) stt2 = VM_READ_RAISED;              // mode R returns an unbound `factor` for <= 2 anchors (mammap_noprefercloser.py:24417)
         if (status_per_read) status_per_read[r] = stt2;
         if (stt2 != 0) { st.n_failed++; continue; }

@@ -6,9 +6,12 @@
 
 using namespace vmx;
 
-__global__ void k_chain_linked(vmx_link_job* jobs, int n_jobs, vmx_tables tab, const double* gapcost_list, double skipcost, int maxdiff, int maxgap, int lc, double margin_base);
+__global__ void k_chain_linked(vmx_link_job* jobs, int n_jobs, vmx_tables tab, const double* gapcost_list, double skipcost, int maxdiff, int maxgap, int lc, double margin_base, double max_factor);
+// max_factor of the fork's GC-exact (mammap_asm.py:21757). Test hook VMX_TEST_ASM_MAX_FACTOR: a lower value drives batches into the linked GC-fast
+static double asm_max_factor() { const char* e = getenv("VMX_TEST_ASM_MAX_FACTOR"); return e ? atof(e) : 1000.0; }
 __global__ void k_link_carry(vmx_link_job* jobs, int n_jobs, double skipcost);
 __global__ void k_link_place(vmx_link_job* jobs, int n_jobs);
+__global__ void k_chain_linked_fast(vmx_link_job* jobs, int n_jobs, vmx_tables tab, const double* gapcost_list, double skipcost, int maxdiff, int maxgap);
 
 namespace {
 struct Bufs { Bufs() = default; Bufs(const Bufs&) = delete; DevBuf st, preS, preP, preR, rows, S, P, SA, job, gap; ~Bufs() { st.release(); preS.release(); preP.release(); preR.release(); rows.release(); S.release(); P.release(); SA.release(); job.release(); gap.release(); } };
@@ -23,7 +26,7 @@ extern "C" void vm_linked_out_free(vm_linked_out* o) {
 extern "C" int vm_chain_linked(vm_ctx* c, int which, int kmersize, double skipcost, int maxdiff, int maxgap, int64_t n, const int64_t* rows, int64_t n_pre,
                                const double* pre_S, const int64_t* pre_P, double g_max_scores, int64_t g_max_index, int64_t prereadloc, vm_linked_out* out) {
     if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
-    if (!out || n <= 0 || n_pre < 0 || n_pre >= n || (which != 0 && which != 2) || maxdiff > 62) { set_error("vm_chain_linked: bad arguments"); return VM_ERR_ARG; }
+    if (!out || n <= 0 || n_pre < 0 || n_pre >= n || which < 0 || which > 2 || maxdiff > 62) { set_error("vm_chain_linked: bad arguments"); return VM_ERR_ARG; }
     memset(out, 0, sizeof(*out));
     VMX_HIP(hipSetDevice(c->device));
     const int lc = which == 2;
@@ -57,10 +60,16 @@ extern "C" int vm_chain_linked(vm_ctx* c, int which, int kmersize, double skipco
     vmx_link_job hj; memset(&hj, 0, sizeof hj);
     hj.state = B.st.as<vmx_link_state>(); hj.rows = B.rows.as<vmx_anchor>(); hj.S = B.S.as<double>(); hj.P = B.P.as<int32_t>(); hj.SA = B.SA.as<int32_t>();
     hj.cap_pre = cap_pre; hj.n_new = (int32_t)n_new;
+    DevBuf fSi, fT, fCNT; struct RelF { DevBuf *a, *b, *c3; ~RelF() { a->release(); b->release(); c3->release(); } } relf{&fSi, &fT, &fCNT};
+    if (which == 1) {                                            // the fork's linked GC-fast on its own (:21871; with n_pre = 0 its plain GC-fast, :20738)
+        VMX_TRY(fSi.reserve(4 * tot)); VMX_TRY(fT.reserve(8 * tot)); VMX_TRY(fCNT.reserve(4 * ((size_t)hr.back().q + 50 + 64)));
+        hj.Si = fSi.as<int32_t>(); hj.T = fT.as<int64_t>(); hj.CNT = fCNT.as<int32_t>(); hj.ran = 1; hj.gmax = -1;
+    }
     VMX_TRY(upload(B.job, &hj, 1, c->stream));
     vmx_link_job* d_job = B.job.as<vmx_link_job>(); const double* d_gap = B.gap.as<double>(); const vmx_tables tabs = c->tables; hipStream_t stq = c->stream;
     hipLaunchKernelGGL(k_link_place, dim3(1), dim3(256), 0, stq, d_job, 1);
-    hipLaunchKernelGGL(k_chain_linked, dim3(1), dim3(64), 0, stq, d_job, 1, tabs, d_gap, skipcost, maxdiff, maxgap, lc, margin_base);
+    if (which == 1) hipLaunchKernelGGL(k_chain_linked_fast, dim3(1), dim3(64), 0, stq, d_job, 1, tabs, d_gap, skipcost, maxdiff, maxgap);
+    else hipLaunchKernelGGL(k_chain_linked, dim3(1), dim3(64), 0, stq, d_job, 1, tabs, d_gap, skipcost, maxdiff, maxgap, lc, margin_base, asm_max_factor());
     hipLaunchKernelGGL(k_link_carry, dim3(1), dim3(64), 0, stq, d_job, 1, skipcost);
     VMX_TRY(download(&hj, B.job.p, 1, c->stream)); VMX_TRY(download(&hs, B.st.p, 1, c->stream));
     VMX_HIP(vmx_stream_sync(c));
@@ -111,11 +120,11 @@ namespace {
 
 struct LinkRound {
     vm_ctx* c = nullptr; int lc = 0, kmersize = 15, maxdiff = 50, maxgap = 1000, cap_pre = 4096; double skipcost = 30., margin_base = 0.;
-    DevBuf st, preS, preP, preR, rows, S, P, SA, job, gap;
+    DevBuf st, preS, preP, preR, rows, S, P, SA, job, gap, fSi, fT, fCNT;
     std::vector<std::vector<vmx_anchor>> saved_rows; std::vector<std::vector<int32_t>> saved_P;
     int64_t pre_g_max_index = 0; bool have = false; int cur_n_pre = 0;
     LinkRound() = default; LinkRound(const LinkRound&) = delete;
-    ~LinkRound() { for (DevBuf* b : {&st, &preS, &preP, &preR, &rows, &S, &P, &SA, &job, &gap}) b->release(); }
+    ~LinkRound() { for (DevBuf* b : {&st, &preS, &preP, &preR, &rows, &S, &P, &SA, &job, &gap, &fSi, &fT, &fCNT}) b->release(); }
     int init(vm_ctx* ctx, int lc_, int k, double skip, int md, int mg) {
         c = ctx; lc = lc_; kmersize = k; skipcost = skip; maxdiff = md; maxgap = mg;
         if (md > 62) { set_error("maxdiff > 62 unsupported"); return VM_ERR_UNSUPPORTED; }
@@ -194,14 +203,40 @@ int run_jobs(vm_ctx* c, DevBuf& d_jobs, const std::vector<LinkRound*>& rounds, c
     VMX_TRY(upload(d_jobs, hj.data(), nj, c->stream));
     const LinkRound& R0 = *rounds[0];
     vmx_link_job* dj = d_jobs.as<vmx_link_job>(); const double* d_gap = R0.gap.as<double>(); const vmx_tables tabs = c->tables; hipStream_t stq = c->stream;
-    const double sk = R0.skipcost, mb = R0.margin_base; const int md = R0.maxdiff, mg = R0.maxgap, l = R0.lc, n_jobs = (int)nj;
+    const double sk = R0.skipcost, mb = R0.margin_base, mf = asm_max_factor(); const int md = R0.maxdiff, mg = R0.maxgap, l = R0.lc, n_jobs = (int)nj;
     hipLaunchKernelGGL(k_link_place, dim3((unsigned)nj), dim3(256), 0, stq, dj, n_jobs);
-    hipLaunchKernelGGL(k_chain_linked, dim3((unsigned)nj), dim3(64), 0, stq, dj, n_jobs, tabs, d_gap, sk, md, mg, l, mb);
+    hipLaunchKernelGGL(k_chain_linked, dim3((unsigned)nj), dim3(64), 0, stq, dj, n_jobs, tabs, d_gap, sk, md, mg, l, mb, mf);
     hipLaunchKernelGGL(k_link_carry, dim3((unsigned)nj), dim3(64), 0, stq, dj, n_jobs, sk);
     VMX_TRY(download(hj.data(), d_jobs.p, nj, c->stream));
     for (size_t i = 0; i < nj; ++i) VMX_TRY(download(&hs[i], rounds[i]->st.p, 1, c->stream));
     VMX_HIP(vmx_stream_sync(c));
     VMX_HIP(hipGetLastError());
+    // :23246-23247: a batch whose linked GC-exact bailed out (opcount / i > 1000: repeat arrays) is chained again with the fork's linked GC-fast
+    if (!R0.lc) {
+        std::vector<size_t> bailed;
+        for (size_t i = 0; i < nj; ++i) if (hs[i].status == VM_LINK_BAILED && hj[i].ran && hj[i].gmax == -1) bailed.push_back(i);
+        if (!bailed.empty()) {
+            std::vector<vmx_link_job> fj(bailed.size());
+            for (size_t b = 0; b < bailed.size(); ++b) {
+                const size_t i = bailed[b]; LinkRound& R = *rounds[i];
+                const size_t tot = (size_t)R.cap_pre + news[i]->size();
+                const size_t cnt_n = (size_t)news[i]->back().q + 50 + 64;
+                VMX_TRY(R.fSi.reserve(4 * tot)); VMX_TRY(R.fT.reserve(8 * tot)); VMX_TRY(R.fCNT.reserve(4 * cnt_n));
+                hs[i].status = 0;
+                VMX_HIP(hipMemcpyAsync(R.st.p, &hs[i], sizeof(vmx_link_state), hipMemcpyHostToDevice, c->stream));
+                fj[b] = hj[i]; fj[b].Si = R.fSi.as<int32_t>(); fj[b].T = R.fT.as<int64_t>(); fj[b].CNT = R.fCNT.as<int32_t>();
+            }
+            VMX_TRY(upload(d_jobs, fj.data(), fj.size(), c->stream));
+            const int nb = (int)fj.size();
+            hipLaunchKernelGGL(k_chain_linked_fast, dim3((unsigned)nb), dim3(64), 0, stq, dj, nb, tabs, d_gap, sk, md, mg);
+            hipLaunchKernelGGL(k_link_carry, dim3((unsigned)nb), dim3(64), 0, stq, dj, nb, sk);
+            VMX_TRY(download(fj.data(), d_jobs.p, fj.size(), c->stream));
+            for (size_t b = 0; b < bailed.size(); ++b) VMX_TRY(download(&hs[bailed[b]], rounds[bailed[b]]->st.p, 1, c->stream));
+            VMX_HIP(vmx_stream_sync(c));
+            VMX_HIP(hipGetLastError());
+            for (size_t b = 0; b < bailed.size(); ++b) hj[bailed[b]] = fj[b];
+        }
+    }
     for (size_t i = 0; i < nj; ++i) {
         const int r = rounds[i]->finish(hj[i], hs[i], *news[i]);
         if (r == VM_READ_RAISED || r == VM_READ_UNSUPPORTED || r == VM_READ_CAPACITY) rc[i] = r; else if (r < 0) return r;
@@ -562,4 +597,128 @@ int vmx_align_batch_asm_mixed(vm_ctx* c, const vm_index* mi, const vm_params* pr
     if (status_per_read) for (int64_t r = 0; r < n; ++r) status_per_read[r] = st[(size_t)r];
     if (stats) *stats = tot;
     return VM_OK;
+}
+
+// ================================================================================================ decode_hit's tie-break (mammap_asm.py:21302-21326)
+// When MAPQ is 0 and the primary's group holds chains within 0.1 % of its score, the fork picks, among them, the chain whose longest co-linear
+// stretch (return_main_alignment_size :21244) is least divergent (edlib). k_chain_select marks such a contig (n_paths = -7) and leaves the choice
+// to this host step: it repeats the peel and the grouping on the contig's S / P / S_arg (vmx_select.h, the code the kernel runs), computes the
+// candidates' edit distances on the device (vm_edit_distance_batch) and writes the chosen path back. Rare: equal-score placements of a contig.
+#include "vmx_select.h"
+
+namespace {
+std::string py_slice(const std::string& s, int64_t a, int64_t b) {
+    const int64_t n = (int64_t)s.size();
+    if (a < 0) { a += n; if (a < 0) a = 0; } else if (a > n) a = n;
+    if (b < 0) { b += n; if (b < 0) b = 0; } else if (b > n) b = n;
+    return b <= a ? std::string() : s.substr((size_t)a, (size_t)(b - a));
+}
+int p2c_host(const std::vector<int64_t>& coff, int64_t pos) { int pre = 0; for (size_t ci = 0; ci + 1 < coff.size(); ++ci) { if (pos < coff[ci]) break; pre = (int)ci; } return pre; }
+}
+
+// status_override[r]: 0 = resolved (or not a tie), VM_READ_RAISED where the reference raises (division by zero, :21318)
+int vmx_asm_resolve_ties(vm_ctx* c, const vm_index* mi, int64_t n, const std::vector<int64_t>& h_roff, const std::vector<int64_t>& h_aoff, const uint8_t* d_codes,
+                         const vmx_anchor* d_sorted, const double* d_S, const int32_t* d_P, const int32_t* d_SA, const int64_t* d_gmax, const int32_t* d_flip,
+                         int32_t* d_mapq, double* d_gscore, int32_t* d_np, int32_t* d_plen, vmx_anchor* d_prow, std::vector<int32_t>& status_override) {
+    status_override.assign((size_t)n, 0);
+    std::vector<int32_t> h_np((size_t)n);
+    VMX_TRY(download(h_np.data(), d_np, (size_t)n, c->stream));
+    VMX_HIP(vmx_stream_sync(c));
+    std::vector<int64_t> coff; { const int ns = vm_index_nseq(mi); coff.resize((size_t)ns + 1); for (int i = 0; i < ns; ++i) { const char* nm; int64_t ln, of; vm_index_seq_info(mi, i, &nm, &ln, &of); coff[(size_t)i] = of; coff[(size_t)i + 1] = of + ln; } }
+    for (int64_t r = 0; r < n; ++r) {
+        if (h_np[(size_t)r] != -7) continue;
+        const int64_t a0 = h_aoff[(size_t)r]; const int m = (int)(h_aoff[(size_t)r + 1] - a0); const int64_t L = h_roff[(size_t)r + 1] - h_roff[(size_t)r];
+        std::vector<vmx_anchor> A((size_t)m); std::vector<double> S((size_t)m); std::vector<int32_t> P((size_t)m), SA((size_t)m); int64_t gmax = 0; int32_t flip = 0;
+        std::vector<uint8_t> codes((size_t)L);
+        VMX_TRY(download(A.data(), d_sorted + a0, (size_t)m, c->stream)); VMX_TRY(download(S.data(), d_S + a0, (size_t)m, c->stream));
+        VMX_TRY(download(P.data(), d_P + a0, (size_t)m, c->stream)); VMX_TRY(download(SA.data(), d_SA + a0, (size_t)m, c->stream));
+        VMX_TRY(download(&gmax, d_gmax + r, 1, c->stream)); VMX_TRY(download(&flip, d_flip + r, 1, c->stream));
+        VMX_TRY(download(codes.data(), d_codes + h_roff[(size_t)r], (size_t)L, c->stream));
+        VMX_HIP(vmx_stream_sync(c));
+        // the peel and the grouping, as k_chain_select ran them
+        std::vector<char> scratch((size_t)vmx_select_scratch_bytes(m) + 64);
+        vmx_select_scr W = vmx_select_scratch(scratch.data(), m);
+        std::vector<unsigned char> used((size_t)m, 0);
+        const int nch = vmx_select_peel(m, S.data(), P.data(), SA.data(), (int)gmax, 4, used.data(), W.cscore, W.coff, W.cidx);
+        if (nch <= 0) continue;                                  // (cannot happen for a marked contig)
+        std::vector<int> order((size_t)nch);
+        for (int ci = 0; ci < nch; ++ci) { int pos = 0; while (pos < ci && W.cscore[order[(size_t)pos]] > W.cscore[ci]) ++pos; for (int t = ci; t > pos; --t) order[(size_t)t] = order[(size_t)t - 1]; order[(size_t)pos] = ci; }
+        auto bins_of = [&](int ch) { std::vector<int> b; int last = -1; for (int t = W.coff[ch]; t < W.coff[ch + 1]; ++t) { const int v = A[(size_t)W.cidx[t]].q / 100; if (v != last) { b.push_back(v); last = v; } } return b; };
+        std::vector<std::vector<int>> prim_bins; std::vector<int> group0;
+        prim_bins.push_back(bins_of(order[0])); group0.push_back(order[0]);
+        for (int oi = 1; oi < nch; ++oi) {
+            const int ch = order[(size_t)oi]; const std::vector<int> b = bins_of(ch);
+            double maxov = 0.0; size_t prefer = 0;
+            for (size_t p = 0; p < prim_bins.size(); ++p) {
+                const int inter = vmx_desc_intersect(b.data(), (int)b.size(), prim_bins[p].data(), (int)prim_bins[p].size());
+                const double ov = (double)inter / (double)std::min(b.size(), prim_bins[p].size());
+                if (ov > maxov) { maxov = ov; prefer = p; }
+            }
+            if (maxov < 0.5) prim_bins.push_back(b); else if (prefer == 0) group0.push_back(ch);
+        }
+        // :21305-21326
+        std::string fwd((size_t)L, 'N'); for (int64_t i = 0; i < L; ++i) fwd[(size_t)i] = "ACGTN"[codes[(size_t)i] > 4 ? 4 : codes[(size_t)i]];
+        std::string rcs((size_t)L, 'N'); for (int64_t i = 0; i < L; ++i) { const uint8_t cc = codes[(size_t)(L - 1 - i)]; rcs[(size_t)i] = cc < 4 ? "TGCA"[cc] : 'N'; }
+        const std::string& rd = flip ? rcs : fwd; const std::string& rc = flip ? fwd : rcs;
+        const double base_score = W.cscore[group0[0]];
+        std::vector<int> cand; std::vector<std::string> qs, ts;
+        bool raised = false;
+        for (size_t t = 0; t < group0.size(); ++t) {
+            const int ch = group0[t];
+            if (W.cscore[ch] / base_score < 0.999) break;
+            // return_main_alignment_size on the path in ascending read order
+            std::vector<vmx_anchor> asc; for (int x = W.coff[ch + 1] - 1; x >= W.coff[ch]; --x) asc.push_back(A[(size_t)W.cidx[x]]);
+            vmx_anchor pre = asc[0], st_item = pre, best_st = pre, best_en = pre; int64_t size = 0;
+            for (size_t x = 1; x < asc.size(); ++x) {
+                const vmx_anchor now = asc[x];
+                if (pre.s == now.s) {
+                    const int64_t readgap = (int64_t)now.q - pre.q - ((int)pre.l & 0xffff);
+                    if (readgap < 0) continue;
+                    const int64_t refgap = pre.s == 1 ? now.r - pre.r - ((int)pre.l & 0xffff) : pre.r - now.r - ((int)now.l & 0xffff);
+                    if (std::llabs(readgap - refgap) <= 30 && refgap >= 0 && p2c_host(coff, pre.r) == p2c_host(coff, now.r)) { pre = now; continue; }
+                }
+                if (pre.q - st_item.q > size) { size = pre.q - st_item.q; best_st = st_item; best_en = pre; }
+                pre = now; st_item = pre;
+            }
+            if (pre.q - st_item.q > size) { best_st = st_item; best_en = pre; }
+            const vmx_anchor p0 = best_st, p1 = best_en;
+            if (p0.s != p1.s || p0.q == p1.q) continue;
+            std::string query, target;
+            if (p0.s == 1) {
+                const int ci = p2c_host(coff, p0.r); const int64_t bias = coff[(size_t)ci];
+                query = py_slice(rd, p0.q, p1.q);
+                const int64_t ta = std::max<int64_t>(0, p0.r - bias), tb = std::min<int64_t>(coff[(size_t)ci + 1] - bias, p1.r - bias);
+                if (tb > ta) { target.resize((size_t)(tb - ta)); vm_index_seq(mi, ci, ta, tb, &target[0]); }
+            } else {
+                const int ci = p2c_host(coff, p1.r); const int64_t bias = coff[(size_t)ci];
+                query = py_slice(rc, L - p1.q, L - p0.q);
+                const int64_t ta = std::max<int64_t>(0, p1.r + ((int)p1.l & 0xffff) - bias), tb = std::min<int64_t>(coff[(size_t)ci + 1] - bias, p0.r + ((int)p0.l & 0xffff) - bias);
+                if (tb > ta) { target.resize((size_t)(tb - ta)); vm_index_seq(mi, ci, ta, tb, &target[0]); }
+            }
+            if (std::min(query.size(), target.size()) == 0) { raised = true; break; }           // ZeroDivisionError (:21318)
+            cand.push_back(ch); qs.push_back(query); ts.push_back(target);
+        }
+        if (raised) { status_override[(size_t)r] = VM_READ_RAISED; const int32_t zero = 0; VMX_HIP(hipMemcpyAsync(d_np + r, &zero, 4, hipMemcpyHostToDevice, c->stream)); VMX_HIP(vmx_stream_sync(c)); continue; }
+        int base = group0[0];
+        if (!cand.empty()) {
+            std::string qcat, tcat; std::vector<int64_t> qo(1, 0), to(1, 0);
+            for (size_t i = 0; i < cand.size(); ++i) { qcat += qs[i]; tcat += ts[i]; qo.push_back((int64_t)qcat.size()); to.push_back((int64_t)tcat.size()); }
+            int64_t* dist = nullptr;
+            VMX_TRY(vm_edit_distance_batch(c, (int64_t)cand.size(), qcat.data(), qo.data(), tcat.data(), to.data(), &dist));
+            double min_diff = 10;
+            for (size_t i = 0; i < cand.size(); ++i) {
+                const double diff = (double)dist[i] / (double)std::min(qs[i].size(), ts[i].size());
+                if (diff <= min_diff) { min_diff = diff; base = cand[i]; }
+            }
+            free(dist);
+        }
+        // write the choice back: MAPQ 0, signed score, one path (descending read order)
+        std::vector<vmx_anchor> path; for (int x = W.coff[base]; x < W.coff[base + 1]; ++x) path.push_back(A[(size_t)W.cidx[x]]);
+        const int32_t mq = 0, one = 1, pl = (int32_t)path.size(); const double sc = flip ? -W.cscore[base] : W.cscore[base];
+        VMX_HIP(hipMemcpyAsync(d_mapq + r, &mq, 4, hipMemcpyHostToDevice, c->stream)); VMX_HIP(hipMemcpyAsync(d_gscore + r, &sc, 8, hipMemcpyHostToDevice, c->stream));
+        VMX_HIP(hipMemcpyAsync(d_np + r, &one, 4, hipMemcpyHostToDevice, c->stream)); VMX_HIP(hipMemcpyAsync(d_plen + a0, &pl, 4, hipMemcpyHostToDevice, c->stream));
+        VMX_HIP(hipMemcpyAsync(d_prow + a0, path.data(), sizeof(vmx_anchor) * path.size(), hipMemcpyHostToDevice, c->stream));
+        VMX_HIP(vmx_stream_sync(c));
+    }
+    return 0;
 }

@@ -492,6 +492,7 @@ int vm_chain_global_batch(vm_ctx* c, const vm_params* prm, int kmersize, int64_t
     VMX_HIP(hipStreamSynchronize(c->stream));
     VMX_HIP(hipGetLastError());
     if (want_raw) for (int64_t i = 0; i < tot; ++i) { out->P[i] = hP[i]; out->S_arg[i] = hSA[i]; }
+    for (int64_t r = 0; r < n; ++r) if (h_np[r] < 0) h_np[r] = 0;      // -mode asm: a contig waiting for decode_hit's edlib tie-break (made inside vm_align_batch) has no path at this stage entry
     int64_t npaths = 0, nrows = 0;
     for (int64_t r = 0; r < n; ++r) { npaths += h_np[r]; for (int p = 0; p < h_np[r]; ++p) nrows += h_plen[aoff[r] + p]; }
     if (n) { VMX_TRY(download(out->fast_used, c->b[24].p, (size_t)n, c->stream)); VMX_HIP(hipStreamSynchronize(c->stream)); }

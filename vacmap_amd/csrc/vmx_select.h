@@ -84,8 +84,8 @@ __host__ __device__ VMX_SELECT_INLINE int vmx_select_peel(int n, const double* S
 // Sg / cidx: S and the chain node list in HBM (read a few times by the secondary test). Returns the number of secondaries (sec[]).
 // mode 4 (-mode asm, mammap_asm.py:18551-18602 + decode_hit :21280-21348): the chains keep their score order (no "best chain first" swap), the
 // primary is order[0] (*out_prim), there are no secondaries; when MAPQ is 0 and the primary's group holds a second chain within 0.1 % of its
-// score the reference picks the least divergent of them with edlib (:21302-21326) — that choice is not made here: returns -2 and the caller
-// reports the contig as VM_READ_UNSUPPORTED instead of guessing.
+// score the reference picks the least divergent of them with edlib (:21302-21326) — that choice is not made here: returns -2, the kernel
+// marks the contig (n_paths = -7) and the host makes the choice with the device's edit-distance kernels (vmx_asm_resolve_ties, vmx_asm.hip).
 __host__ __device__ VMX_SELECT_INLINE int vmx_select_rank(int nch, int mode, const double* cscore, const int* coff, const int* cq, const double* Sg, const int* cidx,
                                                           int* order, int* bins, int* boff, int* prim, int* sec, int* out_mapq, int* out_prim) {
     const int sec_min_span = (mode == 3) ? 100 : 50;
