@@ -14,6 +14,7 @@
 #include "vmx_device.h"
 #include "vmx_kernels.h"
 #include "vmx_select.h"
+#include "vmx_link.h"
 
 // ------------------------------------------------------------------------------------------------ block bitonic sort
 __device__ void vmx_block_bitonic_u64(uint64_t* a, int N) {   // N power of two, all threads of the block call it
@@ -153,13 +154,17 @@ __device__ __forceinline__ void vmx_gap_geometry_asm(int qi, long long ri, int s
 // One read. IN_LDS is a compile-time switch so that the working arrays are plain LDS pointers (ds_read / ds_write) in the instantiation the
 // buckets run and plain global pointers in the other; a run-time choice between the two would turn every access into a flat_load.
 // VAR: 0 = modes H / L / S, 1 = mode R, 2 = -mode asm (mammap_asm.py:20551-20737: no coverage terms, vmx_gap_geometry_asm, H's scoring)
-template <bool IN_LDS, int VAR>
+// LINK (with VAR 2, IN_LDS false): the batch-LINKED forms of -mode asm (mammap_asm.py:21686-21870 GC-exact, :21504-21685 LC): the first lk->n_pre
+// rows carry S / P from the previous batch (already in S_out / P_out), the index starts with row 0 alone, the loop behind the carried rows,
+// the running maximum and prereadloc come from the caller; lk->lc: co-linear steps also pay readgapcost_list[readgap], no bail-out
+struct vmx_link_in { int n_pre; double g_max_scores; int g_max_index; long long prereadloc; int lc; double max_factor; };
+template <bool IN_LDS, int VAR, bool LINK = false>
 __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restrict__ anchors, int rd, int64_t a0, int n, long long rmin, char* smem,
                                                       const double* s_gapcost, int lds_cap, const vmx_tables& tab, double oskipcost, int omaxdiff,
                                                       int maxgap, double* __restrict__ S_out, int32_t* __restrict__ P_out,
                                                       int32_t* __restrict__ SA_out, uint8_t* __restrict__ cov_pool,
                                                       int64_t* __restrict__ gmax_out, int64_t* __restrict__ opcount_out,
-                                                      double* __restrict__ FP_pool, double* __restrict__ PP_pool) {
+                                                      double* __restrict__ FP_pool, double* __restrict__ PP_pool, const vmx_link_in* lk = nullptr) {
     const int lane = vmx_lane();
     constexpr bool in_lds = IN_LDS;
     constexpr bool rmode = VAR == 1;
@@ -172,12 +177,12 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
         // comes out by v_readlane), the candidates' fields live in the register window (vmx_cwin), and the rare paths (an insertion below the
         // window or among equal scores, a scan past 64 candidates) read A[j] directly. P (written once per anchor) goes to its HBM output array.
         (void)rmin; (void)in_lds;
-        double* S; int* SA; uint8_t* COV = cov_pool + a0;
+        double* S; int* SA; uint8_t* COV = nocov ? nullptr : cov_pool + a0;
         int* P = P_out + a0;
         if constexpr (IN_LDS) { S = (double*)smem; SA = (int*)(S + lds_cap); }
         else { S = S_out + a0; SA = SA_out + a0; }
         // coverage (number of anchors sharing the read position, capped at 20: :24865-24868)
-        for (int i = lane; i < n; i += 64) {
+        if constexpr (!nocov) for (int i = lane; i < n; i += 64) {
             vmx_anchor a = A[i];
             int c = 1;
             for (int x = i - 1; x >= 0 && A[x].q == a.q && c < 20; --x) ++c;
@@ -189,36 +194,41 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
 #define AR(i) ((long long)A[i].r)
 #define AL(i) ((int)A[i].l & 0xffff)
 #define AS(i) ((int)A[i].s)
-        int prereadloc = AQ(0);
+        int i0 = 1;                       // first anchor the loop computes (LINK: behind the carried rows)
+        if constexpr (LINK) { if (lk->n_pre > 0) i0 = lk->n_pre; }
+        const bool carried = LINK && i0 > 1;
+        int prereadloc = carried ? (int)lk->prereadloc : AQ(0);
         // rmode: mode R's body (mammap_noprefercloser.py:22839-23057) has no coverage terms; a non-co-linear step costs the fixed skipcost,
         // remembered per anchor in fixed_penatly / pre_penatly (FP / PP, in HBM) and refunded after skipcost co-linear bases
         double* FP = rmode ? FP_pool + a0 : nullptr; double* PP = rmode ? PP_pool + a0 : nullptr;
         double skipcost = nocov ? oskipcost : oskipcost + (double)COV[0];
         int maxdiff = nocov ? omaxdiff : omaxdiff - (int)COV[0]; if (maxdiff < 10) maxdiff = 10;
         int testspace_en = 1;
-        if (lane == 0) { SA[0] = 0; S[0] = (double)AL(0); P[0] = VMX_NOPRE; if (rmode) { FP[0] = 0.0; PP[0] = 0.0; } }
+        if (lane == 0) { SA[0] = 0; if (!carried) { S[0] = (double)AL(0); P[0] = VMX_NOPRE; } if (rmode) { FP[0] = 0.0; PP[0] = 0.0; } }
         __syncthreads();
-        double g_max_scores = (double)AL(0); int g_max_index = 0;
+        double g_max_scores = carried ? lk->g_max_scores : (double)AL(0); int g_max_index = carried ? lk->g_max_index : 0;
         long long opcount = 0;
         bool bailed = false;
         // candidate window: the testspace_en entries of S_arg, best first, the top 64 of them in registers
-        vmx_cwin win; win.j = 0; win.q = AQ(0); win.ls = AL(0) | (AS(0) << 16); win.S = (double)AL(0); win.r = AR(0);
+        vmx_cwin win; win.j = 0; win.q = AQ(0); win.ls = AL(0) | (AS(0) << 16); win.S = carried ? S[0] : (double)AL(0); win.r = AR(0);
         // anchors [bb, bb + 64) in registers (lane t: anchor bb + t), the next block already on its way
         int bq = 0, bls = 0, bcov = 0, nbq = 0, nbls = 0, nbcov = 0; long long br = 0, nbr = 0;
-        { const int x = lane < n ? lane : n - 1; const vmx_anchor a = A[x]; bq = a.q; bls = ((int)a.l & 0xffff) | ((int)a.s << 16); br = a.r; bcov = COV[x]; }
-        { const int x = 64 + lane < n ? 64 + lane : n - 1; const vmx_anchor a = A[x]; nbq = a.q; nbls = ((int)a.l & 0xffff) | ((int)a.s << 16); nbr = a.r; nbcov = COV[x]; }
+        const int cb = (i0 - 1) & ~63;    // the block anchor i0 - 1 lies in (0 unless LINK)
+        { const int x = cb + lane < n ? cb + lane : n - 1; const vmx_anchor a = A[x]; bq = a.q; bls = ((int)a.l & 0xffff) | ((int)a.s << 16); br = a.r; bcov = nocov ? 0 : COV[x]; }
+        { const int x = cb + 64 + lane < n ? cb + 64 + lane : n - 1; const vmx_anchor a = A[x]; nbq = a.q; nbls = ((int)a.l & 0xffff) | ((int)a.s << 16); nbr = a.r; nbcov = nocov ? 0 : COV[x]; }
         int pq = win.q, pls = win.ls; long long pr = win.r; double pS = win.S;      // anchor i-1 and its score
-        for (int i = 1; i < n; ++i) {
+        if (carried) { const int x = i0 - 1; pq = AQ(x); pls = AL(x) | (AS(x) << 16); pr = AR(x); pS = S[x]; }
+        for (int i = i0; i < n; ++i) {
             if ((i & 63) == 0) {
                 bq = nbq; bls = nbls; br = nbr; bcov = nbcov;
-                const int x = i + 64 + lane < n ? i + 64 + lane : n - 1; const vmx_anchor a = A[x]; nbq = a.q; nbls = ((int)a.l & 0xffff) | ((int)a.s << 16); nbr = a.r; nbcov = COV[x];
+                const int x = i + 64 + lane < n ? i + 64 + lane : n - 1; const vmx_anchor a = A[x]; nbq = a.q; nbls = ((int)a.l & 0xffff) | ((int)a.s << 16); nbr = a.r; nbcov = nocov ? 0 : COV[x];
             }
             // the current anchor is the same in every lane: scalar registers, scalar branches on its strand
             const int bl = i & 63, bb = i & ~63;
             const int qi = vmx_readlane(bq, bl); const int lsi = vmx_readlane(bls, bl); const int li = lsi & 0xffff, si = lsi >> 16;
             long long ri; { union { long long d; int w[2]; } u; u.d = br; u.w[0] = vmx_readlane(u.w[0], bl); u.w[1] = vmx_readlane(u.w[1], bl); ri = u.d; }
             if (prereadloc < qi) {
-                if (((double)opcount / (double)i) > 1000.0) { bailed = true; break; }   // :24914 max_factor
+                if (LINK ? (!lk->lc && ((double)opcount / (double)i) > lk->max_factor) : (((double)opcount / (double)i) > 1000.0)) { bailed = true; break; }   // :24914 max_factor
                 for (int k = testspace_en; k < i; ++k) {
                     double Sk; int qk, lsk; long long rk;
                     if (k == i - 1) { Sk = pS; qk = pq; lsk = pls; rk = pr; }
@@ -276,6 +286,7 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
                         }
                     } else if (si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
                         test = Sj + (double)bonus - s_gapcost[gapcost];
+                        if constexpr (LINK) { if (lk->lc) test = test - (double)tab.readgap_r[readgap]; }      // :21644
                     } else {
                         test = Sj - skipcost + (double)bonus - vmx_extra_cost(tab, gapcost);
                     }
@@ -349,6 +360,34 @@ __global__ void __launch_bounds__(64) k_chain_global(const vmx_anchor* __restric
         if (n <= lds_cap) { if (rmode == 1) VMX_GC_CALL(true, 1); else if (rmode == 2) VMX_GC_CALL(true, 2); else VMX_GC_CALL(true, 0); }
         else { if (rmode == 1) VMX_GC_CALL(false, 1); else if (rmode == 2) VMX_GC_CALL(false, 2); else VMX_GC_CALL(false, 0); }
 #undef VMX_GC_CALL
+    }
+}
+
+// -mode asm, contigs of 500 kb and more: one batch of one contig per workgroup (one wavefront), the register-window form of k_chain_linked
+// (k_chain_linked.hip keeps the plain form: VMX_LINK_PLAIN=1 selects it). Every entry is stored (no cold entries): hot = n.
+__global__ void __launch_bounds__(64) k_chain_linked_win(vmx_link_job* __restrict__ jobs, int n_jobs, vmx_tables tab, const double* __restrict__ gapcost_list,
+                                                        double skipcost, int maxdiff, int maxgap, int lc, double max_factor) {
+    VMX_DYN_SHARED(char, smem);
+    __shared__ double s_gapcost[64];
+    const int lane = vmx_lane();
+    for (int x = lane; x <= maxdiff && x < 64; x += 64) s_gapcost[x] = gapcost_list[x];
+    __syncthreads();
+    for (int jb = (int)blockIdx.x; jb < n_jobs; jb += (int)gridDim.x) {
+        vmx_link_job& J = jobs[jb];
+        vmx_link_state& ST = *J.state;
+        if (ST.status != 0 || J.n_new <= 0) { if (lane == 0) J.ran = 0; continue; }
+        const int n_pre = ST.n_pre, base = J.cap_pre - n_pre, n = n_pre + J.n_new;
+        double* S = J.S + base; int32_t* P = J.P + base;
+        for (int i = lane; i < n_pre; i += 64) { S[i] = ST.pre_S[i]; P[i] = ST.pre_P[i]; }
+        __syncthreads();
+        vmx_link_in lk; lk.n_pre = n_pre; lk.g_max_scores = ST.g_max_scores; lk.g_max_index = ST.g_max_index; lk.prereadloc = ST.prereadloc; lk.lc = lc; lk.max_factor = max_factor;
+        int64_t gm = 0, opc = 0;
+        __shared__ int64_t s_out[2];
+        vmx_chain_global_read<false, 2, true>(J.rows + base, 0, 0, n, 0, smem, s_gapcost, 0, tab, skipcost, maxdiff, maxgap, S, P, J.SA, nullptr, &s_out[0], &s_out[1], nullptr, nullptr, &lk);
+        __syncthreads();
+        gm = s_out[0]; opc = s_out[1];
+        if (lane == 0) { J.ran = 1; J.n = n; J.hot = n; J.n_cold = 0; J.cold_max = -1e300; J.gmax = gm; J.opcount = opc; }
+        __syncthreads();
     }
 }
 

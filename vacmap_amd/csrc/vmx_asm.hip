@@ -8,6 +8,9 @@ using namespace vmx;
 
 __global__ void k_chain_linked(vmx_link_job* jobs, int n_jobs, vmx_tables tab, const double* gapcost_list, double skipcost, int maxdiff, int maxgap, int lc, double margin_base, double max_factor);
 // max_factor of the fork's GC-exact (mammap_asm.py:21757). Test hook VMX_TEST_ASM_MAX_FACTOR: a lower value drives batches into the linked GC-fast
+__global__ void k_chain_linked_win(vmx_link_job* jobs, int n_jobs, vmx_tables tab, const double* gapcost_list, double skipcost, int maxdiff, int maxgap, int lc, double max_factor);
+// VMX_LINK_PLAIN=1: the plain form of the linked DP (k_chain_linked.hip) instead of the register-window form (k_chain_linked_win, k_chain.hip)
+static bool asm_link_plain() { static const bool v = getenv("VMX_LINK_PLAIN") != nullptr; return v; }
 static double asm_max_factor() { const char* e = getenv("VMX_TEST_ASM_MAX_FACTOR"); return e ? atof(e) : 1000.0; }
 __global__ void k_link_carry(vmx_link_job* jobs, int n_jobs, double skipcost);
 __global__ void k_link_place(vmx_link_job* jobs, int n_jobs);
@@ -69,7 +72,8 @@ extern "C" int vm_chain_linked(vm_ctx* c, int which, int kmersize, double skipco
     vmx_link_job* d_job = B.job.as<vmx_link_job>(); const double* d_gap = B.gap.as<double>(); const vmx_tables tabs = c->tables; hipStream_t stq = c->stream;
     hipLaunchKernelGGL(k_link_place, dim3(1), dim3(256), 0, stq, d_job, 1);
     if (which == 1) hipLaunchKernelGGL(k_chain_linked_fast, dim3(1), dim3(64), 0, stq, d_job, 1, tabs, d_gap, skipcost, maxdiff, maxgap);
-    else hipLaunchKernelGGL(k_chain_linked, dim3(1), dim3(64), 0, stq, d_job, 1, tabs, d_gap, skipcost, maxdiff, maxgap, lc, margin_base, asm_max_factor());
+    else if (asm_link_plain()) hipLaunchKernelGGL(k_chain_linked, dim3(1), dim3(64), 0, stq, d_job, 1, tabs, d_gap, skipcost, maxdiff, maxgap, lc, margin_base, asm_max_factor());
+    else hipLaunchKernelGGL(k_chain_linked_win, dim3(1), dim3(64), 0, stq, d_job, 1, tabs, d_gap, skipcost, maxdiff, maxgap, lc, asm_max_factor());
     hipLaunchKernelGGL(k_link_carry, dim3(1), dim3(64), 0, stq, d_job, 1, skipcost);
     VMX_TRY(download(&hj, B.job.p, 1, c->stream)); VMX_TRY(download(&hs, B.st.p, 1, c->stream));
     VMX_HIP(vmx_stream_sync(c));
@@ -205,7 +209,8 @@ int run_jobs(vm_ctx* c, DevBuf& d_jobs, const std::vector<LinkRound*>& rounds, c
     vmx_link_job* dj = d_jobs.as<vmx_link_job>(); const double* d_gap = R0.gap.as<double>(); const vmx_tables tabs = c->tables; hipStream_t stq = c->stream;
     const double sk = R0.skipcost, mb = R0.margin_base, mf = asm_max_factor(); const int md = R0.maxdiff, mg = R0.maxgap, l = R0.lc, n_jobs = (int)nj;
     hipLaunchKernelGGL(k_link_place, dim3((unsigned)nj), dim3(256), 0, stq, dj, n_jobs);
-    hipLaunchKernelGGL(k_chain_linked, dim3((unsigned)nj), dim3(64), 0, stq, dj, n_jobs, tabs, d_gap, sk, md, mg, l, mb, mf);
+    if (asm_link_plain()) hipLaunchKernelGGL(k_chain_linked, dim3((unsigned)nj), dim3(64), 0, stq, dj, n_jobs, tabs, d_gap, sk, md, mg, l, mb, mf);
+    else hipLaunchKernelGGL(k_chain_linked_win, dim3((unsigned)nj), dim3(64), 0, stq, dj, n_jobs, tabs, d_gap, sk, md, mg, l, mf);
     hipLaunchKernelGGL(k_link_carry, dim3((unsigned)nj), dim3(64), 0, stq, dj, n_jobs, sk);
     VMX_TRY(download(hj.data(), d_jobs.p, nj, c->stream));
     for (size_t i = 0; i < nj; ++i) VMX_TRY(download(&hs[i], rounds[i]->st.p, 1, c->stream));
