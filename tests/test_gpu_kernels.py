@@ -360,3 +360,28 @@ def test_mode_asm_linked_dp(ctx, oracle):
     KC.check_asm_linked_noise(ctx, oracle, seed=6, noise_per_anchor=3, which=2)
     KC.check_asm_linked_noise(ctx, oracle, seed=7, noise_per_anchor=8, which=0, contig=0)
     KC.check_asm_linked_fast_golden(ctx, oracle)                 # the fork's GC-fast, plain and linked (k_chain_linked_fast), against the reference's direct calls
+
+
+def test_driver_mode_asm(ctx, oracle, tmp_path):
+    """`-mode asm -workdir` through the command-line driver: assembly contigs (FASTA) in, SAM out; body lines = the reference's
+    iterator_get_bam_dict_str lines for the same contigs (tests/golden/sam_asm.json: AS1's ten contigs and AS5's MAPQ-0 contigs)"""
+    import json, os
+    import sam_cases as SC
+    from vacmap_amd import driver
+    meta, arr = KC.asm_golden()
+    entries = [e for e in json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'sam_asm.json')))
+               if e['opt'] == {'md': False, 'shortcs': True, 'cigar2cg': False, 'markunbalancetra': False, 'H': False, 'fakecigar': False, 'rg': '1'}]
+    for cid in ('AS1', 'AS5'):
+        c = meta[cid]
+        ref = tmp_path / ('ref%s.fa' % cid); fa = tmp_path / ('ctg%s.fa' % cid); out = tmp_path / ('out%s.sam' % cid)
+        with open(ref, 'w') as f:
+            for i, n in enumerate(c['names']):
+                f.write('>%s\n%s\n' % (n, arr['%s_ref%d' % (cid, i)].tobytes().decode()))
+        expect = []
+        with open(fa, 'w') as f:
+            for ci, g in enumerate(c['contigs']):
+                f.write('>%s\n%s\n' % (g['name'], arr['%s_c%d_seq' % (cid, ci)].tobytes().decode()))
+                expect += [d for e in entries if e['case'] == cid and e['contig'] == ci for d in e['digest']]
+        assert driver.main(['-ref', str(ref), '-read', str(fa), '-mode', 'asm', '-workdir', str(tmp_path / 'wd'), '-o', str(out), '--nowriteindex']) == 0
+        body = [x for x in open(out).read().split('\n') if x and not x.startswith('@')]
+        assert [SC.digest(x) for x in body] == expect, cid

@@ -159,3 +159,40 @@ def test_blob_gather_parts_restores_input_order():
         keys.append(idx.astype(np.int64))
     out = VL.blob_gather_parts(L, blobs, offs, keys)
     assert out.tobytes() == b''.join(texts)
+
+
+def test_sam_lines_asm_match_reference():
+    """-mode asm's emitter (sam.sam_lines(asm=True)) against the reference's iterator_get_bam_dict_str / _comments (mammap_asm.py:22757, :22942) on the
+    records of the asm goldens (tests/golden/sam_asm.json, tools/harness/gen_golden_sam_asm.py)"""
+    import zlib
+    import numpy as np
+    import oracle_lib as O
+    meta = json.load(open(os.path.join(GOLD, 'asm.json'))); arr = np.load(os.path.join(GOLD, 'asm.npz'))
+    entries = json.load(open(os.path.join(GOLD, 'sam_asm.json')))
+    nlines = 0
+    cache = {}
+    for e in entries:
+        cid, ci, o = e['case'], e['contig'], e['opt']
+        c = meta[cid]; g = c['contigs'][ci]
+        contigs = {n: arr['%s_ref%d' % (cid, i)].tobytes().decode() for i, n in enumerate(c['names'])}
+        query = arr['%s_c%d_seq' % (cid, ci)].tobytes().decode()
+        if all(len(r) == 10 for r in g['records']):
+            recs = [(g['name'], r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[9]) for r in g['records']]
+        else:                                    # long CIGARs are stored as (length, crc): take them from the oracle, which the record goldens pin
+            if (cid, ci) not in cache:
+                oi = O.Index.from_seqs(c['names'], [contigs[n] for n in c['names']], k=c['k'], w=c['w'])
+                rc, orecs = O.align_asm(oi, query, O.params('asm'), *c['sizes'])
+                assert [zlib.crc32(t[8].encode()) for t in orecs] == [r[8] for r in g['records']]
+                cache[(cid, ci)] = [(g['name'], c['names'][t[1]], t[2], t[3], t[4], t[5], t[6], t[7], t[8]) for t in orecs]
+            recs = cache[(cid, ci)]
+        kw = dict(md=o['md'], shortcs=o['shortcs'], cigar2cg=o['cigar2cg'], markunbalancetra=o['markunbalancetra'], hardclip=o['H'], fakecigar=o['fakecigar'],
+                  rg_id=o.get('rg'), comments=o['comments'].replace('\\t', '\t') if 'comments' in o else None, asm=True)
+        if e['raised']:
+            with pytest.raises(Exception):
+                sam.sam_lines(recs, query, None, lambda cn, a, b: contigs[cn][a:b], **kw)
+            continue
+        lines = sam.sam_lines(recs, query, None, lambda cn, a, b: contigs[cn][a:b], **kw)
+        assert [SC.head(x) for x in lines] == e['head'], (cid, ci, o)
+        assert [SC.digest(x) for x in lines] == e['digest'], (cid, ci, o)
+        nlines += len(lines)
+    assert nlines >= 100

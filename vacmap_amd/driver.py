@@ -13,8 +13,9 @@ text with `-t` host threads (vm_sam_emit, the C++ twin of vacmap_amd/sam.py) whi
 in input order. Like the reference's worker (:24116-24134) a read whose path or whose emission raises is skipped, and a read without
 records produces no line.
 With N ranks, rank 0 builds the index and broadcasts it over RCCL (vacmap_amd/dist.py), batch i of a window goes to rank i mod N, and
-rank 0 gathers and writes the lines. `-mode asm` is not provided by this driver (its SAM emitters are a fork of their own,
-mammap_asm.py:22757; the mode itself is reachable through the C-ABI: VM_MODE_ASM, include/vacmapx.h).
+rank 0 gathers and writes the lines. `-mode asm` (assembly contigs; one GPU): the contigs go through vm_align_batch with VM_MODE_ASM in
+groups, in input order, and their lines come from the Python statement of the asm emitter (sam.sam_lines(asm=True) =
+iterator_get_bam_dict_str, mammap_asm.py:22757); `-workdir` is accepted and created like the reference's, but nothing is spilled into it.
 """
 import argparse, gzip, os, shutil, struct, subprocess, sys, threading, time, queue
 
@@ -118,7 +119,7 @@ RG_ARGS = (('rg-id', 'ID'), ('rg-sm', 'SM'), ('rg-lb', 'LB'), ('rg-pl', 'PL'), (
 def build_parser():
     p = argparse.ArgumentParser(prog='vacmapx', description='MI355X-native VACmap path: seed, non-linear chain, extend; SAM output')
     p.add_argument('-ref', required=True); p.add_argument('-read', required=True, nargs='+', action='append')
-    p.add_argument('-mode', required=True, choices=['H', 'L', 'S', 'R'])
+    p.add_argument('-mode', required=True, choices=['H', 'L', 'S', 'R', 'asm']); p.add_argument('-workdir')
     p.add_argument('-o', default='-'); p.add_argument('--force', action='store_true'); p.add_argument('--nowriteindex', action='store_true')
     p.add_argument('-t', type=int, default=8); p.add_argument('-k', type=str, default='15'); p.add_argument('-w', type=str, default='10')
     p.add_argument('-c', type=int, default=100); p.add_argument('-maxdivergence', type=float)
@@ -150,6 +151,75 @@ def _open_output(path):
 
 
 last_timing = {}          # wall seconds of the last main() call by phase (tools/driver_bench.py reads it)
+
+
+def _run_asm(args, lib, ctx, index, prm, rg, mark, out, proc, world, t_start):
+    """-mode asm (src/vacmap/vacmap:245-255, :394-411; worker mammap_asm.py:23462-23511): every input sequence is an assembly contig. --eqx is
+    forced and maxdivergence set to 1 by vm_params_default(VM_MODE_ASM); contigs are aligned in groups (the long ones of a group side by side on
+    the GPU) and their SAM lines written in input order. A contig the reference would skip (raised) is logged and skipped."""
+    from .lib import Fastx, align_batch
+    if world > 1:
+        sys.exit('-mode asm runs on one GPU')
+    if not args.workdir:
+        sys.exit('workdir not provided! -workdir /path/to/workdir')                      # vacmap:247-249
+    os.makedirs(args.workdir, exist_ok=True)
+    prm.eqx = 1
+    names = index.names
+    seen = set(); n_contigs = n_lines = n_skipped = 0
+
+    def refseq(cn, a, b):
+        return index.seq(names.index(cn), a, b)
+
+    def flush(group):
+        nonlocal n_lines, n_skipped
+        status, recs, _ = align_batch(ctx, index, prm, [g[1] for g in group])
+        for x, (nm, seq, qual, com) in enumerate(group):
+            if status[x] != 0:
+                sys.stderr.write('%s is not aligned.\n' % nm); n_skipped += 1
+                continue
+            mine = [(nm, names[t[1]]) + tuple(t[2:]) for t in recs if t[0] == x]
+            if not mine:
+                continue
+            try:
+                lines = sam.sam_lines(mine, seq, qual or None, refseq, md=bool(args.MD), shortcs=args.cs != 'long', cigar2cg=bool(args.L), markunbalancetra=bool(mark),
+                                      hardclip=bool(args.H), fakecigar=bool(args.fakecigar), rg_id=rg['ID'], comments=(com if args.copycomments else None), asm=True)
+            except Exception as e:                                                          # the worker's except (:23493-23498)
+                sys.stderr.write('%s is not aligned.\n%s\n' % (nm, e)); n_skipped += 1
+                continue
+            for ln in lines:
+                out.write(ln.encode() + b'\n')
+            n_lines += len(lines)
+
+    group, gbases = [], 0
+    for grp in args.read:
+        for path in grp:
+            rd = Fastx(path, lib=lib)
+            while True:
+                ch = rd.read(64)
+                if ch is None:
+                    break
+                nb, no, sb, so = ch['names'].tobytes(), ch['names_off'], ch['seqs'].tobytes(), ch['seqs_off']
+                qb, qo, cb, co = ch['quals'].tobytes(), ch['quals_off'], ch['comments'].tobytes(), ch['comments_off']
+                for i in range(len(so) - 1):
+                    nm = nb[no[i]:no[i + 1]].decode()
+                    if nm in seen:
+                        continue
+                    seen.add(nm); n_contigs += 1
+                    group.append((nm, sb[so[i]:so[i + 1]].decode(), '' if args.Q else qb[qo[i]:qo[i + 1]].decode(), cb[co[i]:co[i + 1]].decode()))
+                    gbases += so[i + 1] - so[i]
+                    if len(group) >= 64 or gbases >= 400_000_000:
+                        flush(group); group, gbases = [], 0
+    if group:
+        flush(group)
+    if proc is not None:
+        out.close(); proc.wait()
+    elif args.o != '-':
+        out.close()
+    else:
+        out.flush()
+    tt = max(time.time() - t_start, 0.001)
+    sys.stderr.write('vacmapx: %d contigs, %d SAM lines, %d contigs skipped, %.1f s\n' % (n_contigs, n_lines, n_skipped, tt))
+    return 0
 
 
 def main(argv=None, comm=None):
@@ -211,7 +281,7 @@ def main(argv=None, comm=None):
         sys.exit('The --rg-id option is required when any other --rg-* option is supplied.')
     if not rg:
         rg = {'ID': '1', 'SM': 'sample'}
-    mark = args.markunbalancetra or args.mode in ('H', 'L')          # mode defaults of vacmap:286-296
+    mark = args.markunbalancetra or args.mode in ('H', 'L')          # mode defaults of vacmap:286-296 (False for asm unless asked)
     from .lib import SamOpts, Fastx, align_batch_raw, sam_emit, blob_gather, blob_gather_parts
     opts = SamOpts(int(bool(args.MD)), int(args.cs != 'long'), int(bool(args.L)), int(bool(mark)), int(bool(args.H)), int(bool(args.fakecigar)), rg['ID'].encode())
     out, proc = (None, None)
@@ -219,6 +289,8 @@ def main(argv=None, comm=None):
         out, proc = _open_output(args.o)
         for ln in sam.header_lines([(n, ln_) for n, ln_ in zip(names, index.lens)], ' '.join(sys.argv if argv is None else ['vacmapx'] + list(argv)), rg):
             out.write(ln.encode() + b'\n')
+    if args.mode == 'asm':
+        return _run_asm(args, lib, ctx, index, prm, rg, mark, out, proc, world, t_start)
     pipe = pipeline.Pipeline(index, prm, device=device, inflight=args.inflight, first_ctx=ctx)
     if os.environ.get('VMX_SPIN_SYNC') != '1':
         for cx in pipe.ctxs:

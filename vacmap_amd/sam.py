@@ -36,6 +36,30 @@ def merge_cigar(cigar):
     return ops
 
 
+def merge_cigar_nm(cigar):
+    """mergecigar_nm_ of the -mode asm fork (mammap_asm.py:23125-23155): merge_cigar plus the edit distance the fork reports as NM — the counts
+    of X, D and I operators, where a run that continues the operator before it is merged but NOT counted (:23142-23145), as in the reference"""
+    ops = []
+    num = 0
+    pre_op, pre_num = '0', 0
+    nm = 0
+    for ch in cigar:
+        if '0' <= ch <= '9':
+            num = num * 10 + ord(ch) - 48
+        else:
+            if pre_op == ch:
+                pre_num += num
+                ops[-2] = str(pre_num)
+            else:
+                pre_num = num
+                ops.append(str(num)); ops.append(ch)
+                if ch in 'XDI':
+                    nm += num
+                pre_op = ch
+            num = 0
+    return ops, nm
+
+
 def nm_from_cigar(cigar, query, ref):
     """NM of a SAM record from its CIGAR (the reference's `nm_from_cigar`, output_functions.py:300, pinned by its nine known-answer
     tests): inserted + deleted + X-run bases, plus the mismatching columns of M runs (compared case-insensitively). S / I consume the
@@ -192,12 +216,15 @@ def _fake_cigar(r, qlen, clip):
 
 
 def sam_lines(records, query, qual, refseq, md=False, shortcs=True, cigar2cg=False, markunbalancetra=True, hardclip=False,
-              fakecigar=False, rg_id=None, comments=None):
+              fakecigar=False, rg_id=None, comments=None, asm=False):
     """SAM lines of one read (:20841-21020; with `comments`: the `_comments` twin :21022, which appends the FASTQ comment).
 
     records: 9-tuples (qname, contig, strand, q_st, q_en, r_st, r_en, mapq, cigar) in the path's order; q_st/q_en index the read for
     '+' and its reverse complement for '-'. refseq(contig, start, end) -> reference bases. Raises what the reference raises (the
-    caller skips the read, :24127-24134)."""
+    caller skips the read, :24127-24134).
+    asm: the emitter of -mode asm, `iterator_get_bam_dict_str` / `_comments` (mammap_asm.py:22757-22940, :22942): NM comes from the CIGAR's X / D / I
+    counts (`mergecigar_nm_` :23125), MAPQ is written as 60 (or 1 for 0) in the MAPQ column and in SA, and the second-longest record is the
+    primary one when the longest has MAPQ 1 and it has not (:22847-22850)."""
     recs = reassign_mapq(records) if markunbalancetra else [list(r) for r in records]
     rc_query = revcomp(query)
     recs.sort(key=lambda x: x[4] - x[3])          # stable, then reversed: longest first, later ones first among equals
@@ -206,30 +233,32 @@ def sam_lines(records, query, qual, refseq, md=False, shortcs=True, cigar2cg=Fal
     clip = 'H' if hardclip else 'S'
     for r in recs:
         if not md:
-            ops = merge_cigar(r[8])
+            ops, nm_asm = merge_cigar_nm(r[8]) if asm else (merge_cigar(r[8]), None)
             r[8] = ''.join(ops)
-            nms.append(nm_from_cigar(r[8], query if r[2] == '+' else rc_query, refseq(r[1], r[5], r[6])))
+            nms.append(nm_asm if asm else nm_from_cigar(r[8], query if r[2] == '+' else rc_query, refseq(r[1], r[5], r[6])))
             ncig.append(len(ops))
         else:
             q = (query if r[2] == '+' else rc_query)[r[3]:r[4]]
             t = refseq(r[1], r[5], r[6])
-            ops = merge_cigar(r[8])
+            ops, nm_asm = merge_cigar_nm(r[8]) if asm else (merge_cigar(r[8]), None)
             m_, c_ = md_cs(ops, t, q, shortcs)
             r[8] = ''.join(ops)
-            nms.append(nm_from_cigar(r[8], q, t))
+            nms.append(nm_asm if asm else nm_from_cigar(r[8], q, t))
             mds.append(m_); css.append(c_); ncig.append(len(ops))
         if fakecigar:
             fakes.append(_fake_cigar(r, len(query), clip))
     has_qual = qual is not None and len(qual) == len(query)
     rc_qual = qual[::-1] if has_qual else None
     lines = []
+    primary = 1 if asm and len(recs) > 1 and recs[0][7] == 1 and recs[1][7] != 1 else 0
+    mq_out = (lambda v: 60 if v != 0 else 1) if asm else (lambda v: v)
     for i, r in enumerate(recs):
         d = {}
         if rg_id is not None:
             d['RG'] = rg_id
         d['QNAME'] = r[0]
         d['RNAME'] = r[1]
-        base = 0 if i == 0 else 2048
+        base = 0 if i == primary else 2048
         d['FLAG'] = str(base if r[2] == '+' else 16 + base)
         d['POS'] = str(r[5] + 1)
         if ncig[i] > 65535 and cigar2cg:
@@ -241,9 +270,9 @@ def sam_lines(records, query, qual, refseq, md=False, shortcs=True, cigar2cg=Fal
             for t, x in enumerate(recs):
                 if t == i:
                     continue
-                sa.append('%s,%d,%s,%s,%d,%d;' % (x[1], x[5] + 1, x[2], fakes[t] if fakecigar else x[8], x[7], nms[t]))
+                sa.append('%s,%d,%s,%s,%d,%d;' % (x[1], x[5] + 1, x[2], fakes[t] if fakecigar else x[8], mq_out(x[7]), nms[t]))
             d['SA'] = ''.join(sa)
-        d['MAPQ'] = str(r[7])
+        d['MAPQ'] = str(mq_out(r[7]))
         seq, ql = (query, qual) if r[2] == '+' else (rc_query, rc_qual)
         if not hardclip:
             d['SEQ'] = seq
