@@ -921,3 +921,28 @@ def check_asm_long_forced_fast(ctx, O, monkeypatch, cid='AS3', contig=2, factor=
     assert nfast >= 2, nfast
     assert (st == 0) == (ost == 0) and [t[1:] for t in recs] == [t[1:] for t in orecs], 'records differ from the oracle'
     return nfast, len(recs)
+
+
+def check_asm_ragged(ctx, O):
+    """edge contigs of -mode asm in one batch: tiny, all-N, N runs inside, lower case, unmappable, a contig spanning two reference contigs — statuses and
+    records = the oracle's"""
+    from vacmap_amd.lib import align_batch
+    from vacmap_amd import synth
+    meta, arr = asm_golden()
+    gi, oi = _asm_index(ctx, O, meta, arr, 'AS1')
+    ref0 = arr['AS1_ref0'].tobytes().decode(); ref1 = arr['AS1_ref1'].tobytes().decode()
+    rng = np.random.default_rng(77)
+    base = synth.tostr(synth.mutate(np.frombuffer(ref0[120000:150000].encode(), np.uint8), 0.004, rng))
+    withn = base[:8000] + 'N' * 700 + base[8700:20000] + 'N' + base[20001:]
+    contigs = ['ACGTACGTACGT', 'N' * 4000, withn, base.lower(), synth.tostr(synth.make_reference([6000], seed=78)[0]),
+               ref0[280000:299000] + ref1[1000:21000], base[:300]]
+    prm = ctx.lib.params('asm'); oprm = O.params('asm')
+    status, recs, _ = align_batch(ctx, gi, prm, contigs)
+    n = 0
+    for x, s in enumerate(contigs):
+        ost, orecs = O.align_asm(oi, s, oprm)
+        mine = [t[1:] for t in recs if t[0] == x]
+        assert (status[x] == 0) == (ost == 0), (x, int(status[x]), ost)
+        assert mine == [t[1:] for t in orecs], (x, 'records differ from the oracle')
+        n += len(mine)
+    return n

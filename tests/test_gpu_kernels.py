@@ -330,6 +330,7 @@ def test_mode_asm(ctx, oracle):
     assert KC.check_asm_golden(ctx, oracle, cases=['AS5']) == 4       # MAPQ 0 between two near-identical copies: decode_hit's edlib tie-break (mammap_asm.py:21302-21326)
     assert KC.check_asm_golden(ctx, oracle, cases=['AS3'], vs_golden=False) == 3
     assert KC.check_asm_golden(ctx, oracle, cases=['AS2']) == 1       # the 600 kb contig: vm_align_batch hands it to the batch-linked path
+    assert KC.check_asm_ragged(ctx, oracle) >= 4                       # tiny / all-N / N runs / lower case / unmappable / two-contig / 300-base contigs
 
 
 def test_mode_asm_long_contigs(ctx, oracle):
