@@ -115,6 +115,37 @@ __device__ __forceinline__ int vmx_insertpoint_score_wave(const double* S, doubl
     return j;
 }
 
+// The same (a, b) found by walking the index down from its top, 64 entries per step: in the linked DPs of -mode asm the index holds 10^5..10^6
+// entries and a new one lands a few dozen to a few hundred places below the top (every anchor, noise hits included, hangs itself onto the best
+// chain at the skip penalty), so one or two steps replace the four dependent rounds of the 64-ary search over the whole index.
+__device__ __forceinline__ int vmx_insertpoint_score_topdown(const double* S, double target, int k, const int* SA, int lane) {
+    int a = 0;
+    for (int base = k - 1; base >= 0; base -= 64) {
+        const int x = base - lane;
+        const bool lt = x >= 0 && S[SA[x]] < target;
+        const unsigned long long m = __ballot(lt);
+        if (m) { a = base - (__ffsll((unsigned long long)m) - 1) + 1; break; }
+    }
+    int b = a;
+    if (a < k && S[SA[a]] == target) {
+        b = k;
+        for (int base = a; base < k; base += 64) {
+            const int x = base + lane;
+            const bool gt = x < k && S[SA[x]] > target;
+            const unsigned long long m = __ballot(gt);
+            if (m) { b = base + (__ffsll((unsigned long long)m) - 1); break; }
+        }
+    }
+    int i = 0, j = k;
+    while (i < j) {
+        const int mid = (i + j) >> 1;
+        if (mid < a) i = mid + 1;
+        else if (mid >= b) j = mid;
+        else return mid + 1;
+    }
+    return j;
+}
+
 // shared gap geometry of GC and LC (:24953-24984, :27418-27456)
 __device__ __forceinline__ void vmx_gap_geometry(int qi, long long ri, int si, int li, int qj, long long rj, int sj, int lj,
                                                  long long& readgap, long long& refgap, long long& bonus) {
@@ -245,9 +276,10 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
                         vmx_cwin_insert(win, above, k, Sk, qk, lsk, rk, lane);
                         if (lane <= above) SA[k - lane] = win.j;
                     } else {
-                        const int loc = vmx_insertpoint_score_wave(S, Sk, k, SA, lane);
+                        const int loc = LINK ? vmx_insertpoint_score_topdown(S, Sk, k, SA, lane) : vmx_insertpoint_score_wave(S, Sk, k, SA, lane);
                         vmx_sarg_insert4(SA, loc, k, lane);
-                        if (lane <= k) { const int j = SA[k - lane]; win.j = j; win.S = S[j]; win.q = AQ(j); win.ls = AL(j) | (AS(j) << 16); win.r = AR(j); }
+                        // (an entry that lands below the 64 of the window leaves the window as it is)
+                        if ((!LINK || k - loc < 64) && lane <= k) { const int j = SA[k - lane]; win.j = j; win.S = S[j]; win.q = AQ(j); win.ls = AL(j) | (AS(j) << 16); win.r = AR(j); }
                     }
                 }
                 testspace_en = i;
