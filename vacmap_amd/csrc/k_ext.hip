@@ -310,9 +310,6 @@ __global__ void __launch_bounds__(64) k_ext_records(vmx_ext_args A, const vmx_dp
                 const char last = BLOB[w - 1];
                 int j = 0; long long num2 = 0;
                 while (j < n && src[j] >= '0' && src[j] <= '9') { num2 = num2 * 10 + (src[j] - '0'); ++j; }
-#ifdef VMX_EMU
-                if (getenv("VMX_DBG_LINK") && lane == 0) fprintf(stderr, "[link] seg %d piece %d/%d n %d last %c first %c num2 %lld\n", s, x, np, n, last, j < n ? src[j] : '?', num2);
-#endif
                 if (j < n && src[j] == last) {
                     long long i = w - 1, num1 = 0, factor = 1; bool brk = false;
                     while (i > wc0) { --i; const char ch = BLOB[i]; if (ch >= '0' && ch <= '9') { num1 += (long long)(ch - '0') * factor; factor *= 10; } else { brk = true; break; } }
