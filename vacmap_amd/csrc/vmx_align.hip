@@ -313,22 +313,28 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     // -mode asm, contig of 500 kb and more (vmx_asm.hip): the chain comes from the linked DPs; the extend stage below runs on it as
     // ass_extend_func does (mammap_asm.py:23423-23460): forward orientation, MAPQ 60
     auto front_preset = [&]() -> int {
-        if (n != 1 || preset->len < 2) { set_error("preset chain: one contig with a chain of two anchors or more"); return VM_ERR_ARG; }
+        int64_t tot_chain = 0;
+        for (int64_t r = 0; r < n; ++r) { if (preset[r].len < 2) { set_error("preset chain: every contig needs a chain of two anchors or more"); return VM_ERR_ARG; } tot_chain += preset[r].len; }
         VMX_TRY(B.ocodes.reserve((size_t)total_bases + 64));
         VMX_HIP(hipMemcpyAsync(B.ocodes.p, d_codes, (size_t)total_bases, hipMemcpyDeviceToDevice, c->stream));
         VMX_TRY(B.res.reserve(16 * (size_t)(n + 2) + 64));
         d_gscore = B.res.as<double>(); d_mapq = (int32_t*)(d_gscore + n + 1); d_np = d_mapq + n + 1;
-        const double gs = 1.0; const int32_t mq = 60, one = 1, zero = 0, len32 = (int32_t)preset->len;
-        VMX_HIP(hipMemcpyAsync(d_gscore, &gs, 8, hipMemcpyHostToDevice, c->stream)); VMX_HIP(hipMemcpyAsync(d_mapq, &mq, 4, hipMemcpyHostToDevice, c->stream));
-        VMX_HIP(hipMemcpyAsync(d_np, &one, 4, hipMemcpyHostToDevice, c->stream));
+        std::vector<double> gs((size_t)n, 1.0); std::vector<int32_t> mq((size_t)n, 60), one((size_t)n, 1), zero((size_t)n, 0), len32((size_t)n);
+        std::vector<vmx_anchor> chains; chains.reserve((size_t)tot_chain);
+        L.h_la_off.assign((size_t)n + 1, 0); L.h_la_cnt.assign((size_t)n, 0);
+        for (int64_t r = 0; r < n; ++r) {
+            len32[(size_t)r] = (int32_t)preset[r].len; L.h_la_cnt[(size_t)r] = (int32_t)preset[r].len; L.h_la_off[(size_t)r + 1] = L.h_la_off[(size_t)r] + preset[r].len;
+            chains.insert(chains.end(), preset[r].chain_desc, preset[r].chain_desc + preset[r].len);
+            h_aoff[(size_t)r + 1] = h_aoff[(size_t)r] + 3;
+        }
+        VMX_HIP(hipMemcpyAsync(d_gscore, gs.data(), 8 * (size_t)n, hipMemcpyHostToDevice, c->stream)); VMX_HIP(hipMemcpyAsync(d_mapq, mq.data(), 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        VMX_HIP(hipMemcpyAsync(d_np, one.data(), 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
         VMX_TRY(B.gmax.reserve(8 * (size_t)(n + 1))); VMX_HIP(hipMemsetAsync(B.gmax.p, 0, 8 * (size_t)n, c->stream));
-        h_aoff[0] = 0; h_aoff[1] = 3;
-        L.h_la_off.assign(2, 0); L.h_la_off[1] = preset->len; L.h_la_cnt.assign(1, len32);
-        VMX_TRY(upload(L.la_off, L.h_la_off.data(), 2, c->stream));
-        VMX_TRY(upload(L.chain, preset->chain_desc, (size_t)preset->len, c->stream));
-        VMX_TRY(L.chain_len.reserve(8)); VMX_HIP(hipMemcpyAsync(L.chain_len.p, &len32, 4, hipMemcpyHostToDevice, c->stream));
-        VMX_TRY(L.status.reserve(8)); VMX_HIP(hipMemcpyAsync(L.status.p, &zero, 4, hipMemcpyHostToDevice, c->stream));
-        VMX_HIP(vmx_stream_sync(c));                              // the small host values above are on their way
+        VMX_TRY(upload(L.la_off, L.h_la_off.data(), (size_t)n + 1, c->stream));
+        VMX_TRY(upload(L.chain, chains.data(), chains.size(), c->stream));
+        VMX_TRY(upload(L.chain_len, len32.data(), (size_t)n, c->stream));
+        VMX_TRY(upload(L.status, zero.data(), (size_t)n, c->stream));
+        VMX_HIP(vmx_stream_sync(c));                              // the host vectors above are on their way
         for (int e = 0; e < 3; ++e) VMX_HIP(hipEventRecord(ev[nev++], c->stream));
         return 0;
     };

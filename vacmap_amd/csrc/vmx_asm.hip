@@ -489,7 +489,8 @@ int asm_long_group(vm_ctx* c, const vm_index* mi, const vm_params* prm, std::vec
     lap(t_seed2);
     VMX_TRY(run_round(true));
     lap(t_dp2);
-    // ---- traceback, overlap trim (:23400-23412), ass_extend_func (:23414)
+    // ---- traceback, overlap trim (:23400-23412), ass_extend_func (:23414) for all contigs of the group in one pass of the extend stage
+    std::vector<LongContig*> X;
     for (LongContig* Cn : G) {
         LongContig& C = *Cn;
         if (C.done) continue;
@@ -508,16 +509,41 @@ int asm_long_group(vm_ctx* c, const vm_index* mi, const vm_params* prm, std::vec
             pre = now;
         }
         dump_rows("path2.bin", C.path2);
-        const int64_t off1[2] = {0, C.len};
-        DevBuf d_off; struct Rel1 { DevBuf* a; ~Rel1() { a->release(); } } rel1{&d_off};
-        VMX_TRY(upload(d_off, off1, 2, c->stream));
-        std::vector<int64_t> h_off(off1, off1 + 2);
-        vmx_preset ps; ps.chain_desc = C.path2.data(); ps.len = (int64_t)C.path2.size();     // descending read order, as the extend stage takes a local chain
-        int32_t st1 = 0;
-        const int rce = align_device(c, mi, prm, 1, C.d_codes.as<uint8_t>(), d_off.as<int64_t>(), h_off, &C.recs, &C.n_recs, &C.blob, &st1, nullptr, nullptr, &ps);
-        if (rce < 0) return rce;
-        C.status = st1; C.done = true;
-        C.d_codes.release();
+        X.push_back(Cn);
+    }
+    if (!X.empty()) {
+        const int64_t nx = (int64_t)X.size();
+        std::vector<int64_t> h_off((size_t)nx + 1, 0);
+        for (int64_t i = 0; i < nx; ++i) h_off[(size_t)i + 1] = h_off[(size_t)i] + X[(size_t)i]->len;
+        DevBuf d_off, d_all; struct Rel1 { DevBuf *a, *b; ~Rel1() { a->release(); b->release(); } } rel1{&d_off, &d_all};
+        VMX_TRY(upload(d_off, h_off.data(), (size_t)nx + 1, c->stream));
+        const uint8_t* codes = X[0]->d_codes.as<uint8_t>();
+        if (nx > 1) {
+            VMX_TRY(d_all.reserve((size_t)h_off[(size_t)nx] + 64));
+            for (int64_t i = 0; i < nx; ++i) VMX_HIP(hipMemcpyAsync(d_all.as<uint8_t>() + h_off[(size_t)i], X[(size_t)i]->d_codes.p, (size_t)X[(size_t)i]->len, hipMemcpyDeviceToDevice, c->stream));
+            VMX_HIP(vmx_stream_sync(c));
+            for (int64_t i = 0; i < nx; ++i) X[(size_t)i]->d_codes.release();
+            codes = d_all.as<uint8_t>();
+        }
+        std::vector<vmx_preset> ps((size_t)nx);
+        for (int64_t i = 0; i < nx; ++i) { ps[(size_t)i].chain_desc = X[(size_t)i]->path2.data(); ps[(size_t)i].len = (int64_t)X[(size_t)i]->path2.size(); }     // descending read order, as the extend stage takes a local chain
+        vm_record* r0 = nullptr; int64_t nr = 0; char* cb = nullptr; std::vector<int32_t> st((size_t)nx, 0);
+        const int rce = align_device(c, mi, prm, nx, codes, d_off.as<int64_t>(), h_off, &r0, &nr, &cb, st.data(), nullptr, nullptr, ps.data());
+        if (rce < 0) { free(r0); free(cb); return rce; }
+        for (int64_t i = 0; i < nx; ++i) {
+            LongContig& C = *X[(size_t)i];
+            int64_t cnt = 0; size_t bytes = 0;
+            for (int64_t x = 0; x < nr; ++x) if (r0[x].read_idx == (int32_t)i) { ++cnt; bytes += (size_t)r0[x].cigar_len + 1; }
+            C.recs = (vm_record*)malloc(sizeof(vm_record) * (size_t)std::max<int64_t>(cnt, 1)); C.blob = (char*)malloc(std::max<size_t>(bytes, 1));
+            int64_t w = 0; size_t bo = 0;
+            for (int64_t x = 0; x < nr; ++x) if (r0[x].read_idx == (int32_t)i) {
+                vm_record y = r0[x]; y.read_idx = 0; memcpy(C.blob + bo, cb + r0[x].cigar_off, (size_t)r0[x].cigar_len); C.blob[bo + (size_t)r0[x].cigar_len] = 0;
+                y.cigar_off = (int64_t)bo; bo += (size_t)r0[x].cigar_len + 1; C.recs[w++] = y;
+            }
+            C.n_recs = cnt; C.status = st[(size_t)i]; C.done = true;
+            C.d_codes.release();
+        }
+        free(r0); free(cb);
     }
     lap(t_ext);
     if (timing) fprintf(stderr, "[asm] %zu contigs, %lld bases: windows+seed %.2f s, linked GC %.2f s (%lld anchors), re-seed %.2f s, linked LC %.2f s (%lld anchors), traceback+extend %.2f s\n",

@@ -10,7 +10,7 @@ struct vm_index_view {
 void vmx_index_view(const vm_index* mi, vm_index_view* v);
 
 // a chain handed to the extend stage instead of the seed / chain stages (host rows, DESCENDING read order like a local chain)
-struct vmx_preset { const vmx_anchor* chain_desc; int64_t len; };
+struct vmx_preset { const vmx_anchor* chain_desc; int64_t len; };      // one per read of the call (align_device takes an array of n)
 
 struct vmx_local_bufs {
     vmx::DevBuf sq, dst, rorder, pc2, stg, si, tg, cntp, fp, pp;
