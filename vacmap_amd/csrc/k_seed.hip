@@ -260,7 +260,12 @@ __global__ void __launch_bounds__(256) k_fill_hits(const uint32_t* __restrict__ 
 #endif
 #define VMX_CF_F_U64 (1 << (VMX_CF_SLOT_BITS - 5))                       /* filter: 2 bits per slot */
 #define VMX_CF_CS_U64 ((VMX_CF_CAND + 512) / 4)                          /* cluster starts, uint16 each */
-#define VMX_CF_TOTAL_U64 (VMX_CF_F_U64 + VMX_CF_CAND + VMX_CF_CS_U64 + 1024 + 1024)
+/* the filter and the arrays of the later phases share the tile: the filter's verdict on every hit goes to a byte array in HBM, the candidate keys
+   pass through HBM once, and everything after the filter phase (candidates, cluster starts, histogram, selection) overlays the filter's 64 KB.
+   64 KB instead of 121 KB per workgroup: the kernel no longer needs a CU's LDS to itself (VMX_CLUSTER_BIG=0, the 32 KB kernel without this
+   form, timed the same in the pipeline as the 121 KB form — what the filtered form saved alone it lost by keeping k_local_seed off its CUs) */
+#define VMX_CF_REST_U64 (VMX_CF_CAND + VMX_CF_CS_U64 + 1024 + 1024)
+#define VMX_CF_TOTAL_U64 (VMX_CF_F_U64 > VMX_CF_REST_U64 ? VMX_CF_F_U64 : VMX_CF_REST_U64)
 __device__ __forceinline__ bool vmx_cf_is_cand(const uint32_t* F, uint64_t key) {
     const unsigned slot = (unsigned)((key >> 28) >> 13) & ((1u << VMX_CF_SLOT_BITS) - 1u);
     const unsigned lo = (slot - 1u) & ((1u << VMX_CF_SLOT_BITS) - 1u), hi = (slot + 1u) & ((1u << VMX_CF_SLOT_BITS) - 1u);
@@ -275,8 +280,10 @@ template <int BLOCK>
 __device__ __forceinline__ bool vmx_cluster_filtered(const uint64_t* __restrict__ K, int n, int check_num, int kmer, uint64_t* s_sort, int* s_scan,
                                                      int64_t* __restrict__ out, int32_t* __restrict__ n_anchors_r) {
     __shared__ int s_cf[8];
-    uint32_t* F = (uint32_t*)s_sort;                              // 64 KB: 2 bits per slot
-    uint64_t* CAND = s_sort + VMX_CF_F_U64;                       // 32 KB: candidate keys, sorted in place
+    uint32_t* F = (uint32_t*)s_sort;                              // 64 KB: 2 bits per slot (filter phase only)
+    uint64_t* CAND = s_sort;                                      // 32 KB: candidate keys, sorted in place (over the filter, once it is done)
+    uint64_t* GC = (uint64_t*)out;                                // HBM scratch in the read's (still unused) output rows: candidate keys ...
+    uint8_t* FLAG = (uint8_t*)out + 8 * (size_t)n;                // ... and the filter's verdict per hit (1 = candidate); 9 n of the 32 n bytes
     uint16_t* CS = (uint16_t*)(CAND + VMX_CF_CAND);               // 9 KB: first hit of every candidate cluster (+ end); later the output offsets
     uint32_t* HIST = (uint32_t*)(CAND + VMX_CF_CAND + VMX_CF_CS_U64);     // 8 KB: radix-select / size histogram; later the isolated keys that were selected
     uint64_t* ISO = (uint64_t*)HIST;
@@ -295,12 +302,16 @@ __device__ __forceinline__ bool vmx_cluster_filtered(const uint64_t* __restrict_
     __syncthreads();
     for (int i = tid; i < n; i += BLOCK) {
         const uint64_t key = K[i];
-        if (vmx_cf_is_cand(F, key)) { const int p = atomicAdd(&s_cf[0], 1); if (p < VMX_CF_CAND) CAND[p] = key; }
+        const bool cnd = vmx_cf_is_cand(F, key);
+        FLAG[i] = cnd ? 1 : 0;
+        if (cnd) { const int p = atomicAdd(&s_cf[0], 1); if (p < VMX_CF_CAND) GC[p] = key; }
     }
     __syncthreads();
     const int ncand = s_cf[0];
     __syncthreads();
     if (ncand > VMX_CF_CAND) return false;
+    for (int i = tid; i < ncand; i += BLOCK) CAND[i] = GC[i];     // the filter is dead from here on: its LDS holds the later phases' arrays
+    __syncthreads();
     int NC = 1; while (NC < ncand) NC <<= 1;
     for (int i = ncand + tid; i < NC; i += BLOCK) CAND[i] = VMX_INF64;
     __syncthreads();
@@ -386,7 +397,7 @@ __device__ __forceinline__ bool vmx_cluster_filtered(const uint64_t* __restrict_
                 }
                 for (int i = tid; i < n; i += BLOCK) {
                     const uint64_t key = K[i];
-                    if (!vmx_cf_is_cand(F, key)) { const uint64_t v = key >> 28; if ((v & himask) == prefix) { const unsigned b = (unsigned)(v >> shift) & 0xfffu; atomicAdd(&HIST[b >> 1], 1u << (16 * (b & 1))); } }
+                    if (!FLAG[i]) { const uint64_t v = key >> 28; if ((v & himask) == prefix) { const unsigned b = (unsigned)(v >> shift) & 0xfffu; atomicAdd(&HIST[b >> 1], 1u << (16 * (b & 1))); } }
                 }
                 __syncthreads();
                 // bins 4 tid .. 4 tid + 3 per thread; the bin where the running count reaches `rem`
@@ -414,7 +425,7 @@ __device__ __forceinline__ bool vmx_cluster_filtered(const uint64_t* __restrict_
         }
         for (int i = tid; i < n; i += BLOCK) {
             const uint64_t key = K[i];
-            if (!vmx_cf_is_cand(F, key) && (key >> 28) <= T) {
+            if (!FLAG[i] && (key >> 28) <= T) {
                 const int q = atomicAdd(&s_cf[6], 1);
                 if (nsel + q < 1024) { ISO[q] = key; SEL[nsel + q] = ((uint64_t)(0x3fffu - 1u) << 50) | ((key >> 28) << 14) | (uint64_t)(0x2000 | q); }
             }
@@ -470,7 +481,7 @@ __device__ __forceinline__ void vmx_cluster_body(uint64_t* __restrict__ keys, ui
         int N = 1; while (N < n) N <<= 1;
         uint64_t* K = keys + key_off[r];
         uint64_t* CK = cl_keys + key_off[r];
-        if (BLOCK == 1024 && tile >= VMX_CF_TOTAL_U64 && n <= tile && check_num > 0 && check_num <= 1024) {
+        if (BLOCK == 1024 && tile >= VMX_CF_TOTAL_U64 && check_num > 0 && check_num <= 1024) {
             // (uniform: every thread sees the same n and gets the same answer)
             const bool cf_done = vmx_cluster_filtered<BLOCK>(K, n, check_num, kmer, s_sort, s_scan, rows + 4 * key_off[r], &n_anchors[r]);
 #ifdef VMX_EMU

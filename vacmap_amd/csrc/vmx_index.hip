@@ -651,8 +651,19 @@ int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, in
 #ifndef VMX_EMU
             VMX_HIP(hipFuncSetAttribute((const void*)k_cluster_big, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * VMX_SORT_LDS_BIG));
 #endif
-            hipLaunchKernelGGL(k_cluster_big, dim3((unsigned)std::min<int64_t>((int64_t)big.size(), c->num_cu)), dim3(1024), 8 * VMX_SORT_LDS_BIG, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(),
-                               koff.as<int64_t>(), nh.as<int64_t>(), d_rl + small.size(), (int)big.size(), VMX_SORT_LDS_BIG, check_num, mi->k, rows.as<int64_t>(), nanc.as<int32_t>());
+            // `big` is ordered by hit count, largest first: reads with more than 16383 hits (the filtered form declines them: cluster sizes travel
+            // in 14 bits) take the 128 KB tile of the general path; the others run the filtered form in a 64 KB tile, two workgroups per CU or
+            // one next to k_local_seed's (VMX_CLUSTER_TILE: keys of that tile, tuning knob)
+            static const int mid_tile = [] { const char* e = getenv("VMX_CLUSTER_TILE"); const int v = e ? atoi(e) : 0; return v >= 8192 && v <= VMX_SORT_LDS_BIG ? v : (VMX_SORT_LDS_BIG >= 16384 ? 8192 : VMX_SORT_LDS_BIG); }();
+            size_t n_huge = 0; while (n_huge < big.size() && h_nhits[big[n_huge]] > 0x3fff) ++n_huge;
+            if (mid_tile >= VMX_SORT_LDS_BIG) n_huge = big.size();
+            const size_t n_mid = big.size() - n_huge;
+            if (n_huge)
+                hipLaunchKernelGGL(k_cluster_big, dim3((unsigned)std::min<int64_t>((int64_t)n_huge, c->num_cu)), dim3(1024), 8 * VMX_SORT_LDS_BIG, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(),
+                                   koff.as<int64_t>(), nh.as<int64_t>(), d_rl + small.size(), (int)n_huge, VMX_SORT_LDS_BIG, check_num, mi->k, rows.as<int64_t>(), nanc.as<int32_t>());
+            if (n_mid)
+                hipLaunchKernelGGL(k_cluster_big, dim3((unsigned)std::min<int64_t>((int64_t)n_mid, (int64_t)c->num_cu * 2)), dim3(1024), (size_t)8 * mid_tile, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(),
+                                   koff.as<int64_t>(), nh.as<int64_t>(), d_rl + small.size() + n_huge, (int)n_mid, mid_tile, check_num, mi->k, rows.as<int64_t>(), nanc.as<int32_t>());
         }
         if (!small.empty())
             hipLaunchKernelGGL(k_cluster, dim3((unsigned)std::min<int64_t>((int64_t)small.size(), (int64_t)c->num_cu * 4)), dim3(256), 8 * VMX_SORT_LDS, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(),
