@@ -235,3 +235,12 @@ __global__ void k_link_place(vmx_link_job* __restrict__ jobs, int n_jobs) {
         for (int i = (int)threadIdx.x; i < n_pre; i += (int)blockDim.x) J.rows[base + i] = ST.pre_rows[i];
     }
 }
+
+// a batch's anchors in read order (yield_mapinfo's one_mapinfo[np.argsort(one_mapinfo[:, 0])], :22431 — stable): keys for the device-wide radix sort
+// (stable, rocPRIM through vmx_index_prim.h) and the gather by the sorted index
+__global__ void k_link_sort_keys(const vmx_anchor* __restrict__ rows, int64_t n, uint64_t* __restrict__ key, uint64_t* __restrict__ idx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { key[i] = (uint64_t)(uint32_t)rows[i].q; idx[i] = (uint64_t)i; }
+}
+__global__ void k_link_sort_gather(const vmx_anchor* __restrict__ rows, const uint64_t* __restrict__ idx, int64_t n, vmx_anchor* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = rows[idx[i]];
+}

@@ -2,6 +2,7 @@
 // The per-read function of the fork (contigs below 500 kb) runs through vm_align_batch with VM_MODE_ASM (vmx_align.hip).
 #include "vmx_host.h"
 #include "vmx_link.h"
+#include "vmx_index_prim.h"
 #include <cstring>
 
 using namespace vmx;
@@ -14,6 +15,8 @@ static bool asm_link_plain() { static const bool v = getenv("VMX_LINK_PLAIN") !=
 static double asm_max_factor() { const char* e = getenv("VMX_TEST_ASM_MAX_FACTOR"); return e ? atof(e) : 1000.0; }
 __global__ void k_link_carry(vmx_link_job* jobs, int n_jobs, double skipcost);
 __global__ void k_link_place(vmx_link_job* jobs, int n_jobs);
+__global__ void k_link_sort_keys(const vmx_anchor* rows, int64_t n, uint64_t* key, uint64_t* idx);
+__global__ void k_link_sort_gather(const vmx_anchor* rows, const uint64_t* idx, int64_t n, vmx_anchor* out);
 __global__ void k_chain_linked_fast(vmx_link_job* jobs, int n_jobs, vmx_tables tab, const double* gapcost_list, double skipcost, int maxdiff, int maxgap);
 
 namespace {
@@ -355,6 +358,29 @@ int second_round_seed(vm_ctx* c, const vm_index_view& ix, int k, const uint8_t* 
 
 namespace {
 
+// one_mapinfo[np.argsort(one_mapinfo[:, 0])] (:22431, stable) on the device: radix sort of (read position, index) pairs, gather, back to the host copy
+struct SortBufs { DevBuf in, out, k0, k1, v0, v1, tmp; SortBufs() = default; SortBufs(const SortBufs&) = delete; ~SortBufs() { for (DevBuf* b : {&in, &out, &k0, &k1, &v0, &v1, &tmp}) b->release(); } };
+int device_sort_by_q(vm_ctx* c, SortBufs& B, std::vector<vmx_anchor>& rows) {
+    const size_t n = rows.size();
+    if (n < 2) return 0;
+    VMX_TRY(upload(B.in, rows.data(), n, c->stream)); VMX_TRY(B.out.reserve(sizeof(vmx_anchor) * n));
+    VMX_TRY(B.k0.reserve(8 * n)); VMX_TRY(B.k1.reserve(8 * n)); VMX_TRY(B.v0.reserve(8 * n)); VMX_TRY(B.v1.reserve(8 * n));
+    const vmx_anchor* d_in = B.in.as<vmx_anchor>(); vmx_anchor* d_out = B.out.as<vmx_anchor>();
+    uint64_t *k0 = B.k0.as<uint64_t>(), *k1 = B.k1.as<uint64_t>(), *v0 = B.v0.as<uint64_t>(), *v1 = B.v1.as<uint64_t>();
+    const int64_t nn = (int64_t)n; hipStream_t stq = c->stream;
+    const unsigned grid = (unsigned)std::min<int64_t>((nn + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_link_sort_keys, dim3(grid), dim3(256), 0, stq, d_in, nn, k0, v0);
+    size_t tb = 0;
+    VMX_HIP((hipError_t)vmx_prim_sort_pairs_u64(nullptr, &tb, k0, k1, v0, v1, n, 32, c->stream));
+    VMX_TRY(B.tmp.reserve(tb + 64));
+    VMX_HIP((hipError_t)vmx_prim_sort_pairs_u64(B.tmp.p, &tb, k0, k1, v0, v1, n, 32, c->stream));
+    hipLaunchKernelGGL(k_link_sort_gather, dim3(grid), dim3(256), 0, stq, d_in, (const uint64_t*)v1, nn, d_out);
+    VMX_TRY(download(rows.data(), B.out.p, n, c->stream));
+    VMX_HIP(vmx_stream_sync(c));
+    VMX_HIP(hipGetLastError());
+    return 0;
+}
+
 struct LongContig {
     const char* src = nullptr; int64_t len = 0;
     std::string seq; int status = 0; bool done = false;           // done: finished (records or a status), nothing more to run
@@ -378,6 +404,7 @@ int asm_long_group(vm_ctx* c, const vm_index* mi, const vm_params* prm, std::vec
     double t_mark = now_s(), t_seed = 0, t_dp1 = 0, t_seed2 = 0, t_dp2 = 0, t_ext = 0; int64_t n_a1 = 0, n_a2 = 0, bases = 0;
     auto lap = [&](double& acc) { const double t = now_s(); acc += t - t_mark; t_mark = t; };
     DevBuf d_jobs; struct RelJ { DevBuf* a; ~RelJ() { a->release(); } } relj{&d_jobs};
+    SortBufs sortb;
     // ---- first round :23214-23292: the batches of every contig (yield_mapinfo :22411-22443)
     for (LongContig* Cn : G) {
         LongContig& C = *Cn;
@@ -387,10 +414,11 @@ int asm_long_group(vm_ctx* c, const vm_index* mi, const vm_params* prm, std::vec
         VMX_TRY(C.r1.init(c, 0, ix.k, prm->global_skipcost, prm->global_maxdiff, 1000));
         std::vector<std::vector<vmx_anchor>> cache; int64_t cache_size = 0;
         std::vector<vmx_anchor> one;
-        auto emit = [&](std::vector<vmx_anchor>& batch) {
-            std::stable_sort(batch.begin(), batch.end(), [](const vmx_anchor& a, const vmx_anchor& b) { return a.q < b.q; });
+        auto emit = [&](std::vector<vmx_anchor>& batch) -> int {
+            VMX_TRY(device_sort_by_q(c, sortb, batch));
             n_a1 += (int64_t)batch.size();
             if (!batch.empty()) C.batches.push_back(batch);        // :23231 an empty pack is skipped
+            return 0;
         };
         const int64_t n_win = (C.len + window - 1) / window;
         const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(256, ((int64_t)32 << 20) / window));
@@ -411,7 +439,7 @@ int asm_long_group(vm_ctx* c, const vm_index* mi, const vm_params* prm, std::vec
                         one.swap(all); cache_size = 0; cache.clear();
                     }
                     std::vector<vmx_anchor> batch = one;
-                    emit(batch);
+                    { const int rcs = emit(batch); if (rcs < 0) { free(anchors); free(aoff); return rcs; } }
                 } else if (!one.empty()) { cache.push_back(one); cache_size += (int64_t)one.size(); }
             }
             free(anchors); free(aoff);
@@ -419,7 +447,7 @@ int asm_long_group(vm_ctx* c, const vm_index* mi, const vm_params* prm, std::vec
         if (cache_size > 0) {                                    // :22439-22443, including the second copy of the last window's anchors
             if (!one.empty()) cache.push_back(one);
             std::vector<vmx_anchor> all; for (auto& cc : cache) all.insert(all.end(), cc.begin(), cc.end());
-            emit(all);
+            VMX_TRY(emit(all));
         }
     }
     lap(t_seed);
