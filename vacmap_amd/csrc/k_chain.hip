@@ -185,6 +185,17 @@ __device__ __forceinline__ void vmx_gap_geometry_asm(int qi, long long ri, int s
 // One read. IN_LDS is a compile-time switch so that the working arrays are plain LDS pointers (ds_read / ds_write) in the instantiation the
 // buckets run and plain global pointers in the other; a run-time choice between the two would turn every access into a flat_load.
 // VAR: 0 = modes H / L / S, 1 = mode R, 2 = -mode asm (mammap_asm.py:20551-20737: no coverage terms, vmx_gap_geometry_asm, H's scoring)
+// LINK defers the wait for its own stores: the common path of an anchor reads nothing it has written (scores of the current group, window and
+// anchor blocks are registers), so the wave does not stop at every anchor for its S / P / S_arg stores to be acknowledged; the rare paths that
+// do read them back (an insertion or a scan through the index in HBM, a group that straddles an anchor block) wait first. The emulator's
+// fibers need the barrier at every anchor (its lanes run one after the other between collectives).
+#ifdef VMX_EMU
+#define VMX_LINK_WAIT() ((void)0)
+#define VMX_LINK_STEP_BARRIER(link) __syncthreads()
+#else
+#define VMX_LINK_WAIT() __syncthreads()
+#define VMX_LINK_STEP_BARRIER(link) do { if (!(link)) __syncthreads(); } while (0)
+#endif
 // LINK (with VAR 2, IN_LDS false): the batch-LINKED forms of -mode asm (mammap_asm.py:21686-21870 GC-exact, :21504-21685 LC): the first lk->n_pre
 // rows carry S / P from the previous batch (already in S_out / P_out), the index starts with row 0 alone, the loop behind the carried rows,
 // the running maximum and prereadloc come from the caller; lk->lc: co-linear steps also pay readgapcost_list[readgap], no bail-out
@@ -239,8 +250,10 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
         __syncthreads();
         double g_max_scores = carried ? lk->g_max_scores : (double)AL(0); int g_max_index = carried ? lk->g_max_index : 0;
         long long opcount = 0;
+        long long dbg_fallback = 0, dbg_block2 = 0, dbg_groups = 0;      // LINK: tuning counters (insertions through HBM, scans past the window, position advances)
         bool bailed = false;
         // candidate window: the testspace_en entries of S_arg, best first, the top 64 of them in registers
+        double gS = 0.0; int gbase = 0x7fffffff;      // LINK: score of the (lane)-th anchor computed since the last position advance (anchor gbase + lane)
         vmx_cwin win; win.j = 0; win.q = AQ(0); win.ls = AL(0) | (AS(0) << 16); win.S = carried ? S[0] : (double)AL(0); win.r = AR(0);
         // anchors [bb, bb + 64) in registers (lane t: anchor bb + t), the next block already on its way
         int bq = 0, bls = 0, bcov = 0, nbq = 0, nbls = 0, nbcov = 0; long long br = 0, nbr = 0;
@@ -264,25 +277,54 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
                     double Sk; int qk, lsk; long long rk;
                     if (k == i - 1) { Sk = pS; qk = pq; lsk = pls; rk = pr; }
                     else if (k >= bb) {
-                        const int kl = k - bb; Sk = S[k]; qk = vmx_readlane(bq, kl); lsk = vmx_readlane(bls, kl);
+                        // (LINK: the scores of the anchors computed since the last advance wait in a register, lane = place in that group — several
+                        // noise hits share a read position there, and S[k] would be a load of a value this wave stored a moment ago)
+                        const int kl = k - bb;
+                        if (LINK && k >= gbase && k - gbase < 64) Sk = vmx_readlane_f64(gS, k - gbase); else { if constexpr (LINK) VMX_LINK_WAIT(); Sk = S[k]; }
+                        qk = vmx_readlane(bq, kl); lsk = vmx_readlane(bls, kl);
                         union { long long d; int w[2]; } u; u.d = br; u.w[0] = vmx_readlane(u.w[0], kl); u.w[1] = vmx_readlane(u.w[1], kl); rk = u.d;
-                    } else { Sk = S[k]; qk = AQ(k); lsk = AL(k) | (AS(k) << 16); rk = AR(k); }
+                    } else { if constexpr (LINK) VMX_LINK_WAIT(); Sk = S[k]; qk = AQ(k); lsk = AL(k) | (AS(k) << 16); rk = AR(k); }
                     // the reference's bisection (:19369-19387) puts a score without an equal behind all smaller ones; among equals the place
                     // depends on its probe sequence (vmx_insertpoint_score_wave): the window handles the first case
                     const int W = k < 64 ? k : 64;               // k entries so far
                     const unsigned long long gt = __ballot(lane < W && win.S > Sk), ge = __ballot(lane < W && win.S >= Sk);
                     const int above = __popcll(gt);
+                    if constexpr (LINK) {
+                        // Equal scores are the rule here, not the exception: against an hg38-size reference nine in ten anchors are noise hits, each
+                        // hangs itself onto the best chain at skipcost + extra's last value (36), and all that do so between two steps of the chain
+                        // score S_top - 51 + l exactly. When the run of equal scores ends inside the window its bounds (#entries below, #not above)
+                        // follow from the two ballots, the reference's bisection is replayed on them in scalar registers, and the entry is placed
+                        // among its equals in the window — no walk through the index in HBM.
+                        const int cge = __popcll(ge);
+                        if (above < 64 && (cge < W || W == k)) {
+                            int at = above;
+                            if (gt != ge) {
+                                const int a = k - cge, b = k - above;
+                                int i2 = 0, j2 = k, loc = -1;
+                                while (i2 < j2) { const int mid = (i2 + j2) >> 1; if (mid < a) i2 = mid + 1; else if (mid >= b) j2 = mid; else { loc = mid + 1; break; } }
+                                if (loc < 0) loc = j2;
+                                at = k - loc;
+                            }
+                            if (at < 64) {
+                                vmx_cwin_insert(win, at, k, Sk, qk, lsk, rk, lane);
+                                if (lane <= at) SA[k - lane] = win.j;
+                                continue;
+                            }
+                        }
+                    }
                     if (gt == ge && above < 64 && (above < W || W == k)) {
                         vmx_cwin_insert(win, above, k, Sk, qk, lsk, rk, lane);
                         if (lane <= above) SA[k - lane] = win.j;
                     } else {
+                        ++dbg_fallback;
+                        if constexpr (LINK) VMX_LINK_WAIT();
                         const int loc = LINK ? vmx_insertpoint_score_topdown(S, Sk, k, SA, lane) : vmx_insertpoint_score_wave(S, Sk, k, SA, lane);
                         vmx_sarg_insert4(SA, loc, k, lane);
                         // (an entry that lands below the 64 of the window leaves the window as it is)
                         if ((!LINK || k - loc < 64) && lane <= k) { const int j = SA[k - lane]; win.j = j; win.S = S[j]; win.q = AQ(j); win.ls = AL(j) | (AS(j) << 16); win.r = AR(j); }
                     }
                 }
-                testspace_en = i;
+                testspace_en = i; ++dbg_groups; gbase = i;
                 if (!nocov) {
                     const int covi = vmx_readlane(bcov, bl);
                     skipcost = oskipcost + (double)covi;
@@ -301,7 +343,7 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
                 if (valid) {
                     int qj, lj, sj; long long rj;
                     if (base == testspace_en - 1) { j = win.j; Sj = win.S; qj = win.q; lj = win.ls & 0xffff; sj = win.ls >> 16; rj = win.r; }   // first 64: registers
-                    else { j = SA[x]; Sj = S[j]; qj = AQ(j); lj = AL(j); sj = AS(j); rj = AR(j); }
+                    else { j = SA[x]; Sj = S[j]; qj = AQ(j); lj = AL(j); sj = AS(j); rj = AR(j); if (lane == 0) ++dbg_block2; }      // (LINK: the wait is in front of the loop's second turn, below)
                     long long readgap, refgap, bonus;
                     if constexpr (VAR == 2) vmx_gap_geometry_asm(qi, ri, si, li, qj, rj, sj, lj, readgap, refgap, bonus);
                     else vmx_gap_geometry(qi, ri, si, li, qj, rj, sj, lj, readgap, refgap, bonus);
@@ -341,11 +383,13 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
                     }
                 }
                 if (first < 64) break;
+                if constexpr (LINK) VMX_LINK_WAIT();              // the next block of candidates comes from the index in HBM
             }
             if (lane == 0) { S[i] = max_scores; P[i] = pre_index; if (rmode) { FP[i] = fp_i; PP[i] = pp_i; } }
+            if constexpr (LINK) { if (i - gbase < 64 && lane == i - gbase) gS = max_scores; }
             if (max_scores > g_max_scores) { g_max_scores = max_scores; g_max_index = i; }
             pS = max_scores; pq = qi; pls = lsi; pr = ri;
-            if constexpr (IN_LDS && VAR != 1) vmx_wave_lds_fence(); else __syncthreads();     // (mode R: FP / PP go through HBM)
+            if constexpr (IN_LDS && VAR != 1) vmx_wave_lds_fence(); else VMX_LINK_STEP_BARRIER(LINK);     // (mode R: FP / PP go through HBM)
         }
         __syncthreads();
         if (!bailed) {
@@ -357,7 +401,7 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
         if constexpr (IN_LDS) {
             for (int i = lane; i < n; i += 64) { S_out[a0 + i] = S[i]; SA_out[a0 + i] = SA[i]; }
         }
-        if (lane == 0) { gmax_out[rd] = bailed ? -1 : g_max_index; opcount_out[rd] = opcount; }
+        if (lane == 0) { gmax_out[rd] = bailed ? -1 : g_max_index; opcount_out[rd] = opcount; if constexpr (LINK) { opcount_out[rd + 1] = dbg_fallback; opcount_out[rd + 2] = dbg_block2; opcount_out[rd + 3] = dbg_groups; } }
         __syncthreads();
 #undef AQ
 #undef AR
@@ -414,11 +458,12 @@ __global__ void __launch_bounds__(64) k_chain_linked_win(vmx_link_job* __restric
         __syncthreads();
         vmx_link_in lk; lk.n_pre = n_pre; lk.g_max_scores = ST.g_max_scores; lk.g_max_index = ST.g_max_index; lk.prereadloc = ST.prereadloc; lk.lc = lc; lk.max_factor = max_factor;
         int64_t gm = 0, opc = 0;
-        __shared__ int64_t s_out[2];
+        __shared__ int64_t s_out[8];
         vmx_chain_global_read<false, 2, true>(J.rows + base, 0, 0, n, 0, smem, s_gapcost, 0, tab, skipcost, maxdiff, maxgap, S, P, J.SA, nullptr, &s_out[0], &s_out[1], nullptr, nullptr, &lk);
         __syncthreads();
         gm = s_out[0]; opc = s_out[1];
-        if (lane == 0) { J.ran = 1; J.n = n; J.hot = n; J.n_cold = 0; J.cold_max = -1e300; J.gmax = gm; J.opcount = opc; }
+        if (lane == 0) { J.ran = 1; J.n = n; J.hot = n; J.n_cold = 0; J.cold_max = -1e300; J.gmax = gm; J.opcount = opc;
+                         if (J.dbg) { J.dbg[0] += n; J.dbg[1] += s_out[2]; J.dbg[2] += s_out[3]; J.dbg[3] += s_out[4]; J.dbg[4] += opc; } }
         __syncthreads();
     }
 }

@@ -207,6 +207,8 @@ int run_jobs(vm_ctx* c, DevBuf& d_jobs, const std::vector<LinkRound*>& rounds, c
     if (!nj) return 0;
     std::vector<vmx_link_job> hj(nj); std::vector<vmx_link_state> hs(nj);
     for (size_t i = 0; i < nj; ++i) VMX_TRY(rounds[i]->stage(*news[i], hj[i]));
+    static DevBuf d_dbg; static const bool dbg_on = getenv("VMX_ASM_TIME") != nullptr;
+    if (dbg_on) { if (!d_dbg.p) { VMX_TRY(d_dbg.reserve(64)); VMX_HIP(hipMemsetAsync(d_dbg.p, 0, 64, c->stream)); } for (size_t i = 0; i < nj; ++i) hj[i].dbg = d_dbg.as<long long>(); }
     VMX_TRY(upload(d_jobs, hj.data(), nj, c->stream));
     const LinkRound& R0 = *rounds[0];
     vmx_link_job* dj = d_jobs.as<vmx_link_job>(); const double* d_gap = R0.gap.as<double>(); const vmx_tables tabs = c->tables; hipStream_t stq = c->stream;
@@ -245,6 +247,8 @@ int run_jobs(vm_ctx* c, DevBuf& d_jobs, const std::vector<LinkRound*>& rounds, c
             for (size_t b = 0; b < bailed.size(); ++b) hj[bailed[b]] = fj[b];
         }
     }
+    if (dbg_on) { long long h[8]; VMX_TRY(download(h, d_dbg.p, 8, c->stream)); VMX_HIP(vmx_stream_sync(c));
+                  fprintf(stderr, "[asm] linked DP so far: %lld anchors, %lld insertions through HBM, %lld scan blocks past the window, %lld position advances, %lld candidates\n", h[0], h[1], h[2], h[3], h[4]); }
     for (size_t i = 0; i < nj; ++i) {
         const int r = rounds[i]->finish(hj[i], hs[i], *news[i]);
         if (r == VM_READ_RAISED || r == VM_READ_UNSUPPORTED || r == VM_READ_CAPACITY) rc[i] = r; else if (r < 0) return r;

@@ -26,6 +26,7 @@ struct vmx_link_job {
     int32_t* SA;                  // hot part of the score-sorted index (up to n_pre + n_new entries)
     int32_t cap_pre, n_new;
     int32_t* Si; int64_t* T; int32_t* CNT;   // linked GC-fast only (k_chain_linked_fast): int(S), diagonal key, S_i_count[last q + 50]; null otherwise
+    long long* dbg;               // optional tuning counters (VMX_ASM_TIME): anchors, insertions through HBM, scan blocks past the window, position advances, candidates
     // results
     int32_t ran, saved, n, hot; long long n_cold; double cold_max; long long gmax, opcount;
 };
