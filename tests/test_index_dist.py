@@ -174,9 +174,30 @@ from vacmap_amd import driver
 rc = driver.main(['-ref', os.path.join(tmp, 'ref.fa'), '-read', os.path.join(tmp, 'reads.fa'), '-mode', 'H', '-o', os.path.join(tmp, 'out.sam'), '-t', '8',     # 2 concurrent emit jobs: the replica's host copy of the bases is decoded once, under call_once
                   '--nowriteindex', '--batch-reads', '2', '--window-batches', '2', '--force'], comm=dist)
 assert rc == 0
+# -mode asm, sharded: contig c -> rank c mod 2, rank 0 writes the lines of every contig in input order
+asm_q = [synth.mutate(contigs[0][a:b], 0.01, np.random.default_rng(50 + a)).tobytes().decode() for a, b in ((1000, 4000), (9000, 15000), (20000, 22500), (25000, 31000), (33000, 36000))]
 if rank == 0:
+    with open(os.path.join(tmp, 'asm.fa'), 'w') as f:
+        for i, q in enumerate(asm_q):
+            f.write('>c%%d\n%%s\n' %% (i, q))
+dist.barrier()
+rc = driver.main(['-ref', os.path.join(tmp, 'ref.fa'), '-read', os.path.join(tmp, 'asm.fa'), '-mode', 'asm', '-workdir', os.path.join(tmp, 'wd%%d' %% rank),
+                  '-o', os.path.join(tmp, 'asm.sam'), '--nowriteindex', '--force'], comm=dist)
+assert rc == 0
+if rank == 0:
+    from vacmap_amd import sam as S
+    from vacmap_amd.lib import align_batch
+    prm = ctx.lib.params('asm'); prm.eqx = 1
+    st, recs, _ = align_batch(ctx, index, prm, asm_q)
+    want = []
+    for x, q in enumerate(asm_q):
+        mine = [('c%%d' %% x, index.names[t[1]]) + tuple(t[2:]) for t in recs if t[0] == x]
+        assert st[x] == 0 and mine
+        want += S.sam_lines(mine, q, None, lambda cn, a, b: index.seq(index.names.index(cn), a, b), rg_id='1', asm=True)
+    got_asm = [l.rstrip('\n') for l in open(os.path.join(tmp, 'asm.sam')) if not l.startswith('@')]
+    assert got_asm == want, (len(got_asm), len(want))
     body = [l.split('\t')[0] for l in open(os.path.join(tmp, 'out.sam')) if not l.startswith('@')]
-    print(json.dumps({'names': body, 'secs': secs}))
+    print(json.dumps({'names': body, 'secs': secs, 'asm_lines': len(got_asm)}))
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -194,6 +215,7 @@ def test_two_rank_index_broadcast_and_sharded_driver_gloo(tmp_path):
     names = d['names']
     assert sorted(set(names), key=lambda s: int(s[1:])) == ['r%d' % i for i in range(7)]
     assert names == sorted(names, key=lambda s: int(s[1:]))          # input order
+    assert d['asm_lines'] >= 5                                        # -mode asm sharded by contig: lines equal the one-rank records' (checked in the worker)
 
 
 # ---------------------------------------------------------------- minimap2 index files

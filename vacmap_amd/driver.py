@@ -13,7 +13,7 @@ text with `-t` host threads (vm_sam_emit, the C++ twin of vacmap_amd/sam.py) whi
 in input order. Like the reference's worker (:24116-24134) a read whose path or whose emission raises is skipped, and a read without
 records produces no line.
 With N ranks, rank 0 builds the index and broadcasts it over RCCL (vacmap_amd/dist.py), batch i of a window goes to rank i mod N, and
-rank 0 gathers and writes the lines. `-mode asm` (assembly contigs; one GPU): the contigs go through vm_align_batch with VM_MODE_ASM in
+rank 0 gathers and writes the lines. `-mode asm` (assembly contigs; contig c -> rank c mod N): the contigs go through vm_align_batch with VM_MODE_ASM in
 groups, in input order, and their lines come from the Python statement of the asm emitter (sam.sam_lines(asm=True) =
 iterator_get_bam_dict_str, mammap_asm.py:22757); `-workdir` is accepted and created like the reference's, but nothing is spilled into it.
 """
@@ -153,13 +153,13 @@ def _open_output(path):
 last_timing = {}          # wall seconds of the last main() call by phase (tools/driver_bench.py reads it)
 
 
-def _run_asm(args, lib, ctx, index, prm, rg, mark, out, proc, world, t_start):
+def _run_asm(args, lib, ctx, index, prm, rg, mark, out, proc, world, rank, text_group, t_start):
     """-mode asm (src/vacmap/vacmap:245-255, :394-411; worker mammap_asm.py:23462-23511): every input sequence is an assembly contig. --eqx is
     forced and maxdivergence set to 1 by vm_params_default(VM_MODE_ASM); contigs are aligned in groups (the long ones of a group side by side on
-    the GPU) and their SAM lines written in input order. A contig the reference would skip (raised) is logged and skipped."""
+    the GPU) and their SAM lines written in input order. A contig the reference would skip (raised) is logged and skipped.
+    With N ranks every rank parses the input, contig c of it goes to rank c mod N (contigs are independent: no data-path collective), and
+    rank 0 gathers each group's lines and writes them in input order."""
     from .lib import Fastx, align_batch
-    if world > 1:
-        sys.exit('-mode asm runs on one GPU')
     if not args.workdir:
         sys.exit('workdir not provided! -workdir /path/to/workdir')                      # vacmap:247-249
     os.makedirs(args.workdir, exist_ok=True)
@@ -171,24 +171,41 @@ def _run_asm(args, lib, ctx, index, prm, rg, mark, out, proc, world, t_start):
         return index.seq(names.index(cn), a, b)
 
     def flush(group):
+        """group: (input index, name, sequence, quality, comment) of consecutive input contigs, the same list on every rank"""
         nonlocal n_lines, n_skipped
-        status, recs, _ = align_batch(ctx, index, prm, [g[1] for g in group])
-        for x, (nm, seq, qual, com) in enumerate(group):
-            if status[x] != 0:
-                sys.stderr.write('%s is not aligned.\n' % nm); n_skipped += 1
+        share = [g for g in group if g[0] % world == rank]
+        done = {}                                                                           # input index -> lines, None = skipped
+        if share:
+            status, recs, _ = align_batch(ctx, index, prm, [g[2] for g in share])
+            for x, (gi, nm, seq, qual, com) in enumerate(share):
+                if status[x] != 0:
+                    sys.stderr.write('%s is not aligned.\n' % nm); done[gi] = None
+                    continue
+                mine = [(nm, names[t[1]]) + tuple(t[2:]) for t in recs if t[0] == x]
+                if not mine:
+                    done[gi] = []
+                    continue
+                try:
+                    done[gi] = sam.sam_lines(mine, seq, qual or None, refseq, md=bool(args.MD), shortcs=args.cs != 'long', cigar2cg=bool(args.L),
+                                             markunbalancetra=bool(mark), hardclip=bool(args.H), fakecigar=bool(args.fakecigar), rg_id=rg['ID'],
+                                             comments=(com if args.copycomments else None), asm=True)
+                except Exception as e:                                                      # the worker's except (:23493-23498)
+                    sys.stderr.write('%s is not aligned.\n%s\n' % (nm, e)); done[gi] = None
+        if world > 1:
+            from .dist import gather_lines
+            parts = gather_lines(done, dst=0, group=text_group)
+            if rank != 0:
+                return
+            done = {}
+            for d in parts:
+                done.update(d)
+        for gi in sorted(done):
+            if done[gi] is None:
+                n_skipped += 1
                 continue
-            mine = [(nm, names[t[1]]) + tuple(t[2:]) for t in recs if t[0] == x]
-            if not mine:
-                continue
-            try:
-                lines = sam.sam_lines(mine, seq, qual or None, refseq, md=bool(args.MD), shortcs=args.cs != 'long', cigar2cg=bool(args.L), markunbalancetra=bool(mark),
-                                      hardclip=bool(args.H), fakecigar=bool(args.fakecigar), rg_id=rg['ID'], comments=(com if args.copycomments else None), asm=True)
-            except Exception as e:                                                          # the worker's except (:23493-23498)
-                sys.stderr.write('%s is not aligned.\n%s\n' % (nm, e)); n_skipped += 1
-                continue
-            for ln in lines:
+            for ln in done[gi]:
                 out.write(ln.encode() + b'\n')
-            n_lines += len(lines)
+            n_lines += len(done[gi])
 
     group, gbases = [], 0
     for grp in args.read:
@@ -204,21 +221,25 @@ def _run_asm(args, lib, ctx, index, prm, rg, mark, out, proc, world, t_start):
                     nm = nb[no[i]:no[i + 1]].decode()
                     if nm in seen:
                         continue
-                    seen.add(nm); n_contigs += 1
-                    group.append((nm, sb[so[i]:so[i + 1]].decode(), '' if args.Q else qb[qo[i]:qo[i + 1]].decode(), cb[co[i]:co[i + 1]].decode()))
+                    seen.add(nm)
+                    keep = n_contigs % world == rank                                       # the other ranks' contigs only hold their place
+                    group.append((n_contigs, nm, sb[so[i]:so[i + 1]].decode() if keep else '', ('' if args.Q or not keep else qb[qo[i]:qo[i + 1]].decode()),
+                                  cb[co[i]:co[i + 1]].decode() if keep else ''))
+                    n_contigs += 1
                     gbases += so[i + 1] - so[i]
-                    if len(group) >= 64 or gbases >= 400_000_000:
+                    if len(group) >= 64 * world or gbases >= 400_000_000 * world:
                         flush(group); group, gbases = [], 0
     if group:
         flush(group)
-    if proc is not None:
-        out.close(); proc.wait()
-    elif args.o != '-':
-        out.close()
-    else:
-        out.flush()
-    tt = max(time.time() - t_start, 0.001)
-    sys.stderr.write('vacmapx: %d contigs, %d SAM lines, %d contigs skipped, %.1f s\n' % (n_contigs, n_lines, n_skipped, tt))
+    if rank == 0:
+        if proc is not None:
+            out.close(); proc.wait()
+        elif args.o != '-':
+            out.close()
+        else:
+            out.flush()
+        tt = max(time.time() - t_start, 0.001)
+        sys.stderr.write('vacmapx: %d contigs, %d SAM lines, %d contigs skipped, %.1f s\n' % (n_contigs, n_lines, n_skipped, tt))
     return 0
 
 
@@ -290,7 +311,7 @@ def main(argv=None, comm=None):
         for ln in sam.header_lines([(n, ln_) for n, ln_ in zip(names, index.lens)], ' '.join(sys.argv if argv is None else ['vacmapx'] + list(argv)), rg):
             out.write(ln.encode() + b'\n')
     if args.mode == 'asm':
-        return _run_asm(args, lib, ctx, index, prm, rg, mark, out, proc, world, t_start)
+        return _run_asm(args, lib, ctx, index, prm, rg, mark, out, proc, world, rank, text_group, t_start)
     pipe = pipeline.Pipeline(index, prm, device=device, inflight=args.inflight, first_ctx=ctx)
     if os.environ.get('VMX_SPIN_SYNC') != '1':
         for cx in pipe.ctxs:
