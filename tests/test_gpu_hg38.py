@@ -91,6 +91,23 @@ def test_hg38_size_index_map_and_records(ctx, oracle, hg38_ref, mode, k, shape):
     assert [(int(x) == 0) for x in bst] == [(int(x) == 0) for x in ost]
     assert brecs == orecs, 'bulk sample: records differ from the oracle'
     assert len(orecs) >= 200
+    if mode == 'H':
+        # -mode asm at this size: assembly contigs with SVs against the same index — one below 500 kb (the fork's per-read
+        # function), one above (the batch-linked path; noise hits outnumber the true ones nine to one here), one from the last contig (> 2^31)
+        rng = np.random.default_rng(77)
+        nc = len(contigs)
+        asm = []
+        for c, st, ln, ops, rev in ((2, 30_000_000, 180_000, [('INV', 60_000, 2500), ('DEL', 120_000, 900)], 0),
+                                    (nc // 2, 12_000_000, 750_000, [('DEL', 100_000, 3000), ('INV', 330_000, 1800), ('DUP', 560_000, 1500, 2)], 1),
+                                    (nc - 1, 20_000_000, 560_000, [('INS', 200_000, 700, 5), ('INV', 410_000, 3000)], 0)):
+            seq = synth.mutate(synth.implant_svs(contigs[c][st:st + ln], ops), 0.003, rng)
+            asm.append(synth.tostr(synth.revcomp(seq) if rev else seq))
+        aprm = ctx.lib.params('asm'); aop = oracle.params('asm')
+        ast, arecs, _ = align_batch(ctx, gi, aprm, asm)
+        for x, cseq in enumerate(asm):
+            ost, orecs = oracle.align_asm(oi, cseq, aop)
+            assert ost == 0 and ast[x] == 0 and len(orecs) >= 2
+            assert [t[1:] for t in arecs if t[0] == x] == [t[1:] for t in orecs], 'asm contig %d: records differ from the oracle' % x
     # a replica allocated from the metadata and filled from the builder's HBM pieces maps identically (the broadcast's receive side)
     from vacmap_amd.dist import index_blobs
     rep = Index.from_meta(ctx, gi.meta())
