@@ -147,39 +147,14 @@ __device__ __forceinline__ int vmx_insertpoint_score_topdown(const double* S, do
 }
 
 // shared gap geometry of GC and LC (:24953-24984, :27418-27456)
+// (vmx_gap_geometry_sel: vmx_kernels.h)
 __device__ __forceinline__ void vmx_gap_geometry(int qi, long long ri, int si, int li, int qj, long long rj, int sj, int lj,
                                                  long long& readgap, long long& refgap, long long& bonus) {
-    readgap = (long long)qi - qj - lj;
-    if (readgap < 0) {
-        bonus = (long long)qi + li - qj - lj;
-        readgap = 0;
-        long long overlap = (long long)qj + lj - qi;
-        if (si == sj) { if (si == 1) refgap = ri + overlap - (rj + lj); else refgap = rj - (ri + bonus); }
-        else { if (sj == -1) refgap = ri + overlap - rj + 1; else refgap = ri + bonus - 1 - (rj + lj); }
-    } else {
-        bonus = li;
-        if (si == sj) { if (si == 1) refgap = ri - rj - lj; else refgap = rj - ri - li; }
-        else { if (sj == -1) refgap = ri - rj + 1; else refgap = ri + li - 1 - rj - lj; }
-    }
+    vmx_gap_geometry_sel<false>(qi, ri, si, li, qj, rj, sj, lj, readgap, refgap, bonus);
 }
-
-
-// the -mode asm fork's geometry (mammap_asm.py:20660-20688, the same lines in its GC-fast, LC and linked DPs): the overlap case is written
-// with non_overlap_size = q_i - q_j and the opposite-strand cases carry no +-1
 __device__ __forceinline__ void vmx_gap_geometry_asm(int qi, long long ri, int si, int li, int qj, long long rj, int sj, int lj,
                                                      long long& readgap, long long& refgap, long long& bonus) {
-    readgap = (long long)qi - qj - lj;
-    if (readgap < 0) {
-        bonus = (long long)qi + li - qj - lj;
-        readgap = 0;
-        const long long nov = (long long)qi - qj;
-        if (si == sj) { if (si == 1) refgap = ri - rj - nov; else refgap = rj + lj - nov - ri - li; }
-        else { if (sj == -1) refgap = ri + lj - nov - rj; else refgap = ri + li - rj - nov; }
-    } else {
-        bonus = li;
-        if (si == sj) { if (si == 1) refgap = ri - rj - lj; else refgap = rj - ri - li; }
-        else { if (sj == -1) refgap = ri - rj; else refgap = ri + li - rj - lj; }
-    }
+    vmx_gap_geometry_sel<true>(qi, ri, si, li, qj, rj, sj, lj, readgap, refgap, bonus);
 }
 
 // One read. IN_LDS is a compile-time switch so that the working arrays are plain LDS pointers (ds_read / ds_write) in the instantiation the
@@ -300,7 +275,17 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
                             int at = above;
                             if (gt != ge) {
                                 const int a = k - cge, b = k - above;
-                                int i2 = 0, j2 = k, loc = -1;
+                                // The run of equals ends within 64 places of the top, so the bisection over [0, k) first goes right log2(k / cge)
+                                // times in a row. Those steps have a closed form: with g = k - i, a step to the right is g <- (g - 1) >> 1, i.e.
+                                // g_t + 1 = (k + 1) >> t, and step t is taken while its probe k - 1 - g_(t+1) lies below a, i.e. while
+                                // (k + 1) >> (t + 1) >= cge + 1. The loop below starts behind them (it was ~20 scalar rounds per insertion).
+                                int i2, j2 = k, loc = -1;
+                                {
+                                    const unsigned n1 = (unsigned)k + 1u, c1 = (unsigned)cge + 1u;
+                                    int T = (31 - __builtin_clz(n1)) - (31 - __builtin_clz(c1));
+                                    if ((n1 >> T) < c1) --T;
+                                    i2 = k + 1 - (int)(n1 >> T);
+                                }
                                 while (i2 < j2) { const int mid = (i2 + j2) >> 1; if (mid < a) i2 = mid + 1; else if (mid >= b) j2 = mid; else { loc = mid + 1; break; } }
                                 if (loc < 0) loc = j2;
                                 at = k - loc;
@@ -358,11 +343,14 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
                             test = Sj + (double)bonus - skipcost;
                             nfp = -skipcost + (double)bonus; npp = skipcost;
                         }
-                    } else if (si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
-                        test = Sj + (double)bonus - s_gapcost[gapcost];
-                        if constexpr (LINK) { if (lk->lc) test = test - (double)tab.readgap_r[readgap]; }      // :21644
                     } else {
-                        test = Sj - skipcost + (double)bonus - vmx_extra_cost(tab, gapcost);
+                        // both forms are computed and one is selected: a wave's candidates are a mix of co-linear and other steps, and as two
+                        // branches each paid its own exec-mask region around a handful of adds
+                        const bool col = si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff;
+                        double tc = Sj + (double)bonus - s_gapcost[col ? (int)gapcost : 0];
+                        if constexpr (LINK) { if (lk->lc) tc = tc - (double)tab.readgap_r[col ? readgap : 0]; }      // :21644
+                        const double tn = Sj - skipcost + (double)bonus - vmx_extra_cost(tab, col ? 0x7fffffffffffffffLL : gapcost);
+                        test = col ? tc : tn;
                     }
                 }
                 const double incl = vmx_wave_incl_max_f64(test);                 // prefix max of the candidates' scores, in scan order

@@ -114,32 +114,10 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
                     int qj, lj, sj; long long rj;
                     if (base == testspace_en - 1) { j = win.j; Sj = win.S; qj = win.q; lj = win.ls & 0xffff; sj = win.ls >> 16; rj = win.r; }   // first 64: registers
                     else { j = SA[x]; Sj = S[j]; qj = AQ(j); lj = AL(j); sj = AS(j); rj = AR(j); }
-                    long long readgap = (long long)qi - qj - lj, refgap, bonus;
-                    bool skip = false;
-                    if (asmv) {
-                        if (readgap < 0) {
-                            bonus = (long long)qi + li - qj - lj;
-                            readgap = 0;
-                            const long long nov = (long long)qi - qj;
-                            if (si == sj) { if (si == 1) refgap = ri - rj - nov; else refgap = rj + lj - nov - ri - li; }
-                            else { if (sj == -1) refgap = ri + lj - nov - rj; else refgap = ri + li - rj - nov; }
-                        } else {
-                            bonus = li;
-                            if (si == sj) { if (si == 1) refgap = ri - rj - lj; else refgap = rj - ri - li; }
-                            else { if (sj == -1) refgap = ri - rj; else refgap = ri + li - rj - lj; }
-                        }
-                    } else if (readgap < 0) {
-                        bonus = (long long)qi + li - qj - lj;
-                        if (bonus <= 0) skip = true;
-                        readgap = 0;
-                        long long overlap = (long long)qj + lj - qi;
-                        if (si == sj) { if (si == 1) refgap = ri + overlap - (rj + lj); else refgap = rj - (ri + bonus); }
-                        else { if (sj == -1) refgap = ri + overlap - rj + 1; else refgap = ri + bonus - 1 - (rj + lj); }
-                    } else {
-                        bonus = li;
-                        if (si == sj) { if (si == 1) refgap = ri - rj - lj; else refgap = rj - ri - li; }
-                        else { if (sj == -1) refgap = ri - rj + 1; else refgap = ri + li - 1 - rj - lj; }
-                    }
+                    long long readgap, refgap, bonus;
+                    if (asmv) vmx_gap_geometry_sel<true>(qi, ri, si, li, qj, rj, sj, lj, readgap, refgap, bonus);
+                    else vmx_gap_geometry_sel<false>(qi, ri, si, li, qj, rj, sj, lj, readgap, refgap, bonus);
+                    const bool skip = !asmv && bonus <= 0;            // only an overlap can bring the bonus to zero or below (:27425)
                     if (!skip) {
                         long long gapcost = readgap - refgap; if (gapcost < 0) gapcost = -gapcost;
                         if (scar) {

@@ -46,6 +46,28 @@ __device__ __forceinline__ double vmx_extra_cost(const vmx_tables& tab, long lon
     return (double)tab.extra[g];
 }
 
+// ---- gap geometry shared by the chain DPs (GC :24953-24984, LC :27418-27456) ----
+// Both geometries without data-dependent branches. With rg = q_i - q_j - l_j, m = min(rg, 0) (the overlap, negated) and d = r_i - r_j the eight
+// cases of :24953-24984 collapse to  readgap = rg - m,  bonus = l_i + m,  refgap = +-d + c  with a 32-bit c:
+//   s_i = s_j = +1:  d - m - l_j          s_i = +1, s_j = -1:  d - m + 1
+//   s_i = s_j = -1: -d - l_i - m          s_i = -1, s_j = +1:  d + l_i + m - 1 - l_j
+// and the -mode asm fork's (mammap_asm.py:20660-20688: non_overlap_size = q_i - q_j, no +-1 between opposite strands) to the same two lines for
+// equal strands and  d - m  /  d + l_i - m - l_j  for opposite ones. The lanes of a wavefront hold candidates on both strands, with and without
+// overlap: as nested ifs the compiler emits an exec-mask region per case; as selects it is a dozen VALU instructions.
+template <bool ASMV>
+__device__ __forceinline__ void vmx_gap_geometry_sel(int qi, long long ri, int si, int li, int qj, long long rj, int sj, int lj,
+                                                     long long& readgap, long long& refgap, long long& bonus) {
+    const int rg = qi - qj - lj;                       // read positions and lengths: 32-bit
+    const int m = rg < 0 ? rg : 0;
+    readgap = (long long)(rg - m);
+    bonus = (long long)(li + m);
+    const long long d = ri - rj;
+    const bool same = si == sj;
+    int c; long long t;
+    if (si == 1) { c = (same ? -lj : (ASMV ? 0 : 1)) - m; t = d; }
+    else { c = same ? -li - m : li - lj + (ASMV ? -m : m - 1); t = same ? -d : d; }
+    refgap = t + (long long)c;
+}
 // arguments of k_local_seed (L2): inputs, per-workgroup-slot scratch pools, outputs
 struct vmx_lseed_args {
     const uint8_t* ocodes; const int64_t* roff;            // oriented read codes
