@@ -440,14 +440,18 @@ __global__ void __launch_bounds__(64) k_chain_linked_win(vmx_link_job* __restric
         vmx_link_job& J = jobs[jb];
         vmx_link_state& ST = *J.state;
         if (ST.status != 0 || J.n_new <= 0) { if (lane == 0) J.ran = 0; continue; }
-        const int n_pre = ST.n_pre, base = J.cap_pre - n_pre, n = n_pre + J.n_new;
-        double* S = J.S + base; int32_t* P = J.P + base;
+        // everything the loop branches on is the same in every lane; read from the job record it would live in vector registers and every
+        // `if` / loop of the DP would be an exec-mask region instead of a scalar branch
+        const int n_pre = vmx_uniform_i32(ST.n_pre), base = vmx_uniform_i32(J.cap_pre) - n_pre, n = n_pre + vmx_uniform_i32(J.n_new);
+        double* S = VMX_GLOBAL_PTR(double, J.S + base); int32_t* P = VMX_GLOBAL_PTR(int32_t, J.P + base);
+        int32_t* SAg = VMX_GLOBAL_PTR(int32_t, J.SA); const vmx_anchor* rows = VMX_GLOBAL_PTR(const vmx_anchor, J.rows + base);
         for (int i = lane; i < n_pre; i += 64) { S[i] = ST.pre_S[i]; P[i] = ST.pre_P[i]; }
         __syncthreads();
-        vmx_link_in lk; lk.n_pre = n_pre; lk.g_max_scores = ST.g_max_scores; lk.g_max_index = ST.g_max_index; lk.prereadloc = ST.prereadloc; lk.lc = lc; lk.max_factor = max_factor;
+        vmx_link_in lk; lk.n_pre = n_pre; lk.g_max_scores = vmx_uniform_f64(ST.g_max_scores); lk.g_max_index = vmx_uniform_i32(ST.g_max_index);
+        lk.prereadloc = vmx_uniform_i64(ST.prereadloc); lk.lc = lc; lk.max_factor = max_factor;
         int64_t gm = 0, opc = 0;
         __shared__ int64_t s_out[8];
-        vmx_chain_global_read<false, 2, true>(J.rows + base, 0, 0, n, 0, smem, s_gapcost, 0, tab, skipcost, maxdiff, maxgap, S, P, J.SA, nullptr, &s_out[0], &s_out[1], nullptr, nullptr, &lk);
+        vmx_chain_global_read<false, 2, true>(rows, 0, 0, n, 0, smem, s_gapcost, 0, tab, skipcost, maxdiff, maxgap, S, P, SAg, nullptr, &s_out[0], &s_out[1], nullptr, nullptr, &lk);
         __syncthreads();
         gm = s_out[0]; opc = s_out[1];
         if (lane == 0) { J.ran = 1; J.n = n; J.hot = n; J.n_cold = 0; J.cold_max = -1e300; J.gmax = gm; J.opcount = opc;

@@ -102,6 +102,19 @@ __device__ __forceinline__ long long vmx_uniform_i64(long long v) {
     u.i[0] = vmx_uniform_i32(u.i[0]); u.i[1] = vmx_uniform_i32(u.i[1]);
     return u.d;
 }
+__device__ __forceinline__ double vmx_uniform_f64(double v) {
+    union { double d; int i[2]; } u; u.d = v;
+    u.i[0] = vmx_uniform_i32(u.i[0]); u.i[1] = vmx_uniform_i32(u.i[1]);
+    return u.d;
+}
+// a pointer read from a structure in memory is a generic (flat) pointer to the compiler: every access through it is a flat_load that counts
+// on both wait counters and cannot take a scalar base. VMX_GLOBAL_PTR says "this is device memory" (address space 1) and "the same in every
+// lane" (scalar register pair): accesses become global_load v, v_off, s[base].
+#ifdef VMX_EMU
+#define VMX_GLOBAL_PTR(T, p) (p)
+#else
+#define VMX_GLOBAL_PTR(T, p) ((T*)(__attribute__((address_space(1))) T*)(unsigned long long)vmx_uniform_i64((long long)(p)))
+#endif
 // broadcast lane 0's value to the wave
 #ifdef VMX_EMU
 __device__ __forceinline__ int vmx_bcast0(int v) { return __shfl(v, 0); }
