@@ -130,19 +130,22 @@ __device__ __forceinline__ void vmx_chain_local_read(const vmx_anchor* __restric
                                 test = Sj + (double)bonus - skipcost;                                          // :23577-23578
                                 nfp = -skipcost + (double)bonus; npp = skipcost;
                             }
-                        } else if (si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff) {
-                            test = Sj + (double)bonus - s_gapcost[gapcost] - (double)rgc[readgap];
-                        } else if (asmv) {
-                            test = Sj - skipcost + (double)bonus - vmx_extra_cost(tab, gapcost);
-                        } else if (!mm) {
-                            const double ex = vmx_extra_cost(tab, gapcost);
-                            double pen;
-                            if (si != sj) pen = (skipcost < 50.0 ? skipcost : 50.0) + ex;
-                            else pen = skipcost + ex;
-                            test = Sj + (double)bonus - pen;
                         } else {
-                            double pen = skipcost + tab.log2cache[gapcost < l2c_size ? gapcost : l2c_size];
-                            test = Sj + (double)bonus - pen;
+                            // both forms computed, one selected (see k_chain.hip): no exec-mask region per kind of step
+                            const bool col = si == sj && refgap >= 0 && readgap <= maxgap && gapcost <= maxdiff;
+                            const double tc = Sj + (double)bonus - s_gapcost[col ? gapcost : 0] - (double)rgc[col ? readgap : 0];
+                            const long long gx = col ? 0x7fffffffffffffffLL : gapcost;
+                            double tn;
+                            if (asmv) tn = Sj - skipcost + (double)bonus - vmx_extra_cost(tab, gx);
+                            else if (!mm) {
+                                const double ex = vmx_extra_cost(tab, gx);
+                                const double pen = (si != sj ? (skipcost < 50.0 ? skipcost : 50.0) : skipcost) + ex;
+                                tn = Sj + (double)bonus - pen;
+                            } else {
+                                const double pen = skipcost + tab.log2cache[gapcost < l2c_size ? gapcost : l2c_size];
+                                tn = Sj + (double)bonus - pen;
+                            }
+                            test = col ? tc : tn;
                         }
                     }
                 }
