@@ -255,10 +255,17 @@ __device__ __forceinline__ void vmx_chain_global_read(const vmx_anchor* __restri
                         // (LINK: the scores of the anchors computed since the last advance wait in a register, lane = place in that group — several
                         // noise hits share a read position there, and S[k] would be a load of a value this wave stored a moment ago)
                         const int kl = k - bb;
-                        if (LINK && k >= gbase && k - gbase < 64) Sk = vmx_readlane_f64(gS, k - gbase); else { if constexpr (LINK) VMX_LINK_WAIT(); Sk = S[k]; }
+                        // (a value that does come from memory is handed over in scalar registers: the wait for the load then sits inside this rare
+                        // branch. Left in vector registers, the compiler has to wait at the merge point — for EVERY outstanding memory operation,
+                        // i.e. for the acknowledgement of the S / P / S_arg stores of the anchors before, at every insertion)
+                        if (LINK && k >= gbase && k - gbase < 64) Sk = vmx_readlane_f64(gS, k - gbase); else { if constexpr (LINK) VMX_LINK_WAIT(); Sk = IN_LDS ? S[k] : vmx_uniform_f64(S[k]); }
                         qk = vmx_readlane(bq, kl); lsk = vmx_readlane(bls, kl);
                         union { long long d; int w[2]; } u; u.d = br; u.w[0] = vmx_readlane(u.w[0], kl); u.w[1] = vmx_readlane(u.w[1], kl); rk = u.d;
-                    } else { if constexpr (LINK) VMX_LINK_WAIT(); Sk = S[k]; qk = AQ(k); lsk = AL(k) | (AS(k) << 16); rk = AR(k); }
+                    } else {
+                        if constexpr (LINK) VMX_LINK_WAIT();
+                        Sk = S[k]; qk = AQ(k); lsk = AL(k) | (AS(k) << 16); rk = AR(k);
+                        if constexpr (!IN_LDS) { Sk = vmx_uniform_f64(Sk); qk = vmx_uniform_i32(qk); lsk = vmx_uniform_i32(lsk); rk = vmx_uniform_i64(rk); }
+                    }
                     // the reference's bisection (:19369-19387) puts a score without an equal behind all smaller ones; among equals the place
                     // depends on its probe sequence (vmx_insertpoint_score_wave): the window handles the first case
                     const int W = k < 64 ? k : 64;               // k entries so far
