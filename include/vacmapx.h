@@ -277,6 +277,9 @@ int vm_align_trace(vm_ctx*, const vm_index*, const vm_params*, int64_t n_reads, 
 typedef struct vm_sam_opts {
     int32_t md, shortcs, cigar2cg, markunbalancetra, hardclip, fakecigar;
     const char* rg_id;           /* RG:Z: value on every line; NULL = none (the reference's driver always sets one, vacmap:211-214) */
+    int32_t asm_mode;            /* 1: the emitter of -mode asm, iterator_get_bam_dict_str / _comments (mammap_asm.py:22757, :22942): NM = the CIGAR's X / D / I
+                                  * counts as mergecigar_nm_ takes them (:23125), MAPQ written as 60 (1 for 0) in the column and in SA, the second record
+                                  * primary when the first has MAPQ 1 and it has not (:22847-22850) */
 } vm_sam_opts;
 /* reads as blobs with offsets[n + 1] (quals / comments and their offsets may be NULL; a read whose quality string is empty or of another
  * length than its sequence gets '*'); recs / cigar_blob / status as returned by vm_align_batch for these reads. text: the lines

@@ -161,18 +161,16 @@ def test_blob_gather_parts_restores_input_order():
     assert out.tobytes() == b''.join(texts)
 
 
-def test_sam_lines_asm_match_reference():
-    """-mode asm's emitter (sam.sam_lines(asm=True)) against the reference's iterator_get_bam_dict_str / _comments (mammap_asm.py:22757, :22942) on the
-    records of the asm goldens (tests/golden/sam_asm.json, tools/harness/gen_golden_sam_asm.py)"""
+def _asm_sam_entries():
+    """(entry, records as 9-tuples, query, contig dict, case meta) of tests/golden/sam_asm.json (tools/harness/gen_golden_sam_asm.py)"""
     import zlib
     import numpy as np
     import oracle_lib as O
     meta = json.load(open(os.path.join(GOLD, 'asm.json'))); arr = np.load(os.path.join(GOLD, 'asm.npz'))
     entries = json.load(open(os.path.join(GOLD, 'sam_asm.json')))
-    nlines = 0
     cache = {}
     for e in entries:
-        cid, ci, o = e['case'], e['contig'], e['opt']
+        cid, ci = e['case'], e['contig']
         c = meta[cid]; g = c['contigs'][ci]
         contigs = {n: arr['%s_ref%d' % (cid, i)].tobytes().decode() for i, n in enumerate(c['names'])}
         query = arr['%s_c%d_seq' % (cid, ci)].tobytes().decode()
@@ -185,6 +183,15 @@ def test_sam_lines_asm_match_reference():
                 assert [zlib.crc32(t[8].encode()) for t in orecs] == [r[8] for r in g['records']]
                 cache[(cid, ci)] = [(g['name'], c['names'][t[1]], t[2], t[3], t[4], t[5], t[6], t[7], t[8]) for t in orecs]
             recs = cache[(cid, ci)]
+        yield e, recs, query, contigs, c
+
+
+def test_sam_lines_asm_match_reference():
+    """-mode asm's emitter (sam.sam_lines(asm=True)) against the reference's iterator_get_bam_dict_str / _comments (mammap_asm.py:22757, :22942) on the
+    records of the asm goldens (tests/golden/sam_asm.json, tools/harness/gen_golden_sam_asm.py)"""
+    nlines = 0
+    for e, recs, query, contigs, c in _asm_sam_entries():
+        cid, ci, o = e['case'], e['contig'], e['opt']
         kw = dict(md=o['md'], shortcs=o['shortcs'], cigar2cg=o['cigar2cg'], markunbalancetra=o['markunbalancetra'], hardclip=o['H'], fakecigar=o['fakecigar'],
                   rg_id=o.get('rg'), comments=o['comments'].replace('\\t', '\t') if 'comments' in o else None, asm=True)
         if e['raised']:
@@ -192,6 +199,35 @@ def test_sam_lines_asm_match_reference():
                 sam.sam_lines(recs, query, None, lambda cn, a, b: contigs[cn][a:b], **kw)
             continue
         lines = sam.sam_lines(recs, query, None, lambda cn, a, b: contigs[cn][a:b], **kw)
+        assert [SC.head(x) for x in lines] == e['head'], (cid, ci, o)
+        assert [SC.digest(x) for x in lines] == e['digest'], (cid, ci, o)
+        nlines += len(lines)
+    assert nlines >= 100
+
+
+def test_native_sam_emitter_asm_matches_reference():
+    """vm_sam_emit with asm_mode (what the driver's -mode asm path calls) against the same 118 reference lines"""
+    import numpy as np
+    import emu_lib
+    from vacmap_amd import lib as VL
+    ctx = emu_lib.context()
+    idx = {}
+    nlines = 0
+    for e, recs, query, contigs, c in _asm_sam_entries():
+        cid, ci, o = e['case'], e['contig'], e['opt']
+        if cid not in idx:
+            idx[cid] = VL.Index.from_seqs(ctx, c['names'], [contigs[n] for n in c['names']], k=c['k'], w=c['w'])
+        raw = _raw_from_tuples(VL, recs, c['names'])
+        opts = VL.SamOpts(int(o['md']), int(o['shortcs']), int(o['cigar2cg']), int(o['markunbalancetra']), int(o['H']), int(o['fakecigar']),
+                          o['rg'].encode() if 'rg' in o else None, 1)
+        nm = recs[0][0].encode()
+        com = o['comments'].replace('\\t', '\t').encode() if 'comments' in o else None
+        buf, off, nl, ns = VL.sam_emit(ctx.lib, idx[cid], opts, np.frombuffer(nm, np.uint8), [0, len(nm)], np.frombuffer(query.encode(), np.uint8), [0, len(query)], raw,
+                                       comments=np.frombuffer(com, np.uint8) if com else None, com_off=[0, len(com)] if com else None, nthreads=2)
+        lines = buf.tobytes().decode().split('\n')[:-1] if len(buf) else []
+        if e['raised']:
+            assert ns == 1 and not lines, (cid, ci, o)
+            continue
         assert [SC.head(x) for x in lines] == e['head'], (cid, ci, o)
         assert [SC.digest(x) for x in lines] == e['digest'], (cid, ci, o)
         nlines += len(lines)

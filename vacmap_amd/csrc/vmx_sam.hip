@@ -101,6 +101,19 @@ static int64_t merge_cigar_nm(const char* c, int64_t len, const char* q, int64_t
     return nm;
 }
 
+// NM of the -mode asm emitter (mergecigar_nm_, mammap_asm.py:23125-23155): the lengths of the X / D / I runs of the UNMERGED text, where a run that
+// continues the operator before it (the joins between gap-fill pieces) is merged but not counted (:23142-23145)
+static int64_t nm_asm_text(const char* c, int64_t len) {
+    int64_t nm = 0, num = 0; char pre = 0;
+    for (int64_t i = 0; i < len; ++i) {
+        const char ch = c[i];
+        if (ch >= '0' && ch <= '9') { num = num * 10 + (ch - '0'); continue; }
+        if (ch != pre) { if (ch == 'X' || ch == 'D' || ch == 'I') nm += num; pre = ch; }
+        num = 0;
+    }
+    return nm;
+}
+
 // nm_from_cigar (output_functions.py:300): q / t are the sequences the CIGAR walks from their position 0
 static int64_t nm_from_cigar(const Ops& o, const char* q, int64_t ql, const char* t, int64_t tl) {
     int64_t nm = 0, qp = 0, rp = 0;
@@ -222,26 +235,31 @@ static int emit_read(const vm_index* mi, const std::string& bases, const vm_sam_
             int64_t ta = r.r_st < 0 ? 0 : (r.r_st > clen ? clen : r.r_st), tb = r.r_en < 0 ? 0 : (r.r_en > clen ? clen : r.r_en);     // Python slice semantics of contig[a:b]
             if (tb < ta) tb = ta;
             const char* t = bases.data() + mi->offsets[(size_t)r.contig] + ta; const int64_t tl = tb - ta;
-            if (!o->md) S.nm[i] = merge_cigar_nm(r.cigar, r.cigar_len, qs, qlen, t, tl, S.cig[i], &S.nops[i]);      // one pass: merged text + NM
+            if (!o->md && o->asm_mode) {                           // asm: no walk over the sequences at all
+                merge_cigar(r.cigar, r.cigar_len, S.ops[i]); join_ops(S.ops[i], S.cig[i]); S.nops[i] = (int64_t)S.ops[i].op.size();
+                S.nm[i] = nm_asm_text(r.cigar, r.cigar_len);
+            } else if (!o->md) S.nm[i] = merge_cigar_nm(r.cigar, r.cigar_len, qs, qlen, t, tl, S.cig[i], &S.nops[i]);      // one pass: merged text + NM
             else {
                 merge_cigar(r.cigar, r.cigar_len, S.ops[i]);
                 join_ops(S.ops[i], S.cig[i]);
                 S.nops[i] = (int64_t)S.ops[i].op.size();
                 int64_t qa = r.q_st < 0 ? 0 : (r.q_st > qlen ? qlen : r.q_st), qb = r.q_en < 0 ? 0 : (r.q_en > qlen ? qlen : r.q_en); if (qb < qa) qb = qa;
                 md_cs(S.ops[i], t, tl, qs + qa, qb - qa, o->shortcs != 0, S.md[i], S.cs[i]);
-                S.nm[i] = nm_from_cigar(S.ops[i], qs + qa, qb - qa, t, tl);
+                S.nm[i] = o->asm_mode ? nm_asm_text(r.cigar, r.cigar_len) : nm_from_cigar(S.ops[i], qs + qa, qb - qa, t, tl);
             }
             if (o->fakecigar) fake_cigar(r, qlen, clip, S.fake[i]);
         }
         int lines = 0;
+        const size_t primary = (o->asm_mode && n > 1 && S.recs[0].mapq == 1 && S.recs[1].mapq != 1) ? 1 : 0;     // mammap_asm.py:22847-22850
+        auto mq_out = [&](int v) { return o->asm_mode ? (v != 0 ? 60 : 1) : v; };
         for (size_t i = 0; i < n; ++i) {
             const Rec& r = S.recs[i];
             const bool cg = 2 * S.nops[i] > 65535 && o->cigar2cg;          // Q4: the reference counts two list entries per operator
             out.append(name, (size_t)name_len); out.push_back('\t');
-            put_int(out, (i == 0 ? 0 : 2048) + (r.strand == '+' ? 0 : 16)); out.push_back('\t');
+            put_int(out, (i == primary ? 0 : 2048) + (r.strand == '+' ? 0 : 16)); out.push_back('\t');
             out.append(mi->names[(size_t)r.contig]); out.push_back('\t');
             put_int(out, r.r_st + 1); out.push_back('\t');
-            put_int(out, r.mapq); out.push_back('\t');
+            put_int(out, mq_out(r.mapq)); out.push_back('\t');
             if (cg) out.push_back('*'); else out.append(S.cig[i]);
             out.append("\t*\t0\t0\t");
             const char* sq = r.strand == '+' ? query : S.rcq.data();
@@ -259,7 +277,7 @@ static int emit_read(const vm_index* mi, const std::string& bases, const vm_sam_
                     if (x == i) continue;
                     const Rec& y = S.recs[x];
                     out.append(mi->names[(size_t)y.contig]); out.push_back(','); put_int(out, y.r_st + 1); out.push_back(','); out.push_back(y.strand); out.push_back(',');
-                    out.append(o->fakecigar ? S.fake[x] : S.cig[x]); out.push_back(','); put_int(out, y.mapq); out.push_back(','); put_int(out, S.nm[x]); out.push_back(';');
+                    out.append(o->fakecigar ? S.fake[x] : S.cig[x]); out.push_back(','); put_int(out, mq_out(y.mapq)); out.push_back(','); put_int(out, S.nm[x]); out.push_back(';');
                 }
             }
             out.append("\tNM:i:"); put_int(out, S.nm[i]);

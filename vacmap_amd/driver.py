@@ -14,8 +14,8 @@ in input order. Like the reference's worker (:24116-24134) a read whose path or 
 records produces no line.
 With N ranks, rank 0 builds the index and broadcasts it over RCCL (vacmap_amd/dist.py), batch i of a window goes to rank i mod N, and
 rank 0 gathers and writes the lines. `-mode asm` (assembly contigs; contig c -> rank c mod N): the contigs go through vm_align_batch with VM_MODE_ASM in
-groups, in input order, and their lines come from the Python statement of the asm emitter (sam.sam_lines(asm=True) =
-iterator_get_bam_dict_str, mammap_asm.py:22757); `-workdir` is accepted and created like the reference's, but nothing is spilled into it.
+groups, in input order, and their lines come from the native emitter in its asm form (vm_sam_opts.asm_mode = iterator_get_bam_dict_str,
+mammap_asm.py:22757; vacmap_amd/sam.py holds the same emitter in Python); `-workdir` is accepted and created like the reference's, but nothing is spilled into it.
 """
 import argparse, gzip, os, shutil, struct, subprocess, sys, threading, time, queue
 
@@ -159,38 +159,38 @@ def _run_asm(args, lib, ctx, index, prm, rg, mark, out, proc, world, rank, text_
     the GPU) and their SAM lines written in input order. A contig the reference would skip (raised) is logged and skipped.
     With N ranks every rank parses the input, contig c of it goes to rank c mod N (contigs are independent: no data-path collective), and
     rank 0 gathers each group's lines and writes them in input order."""
-    from .lib import Fastx, align_batch
+    import numpy as np
+    from .lib import Fastx, SamOpts, align_batch_raw, sam_emit
     if not args.workdir:
         sys.exit('workdir not provided! -workdir /path/to/workdir')                      # vacmap:247-249
     os.makedirs(args.workdir, exist_ok=True)
     prm.eqx = 1
-    names = index.names
+    opts = SamOpts(int(bool(args.MD)), int(args.cs != 'long'), int(bool(args.L)), int(bool(mark)), int(bool(args.H)), int(bool(args.fakecigar)), rg['ID'].encode(), 1)
     seen = set(); n_contigs = n_lines = n_skipped = 0
 
-    def refseq(cn, a, b):
-        return index.seq(names.index(cn), a, b)
+    def blob(parts):
+        off = np.zeros(len(parts) + 1, np.int64)
+        np.cumsum([len(x) for x in parts], out=off[1:])
+        return np.frombuffer(b''.join(parts) or b'\0', np.uint8), off
 
     def flush(group):
-        """group: (input index, name, sequence, quality, comment) of consecutive input contigs, the same list on every rank"""
+        """group: (input index, name, sequence, quality, comment — bytes) of consecutive input contigs, the same list on every rank"""
         nonlocal n_lines, n_skipped
         share = [g for g in group if g[0] % world == rank]
-        done = {}                                                                           # input index -> lines, None = skipped
+        done = {}                                                                           # input index -> text of its lines, None = skipped
         if share:
-            status, recs, _ = align_batch(ctx, index, prm, [g[2] for g in share])
-            for x, (gi, nm, seq, qual, com) in enumerate(share):
-                if status[x] != 0:
-                    sys.stderr.write('%s is not aligned.\n' % nm); done[gi] = None
-                    continue
-                mine = [(nm, names[t[1]]) + tuple(t[2:]) for t in recs if t[0] == x]
-                if not mine:
-                    done[gi] = []
-                    continue
-                try:
-                    done[gi] = sam.sam_lines(mine, seq, qual or None, refseq, md=bool(args.MD), shortcs=args.cs != 'long', cigar2cg=bool(args.L),
-                                             markunbalancetra=bool(mark), hardclip=bool(args.H), fakecigar=bool(args.fakecigar), rg_id=rg['ID'],
-                                             comments=(com if args.copycomments else None), asm=True)
-                except Exception as e:                                                      # the worker's except (:23493-23498)
-                    sys.stderr.write('%s is not aligned.\n%s\n' % (nm, e)); done[gi] = None
+            nb, no = blob([g[1] for g in share]); sb, so = blob([g[2] for g in share])
+            qb, qo = blob([g[3] for g in share]); cb, co = blob([g[4] for g in share])
+            raw = align_batch_raw(ctx, index, prm, sb, so)
+            # the asm emitter (iterator_get_bam_dict_str, mammap_asm.py:22757) in the native emitter: vm_sam_opts.asm_mode
+            text, toff, _, ns = sam_emit(lib, index, opts, nb, no, sb, so, raw, quals=qb, qual_off=qo, comments=cb if args.copycomments else None,
+                                         com_off=co if args.copycomments else None, nthreads=max(1, args.t))
+            for x, g in enumerate(share):
+                if raw.status[x] != 0:                                                      # the worker's except (:23493-23498)
+                    sys.stderr.write('%s is not aligned.\n' % g[1].decode()); done[g[0]] = None
+                else:
+                    done[g[0]] = text[int(toff[x]):int(toff[x + 1])].tobytes()
+            raw.close()
         if world > 1:
             from .dist import gather_lines
             parts = gather_lines(done, dst=0, group=text_group)
@@ -203,9 +203,8 @@ def _run_asm(args, lib, ctx, index, prm, rg, mark, out, proc, world, rank, text_
             if done[gi] is None:
                 n_skipped += 1
                 continue
-            for ln in done[gi]:
-                out.write(ln.encode() + b'\n')
-            n_lines += len(done[gi])
+            out.write(done[gi])
+            n_lines += done[gi].count(b'\n')
 
     group, gbases = [], 0
     for grp in args.read:
@@ -218,13 +217,13 @@ def _run_asm(args, lib, ctx, index, prm, rg, mark, out, proc, world, rank, text_
                 nb, no, sb, so = ch['names'].tobytes(), ch['names_off'], ch['seqs'].tobytes(), ch['seqs_off']
                 qb, qo, cb, co = ch['quals'].tobytes(), ch['quals_off'], ch['comments'].tobytes(), ch['comments_off']
                 for i in range(len(so) - 1):
-                    nm = nb[no[i]:no[i + 1]].decode()
+                    nm = nb[no[i]:no[i + 1]]
                     if nm in seen:
                         continue
                     seen.add(nm)
                     keep = n_contigs % world == rank                                       # the other ranks' contigs only hold their place
-                    group.append((n_contigs, nm, sb[so[i]:so[i + 1]].decode() if keep else '', ('' if args.Q or not keep else qb[qo[i]:qo[i + 1]].decode()),
-                                  cb[co[i]:co[i + 1]].decode() if keep else ''))
+                    group.append((n_contigs, nm, sb[so[i]:so[i + 1]] if keep else b'', (b'' if args.Q or not keep else qb[qo[i]:qo[i + 1]]),
+                                  cb[co[i]:co[i + 1]] if keep else b''))
                     n_contigs += 1
                     gbases += so[i + 1] - so[i]
                     if len(group) >= 64 * world or gbases >= 400_000_000 * world:

@@ -63,7 +63,7 @@ class Record(C.Structure):
 
 class SamOpts(C.Structure):
     _fields_ = [('md', C.c_int32), ('shortcs', C.c_int32), ('cigar2cg', C.c_int32), ('markunbalancetra', C.c_int32), ('hardclip', C.c_int32),
-                ('fakecigar', C.c_int32), ('rg_id', C.c_char_p)]
+                ('fakecigar', C.c_int32), ('rg_id', C.c_char_p), ('asm_mode', C.c_int32)]
 
 
 class BatchStats(C.Structure):
