@@ -63,6 +63,7 @@ def main():
     ap.add_argument('--streams', type=int, default=3, help='batches in flight per GPU (vacmap_amd.pipeline)')
     ap.add_argument('--window-batches', type=int, default=16, help='length binning window of the scheduler, in batches')
     ap.add_argument('--arrival-order', action='store_true', help='no length binning: batches in arrival order (measured once for comparison)')
+    ap.add_argument('--host-input', action='store_true', help='also time the same batches handed over as HOST buffers (vm_align_batch uploads them: the PCIe-inclusive rate; reported next to `value`, never as it)')
     ap.add_argument('--verify', type=int, default=64, help='reads of the first batch cross-checked against the oracle (0 disables)')
     args = ap.parse_args()
 
@@ -167,6 +168,25 @@ def main():
     barrier()
     dt = time.time() - t1
 
+    host_rate = None
+    if args.host_input and rank == 0 and world == 1:
+        blobs = []
+        for idx in plan:
+            ln = lens[idx]; off = np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
+            cat = np.empty(int(off[-1]), np.uint8)
+            for j, i in enumerate(idx):
+                cat[off[j]:off[j + 1]] = pool_cat[pool_off[i]:pool_off[i + 1]]
+            blobs.append((cat, off))
+        hagg = {'aligned': 0}
+
+        def on_host(i, st):
+            hagg['aligned'] += st['aligned_bases']
+        barrier(); th = time.time()
+        pipe.run_host_blobs(blobs, on_result=on_host)
+        barrier(); dth = time.time() - th
+        host_rate = {'aligned_Gbp_per_s': hagg['aligned'] / dth / 1e9, 'ms_per_step': dth / len(blobs) * 1e3,
+                     'note': 'same batches, same schedule, reads handed over in pageable host memory (1 B/base) and uploaded inside vm_align_batch'}
+
     vals = torch.tensor([dt, float(agg['aligned_bases']), float(agg['n_reads']), float(agg['read_bases']), float(agg['n_failed'])], dtype=torch.float64, device='cuda')
     if dist is not None:
         tmax = vals[0:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -269,6 +289,8 @@ def main():
             'index_minimizers': int(n_minimizers), 'index_mid_occ': int(index.mid_occ), 'oracle_index_build_s': t_oracle_index, 'hbm_used_gb': hbm_used_gb,
             'roofline': roofline, 'cpu_baseline': cpu,
         }
+        if host_rate is not None:
+            out['host_input'] = host_rate
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -159,6 +159,18 @@ class Pipeline:
         """batches: list of lists of read sequences (host memory; uploaded by vm_align_batch). on_result(i, (status, records, stats))"""
         self._run(len(batches), lambda i, cx: align_batch(cx, self.index, self.prm, batches[i]), on_result)
 
+    def run_host_blobs(self, blobs, on_result=None):
+        """blobs: list of (uint8 array of the batch's reads back to back, int64 offsets[n + 1]) in HOST memory: vm_align_batch uploads them
+        inside the call (the PCIe-inclusive path). on_result(i, stats dict)"""
+        from .lib import align_batch_raw
+
+        def job(i, cx):
+            raw = align_batch_raw(cx, self.index, self.prm, blobs[i][0], blobs[i][1])
+            st = raw.stats
+            raw.close()
+            return st
+        self._run(len(blobs), job, on_result)
+
     def warm(self, resident):
         """run every context once on `resident` (the largest batch): sizes the grow-only work pools so that no hipMalloc happens later"""
         for cx in self.ctxs:
