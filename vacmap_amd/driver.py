@@ -373,7 +373,8 @@ def main(argv=None, comm=None):
     tm = {'setup': time.time() - t_start, 'wait_input': 0.0, 'assemble_write': 0.0, 'job_gather': 0.0, 'job_align': 0.0, 'job_emit': 0.0}
     tml = threading.Lock()
     errs = []
-    slots = threading.Semaphore(3)                      # windows in memory at a time (input blobs + SAM text)
+    n_slots = max(2, int(os.environ.get('VMX_DRIVER_WINDOWS', '3')))
+    slots = threading.Semaphore(n_slots)                # windows in memory at a time (input blobs + SAM text)
     oq = queue.Queue()                                  # windows in input order -> writer
     emit_pool = ThreadPoolExecutor(max_workers=emit_jobs)
 
@@ -480,7 +481,7 @@ def main(argv=None, comm=None):
         except BaseException as e:
             errs.append(e)
         finally:
-            for _ in range(3):                          # whatever ended the writer, nobody stays parked on a window slot
+            for _ in range(n_slots):                    # whatever ended the writer, nobody stays parked on a window slot
                 slots.release()
 
     wq = queue.Queue(maxsize=2)
