@@ -296,6 +296,12 @@ int vm_sam_emit(const vm_index*, const vm_sam_opts*, int64_t n_reads, const char
 int64_t vm_blob_gather(const char* blob, const int64_t* off, const int64_t* idx, int64_t n, char* out, int64_t* out_off);
 /* the same over several blobs: output entry j = entry idx[j] of blob part[j]; returns the bytes written (out must hold them) */
 int64_t vm_blob_gather_parts(const char* const* blobs, const int64_t* const* offs, const int32_t* part, const int64_t* idx, int64_t n, char* out);
+/* page-locked host memory for the read blobs a caller hands to vm_align_batch: the upload is then a DMA the host thread does not wait for
+ * (from pageable memory the runtime stages it through bounce buffers on the calling thread: ~10 ms per 60 MB batch, more under memory load) */
+void* vm_pinned_alloc(int64_t bytes);
+void vm_pinned_free(void* p);
+/* vm_blob_gather_parts written to a file descriptor with writev() instead of into a buffer; returns the bytes written or -1 */
+int64_t vm_blob_write_parts(int fd, const char* const* blobs, const int64_t* const* offs, const int32_t* part, const int64_t* idx, int64_t n);
 typedef struct vm_fastx vm_fastx;
 int vm_fastx_open(const char* path, vm_fastx** out);
 void vm_fastx_close(vm_fastx*);

@@ -161,6 +161,7 @@ template <class T> inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v,
 // host API subset
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+enum { hipHostMallocDefault = 0, hipHostMallocPortable = 1 };
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }

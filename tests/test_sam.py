@@ -159,6 +159,21 @@ def test_blob_gather_parts_restores_input_order():
         keys.append(idx.astype(np.int64))
     out = VL.blob_gather_parts(L, blobs, offs, keys)
     assert out.tobytes() == b''.join(texts)
+    # the same merge written to a file descriptor (writev, > 1024 pieces: several calls; neighbours in memory coalesced)
+    import os, tempfile
+    big = [bytes(rng.integers(65, 91, int(rng.integers(0, 12)), dtype=np.uint8)) for _ in range(5000)]
+    perm2 = rng.permutation(5000)
+    b2, o2, k2 = [], [], []
+    for a, b in ((0, 2500), (2500, 2500), (2500, 5000)):
+        idx = np.sort(perm2[a:b])
+        b2.append(np.frombuffer(b''.join(big[i] for i in idx) or b'\0', dtype=np.uint8)); k2.append(idx.astype(np.int64))
+        o2.append(np.concatenate([[0], np.cumsum([len(big[i]) for i in idx])]).astype(np.int64))
+    with tempfile.TemporaryFile() as f:
+        f.write(b'head\n'); f.flush()
+        w = VL.blob_write_parts(L, f.fileno(), b2, o2, k2)
+        assert w == sum(len(t) for t in big)
+        f.seek(0)
+        assert f.read() == b'head\n' + b''.join(big)
 
 
 def _asm_sam_entries():

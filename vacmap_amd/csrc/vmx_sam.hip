@@ -18,6 +18,7 @@
 #include <zlib.h>
 #include <fcntl.h>
 #include <unistd.h>
+#include <sys/uio.h>
 #include <errno.h>
 
 using namespace vmx;
@@ -383,6 +384,13 @@ int vm_sam_emit(const vm_index* mi, const vm_sam_opts* o, int64_t n_reads, const
 
 // out = the entries idx[0..n) of a blob (offsets off) back to back, out_off[n + 1]; out must hold the sum of their lengths (the
 // driver's window -> length-binned batch and batch -> input order shuffles of read / name / quality / SAM text blobs)
+void* vm_pinned_alloc(int64_t bytes) {
+    void* p = nullptr;
+    if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void vm_pinned_free(void* p) { if (p) (void)hipHostFree(p); }
+
 int64_t vm_blob_gather(const char* blob, const int64_t* off, const int64_t* idx, int64_t n, char* out, int64_t* out_off) {
     int64_t w = 0;
     for (int64_t j = 0; j < n; ++j) { const int64_t a = off[idx[j]], b = off[idx[j] + 1]; out_off[j] = w; if (out && b > a) memcpy(out + w, blob + a, (size_t)(b - a)); w += b - a; }
@@ -392,6 +400,37 @@ int64_t vm_blob_gather(const char* blob, const int64_t* off, const int64_t* idx,
 
 // the same over several blobs: entry j of the output is entry idx[j] of blob part[j] (the writer's batch texts -> input order, without
 // concatenating the batches first). out must hold the sum of the lengths; returns that sum.
+// the same merge written straight to a file descriptor with writev(): no assembled copy of the window's text (a gigabyte that was written once
+// into fresh memory and read again by write()). Entries that are neighbours in memory go out as one iovec. Returns the bytes written or -1.
+int64_t vm_blob_write_parts(int fd, const char* const* blobs, const int64_t* const* offs, const int32_t* part, const int64_t* idx, int64_t n) {
+    std::vector<struct iovec> iov; iov.reserve(1024);
+    int64_t total = 0;
+    auto flush = [&]() -> bool {
+        size_t k = 0;
+        while (k < iov.size()) {
+            ssize_t w;
+            do { w = writev(fd, iov.data() + k, (int)std::min<size_t>(iov.size() - k, 1024)); } while (w < 0 && errno == EINTR);
+            if (w < 0) return false;
+            total += w;
+            while (k < iov.size() && (size_t)w >= iov[k].iov_len) { w -= (ssize_t)iov[k].iov_len; ++k; }
+            if (k < iov.size() && w > 0) { iov[k].iov_base = (char*)iov[k].iov_base + w; iov[k].iov_len -= (size_t)w; }
+        }
+        iov.clear();
+        return true;
+    };
+    for (int64_t j = 0; j < n; ++j) {
+        const int64_t* off = offs[part[j]];
+        const int64_t a = off[idx[j]], b = off[idx[j] + 1];
+        if (b <= a) continue;
+        const char* p = blobs[part[j]] + a;
+        if (!iov.empty() && (const char*)iov.back().iov_base + iov.back().iov_len == p) { iov.back().iov_len += (size_t)(b - a); continue; }
+        if (iov.size() == 1024 && !flush()) { set_error("write failed"); return -1; }
+        struct iovec v; v.iov_base = (void*)p; v.iov_len = (size_t)(b - a); iov.push_back(v);
+    }
+    if (!flush()) { set_error("write failed"); return -1; }
+    return total;
+}
+
 int64_t vm_blob_gather_parts(const char* const* blobs, const int64_t* const* offs, const int32_t* part, const int64_t* idx, int64_t n, char* out) {
     // a window's SAM text is gigabytes: the output offsets come from one pass over the lengths, the copies run on a few threads
     // (one thread moves ~5 GB/s; the writer thread of the driver was the longest stage of its loop)

@@ -242,10 +242,30 @@ def _run_asm(args, lib, ctx, index, prm, rg, mark, out, proc, world, rank, text_
     return 0
 
 
+def _keep_heap_pages():
+    """A window of input is ~1 GB of blobs, a batch's SAM text ~125 MB, all short-lived: glibc serves blocks that large from fresh mmap()s and
+    unmaps them on free, so every byte the host pipeline writes lands on a page that is faulted in and zeroed first — measured on the FASTQ
+    parser alone: 1.25 -> 2.85 GB/s once the pages are reused. One arena, no mmap for malloc, no trimming: freed blocks stay in the heap and
+    the next window / batch reuses them. (VMX_DRIVER_MALLOPT=0 leaves the allocator alone.)"""
+    if os.environ.get('VMX_DRIVER_MALLOPT', '1') == '0':
+        return
+    try:
+        import ctypes
+        libc = ctypes.CDLL(None)
+        libc.mallopt(-8, 1)                     # M_ARENA_MAX: worker threads allocate from the main heap too
+        libc.mallopt(-4, 0)                     # M_MMAP_MAX: no direct mmap for large requests
+        libc.mallopt(-1, 2 ** 31 - 1)           # M_TRIM_THRESHOLD: do not hand freed memory back
+        libc.mallopt(-2, 256 << 20)             # M_TOP_PAD: grow the heap in large steps
+    except Exception:
+        pass
+
+
 def main(argv=None, comm=None):
     """comm: an initialised torch.distributed module (tests); under torchrun (WORLD_SIZE > 1) the process group is created here"""
     t_start = time.time()
-    args, _unknown = build_parser().parse_known_args(argv)          # unknown flags are ignored like the reference's parse_known_args (vacmap:152)
+    args, _unknown = build_parser().parse_known_args(argv)
+    if comm is None:                            # (a process of its own, not a test harness that shares the interpreter)
+        _keep_heap_pages()          # unknown flags are ignored like the reference's parse_known_args (vacmap:152)
     if args.o != '-' and not (args.o.endswith('.sam') or args.o.endswith('.bam')):
         sys.exit("Output path must end with .sam, .bam, .sorted.bam, or be '-' for stdout.")
     world, rank, local_rank = 1, 0, 0
@@ -302,7 +322,7 @@ def main(argv=None, comm=None):
     if not rg:
         rg = {'ID': '1', 'SM': 'sample'}
     mark = args.markunbalancetra or args.mode in ('H', 'L')          # mode defaults of vacmap:286-296 (False for asm unless asked)
-    from .lib import SamOpts, Fastx, align_batch_raw, sam_emit, blob_gather, blob_gather_parts
+    from .lib import SamOpts, Fastx, PinnedPool, align_batch_raw, sam_emit, blob_gather, blob_gather_parts, blob_write_parts
     opts = SamOpts(int(bool(args.MD)), int(args.cs != 'long'), int(bool(args.L)), int(bool(mark)), int(bool(args.H)), int(bool(args.fakecigar)), rg['ID'].encode())
     out, proc = (None, None)
     if rank == 0:
@@ -416,27 +436,35 @@ def main(argv=None, comm=None):
                 yield w, i
         oq.put(None)
 
+    # the batch's reads are gathered into page-locked memory: vm_align_batch's upload becomes a DMA the aligner thread does not wait for
+    # (VMX_DRIVER_PINNED=0: pageable numpy arrays, the runtime stages the copy on the calling thread)
+    pinned = PinnedPool(lib) if os.environ.get('VMX_DRIVER_PINNED', '1') != '0' else None
+
     def emit(w, i, ix, sb, so, raw):
         t0 = time.time()
-        if os.environ.get('VMX_SKIP_EMIT') == '1':          # diagnostic: aligners alone
+        try:
+            if os.environ.get('VMX_SKIP_EMIT') == '1':          # diagnostic: aligners alone
+                raw.close()
+                return ix, np.zeros(0, np.uint8), np.zeros(len(ix) + 1, np.int64), 0, 0
+            wnd = w.wnd
+            nb, no = blob_gather(lib, wnd['names'], wnd['names_off'], ix)
+            qb, qo = blob_gather(lib, wnd['quals'], wnd['quals_off'], ix) if w.has_q else (None, None)
+            cb, co = blob_gather(lib, wnd['comments'], wnd['comments_off'], ix) if w.has_c else (None, None)
+            text, toff, nl, ns = sam_emit(lib, index, opts, nb, no, sb, so, raw, quals=qb, qual_off=qo, comments=cb, com_off=co, nthreads=emit_threads)
             raw.close()
-            return ix, np.zeros(0, np.uint8), np.zeros(len(ix) + 1, np.int64), 0, 0
-        wnd = w.wnd
-        nb, no = blob_gather(lib, wnd['names'], wnd['names_off'], ix)
-        qb, qo = blob_gather(lib, wnd['quals'], wnd['quals_off'], ix) if w.has_q else (None, None)
-        cb, co = blob_gather(lib, wnd['comments'], wnd['comments_off'], ix) if w.has_c else (None, None)
-        text, toff, nl, ns = sam_emit(lib, index, opts, nb, no, sb, so, raw, quals=qb, qual_off=qo, comments=cb, com_off=co, nthreads=emit_threads)
-        raw.close()
-        with tml:
-            tm['job_emit'] += time.time() - t0
-        return ix, text, toff, nl, ns
+            with tml:
+                tm['job_emit'] += time.time() - t0
+            return ix, text, toff, nl, ns
+        finally:
+            if pinned is not None:
+                pinned.release(sb)
 
     def align(job, cx):
         """one batch: gather its reads from the window, align (GPU), hand the records to the emit pool; the library calls release the GIL"""
         w, i = job
         ix = w.plan[i]
         t0 = time.time()
-        sb, so = blob_gather(lib, w.wnd['seqs'], w.wnd['seqs_off'], ix)
+        sb, so = blob_gather(lib, w.wnd['seqs'], w.wnd['seqs_off'], ix, alloc=pinned.get if pinned is not None else None)
         t1 = time.time()
         raw = align_batch_raw(cx, index, prm, sb, so)
         t2 = time.time()
@@ -448,6 +476,13 @@ def main(argv=None, comm=None):
             w.left -= 1
             if w.left == 0:
                 w.ready.set()
+
+    out_fd = None
+    if rank == 0 and os.environ.get('VMX_DRIVER_WRITEV', '1') != '0':
+        try:
+            out_fd = out.fileno()
+        except Exception:
+            out_fd = None
 
     def writer():
         """a window's lines in input order (one more gather over the concatenated batch texts) while later windows align and emit"""
@@ -472,8 +507,12 @@ def main(argv=None, comm=None):
                         parts = []
                 counts['lines'] += nl; counts['skipped'] += ns
                 if parts:
-                    txt = blob_gather_parts(lib, [p[1] for p in parts], [p[2] for p in parts], [p[0] for p in parts])
-                    out.write(memoryview(txt))
+                    if out_fd is not None:           # straight from the batches' texts to the file: writev, no assembled copy of the window
+                        out.flush()
+                        blob_write_parts(lib, out_fd, [p[1] for p in parts], [p[2] for p in parts], [p[0] for p in parts])
+                    else:
+                        txt = blob_gather_parts(lib, [p[1] for p in parts], [p[2] for p in parts], [p[0] for p in parts])
+                        out.write(memoryview(txt))
                 w.wnd = None; w.futs = None
                 slots.release()
                 with tml:
@@ -539,6 +578,8 @@ def main(argv=None, comm=None):
     if os.environ.get('VMX_DRIVER_TIMING'):
         sys.stderr.write('vacmapx timing (s): %s\n' % ' '.join('%s=%.2f' % kv for kv in tm.items()))
     pipe.close()
+    if pinned is not None:
+        pinned.close()
     if rank == 0:
         if proc is not None:
             out.close()

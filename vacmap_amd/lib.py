@@ -162,6 +162,9 @@ class VmxLib:
         L.vm_align_trace.argtypes = [vp, vp, P(Params), i64, cp, vp, C.c_int, P(P(i64)), P(P(i64))]
         L.vm_sam_emit.argtypes = [vp, P(SamOpts), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, C.c_int, P(vp), P(P(i64)), P(i64), P(i64)]
         L.vm_blob_gather.argtypes = [vp, vp, vp, i64, vp, vp]; L.vm_blob_gather.restype = i64
+        L.vm_blob_write_parts.argtypes = [C.c_int, vp, vp, vp, vp, i64]; L.vm_blob_write_parts.restype = i64
+        L.vm_pinned_alloc.argtypes = [i64]; L.vm_pinned_alloc.restype = vp
+        L.vm_pinned_free.argtypes = [vp]; L.vm_pinned_free.restype = None
         L.vm_blob_gather_parts.argtypes = [vp, vp, vp, vp, i64, vp]; L.vm_blob_gather_parts.restype = i64
         L.vm_fastx_open.argtypes = [cp, P(vp)]; L.vm_fastx_close.argtypes = [vp]
         L.vm_fastx_read.argtypes = [vp, i64, i64] + [P(vp), P(P(i64))] * 4; L.vm_fastx_read.restype = i64
@@ -500,13 +503,58 @@ class _OwnedText:
         weakref.finalize(base, lib.L.vm_free, ptr)
 
 
-def blob_gather(lib, blob, off, idx):
-    """entries idx of (blob, off) back to back: (uint8 array, int64 offsets) — one memcpy loop in the library (vm_blob_gather)"""
+class PinnedPool:
+    """page-locked host buffers (vm_pinned_alloc) handed out as uint8 arrays and taken back for reuse: the driver gathers a batch's reads into
+    one, so that vm_align_batch's upload is a DMA instead of a staged copy on the aligner thread. get() falls back to pageable memory when the
+    runtime refuses (returns a plain array; release() ignores those)."""
+
+    def __init__(self, lib):
+        import threading
+        self.lib, self.free, self.lock, self.owned = lib, [], threading.Lock(), {}
+
+    def get(self, nbytes):
+        nbytes = max(int(nbytes), 1)
+        with self.lock:
+            for i, (cap, ptr) in enumerate(self.free):
+                if cap >= nbytes:
+                    self.free.pop(i)
+                    break
+            else:
+                cap, ptr = 0, None
+        if ptr is None:
+            cap = max(nbytes + nbytes // 4, 1 << 20)
+            ptr = self.lib.L.vm_pinned_alloc(cap)
+            if not ptr:
+                return np.empty(nbytes, np.uint8)
+        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(cap,))
+        with self.lock:
+            self.owned[arr.ctypes.data] = (cap, ptr)
+        return arr
+
+    def release(self, arr):
+        base = arr
+        while isinstance(getattr(base, 'base', None), np.ndarray):
+            base = base.base
+        with self.lock:
+            ent = self.owned.pop(base.ctypes.data, None)
+            if ent is not None:
+                self.free.append(ent)
+
+    def close(self):
+        with self.lock:
+            for cap, ptr in self.free:
+                self.lib.L.vm_pinned_free(ptr)
+            self.free = []
+
+
+def blob_gather(lib, blob, off, idx, alloc=None):
+    """entries idx of (blob, off) back to back: (uint8 array, int64 offsets) — one memcpy loop in the library (vm_blob_gather).
+    alloc(nbytes) -> uint8 array of at least that many bytes to gather into (e.g. PinnedPool.get)"""
     blob = _u8(blob); off = np.ascontiguousarray(off, dtype=np.int64); idx = np.ascontiguousarray(idx, dtype=np.int64)
     n = len(idx)
     oo = np.empty(n + 1, np.int64)
     tot = int((off[idx + 1] - off[idx]).sum()) if n else 0
-    out = np.empty(max(tot, 1), np.uint8)
+    out = alloc(max(tot, 1)) if alloc is not None else np.empty(max(tot, 1), np.uint8)
     lib.L.vm_blob_gather(blob.ctypes.data, off.ctypes.data, idx.ctypes.data, n, out.ctypes.data, oo.ctypes.data)
     return out[:tot], oo
 
@@ -525,6 +573,25 @@ def blob_gather_parts(lib, blobs, offs, order_keys):
     bp = (C.c_void_p * len(blobs))(*[b.ctypes.data for b in blobs]); op = (C.c_void_p * len(offs))(*[o.ctypes.data for o in offs])
     w = lib.L.vm_blob_gather_parts(bp, op, part.ctypes.data, local.ctypes.data, len(local), out.ctypes.data)
     return out[:w]
+
+
+def _parts_order(blobs, offs, order_keys):
+    keys = np.concatenate([np.asarray(k, dtype=np.int64) for k in order_keys]) if blobs else np.zeros(0, np.int64)
+    part = np.concatenate([np.full(len(k), i, np.int32) for i, k in enumerate(order_keys)]) if blobs else np.zeros(0, np.int32)
+    local = np.concatenate([np.arange(len(k), dtype=np.int64) for k in order_keys]) if blobs else np.zeros(0, np.int64)
+    order = np.argsort(keys, kind='stable')
+    return np.ascontiguousarray(part[order]), np.ascontiguousarray(local[order])
+
+
+def blob_write_parts(lib, fd, blobs, offs, order_keys):
+    """blob_gather_parts written to the file descriptor `fd` (writev, no assembled copy): returns the bytes written"""
+    blobs = [_u8(b) for b in blobs]; offs = [np.ascontiguousarray(o, dtype=np.int64) for o in offs]
+    part, local = _parts_order(blobs, offs, order_keys)
+    bp = (C.c_void_p * len(blobs))(*[b.ctypes.data for b in blobs]); op = (C.c_void_p * len(offs))(*[o.ctypes.data for o in offs])
+    w = lib.L.vm_blob_write_parts(int(fd), bp, op, part.ctypes.data, local.ctypes.data, len(local))
+    if w < 0:
+        raise VmxError(-1, lib.err())
+    return int(w)
 
 
 class Fastx:
