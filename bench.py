@@ -50,6 +50,8 @@ def latest_pmc(workload_id):
 
 
 def main():
+    from vacmap_amd.driver import _keep_heap_pages
+    _keep_heap_pages()                          # the driver's allocator setting (freed result buffers are reused, not unmapped): VMX_DRIVER_MALLOPT=0 disables
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=12, help='timed batches (default 12; 25 = the 100k reads of configs[1]/[2])')
