@@ -263,9 +263,9 @@ def _keep_heap_pages():
 def main(argv=None, comm=None):
     """comm: an initialised torch.distributed module (tests); under torchrun (WORLD_SIZE > 1) the process group is created here"""
     t_start = time.time()
-    args, _unknown = build_parser().parse_known_args(argv)
+    args, _unknown = build_parser().parse_known_args(argv)          # unknown flags are ignored like the reference's parse_known_args (vacmap:152)
     if comm is None:                            # (a process of its own, not a test harness that shares the interpreter)
-        _keep_heap_pages()          # unknown flags are ignored like the reference's parse_known_args (vacmap:152)
+        _keep_heap_pages()
     if args.o != '-' and not (args.o.endswith('.sam') or args.o.endswith('.bam')):
         sys.exit("Output path must end with .sam, .bam, .sorted.bam, or be '-' for stdout.")
     world, rank, local_rank = 1, 0, 0
@@ -288,6 +288,8 @@ def main(argv=None, comm=None):
         world, rank = comm.get_world_size(), comm.get_rank()
     if rank == 0 and args.o != '-' and os.path.exists(args.o) and not args.force:
         sys.exit('%s exists (use --force)' % args.o)
+    if comm is None and world == 1 and __name__ == '__main__':
+        os.environ.setdefault('VACMAPX_SKIP_TORCH', '1')        # one GPU from the command line: nothing here needs torch (its import is 1.5-2 s)
     from .lib import Context, Index, load
     from . import pipeline
     lib = load()

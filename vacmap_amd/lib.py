@@ -110,6 +110,8 @@ class VmxLib:
     def __init__(self, path=None):
         path = path or DEFAULT_SO
         try:        # one HIP runtime per process: torch bundles its own libamdhip64, and whichever copy is loaded first serves both. Load
+            if os.environ.get('VACMAPX_SKIP_TORCH') == '1' and 'torch' not in __import__('sys').modules:
+                raise ImportError('single-GPU command line: no torch, the library brings the system HIP runtime (saves ~1.5 s of start-up)')
             import torch  # noqa: F401   torch's before this library so that vacmap_amd.dist (RCCL broadcast of the HBM-resident index) works
         except ImportError:               # whatever the import order of the caller; without torch there is simply no multi-GPU plumbing
             pass
