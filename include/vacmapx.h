@@ -298,7 +298,7 @@ int64_t vm_blob_gather(const char* blob, const int64_t* off, const int64_t* idx,
 int64_t vm_blob_gather_parts(const char* const* blobs, const int64_t* const* offs, const int32_t* part, const int64_t* idx, int64_t n, char* out);
 /* page-locked host memory for the read blobs a caller hands to vm_align_batch: the upload is then a DMA the host thread does not wait for
  * (from pageable memory the runtime stages it through bounce buffers on the calling thread: ~10 ms per 60 MB batch, more under memory load) */
-void* vm_pinned_alloc(int64_t bytes);
+void* vm_pinned_alloc(int64_t bytes, int device);      /* device: the GPU the calling process works on (the allocation must not open a context on GPU 0 from every rank); -1 = the thread's current one */
 void vm_pinned_free(void* p);
 /* vm_blob_gather_parts written to a file descriptor with writev() instead of into a buffer; returns the bytes written or -1 */
 int64_t vm_blob_write_parts(int fd, const char* const* blobs, const int64_t* const* offs, const int32_t* part, const int64_t* idx, int64_t n);

@@ -384,8 +384,9 @@ int vm_sam_emit(const vm_index* mi, const vm_sam_opts* o, int64_t n_reads, const
 
 // out = the entries idx[0..n) of a blob (offsets off) back to back, out_off[n + 1]; out must hold the sum of their lengths (the
 // driver's window -> length-binned batch and batch -> input order shuffles of read / name / quality / SAM text blobs)
-void* vm_pinned_alloc(int64_t bytes) {
+void* vm_pinned_alloc(int64_t bytes, int device) {
     void* p = nullptr;
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
 }

@@ -440,7 +440,7 @@ def main(argv=None, comm=None):
 
     # the batch's reads are gathered into page-locked memory: vm_align_batch's upload becomes a DMA the aligner thread does not wait for
     # (VMX_DRIVER_PINNED=0: pageable numpy arrays, the runtime stages the copy on the calling thread)
-    pinned = PinnedPool(lib) if os.environ.get('VMX_DRIVER_PINNED', '1') != '0' else None
+    pinned = PinnedPool(lib, device) if os.environ.get('VMX_DRIVER_PINNED', '1') != '0' else None
 
     def emit(w, i, ix, sb, so, raw):
         t0 = time.time()

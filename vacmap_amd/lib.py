@@ -165,7 +165,7 @@ class VmxLib:
         L.vm_sam_emit.argtypes = [vp, P(SamOpts), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, C.c_int, P(vp), P(P(i64)), P(i64), P(i64)]
         L.vm_blob_gather.argtypes = [vp, vp, vp, i64, vp, vp]; L.vm_blob_gather.restype = i64
         L.vm_blob_write_parts.argtypes = [C.c_int, vp, vp, vp, vp, i64]; L.vm_blob_write_parts.restype = i64
-        L.vm_pinned_alloc.argtypes = [i64]; L.vm_pinned_alloc.restype = vp
+        L.vm_pinned_alloc.argtypes = [i64, C.c_int]; L.vm_pinned_alloc.restype = vp
         L.vm_pinned_free.argtypes = [vp]; L.vm_pinned_free.restype = None
         L.vm_blob_gather_parts.argtypes = [vp, vp, vp, vp, i64, vp]; L.vm_blob_gather_parts.restype = i64
         L.vm_fastx_open.argtypes = [cp, P(vp)]; L.vm_fastx_close.argtypes = [vp]
@@ -510,9 +510,9 @@ class PinnedPool:
     one, so that vm_align_batch's upload is a DMA instead of a staged copy on the aligner thread. get() falls back to pageable memory when the
     runtime refuses (returns a plain array; release() ignores those)."""
 
-    def __init__(self, lib):
+    def __init__(self, lib, device=-1):
         import threading
-        self.lib, self.free, self.lock, self.owned = lib, [], threading.Lock(), {}
+        self.lib, self.device, self.free, self.lock, self.owned = lib, int(device), [], threading.Lock(), {}
 
     def get(self, nbytes):
         nbytes = max(int(nbytes), 1)
@@ -525,7 +525,7 @@ class PinnedPool:
                 cap, ptr = 0, None
         if ptr is None:
             cap = max(nbytes + nbytes // 4, 1 << 20)
-            ptr = self.lib.L.vm_pinned_alloc(cap)
+            ptr = self.lib.L.vm_pinned_alloc(cap, self.device)
             if not ptr:
                 return np.empty(nbytes, np.uint8)
         arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(cap,))
