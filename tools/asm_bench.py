@@ -15,6 +15,8 @@ def main():
     ap.add_argument('--seed', type=int, default=1); ap.add_argument('--no-oracle', action='store_true')
     a = ap.parse_args()
     from vacmap_amd import synth
+    from vacmap_amd.driver import _keep_heap_pages
+    _keep_heap_pages()                          # the driver's allocator setting (VMX_DRIVER_MALLOPT=0: off)
     from vacmap_amd.lib import Context, Index, align_batch
     import oracle_lib as O
     ctx = Context(0)
