@@ -128,8 +128,8 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
     int32_t* NEXT = A.next_pool + (size_t)blockIdx.x * (size_t)A.tpos_cap;
     uint64_t* HKEY = A.hkey_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;
     uint64_t* HKEY2 = A.hkey2_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;
-    int64_t* HVAL = A.hval_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;     // by stream index: refloc << 1 | (strand == +1)
-    int32_t* HQ = A.hq_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;         // by stream index: read position
+    int64_t* HVAL = A.hval_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;     // by stream index: read position << 34 | refloc << 1 | (strand == +1)
+#define VMX_HV(q, rl, f) ((int64_t)(((uint64_t)(q) << 34) | ((uint64_t)(rl) << 1) | (uint64_t)(f)))          /* refloc < 2^33, read position < 2^30 */
     int32_t* SQ = A.sq_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;         // by sorted index: read position
     int32_t* DST = A.dst_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;       // by sorted index: start of the diagonal group
     int32_t* GOFF = A.goff_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 if (A.r_st) { readstart = A.r_st[r]; readend = A.r_en[r] - k; }          // :22580, :22589
             }
             int npos = (status == 0 && readend > readstart) ? readend - readstart : 0;
-            if (npos > A.pcnt_cap) { status = VM_READ_CAPACITY_DEV; npos = 0; }
+            if (npos > A.pcnt_cap || readend >= (1 << 30)) { status = VM_READ_CAPACITY_DEV; npos = 0; }      // (read positions travel in 30 bits of the hit value)
             // --- table: one atomic exchange per window position links it in front of its 9-mer's list
             if (use_bm) {
                 // only the window positions whose 9-mer the read can ask for are linked (about one in nine: the read window holds ~30 k of the
@@ -374,8 +374,8 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 if (c2 == 0) continue;
                 long long w = PCNT[pi];
                 if (cf <= 1 && cr <= 1) {
-                    if (cf) { const long long rl = STG[2 * pi]; HKEY[w] = ((uint64_t)((rl - iloc) + (1LL << 36)) << 26) | (uint64_t)w; HVAL[w] = (rl << 1) | 1; HQ[w] = iloc; ++w; }
-                    if (cr) { const long long rl = STG[2 * pi + 1]; HKEY[w] = ((uint64_t)(-(rl + iloc) + (1LL << 36)) << 26) | (uint64_t)w; HVAL[w] = (rl << 1); HQ[w] = iloc; }
+                    if (cf) { const long long rl = STG[2 * pi]; HKEY[w] = ((uint64_t)((rl - iloc) + (1LL << 36)) << 26) | (uint64_t)w; HVAL[w] = VMX_HV(iloc, rl, 1); ++w; }
+                    if (cr) { const long long rl = STG[2 * pi + 1]; HKEY[w] = ((uint64_t)(-(rl + iloc) + (1LL << 36)) << 26) | (uint64_t)w; HVAL[w] = VMX_HV(iloc, rl, 0); }
                     continue;
                 }
                 bool ok; const uint32_t fw = vmx_kmer_at(RD, iloc, k, ok);
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 for (long long x = wf; x < w; ++x) {
                     const long long rl = HVAL[x]; const bool fwd = x < wr;
                     const long long point = fwd ? rl - iloc : -(rl + iloc);
-                    HKEY[x] = ((uint64_t)(point + (1LL << 36)) << 26) | (uint64_t)x; HVAL[x] = (rl << 1) | (fwd ? 1 : 0); HQ[x] = iloc;
+                    HKEY[x] = ((uint64_t)(point + (1LL << 36)) << 26) | (uint64_t)x; HVAL[x] = VMX_HV(iloc, rl, fwd ? 1 : 0);
                 }
             }
             __syncthreads();
@@ -453,8 +453,9 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                     int v = -1;
                     if (i < H) {
                         const uint64_t sidx = HKEY[i] & ((1ULL << 26) - 1);
-                        SQ[i] = HQ[sidx];
-                        SV[i] = HVAL[sidx];
+                        const int64_t hv = HVAL[sidx];              // one gather per hit: read position and hit value travel together
+                        SQ[i] = (int)((uint64_t)hv >> 34);
+                        SV[i] = hv & ((1LL << 34) - 1);
                         if (i == 0 || (HKEY[i] >> 26) != (HKEY[i - 1] >> 26)) v = (int)i;
                     }
                     for (int o = 1; o < 64; o <<= 1) { int x = __shfl_up(v, o); if (vmx_lane() >= o) v = x > v ? x : v; }
@@ -560,6 +561,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
     }
     if (threadIdx.x == 0) A.epoch_pool[blockIdx.x] = (int)ep;
 #undef VMX_HEAD_IDX
+#undef VMX_HV
 #undef VMX_HB
 #undef VMX_ENT_OK
 #undef VMX_ENT_NEXT

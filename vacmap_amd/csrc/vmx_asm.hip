@@ -325,7 +325,7 @@ int second_round_seed(vm_ctx* c, const vm_index_view& ix, int k, const uint8_t* 
     VMX_TRY(B.next.reserve(4 * (size_t)G * (size_t)tpos_cap));
     VMX_TRY(B.sq.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(B.dst.reserve(4 * (size_t)G * (size_t)hit_cap));
     VMX_TRY(B.hkey.reserve(8 * (size_t)G * (size_t)hit_cap)); VMX_TRY(B.hkey2.reserve(8 * (size_t)G * (size_t)hit_cap)); VMX_TRY(B.hval.reserve(8 * (size_t)G * (size_t)hit_cap));
-    VMX_TRY(B.hq.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(B.goff.reserve(4 * (size_t)G * (size_t)hit_cap));
+    VMX_TRY(B.goff.reserve(4 * (size_t)G * (size_t)hit_cap));
     VMX_TRY(B.pcnt.reserve(4 * (size_t)G * (size_t)pcnt_cap)); VMX_TRY(B.pc2.reserve(4 * (size_t)G * (size_t)pcnt_cap)); VMX_TRY(B.stg.reserve(16 * (size_t)G * (size_t)pcnt_cap));
     VMX_TRY(B.gkey.reserve(8 * (size_t)G * (size_t)gkey_cap)); VMX_TRY(B.gq.reserve(4 * (size_t)G * (size_t)gkey_cap)); VMX_TRY(B.gr.reserve(8 * (size_t)G * (size_t)gkey_cap));
     VMX_TRY(B.la_rows.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1))); VMX_TRY(B.la_ekey.reserve(8 * (size_t)(la_tot + 1))); VMX_TRY(B.la_sorted.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1)));
@@ -337,7 +337,7 @@ int second_round_seed(vm_ctx* c, const vm_index_view& ix, int k, const uint8_t* 
     A.queue = B.order.as<int32_t>(); A.order = B.order.as<int32_t>() + 1; A.la_slot_len = 1;
     A.head_pool = B.head.as<int32_t>(); A.next_pool = B.next.as<int32_t>(); A.head_stride = head_stride; A.epoch_pool = B.epoch.as<int32_t>();
     A.sq_pool = B.sq.as<int32_t>(); A.dst_pool = B.dst.as<int32_t>(); A.tpos_pool = nullptr; A.tpos_cap = tpos_cap; A.dbg = nullptr;
-    A.hkey2_pool = B.hkey2.as<uint64_t>(); A.hkey_pool = B.hkey.as<uint64_t>(); A.hval_pool = B.hval.as<int64_t>(); A.hq_pool = B.hq.as<int32_t>(); A.goff_pool = B.goff.as<int32_t>(); A.hit_cap = hit_cap;
+    A.hkey2_pool = B.hkey2.as<uint64_t>(); A.hkey_pool = B.hkey.as<uint64_t>(); A.hval_pool = B.hval.as<int64_t>(); A.goff_pool = B.goff.as<int32_t>(); A.hit_cap = hit_cap;
     A.pcnt_pool = B.pcnt.as<int32_t>(); A.pcnt_cap = pcnt_cap; A.pc2_pool = B.pc2.as<int32_t>(); A.stg_pool = B.stg.as<int64_t>();
     A.gkey_pool = B.gkey.as<uint64_t>(); A.gq_pool = B.gq.as<int32_t>(); A.gr_pool = B.gr.as<int64_t>(); A.gkey_cap = gkey_cap;
     A.la_rows = B.la_rows.as<vmx_anchor>(); A.la_ekey = B.la_ekey.as<uint64_t>(); A.la_sorted = B.la_sorted.as<vmx_anchor>(); A.la_off = B.la_off.as<int64_t>();

@@ -83,7 +83,7 @@ struct vmx_lseed_args {
     int64_t* tpos_pool; int64_t tpos_cap;
     unsigned long long* dbg;    // optional phase timers (VMX_DBG=1)
     uint64_t* hkey2_pool;
-    uint64_t* hkey_pool; int64_t* hval_pool; int32_t* hq_pool; int32_t* goff_pool; int64_t hit_cap;
+    uint64_t* hkey_pool; int64_t* hval_pool; int32_t* goff_pool; int64_t hit_cap;
     int32_t* pcnt_pool; int64_t pcnt_cap; int32_t* pc2_pool; int64_t* stg_pool;
     uint64_t* gkey_pool; int32_t* gq_pool; int64_t* gr_pool; int64_t gkey_cap;
     vmx_anchor* la_rows; uint64_t* la_ekey; vmx_anchor* la_sorted; const int64_t* la_off; int32_t* la_cnt; int32_t* status;

@@ -90,7 +90,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         VMX_TRY(L.cur.reserve(4 * (size_t)G * (size_t)tpos_cap));
         VMX_TRY(L.sq.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.dst.reserve(4 * (size_t)G * (size_t)hit_cap));
         VMX_TRY(L.hkey.reserve(8 * (size_t)G * (size_t)hit_cap));
-        VMX_TRY(L.hval.reserve(8 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.hq.reserve(4 * (size_t)G * (size_t)hit_cap));
+        VMX_TRY(L.hval.reserve(8 * (size_t)G * (size_t)hit_cap));
         VMX_TRY(L.goff.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.pcnt.reserve(4 * (size_t)G * (size_t)pcnt_cap));
         VMX_TRY(L.gkey.reserve(8 * (size_t)G * (size_t)gkey_cap)); VMX_TRY(L.gq.reserve(4 * (size_t)G * (size_t)gkey_cap)); VMX_TRY(L.gr.reserve(8 * (size_t)G * (size_t)gkey_cap));
         VMX_TRY(L.la_rows.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1))); VMX_TRY(L.la_ekey.reserve(8 * (size_t)(la_tot + 1)));
@@ -107,7 +107,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         A.head_stride = head_stride; A.head_pool = L.cnt.as<int32_t>(); A.next_pool = L.cur.as<int32_t>(); A.sq_pool = L.sq.as<int32_t>(); A.dst_pool = L.dst.as<int32_t>(); A.tpos_pool = nullptr; A.tpos_cap = tpos_cap;          // window positions are implied by the interval list (k_local_seed)
         VMX_TRY(L.hkey2.reserve(8 * (size_t)G * (size_t)hit_cap));
         A.hkey2_pool = L.hkey2.as<uint64_t>();
-        A.hkey_pool = L.hkey.as<uint64_t>(); A.hval_pool = L.hval.as<int64_t>(); A.hq_pool = L.hq.as<int32_t>(); A.goff_pool = L.goff.as<int32_t>(); A.hit_cap = hit_cap;
+        A.hkey_pool = L.hkey.as<uint64_t>(); A.hval_pool = L.hval.as<int64_t>(); A.goff_pool = L.goff.as<int32_t>(); A.hit_cap = hit_cap;
         VMX_TRY(L.pc2.reserve(4 * (size_t)G * (size_t)pcnt_cap)); VMX_TRY(L.stg.reserve(16 * (size_t)G * (size_t)pcnt_cap));
         A.pc2_pool = L.pc2.as<int32_t>(); A.stg_pool = L.stg.as<int64_t>();
         A.pcnt_pool = L.pcnt.as<int32_t>(); A.pcnt_cap = pcnt_cap; A.gkey_pool = L.gkey.as<uint64_t>(); A.gq_pool = L.gq.as<int32_t>(); A.gr_pool = L.gr.as<int64_t>();
