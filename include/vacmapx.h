@@ -32,8 +32,8 @@ typedef enum vm_status {
     VM_READ_RAISED = -10,       /* the reference's Python would have raised inside the per-read path */
     VM_READ_CAPACITY = -20,     /* a device work buffer overflowed for this read (reported, never silently truncated) */
     VM_READ_FASTPATH = -21,     /* internal hand-off to the `_fast` chain kernels (:23570, :24914, :27380); never returned by vm_align_batch */
-    VM_READ_UNSUPPORTED = -22   /* -mode asm only: a contig whose equal-score chains need the edlib tie-break of mammap_asm.py:21302-21326 (MAPQ 0), or a
-                                   long contig whose carried slice leaves the stored part of the score index (k_chain_linked.hip): reported, not approximated */
+    VM_READ_UNSUPPORTED = -22   /* -mode asm only: a long contig whose carried slice leaves the stored part of the score index (k_chain_linked.hip):
+                                   reported, not approximated. (The MAPQ-0 edlib tie-break of mammap_asm.py:21302-21326 is built: it no longer refuses.) */
 } vm_status;
 
 enum { VM_MODE_H = 0, VM_MODE_L = 1, VM_MODE_S = 2, VM_MODE_R = 3,   /* -mode (src/vacmap/vacmap:87) */

@@ -128,14 +128,14 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
     int32_t* NEXT = A.next_pool + (size_t)blockIdx.x * (size_t)A.tpos_cap;
     uint64_t* HKEY = A.hkey_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;
     uint64_t* HKEY2 = A.hkey2_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;
-    int64_t* HVAL = A.hval_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;     // by stream index: read position << 34 | refloc << 1 | (strand == +1)
-#define VMX_HV(q, rl, f) ((int64_t)(((uint64_t)(q) << 34) | ((uint64_t)(rl) << 1) | (uint64_t)(f)))          /* refloc < 2^33, read position < 2^30 */
+    int64_t* HVAL = A.hval_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;     // by stream index: read position << 24 | window index << 1 | (strand == +1)
+#define VMX_HV(q, t, f) ((int64_t)(((uint64_t)(q) << 24) | ((uint64_t)(t) << 1) | (uint64_t)(f)))          /* window index < 2^23 (checked with the windows): no limit on the reference's size */
     int32_t* SQ = A.sq_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;         // by sorted index: read position
     int32_t* DST = A.dst_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;       // by sorted index: start of the diagonal group
     int32_t* GOFF = A.goff_pool + (size_t)blockIdx.x * (size_t)A.hit_cap;
     int32_t* PCNT = A.pcnt_pool + (size_t)blockIdx.x * (size_t)A.pcnt_cap;
     int32_t* PC2 = A.pc2_pool + (size_t)blockIdx.x * (size_t)A.pcnt_cap;             // per read position: accepted forward | reverse << 16
-    int64_t* STG = A.stg_pool + (size_t)blockIdx.x * 2 * (size_t)A.pcnt_cap;         // per read position: first accepted forward / reverse ref position
+    int64_t* STG = A.stg_pool + (size_t)blockIdx.x * 2 * (size_t)A.pcnt_cap;         // per read position: window index of the first accepted forward / reverse hit
     uint64_t* GKEY = A.gkey_pool + (size_t)blockIdx.x * (size_t)A.gkey_cap;
     int32_t* GQg = A.gq_pool + (size_t)blockIdx.x * (size_t)A.gkey_cap;
     int64_t* GRg = A.gr_pool + (size_t)blockIdx.x * (size_t)A.gkey_cap;
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 if (A.r_st) { readstart = A.r_st[r]; readend = A.r_en[r] - k; }          // :22580, :22589
             }
             int npos = (status == 0 && readend > readstart) ? readend - readstart : 0;
-            if (npos > A.pcnt_cap || readend >= (1 << 30)) { status = VM_READ_CAPACITY_DEV; npos = 0; }      // (read positions travel in 30 bits of the hit value)
+            if (npos > A.pcnt_cap) { status = VM_READ_CAPACITY_DEV; npos = 0; }
             // --- table: one atomic exchange per window position links it in front of its 9-mer's list
             if (use_bm) {
                 // only the window positions whose 9-mer the read can ask for are linked (about one in nine: the read window holds ~30 k of the
@@ -340,8 +340,8 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                     long long interval = (long long)b0 + b1 + 500; if (interval > 2000) interval = 2000;
                     const long long ref1 = GR[c0], ref2 = GR[c1];
                     long long rgap = (long long)iloc - GQ[c0]; if (rgap < 0) rgap = -rgap;
-                    for (int t = hf; t >= 0;) { const int e = NEXT[t]; if (VMX_ENT_OK(e, fw)) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cf == 0) ff = rl; ++cf; } } t = VMX_ENT_NEXT(e); }
-                    for (int t = hr; t >= 0;) { const int e = NEXT[t]; if (VMX_ENT_OK(e, rv)) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cr == 0) fr = rl; ++cr; } } t = VMX_ENT_NEXT(e); }
+                    for (int t = hf; t >= 0;) { const int e = NEXT[t]; if (VMX_ENT_OK(e, fw)) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cf == 0) ff = t; ++cf; } } t = VMX_ENT_NEXT(e); }
+                    for (int t = hr; t >= 0;) { const int e = NEXT[t]; if (VMX_ENT_OK(e, rv)) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) { if (cr == 0) fr = t; ++cr; } } t = VMX_ENT_NEXT(e); }
                 }
                 PCNT[pi] = cf + cr;
                 PC2[pi] = (cf > 0xffff ? 0xffff : cf) | ((cr > 0x7fff ? 0x7fff : cr) << 16);
@@ -374,8 +374,8 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 if (c2 == 0) continue;
                 long long w = PCNT[pi];
                 if (cf <= 1 && cr <= 1) {
-                    if (cf) { const long long rl = STG[2 * pi]; HKEY[w] = ((uint64_t)((rl - iloc) + (1LL << 36)) << 26) | (uint64_t)w; HVAL[w] = VMX_HV(iloc, rl, 1); ++w; }
-                    if (cr) { const long long rl = STG[2 * pi + 1]; HKEY[w] = ((uint64_t)(-(rl + iloc) + (1LL << 36)) << 26) | (uint64_t)w; HVAL[w] = VMX_HV(iloc, rl, 0); }
+                    if (cf) { const int t = (int)STG[2 * pi]; const long long rl = tpos_of(t); HKEY[w] = ((uint64_t)((rl - iloc) + (1LL << 36)) << 26) | (uint64_t)w; HVAL[w] = VMX_HV(iloc, t, 1); ++w; }
+                    if (cr) { const int t = (int)STG[2 * pi + 1]; const long long rl = tpos_of(t); HKEY[w] = ((uint64_t)(-(rl + iloc) + (1LL << 36)) << 26) | (uint64_t)w; HVAL[w] = VMX_HV(iloc, t, 0); }
                     continue;
                 }
                 bool ok; const uint32_t fw = vmx_kmer_at(RD, iloc, k, ok);
@@ -386,15 +386,15 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                 long long rgap = (long long)iloc - GQ[c0]; if (rgap < 0) rgap = -rgap;
                 const long long wf = w;
                 const bool pf = !use_bm || ((BM[fw >> 5] >> (fw & 31)) & 1u), pr = iloc > 0 && (!use_bm || ((BM[rv >> 5] >> (rv & 31)) & 1u));
-                for (int t = pf ? VMX_HEAD_IDX(HEAD[VMX_HB(fw)]) : -1; t >= 0;) { const int e = NEXT[t]; if (VMX_ENT_OK(e, fw)) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; } t = VMX_ENT_NEXT(e); }
+                for (int t = pf ? VMX_HEAD_IDX(HEAD[VMX_HB(fw)]) : -1; t >= 0;) { const int e = NEXT[t]; if (VMX_ENT_OK(e, fw)) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = t; } t = VMX_ENT_NEXT(e); }
                 const long long wr = w;
-                if (pr) for (int t = VMX_HEAD_IDX(HEAD[VMX_HB(rv)]); t >= 0;) { const int e = NEXT[t]; if (VMX_ENT_OK(e, rv)) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = rl; } t = VMX_ENT_NEXT(e); }
+                if (pr) for (int t = VMX_HEAD_IDX(HEAD[VMX_HB(rv)]); t >= 0;) { const int e = NEXT[t]; if (VMX_ENT_OK(e, rv)) { const long long rl = tpos_of(t); if (vmx_local_accept(rl, ref1, ref2, interval, rgap)) HVAL[w++] = t; } t = VMX_ENT_NEXT(e); }
                 if (wr - wf > 1) vmx_isort_i64(HVAL + wf, (int)(wr - wf));
                 if (w - wr > 1) vmx_isort_i64(HVAL + wr, (int)(w - wr));
                 for (long long x = wf; x < w; ++x) {
-                    const long long rl = HVAL[x]; const bool fwd = x < wr;
+                    const int t = (int)HVAL[x]; const long long rl = tpos_of(t); const bool fwd = x < wr;      // (window indices ascend with the reference position)
                     const long long point = fwd ? rl - iloc : -(rl + iloc);
-                    HKEY[x] = ((uint64_t)(point + (1LL << 36)) << 26) | (uint64_t)x; HVAL[x] = VMX_HV(iloc, rl, fwd ? 1 : 0);
+                    HKEY[x] = ((uint64_t)(point + (1LL << 36)) << 26) | (uint64_t)x; HVAL[x] = VMX_HV(iloc, t, fwd ? 1 : 0);
                 }
             }
             __syncthreads();
@@ -454,8 +454,8 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                     if (i < H) {
                         const uint64_t sidx = HKEY[i] & ((1ULL << 26) - 1);
                         const int64_t hv = HVAL[sidx];              // one gather per hit: read position and hit value travel together
-                        SQ[i] = (int)((uint64_t)hv >> 34);
-                        SV[i] = hv & ((1LL << 34) - 1);
+                        SQ[i] = (int)((uint64_t)hv >> 24);
+                        SV[i] = (tpos_of((int)((hv >> 1) & 0x7fffff)) << 1) | (hv & 1);
                         if (i == 0 || (HKEY[i] >> 26) != (HKEY[i - 1] >> 26)) v = (int)i;
                     }
                     for (int o = 1; o < 64; o <<= 1) { int x = __shfl_up(v, o); if (vmx_lane() >= o) v = x > v ? x : v; }

@@ -164,7 +164,8 @@ def _run_asm(args, lib, ctx, index, prm, rg, mark, out, proc, world, rank, text_
     if not args.workdir:
         sys.exit('workdir not provided! -workdir /path/to/workdir')                      # vacmap:247-249
     os.makedirs(args.workdir, exist_ok=True)
-    prm.eqx = 1
+    # the fork hard-codes these, whatever -c / -maxdivergence say: check_num = -1 (mammap_asm.py:23206), maxdivergence = 1.0 (:23483), --eqx
+    prm.eqx = 1; prm.check_num = -1; prm.maxdivergence = 1.0
     opts = SamOpts(int(bool(args.MD)), int(args.cs != 'long'), int(bool(args.L)), int(bool(mark)), int(bool(args.H)), int(bool(args.fakecigar)), rg['ID'].encode(), 1)
     seen = set(); n_contigs = n_lines = n_skipped = 0
 
@@ -209,11 +210,9 @@ def _run_asm(args, lib, ctx, index, prm, rg, mark, out, proc, world, rank, text_
     group, gbases = [], 0
     for grp in args.read:
         for path in grp:
-            rd = Fastx(path, lib=lib)
-            while True:
-                ch = rd.read(64)
-                if ch is None:
-                    break
+            # (.bam input like every other mode: vacmap:452-470)
+            chunks = _bam_chunks(path, 64) if path.endswith('.bam') else iter(lambda rd=Fastx(path, lib=lib): rd.read(64), None)
+            for ch in chunks:
                 nb, no, sb, so = ch['names'].tobytes(), ch['names_off'], ch['seqs'].tobytes(), ch['seqs_off']
                 qb, qo, cb, co = ch['quals'].tobytes(), ch['quals_off'], ch['comments'].tobytes(), ch['comments_off']
                 for i in range(len(so) - 1):
@@ -332,7 +331,11 @@ def main(argv=None, comm=None):
         for ln in sam.header_lines([(n, ln_) for n, ln_ in zip(names, index.lens)], ' '.join(sys.argv if argv is None else ['vacmapx'] + list(argv)), rg):
             out.write(ln.encode() + b'\n')
     if args.mode == 'asm':
-        return _run_asm(args, lib, ctx, index, prm, rg, mark, out, proc, world, rank, text_group, t_start)
+        rc = _run_asm(args, lib, ctx, index, prm, rg, mark, out, proc, world, rank, text_group, t_start)
+        ctx.close()
+        if own_group:                                   # no rank leaves while rank 0 still gathers and writes
+            comm.barrier(); comm.destroy_process_group()
+        return rc
     pipe = pipeline.Pipeline(index, prm, device=device, inflight=args.inflight, first_ctx=ctx)
     if os.environ.get('VMX_SPIN_SYNC') != '1':
         for cx in pipe.ctxs:
