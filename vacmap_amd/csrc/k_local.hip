@@ -20,13 +20,10 @@
 #include "vmx_device.h"
 #include "vmx_kernels.h"
 #include "vmx_local.h"
+#include "vmx_local_dev.h"
 
 #define vmx_block_sort_u64(g, N, lds) vmx_block_sort_u64_impl((g), (N), (lds), VMX_SORT_LDS)
 #define VMX_GUIDE_LDS 1024      // guide anchors kept in LDS (q 4 B + r 8 B); longer guides are read from HBM
-
-__device__ __forceinline__ vmx_anchor vmx_mk_anchor(long long q, long long r, int s, long long l) {
-    vmx_anchor a; a.q = (int32_t)q; a.r = r; a.s = (int16_t)s; a.l = (int16_t)l; return a;
-}
 
 // ------------------------------------------------------------------------------------------------ orient
 __global__ void k_orient(const uint8_t* __restrict__ codes, const int64_t* __restrict__ roff, const double* __restrict__ gscore, int n_reads,
@@ -56,38 +53,6 @@ __global__ void k_local_prep(const vmx_anchor* __restrict__ path_rows, const int
 }
 
 // ------------------------------------------------------------------------------------------------ L2 seeding
-__device__ __forceinline__ int vmx_pos2contig(const int64_t* __restrict__ coff, int nseq, long long pos) {   // :51-59
-    int lo = 0, hi = nseq;                        // bisection: same index as the reference's linear scan of the contig starts
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (coff[mid] <= pos) lo = mid; else hi = mid; }
-    return lo;
-}
-
-// findClosest_1 :17560-17582 on the guide sorted by read position (gq ascending)
-__device__ __forceinline__ void vmx_find_closest(const int* gq, int n, int target, int& b0, int& b1, int& i0, int& i1) {
-    if (target <= gq[0]) { b0 = b1 = gq[0] - target; i0 = i1 = 0; return; }
-    if (target >= gq[n - 1]) { b0 = b1 = target - gq[n - 1]; i0 = i1 = n - 1; return; }
-    int i = 0, j = n, mid = 0;
-    while (i < j) {
-        mid = (i + j) >> 1;
-        if (gq[mid] == target) { b0 = b1 = 0; i0 = i1 = mid; return; }
-        if (target < gq[mid]) j = mid; else i = mid + 1;
-    }
-    b0 = gq[j - 1] - target; if (b0 < 0) b0 = -b0;
-    b1 = gq[j] - target; if (b1 < 0) b1 = -b1;
-    i0 = j - 1; i1 = j;
-}
-
-__device__ __forceinline__ uint32_t vmx_kmer_at(const uint8_t* s, long long x, int k, bool& ok) {
-    uint32_t v = 0; ok = true;
-    for (int i = 0; i < k; ++i) { uint8_t c = s[x + i]; if (c > 3) ok = false; v = (v << 2) | (uint32_t)(c & 3); }
-    return v;
-}
-__device__ __forceinline__ uint32_t vmx_kmer_rc(uint32_t fw, int k) {
-    uint32_t rv = 0;
-    for (int i = 0; i < k; ++i) { rv = (rv << 2) | (3 - (fw & 3)); fw >>= 2; }
-    return rv;
-}
-
 // ascending insertion sort of a short run of int64 values in HBM (accepted hits of one read position and strand)
 __device__ __forceinline__ void vmx_isort_i64(int64_t* a, int n) {
     for (int i = 1; i < n; ++i) { int64_t v = a[i]; int j = i - 1; while (j >= 0 && a[j] > v) { a[j + 1] = a[j]; --j; } a[j + 1] = v; }

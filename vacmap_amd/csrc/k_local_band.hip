@@ -1,0 +1,518 @@
+// k_local_band.hip — local 9-mer re-seeding around the guide chains, guide-banded and LDS-tiled.
+//
+//   k_local_seed_band   get_localmap_multi_all_forDP_inv_guide_1 (/root/reference/src/vacmap/mammap_clrnano.py:23069-23345), one workgroup
+//                       per read, same inputs / outputs / scratch pools as k_local_seed (k_local.hip), which stays as the general form: a
+//                       read this kernel cannot take (VM_READ_BANDFALL_DEV) is re-run there by vmx_local_stage.
+//
+// Why a second form. The reference joins the 9-mers of the read window with those of the reference windows (guide +- 7000) and THEN drops
+// every hit that is not near the two guide anchors closest to the read position (:23216-23231: |refloc - ref1| within `interval` <= 2000,
+// the same around ref2, or |readgap - refgap| < 500). k_local_seed does literally that through HBM: a hash table of the windows per read,
+// hit pools, three sorts over all hits of a guide — 145x the algorithmic bytes. Here the read window is cut into CHUNKS of
+// LB_QC positions; for a chunk the filter itself bounds the reference positions that can be accepted to a few intervals around the guide
+// anchors bracketing the chunk (the BAND, clipped to the reference windows: a position outside every window is not in the reference's
+// table). The chunk's forward and reverse-complement 9-mers go into an LDS hash table (bucket heads + entries whose index IS the read
+// position and strand), the band is streamed through it (rolling 9-mers, every in-band position is examined, so a repeated k-mer yields
+// all its positions like local_lookuptable_m), candidates are tested with the exact filter of :23231, and the accepted hits
+// (strand, diagonal, read position) are sorted in LDS.
+//   The run merge (:23232-23344) couples only hits of one diagonal that are <= k read positions apart: inside a chunk a lane walks each run.
+// Across chunks three things survive, all of them small:
+//   * a run whose last hit lies in the chunk's last k positions may go on in the next chunk: its state waits in an LDS list ("open runs");
+//   * the leftover anchor of a diagonal's last run is appended by the reference either when the NEXT hit on that diagonal arrives, however
+//     much later (:23248), or at the very end in first-appearance order of the diagonals (:23343): chunks append (diagonal, chunk, HEAD =
+//     emission key of the group's first hit | TAIL = the pending anchor) records to a log in HBM — two per (diagonal, chunk) group, ~0.25
+//     per read base instead of ~25 B x 10 per hit — which is sorted once per guide and resolved pairwise;
+//   * the order in which the reference appended the anchors ("emission key": the (read position, strand, window index) of the hit that
+//     triggered the append, or FINAL | key of the diagonal's first hit) — restored by one sort per guide, then the stable argsort by
+//     q + l (:28585) as before.
+// HBM traffic per read: the read and ~(1 + 4000 / LB_QC) x the window bases (L2 hits mostly), the log, the anchors and their two sorts.
+// Deviation D1: a 9-mer holding a non-ACGT base never matches.
+#define VMX_SORT_LOGR 3
+#include "vmx_device.h"
+#include "vmx_kernels.h"
+#include "vmx_local.h"
+#include "vmx_local_dev.h"
+
+#define LB_NBLOG 12
+#define LB_NB (1 << LB_NBLOG)       // bucket heads of the chunk table
+#define LB_OPEN 64                  // runs that may cross one chunk boundary
+#define LB_PIECES 32                // disjoint band intervals of a chunk (after clipping to the windows)
+#define LB_HULL_ONE 16384           // the <= 4 accept intervals of one guide segment are taken as their hull up to this many positions
+#define LB_SLACK 64                 // band intervals closer than this are streamed as one
+#define LB_QB 26                    // bits of a hit key that hold the read position (relative to the read window)
+#define LB_SEQB 13                  // bits of a log key that hold the chunk number
+
+__device__ __forceinline__ int vmx_bits_u64(unsigned long long v) { int b = 0; while (b < 64 && (v >> b)) ++b; return b; }
+
+__global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
+    VMX_DYN_SHARED(uint64_t, s_u);                 // 8 * (4096 + VMX_LB_HCAP) bytes
+    uint64_t* const s_sort = s_u;                  // [0, 32 KB): block sorts / the sorted hits of a chunk
+    uint32_t* const s_head = (uint32_t*)s_u;       // [0, 16 KB): bucket heads (entry index + 1, 0 = empty)
+    uint32_t* const s_ent = s_head + LB_NB;        // [16, 32 KB): entry 2 i + s of chunk position i, strand s: (k-mer >> 12) << 13 | next
+    uint64_t* const s_hit = s_u + 4096;            // [32 KB, ..): band intervals of the plan, then the chunk's hits
+    __shared__ int s_gq[VMX_LB_GS];
+    __shared__ long long s_gr[VMX_LB_GS];
+    __shared__ unsigned short s_seg[VMX_LB_QC];
+    __shared__ long long s_iv[64][2];
+    __shared__ int s_ivbase[65];
+    __shared__ long long s_pc[LB_PIECES][2];
+    __shared__ unsigned long long s_opd[2][LB_OPEN];
+    __shared__ long long s_opr[2][LB_OPEN];
+    __shared__ int s_opq[2][LB_OPEN], s_opp[2][LB_OPEN], s_opl[2][LB_OPEN], s_opu[LB_OPEN];
+    __shared__ int s_nop[2];
+    __shared__ int s_scan[20];
+    __shared__ int s_niv, s_flag, s_next, s_fail, s_cnt, s_nit, s_npc, s_nhit, s_nlog, s_emit;
+    __shared__ unsigned long long s_hlo, s_hhi;
+    const int T = (int)blockDim.x, tid = (int)threadIdx.x;
+    const int k = A.k;
+    const uint32_t KMASK = (1u << (2 * k)) - 1u;
+    const int64_t hit_cap = A.hit_cap;
+    uint64_t* HKEY = A.hkey_pool + (size_t)blockIdx.x * (size_t)hit_cap;        // log keys, then the emission / final sort keys
+    uint64_t* LOGV0 = A.hkey2_pool + (size_t)blockIdx.x * (size_t)hit_cap;      // log values: HEAD emission key | TAIL q << 32 | l
+    int64_t* LOGV1 = A.hval_pool + (size_t)blockIdx.x * (size_t)hit_cap;        //             TAIL reference position
+    int32_t* GOFF = A.goff_pool + (size_t)blockIdx.x * (size_t)hit_cap;
+    uint64_t* GKEY = A.gkey_pool + (size_t)blockIdx.x * (size_t)A.gkey_cap;
+    long long vt0 = VMX_CLOCK();
+#define VMX_T(ph) do { if (A.dbg && threadIdx.x == 0) { long long t1_ = VMX_CLOCK(); atomicAdd(&A.dbg[ph], (unsigned long long)(t1_ - vt0)); vt0 = t1_; } } while (0)
+    while (true) {
+        if (tid == 0) s_next = atomicAdd(A.queue, 1);
+        __syncthreads();
+        const int qi = vmx_uniform_i32(s_next);
+        __syncthreads();
+        if (qi >= A.n_reads) break;
+        const int r = A.order[qi];
+        const int ng = A.n_guides_used[r];
+        const int64_t a0 = A.aoff[r];
+        const uint8_t* RD = A.ocodes + (A.rd_off ? A.rd_off[r] : A.roff[r]);
+        const int L = A.rd_off ? (int)A.rd_len[r] : (int)(A.roff[r + 1] - A.roff[r]);
+        vmx_anchor* OUT = A.la_rows + A.la_off[r];
+        uint64_t* OKEY = A.la_ekey + A.la_off[r];
+        vmx_anchor* SORTED = A.la_sorted + A.la_off[r];
+        const int out_cap = A.rd_off ? (int)(A.la_off[r + 1] - A.la_off[r]) : (int)(A.la_slot_len * VMX_LA_SLOT((int64_t)L));
+        int n_out = 0;
+        int status = 0;
+        int gbase = 0;
+        for (int g = 0; g < ng; ++g) {
+            // (as in k_local_seed: a failed guide sets `status`, every later phase runs on empty ranges and all waves meet every barrier)
+            const vmx_anchor* G = A.guide_rows + a0 + gbase;     // descending read order
+            const int m = A.guide_len[a0 + g];
+            gbase += m;
+            int N = 1; while (N < m) N <<= 1;
+            if (N > A.gkey_cap) status = VM_READ_BANDFALL_DEV;
+            const int mm = status ? 0 : m;
+            // --- :23095-23102 readgap
+            int rg = 0;
+            for (int i = 1 + tid; i < mm; i += T) { int d = G[i].q - G[i - 1].q; if (d < 0) d = -d; rg = d > rg ? d : rg; }
+            rg = vmx_wave_max_i32(rg);
+            if (tid == 0) { s_flag = 0; s_fail = 0; }
+            __syncthreads();
+            if (vmx_lane() == 0) atomicMax(&s_flag, rg);
+            __syncthreads();
+            long long readgap = (long long)s_flag + 1000; if (readgap < 5000) readgap = 5000;
+            __syncthreads();
+            // --- guide sorted by ref position (stable, :23103): key = r << 24 | original index
+            const int NN = status ? 0 : N;
+            for (int i = tid; i < NN; i += T) GKEY[i] = i < m ? (((uint64_t)G[i].r << 24) | (uint64_t)i) : ~0ULL;
+            __syncthreads();
+            int gk_lds = 0;
+            if (NN > 1) gk_lds = vmx_block_sort_u64_tiled(GKEY, NN, s_sort, VMX_SORT_LDS);
+            // --- windows (serial, thread 0): :23105-23180 — disjoint intervals of k-mer starts [lo, hi) in global reference coordinates
+            if (tid == 0) {
+                auto GK = [&](int i) -> uint64_t { return gk_lds == 2 ? s_sort[vmx_sw(i)] : (gk_lds == 1 ? s_sort[i] : GKEY[i]); };
+                int niv = 0; bool overflow = false;
+                for (int attempt = 0; attempt < 2 && mm > 0; ++attempt) {
+                    const bool split = attempt == 1;
+                    niv = 0; bool retry = false;
+                    long long ws = (long long)(GK(0) >> 24), we = ws;
+                    int cur = vmx_pos2contig(A.coff, A.nseq, ws);
+                    for (int i = 1; i <= mm; ++i) {
+                        bool close_it = true; long long rr = 0;
+                        if (i < mm) {
+                            rr = (long long)(GK(i) >> 24);
+                            bool same = (rr - we) < readgap;
+                            if (split) same = same && (cur == vmx_pos2contig(A.coff, A.nseq, rr));
+                            if (same) { we = rr; close_it = false; }
+                        }
+                        if (close_it) {
+                            if (ws != we) {   // single-point windows are dropped (:23110, :23113)
+                                int c = vmx_pos2contig(A.coff, A.nseq, ws);
+                                if (c != vmx_pos2contig(A.coff, A.nseq, we)) { retry = true; break; }
+                                long long cst = A.coff[c], clen = A.coff[c + 1] - cst;
+                                long long lf = ws - cst < A.look_span ? ws - cst : A.look_span;
+                                long long lo = ws - lf - cst, hi = we + A.look_span - cst; if (hi > clen) hi = clen;
+                                long long nk = (hi - lo) - k + 1;
+                                if (nk > 0) {
+                                    long long a = cst + lo, b = a + nk;
+                                    if (niv > 0 && a <= s_iv[niv - 1][1]) { if (b > s_iv[niv - 1][1]) s_iv[niv - 1][1] = b; }     // (touching intervals are one: a run may cross)
+                                    else if (niv < 64) { s_iv[niv][0] = a; s_iv[niv][1] = b; ++niv; }
+                                    else overflow = true;
+                                }
+                            }
+                            if (i < mm) { ws = we = rr; if (split) cur = vmx_pos2contig(A.coff, A.nseq, rr); }
+                        }
+                    }
+                    if (!retry) break;
+                }
+                long long tot = 0;
+                for (int v = 0; v < niv; ++v) { s_ivbase[v] = (int)tot; tot += s_iv[v][1] - s_iv[v][0]; }
+                s_ivbase[niv] = (int)(tot < 0x7fffffff ? tot : 0x7fffffff);
+                if (tot >= 0x7fffffff) overflow = true;
+                s_niv = niv; s_flag = overflow ? 1 : 0;
+            }
+            __syncthreads();
+            if (s_flag) status = VM_READ_BANDFALL_DEV;
+            const int niv = status ? 0 : s_niv;
+            // the window index of a reference position inside the windows (ascends with the position)
+            auto t_of = [&](long long x) -> long long { int v = 0; while (v + 1 < niv && x >= s_iv[v + 1][0]) ++v; return (long long)s_ivbase[v] + (x - s_iv[v][0]); };
+            // --- read window :23183-23191 (GQ ascending = the stored order reversed)
+            int readstart = 0, readend = 0;
+            if (mm > 0) {
+                readstart = G[mm - 1].q - A.read_span; if (readstart < 0) readstart = 0;
+                readend = G[0].q + A.read_span; if (readend > L - k + 1) readend = L - k + 1;
+                if (A.r_st) { readstart = A.r_st[r]; readend = A.r_en[r] - k; }          // :22580, :22589
+            }
+            int npos = (status == 0 && niv > 0 && readend > readstart) ? readend - readstart : 0;
+            const long long wlo = niv ? s_iv[0][0] : 0, whi = niv ? s_iv[niv - 1][1] : 0;
+            // key layouts of this guide. hit: (strand | diagonal) << 26 | read position; log: ((strand | diagonal) << 13 | chunk) << 1 | TAIL, then the
+            // record index; emission: read position, strand, window index, FINAL on top
+            const int dbits = vmx_bits_u64((unsigned long long)((whi - wlo) + npos));
+            const int tb = vmx_bits_u64((unsigned long long)s_ivbase[niv > 0 ? niv : 0]), pb = vmx_bits_u64((unsigned long long)npos);
+            const int ilb = 64 - (1 + dbits + LB_SEQB + 1);
+            const int ekb = pb + tb + 1;                                    // bit of the FINAL flag
+            if (npos > 0 && (npos >= (1 << LB_QB) || 1 + dbits + LB_QB > 63 || ilb < 14 || ekb + 1 > 50)) { status = VM_READ_BANDFALL_DEV; npos = 0; }
+            const unsigned long long DM = dbits >= 64 ? ~0ULL : ((1ULL << dbits) - 1ULL);
+            const unsigned long long QM = (1ULL << LB_QB) - 1ULL;
+            auto ekey_of = [&](int q, int sb, long long x) -> uint64_t { return ((uint64_t)(unsigned)(q - readstart) << (tb + 1)) | ((uint64_t)sb << tb) | (uint64_t)t_of(x); };
+            // lower-bound cursor of the guide: anchors with GQ < readstart
+            if (tid == 0) { s_cnt = 0; s_nop[0] = 0; s_nop[1] = 0; s_nlog = 0; s_emit = 0; }
+            __syncthreads();
+            if (npos > 0) {
+                int c = 0;
+                for (int i = tid; i < mm; i += T) c += G[mm - 1 - i].q < readstart ? 1 : 0;
+                c = vmx_wave_sum_i32(c);
+                if (vmx_lane() == 0 && c) atomicAdd(&s_cnt, c);
+            }
+            __syncthreads();
+            int cj = s_cnt;
+            __syncthreads();
+            VMX_T(0);
+            int q0 = readstart, qc = VMX_LB_QC, seq = 0, cur = 0;
+            const int qend = npos > 0 ? readend : readstart;
+            while (q0 < qend) {
+                // ---------------------------------------------------------------- plan: guide slice, closest anchors, band
+                const int js = cj > 0 ? cj - 1 : 0;
+                const int navail = mm - js < VMX_LB_GS ? mm - js : VMX_LB_GS;
+                for (int i = tid; i < navail; i += T) { const vmx_anchor a = G[mm - 1 - (js + i)]; s_gq[i] = a.q; s_gr[i] = a.r; }
+                if (tid == 0) { s_cnt = 0; s_nit = 0; s_nhit = 0; s_hlo = ~0ULL; s_hhi = 0ULL; s_nop[cur ^ 1] = 0; }
+                for (int i = tid; i < LB_OPEN; i += T) s_opu[i] = 0;
+                __syncthreads();
+                int qb = q0 + qc < qend ? q0 + qc : qend;
+                {
+                    int c = 0;
+                    for (int i = tid; i < navail; i += T) c += s_gq[i] <= qb - 1 ? 1 : 0;
+                    c = vmx_wave_sum_i32(c);
+                    if (vmx_lane() == 0 && c) atomicAdd(&s_cnt, c);
+                }
+                __syncthreads();
+                int je = s_cnt;                                   // staged anchors at or before the chunk's last position
+                if (je >= navail && js + navail < mm) { qb = s_gq[navail - 1]; je = navail - 1; }       // more anchors than the slice holds: the chunk ends at the last staged one
+                const int ns = je + 1 < navail ? je + 1 : navail;
+                const int cj_next = js + je;
+                const int qlen = qb - q0;
+                const bool g_first = js == 0, g_last = js + ns == mm;
+                // closest guide anchors of every chunk position (findClosest_1 :17560 on the slice: same answer, the read positions are distinct)
+                for (int i = tid; i < qlen; i += T) {
+                    const int p = q0 + i;
+                    int lo = 0, hi = ns;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_gq[mid] <= p) lo = mid + 1; else hi = mid; }
+                    int c0, c1;
+                    if (lo > 0 && s_gq[lo - 1] == p) c0 = c1 = lo - 1;
+                    else if (lo == 0) c0 = c1 = 0;
+                    else if (lo == ns) c0 = c1 = ns - 1;
+                    else { c0 = lo - 1; c1 = lo; }
+                    s_seg[i] = (unsigned short)((c0 << 1) | (c1 != c0 ? 1 : 0));
+                }
+                // the reference positions :23231 can accept for the chunk's positions, per guide anchor / segment between two anchors / head / tail
+                {
+                    auto push = [&](long long lo, long long hi) {
+                        if (lo < 0) lo = 0;
+                        if (hi < lo) return;
+                        if (hi - lo >= (1LL << 28) - 1) { s_fail = 1; return; }
+                        const int o = atomicAdd(&s_nit, 1);
+                        if (o < VMX_LB_HCAP) s_hit[o] = ((uint64_t)lo << 28) | (uint64_t)(hi - lo + 1); else s_fail = 1;
+                        atomicMin(&s_hlo, (unsigned long long)lo); atomicMax(&s_hhi, (unsigned long long)hi);
+                    };
+                    // positions whose closest anchors are (ref1, ref2), interval <= iv, |read gap to ref1| in [da, db]
+                    auto item = [&](long long ref1, long long ref2, long long iv, long long da, long long db) {
+                        const long long l1 = ref1 - iv, h1 = ref1 + iv, l2 = ref2 - iv, h2 = ref2 + iv;
+                        const long long l3 = ref1 + da - 499, h3 = ref1 + db + 499, l4 = ref1 - db - 499, h4 = ref1 - da + 499;
+                        long long lo = l1 < l2 ? l1 : l2; lo = lo < l4 ? lo : l4; lo = lo < l3 ? lo : l3;
+                        long long hi = h1 > h2 ? h1 : h2; hi = hi > h3 ? hi : h3; hi = hi > h4 ? hi : h4;
+                        if (hi - lo <= LB_HULL_ONE) push(lo, hi);
+                        else { push(l1, h1); push(l2, h2); push(l3, h3); push(l4, h4); }
+                    };
+                    for (int x = tid; x < ns; x += T) {
+                        const int gx = s_gq[x]; const long long rx = s_gr[x];
+                        if (gx >= q0 && gx < qb) item(rx, rx, 500, 0, 0);
+                        if (x >= 1) {
+                            const int gp = s_gq[x - 1];
+                            const int pa = gp + 1 > q0 ? gp + 1 : q0, pe = gx - 1 < qb - 1 ? gx - 1 : qb - 1;
+                            if (pa <= pe) { long long iv = (long long)(gx - gp) + 500; if (iv > 2000) iv = 2000; item(s_gr[x - 1], rx, iv, pa - gp, pe - gp); }
+                        }
+                        if (x == 0 && g_first) {
+                            const int pa = q0, pe = gx - 1 < qb - 1 ? gx - 1 : qb - 1;
+                            if (pa <= pe) { long long iv = 2LL * (gx - pa) + 500; if (iv > 2000) iv = 2000; item(rx, rx, iv, gx - pe, gx - pa); }
+                        }
+                        if (x == ns - 1 && g_last) {
+                            const int pa = gx + 1 > q0 ? gx + 1 : q0, pe = qb - 1;
+                            if (pa <= pe) { long long iv = 2LL * (pe - gx) + 500; if (iv > 2000) iv = 2000; item(rx, rx, iv, pa - gx, pe - gx); }
+                        }
+                    }
+                }
+                __syncthreads();
+                const int nit = s_nit < VMX_LB_HCAP ? s_nit : VMX_LB_HCAP;
+                const bool one_piece = nit > 0 && (long long)(s_hhi - s_hlo) <= (long long)qlen + 12288;
+                if (!one_piece && nit > 1) {
+                    int NI = 1; while (NI < nit) NI <<= 1;
+                    for (int i = nit + tid; i < NI; i += T) s_hit[i] = ~0ULL;
+                    __syncthreads();
+                    vmx_block_bitonic_passes(s_hit, NI);
+                }
+                if (tid == 0) {
+                    int np = 0, wv = 0; bool over = false;
+                    auto clip = [&](long long lo, long long hi) {            // [lo, hi) against the windows; pieces and windows both ascend
+                        while (wv < niv && s_iv[wv][1] <= lo) ++wv;
+                        for (int v = wv; v < niv && s_iv[v][0] < hi; ++v) {
+                            const long long a = lo > s_iv[v][0] ? lo : s_iv[v][0], b = hi < s_iv[v][1] ? hi : s_iv[v][1];
+                            if (a >= b) continue;
+                            if (np > 0 && a <= s_pc[np - 1][1]) { if (b > s_pc[np - 1][1]) s_pc[np - 1][1] = b; }
+                            else if (np < LB_PIECES) { s_pc[np][0] = a; s_pc[np][1] = b; ++np; }
+                            else over = true;
+                        }
+                    };
+                    if (one_piece) clip((long long)s_hlo, (long long)s_hhi + 1);
+                    else if (nit > 0) {
+                        long long clo = (long long)(s_hit[0] >> 28), chi = clo + (long long)(s_hit[0] & ((1ULL << 28) - 1));
+                        for (int i = 1; i < nit; ++i) {
+                            const long long lo = (long long)(s_hit[i] >> 28), hi = lo + (long long)(s_hit[i] & ((1ULL << 28) - 1));
+                            if (lo <= chi + LB_SLACK) { if (hi > chi) chi = hi; }
+                            else { clip(clo, chi); clo = lo; chi = hi; }
+                        }
+                        clip(clo, chi);
+                    }
+                    s_npc = np;
+                    if (over) s_fail = 1;
+                }
+                // ---------------------------------------------------------------- the chunk's 9-mers (both strands) in the LDS table
+                // (heads and entries lie below the interval list: disjoint)
+                for (int i = tid; i < LB_NB; i += T) s_head[i] = 0u;
+                __syncthreads();
+                const int npc = s_fail ? 0 : s_npc;
+                for (int i = tid; i < qlen; i += T) {
+                    const int p = q0 + i;
+                    bool ok; const uint32_t fw = vmx_kmer_at(RD, p, k, ok);
+                    const uint32_t rv = vmx_kmer_rc(fw, k);
+                    if (ok && fw != rv) {                                                // :23213
+                        uint32_t old = atomicExch(&s_head[fw & (LB_NB - 1)], (uint32_t)(2 * i + 1));
+                        s_ent[2 * i] = ((fw >> LB_NBLOG) << 13) | old;
+                        if (p > 0) {                                                     // rc_testseq[-(iloc + k): -iloc] is '' at iloc == 0 (:23212)
+                            old = atomicExch(&s_head[rv & (LB_NB - 1)], (uint32_t)(2 * i + 2));
+                            s_ent[2 * i + 1] = ((rv >> LB_NBLOG) << 13) | old;
+                        }
+                    }
+                }
+                __syncthreads();
+                // ---------------------------------------------------------------- stream the band through it
+                for (int pc = 0; pc < npc; ++pc) {
+                    const long long lo = s_pc[pc][0], hi = s_pc[pc][1];
+                    for (long long x0 = lo + 4LL * tid; x0 < hi; x0 += 4LL * T) {
+                        uint32_t km = 0; int nval = 0;
+                        for (int i = 0; i < k - 1; ++i) { const uint8_t c = A.ref[x0 + i]; nval = c > 3 ? 0 : nval + 1; km = (km << 2) | (uint32_t)(c & 3); }
+                        for (int j = 0; j < 4 && x0 + j < hi; ++j) {
+                            const uint8_t c = A.ref[x0 + j + k - 1]; nval = c > 3 ? 0 : nval + 1; km = ((km << 2) | (uint32_t)(c & 3)) & KMASK;
+                            if (nval < k) continue;
+                            const uint32_t chk = km >> LB_NBLOG;
+                            const long long x = x0 + j;
+                            for (uint32_t e = s_head[km & (LB_NB - 1)]; e != 0u;) {
+                                const uint32_t ent = s_ent[e - 1];
+                                if ((ent >> 13) == chk) {
+                                    const int i = (int)((e - 1) >> 1), sb = (int)((e - 1) & 1);
+                                    const int q = q0 + i;
+                                    const int sg = s_seg[i], c0 = sg >> 1, c1 = c0 + (sg & 1);
+                                    int b0 = s_gq[c0] - q; if (b0 < 0) b0 = -b0;
+                                    int b1 = s_gq[c1] - q; if (b1 < 0) b1 = -b1;
+                                    long long interval = (long long)b0 + b1 + 500; if (interval > 2000) interval = 2000;
+                                    if (vmx_local_accept(x, s_gr[c0], s_gr[c1], interval, (long long)b0)) {
+                                        const unsigned long long drel = (unsigned long long)(sb ? (x - wlo) + (q - readstart) : (x - wlo) + (readend - 1 - q));
+                                        const int o = atomicAdd(&s_nhit, 1);
+                                        if (o < VMX_LB_HCAP) s_hit[o] = (((((uint64_t)sb << dbits) | drel) << LB_QB) | (uint64_t)(unsigned)(q - readstart));
+                                    }
+                                }
+                                e = ent & 0x1fffu;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                const int nhit = s_nhit;
+                if (s_fail) { status = VM_READ_BANDFALL_DEV; break; }                     // (uniform: s_fail is read after a barrier)
+                if (nhit > VMX_LB_HCAP) {                                                 // more hits than the tile holds: the same positions in narrower chunks
+                    if (qc <= 16) { status = VM_READ_BANDFALL_DEV; break; }
+                    qc >>= 1;
+                    __syncthreads();
+                    continue;
+                }
+                VMX_T(1);
+                // ---------------------------------------------------------------- sort the hits by (strand, diagonal, read position)
+                int NH = 2; while (NH < nhit) NH <<= 1;
+                const bool sw = vmx_bitonic_fast_ok(NH);
+                for (int i = tid; i < NH; i += T) s_sort[sw ? vmx_sw(i) : i] = i < nhit ? s_hit[i] : ~0ULL;
+                __syncthreads();
+                if (sw) vmx_bitonic_tile_sw(s_sort, NH, 0, NH); else vmx_block_bitonic_passes(s_sort, NH);
+                VMX_T(2);
+                // ---------------------------------------------------------------- walk the runs (:23232-23344)
+                {
+                    const int nprev = s_nop[cur];
+                    auto KH = [&](int i) -> uint64_t { return s_sort[sw ? vmx_sw(i) : i]; };
+                    auto emit = [&](long long cq, long long cr, int cs, long long cl, uint64_t ek) {
+                        const int o = n_out + atomicAdd(&s_emit, 1);
+                        if (o < out_cap) { OUT[o] = vmx_mk_anchor(cq, cr, cs, cl); OKEY[o] = ek; }
+                    };
+                    auto logrec = [&](unsigned long long dk, int sq, int tail, uint64_t v0, int64_t v1) {
+                        const int o = atomicAdd(&s_nlog, 1);
+                        if ((int64_t)o < hit_cap && ((unsigned long long)o >> ilb) == 0ULL) {
+                            HKEY[o] = (((((uint64_t)dk << LB_SEQB) | (uint64_t)sq) << 1 | (uint64_t)tail) << ilb) | (uint64_t)o;
+                            LOGV0[o] = v0; LOGV1[o] = v1;
+                        } else s_fail = 1;
+                    };
+                    for (int j0 = tid; j0 < nhit; j0 += T) {
+                        const uint64_t kj = KH(j0); const unsigned long long dk = kj >> LB_QB;
+                        const int qj = readstart + (int)(kj & QM);
+                        bool prevD = false; int qprev = 0;
+                        if (j0 > 0) { const uint64_t kp = KH(j0 - 1); prevD = (kp >> LB_QB) == dk; qprev = readstart + (int)(kp & QM); }
+                        if (prevD && qj - qprev <= k) continue;                         // inside a run
+                        const int sb = (int)(dk >> dbits); const long long drel = (long long)(dk & DM);
+                        auto rof = [&](int q) -> long long { return sb ? wlo + drel - (q - readstart) : wlo + drel - (readend - 1 - q); };
+                        long long cq = 0, cr = 0, cl = 0; int prevq = 0, j = j0;
+                        bool cont = false;
+                        if (!prevD && qj < q0 + k) {                                    // may go on a run the previous chunk left open
+                            for (int e = 0; e < nprev; ++e)
+                                if (s_opd[cur][e] == dk && qj - s_opp[cur][e] <= k) {
+                                    cont = true; cq = s_opq[cur][e]; cr = s_opr[cur][e]; cl = s_opl[cur][e]; prevq = s_opp[cur][e]; s_opu[e] = 1; break;
+                                }
+                        }
+                        if (!cont) {
+                            const long long r0 = rof(qj);
+                            if (!prevD) logrec(dk, seq, 0, ekey_of(qj, sb, r0), 0);       // first hit of the diagonal in this chunk
+                            cq = qj; cr = r0; cl = k; prevq = qj; j = j0 + 1;
+                        }
+                        const int cs = sb ? -1 : 1;
+                        for (; j < nhit; ++j) {
+                            const uint64_t k2 = KH(j);
+                            if ((k2 >> LB_QB) != dk) break;
+                            const int q2 = readstart + (int)(k2 & QM);
+                            if (q2 - prevq > k) break;
+                            const long long refloc = rof(q2);
+                            const long long bouns = (long long)q2 - (cq + cl) + k;          // > 0 inside a run
+                            if (cl + bouns < 20) { if (sb) cr = refloc; cl += bouns; }
+                            else {
+                                emit(cq, cr, cs, cl, ekey_of(q2, sb, refloc));
+                                const long long nq = cq + cl;
+                                if (sb) cr = refloc; else cr = cr + cl;
+                                cq = nq; cl = bouns;
+                            }
+                            prevq = q2;
+                        }
+                        if (j < nhit && (KH(j) >> LB_QB) == dk) {                         // the next hit on the diagonal appends the leftover (:23248)
+                            const int q2 = readstart + (int)(KH(j) & QM);
+                            emit(cq, cr, cs, cl, ekey_of(q2, sb, rof(q2)));
+                        } else if (prevq + k >= qb && qb < qend) {                         // may go on in the next chunk
+                            const int o = atomicAdd(&s_nop[cur ^ 1], 1);
+                            if (o < LB_OPEN) { s_opd[cur ^ 1][o] = dk; s_opq[cur ^ 1][o] = (int)cq; s_opr[cur ^ 1][o] = cr; s_opl[cur ^ 1][o] = (int)cl; s_opp[cur ^ 1][o] = prevq; }
+                            else s_fail = 1;
+                        } else logrec(dk, seq, 1, ((uint64_t)(unsigned)cq << 32) | (uint64_t)(unsigned)cl, cr);
+                    }
+                    __syncthreads();
+                    // open runs of the previous chunk nobody went on with: pending leftovers of that chunk
+                    for (int e = tid; e < nprev; e += T)
+                        if (!s_opu[e]) logrec(s_opd[cur][e], seq - 1, 1, ((uint64_t)(unsigned)s_opq[cur][e] << 32) | (uint64_t)(unsigned)s_opl[cur][e], s_opr[cur][e]);
+                }
+                __syncthreads();
+                if (s_fail || s_nop[cur ^ 1] > LB_OPEN) { status = VM_READ_BANDFALL_DEV; break; }
+                cur ^= 1; q0 = qb; cj = cj_next; ++seq;
+                if (qc < VMX_LB_QC) qc <<= 1;
+                if (seq >= (1 << LB_SEQB) - 1) { status = VM_READ_BANDFALL_DEV; break; }
+                __syncthreads();
+                VMX_T(3);
+            }
+            __syncthreads();
+            // ---------------------------------------------------------------- resolve the log: who appends every pending leftover
+            {
+                const int nlog = status ? 0 : s_nlog;
+                int NL = 1; while (NL < nlog) NL <<= 1;
+                if (nlog > 0 && (int64_t)NL > hit_cap) status = VM_READ_BANDFALL_DEV;
+                const int nl = status ? 0 : nlog;
+                for (int i = nl + tid; i < (nl ? NL : 0); i += T) HKEY[i] = ~0ULL;
+                __syncthreads();
+                if (nl > 1) vmx_block_sort_u64_tiled(HKEY, NL, s_sort, VMX_SORT_LDS);
+                __syncthreads();
+                const unsigned long long IM = (1ULL << ilb) - 1ULL;
+                const int dsh = ilb + 1 + LB_SEQB;
+                for (int i = tid; i < nl; i += T) {
+                    const uint64_t key = HKEY[i];
+                    if (!((key >> ilb) & 1ULL)) continue;                                // HEAD
+                    const unsigned long long dk = key >> dsh;
+                    const int idx = (int)(key & IM);
+                    uint64_t ek;
+                    if (i + 1 < nl && (HKEY[i + 1] >> dsh) == dk) ek = LOGV0[HKEY[i + 1] & IM];      // the next group's first hit appends it
+                    else {                                                               // the diagonal's last: appended at the end, in first-appearance order (:23343)
+                        int f = i; while (f > 0 && (HKEY[f - 1] >> dsh) == dk) --f;
+                        ek = (1ULL << ekb) | LOGV0[HKEY[f] & IM];
+                    }
+                    const uint64_t v0 = LOGV0[idx];
+                    const int sb = (int)(dk >> dbits);
+                    const int o = n_out + atomicAdd(&s_emit, 1);
+                    if (o < out_cap) { OUT[o] = vmx_mk_anchor((long long)(v0 >> 32), LOGV1[idx], sb ? -1 : 1, (long long)(v0 & 0xffffffffULL)); OKEY[o] = ek; }
+                }
+                __syncthreads();
+            }
+            VMX_T(4);
+            // ---------------------------------------------------------------- the reference's append order inside this guide
+            {
+                const int ng_out = status ? 0 : s_emit;
+                if (n_out + ng_out > out_cap) status = VM_READ_CAPACITY_DEV;
+                const int ib = 64 - (ekb + 1);
+                int NG = 1; while (NG < ng_out) NG <<= 1;
+                if (!status && ng_out > 0 && ((int64_t)NG > hit_cap || ((unsigned long long)ng_out >> ib) != 0ULL)) status = VM_READ_BANDFALL_DEV;
+                const int no = status ? 0 : ng_out;
+                for (int i = tid; i < (no ? NG : 0); i += T) HKEY[i] = i < no ? ((OKEY[n_out + i] << ib) | (uint64_t)i) : ~0ULL;
+                __syncthreads();
+                if (no > 1) vmx_block_sort_u64_tiled(HKEY, NG, s_sort, VMX_SORT_LDS);
+                __syncthreads();
+                const unsigned long long IBM = (1ULL << ib) - 1ULL;
+                for (int e = tid; e < no; e += T) GOFF[n_out + e] = n_out + (int)(HKEY[e] & IBM);   // rank -> anchor index
+                __syncthreads();
+                n_out += no;
+            }
+        }
+        // --- the stable argsort by q + l (:28585; mode R sorts by read start)
+        {
+            long long NO = 1; while (NO < n_out) NO <<= 1;
+            if (status == 0 && n_out > 0 && NO > hit_cap) status = VM_READ_BANDFALL_DEV;
+            const long long no = status ? 0 : n_out;
+            const long long NP = no > 0 ? NO : 0;
+            for (long long e = tid; e < NP; e += T) {
+                uint64_t kk = ~0ULL;
+                if (e < no) { const vmx_anchor a = OUT[GOFF[e]]; kk = ((uint64_t)(uint32_t)(A.sort_by_start ? a.q : a.q + a.l) << 32) | (uint64_t)e; }
+                HKEY[e] = kk;
+            }
+            __syncthreads();
+            if (NP > 1) vmx_block_sort_u64_tiled(HKEY, (int)NP, s_sort, VMX_SORT_LDS);
+            __syncthreads();
+            for (long long x = tid; x < no; x += T) SORTED[x] = OUT[GOFF[(int)(HKEY[x] & 0xffffffffu)]];
+            __syncthreads();
+        }
+        VMX_T(5);
+        if (tid == 0) { A.la_cnt[r] = status ? 0 : n_out; A.status[r] = status; }
+        __syncthreads();
+    }
+}

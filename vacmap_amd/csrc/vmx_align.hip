@@ -194,7 +194,7 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     vm_batch_stats st; memset(&st, 0, sizeof st);
     st.n_reads = n; st.read_bases = total_bases;
     hipEvent_t* ev = c->ev; int nev = 0;
-    c->n_syncs = 0; c->kev_set = 0;
+    c->n_syncs = 0; c->n_bandfall = 0; c->kev_set = 0;
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));
     if (n == 0) { *recs = (vm_record*)malloc(sizeof(vm_record)); *cigar_blob = (char*)malloc(1); if (stats) *stats = st; return VM_OK; }
 
@@ -611,7 +611,7 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     for (int i = 1; i < nev && i < 16; ++i) { hipEventElapsedTime(&ms, ev[i - 1], ev[i]); st.ms_stage[i - 1] = ms; }
     if ((c->kev_set & 1) && hipEventElapsedTime(&ms, c->kev[0], c->kev[1]) == hipSuccess) st.ms_local_seed = ms;
     if ((c->kev_set & 2) && hipEventElapsedTime(&ms, c->kev[2], c->kev[3]) == hipSuccess) st.ms_cluster = ms;
-    st.n_host_syncs = c->n_syncs;
+    st.n_host_syncs = c->n_syncs; st.n_local_general = c->n_bandfall;
     for (int pass = 0; pass < 2; ++pass)
         for (int q = 0; q < c->n_gev[pass]; ++q) {
             hipEvent_t* ke = c->gev + 24 * pass + 3 * q;
@@ -749,7 +749,7 @@ int vm_align_batch(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t 
             tot.ms_total += st.ms_total; for (int i = 0; i < 16; ++i) tot.ms_stage[i] += st.ms_stage[i];
             tot.ms_gapfill_fill += st.ms_gapfill_fill; tot.ms_gapfill_trace += st.ms_gapfill_trace; tot.n_gapfill_launches += st.n_gapfill_launches;
             tot.n_ed_full += st.n_ed_full; tot.n_ed_tier2 += st.n_ed_tier2; tot.n_ed_tier1 += st.n_ed_tier1;
-            tot.n_dp_redo += st.n_dp_redo; tot.dp_redo_tb_bytes += st.dp_redo_tb_bytes; tot.ms_local_seed += st.ms_local_seed; tot.ms_cluster += st.ms_cluster; tot.n_host_syncs += st.n_host_syncs;
+            tot.n_dp_redo += st.n_dp_redo; tot.dp_redo_tb_bytes += st.dp_redo_tb_bytes; tot.ms_local_seed += st.ms_local_seed; tot.ms_cluster += st.ms_cluster; tot.n_host_syncs += st.n_host_syncs; tot.n_local_general += st.n_local_general;
         }
     }
     *recs = (vm_record*)malloc(sizeof(vm_record) * std::max<size_t>(all.size(), 1)); *cigar_blob = (char*)malloc(std::max<size_t>(blob.size(), 1));

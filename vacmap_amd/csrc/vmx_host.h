@@ -105,6 +105,7 @@ struct vm_ctx {
     int n_gev[2] = {0, 0};                        // chunks recorded by the last batch per pass
     hipEvent_t kev[4] = {nullptr, nullptr, nullptr, nullptr};   // around k_local_seed's main launch [0,1] and the clustering kernels [2,3] of the last batch
     int kev_set = 0;                              // bit 0: [0,1] recorded, bit 1: [2,3] recorded
+    int64_t n_bandfall = 0;                       // reads k_local_seed_band handed back to k_local_seed (reset per batch)
     int64_t n_syncs = 0;                          // host waits on this context's stream (reset per batch)
     double res_rec_per_read = 0.0, res_blob_per_base = 0.0;   // largest records per read / CIGAR bytes per base a batch of this context produced (result copy size guess)
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams for independent launches (LDS-bucketed kernels)

@@ -92,6 +92,17 @@ struct vmx_lseed_args {
     const int64_t* rd_off; const int64_t* rd_len; const int32_t* r_st; const int32_t* r_en;
 };
 
+// k_local_seed_band (k_local_band.hip): read positions per chunk, hits per chunk (LDS tile), guide anchors staged per chunk
+#ifdef VMX_EMU
+#define VMX_LB_QC 256               // emulator build: small chunks so that the CPU tests cross many chunk boundaries, cut chunks at the guide slice and overflow the hit tile
+#define VMX_LB_HCAP 512
+#define VMX_LB_GS 24
+#else
+#define VMX_LB_QC 2048
+#define VMX_LB_HCAP 4096
+#define VMX_LB_GS 256
+#endif
+#define VMX_LB_LDS_BYTES (8 * (4096 + VMX_LB_HCAP))
 #define VMX_ED_WAVES 16              // max waves per workgroup of k_edit_distance (passes pipelined across them) = carry ring depth
 #define VMX_ED_LONG 16384            // patterns longer than this (> 4 passes) go to the 16-wave launch
 #define VMX_EDB_HW 768               // k_ed_banded: half width of the band in rows

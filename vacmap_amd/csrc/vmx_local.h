@@ -11,6 +11,7 @@
 
 #define VM_READ_CAPACITY_DEV (-20)
 #define VM_READ_RAISED_DEV (-10)
+#define VM_READ_BANDFALL_DEV (-23)   // k_local_seed_band hands the read to the general kernel k_local_seed (internal: never returned by vm_align_batch)
 #define VMX_MAX_PATHS 64     // secondaries beyond this are ignored by the product (reported through status)
 
 // :23231 acceptance of a table hit at `refloc` given the two closest guide anchors

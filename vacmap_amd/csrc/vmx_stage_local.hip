@@ -13,6 +13,7 @@ using namespace vmx;
 __global__ void k_local_prep(const vmx_anchor* path_rows, const int32_t* path_len, const int32_t* n_paths, const int64_t* aoff, const double* gscore,
                              int n_reads, int mode, vmx_anchor* guide_rows, int32_t* guide_len, int32_t* n_guides_used, int32_t* n_guides_total);
 __global__ void k_local_seed(vmx_lseed_args A);
+__global__ void k_local_seed_band(vmx_lseed_args A);
 __global__ void k_chain_local_fast(const vmx_anchor* anchors, const int64_t* la_off, const int32_t* la_cnt, const int32_t* n_guides_total, int n_reads,
                                    const int64_t* roff, vmx_tables tab, const double* gapcost_list, double skip_exact, double skip_mm, int maxdiff, int maxgap,
                                    int mode, double* S_pool, int32_t* P_pool, int32_t* SA_pool, int32_t* si_pool, int64_t* t_pool, int32_t* cnt_pool,
@@ -58,6 +59,18 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     if (const char* e = getenv("VMX_LSEED_WGS")) { int v = atoi(e); if (v >= 1) occ = v; }                  // tuning knob: workgroups per CU
 #endif
     const int G = (int)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)c->num_cu * occ));
+    // the guide-banded form (k_local_band.hip) takes every read first; what it hands back (VM_READ_BANDFALL_DEV) runs through k_local_seed
+    static const bool band_on = [] { const char* e = getenv("VMX_LSEED_BAND"); return !e || atoi(e) != 0; }();
+    int occ_b = 2;
+#ifndef VMX_EMU
+    if (band_on) {
+        VMX_HIP(hipFuncSetAttribute((const void*)k_local_seed_band, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VMX_LB_LDS_BYTES));
+        VMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, (const void*)k_local_seed_band, TPB, VMX_LB_LDS_BYTES));
+        if (occ_b < 1) occ_b = 1;
+        if (const char* e = getenv("VMX_LSEED_BAND_WGS")) { int v = atoi(e); if (v >= 1) occ_b = v; }
+    }
+#endif
+    const int GB = (int)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)c->num_cu * occ_b));
     {
         std::vector<int32_t> ord((size_t)n + 1);
         for (int64_t r = 0; r < n; ++r) ord[(size_t)r + 1] = (int32_t)r;
@@ -75,10 +88,10 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     A.rd_off = nullptr; A.rd_len = nullptr; A.r_st = nullptr; A.r_en = nullptr;
     static const bool dbg_on = getenv("VMX_DBG") != nullptr;
     // one launch over the reads listed in L.rorder[1 .. cnt] with `slots` workgroups and per-slot hit pools of `hcap` entries
-    auto run_seed = [&](int cnt, int slots, int64_t hcap) -> int {
+    auto run_seed = [&](int cnt, int slots, int64_t hcap, bool band) -> int {
         const int64_t hit_cap = hcap;
         const int G = slots;
-        {   // head tables: entries are tagged with the slot's epoch (k_local_seed), so only fresh memory is filled (0xff = epoch 511, never current)
+        if (!band) {   // head tables: entries are tagged with the slot's epoch (k_local_seed), so only fresh memory is filled (0xff = epoch 511, never current)
             const size_t need = 4 * (size_t)G * (size_t)head_stride;
             const void* before = L.cnt.p; const size_t cap_before = L.cnt.cap;
             const void* ebefore = L.epoch.p;
@@ -87,12 +100,16 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
                 VMX_HIP(hipMemsetAsync(L.cnt.p, 0xff, L.cnt.cap, c->stream)); VMX_HIP(hipMemsetAsync(L.epoch.p, 0, L.epoch.cap, c->stream));
             }
         }
-        VMX_TRY(L.cur.reserve(4 * (size_t)G * (size_t)tpos_cap));
-        VMX_TRY(L.sq.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.dst.reserve(4 * (size_t)G * (size_t)hit_cap));
+        if (!band) {
+            VMX_TRY(L.cur.reserve(4 * (size_t)G * (size_t)tpos_cap));
+            VMX_TRY(L.sq.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.dst.reserve(4 * (size_t)G * (size_t)hit_cap));
+            VMX_TRY(L.pcnt.reserve(4 * (size_t)G * (size_t)pcnt_cap)); VMX_TRY(L.gq.reserve(4 * (size_t)G * (size_t)gkey_cap)); VMX_TRY(L.gr.reserve(8 * (size_t)G * (size_t)gkey_cap));
+            VMX_TRY(L.pc2.reserve(4 * (size_t)G * (size_t)pcnt_cap)); VMX_TRY(L.stg.reserve(16 * (size_t)G * (size_t)pcnt_cap));
+        }
         VMX_TRY(L.hkey.reserve(8 * (size_t)G * (size_t)hit_cap));
         VMX_TRY(L.hval.reserve(8 * (size_t)G * (size_t)hit_cap));
-        VMX_TRY(L.goff.reserve(4 * (size_t)G * (size_t)hit_cap)); VMX_TRY(L.pcnt.reserve(4 * (size_t)G * (size_t)pcnt_cap));
-        VMX_TRY(L.gkey.reserve(8 * (size_t)G * (size_t)gkey_cap)); VMX_TRY(L.gq.reserve(4 * (size_t)G * (size_t)gkey_cap)); VMX_TRY(L.gr.reserve(8 * (size_t)G * (size_t)gkey_cap));
+        VMX_TRY(L.goff.reserve(4 * (size_t)G * (size_t)hit_cap));
+        VMX_TRY(L.gkey.reserve(8 * (size_t)G * (size_t)gkey_cap));
         VMX_TRY(L.la_rows.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1))); VMX_TRY(L.la_ekey.reserve(8 * (size_t)(la_tot + 1)));
         VMX_TRY(L.la_sorted.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1)));
         VMX_TRY(upload(L.la_off, L.h_la_off.data(), (size_t)n + 1, c->stream));
@@ -108,7 +125,6 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         VMX_TRY(L.hkey2.reserve(8 * (size_t)G * (size_t)hit_cap));
         A.hkey2_pool = L.hkey2.as<uint64_t>();
         A.hkey_pool = L.hkey.as<uint64_t>(); A.hval_pool = L.hval.as<int64_t>(); A.goff_pool = L.goff.as<int32_t>(); A.hit_cap = hit_cap;
-        VMX_TRY(L.pc2.reserve(4 * (size_t)G * (size_t)pcnt_cap)); VMX_TRY(L.stg.reserve(16 * (size_t)G * (size_t)pcnt_cap));
         A.pc2_pool = L.pc2.as<int32_t>(); A.stg_pool = L.stg.as<int64_t>();
         A.pcnt_pool = L.pcnt.as<int32_t>(); A.pcnt_cap = pcnt_cap; A.gkey_pool = L.gkey.as<uint64_t>(); A.gq_pool = L.gq.as<int32_t>(); A.gr_pool = L.gr.as<int64_t>();
         A.gkey_cap = gkey_cap;
@@ -116,14 +132,16 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         A.la_cnt = L.la_cnt.as<int32_t>(); A.status = L.status.as<int32_t>();
         A.dbg = nullptr;
         if (dbg_on) { VMX_TRY(L.dbg.reserve(64)); VMX_HIP(hipMemsetAsync(L.dbg.p, 0, 64, c->stream)); A.dbg = L.dbg.as<unsigned long long>(); }
-        hipLaunchKernelGGL(k_local_seed, dim3((unsigned)G), dim3(TPB), 0, c->stream, A);
+        if (band) hipLaunchKernelGGL(k_local_seed_band, dim3((unsigned)G), dim3(TPB), VMX_LB_LDS_BYTES, c->stream, A);
+        else hipLaunchKernelGGL(k_local_seed, dim3((unsigned)G), dim3(TPB), 0, c->stream, A);
         if (dbg_on) { unsigned long long h[8]; VMX_TRY(download(h, L.dbg.p, 8, c->stream)); VMX_HIP(vmx_stream_sync(c));
-                      fprintf(stderr, "k_local_seed phase ticks (100MHz, summed over blocks): guide+windows %llu table %llu passA %llu passB+sort %llu merge %llu finalsort %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]); }
+                      fprintf(stderr, band ? "k_local_seed_band phase ticks (100MHz, summed over blocks): guide+windows %llu plan+join %llu hit sort %llu walk %llu log %llu emission+final sorts %llu\n"
+                                           : "k_local_seed phase ticks (100MHz, summed over blocks): guide+windows %llu table %llu passA %llu passB+sort %llu merge %llu finalsort %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]); }
         return 0;
     };
     A.la_slot_len = 1;
     (void)hipEventRecord(c->kev[0], c->stream);
-    VMX_TRY(run_seed((int)n, G, hit_cap));
+    VMX_TRY(run_seed((int)n, band_on ? GB : G, hit_cap, band_on));
     (void)hipEventRecord(c->kev[1], c->stream); c->kev_set |= 1;
     // sizing sync #2: local anchor counts decide the LDS bucket of every read in the local chain DP
     L.h_la_cnt.resize((size_t)n);
@@ -132,6 +150,22 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     VMX_TRY(download(h_lstatus.data(), L.status.p, (size_t)n, c->stream));
     VMX_HIP(vmx_stream_sync(c));
     VMX_HIP(hipGetLastError());
+    if (band_on) {   // reads the banded form handed back (hit tile / open-run list / key width exceeded): the general kernel, same slots
+        std::vector<int32_t> ord(1, 0);
+        for (int64_t r = 0; r < n; ++r) if (h_lstatus[r] == VM_READ_BANDFALL_DEV) ord.push_back((int32_t)r);
+        const int cnt = (int)ord.size() - 1;
+        c->n_bandfall += cnt;
+        if (getenv("VMX_LSEED_TRACE")) fprintf(stderr, "k_local_seed_band: %lld reads, %d handed to k_local_seed\n", (long long)n, cnt);
+        if (cnt) {
+            std::stable_sort(ord.begin() + 1, ord.end(), [&](int32_t a, int32_t b) { return h_roff[a + 1] - h_roff[a] > h_roff[b + 1] - h_roff[b]; });
+            VMX_TRY(upload(L.rorder, ord.data(), ord.size(), c->stream));
+            VMX_TRY(run_seed(cnt, std::min(cnt, G), hit_cap, false));
+            VMX_TRY(download(L.h_la_cnt.data(), L.la_cnt.p, (size_t)n, c->stream));
+            VMX_TRY(download(h_lstatus.data(), L.status.p, (size_t)n, c->stream));
+            VMX_HIP(vmx_stream_sync(c));
+            VMX_HIP(hipGetLastError());
+        }
+    }
     {   // capacity retries: 8x, 64x, 512x, 4096x the regular slot / hit pool, as long as the overflow area lasts
         int64_t ovf_used = 0;
         for (int round = 1; round <= 4; ++round) {
@@ -153,7 +187,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
             int64_t hcap = 1; while (hcap < mult * 4 * (lmax_f + 14000)) hcap <<= 1;
             if (hcap > ((int64_t)1 << 26)) hcap = (int64_t)1 << 26;          // stream indices are 26-bit
             A.la_slot_len = mult;                                            // slot length = mult * VMX_LA_SLOT(len) for the listed reads
-            VMX_TRY(run_seed(cnt, std::min(cnt, 8), hcap));
+            VMX_TRY(run_seed(cnt, std::min(cnt, 8), hcap, false));
             VMX_TRY(download(L.h_la_cnt.data(), L.la_cnt.p, (size_t)n, c->stream));
             VMX_TRY(download(h_lstatus.data(), L.status.p, (size_t)n, c->stream));
             VMX_HIP(vmx_stream_sync(c));
