@@ -24,6 +24,12 @@
 //   * the order in which the reference appended the anchors ("emission key": the (read position, strand, window index) of the hit that
 //     triggered the append, or FINAL | key of the diagonal's first hit) — restored by one sort per guide, then the stable argsort by
 //     q + l (:28585) as before.
+// Execution model: ONE WAVEFRONT per read (a 64-thread workgroup), as many as the LDS lets a CU hold. A chunk offers a few hundred to a
+// couple of thousand independent items at a time (positions to hash, band positions to probe, hits to sort, runs to walk) and the chunks of a
+// read depend on each other through the open runs, so a 512-thread workgroup per read spent its time in barriers and behind one-thread
+// sections (first form of this kernel: 6 ms per batch, 39 % plan + join, 22 % walk, 19 % guide + windows). A wave alone needs no barrier at
+// all (LDS operations of one wave execute in order), a serial step stalls only its own read, and the latency of the band's loads is hidden
+// by the other reads resident on the CU.
 // HBM traffic per read: the read and ~(1 + 4000 / LB_QC) x the window bases (L2 hits mostly), the log, the anchors and their two sorts.
 // Deviation D1: a 9-mer holding a non-ACGT base never matches.
 #define VMX_SORT_LOGR 3
@@ -32,34 +38,89 @@
 #include "vmx_local.h"
 #include "vmx_local_dev.h"
 
-#define LB_NBLOG 12
+#define LB_NBLOG VMX_LB_NBLOG
 #define LB_NB (1 << LB_NBLOG)       // bucket heads of the chunk table
-#define LB_OPEN 64                  // runs that may cross one chunk boundary
-#define LB_PIECES 32                // disjoint band intervals of a chunk (after clipping to the windows)
+#define LB_OPEN 32                  // runs that may cross one chunk boundary
+#define LB_PIECES 16                // disjoint band intervals of a chunk (after clipping to the windows)
+#define LB_WIN 32                   // reference windows of a guide
 #define LB_HULL_ONE 16384           // the <= 4 accept intervals of one guide segment are taken as their hull up to this many positions
 #define LB_SLACK 64                 // band intervals closer than this are streamed as one
 #define LB_QB 26                    // bits of a hit key that hold the read position (relative to the read window)
 #define LB_SEQB 13                  // bits of a log key that hold the chunk number
 
+static_assert(4 * ((1 << VMX_LB_NBLOG) + 2 * VMX_LB_QC + 512) <= 8 * VMX_LB_SORTK && VMX_LB_HCAP <= VMX_LB_SORTK && 2 * VMX_LB_QC < (1 << 13), "k_local_seed_band: LDS layout");
 __device__ __forceinline__ int vmx_bits_u64(unsigned long long v) { int b = 0; while (b < 64 && (v >> b)) ++b; return b; }
 
-__global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
-    VMX_DYN_SHARED(uint64_t, s_u);                 // 8 * (4096 + VMX_LB_HCAP) bytes
-    uint64_t* const s_sort = s_u;                  // [0, 32 KB): block sorts / the sorted hits of a chunk
-    uint32_t* const s_head = (uint32_t*)s_u;       // [0, 16 KB): bucket heads (entry index + 1, 0 = empty)
-    uint32_t* const s_ent = s_head + LB_NB;        // [16, 32 KB): entry 2 i + s of chunk position i, strand s: (k-mer >> 12) << 13 | next
-    uint64_t* const s_hit = s_u + 4096;            // [32 KB, ..): band intervals of the plan, then the chunk's hits
+// k-mers of the 8 consecutive positions x .. x + 7 of a 1-byte-per-base code array (any alignment; the arrays are padded by 64 bytes):
+// km[j] = the k-mer starting at x + j, bit j of the returned mask = it holds no ambiguous base. Two 8-byte loads (three for k > 9).
+__device__ __forceinline__ unsigned vmx_kmers8_w(uint64_t w0, uint64_t w1, uint64_t w2, int k, uint32_t KMASK, uint32_t km[8]) {
+    uint32_t v = 0; int nval = 0; unsigned ok = 0;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+        if (i >= 7 + k) break;
+        const uint32_t c = (uint32_t)((i < 8 ? w0 >> (8 * i) : (i < 16 ? w1 >> (8 * (i - 8)) : w2 >> (8 * (i - 16)))) & 0xffu);
+        nval = c > 3u ? 0 : nval + 1;
+        v = ((v << 2) | (c & 3u)) & KMASK;
+        const int j = i - (k - 1);
+        if (j >= 0 && j < 8) { km[j] = v; if (nval >= k) ok |= 1u << j; }
+    }
+    return ok;
+}
+__device__ __forceinline__ unsigned vmx_kmers8(const uint8_t* base, int k, uint32_t KMASK, uint32_t km[8]) {
+    uint64_t w0, w1, w2 = 0;
+    __builtin_memcpy(&w0, base, 8); __builtin_memcpy(&w1, base + 8, 8);
+    if (k > 9) __builtin_memcpy(&w2, base + 16, 8);
+    return vmx_kmers8_w(w0, w1, w2, k, KMASK, km);
+}
+
+// reverse complement of a k-mer in 2-bit codes: complement, reverse the bits, swap the two bits of every base, drop the low 32 - 2 k bits
+__device__ __forceinline__ uint32_t vmx_kmer_rc_fast(uint32_t fw, int k) {
+#ifdef VMX_EMU
+    uint32_t x = ~fw, r = 0; for (int i = 0; i < 32; ++i) { r = (r << 1) | (x & 1u); x >>= 1; }
+#else
+    uint32_t r = __brev(~fw);
+#endif
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+    return r >> (32 - 2 * k);
+}
+// the block sorts of vmx_device.h unroll their compare-exchange networks: called from five places they made 82 KB of code (the
+// instruction cache shared by two CUs holds 64 KB, and nine wavefronts per CU sit in different phases). One copy each.
+// (they take the LDS buffers from the kernel's dynamic shared array themselves: a pointer PASSED to a function that is not inlined is a generic
+// pointer, and every access through it a flat_load / flat_store — measured 3.7x on the hit sort)
+__device__ __attribute__((noinline)) int lb_sort_hbm(uint64_t* g, int N) {
+    VMX_DYN_SHARED(uint64_t, s_u);
+    return vmx_block_sort_u64_tiled(g, N, s_u, VMX_LB_SORTK);
+}
+__device__ __forceinline__ bool lb_sort_hits(int n) {      // s_hit[0 .. n) -> sort region, sorted; true: swizzled order
+    VMX_DYN_SHARED(uint64_t, s_u);
+    uint64_t* const lds = s_u; const uint64_t* const src = s_u + VMX_LB_SORTK;
+    const int T = (int)blockDim.x, tid = (int)threadIdx.x;
+    int NH = 2; while (NH < n) NH <<= 1;
+    const bool sw = vmx_bitonic_fast_ok(NH);
+    for (int i = tid; i < NH; i += T) lds[sw ? vmx_sw(i) : i] = i < n ? src[i] : ~0ULL;
+    __syncthreads();
+    if (sw) vmx_bitonic_tile_sw(lds, NH, 0, NH); else vmx_block_bitonic_passes(lds, NH);
+    return sw;
+}
+
+__global__ void __launch_bounds__(64) k_local_seed_band(vmx_lseed_args A) {
+    VMX_DYN_SHARED(uint64_t, s_u);                 // VMX_LB_LDS_BYTES
+    uint64_t* const s_sort = s_u;                  // [0, 8 VMX_LB_SORTK): sorts / the sorted hits of a chunk
+    uint32_t* const s_head = (uint32_t*)s_u;       // LB_NB bucket heads (entry index + 1, 0 = empty) ...
+    uint32_t* const s_ent = s_head + LB_NB;        // ... the entries: 2 i + s of chunk position i, strand s: (k-mer >> LB_NBLOG) << 13 | next ...
+    uint32_t* const s_bm = s_ent + 2 * VMX_LB_QC;  // ... and a 2^14-bit occupancy map of the chunk's k-mers (their low 14 bits): together <= the sort region
+    uint64_t* const s_hit = s_u + VMX_LB_SORTK;    // band intervals of the plan, then the chunk's hits
+    uint32_t* const s_cq = (uint32_t*)(s_hit + VMX_LB_HCAP);   // candidates of one sweep over the band: (lane * 8 + j) << 22 | k-mer
     __shared__ int s_gq[VMX_LB_GS];
     __shared__ long long s_gr[VMX_LB_GS];
     __shared__ unsigned short s_seg[VMX_LB_QC];
-    __shared__ long long s_iv[64][2];
-    __shared__ int s_ivbase[65];
+    __shared__ long long s_iv[LB_WIN][2];
+    __shared__ int s_ivbase[LB_WIN + 1];
     __shared__ long long s_pc[LB_PIECES][2];
     __shared__ unsigned long long s_opd[2][LB_OPEN];
     __shared__ long long s_opr[2][LB_OPEN];
     __shared__ int s_opq[2][LB_OPEN], s_opp[2][LB_OPEN], s_opl[2][LB_OPEN], s_opu[LB_OPEN];
     __shared__ int s_nop[2];
-    __shared__ int s_scan[20];
     __shared__ int s_niv, s_flag, s_next, s_fail, s_cnt, s_nit, s_npc, s_nhit, s_nlog, s_emit;
     __shared__ unsigned long long s_hlo, s_hhi;
     const int T = (int)blockDim.x, tid = (int)threadIdx.x;
@@ -89,7 +150,7 @@ __global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
         vmx_anchor* SORTED = A.la_sorted + A.la_off[r];
         const int out_cap = A.rd_off ? (int)(A.la_off[r + 1] - A.la_off[r]) : (int)(A.la_slot_len * VMX_LA_SLOT((int64_t)L));
         int n_out = 0;
-        int status = 0;
+        int status = 0, why = 0;                  // why: what made the kernel hand the read back (VMX_LSEED_TRACE), 0 = nothing
         int gbase = 0;
         for (int g = 0; g < ng; ++g) {
             // (as in k_local_seed: a failed guide sets `status`, every later phase runs on empty ranges and all waves meet every barrier)
@@ -97,7 +158,7 @@ __global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
             const int m = A.guide_len[a0 + g];
             gbase += m;
             int N = 1; while (N < m) N <<= 1;
-            if (N > A.gkey_cap) status = VM_READ_BANDFALL_DEV;
+            if (N > A.gkey_cap) { status = VM_READ_BANDFALL_DEV; why = 1; }
             const int mm = status ? 0 : m;
             // --- :23095-23102 readgap
             int rg = 0;
@@ -114,7 +175,7 @@ __global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
             for (int i = tid; i < NN; i += T) GKEY[i] = i < m ? (((uint64_t)G[i].r << 24) | (uint64_t)i) : ~0ULL;
             __syncthreads();
             int gk_lds = 0;
-            if (NN > 1) gk_lds = vmx_block_sort_u64_tiled(GKEY, NN, s_sort, VMX_SORT_LDS);
+            if (NN > 1) gk_lds = lb_sort_hbm(GKEY, NN);
             // --- windows (serial, thread 0): :23105-23180 — disjoint intervals of k-mer starts [lo, hi) in global reference coordinates
             if (tid == 0) {
                 auto GK = [&](int i) -> uint64_t { return gk_lds == 2 ? s_sort[vmx_sw(i)] : (gk_lds == 1 ? s_sort[i] : GKEY[i]); };
@@ -143,7 +204,7 @@ __global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
                                 if (nk > 0) {
                                     long long a = cst + lo, b = a + nk;
                                     if (niv > 0 && a <= s_iv[niv - 1][1]) { if (b > s_iv[niv - 1][1]) s_iv[niv - 1][1] = b; }     // (touching intervals are one: a run may cross)
-                                    else if (niv < 64) { s_iv[niv][0] = a; s_iv[niv][1] = b; ++niv; }
+                                    else if (niv < LB_WIN) { s_iv[niv][0] = a; s_iv[niv][1] = b; ++niv; }
                                     else overflow = true;
                                 }
                             }
@@ -159,7 +220,7 @@ __global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
                 s_niv = niv; s_flag = overflow ? 1 : 0;
             }
             __syncthreads();
-            if (s_flag) status = VM_READ_BANDFALL_DEV;
+            if (s_flag) { status = VM_READ_BANDFALL_DEV; why = 2; }
             const int niv = status ? 0 : s_niv;
             // the window index of a reference position inside the windows (ascends with the position)
             auto t_of = [&](long long x) -> long long { int v = 0; while (v + 1 < niv && x >= s_iv[v + 1][0]) ++v; return (long long)s_ivbase[v] + (x - s_iv[v][0]); };
@@ -178,7 +239,7 @@ __global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
             const int tb = vmx_bits_u64((unsigned long long)s_ivbase[niv > 0 ? niv : 0]), pb = vmx_bits_u64((unsigned long long)npos);
             const int ilb = 64 - (1 + dbits + LB_SEQB + 1);
             const int ekb = pb + tb + 1;                                    // bit of the FINAL flag
-            if (npos > 0 && (npos >= (1 << LB_QB) || 1 + dbits + LB_QB > 63 || ilb < 14 || ekb + 1 > 50)) { status = VM_READ_BANDFALL_DEV; npos = 0; }
+            if (npos > 0 && (npos >= (1 << LB_QB) || 1 + dbits + LB_QB > 63 || ilb < 14 || ekb + 1 > 50)) { status = VM_READ_BANDFALL_DEV; why = 3; npos = 0; }
             const unsigned long long DM = dbits >= 64 ? ~0ULL : ((1ULL << dbits) - 1ULL);
             const unsigned long long QM = (1ULL << LB_QB) - 1ULL;
             auto ekey_of = [&](int q, int sb, long long x) -> uint64_t { return ((uint64_t)(unsigned)(q - readstart) << (tb + 1)) | ((uint64_t)sb << tb) | (uint64_t)t_of(x); };
@@ -220,25 +281,28 @@ __global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
                 const int qlen = qb - q0;
                 const bool g_first = js == 0, g_last = js + ns == mm;
                 // closest guide anchors of every chunk position (findClosest_1 :17560 on the slice: same answer, the read positions are distinct)
-                for (int i = tid; i < qlen; i += T) {
-                    const int p = q0 + i;
+                for (int i0 = 8 * tid; i0 < qlen; i0 += 8 * T) {                          // eight consecutive positions per lane: one bisection, then the slice is walked
                     int lo = 0, hi = ns;
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_gq[mid] <= p) lo = mid + 1; else hi = mid; }
-                    int c0, c1;
-                    if (lo > 0 && s_gq[lo - 1] == p) c0 = c1 = lo - 1;
-                    else if (lo == 0) c0 = c1 = 0;
-                    else if (lo == ns) c0 = c1 = ns - 1;
-                    else { c0 = lo - 1; c1 = lo; }
-                    s_seg[i] = (unsigned short)((c0 << 1) | (c1 != c0 ? 1 : 0));
+                    { const int p = q0 + i0; while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_gq[mid] <= p) lo = mid + 1; else hi = mid; } }
+                    for (int j = 0; j < 8 && i0 + j < qlen; ++j) {
+                        const int p = q0 + i0 + j;
+                        while (lo < ns && s_gq[lo] <= p) ++lo;                         // first staged anchor beyond p
+                        int c0, c1;
+                        if (lo > 0 && s_gq[lo - 1] == p) c0 = c1 = lo - 1;
+                        else if (lo == 0) c0 = c1 = 0;
+                        else if (lo == ns) c0 = c1 = ns - 1;
+                        else { c0 = lo - 1; c1 = lo; }
+                        s_seg[i0 + j] = (unsigned short)((c0 << 1) | (c1 != c0 ? 1 : 0));
+                    }
                 }
                 // the reference positions :23231 can accept for the chunk's positions, per guide anchor / segment between two anchors / head / tail
                 {
                     auto push = [&](long long lo, long long hi) {
                         if (lo < 0) lo = 0;
                         if (hi < lo) return;
-                        if (hi - lo >= (1LL << 28) - 1) { s_fail = 1; return; }
+                        if (hi - lo >= (1LL << 28) - 1) { s_fail = 4; return; }
                         const int o = atomicAdd(&s_nit, 1);
-                        if (o < VMX_LB_HCAP) s_hit[o] = ((uint64_t)lo << 28) | (uint64_t)(hi - lo + 1); else s_fail = 1;
+                        if (o < VMX_LB_HCAP) s_hit[o] = ((uint64_t)lo << 28) | (uint64_t)(hi - lo + 1); else s_fail = 4;
                         atomicMin(&s_hlo, (unsigned long long)lo); atomicMax(&s_hhi, (unsigned long long)hi);
                     };
                     // positions whose closest anchors are (ref1, ref2), interval <= iv, |read gap to ref1| in [da, db]
@@ -269,6 +333,7 @@ __global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
                     }
                 }
                 __syncthreads();
+                VMX_T(6);
                 const int nit = s_nit < VMX_LB_HCAP ? s_nit : VMX_LB_HCAP;
                 const bool one_piece = nit > 0 && (long long)(s_hhi - s_hlo) <= (long long)qlen + 12288;
                 if (!one_piece && nit > 1) {
@@ -300,38 +365,72 @@ __global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
                         clip(clo, chi);
                     }
                     s_npc = np;
-                    if (over) s_fail = 1;
+                    if (over) s_fail = 5;
                 }
                 // ---------------------------------------------------------------- the chunk's 9-mers (both strands) in the LDS table
                 // (heads and entries lie below the interval list: disjoint)
                 for (int i = tid; i < LB_NB; i += T) s_head[i] = 0u;
+                for (int i = tid; i < 512; i += T) s_bm[i] = 0u;
                 __syncthreads();
                 const int npc = s_fail ? 0 : s_npc;
-                for (int i = tid; i < qlen; i += T) {
-                    const int p = q0 + i;
-                    bool ok; const uint32_t fw = vmx_kmer_at(RD, p, k, ok);
-                    const uint32_t rv = vmx_kmer_rc(fw, k);
-                    if (ok && fw != rv) {                                                // :23213
-                        uint32_t old = atomicExch(&s_head[fw & (LB_NB - 1)], (uint32_t)(2 * i + 1));
-                        s_ent[2 * i] = ((fw >> LB_NBLOG) << 13) | old;
-                        if (p > 0) {                                                     // rc_testseq[-(iloc + k): -iloc] is '' at iloc == 0 (:23212)
-                            old = atomicExch(&s_head[rv & (LB_NB - 1)], (uint32_t)(2 * i + 2));
-                            s_ent[2 * i + 1] = ((rv >> LB_NBLOG) << 13) | old;
+                VMX_T(7);
+                for (int i0 = 8 * tid; i0 < qlen; i0 += 8 * T) {                          // eight consecutive positions per lane: two 8-byte loads
+                    uint32_t km[8]; const unsigned okm = vmx_kmers8(RD + q0 + i0, k, KMASK, km);
+                    uint32_t rvs[8], of[8], orv[8]; unsigned use = 0, user = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        rvs[j] = vmx_kmer_rc_fast(km[j], k);
+                        if (i0 + j < qlen && ((okm >> j) & 1u) && km[j] != rvs[j]) {         // :23213
+                            use |= 1u << j;
+                            if (q0 + i0 + j > 0) user |= 1u << j;                        // rc_testseq[-(iloc + k): -iloc] is '' at iloc == 0 (:23212)
                         }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {                                        // all exchanges in flight together, the links afterwards
+                        if ((use >> j) & 1u) { of[j] = atomicExch(&s_head[km[j] & (LB_NB - 1)], (uint32_t)(2 * (i0 + j) + 1)); atomicOr(&s_bm[(km[j] & 0x3fffu) >> 5], 1u << (km[j] & 31u)); }
+                        if ((user >> j) & 1u) { orv[j] = atomicExch(&s_head[rvs[j] & (LB_NB - 1)], (uint32_t)(2 * (i0 + j) + 2)); atomicOr(&s_bm[(rvs[j] & 0x3fffu) >> 5], 1u << (rvs[j] & 31u)); }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if ((use >> j) & 1u) s_ent[2 * (i0 + j)] = ((km[j] >> LB_NBLOG) << 13) | of[j];
+                        if ((user >> j) & 1u) s_ent[2 * (i0 + j) + 1] = ((rvs[j] >> LB_NBLOG) << 13) | orv[j];
                     }
                 }
                 __syncthreads();
+                VMX_T(8);
                 // ---------------------------------------------------------------- stream the band through it
+                if (A.dbg && tid == 0) { long long bl = 0; for (int pc = 0; pc < npc; ++pc) bl += s_pc[pc][1] - s_pc[pc][0]; atomicAdd(&A.dbg[9], (unsigned long long)bl); atomicAdd(&A.dbg[10], 1ULL); atomicAdd(&A.dbg[12], (unsigned long long)qlen); }
+                // Sweep = 512 band positions, eight per lane: (1) every lane rolls its k-mers and tests the occupancy map — no divergence, the
+                // passing (position, k-mer) pairs are packed into a queue with a ballot; (2) the queue is drained one candidate per lane: bucket
+                // list, exact k-mer check, the filter of :23231. (As one loop per position the list walks of 64 lanes ran in lockstep behind the
+                // longest of them: 60 us per chunk.)
                 for (int pc = 0; pc < npc; ++pc) {
                     const long long lo = s_pc[pc][0], hi = s_pc[pc][1];
-                    for (long long x0 = lo + 4LL * tid; x0 < hi; x0 += 4LL * T) {
-                        uint32_t km = 0; int nval = 0;
-                        for (int i = 0; i < k - 1; ++i) { const uint8_t c = A.ref[x0 + i]; nval = c > 3 ? 0 : nval + 1; km = (km << 2) | (uint32_t)(c & 3); }
-                        for (int j = 0; j < 4 && x0 + j < hi; ++j) {
-                            const uint8_t c = A.ref[x0 + j + k - 1]; nval = c > 3 ? 0 : nval + 1; km = ((km << 2) | (uint32_t)(c & 3)) & KMASK;
-                            if (nval < k) continue;
+                    uint64_t wn0 = 0, wn1 = 0;                                           // the next sweep's bases are on their way while this one is probed
+                    if (lo + 8LL * tid < hi) { __builtin_memcpy(&wn0, A.ref + lo + 8LL * tid, 8); __builtin_memcpy(&wn1, A.ref + lo + 8LL * tid + 8, 8); }
+                    for (long long xs = lo; xs < hi; xs += 8LL * T) {
+                        const long long x0 = xs + 8LL * tid;
+                        int ncq = 0;
+                        {
+                            uint32_t kms[8]; unsigned okm = 0;
+                            const uint64_t w0 = wn0, w1 = wn1; uint64_t w2 = 0;
+                            if (x0 + 8LL * T < hi) { __builtin_memcpy(&wn0, A.ref + x0 + 8LL * T, 8); __builtin_memcpy(&wn1, A.ref + x0 + 8LL * T + 8, 8); }
+                            if (x0 < hi) { if (k > 9) __builtin_memcpy(&w2, A.ref + x0 + 16, 8); okm = vmx_kmers8_w(w0, w1, w2, k, KMASK, kms); }
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                bool pass = x0 + j < hi && ((okm >> j) & 1u);
+                                if (pass) pass = (s_bm[(kms[j] & 0x3fffu) >> 5] >> (kms[j] & 31u)) & 1u;
+                                const unsigned long long bal = __ballot(pass);
+                                if (pass) s_cq[ncq + __popcll(bal & ((1ULL << vmx_lane()) - 1ULL))] = ((uint32_t)(8 * tid + j) << 22) | kms[j];
+                                ncq += __popcll(bal);
+                            }
+                        }
+                        __syncthreads();
+                        for (int c = tid; c < ncq; c += T) {
+                            const uint32_t cw = s_cq[c];
+                            const uint32_t km = cw & 0x3fffffu;
+                            const long long x = xs + (long long)(cw >> 22);
                             const uint32_t chk = km >> LB_NBLOG;
-                            const long long x = x0 + j;
                             for (uint32_t e = s_head[km & (LB_NB - 1)]; e != 0u;) {
                                 const uint32_t ent = s_ent[e - 1];
                                 if ((ent >> 13) == chk) {
@@ -350,24 +449,22 @@ __global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
                                 e = ent & 0x1fffu;
                             }
                         }
+                        __syncthreads();
                     }
                 }
                 __syncthreads();
                 const int nhit = s_nhit;
-                if (s_fail) { status = VM_READ_BANDFALL_DEV; break; }                     // (uniform: s_fail is read after a barrier)
+                if (A.dbg && tid == 0) atomicAdd(&A.dbg[11], (unsigned long long)nhit);
+                if (s_fail) { status = VM_READ_BANDFALL_DEV; why = s_fail; break; }        // (uniform: s_fail is read after a barrier)
                 if (nhit > VMX_LB_HCAP) {                                                 // more hits than the tile holds: the same positions in narrower chunks
-                    if (qc <= 16) { status = VM_READ_BANDFALL_DEV; break; }
+                    if (qc <= 16) { status = VM_READ_BANDFALL_DEV; why = 6; break; }
                     qc >>= 1;
                     __syncthreads();
                     continue;
                 }
                 VMX_T(1);
                 // ---------------------------------------------------------------- sort the hits by (strand, diagonal, read position)
-                int NH = 2; while (NH < nhit) NH <<= 1;
-                const bool sw = vmx_bitonic_fast_ok(NH);
-                for (int i = tid; i < NH; i += T) s_sort[sw ? vmx_sw(i) : i] = i < nhit ? s_hit[i] : ~0ULL;
-                __syncthreads();
-                if (sw) vmx_bitonic_tile_sw(s_sort, NH, 0, NH); else vmx_block_bitonic_passes(s_sort, NH);
+                const bool sw = lb_sort_hits(nhit);
                 VMX_T(2);
                 // ---------------------------------------------------------------- walk the runs (:23232-23344)
                 {
@@ -382,7 +479,7 @@ __global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
                         if ((int64_t)o < hit_cap && ((unsigned long long)o >> ilb) == 0ULL) {
                             HKEY[o] = (((((uint64_t)dk << LB_SEQB) | (uint64_t)sq) << 1 | (uint64_t)tail) << ilb) | (uint64_t)o;
                             LOGV0[o] = v0; LOGV1[o] = v1;
-                        } else s_fail = 1;
+                        } else s_fail = 8;
                     };
                     for (int j0 = tid; j0 < nhit; j0 += T) {
                         const uint64_t kj = KH(j0); const unsigned long long dk = kj >> LB_QB;
@@ -428,7 +525,7 @@ __global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
                         } else if (prevq + k >= qb && qb < qend) {                         // may go on in the next chunk
                             const int o = atomicAdd(&s_nop[cur ^ 1], 1);
                             if (o < LB_OPEN) { s_opd[cur ^ 1][o] = dk; s_opq[cur ^ 1][o] = (int)cq; s_opr[cur ^ 1][o] = cr; s_opl[cur ^ 1][o] = (int)cl; s_opp[cur ^ 1][o] = prevq; }
-                            else s_fail = 1;
+                            else s_fail = 7;
                         } else logrec(dk, seq, 1, ((uint64_t)(unsigned)cq << 32) | (uint64_t)(unsigned)cl, cr);
                     }
                     __syncthreads();
@@ -437,10 +534,10 @@ __global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
                         if (!s_opu[e]) logrec(s_opd[cur][e], seq - 1, 1, ((uint64_t)(unsigned)s_opq[cur][e] << 32) | (uint64_t)(unsigned)s_opl[cur][e], s_opr[cur][e]);
                 }
                 __syncthreads();
-                if (s_fail || s_nop[cur ^ 1] > LB_OPEN) { status = VM_READ_BANDFALL_DEV; break; }
+                if (s_fail || s_nop[cur ^ 1] > LB_OPEN) { status = VM_READ_BANDFALL_DEV; why = s_fail ? s_fail : 7; break; }
                 cur ^= 1; q0 = qb; cj = cj_next; ++seq;
                 if (qc < VMX_LB_QC) qc <<= 1;
-                if (seq >= (1 << LB_SEQB) - 1) { status = VM_READ_BANDFALL_DEV; break; }
+                if (seq >= (1 << LB_SEQB) - 1) { status = VM_READ_BANDFALL_DEV; why = 9; break; }
                 __syncthreads();
                 VMX_T(3);
             }
@@ -449,11 +546,11 @@ __global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
             {
                 const int nlog = status ? 0 : s_nlog;
                 int NL = 1; while (NL < nlog) NL <<= 1;
-                if (nlog > 0 && (int64_t)NL > hit_cap) status = VM_READ_BANDFALL_DEV;
+                if (nlog > 0 && (int64_t)NL > hit_cap) { status = VM_READ_BANDFALL_DEV; why = 10; }
                 const int nl = status ? 0 : nlog;
                 for (int i = nl + tid; i < (nl ? NL : 0); i += T) HKEY[i] = ~0ULL;
                 __syncthreads();
-                if (nl > 1) vmx_block_sort_u64_tiled(HKEY, NL, s_sort, VMX_SORT_LDS);
+                if (nl > 1) lb_sort_hbm(HKEY, NL);
                 __syncthreads();
                 const unsigned long long IM = (1ULL << ilb) - 1ULL;
                 const int dsh = ilb + 1 + LB_SEQB;
@@ -482,11 +579,11 @@ __global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
                 if (n_out + ng_out > out_cap) status = VM_READ_CAPACITY_DEV;
                 const int ib = 64 - (ekb + 1);
                 int NG = 1; while (NG < ng_out) NG <<= 1;
-                if (!status && ng_out > 0 && ((int64_t)NG > hit_cap || ((unsigned long long)ng_out >> ib) != 0ULL)) status = VM_READ_BANDFALL_DEV;
+                if (!status && ng_out > 0 && ((int64_t)NG > hit_cap || ((unsigned long long)ng_out >> ib) != 0ULL)) { status = VM_READ_BANDFALL_DEV; why = 10; }
                 const int no = status ? 0 : ng_out;
                 for (int i = tid; i < (no ? NG : 0); i += T) HKEY[i] = i < no ? ((OKEY[n_out + i] << ib) | (uint64_t)i) : ~0ULL;
                 __syncthreads();
-                if (no > 1) vmx_block_sort_u64_tiled(HKEY, NG, s_sort, VMX_SORT_LDS);
+                if (no > 1) lb_sort_hbm(HKEY, NG);
                 __syncthreads();
                 const unsigned long long IBM = (1ULL << ib) - 1ULL;
                 for (int e = tid; e < no; e += T) GOFF[n_out + e] = n_out + (int)(HKEY[e] & IBM);   // rank -> anchor index
@@ -497,7 +594,7 @@ __global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
         // --- the stable argsort by q + l (:28585; mode R sorts by read start)
         {
             long long NO = 1; while (NO < n_out) NO <<= 1;
-            if (status == 0 && n_out > 0 && NO > hit_cap) status = VM_READ_BANDFALL_DEV;
+            if (status == 0 && n_out > 0 && NO > hit_cap) { status = VM_READ_BANDFALL_DEV; why = 10; }
             const long long no = status ? 0 : n_out;
             const long long NP = no > 0 ? NO : 0;
             for (long long e = tid; e < NP; e += T) {
@@ -506,13 +603,13 @@ __global__ void __launch_bounds__(512, 4) k_local_seed_band(vmx_lseed_args A) {
                 HKEY[e] = kk;
             }
             __syncthreads();
-            if (NP > 1) vmx_block_sort_u64_tiled(HKEY, (int)NP, s_sort, VMX_SORT_LDS);
+            if (NP > 1) lb_sort_hbm(HKEY, (int)NP);
             __syncthreads();
             for (long long x = tid; x < no; x += T) SORTED[x] = OUT[GOFF[(int)(HKEY[x] & 0xffffffffu)]];
             __syncthreads();
         }
         VMX_T(5);
-        if (tid == 0) { A.la_cnt[r] = status ? 0 : n_out; A.status[r] = status; }
+        if (tid == 0) { A.la_cnt[r] = status ? -why : n_out; A.status[r] = status; }
         __syncthreads();
     }
 }

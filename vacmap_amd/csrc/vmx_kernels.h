@@ -92,17 +92,23 @@ struct vmx_lseed_args {
     const int64_t* rd_off; const int64_t* rd_len; const int32_t* r_st; const int32_t* r_en;
 };
 
-// k_local_seed_band (k_local_band.hip): read positions per chunk, hits per chunk (LDS tile), guide anchors staged per chunk
+// k_local_seed_band (k_local_band.hip), one wavefront per read: read positions per chunk, hits per chunk (LDS tile; also the capacity of the
+// plan's interval list), guide anchors staged per chunk, log2 of the chunk table's bucket heads, keys of the LDS sort region
+// (4 * (heads + 2 * QC + 512) <= 8 * SORTK and HCAP <= SORTK: the table with its occupancy map and the sorted hits live there in turn)
 #ifdef VMX_EMU
-#define VMX_LB_QC 256               // emulator build: small chunks so that the CPU tests cross many chunk boundaries, cut chunks at the guide slice and overflow the hit tile
-#define VMX_LB_HCAP 512
-#define VMX_LB_GS 24
+#define VMX_LB_QC 128               // emulator build: small chunks so that the CPU tests cross many chunk boundaries, cut chunks at the guide slice and overflow the hit tile
+#define VMX_LB_HCAP 256
+#define VMX_LB_GS 20
+#define VMX_LB_NBLOG 8
+#define VMX_LB_SORTK 512
 #else
-#define VMX_LB_QC 2048
-#define VMX_LB_HCAP 4096
-#define VMX_LB_GS 256
+#define VMX_LB_QC 512
+#define VMX_LB_HCAP 512
+#define VMX_LB_GS 64
+#define VMX_LB_NBLOG 9
+#define VMX_LB_SORTK 1024
 #endif
-#define VMX_LB_LDS_BYTES (8 * (4096 + VMX_LB_HCAP))
+#define VMX_LB_LDS_BYTES (8 * (VMX_LB_SORTK + VMX_LB_HCAP) + 4 * 512)     /* + the candidate queue of one sweep */
 #define VMX_ED_WAVES 16              // max waves per workgroup of k_edit_distance (passes pipelined across them) = carry ring depth
 #define VMX_ED_LONG 16384            // patterns longer than this (> 4 passes) go to the 16-wave launch
 #define VMX_EDB_HW 768               // k_ed_banded: half width of the band in rows

@@ -61,11 +61,11 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     const int G = (int)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)c->num_cu * occ));
     // the guide-banded form (k_local_band.hip) takes every read first; what it hands back (VM_READ_BANDFALL_DEV) runs through k_local_seed
     static const bool band_on = [] { const char* e = getenv("VMX_LSEED_BAND"); return !e || atoi(e) != 0; }();
-    int occ_b = 2;
+    int occ_b = 8;
 #ifndef VMX_EMU
     if (band_on) {
         VMX_HIP(hipFuncSetAttribute((const void*)k_local_seed_band, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VMX_LB_LDS_BYTES));
-        VMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, (const void*)k_local_seed_band, TPB, VMX_LB_LDS_BYTES));
+        VMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, (const void*)k_local_seed_band, 64, VMX_LB_LDS_BYTES));      // one wavefront per read: the LDS decides (~10 per CU)
         if (occ_b < 1) occ_b = 1;
         if (const char* e = getenv("VMX_LSEED_BAND_WGS")) { int v = atoi(e); if (v >= 1) occ_b = v; }
     }
@@ -131,17 +131,19 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         A.la_rows = L.la_rows.as<vmx_anchor>(); A.la_ekey = L.la_ekey.as<uint64_t>(); A.la_sorted = L.la_sorted.as<vmx_anchor>(); A.la_off = L.la_off.as<int64_t>();
         A.la_cnt = L.la_cnt.as<int32_t>(); A.status = L.status.as<int32_t>();
         A.dbg = nullptr;
-        if (dbg_on) { VMX_TRY(L.dbg.reserve(64)); VMX_HIP(hipMemsetAsync(L.dbg.p, 0, 64, c->stream)); A.dbg = L.dbg.as<unsigned long long>(); }
-        if (band) hipLaunchKernelGGL(k_local_seed_band, dim3((unsigned)G), dim3(TPB), VMX_LB_LDS_BYTES, c->stream, A);
+        if (dbg_on) { VMX_TRY(L.dbg.reserve(128)); VMX_HIP(hipMemsetAsync(L.dbg.p, 0, 128, c->stream)); A.dbg = L.dbg.as<unsigned long long>(); }
+        if (band) hipLaunchKernelGGL(k_local_seed_band, dim3((unsigned)G), dim3(64), VMX_LB_LDS_BYTES, c->stream, A);
         else hipLaunchKernelGGL(k_local_seed, dim3((unsigned)G), dim3(TPB), 0, c->stream, A);
-        if (dbg_on) { unsigned long long h[8]; VMX_TRY(download(h, L.dbg.p, 8, c->stream)); VMX_HIP(vmx_stream_sync(c));
-                      fprintf(stderr, band ? "k_local_seed_band phase ticks (100MHz, summed over blocks): guide+windows %llu plan+join %llu hit sort %llu walk %llu log %llu emission+final sorts %llu\n"
-                                           : "k_local_seed phase ticks (100MHz, summed over blocks): guide+windows %llu table %llu passA %llu passB+sort %llu merge %llu finalsort %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]); }
+        if (dbg_on) { unsigned long long h[16]; VMX_TRY(download(h, L.dbg.p, 16, c->stream)); VMX_HIP(vmx_stream_sync(c));
+                      fprintf(stderr, band ? "k_local_seed_band phase ticks (100MHz, summed over blocks): guide+windows %llu stream %llu hit sort %llu walk %llu log %llu emission+final sorts %llu | slice+closest+items %llu pieces %llu table %llu | band positions %llu chunks %llu hits %llu read positions %llu\n"
+                                           : "k_local_seed phase ticks (100MHz, summed over blocks): guide+windows %llu table %llu passA %llu passB+sort %llu merge %llu finalsort %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12]); }
         return 0;
     };
     A.la_slot_len = 1;
     (void)hipEventRecord(c->kev[0], c->stream);
-    VMX_TRY(run_seed((int)n, band_on ? GB : G, hit_cap, band_on));
+    // (the banded form keeps no hits in HBM: its per-slot pools hold the chunk log and the anchors' sort keys only)
+    int64_t hit_cap_b = 1; while (hit_cap_b < Lmax + 8192) hit_cap_b <<= 1;
+    VMX_TRY(run_seed((int)n, band_on ? GB : G, band_on ? hit_cap_b : hit_cap, band_on));
     (void)hipEventRecord(c->kev[1], c->stream); c->kev_set |= 1;
     // sizing sync #2: local anchor counts decide the LDS bucket of every read in the local chain DP
     L.h_la_cnt.resize((size_t)n);
@@ -155,7 +157,12 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         for (int64_t r = 0; r < n; ++r) if (h_lstatus[r] == VM_READ_BANDFALL_DEV) ord.push_back((int32_t)r);
         const int cnt = (int)ord.size() - 1;
         c->n_bandfall += cnt;
-        if (getenv("VMX_LSEED_TRACE")) fprintf(stderr, "k_local_seed_band: %lld reads, %d handed to k_local_seed\n", (long long)n, cnt);
+        if (getenv("VMX_LSEED_TRACE")) {
+            int why[12] = {0};
+            for (int i = 1; i <= cnt; ++i) { const int w = -L.h_la_cnt[ord[i]]; ++why[w >= 0 && w < 12 ? w : 11]; }
+            fprintf(stderr, "k_local_seed_band: %lld reads, %d handed to k_local_seed (guide sort %d, windows %d, key width %d, intervals %d, pieces %d, hit tile %d, open runs %d, log %d, chunks %d, sorts %d)\n",
+                    (long long)n, cnt, why[1], why[2], why[3], why[4], why[5], why[6], why[7], why[8], why[9], why[10]);
+        }
         if (cnt) {
             std::stable_sort(ord.begin() + 1, ord.end(), [&](int32_t a, int32_t b) { return h_roff[a + 1] - h_roff[a] > h_roff[b + 1] - h_roff[b]; });
             VMX_TRY(upload(L.rorder, ord.data(), ord.size(), c->stream));
