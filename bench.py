@@ -21,6 +21,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
+# single-GPU workloads of BASELINE.json `configs`: reference, read shape, mode, k
+CONFIGS = {
+    'ont_hg38': dict(ref_mb=0, shape='ont', mean_len=15000, err=0.10, min_len=1000, mode='H', k=15, tag='ont15k_hg38size_H_k15',
+                     what='the metric\'s configuration (configs[3] on one GPU): synthetic ONT reads (Gamma mean %d bp, %.1f%% err) vs hg38-size synthetic ref (24 contigs, hg38 proportions, 3.1 Gb, seed 3), -mode H -k 15 -w 10 -c 100'),
+    'ont_100mb': dict(ref_mb=100, shape='ont', mean_len=15000, err=0.10, min_len=1000, mode='H', k=15, tag='ont15k_ref100mb_H_k15',
+                      what='configs[1]: synthetic ONT reads (Gamma mean %d bp, %.1f%% err) vs 100 Mb synthetic ref (1 contig), -mode H -k 15 -w 10 -c 100'),
+    'hifi_hg38': dict(ref_mb=0, shape='hifi', mean_len=18000, err=0.005, min_len=5000, mode='L', k=19, tag='hifi18k_hg38size_L_k19',
+                      what='configs[2]: synthetic HiFi reads (Normal mean %d bp, sd 2000, %.1f%% err) vs hg38-size synthetic ref (24 contigs, 3.1 Gb, seed 3), -mode L -k 19 -w 10 -c 100'),
+}
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 METRIC = 'aligned Gbp/s (whole node) + reads/s, 15 kb ONT-shape reads vs hg38-size ref, 1/2/4/8 MI355X'      # BASELINE.json
 
@@ -54,12 +63,12 @@ def main():
     _keep_heap_pages()                          # the driver's allocator setting (freed result buffers are reused, not unmapped): VMX_DRIVER_MALLOPT=0 disables
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=12, help='timed batches (default 12; 25 = the 100k reads of configs[1]/[2])')
+    ap.add_argument('--steps', type=int, default=25, help='timed batches (default 25 x 4096 = the 100k reads of configs[1]/[2])')
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--reads-per-step', type=int, default=4096)
     ap.add_argument('--ref-mb', type=float, default=0.0, help='0 (default): hg38-size 3.1 Gb / 24 contigs; M > 0: one contig of M Mb (100 = BASELINE configs[1])')
-    ap.add_argument('--mean-len', type=int, default=15000)
-    ap.add_argument('--err', type=float, default=0.10)
+    ap.add_argument('--mean-len', type=int, default=0, help='0: the config\'s (15000 ONT, 18000 HiFi)')
+    ap.add_argument('--err', type=float, default=None, help='default: the config\'s (0.10 ONT, 0.005 HiFi)')
     ap.add_argument('--cpu-sample', type=int, default=96, help='minimum reads for the CPU baseline leg (rank 0, N=1 only); 0 disables')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='target wall time of the CPU baseline leg (the sample is sized by a pilot)')
     ap.add_argument('--streams', type=int, default=3, help='batches in flight per GPU (vacmap_amd.pipeline)')
@@ -67,23 +76,49 @@ def main():
     ap.add_argument('--arrival-order', action='store_true', help='no length binning: batches in arrival order (measured once for comparison)')
     ap.add_argument('--host-input', action='store_true', help='also time the same batches handed over as HOST buffers (vm_align_batch uploads them: the PCIe-inclusive rate; reported next to `value`, never as it)')
     ap.add_argument('--verify', type=int, default=64, help='reads of the first batch cross-checked against the oracle (0 disables)')
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='ont_hg38', help='BASELINE.json workload: ont_hg38 = the metric\'s configuration (default), '
+                    'ont_100mb = configs[1], hifi_hg38 = configs[2] (HiFi 18 kb, 0.5 %% error, -mode L -k 19)')
+    ap.add_argument('--extra-configs', default='ont_100mb,hifi_hg38', help='other single-GPU BASELINE configs timed in their own short runs of this script (N = 1 only) and '
+                    'reported under extra.configs next to the headline; "" disables')
+    ap.add_argument('--extra-steps', type=int, default=6)
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    if args.ref_mb > 0:                               # (kept: --ref-mb M = the ONT workload against one contig of M Mb)
+        cfg = dict(CONFIGS['ont_100mb']); cfg['ref_mb'] = args.ref_mb
+    mean_len = args.mean_len if args.mean_len else cfg['mean_len']
+    err = args.err if args.err is not None else cfg['err']
 
     rank = int(os.environ.get('RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1')); local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     from vacmap_amd import synth, pipeline
     t0 = time.time()
     cores = host_cores()
-    if args.ref_mb > 0:
-        names = ['chr1']; k = 15
-        contigs = synth.make_reference([int(args.ref_mb * 1e6)], seed=1)             # configs[1]: 1 contig x 100 Mb, seed 1
-        workload_id = 'ont15k_ref%dmb_H_k15' % int(args.ref_mb)
-        workload = 'configs[1]: synthetic ONT reads (Gamma mean %d bp, %.0f%% err) vs %.0f Mb synthetic ref (1 contig), -mode H -k 15 -w 10 -c 100' % (args.mean_len, args.err * 100, args.ref_mb)
+    k = cfg['k']
+    extra = None
+    if rank == 0 and world == 1 and args.extra_configs:
+        # the other single-GPU configs, each in its own process BEFORE this one takes the GPU (own reference, index and work pools)
+        import subprocess
+        extra = {'configs': []}
+        for name in [c for c in args.extra_configs.split(',') if c and c != args.config]:
+            cmd = [sys.executable, os.path.abspath(__file__), '--config', name, '--steps', str(args.extra_steps), '--cpu-sample', '0', '--verify', '16', '--extra-configs', '',
+                   '--streams', str(args.streams), '--reads-per-step', str(args.reads_per_step)]
+            try:
+                pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                d = json.loads(pr.stdout.decode().strip().splitlines()[-1])
+                extra['configs'].append({kk: d[kk] for kk in ('value', 'unit', 'ms_per_step', 'steps', 'reads_per_s', 'failed_reads', 'unmapped_reads', 'oracle_crosscheck', 'per_read', 'stage_ms_per_step',
+                                                              'hbm_used_gb', 'local_general_reads')} | {'config': name, 'workload': d['config']['workload'], 'dominant_kernel': d['roofline']['kernel'],
+                                                              'kernel_ms_per_step': {kn: e['ms_per_step'] for kn, e in d['roofline']['kernels'].items()}})
+            except Exception as e:                                                     # a failed side run is reported, never hidden
+                extra['configs'].append({'config': name, 'error': repr(e)[:300]})
+    if cfg['ref_mb'] > 0:
+        names = ['chr1']
+        contigs = synth.make_reference([int(cfg['ref_mb'] * 1e6)], seed=1)             # configs[1]: 1 contig x 100 Mb, seed 1
+        workload_id = cfg['tag'] if cfg['ref_mb'] == 100 else 'ont15k_ref%dmb_H_k15' % int(cfg['ref_mb'])
+        workload = (cfg['what'] % (mean_len, err * 100)).replace('100 Mb', '%.0f Mb' % cfg['ref_mb'])
     else:
-        names = list(synth.HG38_NAMES); k = 15
+        names = list(synth.HG38_NAMES)
         contigs = synth.make_reference_fast(synth.hg38_like_lengths(), seed=3, threads=max(1, cores // max(1, min(world, 8))))
-        workload_id = 'ont15k_hg38size_H_k15'
-        workload = ('the metric\'s configuration (configs[3] on one GPU): synthetic ONT reads (Gamma mean %d bp, %.0f%% err) vs hg38-size synthetic ref '
-                    '(24 contigs, hg38 proportions, 3.1 Gb, seed 3), -mode H -k 15 -w 10 -c 100' % (args.mean_len, args.err * 100))
+        workload_id = cfg['tag']
+        workload = cfg['what'] % (mean_len, err * 100)
     t_ref = time.time() - t0
 
     nsteps = args.steps
@@ -92,7 +127,7 @@ def main():
     pool_cat, pool_off = [], [0]
     for s in range(nsteps):
         seed = 1000 + 7919 * (s * world + rank)
-        cat, off, truth = synth.sample_reads_concat(contigs, args.reads_per_step, mean_len=args.mean_len, err=args.err, seed=seed)
+        cat, off, truth = synth.sample_reads_concat(contigs, args.reads_per_step, mean_len=mean_len, err=err, seed=seed, shape=cfg['shape'], min_len=cfg['min_len'])
         pool_cat.append(cat); pool_off.extend((off[1:] + pool_off[-1]).tolist())
     pool_cat = np.concatenate(pool_cat); pool_off = np.asarray(pool_off, dtype=np.int64)
     lens = np.diff(pool_off)
@@ -110,7 +145,7 @@ def main():
     from vacmap_amd.lib import Context, Index, load
     ctx = Context(local_rank)                 # raises without the HIP library / a GPU: no fallback
     lib = load()
-    prm = lib.params('H')
+    prm = lib.params(cfg['mode'])
 
     # index: built ON THE GPU by rank 0 only; the other ranks receive it over RCCL into their own HBM
     t1 = time.time()
@@ -144,7 +179,7 @@ def main():
             tq = time.time()
             oi = O.Index.from_seqs(names, contigs, k=k, w=10)
             t_oracle_index = time.time() - tq
-            op = O.params('H')
+            op = O.params(cfg['mode'])
             idx = plan[longest]
             nv = min(args.verify, len(idx)); ok = 0
             for j in np.linspace(0, len(idx) - 1, nv).astype(int):
@@ -247,7 +282,7 @@ def main():
                 tq = time.time()
                 oi = O.Index.from_seqs(names, contigs, k=k, w=10)
                 t_oracle_index = time.time() - tq
-            op = O.params('H')
+            op = O.params(cfg['mode'])
             order = np.argsort(lens, kind='stable')
 
             def cpu_leg(ns):       # ns reads evenly spaced over the length-sorted timed pool (same length mix as the timed workload)
@@ -289,8 +324,11 @@ def main():
             'dp_redo_per_step': agg.get('n_dp_redo', 0) / K, 'dp_redo_tb_bytes_per_step': agg.get('dp_redo_tb_bytes', 0) / K,
             'oracle_crosscheck': verified, 'setup_s': t_setup, 'reference_gen_s': t_ref, 'read_gen_s': t_reads, 'index_build_s': t_index, 'index_broadcast_s': t_bcast,
             'index_minimizers': int(n_minimizers), 'index_mid_occ': int(index.mid_occ), 'oracle_index_build_s': t_oracle_index, 'hbm_used_gb': hbm_used_gb,
+            'local_general_reads': int(agg.get('n_local_general', 0)),
             'roofline': roofline, 'cpu_baseline': cpu,
         }
+        if extra is not None:
+            out['extra'] = extra
         if host_rate is not None:
             out['host_input'] = host_rate
         print(json.dumps(out))

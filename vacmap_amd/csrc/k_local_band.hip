@@ -48,7 +48,7 @@
 #define LB_QB 26                    // bits of a hit key that hold the read position (relative to the read window)
 #define LB_SEQB 13                  // bits of a log key that hold the chunk number
 
-static_assert(4 * ((1 << VMX_LB_NBLOG) + 2 * VMX_LB_QC + 512) <= 8 * VMX_LB_SORTK && VMX_LB_HCAP <= VMX_LB_SORTK && 2 * VMX_LB_QC < (1 << 13), "k_local_seed_band: LDS layout");
+static_assert(VMX_LB_HCAP <= VMX_LB_SORTK && 2 * VMX_LB_QC < (1 << 13), "k_local_seed_band: LDS layout");
 __device__ __forceinline__ int vmx_bits_u64(unsigned long long v) { int b = 0; while (b < 64 && (v >> b)) ++b; return b; }
 
 // k-mers of the 8 consecutive positions x .. x + 7 of a 1-byte-per-base code array (any alignment; the arrays are padded by 64 bytes):
@@ -93,7 +93,7 @@ __device__ __attribute__((noinline)) int lb_sort_hbm(uint64_t* g, int N) {
 }
 __device__ __forceinline__ bool lb_sort_hits(int n) {      // s_hit[0 .. n) -> sort region, sorted; true: swizzled order
     VMX_DYN_SHARED(uint64_t, s_u);
-    uint64_t* const lds = s_u; const uint64_t* const src = s_u + VMX_LB_SORTK;
+    uint64_t* const lds = s_u; const uint64_t* const src = s_u + VMX_LB_REGION_U64;
     const int T = (int)blockDim.x, tid = (int)threadIdx.x;
     int NH = 2; while (NH < n) NH <<= 1;
     const bool sw = vmx_bitonic_fast_ok(NH);
@@ -103,13 +103,13 @@ __device__ __forceinline__ bool lb_sort_hits(int n) {      // s_hit[0 .. n) -> s
     return sw;
 }
 
-__global__ void __launch_bounds__(64) k_local_seed_band(vmx_lseed_args A) {
+__global__ void __launch_bounds__(64, VMX_LB_WAVES) k_local_seed_band(vmx_lseed_args A) {
     VMX_DYN_SHARED(uint64_t, s_u);                 // VMX_LB_LDS_BYTES
     uint64_t* const s_sort = s_u;                  // [0, 8 VMX_LB_SORTK): sorts / the sorted hits of a chunk
     uint32_t* const s_head = (uint32_t*)s_u;       // LB_NB bucket heads (entry index + 1, 0 = empty) ...
     uint32_t* const s_ent = s_head + LB_NB;        // ... the entries: 2 i + s of chunk position i, strand s: (k-mer >> LB_NBLOG) << 13 | next ...
     uint32_t* const s_bm = s_ent + 2 * VMX_LB_QC;  // ... and a 2^14-bit occupancy map of the chunk's k-mers (their low 14 bits): together <= the sort region
-    uint64_t* const s_hit = s_u + VMX_LB_SORTK;    // band intervals of the plan, then the chunk's hits
+    uint64_t* const s_hit = s_u + VMX_LB_REGION_U64;    // band intervals of the plan, then the chunk's hits
     uint32_t* const s_cq = (uint32_t*)(s_hit + VMX_LB_HCAP);   // candidates of one sweep over the band: (lane * 8 + j) << 22 | k-mer
     __shared__ int s_gq[VMX_LB_GS];
     __shared__ long long s_gr[VMX_LB_GS];
@@ -117,9 +117,8 @@ __global__ void __launch_bounds__(64) k_local_seed_band(vmx_lseed_args A) {
     __shared__ long long s_iv[LB_WIN][2];
     __shared__ int s_ivbase[LB_WIN + 1];
     __shared__ long long s_pc[LB_PIECES][2];
-    __shared__ unsigned long long s_opd[2][LB_OPEN];
-    __shared__ long long s_opr[2][LB_OPEN];
-    __shared__ int s_opq[2][LB_OPEN], s_opp[2][LB_OPEN], s_opl[2][LB_OPEN], s_opu[LB_OPEN];
+    __shared__ unsigned long long s_opd[2][LB_OPEN];          // open runs: (strand | diagonal) ...
+    __shared__ int s_opq[2][LB_OPEN], s_opp[2][LB_OPEN];      // ... start of the anchor in progress, read position of the run's last hit
     __shared__ int s_nop[2];
     __shared__ int s_niv, s_flag, s_next, s_fail, s_cnt, s_nit, s_npc, s_nhit, s_nlog, s_emit;
     __shared__ unsigned long long s_hlo, s_hhi;
@@ -176,48 +175,77 @@ __global__ void __launch_bounds__(64) k_local_seed_band(vmx_lseed_args A) {
             __syncthreads();
             int gk_lds = 0;
             if (NN > 1) gk_lds = lb_sort_hbm(GKEY, NN);
-            // --- windows (serial, thread 0): :23105-23180 — disjoint intervals of k-mer starts [lo, hi) in global reference coordinates
-            if (tid == 0) {
+            // --- windows :23105-23180 — disjoint intervals of k-mer starts [lo, hi) in global reference coordinates. A window is a maximal stretch
+            // of the sorted guide whose neighbours lie closer than `readgap` (on the retry: and on one contig); every lane tests its own
+            // anchors, a running maximum carries the window's first index to its last anchor, whose lane turns (first, last) into an interval;
+            // the few raw intervals are merged by one lane. (The lane-0 walk over a HiFi guide of ~3000 anchors was 16 % of the kernel.)
+            {
                 auto GK = [&](int i) -> uint64_t { return gk_lds == 2 ? s_sort[vmx_sw(i)] : (gk_lds == 1 ? s_sort[i] : GKEY[i]); };
-                int niv = 0; bool overflow = false;
+                long long* const RW = (long long*)s_hit;                   // raw windows (a, b), ascending; at most VMX_LB_HCAP / 2
+                bool retry = false, overflow = false;
+                int nraw = 0;
                 for (int attempt = 0; attempt < 2 && mm > 0; ++attempt) {
                     const bool split = attempt == 1;
-                    niv = 0; bool retry = false;
-                    long long ws = (long long)(GK(0) >> 24), we = ws;
-                    int cur = vmx_pos2contig(A.coff, A.nseq, ws);
-                    for (int i = 1; i <= mm; ++i) {
-                        bool close_it = true; long long rr = 0;
-                        if (i < mm) {
-                            rr = (long long)(GK(i) >> 24);
-                            bool same = (rr - we) < readgap;
-                            if (split) same = same && (cur == vmx_pos2contig(A.coff, A.nseq, rr));
-                            if (same) { we = rr; close_it = false; }
+                    nraw = 0; retry = false;
+                    int carry = 0;                                          // first index of the window the previous block ended in
+                    for (int i0 = 0; i0 < mm; i0 += T) {
+                        const int i = i0 + tid;
+                        const bool in = i < mm;
+                        long long rr = 0, rp = 0, rn = 0;
+                        if (in) { rr = (long long)(GK(i) >> 24); rp = i > 0 ? (long long)(GK(i - 1) >> 24) : rr; rn = i + 1 < mm ? (long long)(GK(i + 1) >> 24) : rr; }
+                        int cr_ = 0;
+                        bool first = in && (i == 0 || !((rr - rp) < readgap)), lastw = in && (i + 1 == mm || !((rn - rr) < readgap));
+                        if (split && in) {
+                            cr_ = vmx_pos2contig(A.coff, A.nseq, rr);
+                            if (i > 0 && cr_ != vmx_pos2contig(A.coff, A.nseq, rp)) first = true;
+                            if (i + 1 < mm && cr_ != vmx_pos2contig(A.coff, A.nseq, rn)) lastw = true;
                         }
-                        if (close_it) {
-                            if (ws != we) {   // single-point windows are dropped (:23110, :23113)
-                                int c = vmx_pos2contig(A.coff, A.nseq, ws);
-                                if (c != vmx_pos2contig(A.coff, A.nseq, we)) { retry = true; break; }
-                                long long cst = A.coff[c], clen = A.coff[c + 1] - cst;
-                                long long lf = ws - cst < A.look_span ? ws - cst : A.look_span;
-                                long long lo = ws - lf - cst, hi = we + A.look_span - cst; if (hi > clen) hi = clen;
-                                long long nk = (hi - lo) - k + 1;
-                                if (nk > 0) {
-                                    long long a = cst + lo, b = a + nk;
-                                    if (niv > 0 && a <= s_iv[niv - 1][1]) { if (b > s_iv[niv - 1][1]) s_iv[niv - 1][1] = b; }     // (touching intervals are one: a run may cross)
-                                    else if (niv < LB_WIN) { s_iv[niv][0] = a; s_iv[niv][1] = b; ++niv; }
-                                    else overflow = true;
+                        int v = first ? i : -1;
+                        for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(v, o); if (vmx_lane() >= o) v = x > v ? x : v; }
+                        if (v < carry) v = carry;
+                        carry = __shfl(v, 63);
+                        // the window's last anchor makes the interval
+                        bool emit = false; long long ia = 0, ib = 0; bool bad = false;
+                        if (lastw) {
+                            const long long ws = (long long)(GK(v) >> 24), we = rr;
+                            if (ws != we) {                                // single-point windows are dropped (:23110, :23113)
+                                const int c = vmx_pos2contig(A.coff, A.nseq, ws);
+                                if (c != vmx_pos2contig(A.coff, A.nseq, we)) bad = true;                 // retry_diffcontig (:23142)
+                                else {
+                                    const long long cst = A.coff[c], clen = A.coff[c + 1] - cst;
+                                    const long long lf = ws - cst < A.look_span ? ws - cst : A.look_span;
+                                    long long lo = ws - lf - cst, hi = we + A.look_span - cst; if (hi > clen) hi = clen;
+                                    const long long nk = (hi - lo) - k + 1;
+                                    if (nk > 0) { emit = true; ia = cst + lo; ib = ia + nk; }
                                 }
                             }
-                            if (i < mm) { ws = we = rr; if (split) cur = vmx_pos2contig(A.coff, A.nseq, rr); }
                         }
+                        if (__ballot(bad)) {
+                            // the reference stops at the first window that spans two contigs: everything before it would be thrown away with the retry
+                            retry = true;
+                        }
+                        const unsigned long long bal = __ballot(emit);
+                        if (emit) { const int o = nraw + __popcll(bal & ((1ULL << vmx_lane()) - 1ULL)); if (o < VMX_LB_HCAP / 2) { RW[2 * o] = ia; RW[2 * o + 1] = ib; } }
+                        nraw += __popcll(bal);
                     }
-                    if (!retry) break;
+                    if (nraw > VMX_LB_HCAP / 2) { overflow = true; nraw = 0; }
+                    if (!retry || split) break;
                 }
-                long long tot = 0;
-                for (int v = 0; v < niv; ++v) { s_ivbase[v] = (int)tot; tot += s_iv[v][1] - s_iv[v][0]; }
-                s_ivbase[niv] = (int)(tot < 0x7fffffff ? tot : 0x7fffffff);
-                if (tot >= 0x7fffffff) overflow = true;
-                s_niv = niv; s_flag = overflow ? 1 : 0;
+                __syncthreads();
+                if (tid == 0) {
+                    int niv = 0;
+                    for (int w = 0; w < nraw; ++w) {
+                        const long long a = RW[2 * w], b = RW[2 * w + 1];
+                        if (niv > 0 && a <= s_iv[niv - 1][1]) { if (b > s_iv[niv - 1][1]) s_iv[niv - 1][1] = b; }     // (touching intervals are one: a run may cross)
+                        else if (niv < LB_WIN) { s_iv[niv][0] = a; s_iv[niv][1] = b; ++niv; }
+                        else overflow = true;
+                    }
+                    long long tot = 0;
+                    for (int v = 0; v < niv; ++v) { s_ivbase[v] = (int)tot; tot += s_iv[v][1] - s_iv[v][0]; }
+                    s_ivbase[niv] = (int)(tot < 0x7fffffff ? tot : 0x7fffffff);
+                    if (tot >= 0x7fffffff) overflow = true;
+                    s_niv = niv; s_flag = overflow ? 1 : 0;
+                }
             }
             __syncthreads();
             if (s_flag) { status = VM_READ_BANDFALL_DEV; why = 2; }
@@ -263,8 +291,7 @@ __global__ void __launch_bounds__(64) k_local_seed_band(vmx_lseed_args A) {
                 const int js = cj > 0 ? cj - 1 : 0;
                 const int navail = mm - js < VMX_LB_GS ? mm - js : VMX_LB_GS;
                 for (int i = tid; i < navail; i += T) { const vmx_anchor a = G[mm - 1 - (js + i)]; s_gq[i] = a.q; s_gr[i] = a.r; }
-                if (tid == 0) { s_cnt = 0; s_nit = 0; s_nhit = 0; s_hlo = ~0ULL; s_hhi = 0ULL; s_nop[cur ^ 1] = 0; }
-                for (int i = tid; i < LB_OPEN; i += T) s_opu[i] = 0;
+                if (tid == 0) { s_cnt = 0; s_nit = 0; s_hlo = ~0ULL; s_hhi = 0ULL; s_nop[cur ^ 1] = 0; }
                 __syncthreads();
                 int qb = q0 + qc < qend ? q0 + qc : qend;
                 {
@@ -399,6 +426,13 @@ __global__ void __launch_bounds__(64) k_local_seed_band(vmx_lseed_args A) {
                 __syncthreads();
                 VMX_T(8);
                 // ---------------------------------------------------------------- stream the band through it
+                // the runs the previous chunk left open come back as one VIRTUAL hit each, at the read position of the run's last hit: the sort puts
+                // it in front of the chunk's hits on its diagonal, and the run walk treats it like any other hit (a run it starts begins its
+                // first anchor at the carried start)
+                const int nprev = s_nop[cur];
+                for (int e = tid; e < nprev; e += T) s_hit[e] = (s_opd[cur][e] << LB_QB) | (uint64_t)(unsigned)(s_opp[cur][e] - readstart);
+                if (tid == 0) s_nhit = nprev;
+                __syncthreads();
                 if (A.dbg && tid == 0) { long long bl = 0; for (int pc = 0; pc < npc; ++pc) bl += s_pc[pc][1] - s_pc[pc][0]; atomicAdd(&A.dbg[9], (unsigned long long)bl); atomicAdd(&A.dbg[10], 1ULL); atomicAdd(&A.dbg[12], (unsigned long long)qlen); }
                 // Sweep = 512 band positions, eight per lane: (1) every lane rolls its k-mers and tests the occupancy map — no divergence, the
                 // passing (position, k-mer) pairs are packed into a queue with a ballot; (2) the queue is drained one candidate per lane: bucket
@@ -416,10 +450,13 @@ __global__ void __launch_bounds__(64) k_local_seed_band(vmx_lseed_args A) {
                             const uint64_t w0 = wn0, w1 = wn1; uint64_t w2 = 0;
                             if (x0 + 8LL * T < hi) { __builtin_memcpy(&wn0, A.ref + x0 + 8LL * T, 8); __builtin_memcpy(&wn1, A.ref + x0 + 8LL * T + 8, 8); }
                             if (x0 < hi) { if (k > 9) __builtin_memcpy(&w2, A.ref + x0 + 16, 8); okm = vmx_kmers8_w(w0, w1, w2, k, KMASK, kms); }
+                            uint32_t bw[8];
+                            if (x0 >= hi) { for (int j = 0; j < 8; ++j) kms[j] = 0u; }
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) bw[j] = s_bm[(kms[j] & 0x3fffu) >> 5];          // all eight words in flight together
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
-                                bool pass = x0 + j < hi && ((okm >> j) & 1u);
-                                if (pass) pass = (s_bm[(kms[j] & 0x3fffu) >> 5] >> (kms[j] & 31u)) & 1u;
+                                const bool pass = x0 + j < hi && ((okm >> j) & 1u) && ((bw[j] >> (kms[j] & 31u)) & 1u);
                                 const unsigned long long bal = __ballot(pass);
                                 if (pass) s_cq[ncq + __popcll(bal & ((1ULL << vmx_lane()) - 1ULL))] = ((uint32_t)(8 * tid + j) << 22) | kms[j];
                                 ncq += __popcll(bal);
@@ -466,10 +503,22 @@ __global__ void __launch_bounds__(64) k_local_seed_band(vmx_lseed_args A) {
                 // ---------------------------------------------------------------- sort the hits by (strand, diagonal, read position)
                 const bool sw = lb_sort_hits(nhit);
                 VMX_T(2);
-                // ---------------------------------------------------------------- walk the runs (:23232-23344)
+                // ---------------------------------------------------------------- the runs (:23232-23344), every hit on its own lane
+                // A RUN = hits of one diagonal whose read positions are <= k apart. Along a run the reference's cache entry (q, r, s, l) only ever
+                // does this: the anchor that starts at `st` takes every hit with q < st + 20 - k (:23241, l + bouns < 20), the first hit beyond
+                // appends it with l = (its last hit's q) + k - st and the next anchor starts at (that last hit's q) + k. So the last hit b of an
+                // anchor fixes the next anchor's last hit: NX(b) = the last hit of the run with q < q_b + 20 — a function of b alone. The anchors
+                // of a run are the chain b1 = (last hit with q < q_first + 20 - k), b2 = NX(b1), ...: the chain is marked by pointer doubling
+                // (J <- J o J, marks follow the current power), then every marked hit and every run start emits its anchor. Sequentially this
+                // was one lane per run and one dependent LDS load per hit (47 % of the kernel on HiFi reads, whose runs fill the chunk).
                 {
-                    const int nprev = s_nop[cur];
                     auto KH = [&](int i) -> uint64_t { return s_sort[sw ? vmx_sw(i) : i]; };
+                    uint32_t* const QR = (uint32_t*)s_hit;                              // (index of the run's first hit) << 16 | (q - qbase): ascending
+                    unsigned short* const NX = (unsigned short*)(QR + VMX_LB_HCAP);      // last hit of the anchor that follows hit i
+                    unsigned short* const JP = NX + VMX_LB_HCAP;                         // its powers
+                    uint32_t* const MK = s_cq;                                            // marks, one bit per hit
+                    unsigned short* const TMP = (unsigned short*)(s_cq + 32);
+                    const int qbase = q0 - 64;
                     auto emit = [&](long long cq, long long cr, int cs, long long cl, uint64_t ek) {
                         const int o = n_out + atomicAdd(&s_emit, 1);
                         if (o < out_cap) { OUT[o] = vmx_mk_anchor(cq, cr, cs, cl); OKEY[o] = ek; }
@@ -481,62 +530,105 @@ __global__ void __launch_bounds__(64) k_local_seed_band(vmx_lseed_args A) {
                             LOGV0[o] = v0; LOGV1[o] = v1;
                         } else s_fail = 8;
                     };
-                    for (int j0 = tid; j0 < nhit; j0 += T) {
-                        const uint64_t kj = KH(j0); const unsigned long long dk = kj >> LB_QB;
-                        const int qj = readstart + (int)(kj & QM);
-                        bool prevD = false; int qprev = 0;
-                        if (j0 > 0) { const uint64_t kp = KH(j0 - 1); prevD = (kp >> LB_QB) == dk; qprev = readstart + (int)(kp & QM); }
-                        if (prevD && qj - qprev <= k) continue;                         // inside a run
-                        const int sb = (int)(dk >> dbits); const long long drel = (long long)(dk & DM);
-                        auto rof = [&](int q) -> long long { return sb ? wlo + drel - (q - readstart) : wlo + drel - (readend - 1 - q); };
-                        long long cq = 0, cr = 0, cl = 0; int prevq = 0, j = j0;
-                        bool cont = false;
-                        if (!prevD && qj < q0 + k) {                                    // may go on a run the previous chunk left open
-                            for (int e = 0; e < nprev; ++e)
-                                if (s_opd[cur][e] == dk && qj - s_opp[cur][e] <= k) {
-                                    cont = true; cq = s_opq[cur][e]; cr = s_opr[cur][e]; cl = s_opl[cur][e]; prevq = s_opp[cur][e]; s_opu[e] = 1; break;
-                                }
-                        }
-                        if (!cont) {
-                            const long long r0 = rof(qj);
-                            if (!prevD) logrec(dk, seq, 0, ekey_of(qj, sb, r0), 0);       // first hit of the diagonal in this chunk
-                            cq = qj; cr = r0; cl = k; prevq = qj; j = j0 + 1;
-                        }
-                        const int cs = sb ? -1 : 1;
-                        for (; j < nhit; ++j) {
-                            const uint64_t k2 = KH(j);
-                            if ((k2 >> LB_QB) != dk) break;
-                            const int q2 = readstart + (int)(k2 & QM);
-                            if (q2 - prevq > k) break;
-                            const long long refloc = rof(q2);
-                            const long long bouns = (long long)q2 - (cq + cl) + k;          // > 0 inside a run
-                            if (cl + bouns < 20) { if (sb) cr = refloc; cl += bouns; }
-                            else {
-                                emit(cq, cr, cs, cl, ekey_of(q2, sb, refloc));
-                                const long long nq = cq + cl;
-                                if (sb) cr = refloc; else cr = cr + cl;
-                                cq = nq; cl = bouns;
+                    for (int i = tid; i < 32; i += T) MK[i] = 0u;
+                    // (1) run starts, carried to every hit of the run by a running maximum
+                    {
+                        int carry = 0;
+                        for (int i0 = 0; i0 < nhit; i0 += T) {
+                            const int i = i0 + tid; const bool in = i < nhit;
+                            int v = -1, qr = 0;
+                            if (in) {
+                                const uint64_t kj = KH(i); const int qj = readstart + (int)(kj & QM);
+                                bool nr = i == 0;
+                                if (i > 0) { const uint64_t kp = KH(i - 1); nr = (kp >> LB_QB) != (kj >> LB_QB) || qj - (readstart + (int)(kp & QM)) > k; }
+                                v = nr ? i : -1; qr = qj - qbase;
                             }
-                            prevq = q2;
+                            for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(v, o); if (vmx_lane() >= o) v = x > v ? x : v; }
+                            if (v < carry) v = carry;
+                            carry = __shfl(v, 63);
+                            if (in) QR[i] = ((uint32_t)v << 16) | (uint32_t)qr;
                         }
-                        if (j < nhit && (KH(j) >> LB_QB) == dk) {                         // the next hit on the diagonal appends the leftover (:23248)
-                            const int q2 = readstart + (int)(KH(j) & QM);
-                            emit(cq, cr, cs, cl, ekey_of(q2, sb, rof(q2)));
-                        } else if (prevq + k >= qb && qb < qend) {                         // may go on in the next chunk
-                            const int o = atomicAdd(&s_nop[cur ^ 1], 1);
-                            if (o < LB_OPEN) { s_opd[cur ^ 1][o] = dk; s_opq[cur ^ 1][o] = (int)cq; s_opr[cur ^ 1][o] = cr; s_opl[cur ^ 1][o] = (int)cl; s_opp[cur ^ 1][o] = prevq; }
-                            else s_fail = 7;
-                        } else logrec(dk, seq, 1, ((uint64_t)(unsigned)cq << 32) | (uint64_t)(unsigned)cl, cr);
                     }
                     __syncthreads();
-                    // open runs of the previous chunk nobody went on with: pending leftovers of that chunk
-                    for (int e = tid; e < nprev; e += T)
-                        if (!s_opu[e]) logrec(s_opd[cur][e], seq - 1, 1, ((uint64_t)(unsigned)s_opq[cur][e] << 32) | (uint64_t)(unsigned)s_opl[cur][e], s_opr[cur][e]);
+                    // last index j in [i, i + 19] with QR[j] < lim (QR ascends; QR[i] < lim)
+                    auto last_below = [&](int i, uint32_t lim) -> int {
+                        int lo = i, hi = i + 19 < nhit - 1 ? i + 19 : nhit - 1;
+                        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (QR[mid] < lim) lo = mid; else hi = mid - 1; }
+                        return lo;
+                    };
+                    auto carried_start = [&](unsigned long long dk) -> int {           // the open run a virtual hit stands for
+                        for (int e = 0; e < nprev; ++e) if (s_opd[cur][e] == dk) return s_opq[cur][e];
+                        return 0;
+                    };
+                    // first anchor of the run that starts at hit i: it starts at the hit (at the carried start for a virtual hit) and takes q < start + 20 - k
+                    auto root_last = [&](int i, int qi, unsigned long long dk, int& st) -> int {
+                        st = qi < q0 ? carried_start(dk) : qi;
+                        return last_below(i, ((uint32_t)i << 16) | (uint32_t)(st - qbase + 20 - k));
+                    };
+                    // (2) NX, and the mark of every run's first chain element
+                    for (int i = tid; i < nhit; i += T) {
+                        const uint32_t w = QR[i];
+                        const int nx = last_below(i, w + 20u);
+                        NX[i] = (unsigned short)nx; JP[i] = (unsigned short)nx;
+                        if ((int)(w >> 16) == i) {
+                            const uint64_t kj = KH(i); int st;
+                            const int b1 = root_last(i, readstart + (int)(kj & QM), kj >> LB_QB, st);
+                            atomicOr(&MK[b1 >> 5], 1u << (b1 & 31));
+                        }
+                    }
+                    __syncthreads();
+                    // (3) pointer doubling: marks at distance < 2^r from the first element reach distance < 2^(r+1)
+                    for (int round = 0; round < 12; ++round) {
+                        bool ch = false;
+                        for (int i = tid; i < nhit; i += T) {
+                            const int j = JP[i];
+                            if ((MK[i >> 5] >> (i & 31)) & 1u) atomicOr(&MK[j >> 5], 1u << (j & 31));
+                            const int jj = JP[j];
+                            TMP[i] = (unsigned short)jj; ch = ch || jj != j;
+                        }
+                        __syncthreads();
+                        for (int i = tid; i < nhit; i += T) JP[i] = TMP[i];
+                        __syncthreads();
+                        if (!__any(ch)) break;
+                    }
+                    // (4) anchors: the one a run starts with, and the one behind every marked hit that is not the run's last
+                    for (int i = tid; i < nhit; i += T) {
+                        const uint64_t kj = KH(i); const unsigned long long dk = kj >> LB_QB;
+                        const int qi = readstart + (int)(kj & QM);
+                        const uint32_t w = QR[i]; const int rs = (int)(w >> 16);
+                        const int sb = (int)(dk >> dbits); const long long drel = (long long)(dk & DM);
+                        const int cs = sb ? -1 : 1;
+                        auto rof = [&](int q) -> long long { return sb ? wlo + drel - (q - readstart) : wlo + drel - (readend - 1 - q); };
+                        const bool newD = i == 0 || (KH(i - 1) >> LB_QB) != dk;
+                        if (newD && qi >= q0) logrec(dk, seq, 0, ekey_of(qi, sb, rof(qi)), 0);          // first hit of the diagonal in this chunk (not a carried one)
+                        // anchor [st, q_b + k) whose last hit is b
+                        auto anchor = [&](int st, int b) {
+                            const uint64_t kb = KH(b); const int qbh = readstart + (int)(kb & QM);
+                            const long long len = (long long)qbh + k - st;
+                            const long long cr = sb ? rof(qbh) : rof(st);
+                            if (b + 1 < nhit && (KH(b + 1) >> LB_QB) == dk) {                              // the next hit on the diagonal appends it (:23241 / :23248)
+                                const int q2 = readstart + (int)(KH(b + 1) & QM);
+                                emit(st, cr, cs, len, ekey_of(q2, sb, rof(q2)));
+                            } else if (qbh + k >= qb && qb < qend) {                                       // may go on in the next chunk
+                                const int o = atomicAdd(&s_nop[cur ^ 1], 1);
+                                if (o < LB_OPEN) { s_opd[cur ^ 1][o] = dk; s_opq[cur ^ 1][o] = st; s_opp[cur ^ 1][o] = qbh; }
+                                else s_fail = 7;
+                            } else logrec(dk, seq, 1, ((uint64_t)(unsigned)st << 32) | (uint64_t)(unsigned)len, cr);
+                        };
+                        if (rs == i) { int st; const int b1 = root_last(i, qi, dk, st); anchor(st, b1); }
+                        const bool run_last = i + 1 == nhit || (int)(QR[i + 1] >> 16) != rs;
+                        if (((MK[i >> 5] >> (i & 31)) & 1u) && !run_last) anchor(qi + k, (int)NX[i]);
+                    }
+                    __syncthreads();
                 }
-                __syncthreads();
                 if (s_fail || s_nop[cur ^ 1] > LB_OPEN) { status = VM_READ_BANDFALL_DEV; why = s_fail ? s_fail : 7; break; }
                 cur ^= 1; q0 = qb; cj = cj_next; ++seq;
-                if (qc < VMX_LB_QC) qc <<= 1;
+                {   // next chunk: as many positions as fill three quarters of the hit tile at this chunk's hit density (a HiFi read hits at nearly every
+                    // position: fixed 512-position chunks overflowed the tile and were done twice, every time)
+                    long long want = nhit > 0 ? (long long)qlen * (3 * VMX_LB_HCAP / 4) / nhit : VMX_LB_QC;
+                    want &= ~7LL;
+                    qc = (int)(want < 32 ? 32 : (want > VMX_LB_QC ? VMX_LB_QC : want));
+                }
                 if (seq >= (1 << LB_SEQB) - 1) { status = VM_READ_BANDFALL_DEV; why = 9; break; }
                 __syncthreads();
                 VMX_T(3);

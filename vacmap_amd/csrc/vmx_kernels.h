@@ -102,13 +102,21 @@ struct vmx_lseed_args {
 #define VMX_LB_NBLOG 8
 #define VMX_LB_SORTK 512
 #else
+#ifndef VMX_LB_QC                    /* (tuning builds override the set: VMX_EXTRA_FLAGS="-DVMX_LB_QC=256 -DVMX_LB_HCAP=256 -DVMX_LB_SORTK=512 -DVMX_LB_NBLOG=8") */
 #define VMX_LB_QC 512
 #define VMX_LB_HCAP 512
-#define VMX_LB_GS 64
 #define VMX_LB_NBLOG 9
 #define VMX_LB_SORTK 1024
 #endif
-#define VMX_LB_LDS_BYTES (8 * (VMX_LB_SORTK + VMX_LB_HCAP) + 4 * 512)     /* + the candidate queue of one sweep */
+#define VMX_LB_GS 64
+#endif
+#ifndef VMX_LB_WAVES
+#define VMX_LB_WAVES 2               /* waves per SIMD the register allocation of k_local_seed_band is held to */
+#endif
+#define VMX_LB_TABLE_U64 (((1 << VMX_LB_NBLOG) + 2 * VMX_LB_QC + 512) / 2)          /* heads + entries + occupancy map, in 8-byte units */
+#define VMX_LB_REGION_U64 (VMX_LB_SORTK > VMX_LB_TABLE_U64 ? VMX_LB_SORTK : VMX_LB_TABLE_U64)
+#define VMX_LB_CQ_BYTES (128 + 2 * VMX_LB_HCAP > 2048 ? 128 + 2 * VMX_LB_HCAP : 2048)     /* candidate queue of one sweep (512 words); later the run walk's marks + one index per hit */
+#define VMX_LB_LDS_BYTES (8 * (VMX_LB_REGION_U64 + VMX_LB_HCAP) + VMX_LB_CQ_BYTES)
 #define VMX_ED_WAVES 16              // max waves per workgroup of k_edit_distance (passes pipelined across them) = carry ring depth
 #define VMX_ED_LONG 16384            // patterns longer than this (> 4 passes) go to the 16-wave launch
 #define VMX_EDB_HW 768               // k_ed_banded: half width of the band in rows
