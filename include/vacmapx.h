@@ -305,6 +305,10 @@ void vm_pinned_free(void* p);
 int64_t vm_blob_write_parts(int fd, const char* const* blobs, const int64_t* const* offs, const int32_t* part, const int64_t* idx, int64_t n);
 typedef struct vm_fastx vm_fastx;
 int vm_fastx_open(const char* path, vm_fastx** out);
+/* the records whose FIRST byte lies in [begin, end) of a plain FASTA / FASTQ file (end < 0: to the end of the file): N readers over N consecutive
+ * ranges see every record exactly once — the sharded driver gives every rank a range and its parser threads slices of it (the reference has one
+ * reader process, vacmap:445-497). Compressed input: VM_ERR_UNSUPPORTED for begin > 0. */
+int vm_fastx_open_range(const char* path, int64_t begin, int64_t end, vm_fastx** out);
 void vm_fastx_close(vm_fastx*);
 int64_t vm_fastx_read(vm_fastx*, int64_t max_reads, int64_t max_bases, char** names, int64_t** name_off, char** seqs, int64_t** seq_off, char** quals,
                       int64_t** qual_off, char** comments, int64_t** com_off);

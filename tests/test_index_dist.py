@@ -372,3 +372,95 @@ def test_driver_native_path_matches_python_emitter(ctx, oracle, tmp_path, monkey
         if status[i] == 0 and rr:
             expect += sam.sam_lines(rr, sq, ql, lambda n, a, b: cs[n][a:b], md=True, shortcs=True, markunbalancetra=True, rg_id='1', comments=com)
     assert body == expect and len(body) >= 6
+
+
+# ---------------------------------------------------------------- N-rank driver on the host: byte-range sharding, per-rank parts
+_RANGE_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import torch.distributed as dist
+dist.init_process_group(backend='gloo')
+import emu_lib                                   # TEST-ONLY: the product's sources on the CPU fiber emulator
+ctx = emu_lib.context()
+import vacmap_amd.lib as VL
+VL._default = ctx.lib
+from vacmap_amd import driver
+tmp, mode = sys.argv[1], sys.argv[2]
+extra = ['--parts'] if mode == 'parts' else (['--shard', 'batch'] if mode == 'batch' else [])
+rc = driver.main(['-ref', os.path.join(tmp, 'ref.fa'), '-read', os.path.join(tmp, 'reads.fq'), '-mode', 'H', '-o', os.path.join(tmp, 'out_%%s_%%d.sam' %% (mode, dist.get_world_size())),
+                  '-t', '4', '--nowriteindex', '--batch-reads', '2', '--window-batches', '2', '--force', '--parse-threads', '2'] + extra, comm=dist)
+assert rc == 0
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_fastx_byte_ranges_partition_the_records(ctx, tmp_path):
+    """vm_fastx_open_range: whatever the cut points, consecutive ranges yield every record exactly once, in order — FASTQ whose quality lines
+    begin with '@', '+' and '>', multi-line FASTA, more ranges than records"""
+    import random
+    from vacmap_amd.lib import Fastx
+    rng = random.Random(5)
+    for fq in (True, False):
+        R = []
+        for i in range(200):
+            L = rng.randint(1, 300)
+            R.append(('r%d' % i, ''.join(rng.choice('ACGTNacgt') for _ in range(L)), ''.join(rng.choice('@+!IJ5>') for _ in range(L))))
+        path = str(tmp_path / ('t.fq' if fq else 't.fa'))
+        with open(path, 'w') as f:
+            for nm, s_, q in R:
+                if fq:
+                    f.write('@%s c%s\n%s\n+\n%s\n' % (nm, nm, s_, q))
+                else:
+                    f.write('>%s\n' % nm + ''.join(s_[a:a + 60] + '\n' for a in range(0, len(s_), 60)))
+        size = os.path.getsize(path)
+        want = [(nm, s_.upper(), q if fq else '') for nm, s_, q in R]
+        for N in (1, 2, 3, 7, 64, 201):
+            cuts = [size * r // N for r in range(N + 1)] if N != 7 else sorted(set([0, size] + [rng.randint(0, size) for _ in range(6)]))
+            got = []
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                rd = Fastx(path, lib=ctx.lib, byte_range=(a, b))
+                for ch in iter(lambda: rd.read(17), None):
+                    nb, no, sb, so, qb, qo = ch['names'].tobytes(), ch['names_off'], ch['seqs'].tobytes(), ch['seqs_off'], ch['quals'].tobytes(), ch['quals_off']
+                    got += [(nb[no[i]:no[i + 1]].decode(), sb[so[i]:so[i + 1]].decode(), qb[qo[i]:qo[i + 1]].decode()) for i in range(len(no) - 1)]
+                rd.close()
+            assert got == want, (fq, N)
+
+
+def test_n_rank_driver_range_sharding_parts_gloo(ctx, tmp_path, monkeypatch):
+    """world 2 and 4, gloo: every rank parses its own byte range of the FASTQ input (two parser threads over slices) and writes its own part;
+    the joined file (and the parts left by --parts, and the --shard batch run) hold the one-rank run's lines — the same multiset, and the
+    same bytes once sorted"""
+    import vacmap_amd.lib as VL
+    from vacmap_amd import synth, driver
+    monkeypatch.setattr(VL, '_default', ctx.lib)
+    contigs = synth.make_reference([30000, 8000], seed=41)
+    with open(tmp_path / 'ref.fa', 'w') as f:
+        for n, c in zip(['a', 'b'], contigs):
+            f.write('>%s\n%s\n' % (n, c.tobytes().decode()))
+    cat, off, _ = synth.sample_reads_concat(contigs, 11, mean_len=1200, err=0.06, seed=43, min_len=400, max_len=2500)
+    with open(tmp_path / 'reads.fq', 'w') as f:
+        for i in range(11):
+            s_ = cat[off[i]:off[i + 1]].tobytes().decode()
+            f.write('@r%d\n%s\n+\n%s\n' % (i, s_, '@' * len(s_)))          # (quality lines of '@': the resynchronisation must not take them for headers)
+    monkeypatch.setenv('VMX_SLICE_MB', '0.004')                            # ~4 KB slices: several per rank
+    one = str(tmp_path / 'one.sam')
+    assert driver.main(['-ref', str(tmp_path / 'ref.fa'), '-read', str(tmp_path / 'reads.fq'), '-mode', 'H', '-o', one, '-t', '4', '--nowriteindex',
+                        '--batch-reads', '2', '--window-batches', '2', '--force', '--parse-threads', '2']) == 0
+    want = sorted(l for l in open(one) if not l.startswith('@'))
+    header = [l for l in open(one) if l.startswith('@') and not l.startswith('@PG')]
+    assert len(want) >= 11
+    script = tmp_path / 'w.py'
+    script.write_text(_RANGE_WORKER % (ROOT, ROOT))
+    port = 29651
+    for world, mode in ((2, 'join'), (4, 'join'), (2, 'parts'), (2, 'batch')):
+        port += 1
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), VMX_SLICE_MB='0.004')
+        out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+                              '--master-port', str(port), str(script), str(tmp_path), mode], capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        base = str(tmp_path / ('out_%s_%d.sam' % (mode, world)))
+        files = [base + '.part%03d' % r for r in range(world)] if mode == 'parts' else [base]
+        assert all(os.path.exists(f) for f in files) and (mode == 'parts' or not os.path.exists(base + '.part000'))
+        lines = [l for f in files for l in open(f)]
+        assert [l for l in lines if l.startswith('@') and not l.startswith('@PG')] == header, (world, mode)       # the header once
+        assert sorted(l for l in lines if not l.startswith('@')) == want, (world, mode)

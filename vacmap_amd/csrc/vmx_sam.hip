@@ -464,7 +464,10 @@ int64_t vm_blob_gather_parts(const char* const* blobs, const int64_t* const* off
 // ------------------------------------------------------------------------------------------------ FASTA / FASTQ(.gz) reader
 // Plain files are read with read(2) straight into the line buffer (gzread's transparent mode costs a copy); gzip members go through zlib.
 // The output blobs grow by realloc (large blocks move by remapping, not by copying) and are handed to the caller as they are.
-struct vm_fastx { gzFile f = nullptr; int fd = -1; char* buf = nullptr; size_t cap = 0, len = 0, pos = 0; bool eof = false, io_error = false; size_t hint = 0; };
+struct vm_fastx { gzFile f = nullptr; int fd = -1; char* buf = nullptr; size_t cap = 0, len = 0, pos = 0; bool eof = false, io_error = false; size_t hint = 0;
+                  int64_t base = 0;          // file offset of buf[0] (plain files)
+                  int64_t range_end = -1;    // byte-range reader: records that START at or beyond this offset belong to the next range (-1: to the end)
+                  bool fastq = false; };
 
 struct Blob {
     char* p = nullptr; size_t n = 0, cap = 0;
@@ -483,7 +486,7 @@ struct Blob {
 
 static bool fx_fill(vm_fastx* x) {
     if (x->eof) return false;
-    if (x->pos > 0) { memmove(x->buf, x->buf + x->pos, x->len - x->pos); x->len -= x->pos; x->pos = 0; }
+    if (x->pos > 0) { memmove(x->buf, x->buf + x->pos, x->len - x->pos); x->len -= x->pos; x->base += (int64_t)x->pos; x->pos = 0; }
     const size_t want = (size_t)8 << 20;
     if (x->len + want > x->cap) {
         size_t c = x->cap ? x->cap : 2 * want; while (c < x->len + want) c *= 2;
@@ -513,6 +516,24 @@ static bool fx_line(vm_fastx* x, const char*& p, size_t& len, bool peek = false)
         return true;
     }
 }
+// the line `skip` lines below the current one, nothing consumed (the buffer may be refilled: views taken before are stale); false at end of input
+static bool fx_peek_ahead(vm_fastx* x, int skip, const char*& p, size_t& len) {
+    size_t off = 0;                                      // relative to x->pos, which a refill moves to 0 together with the bytes
+    for (int i = 0;; ++i) {
+        while (true) {
+            const char* b = x->buf + x->pos + off; const size_t n = x->len - x->pos - off;
+            const char* nl = n ? (const char*)memchr(b, '\n', n) : nullptr;
+            if (nl) {
+                const size_t l = (size_t)(nl - b);
+                if (i == skip) { p = b; len = (l && b[l - 1] == '\r') ? l - 1 : l; return true; }
+                off += l + 1; break;
+            }
+            if (fx_fill(x)) continue;
+            if (n == 0 || i != skip) return false;
+            p = b; len = n; return true;
+        }
+    }
+}
 static inline void fx_append_upper(Blob& dst, const char* p, size_t n) {
     dst.need(n);
     char* d = dst.p + dst.n;
@@ -535,6 +556,42 @@ int vm_fastx_open(const char* path, vm_fastx** out) {
     *out = x;
     return VM_OK;
 }
+// The records of the byte range [begin, end) of a PLAIN FASTA / FASTQ file: a record belongs to the range its first byte lies in, so N readers
+// over N consecutive ranges see every record exactly once, whatever the cut points (sharded driver: one range per rank, cut again into slices for
+// the rank's parser threads). The reader seeks to `begin` and resynchronises on the next record start: a line that begins with '>' (FASTA), or with
+// '@' and is followed two lines later by a line that begins with '+' (four-line FASTQ — a quality line may begin with '@', but the line two
+// below it is a sequence). Compressed input cannot be entered in the middle: VM_ERR_UNSUPPORTED for begin > 0 (the caller parses it on one rank).
+int vm_fastx_open_range(const char* path, int64_t begin, int64_t end, vm_fastx** out) {
+    const int rc = vm_fastx_open(path, out);
+    if (rc != VM_OK) return rc;
+    vm_fastx* x = *out;
+    if (x->f) {
+        if (begin > 0) { vm_fastx_close(x); *out = nullptr; set_error("byte ranges need uncompressed FASTA / FASTQ input"); return VM_ERR_UNSUPPORTED; }
+        return VM_OK;                                            // (a compressed file is one range: `end` is ignored)
+    }
+    try {
+        unsigned char first = 0;
+        if (pread(x->fd, &first, 1, 0) == 1) x->fastq = first == '@';
+        x->range_end = end;
+        if (begin <= 0) return VM_OK;
+        // start one byte early: whether `begin` is itself a line start depends on the byte before it
+        if (lseek(x->fd, (off_t)(begin - 1), SEEK_SET) < 0) { vm_fastx_close(x); *out = nullptr; set_error("seek failed"); return VM_ERR_IO; }
+        x->base = begin - 1;
+        const char* p; size_t len;
+        if (!fx_line(x, p, len)) return VM_OK;                   // (the rest of the line `begin - 1` lies in: never a record start of this range; empty range at EOF)
+        while (true) {
+            if (x->range_end >= 0 && x->base + (int64_t)x->pos >= x->range_end) { x->eof = true; x->len = x->pos; return VM_OK; }     // no record starts in the range
+            if (!fx_line(x, p, len, true)) return VM_OK;
+            if (len && p[0] == '>' && !x->fastq) return VM_OK;
+            if (len && p[0] == '@' && x->fastq) {
+                const char* q; size_t l2;
+                if (fx_peek_ahead(x, 2, q, l2) && l2 && q[0] == '+') return VM_OK;
+            }
+            fx_line(x, p, len);                                  // not a record start: next line
+        }
+    }
+    catch (const std::bad_alloc&) { vm_fastx_close(x); *out = nullptr; set_error("vm_fastx_open_range: out of host memory"); return VM_ERR_OOM; }
+}
 void vm_fastx_close(vm_fastx* x) { if (!x) return; if (x->f) gzclose(x->f); else if (x->fd >= 0) close(x->fd); free(x->buf); delete x; }
 
 // up to max_reads records (and at most max_bases bases) appended as blobs: names, upper-cased sequences, qualities (empty for FASTA),
@@ -547,6 +604,10 @@ int64_t vm_fastx_read(vm_fastx* x, int64_t max_reads, int64_t max_bases, char** 
         if (x->hint) { sb.need(x->hint); qb.need(x->hint); }          // the previous call's size: one allocation instead of a growth series
         int64_t n = 0; const char* p; size_t len;
         while (n < max_reads && (int64_t)sb.n < max_bases) {
+            if (x->range_end >= 0 && !x->f) {                     // byte-range reader: the record that starts at or beyond the end is the next range's
+                if (!fx_line(x, p, len, true)) break;
+                if (x->base + (int64_t)x->pos >= x->range_end) break;
+            }
             if (!fx_line(x, p, len)) break;
             if (len == 0) continue;
             if (p[0] != '>' && p[0] != '@') { set_error("not FASTA/FASTQ: " + std::string(p, len < 40 ? len : 40)); return VM_ERR_IO; }

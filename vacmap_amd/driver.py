@@ -112,6 +112,31 @@ def _bam_chunks(path, n_max):
         yield pack(cur)
 
 
+def _is_plain_fastx(path):
+    """an uncompressed FASTA / FASTQ file (byte ranges of it can be parsed independently)"""
+    if path.endswith('.bam') or not os.path.isfile(path):
+        return False
+    with open(path, 'rb') as f:
+        return f.read(2) != b'\x1f\x8b'
+
+
+def _concat_parts(dst, parts):
+    """the ranks' SAM parts, in rank order, into one file (in-kernel copies; the parts are removed)"""
+    with open(dst, 'wb') as o:
+        for pth in parts:
+            with open(pth, 'rb') as f:
+                size = os.fstat(f.fileno()).st_size; off = 0
+                while off < size:
+                    try:
+                        n = os.sendfile(o.fileno(), f.fileno(), off, min(size - off, 1 << 30))
+                    except OSError:
+                        n = 0
+                    if n <= 0:                      # (a file system without sendfile between regular files: plain copy)
+                        f.seek(off); shutil.copyfileobj(f, o, 16 << 20); break
+                    off += n
+            os.remove(pth)
+
+
 RG_ARGS = (('rg-id', 'ID'), ('rg-sm', 'SM'), ('rg-lb', 'LB'), ('rg-pl', 'PL'), ('rg-ds', 'DS'), ('rg-dt', 'DT'), ('rg-pu', 'PU'), ('rg-pi', 'PI'),
            ('rg-pg', 'PG'), ('rg-cn', 'CN'), ('rg-fo', 'FO'), ('rg-ks', 'KS'), ('rg-pm', 'PM'), ('rg-bc', 'BC'))       # vacmap:45-60
 
@@ -134,6 +159,12 @@ def build_parser():
         p.add_argument('--' + a, dest=a.replace('-', '_'))
     p.add_argument('--device', type=int, default=None); p.add_argument('--batch-reads', type=int, default=4096)
     p.add_argument('--window-batches', type=int, default=8); p.add_argument('--inflight', type=int, default=3)
+    # N ranks (torchrun): 'range' = every rank parses its own byte range of each plain FASTA / FASTQ input and writes its own part of the SAM file
+    # (<out>.partNNN, concatenated by rank 0 at the end unless --parts); 'batch' = every rank parses everything and keeps every N-th batch, rank 0
+    # gathers the text (compressed / BAM input, stdout or BAM output); 'auto' picks 'range' whenever input and output allow it
+    p.add_argument('--shard', choices=['auto', 'range', 'batch'], default='auto'); p.add_argument('--parts', action='store_true')
+    p.add_argument('--parse-threads', type=int, default=0, help='parser threads per rank over record-aligned slices of a plain input (0: max(1, min(4, t / 4)))')
+    p.add_argument('--debug', action='store_true', help='log every read the aligner skipped with its status (vacmap:127; mammap_clrnano.py:24120-24123)')
     return p
 
 
@@ -325,9 +356,16 @@ def main(argv=None, comm=None):
     mark = args.markunbalancetra or args.mode in ('H', 'L')          # mode defaults of vacmap:286-296 (False for asm unless asked)
     from .lib import SamOpts, Fastx, PinnedPool, align_batch_raw, sam_emit, blob_gather, blob_gather_parts, blob_write_parts
     opts = SamOpts(int(bool(args.MD)), int(args.cs != 'long'), int(bool(args.L)), int(bool(mark)), int(bool(args.H)), int(bool(args.fakecigar)), rg['ID'].encode())
+    plain = all(_is_plain_fastx(pth) for grp in args.read for pth in grp)
+    range_mode = world > 1 and args.mode != 'asm' and args.shard != 'batch' and plain and args.o.endswith('.sam')
+    if world > 1 and args.shard == 'range' and not range_mode:
+        sys.exit('--shard range needs uncompressed FASTA / FASTQ input and a .sam output path')
+    part_path = '%s.part%03d' % (args.o, rank) if range_mode else None
     out, proc = (None, None)
+    if range_mode and rank != 0:
+        out = open(part_path, 'wb')
     if rank == 0:
-        out, proc = _open_output(args.o)
+        out, proc = (open(part_path, 'wb'), None) if range_mode else _open_output(args.o)
         for ln in sam.header_lines([(n, ln_) for n, ln_ in zip(names, index.lens)], ' '.join(sys.argv if argv is None else ['vacmapx'] + list(argv)), rg):
             out.write(ln.encode() + b'\n')
     if args.mode == 'asm':
@@ -351,18 +389,45 @@ def main(argv=None, comm=None):
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
 
+    parse_threads = args.parse_threads or max(1, min(4, args.t // 4))
+
+    def chunks_of(path):
+        """blob chunks of one input in file order. A plain FASTA / FASTQ file is cut into record-aligned slices (vm_fastx_open_range): in range
+        mode the rank takes its own byte range of the file, and `parse_threads` threads parse slices ahead of the consumer (one thread
+        parses ~3 GB/s: a third of what one GPU aligns)"""
+        if path.endswith('.bam'):
+            yield from _bam_chunks(path, win_reads)
+            return
+        if not _is_plain_fastx(path):
+            rd = Fastx(path, lib=lib)
+            yield from iter(lambda: rd.read(win_reads), None)
+            return
+        size = os.path.getsize(path)
+        lo, hi = (size * rank // world, size * (rank + 1) // world) if range_mode else (0, size)
+        target = max(1 << 20, int(float(os.environ.get('VMX_SLICE_MB', '1024')) * (1 << 20)))
+        ns = max(1, -(-(hi - lo) // target))
+        cuts = [lo + (hi - lo) * i // ns for i in range(ns + 1)]
+
+        def parse(a, b):
+            rd = Fastx(path, lib=lib, byte_range=(a, b))
+            try:
+                return list(iter(lambda: rd.read(win_reads), None))
+            finally:
+                rd.close()
+        with ThreadPoolExecutor(max_workers=parse_threads) as pool:
+            futs, nxt = [], 0
+            while nxt < ns or futs:
+                while nxt < ns and len(futs) < parse_threads + 1:
+                    futs.append(pool.submit(parse, cuts[nxt], cuts[nxt + 1])); nxt += 1
+                yield from futs.pop(0).result()
+
     def windows():
         """input records in arrival order as blobs (names, upper-cased sequences, qualities, comments), de-duplicated by name
-        (vacmap:457,475,487), one window of at most win_reads reads at a time"""
+        (vacmap:457,475,487; in range mode inside the rank's own part of the input), one window of at most win_reads reads at a time"""
         seen = set()
         for group in args.read:
             for path in group:
-                if path.endswith('.bam'):
-                    chunks = _bam_chunks(path, win_reads)
-                else:
-                    rd = Fastx(path, lib=lib)
-                    chunks = iter(lambda rd=rd: rd.read(win_reads), None)
-                for ch in chunks:
+                for ch in chunks_of(path):
                     n = len(ch['seqs_off']) - 1
                     nb, no = ch['names'].tobytes(), ch['names_off']
                     keep = []
@@ -434,7 +499,8 @@ def main(argv=None, comm=None):
             counts['reads'] += len(wnd['seqs_off']) - 1
             progress(counts['reads'])
             plan = pipeline.plan_batches(np.diff(wnd['seqs_off']), args.batch_reads, args.window_batches)
-            plan = [plan[i] for i in range(rank, len(plan), world)]        # static sharding: batch i -> rank i mod N
+            if not range_mode:
+                plan = [plan[i] for i in range(rank, len(plan), world)]        # static sharding: batch i -> rank i mod N (range mode: the rank's own reads)
             w = Window(wnd, plan)
             oq.put(w)
             for i in range(len(plan)):
@@ -456,6 +522,10 @@ def main(argv=None, comm=None):
             qb, qo = blob_gather(lib, wnd['quals'], wnd['quals_off'], ix) if w.has_q else (None, None)
             cb, co = blob_gather(lib, wnd['comments'], wnd['comments_off'], ix) if w.has_c else (None, None)
             text, toff, nl, ns = sam_emit(lib, index, opts, nb, no, sb, so, raw, quals=qb, qual_off=qo, comments=cb, com_off=co, nthreads=emit_threads)
+            if args.debug and ns:                       # the reference's per-read failure log (--debug, mammap_clrnano.py:24120-24123)
+                nbb = nb.tobytes() if hasattr(nb, 'tobytes') else bytes(nb)
+                for x in np.nonzero(np.asarray(raw.status) != 0)[0]:
+                    sys.stderr.write('vacmapx --debug: read %s skipped, status %d\n' % (nbb[int(no[x]):int(no[x + 1])].decode(errors='replace'), int(raw.status[x])))
             raw.close()
             with tml:
                 tm['job_emit'] += time.time() - t0
@@ -483,7 +553,7 @@ def main(argv=None, comm=None):
                 w.ready.set()
 
     out_fd = None
-    if rank == 0 and os.environ.get('VMX_DRIVER_WRITEV', '1') != '0':
+    if (rank == 0 or range_mode) and os.environ.get('VMX_DRIVER_WRITEV', '1') != '0':
         try:
             out_fd = out.fileno()
         except Exception:
@@ -503,7 +573,7 @@ def main(argv=None, comm=None):
                 nl, ns = sum(r[3] for r in done), sum(r[4] for r in done)
                 parts = [(ix, text, toff) for ix, text, toff, _, _ in done]
                 t0 = time.time()
-                if world > 1:
+                if world > 1 and not range_mode:
                     from .dist import gather_lines
                     allp = gather_lines((parts, nl, ns), dst=0, group=text_group)
                     if rank == 0:
@@ -549,10 +619,12 @@ def main(argv=None, comm=None):
     # (rocprofv3 trace of a 131 k-read run: no kernel resident 73 % of the time, 2 s batches; `profiles/r03_l_*`).
     if os.environ.get('VMX_NO_WARM') != '1':
         first = wq.get()
+        tm['first_window'] = time.time() - t_loop
         pending.append(first)
         if first is not None and not isinstance(first, BaseException):
             plan0 = pipeline.plan_batches(np.diff(first['seqs_off']), args.batch_reads, args.window_batches)
-            plan0 = [plan0[i] for i in range(rank, len(plan0), world)]
+            if not range_mode:
+                plan0 = [plan0[i] for i in range(rank, len(plan0), world)]
             if plan0:
                 ix0 = max(plan0, key=lambda ix: int(np.diff(first['seqs_off'])[ix].sum()))
                 sb0, so0 = blob_gather(lib, first['seqs'], first['seqs_off'], ix0)
@@ -585,12 +657,26 @@ def main(argv=None, comm=None):
     pipe.close()
     if pinned is not None:
         pinned.close()
+    if range_mode:
+        # every rank wrote its own part; the counts travel to rank 0 (three integers), which joins the parts in rank order (the reference's output order
+        # is not the input's either: mammap_clrnano.py:24147-24150)
+        out.close()
+        from .dist import gather_lines
+        allc = gather_lines((counts['reads'], counts['lines'], counts['skipped']), dst=0, group=text_group)
+        if rank == 0:
+            counts['reads'], counts['lines'], counts['skipped'] = (sum(c[i] for c in allc) for i in range(3))
+            if not args.parts:
+                tj = time.time()
+                _concat_parts(args.o, ['%s.part%03d' % (args.o, r) for r in range(world)])
+                last_timing['concat_parts'] = time.time() - tj
     if rank == 0:
         if proc is not None:
             out.close()
             rc = proc.wait()
             if rc != 0:
                 sys.stderr.write('Error: samtools exited with code %d\n' % rc)
+        elif range_mode:
+            pass
         elif args.o != '-':
             out.close()
         else:

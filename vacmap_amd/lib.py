@@ -168,7 +168,7 @@ class VmxLib:
         L.vm_pinned_alloc.argtypes = [i64, C.c_int]; L.vm_pinned_alloc.restype = vp
         L.vm_pinned_free.argtypes = [vp]; L.vm_pinned_free.restype = None
         L.vm_blob_gather_parts.argtypes = [vp, vp, vp, vp, i64, vp]; L.vm_blob_gather_parts.restype = i64
-        L.vm_fastx_open.argtypes = [cp, P(vp)]; L.vm_fastx_close.argtypes = [vp]
+        L.vm_fastx_open.argtypes = [cp, P(vp)]; L.vm_fastx_close.argtypes = [vp]; L.vm_fastx_open_range.argtypes = [cp, i64, i64, P(vp)]
         L.vm_fastx_read.argtypes = [vp, i64, i64] + [P(vp), P(P(i64))] * 4; L.vm_fastx_read.restype = i64
         L.vm_reads_upload.argtypes = [vp, i64, cp, vp, P(vp)]
         L.vm_reads_free.argtypes = [vp]
@@ -599,10 +599,14 @@ def blob_write_parts(lib, fd, blobs, offs, order_keys):
 class Fastx:
     """FASTA / FASTQ(.gz) reader into blobs (vm_fastx_*): the native counterpart of mp.fastx_read (vacmap:445)"""
 
-    def __init__(self, path, lib=None):
+    def __init__(self, path, lib=None, byte_range=None):
+        """byte_range = (begin, end): only the records whose first byte lies in [begin, end) of a plain file (vm_fastx_open_range)"""
         self.lib = lib or load()
         h = C.c_void_p()
-        self.lib.check(self.lib.L.vm_fastx_open(_b(path), C.byref(h)))
+        if byte_range is None:
+            self.lib.check(self.lib.L.vm_fastx_open(_b(path), C.byref(h)))
+        else:
+            self.lib.check(self.lib.L.vm_fastx_open_range(_b(path), int(byte_range[0]), int(byte_range[1]), C.byref(h)))
         self.h = h
 
     def read(self, max_reads, max_bases=1 << 62):
