@@ -55,6 +55,8 @@ __device__ __forceinline__ unsigned vmx_pk_max(unsigned a, unsigned b) {
     return vmx_pk(l, h);
 }
 __device__ __forceinline__ unsigned vmx_pk_neg(unsigned a) { return (vmx_pk_lo(a) < 0 ? 0xffffu : 0u) | (vmx_pk_hi(a) < 0 ? 0xffff0000u : 0u); }
+__device__ __forceinline__ unsigned vmx_pk_min_u16(unsigned a, unsigned b) { const unsigned al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16; return (al < bl ? al : bl) | ((ah < bh ? ah : bh) << 16); }
+__device__ __forceinline__ unsigned vmx_pk_mad(unsigned a, unsigned b, unsigned c) { return vmx_pk(vmx_pk_lo(a) * vmx_pk_lo(b) + vmx_pk_lo(c), vmx_pk_hi(a) * vmx_pk_hi(b) + vmx_pk_hi(c)); }
 __device__ __forceinline__ unsigned vmx_alignbit16(unsigned hi, unsigned lo) { return (hi << 16) | (lo >> 16); }
 #else
 typedef short vmx_v2s __attribute__((ext_vector_type(2)));
@@ -66,6 +68,8 @@ __device__ __forceinline__ unsigned vmx_pk_sub(unsigned a, unsigned b) { return 
 __device__ __forceinline__ unsigned vmx_pk_max(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(vmx_v2s, a), __builtin_bit_cast(vmx_v2s, b))); }
 // opaque on purpose: given the plain shift the compiler turns every use of the mask back into per-half compares and selects
 __device__ __forceinline__ unsigned vmx_pk_neg(unsigned a) { unsigned r; asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }
+__device__ __forceinline__ unsigned vmx_pk_min_u16(unsigned a, unsigned b) { unsigned r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned vmx_pk_mad(unsigned a, unsigned b, unsigned c) { unsigned r; asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ unsigned vmx_alignbit16(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
 #endif
 // low bytes of the two halves of a packed register, side by side in the low 16 bits (one v_perm_b32)

@@ -35,22 +35,32 @@ __device__ __forceinline__ int vmx_r16_shl1_in(int v, int in) { return __builtin
 __device__ __forceinline__ unsigned vmx_perm(unsigned s0, unsigned s1, unsigned sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
 #endif
 
-struct vmx_ad_consts { unsigned O1, O2, E1, E2, MATCH, MISM, ONE, NEGP; };
+// Scores are kept BIASED: a register half holds score + VMX_AD_BIAS, always in [0, 32767]. Every wave-instruction of the two-operand 32-bit
+// class (v_add_u32, v_sub_u32, v_and / or / xor, v_ashrrev_i32) issues in 2.3 cycles on gfx950, everything in the VOP3 / VOP3P / DPP class —
+// all packed-int16 arithmetic — in 4.2 (profiles/r04_q_valu_calibration.md). With non-negative halves that can neither borrow nor carry
+// into each other, subtracting a gap cost or adding the match score is a plain 32-bit subtract / add of the two halves at once, and a
+// half's sign bit becomes a traceback flag with one 32-bit arithmetic shift and a mask; only what compares two scores (v_pk_max_i16, the
+// sign of a v_pk_sub_i16) still needs the packed forms. 26 four-cycle + 22 two-cycle instructions per cell pair (was 40 + 9).
+//   Range: real cells of a problem with tl + ql <= 1024 score in [-1100, 1024]; "-infinity" is -4096 and loses at most 2 per step
+// (1024 steps) plus one gap opening, so with the bias 8192 every half stays in [2000, 9300].
+#define VMX_AD_BIAS 8192
+#define VMX_AD_NEGINF (-4096)
+struct vmx_ad_consts { unsigned O1, O2, E1, E2, MATCH, NMIS, ONE, NEGP; };
 
 // one cell (both halves): up = (H, E1, E2) of the cell above, left = (H, F1, F2) of the cell to the left, H = the diagonal predecessor on
 // entry and the cell's H on return; tc / qc = target / query codes. Returns the traceback byte (bits 0-6 of each half).
 __device__ __forceinline__ unsigned vmx_ad_cell(const vmx_ad_consts& K, unsigned upH, unsigned upE1, unsigned upE2, unsigned leftH, unsigned leftF1,
                                                 unsigned leftF2, unsigned tc, unsigned qc, unsigned& H, unsigned& E1, unsigned& E2, unsigned& F1, unsigned& F2) {
-    const unsigned a1 = vmx_pk_sub(upH, K.O1), a2 = vmx_pk_sub(upH, K.O2);
-    unsigned b = vmx_pk_neg(vmx_pk_sub(a1, upE1)) & 0x00080008u;                       // upE1 > a1: E1 extends
-    b |= vmx_pk_neg(vmx_pk_sub(a2, upE2)) & 0x00100010u;
-    const unsigned e1v = vmx_pk_sub(vmx_pk_max(a1, upE1), K.E1), e2v = vmx_pk_sub(vmx_pk_max(a2, upE2), K.E2);
-    const unsigned c1 = vmx_pk_sub(leftH, K.O1), c2 = vmx_pk_sub(leftH, K.O2);
-    b |= vmx_pk_neg(vmx_pk_sub(c1, leftF1)) & 0x00200020u;                             // F1 > c1
-    b |= vmx_pk_neg(vmx_pk_sub(c2, leftF2)) & 0x00400040u;
-    const unsigned f1v = vmx_pk_sub(vmx_pk_max(c1, leftF1), K.E1), f2v = vmx_pk_sub(vmx_pk_max(c2, leftF2), K.E2);
-    const unsigned eqm = vmx_pk_neg(vmx_pk_sub(tc ^ qc, K.ONE));                       // codes are 0..6: x - 1 < 0 iff x == 0
-    unsigned h = vmx_pk_add(H, vmx_bfi(eqm, K.MATCH, K.MISM));
+    const unsigned a1 = upH - K.O1, a2 = upH - K.O2;                                   // (32-bit subtract: no half borrows)
+    unsigned b = (unsigned)((int)vmx_pk_sub(a1, upE1) >> 12) & 0x00080008u;             // upE1 > a1: E1 extends (the halves' sign bits land on bits 3 and 19)
+    b |= (unsigned)((int)vmx_pk_sub(a2, upE2) >> 11) & 0x00100010u;
+    const unsigned e1v = vmx_pk_max(a1, upE1) - K.E1, e2v = vmx_pk_max(a2, upE2) - K.E2;
+    const unsigned c1 = leftH - K.O1, c2 = leftH - K.O2;
+    b |= (unsigned)((int)vmx_pk_sub(c1, leftF1) >> 10) & 0x00200020u;                   // F1 > c1
+    b |= (unsigned)((int)vmx_pk_sub(c2, leftF2) >> 9) & 0x00400040u;
+    const unsigned f1v = vmx_pk_max(c1, leftF1) - K.E1, f2v = vmx_pk_max(c2, leftF2) - K.E2;
+    // codes are 0..6: min(tc ^ qc, 1) = 1 on a mismatch; h = H + match - (match - mismatch) * that
+    unsigned h = vmx_pk_mad(vmx_pk_min_u16(tc ^ qc, K.ONE), K.NMIS, H) + K.MATCH;
     unsigned src = 0, m;
     m = vmx_pk_neg(vmx_pk_sub(h, e1v)); src = vmx_bfi(m, 0x00010001u, src); h = vmx_pk_max(h, e1v);
     m = vmx_pk_neg(vmx_pk_sub(h, f1v)); src = vmx_bfi(m, 0x00030003u, src); h = vmx_pk_max(h, f1v);     // ksw2's order: diagonal > E1 > F1 > E2 > F2
@@ -78,7 +88,7 @@ __device__ __forceinline__ void vmx_gapfill_fill_ad(const uint8_t* __restrict__ 
     const int l = lane & 15;
     vmx_ad_consts K;
     K.O1 = vmx_pk(o1, o1); K.O2 = vmx_pk(o2, o2); K.E1 = vmx_pk(e1, e1); K.E2 = vmx_pk(e2, e2);
-    K.MATCH = vmx_pk(match, match); K.MISM = vmx_pk(mismatch, mismatch); K.ONE = vmx_pk(1, 1); K.NEGP = vmx_pk(VMX_NEG16, VMX_NEG16);
+    K.MATCH = vmx_pk(match, match); K.NMIS = vmx_pk(mismatch - match, mismatch - match); K.ONE = vmx_pk(1, 1); K.NEGP = vmx_pk(VMX_AD_NEGINF + VMX_AD_BIAS, VMX_AD_NEGINF + VMX_AD_BIAS);
     const int afX = (tlX > 0 && qlX > 0) ? tlX + qlX : 0, afY = (tlY > 0 && qlY > 0) ? tlY + qlY : 0;     // the last anti-diagonal: cell (tl, ql)
     const int total = vmx_uniform_i32(vmx_wave_max_i32(afX > afY ? afX : afY));
     const int npairs = (total + 1) >> 1;                        // pair p = 1 ..: the odd step a = 2p - 1 (C sets), then the even step a = 2p (A sets)
@@ -100,7 +110,7 @@ __device__ __forceinline__ void vmx_gapfill_fill_ad(const uint8_t* __restrict__ 
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             const unsigned m = ((l == l0X && k == k0X) ? 0xffffu : 0u) | ((l == l0Y && k == k0Y) ? 0xffff0000u : 0u);
-            HA[k] = vmx_bfi(m, 0u, K.NEGP);
+            HA[k] = vmx_bfi(m, vmx_pk(VMX_AD_BIAS, VMX_AD_BIAS), K.NEGP);
             E1A[k] = K.NEGP; E2A[k] = K.NEGP; F1A[k] = K.NEGP; F2A[k] = K.NEGP;
             HC[k] = K.NEGP; E1C[k] = K.NEGP; E2C[k] = K.NEGP; F1C[k] = K.NEGP; F2C[k] = K.NEGP;
         }
@@ -183,8 +193,8 @@ __device__ __forceinline__ void vmx_gapfill_fill_ad(const uint8_t* __restrict__ 
             if (__any(p == poX || p == poY)) {
                 const unsigned aX = vmx_ad_pick<NS>(HA, kfX), cX = vmx_ad_pick<NS>(HC, kfX), aY = vmx_ad_pick<NS>(HA, kfY), cY = vmx_ad_pick<NS>(HC, kfY);
                 const unsigned vX = (afX & 1) ? cX : aX, vY = (afY & 1) ? cY : aY;
-                if (p == poX && l == lfX) finX = vmx_pk_lo(vX);
-                if (p == poY && l == lfY) finY = vmx_pk_hi(vY);
+                if (p == poX && l == lfX) finX = vmx_pk_lo(vX) - VMX_AD_BIAS;
+                if (p == poY && l == lfY) finY = vmx_pk_hi(vY) - VMX_AD_BIAS;
             }
         }
     }
