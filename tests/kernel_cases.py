@@ -946,3 +946,36 @@ def check_asm_ragged(ctx, O):
         assert mine == [t[1:] for t in orecs], (x, 'records differ from the oracle')
         n += len(mine)
     return n
+
+
+def check_local_many_chains(ctx, O, copies=80, unit=900, seed=91):
+    """mode S re-seeds EVERY chain of hit2work_1 (mammap_sensitive.py: no budget): a read with far more than 64 chains (the cap the local stage
+    had, DESIGN D5) — one per dispersed copy of its sequence — through vm_local_chain_batch vs the oracle: raw local anchors, variant, score, chain"""
+    from vacmap_amd.lib import Index, local_chain_batch
+    rng = np.random.default_rng(seed)
+    base = rand_seq(rng, unit)
+    parts, starts, pos = [], [], 0
+    for c in range(copies):
+        spacer = rand_seq(rng, 2600)
+        cp = mutate(rng, base, 0.02) if c else base
+        parts += [spacer, cp]; starts.append(pos + len(spacer)); pos += len(spacer) + len(cp)
+    ref = ''.join(parts) + rand_seq(rng, 3000)
+    gi = Index.from_seqs(ctx, ['c'], [np.frombuffer(ref.encode(), np.uint8)], k=15, w=10)
+    oi = O.Index.from_seqs(['c'], [ref], k=15, w=10)
+    read = mutate(rng, base, 0.03)
+    # one chain per copy, the true one first (descending read order, rows (q, r, strand, len)): anchors every ~150 bases along the copy's diagonal
+    qs = list(range(unit - 120, 40, -150))
+    paths = [np.array([[q, starts[c] + q, 1, 15] for q in qs], dtype=np.int64) for c in range(copies)]
+    assert len(paths) > 64
+    for mode in ('S', 'H'):
+        prm = ctx.lib.params(mode); oprm = O.params(mode)
+        g = local_chain_batch(ctx, gi, prm, [read.encode()], [paths])[0]
+        o = O.local_chain(oi, read.encode(), paths, oprm)
+        oraw = o['raw'][np.argsort(o['raw'][:, 0] + o['raw'][:, 3], kind='stable')] if len(o['raw']) else o['raw']
+        assert g['status'] == 0, (mode, g['status'])
+        assert np.array_equal(g['raw'], oraw), mode + ': raw local anchors differ from the oracle'
+        assert g['variant'] == o['variant'] and g['score'] == o['score'] and np.array_equal(g['chain'], o['chain']), mode
+        if mode == 'S':
+            rr = g['raw'][:, 1]
+            assert sum(bool(np.any((rr >= st) & (rr < st + unit))) for st in starts) > 64      # anchors inside more than 64 copies: every chain was re-seeded
+    gi.close()

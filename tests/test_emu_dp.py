@@ -77,6 +77,10 @@ def test_emu_seed_sparse_noise(ctx, oracle, monkeypatch):
     assert f(0) - t0 >= 8 and f(1) - d0 <= 6, (f(0) - t0, f(1) - d0)     # the filtered form answered (it declines check_num > 1024 and -1)
 
 
+def test_emu_local_many_chains(ctx, oracle):
+    KC.check_local_many_chains(ctx, oracle, copies=70, unit=500)
+
+
 def test_emu_local(ctx, oracle, golden):
     KC.check_local_golden(ctx, oracle, golden, cases=['B', 'D'])
     KC.check_local_golden(ctx, oracle, golden, cases=['P'])                  # mode R (_scar chains), 20 reads

@@ -90,6 +90,11 @@ def test_seed_golden(ctx, oracle, golden):
     KC.check_seed_golden(ctx, oracle, golden)
 
 
+def test_local_many_chains(ctx, oracle):
+    KC.check_local_many_chains(ctx, oracle)
+
+
+@pytest.mark.gpu
 def test_local_golden(ctx, oracle, golden):
     KC.check_local_golden(ctx, oracle, golden)
 

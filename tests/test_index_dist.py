@@ -464,3 +464,32 @@ def test_n_rank_driver_range_sharding_parts_gloo(ctx, tmp_path, monkeypatch):
         lines = [l for f in files for l in open(f)]
         assert [l for l in lines if l.startswith('@') and not l.startswith('@PG')] == header, (world, mode)       # the header once
         assert sorted(l for l in lines if not l.startswith('@')) == want, (world, mode)
+
+
+def test_driver_mode_asm_ignores_c_and_maxdivergence_reads_bam(ctx, tmp_path, monkeypatch):
+    """-mode asm through the command line: the fork hard-codes check_num = -1 and maxdivergence = 1.0 (mammap_asm.py:23206, :23483) whatever -c /
+    -maxdivergence say (the driver used to pass -c 100 on, keeping only the top 100 clusters), and contigs may come from a .bam"""
+    from vacmap_amd import synth, driver
+    import vacmap_amd.lib as VL
+    import vacmap_amd.driver as D
+    from test_host_logic import _write_bam
+    monkeypatch.setattr(VL, '_default', ctx.lib)
+    contigs = synth.make_reference([30000], seed=77)
+    fa = tmp_path / 'ref.fa'
+    fa.write_text('>c\n%s\n' % contigs[0].tobytes().decode())
+    q = [synth.mutate(contigs[0][a:b], 0.01, np.random.default_rng(a)).tobytes().decode() for a, b in ((2000, 6000), (10000, 13000))]
+    bam = tmp_path / 'asm.bam'
+    _write_bam(str(bam), [('k0', q[0], 'I' * len(q[0]), 0), ('k1', q[1], 'I' * len(q[1]), 0)])
+    seen = []
+    real = VL.align_batch_raw
+
+    def spy(cx, index, prm, sb, so):
+        seen.append((int(prm.check_num), float(prm.maxdivergence), int(prm.eqx)))
+        return real(cx, index, prm, sb, so)
+    monkeypatch.setattr(VL, 'align_batch_raw', spy)
+    out = tmp_path / 'asm.sam'
+    assert driver.main(['-ref', str(fa), '-read', str(bam), '-mode', 'asm', '-workdir', str(tmp_path / 'wd'), '-o', str(out), '-c', '100', '-maxdivergence', '0.2',
+                        '--nowriteindex', '--force']) == 0
+    assert seen and all(s == (-1, 1.0, 1) for s in seen), seen
+    body = [l.split('\t')[0] for l in open(out) if not l.startswith('@')]
+    assert sorted(set(body)) == ['k0', 'k1']

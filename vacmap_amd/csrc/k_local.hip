@@ -43,13 +43,13 @@ __global__ void k_orient(const uint8_t* __restrict__ codes, const int64_t* __res
 __global__ void k_local_prep(const vmx_anchor* __restrict__ path_rows, const int32_t* __restrict__ path_len, const int32_t* __restrict__ n_paths,
                              const int64_t* __restrict__ aoff, const double* __restrict__ gscore, int n_reads, int mode,
                              vmx_anchor* __restrict__ guide_rows, int32_t* __restrict__ guide_len, int32_t* __restrict__ n_guides_used,
-                             int32_t* __restrict__ n_guides_total) {
+                             int32_t* __restrict__ n_guides_total, int32_t* __restrict__ ws_pool) {
     int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (r >= n_reads) return;
     const int64_t a0 = aoff[r];
     n_guides_used[r] = 0; n_guides_total[r] = 0;
     if (gscore[r] == 0.0 || n_paths[r] <= 0) return;
-    vmx_local_prep(path_rows + a0, path_len + a0, n_paths[r], mode, guide_rows + a0, guide_len + a0, &n_guides_used[r], &n_guides_total[r]);
+    vmx_local_prep(path_rows + a0, path_len + a0, n_paths[r], mode, guide_rows + a0, guide_len + a0, &n_guides_used[r], &n_guides_total[r], ws_pool + VMX_PREP_WS * a0);      // (a read has at most as many paths as anchors)
 }
 
 // ------------------------------------------------------------------------------------------------ L2 seeding
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
         vmx_anchor* SORTED = A.la_sorted + A.la_off[r];
         const int out_cap = A.rd_off ? (int)(A.la_off[r + 1] - A.la_off[r]) : (int)(A.la_slot_len * VMX_LA_SLOT((int64_t)L));     // slot of this read in the local-anchor pools
         int n_out = 0;
-        int status = 0;
+        int status = ng > 511 ? VM_READ_CAPACITY_DEV : 0;          // (the guide index travels in 9 bits of the emission key)
         int gbase = 0;
         for (int g = 0; g < ng; ++g) {
             // NOTE: no barrier-skipping break/continue below: a failed guide sets `status` and every later phase of this guide runs on
@@ -503,11 +503,11 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             if (status == 0 && n_out > 0 && NO > A.hit_cap) status = VM_READ_CAPACITY_DEV;
             const long long no = status ? 0 : n_out;
             const long long NP = no > 0 ? NO : 0;
-            for (long long i = threadIdx.x; i < NP; i += blockDim.x) HKEY[i] = i < no ? ((OKEY[i] << 32) | (uint64_t)i) : ~0ULL;
+            for (long long i = threadIdx.x; i < NP; i += blockDim.x) HKEY[i] = i < no ? ((OKEY[i] << 27) | (uint64_t)i) : ~0ULL;      // guide (< 512) | final flag | stream index (26 bits), then the anchor's index (< 2^27)
             __syncthreads();
             if (NP > 1) vmx_block_sort_u64_tiled(HKEY, (int)NP, s_sort, VMX_SORT_LDS);
             __syncthreads();
-            for (long long e = threadIdx.x; e < no; e += blockDim.x) GOFF[e] = (int)(HKEY[e] & 0xffffffffu);   // rank e -> anchor index
+            for (long long e = threadIdx.x; e < no; e += blockDim.x) GOFF[e] = (int)(HKEY[e] & 0x7ffffffu);   // rank e -> anchor index
             __syncthreads();
             for (long long e = threadIdx.x; e < NP; e += blockDim.x) {
                 uint64_t kk = ~0ULL;

@@ -574,6 +574,8 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     std::vector<vmx_ext_read> er((size_t)n);
     std::vector<int64_t> h_gmax((size_t)n);
     *recs = (vm_record*)malloc(sizeof(vm_record) * (size_t)std::max<int64_t>(g_nr, 1)); *cigar_blob = (char*)malloc((size_t)std::max<int64_t>(g_nb, 1));
+    // every error return below hands the caller NULL outputs (callers raise without calling vm_free: ADVICE r3)
+    struct OutGuard { vm_record** r; char** b; bool keep = false; ~OutGuard() { if (!keep) { free(*r); free(*b); *r = nullptr; *b = nullptr; } } } out_guard{recs, cigar_blob};
     if (!*recs || !*cigar_blob) { set_error("out of host memory"); return VM_ERR_OOM; }
     VMX_TRY(download(fin, B.statblk.as<int64_t>() + 32, 14, c->stream));          // record / blob totals, overflow flag, tier counters, per-round problem counts: one copy
     VMX_TRY(download(er.data(), B.er.p, (size_t)n, c->stream)); VMX_TRY(download(h_gmax.data(), B.gmax.p, (size_t)n, c->stream));
@@ -631,6 +633,7 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
                 (long long)vmx::devbuf_stats().grows.load(), vmx::devbuf_stats().ns.load() * 1e-9);
     }
     if (stats) *stats = st;
+    out_guard.keep = true;
     return VM_OK;
 }
 

@@ -126,7 +126,9 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
 namespace {
 
 struct LinkRound {
-    vm_ctx* c = nullptr; int lc = 0, kmersize = 15, maxdiff = 50, maxgap = 1000, cap_pre = 4096; double skipcost = 30., margin_base = 0.;
+    // cap_pre: anchors of the slice carried between batches that the staging area holds (the reference keeps them all, mammap_asm.py:23250-23272):
+    // 2^18 — a repeat-rich window under check_num = -1 carried more than the 4096 of round 3 — 7 MB per contig in flight
+    vm_ctx* c = nullptr; int lc = 0, kmersize = 15, maxdiff = 50, maxgap = 1000, cap_pre = 1 << 18; double skipcost = 30., margin_base = 0.;
     DevBuf st, preS, preP, preR, rows, S, P, SA, job, gap, fSi, fT, fCNT;
     std::vector<std::vector<vmx_anchor>> saved_rows; std::vector<std::vector<int32_t>> saved_P;
     int64_t pre_g_max_index = 0; bool have = false; int cur_n_pre = 0;
@@ -162,7 +164,7 @@ struct LinkRound {
     }
     int finish(const vmx_link_job& hj, const vmx_link_state& hs, const std::vector<vmx_anchor>& rows_new) {
         if (hs.status == VM_LINK_RAISED) { set_error("asm: the reference raises on this contig (linked chain)"); return VM_READ_RAISED; }
-        if (hs.status != 0) { set_error(hs.status == VM_LINK_BAILED ? "asm: GC-exact bailed out; the fork's linked GC-fast is not on the device" : "asm: carried slice outside the stored index / staging area"); return VM_READ_UNSUPPORTED; }
+        if (hs.status != 0) { set_error(hs.status == VM_LINK_BAILED ? "asm: GC-exact bailed out and the batch was not re-run by the linked GC-fast" : "asm: carried slice outside the stored index / staging area"); return VM_READ_UNSUPPORTED; }
         if (!hj.ran) { set_error("asm: a linked batch did not run"); return VM_ERR_HIP; }
         have = true; pre_g_max_index = hs.pre_g_max_index;
         if (hj.saved) {

@@ -12,7 +12,7 @@
 #define VM_READ_CAPACITY_DEV (-20)
 #define VM_READ_RAISED_DEV (-10)
 #define VM_READ_BANDFALL_DEV (-23)   // k_local_seed_band hands the read to the general kernel k_local_seed (internal: never returned by vm_align_batch)
-#define VMX_MAX_PATHS 64     // secondaries beyond this are ignored by the product (reported through status)
+#define VMX_PREP_WS 7        // ints of scratch per path of a read that vmx_local_prep needs (no limit on the number of chains: mode S re-seeds them all)
 
 // :23231 acceptance of a table hit at `refloc` given the two closest guide anchors
 __host__ __device__ inline bool vmx_local_accept(long long refloc, long long ref1, long long ref2, long long interval, long long readgap) {
@@ -24,9 +24,9 @@ __host__ __device__ inline bool vmx_local_accept(long long refloc, long long ref
 // L1. paths: return_path_list of decode_hit (primary first), each in descending read order, concatenated in `rows` with lengths `len`.
 // out: the guide chains that will be re-seeded (in processing order), concatenated in out_rows (capacity = total anchors), lengths out_len;
 // *n_used = how many are re-seeded (<= 5 H, <= 3 L, all S), *n_total = len(list after drop_somechains) (> 1 selects LC-mm).
+// ws: VMX_PREP_WS * np ints of scratch.
 __host__ __device__ inline void vmx_local_prep(const vmx_anchor* rows, const int32_t* len, int np, int mode, vmx_anchor* out_rows,
-                                               int32_t* out_len, int32_t* n_used, int32_t* n_total) {
-    if (np > VMX_MAX_PATHS) np = VMX_MAX_PATHS;
+                                               int32_t* out_len, int32_t* n_used, int32_t* n_total, int32_t* ws) {
     if (mode == 3 || mode == 4) {
         // mode R (mammap_noprefercloser.py:23902-23914): every chain is re-seeded, in the order given, no merge / drop / cap
         // (-mode asm, mammap_asm.py:19714-19719: decode_hit returns the primary path only, and that one is re-seeded)
@@ -35,11 +35,11 @@ __host__ __device__ inline void vmx_local_prep(const vmx_anchor* rows, const int
         *n_used = np; *n_total = np;
         return;
     }
-    int start[VMX_MAX_PATHS];
+    int32_t* const start = ws;
     { int o = 0; for (int p = 0; p < np; ++p) { start[p] = o; o += len[p]; } }
     // a chain = ordered list of original paths (concatenation); next[] links, head/tail per chain
-    int head[VMX_MAX_PATHS], tail[VMX_MAX_PATHS], nxt[VMX_MAX_PATHS], clen[VMX_MAX_PATHS];
-    int chains[VMX_MAX_PATHS]; int nc = 0;
+    int32_t* const head = ws + np; int32_t* const tail = ws + 2 * np; int32_t* const nxt = ws + 3 * np; int32_t* const clen = ws + 4 * np;
+    int32_t* const chains = ws + 5 * np; int nc = 0;
     for (int p = 1; p < np; ++p) { head[p] = p; tail[p] = p; nxt[p] = -1; clen[p] = len[p]; chains[nc++] = p; }
     // chains.sort(key = start read position) stable
     for (int i = 1; i < nc; ++i) {
@@ -72,7 +72,7 @@ __host__ __device__ inline void vmx_local_prep(const vmx_anchor* rows, const int
     for (int i = 1; i < nc; ++i) { int c = chains[i]; int j = i - 1; while (j >= 0 && clen[chains[j]] > clen[c]) { chains[j + 1] = chains[j]; --j; } chains[j + 1] = c; }
     // list = [primary] + chains ; primary is "chain 0"
     head[0] = 0; tail[0] = 0; nxt[0] = -1; clen[0] = len[0];
-    int lst[VMX_MAX_PATHS]; int nl = 0;
+    int32_t* const lst = ws + 6 * np; int nl = 0;
     lst[nl++] = 0;
     // drop_somechains
     for (int ci = 0; ci < nc; ++ci) {

@@ -13,14 +13,14 @@ void vmx_index_view(const vm_index* mi, vm_index_view* v);
 struct vmx_preset { const vmx_anchor* chain_desc; int64_t len; };      // one per read of the call (align_device takes an array of n)
 
 struct vmx_local_bufs {
-    vmx::DevBuf sq, dst, rorder, pc2, stg, si, tg, cntp, fp, pp;
+    vmx::DevBuf sq, dst, rorder, pc2, stg, si, tg, cntp, fp, pp, prep_ws;
     vmx::DevBuf guide_rows, guide_len, ng_used, ng_total, cnt, cur, tpos, hkey, hkey2, dbg, hval, hq, goff, pcnt, gkey, gq, gr, epoch;
     vmx::DevBuf la_rows, la_ekey, la_sorted, la_off, la_cnt, status, gap, rlist, S, P, SA, chain, chain_len, score, variant;
     int64_t la_pool_rows = 0;            // rows of the local-anchor pools (regular slots + overflow area)
     std::vector<int64_t> h_la_off;
     std::vector<int32_t> h_la_cnt;
     void release() {
-        vmx::DevBuf* all[] = {&sq, &dst, &rorder, &pc2, &stg, &si, &tg, &cntp, &fp, &pp, &dbg, &epoch, &hkey2, &guide_rows, &guide_len, &ng_used, &ng_total, &cnt, &cur, &tpos, &hkey, &hval, &hq, &goff, &pcnt, &gkey, &gq, &gr,
+        vmx::DevBuf* all[] = {&prep_ws, &sq, &dst, &rorder, &pc2, &stg, &si, &tg, &cntp, &fp, &pp, &dbg, &epoch, &hkey2, &guide_rows, &guide_len, &ng_used, &ng_total, &cnt, &cur, &tpos, &hkey, &hval, &hq, &goff, &pcnt, &gkey, &gq, &gr,
                               &la_rows, &la_ekey, &la_sorted, &la_off, &la_cnt, &status, &gap, &rlist, &S, &P, &SA, &chain, &chain_len, &score, &variant};
         for (auto* b : all) b->release();
     }

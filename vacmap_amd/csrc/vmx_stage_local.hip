@@ -11,7 +11,7 @@
 using namespace vmx;
 
 __global__ void k_local_prep(const vmx_anchor* path_rows, const int32_t* path_len, const int32_t* n_paths, const int64_t* aoff, const double* gscore,
-                             int n_reads, int mode, vmx_anchor* guide_rows, int32_t* guide_len, int32_t* n_guides_used, int32_t* n_guides_total);
+                             int n_reads, int mode, vmx_anchor* guide_rows, int32_t* guide_len, int32_t* n_guides_used, int32_t* n_guides_total, int32_t* ws_pool);
 __global__ void k_local_seed(vmx_lseed_args A);
 __global__ void k_local_seed_band(vmx_lseed_args A);
 __global__ void k_chain_local_fast(const vmx_anchor* anchors, const int64_t* la_off, const int32_t* la_cnt, const int32_t* n_guides_total, int n_reads,
@@ -42,9 +42,9 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     const int64_t la_tot = la_regular + la_overflow;
     L.la_pool_rows = la_tot;
     VMX_TRY(L.guide_rows.reserve(sizeof(vmx_anchor) * (size_t)(tot_anchors + 1))); VMX_TRY(L.guide_len.reserve(4 * (size_t)(tot_anchors + 1)));
-    VMX_TRY(L.ng_used.reserve(4 * (size_t)(n + 1))); VMX_TRY(L.ng_total.reserve(4 * (size_t)(n + 1)));
+    VMX_TRY(L.ng_used.reserve(4 * (size_t)(n + 1))); VMX_TRY(L.ng_total.reserve(4 * (size_t)(n + 1))); VMX_TRY(L.prep_ws.reserve(4 * VMX_PREP_WS * (size_t)(tot_anchors + 1)));
     hipLaunchKernelGGL(k_local_prep, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, d_path_rows, d_path_len, d_npaths, d_aoff, d_gscore, (int)n,
-                       prm->mode, L.guide_rows.as<vmx_anchor>(), L.guide_len.as<int32_t>(), L.ng_used.as<int32_t>(), L.ng_total.as<int32_t>());
+                       prm->mode, L.guide_rows.as<vmx_anchor>(), L.guide_len.as<int32_t>(), L.ng_used.as<int32_t>(), L.ng_total.as<int32_t>(), L.prep_ws.as<int32_t>());
     // scratch per workgroup slot
     // exactly as many workgroups as the device keeps resident; they pull reads longest-first from a device-side queue
     const int TPB = 512;
