@@ -71,7 +71,7 @@ def main():
     ap.add_argument('--err', type=float, default=None, help='default: the config\'s (0.10 ONT, 0.005 HiFi)')
     ap.add_argument('--cpu-sample', type=int, default=96, help='minimum reads for the CPU baseline leg (rank 0, N=1 only); 0 disables')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='target wall time of the CPU baseline leg (the sample is sized by a pilot)')
-    ap.add_argument('--streams', type=int, default=3, help='batches in flight per GPU (vacmap_amd.pipeline)')
+    ap.add_argument('--streams', type=int, default=4, help='batches in flight per GPU (vacmap_amd.pipeline)')
     ap.add_argument('--window-batches', type=int, default=16, help='length binning window of the scheduler, in batches')
     ap.add_argument('--arrival-order', action='store_true', help='no length binning: batches in arrival order (measured once for comparison)')
     ap.add_argument('--host-input', action='store_true', help='also time the same batches handed over as HOST buffers (vm_align_batch uploads them: the PCIe-inclusive rate; reported next to `value`, never as it)')
@@ -241,6 +241,7 @@ def main():
         _free, _tot = torch.cuda.mem_get_info(local_rank); hbm_used_gb = (_tot - _free) / 1e9      # index + reads + every context's work pools
         algo_bytes = (agg['read_bases'] + 16 * agg['n_minimizers'] + 8 * agg['n_anchors'] + (agg['read_bases'] + 14000 * agg['n_reads']) / 4.0 +
                       40 * agg['n_records'] + agg['cigar_bytes'])
+        # ('k_local_seed' = the local stage's main launch: k_local_seed_band since round 4)
         kms = {'k_gapfill_fill_ns': agg['ms_gapfill_fill'] / K, 'k_local_seed': agg.get('ms_local_seed', 0.0) / K, 'k_cluster_big': agg.get('ms_cluster', 0.0) / K}
         # what each of them must move at the least (its own algorithmic bytes per step): fill = the DP strings + one traceback byte per band
         # cell; local re-seeding = the read (1 B/base) + the 2-bit reference window (SURVEY 8(d)'s (L + 14000)/4); clustering = 8 B per hit in, 32 B per anchor out
@@ -254,7 +255,8 @@ def main():
         per_kernel = {}
         for kn in kms:
             e = {'ms_per_step': kms[kn], 'kernel_algorithmic_bytes_per_step': kalgo[kn], 'traffic': None, 'traffic_over_algorithmic': None, 'valu': None}
-            pk = ((pj or {}).get('kernels') or {}).get(kn if kn != 'k_cluster_big' or 'k_cluster_big' in ((pj or {}).get('kernels') or {}) else 'k_cluster')
+            pks = (pj or {}).get('kernels') or {}
+            pk = pks.get('k_local_seed_band' if kn == 'k_local_seed' and 'k_local_seed_band' in pks else (kn if kn != 'k_cluster_big' or 'k_cluster_big' in pks else 'k_cluster'))
             if pk:
                 e['traffic'] = pk.get('hbm_bytes_per_step'); e['valu'] = pk.get('valu')
                 if e['traffic'] and kalgo[kn] > 0:

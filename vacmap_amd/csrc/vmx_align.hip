@@ -428,10 +428,11 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
         hipLaunchKernelGGL(k_dp_sizes, dim3(G), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.dpsz[0].as<int64_t>(), B.dpsz[1].as<int64_t>(),
                            B.dpsz[2].as<int64_t>(), B.dpsz[3].as<int64_t>());
         for (int i = 0; i < 4; ++i) VMX_TRY(dev_scan_dev(c, B, B.dpsz[i].as<int64_t>(), B.dpoff[i].as<int64_t>(), B.rcount.as<int32_t>()));
+        static const int64_t tb_chunk = [] { const char* e = getenv("VMX_TB_CHUNK_GB"); const double v = e ? atof(e) : 0.0; return v > 0.5 ? (int64_t)(v * (double)(1 << 30)) : (int64_t)VMX_TB_CHUNK; }();     // tuning knob
         // sizing sync #3 (the only one of the round): problem count, pool totals, chunk cuts (at most VMX_TB_CHUNK traceback bytes per chunk)
         int64_t plan[8 + 2 * (VMX_MAX_CHUNKS + 1)];
         hipLaunchKernelGGL(k_tb_plan, dim3(1), dim3(1), 0, c->stream, B.dpoff[0].as<int64_t>(), B.dpoff[1].as<int64_t>(), B.dpoff[2].as<int64_t>(), B.dpoff[3].as<int64_t>(),
-                           B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.rcount.as<int32_t>(), (int64_t)VMX_TB_CHUNK, B.statblk.as<int64_t>() + 64);
+                           B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.rcount.as<int32_t>(), tb_chunk, B.statblk.as<int64_t>() + 64);
         VMX_TRY(download(plan, B.statblk.as<int64_t>() + 64, sizeof(plan) / 8, c->stream));
         VMX_HIP(vmx_stream_sync(c));
         const int cnt = (int)plan[0];

@@ -142,7 +142,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     A.la_slot_len = 1;
     (void)hipEventRecord(c->kev[0], c->stream);
     // (the banded form keeps no hits in HBM: its per-slot pools hold the chunk log and the anchors' sort keys only)
-    int64_t hit_cap_b = 1; while (hit_cap_b < Lmax + 8192) hit_cap_b <<= 1;
+    int64_t hit_cap_b = 1; while (hit_cap_b < Lmax / 2 + 8192) hit_cap_b <<= 1;        // >= the read's anchor slot (len / 2 + 4096) and its chunk log (~0.25 records per base)
     VMX_TRY(run_seed((int)n, band_on ? GB : G, band_on ? hit_cap_b : hit_cap, band_on));
     (void)hipEventRecord(c->kev[1], c->stream); c->kev_set |= 1;
     // sizing sync #2: local anchor counts decide the LDS bucket of every read in the local chain DP
