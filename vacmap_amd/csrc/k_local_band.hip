@@ -39,6 +39,7 @@
 #include "vmx_local_dev.h"
 
 #define LB_NBLOG VMX_LB_NBLOG
+#define LB_BMMASK ((1u << VMX_LB_BMLOG) - 1u)
 #define LB_NB (1 << LB_NBLOG)       // bucket heads of the chunk table
 #define LB_OPEN 32                  // runs that may cross one chunk boundary
 #define LB_PIECES 16                // disjoint band intervals of a chunk (after clipping to the windows)
@@ -48,7 +49,7 @@
 #define LB_QB 26                    // bits of a hit key that hold the read position (relative to the read window)
 #define LB_SEQB 13                  // bits of a log key that hold the chunk number
 
-static_assert(VMX_LB_HCAP <= VMX_LB_SORTK && 2 * VMX_LB_QC < (1 << 13), "k_local_seed_band: LDS layout");
+static_assert(VMX_LB_GS <= 128 && VMX_LB_HCAP <= VMX_LB_SORTK && 2 * VMX_LB_QC < (1 << 13), "k_local_seed_band: LDS layout");
 __device__ __forceinline__ int vmx_bits_u64(unsigned long long v) { int b = 0; while (b < 64 && (v >> b)) ++b; return b; }
 
 // k-mers of the 8 consecutive positions x .. x + 7 of a 1-byte-per-base code array (any alignment; the arrays are padded by 64 bytes):
@@ -66,10 +67,28 @@ __device__ __forceinline__ unsigned vmx_kmers8_w(uint64_t w0, uint64_t w1, uint6
     }
     return ok;
 }
+// The same for k <= 9 in a dozen instructions per position less: the 16 bases are packed to 2 bits each first (base i at bits 2 i .. 2 i + 1), and
+// the key of position j is bits 2 j .. 2 j + 2 k - 1 of that word — the k-mer with its FIRST base lowest. Keys never leave the kernel (bucket,
+// occupancy bit, equality), so any one-to-one coding serves as long as the read and the band use the same one; the reverse complement is
+// the same bit operation in either coding (complement, reverse the order of the 2-bit groups).
+__device__ __forceinline__ uint32_t lb_pack4(uint32_t w) { uint32_t x = w & 0x03030303u; x = (x | (x >> 6)) & 0x000F000Fu; return (x | (x >> 12)) & 0xFFu; }
+__device__ __forceinline__ uint32_t lb_bad4(uint32_t w) { uint32_t y = (w >> 2) & 0x01010101u; y = (y | (y >> 7)) & 0x00030003u; return (y | (y >> 14)) & 0xFu; }
+__device__ __forceinline__ unsigned vmx_kmers8_le(uint64_t w0, uint64_t w1, int k, uint32_t KMASK, uint32_t km[8]) {
+    const uint32_t a = (uint32_t)w0, b = (uint32_t)(w0 >> 32), c = (uint32_t)w1, d = (uint32_t)(w1 >> 32);
+    const uint32_t P = lb_pack4(a) | (lb_pack4(b) << 8) | (lb_pack4(c) << 16) | (lb_pack4(d) << 24);
+    uint32_t bad = 0;
+    if ((a | b | c | d) & 0x04040404u) bad = lb_bad4(a) | (lb_bad4(b) << 4) | (lb_bad4(c) << 8) | (lb_bad4(d) << 12);     // codes above 3: ambiguous bases (rare)
+    const uint32_t kb = (1u << k) - 1u;
+    unsigned ok = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { km[j] = (P >> (2 * j)) & KMASK; if (((bad >> j) & kb) == 0u) ok |= 1u << j; }
+    return ok;
+}
 __device__ __forceinline__ unsigned vmx_kmers8(const uint8_t* base, int k, uint32_t KMASK, uint32_t km[8]) {
     uint64_t w0, w1, w2 = 0;
     __builtin_memcpy(&w0, base, 8); __builtin_memcpy(&w1, base + 8, 8);
-    if (k > 9) __builtin_memcpy(&w2, base + 16, 8);
+    if (k <= 9) return vmx_kmers8_le(w0, w1, k, KMASK, km);
+    __builtin_memcpy(&w2, base + 16, 8);
     return vmx_kmers8_w(w0, w1, w2, k, KMASK, km);
 }
 
@@ -113,7 +132,7 @@ __global__ void __launch_bounds__(64, VMX_LB_WAVES) k_local_seed_band(vmx_lseed_
     uint32_t* const s_cq = (uint32_t*)(s_hit + VMX_LB_HCAP);   // candidates of one sweep over the band: (lane * 8 + j) << 22 | k-mer
     __shared__ int s_gq[VMX_LB_GS];
     __shared__ long long s_gr[VMX_LB_GS];
-    __shared__ unsigned short s_seg[VMX_LB_QC];
+    __shared__ unsigned char s_seg[VMX_LB_QC];               // closest staged guide anchor of every chunk position << 1 | (the next one too)
     __shared__ long long s_iv[LB_WIN][2];
     __shared__ int s_ivbase[LB_WIN + 1];
     __shared__ long long s_pc[LB_PIECES][2];
@@ -311,15 +330,16 @@ __global__ void __launch_bounds__(64, VMX_LB_WAVES) k_local_seed_band(vmx_lseed_
                 for (int i0 = 8 * tid; i0 < qlen; i0 += 8 * T) {                          // eight consecutive positions per lane: one bisection, then the slice is walked
                     int lo = 0, hi = ns;
                     { const int p = q0 + i0; while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_gq[mid] <= p) lo = mid + 1; else hi = mid; } }
+                    int gcur = lo < ns ? s_gq[lo] : 0x7fffffff, gprev = lo > 0 ? s_gq[lo - 1] : -1;      // (kept in registers: the slice is read only when the walk advances)
                     for (int j = 0; j < 8 && i0 + j < qlen; ++j) {
                         const int p = q0 + i0 + j;
-                        while (lo < ns && s_gq[lo] <= p) ++lo;                         // first staged anchor beyond p
+                        while (gcur <= p) { gprev = gcur; ++lo; gcur = lo < ns ? s_gq[lo] : 0x7fffffff; }      // first staged anchor beyond p
                         int c0, c1;
-                        if (lo > 0 && s_gq[lo - 1] == p) c0 = c1 = lo - 1;
+                        if (lo > 0 && gprev == p) c0 = c1 = lo - 1;
                         else if (lo == 0) c0 = c1 = 0;
                         else if (lo == ns) c0 = c1 = ns - 1;
                         else { c0 = lo - 1; c1 = lo; }
-                        s_seg[i0 + j] = (unsigned short)((c0 << 1) | (c1 != c0 ? 1 : 0));
+                        s_seg[i0 + j] = (unsigned char)((c0 << 1) | (c1 != c0 ? 1 : 0));
                     }
                 }
                 // the reference positions :23231 can accept for the chunk's positions, per guide anchor / segment between two anchors / head / tail
@@ -397,7 +417,7 @@ __global__ void __launch_bounds__(64, VMX_LB_WAVES) k_local_seed_band(vmx_lseed_
                 // ---------------------------------------------------------------- the chunk's 9-mers (both strands) in the LDS table
                 // (heads and entries lie below the interval list: disjoint)
                 for (int i = tid; i < LB_NB; i += T) s_head[i] = 0u;
-                for (int i = tid; i < 512; i += T) s_bm[i] = 0u;
+                for (int i = tid; i < (1 << (VMX_LB_BMLOG - 5)); i += T) s_bm[i] = 0u;
                 __syncthreads();
                 const int npc = s_fail ? 0 : s_npc;
                 VMX_T(7);
@@ -414,8 +434,8 @@ __global__ void __launch_bounds__(64, VMX_LB_WAVES) k_local_seed_band(vmx_lseed_
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {                                        // all exchanges in flight together, the links afterwards
-                        if ((use >> j) & 1u) { of[j] = atomicExch(&s_head[km[j] & (LB_NB - 1)], (uint32_t)(2 * (i0 + j) + 1)); atomicOr(&s_bm[(km[j] & 0x3fffu) >> 5], 1u << (km[j] & 31u)); }
-                        if ((user >> j) & 1u) { orv[j] = atomicExch(&s_head[rvs[j] & (LB_NB - 1)], (uint32_t)(2 * (i0 + j) + 2)); atomicOr(&s_bm[(rvs[j] & 0x3fffu) >> 5], 1u << (rvs[j] & 31u)); }
+                        if ((use >> j) & 1u) { of[j] = atomicExch(&s_head[km[j] & (LB_NB - 1)], (uint32_t)(2 * (i0 + j) + 1)); atomicOr(&s_bm[(km[j] & LB_BMMASK) >> 5], 1u << (km[j] & 31u)); }
+                        if ((user >> j) & 1u) { orv[j] = atomicExch(&s_head[rvs[j] & (LB_NB - 1)], (uint32_t)(2 * (i0 + j) + 2)); atomicOr(&s_bm[(rvs[j] & LB_BMMASK) >> 5], 1u << (rvs[j] & 31u)); }
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -438,57 +458,73 @@ __global__ void __launch_bounds__(64, VMX_LB_WAVES) k_local_seed_band(vmx_lseed_
                 // passing (position, k-mer) pairs are packed into a queue with a ballot; (2) the queue is drained one candidate per lane: bucket
                 // list, exact k-mer check, the filter of :23231. (As one loop per position the list walks of 64 lanes ran in lockstep behind the
                 // longest of them: 60 us per chunk.)
+                // Candidates of several sweeps share the queue when their positions fit next to the k-mer in 32 bits (relative to the band's first
+                // position): after a sweep only whole groups of 64 are drained, the remainder (< 64) waits for the next sweep's — every lane busy
+                // in the bucket walks. Otherwise (a band spread over > 2^(32 - 2k) positions, k > 9) the queue is emptied after every sweep.
+                const int relbits = 32 - 2 * k;
+                const long long xbase_all = npc ? s_pc[0][0] : 0;
+                const bool accumulate = npc > 0 && k <= 9 && (s_pc[npc - 1][1] - xbase_all) < (1LL << relbits);
+                int ncq = 0;
+                auto drain = [&](int cnt, long long xb) {                                 // candidates [0, cnt) of the queue; x = xb + the entry's offset
+                    for (int c = tid; c < cnt; c += T) {
+                        const uint32_t cw = s_cq[c];
+                        const uint32_t km = cw & KMASK;
+                        const long long x = xb + (long long)(cw >> (2 * k));
+                        const uint32_t chk = km >> LB_NBLOG;
+                        for (uint32_t e = s_head[km & (LB_NB - 1)]; e != 0u;) {
+                            const uint32_t ent = s_ent[e - 1];
+                            if ((ent >> 13) == chk) {
+                                const int i = (int)((e - 1) >> 1), sb = (int)((e - 1) & 1);
+                                const int q = q0 + i;
+                                const int sg = s_seg[i], c0 = sg >> 1, c1 = c0 + (sg & 1);
+                                int b0 = s_gq[c0] - q; if (b0 < 0) b0 = -b0;
+                                int b1 = s_gq[c1] - q; if (b1 < 0) b1 = -b1;
+                                long long interval = (long long)b0 + b1 + 500; if (interval > 2000) interval = 2000;
+                                if (vmx_local_accept(x, s_gr[c0], s_gr[c1], interval, (long long)b0)) {
+                                    const unsigned long long drel = (unsigned long long)(sb ? (x - wlo) + (q - readstart) : (x - wlo) + (readend - 1 - q));
+                                    const int o = atomicAdd(&s_nhit, 1);
+                                    if (o < VMX_LB_HCAP) s_hit[o] = (((((uint64_t)sb << dbits) | drel) << LB_QB) | (uint64_t)(unsigned)(q - readstart));
+                                }
+                            }
+                            e = ent & 0x1fffu;
+                        }
+                    }
+                };
                 for (int pc = 0; pc < npc; ++pc) {
                     const long long lo = s_pc[pc][0], hi = s_pc[pc][1];
                     uint64_t wn0 = 0, wn1 = 0;                                           // the next sweep's bases are on their way while this one is probed
                     if (lo + 8LL * tid < hi) { __builtin_memcpy(&wn0, A.ref + lo + 8LL * tid, 8); __builtin_memcpy(&wn1, A.ref + lo + 8LL * tid + 8, 8); }
                     for (long long xs = lo; xs < hi; xs += 8LL * T) {
                         const long long x0 = xs + 8LL * tid;
-                        int ncq = 0;
+                        const long long xb = accumulate ? xbase_all : xs;
                         {
                             uint32_t kms[8]; unsigned okm = 0;
                             const uint64_t w0 = wn0, w1 = wn1; uint64_t w2 = 0;
                             if (x0 + 8LL * T < hi) { __builtin_memcpy(&wn0, A.ref + x0 + 8LL * T, 8); __builtin_memcpy(&wn1, A.ref + x0 + 8LL * T + 8, 8); }
-                            if (x0 < hi) { if (k > 9) __builtin_memcpy(&w2, A.ref + x0 + 16, 8); okm = vmx_kmers8_w(w0, w1, w2, k, KMASK, kms); }
+                            if (x0 < hi) { if (k > 9) { __builtin_memcpy(&w2, A.ref + x0 + 16, 8); okm = vmx_kmers8_w(w0, w1, w2, k, KMASK, kms); } else okm = vmx_kmers8_le(w0, w1, k, KMASK, kms); }
                             uint32_t bw[8];
                             if (x0 >= hi) { for (int j = 0; j < 8; ++j) kms[j] = 0u; }
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) bw[j] = s_bm[(kms[j] & 0x3fffu) >> 5];          // all eight words in flight together
+                            for (int j = 0; j < 8; ++j) bw[j] = s_bm[(kms[j] & LB_BMMASK) >> 5];          // all eight words in flight together
+                            const uint32_t rel0 = (uint32_t)(x0 - xb);
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
                                 const bool pass = x0 + j < hi && ((okm >> j) & 1u) && ((bw[j] >> (kms[j] & 31u)) & 1u);
                                 const unsigned long long bal = __ballot(pass);
-                                if (pass) s_cq[ncq + __popcll(bal & ((1ULL << vmx_lane()) - 1ULL))] = ((uint32_t)(8 * tid + j) << 22) | kms[j];
+                                if (pass) s_cq[ncq + __popcll(bal & ((1ULL << vmx_lane()) - 1ULL))] = ((rel0 + (uint32_t)j) << (2 * k)) | kms[j];
                                 ncq += __popcll(bal);
                             }
                         }
                         __syncthreads();
-                        for (int c = tid; c < ncq; c += T) {
-                            const uint32_t cw = s_cq[c];
-                            const uint32_t km = cw & 0x3fffffu;
-                            const long long x = xs + (long long)(cw >> 22);
-                            const uint32_t chk = km >> LB_NBLOG;
-                            for (uint32_t e = s_head[km & (LB_NB - 1)]; e != 0u;) {
-                                const uint32_t ent = s_ent[e - 1];
-                                if ((ent >> 13) == chk) {
-                                    const int i = (int)((e - 1) >> 1), sb = (int)((e - 1) & 1);
-                                    const int q = q0 + i;
-                                    const int sg = s_seg[i], c0 = sg >> 1, c1 = c0 + (sg & 1);
-                                    int b0 = s_gq[c0] - q; if (b0 < 0) b0 = -b0;
-                                    int b1 = s_gq[c1] - q; if (b1 < 0) b1 = -b1;
-                                    long long interval = (long long)b0 + b1 + 500; if (interval > 2000) interval = 2000;
-                                    if (vmx_local_accept(x, s_gr[c0], s_gr[c1], interval, (long long)b0)) {
-                                        const unsigned long long drel = (unsigned long long)(sb ? (x - wlo) + (q - readstart) : (x - wlo) + (readend - 1 - q));
-                                        const int o = atomicAdd(&s_nhit, 1);
-                                        if (o < VMX_LB_HCAP) s_hit[o] = (((((uint64_t)sb << dbits) | drel) << LB_QB) | (uint64_t)(unsigned)(q - readstart));
-                                    }
-                                }
-                                e = ent & 0x1fffu;
-                            }
-                        }
+                        const int take = accumulate ? (ncq & ~63) : ncq;
+                        drain(take, xb);
+                        __syncthreads();
+                        if (take < ncq) { uint32_t v = 0; if (tid < ncq - take) v = s_cq[take + tid]; __syncthreads(); if (tid < ncq - take) s_cq[tid] = v; }
+                        ncq -= take;
                         __syncthreads();
                     }
                 }
+                drain(ncq, xbase_all);
                 __syncthreads();
                 const int nhit = s_nhit;
                 if (A.dbg && tid == 0) atomicAdd(&A.dbg[11], (unsigned long long)nhit);

@@ -110,12 +110,15 @@ struct vmx_lseed_args {
 #endif
 #define VMX_LB_GS 64
 #endif
+#ifndef VMX_LB_BMLOG
+#define VMX_LB_BMLOG 14              /* log2 of the bits of the chunk table's occupancy map */
+#endif
 #ifndef VMX_LB_WAVES
 #define VMX_LB_WAVES 2               /* waves per SIMD the register allocation of k_local_seed_band is held to */
 #endif
-#define VMX_LB_TABLE_U64 (((1 << VMX_LB_NBLOG) + 2 * VMX_LB_QC + 512) / 2)          /* heads + entries + occupancy map, in 8-byte units */
+#define VMX_LB_TABLE_U64 (((1 << VMX_LB_NBLOG) + 2 * VMX_LB_QC + (1 << (VMX_LB_BMLOG - 5))) / 2)          /* heads + entries + occupancy map, in 8-byte units */
 #define VMX_LB_REGION_U64 (VMX_LB_SORTK > VMX_LB_TABLE_U64 ? VMX_LB_SORTK : VMX_LB_TABLE_U64)
-#define VMX_LB_CQ_BYTES (128 + 2 * VMX_LB_HCAP > 2048 ? 128 + 2 * VMX_LB_HCAP : 2048)     /* candidate queue of one sweep (512 words); later the run walk's marks + one index per hit */
+#define VMX_LB_CQ_BYTES (128 + 2 * VMX_LB_HCAP > 2304 ? 128 + 2 * VMX_LB_HCAP : 2304)     /* candidate queue: one sweep (512 words) + the < 64 left over from the sweep before; later the run walk's marks + one index per hit */
 #define VMX_LB_LDS_BYTES (8 * (VMX_LB_REGION_U64 + VMX_LB_HCAP) + VMX_LB_CQ_BYTES)
 #define VMX_ED_WAVES 16              // max waves per workgroup of k_edit_distance (passes pipelined across them) = carry ring depth
 #define VMX_ED_LONG 16384            // patterns longer than this (> 4 passes) go to the 16-wave launch
