@@ -476,6 +476,120 @@ __global__ void __launch_bounds__(64) k_chain_linked_win(vmx_link_job* __restric
 //   3 wave   read positions of the chain nodes (cq[t] = A[cidx[t]].q: the loads lane 0 used to make one after the other at HBM latency)
 //   4 lane 0 order / read bins / primaries / MAPQ / secondaries on LDS arrays
 //   5 wave   copy of the selected paths (decode_hit :23981-24020)
+// hit2work_1's peel (:23588-23640, vmx_select_peel) on the whole wavefront. The serial form visits the chain ends in descending S (S_arg) and
+// walks each down its predecessors until it meets an anchor an earlier chain took: an anchor therefore belongs to the end with the highest
+// priority (position in S_arg; the best chain's end above all) among the anchors whose predecessor path leads through it — the maximum of
+// the priorities over its SUBTREE in the predecessor forest. That maximum, every anchor's depth and its root come out of ceil(log2(depth))
+// rounds of pointer doubling (M'[J[a]] = max(M[J[a]], M[a]), J' = J o J, D' = D + D o J); a chain is then the stretch of one owner along
+// a path, its last anchor ("bottom") the one whose predecessor has another owner, its score S[end] - S[predecessor of the bottom], and the
+// serial order of the kept chains is descending priority: one scan over the priorities lays out cscore / coff, and every anchor writes
+// itself to cidx at (its chain's offset) + (depth of the end) - (its depth). Same cscore / coff / cidx as the serial peel, bit for bit
+// (the score is the same single subtraction). lds: 16 n bytes; n < 65535.
+__device__ __forceinline__ int vmx_select_peel_wave(int n, const double* __restrict__ S, const int32_t* __restrict__ P, const int32_t* __restrict__ SA, int gmax, int mode,
+                                                    char* lds, double* cscore, int* coff, int* cidx, int lane) {
+    uint32_t* M = (uint32_t*)lds; uint32_t* Mn = M + n;
+    unsigned short* J = (unsigned short*)(Mn + n); unsigned short* Jn = J + n; unsigned short* D = Jn + n; unsigned short* Dn = D + n;
+    for (int x = lane; x < n; x += 64) M[SA[x]] = (uint32_t)x;
+    __syncthreads();
+    for (int a = lane; a < n; a += 64) {
+        const uint32_t pr = a == gmax ? (uint32_t)n : M[a];
+        const int p = P[a];
+        M[a] = pr; Mn[a] = pr; J[a] = (unsigned short)(p == VMX_NOPRE ? a : p); D[a] = p == VMX_NOPRE ? 0 : 1;
+    }
+    __syncthreads();
+    for (int round = 0; round < 17; ++round) {
+        bool ch = false;
+        for (int a = lane; a < n; a += 64) {
+            const int j = J[a];
+            if (j != a) atomicMax(&Mn[j], M[a]);
+            const int jj = J[j];
+            Jn[a] = (unsigned short)jj; Dn[a] = (unsigned short)(D[a] + D[j]); ch = ch || jj != j;
+        }
+        __syncthreads();
+        for (int a = lane; a < n; a += 64) { M[a] = Mn[a]; J[a] = Jn[a]; D[a] = Dn[a]; }
+        __syncthreads();
+        if (!__any(ch)) break;
+    }
+    // bottoms: the last anchor of every owner's stretch (priority n = the best chain, whose stretch runs to a root)
+    uint32_t* BOT = Mn;
+    for (int a = lane; a < n; a += 64) BOT[a] = 0xffffffffu;
+    __syncthreads();
+    for (int a = lane; a < n; a += 64) {
+        const int p = P[a]; const uint32_t o = M[a];
+        if (o < (uint32_t)n && (p == VMX_NOPRE || M[p] != o)) BOT[o] = (uint32_t)a;
+    }
+    __syncthreads();
+    const double scores = S[gmax];
+    if (!(scores > 40)) return -1;                                   // hit == False: unmapped whatever follows
+    const double accept = (mode == 0) ? 60.0 : 40.0;
+    unsigned short* CH = Jn; unsigned short* CO = Dn;               // chain index / offset of a priority's chain (0xffff: dropped or none)
+    int nch = 1, w = (int)D[gmax] + 1;
+    if (lane == 0) { cscore[0] = scores; coff[0] = 0; }
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int pr = n - 1 - (i0 + lane);
+        int keep = 0, len = 0; double sc = 0.0;
+        if (pr >= 0) {
+            const uint32_t b = BOT[pr];
+            if (b != 0xffffffffu) {
+                const int e = SA[pr]; const int pb = P[b];
+                sc = S[e]; if (pb != VMX_NOPRE) sc = sc - S[pb];
+                keep = sc > 40; len = (int)D[e] - (int)D[b] + 1;
+            }
+        }
+        const int ik = vmx_wave_incl_scan_i32(keep), il = vmx_wave_incl_scan_i32(keep ? len : 0);
+        if (pr >= 0) {
+            if (keep) { const int c = nch + ik - 1, o = w + il - len; cscore[c] = sc; coff[c] = o; CH[pr] = (unsigned short)c; CO[pr] = (unsigned short)o; }
+            else CH[pr] = 0xffff;
+        }
+        nch += __shfl(ik, 63); w += __shfl(il, 63);
+    }
+    if (lane == 0) coff[nch] = w;
+    __syncthreads();
+    const int dg = (int)D[gmax];
+    for (int a = lane; a < n; a += 64) {
+        const uint32_t o = M[a];
+        if (o == (uint32_t)n) cidx[dg - (int)D[a]] = a;
+        else if (CH[o] != 0xffff) cidx[(int)CO[o] + (int)D[SA[o]] - (int)D[a]] = a;
+    }
+    __syncthreads();
+    const double max_scores = scores > 0 ? scores : 0;
+    if (!(max_scores > accept)) return -1;
+    return nch;
+}
+
+// the two loops of vmx_select_rank that touch every chain pair / every chain node, on the whole wavefront: order[] (descending score, equal
+// scores in descending index = the stable argsort reversed, then "best chain first") and the chains' unique read-position bins (bins / boff)
+__device__ __forceinline__ void vmx_select_order_bins_wave(int nch, int w, int mode, const double* cscore, const int* coff, const int* cq, int* order, int* bins, int* boff, int lane) {
+    for (int c = lane; c < nch; c += 64) {
+        const double sc = cscore[c]; int pos = 0;
+        for (int d = 0; d < nch; ++d) { const double sd = cscore[d]; pos += (sd > sc || (sd == sc && d > c)) ? 1 : 0; }
+        order[pos] = c;
+    }
+    __syncthreads();
+    if (mode != 4 && lane == 0 && order[0] != 0) { for (int i = 0; i < nch; ++i) if (order[i] == 0) { order[i] = order[0]; order[0] = 0; break; } }
+    // a node opens a bin when it is its chain's first or its bin differs from the node before it; bins are written in node order, and a
+    // chain's boff is the number of bins opened before its first node
+    int carry = 0;
+    for (int t0 = 0; t0 < w; t0 += 64) {
+        const int t = t0 + lane;
+        int f = 0, b = 0, cs = -1;
+        if (t < w) {
+            b = cq[t] / 100;
+            int lo = 0, hi = nch; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (coff[mid] <= t) lo = mid; else hi = mid; }      // the node's chain
+            const bool start = coff[lo] == t;
+            f = (start || cq[t - 1] / 100 != b) ? 1 : 0;
+            if (start) cs = lo;
+        }
+        const int inc = vmx_wave_incl_scan_i32(f);
+        const int at = carry + inc - f;
+        if (f) bins[at] = b;
+        if (cs >= 0) boff[cs] = at;
+        carry += __shfl(inc, 63);
+    }
+    if (lane == 0) boff[nch] = carry;
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(64) k_chain_select(const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ aoff, const int64_t* __restrict__ readlens,
                                const int32_t* __restrict__ rlist, int nlist, int lds_cap, const double* __restrict__ S, const int32_t* __restrict__ P, const int32_t* __restrict__ SA,
                                const int64_t* __restrict__ gmax, const int32_t* __restrict__ need_reverse, int mode,
@@ -487,7 +601,8 @@ __global__ void __launch_bounds__(64) k_chain_select(const vmx_anchor* __restric
     __shared__ int s_hdr[4];
     const int lane = vmx_lane();
     const int lds_bytes = lds_cap * 17 + 64;
-    (void)readlens;
+    const bool serial_peel = readlens == nullptr;                    // (test knob: a null length array selects the one-lane peel)
+
     for (int x = (int)blockIdx.x; x < nlist; x += (int)gridDim.x) {
         const int r = rlist ? rlist[x] : x;
         const int64_t a0 = aoff[r];
@@ -501,10 +616,15 @@ __global__ void __launch_bounds__(64) k_chain_select(const vmx_anchor* __restric
         const bool in_lds = n <= lds_cap;
         vmx_select_scr W = vmx_select_scratch(scratch + scratch_off[r], n);
         double* s_S = (double*)s_buf; int32_t* s_P = (int32_t*)(s_S + n); int32_t* s_SA = s_P + n; unsigned char* s_used = (unsigned char*)(s_SA + n);
-        if (in_lds) { for (int i = lane; i < n; i += 64) { s_S[i] = S[a0 + i]; s_P[i] = P[a0 + i]; s_SA[i] = SA[a0 + i]; s_used[i] = 0; } }
+        if (in_lds && n < 65535 && !serial_peel) { }                  // (the wave-parallel peel stages nothing)
+        else if (in_lds) { for (int i = lane; i < n; i += 64) { s_S[i] = S[a0 + i]; s_P[i] = P[a0 + i]; s_SA[i] = SA[a0 + i]; s_used[i] = 0; } }
         else { for (int i = lane; i < n; i += 64) W.used[i] = 0; }
         __syncthreads();
-        if (lane == 0) {
+        if (in_lds && n < 65535 && !serial_peel) {                   // the whole wavefront (arrays of the doubling rounds in LDS, S / P / S_arg read from HBM)
+            const int nchw = vmx_select_peel_wave(n, S + a0, P + a0, SA + a0, (int)gmax[r], mode, s_buf, W.cscore, W.coff, W.cidx, lane);
+            __syncthreads();
+            if (lane == 0) { s_hdr[0] = nchw; s_hdr[1] = nchw > 0 ? W.coff[nchw] : 0; }
+        } else if (lane == 0) {
             int nch;
             if (in_lds) nch = vmx_select_peel(n, s_S, s_P, s_SA, (int)gmax[r], mode, s_used, W.cscore, W.coff, W.cidx);
             else nch = vmx_select_peel(n, S + a0, P + a0, SA + a0, (int)gmax[r], mode, W.used, W.cscore, W.coff, W.cidx);
@@ -530,10 +650,12 @@ __global__ void __launch_bounds__(64) k_chain_select(const vmx_anchor* __restric
             for (int t = lane; t < w; t += 64) W.cq[t] = A[W.cidx[t]].q;
         }
         __syncthreads();
+        if (fit) vmx_select_order_bins_wave(nch, w, mode, l_cscore, l_coff, l_cq, l_order, l_bins, l_boff, lane);
+        else vmx_select_order_bins_wave(nch, w, mode, W.cscore, W.coff, W.cq, W.order, W.bins, W.boff, lane);
         if (lane == 0) {
             int mapq = 0, nsec, pidx = 0;
-            if (fit) nsec = vmx_select_rank(nch, mode, l_cscore, l_coff, l_cq, S + a0, W.cidx, l_order, l_bins, l_boff, l_prim, l_sec, &mapq, &pidx);
-            else nsec = vmx_select_rank(nch, mode, W.cscore, W.coff, W.cq, S + a0, W.cidx, W.order, W.bins, W.boff, W.prim, W.sec, &mapq, &pidx);
+            if (fit) nsec = vmx_select_rank(nch, mode, l_cscore, l_coff, l_cq, S + a0, W.cidx, l_order, l_bins, l_boff, l_prim, l_sec, &mapq, &pidx, true);
+            else nsec = vmx_select_rank(nch, mode, W.cscore, W.coff, W.cq, S + a0, W.cidx, W.order, W.bins, W.boff, W.prim, W.sec, &mapq, &pidx, true);
             const double sc = fit ? l_cscore[pidx] : W.cscore[pidx];
             if (nsec == -2) {                          // -mode asm: decode_hit's edlib tie-break among equal chains is made by the host (vmx_asm_resolve_ties)
                 out_mapq[r] = 0; out_score[r] = need_reverse[r] ? -0.0 : 0.0; out_npaths[r] = -7;

@@ -103,6 +103,7 @@ int vmx_launch_chain_select(vm_ctx* c, int64_t n, const int64_t* h_aoff, DevBuf&
     if (n <= 0) return 0;
     constexpr int NC = 6;
     const int caps[NC] = {192, 384, 768, 1536, 3072, 0};
+    static const bool serial_peel = getenv("VMX_SELECT_SERIAL") != nullptr;      // A/B knob: the one-lane peel of round 3
     std::vector<int32_t> lists[NC];
     for (int64_t r = 0; r < n; ++r) {
         const int64_t m = h_aoff[r + 1] - h_aoff[r];
@@ -118,7 +119,7 @@ int vmx_launch_chain_select(vm_ctx* c, int64_t n, const int64_t* h_aoff, DevBuf&
     vmx_fork fk(c);
     for (int q = NC - 1; q >= 0; --q) {                          // the classes with the longest walks first
         const int cnt = (int)lists[q].size(); if (!cnt) continue;
-        hipLaunchKernelGGL(k_chain_select, dim3((unsigned)cnt), dim3(64), (size_t)caps[q] * 17 + 64, fk.next(), sorted, d_aoff, d_lens, d_list.as<int32_t>() + off[q], cnt, caps[q],
+        hipLaunchKernelGGL(k_chain_select, dim3((unsigned)cnt), dim3(64), (size_t)caps[q] * 17 + 64, fk.next(), sorted, d_aoff, serial_peel ? nullptr : d_lens, d_list.as<int32_t>() + off[q], cnt, caps[q],
                            S, P, SA, gmax, flip, mode, scr, soff, d_mapq, d_score, d_np, plen, prow);
     }
     fk.join();

@@ -87,11 +87,12 @@ __host__ __device__ VMX_SELECT_INLINE int vmx_select_peel(int n, const double* S
 // score the reference picks the least divergent of them with edlib (:21302-21326) — that choice is not made here: returns -2, the kernel
 // marks the contig (n_paths = -7) and the host makes the choice with the device's edit-distance kernels (vmx_asm_resolve_ties, vmx_asm.hip).
 __host__ __device__ VMX_SELECT_INLINE int vmx_select_rank(int nch, int mode, const double* cscore, const int* coff, const int* cq, const double* Sg, const int* cidx,
-                                                          int* order, int* bins, int* boff, int* prim, int* sec, int* out_mapq, int* out_prim) {
+                                                          int* order, int* bins, int* boff, int* prim, int* sec, int* out_mapq, int* out_prim, bool have_order_bins = false) {
     const int sec_min_span = (mode == 3) ? 100 : 50;
     const bool asmv = mode == 4;
     // order = argsort(scores)[::-1] (stable): descending score, equal scores in descending index
-    for (int c = 0; c < nch; ++c) {
+    // (have_order_bins: k_chain_select has filled order / bins / boff with the whole wavefront — vmx_select_order_bins_wave, k_chain.hip)
+    if (!have_order_bins) for (int c = 0; c < nch; ++c) {
         int pos = 0;
         while (pos < c && cscore[order[pos]] > cscore[c]) ++pos;
         for (int t = c; t > pos; --t) order[t] = order[t - 1];
@@ -101,7 +102,7 @@ __host__ __device__ VMX_SELECT_INLINE int vmx_select_rank(int nch, int mode, con
     const int pc0 = order[0];
     *out_prim = pc0;
     // read-position bins (//100) per chain, unique, descending
-    {
+    if (!have_order_bins) {
         int bw = 0;
         for (int c = 0; c < nch; ++c) {
             boff[c] = bw; int last = -1;
