@@ -40,16 +40,34 @@ __global__ void k_orient(const uint8_t* __restrict__ codes, const int64_t* __res
 }
 
 // ------------------------------------------------------------------------------------------------ L1 prep
-__global__ void k_local_prep(const vmx_anchor* __restrict__ path_rows, const int32_t* __restrict__ path_len, const int32_t* __restrict__ n_paths,
+__global__ void __launch_bounds__(64) k_local_prep(const vmx_anchor* __restrict__ path_rows, const int32_t* __restrict__ path_len, const int32_t* __restrict__ n_paths,
                              const int64_t* __restrict__ aoff, const double* __restrict__ gscore, int n_reads, int mode,
                              vmx_anchor* __restrict__ guide_rows, int32_t* __restrict__ guide_len, int32_t* __restrict__ n_guides_used,
                              int32_t* __restrict__ n_guides_total, int32_t* __restrict__ ws_pool) {
-    int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (r >= n_reads) return;
-    const int64_t a0 = aoff[r];
-    n_guides_used[r] = 0; n_guides_total[r] = 0;
-    if (gscore[r] == 0.0 || n_paths[r] <= 0) return;
-    vmx_local_prep(path_rows + a0, path_len + a0, n_paths[r], mode, guide_rows + a0, guide_len + a0, &n_guides_used[r], &n_guides_total[r], ws_pool + VMX_PREP_WS * a0);      // (a read has at most as many paths as anchors)
+    // one wavefront per read: lane 0 takes the decisions (a handful of chains), all lanes copy the guide rows (a HiFi guide holds ~3000 anchors:
+    // copied by the deciding thread alone they were most of the kernel's 1.5 ms)
+    __shared__ int s_n;
+    for (int r = (int)blockIdx.x; r < n_reads; r += (int)gridDim.x) {
+        const int64_t a0 = aoff[r];
+        int32_t* ws = ws_pool + VMX_PREP_WS * a0;                    // (a read has at most as many paths as anchors)
+        const int np = n_paths[r];
+        if (threadIdx.x == 0) {
+            int32_t segs = 0;
+            n_guides_used[r] = 0; n_guides_total[r] = 0;
+            if (!(gscore[r] == 0.0 || np <= 0))
+                vmx_local_prep(path_rows + a0, path_len + a0, np, mode, guide_rows + a0, guide_len + a0, &n_guides_used[r], &n_guides_total[r], ws, &segs);
+            s_n = segs;
+        }
+        __syncthreads();
+        const int nseg = s_n;
+        int w = 0;
+        for (int sgi = 0; sgi < nseg; ++sgi) {
+            const int src = ws[7 * np + sgi], ln = ws[8 * np + sgi];
+            for (int t = (int)threadIdx.x; t < ln; t += (int)blockDim.x) guide_rows[a0 + w + t] = path_rows[a0 + src + t];
+            w += ln;
+        }
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ L2 seeding

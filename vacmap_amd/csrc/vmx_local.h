@@ -12,7 +12,7 @@
 #define VM_READ_CAPACITY_DEV (-20)
 #define VM_READ_RAISED_DEV (-10)
 #define VM_READ_BANDFALL_DEV (-23)   // k_local_seed_band hands the read to the general kernel k_local_seed (internal: never returned by vm_align_batch)
-#define VMX_PREP_WS 7        // ints of scratch per path of a read that vmx_local_prep needs (no limit on the number of chains: mode S re-seeds them all)
+#define VMX_PREP_WS 9        // ints of scratch per path of a read that vmx_local_prep needs (no limit on the number of chains: mode S re-seeds them all)
 
 // :23231 acceptance of a table hit at `refloc` given the two closest guide anchors
 __host__ __device__ inline bool vmx_local_accept(long long refloc, long long ref1, long long ref2, long long interval, long long readgap) {
@@ -24,15 +24,22 @@ __host__ __device__ inline bool vmx_local_accept(long long refloc, long long ref
 // L1. paths: return_path_list of decode_hit (primary first), each in descending read order, concatenated in `rows` with lengths `len`.
 // out: the guide chains that will be re-seeded (in processing order), concatenated in out_rows (capacity = total anchors), lengths out_len;
 // *n_used = how many are re-seeded (<= 5 H, <= 3 L, all S), *n_total = len(list after drop_somechains) (> 1 selects LC-mm).
-// ws: VMX_PREP_WS * np ints of scratch.
+// ws: VMX_PREP_WS * np ints of scratch. segs != nullptr: the rows are NOT copied; instead the (source start, length) pieces that make out_rows, in
+// order, go to ws[7 np ..] / ws[8 np ..] and their number to *segs (k_local_prep copies them with the whole wavefront).
 __host__ __device__ inline void vmx_local_prep(const vmx_anchor* rows, const int32_t* len, int np, int mode, vmx_anchor* out_rows,
-                                               int32_t* out_len, int32_t* n_used, int32_t* n_total, int32_t* ws) {
+                                               int32_t* out_len, int32_t* n_used, int32_t* n_total, int32_t* ws, int32_t* segs = nullptr) {
+    int32_t* const seg_src = ws + 7 * np; int32_t* const seg_len = ws + 8 * np; int nseg = 0;
     if (mode == 3 || mode == 4) {
         // mode R (mammap_noprefercloser.py:23902-23914): every chain is re-seeded, in the order given, no merge / drop / cap
         // (-mode asm, mammap_asm.py:19714-19719: decode_hit returns the primary path only, and that one is re-seeded)
         int w = 0;
-        for (int p = 0; p < np; ++p) { for (int t = 0; t < len[p]; ++t) { out_rows[w] = rows[w]; ++w; } out_len[p] = len[p]; }
+        for (int p = 0; p < np; ++p) {
+            if (segs) { seg_src[nseg] = w; seg_len[nseg] = len[p]; ++nseg; w += len[p]; }
+            else for (int t = 0; t < len[p]; ++t) { out_rows[w] = rows[w]; ++w; }
+            out_len[p] = len[p];
+        }
         *n_used = np; *n_total = np;
+        if (segs) *segs = nseg;
         return;
     }
     int32_t* const start = ws;
@@ -106,10 +113,14 @@ __host__ __device__ inline void vmx_local_prep(const vmx_anchor* rows, const int
     int w = 0;
     for (int gi = 0; gi < used; ++gi) {
         int c = lst[gi]; int n = 0;
-        for (int p = head[c]; p >= 0; p = nxt[p]) for (int t = 0; t < len[p]; ++t) { out_rows[w++] = rows[start[p] + t]; ++n; }
+        for (int p = head[c]; p >= 0; p = nxt[p]) {
+            if (segs) { seg_src[nseg] = start[p]; seg_len[nseg] = len[p]; ++nseg; n += len[p]; w += len[p]; }
+            else for (int t = 0; t < len[p]; ++t) { out_rows[w++] = rows[start[p] + t]; ++n; }
+        }
         out_len[gi] = n;
     }
     *n_used = used; *n_total = nl;
+    if (segs) *segs = nseg;
 }
 
 #endif

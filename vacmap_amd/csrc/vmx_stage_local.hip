@@ -43,7 +43,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     L.la_pool_rows = la_tot;
     VMX_TRY(L.guide_rows.reserve(sizeof(vmx_anchor) * (size_t)(tot_anchors + 1))); VMX_TRY(L.guide_len.reserve(4 * (size_t)(tot_anchors + 1)));
     VMX_TRY(L.ng_used.reserve(4 * (size_t)(n + 1))); VMX_TRY(L.ng_total.reserve(4 * (size_t)(n + 1))); VMX_TRY(L.prep_ws.reserve(4 * VMX_PREP_WS * (size_t)(tot_anchors + 1)));
-    hipLaunchKernelGGL(k_local_prep, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, d_path_rows, d_path_len, d_npaths, d_aoff, d_gscore, (int)n,
+    hipLaunchKernelGGL(k_local_prep, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 32)), dim3(64), 0, c->stream, d_path_rows, d_path_len, d_npaths, d_aoff, d_gscore, (int)n,
                        prm->mode, L.guide_rows.as<vmx_anchor>(), L.guide_len.as<int32_t>(), L.ng_used.as<int32_t>(), L.ng_total.as<int32_t>(), L.prep_ws.as<int32_t>());
     // scratch per workgroup slot
     // exactly as many workgroups as the device keeps resident; they pull reads longest-first from a device-side queue
