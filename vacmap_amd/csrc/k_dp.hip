@@ -617,11 +617,12 @@ __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_
             // diagonal are loaded TOGETHER and consumed as long as the path stays on it: one memory latency per eight steps instead
             // of one per step (the walk is a chain of dependent loads, this kernel's whole cost).
             const int x = (j - i) - dlo, l = x / (2 * ns), k = (x - 2 * ns * l) >> 1;
-            const uint8_t* cell = tb + (size_t)(i + j - 1) * 64 + (size_t)(4 * l + k);
+            const uint8_t* cell = tb + VMX_AD_TB_OFF(0, l) + k;
+            const int s0 = i + j - 1;
             int m = i < j ? i : j; if (m > 8) m = 8;
             uint8_t bb[8], ta[8], qa[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (u < m) { bb[u] = cell[-(ptrdiff_t)128 * u]; if (eqx) { ta[u] = T[i - 1 - u]; qa[u] = Q[j - 1 - u]; } }
+            for (int u = 0; u < 8; ++u) if (u < m) { bb[u] = cell[VMX_AD_TB_OFF(s0 - 2 * u, 0)]; if (eqx) { ta[u] = T[i - 1 - u]; qa[u] = Q[j - 1 - u]; } }
             int u = 0;
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
@@ -634,7 +635,7 @@ __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_
             if (state == 0) continue;                 // the whole batch was diagonal (or the matrix edge was reached)
             // a gap starts at cell (i, j): the generic step below re-reads its byte in the gap state
         }
-        if (ns) { const int x = (j - i) - dlo, l = x / (2 * ns), k = (x - 2 * ns * l) >> 1; b = tb[(size_t)(i + j - 1) * 64 + (size_t)(4 * l + k)]; }
+        if (ns) { const int x = (j - i) - dlo, l = x / (2 * ns), k = (x - 2 * ns * l) >> 1; b = tb[VMX_AD_TB_OFF(i + j - 1, l) + k]; }
         else if (x4) { const int s = (i - 1) >> 5, r = (i - 1) & 31, t = (j - 1) + r; b = tb[(((size_t)s * (size_t)W + (size_t)t) * 16 + (r >> 1)) * 2 + (r & 1)]; }
         else if (pk) { const int s = (i - 1) >> 7, r = (i - 1) & 127, t = (j - 1) + r; b = tb[(((size_t)s * (size_t)W + (size_t)t) * 64 + (r >> 1)) * 2 + (r & 1)]; }
         else { const int s = (i - 1) >> 6, l = (i - 1) & 63, t = (j - 1) + l; b = tb[((size_t)s * (size_t)W + (size_t)t) * 64 + l]; }

@@ -14,8 +14,8 @@
 // cells past tl / ql compute garbage that only ever feeds other garbage. Target codes move down the lanes one diagonal pair per two
 // steps, query codes move up (one DPP each per step pair), fed at lane 0 / lane 15 from 16-entry chunk registers that rotate one lane
 // per use and are refilled with one coalesced load every 16 pairs.
-// Traceback bytes: tb[(a - 1) * 64 + l * 4 + k] for the cell of anti-diagonal a on diagonal x = 2 NS l + 2 k + (a & 1): one dword per lane,
-// problem and step.
+// Traceback bytes: tb[VMX_AD_TB_OFF(a - 1, l) + k] for the cell of anti-diagonal a on diagonal x = 2 NS l + 2 k + (a & 1): one dword per lane,
+// problem and step (vmx_kernels.h: lines of VMX_AD_AB anti-diagonals x 16 / VMX_AD_AB lanes).
 #ifndef VMX_DP_AD_H
 #define VMX_DP_AD_H
 
@@ -119,8 +119,8 @@ __device__ __forceinline__ void vmx_gapfill_fill_ad(const uint8_t* __restrict__ 
     const int xfX = (qlX - tlX) - dloX, xfY = (qlY - tlY) - dloY;
     const int lfX = xfX / (2 * NS), kfX = (xfX % (2 * NS)) >> 1, lfY = xfY / (2 * NS), kfY = (xfY % (2 * NS)) >> 1;
     int finX = 0, finY = 0;
-    uint8_t* pX = tbX + 4 * l;
-    uint8_t* pY = tbY + 4 * l;
+    uint8_t* const pX = tbX + VMX_AD_TB_OFF(0, l);            // the lane's slot of anti-diagonal 0; the step's part of the offset is added per store
+    uint8_t* const pY = tbY + VMX_AD_TB_OFF(0, l);
     // chunk of block b (pairs 16 b + 1 .. 16 b + 16): lane m holds the target code lane 0 takes in the block's pair m (row 16 b + 1 + m - h),
     // lane 15 - m the query code lane 15 takes in it (column 16 b + m + h + 16 NS)
     auto load_chunks = [&](int b16, unsigned& tch, unsigned& qch) {
@@ -159,8 +159,9 @@ __device__ __forceinline__ void vmx_gapfill_fill_ad(const uint8_t* __restrict__ 
                 if (NS > 1) w01 |= bb[NS > 1 ? 1 : 0] << 8;
                 if (NS > 2) w23 = bb[NS > 2 ? 2 : 0];
                 if (NS > 3) w23 |= bb[NS > 3 ? 3 : 0] << 8;
-                if (p <= poX) *(uint32_t*)pX = vmx_perm(w23, w01, 0x05040100u);
-                if (p <= poY) *(uint32_t*)pY = vmx_perm(w23, w01, 0x07060302u);
+                const size_t so = VMX_AD_TB_OFF(2 * p - 2, 0);        // anti-diagonal a = 2p - 1 is step s = a - 1
+                if (p <= poX) *(uint32_t*)(pX + so) = vmx_perm(w23, w01, 0x05040100u);
+                if (p <= poY) *(uint32_t*)(pY + so) = vmx_perm(w23, w01, 0x07060302u);
             }
             // target codes move down one diagonal pair
             {
@@ -185,10 +186,10 @@ __device__ __forceinline__ void vmx_gapfill_fill_ad(const uint8_t* __restrict__ 
                 if (NS > 1) w01 |= bb[NS > 1 ? 1 : 0] << 8;
                 if (NS > 2) w23 = bb[NS > 2 ? 2 : 0];
                 if (NS > 3) w23 |= bb[NS > 3 ? 3 : 0] << 8;
-                if (p <= peX) *(uint32_t*)(pX + 64) = vmx_perm(w23, w01, 0x05040100u);
-                if (p <= peY) *(uint32_t*)(pY + 64) = vmx_perm(w23, w01, 0x07060302u);
+                const size_t so = VMX_AD_TB_OFF(2 * p - 1, 0);
+                if (p <= peX) *(uint32_t*)(pX + so) = vmx_perm(w23, w01, 0x05040100u);
+                if (p <= peY) *(uint32_t*)(pY + so) = vmx_perm(w23, w01, 0x07060302u);
             }
-            pX += 128; pY += 128;
             // the pair that holds the problem's last anti-diagonal: its cell (tl, ql) was written by this pair's odd or even step
             if (__any(p == poX || p == poY)) {
                 const unsigned aX = vmx_ad_pick<NS>(HA, kfX), cX = vmx_ad_pick<NS>(HC, kfX), aY = vmx_ad_pick<NS>(HA, kfY), cY = vmx_ad_pick<NS>(HC, kfY);

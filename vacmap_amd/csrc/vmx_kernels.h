@@ -203,7 +203,15 @@ __host__ __device__ static inline int vmx_ad_ns(int tl, int ql, int match, int o
 #define VMX_REDO_PK(tl, ql) ((tl) > 0 && (ql) > 0 && VMX_DP16X4_OK(tl, ql) && (tl) + (ql) >= VMX_REDO_PK_MIN)
 #endif
 #define VMX_PK_TB_BYTES(tl, ql) ((int64_t)(((tl) + 127) / 128) * ((ql) + 127) * 128)
-#define VMX_AD_TB_BYTES(tl, ql) ((int64_t)((tl) + (ql)) * 64)      /* one 4-byte slot per lane and anti-diagonal */
+/* Traceback of the anti-diagonal layout: one 4-byte slot per lane and anti-diagonal, in 64-byte lines of VMX_AD_AB consecutive anti-diagonals x
+   16 / VMX_AD_AB consecutive lanes. AB = 1 (rounds 2-3): a line = one anti-diagonal of a problem, the fill's row store is one line, but the
+   traceback walk — nine steps in ten go down a diagonal, two anti-diagonals back in the same lane — fetched a new 64-byte sector per step
+   (5.2 GB per step of the pipeline for ~80 MB of bytes used). With AB anti-diagonals per line a diagonal stretch reads a line per AB / 2 steps. */
+#ifndef VMX_AD_AB
+#define VMX_AD_AB 8
+#endif
+#define VMX_AD_TB_OFF(s, l) ((((size_t)(s) & ~(size_t)(VMX_AD_AB - 1)) << 6) + ((size_t)(s) & (VMX_AD_AB - 1)) * (64 / VMX_AD_AB) + ((size_t)(l) / (16 / VMX_AD_AB)) * 64 + ((size_t)(l) % (16 / VMX_AD_AB)) * 4)   /* byte offset of lane l's slot on anti-diagonal s (0-based) */
+#define VMX_AD_TB_BYTES(tl, ql) ((int64_t)(((tl) + (ql) + VMX_AD_AB - 1) & ~(VMX_AD_AB - 1)) * 64)
 #define VMX_X4_TB_BYTES(tl, ql) ((int64_t)(((tl) + 31) / 32) * VMX_X4_W(ql) * 32)
 // traceback bytes of a problem. VMX_TB_BYTES: the full-matrix forms (k_gapfill_fill). VMX_TB_BYTES_NS: the batched path (k_gapfill_fill_ns), whose
 // small problems get the anti-diagonal layout's (tl + ql) * 64 bytes only; the few that have to be filled again in full take
