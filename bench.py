@@ -189,6 +189,7 @@ def main():
                 ok += int((st[j] == 0) == (ost == 0) and mine == [t[1:] for t in orecs])
             verified = '%d/%d' % (ok, nv)
         pipe.warm(resident[longest]); warm_runs += pipe.inflight
+    pipe.trim_to_memory()          # (the product's rule: a context is given up when the sized pools leave < 10 GB of HBM free; not the case at these sizes)
 
     agg = {}
 

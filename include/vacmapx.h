@@ -75,6 +75,9 @@ int vm_ctx_set_inflight(vm_ctx*, int n_contexts);
  * latency). For processes whose other threads need the cores — vacmap_amd.driver's SAM emitters under a CPU quota. */
 int vm_ctx_set_blocking_sync(vm_ctx*, int on);
 int vm_device_count(void);
+/* free / total bytes of the context's device (hipMemGetInfo): the driver drops a context when the grow-only work pools of the batches in flight
+ * leave less than a safety margin of HBM free after their sizing run */
+int vm_ctx_mem_info(vm_ctx*, int64_t* free_bytes, int64_t* total_bytes);
 
 /* build the minimizer index of a FASTA file / in-memory contigs ON THE GPU and keep it resident in HBM
  * (replaces `mp.Aligner(path, w=, k=)`, src/vacmap/vacmap:344; index.py:26) */

@@ -125,6 +125,19 @@ int vm_ctx_set_inflight(vm_ctx* c, int n_contexts) {
     return VM_OK;
 }
 
+int vm_ctx_mem_info(vm_ctx* c, int64_t* free_bytes, int64_t* total_bytes) {
+    if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
+    size_t f = 0, t = 0;
+#ifndef VMX_EMU
+    VMX_HIP(hipSetDevice(c->device));
+    VMX_HIP(hipMemGetInfo(&f, &t));
+#else
+    f = (size_t)1 << 34; t = (size_t)1 << 34;
+#endif
+    *free_bytes = (int64_t)f; *total_bytes = (int64_t)t;
+    return VM_OK;
+}
+
 int vm_ctx_set_blocking_sync(vm_ctx* c, int on) {
     if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
 #ifndef VMX_EMU

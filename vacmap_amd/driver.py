@@ -639,6 +639,9 @@ def main(argv=None, comm=None):
                     t_.start()
                 for t_ in wth:
                     t_.join()
+        dropped = pipe.trim_to_memory(float(os.environ.get('VMX_MIN_FREE_GB', '10')))
+        if dropped and rank == 0:
+            sys.stderr.write('vacmapx: %d of %d batches in flight given up to keep HBM head-room\n' % (dropped, dropped + pipe.inflight))
         tm['warm'] = time.time() - t_loop
     try:
         pipe.run_stream(job_source(), align, errs)

@@ -127,6 +127,7 @@ class VmxLib:
         L.vm_ctx_destroy.argtypes = [vp]
         L.vm_ctx_set_inflight.argtypes = [vp, C.c_int]
         L.vm_ctx_set_blocking_sync.argtypes = [vp, C.c_int]
+        L.vm_ctx_mem_info.argtypes = [vp, P(i64), P(i64)]
         L.vm_table.argtypes = [vp, C.c_int, P(vp)]; L.vm_table.restype = i64
         L.vm_edit_distance_batch.argtypes = [vp, i64, cp, vp, cp, vp, P(P(i64))]
         L.vm_edit_distance_bound_batch.argtypes = [vp, C.c_int, i64, cp, vp, cp, vp, P(P(i64))]
@@ -216,6 +217,12 @@ class Context:
     def set_blocking_sync(self, on=True):
         """sleep instead of spinning while waiting for the GPU (vm_ctx_set_blocking_sync)"""
         self.lib.check(self.lib.L.vm_ctx_set_blocking_sync(self.h, int(bool(on))))
+
+    def mem_info(self):
+        """(free, total) bytes of the device's memory"""
+        f = C.c_int64(); t = C.c_int64()
+        self.lib.check(self.lib.L.vm_ctx_mem_info(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def close(self):
         if self.h:

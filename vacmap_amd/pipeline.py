@@ -85,6 +85,22 @@ class Pipeline:
             cx.close()
         self.ctxs = self.ctxs[:1]
 
+    def trim_to_memory(self, min_free_gb=10.0, keep=2):
+        """after the sizing run of every context (warm): the grow-only pools scale with the longest batch, and four contexts' pools of a long-read
+        batch may leave the device without head-room; contexts are given up (their pools freed) until `min_free_gb` is free or `keep` remain.
+        Returns the number of contexts dropped."""
+        dropped = 0
+        while len(self.ctxs) > max(1, keep):
+            free, _ = self.ctxs[0].mem_info()
+            if free >= min_free_gb * 1e9:
+                break
+            self.ctxs.pop().close(); dropped += 1
+        if dropped:
+            self.inflight = len(self.ctxs)
+            for cx in self.ctxs:
+                cx.set_inflight(self.inflight)
+        return dropped
+
     def _run(self, n_jobs, do_job, on_result):
         """`inflight` threads pull job indices in order; do_job(i, ctx) -> result; on_result(i, result) is called under a lock"""
         lock = threading.Lock()
