@@ -240,7 +240,7 @@ def ad_margin(g, match=2, o1=4, e1=2, o2=24, e2=1):
     return match * g + 2 * min(o1 + g * e1, o2 + g * e2)
 
 
-def ad_ns(tl, ql, pct=100, pct_min=65):
+def ad_ns(tl, ql, pct=90, pct_min=65):
     if tl <= 0 or ql <= 0:
         return 0
     mn = min(tl, ql); g = 0
@@ -251,7 +251,7 @@ def ad_ns(tl, ql, pct=100, pct_min=65):
     return AD_NS_MAX if (g >= 1 and ad_margin(g) * 100 >= pct_min * mn) else 0
 
 
-def gapfill_banded_cases(rng, x4_max, dp16_max, base_len, big=True, pct=100, pct_min=65):
+def gapfill_banded_cases(rng, x4_max, dp16_max, base_len, big=True, pct=90, pct_min=65):
     """adversarial (target, query) pairs for the banded gap fill (k_gapfill_fill_ns): see check_gapfill_banded"""
     ts, qs, tag = [], [], []
 
@@ -327,7 +327,7 @@ def gapfill_banded_cases(rng, x4_max, dp16_max, base_len, big=True, pct=100, pct
     return ts, qs, tag
 
 
-def check_gapfill_banded(ctx, O, x4_max, dp16_max, base_len, seed=44, big=True, min_counts=(10, 10, 5), pct=100, pct_min=65, redo_pk_min=384):
+def check_gapfill_banded(ctx, O, x4_max, dp16_max, base_len, seed=44, big=True, min_counts=(10, 10, 5), pct=90, pct_min=65, redo_pk_min=384):
     """E5 through the schedule of the batched path (vm_k_cigar_batch_banded -> k_gapfill_fill_ns: anti-diagonal band fill of eight problems
     per wave, optimality proof, redo queue, per-problem layout flag read by k_gapfill_trace) vs the oracle's full DP (mammap_clrnano.py:21554,
     :21598 call sites): identical CIGARs with eqx on and off, in shuffled order (waves mix proven, unproven, never-tried and idle rows and

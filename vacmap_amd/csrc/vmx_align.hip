@@ -457,7 +457,7 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
             int32_t* d_redo_list = B.order.as<int32_t>() + round_cap + 32; int32_t* d_redo_cnt = d_range + 12;     // problems whose band was not proven
             std::vector<int32_t> csz; for (size_t q = 0; q + 1 < cuts.size(); ++q) csz.push_back(cuts[q + 1] - cuts[q]);
             VMX_TRY(upload(B.chunkn, csz.data(), csz.size(), c->stream));
-            const int ad_pct = vmx_ad_pct_env();
+            const int ad_pct = vmx_ad_pct_env(prm->mode);
             int fill_waves = 16;                                  // waves per CU of the fill kernel (tuning knob: VMX_FILL_WAVES)
             if (const char* e = getenv("VMX_FILL_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 32) fill_waves = v; }
             for (size_t q = 0; q + 1 < cuts.size(); ++q) {
