@@ -39,7 +39,8 @@ __global__ void k_flip_sort(const int64_t* __restrict__ rows, const int64_t* __r
                             int n_reads, uint64_t* __restrict__ key_pool, const int64_t* __restrict__ key_off,
                             vmx_anchor* __restrict__ sorted, int32_t* __restrict__ need_reverse) {
     __shared__ int s_cnt[2];
-    __shared__ uint64_t s_sort[VMX_SORT_LDS];                // the sort's LDS tile (round 4: the plain bitonic passes ran through HBM — 78 barriers and passes for a HiFi read's 3000 anchors)
+    __shared__ uint64_t s_sort[VMX_SORT_LDS / 2];            // the sort's LDS tile (round 4: the plain bitonic passes ran through HBM — 78 barriers and passes for a HiFi read's
+                                                             // 3000 anchors). 16 KB: an ONT read's ~750 anchors fit; with 32 KB the workgroups queued for LDS behind the other batches' kernels
     for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
         const int64_t* A = rows + 4 * aoff[r];
         const int n = (int)(aoff[r + 1] - aoff[r]);
@@ -64,7 +65,7 @@ __global__ void k_flip_sort(const int64_t* __restrict__ rows, const int64_t* __r
             keys[i] = k;
         }
         __syncthreads();
-        if (N > 1) vmx_block_sort_u64_tiled(keys, N, s_sort, VMX_SORT_LDS);
+        if (N > 1) vmx_block_sort_u64_tiled(keys, N, s_sort, VMX_SORT_LDS / 2);
         vmx_anchor* out = sorted + aoff[r];
         for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
             uint64_t k = keys[i];
