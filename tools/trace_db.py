@@ -26,7 +26,7 @@ def main():
             for n, a in sorted(agg.items(), key=lambda x: -x[1][1]):
                 w.writerow([n, a[0], a[1], '%.1f' % (a[1] / a[0]), '%.2f' % (100.0 * a[1] / tot), a[2], a[3]])
     # timed region: from the k_sketch launch that follows the warm-up batches to the end
-    sk = [r for r in rows if r[0] == 'k_sketch']
+    sk = [r for r in rows if r[0] in ('k_sketch', 'k_sketch32')]
     skip = int(sys.argv[sys.argv.index('--skip') + 1]) if '--skip' in sys.argv else 4      # verify batch + 3 warm-ups
     t0 = sk[skip][1] if len(sk) > skip else rows[0][1]
     sel = [r for r in rows if r[1] >= t0 and not r[0].startswith('__amd')]

@@ -3,7 +3,7 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = [(r['Kernel_Name'].split('(')[0], int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp']), r['Grid_Size_X']) for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: r[1])
-idx = [i for i, r in enumerate(rows) if r[0] == 'k_sketch'] + [len(rows)]
+idx = [i for i, r in enumerate(rows) if r[0] in ('k_sketch', 'k_sketch32')] + [len(rows)]
 for b in range(len(idx) - 1):
     seg = rows[idx[b]:idx[b + 1]]; t0 = seg[0][1]; tot = {}
     for r in seg: tot[r[0]] = tot.get(r[0], 0) + r[2]

@@ -28,16 +28,104 @@ __device__ __forceinline__ uint64_t vmx_hash64(uint64_t key, uint64_t mask) {
 #define VMX_SK_HALO 256           // >= w-1 on each side
 #define VMX_INF64 (~0ULL)
 
+// the w = 10 form of k_sketch (below), with the hashes in H = uint32_t when 2 k <= 32 (k = 15: 30-bit hashes — half the LDS, half the
+// instructions of the 64-bit form, the same values: every step of the hash is taken modulo 2^(2k)) or uint64_t (k = 19)
+template <typename H> __device__ __forceinline__ H vmx_hash_t(H key, H mask) {
+    key = (H)((~key + (key << 21)) & mask);
+    key = (H)(key ^ key >> 24);
+    key = (H)(((key + (key << 3)) + (key << 8)) & mask);
+    key = (H)(key ^ key >> 14);
+    key = (H)(((key + (key << 2)) + (key << 4)) & mask);
+    key = (H)(key ^ key >> 28);
+    key = (H)((key + (key << 31)) & mask);
+    return key;
+}
+template <typename H>
+__device__ __forceinline__ int vmx_sketch_w10(const uint8_t* __restrict__ C, int P, int k, int nwin, uint8_t* s_codes, H* s_h, H* s_wmin, uint8_t* s_z, int* s_scan,
+                                              uint64_t* __restrict__ oh, uint32_t* __restrict__ op) {
+    const H mask = (H)((2 * k >= (int)(8 * sizeof(H))) ? ~(H)0 : (((H)1 << (2 * k)) - 1));
+    const int shift = 2 * (k - 1);
+    const H HINF = ~(H)0;
+    int written = 0;
+            for (int t0 = 0; t0 < P; t0 += VMX_SK_TILE) {
+    const int lo = t0 - 9 > 0 ? t0 - 9 : 0;
+    int hi = t0 + VMX_SK_TILE + 9; if (hi > P) hi = P;
+    const int npos = hi - lo;
+    for (int x = (int)threadIdx.x; x < npos + k - 1; x += 256) s_codes[x] = C[lo + x];
+    __syncthreads();
+    for (int x0 = 8 * (int)threadIdx.x; x0 < npos; x0 += 8 * 256) {
+        H fwd = 0, rc = 0; int nval = 0;
+        for (int i = 0; i < k - 1; ++i) { const uint8_t c = s_codes[x0 + i]; nval = c > 3 ? 0 : nval + 1; fwd = (H)((fwd << 2) | (H)(c & 3)); rc = (H)((rc >> 2) | ((H)(3 - (c & 3)) << shift)); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (x0 + j < npos) {
+                const uint8_t c = s_codes[x0 + j + k - 1]; nval = c > 3 ? 0 : nval + 1;
+                fwd = (H)(((fwd << 2) | (H)(c & 3)) & mask); rc = (H)((rc >> 2) | ((H)(3 - (c & 3)) << shift));
+                H h = HINF; uint8_t z = 0;
+                if (nval >= k && fwd != rc) { z = rc < fwd ? 1 : 0; h = vmx_hash_t<H>(fwd < rc ? fwd : rc, mask); }
+                s_h[x0 + j] = h; s_z[x0 + j] = z;
+            }
+        }
+    }
+    __syncthreads();
+    for (int x0 = 8 * (int)threadIdx.x; x0 < npos; x0 += 8 * 256) {
+        H v[17], m2[16], m4[14], m8[8];
+#pragma unroll
+        for (int i = 0; i < 17; ++i) v[i] = x0 + i < npos ? s_h[x0 + i] : HINF;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m2[i] = v[i] < v[i + 1] ? v[i] : v[i + 1];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) m4[i] = m2[i] < m2[i + 2] ? m2[i] : m2[i + 2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { m8[i] = m4[i] < m4[i + 4] ? m4[i] : m4[i + 4]; const H m = m8[i] < m2[i + 8] ? m8[i] : m2[i + 8]; if (x0 + i < npos) s_wmin[x0 + i] = (lo + x0 + i < nwin) ? m : (H)0; }
+    }
+    __syncthreads();
+    int pend = t0 + VMX_SK_TILE; if (pend > P) pend = P;
+    const int p0 = t0 + 8 * (int)threadIdx.x;               // this thread's positions p0 .. p0 + 7
+    unsigned selmask = 0; H hs[8];
+    if (p0 < pend) {
+        const int xa = p0 - 9 - lo;                          // LDS index of window start p0 - 9 (negative: before the sequence)
+        H v[17], m2[16], m4[14];
+#pragma unroll
+        for (int i = 0; i < 17; ++i) v[i] = (xa + i >= 0 && xa + i < npos) ? s_wmin[xa + i] : (H)0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m2[i] = v[i] > v[i + 1] ? v[i] : v[i + 1];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) m4[i] = m2[i] > m2[i + 2] ? m2[i] : m2[i + 2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const H m8 = m4[j] > m4[j + 4] ? m4[j] : m4[j + 4];
+            const H mx = m8 > m2[j + 8] ? m8 : m2[j + 8];          // windows p - 9 .. p
+            const H h = p0 + j < pend ? s_h[p0 + j - lo] : HINF;
+            hs[j] = h;
+            if (h != HINF && mx == h) selmask |= 1u << j;
+        }
+    }
+    int tot; const int ex = vmx_block_excl_scan(__popc(selmask), s_scan, &tot);
+    if (selmask) {
+        int o = written + ex;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if ((selmask >> j) & 1u) { oh[o] = (uint64_t)hs[j]; op[o] = ((uint32_t)(p0 + j) << 1) | s_z[p0 + j - lo]; ++o; }
+    }
+    written += tot;
+    __syncthreads();
+}
+    return written;
+}
+
 // codes: 1 byte per base (0..4). Outputs per read at mz_off[r] (capacity = number of k-mer starts): hash, pos<<1|strand.
-__global__ void __launch_bounds__(256) k_sketch(const uint8_t* __restrict__ codes, const int64_t* __restrict__ roff, int n_reads, int k, int w,
+// H: uint32_t for 2 k <= 32 (k_sketch32: 25 KB of LDS per workgroup instead of 46), uint64_t otherwise (k_sketch).
+template <typename H>
+__device__ __forceinline__ void vmx_sketch_body(const uint8_t* __restrict__ codes, const int64_t* __restrict__ roff, int n_reads, int k, int w,
                                                 uint64_t* __restrict__ mz_hash, uint32_t* __restrict__ mz_ps, const int64_t* __restrict__ mz_off,
                                                 int32_t* __restrict__ mz_cnt) {
     __shared__ uint8_t s_codes[VMX_SK_TILE + 2 * VMX_SK_HALO + 64];
-    __shared__ uint64_t s_h[VMX_SK_TILE + 2 * VMX_SK_HALO];
-    __shared__ uint64_t s_wmin[VMX_SK_TILE + 2 * VMX_SK_HALO];
+    __shared__ H s_h[VMX_SK_TILE + 2 * VMX_SK_HALO];
+    __shared__ H s_wmin[VMX_SK_TILE + 2 * VMX_SK_HALO];
     __shared__ uint8_t s_z[VMX_SK_TILE + 2 * VMX_SK_HALO];
     __shared__ int s_scan[20];
-    const uint64_t mask = (1ULL << (2 * k)) - 1;
+    const H mask = (H)((2 * k >= (int)(8 * sizeof(H))) ? ~(H)0 : (((H)1 << (2 * k)) - 1));
+    const H HINF = ~(H)0;
     const int shift = 2 * (k - 1);
     for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
         const uint8_t* C = codes + roff[r];
@@ -57,69 +145,7 @@ __global__ void __launch_bounds__(256) k_sketch(const uint8_t* __restrict__ code
             //    hash, so that is the same as: the MAXIMUM of the minima of the windows holding it equals the hash — again a width-10
             //    sliding reduction by doubling (windows outside [0, nwin) count as 0, below every hash that could match);
             //  * one block scan per tile places the tile's minimizers in order.
-            for (int t0 = 0; t0 < P; t0 += VMX_SK_TILE) {
-                const int lo = t0 - 9 > 0 ? t0 - 9 : 0;
-                int hi = t0 + VMX_SK_TILE + 9; if (hi > P) hi = P;
-                const int npos = hi - lo;
-                for (int x = (int)threadIdx.x; x < npos + k - 1; x += 256) s_codes[x] = C[lo + x];
-                __syncthreads();
-                for (int x0 = 8 * (int)threadIdx.x; x0 < npos; x0 += 8 * 256) {
-                    uint64_t fwd = 0, rc = 0; int nval = 0;
-                    for (int i = 0; i < k - 1; ++i) { const uint8_t c = s_codes[x0 + i]; nval = c > 3 ? 0 : nval + 1; fwd = (fwd << 2) | (uint64_t)(c & 3); rc = (rc >> 2) | ((uint64_t)(3 - (c & 3)) << shift); }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if (x0 + j < npos) {
-                            const uint8_t c = s_codes[x0 + j + k - 1]; nval = c > 3 ? 0 : nval + 1;
-                            fwd = ((fwd << 2) | (uint64_t)(c & 3)) & mask; rc = (rc >> 2) | ((uint64_t)(3 - (c & 3)) << shift);
-                            uint64_t h = VMX_INF64; uint8_t z = 0;
-                            if (nval >= k && fwd != rc) { z = rc < fwd ? 1 : 0; h = vmx_hash64(fwd < rc ? fwd : rc, mask); }
-                            s_h[x0 + j] = h; s_z[x0 + j] = z;
-                        }
-                    }
-                }
-                __syncthreads();
-                for (int x0 = 8 * (int)threadIdx.x; x0 < npos; x0 += 8 * 256) {
-                    uint64_t v[17], m2[16], m4[14], m8[8];
-#pragma unroll
-                    for (int i = 0; i < 17; ++i) v[i] = x0 + i < npos ? s_h[x0 + i] : VMX_INF64;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) m2[i] = v[i] < v[i + 1] ? v[i] : v[i + 1];
-#pragma unroll
-                    for (int i = 0; i < 14; ++i) m4[i] = m2[i] < m2[i + 2] ? m2[i] : m2[i + 2];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { m8[i] = m4[i] < m4[i + 4] ? m4[i] : m4[i + 4]; const uint64_t m = m8[i] < m2[i + 8] ? m8[i] : m2[i + 8]; if (x0 + i < npos) s_wmin[x0 + i] = (lo + x0 + i < nwin) ? m : 0ULL; }
-                }
-                __syncthreads();
-                int pend = t0 + VMX_SK_TILE; if (pend > P) pend = P;
-                const int p0 = t0 + 8 * (int)threadIdx.x;               // this thread's positions p0 .. p0 + 7
-                unsigned selmask = 0; uint64_t hs[8];
-                if (p0 < pend) {
-                    const int xa = p0 - 9 - lo;                          // LDS index of window start p0 - 9 (negative: before the sequence)
-                    uint64_t v[17], m2[16], m4[14];
-#pragma unroll
-                    for (int i = 0; i < 17; ++i) v[i] = (xa + i >= 0 && xa + i < npos) ? s_wmin[xa + i] : 0ULL;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) m2[i] = v[i] > v[i + 1] ? v[i] : v[i + 1];
-#pragma unroll
-                    for (int i = 0; i < 14; ++i) m4[i] = m2[i] > m2[i + 2] ? m2[i] : m2[i + 2];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const uint64_t m8 = m4[j] > m4[j + 4] ? m4[j] : m4[j + 4];
-                        const uint64_t mx = m8 > m2[j + 8] ? m8 : m2[j + 8];          // windows p - 9 .. p
-                        const uint64_t h = p0 + j < pend ? s_h[p0 + j - lo] : VMX_INF64;
-                        hs[j] = h;
-                        if (h != VMX_INF64 && mx == h) selmask |= 1u << j;
-                    }
-                }
-                int tot; const int ex = vmx_block_excl_scan(__popc(selmask), s_scan, &tot);
-                if (selmask) {
-                    int o = written + ex;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) if ((selmask >> j) & 1u) { oh[o] = hs[j]; op[o] = ((uint32_t)(p0 + j) << 1) | s_z[p0 + j - lo]; ++o; }
-                }
-                written += tot;
-                __syncthreads();
-            }
+            const int written = vmx_sketch_w10<H>(C, P, k, nwin, s_codes, s_h, s_wmin, s_z, s_scan, oh, op);
             if (threadIdx.x == 0) mz_cnt[r] = written;
             continue;
         }
@@ -131,22 +157,22 @@ __global__ void __launch_bounds__(256) k_sketch(const uint8_t* __restrict__ code
             for (int x = (int)threadIdx.x; x < npos + k - 1; x += (int)blockDim.x) s_codes[x] = C[lo + x];
             __syncthreads();
             for (int x = (int)threadIdx.x; x < npos; x += (int)blockDim.x) {
-                uint64_t fwd = 0, rc = 0; bool ok = true;
+                H fwd = 0, rc = 0; bool ok = true;
                 for (int i = 0; i < k; ++i) {
                     uint8_t c = s_codes[x + i];
                     if (c > 3) ok = false;
-                    fwd = (fwd << 2) | (uint64_t)(c & 3);
-                    rc = (rc >> 2) | ((uint64_t)(3 - (c & 3)) << shift);
+                    fwd = (H)((fwd << 2) | (H)(c & 3));
+                    rc = (H)((rc >> 2) | ((H)(3 - (c & 3)) << shift));
                 }
-                uint64_t h = VMX_INF64; uint8_t z = 0;
-                if (ok && fwd != rc) { z = rc < fwd ? 1 : 0; h = vmx_hash64(fwd < rc ? fwd : rc, mask); }
+                H h = HINF; uint8_t z = 0;
+                if (ok && fwd != rc) { z = rc < fwd ? 1 : 0; h = vmx_hash_t<H>((H)(fwd & mask) < rc ? (H)(fwd & mask) : rc, mask); }
                 s_h[x] = h; s_z[x] = z;
             }
             __syncthreads();
             // window minima for window starts a in [lo, min(hi, nwin)): min over [a, a+wl)
             for (int x = (int)threadIdx.x; x < npos; x += (int)blockDim.x) {
-                int a = lo + x; uint64_t m = VMX_INF64;
-                if (a < nwin) { for (int j = 0; j < wl; ++j) { int y = x + j; if (y < npos) { uint64_t v = s_h[y]; m = v < m ? v : m; } } }
+                int a = lo + x; H m = HINF;
+                if (a < nwin) { for (int j = 0; j < wl; ++j) { int y = x + j; if (y < npos) { H v = s_h[y]; m = v < m ? v : m; } } }
                 s_wmin[x] = m;   // windows whose span leaves [lo,hi) are never consulted for this tile's positions
             }
             __syncthreads();
@@ -154,23 +180,34 @@ __global__ void __launch_bounds__(256) k_sketch(const uint8_t* __restrict__ code
             int pend = t0 + VMX_SK_TILE; if (pend > P) pend = P;
             for (int pb = t0; pb < pend; pb += (int)blockDim.x) {
                 int p = pb + (int)threadIdx.x;
-                int sel = 0; uint64_t h = VMX_INF64; uint8_t z = 0;
+                int sel = 0; H h = HINF; uint8_t z = 0;
                 if (p < pend) {
                     int x = p - lo; h = s_h[x]; z = s_z[x];
-                    if (h != VMX_INF64) {
+                    if (h != HINF) {
                         int a0 = p - wl + 1; if (a0 < 0) a0 = 0;
                         int a1 = p; if (a1 > nwin - 1) a1 = nwin - 1;
                         for (int a = a0; a <= a1; ++a) if (s_wmin[a - lo] == h) { sel = 1; break; }
                     }
                 }
                 int tot; int ex = vmx_block_excl_scan(sel, s_scan, &tot);
-                if (sel) { oh[written + ex] = h; op[written + ex] = ((uint32_t)p << 1) | z; }
+                if (sel) { oh[written + ex] = (uint64_t)h; op[written + ex] = ((uint32_t)p << 1) | z; }
                 written += tot;
                 __syncthreads();
             }
         }
         if (threadIdx.x == 0) mz_cnt[r] = written;
     }
+}
+
+__global__ void __launch_bounds__(256) k_sketch(const uint8_t* __restrict__ codes, const int64_t* __restrict__ roff, int n_reads, int k, int w,
+                                                uint64_t* __restrict__ mz_hash, uint32_t* __restrict__ mz_ps, const int64_t* __restrict__ mz_off,
+                                                int32_t* __restrict__ mz_cnt) {
+    vmx_sketch_body<uint64_t>(codes, roff, n_reads, k, w, mz_hash, mz_ps, mz_off, mz_cnt);
+}
+__global__ void __launch_bounds__(256) k_sketch32(const uint8_t* __restrict__ codes, const int64_t* __restrict__ roff, int n_reads, int k, int w,
+                                                  uint64_t* __restrict__ mz_hash, uint32_t* __restrict__ mz_ps, const int64_t* __restrict__ mz_off,
+                                                  int32_t* __restrict__ mz_cnt) {
+    vmx_sketch_body<uint32_t>(codes, roff, n_reads, k, w, mz_hash, mz_ps, mz_off, mz_cnt);
 }
 
 // open-addressing table: slot = {key, start, count}; empty key = ~0. probe = golden-ratio multiplicative hash, linear.

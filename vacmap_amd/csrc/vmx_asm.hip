@@ -85,6 +85,7 @@ extern "C" int vm_chain_linked(vm_ctx* c, int which, int kmersize, double skipco
     out->gmax = hj.gmax; out->n_hot = hj.hot; out->n_cold = hj.n_cold; out->cold_max = hj.cold_max; out->opcount = hj.opcount;
     const int base = cap_pre - (int)n_pre;
     out->S = (double*)malloc(8 * (size_t)n); out->P = (int64_t*)malloc(8 * (size_t)n); out->S_arg_hot = (int64_t*)malloc(8 * (size_t)std::max<int64_t>(1, hj.hot));
+    struct LinkedOutGuard { vm_linked_out* o; bool keep = false; ~LinkedOutGuard() { if (!keep) vm_linked_out_free(o); } } out_guard{out};      // (an error below frees what was allocated: ADVICE r3)
     std::vector<int32_t> p32((size_t)n), sa32((size_t)std::max<int64_t>(1, hj.hot));
     VMX_TRY(download(out->S, B.S.as<double>() + base, (size_t)n, c->stream)); VMX_TRY(download(p32.data(), B.P.as<int32_t>() + base, (size_t)n, c->stream));
     VMX_TRY(download(sa32.data(), B.SA.p, (size_t)hj.hot, c->stream));
@@ -104,6 +105,7 @@ extern "C" int vm_chain_linked(vm_ctx* c, int which, int kmersize, double skipco
         out->carry_P[i] = cp[i];
         out->carry_rows[4 * i] = cr[i].q; out->carry_rows[4 * i + 1] = cr[i].r; out->carry_rows[4 * i + 2] = cr[i].s; out->carry_rows[4 * i + 3] = (int)cr[i].l & 0xffff;
     }
+    out_guard.keep = true;
     return VM_OK;
 }
 

@@ -25,6 +25,7 @@ using namespace vmx;
 
 #include "vmx_index_priv.h"
 
+__global__ void k_sketch32(const uint8_t* codes, const int64_t* roff, int n_reads, int k, int w, uint64_t* mz_hash, uint32_t* mz_ps, const int64_t* mz_off, int32_t* mz_cnt);
 __global__ void k_sketch(const uint8_t* codes, const int64_t* roff, int n_reads, int k, int w, uint64_t* mz_hash, uint32_t* mz_ps,
                          const int64_t* mz_off, int32_t* mz_cnt);
 __global__ void k_lookup(const uint64_t* mz_hash, const int64_t* mz_off, const int32_t* mz_cnt, int n_reads, const vmx_slot* tab, int bits,
@@ -618,7 +619,8 @@ int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, in
     VMX_TRY(mst.reserve(4 * (size_t)(total_bases + 1))); VMX_TRY(mcn.reserve(4 * (size_t)(total_bases + 1))); VMX_TRY(mho.reserve(4 * (size_t)(total_bases + 1)));
     VMX_TRY(nh.reserve(8 * (size_t)(n + 2))); VMX_TRY(koff.reserve(8 * (size_t)(n + 2))); VMX_TRY(nanc.reserve(4 * (size_t)(n + 1)));
     const unsigned grid = (unsigned)std::max<int64_t>(std::min<int64_t>(n, (int64_t)c->num_cu * 4), 1);
-    hipLaunchKernelGGL(k_sketch, dim3(grid), dim3(256), 0, c->stream, d_codes, d_roff, (int)n, mi->k, mi->w, mzh.as<uint64_t>(), mzp.as<uint32_t>(), d_roff, mzc.as<int32_t>());
+    if (2 * mi->k <= 32) hipLaunchKernelGGL(k_sketch32, dim3(grid), dim3(256), 0, c->stream, d_codes, d_roff, (int)n, mi->k, mi->w, mzh.as<uint64_t>(), mzp.as<uint32_t>(), d_roff, mzc.as<int32_t>());      // 30-bit hashes (k = 15): the 32-bit form
+    else hipLaunchKernelGGL(k_sketch, dim3(grid), dim3(256), 0, c->stream, d_codes, d_roff, (int)n, mi->k, mi->w, mzh.as<uint64_t>(), mzp.as<uint32_t>(), d_roff, mzc.as<int32_t>());
     hipLaunchKernelGGL(k_lookup, dim3(grid), dim3(256), 0, c->stream, mzh.as<uint64_t>(), d_roff, mzc.as<int32_t>(), (int)n, mi->d_table.as<vmx_slot>(), mi->table_bits, mid_occ,
                        mst.as<uint32_t>(), mcn.as<uint32_t>(), mho.as<uint32_t>(), nh.as<int64_t>());
     hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, nh.as<int64_t>(), koff.as<int64_t>(), n, 1);
