@@ -78,6 +78,66 @@ __global__ void __launch_bounds__(1024) k_size_order(const int64_t* __restrict__
     }
 }
 
+// The same ordering on the whole device (round 4): k_size_order is ONE workgroup walking all ~230 k problems of a batch twice (0.55 ms during which its
+// stream's batch does nothing else). k_size_hist counts the classes with any number of workgroups (per-workgroup LDS histogram, then one global
+// atomic per class), k_size_scatter turns the counts into class bases (largest class first) and places every problem with one global atomic
+// per wave and class. ghist[257] (class counts, [256] = problems above `thresh`) and gcur[256] must be zero at launch. The order INSIDE a class
+// is whatever the atomics give — it only ever decided which of two equally large problems a wave takes first.
+__global__ void __launch_bounds__(256) k_size_hist(const int64_t* __restrict__ size, const int32_t* __restrict__ n_ptr, int64_t thresh, int32_t* __restrict__ ghist) {
+    __shared__ int s_hist[257];
+    const int n = *n_ptr;
+    const int lane = vmx_lane();
+    for (int t = (int)threadIdx.x; t < 257; t += (int)blockDim.x) s_hist[t] = 0;
+    __syncthreads();
+    int nl = 0;
+    for (int i0 = (int)(blockIdx.x * blockDim.x); i0 < n; i0 += (int)(gridDim.x * blockDim.x)) {
+        const int i = i0 + (int)threadIdx.x;
+        const long long s = i < n ? size[i] : -1;
+        const int b = vmx_size_class(s);
+        if (s > thresh) ++nl;
+        unsigned long long todo = __ballot(b >= 0);
+        while (todo) {
+            const int leader = __ffsll((unsigned long long)todo) - 1;
+            const int b0 = vmx_readlane(b, leader);
+            const unsigned long long same = __ballot(b == b0);
+            if (lane == leader) atomicAdd(&s_hist[b0], __popcll(same));
+            todo &= ~same;
+        }
+    }
+    if (nl) atomicAdd(&s_hist[256], nl);
+    __syncthreads();
+    for (int t = (int)threadIdx.x; t < 257; t += (int)blockDim.x) if (s_hist[t]) atomicAdd(&ghist[t], s_hist[t]);
+}
+__global__ void __launch_bounds__(256) k_size_scatter(const int64_t* __restrict__ size, const int32_t* __restrict__ n_ptr, const int32_t* __restrict__ ghist,
+                                                      int32_t* __restrict__ gcur, int32_t* __restrict__ order, int32_t* __restrict__ range, int32_t* __restrict__ counters) {
+    VMX_SETPRIO(3);
+    __shared__ int s_base[256];
+    const int n = *n_ptr;
+    const int lane = vmx_lane();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 255; b >= 0; --b) { s_base[b] = acc; acc += ghist[b]; }
+        if (blockIdx.x == 0) { range[0] = ghist[256]; range[1] = acc; counters[0] = 0; counters[1] = 0; counters[2] = 0; counters[3] = 0; }
+    }
+    __syncthreads();
+    for (int i0 = (int)(blockIdx.x * blockDim.x); i0 < n; i0 += (int)(gridDim.x * blockDim.x)) {
+        const int i = i0 + (int)threadIdx.x;
+        const long long s = i < n ? size[i] : -1;
+        const int b = vmx_size_class(s);
+        unsigned long long todo = __ballot(b >= 0);
+        while (todo) {
+            const int leader = __ffsll((unsigned long long)todo) - 1;
+            const int b0 = vmx_readlane(b, leader);
+            const unsigned long long same = __ballot(b == b0);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&gcur[b0], __popcll(same));
+            base = vmx_readlane(base, leader);
+            if (b == b0) order[s_base[b0] + base + __popcll(same & ((1ULL << lane) - 1ULL))] = i;
+            todo &= ~same;
+        }
+    }
+}
+
 // which = 0: problems order[0 .. range[0]) (long), which = 1: order[range[0] .. range[1]). blockDim.x = 64 * W, W <= VMX_ED_WAVES.
 __global__ void __launch_bounds__(64 * VMX_ED_WAVES) k_edit_distance(const uint8_t* __restrict__ qcodes, const int64_t* __restrict__ q_off,
                                                                       const uint8_t* __restrict__ tcodes, const int64_t* __restrict__ t_off,

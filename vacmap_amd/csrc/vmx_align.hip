@@ -88,7 +88,7 @@ struct vmx_batch_bufs {
     // extend stage
     DevBuf er, coff3, soff2, segA, st, en, segA_s, st_s, en_s, segprob, dup, desc[2], rcount, oflow, probread, tl, ql, toff, qoff, tpool, qpool;
     DevBuf edout, carry, ext3, dpsz[4], dpoff[4], dptab, tb, tbredo, bnd, run, cig, ciglen, dpscore, rec, blob, bloboff, reccoff, recclen, dupd, totals;
-    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp, chunkn, sellist, cigq, statblk;
+    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp, chunkn, sellist, cigq, statblk, szh;
     void release() { DevBuf* p = (DevBuf*)this; for (size_t i = 0; i < sizeof(*this) / sizeof(DevBuf); ++i) p[i].release(); }
 };
 static vmx_batch_bufs* batch_bufs(vm_ctx* c) { if (!c->bbufs) c->bbufs = new vmx_batch_bufs(); return c->bbufs; }
@@ -451,7 +451,7 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
         st.dp_string_bytes += tq[0] + tq[1];
         c->n_gev[redo_only ? 1 : 0] = 0;
         if (cnt) {
-            VMX_TRY(B.order.reserve(4 * (size_t)(2 * round_cap + 64))); VMX_TRY(B.qrange.reserve(128));
+            VMX_TRY(B.order.reserve(4 * (size_t)(2 * round_cap + 64))); VMX_TRY(B.qrange.reserve(128)); VMX_TRY(B.szh.reserve(4 * 520));
             int32_t* d_range = B.qrange.as<int32_t>(); int32_t* d_cnt = d_range + 4;
             unsigned long long* d_redo_bytes = (unsigned long long*)(d_range + 16);
             int32_t* d_redo_list = B.order.as<int32_t>() + round_cap + 32; int32_t* d_redo_cnt = d_range + 12;     // problems whose band was not proven
@@ -465,7 +465,7 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
                 // the problems' absolute traceback offsets index a buffer that holds this chunk only
                 uint8_t* tb_base = B.tb.as<uint8_t>() - h_tboff_at[q];
                 hipEvent_t* ke = q < 8 ? c->gev + (redo_only ? 24 : 0) + 3 * q : nullptr;      // HIP events around the dominant kernel, on the stream it runs on
-                hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>() + p0, B.chunkn.as<int32_t>() + q, (int64_t)VMX_HEAD_THRESH, B.order.as<int32_t>(), d_range, d_cnt);
+                vmx_size_order_wide(c, B.dpsz[0].as<int64_t>() + p0, B.chunkn.as<int32_t>() + q, pn, (int64_t)VMX_HEAD_THRESH, B.order.as<int32_t>(), d_range, d_cnt, B.szh.as<int32_t>());
                 (void)hipMemsetAsync(d_redo_cnt, 0, 16, c->stream); (void)hipMemsetAsync(d_redo_bytes, 0, 8, c->stream);
                 if (ke) (void)hipEventRecord(ke[0], c->stream);
                 hipLaunchKernelGGL(k_gapfill_fill_ns, dim3((unsigned)std::min<int64_t>(pn, (int64_t)c->num_cu * fill_waves)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
@@ -503,7 +503,7 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
         if (rc0 < 0) return rc0;
         const int64_t cnt = round_cap;                           // launch widths only: every kernel below reads the real count on the device
         {
-            VMX_TRY(B.order.reserve(4 * (size_t)(2 * round_cap + 64))); VMX_TRY(B.qrange.reserve(128));
+            VMX_TRY(B.order.reserve(4 * (size_t)(2 * round_cap + 64))); VMX_TRY(B.qrange.reserve(128)); VMX_TRY(B.szh.reserve(4 * 520));
             int32_t* d_range = B.qrange.as<int32_t>(); int32_t* d_cnt = d_range + 4; int32_t* d_nfull = d_range + 8;
             VMX_TRY(B.dpsz[0].reserve(8 * (size_t)(round_cap + 2))); VMX_TRY(B.dpsz[1].reserve(8 * (size_t)(round_cap + 2)));
             // tier 0 (k_ed_anchor_bound, k_ext.hip): the segment's own anchors cut the pair into independent short pieces whose summed cost
@@ -515,17 +515,17 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
                                B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.dpsz[1].as<int64_t>());
             hipLaunchKernelGGL(k_ed_flag, dim3((unsigned)std::min<int64_t>((cnt + 255) / 256, 1024)), dim3(256), 0, c->stream, B.dpsz[1].as<int64_t>(), B.qoff.as<int64_t>(), B.toff.as<int64_t>(),
                                B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_n1, 1);
-            hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt);
+            vmx_size_order_wide(c, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), cnt, (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt, B.szh.as<int32_t>());
             hipLaunchKernelGGL(k_ed_banded4, dim3((unsigned)std::min<int64_t>((cnt + 3) / 4, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(),
                                B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.order.as<int32_t>(), d_range, d_cnt + 2, B.dpsz[1].as<int64_t>());
             hipLaunchKernelGGL(k_ed_flag, dim3((unsigned)std::min<int64_t>((cnt + 255) / 256, 1024)), dim3(256), 0, c->stream, B.dpsz[1].as<int64_t>(), B.qoff.as<int64_t>(), B.toff.as<int64_t>(),
                                B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_n2, 0);
-            hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt);
+            vmx_size_order_wide(c, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), cnt, (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt, B.szh.as<int32_t>());
             hipLaunchKernelGGL(k_ed_banded, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(),
                                B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.order.as<int32_t>(), d_range, d_cnt + 2, B.dpsz[1].as<int64_t>());
             hipLaunchKernelGGL(k_ed_flag, dim3((unsigned)std::min<int64_t>((cnt + 255) / 256, 1024)), dim3(256), 0, c->stream, B.dpsz[1].as<int64_t>(), B.qoff.as<int64_t>(), B.toff.as<int64_t>(),
                                B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_nfull, 0);
-            hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt);
+            vmx_size_order_wide(c, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), cnt, (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt, B.szh.as<int32_t>());
             // the exact tier is hardly ever needed (0 problems per step on the bench workload), and its wide workgroups wait for room on a
             // GPU the other batches keep full — an empty launch cost more than this 4-byte read-back does: launch only when something is left
             int32_t h_nfull = 0;

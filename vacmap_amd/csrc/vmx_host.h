@@ -150,6 +150,18 @@ __global__ void k_edit_distance(const uint8_t* qcodes, const int64_t* q_off, con
                                 int8_t* carry_pool, const int32_t* order, const int32_t* range, int32_t* counters, int which, int64_t* out,
                                 int64_t carry_stride, int32_t* oflow);
 __global__ void k_size_order(const int64_t* size, const int32_t* n_ptr, int64_t thresh, int32_t* order, int32_t* range, int32_t* counters);
+__global__ void k_size_hist(const int64_t* size, const int32_t* n_ptr, int64_t thresh, int32_t* ghist);
+__global__ void k_size_scatter(const int64_t* size, const int32_t* n_ptr, const int32_t* ghist, int32_t* gcur, int32_t* order, int32_t* range, int32_t* counters);
+// k_size_order's result with the whole device (k_ed.hip): n_upper = a host-side bound on *n_ptr (grid size); scratch: 513 ints
+static inline void vmx_size_order_wide(vm_ctx* c, const int64_t* size, const int32_t* n_ptr, int64_t n_upper, int64_t thresh, int32_t* order, int32_t* range, int32_t* counters,
+                                       int32_t* scratch) {
+    static const bool one_wg = getenv("VMX_SIZE_ORDER_ONE") != nullptr;          // A/B knob: the one-workgroup kernel of round 3
+    if (one_wg) { hipLaunchKernelGGL(k_size_order, dim3(1), dim3(1024), 0, c->stream, size, n_ptr, thresh, order, range, counters); return; }
+    (void)hipMemsetAsync(scratch, 0, 4 * 513, c->stream);
+    const unsigned G = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_upper + 1023) / 1024, (int64_t)c->num_cu * 2));
+    hipLaunchKernelGGL(k_size_hist, dim3(G), dim3(256), 0, c->stream, size, n_ptr, thresh, scratch);
+    hipLaunchKernelGGL(k_size_scatter, dim3(G), dim3(256), 0, c->stream, size, n_ptr, (const int32_t*)scratch, scratch + 257, order, range, counters);
+}
 __global__ void k_ed_banded(const uint8_t* qcodes, const int64_t* q_off, const uint8_t* tcodes, const int64_t* t_off, const int32_t* order,
                             const int32_t* range, int32_t* counter, int64_t* ub_out);
 struct vmx_ext_args;
