@@ -389,7 +389,7 @@ def main(argv=None, comm=None):
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
 
-    parse_threads = args.parse_threads or max(1, min(4, args.t // 4))
+    parse_threads = args.parse_threads or int(os.environ.get('VMX_PARSE_THREADS', '0')) or max(1, min(4, args.t // 4))
 
     def chunks_of(path):
         """blob chunks of one input in file order. A plain FASTA / FASTQ file is cut into record-aligned slices (vm_fastx_open_range): in range
