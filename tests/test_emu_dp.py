@@ -77,6 +77,12 @@ def test_emu_seed_sparse_noise(ctx, oracle, monkeypatch):
     assert f(0) - t0 >= 8 and f(1) - d0 <= 6, (f(0) - t0, f(1) - d0)     # the filtered form answered (it declines check_num > 1024 and -1)
 
 
+def test_emu_local_general_kernel(ctx, oracle, golden, monkeypatch):
+    """k_local_seed, the general form that takes the reads k_local_seed_band hands back, on its own (VMX_LSEED_BAND=0)"""
+    monkeypatch.setenv('VMX_LSEED_BAND', '0')
+    KC.check_local_golden(ctx, oracle, golden, cases=['B', 'D', 'G'])
+
+
 def test_emu_local_many_chains(ctx, oracle):
     KC.check_local_many_chains(ctx, oracle, copies=70, unit=500)
 

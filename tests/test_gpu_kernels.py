@@ -90,6 +90,12 @@ def test_seed_golden(ctx, oracle, golden):
     KC.check_seed_golden(ctx, oracle, golden)
 
 
+def test_local_general_kernel(ctx, oracle, golden, monkeypatch):
+    """k_local_seed, the general form that takes the reads k_local_seed_band hands back, on its own (VMX_LSEED_BAND=0): goldens of all four modes"""
+    monkeypatch.setenv('VMX_LSEED_BAND', '0')
+    KC.check_local_golden(ctx, oracle, golden, cases=['A', 'B', 'C', 'D', 'G', 'J', 'K'])
+
+
 def test_local_many_chains(ctx, oracle):
     KC.check_local_many_chains(ctx, oracle)
 

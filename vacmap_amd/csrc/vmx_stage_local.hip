@@ -60,7 +60,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
 #endif
     const int G = (int)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)c->num_cu * occ));
     // the guide-banded form (k_local_band.hip) takes every read first; what it hands back (VM_READ_BANDFALL_DEV) runs through k_local_seed
-    static const bool band_on = [] { const char* e = getenv("VMX_LSEED_BAND"); return !e || atoi(e) != 0; }();
+    const bool band_on = [] { const char* e = getenv("VMX_LSEED_BAND"); return !e || atoi(e) != 0; }();      // (read per call: the tests run both kernels in one process)
     int occ_b = 8;
 #ifndef VMX_EMU
     if (band_on) {
