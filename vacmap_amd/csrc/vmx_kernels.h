@@ -108,7 +108,9 @@ struct vmx_lseed_args {
 #define VMX_LB_NBLOG 9
 #define VMX_LB_SORTK 1024
 #endif
+#ifndef VMX_LB_GS
 #define VMX_LB_GS 64
+#endif
 #endif
 #ifndef VMX_LB_BMLOG
 #define VMX_LB_BMLOG 14              /* log2 of the bits of the chunk table's occupancy map */
