@@ -74,7 +74,17 @@ def test_emu_seed_sparse_noise(ctx, oracle, monkeypatch):
     f = ctx.lib.L.vmx_emu_cf_count; f.argtypes = [ctypes.c_int]
     t0, d0 = f(0), f(1)
     KC.check_seed_sparse_noise(ctx, oracle, ref_mb=10, read_len=4000, seed=71, min_hits=900)
-    assert f(0) - t0 >= 8 and f(1) - d0 <= 6, (f(0) - t0, f(1) - d0)     # the filtered form answered (it declines check_num > 1024 and -1)
+    assert f(0) - t0 >= 8 and f(1) - d0 <= 12, (f(0) - t0, f(1) - d0)    # the filtered form answered (it declines check_num > 1024 and -1; k_cluster_gen's long form then declines them again)
+
+
+def test_emu_seed_sparse_noise_long_form(ctx, oracle, monkeypatch):
+    """the LONG filtered form inside k_cluster_gen (reads of more than 16383 hits on the GPU: candidates sorted through the tile, read from HBM)"""
+    monkeypatch.setenv('VMX_CLUSTER_SMALL_MAX', '256'); monkeypatch.setenv('VMX_CLUSTER_HUGE_MIN', '256')
+    import ctypes
+    f = ctx.lib.L.vmx_emu_cf_count; f.argtypes = [ctypes.c_int]
+    t0, d0 = f(0), f(1)
+    KC.check_seed_sparse_noise(ctx, oracle, ref_mb=10, read_len=4000, seed=73, min_hits=900)
+    assert f(0) - t0 >= 8 and f(1) - d0 <= 6, (f(0) - t0, f(1) - d0)
 
 
 def test_emu_local_general_kernel(ctx, oracle, golden, monkeypatch):

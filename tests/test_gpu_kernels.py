@@ -48,8 +48,14 @@ def test_seed_sparse_noise(ctx, oracle, monkeypatch):
     KC.check_seed_sparse_noise(ctx, oracle, ref_mb=60, read_len=12000, seed=73, min_hits=6000)
 
 
+def test_seed_sparse_noise_long_form(ctx, oracle, monkeypatch):
+    """the LONG filtered form inside k_cluster_gen (reads of more than 16383 hits in the product; the knob sends these shorter ones there)"""
+    monkeypatch.setenv('VMX_CLUSTER_SMALL_MAX', '256'); monkeypatch.setenv('VMX_CLUSTER_HUGE_MIN', '256')
+    KC.check_seed_sparse_noise(ctx, oracle, ref_mb=40, read_len=9000, seed=74, min_hits=4200)
+
+
 def test_seed_many_hits(ctx, oracle):
-    """k_cluster_big: reads with more hits than one / several 16384-key LDS tiles (tiled bitonic sort with its HBM steps)"""
+    """k_cluster_gen: reads with more hits than one / several 16384-key LDS tiles (tiled bitonic sort with its HBM steps)"""
     KC.check_seed_many_hits(ctx, oracle, copies=44, unit=2500, read_len=4500, seed=61, min_hits=9000)
     KC.check_seed_many_hits(ctx, oracle, copies=90, unit=3000, read_len=9000, seed=62, min_hits=30000)       # 2 tiles
     KC.check_seed_many_hits(ctx, oracle, copies=200, unit=3000, read_len=9000, seed=63, min_hits=66000)      # 8 tiles (131072 keys)

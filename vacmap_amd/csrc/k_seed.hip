@@ -291,9 +291,11 @@ __global__ void __launch_bounds__(256) k_fill_hits(const uint32_t* __restrict__ 
 #ifdef VMX_EMU
 #define VMX_CF_SLOT_BITS 15                 // emulator build: a layout that fits its 8192-key tile, so that the CPU tests run this path
 #define VMX_CF_CAND 2048
+#define VMX_CFB_SLOT_BITS 15
 #else
 #define VMX_CF_SLOT_BITS 18
 #define VMX_CF_CAND 4096
+#define VMX_CFB_SLOT_BITS 19
 #endif
 #define VMX_CF_F_U64 (1 << (VMX_CF_SLOT_BITS - 5))                       /* filter: 2 bits per slot */
 #define VMX_CF_CS_U64 ((VMX_CF_CAND + 512) / 4)                          /* cluster starts, uint16 each */
@@ -303,9 +305,15 @@ __global__ void __launch_bounds__(256) k_fill_hits(const uint32_t* __restrict__ 
    form, timed the same in the pipeline as the 121 KB form — what the filtered form saved alone it lost by keeping k_local_seed off its CUs) */
 #define VMX_CF_REST_U64 (VMX_CF_CAND + VMX_CF_CS_U64 + 1024 + 1024)
 #define VMX_CF_TOTAL_U64 (VMX_CF_F_U64 > VMX_CF_REST_U64 ? VMX_CF_F_U64 : VMX_CF_REST_U64)
+/* the LONG form (reads of more than 16383 hits, inside k_cluster_gen, a CU's LDS to itself): a filter of 2^19 slots in the whole 128 KB tile,
+   up to tile - 1024 candidates (15360) sorted through the tile like any one-tile sort of the general path and then read from HBM (their copy lives in
+   the cl_keys scratch), the small arrays of the later phases at the start of the tile. A 40 kb read: 30 k hits, ~8 k candidates, one 8192-key tile
+   sort instead of the general path's two 16384-key tiles and their HBM steps; reads of more than 65535 hits or 15360 candidates keep the general path. */
+#define VMX_CFB_CAP (VMX_SORT_LDS_BIG - 1024)
+template <int SB>
 __device__ __forceinline__ bool vmx_cf_is_cand(const uint32_t* F, uint64_t key) {
-    const unsigned slot = (unsigned)((key >> 28) >> 13) & ((1u << VMX_CF_SLOT_BITS) - 1u);
-    const unsigned lo = (slot - 1u) & ((1u << VMX_CF_SLOT_BITS) - 1u), hi = (slot + 1u) & ((1u << VMX_CF_SLOT_BITS) - 1u);
+    const unsigned slot = (unsigned)((key >> 28) >> 13) & ((1u << SB) - 1u);
+    const unsigned lo = (slot - 1u) & ((1u << SB) - 1u), hi = (slot + 1u) & ((1u << SB) - 1u);
     return ((F[slot >> 4] >> (2 * (slot & 15))) & 2u) || ((F[lo >> 4] >> (2 * (lo & 15))) & 1u) || ((F[hi >> 4] >> (2 * (hi & 15))) & 1u);
 }
 #ifdef VMX_EMU
@@ -313,52 +321,87 @@ __device__ __forceinline__ bool vmx_cf_is_cand(const uint32_t* F, uint64_t key) 
 static int g_vmx_cf_taken = 0, g_vmx_cf_declined = 0;
 extern "C" int vmx_emu_cf_count(int which) { return which ? g_vmx_cf_declined : g_vmx_cf_taken; }
 #endif
-template <int BLOCK>
-__device__ __forceinline__ bool vmx_cluster_filtered(const uint64_t* __restrict__ K, int n, int check_num, int kmer, uint64_t* s_sort, int* s_scan,
-                                                     int64_t* __restrict__ out, int32_t* __restrict__ n_anchors_r) {
+#ifdef VMX_CF_TICKS
+__device__ unsigned long long g_vmx_cf_ticks[24];
+extern "C" void vmx_cf_ticks_dump() { unsigned long long h[24]; (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_vmx_cf_ticks), sizeof h);
+    fprintf(stderr, "cf ticks:"); for (int i = 0; i < 24; ++i) fprintf(stderr, " %llu", h[i]); fprintf(stderr, "\n"); }
+#define VMX_CFT(ph) do { __syncthreads(); if (threadIdx.x == 0) { long long t1_ = VMX_CLOCK(); atomicAdd(&g_vmx_cf_ticks[ph], (unsigned long long)(t1_ - cft0)); cft0 = t1_; } } while (0)
+#else
+#define VMX_CFT(ph) do { } while (0)
+#endif
+#ifndef VMX_CF_WAVES
+#define VMX_CF_WAVES 8                      // waves per SIMD the filtered kernel is built for: 8 = two 1024-thread workgroups per CU
+#endif
+template <int BLOCK, bool LONG>
+__device__ __forceinline__ bool vmx_cluster_filtered(const uint64_t* __restrict__ K, int n, int check_num, int kmer, uint64_t* s_sort, int tile, int* s_scan,
+                                                     int64_t* __restrict__ out, uint64_t* __restrict__ CK, int32_t* __restrict__ n_anchors_r) {
     __shared__ int s_cf[8];
-    uint32_t* F = (uint32_t*)s_sort;                              // 64 KB: 2 bits per slot (filter phase only)
-    uint64_t* CAND = s_sort;                                      // 32 KB: candidate keys, sorted in place (over the filter, once it is done)
-    uint64_t* GC = (uint64_t*)out;                                // HBM scratch in the read's (still unused) output rows: candidate keys ...
+    constexpr int SB = LONG ? VMX_CFB_SLOT_BITS : VMX_CF_SLOT_BITS;
+    constexpr int CAP = LONG ? VMX_CFB_CAP : VMX_CF_CAND;        // candidates the form can take
+    constexpr int HB = LONG ? VMX_CFB_CAP : 0x2000;              // handles of the rank keys: below HB a start among the candidates, from HB on a slot of ISO
+    constexpr int CS_U64 = (CAP + 512) / 4;
+    uint32_t* F = (uint32_t*)s_sort;                              // 64 KB (LONG: 128 KB): 2 bits per slot (filter phase only)
+    uint64_t* CAND = s_sort;                                      // 32 KB: candidate keys, sorted in place (over the filter, once it is done); LONG: not used
+    uint64_t* GC = LONG ? CK : (uint64_t*)out;                    // HBM: candidate keys — in the read's (still unused) output rows, LONG: in its cl_keys scratch, where they stay
     uint8_t* FLAG = (uint8_t*)out + 8 * (size_t)n;                // ... and the filter's verdict per hit (1 = candidate); 9 n of the 32 n bytes
-    uint16_t* CS = (uint16_t*)(CAND + VMX_CF_CAND);               // 9 KB: first hit of every candidate cluster (+ end); later the output offsets
-    uint32_t* HIST = (uint32_t*)(CAND + VMX_CF_CAND + VMX_CF_CS_U64);     // 8 KB: radix-select / size histogram; later the isolated keys that were selected
+    uint64_t* REST = LONG ? s_sort : CAND + CAP;                  // the later phases' arrays
+    uint16_t* CS = (uint16_t*)REST;                               // 9 KB: first hit of every candidate cluster (+ end); later the output offsets
+    uint32_t* HIST = (uint32_t*)(REST + CS_U64);                  // 8 KB: radix-select / size histogram; later the isolated keys that were selected
     uint64_t* ISO = (uint64_t*)HIST;
-    uint64_t* SEL = CAND + VMX_CF_CAND + VMX_CF_CS_U64 + 1024;    // 8 KB: rank keys of the selected clusters
+    uint64_t* SEL = REST + CS_U64 + 1024;                         // 8 KB: rank keys of the selected clusters
+    (void)tile; (void)CAND;
     const int tid = (int)threadIdx.x;
-    if (n > 0x3fff) return false;                                 // cluster sizes travel in 14 bits of the rank key
-    for (int i = tid; i < (1 << VMX_CF_SLOT_BITS) / 16; i += BLOCK) F[i] = 0u;
+#ifdef VMX_CF_TICKS
+    long long cft0 = VMX_CLOCK();
+#endif
+    if (n > (LONG ? 0xffff : 0x3fff)) return false;               // (the radix select counts in 16 bits; the host sends reads of more than 16383 hits to the LONG form)
+    { struct alignas(16) q128 { uint64_t a, b; }; for (int i = tid; i < (1 << SB) / 64; i += BLOCK) ((q128*)F)[i] = q128{0ULL, 0ULL}; }   // 16-byte stores
     if (tid == 0) { s_cf[0] = 0; s_cf[3] = 0; }
     __syncthreads();
-    for (int i = tid; i < n; i += BLOCK) {
-        const unsigned slot = (unsigned)((K[i] >> 28) >> 13) & ((1u << VMX_CF_SLOT_BITS) - 1u);
-        const unsigned sh = 2 * (slot & 15);
-        const unsigned old = atomicOr(&F[slot >> 4], 1u << sh);
-        if ((old >> sh) & 1u) atomicOr(&F[slot >> 4], 2u << sh);
+    for (int i0 = tid; i0 < n; i0 += 4 * BLOCK) {                // four keys on their way per thread before the first atomic
+        uint64_t kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * BLOCK; kk[u] = K[i < n ? i : i0]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i0 + u * BLOCK < n) {
+            const unsigned slot = (unsigned)((kk[u] >> 28) >> 13) & ((1u << SB) - 1u);
+            const unsigned sh = 2 * (slot & 15);
+            const unsigned old = atomicOr(&F[slot >> 4], 1u << sh);
+            if ((old >> sh) & 1u) atomicOr(&F[slot >> 4], 2u << sh);
+        }
     }
     __syncthreads();
+    VMX_CFT(0);
     for (int i = tid; i < n; i += BLOCK) {
         const uint64_t key = K[i];
-        const bool cnd = vmx_cf_is_cand(F, key);
+        const bool cnd = vmx_cf_is_cand<SB>(F, key);
         FLAG[i] = cnd ? 1 : 0;
-        if (cnd) { const int p = atomicAdd(&s_cf[0], 1); if (p < VMX_CF_CAND) GC[p] = key; }
+        if (cnd) { const int p = atomicAdd(&s_cf[0], 1); if (p < CAP) GC[p] = key; }
     }
     __syncthreads();
     const int ncand = s_cf[0];
     __syncthreads();
-    if (ncand > VMX_CF_CAND) return false;
-    for (int i = tid; i < ncand; i += BLOCK) CAND[i] = GC[i];     // the filter is dead from here on: its LDS holds the later phases' arrays
-    __syncthreads();
+    VMX_CFT(1);
+    if (ncand > CAP) return false;
     int NC = 1; while (NC < ncand) NC <<= 1;
-    for (int i = ncand + tid; i < NC; i += BLOCK) CAND[i] = VMX_INF64;
-    __syncthreads();
-    const bool fast = NC > 1 && vmx_bitonic_fast_ok(NC);
-    if (fast) {
-        for (int i = tid; i < NC; i += BLOCK) { const int j = vmx_sw(i); if (j > i) { const uint64_t a = CAND[i]; CAND[i] = CAND[j]; CAND[j] = a; } }   // linear -> swizzled (an involution)
+    if constexpr (LONG) {
+        // the filter is dead from here on: the tile sorts the candidates (where they are, in HBM), then holds the later phases' arrays
+        for (int i = ncand + tid; i < NC; i += BLOCK) GC[i] = VMX_INF64;
         __syncthreads();
-        vmx_bitonic_tile_sw(CAND, NC, 0, NC);
-    } else if (NC > 1) vmx_block_bitonic_passes(CAND, NC);
-#define VMX_CF_C(i) (CAND[fast ? vmx_sw(i) : (i)])
+        VMX_CFT(2);
+        if (NC > 1) (void)vmx_block_sort_u64_tiled(GC, NC, s_sort, tile);
+        __syncthreads();
+    } else {
+        for (int i = tid; i < ncand; i += BLOCK) CAND[i] = GC[i]; // the filter is dead from here on: its LDS holds the later phases' arrays
+        __syncthreads();
+        for (int i = ncand + tid; i < NC; i += BLOCK) CAND[i] = VMX_INF64;
+        __syncthreads();
+        VMX_CFT(2);
+        if (NC >= 4) vmx_rank_merge_sort_lds(CAND, CAND + CAP, NC);   // (the second buffer lies over CS / HIST / SEL, which are not in use yet)
+        else if (NC > 1) vmx_block_bitonic_passes(CAND, NC);
+    }
+#define VMX_CF_C(i) (LONG ? GC[i] : CAND[i])
+    VMX_CFT(3);
     // candidate clusters: starts in order (CS), then sizes by difference
     int ncl = 0;
     for (int i0 = 0; i0 < ncand; i0 += BLOCK) {
@@ -373,6 +416,7 @@ __device__ __forceinline__ bool vmx_cluster_filtered(const uint64_t* __restrict_
     if (tid == 0) CS[ncl] = (uint16_t)ncand;
     for (int i = tid; i < 2048; i += BLOCK) HIST[i] = 0u;
     __syncthreads();
+    VMX_CFT(4);
     // clusters of two or more: how many, and the histogram of their sizes (bin 1023 = larger)
     int m2 = 0;
     for (int c = tid; c < ncl; c += BLOCK) { const int sz = (int)CS[c + 1] - (int)CS[c]; if (sz >= 2) { ++m2; atomicAdd(&HIST[sz < 1023 ? sz : 1023], 1u); } }
@@ -381,16 +425,16 @@ __device__ __forceinline__ bool vmx_cluster_filtered(const uint64_t* __restrict_
     const int niso = n - ncand;                                   // isolated hits: singletons by construction
     const int nsingle = (ncl - m2) + niso;
     int nsel = 0;
+    VMX_CFT(5);
+#ifdef VMX_CF_TICKS
+    if (tid == 0) { atomicAdd(&g_vmx_cf_ticks[m2 >= check_num ? 20 : 21], 1ULL); atomicAdd(&g_vmx_cf_ticks[22], (unsigned long long)n); atomicAdd(&g_vmx_cf_ticks[23], (unsigned long long)ncand); }
+#endif
     if (m2 >= check_num) {
         // the cut falls among the clusters of two or more: size s* of the check_num-th, everything larger, and the first of size s* in reference order
-        if (tid == 0) {
-            int acc = 0, sstar = 0, above = 0;
-            for (int b = 1023; b >= 2; --b) { if (acc + (int)HIST[b] >= check_num) { sstar = b; above = acc; break; } acc += (int)HIST[b]; }
-            s_cf[1] = sstar; s_cf[2] = above;
-        }
-        __syncthreads();
+        vmx_hist_cut(HIST, 2, check_num, s_scan, &s_cf[1]);
         const int sstar = s_cf[1], need = check_num - s_cf[2];
         __syncthreads();
+        VMX_CFT(6);
         if (sstar >= 1023 || sstar < 2) return false;
         int neq = 0;
         for (int c0 = 0; c0 < ncl; c0 += BLOCK) {
@@ -406,6 +450,7 @@ __device__ __forceinline__ bool vmx_cluster_filtered(const uint64_t* __restrict_
             nsel += tott; neq += toteq;
             __syncthreads();
         }
+        VMX_CFT(7);
     } else {
         // every cluster of two or more is taken; the rest are the R singletons with the smallest reference positions
         for (int c0 = 0; c0 < ncl; c0 += BLOCK) {
@@ -419,6 +464,7 @@ __device__ __forceinline__ bool vmx_cluster_filtered(const uint64_t* __restrict_
             nsel += tott;
             __syncthreads();
         }
+        VMX_CFT(8);
         int R = check_num - m2; if (R > nsingle) R = nsingle;
         uint64_t T = ~0ULL;                                       // singletons with reference position <= T are taken
         if (R < nsingle) {
@@ -448,6 +494,7 @@ __device__ __forceinline__ bool vmx_cluster_filtered(const uint64_t* __restrict_
             }
             T = prefix;
         }
+        VMX_CFT(9);
         // collect the singletons at or below T: candidate clusters of one (handle = start in CAND) and isolated hits (handle = slot in ISO)
         if (tid == 0) s_cf[6] = 0;
         __syncthreads();
@@ -464,20 +511,23 @@ __device__ __forceinline__ bool vmx_cluster_filtered(const uint64_t* __restrict_
             const uint64_t key = K[i];
             if (!FLAG[i] && (key >> 28) <= T) {
                 const int q = atomicAdd(&s_cf[6], 1);
-                if (nsel + q < 1024) { ISO[q] = key; SEL[nsel + q] = ((uint64_t)(0x3fffu - 1u) << 50) | ((key >> 28) << 14) | (uint64_t)(0x2000 | q); }
+                if (nsel + q < 1024) { ISO[q] = key; SEL[nsel + q] = ((uint64_t)(0x3fffu - 1u) << 50) | ((key >> 28) << 14) | (uint64_t)(HB + q); }
             }
         }
         __syncthreads();
         nsel += s_cf[6];
         __syncthreads();
         if (nsel > 1024 || s_cf[3]) return false;
+        VMX_CFT(10);
     }
     if (nsel > check_num) return false;                           // (cannot happen; the general path is the safe answer to a broken invariant)
     int NS = 1; while (NS < nsel) NS <<= 1;
     for (int i = nsel + tid; i < NS; i += BLOCK) SEL[i] = VMX_INF64;
     __syncthreads();
-    if (NS > 1) vmx_block_bitonic_passes(SEL, NS);
+    if (NS >= 4 && NS <= CS_U64) vmx_rank_merge_sort_lds(SEL, (uint64_t*)CS, NS);     // (CS is done with: its slots are the second buffer)
+    else if (NS > 1) vmx_block_bitonic_passes(SEL, NS);
     __syncthreads();
+    VMX_CFT(11);
     // emit cluster by cluster in rank order: output offsets (over CS, which is done with), then every thread copies hits
     uint32_t* OFF = (uint32_t*)CS;
     int total = 0;
@@ -490,24 +540,28 @@ __device__ __forceinline__ bool vmx_cluster_filtered(const uint64_t* __restrict_
         total += tot;
         __syncthreads();
     }
+    VMX_CFT(12);
     for (int e = tid; e < total; e += BLOCK) {
         int lo = 0, hi = nsel;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)OFF[mid] <= e) lo = mid; else hi = mid; }
         const uint64_t sk = SEL[lo]; const int h = (int)(sk & 0x3fffu);
-        const uint64_t hk = (h & 0x2000) ? ISO[h & 0x1fff] : VMX_CF_C(h + (e - (int)OFF[lo]));
+        const uint64_t hk = h >= HB ? ISO[h - HB] : VMX_CF_C(h + (e - (int)OFF[lo]));
         int64_t* o = out + 4 * (int64_t)e;
         o[0] = (int64_t)((hk >> 1) & 0x7ffffffULL); o[1] = (int64_t)(hk >> 28); o[2] = (hk & 1) ? 1 : -1; o[3] = kmer;
     }
     if (tid == 0) *n_anchors_r = total;
     __syncthreads();
+    VMX_CFT(13);
     return true;
 #undef VMX_CF_C
 }
 
-template <int BLOCK>
+// FORM 0: the general path. FORM 1: the filtered form alone; a read it declines goes on the `decl` list (count in *n_decl) for a later launch
+// of the general path — the two forms in one kernel cost the filtered one the general path's 128 registers, i.e. one workgroup per CU.
+template <int BLOCK, int FORM>
 __device__ __forceinline__ void vmx_cluster_body(uint64_t* __restrict__ keys, uint64_t* __restrict__ cl_keys, const int64_t* __restrict__ key_off,
                                                  const int64_t* __restrict__ nhits, const int32_t* __restrict__ rlist, int nlist, int tile, int check_num, int kmer,
-                                                 int64_t* __restrict__ rows, int32_t* __restrict__ n_anchors) {
+                                                 int64_t* __restrict__ rows, int32_t* __restrict__ n_anchors, int32_t* __restrict__ decl = nullptr, int32_t* __restrict__ n_decl = nullptr) {
     VMX_DYN_SHARED(uint64_t, s_sort);
     __shared__ int s_scan[20];
     __shared__ int s_ncl;
@@ -518,14 +572,26 @@ __device__ __forceinline__ void vmx_cluster_body(uint64_t* __restrict__ keys, ui
         int N = 1; while (N < n) N <<= 1;
         uint64_t* K = keys + key_off[r];
         uint64_t* CK = cl_keys + key_off[r];
-        if (BLOCK == 1024 && tile >= VMX_CF_TOTAL_U64 && check_num > 0 && check_num <= 1024) {
+        if constexpr (FORM == 1) {
             // (uniform: every thread sees the same n and gets the same answer)
-            const bool cf_done = vmx_cluster_filtered<BLOCK>(K, n, check_num, kmer, s_sort, s_scan, rows + 4 * key_off[r], &n_anchors[r]);
+            const bool cf_done = tile >= VMX_CF_TOTAL_U64 && check_num > 0 && check_num <= 1024 &&
+                                 vmx_cluster_filtered<BLOCK, false>(K, n, check_num, kmer, s_sort, tile, s_scan, rows + 4 * key_off[r], CK, &n_anchors[r]);
 #ifdef VMX_EMU
             if (threadIdx.x == 0) ++(cf_done ? g_vmx_cf_taken : g_vmx_cf_declined);
 #endif
-            if (cf_done) continue;
+            if (!cf_done && threadIdx.x == 0) decl[atomicAdd(n_decl, 1)] = r;
             __syncthreads();
+            continue;
+        }
+        if constexpr (FORM == 2) {
+            // the LONG filtered form first (reads of up to 65535 hits, up to 15360 candidates); what it declines takes the general path below
+            const bool cf_done = tile >= VMX_SORT_LDS_BIG && check_num > 0 && check_num <= 1024 &&
+                                 vmx_cluster_filtered<BLOCK, true>(K, n, check_num, kmer, s_sort, tile, s_scan, rows + 4 * key_off[r], CK, &n_anchors[r]);
+#ifdef VMX_EMU
+            if (threadIdx.x == 0) ++(cf_done ? g_vmx_cf_taken : g_vmx_cf_declined);
+#endif
+            __syncthreads();
+            if (cf_done) continue;
         }
         if (N > 1) vmx_block_sort_u64_tiled(K, N, s_sort, tile);
         __syncthreads();
@@ -559,13 +625,9 @@ __device__ __forceinline__ void vmx_cluster_body(uint64_t* __restrict__ keys, ui
                 atomicAdd(&hist[sz < 1023 ? sz : 1023], 1);
             }
             __syncthreads();
-            if (threadIdx.x == 0) {
-                int acc = 0, sstar = 0, above = 0;
-                for (int b = 1023; b >= 1; --b) { if (acc + hist[b] >= check_num) { sstar = b; above = acc; break; } acc += hist[b]; }
-                s_ncl = sstar; s_scan[18] = above;                    // clusters strictly larger than s*, and s* (1023: the overflow bin holds the cut)
-            }
-            __syncthreads();
-            const int sstar = s_ncl, above = s_scan[18];
+            __shared__ int s_cut[2];                                  // s*, and the clusters strictly larger than s* (1023: the overflow bin holds the cut)
+            vmx_hist_cut((const uint32_t*)hist, 1, check_num, s_scan, s_cut);
+            const int sstar = s_cut[0], above = s_cut[1];
             __syncthreads();
             if (sstar >= 1023 || sstar == 0) {
                 // the cut falls among clusters of 1023 hits or more (or nothing was found): keep the general path
@@ -662,12 +724,19 @@ __device__ __forceinline__ void vmx_cluster_body(uint64_t* __restrict__ keys, ui
 __global__ void __launch_bounds__(256) k_cluster(uint64_t* __restrict__ keys, uint64_t* __restrict__ cl_keys, const int64_t* __restrict__ key_off,
                                                  const int64_t* __restrict__ nhits, const int32_t* __restrict__ rlist, int nlist, int tile, int check_num, int kmer,
                                                  int64_t* __restrict__ rows, int32_t* __restrict__ n_anchors) {
-    vmx_cluster_body<256>(keys, cl_keys, key_off, nhits, rlist, nlist, tile, check_num, kmer, rows, n_anchors);
+    vmx_cluster_body<256, 0>(keys, cl_keys, key_off, nhits, rlist, nlist, tile, check_num, kmer, rows, n_anchors);
 }
-__global__ void __launch_bounds__(1024) k_cluster_big(uint64_t* __restrict__ keys, uint64_t* __restrict__ cl_keys, const int64_t* __restrict__ key_off,
+// reads with more hits than k_cluster's tile: the filtered form, two 1024-thread workgroups per CU (64 KB of LDS, 64 registers) ...
+__global__ void __launch_bounds__(1024, VMX_CF_WAVES) k_cluster_big(uint64_t* __restrict__ keys, uint64_t* __restrict__ cl_keys, const int64_t* __restrict__ key_off,
                                                       const int64_t* __restrict__ nhits, const int32_t* __restrict__ rlist, int nlist, int tile, int check_num, int kmer,
-                                                      int64_t* __restrict__ rows, int32_t* __restrict__ n_anchors) {
-    vmx_cluster_body<1024>(keys, cl_keys, key_off, nhits, rlist, nlist, tile, check_num, kmer, rows, n_anchors);
+                                                      int64_t* __restrict__ rows, int32_t* __restrict__ n_anchors, int32_t* __restrict__ decl, int32_t* __restrict__ n_decl) {
+    vmx_cluster_body<1024, 1>(keys, cl_keys, key_off, nhits, rlist, nlist, tile, check_num, kmer, rows, n_anchors, decl, n_decl);
+}
+// ... and the general path for the reads that form declines or cannot take (more than 16383 hits); nlist_dev: the list's length, on the device
+__global__ void __launch_bounds__(1024) k_cluster_gen(uint64_t* __restrict__ keys, uint64_t* __restrict__ cl_keys, const int64_t* __restrict__ key_off,
+                                                      const int64_t* __restrict__ nhits, const int32_t* __restrict__ rlist, int nlist, const int32_t* __restrict__ nlist_dev,
+                                                      int tile, int check_num, int kmer, int64_t* __restrict__ rows, int32_t* __restrict__ n_anchors) {
+    vmx_cluster_body<1024, 2>(keys, cl_keys, key_off, nhits, rlist, nlist_dev ? *nlist_dev : nlist, tile, check_num, kmer, rows, n_anchors);
 }
 
 // three-phase exclusive scan for large n: per-chunk sums -> k_scan_i64 over the sums -> per-chunk scan with its base

@@ -99,10 +99,16 @@ int vm_ctx_create(int device_id, vm_ctx** out) {
     return VM_OK;
 }
 
+#ifdef VMX_CF_TICKS
+extern "C" void vmx_cf_ticks_dump();
+#endif
 void vm_ctx_destroy(vm_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+#ifdef VMX_CF_TICKS
+    vmx_cf_ticks_dump();
+#endif
     for (int i = 0; i < VMX_NBUF; ++i) c->b[i].release();
     vmx_ctx_free_local_bufs(c);
     vmx_ctx_free_batch_bufs(c);

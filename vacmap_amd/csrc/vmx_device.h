@@ -262,11 +262,34 @@ __device__ __forceinline__ int vmx_block_excl_scan(int v, int* scratch, int* tot
     __syncthreads();
     if (lane == 63) scratch[w] = inc;
     __syncthreads();
-    if (threadIdx.x == 0) { int s = 0; for (int i = 0; i < nw; ++i) { int t = scratch[i]; scratch[i] = s; s += t; } scratch[16] = s; }
+    if (w == 0) {                                                  // the (<= 16) wave totals: one more wave-level scan, not a loop in one thread
+        const int t = lane < nw ? scratch[lane] : 0;
+        const int i2 = vmx_wave_incl_scan_i32(t);
+        if (lane < nw) scratch[lane] = i2 - t;
+        if (lane == nw - 1) scratch[16] = i2;
+    }
     __syncthreads();
     int base = scratch[w];
     *total = scratch[16];
     return base + inc - v;
+}
+// histogram cut: with bins summed from 1023 downwards (bins below `lo` left out), the bin where the running count reaches `want`:
+// res[0] = that bin (0: never reached), res[1] = the count in the bins above it. hist: 1024 bins in LDS; res: two ints in LDS; every
+// thread of the workgroup calls it. (One thread walking the bins cost a 1024-thread workgroup 65 us per read: more than the rest of
+// k_cluster_big together.)
+__device__ __forceinline__ void vmx_hist_cut(const uint32_t* hist, int lo, int want, int* scratch, int* res) {
+    if (threadIdx.x == 0) { res[0] = 0; res[1] = 0; }
+    __syncthreads();
+    int acc = 0;
+    for (int b0 = 1023; b0 >= lo; b0 -= (int)blockDim.x) {
+        const int b = b0 - (int)threadIdx.x;
+        const int v = b >= lo ? (int)hist[b] : 0;
+        int tot; const int ex = acc + vmx_block_excl_scan(v, scratch, &tot);
+        if (ex < want && ex + v >= want) { res[0] = b; res[1] = ex; }
+        acc += tot;
+        __syncthreads();
+        if (acc >= want) break;
+    }
 }
 
 // block-wide bitonic sort of N (power of two) uint64 keys living in HBM at g; staged through `lds` (lds_cap keys) when they fit.
@@ -354,6 +377,52 @@ __device__ __forceinline__ void vmx_bitonic_tile_sw(uint64_t* lds, int N, int gb
 }
 // is the register-blocked form worth it? it needs R keys per working thread; below a quarter of the workgroup the plain passes win
 __device__ __forceinline__ bool vmx_bitonic_fast_ok(int N) { return N >= 4 * VMX_SORT_R && (N >> VMX_SORT_LOGR) >= ((int)blockDim.x >> 2); }
+
+// ---- rank-merge sort of an LDS tile --------------------------------------------------------------------------------------------
+// For a few thousand keys under a 1024-thread workgroup the bitonic forms are bound by their barriers (66 stages for 2048 keys) or, register-
+// blocked, by the two wavefronts that hold all the keys. Here every thread sorts four consecutive keys in registers, then runs double in length
+// round by round: an element's slot in the merged run is its offset in its own run plus its rank in the sibling run (a branch-free binary
+// search; left runs count the sibling's smaller keys, right runs the smaller-or-equal ones, so equal keys — the padding — get distinct slots).
+// log2(N) - 2 rounds of one barrier each, every thread busy, keys in linear order. A: the keys (N a power of two >= 4), B: N more slots;
+// the result is in A. Every thread of the workgroup must call it.
+__device__ __forceinline__ void vmx_rank_merge_sort_lds(uint64_t* A, uint64_t* B, int N) {
+    const int T = (int)blockDim.x, tid = (int)threadIdx.x;
+    int rounds = 0; for (int L = 4; L < N; L <<= 1) ++rounds;
+    uint64_t* src = (rounds & 1) ? B : A;                         // an odd number of rounds starts from B, so that the last one lands in A
+    uint64_t* dst = (rounds & 1) ? A : B;
+    for (int g = tid; g < (N >> 2); g += T) {
+        uint64_t r0 = A[4 * g], r1 = A[4 * g + 1], r2 = A[4 * g + 2], r3 = A[4 * g + 3];
+        vmx_ce_u64(r0, r1, true); vmx_ce_u64(r2, r3, true); vmx_ce_u64(r0, r2, true); vmx_ce_u64(r1, r3, true); vmx_ce_u64(r1, r2, true);
+        src[4 * g] = r0; src[4 * g + 1] = r1; src[4 * g + 2] = r2; src[4 * g + 3] = r3;
+    }
+    __syncthreads();
+    for (int L = 4; L < N; L <<= 1) {
+        // two elements per thread and step: the two searches are independent, their LDS reads overlap
+        for (int i0 = tid; i0 < N; i0 += 2 * T) {
+            const int i1 = i0 + T < N ? i0 + T : i0;
+            const uint64_t x0 = src[i0], x1 = src[i1];
+            const bool l0 = (i0 & L) == 0, l1 = (i1 & L) == 0;
+            const int b0 = i0 & ~(2 * L - 1), b1 = i1 & ~(2 * L - 1);
+            const uint64_t* s0 = src + b0 + (l0 ? L : 0);
+            const uint64_t* s1 = src + b1 + (l1 ? L : 0);
+            // right runs count the keys <= x, i.e. < x + 1; the all-ones padding in a right run goes behind everything on the left
+            const bool top0 = !l0 && x0 == ~0ULL, top1 = !l1 && x1 == ~0ULL;
+            const uint64_t a0 = l0 || top0 ? x0 : x0 + 1, a1 = l1 || top1 ? x1 : x1 + 1;
+            int p0 = 0, p1 = 0;
+            for (int st = L >> 1; st > 0; st >>= 1) {
+                const uint64_t v0 = s0[p0 + st - 1], v1 = s1[p1 + st - 1];
+                p0 += v0 < a0 ? st : 0; p1 += v1 < a1 ? st : 0;
+            }
+            { const uint64_t v0 = s0[p0], v1 = s1[p1]; p0 += v0 < a0 ? 1 : 0; p1 += v1 < a1 ? 1 : 0; }
+            if (top0) p0 = L;
+            if (top1) p1 = L;
+            dst[b0 + (i0 & (L - 1)) + p0] = x0;
+            if (i1 != i0) dst[b1 + (i1 & (L - 1)) + p1] = x1;
+        }
+        __syncthreads();
+        uint64_t* t = src; src = dst; dst = t;
+    }
+}
 
 // (the passes are instantiated once on the LDS buffer and once on the HBM array: a pointer chosen at run time would make them flat accesses)
 __device__ inline void vmx_block_sort_u64_impl(uint64_t* g, int N, uint64_t* lds, int lds_cap) {
