@@ -48,12 +48,27 @@ def main():
         (live.add if d > 0 else live.discard)(i)
     wall = t1 - t0
     nb = len(sk) - skip
+    # per kernel name: time at least one launch of it is resident (union over the streams), time two or more are, and the sum of durations
+    names = sorted(set(r[0] for r in sel))
+    uni = collections.Counter(); multi = collections.Counter(); tot = collections.Counter()
+    for nm in names:
+        e2 = []
+        for r in sel:
+            if r[0] == nm: e2.append((r[1], 1)); e2.append((r[2], -1)); tot[nm] += r[2] - r[1]
+        e2.sort(); k = 0; lt = t0
+        for t, d in e2:
+            if k >= 1: uni[nm] += t - lt
+            if k >= 2: multi[nm] += t - lt
+            lt = t; k += d
     print('timed region %.1f ms, %d batches, %d kernel launches' % (wall / 1e6, nb, len(sel)))
     for k in range(5):
         print('  %s kernels resident: %6.1f ms (%4.1f %%)' % (('%d' % k) if k < 4 else '4+', hist[k] / 1e6, 100.0 * hist[k] / wall))
     print('wall-time share per kernel (an instant is split evenly among the kernels resident in it): ms, %, ms per batch; time alone on the GPU')
     for n, v in sorted(under.items(), key=lambda x: -x[1])[:18]:
         print('  %-24s %7.1f  %4.1f %%  %5.2f   alone %6.1f ms' % (n, v / 1e6, 100.0 * v / wall, v / 1e6 / max(nb, 1), solo[n] / 1e6))
+    print('residency per kernel name, ms per batch: sum of launch durations / time one or more launches are resident / time two or more are')
+    for n, v in sorted(tot.items(), key=lambda x: -x[1])[:14]:
+        print('  %-24s sum %6.2f   one+ %6.2f   two+ %6.2f' % (n, v / 1e6 / max(nb, 1), uni[n] / 1e6 / max(nb, 1), multi[n] / 1e6 / max(nb, 1)))
 
 
 if __name__ == '__main__':
