@@ -71,7 +71,7 @@ def main():
     ap.add_argument('--err', type=float, default=None, help='default: the config\'s (0.10 ONT, 0.005 HiFi)')
     ap.add_argument('--cpu-sample', type=int, default=96, help='minimum reads for the CPU baseline leg (rank 0, N=1 only); 0 disables')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='target wall time of the CPU baseline leg (the sample is sized by a pilot)')
-    ap.add_argument('--streams', type=int, default=4, help='batches in flight per GPU (vacmap_amd.pipeline)')
+    ap.add_argument('--streams', type=int, default=5, help='batches in flight per GPU (vacmap_amd.pipeline)')
     ap.add_argument('--window-batches', type=int, default=16, help='length binning window of the scheduler, in batches')
     ap.add_argument('--arrival-order', action='store_true', help='no length binning: batches in arrival order (measured once for comparison)')
     ap.add_argument('--host-input', action='store_true', help='also time the same batches handed over as HOST buffers (vm_align_batch uploads them: the PCIe-inclusive rate; reported next to `value`, never as it)')
@@ -80,7 +80,7 @@ def main():
                     'ont_100mb = configs[1], hifi_hg38 = configs[2] (HiFi 18 kb, 0.5 %% error, -mode L -k 19)')
     ap.add_argument('--extra-configs', default='ont_100mb,hifi_hg38', help='other single-GPU BASELINE configs timed in their own short runs of this script (N = 1 only) and '
                     'reported under extra.configs next to the headline; "" disables')
-    ap.add_argument('--extra-steps', type=int, default=6)
+    ap.add_argument('--extra-steps', type=int, default=15)
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     if args.ref_mb > 0:                               # (kept: --ref-mb M = the ONT workload against one contig of M Mb)

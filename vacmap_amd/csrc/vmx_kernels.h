@@ -229,8 +229,8 @@ __device__ __forceinline__ uint8_t* vmx_tb_ptr(const uint8_t* tb_pool, const uin
     return (uint8_t*)(base + (unsigned long long)(off >= 0 ? off : -off - 1));
 }
 #define VMX_HEAD_THRESH (((int64_t)1 << 18) - 1)   /* traceback bytes above which a gap-fill problem is taken from the queue alone (k_size_order thresh): ~450 x 450 and up */
-#define VMX_TB_CHUNK ((int64_t)8 << 30)    // gap fill: traceback bytes held at a time; a batch needing more runs fill + trace chunk by chunk. 8 GB (12 in round 3): four batches in
-                                          // flight fit in 288 GB (262 GB at hg38 size) and the step does not notice the extra chunk (VMX_TB_CHUNK_GB: tuning knob)
+#define VMX_TB_CHUNK ((int64_t)4 << 30)    // gap fill: traceback bytes held at a time; a batch needing more runs fill + trace chunk by chunk. 4 GB (12 in round 3, 8 earlier
+                                          // in round 4): FIVE batches in flight fit at hg38 size (296 of 309 GB) and the step does not notice the extra chunks (VMX_TB_CHUNK_GB: tuning knob)
 #ifdef VMX_EMU
 #define VMX_MAX_BATCH_BASES 20000          // emulator build: small limits so that the CPU tests split a batch
 #define VMX_MAX_BATCH_READS 6

@@ -158,7 +158,7 @@ def build_parser():
     for a, _ in RG_ARGS:
         p.add_argument('--' + a, dest=a.replace('-', '_'))
     p.add_argument('--device', type=int, default=None); p.add_argument('--batch-reads', type=int, default=4096)
-    p.add_argument('--window-batches', type=int, default=8); p.add_argument('--inflight', type=int, default=4)
+    p.add_argument('--window-batches', type=int, default=8); p.add_argument('--inflight', type=int, default=5)
     # N ranks (torchrun): 'range' = every rank parses its own byte range of each plain FASTA / FASTQ input and writes its own part of the SAM file
     # (<out>.partNNN, concatenated by rank 0 at the end unless --parts); 'batch' = every rank parses everything and keeps every N-th batch, rank 0
     # gathers the text (compressed / BAM input, stdout or BAM output); 'auto' picks 'range' whenever input and output allow it

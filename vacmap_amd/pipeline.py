@@ -47,7 +47,7 @@ class _Roctx:
 
 _roctx = _Roctx()
 
-DEFAULT_INFLIGHT = 4
+DEFAULT_INFLIGHT = 5
 DEFAULT_BATCH_READS = 4096
 DEFAULT_WINDOW_BATCHES = 16
 
