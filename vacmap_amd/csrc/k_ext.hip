@@ -172,7 +172,7 @@ __global__ void k_desc_lens(const vmx_pair_desc* __restrict__ desc, const int32_
 __device__ __forceinline__ void vmx_gather_one(const vmx_sdesc& d, const uint8_t* rd, const uint8_t* ref, uint8_t* out) {
     const uint8_t* src = d.src == 0 ? rd : ref;
     const int n = d.len;
-    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
+    for (int i = (int)(threadIdx.x & 63); i < n; i += 64) {       // one wavefront per problem
         uint8_t c;
         if (d.op == 0) c = src[d.start + i];
         else if (d.op == 1) c = src[d.start + n - 1 - i];
@@ -187,10 +187,13 @@ __global__ void __launch_bounds__(256) k_gather(const vmx_pair_desc* __restrict_
                                                 const uint8_t* __restrict__ ocodes, const int64_t* __restrict__ roff, const uint8_t* __restrict__ ref,
                                                 const int64_t* __restrict__ t_off, const int64_t* __restrict__ q_off, uint8_t* __restrict__ tpool,
                                                 uint8_t* __restrict__ qpool, int64_t pool_cap, int32_t* __restrict__ overflow) {
+    // a problem's two strings are a few hundred bytes: one wavefront each (a 256-thread workgroup per problem kept a quarter as many
+    // descriptor / source loads in flight and left most of its threads without a byte to copy)
     const int n = *n_prob;
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int wpb = (int)(blockDim.x >> 6), wv = (int)(threadIdx.x >> 6);
+    for (int i = (int)blockIdx.x * wpb + wv; i < n; i += (int)gridDim.x * wpb) {
         const vmx_pair_desc d = desc[i];
-        if (t_off[i] + d.t.len > pool_cap || q_off[i] + d.q.len > pool_cap) { if (threadIdx.x == 0) atomicExch(overflow, 1); continue; }
+        if (t_off[i] + d.t.len > pool_cap || q_off[i] + d.q.len > pool_cap) { if ((threadIdx.x & 63) == 0) atomicExch(overflow, 1); continue; }
         const uint8_t* rd = ocodes + roff[prob_read[i]];
         vmx_gather_one(d.t, rd, ref, tpool + t_off[i]);
         vmx_gather_one(d.q, rd, ref, qpool + q_off[i]);

@@ -389,7 +389,13 @@ __device__ __forceinline__ bool vmx_cluster_filtered(const uint64_t* __restrict_
         for (int i = ncand + tid; i < NC; i += BLOCK) GC[i] = VMX_INF64;
         __syncthreads();
         VMX_CFT(2);
-        if (NC > 1) (void)vmx_block_sort_u64_tiled(GC, NC, s_sort, tile);
+        // (eight keys per thread: the sixteen-key form of the general path needs its 128 registers)
+        const bool rb = NC >= 64;
+        for (int i = tid; i < NC; i += BLOCK) s_sort[rb ? vmx_sw(i) : i] = GC[i];
+        __syncthreads();
+        if (rb) vmx_bitonic_tile_sw_t<3>(s_sort, NC, 0, NC); else if (NC > 1) vmx_block_bitonic_passes(s_sort, NC);
+        __syncthreads();
+        for (int i = tid; i < NC; i += BLOCK) GC[i] = s_sort[rb ? vmx_sw(i) : i];
         __syncthreads();
     } else {
         for (int i = tid; i < ncand; i += BLOCK) CAND[i] = GC[i]; // the filter is dead from here on: its LDS holds the later phases' arrays
@@ -583,15 +589,16 @@ __device__ __forceinline__ void vmx_cluster_body(uint64_t* __restrict__ keys, ui
             __syncthreads();
             continue;
         }
-        if constexpr (FORM == 2) {
-            // the LONG filtered form first (reads of up to 65535 hits, up to 15360 candidates); what it declines takes the general path below
+        if constexpr (FORM == 3) {
+            // the LONG filtered form alone (reads of up to 65535 hits, up to 15360 candidates); what it declines goes on the list for the general path
             const bool cf_done = tile >= VMX_SORT_LDS_BIG && check_num > 0 && check_num <= 1024 &&
                                  vmx_cluster_filtered<BLOCK, true>(K, n, check_num, kmer, s_sort, tile, s_scan, rows + 4 * key_off[r], CK, &n_anchors[r]);
 #ifdef VMX_EMU
             if (threadIdx.x == 0) ++(cf_done ? g_vmx_cf_taken : g_vmx_cf_declined);
 #endif
+            if (!cf_done && threadIdx.x == 0) decl[atomicAdd(n_decl, 1)] = r;
             __syncthreads();
-            if (cf_done) continue;
+            continue;
         }
         if (N > 1) vmx_block_sort_u64_tiled(K, N, s_sort, tile);
         __syncthreads();
@@ -736,7 +743,15 @@ __global__ void __launch_bounds__(1024, VMX_CF_WAVES) k_cluster_big(uint64_t* __
 __global__ void __launch_bounds__(1024) k_cluster_gen(uint64_t* __restrict__ keys, uint64_t* __restrict__ cl_keys, const int64_t* __restrict__ key_off,
                                                       const int64_t* __restrict__ nhits, const int32_t* __restrict__ rlist, int nlist, const int32_t* __restrict__ nlist_dev,
                                                       int tile, int check_num, int kmer, int64_t* __restrict__ rows, int32_t* __restrict__ n_anchors) {
-    vmx_cluster_body<1024, 2>(keys, cl_keys, key_off, nhits, rlist, nlist_dev ? *nlist_dev : nlist, tile, check_num, kmer, rows, n_anchors);
+    vmx_cluster_body<1024, 0>(keys, cl_keys, key_off, nhits, rlist, nlist_dev ? *nlist_dev : nlist, tile, check_num, kmer, rows, n_anchors);
+}
+// the LONG filtered form (reads of more than 16383 hits, and the reads k_cluster_big declines): one workgroup per CU (128 KB of LDS) at 64
+// registers, so that the CU's other half of the register file stays free for LDS-less kernels of the other batches (the gap fill)
+__global__ void __launch_bounds__(1024, VMX_CF_WAVES) k_cluster_long(uint64_t* __restrict__ keys, uint64_t* __restrict__ cl_keys, const int64_t* __restrict__ key_off,
+                                                      const int64_t* __restrict__ nhits, const int32_t* __restrict__ rlist, int nlist, const int32_t* __restrict__ nlist_dev,
+                                                      int tile, int check_num, int kmer, int64_t* __restrict__ rows, int32_t* __restrict__ n_anchors,
+                                                      int32_t* __restrict__ decl, int32_t* __restrict__ n_decl) {
+    vmx_cluster_body<1024, 3>(keys, cl_keys, key_off, nhits, rlist, nlist_dev ? *nlist_dev : nlist, tile, check_num, kmer, rows, n_anchors, decl, n_decl);
 }
 
 // three-phase exclusive scan for large n: per-chunk sums -> k_scan_i64 over the sums -> per-chunk scan with its base

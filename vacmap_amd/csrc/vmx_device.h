@@ -331,50 +331,57 @@ __device__ __forceinline__ void vmx_ce_u64(uint64_t& x, uint64_t& y, bool asc) {
 #define VMX_SORT_LOGR 4
 #endif
 #define VMX_SORT_R (1 << VMX_SORT_LOGR)
-__device__ __forceinline__ void vmx_bitonic_roundtrip(uint64_t* lds, int N, int gbase, int k, int b, int nst, bool first) {
+template <int LOGR>
+__device__ __forceinline__ void vmx_bitonic_roundtrip_t(uint64_t* lds, int N, int gbase, int k, int b, int nst, bool first) {
+    constexpr int R = 1 << LOGR;
     const int T = (int)blockDim.x;
-    for (int g = (int)threadIdx.x; g < (N >> VMX_SORT_LOGR); g += T) {
-        const int base = ((g >> b) << (b + VMX_SORT_LOGR)) | (g & ((1 << b) - 1));
-        uint64_t r[VMX_SORT_R];
+    for (int g = (int)threadIdx.x; g < (N >> LOGR); g += T) {
+        const int base = ((g >> b) << (b + LOGR)) | (g & ((1 << b) - 1));
+        uint64_t r[R];
 #pragma unroll
-        for (int m = 0; m < VMX_SORT_R; ++m) r[m] = lds[vmx_sw(base | (m << b))];
+        for (int m = 0; m < R; ++m) r[m] = lds[vmx_sw(base | (m << b))];
         if (first) {
-            const bool ascR = ((gbase + base) & VMX_SORT_R) == 0;
+            const bool ascR = ((gbase + base) & R) == 0;
 #pragma unroll
-            for (int kk = 2; kk <= VMX_SORT_R; kk <<= 1)
+            for (int kk = 2; kk <= R; kk <<= 1)
 #pragma unroll
                 for (int jj = kk >> 1; jj > 0; jj >>= 1)
 #pragma unroll
-                    for (int m = 0; m < VMX_SORT_R; ++m)
-                        if ((m ^ jj) > m) vmx_ce_u64(r[m], r[m ^ jj], kk == VMX_SORT_R ? ascR : ((m & kk) == 0));
+                    for (int m = 0; m < R; ++m)
+                        if ((m ^ jj) > m) vmx_ce_u64(r[m], r[m ^ jj], kk == R ? ascR : ((m & kk) == 0));
         } else {
             const bool asc = ((gbase + base) & k) == 0;
 #pragma unroll
-            for (int s = VMX_SORT_LOGR - 1; s >= 0; --s) {
+            for (int s = LOGR - 1; s >= 0; --s) {
                 if (nst > s) {
 #pragma unroll
-                    for (int m = 0; m < VMX_SORT_R; ++m) if (!(m & (1 << s))) vmx_ce_u64(r[m], r[m | (1 << s)], asc);
+                    for (int m = 0; m < R; ++m) if (!(m & (1 << s))) vmx_ce_u64(r[m], r[m | (1 << s)], asc);
                 }
             }
         }
 #pragma unroll
-        for (int m = 0; m < VMX_SORT_R; ++m) lds[vmx_sw(base | (m << b))] = r[m];
+        for (int m = 0; m < R; ++m) lds[vmx_sw(base | (m << b))] = r[m];
     }
     __syncthreads();
 }
 // stages j = 2^e .. 1 of phase k on the swizzled tile (e < log2 N; k > 2^e)
-__device__ __forceinline__ void vmx_bitonic_phase_tail(uint64_t* lds, int N, int gbase, int k, int e) {
+template <int LOGR>
+__device__ __forceinline__ void vmx_bitonic_phase_tail_t(uint64_t* lds, int N, int gbase, int k, int e) {
     while (e >= 0) {
-        const int b = e >= VMX_SORT_LOGR - 1 ? e - (VMX_SORT_LOGR - 1) : 0;
-        vmx_bitonic_roundtrip(lds, N, gbase, k, b, e - b + 1, false);
+        const int b = e >= LOGR - 1 ? e - (LOGR - 1) : 0;
+        vmx_bitonic_roundtrip_t<LOGR>(lds, N, gbase, k, b, e - b + 1, false);
         e = b - 1;
     }
 }
 // all phases k = 2 .. kmax of a swizzled tile of N >= R keys (N a power of two). every thread of the workgroup must call it.
-__device__ __forceinline__ void vmx_bitonic_tile_sw(uint64_t* lds, int N, int gbase, int kmax) {
-    vmx_bitonic_roundtrip(lds, N, gbase, VMX_SORT_R, 0, VMX_SORT_LOGR, true);
-    for (int k = 2 * VMX_SORT_R, p = VMX_SORT_LOGR + 1; k <= kmax; k <<= 1, ++p) vmx_bitonic_phase_tail(lds, N, gbase, k, p - 1);
+template <int LOGR>
+__device__ __forceinline__ void vmx_bitonic_tile_sw_t(uint64_t* lds, int N, int gbase, int kmax) {
+    constexpr int R = 1 << LOGR;
+    vmx_bitonic_roundtrip_t<LOGR>(lds, N, gbase, R, 0, LOGR, true);
+    for (int k = 2 * R, p = LOGR + 1; k <= kmax; k <<= 1, ++p) vmx_bitonic_phase_tail_t<LOGR>(lds, N, gbase, k, p - 1);
 }
+__device__ __forceinline__ void vmx_bitonic_tile_sw(uint64_t* lds, int N, int gbase, int kmax) { vmx_bitonic_tile_sw_t<VMX_SORT_LOGR>(lds, N, gbase, kmax); }
+__device__ __forceinline__ void vmx_bitonic_phase_tail(uint64_t* lds, int N, int gbase, int k, int e) { vmx_bitonic_phase_tail_t<VMX_SORT_LOGR>(lds, N, gbase, k, e); }
 // is the register-blocked form worth it? it needs R keys per working thread; below a quarter of the workgroup the plain passes win
 __device__ __forceinline__ bool vmx_bitonic_fast_ok(int N) { return N >= 4 * VMX_SORT_R && (N >> VMX_SORT_LOGR) >= ((int)blockDim.x >> 2); }
 

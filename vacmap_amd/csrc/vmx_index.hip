@@ -39,6 +39,8 @@ __global__ void k_cluster_gen(uint64_t* keys, uint64_t* cl_keys, const int64_t* 
                               int kmer, int64_t* rows, int32_t* n_anchors);
 __global__ void k_cluster_big(uint64_t* keys, uint64_t* cl_keys, const int64_t* key_off, const int64_t* nhits, const int32_t* rlist, int nlist, int tile, int check_num, int kmer,
                               int64_t* rows, int32_t* n_anchors, int32_t* decl, int32_t* n_decl);
+__global__ void k_cluster_long(uint64_t* keys, uint64_t* cl_keys, const int64_t* key_off, const int64_t* nhits, const int32_t* rlist, int nlist, const int32_t* nlist_dev, int tile, int check_num,
+                               int kmer, int64_t* rows, int32_t* n_anchors, int32_t* decl, int32_t* n_decl);
 __global__ void k_scan_i64(const int64_t* in, int64_t* out, int64_t n, int pow2_round);
 
 // ------------------------------------------------------------------------------------------------ build kernels (spec VMX-S1)
@@ -647,37 +649,44 @@ int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, in
         for (int64_t r = 0; r < n; ++r) ((h_nhits[r] <= small_max || !use_big) ? small : big).push_back((int32_t)r);
         if (!use_big) std::stable_sort(small.begin(), small.end(), [&](int32_t a, int32_t b) { return h_nhits[a] > h_nhits[b]; });
         std::stable_sort(big.begin(), big.end(), [&](int32_t a, int32_t b) { return h_nhits[a] > h_nhits[b]; });
-        // the read list, then the list of the reads the filtered form declines and its length (zero), filled on the device
+        // the read list, then two lists filled on the device, each followed by its length (zero): the reads k_cluster_big declines (they go to
+        // k_cluster_long) and the reads k_cluster_long declines (they take the general path)
         std::vector<int32_t> rl(small); rl.insert(rl.end(), big.begin(), big.end());
         const size_t decl_at = rl.size();
-        rl.resize(decl_at + big.size() + 1, 0);
+        rl.resize(decl_at + 2 * (big.size() + 1), 0);
         VMX_TRY(upload(B[12], rl.data(), rl.size(), c->stream));
         const int32_t* d_rl = B[12].as<int32_t>();
         int32_t* d_decl = B[12].as<int32_t>() + decl_at; int32_t* d_ndecl = d_decl + big.size();
+        int32_t* d_decl2 = d_ndecl + 1; int32_t* d_ndecl2 = d_decl2 + big.size();
         (void)hipEventRecord(c->kev[2], c->stream);
         if (!big.empty()) {
 #ifndef VMX_EMU
             VMX_HIP(hipFuncSetAttribute((const void*)k_cluster_gen, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * VMX_SORT_LDS_BIG));
+            VMX_HIP(hipFuncSetAttribute((const void*)k_cluster_long, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * VMX_SORT_LDS_BIG));
             VMX_HIP(hipFuncSetAttribute((const void*)k_cluster_big, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * VMX_SORT_LDS_BIG));
 #endif
-            // `big` is ordered by hit count, largest first: reads with more than 16383 hits (the filtered form cannot take them: cluster sizes travel
-            // in 14 bits) go straight to the general path and its 128 KB tile; the others run the filtered form in a 64 KB tile, two workgroups
-            // per CU (VMX_CLUSTER_TILE: keys of that tile, tuning knob), and those it declines follow in a second launch of the general path
+            // `big` is ordered by hit count, largest first: reads with more than 16383 hits go straight to the LONG filtered form (k_cluster_long: 128 KB
+            // tile); the others run the filtered form in a 64 KB tile, two workgroups per CU (k_cluster_big; VMX_CLUSTER_TILE: keys of that tile, tuning
+            // knob), those it declines follow in a second launch of k_cluster_long, and what that declines takes the general path (k_cluster_gen)
             static const int mid_tile = [] { const char* e = getenv("VMX_CLUSTER_TILE"); const int v = e ? atoi(e) : 0; return v >= 8192 && v <= VMX_SORT_LDS_BIG ? v : (VMX_SORT_LDS_BIG >= 16384 ? 8192 : VMX_SORT_LDS_BIG); }();
             static const int filt_wgs = [] { const char* e = getenv("VMX_CLUSTER_WGS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 2; }();
-            int64_t huge_min = 0x3fff;                                 // test knob: reads with more hits than this go straight to k_cluster_gen (its LONG filtered form)
+            int64_t huge_min = 0x3fff;                                 // test knob: reads with more hits than this go straight to k_cluster_long
             if (const char* e = getenv("VMX_CLUSTER_HUGE_MIN")) { const long long v = atoll(e); if (v >= 0 && v <= 0x3fff) huge_min = v; }
             size_t n_huge = 0; while (n_huge < big.size() && h_nhits[big[n_huge]] > huge_min) ++n_huge;
             const size_t n_mid = big.size() - n_huge;
             if (n_huge)
-                hipLaunchKernelGGL(k_cluster_gen, dim3((unsigned)std::min<int64_t>((int64_t)n_huge, c->num_cu)), dim3(1024), 8 * VMX_SORT_LDS_BIG, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(),
-                                   koff.as<int64_t>(), nh.as<int64_t>(), d_rl + small.size(), (int)n_huge, (const int32_t*)nullptr, VMX_SORT_LDS_BIG, check_num, mi->k, rows.as<int64_t>(), nanc.as<int32_t>());
+                hipLaunchKernelGGL(k_cluster_long, dim3((unsigned)std::min<int64_t>((int64_t)n_huge, c->num_cu)), dim3(1024), 8 * VMX_SORT_LDS_BIG, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(),
+                                   koff.as<int64_t>(), nh.as<int64_t>(), d_rl + small.size(), (int)n_huge, (const int32_t*)nullptr, VMX_SORT_LDS_BIG, check_num, mi->k, rows.as<int64_t>(), nanc.as<int32_t>(),
+                                   d_decl2, d_ndecl2);
             if (n_mid) {
                 hipLaunchKernelGGL(k_cluster_big, dim3((unsigned)std::min<int64_t>((int64_t)n_mid, (int64_t)c->num_cu * filt_wgs)), dim3(1024), (size_t)8 * mid_tile, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(),
                                    koff.as<int64_t>(), nh.as<int64_t>(), d_rl + small.size() + n_huge, (int)n_mid, mid_tile, check_num, mi->k, rows.as<int64_t>(), nanc.as<int32_t>(), d_decl, d_ndecl);
-                hipLaunchKernelGGL(k_cluster_gen, dim3((unsigned)std::min<int64_t>((int64_t)n_mid, c->num_cu)), dim3(1024), 8 * VMX_SORT_LDS_BIG, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(),
-                                   koff.as<int64_t>(), nh.as<int64_t>(), (const int32_t*)d_decl, 0, (const int32_t*)d_ndecl, VMX_SORT_LDS_BIG, check_num, mi->k, rows.as<int64_t>(), nanc.as<int32_t>());
+                hipLaunchKernelGGL(k_cluster_long, dim3((unsigned)std::min<int64_t>((int64_t)n_mid, c->num_cu)), dim3(1024), 8 * VMX_SORT_LDS_BIG, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(),
+                                   koff.as<int64_t>(), nh.as<int64_t>(), (const int32_t*)d_decl, 0, (const int32_t*)d_ndecl, VMX_SORT_LDS_BIG, check_num, mi->k, rows.as<int64_t>(), nanc.as<int32_t>(),
+                                   d_decl2, d_ndecl2);
             }
+            hipLaunchKernelGGL(k_cluster_gen, dim3((unsigned)std::min<int64_t>((int64_t)big.size(), c->num_cu)), dim3(1024), 8 * VMX_SORT_LDS_BIG, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(),
+                               koff.as<int64_t>(), nh.as<int64_t>(), (const int32_t*)d_decl2, 0, (const int32_t*)d_ndecl2, VMX_SORT_LDS_BIG, check_num, mi->k, rows.as<int64_t>(), nanc.as<int32_t>());
         }
         if (!small.empty())
             hipLaunchKernelGGL(k_cluster, dim3((unsigned)std::min<int64_t>((int64_t)small.size(), (int64_t)c->num_cu * 4)), dim3(256), 8 * VMX_SORT_LDS, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(),
