@@ -34,13 +34,147 @@ __device__ __forceinline__ int vmx_alloc_probs(const vmx_ext_args& A, int n) {
     return b;
 }
 
+// ---- wave-cooperative forms of the segment walks (k_ext_phase with spread 64: one wavefront per read) ----------------------------------
+// The walks of vmx_extend.h are chains of dependent loads on one lane: a 35 kb read's 3000 anchors cost its lane 3000 steps (375 with the
+// eight-anchor prefetch), and the lane's wave waits on HBM for every one. Here the 64 lanes look at 64 consecutive anchors at once
+// against the same `pre` (the last anchor kept) and a ballot finds the next one kept: one step per checkpoint, not per anchor.
+// Every lane holds the same scalars; lane 0 stores. Lane 0's stores are followed by a wave exchange before another lane reads them.
+__device__ __forceinline__ vmx_anchor vmx_anchor_from_lane(const vmx_anchor& a, int src) {
+    vmx_anchor o; o.q = __shfl(a.q, src); const int ls = __shfl((int)(uint16_t)a.l | ((int)a.s << 16), src); o.l = (int16_t)(ls & 0xffff); o.s = (int16_t)(ls >> 16);
+    o.r = __shfl((long long)a.r, src); return o;
+}
+// vmx_split_alignment (E5 checkpoints :21505-21617) on a wavefront; same results, same return codes
+__device__ __forceinline__ int vmx_split_alignment_w(vmx_segs& S, int s, long long L, const vmx_ref_view& R, vmx_pair_desc* out, int cap, bool asmv, int lane) {
+    const long long min_gap_forcigar = 200;
+    int np = 0;
+    const int st = S.st[s], en = S.en[s];
+    const bool fwd = S.A[st].s == 1;
+    if (lane == 0) {
+        if (fwd) { vmx_anchor& last = S.A[en - 1]; if (last.l != 0) last = vmx_mk((long long)last.q + last.l, last.r + last.l, 1, 0); }
+        else {
+            if (S.A[st].l != 0) S.A[st] = vmx_mk(S.A[st].q, S.A[st].r + S.A[st].l, -1, 0);
+            if (S.A[en - 1].l != 0) S.A[en - 1] = vmx_mk((long long)S.A[en - 1].q + S.A[en - 1].l, S.A[en - 1].r, -1, 0);
+        }
+    }
+    __threadfence_block();
+    (void)__ballot(1);                                           // (the end anchors are rewritten before any lane reads them)
+    vmx_anchor pre = fwd ? S.A[st] : S.A[en - 1];
+    // forward: i runs st + 1 .. en - 1 upwards; reverse (alignment[::-1]): en - 2 .. st downwards. k counts the anchors already passed.
+    const int nwalk = en - st - 1;
+    int k = 0;
+    while (k < nwalk) {
+        const int kk = k + lane < nwalk ? k + lane : nwalk - 1;
+        const int i = fwd ? st + 1 + kk : en - 2 - kk;
+        const vmx_anchor now = S.A[i];
+        long long readgap, refgap;
+        if (fwd) { readgap = (long long)now.q - pre.q - pre.l; refgap = (long long)now.r - pre.r - pre.l; }
+        else { readgap = (long long)pre.q - now.q - now.l; refgap = (long long)now.r - pre.r - pre.l; }
+        const long long mn = readgap < refgap ? readgap : refgap, mx = readgap < refgap ? refgap : readgap;
+        const bool lastone = fwd ? (i + 1 == en) : (i == st);
+        const bool skip = (!asmv || mx < 2000) && (now.l < 19 || mn < min_gap_forcigar) && !lastone;
+        const unsigned long long m = __ballot(k + lane < nwalk && !skip);
+        if (!m) { k += 64; continue; }
+        const int e = __ffsll((unsigned long long)m) - 1;
+        const vmx_anchor kept = vmx_anchor_from_lane(now, e);
+        if (out && np >= cap) return VM_READ_CAPACITY_DEV;
+        vmx_pair_desc d;
+        if (fwd) vmx_qt_for_cigar(pre, kept, L, R, &d); else vmx_qt_for_cigar(kept, pre, L, R, &d);
+        if (out && lane == 0) out[np] = d;
+        if (d.t.len <= 0 || d.q.len <= 0) return VM_READ_RAISED_DEV;    // "Failed to compute CIGAR" :21562
+        ++np; pre = kept; k += e + 1;
+    }
+    if (np == 0) return VM_READ_RAISED_DEV;
+    return np;
+}
+
+__device__ __forceinline__ vmx_anchor vmx_anchor_up1(const vmx_anchor& a) {      // lane j <- lane j - 1 (lane 0 keeps its own)
+    vmx_anchor o; o.q = __shfl_up(a.q, 1); const int ls = __shfl_up((int)(uint16_t)a.l | ((int)a.s << 16), 1); o.l = (int16_t)(ls & 0xffff); o.s = (int16_t)(ls >> 16);
+    o.r = __shfl_up((long long)a.r, 1); return o;
+}
+// vmx_rebuild_chain_break (E1 :23437-23484) on a wavefront. Nearly every anchor of a chain joins the segment of the anchor before it, so the 64
+// lanes test 64 consecutive anchors each against its predecessor; the run of joins up to the first anchor that does something else is
+// appended in one step, that anchor (a skip: `pre` stays, or a break: new segment) is handled with the scalars every lane holds, and the
+// lanes behind it are tested again. Same segments, same return codes as the one-lane form.
+__device__ __forceinline__ int vmx_rebuild_chain_break_w(const vmx_anchor* chain_desc, int n, const vmx_ref_view& R, int large_cost, int small_alignment, vmx_segs& S, bool asmv, int lane) {
+    S.nseg = 0;
+    if (S.capS < 1 || S.capA < 4) return VM_READ_CAPACITY_DEV;
+    vmx_anchor pre = chain_desc[n - 1];
+    int w = 2, nseg = 1, st_cur = 1; long long segq0 = pre.q;     // the open segment: A[st_cur .. w), its first anchor's q; closed segments live in st / en
+    bool cur_alive = true;
+    if (lane == 0) { S.st[0] = 1; S.A[1] = pre; }
+    for (int x0 = 1; x0 < n; x0 += 64) {
+        const int nv = n - x0 < 64 ? n - x0 : 64;                 // anchors of this chunk
+        const vmx_anchor now = chain_desc[n - 1 - (lane < nv ? x0 + lane : n - 1)];
+        const vmx_anchor up = vmx_anchor_up1(now);
+        int pos = 0;
+        while (pos < nv) {
+            const vmx_anchor pv = lane == pos ? pre : up;
+            int kind = 2;                                        // 0 join, 1 skip, 2 break
+            if (pv.s == now.s) {
+                const long long readgap = (long long)now.q - pv.q - pv.l;
+                const long long refgap = pv.s == 1 ? (long long)now.r - pv.r - pv.l : (long long)pv.r - now.r - now.l;
+                long long d = readgap - refgap; if (d < 0) d = -d;
+                if (d <= large_cost && refgap >= (asmv ? 0 : -20) && readgap < 100 && vmx_p2c(R, pv.r) == vmx_p2c(R, now.r)) kind = refgap >= 0 ? 0 : (readgap <= 20 ? 1 : 0);
+            }
+            const unsigned long long ev = __ballot(lane >= pos && lane < nv && kind != 0);
+            const int e = ev ? __ffsll((unsigned long long)ev) - 1 : nv;
+            const int cnt = e - pos;
+            if (cnt > 0) {
+                if (w + cnt + 1 > S.capA) return VM_READ_CAPACITY_DEV;
+                if (lane >= pos && lane < e) S.A[w + lane - pos] = now;
+                w += cnt; pre = vmx_anchor_from_lane(now, e - 1);
+            }
+            if (e >= nv) break;
+            const int ekind = __shfl(kind, e);
+            const vmx_anchor ea = vmx_anchor_from_lane(now, e);
+            pos = e + 1;
+            if (ekind == 1) continue;                            // readgap <= 20 on a back-step: the anchor is dropped, `pre` stays
+            // a new segment starts at ea: close the open one (single anchors and short segments are dropped), leave a spare slot
+            if (lane == 0) S.en[nseg - 1] = w;
+            const int cur_en = w;
+            cur_alive = true;
+            if (cur_en - st_cur == 1) { w = st_cur; --nseg; cur_alive = false; }
+            if (nseg > 0) {
+                if (cur_alive) { if (((long long)pre.q + pre.l - segq0) < small_alignment) { w = st_cur; --nseg; cur_alive = false; } }
+                else {
+                    __threadfence_block(); (void)__ballot(1);
+                    const int ps = S.st[nseg - 1], pe = S.en[nseg - 1]; const vmx_anchor fa = S.A[ps], la = S.A[pe - 1];
+                    if (((long long)la.q + la.l - fa.q) < small_alignment) { w = ps; --nseg; }
+                }
+            }
+            if (nseg > 0) {
+                int last_en = cur_en;
+                if (!cur_alive) { __threadfence_block(); (void)__ballot(1); last_en = S.en[nseg - 1]; }
+                w = last_en + 2;
+            } else w = 1;
+            if (nseg + 1 > S.capS || w + 2 > S.capA) return VM_READ_CAPACITY_DEV;
+            if (lane == 0) { S.st[nseg] = w; S.A[w] = ea; }
+            st_cur = w; ++w; ++nseg; pre = ea; segq0 = ea.q; cur_alive = true;
+        }
+    }
+    if (lane == 0) S.en[nseg - 1] = w;
+    cur_alive = true;
+    if (w - st_cur == 1) { --nseg; cur_alive = false; }
+    if (nseg == 0) { S.nseg = 0; return VM_READ_RAISED_DEV; }
+    if (cur_alive) { if (((long long)pre.q + pre.l - segq0) < small_alignment) --nseg; }
+    else {
+        __threadfence_block(); (void)__ballot(1);
+        const int ps = S.st[nseg - 1], pe = S.en[nseg - 1]; const vmx_anchor fa = S.A[ps], la = S.A[pe - 1];
+        if (((long long)la.q + la.l - fa.q) < small_alignment) --nseg;
+    }
+    S.nseg = nseg;
+    return 0;
+}
+
 __global__ void k_ext_phase(vmx_ext_args A, int phase) {
     VMX_SETPRIO(3);
     // one lane per read, every A.spread-th lane of the grid: a read's walk is a chain of dependent loads and data-dependent branches, and the
     // 64 reads of a full wave execute the union of their branches in lock step
     const int sp = A.spread > 1 ? A.spread : 1;
     const int gt = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (gt % sp) return;
+    const bool wave = sp == 64 && (phase == 0 || phase == 3 || phase == 5);   // one wavefront per read: the anchor walks run on all 64 lanes, the rest on lane 0
+    const int lane = gt & 63;
+    if (!wave && gt % sp) return;
     const int r = gt / sp;
     if (r >= A.n_reads) return;
     vmx_ext_read& E = A.er[r];
@@ -57,7 +191,14 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
     int32_t* segprob = A.seg_prob + A.soff[r];
     const bool nofilter = A.nodiscard || E.pass == 1;
     if (phase == 0) {
-        int rc = vmx_rebuild_chain_break(A.chain + A.la_off[r], cl, R, A.local_maxdiff, A.asm_long ? 30 : (A.mode == 4 ? 40 : 50), S, A.mode == 4);     // small_alignment 40 in the asm fork (mammap_asm.py:22321), 30 in ass_extend_func (:23426)
+        int rc;
+        if (wave) {
+            (void)__ballot(1);                                   // (every lane has read the read's state before lane 0 changes it)
+            rc = vmx_rebuild_chain_break_w(A.chain + A.la_off[r], cl, R, A.local_maxdiff, A.asm_long ? 30 : (A.mode == 4 ? 40 : 50), S, A.mode == 4, lane);
+            __threadfence_block(); (void)__ballot(1);            // the anchors the other lanes stored, before lane 0 reads the segments' ends
+            if (lane != 0) return;
+        } else
+        rc = vmx_rebuild_chain_break(A.chain + A.la_off[r], cl, R, A.local_maxdiff, A.asm_long ? 30 : (A.mode == 4 ? 40 : 50), S, A.mode == 4);     // small_alignment 40 in the asm fork (mammap_asm.py:22321), 30 in ass_extend_func (:23426)
         if (rc < 0) { E.status = rc; return; }
         E.nseg = S.nseg;
         if (A.asm_long) { E.prob_base = 0; E.prob_n = 0; return; }                  // ass_extend_func has no divergence filter
@@ -88,15 +229,69 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
         // apply right-end results, then set up the left ends (they see the extended right end of their left neighbour)
         for (int s = 0; s < S.nseg; ++s) if (segprob[s] >= 0) vmx_ext_apply(S, s, 1, A.ext_te[E.prob_base + segprob[s]], A.ext_qe[E.prob_base + segprob[s]]);
     }
-    if (phase == 3 || phase == 5) {
+    if (wave && phase == 3) {
+        // phase 3 on a wavefront: lane 0 applies the left-end results, all lanes copy the snapshot for the nofilter redo, lane 0 goes on alone
+        (void)__ballot(1);
+        if (lane == 0 && E.skip_ext == 0) for (int s = 0; s < S.nseg; ++s) if (segprob[s] >= 0) vmx_ext_apply(S, s, 0, A.ext_te[E.prob_base + segprob[s]], A.ext_qe[E.prob_base + segprob[s]]);
+        __threadfence_block(); (void)__ballot(1);
+        if (E.pass == 0) {
+            vmx_segs P = vmx_read_segs(A, r, true);
+            for (int s = 0; s < S.nseg; ++s) {
+                const int a = S.st[s] - 1, b = S.en[s];
+                for (int t = a + lane; t <= b; t += 64) P.A[t] = S.A[t];
+                if (lane == 0) { P.st[s] = S.st[s]; P.en[s] = S.en[s]; }
+            }
+        }
+        (void)__ballot(1);
+        if (lane != 0) return;
+    }
+    if (wave && phase == 5) {
+        // phase 5 on a wavefront: lane 0 applies the left-end results and runs the segment-level steps (merge, fix_simple_inv: a few
+        // segments), every lane takes part in the checkpoint walks
+        int rc = 0, nseg = S.nseg;
+        (void)__ballot(1);                                       // (every lane has read the read's state before lane 0 changes it)
+        if (lane == 0) {
+            if (E.skip_ext == 0) for (int s = 0; s < S.nseg; ++s) if (segprob[s] >= 0) vmx_ext_apply(S, s, 0, A.ext_te[E.prob_base + segprob[s]], A.ext_qe[E.prob_base + segprob[s]]);
+            E.prob_n = 0;
+            vmx_merge_conjacent(S, R, A.dup + A.soff[r]);
+            rc = vmx_fix_simple_inv(S, R, RD, L, A.mode == 3 || A.mode == 4);
+            nseg = S.nseg;
+            if (rc < 0) E.status = rc; else E.nseg = nseg;
+        }
+        __threadfence_block();
+        rc = __shfl(rc, 0); nseg = __shfl(nseg, 0);
+        if (rc < 0) return;
+        S.nseg = nseg;
+        int total = 0;
+        for (int s = 0; s < S.nseg; ++s) {
+            const int np = vmx_split_alignment_w(S, s, L, R, nullptr, 0, A.mode == 4, lane);
+            if (np < 0) { if (lane == 0) E.status = np; return; }
+            if (lane == 0) segprob[s] = np;
+            total += np;
+        }
+        int b = lane == 0 ? vmx_alloc_probs(A, total) : 0;
+        b = __shfl(b, 0);
+        if (b < 0) { if (lane == 0) E.status = VM_READ_CAPACITY_DEV; return; }
+        int k = 0;
+        for (int s = 0; s < S.nseg; ++s) {
+            const int np = vmx_split_alignment_w(S, s, L, R, A.desc + b + k, total - k, A.mode == 4, lane);
+            if (np < 0) { if (lane == 0) E.status = np; return; }
+            k += np;
+        }
+        if (lane == 0) { E.dp_base = b; E.dp_n = k; E.prob_base = b; E.prob_n = total; }
+        return;
+    }
+    if ((phase == 3 && !wave) || phase == 5) {
         if (E.skip_ext == 0) for (int s = 0; s < S.nseg; ++s) if (segprob[s] >= 0) vmx_ext_apply(S, s, 0, A.ext_te[E.prob_base + segprob[s]], A.ext_qe[E.prob_base + segprob[s]]);
     }
     if (phase >= 1 && phase <= 5) E.prob_n = 0;      // results of the previous round are consumed; a new round may follow below
     if (phase == 3) {
         // snapshot for the nofilter redo (:24080 restarts extend_func; everything up to here is identical in both runs)
         if (E.pass == 0) {
-            vmx_segs P = vmx_read_segs(A, r, true);
-            for (int s = 0; s < S.nseg; ++s) { P.st[s] = S.st[s]; P.en[s] = S.en[s]; for (int t = S.st[s] - 1; t <= S.en[s]; ++t) P.A[t] = S.A[t]; }
+            if (!wave) {
+                vmx_segs P = vmx_read_segs(A, r, true);
+                for (int s = 0; s < S.nseg; ++s) { P.st[s] = S.st[s]; P.en[s] = S.en[s]; for (int t = S.st[s] - 1; t <= S.en[s]; ++t) P.A[t] = S.A[t]; }
+            }
             E.nseg_snap = S.nseg;
         }
         const int o_len = S.nseg;

@@ -388,9 +388,13 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     static const int rec_env = [] { const char* e = getenv("VMX_REC_SPREAD"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 0; }();
     const int ext_spread = ext_env ? ext_env : (c->inflight >= 2 ? 1 : 16), rec_spread = rec_env ? rec_env : (c->inflight >= 2 ? 1 : 4);
     const unsigned gridX = (unsigned)((n * ext_spread + 63) / 64), gridXR = (unsigned)((n * rec_spread + 63) / 64);
+    static const bool ext_wave = [] { const char* e = getenv("VMX_EXT_WAVE"); return !(e && atoi(e) == 0); }();
     int cur = 0;
     auto phase = [&](int ph) { A.desc = B.desc[cur].as<vmx_pair_desc>(); A.desc_prev = B.desc[cur ^ 1].as<vmx_pair_desc>();
-                               (void)hipMemsetAsync(B.rcount.p, 0, 4, c->stream); A.spread = ext_spread; hipLaunchKernelGGL(k_ext_phase, dim3(gridX), dim3(64), 0, c->stream, A, ph);
+                               (void)hipMemsetAsync(B.rcount.p, 0, 4, c->stream);
+                               // the phases that walk every anchor (0 rebuild, 3 snapshot copy, 5 checkpoints) run one wavefront per read; VMX_EXT_WAVE=0: the one-lane form
+                               const bool wv = ext_wave && (ph == 0 || ph == 3 || ph == 5);
+                               A.spread = wv ? 64 : ext_spread; hipLaunchKernelGGL(k_ext_phase, dim3(wv ? (unsigned)n : gridX), dim3(64), 0, c->stream, A, ph);
                                if (trace && trace->stage == ph && !A.redo_only && trace->off.empty()) {
                                    std::vector<vmx_ext_read> er((size_t)n); std::vector<vmx_anchor> sa((size_t)cA + 1); std::vector<int32_t> st_((size_t)cS + 1), en_((size_t)cS + 1);
                                    (void)hipMemcpyAsync(er.data(), B.er.p, sizeof(vmx_ext_read) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
