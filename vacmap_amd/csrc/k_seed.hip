@@ -253,17 +253,32 @@ __global__ void __launch_bounds__(256) k_fill_hits(const uint32_t* __restrict__ 
         const int64_t base = mz_off[r];
         const int M = mz_cnt[r];
         uint64_t* K = keys + key_off[r];
-        for (int m = (int)threadIdx.x; m < M; m += (int)blockDim.x) {
-            uint32_t cn = m_cnt[base + m];
-            if (!cn) continue;
-            uint32_t ps = mz_ps[base + m];
-            uint64_t q = ps >> 1; uint32_t zq = ps & 1;
-            uint64_t* out = K + m_hoff[base + m];
-            const uint64_t* src = idx_pos + m_start[base + m];
-            for (uint32_t e = 0; e < cn; ++e) {
-                uint64_t pv = src[e];
-                uint64_t sb = ((uint32_t)(pv & 1) == zq) ? 1ULL : 0ULL;
-                out[e] = ((pv >> 1) << 28) | (q << 1) | sb;
+        // a wavefront takes 64 minimizers at a time and copies their hits 64 at a time: hit j of the group belongs to the first lane whose
+        // running count passes j (a six-step search over the lanes' counts), so every lane has a hit to copy and the 64 keys go out as one
+        // contiguous store. (One thread per minimizer copied its own run: a wave took as long as its most frequent minimizer — tens of
+        // positions against an average of four.)
+        const int lane = vmx_lane(), wv = (int)(threadIdx.x >> 6), nwv = (int)(blockDim.x >> 6);
+        for (int m0 = wv * 64; m0 < M; m0 += nwv * 64) {
+            const int m = m0 + lane;
+            int cn = 0, hoff = 0, start = 0, ps = 0;
+            if (m < M) { cn = (int)m_cnt[base + m]; hoff = (int)m_hoff[base + m]; start = (int)m_start[base + m]; ps = (int)mz_ps[base + m]; }
+            const int inc = vmx_wave_incl_scan_i32(cn);
+            const int tot = __shfl(inc, 63);
+            const int ex = inc - cn;
+            const int hoff0 = __shfl(hoff, 0);                       // the group's hits are contiguous in the read's key array
+            for (int j0 = 0; j0 < tot; j0 += 64) {
+                const int j = j0 + lane;
+                int lo = 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) { const int v = __shfl(inc, lo + step - 1); if (v <= j) lo += step; }
+                const int ow = lo < 64 ? lo : 63;
+                const int o_ex = __shfl(ex, ow), o_start = __shfl(start, ow), o_ps = __shfl(ps, ow);
+                if (j < tot) {
+                    const uint64_t pv = idx_pos[(uint32_t)o_start + (uint32_t)(j - o_ex)];
+                    const uint64_t q = (uint32_t)o_ps >> 1; const uint32_t zq = (uint32_t)o_ps & 1u;
+                    const uint64_t sb = ((uint32_t)(pv & 1) == zq) ? 1ULL : 0ULL;
+                    K[hoff0 + j] = ((pv >> 1) << 28) | (q << 1) | sb;
+                }
             }
         }
         // pad to the next power of two for the bitonic sort
