@@ -260,6 +260,8 @@ def main():
             pk = pks.get('k_local_seed_band' if kn == 'k_local_seed' and 'k_local_seed_band' in pks else (kn if kn != 'k_cluster_big' or 'k_cluster_big' in pks else 'k_cluster'))
             if pk:
                 e['traffic'] = pk.get('hbm_bytes_per_step'); e['valu'] = pk.get('valu')
+                if kn == 'k_cluster_big':                   # the HIP events bracket every clustering launch: the filtered form, its LONG form, the general path
+                    e['traffic'] = sum((pks.get(x) or {}).get('hbm_bytes_per_step') or 0.0 for x in ('k_cluster_big', 'k_cluster_long', 'k_cluster_gen', 'k_cluster')) or e['traffic']
                 if e['traffic'] and kalgo[kn] > 0:
                     e['traffic_over_algorithmic'] = e['traffic'] / kalgo[kn]
             e['kernel_GBps'] = (e['traffic'] or kalgo[kn]) / (kms[kn] * 1e-3) / 1e9 if kms[kn] > 0 else 0.0

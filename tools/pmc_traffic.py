@@ -63,7 +63,7 @@ for k in sorted(fa, key=lambda k: -(fa[k]['FETCH_SIZE'] + wa.get(k, {}).get('WRI
     if once(k):
         res.setdefault('once_per_process', {})[k.split('<')[0][:60]] = {'launches': ln, 'hbm_bytes_total': f + w}
         continue
-    if (f + w) * scale > 16e6 or k in ('k_gapfill_fill_ns', 'k_local_seed', 'k_local_seed_band', 'k_cluster_big', 'k_cluster'):
+    if (f + w) * scale > 16e6 or k in ('k_gapfill_fill_ns', 'k_local_seed', 'k_local_seed_band', 'k_cluster_big', 'k_cluster_long', 'k_cluster_gen', 'k_cluster'):
         res['kernels'][k] = e
 res['total_hbm_bytes_per_step'] = sum((fa[k]['FETCH_SIZE'] + wa.get(k, {}).get('WRITE_SIZE', 0)) for k in fa if not once(k)) * 1024 * scale
 json.dump(res, open(out, 'w'), indent=1)
