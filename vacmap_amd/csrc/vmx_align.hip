@@ -208,7 +208,9 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     auto front = [&]() -> int {
     // ---------------- S1 seed
     std::vector<int64_t> h_koff, h_nhits;
-    VMX_TRY(vmx_seed_stage(c, mi, prm->check_num, prm->mid_occ, n, d_codes, d_roff, total_bases, B.seed, h_koff, h_nhits));
+    int64_t* d_seed_rows = nullptr;
+    static const bool seed_arena = [] { const char* e = getenv("VMX_SEED_ARENA"); return !(e && atoi(e) == 0); }();
+    VMX_TRY(vmx_seed_stage(c, mi, prm->check_num, prm->mid_occ, n, d_codes, d_roff, total_bases, B.seed, h_koff, h_nhits, seed_arena ? &B.tb : nullptr, &d_seed_rows));
     for (int64_t r = 0; r < n; ++r) st.n_hits += h_nhits[r];
     st.n_minimizers = c->last_n_minimizers;
     // compact anchors: aoff = scan(n_anchors)
@@ -220,7 +222,7 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     const int64_t tot = h_aoff[n];
     st.n_anchors = tot;
     VMX_TRY(B.rows.reserve(32 * (size_t)(tot + 1)));
-    hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 8)), dim3(128), 0, c->stream, B.seed[10].as<int64_t>(), B.seed[7].as<int64_t>(),
+    hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 8)), dim3(128), 0, c->stream, d_seed_rows, B.seed[7].as<int64_t>(),
                        B.aoff.as<int64_t>(), (int)n, B.rows.as<int64_t>());
     VMX_TRY(B.lens.reserve(8 * (size_t)(n + 1)));
     LAUNCH1D(k_readlens, n, d_roff, B.lens.as<int64_t>(), n);

@@ -616,9 +616,14 @@ int vm_sketch_batch(vm_ctx* c, int k, int w, int64_t n, const char* seqs, const 
 // device-side seed stage shared by vm_map_batch and vm_align_batch: codes/roff already on the device.
 // leaves rows (int64 x4) at key_off[r] with n_anchors[r] valid rows; returns host copies of key_off / nhits totals
 int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, int64_t total_bases,
-                   DevBuf* B /* >= 13 buffers */, std::vector<int64_t>& h_koff, std::vector<int64_t>& h_nhits) {
+                   DevBuf* B /* >= 13 buffers */, std::vector<int64_t>& h_koff, std::vector<int64_t>& h_nhits, DevBuf* arena, int64_t** rows_out) {
     if (mid_occ <= 0) mid_occ = mi->mid_occ;
-    DevBuf &mzh = B[0], &mzp = B[1], &mzc = B[2], &mst = B[3], &mcn = B[4], &mho = B[5], &nh = B[6], &koff = B[7], &keys = B[8], &ckeys = B[9], &rows = B[10], &nanc = B[11];
+    // arena: a pool of the caller that is idle during this stage (the align path hands in its traceback pool, which only the gap fill uses, long
+    // after the rows were compacted): the hit keys, their scratch copy and the row slots (48 B per hit: 8.4 GB for a batch of 35 kb reads) are views
+    // into it instead of three pools of their own. *rows_out = where the rows are.
+    DevBuf vk, vc, vr;
+    DevBuf &mzh = B[0], &mzp = B[1], &mzc = B[2], &mst = B[3], &mcn = B[4], &mho = B[5], &nh = B[6], &koff = B[7], &keys = arena ? vk : B[8], &ckeys = arena ? vc : B[9],
+           &rows = arena ? vr : B[10], &nanc = B[11];
     VMX_TRY(mzh.reserve(8 * (size_t)(total_bases + 1))); VMX_TRY(mzp.reserve(4 * (size_t)(total_bases + 1))); VMX_TRY(mzc.reserve(4 * (size_t)(n + 1)));
     VMX_TRY(mst.reserve(4 * (size_t)(total_bases + 1))); VMX_TRY(mcn.reserve(4 * (size_t)(total_bases + 1))); VMX_TRY(mho.reserve(4 * (size_t)(total_bases + 1)));
     VMX_TRY(nh.reserve(8 * (size_t)(n + 2))); VMX_TRY(koff.reserve(8 * (size_t)(n + 2))); VMX_TRY(nanc.reserve(4 * (size_t)(n + 1)));
@@ -635,7 +640,14 @@ int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, in
     VMX_HIP(vmx_stream_sync(c));   // sizing sync #1: total (power-of-two padded) hits of the batch
     c->last_n_minimizers = 0; for (int64_t r = 0; r < n; ++r) c->last_n_minimizers += h_mzc[r];
     const int64_t ktot = h_koff[n];
-    VMX_TRY(keys.reserve(8 * (size_t)(ktot + 1))); VMX_TRY(ckeys.reserve(8 * (size_t)(ktot + 1))); VMX_TRY(rows.reserve(32 * (size_t)(ktot + 1)));
+    if (arena) {
+        const size_t kb = (8 * (size_t)(ktot + 1) + 255) & ~(size_t)255;
+        VMX_TRY(arena->reserve(2 * kb + 32 * (size_t)(ktot + 1)));
+        vk.p = arena->p; vk.cap = kb; vc.p = (char*)arena->p + kb; vc.cap = kb; vr.p = (char*)arena->p + 2 * kb; vr.cap = 32 * (size_t)(ktot + 1);
+    } else {
+        VMX_TRY(keys.reserve(8 * (size_t)(ktot + 1))); VMX_TRY(ckeys.reserve(8 * (size_t)(ktot + 1))); VMX_TRY(rows.reserve(32 * (size_t)(ktot + 1)));
+    }
+    if (rows_out) *rows_out = rows.as<int64_t>();
     hipLaunchKernelGGL(k_fill_hits, dim3(grid), dim3(256), 0, c->stream, mzp.as<uint32_t>(), d_roff, mzc.as<int32_t>(), (int)n, mst.as<uint32_t>(), mcn.as<uint32_t>(),
                        mho.as<uint32_t>(), mi->d_pos.as<uint64_t>(), keys.as<uint64_t>(), koff.as<int64_t>(), nh.as<int64_t>());
     // clustering, one launch per size class (the sort's LDS tile): reads with <= 4096 hits (32 KB of LDS, several workgroups per CU) and
@@ -701,7 +713,7 @@ int vm_map_batch(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, int6
     VMX_HIP(hipSetDevice(c->device));
     VMX_TRY(upload_reads(c, n, seqs, off, c->b[0], c->b[1], c->b[2]));
     std::vector<int64_t> koff, nhits;
-    if (n) VMX_TRY(vmx_seed_stage(c, mi, check_num, mid_occ, n, c->b[1].as<uint8_t>(), c->b[2].as<int64_t>(), off[n], &c->b[3], koff, nhits));
+    if (n) VMX_TRY(vmx_seed_stage(c, mi, check_num, mid_occ, n, c->b[1].as<uint8_t>(), c->b[2].as<int64_t>(), off[n], &c->b[3], koff, nhits, nullptr, nullptr));
     else koff.assign(1, 0);
     std::vector<int32_t> nanc((size_t)n);
     std::vector<int64_t> rows((size_t)koff[n] * 4);

@@ -28,7 +28,7 @@ struct vmx_local_bufs {
 vmx_local_bufs* vmx_ctx_local_bufs(vm_ctx* c);
 
 extern "C" int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, int64_t total_bases,
-                   vmx::DevBuf* B, std::vector<int64_t>& h_koff, std::vector<int64_t>& h_nhits);
+                   vmx::DevBuf* B, std::vector<int64_t>& h_koff, std::vector<int64_t>& h_nhits, vmx::DevBuf* arena = nullptr, int64_t** rows_out = nullptr);
 int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, int64_t n, const uint8_t* d_ocodes, const int64_t* d_roff,
                     const std::vector<int64_t>& h_roff, const vmx_anchor* d_path_rows, const int32_t* d_path_len, const int32_t* d_npaths,
                     const int64_t* d_aoff, const std::vector<int64_t>& h_aoff, const double* d_gscore, vmx_local_bufs& L);
