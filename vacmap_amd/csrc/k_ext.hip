@@ -358,51 +358,6 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
     }
 }
 
-// exclusive scan of n values by ONE 1024-thread workgroup (tiles of 8192, eight consecutive values per thread, wavefront scans, the sixteen wave
-// totals through LDS); out[n] = total. get(i): the i-th value.
-template <class GET>
-__device__ __forceinline__ void vmx_wg_scan_tiles(int n, GET get, int64_t* __restrict__ out) {
-    __shared__ long long s_w[16];
-    __shared__ long long s_base;
-    const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6, nw = (int)(blockDim.x >> 6);
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += 8 * (int)blockDim.x) {
-        const int b = i0 + 8 * tid;
-        long long v[8]; long long sum = 0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { v[u] = b + u < n ? (long long)get(b + u) : 0; sum += v[u]; }
-        long long inc = sum;
-        for (int o = 1; o < 64; o <<= 1) { const long long x = __shfl_up(inc, o); if (lane >= o) inc += x; }
-        if (lane == 63) s_w[w] = inc;
-        __syncthreads();
-        long long wb = 0, tot = 0;
-        for (int ww = 0; ww < nw; ++ww) { const long long x = s_w[ww]; if (ww < w) wb += x; tot += x; }
-        long long ex = s_base + wb + inc - sum;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { if (b + u < n) out[b + u] = ex; ex += v[u]; }
-        __syncthreads();
-        if (tid == 0) s_base += tot;
-        __syncthreads();
-    }
-    if (tid == 0) out[n] = s_base;
-}
-// the string offsets of every problem of the round in ONE launch: workgroup 0 scans the target lengths, workgroup 1 the query lengths, straight from
-// the descriptors; the round's count goes to its slot of the batch's counter block. (This was k_desc_lens + k_stat_put + two three-phase scans: eight
-// launches per round, seven rounds per batch — launches that each queue behind the other batches' kernels.)
-__global__ void __launch_bounds__(1024) k_desc_offsets(const vmx_pair_desc* __restrict__ desc, const int32_t* __restrict__ n_prob, int64_t* __restrict__ toff,
-                                                       int64_t* __restrict__ qoff, int32_t* __restrict__ stat_out) {
-    const int n = *n_prob;
-    if (blockIdx.x == 0) { if (threadIdx.x == 0 && stat_out) *stat_out = n; vmx_wg_scan_tiles(n, [&](int i) { return desc[i].t.len; }, toff); }
-    else vmx_wg_scan_tiles(n, [&](int i) { return desc[i].q.len; }, qoff);
-}
-// up to four exclusive scans (count on the device) in one launch, one workgroup each
-struct vmx_scan4 { const int64_t* in[4]; int64_t* out[4]; };
-__global__ void __launch_bounds__(1024) k_scan_multi_dev(vmx_scan4 P, const int32_t* __restrict__ n_ptr) {
-    const int n = *n_ptr; const int64_t* in = P.in[blockIdx.x];
-    vmx_wg_scan_tiles(n, [&](int i) { return in[i]; }, P.out[blockIdx.x]);
-}
-
 // lengths of the strings of every problem of the round (for the offset scans)
 __global__ void k_desc_lens(const vmx_pair_desc* __restrict__ desc, const int32_t* __restrict__ n_prob, int64_t* __restrict__ tl, int64_t* __restrict__ ql) {
     const int n = *n_prob;

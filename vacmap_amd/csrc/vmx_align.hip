@@ -128,9 +128,6 @@ int vmx_launch_chain_select(vm_ctx* c, int64_t n, const int64_t* h_aoff, DevBuf&
 
 #define LAUNCH1D(kernel, n, ...) hipLaunchKernelGGL(kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(((n) + 255) / 256, 4096))), dim3(256), 0, c->stream, __VA_ARGS__)
 
-struct vmx_scan4 { const int64_t* in[4]; int64_t* out[4]; };
-__global__ void k_scan_multi_dev(vmx_scan4 P, const int32_t* n_ptr);
-__global__ void k_desc_offsets(const vmx_pair_desc* desc, const int32_t* n_prob, int64_t* toff, int64_t* qoff, int32_t* stat_out);
 __global__ void k_scan_part_dev(const int64_t* in, int64_t* part, const int32_t* n_ptr);
 __global__ void k_scan_apply_dev(const int64_t* in, int64_t* out, const int64_t* part_off, const int32_t* n_ptr);
 __global__ void k_scan_part(const int64_t* in, int64_t* part, int64_t n, int64_t chunk);
@@ -148,7 +145,7 @@ static int dev_scan(vm_ctx* c, vmx_batch_bufs& B, const int64_t* in, int64_t* ou
 }
 
 // the same with the element count on the device (*n_ptr <= cap): no host read-back; out[n] = total
-[[maybe_unused]] static int dev_scan_dev(vm_ctx* c, vmx_batch_bufs& B, const int64_t* in, int64_t* out, const int32_t* n_ptr) {
+static int dev_scan_dev(vm_ctx* c, vmx_batch_bufs& B, const int64_t* in, int64_t* out, const int32_t* n_ptr) {
     const int nb = 512;
     VMX_TRY(B.scanpart.reserve(8 * (size_t)(nb + 2))); VMX_TRY(B.scanoff.reserve(8 * (size_t)(nb + 2)));
     hipLaunchKernelGGL(k_scan_part_dev, dim3(nb), dim3(256), 0, c->stream, in, B.scanpart.as<int64_t>(), n_ptr);
@@ -165,11 +162,13 @@ static int ext_gather_round(vm_ctx* c, vmx_batch_bufs& B, const vm_index_view& i
                             int64_t round_cap, int64_t pool_cap, int stat_slot, bool want_cnt) {
     const int G = c->num_cu * 4;
     hipLaunchKernelGGL(k_prob_owner, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, B.er.as<vmx_ext_read>(), (int)n, redo_only, B.probread.as<int32_t>());
-    (void)round_cap; (void)G;                     // vmx_alloc_probs never lets the published count pass the capacity
-    hipLaunchKernelGGL(k_desc_offsets, dim3(2), dim3(1024), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.toff.as<int64_t>(), B.qoff.as<int64_t>(),
-                       B.statblk.as<int32_t>() + stat_slot);
+    hipLaunchKernelGGL(k_desc_lens, dim3(G), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.tl.as<int64_t>(), B.ql.as<int64_t>());
+    (void)round_cap;                              // vmx_alloc_probs never lets the published count pass the capacity
+    hipLaunchKernelGGL(k_stat_put, dim3(1), dim3(1), 0, c->stream, B.rcount.as<int32_t>(), B.statblk.as<int32_t>() + stat_slot);
     int32_t cnt = 0;
     if (want_cnt) { VMX_TRY(download(&cnt, B.rcount.p, 1, c->stream)); VMX_HIP(vmx_stream_sync(c)); }
+    VMX_TRY(dev_scan_dev(c, B, B.tl.as<int64_t>(), B.toff.as<int64_t>(), B.rcount.as<int32_t>()));
+    VMX_TRY(dev_scan_dev(c, B, B.ql.as<int64_t>(), B.qoff.as<int64_t>(), B.rcount.as<int32_t>()));
     hipLaunchKernelGGL(k_gather, dim3((unsigned)((int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(),
                        B.probread.as<int32_t>(), d_ocodes, d_roff, ix.codes, B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), pool_cap,
                        B.oflow.as<int32_t>());
@@ -435,8 +434,7 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
         const int G = c->num_cu * 4;
         hipLaunchKernelGGL(k_dp_sizes, dim3(G), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.dpsz[0].as<int64_t>(), B.dpsz[1].as<int64_t>(),
                            B.dpsz[2].as<int64_t>(), B.dpsz[3].as<int64_t>());
-        { vmx_scan4 P4; for (int i = 0; i < 4; ++i) { P4.in[i] = B.dpsz[i].as<int64_t>(); P4.out[i] = B.dpoff[i].as<int64_t>(); }
-          hipLaunchKernelGGL(k_scan_multi_dev, dim3(4), dim3(1024), 0, c->stream, P4, (const int32_t*)B.rcount.as<int32_t>()); }
+        for (int i = 0; i < 4; ++i) VMX_TRY(dev_scan_dev(c, B, B.dpsz[i].as<int64_t>(), B.dpoff[i].as<int64_t>(), B.rcount.as<int32_t>()));
         static const int64_t tb_chunk = [] { const char* e = getenv("VMX_TB_CHUNK_GB"); const double v = e ? atof(e) : 0.0; return v > 0.5 ? (int64_t)(v * (double)(1 << 30)) : (int64_t)VMX_TB_CHUNK; }();     // tuning knob
         // sizing sync #3 (the only one of the round): problem count, pool totals, chunk cuts (at most VMX_TB_CHUNK traceback bytes per chunk)
         int64_t plan[8 + 2 * (VMX_MAX_CHUNKS + 1)];
