@@ -505,10 +505,11 @@ __device__ __forceinline__ bool vmx_cluster_filtered(const uint64_t* __restrict_
                 }
                 __syncthreads();
                 // bins 4 tid .. 4 tid + 3 per thread; the bin where the running count reaches `rem`
-                int cnt[4]; int sum = 0;
-                for (int j = 0; j < 4; ++j) { const unsigned b = 4u * (unsigned)tid + (unsigned)j; cnt[j] = b < 4096u ? (int)((HIST[b >> 1] >> (16 * (b & 1))) & 0xffffu) : 0; sum += cnt[j]; }
+                constexpr int PER = 4096 / BLOCK > 0 ? 4096 / BLOCK : 1;          // bins per thread (BLOCK * PER >= 4096)
+                int cnt[PER]; int sum = 0;
+                for (int j = 0; j < PER; ++j) { const unsigned b = (unsigned)PER * (unsigned)tid + (unsigned)j; cnt[j] = b < 4096u ? (int)((HIST[b >> 1] >> (16 * (b & 1))) & 0xffffu) : 0; sum += cnt[j]; }
                 int tot; int ex = vmx_block_excl_scan(sum, s_scan, &tot);
-                for (int j = 0; j < 4; ++j) { if (ex < rem && rem <= ex + cnt[j]) { s_cf[4] = 4 * tid + j; s_cf[5] = ex; } ex += cnt[j]; }
+                for (int j = 0; j < PER; ++j) { if (ex < rem && rem <= ex + cnt[j]) { s_cf[4] = PER * tid + j; s_cf[5] = ex; } ex += cnt[j]; }
                 __syncthreads();
                 prefix |= (uint64_t)(unsigned)s_cf[4] << shift; rem -= s_cf[5];
                 __syncthreads();
@@ -749,10 +750,13 @@ __global__ void __launch_bounds__(256) k_cluster(uint64_t* __restrict__ keys, ui
     vmx_cluster_body<256, 0>(keys, cl_keys, key_off, nhits, rlist, nlist, tile, check_num, kmer, rows, n_anchors);
 }
 // reads with more hits than k_cluster's tile: the filtered form, two 1024-thread workgroups per CU (64 KB of LDS, 64 registers) ...
-__global__ void __launch_bounds__(1024, VMX_CF_WAVES) k_cluster_big(uint64_t* __restrict__ keys, uint64_t* __restrict__ cl_keys, const int64_t* __restrict__ key_off,
+#ifndef VMX_CF_BLOCK
+#define VMX_CF_BLOCK 1024                   // threads of the filtered kernel's workgroup (tuning knob, with the launch in vmx_index.hip)
+#endif
+__global__ void __launch_bounds__(VMX_CF_BLOCK, VMX_CF_WAVES) k_cluster_big(uint64_t* __restrict__ keys, uint64_t* __restrict__ cl_keys, const int64_t* __restrict__ key_off,
                                                       const int64_t* __restrict__ nhits, const int32_t* __restrict__ rlist, int nlist, int tile, int check_num, int kmer,
                                                       int64_t* __restrict__ rows, int32_t* __restrict__ n_anchors, int32_t* __restrict__ decl, int32_t* __restrict__ n_decl) {
-    vmx_cluster_body<1024, 1>(keys, cl_keys, key_off, nhits, rlist, nlist, tile, check_num, kmer, rows, n_anchors, decl, n_decl);
+    vmx_cluster_body<VMX_CF_BLOCK, 1>(keys, cl_keys, key_off, nhits, rlist, nlist, tile, check_num, kmer, rows, n_anchors, decl, n_decl);
 }
 // ... and the general path for the reads that form declines or cannot take (more than 16383 hits); nlist_dev: the list's length, on the device
 __global__ void __launch_bounds__(1024) k_cluster_gen(uint64_t* __restrict__ keys, uint64_t* __restrict__ cl_keys, const int64_t* __restrict__ key_off,

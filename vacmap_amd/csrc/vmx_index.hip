@@ -37,6 +37,9 @@ __global__ void k_cluster(uint64_t* keys, uint64_t* cl_keys, const int64_t* key_
                           int64_t* rows, int32_t* n_anchors);
 __global__ void k_cluster_gen(uint64_t* keys, uint64_t* cl_keys, const int64_t* key_off, const int64_t* nhits, const int32_t* rlist, int nlist, const int32_t* nlist_dev, int tile, int check_num,
                               int kmer, int64_t* rows, int32_t* n_anchors);
+#ifndef VMX_CF_BLOCK
+#define VMX_CF_BLOCK 1024
+#endif
 __global__ void k_cluster_big(uint64_t* keys, uint64_t* cl_keys, const int64_t* key_off, const int64_t* nhits, const int32_t* rlist, int nlist, int tile, int check_num, int kmer,
                               int64_t* rows, int32_t* n_anchors, int32_t* decl, int32_t* n_decl);
 __global__ void k_cluster_long(uint64_t* keys, uint64_t* cl_keys, const int64_t* key_off, const int64_t* nhits, const int32_t* rlist, int nlist, const int32_t* nlist_dev, int tile, int check_num,
@@ -691,7 +694,7 @@ int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, in
                                    koff.as<int64_t>(), nh.as<int64_t>(), d_rl + small.size(), (int)n_huge, (const int32_t*)nullptr, VMX_SORT_LDS_BIG, check_num, mi->k, rows.as<int64_t>(), nanc.as<int32_t>(),
                                    d_decl2, d_ndecl2);
             if (n_mid) {
-                hipLaunchKernelGGL(k_cluster_big, dim3((unsigned)std::min<int64_t>((int64_t)n_mid, (int64_t)c->num_cu * filt_wgs)), dim3(1024), (size_t)8 * mid_tile, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(),
+                hipLaunchKernelGGL(k_cluster_big, dim3((unsigned)std::min<int64_t>((int64_t)n_mid, (int64_t)c->num_cu * filt_wgs)), dim3(VMX_CF_BLOCK), (size_t)8 * mid_tile, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(),
                                    koff.as<int64_t>(), nh.as<int64_t>(), d_rl + small.size() + n_huge, (int)n_mid, mid_tile, check_num, mi->k, rows.as<int64_t>(), nanc.as<int32_t>(), d_decl, d_ndecl);
                 hipLaunchKernelGGL(k_cluster_long, dim3((unsigned)std::min<int64_t>((int64_t)n_mid, c->num_cu)), dim3(1024), 8 * VMX_SORT_LDS_BIG, c->stream, keys.as<uint64_t>(), ckeys.as<uint64_t>(),
                                    koff.as<int64_t>(), nh.as<int64_t>(), (const int32_t*)d_decl, 0, (const int32_t*)d_ndecl, VMX_SORT_LDS_BIG, check_num, mi->k, rows.as<int64_t>(), nanc.as<int32_t>(),
