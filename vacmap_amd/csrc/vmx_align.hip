@@ -360,7 +360,8 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     const int64_t round_cap = cS + 16;                       // one problem per anchor at most in any round
     const int64_t pool_cap = 6 * total_bases + (1 << 20);
     int64_t Lmax_b = 1; for (int64_t r = 0; r < n; ++r) Lmax_b = std::max(Lmax_b, h_roff[r + 1] - h_roff[r]);
-    const int64_t carry_stride = 2 * Lmax_b + 32768;
+    const int64_t carry_stride = preset ? 32768 : 2 * Lmax_b + 32768;      // (ass_extend_func has no divergence filter: a preset chain never reaches the exact kernel, and a ring per
+                                                                           //  workgroup sized by a 100 Mb contig asked for 617 GB)
     const int64_t ed_wgs = std::min<int64_t>(c->num_cu, 64);   // workgroups of the exact kernel (x1 long, x2 short patterns): the last tier of the filter, hardly ever
                                                                // reached (0 problems per step on the bench workload), so its carry rings are kept small (0.8 instead of 3.2 GB)        // exact edit-distance kernel: one carry ring per workgroup (1 + 2 per CU), longest text it takes
     VMX_TRY(B.desc[0].reserve(sizeof(vmx_pair_desc) * (size_t)round_cap)); VMX_TRY(B.desc[1].reserve(sizeof(vmx_pair_desc) * (size_t)round_cap));

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <atomic>
 #include <mutex>
+#include <execinfo.h>
 
 namespace vmx {
 
@@ -59,7 +60,7 @@ struct DevBuf {
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) { (void)hipGetLastError(); devbuf_retired().flush(); e = hipMalloc(&p, want); }                // give the parked memory back first
         if (e != hipSuccess && regrow) { (void)hipGetLastError(); want = bytes + 256; e = hipMalloc(&p, want); }          // no room for the head-room: exact size
-        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+        if (e != hipSuccess) { p = nullptr; if (getenv("VMX_DBG_POOLS")) { fprintf(stderr, "[pools] hipMalloc of %.3f GB (asked: %.3f GB) failed\n", want / 1e9, bytes / 1e9); void* bt[24]; const int nb = backtrace(bt, 24); backtrace_symbols_fd(bt, nb, 2); } return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
         cap = want;
         DevBufStats& st = devbuf_stats(); (regrow ? st.grows : st.first)++;
         const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
