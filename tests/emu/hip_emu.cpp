@@ -48,6 +48,7 @@ static void rendezvous(Rendezvous& rv, int& alive) {
 }
 
 void wave_barrier() { Block* b = g_blk; unsigned w = b->lanes[b->cur].tid >> 6; rendezvous(b->wave_rv[w], b->wave_alive[w]); }
+void row_barrier() { Block* b = g_blk; unsigned r = b->lanes[b->cur].tid >> 4; rendezvous(b->row_rv[r], b->row_alive[r]); }
 void block_barrier() { Block* b = g_blk; rendezvous(b->block_rv, b->block_alive); }
 
 static void trampoline() {
@@ -57,6 +58,7 @@ static void trampoline() {
     l.done = true;
     unsigned w = l.tid >> 6;
     b->wave_alive[w]--; b->block_alive--;
+    { const unsigned r = l.tid >> 4; b->row_alive[r]--; if (b->row_alive[r] > 0 && b->row_rv[r].count >= b->row_alive[r]) { b->row_rv[r].count = 0; b->row_rv[r].gen++; } }
     // a lane leaving may complete a rendezvous the others are waiting on
     if (b->wave_alive[w] > 0 && b->wave_rv[w].count >= b->wave_alive[w]) { b->wave_rv[w].count = 0; b->wave_rv[w].gen++; }
     if (b->block_alive > 0 && b->block_rv.count >= b->block_alive) { b->block_rv.count = 0; b->block_rv.gen++; }
@@ -71,6 +73,8 @@ static void run_block(Block& b, std::vector<char*>& stacks) {
     b.slots.assign(n, 0); b.slots2.assign(n, 0);
     b.wave_rv.assign(nw, Rendezvous()); b.block_rv = Rendezvous();
     b.wave_alive.assign(nw, 0);
+    b.row_rv.assign((n + 15) / 16, Rendezvous()); b.row_alive.assign((n + 15) / 16, 0);
+    for (unsigned t = 0; t < n; ++t) b.row_alive[t >> 4]++;
     for (unsigned t = 0; t < n; ++t) b.wave_alive[t >> 6]++;
     b.block_alive = (int)n;
     b.lanes.resize(n);

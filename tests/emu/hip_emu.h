@@ -62,6 +62,8 @@ struct Block {
     std::vector<uint64_t> slots;          // one exchange slot per lane
     std::vector<uint64_t> slots2;
     std::vector<Rendezvous> wave_rv;      // per wave
+    std::vector<Rendezvous> row_rv;       // per 16-lane row (the chain kernels' row-scoped collectives, vmx_rows.h)
+    std::vector<int> row_alive;
     Rendezvous block_rv;
     std::vector<int> wave_alive;
     int block_alive = 0;
@@ -74,6 +76,7 @@ inline Block* cur() { return g_blk; }
 inline Lane& me() { return g_blk->lanes[g_blk->cur]; }
 void yield();
 void wave_barrier();
+void row_barrier();
 void block_barrier();
 void run_grid(dim3 grid, dim3 block, size_t shmem, std::function<void()> body);
 double now_ms();
@@ -104,6 +107,33 @@ template <class T> inline T emu_exchange(T v, int src_lane_in_wave) {
     hipemu::wave_barrier();
     T r; memcpy(&r, &got, sizeof(T));
     return r;
+}
+// row-scoped collectives: only the (up to) 16 lanes of the caller's row meet, so the rows of a wave may sit in different branches
+// (on the hardware: DPP row operations and ds_bpermute under an exec mask that switches whole rows on and off)
+template <class T> inline T emu_row_exchange(T v, int src_lane_in_row) {
+    static_assert(sizeof(T) <= 8, "emu row exchange: type too wide");
+    hipemu::Block* b = hipemu::cur();
+    unsigned tid = hipemu::me().tid;
+    unsigned rbase = tid & ~15u;
+    uint64_t raw = 0; memcpy(&raw, &v, sizeof(T));
+    b->slots2[tid] = raw;
+    hipemu::row_barrier();
+    unsigned src = rbase + ((unsigned)src_lane_in_row & 15u);
+    uint64_t got = (src < b->nthreads && !b->lanes[src].done) ? b->slots2[src] : raw;
+    hipemu::row_barrier();
+    T r; memcpy(&r, &got, sizeof(T));
+    return r;
+}
+inline unsigned emu_row_ballot(int pred) {
+    hipemu::Block* b = hipemu::cur();
+    unsigned tid = hipemu::me().tid, rbase = tid & ~15u;
+    b->slots2[tid] = pred ? 1 : 0;
+    hipemu::row_barrier();
+    unsigned m = 0;
+    for (unsigned l = 0; l < 16 && rbase + l < b->nthreads; ++l)
+        if (!b->lanes[rbase + l].done && b->slots2[rbase + l]) m |= 1u << l;
+    hipemu::row_barrier();
+    return m;
 }
 template <class T> inline T __shfl(T v, int src, int width = 64) {
     int lane = hipemu::me().tid & 63; int base = lane & ~(width - 1);

@@ -60,6 +60,19 @@ def test_emu_chain_global(ctx, oracle, golden):
     KC.check_chain_global_golden(ctx, oracle, golden, cases=['B', 'D'])
 
 
+def test_emu_chain_rows_small_window(ctx, oracle, golden, monkeypatch):
+    """k_chain_global_rows / k_chain_local_rows with a window of 3 entries instead of 16 (emulator-only hook VMX_RW_WIN): the scan that goes on
+    through the index in HBM and the insertion below the window, rare at 16, are taken at almost every anchor — S / P / S_arg, the local
+    chains and the records must not change. VMX_CHAIN_ROWS=0 runs the one-wavefront-per-read kernels on the same cases."""
+    monkeypatch.setenv('VMX_RW_WIN', '3')
+    KC.check_chain_global_golden(ctx, oracle, golden, cases=['B', 'D'])
+    KC.check_local_golden(ctx, oracle, golden, cases=['D'])
+    KC.check_local_golden(ctx, oracle, golden, cases=['P'])
+    KC.check_align_golden(ctx, oracle, golden, cases=['D'])
+    KC.check_align_golden(ctx, oracle, golden, cases=['H'], reads=[3])        # mode R: the penalty columns ride in the window too
+    monkeypatch.delenv('VMX_RW_WIN')
+
+
 def test_emu_seed(ctx, oracle, golden):
     KC.check_seed_golden(ctx, oracle, golden, cases=['B', 'D'])
 

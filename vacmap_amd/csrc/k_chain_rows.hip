@@ -1,0 +1,439 @@
+// k_chain_rows.hip — the chain DPs with FOUR reads per wavefront, one per 16-lane DPP row (SURVEY §8(a) rows G2, L3, L4, L5 `_scar`).
+//
+//   k_chain_global_rows   G2 get_optimal_chain_sortbyreadpos_forSV_inv_test_merged_fine_list_d_all
+//                         (/root/reference/src/vacmap/mammap_clrnano.py:24828-25031; mode R: mammap_noprefercloser.py:22839-23057)
+//   k_chain_local_rows    L3 LC-exact (:27305-27528), L4 LC-mm (:28250-28476), L5 `_scar` (mammap_noprefercloser.py:23419-23628)
+//
+// Why rows. The reference scans the predecessors of an anchor in descending score and stops at the first one that cannot win any more
+// (:24940 `if S[j] > max_scores - l_i ... else break`): on ONT and HiFi reads 2-3 candidates are looked at per anchor, 16 or more for one
+// anchor in a thousand (tools/ubench/chain_stats.py). k_chain_global / k_chain_local (k_chain.hip, k_chain_local.hip) give a read a whole
+// wavefront and evaluate 64 candidates per step — 60 lanes of every instruction are wasted, and a read owns a wave slot and 12 B of LDS per
+// anchor. Here a ROW of 16 lanes owns a read: its 16 best predecessors sit in registers (the window, lane t = t-th best), one step of the
+// loop finishes one anchor of each of the wave's four reads, nothing is kept in LDS, and the common path reads nothing it has written
+// (S / P / S_arg go to HBM as stores only), so no wait for a store sits on the per-anchor chain.
+//
+// What a step does for anchor i of a row (same arithmetic, same order as the reference, IEEE double, -ffp-contract=off):
+//   1 the anchor's fields come out of a 16-anchor register block by ds_bpermute, a step ahead of their use;
+//   2 if its read position (LC: read end) passes `prereadloc` the candidate space advances: te = i (:24905-24932). The reference inserts the
+//     anchors te .. i-1 into the sorted index at that moment; here every anchor is inserted as soon as its score is known — the index
+//     goes through the same sequence of states, since anchor k is inserted into the entries 0 .. k-1 either way — and an entry with
+//     j >= te is simply not VISIBLE to the scan yet (it is passed over: no break, no opcount);
+//   3 every lane evaluates its window entry against the anchor; an inclusive prefix maximum along the row (row_shr:1/2/4/8) gives the
+//     running maximum the sequential loop would hold at each candidate, a ballot cut to the row's 16 bits the first candidate that breaks
+//     the loop, `opcount` the number of visible candidates before it (T4), and the LAST strict increase before the break the winner (T2);
+//   4 the score, its predecessor and the row's running best are stored / updated; the new entry goes into the window at the number of
+//     larger scores (GC: among equal scores where the reference's bisection :19369-19387 puts it, replayed on the two counts), the top
+//     of S_arg is rewritten by the lanes at or above it.
+// Rare paths, taken by a row on its own while the other rows of the wave wait: a scan that passes all 16 window entries goes on through
+// S_arg / S / the anchors in HBM, 16 candidates per step; an entry that lands below the window (or among equal scores that reach below
+// it) is placed by a 16-ary search and a shift of S_arg in HBM. Both first wait for the row's own stores.
+#include "vmx_device.h"
+#include "vmx_kernels.h"
+#include "vmx_rows.h"
+#include "vmx_local.h"
+
+#define VMX_RW_NONE 0x7fffffff          /* window lane without an entry */
+
+// window entry = one candidate predecessor: anchor index, score, read position, length | strand bit << 16, reference position
+// (mode R / `_scar`: + fixed_penatly / pre_penatly of that anchor)
+struct vmx_rwin { int j, q, ls; double S; long long r; double fp, pp; };
+// the anchor being computed, the same in the 16 lanes of its row
+struct vmx_rcur { int q, l, sneg; long long r; double dl; int te; double skipcost; int maxdiff; };
+
+// strand of an encoded ls word: bit 16 set = -1
+#define VMX_RW_LS(l, s) (((int)(l) & 0xffff) | ((s) < 0 ? 0x10000 : 0))
+
+// gap geometry of :24953-24984 / :27418-27456 (vmx_gap_geometry_sel<false>, vmx_kernels.h) on the row kernels' strand bits
+__device__ __forceinline__ void vmx_rw_geometry(const vmx_rcur& c, int qj, int lj, int snegj, long long rj, int& readgap, long long& refgap, int& bonus) {
+    const int rg = c.q - qj - lj;
+    const int m = rg < 0 ? rg : 0;
+    readgap = rg - m;
+    bonus = c.l + m;
+    const long long d = c.r - rj;
+    const bool same = c.sneg == snegj;
+    int cc; long long t;
+    if (!c.sneg) { cc = (same ? -lj : 1) - m; t = d; }
+    else { cc = same ? -c.l - m : c.l - lj + m - 1; t = same ? -d : d; }
+    refgap = t + (long long)cc;
+}
+
+// KIND: 0 GC modes H / L / S, 1 GC mode R, 2 LC-exact, 3 LC-mm, 4 `_scar`
+template <int KIND> struct vmx_rw_traits {
+    static constexpr bool gc = KIND <= 1;
+    static constexpr bool pen = KIND == 1 || KIND == 4;           // fixed_penatly / pre_penatly bookkeeping
+};
+
+struct vmx_rw_costs {
+    const double* s_gapcost; const float* s_rgc; double skip; int maxgap; long long l2c_size; const double* log2cache;
+};
+
+// score of the step candidate -> anchor (test_scores), and for the penalty variants what the anchor inherits if that candidate wins
+template <int KIND>
+__device__ __forceinline__ double vmx_rw_test(const vmx_rcur& c, const vmx_rw_costs& K, const vmx_tables& tab, const vmx_rwin& w, double& nfp, double& npp) {
+    const int lj = w.ls & 0xffff, snegj = (w.ls >> 16) & 1;
+    int readgap, bonus; long long refgap;
+    vmx_rw_geometry(c, w.q, lj, snegj, w.r, readgap, refgap, bonus);
+    long long gapcost = (long long)readgap - refgap; if (gapcost < 0) gapcost = -gapcost;
+    const bool col = c.sneg == snegj && refgap >= 0 && readgap <= K.maxgap && gapcost <= (long long)c.maxdiff;
+    const double Sj = w.S, db = (double)bonus;
+    nfp = 0.0; npp = 0.0;
+    if constexpr (KIND == 0) {
+        // both forms are computed and one is selected (k_chain.hip): no exec-mask region per kind of step
+        const double tc = Sj + db - K.s_gapcost[col ? (int)gapcost : 0];
+        const double tn = Sj - c.skipcost + db - vmx_extra_cost(tab, col ? 0x7fffffffffffffffLL : gapcost);
+        return col ? tc : tn;
+    } else if constexpr (KIND == 1) {
+        double test;
+        if (col) {
+            test = Sj + db - K.s_gapcost[(int)gapcost];
+            if (w.fp < 0 && (w.fp + db) >= 0) test += w.pp;
+            if (w.fp < 0 && (w.fp + db) < 0) { nfp = w.fp + db; npp = w.pp; }
+        } else {
+            test = Sj + db - c.skipcost;
+            nfp = -c.skipcost + db; npp = c.skipcost;
+        }
+        return test;
+    } else if constexpr (KIND == 2 || KIND == 3) {
+        if (bonus <= 0) return -1e300;                    // only an overlap brings the bonus to zero or below (:27425): evaluated to nothing, still counted
+        const double tc = Sj + db - K.s_gapcost[col ? (int)gapcost : 0] - (double)K.s_rgc[col ? readgap : 0];
+        double tn;
+        if constexpr (KIND == 2) {
+            const double ex = vmx_extra_cost(tab, col ? 0x7fffffffffffffffLL : gapcost);
+            const double pen = (c.sneg != snegj ? (K.skip < 50.0 ? K.skip : 50.0) : K.skip) + ex;
+            tn = Sj + db - pen;
+        } else {
+            const long long gx = col ? 0 : gapcost;
+            const double pen = K.skip + K.log2cache[gx < K.l2c_size ? gx : K.l2c_size];
+            tn = Sj + db - pen;
+        }
+        return col ? tc : tn;
+    } else {
+        if (bonus <= 0) return -1e300;
+        double test;
+        if (col) {
+            test = Sj + db - K.s_gapcost[(int)gapcost] - (double)K.s_rgc[readgap];
+            if (w.fp < 0 && (w.fp + db) >= 0) test += w.pp;                      // refund (:23557-23559)
+            if (w.fp < 0 && (w.fp + db) < 0) { nfp = w.fp + db; npp = w.pp; }
+        } else {
+            test = Sj + db - K.skip;                                                // :23577-23578
+            nfp = -K.skip + db; npp = K.skip;
+        }
+        return test;
+    }
+}
+
+// One block of 16 candidates in scan order (lane 0 first). `end`: no entry in this lane (the index ends here); `vis`: an entry the scan may
+// look at. Carries the sequential loop's state: max_scores / pre_index (/ the penalties the anchor inherits), opcount. Returns the lane of
+// the first candidate that ends the loop (16: none).
+template <int KIND>
+__device__ __forceinline__ int vmx_rw_scan16(const vmx_rcur& c, const vmx_rw_costs& K, const vmx_tables& tab, const vmx_rwin& w, bool end, bool vis,
+                                             double& max_scores, int& pre_index, double& fp_i, double& pp_i, long long& opcount) {
+    constexpr bool gc = vmx_rw_traits<KIND>::gc;
+    double nfp = 0.0, npp = 0.0;
+    double test = VMX_F64_NEG;
+    if (vis) test = vmx_rw_test<KIND>(c, K, tab, w, nfp, npp);
+    const double incl = vmx_row_incl_max_f64(test);                           // prefix max of the candidates' scores, in scan order
+    double m_before = vmx_row_shr_f64<1>(VMX_F64_NEG, incl);                  // lane 0: nothing before it
+    m_before = m_before > max_scores ? m_before : max_scores;                 // the running max the sequential loop holds at this candidate
+    const double lim = m_before - c.dl;
+    const bool brk_real = vis && (gc ? !(w.S > lim) : (w.S < lim));           // GC :24940 breaks on S[j] <= max - l_i, LC :27415 on S[j] < max - l_i
+    const unsigned bm = vmx_row_ballot(brk_real || end), rm = vmx_row_ballot(brk_real), vm = vmx_row_ballot(vis);
+    const unsigned im = vmx_row_ballot(vis && test > m_before);               // strict >: the candidates at which the sequential loop updates
+    const int first = __ffs(bm | 0x10000u) - 1;
+    const unsigned below = (1u << first) - 1u;
+    // opcount: GC counts the candidates that pass the test, LC counts before the test, i.e. the breaking candidate too (:27410-27415)
+    opcount += __popc(vm & below) + ((!gc && ((rm >> first) & 1u)) ? 1 : 0);
+    const unsigned upd = im & below;
+    if (upd) {
+        const int wl = 31 - __clz((int)upd);                                  // the last update wins
+        max_scores = vmx_row_get_f64(test, wl);
+        pre_index = vmx_row_get_i32(w.j, wl);
+        if constexpr (vmx_rw_traits<KIND>::pen) { fp_i = vmx_row_get_f64(nfp, wl); pp_i = vmx_row_get_f64(npp, wl); }
+    }
+    return first;
+}
+
+// number of x in [0, k) with S[SA[x]] < target (le: <= target); S ascending along SA. 16-ary search by the row's 16 lanes.
+__device__ __forceinline__ int vmx_rw_sorted_count(const double* S, const int* SA, int k, double target, bool le, int l16) {
+    int lo = 0, hi = k;                   // elements [0, lo) qualify, elements [hi, k) do not
+    while (hi - lo > 16) {
+        const int stride = (hi - lo + 15) >> 4;
+        const int x = lo + (l16 + 1) * stride - 1;
+        bool in = false;
+        if (x < hi) { const double v = S[SA[x]]; in = le ? v <= target : v < target; }
+        const int cnt = __popc(vmx_row_ballot(in));
+        const int nlo = lo + cnt * stride;
+        int nhi = nlo + stride - 1; if (nhi > hi) nhi = hi;
+        lo = nlo; hi = nhi;
+    }
+    const int x = lo + l16;
+    bool in = false;
+    if (x < hi) { const double v = S[SA[x]]; in = le ? v <= target : v < target; }
+    return lo + __popc(vmx_row_ballot(in));
+}
+// SA[loc + 1 : k + 1] = SA[loc : k]; SA[loc] = k, by the row's 16 lanes from the top down
+__device__ __forceinline__ void vmx_rw_sarg_insert(int* SA, int loc, int k, int l16) {
+    for (int hi = k; hi > loc; hi -= 16) {
+        const int x = hi - l16;
+        int v = 0;
+        if (x > loc) v = SA[x - 1];
+        vmx_row_sync();
+        if (x > loc) SA[x] = v;
+        vmx_row_sync();
+    }
+    if (l16 == 0) SA[loc] = k;
+    vmx_row_sync();
+}
+// the reference's insertpoint_score (:19369-19387) replayed on a = #scores < target and b = #scores <= target (k_chain.hip)
+__device__ __forceinline__ int vmx_rw_bisect_replay(int a, int b, int k) {
+    int i = 0, j = k;
+    while (i < j) {
+        const int mid = (i + j) >> 1;
+        if (mid < a) i = mid + 1;
+        else if (mid >= b) j = mid;
+        else return mid + 1;
+    }
+    return j;
+}
+
+__device__ __forceinline__ void vmx_rw_load_entry(vmx_rwin& w, int j, const vmx_anchor* A, const double* S, const double* FP, const double* PP, bool pen) {
+    const vmx_anchor a = A[j];
+    w.j = j; w.q = a.q; w.ls = VMX_RW_LS(a.l, a.s); w.S = S[j]; w.r = a.r;
+    if (pen) { w.fp = FP[j]; w.pp = PP[j]; }
+}
+
+// The loop over one read's anchors, for one row. A: the read's anchors in the order the variant wants them (GC: by read position; LC-exact /
+// LC-mm: by read end; `_scar`: by read start); S / P / SA: the read's arrays in HBM (outputs of GC, scratch of LC); COV: GC's coverage bytes.
+// Returns the index of the best anchor (GC: -1 after the opcount bail-out :24914; LC: -1 when the reference would switch to its *_fast twin :27380).
+// WW: entries the window holds (16; the CPU-emulator tests also run 3, so that the rare paths are the common ones there: VMX_RW_WIN)
+template <int KIND, int WW>
+__device__ __forceinline__ int vmx_rw_chain(const vmx_anchor* __restrict__ A, int n, const vmx_rw_costs& K, const vmx_tables& tab, double oskipcost, int omaxdiff,
+                                            double* __restrict__ S, int32_t* __restrict__ P, int32_t* __restrict__ SA, const uint8_t* __restrict__ COV,
+                                            double* __restrict__ FP, double* __restrict__ PP, double& best_score, long long& opcount_out, unsigned& slow_out) {
+    constexpr bool gc = vmx_rw_traits<KIND>::gc;
+    constexpr bool pen = vmx_rw_traits<KIND>::pen;
+    constexpr bool cov = KIND == 0;
+    const int l16 = vmx_lane() & 15;
+    // anchors [bb, bb + 16) in registers (lane t: anchor bb + t), the next block already on its way
+    int bq, bls, nbq, nbls; long long br, nbr;
+    { const int x = l16 < n ? l16 : n - 1; const vmx_anchor a = A[x]; bq = a.q; bls = VMX_RW_LS(a.l, a.s) | (cov ? (int)COV[x] << 17 : 0); br = a.r; }
+    { const int x = 16 + l16 < n ? 16 + l16 : n - 1; const vmx_anchor a = A[x]; nbq = a.q; nbls = VMX_RW_LS(a.l, a.s) | (cov ? (int)COV[x] << 17 : 0); nbr = a.r; }
+    const int q0 = vmx_row_get_i32(bq, 0), ls0 = vmx_row_get_i32(bls, 0); const long long r0 = vmx_row_get_i64(br, 0);
+    const int l0 = ls0 & 0xffff;
+    vmx_rwin win;
+    win.j = l16 == 0 ? 0 : VMX_RW_NONE; win.q = q0; win.ls = ls0 & 0x1ffff; win.S = l16 == 0 ? (double)l0 : VMX_F64_NEG; win.r = r0; win.fp = 0.0; win.pp = 0.0;
+    if (l16 == 0) { SA[0] = 0; S[0] = (double)l0; P[0] = VMX_NOPRE; if (pen) { FP[0] = 0.0; PP[0] = 0.0; } }
+    vmx_rcur c;
+    c.te = 1; c.skipcost = cov ? oskipcost + (double)(ls0 >> 17) : oskipcost; c.maxdiff = omaxdiff;
+    if (cov) { c.maxdiff = omaxdiff - (ls0 >> 17); if (c.maxdiff < 10) c.maxdiff = 10; }
+    int prereadloc = gc ? q0 : q0 + l0;
+    double g_max_scores = (double)l0; int g_max_index = 0;
+    long long opcount = 0;
+    unsigned slow = 0;
+    bool bailed = false;
+    // anchor 1, fetched a step ahead
+    int nq = vmx_row_get_i32(bq, 1), nls = vmx_row_get_i32(bls, 1); long long nr = vmx_row_get_i64(br, 1);
+    for (int i = 1; i < n; ++i) {
+        c.q = nq; c.l = nls & 0xffff; c.sneg = (nls >> 16) & 1; c.r = nr; c.dl = (double)c.l;
+        const int covi = nls >> 17;
+        {   // anchor i + 1 for the next step
+            const int x = i + 1;
+            if ((x & 15) == 0) {
+                bq = nbq; bls = nbls; br = nbr;
+                const int y = x + 16 + l16 < n ? x + 16 + l16 : n - 1; const vmx_anchor a = A[y];
+                nbq = a.q; nbls = VMX_RW_LS(a.l, a.s) | (cov ? (int)COV[y] << 17 : 0); nbr = a.r;
+            }
+            nq = vmx_row_get_i32(bq, x & 15); nls = vmx_row_get_i32(bls, x & 15); nr = vmx_row_get_i64(br, x & 15);
+        }
+        const int key = gc ? c.q : c.q + c.l;
+        if (prereadloc < key) {
+            // (opcount / i > 1000 in doubles <=> opcount > 1000 i for these magnitudes: the quotient of two integers below 2^53 that exceeds
+            // 1000 does so by at least 1 / i, far above the spacing of doubles at 1000)
+            if (gc) { if (opcount > 1000LL * (long long)i) { bailed = true; break; } }                                  // :24914 max_factor
+            else if (KIND != 4) { if (opcount > 100000 && opcount > 1000LL * (long long)prereadloc) { bailed = true; break; } }      // :27380 -> *_fast
+            c.te = i;
+            if (cov) { c.skipcost = oskipcost + (double)covi; c.maxdiff = omaxdiff - covi; if (c.maxdiff < 10) c.maxdiff = 10; }
+            prereadloc = key;
+        }
+        double max_scores = c.dl; int pre_index = VMX_NOPRE; double fp_i = 0.0, pp_i = 0.0;
+        const bool wend = win.j == VMX_RW_NONE;
+        int first = vmx_rw_scan16<KIND>(c, K, tab, win, wend, !wend && win.j < c.te, max_scores, pre_index, fp_i, pp_i, opcount);
+        if (first >= WW && i > WW) {
+            // the scan passed the whole window: on through the index in HBM, 16 candidates per step
+            ++slow;
+            vmx_row_sync();
+            for (int base = i - 1 - WW; base >= 0; base -= 16) {
+                const int x = base - l16;
+                vmx_rwin w; w.j = VMX_RW_NONE; w.q = 0; w.ls = 0; w.S = 0.0; w.r = 0; w.fp = 0.0; w.pp = 0.0;
+                if (x >= 0) vmx_rw_load_entry(w, SA[x], A, S, FP, PP, pen);
+                first = vmx_rw_scan16<KIND>(c, K, tab, w, x < 0, x >= 0 && w.j < c.te, max_scores, pre_index, fp_i, pp_i, opcount);
+                if (first < 16) break;
+            }
+        }
+        if (l16 == 0) { S[i] = max_scores; P[i] = pre_index; if (pen) { FP[i] = fp_i; PP[i] = pp_i; } }
+        if (max_scores > g_max_scores) { g_max_scores = max_scores; g_max_index = i; }
+        // the new entry's place: k = i entries so far, the window holds the top min(k, 16)
+        const unsigned gt = vmx_row_ballot(win.S > max_scores), ge = vmx_row_ballot(win.S >= max_scores);
+        const int above = __popc(gt), cge = __popc(ge);
+        const int W = i < WW ? i : WW;
+        int at = -1;
+        if (!gc || gt == ge) { if (above < WW && (above < W || W == i)) at = above; }      // LC: above its equals (smallorequal + 1, :13229-13265)
+        else if (cge < W || W == i) { at = i - vmx_rw_bisect_replay(i - cge, i - above, i); if (at >= WW) at = -1; }      // the run of equal scores ends inside the window
+        if (at >= 0) {
+            const int sj = vmx_row_shr_i32<1>(win.j, win.j), sq = vmx_row_shr_i32<1>(win.q, win.q), sls = vmx_row_shr_i32<1>(win.ls, win.ls);
+            const double sS = vmx_row_shr_f64<1>(win.S, win.S); const long long sr = vmx_row_shr_i64<1>(win.r, win.r);
+            double sfp = 0.0, spp = 0.0;
+            if constexpr (pen) { sfp = vmx_row_shr_f64<1>(win.fp, win.fp); spp = vmx_row_shr_f64<1>(win.pp, win.pp); }
+            if (l16 > at) { win.j = sj; win.q = sq; win.ls = sls; win.S = sS; win.r = sr; if constexpr (pen) { win.fp = sfp; win.pp = spp; } }
+            else if (l16 == at) { win.j = i; win.q = c.q; win.ls = c.l | (c.sneg << 16); win.S = max_scores; win.r = c.r; if constexpr (pen) { win.fp = fp_i; win.pp = pp_i; } }
+            if (WW < 16 && l16 >= WW) { win.j = VMX_RW_NONE; win.S = VMX_F64_NEG; }
+            if (l16 <= at) SA[i - l16] = win.j;
+        } else {
+            // below the window, or among equal scores that reach below it: search and shift in HBM, then the window again from the index
+            ++slow;
+            vmx_row_sync();
+            int loc;
+            if (gc) {
+                const int a = vmx_rw_sorted_count(S, SA, i, max_scores, false, l16);
+                int b = a;
+                if (a < i && S[SA[a]] == max_scores) b = vmx_rw_sorted_count(S, SA, i, max_scores, true, l16);
+                loc = vmx_rw_bisect_replay(a, b, i);
+            } else loc = vmx_rw_sorted_count(S, SA, i, max_scores, true, l16);
+            vmx_rw_sarg_insert(SA, loc, i, l16);
+            if (i - loc < WW) {
+                const int x = i - l16;
+                win.j = VMX_RW_NONE; win.S = VMX_F64_NEG;
+                if (x >= 0 && l16 < WW) vmx_rw_load_entry(win, SA[x], A, S, FP, PP, pen);
+            }
+        }
+    }
+    // (the reference's closing insertions :25018-25027 have all happened)
+    best_score = g_max_scores; opcount_out = opcount; slow_out = slow;
+    return bailed ? -1 : g_max_index;
+}
+
+#ifdef VMX_EMU
+static inline bool vmx_rw_small_window() { const char* e = getenv("VMX_RW_WIN"); return e && atoi(e) == 3; }      // CPU-emulator test hook (read at every launch)
+#endif
+// ------------------------------------------------------------------------------------------------ G2 GC-exact, four reads per wave
+// rlist: the reads of the launch, most anchors first; workgroup (= wavefront) b takes the reads 4 b .. 4 b + 3. rmode: 0 modes H / L / S, 1 mode R.
+// dbg (optional): [0] anchors, [1] steps that left the window (scan or insertion through HBM)
+__global__ void __launch_bounds__(64) k_chain_global_rows(const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ aoff,
+                                                          const int32_t* __restrict__ rlist, int nlist, vmx_tables tab,
+                                                          const double* __restrict__ gapcost_list, double oskipcost, int omaxdiff,
+                                                          int maxgap, double* __restrict__ S_out, int32_t* __restrict__ P_out,
+                                                          int32_t* __restrict__ SA_out, uint8_t* __restrict__ cov_pool,
+                                                          int64_t* __restrict__ gmax_out, int64_t* __restrict__ opcount_out, int rmode,
+                                                          double* __restrict__ FP_pool, double* __restrict__ PP_pool, unsigned long long* __restrict__ dbg) {
+    VMX_SETPRIO(3);
+    __shared__ double s_gapcost[64];
+    const int lane = vmx_lane(), l16 = lane & 15;
+    for (int x = lane; x <= omaxdiff && x < 64; x += 64) s_gapcost[x] = gapcost_list[x];
+    __syncthreads();
+    const int slot = (int)blockIdx.x * 4 + (lane >> 4);
+    if (slot >= nlist) return;
+    const int rd = rlist[slot];
+    const int64_t a0 = aoff[rd];
+    const int n = (int)(aoff[rd + 1] - a0);
+    if (n <= 0) { if (l16 == 0) { gmax_out[rd] = -2; opcount_out[rd] = 0; } return; }
+    const vmx_anchor* A = anchors + a0;
+    uint8_t* COV = cov_pool + a0;
+    if (rmode == 0) {
+        // coverage (number of anchors sharing the read position, capped at 20: :24865-24868)
+        for (int i = l16; i < n; i += 16) {
+            const int q = A[i].q;
+            int cnt = 1;
+            for (int x = i - 1; x >= 0 && A[x].q == q && cnt < 20; --x) ++cnt;
+            for (int x = i + 1; x < n && A[x].q == q && cnt < 20; ++x) ++cnt;
+            COV[i] = (uint8_t)cnt;
+        }
+        vmx_row_sync();
+    }
+    vmx_rw_costs K; K.s_gapcost = s_gapcost; K.s_rgc = nullptr; K.skip = oskipcost; K.maxgap = maxgap; K.l2c_size = 0; K.log2cache = nullptr;
+    double best; long long opc; unsigned slow; int g;
+#ifdef VMX_EMU
+    if (vmx_rw_small_window()) {
+        if (rmode == 0) g = vmx_rw_chain<0, 3>(A, n, K, tab, oskipcost, omaxdiff, S_out + a0, P_out + a0, SA_out + a0, COV, nullptr, nullptr, best, opc, slow);
+        else g = vmx_rw_chain<1, 3>(A, n, K, tab, oskipcost, omaxdiff, S_out + a0, P_out + a0, SA_out + a0, nullptr, FP_pool + a0, PP_pool + a0, best, opc, slow);
+    } else
+#endif
+    if (rmode == 0) g = vmx_rw_chain<0, 16>(A, n, K, tab, oskipcost, omaxdiff, S_out + a0, P_out + a0, SA_out + a0, COV, nullptr, nullptr, best, opc, slow);
+    else g = vmx_rw_chain<1, 16>(A, n, K, tab, oskipcost, omaxdiff, S_out + a0, P_out + a0, SA_out + a0, nullptr, FP_pool + a0, PP_pool + a0, best, opc, slow);
+    if (l16 == 0) {
+        gmax_out[rd] = g; opcount_out[rd] = opc;
+        if (dbg) { atomicAdd(&dbg[0], (unsigned long long)n); atomicAdd(&dbg[1], (unsigned long long)slow); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ L3 / L4 / L5 local chain DP, four reads per wave
+// rlist: the reads of the launch, most local anchors first; workgroup b takes the reads 4 b .. 4 b + 3. A read runs LC-mm when its guide list held
+// more than one chain (n_guides_total > 1, :28583-28590), else LC-exact, `_scar` in mode R; `want` names the variant of this launch (0 / 1 / 2) and
+// a row whose read wants another one leaves at once — the variants are different code, and rows of one wave in different variants would run one
+// after the other. Traceback with overlap trimming (:27508-27526) by the row's first lane.
+__global__ void __launch_bounds__(64) k_chain_local_rows(const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ la_off,
+                                                         const int32_t* __restrict__ la_cnt, const int32_t* __restrict__ n_guides_total,
+                                                         const int32_t* __restrict__ rlist, int nlist, int want, vmx_tables tab,
+                                                         const double* __restrict__ gapcost_list, double skip_exact, double skip_mm, int maxdiff,
+                                                         int maxgap, int mode, double* __restrict__ S_pool, int32_t* __restrict__ P_pool,
+                                                         int32_t* __restrict__ SA_pool, double* __restrict__ out_score,
+                                                         vmx_anchor* __restrict__ out_chain, int32_t* __restrict__ out_len, int32_t* __restrict__ out_variant,
+                                                         int32_t* __restrict__ status, double* __restrict__ FP_pool, double* __restrict__ PP_pool,
+                                                         unsigned long long* __restrict__ dbg) {
+    VMX_SETPRIO(3);
+    __shared__ double s_gapcost[64];
+    __shared__ float s_rgc[128];
+    const int lane = vmx_lane(), l16 = lane & 15;
+    for (int x = lane; x <= maxdiff && x < 64; x += 64) s_gapcost[x] = gapcost_list[x];
+    {
+        const float* rgc_g = want == 1 ? tab.large_readgap : (mode == 3 ? tab.readgap_r : tab.readgap_h);
+        for (int x = lane; x < 100; x += 64) s_rgc[x] = rgc_g[x];          // read-gap cost table of this launch's variant (100 entries, maxgap <= 99)
+    }
+    __syncthreads();
+    const int slot = (int)blockIdx.x * 4 + (lane >> 4);
+    if (slot >= nlist) return;
+    const int rd = rlist[slot];
+    const int64_t a0 = la_off[rd];
+    const int n = la_cnt[rd];
+    const int var = mode == 3 ? 2 : (n_guides_total[rd] > 1 ? 1 : 0);
+    if (var != want) return;
+    if (n <= 0) { if (l16 == 0) { out_len[rd] = 0; out_score[rd] = 0; status[rd] = VM_READ_RAISED_DEV; } return; }   // np.array([]) indexing raises
+    const vmx_anchor* A = anchors + a0;
+    vmx_rw_costs K; K.s_gapcost = s_gapcost; K.s_rgc = s_rgc; K.skip = want == 1 ? skip_mm : skip_exact; K.maxgap = maxgap;
+    K.l2c_size = (long long)tab.log2cache_n - 1; K.log2cache = tab.log2cache;
+    double* S = S_pool + a0; int32_t* P = P_pool + a0; int32_t* SA = SA_pool + a0;
+    double best = 0.0; long long opc = 0; unsigned slow = 0; int g;
+#ifdef VMX_EMU
+    if (vmx_rw_small_window()) {
+        if (want == 0) g = vmx_rw_chain<2, 3>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, nullptr, nullptr, best, opc, slow);
+        else if (want == 1) g = vmx_rw_chain<3, 3>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, nullptr, nullptr, best, opc, slow);
+        else g = vmx_rw_chain<4, 3>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, FP_pool + a0, PP_pool + a0, best, opc, slow);
+    } else
+#endif
+    if (want == 0) g = vmx_rw_chain<2, 16>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, nullptr, nullptr, best, opc, slow);
+    else if (want == 1) g = vmx_rw_chain<3, 16>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, nullptr, nullptr, best, opc, slow);
+    else g = vmx_rw_chain<4, 16>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, FP_pool + a0, PP_pool + a0, best, opc, slow);
+    vmx_row_sync();                                   // (P, written through the loop without waiting, is read back by the traceback)
+    if (l16 == 0) {
+        if (g < 0) { out_len[rd] = 0; out_score[rd] = 0; status[rd] = VM_READ_FASTPATH_DEV; }
+        else {
+            vmx_anchor* O = out_chain + a0;
+            int w = 0; int take = g;
+            vmx_anchor pre = A[take];
+            O[w++] = pre;
+            while (P[take] != VMX_NOPRE) {
+                take = P[take];
+                const vmx_anchor now = A[take];
+                if (pre.q < now.q + ((int)now.l & 0xffff)) {
+                    const int ov = now.q + ((int)now.l & 0xffff) - pre.q;
+                    vmx_anchor t = pre; t.q = pre.q + ov; t.l = (int16_t)(((int)pre.l & 0xffff) - ov); if (pre.s == 1) t.r = pre.r + ov;
+                    O[w - 1] = t;
+                }
+                O[w++] = now;
+                pre = now;
+            }
+            out_len[rd] = w; out_score[rd] = best; status[rd] = 0;
+        }
+        out_variant[rd] = want;
+        if (dbg) { atomicAdd(&dbg[0], (unsigned long long)n); atomicAdd(&dbg[1], (unsigned long long)slow); }
+    }
+}

@@ -257,12 +257,14 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     std::vector<int64_t> asm_long;
     static const int gc_lds_env = [] { const char* e = getenv("VMX_GC_LDS_MAX"); return e ? atoi(e) : -1; }();     // see vmx_stage_local.hip
     const int gc_lds_max = gc_lds_env >= 0 ? gc_lds_env : VMX_CHAIN_LDS_MAX_SHARED;
+    const bool rows_kernel = vmx_chain_rows_on() && rmode != 2;          // four reads per wavefront (k_chain_rows.hip); -mode asm keeps the one-wave kernel
     for (int64_t r = 0; r < n; ++r) {
         int64_t m = h_aoff[r + 1] - h_aoff[r]; const int64_t L = h_roff[r + 1] - h_roff[r];
         if (m <= 2) continue;                                             // :23986 unmapped
         if (prm->mode == VM_MODE_ASM && L >= 500000) { asm_long.push_back(r); continue; }      // mammap_asm.py:23205: the linked path, not built on the device
         if ((double)m / (double)L > 5.0) continue;                        // fast_enable (:23570): gmax stays -1 -> k_chain_global_fast below
         int bk = NB; for (int q = 0; q < NB; ++q) if (m <= caps[q] && caps[q] <= gc_lds_max) { bk = q; break; }
+        if (rows_kernel) bk = NB;                                         // k_chain_global_rows: one list, nothing in LDS
         lists[bk].push_back((int32_t)r);
     }
     {
@@ -281,6 +283,13 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
         for (int q = NB; q >= 0; --q) {                               // slowest (largest reads) first
             int cnt = (int)lists[q].size(); if (!cnt) continue;
             int cap = q < NB ? caps[q] : 0; size_t shmem = (size_t)cap * VMX_GC_BYTES_PER_ANCHOR + 64;
+            if (rows_kernel) {
+                hipLaunchKernelGGL(k_chain_global_rows, dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, fk.next(), B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(),
+                                   B.rl.as<int32_t>() + rl_off[q], cnt, c->tables, B.gap.as<double>(), prm->global_skipcost, prm->global_maxdiff, 1000, B.S.as<double>(),
+                                   B.P.as<int32_t>(), B.SA.as<int32_t>(), B.cov.as<uint8_t>(), B.gmax.as<int64_t>(), B.opc.as<int64_t>(), rmode, B.fp.as<double>(), B.pp.as<double>(),
+                                   (unsigned long long*)nullptr);
+                continue;
+            }
             hipLaunchKernelGGL(k_chain_global, dim3((unsigned)cnt), dim3(64), shmem, fk.next(), B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(),
                                B.rl.as<int32_t>() + rl_off[q], cnt, cap, c->tables, B.gap.as<double>(), prm->global_skipcost, prm->global_maxdiff, 1000, B.S.as<double>(),
                                B.P.as<int32_t>(), B.SA.as<int32_t>(), B.cov.as<uint8_t>(), B.gmax.as<int64_t>(), B.opc.as<int64_t>(), rmode, B.fp.as<double>(), B.pp.as<double>());

@@ -458,6 +458,17 @@ int vm_chain_global_batch(vm_ctx* c, const vm_params* prm, int kmersize, int64_t
     rl_off[5] = (int64_t)rl.size();
     VMX_TRY(upload(d_rl, rl.data(), rl.size(), c->stream));
     VMX_HIP(hipMemsetAsync(d_gmax.p, 0xff, sizeof(int64_t) * (size_t)n, c->stream));   // -1 = needs GC-fast
+    if (vmx_chain_rows_on() && rmode != 2 && !rl.empty()) {            // four reads per wavefront (k_chain_rows.hip), most anchors first
+        std::vector<int32_t> all(rl);
+        std::stable_sort(all.begin(), all.end(), [&](int32_t a, int32_t b) { return aoff[a + 1] - aoff[a] > aoff[b + 1] - aoff[b]; });
+        VMX_TRY(upload(d_rl, all.data(), all.size(), c->stream));
+        const int cnt = (int)all.size();
+        hipLaunchKernelGGL(k_chain_global_rows, dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, c->stream, d_sorted.as<vmx_anchor>(), d_aoff.as<int64_t>(),
+                           d_rl.as<int32_t>(), cnt, c->tables, d_gap.as<double>(), prm->global_skipcost, prm->global_maxdiff,
+                           1000, d_S.as<double>(), d_P.as<int32_t>(), d_SA.as<int32_t>(), d_cov.as<uint8_t>(), d_gmax.as<int64_t>(), d_opc.as<int64_t>(), rmode,
+                           c->b[25].as<double>(), c->b[26].as<double>(), (unsigned long long*)nullptr);
+        for (auto& l : lists) l.clear();
+    }
     for (int k = 0; k < 5; ++k) {
         int cnt = (int)lists[k].size();
         if (!cnt) continue;

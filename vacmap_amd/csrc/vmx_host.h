@@ -196,6 +196,11 @@ __global__ void k_chain_global(const vmx_anchor* anchors, const int64_t* aoff, c
                                vmx_tables tab, const double* gapcost_list, double oskipcost, int omaxdiff, int maxgap,
                                double* S_out, int32_t* P_out, int32_t* SA_out, uint8_t* cov_pool, int64_t* gmax_out, int64_t* opcount_out, int rmode,
                                double* FP_pool, double* PP_pool);
+// k_chain_rows.hip: four reads per wavefront (one per 16-lane row); VMX_CHAIN_ROWS=0 keeps the one-wavefront-per-read kernels for A/B
+__global__ void k_chain_global_rows(const vmx_anchor* anchors, const int64_t* aoff, const int32_t* rlist, int nlist, vmx_tables tab, const double* gapcost_list,
+                                    double oskipcost, int omaxdiff, int maxgap, double* S_out, int32_t* P_out, int32_t* SA_out, uint8_t* cov_pool,
+                                    int64_t* gmax_out, int64_t* opcount_out, int rmode, double* FP_pool, double* PP_pool, unsigned long long* dbg);
+static inline bool vmx_chain_rows_on() { static const bool on = [] { const char* e = getenv("VMX_CHAIN_ROWS"); return !e || atoi(e) != 0; }(); return on; }
 __global__ void k_chain_global_fast(const vmx_anchor* anchors, const int64_t* aoff, int n_reads, const int64_t* roff, vmx_tables tab,
                                     const double* gapcost_list, double oskipcost, int omaxdiff, int maxgap, double* S_out, int32_t* P_out, int32_t* SA_out,
                                     uint8_t* cov_pool, int32_t* si_pool, int64_t* t_pool, int32_t* cnt_pool, int64_t* gmax_out, int32_t* ran, int rmode,

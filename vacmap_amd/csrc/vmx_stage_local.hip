@@ -18,6 +18,10 @@ __global__ void k_chain_local_fast(const vmx_anchor* anchors, const int64_t* la_
                                    const int64_t* roff, vmx_tables tab, const double* gapcost_list, double skip_exact, double skip_mm, int maxdiff, int maxgap,
                                    int mode, double* S_pool, int32_t* P_pool, int32_t* SA_pool, int32_t* si_pool, int64_t* t_pool, int32_t* cnt_pool,
                                    double* out_score, vmx_anchor* out_chain, int32_t* out_len, int32_t* out_variant, int32_t* status);
+__global__ void k_chain_local_rows(const vmx_anchor* anchors, const int64_t* la_off, const int32_t* la_cnt, const int32_t* n_guides_total, const int32_t* rlist, int nlist,
+                                   int want, vmx_tables tab, const double* gapcost_list, double skip_exact, double skip_mm, int maxdiff, int maxgap, int mode, double* S_pool,
+                                   int32_t* P_pool, int32_t* SA_pool, double* out_score, vmx_anchor* out_chain, int32_t* out_len, int32_t* out_variant, int32_t* status,
+                                   double* FP_pool, double* PP_pool, unsigned long long* dbg);
 __global__ void k_chain_local(const vmx_anchor* anchors, const int64_t* la_off, const int32_t* la_cnt, const int32_t* n_guides_total,
                               const int32_t* rlist, int nlist, int lds_cap, vmx_tables tab, const double* gapcost_list, double skip_exact,
                               double skip_mm, int maxdiff, int maxgap, int mode, double* S_pool, int32_t* P_pool, int32_t* SA_pool, double* out_score,
@@ -219,10 +223,12 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     // 46.3 / 46.1 / 44.9 / 43.9 / 44.0 / 43.4 — LDS residency pays for a context that runs alone, not when batches share the GPU.
     static const int lds_env = [] { const char* e = getenv("VMX_LC_LDS_MAX"); return e ? atoi(e) : -1; }();
     const int lds_max = lds_env >= 0 ? lds_env : VMX_CHAIN_LDS_MAX_SHARED;
+    const bool rows_kernel = vmx_chain_rows_on() && prm->mode != VM_MODE_ASM;      // four reads per wavefront (k_chain_rows.hip); -mode asm keeps the one-wave kernel
     for (int64_t r = 0; r < n; ++r) {
         int m = L.h_la_cnt[r];
         if (m <= 0) continue;   // no guide / capacity failure: nothing to chain (status already set by the seeding kernel or stays 0 for unmapped reads)
         int bk = NB; for (int q = 0; q < NB; ++q) if (m <= caps[q] && caps[q] <= lds_max) { bk = q; break; }
+        if (rows_kernel) bk = NB;                                         // k_chain_local_rows: one list, nothing in LDS
         lists[bk].push_back((int32_t)r);
     }
     std::vector<int32_t> rl; int64_t rl_off[NB + 2];
@@ -250,6 +256,16 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         if (!cnt) continue;
         int cap = q < NB ? caps[q] : 0;
         size_t shmem = (size_t)cap * VMX_LC_BYTES_PER_ANCHOR + 64;
+        if (rows_kernel) {
+            // one launch per variant (different code; a row whose read wants the other variant leaves at once): LC-exact and LC-mm, or `_scar` alone in mode R
+            for (int want = (prm->mode == VM_MODE_R ? 2 : 0); want <= (prm->mode == VM_MODE_R ? 2 : 1); ++want)
+                hipLaunchKernelGGL(k_chain_local_rows, dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, fk.next(), L.la_sorted.as<vmx_anchor>(),
+                                   L.la_off.as<int64_t>(), L.la_cnt.as<int32_t>(), L.ng_total.as<int32_t>(), L.rlist.as<int32_t>() + rl_off[q], cnt, want, c->tables,
+                                   L.gap.as<double>(), skip_exact, skip_mm, prm->local_maxdiff, maxgap, prm->mode, L.S.as<double>(), L.P.as<int32_t>(), L.SA.as<int32_t>(),
+                                   L.score.as<double>(), L.chain.as<vmx_anchor>(), L.chain_len.as<int32_t>(), L.variant.as<int32_t>(), L.status.as<int32_t>(),
+                                   L.fp.as<double>(), L.pp.as<double>(), (unsigned long long*)nullptr);
+            continue;
+        }
         hipLaunchKernelGGL(k_chain_local, dim3((unsigned)cnt), dim3(64), shmem, fk.next(), L.la_sorted.as<vmx_anchor>(),
                            L.la_off.as<int64_t>(), L.la_cnt.as<int32_t>(), L.ng_total.as<int32_t>(), L.rlist.as<int32_t>() + rl_off[q], cnt, cap, c->tables,
                            L.gap.as<double>(), skip_exact, skip_mm, prm->local_maxdiff, maxgap, prm->mode, L.S.as<double>(), L.P.as<int32_t>(), L.SA.as<int32_t>(),
