@@ -50,11 +50,11 @@ __device__ __forceinline__ void vmx_rw_geometry(const vmx_rcur& c, int qj, int l
     readgap = rg - m;
     bonus = c.l + m;
     const long long d = c.r - rj;
-    const bool same = c.sneg == snegj;
-    int cc; long long t;
-    if (!c.sneg) { cc = (same ? -lj : 1) - m; t = d; }
-    else { cc = same ? -c.l - m : c.l - lj + m - 1; t = same ? -d : d; }
-    refgap = t + (long long)cc;
+    const bool same = c.sneg == snegj, neg = c.sneg != 0;
+    // (selects: the strand is the same in the 16 lanes of a row, but the four rows of the wave differ, and a branch would be an exec-mask region)
+    const int cpos = (same ? -lj : 1) - m, cneg = same ? -c.l - m : c.l - lj + m - 1;
+    const long long t = (neg && same) ? -d : d;
+    refgap = t + (long long)(neg ? cneg : cpos);
 }
 
 // KIND: 0 GC modes H / L / S, 1 GC mode R, 2 LC-exact, 3 LC-mm, 4 `_scar`
@@ -67,89 +67,100 @@ struct vmx_rw_costs {
     const double* s_gapcost; const float* s_rgc; double skip; int maxgap; long long l2c_size; const double* log2cache;
 };
 
-// score of the step candidate -> anchor (test_scores), and for the penalty variants what the anchor inherits if that candidate wins
+// extra[min(g, extra_n - 1)] (vmx_extra_cost, vmx_kernels.h) for a gap already cut to 32 bits, without a branch on the common forms: the linear
+// prefix of :15371-15376 in closed form, the table's last value 36 at and beyond its end; only the logarithmic stretch in between (gaps of 25 kb to
+// 163 kb: a step across an SV) is loaded, behind a branch no lane takes as a rule.
+__device__ __forceinline__ double vmx_rw_extra(const vmx_tables& tab, int g) {
+    const double dg = (double)g;
+    const double a = dg * 0.01;
+    double ex = (double)(float)((a < 10.0 ? a : 10.0) + dg * 0.001);
+    ex = g >= tab.extra_n - 1 ? 36.0 : ex;
+    if (g >= tab.extra_arith_n && g < tab.extra_n - 1) ex = (double)tab.extra[g];
+    return ex;
+}
+
+// score of the step candidate -> anchor (test_scores), and for the penalty variants what the anchor inherits if that candidate wins.
+// Evaluated by every lane, entry or not (the caller drops what does not count): selects, no exec-mask regions.
 template <int KIND>
 __device__ __forceinline__ double vmx_rw_test(const vmx_rcur& c, const vmx_rw_costs& K, const vmx_tables& tab, const vmx_rwin& w, double& nfp, double& npp) {
     const int lj = w.ls & 0xffff, snegj = (w.ls >> 16) & 1;
     int readgap, bonus; long long refgap;
     vmx_rw_geometry(c, w.q, lj, snegj, w.r, readgap, refgap, bonus);
-    long long gapcost = (long long)readgap - refgap; if (gapcost < 0) gapcost = -gapcost;
-    const bool col = c.sneg == snegj && refgap >= 0 && readgap <= K.maxgap && gapcost <= (long long)c.maxdiff;
+    long long gap64 = (long long)readgap - refgap; if (gap64 < 0) gap64 = -gap64;
+    const int gapcost = gap64 > 0x40000000LL ? 0x40000000 : (int)gap64;      // every use saturates far below 2^30 (maxdiff <= 62, the tables' ends)
+    const bool col = c.sneg == snegj && refgap >= 0 && readgap <= K.maxgap && gapcost <= c.maxdiff;
     const double Sj = w.S, db = (double)bonus;
     nfp = 0.0; npp = 0.0;
     if constexpr (KIND == 0) {
-        // both forms are computed and one is selected (k_chain.hip): no exec-mask region per kind of step
-        const double tc = Sj + db - K.s_gapcost[col ? (int)gapcost : 0];
-        const double tn = Sj - c.skipcost + db - vmx_extra_cost(tab, col ? 0x7fffffffffffffffLL : gapcost);
+        // both forms are computed and one is selected (k_chain.hip)
+        const double tc = Sj + db - K.s_gapcost[col ? gapcost : 0];
+        const double tn = Sj - c.skipcost + db - vmx_rw_extra(tab, col ? 0x40000000 : gapcost);
         return col ? tc : tn;
     } else if constexpr (KIND == 1) {
-        double test;
-        if (col) {
-            test = Sj + db - K.s_gapcost[(int)gapcost];
-            if (w.fp < 0 && (w.fp + db) >= 0) test += w.pp;
-            if (w.fp < 0 && (w.fp + db) < 0) { nfp = w.fp + db; npp = w.pp; }
-        } else {
-            test = Sj + db - c.skipcost;
-            nfp = -c.skipcost + db; npp = c.skipcost;
-        }
-        return test;
+        double tc = Sj + db - K.s_gapcost[col ? gapcost : 0];
+        const double f2 = w.fp + db;
+        const bool owes = w.fp < 0;
+        tc = (owes && f2 >= 0) ? tc + w.pp : tc;                                // refund (mammap_noprefercloser.py:22983-22985)
+        const double tn = Sj + db - c.skipcost;
+        nfp = col ? ((owes && f2 < 0) ? f2 : 0.0) : -c.skipcost + db;
+        npp = col ? ((owes && f2 < 0) ? w.pp : 0.0) : c.skipcost;
+        return col ? tc : tn;
     } else if constexpr (KIND == 2 || KIND == 3) {
-        if (bonus <= 0) return -1e300;                    // only an overlap brings the bonus to zero or below (:27425): evaluated to nothing, still counted
-        const double tc = Sj + db - K.s_gapcost[col ? (int)gapcost : 0] - (double)K.s_rgc[col ? readgap : 0];
+        const double tc = Sj + db - K.s_gapcost[col ? gapcost : 0] - (double)K.s_rgc[col ? readgap : 0];
         double tn;
         if constexpr (KIND == 2) {
-            const double ex = vmx_extra_cost(tab, col ? 0x7fffffffffffffffLL : gapcost);
+            const double ex = vmx_rw_extra(tab, col ? 0x40000000 : gapcost);
             const double pen = (c.sneg != snegj ? (K.skip < 50.0 ? K.skip : 50.0) : K.skip) + ex;
             tn = Sj + db - pen;
         } else {
-            const long long gx = col ? 0 : gapcost;
+            const long long gx = col ? 0 : (long long)gapcost;
             const double pen = K.skip + K.log2cache[gx < K.l2c_size ? gx : K.l2c_size];
             tn = Sj + db - pen;
         }
-        return col ? tc : tn;
+        const double t = col ? tc : tn;
+        return bonus <= 0 ? -1e300 : t;                    // only an overlap brings the bonus to zero or below (:27425): evaluated to nothing, still counted
     } else {
-        if (bonus <= 0) return -1e300;
-        double test;
-        if (col) {
-            test = Sj + db - K.s_gapcost[(int)gapcost] - (double)K.s_rgc[readgap];
-            if (w.fp < 0 && (w.fp + db) >= 0) test += w.pp;                      // refund (:23557-23559)
-            if (w.fp < 0 && (w.fp + db) < 0) { nfp = w.fp + db; npp = w.pp; }
-        } else {
-            test = Sj + db - K.skip;                                                // :23577-23578
-            nfp = -K.skip + db; npp = K.skip;
-        }
-        return test;
+        double tc = Sj + db - K.s_gapcost[col ? gapcost : 0] - (double)K.s_rgc[col ? readgap : 0];
+        const double f2 = w.fp + db;
+        const bool owes = w.fp < 0;
+        tc = (owes && f2 >= 0) ? tc + w.pp : tc;                                // refund (:23557-23559)
+        const double tn = Sj + db - K.skip;                                     // :23577-23578
+        nfp = col ? ((owes && f2 < 0) ? f2 : 0.0) : -K.skip + db;
+        npp = col ? ((owes && f2 < 0) ? w.pp : 0.0) : K.skip;
+        return bonus <= 0 ? -1e300 : (col ? tc : tn);
     }
 }
 
-// One block of 16 candidates in scan order (lane 0 first). `end`: no entry in this lane (the index ends here); `vis`: an entry the scan may
-// look at. Carries the sequential loop's state: max_scores / pre_index (/ the penalties the anchor inherits), opcount. Returns the lane of
-// the first candidate that ends the loop (16: none).
+// One block of 16 candidates in scan order (lane 0 first). A lane without an entry (w.j = VMX_RW_NONE) ends the index; an entry with j >= te
+// is passed over. Carries the sequential loop's state: max_scores / pre_index (/ the penalties the anchor inherits), opcount. Returns the lane
+// of the first candidate that ends the loop (16: none).
 template <int KIND>
-__device__ __forceinline__ int vmx_rw_scan16(const vmx_rcur& c, const vmx_rw_costs& K, const vmx_tables& tab, const vmx_rwin& w, bool end, bool vis,
-                                             double& max_scores, int& pre_index, double& fp_i, double& pp_i, long long& opcount) {
+__device__ __forceinline__ int vmx_rw_scan16(const vmx_rcur& c, const vmx_rw_costs& K, const vmx_tables& tab, const vmx_rwin& w,
+                                             double& max_scores, int& pre_index, double& fp_i, double& pp_i, int& opcount) {
     constexpr bool gc = vmx_rw_traits<KIND>::gc;
-    double nfp = 0.0, npp = 0.0;
-    double test = VMX_F64_NEG;
-    if (vis) test = vmx_rw_test<KIND>(c, K, tab, w, nfp, npp);
-    const double incl = vmx_row_incl_max_f64(test);                           // prefix max of the candidates' scores, in scan order
-    double m_before = vmx_row_shr_f64<1>(VMX_F64_NEG, incl);                  // lane 0: nothing before it
-    m_before = m_before > max_scores ? m_before : max_scores;                 // the running max the sequential loop holds at this candidate
+    double nfp, npp;
+    const double tv = vmx_rw_test<KIND>(c, K, tab, w, nfp, npp);
+    const bool vis = w.j < c.te;                                              // (VMX_RW_NONE is above every te)
+    const double test = vis ? tv : VMX_F64_NEG;
+    const double incl = vmx_row_incl_max0_f64(test);                          // prefix max of the candidates' scores, in scan order (of max(score, 0): max_scores > 0)
+    const double m_before = vmx_max_f64(vmx_row_shr0_f64<1>(incl), max_scores);      // the running max the sequential loop holds at this candidate
     const double lim = m_before - c.dl;
-    const bool brk_real = vis && (gc ? !(w.S > lim) : (w.S < lim));           // GC :24940 breaks on S[j] <= max - l_i, LC :27415 on S[j] < max - l_i
-    const unsigned bm = vmx_row_ballot(brk_real || end), rm = vmx_row_ballot(brk_real), vm = vmx_row_ballot(vis);
-    const unsigned im = vmx_row_ballot(vis && test > m_before);               // strict >: the candidates at which the sequential loop updates
+    // GC :24940 breaks on S[j] <= max - l_i, LC :27415 on S[j] < max - l_i
+    const vmx_rmask vmk = vmx_mask(vis), emk = vmx_mask(w.j == VMX_RW_NONE), cmk = gc ? vmx_mask(!(w.S > lim)) : vmx_mask(w.S < lim);
+    const unsigned bm = vmx_row_bits((vmk & cmk) | emk), vm = vmx_row_bits(vmk);
+    const unsigned im = vmx_row_bits(vmx_mask(test > m_before));              // strict >: the candidates at which the sequential loop updates (an entry out of sight holds -inf)
     const int first = __ffs(bm | 0x10000u) - 1;
     const unsigned below = (1u << first) - 1u;
-    // opcount: GC counts the candidates that pass the test, LC counts before the test, i.e. the breaking candidate too (:27410-27415)
-    opcount += __popc(vm & below) + ((!gc && ((rm >> first) & 1u)) ? 1 : 0);
+    // opcount: GC counts the candidates that pass the test, LC counts before the test, i.e. the breaking candidate too (:27410-27415) — the
+    // lane that stopped the scan, when it is an entry in sight and not the end of the index
+    opcount += __popc(vm & below);
+    if constexpr (!gc) opcount += (int)((vm >> first) & 1u);
     const unsigned upd = im & below;
-    if (upd) {
-        const int wl = 31 - __clz((int)upd);                                  // the last update wins
-        max_scores = vmx_row_get_f64(test, wl);
-        pre_index = vmx_row_get_i32(w.j, wl);
-        if constexpr (vmx_rw_traits<KIND>::pen) { fp_i = vmx_row_get_f64(nfp, wl); pp_i = vmx_row_get_f64(npp, wl); }
-    }
+    // the last update wins; fetched whether there is one or not (lane 0 then, dropped): three or seven ds_bpermute instead of a branch
+    const int wl = upd ? 31 - __clz((int)upd) : 0;
+    const double gM = vmx_row_get_f64(test, wl); const int gj = vmx_row_get_i32(w.j, wl);
+    max_scores = upd ? gM : max_scores; pre_index = upd ? gj : pre_index;
+    if constexpr (vmx_rw_traits<KIND>::pen) { const double gf = vmx_row_get_f64(nfp, wl), gp = vmx_row_get_f64(npp, wl); fp_i = upd ? gf : fp_i; pp_i = upd ? gp : pp_i; }
     return first;
 }
 
@@ -209,7 +220,7 @@ __device__ __forceinline__ void vmx_rw_load_entry(vmx_rwin& w, int j, const vmx_
 template <int KIND, int WW>
 __device__ __forceinline__ int vmx_rw_chain(const vmx_anchor* __restrict__ A, int n, const vmx_rw_costs& K, const vmx_tables& tab, double oskipcost, int omaxdiff,
                                             double* __restrict__ S, int32_t* __restrict__ P, int32_t* __restrict__ SA, const uint8_t* __restrict__ COV,
-                                            double* __restrict__ FP, double* __restrict__ PP, double& best_score, long long& opcount_out, unsigned& slow_out) {
+                                            double* __restrict__ FP, double* __restrict__ PP, double& best_score, long long& opcount_out, unsigned long long& slow_out) {
     constexpr bool gc = vmx_rw_traits<KIND>::gc;
     constexpr bool pen = vmx_rw_traits<KIND>::pen;
     constexpr bool cov = KIND == 0;
@@ -228,8 +239,8 @@ __device__ __forceinline__ int vmx_rw_chain(const vmx_anchor* __restrict__ A, in
     if (cov) { c.maxdiff = omaxdiff - (ls0 >> 17); if (c.maxdiff < 10) c.maxdiff = 10; }
     int prereadloc = gc ? q0 : q0 + l0;
     double g_max_scores = (double)l0; int g_max_index = 0;
-    long long opcount = 0;
-    unsigned slow = 0;
+    int opcount = 0;                     // (bounded by the bail-out rules below: 1000 per anchor)
+    unsigned long long slow = 0;          // tuning counters: scans that left the window (low word), insertions through HBM (high word)
     bool bailed = false;
     // anchor 1, fetched a step ahead
     int nq = vmx_row_get_i32(bq, 1), nls = vmx_row_get_i32(bls, 1); long long nr = vmx_row_get_i64(br, 1);
@@ -246,18 +257,16 @@ __device__ __forceinline__ int vmx_rw_chain(const vmx_anchor* __restrict__ A, in
             nq = vmx_row_get_i32(bq, x & 15); nls = vmx_row_get_i32(bls, x & 15); nr = vmx_row_get_i64(br, x & 15);
         }
         const int key = gc ? c.q : c.q + c.l;
-        if (prereadloc < key) {
-            // (opcount / i > 1000 in doubles <=> opcount > 1000 i for these magnitudes: the quotient of two integers below 2^53 that exceeds
-            // 1000 does so by at least 1 / i, far above the spacing of doubles at 1000)
-            if (gc) { if (opcount > 1000LL * (long long)i) { bailed = true; break; } }                                  // :24914 max_factor
-            else if (KIND != 4) { if (opcount > 100000 && opcount > 1000LL * (long long)prereadloc) { bailed = true; break; } }      // :27380 -> *_fast
-            c.te = i;
-            if (cov) { c.skipcost = oskipcost + (double)covi; c.maxdiff = omaxdiff - covi; if (c.maxdiff < 10) c.maxdiff = 10; }
-            prereadloc = key;
-        }
+        const bool adv = prereadloc < key;
+        // (opcount / i > 1000 in doubles <=> opcount > 1000 i for these magnitudes: the quotient of two integers below 2^53 that exceeds
+        // 1000 does so by at least 1 / i, far above the spacing of doubles at 1000)
+        if (gc) { if (adv && (unsigned)opcount > 1000u * (unsigned)i) { bailed = true; break; } }                                  // :24914 max_factor
+        else if (KIND != 4) { if (adv && opcount > 100000 && (long long)opcount > 1000LL * (long long)prereadloc) { bailed = true; break; } }      // :27380 -> *_fast
+        c.te = adv ? i : c.te;
+        if (cov) { int md = omaxdiff - covi; md = md < 10 ? 10 : md; c.skipcost = adv ? oskipcost + (double)covi : c.skipcost; c.maxdiff = adv ? md : c.maxdiff; }
+        prereadloc = adv ? key : prereadloc;
         double max_scores = c.dl; int pre_index = VMX_NOPRE; double fp_i = 0.0, pp_i = 0.0;
-        const bool wend = win.j == VMX_RW_NONE;
-        int first = vmx_rw_scan16<KIND>(c, K, tab, win, wend, !wend && win.j < c.te, max_scores, pre_index, fp_i, pp_i, opcount);
+        int first = vmx_rw_scan16<KIND>(c, K, tab, win, max_scores, pre_index, fp_i, pp_i, opcount);
         if (first >= WW && i > WW) {
             // the scan passed the whole window: on through the index in HBM, 16 candidates per step
             ++slow;
@@ -266,31 +275,40 @@ __device__ __forceinline__ int vmx_rw_chain(const vmx_anchor* __restrict__ A, in
                 const int x = base - l16;
                 vmx_rwin w; w.j = VMX_RW_NONE; w.q = 0; w.ls = 0; w.S = 0.0; w.r = 0; w.fp = 0.0; w.pp = 0.0;
                 if (x >= 0) vmx_rw_load_entry(w, SA[x], A, S, FP, PP, pen);
-                first = vmx_rw_scan16<KIND>(c, K, tab, w, x < 0, x >= 0 && w.j < c.te, max_scores, pre_index, fp_i, pp_i, opcount);
+                first = vmx_rw_scan16<KIND>(c, K, tab, w, max_scores, pre_index, fp_i, pp_i, opcount);
                 if (first < 16) break;
             }
         }
         if (l16 == 0) { S[i] = max_scores; P[i] = pre_index; if (pen) { FP[i] = fp_i; PP[i] = pp_i; } }
-        if (max_scores > g_max_scores) { g_max_scores = max_scores; g_max_index = i; }
+        { const bool up = max_scores > g_max_scores; g_max_scores = up ? max_scores : g_max_scores; g_max_index = up ? i : g_max_index; }
         // the new entry's place: k = i entries so far, the window holds the top min(k, 16)
-        const unsigned gt = vmx_row_ballot(win.S > max_scores), ge = vmx_row_ballot(win.S >= max_scores);
-        const int above = __popc(gt), cge = __popc(ge);
+        const unsigned gt = vmx_row_ballot(win.S > max_scores);
+        const int above = __popc(gt);
         const int W = i < WW ? i : WW;
-        int at = -1;
-        if (!gc || gt == ge) { if (above < WW && (above < W || W == i)) at = above; }      // LC: above its equals (smallorequal + 1, :13229-13265)
-        else if (cge < W || W == i) { at = i - vmx_rw_bisect_replay(i - cge, i - above, i); if (at >= WW) at = -1; }      // the run of equal scores ends inside the window
+        int at = (above < WW && (above < W || W == i)) ? above : -1;             // LC: above its equals (smallorequal + 1, :13229-13265)
+        if constexpr (gc) {
+            const unsigned ge = vmx_row_ballot(win.S >= max_scores);
+            if (gt != ge) {                                                      // equal scores in the window: where the reference's bisection puts the new one
+                const int cge = __popc(ge);
+                at = -1;
+                if (cge < W || W == i) { at = i - vmx_rw_bisect_replay(i - cge, i - above, i); if (at >= WW) at = -1; }      // the run of equal scores ends inside the window
+            }
+        }
         if (at >= 0) {
             const int sj = vmx_row_shr_i32<1>(win.j, win.j), sq = vmx_row_shr_i32<1>(win.q, win.q), sls = vmx_row_shr_i32<1>(win.ls, win.ls);
             const double sS = vmx_row_shr_f64<1>(win.S, win.S); const long long sr = vmx_row_shr_i64<1>(win.r, win.r);
-            double sfp = 0.0, spp = 0.0;
-            if constexpr (pen) { sfp = vmx_row_shr_f64<1>(win.fp, win.fp); spp = vmx_row_shr_f64<1>(win.pp, win.pp); }
-            if (l16 > at) { win.j = sj; win.q = sq; win.ls = sls; win.S = sS; win.r = sr; if constexpr (pen) { win.fp = sfp; win.pp = spp; } }
-            else if (l16 == at) { win.j = i; win.q = c.q; win.ls = c.l | (c.sneg << 16); win.S = max_scores; win.r = c.r; if constexpr (pen) { win.fp = fp_i; win.pp = pp_i; } }
+            const bool sh = l16 > at, here = l16 == at;
+            win.j = sh ? sj : (here ? i : win.j); win.q = sh ? sq : (here ? c.q : win.q); win.ls = sh ? sls : (here ? (c.l | (c.sneg << 16)) : win.ls);
+            win.S = sh ? sS : (here ? max_scores : win.S); win.r = sh ? sr : (here ? c.r : win.r);
+            if constexpr (pen) {
+                const double sfp = vmx_row_shr_f64<1>(win.fp, win.fp), spp = vmx_row_shr_f64<1>(win.pp, win.pp);
+                win.fp = sh ? sfp : (here ? fp_i : win.fp); win.pp = sh ? spp : (here ? pp_i : win.pp);
+            }
             if (WW < 16 && l16 >= WW) { win.j = VMX_RW_NONE; win.S = VMX_F64_NEG; }
             if (l16 <= at) SA[i - l16] = win.j;
         } else {
             // below the window, or among equal scores that reach below it: search and shift in HBM, then the window again from the index
-            ++slow;
+            slow += 1ULL << 32;
             vmx_row_sync();
             int loc;
             if (gc) {
@@ -308,7 +326,7 @@ __device__ __forceinline__ int vmx_rw_chain(const vmx_anchor* __restrict__ A, in
         }
     }
     // (the reference's closing insertions :25018-25027 have all happened)
-    best_score = g_max_scores; opcount_out = opcount; slow_out = slow;
+    best_score = g_max_scores; opcount_out = (long long)opcount; slow_out = slow;
     return bailed ? -1 : g_max_index;
 }
 
@@ -317,7 +335,7 @@ static inline bool vmx_rw_small_window() { const char* e = getenv("VMX_RW_WIN");
 #endif
 // ------------------------------------------------------------------------------------------------ G2 GC-exact, four reads per wave
 // rlist: the reads of the launch, most anchors first; workgroup (= wavefront) b takes the reads 4 b .. 4 b + 3. rmode: 0 modes H / L / S, 1 mode R.
-// dbg (optional): [0] anchors, [1] steps that left the window (scan or insertion through HBM)
+// dbg (optional, VMX_DBG_CHAIN=1): [0] anchors, [1] scans that left the window, [2] insertions through HBM, [3] opcount; [4..7] the same of k_chain_local_rows
 __global__ void __launch_bounds__(64) k_chain_global_rows(const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ aoff,
                                                           const int32_t* __restrict__ rlist, int nlist, vmx_tables tab,
                                                           const double* __restrict__ gapcost_list, double oskipcost, int omaxdiff,
@@ -350,7 +368,7 @@ __global__ void __launch_bounds__(64) k_chain_global_rows(const vmx_anchor* __re
         vmx_row_sync();
     }
     vmx_rw_costs K; K.s_gapcost = s_gapcost; K.s_rgc = nullptr; K.skip = oskipcost; K.maxgap = maxgap; K.l2c_size = 0; K.log2cache = nullptr;
-    double best; long long opc; unsigned slow; int g;
+    double best; long long opc; unsigned long long slow; int g;
 #ifdef VMX_EMU
     if (vmx_rw_small_window()) {
         if (rmode == 0) g = vmx_rw_chain<0, 3>(A, n, K, tab, oskipcost, omaxdiff, S_out + a0, P_out + a0, SA_out + a0, COV, nullptr, nullptr, best, opc, slow);
@@ -361,7 +379,7 @@ __global__ void __launch_bounds__(64) k_chain_global_rows(const vmx_anchor* __re
     else g = vmx_rw_chain<1, 16>(A, n, K, tab, oskipcost, omaxdiff, S_out + a0, P_out + a0, SA_out + a0, nullptr, FP_pool + a0, PP_pool + a0, best, opc, slow);
     if (l16 == 0) {
         gmax_out[rd] = g; opcount_out[rd] = opc;
-        if (dbg) { atomicAdd(&dbg[0], (unsigned long long)n); atomicAdd(&dbg[1], (unsigned long long)slow); }
+        if (dbg) { atomicAdd(&dbg[0], (unsigned long long)n); atomicAdd(&dbg[1], slow & 0xffffffffULL); atomicAdd(&dbg[2], slow >> 32); atomicAdd(&dbg[3], (unsigned long long)opc); }
     }
 }
 
@@ -401,7 +419,7 @@ __global__ void __launch_bounds__(64) k_chain_local_rows(const vmx_anchor* __res
     vmx_rw_costs K; K.s_gapcost = s_gapcost; K.s_rgc = s_rgc; K.skip = want == 1 ? skip_mm : skip_exact; K.maxgap = maxgap;
     K.l2c_size = (long long)tab.log2cache_n - 1; K.log2cache = tab.log2cache;
     double* S = S_pool + a0; int32_t* P = P_pool + a0; int32_t* SA = SA_pool + a0;
-    double best = 0.0; long long opc = 0; unsigned slow = 0; int g;
+    double best = 0.0; long long opc = 0; unsigned long long slow = 0; int g;
 #ifdef VMX_EMU
     if (vmx_rw_small_window()) {
         if (want == 0) g = vmx_rw_chain<2, 3>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, nullptr, nullptr, best, opc, slow);
@@ -413,27 +431,54 @@ __global__ void __launch_bounds__(64) k_chain_local_rows(const vmx_anchor* __res
     else if (want == 1) g = vmx_rw_chain<3, 16>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, nullptr, nullptr, best, opc, slow);
     else g = vmx_rw_chain<4, 16>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, FP_pool + a0, PP_pool + a0, best, opc, slow);
     vmx_row_sync();                                   // (P, written through the loop without waiting, is read back by the traceback)
-    if (l16 == 0) {
-        if (g < 0) { out_len[rd] = 0; out_score[rd] = 0; status[rd] = VM_READ_FASTPATH_DEV; }
-        else {
-            vmx_anchor* O = out_chain + a0;
-            int w = 0; int take = g;
-            vmx_anchor pre = A[take];
-            O[w++] = pre;
-            while (P[take] != VMX_NOPRE) {
-                take = P[take];
-                const vmx_anchor now = A[take];
-                if (pre.q < now.q + ((int)now.l & 0xffff)) {
-                    const int ov = now.q + ((int)now.l & 0xffff) - pre.q;
-                    vmx_anchor t = pre; t.q = pre.q + ov; t.l = (int16_t)(((int)pre.l & 0xffff) - ov); if (pre.s == 1) t.r = pre.r + ov;
-                    O[w - 1] = t;
-                }
-                O[w++] = now;
-                pre = now;
+    if (g < 0) { if (l16 == 0) { out_len[rd] = 0; out_score[rd] = 0; status[rd] = VM_READ_FASTPATH_DEV; } }
+    else {
+        // Traceback with overlap trimming (:27508-27526) by the whole row. The reference walks take = P[take] from the best anchor; one lane doing
+        // that pays a round trip to HBM per chain node (two dependent loads: 5-7 ms for the 7000-node chain of a 100 kb read, most of the kernel's
+        // time on a batch of long reads). Predecessors have smaller indices and sit a few places below as a rule, so the walk goes down the
+        // anchors in blocks of 16: the block's P and anchors are loaded by the 16 lanes at once (the next block down already on its way),
+        // the hops inside a block are register reads (ds_bpermute), the chain nodes found in it are written in one step — each trimmed by the
+        // node that follows it in the walk (its own predecessor: the reference rewrites O[w - 1] when it reaches `now`), at the place the serial
+        // walk would have written it.
+        vmx_anchor* O = out_chain + a0;
+        int w = 0, cur = g;
+        int b = cur & ~15;
+        int Pn = VMX_NOPRE; vmx_anchor An; An.q = 0; An.l = 0; An.s = 0; An.r = 0;
+        { const int x = b + l16; if (x < n) { Pn = P[x]; An = A[x]; } }
+        while (cur != VMX_NOPRE) {
+            const int Pt = Pn; const vmx_anchor At = An;
+            const int bnext = b - 16;
+            if (bnext >= 0) { Pn = P[bnext + l16]; An = A[bnext + l16]; }              // the block below: the walk goes there next as a rule
+            unsigned m = 0;
+            int nxt;
+            while (true) {
+                m |= 1u << (cur - b);
+                nxt = vmx_row_get_i32(Pt, cur - b);
+                if (nxt == VMX_NOPRE || nxt < b) break;
+                cur = nxt;
             }
-            out_len[rd] = w; out_score[rd] = best; status[rd] = 0;
+            const bool member = (m >> l16) & 1u;
+            if (member) {
+                vmx_anchor t = At;
+                if (Pt != VMX_NOPRE) {
+                    const vmx_anchor now = A[Pt];
+                    const int nowl = (int)now.l & 0xffff;
+                    if (At.q < now.q + nowl) { const int ov = now.q + nowl - At.q; t.q = At.q + ov; t.l = (int16_t)(((int)At.l & 0xffff) - ov); if (At.s == 1) t.r = At.r + ov; }
+                }
+                O[w + __popc(m >> (l16 + 1))] = t;
+            }
+            w += __popc(m);
+            cur = nxt;
+            if (cur != VMX_NOPRE) {
+                const int nb2 = cur & ~15;
+                if (nb2 != bnext) { Pn = P[nb2 + l16]; An = A[nb2 + l16]; }            // a longer jump: that block instead
+                b = nb2;
+            }
         }
+        if (l16 == 0) { out_len[rd] = w; out_score[rd] = best; status[rd] = 0; }
+    }
+    if (l16 == 0) {
         out_variant[rd] = want;
-        if (dbg) { atomicAdd(&dbg[0], (unsigned long long)n); atomicAdd(&dbg[1], (unsigned long long)slow); }
+        if (dbg) { atomicAdd(&dbg[4], (unsigned long long)n); atomicAdd(&dbg[5], slow & 0xffffffffULL); atomicAdd(&dbg[6], slow >> 32); atomicAdd(&dbg[7], (unsigned long long)opc); }
     }
 }

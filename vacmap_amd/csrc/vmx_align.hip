@@ -287,7 +287,7 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
                 hipLaunchKernelGGL(k_chain_global_rows, dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, fk.next(), B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(),
                                    B.rl.as<int32_t>() + rl_off[q], cnt, c->tables, B.gap.as<double>(), prm->global_skipcost, prm->global_maxdiff, 1000, B.S.as<double>(),
                                    B.P.as<int32_t>(), B.SA.as<int32_t>(), B.cov.as<uint8_t>(), B.gmax.as<int64_t>(), B.opc.as<int64_t>(), rmode, B.fp.as<double>(), B.pp.as<double>(),
-                                   (unsigned long long*)nullptr);
+                                   vmx_chain_dbg());
                 continue;
             }
             hipLaunchKernelGGL(k_chain_global, dim3((unsigned)cnt), dim3(64), shmem, fk.next(), B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(),

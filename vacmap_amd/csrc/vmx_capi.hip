@@ -466,7 +466,7 @@ int vm_chain_global_batch(vm_ctx* c, const vm_params* prm, int kmersize, int64_t
         hipLaunchKernelGGL(k_chain_global_rows, dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, c->stream, d_sorted.as<vmx_anchor>(), d_aoff.as<int64_t>(),
                            d_rl.as<int32_t>(), cnt, c->tables, d_gap.as<double>(), prm->global_skipcost, prm->global_maxdiff,
                            1000, d_S.as<double>(), d_P.as<int32_t>(), d_SA.as<int32_t>(), d_cov.as<uint8_t>(), d_gmax.as<int64_t>(), d_opc.as<int64_t>(), rmode,
-                           c->b[25].as<double>(), c->b[26].as<double>(), (unsigned long long*)nullptr);
+                           c->b[25].as<double>(), c->b[26].as<double>(), vmx_chain_dbg());
         for (auto& l : lists) l.clear();
     }
     for (int k = 0; k < 5; ++k) {

@@ -263,7 +263,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
                                    L.la_off.as<int64_t>(), L.la_cnt.as<int32_t>(), L.ng_total.as<int32_t>(), L.rlist.as<int32_t>() + rl_off[q], cnt, want, c->tables,
                                    L.gap.as<double>(), skip_exact, skip_mm, prm->local_maxdiff, maxgap, prm->mode, L.S.as<double>(), L.P.as<int32_t>(), L.SA.as<int32_t>(),
                                    L.score.as<double>(), L.chain.as<vmx_anchor>(), L.chain_len.as<int32_t>(), L.variant.as<int32_t>(), L.status.as<int32_t>(),
-                                   L.fp.as<double>(), L.pp.as<double>(), (unsigned long long*)nullptr);
+                                   L.fp.as<double>(), L.pp.as<double>(), vmx_chain_dbg());
             continue;
         }
         hipLaunchKernelGGL(k_chain_local, dim3((unsigned)cnt), dim3(64), shmem, fk.next(), L.la_sorted.as<vmx_anchor>(),
@@ -273,6 +273,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
                            L.fp.as<double>(), L.pp.as<double>());
     }
     fk.join();
+    vmx_chain_dbg_report(c->stream);
     // L5: reads whose LC launch hit the opcount switch (:27380 / :28333) take the *_fast twin. One wave per read; all other reads
     // return at once.
     VMX_TRY(L.si.reserve(4 * (size_t)(la_tot + 1))); VMX_TRY(L.tg.reserve(8 * (size_t)(la_tot + 1))); VMX_TRY(L.cntp.reserve(4 * (size_t)(h_roff[n] + 50 * n + 64)));
