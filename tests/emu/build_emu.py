@@ -9,7 +9,7 @@ CSRC = os.path.join(ROOT, 'vacmap_amd', 'csrc')
 BUILD = os.path.join(HERE, '_build')
 OUT = os.path.join(BUILD, 'libvacmapx_emu.so')
 FLAGS = ['-O1', '-g', '-std=c++17', '-fPIC', '-ffp-contract=off', '-DVMX_EMU', '-I', HERE, '-I', CSRC, '-pthread', '-Wno-unused-result',
-         '-Wno-attributes']
+         '-Wno-attributes'] + os.environ.get('VMX_EMU_EXTRA_FLAGS', '').split()      # e.g. -DVMX_RW_DPP_WINNER: a kernel variant under test
 
 
 def build(force=False):

@@ -143,3 +143,24 @@ def test_bam_reader_and_blob_chunks(tmp_path):
     assert [len(c['seqs_off']) - 1 for c in chunks] == [3, 1]
     c0 = chunks[0]
     assert c0['seqs'].tobytes() == b'ACGTNACGTATAACCGGTTGATTACA' and c0['quals_off'].tolist() == [0, 10, 19, 19] and c0['names'].tobytes() == b'r1r2r3'
+
+
+def test_pipeline_gives_up_a_context_when_hbm_runs_low():
+    """the pools regrow after trim_to_memory has run; between two batches a worker whose context sees less than the low-water
+    mark free gives the context up (pools freed, thread ends) while more than `keep` are at work; the first context never goes"""
+    from vacmap_amd import pipeline
+
+    class FakeCtx:
+        def __init__(self, free_gb): self.free, self.closed, self.inflight = free_gb, False, None
+        def mem_info(self): return int(self.free * 1e9), int(309e9)
+        def close(self): self.closed = True
+        def set_inflight(self, n): self.inflight = n
+    p = object.__new__(pipeline.Pipeline)
+    p.ctxs = [FakeCtx(2.0) for _ in range(4)]; p.inflight = 4
+    assert not p.retire_if_low(p.ctxs[0])                     # the index's context stays whatever the memory says
+    last = p.ctxs[3]
+    assert p.retire_if_low(last) and last.closed and len(p.ctxs) == 3 and p.inflight == 3 and all(c.inflight == 3 for c in p.ctxs)
+    assert p.retire_if_low(p.ctxs[2]) and len(p.ctxs) == 2
+    assert not p.retire_if_low(p.ctxs[1]) and len(p.ctxs) == 2     # `keep` contexts remain
+    p.ctxs = [FakeCtx(50.0) for _ in range(4)]; p.inflight = 4
+    assert not p.retire_if_low(p.ctxs[3]) and len(p.ctxs) == 4     # enough memory: nothing happens

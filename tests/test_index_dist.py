@@ -385,9 +385,9 @@ ctx = emu_lib.context()
 import vacmap_amd.lib as VL
 VL._default = ctx.lib
 from vacmap_amd import driver
-tmp, mode = sys.argv[1], sys.argv[2]
+tmp, mode, reads = sys.argv[1], sys.argv[2], sys.argv[3]
 extra = ['--parts'] if mode == 'parts' else (['--shard', 'batch'] if mode == 'batch' else [])
-rc = driver.main(['-ref', os.path.join(tmp, 'ref.fa'), '-read', os.path.join(tmp, 'reads.fq'), '-mode', 'H', '-o', os.path.join(tmp, 'out_%%s_%%d.sam' %% (mode, dist.get_world_size())),
+rc = driver.main(['-ref', os.path.join(tmp, 'ref.fa'), '-read', os.path.join(tmp, reads), '-mode', 'H', '-o', os.path.join(tmp, 'out_%%s_%%d.sam' %% (mode, dist.get_world_size())),
                   '-t', '4', '--nowriteindex', '--batch-reads', '2', '--window-batches', '2', '--force', '--parse-threads', '2'] + extra, comm=dist)
 assert rc == 0
 dist.barrier(); dist.destroy_process_group()
@@ -400,13 +400,14 @@ def test_fastx_byte_ranges_partition_the_records(ctx, tmp_path):
     import random
     from vacmap_amd.lib import Fastx
     rng = random.Random(5)
-    for fq in (True, False):
+    for fq, lead in ((True, ''), (False, ''), (True, '\n\n'), (False, ' \n')):      # (a file that begins with blank lines: the format is its first non-blank byte — ADVICE r4)
         R = []
         for i in range(200):
             L = rng.randint(1, 300)
             R.append(('r%d' % i, ''.join(rng.choice('ACGTNacgt') for _ in range(L)), ''.join(rng.choice('@+!IJ5>') for _ in range(L))))
         path = str(tmp_path / ('t.fq' if fq else 't.fa'))
         with open(path, 'w') as f:
+            f.write(lead)
             for nm, s_, q in R:
                 if fq:
                     f.write('@%s c%s\n%s\n+\n%s\n' % (nm, nm, s_, q))
@@ -423,7 +424,7 @@ def test_fastx_byte_ranges_partition_the_records(ctx, tmp_path):
                     nb, no, sb, so, qb, qo = ch['names'].tobytes(), ch['names_off'], ch['seqs'].tobytes(), ch['seqs_off'], ch['quals'].tobytes(), ch['quals_off']
                     got += [(nb[no[i]:no[i + 1]].decode(), sb[so[i]:so[i + 1]].decode(), qb[qo[i]:qo[i + 1]].decode()) for i in range(len(no) - 1)]
                 rd.close()
-            assert got == want, (fq, N)
+            assert got == want, (fq, lead, N)
 
 
 def test_n_rank_driver_range_sharding_parts_gloo(ctx, tmp_path, monkeypatch):
@@ -442,28 +443,37 @@ def test_n_rank_driver_range_sharding_parts_gloo(ctx, tmp_path, monkeypatch):
         for i in range(11):
             s_ = cat[off[i]:off[i + 1]].tobytes().decode()
             f.write('@r%d\n%s\n+\n%s\n' % (i, s_, '@' * len(s_)))          # (quality lines of '@': the resynchronisation must not take them for headers)
+    # the same reads with the last two carrying the names of the first two: the reference keeps the first occurrence of a name, wherever in the
+    # input the later ones are (vacmap:457-487) — here in another rank's byte range
+    with open(tmp_path / 'reads_dup.fq', 'w') as f:
+        for i in range(11):
+            s_ = cat[off[i]:off[i + 1]].tobytes().decode()
+            f.write('@r%d\n%s\n+\n%s\n' % (i if i < 9 else 10 - i, s_, '@' * len(s_)))
     monkeypatch.setenv('VMX_SLICE_MB', '0.004')                            # ~4 KB slices: several per rank
-    one = str(tmp_path / 'one.sam')
-    assert driver.main(['-ref', str(tmp_path / 'ref.fa'), '-read', str(tmp_path / 'reads.fq'), '-mode', 'H', '-o', one, '-t', '4', '--nowriteindex',
-                        '--batch-reads', '2', '--window-batches', '2', '--force', '--parse-threads', '2']) == 0
-    want = sorted(l for l in open(one) if not l.startswith('@'))
-    header = [l for l in open(one) if l.startswith('@') and not l.startswith('@PG')]
-    assert len(want) >= 11
+    wants = {}
+    for rf in ('reads.fq', 'reads_dup.fq'):
+        one = str(tmp_path / ('one_' + rf + '.sam'))
+        assert driver.main(['-ref', str(tmp_path / 'ref.fa'), '-read', str(tmp_path / rf), '-mode', 'H', '-o', one, '-t', '4', '--nowriteindex',
+                            '--batch-reads', '2', '--window-batches', '2', '--force', '--parse-threads', '2']) == 0
+        wants[rf] = sorted(l for l in open(one) if not l.startswith('@'))
+        header = [l for l in open(one) if l.startswith('@') and not l.startswith('@PG')]
+    assert len(wants['reads.fq']) >= 11 and len(wants['reads_dup.fq']) < len(wants['reads.fq'])
     script = tmp_path / 'w.py'
     script.write_text(_RANGE_WORKER % (ROOT, ROOT))
     port = 29651
-    for world, mode in ((2, 'join'), (4, 'join'), (2, 'parts'), (2, 'batch')):
+    for world, mode, rf in ((2, 'join', 'reads.fq'), (4, 'join', 'reads_dup.fq'), (2, 'join', 'reads_dup.fq'), (2, 'parts', 'reads.fq'), (2, 'batch', 'reads_dup.fq')):
         port += 1
+        want = wants[rf]
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), VMX_SLICE_MB='0.004')
         out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
-                              '--master-port', str(port), str(script), str(tmp_path), mode], capture_output=True, text=True, timeout=900, env=env)
+                              '--master-port', str(port), str(script), str(tmp_path), mode, rf], capture_output=True, text=True, timeout=900, env=env)
         assert out.returncode == 0, out.stderr[-3000:]
         base = str(tmp_path / ('out_%s_%d.sam' % (mode, world)))
         files = [base + '.part%03d' % r for r in range(world)] if mode == 'parts' else [base]
         assert all(os.path.exists(f) for f in files) and (mode == 'parts' or not os.path.exists(base + '.part000'))
         lines = [l for f in files for l in open(f)]
         assert [l for l in lines if l.startswith('@') and not l.startswith('@PG')] == header, (world, mode)       # the header once
-        assert sorted(l for l in lines if not l.startswith('@')) == want, (world, mode)
+        assert sorted(l for l in lines if not l.startswith('@')) == want, (world, mode, rf)
 
 
 def test_driver_mode_asm_ignores_c_and_maxdivergence_reads_bam(ctx, tmp_path, monkeypatch):

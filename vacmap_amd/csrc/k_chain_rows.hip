@@ -156,11 +156,22 @@ __device__ __forceinline__ int vmx_rw_scan16(const vmx_rcur& c, const vmx_rw_cos
     opcount += __popc(vm & below);
     if constexpr (!gc) opcount += (int)((vm >> first) & 1u);
     const unsigned upd = im & below;
+#ifdef VMX_RW_DPP_WINNER
+    // the last update wins: its score is the largest of the candidates before the break (every update is an increase), its lane the highest
+    // bit of `upd`; both reach every lane of the row by a butterfly of DPP rotations (no LDS round trip on the per-anchor chain)
+    const int l16 = vmx_lane() & 15;
+    const int wl = 31 - __clz((int)(upd | 1u));
+    const double gM = vmx_row_allmax_f64(((upd >> l16) & 1u) ? test : 0.0);
+    const int gj = vmx_row_allmax_i32(l16 == wl ? w.j : -1);
+    max_scores = upd ? gM : max_scores; pre_index = upd ? gj : pre_index;
+    if constexpr (vmx_rw_traits<KIND>::pen) { const double gf = vmx_row_get_f64(nfp, wl), gp = vmx_row_get_f64(npp, wl); fp_i = upd ? gf : fp_i; pp_i = upd ? gp : pp_i; }
+#else
     // the last update wins; fetched whether there is one or not (lane 0 then, dropped): three or seven ds_bpermute instead of a branch
     const int wl = upd ? 31 - __clz((int)upd) : 0;
     const double gM = vmx_row_get_f64(test, wl); const int gj = vmx_row_get_i32(w.j, wl);
     max_scores = upd ? gM : max_scores; pre_index = upd ? gj : pre_index;
     if constexpr (vmx_rw_traits<KIND>::pen) { const double gf = vmx_row_get_f64(nfp, wl), gp = vmx_row_get_f64(npp, wl); fp_i = upd ? gf : fp_i; pp_i = upd ? gp : pp_i; }
+#endif
     return first;
 }
 
@@ -225,10 +236,12 @@ __device__ __forceinline__ int vmx_rw_chain(const vmx_anchor* __restrict__ A, in
     constexpr bool pen = vmx_rw_traits<KIND>::pen;
     constexpr bool cov = KIND == 0;
     const int l16 = vmx_lane() & 15;
-    // anchors [bb, bb + 16) in registers (lane t: anchor bb + t), the next block already on its way
-    int bq, bls, nbq, nbls; long long br, nbr;
+    // anchors [bb, bb + 16) in registers (lane t: anchor bb + t), the next block already on its way — kept as loaded until it takes over
+    // (anything computed from it at once would make the wave wait for the load, and for every store before it, right there)
+    int bq, bls; long long br;
+    vmx_anchor nba; int nbc = 0;
     { const int x = l16 < n ? l16 : n - 1; const vmx_anchor a = A[x]; bq = a.q; bls = VMX_RW_LS(a.l, a.s) | (cov ? (int)COV[x] << 17 : 0); br = a.r; }
-    { const int x = 16 + l16 < n ? 16 + l16 : n - 1; const vmx_anchor a = A[x]; nbq = a.q; nbls = VMX_RW_LS(a.l, a.s) | (cov ? (int)COV[x] << 17 : 0); nbr = a.r; }
+    { const int x = 16 + l16 < n ? 16 + l16 : n - 1; nba = A[x]; if (cov) nbc = COV[x]; }
     const int q0 = vmx_row_get_i32(bq, 0), ls0 = vmx_row_get_i32(bls, 0); const long long r0 = vmx_row_get_i64(br, 0);
     const int l0 = ls0 & 0xffff;
     vmx_rwin win;
@@ -250,9 +263,9 @@ __device__ __forceinline__ int vmx_rw_chain(const vmx_anchor* __restrict__ A, in
         {   // anchor i + 1 for the next step
             const int x = i + 1;
             if ((x & 15) == 0) {
-                bq = nbq; bls = nbls; br = nbr;
-                const int y = x + 16 + l16 < n ? x + 16 + l16 : n - 1; const vmx_anchor a = A[y];
-                nbq = a.q; nbls = VMX_RW_LS(a.l, a.s) | (cov ? (int)COV[y] << 17 : 0); nbr = a.r;
+                bq = nba.q; bls = VMX_RW_LS(nba.l, nba.s) | (cov ? nbc << 17 : 0); br = nba.r;
+                const int y = x + 16 + l16 < n ? x + 16 + l16 : n - 1;
+                nba = A[y]; if (cov) nbc = COV[y];
             }
             nq = vmx_row_get_i32(bq, x & 15); nls = vmx_row_get_i32(bls, x & 15); nr = vmx_row_get_i64(br, x & 15);
         }

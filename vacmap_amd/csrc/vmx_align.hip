@@ -295,6 +295,7 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
                                B.P.as<int32_t>(), B.SA.as<int32_t>(), B.cov.as<uint8_t>(), B.gmax.as<int64_t>(), B.opc.as<int64_t>(), rmode, B.fp.as<double>(), B.pp.as<double>());
         }
         fk.join();
+        vmx_chain_dbg_report(c->stream);
         // G3: reads left at gmax = -1 (more than 5 anchors per base, :23570, or GC-exact's opcount bail-out, :24914) take GC-fast.
         // One wave per read; reads that do not need it return at once.
         VMX_TRY(B.si.reserve(4 * (size_t)(tot + 1))); VMX_TRY(B.tg.reserve(8 * (size_t)(tot + 1))); VMX_TRY(B.cntp.reserve(4 * (size_t)(total_bases + 50 * n + 64)));

@@ -631,7 +631,7 @@ int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, in
     VMX_TRY(mst.reserve(4 * (size_t)(total_bases + 1))); VMX_TRY(mcn.reserve(4 * (size_t)(total_bases + 1))); VMX_TRY(mho.reserve(4 * (size_t)(total_bases + 1)));
     VMX_TRY(nh.reserve(8 * (size_t)(n + 2))); VMX_TRY(koff.reserve(8 * (size_t)(n + 2))); VMX_TRY(nanc.reserve(4 * (size_t)(n + 1)));
     const unsigned grid = (unsigned)std::max<int64_t>(std::min<int64_t>(n, (int64_t)c->num_cu * 4), 1);
-    if (2 * mi->k <= 32) hipLaunchKernelGGL(k_sketch32, dim3(grid), dim3(256), 0, c->stream, d_codes, d_roff, (int)n, mi->k, mi->w, mzh.as<uint64_t>(), mzp.as<uint32_t>(), d_roff, mzc.as<int32_t>());      // 30-bit hashes (k = 15): the 32-bit form
+    if (2 * mi->k < 32) hipLaunchKernelGGL(k_sketch32, dim3(grid), dim3(256), 0, c->stream, d_codes, d_roff, (int)n, mi->k, mi->w, mzh.as<uint64_t>(), mzp.as<uint32_t>(), d_roff, mzc.as<int32_t>());      // hashes of fewer than 32 bits (k <= 15): the 32-bit form — at k = 16 a valid hash could equal its all-ones sentinel
     else hipLaunchKernelGGL(k_sketch, dim3(grid), dim3(256), 0, c->stream, d_codes, d_roff, (int)n, mi->k, mi->w, mzh.as<uint64_t>(), mzp.as<uint32_t>(), d_roff, mzc.as<int32_t>());
     hipLaunchKernelGGL(k_lookup, dim3(grid), dim3(256), 0, c->stream, mzh.as<uint64_t>(), d_roff, mzc.as<int32_t>(), (int)n, mi->d_table.as<vmx_slot>(), mi->table_bits, mid_occ,
                        mst.as<uint32_t>(), mcn.as<uint32_t>(), mho.as<uint32_t>(), nh.as<int64_t>());

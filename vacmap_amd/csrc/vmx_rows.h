@@ -28,6 +28,7 @@ template <int N> __device__ __forceinline__ int vmx_row_shr0_i32(int v) {
     return l16 >= N ? e : 0;
 }
 __device__ __forceinline__ double vmx_max_f64(double a, double b) { return a > b ? a : b; }
+template <int N> __device__ __forceinline__ int vmx_row_ror_i32(int v) { return emu_row_exchange(v, ((vmx_lane() & 15) - N) & 15); }
 // value of lane `src16` (0..15, the same in every lane of the row) of the caller's row
 __device__ __forceinline__ int vmx_row_get_i32(int v, int src16) { return emu_row_exchange(v, src16); }
 // the row's earlier stores to memory are visible to the row's later loads
@@ -39,6 +40,7 @@ __device__ __forceinline__ unsigned vmx_row_bits(vmx_rmask m) { return (unsigned
 __device__ __forceinline__ unsigned vmx_row_ballot(bool p) { return (unsigned)(__builtin_amdgcn_ballot_w64(p) >> (vmx_lane() & 48)) & 0xffffu; }   // (the compare's own SGPR pair: no 0 / 1 detour)
 template <int N> __device__ __forceinline__ int vmx_row_shr_i32(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x110 + N, 0xf, 0xf, false); }
 template <int N> __device__ __forceinline__ int vmx_row_shr0_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xf, 0xf, true); }      // bound_ctrl:1 — nothing to preset
+template <int N> __device__ __forceinline__ int vmx_row_ror_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x120 + N, 0xf, 0xf, false); }      // rotation inside the row
 // one v_max_f64 (the scores are never NaN; `a > b ? a : b` is a compare and two selects under -fno-fast-math)
 __device__ __forceinline__ double vmx_max_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ int vmx_row_get_i32(int v, int src16) { return __builtin_amdgcn_ds_bpermute(((vmx_lane() & 48) + src16) << 2, v); }
@@ -80,6 +82,23 @@ __device__ __forceinline__ double vmx_row_incl_max0_f64(double v) {
     v = vmx_max_f64(v, vmx_row_shr0_f64<2>(v));
     v = vmx_max_f64(v, vmx_row_shr0_f64<4>(v));
     v = vmx_max_f64(v, vmx_row_shr0_f64<8>(v));
+    return v;
+}
+template <int N> __device__ __forceinline__ double vmx_row_ror_f64(double v) {
+    union { double d; int i[2]; } s, r; s.d = v;
+    r.i[0] = vmx_row_ror_i32<N>(s.i[0]); r.i[1] = vmx_row_ror_i32<N>(s.i[1]);
+    return r.d;
+}
+// maximum over the row, in every lane (butterfly on row_ror:8/4/2/1; no LDS)
+__device__ __forceinline__ double vmx_row_allmax_f64(double v) {
+    v = vmx_max_f64(v, vmx_row_ror_f64<8>(v)); v = vmx_max_f64(v, vmx_row_ror_f64<4>(v));
+    v = vmx_max_f64(v, vmx_row_ror_f64<2>(v)); v = vmx_max_f64(v, vmx_row_ror_f64<1>(v));
+    return v;
+}
+__device__ __forceinline__ int vmx_row_allmax_i32(int v) {
+    int t;
+    t = vmx_row_ror_i32<8>(v); v = t > v ? t : v; t = vmx_row_ror_i32<4>(v); v = t > v ? t : v;
+    t = vmx_row_ror_i32<2>(v); v = t > v ? t : v; t = vmx_row_ror_i32<1>(v); v = t > v ? t : v;
     return v;
 }
 #endif

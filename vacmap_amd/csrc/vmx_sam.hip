@@ -570,8 +570,19 @@ int vm_fastx_open_range(const char* path, int64_t begin, int64_t end, vm_fastx**
         return VM_OK;                                            // (a compressed file is one range: `end` is ignored)
     }
     try {
-        unsigned char first = 0;
-        if (pread(x->fd, &first, 1, 0) == 1) x->fastq = first == '@';
+        // FASTA or FASTQ: the first byte that is not white space, as vm_fastx_read decides it record by record (blank lines are skipped there:
+        // a file that begins with one must not be taken for FASTA by its byte 0 — every range with begin > 0 would then look for '>' lines only)
+        {
+            unsigned char head[4096]; off_t at = 0; unsigned char first = 0;
+            while (!first) {
+                const long got = (long)pread(x->fd, head, sizeof head, at);
+                if (got <= 0) break;
+                for (long i = 0; i < got; ++i) if (head[i] != '\n' && head[i] != '\r' && head[i] != ' ' && head[i] != '\t') { first = head[i]; break; }
+                at += got;
+            }
+            if (first && first != '>' && first != '@') { vm_fastx_close(x); *out = nullptr; set_error("not FASTA/FASTQ: the first record starts with neither '>' nor '@'"); return VM_ERR_IO; }
+            x->fastq = first == '@';
+        }
         x->range_end = end;
         if (begin <= 0) return VM_OK;
         // start one byte early: whether `begin` is itself a line start depends on the byte before it
@@ -610,6 +621,10 @@ int64_t vm_fastx_read(vm_fastx* x, int64_t max_reads, int64_t max_bases, char** 
             }
             if (!fx_line(x, p, len)) break;
             if (len == 0) continue;
+            if (p[0] == ' ' || p[0] == '\t' || p[0] == '\r') {            // a line of white space only counts as blank (vm_fastx_open_range finds the format the same way)
+                size_t a = 0; while (a < len && (p[a] == ' ' || p[a] == '\t' || p[a] == '\r')) ++a;
+                if (a == len) continue;
+            }
             if (p[0] != '>' && p[0] != '@') { set_error("not FASTA/FASTQ: " + std::string(p, len < 40 ? len : 40)); return VM_ERR_IO; }
             const bool fq = p[0] == '@';
             {   // name | comment: at the first blank or tab, whichever comes first (kseq's rule, which mp.fastx_read follows, vacmap:445)

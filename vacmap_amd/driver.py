@@ -120,21 +120,75 @@ def _is_plain_fastx(path):
         return f.read(2) != b'\x1f\x8b'
 
 
-def _concat_parts(dst, parts):
-    """the ranks' SAM parts, in rank order, into one file (in-kernel copies; the parts are removed)"""
-    with open(dst, 'wb') as o:
-        for pth in parts:
+_HASH_POW = None
+
+
+def name_hashes(blob, off):
+    """64-bit hashes of the names in a blob (uint8 array + offsets), the same in every process (Python's hash() of bytes is salted per
+    process): a position-weighted polynomial modulo 2^64 with a splitmix64 finish, in NumPy over the whole blob. Range mode compares the
+    ranks' sets at the end of the run to give the reference's GLOBAL de-duplication by name (vacmap:457-487)."""
+    global _HASH_POW
+    import numpy as np
+    off = np.asarray(off, dtype=np.int64)
+    n = len(off) - 1
+    if n <= 0:
+        return np.zeros(0, np.uint64)
+    lens = np.diff(off)
+    mx = int(lens.max()) if n else 0
+    if _HASH_POW is None or len(_HASH_POW) < mx + 1:
+        pw = np.empty(max(mx + 1, 256), np.uint64); pw[0] = 1
+        with np.errstate(over='ignore'):
+            for i in range(1, len(pw)):
+                pw[i] = pw[i - 1] * np.uint64(0x9E3779B97F4A7C15)
+        _HASH_POW = pw
+    b = np.asarray(blob, dtype=np.uint8)[off[0]:off[-1]]
+    pos = np.arange(len(b), dtype=np.int64) - np.repeat(off[:-1] - off[0], lens)
+    with np.errstate(over='ignore'):
+        contrib = (b.astype(np.uint64) + np.uint64(1)) * _HASH_POW[pos]
+        h = np.zeros(n, np.uint64)
+        nz = lens > 0
+        if len(contrib):
+            st = (off[:-1] - off[0])[nz]
+            h[nz] = np.add.reduceat(contrib, st)
+        h = h + lens.astype(np.uint64) * np.uint64(0xD6E8FEB86659FD93)
+        h ^= h >> np.uint64(30); h *= np.uint64(0xBF58476D1CE4E5B9); h ^= h >> np.uint64(27); h *= np.uint64(0x94D049BB133111EB); h ^= h >> np.uint64(31)
+    return h
+
+
+def _concat_parts(dst, parts, drop=None):
+    """the ranks' SAM parts, in rank order, into one file (in-kernel copies; the parts are removed). drop[r]: name hashes whose lines are
+    left out of part r (a read name that also occurs in a lower rank's byte range: the reference keeps the first occurrence only) — that
+    part is then copied line by line; returns the (reads, lines) left out."""
+    import numpy as np
+    gone_reads, gone_lines = set(), 0
+    with open(dst, 'wb', buffering=0) as o:             # unbuffered: sendfile on the descriptor and write() through the object must not interleave out of order
+        for r, pth in enumerate(parts):
             with open(pth, 'rb') as f:
-                size = os.fstat(f.fileno()).st_size; off = 0
-                while off < size:
-                    try:
-                        n = os.sendfile(o.fileno(), f.fileno(), off, min(size - off, 1 << 30))
-                    except OSError:
-                        n = 0
-                    if n <= 0:                      # (a file system without sendfile between regular files: plain copy)
-                        f.seek(off); shutil.copyfileobj(f, o, 16 << 20); break
-                    off += n
+                if drop and r in drop and len(drop[r]):
+                    bad = set(int(x) for x in drop[r])
+                    for ln in f:
+                        if not ln.startswith(b'@'):
+                            nm = ln[:ln.find(b'\t')]
+                            h = int(name_hashes(np.frombuffer(nm, dtype=np.uint8), [0, len(nm)])[0])
+                            if h in bad:
+                                gone_reads.add(h); gone_lines += 1
+                                continue
+                        o.write(ln)
+                else:
+                    size = os.fstat(f.fileno()).st_size; off = 0
+                    while off < size:
+                        try:
+                            n = os.sendfile(o.fileno(), f.fileno(), off, min(size - off, 1 << 30))
+                        except OSError:
+                            n = 0
+                        if n <= 0:                      # (a file system without sendfile between regular files: plain copy)
+                            f.seek(off)
+                            for blk in iter(lambda: f.read(16 << 20), b''):
+                                o.write(blk)
+                            break
+                        off += n
             os.remove(pth)
+    return len(gone_reads), gone_lines
 
 
 RG_ARGS = (('rg-id', 'ID'), ('rg-sm', 'SM'), ('rg-lb', 'LB'), ('rg-pl', 'PL'), ('rg-ds', 'DS'), ('rg-dt', 'DT'), ('rg-pu', 'PU'), ('rg-pi', 'PI'),
@@ -360,6 +414,20 @@ def main(argv=None, comm=None):
     range_mode = world > 1 and args.mode != 'asm' and args.shard != 'batch' and plain and args.o.endswith('.sam')
     if world > 1 and args.shard == 'range' and not range_mode:
         sys.exit('--shard range needs uncompressed FASTA / FASTQ input and a .sam output path')
+    if range_mode:
+        # every rank writes <out>.partNNN and rank 0 joins them: they must land in one directory. Ranks on several hosts only see each other's
+        # parts on a shared file system — nothing here can check that, so `auto` falls back to the batch scheme (text gathered over gloo) and an
+        # explicit `--shard range` goes on with a warning
+        import socket
+        hosts = [None] * world
+        comm.all_gather_object(hosts, socket.gethostname(), group=text_group)
+        if len(set(hosts)) > 1:
+            if args.shard == 'auto':
+                range_mode = False
+                if rank == 0:
+                    sys.stderr.write('vacmapx: ranks on %d hosts: --shard auto uses the batch scheme (SAM text gathered by rank 0); --shard range needs %s.partNNN on a shared file system\n' % (len(set(hosts)), args.o))
+            elif rank == 0:
+                sys.stderr.write('vacmapx: ranks on %d hosts with --shard range: %s.partNNN of every rank must be visible to rank 0 (shared file system)\n' % (len(set(hosts)), args.o))
     part_path = '%s.part%03d' % (args.o, rank) if range_mode else None
     out, proc = (None, None)
     if range_mode and rank != 0:
@@ -440,6 +508,8 @@ def main(argv=None, comm=None):
                         ix = np.asarray(keep, dtype=np.int64)
                         for key in ('names', 'seqs', 'quals', 'comments'):
                             ch[key], ch[key + '_off'] = blob_gather(lib, ch[key], ch[key + '_off'], ix)
+                    if range_mode and len(ch['names_off']) > 1:
+                        rank_hashes.append(name_hashes(ch['names'], ch['names_off']))      # compared across the ranks at the end of the run
                     if args.Q:
                         ch['quals_off'] = np.zeros(len(ch['seqs_off']), np.int64)
                     if not args.copycomments:
@@ -447,6 +517,7 @@ def main(argv=None, comm=None):
                     if len(ch['seqs_off']) > 1:
                         yield ch
 
+    rank_hashes = []
     prog = {'t0': time.time(), 't': time.time(), 'n': 0, 'next': 100000}
 
     def progress(count):
@@ -665,12 +736,27 @@ def main(argv=None, comm=None):
         # is not the input's either: mammap_clrnano.py:24147-24150)
         out.close()
         from .dist import gather_lines
-        allc = gather_lines((counts['reads'], counts['lines'], counts['skipped']), dst=0, group=text_group)
+        # The reference drops a read name it has seen before, anywhere in the input (vacmap:457-487); a rank only sees its own byte ranges, so the
+        # ranks' name hashes (8 bytes per read) travel with the counts and rank 0 leaves the later occurrences out while it joins the parts:
+        # a name that also occurs in a lower rank's ranges (of any input file) goes. No cross-rank duplicate — the rule — costs one sort.
+        myh = np.concatenate(rank_hashes) if rank_hashes else np.zeros(0, np.uint64)
+        allc = gather_lines((counts['reads'], counts['lines'], counts['skipped'], myh), dst=0, group=text_group)
         if rank == 0:
             counts['reads'], counts['lines'], counts['skipped'] = (sum(c[i] for c in allc) for i in range(3))
+            hs = np.concatenate([c[3] for c in allc]); rk = np.concatenate([np.full(len(c[3]), r, np.int32) for r, c in enumerate(allc)])
+            order = np.lexsort((rk, hs)); hs, rk = hs[order], rk[order]
+            dup = np.zeros(len(hs), bool)
+            if len(hs) > 1:
+                dup[1:] = hs[1:] == hs[:-1]                       # (sorted by hash, then rank: every occurrence but the lowest rank's)
+            drop = {r: hs[dup & (rk == r)] for r in range(1, world) if (dup & (rk == r)).any()}
+            if drop and args.parts:
+                sys.stderr.write('vacmapx: %d read names occur in more than one rank\'s part (--parts keeps the parts as written: later occurrences are NOT removed)\n' % int(dup.sum()))
             if not args.parts:
                 tj = time.time()
-                _concat_parts(args.o, ['%s.part%03d' % (args.o, r) for r in range(world)])
+                gr, gl = _concat_parts(args.o, ['%s.part%03d' % (args.o, r) for r in range(world)], drop)
+                counts['reads'] -= gr; counts['lines'] -= gl
+                if gr:
+                    sys.stderr.write('vacmapx: %d reads whose name occurred earlier in the input (another rank\'s range) were left out, %d SAM lines\n' % (gr, gl))
                 last_timing['concat_parts'] = time.time() - tj
     if rank == 0:
         if proc is not None:

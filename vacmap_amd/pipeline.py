@@ -101,6 +101,23 @@ class Pipeline:
                 cx.set_inflight(self.inflight)
         return dropped
 
+    def retire_if_low(self, cx, low_water_gb=4.0, keep=2):
+        """called by a worker thread between two batches (under the scheduler's lock): the pools are grow-only, and a later window with longer
+        reads regrows every context's pools after trim_to_memory has run. When less than `low_water_gb` of HBM is free and more than
+        `keep` contexts are at work, this one gives up: its pools are freed and its thread ends — the run goes on with one batch fewer in flight
+        instead of failing a hipMalloc (vm_align_batch itself degrades to sub-batches when memory runs out, which is much slower). Returns True
+        when the context was given up. The first context (the index's) never retires."""
+        if cx is self.ctxs[0] or len(self.ctxs) <= max(1, keep):
+            return False
+        free, _ = cx.mem_info()
+        if free >= low_water_gb * 1e9:
+            return False
+        self.ctxs.remove(cx); cx.close()
+        self.inflight = len(self.ctxs)
+        for c in self.ctxs:
+            c.set_inflight(self.inflight)
+        return True
+
     def _run(self, n_jobs, do_job, on_result):
         """`inflight` threads pull job indices in order; do_job(i, ctx) -> result; on_result(i, result) is called under a lock"""
         lock = threading.Lock()
@@ -122,13 +139,16 @@ class Pipeline:
                     if on_result is not None:
                         with lock:
                             on_result(i, res)
+                    with lock:
+                        if self.retire_if_low(cx):
+                            return
             except BaseException as e:                    # a failed batch must fail the run, not hang it
                 errs.append(e)
 
         if self.inflight == 1 or n_jobs <= 1:
             worker(self.ctxs[0])
         else:
-            th = [threading.Thread(target=worker, args=(cx,)) for cx in self.ctxs[:min(self.inflight, n_jobs)]]
+            th = [threading.Thread(target=worker, args=(cx,)) for cx in list(self.ctxs[:min(self.inflight, n_jobs)])]
             for t in th:
                 t.start()
             for t in th:
@@ -156,10 +176,13 @@ class Pipeline:
                         do_job(job, cx)
                     finally:
                         _roctx.pop()
+                    with lock:
+                        if self.retire_if_low(cx):
+                            return
             except BaseException as e:
                 errs.append(e)
 
-        th = [threading.Thread(target=worker, args=(cx,)) for cx in self.ctxs[:self.inflight]]
+        th = [threading.Thread(target=worker, args=(cx,)) for cx in list(self.ctxs[:self.inflight])]
         for t in th:
             t.start()
         for t in th:
