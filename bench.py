@@ -29,7 +29,19 @@ CONFIGS = {
                       what='configs[1]: synthetic ONT reads (Gamma mean %d bp, %.1f%% err) vs 100 Mb synthetic ref (1 contig), -mode H -k 15 -w 10 -c 100'),
     'hifi_hg38': dict(ref_mb=0, shape='hifi', mean_len=18000, err=0.005, min_len=5000, mode='L', k=19, tag='hifi18k_hg38size_L_k19',
                       what='configs[2]: synthetic HiFi reads (Normal mean %d bp, sd 2000, %.1f%% err) vs hg38-size synthetic ref (24 contigs, 3.1 Gb, seed 3), -mode L -k 19 -w 10 -c 100'),
+    'vacsim_r': dict(ref_mb=0, shape='hifi', mean_len=18000, err=0.005, min_len=5000, mode='R', k=15, tag='vacsim_hifi18k_hg38size_R_k15', vacsim=True,
+                     what='configs[4] on one GPU: donor genome made from the hg38-size synthetic ref by the vacsim-grammar implanter (vacmap_amd/vacsim.py: nested INV, DUP:..:rev:times, '
+                          'TRA across contigs, DEL / INS chains, Random{} event sets), HiFi-shape reads (Normal mean %d bp, sd 2000, %.1f%% err) sampled ACROSS the implanted '
+                          'events (every read covers at least one), aligned to the unaltered reference, -mode R -k 15 -w 10 -c 100'),
 }
+# the grammar text of the vacsim_r workload (the line set of tests/test_gpu_kernels.py::test_config5_vacsim_grammar_mode_r, numbers scaled)
+VACSIM_TEXT = '''Specified{INV:300:600,DUP:300:600:1:2,TRA:400:800:1;number=%(n)d}
+Specified{DEL:100:200,INS:100:1000,INV:100:200,DUP:100:200:0:4,TRA:200:400:1;number=%(n)d}
+Specified{INV:400:800,NML:100:200,TRA:400:800:0;number=%(n)d}
+Specified{INV:300:900;number=%(n)d}
+Random{eventset=["DEL:100:200","INS:100:1000","INV:300:600","DUP:300:600","TRA:400:800"];eventcount=[1,5];number=%(n)d}
+Random{eventset=["DEL:100:200,INV:300:600","INS:100:1000,NML:100:200","NML:100:200,INV:300:600","DUP:300:600","TRA:400:800"];eventcount=[4,12];number=%(n)d}
+'''
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 METRIC = 'aligned Gbp/s (whole node) + reads/s, 15 kb ONT-shape reads vs hg38-size ref, 1/2/4/8 MI355X'      # BASELINE.json
 
@@ -74,11 +86,13 @@ def main():
     ap.add_argument('--streams', type=int, default=5, help='batches in flight per GPU (vacmap_amd.pipeline)')
     ap.add_argument('--window-batches', type=int, default=16, help='length binning window of the scheduler, in batches')
     ap.add_argument('--arrival-order', action='store_true', help='no length binning: batches in arrival order (measured once for comparison)')
-    ap.add_argument('--host-input', action='store_true', help='also time the same batches handed over as HOST buffers (vm_align_batch uploads them: the PCIe-inclusive rate; reported next to `value`, never as it)')
+    ap.add_argument('--no-host-input', dest='host_input', action='store_false', help='skip the second timed pass, in which the same batches are handed over as HOST buffers (page-locked, as the '
+                    'product\'s driver holds them) and uploaded inside vm_align_batch: the PCIe-inclusive rate, reported as `host_input` next to `value`, never as it')
     ap.add_argument('--verify', type=int, default=64, help='reads of the first batch cross-checked against the oracle (0 disables)')
     ap.add_argument('--config', choices=sorted(CONFIGS), default='ont_hg38', help='BASELINE.json workload: ont_hg38 = the metric\'s configuration (default), '
-                    'ont_100mb = configs[1], hifi_hg38 = configs[2] (HiFi 18 kb, 0.5 %% error, -mode L -k 19)')
-    ap.add_argument('--extra-configs', default='ont_100mb,hifi_hg38', help='other single-GPU BASELINE configs timed in their own short runs of this script (N = 1 only) and '
+                    'ont_100mb = configs[1], hifi_hg38 = configs[2] (HiFi 18 kb, 0.5 %% error, -mode L -k 19), vacsim_r = configs[4] (vacsim-grammar donor, HiFi-shape reads across the SVs, -mode R)')
+    ap.add_argument('--vacsim-svs', type=int, default=1000, help='vacsim_r: complex SVs per grammar line (six lines)')
+    ap.add_argument('--extra-configs', default='ont_100mb,hifi_hg38,vacsim_r', help='other single-GPU BASELINE configs timed in their own short runs of this script (N = 1 only) and '
                     'reported under extra.configs next to the headline; "" disables')
     ap.add_argument('--extra-steps', type=int, default=15)
     args = ap.parse_args()
@@ -92,6 +106,15 @@ def main():
     from vacmap_amd import synth, pipeline
     t0 = time.time()
     cores = host_cores()
+    # One process per GPU. VMX_FORCE_DIST=1 runs the N-rank code at world 1 as well (process group over nccl = RCCL, index broadcast through a replica
+    # built from the metadata, the all-reduces, the barriers): the one-GPU test of what the driver's 8-GPU run executes (tests/test_gpu_dist.py)
+    force_dist = os.environ.get('VMX_FORCE_DIST') == '1'
+    dist = None
+    if world > 1 or force_dist:
+        import torch, torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29531')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank), rank=rank, world_size=world)
     k = cfg['k']
     extra = None
     if rank == 0 and world == 1 and args.extra_configs:
@@ -100,13 +123,18 @@ def main():
         extra = {'configs': []}
         for name in [c for c in args.extra_configs.split(',') if c and c != args.config]:
             cmd = [sys.executable, os.path.abspath(__file__), '--config', name, '--steps', str(args.extra_steps), '--cpu-sample', '0', '--verify', '16', '--extra-configs', '',
-                   '--streams', str(args.streams), '--reads-per-step', str(args.reads_per_step)]
+                   '--streams', str(args.streams), '--reads-per-step', str(args.reads_per_step), '--no-host-input']
             try:
                 pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
                 d = json.loads(pr.stdout.decode().strip().splitlines()[-1])
                 extra['configs'].append({kk: d[kk] for kk in ('value', 'unit', 'ms_per_step', 'steps', 'reads_per_s', 'failed_reads', 'unmapped_reads', 'oracle_crosscheck', 'per_read', 'stage_ms_per_step',
                                                               'hbm_used_gb', 'local_general_reads')} | {'config': name, 'workload': d['config']['workload'], 'dominant_kernel': d['roofline']['kernel'],
-                                                              'kernel_ms_per_step': {kn: e['ms_per_step'] for kn, e in d['roofline']['kernels'].items()}})
+                                                              'kernel_ms_per_step': {kn: e['ms_per_step'] for kn, e in d['roofline']['kernels'].items()},
+                                                              # the side config's own counters (profiles/r*_pmc_hbm_traffic.json with its workload_id), None until they exist
+                                                              'traffic_over_algorithmic': {kn: e['traffic_over_algorithmic'] for kn, e in d['roofline']['kernels'].items()},
+                                                              'valu_frac_of_calibrated_peak': {kn: (e['valu'] or {}).get('frac_of_calibrated_peak') for kn, e in d['roofline']['kernels'].items()},
+                                                              'ms_per_step_over_valu_floor': (d['roofline']['pipeline_valu'] or {}).get('ms_per_step_over_floor'),
+                                                              'traffic_source': d['roofline']['traffic_source'], 'vacsim': d.get('vacsim')})
             except Exception as e:                                                     # a failed side run is reported, never hidden
                 extra['configs'].append({'config': name, 'error': repr(e)[:300]})
     if cfg['ref_mb'] > 0:
@@ -116,7 +144,27 @@ def main():
         workload = (cfg['what'] % (mean_len, err * 100)).replace('100 Mb', '%.0f Mb' % cfg['ref_mb'])
     else:
         names = list(synth.HG38_NAMES)
-        contigs = synth.make_reference_fast(synth.hg38_like_lengths(), seed=3, threads=max(1, cores // max(1, min(world, 8))))
+        if world > 1:
+            # rank 0 generates the 3.1 Gb once, with every core, into /dev/shm; the other ranks map it (shared pages): eight ranks regenerating it on cores / 8
+            # threads each was the longest part of an 8-rank start
+            lens_c = synth.hg38_like_lengths(); shm = '/dev/shm/vacmapx_bench_ref_seed3_%s.u8' % os.environ.get('MASTER_PORT', '0')
+            if rank == 0:
+                cs = synth.make_reference_fast(lens_c, seed=3, threads=cores)
+                mm = np.lib.format.open_memmap(shm + '.tmp', mode='w+', dtype=np.uint8, shape=(int(sum(lens_c)),))
+                o = 0
+                for c_ in cs:
+                    mm[o:o + len(c_)] = c_; o += len(c_)
+                mm.flush(); del mm, cs
+                os.replace(shm + '.tmp', shm)
+            dist.barrier()
+            whole = np.load(shm, mmap_mode='r')
+            offs = np.concatenate([[0], np.cumsum(lens_c)])
+            contigs = [whole[offs[i]:offs[i + 1]] for i in range(len(lens_c))]
+            dist.barrier()
+            if rank == 0:
+                os.unlink(shm)                        # (the mappings keep the pages until every rank is done)
+        else:
+            contigs = synth.make_reference_fast(synth.hg38_like_lengths(), seed=3, threads=cores)
         workload_id = cfg['tag']
         workload = cfg['what'] % (mean_len, err * 100)
     t_ref = time.time() - t0
@@ -125,9 +173,30 @@ def main():
     # the rank's reads: every (step, rank) draws its own; the product's scheduler forms the batches (length binning inside a bounded
     # window, longest reads first). The K timed steps process exactly the drawn reads, each once.
     pool_cat, pool_off = [], [0]
+    source, around, vacsim_info = contigs, None, None
+    if cfg.get('vacsim'):
+        # configs[4]: the reads come from a DONOR genome (the reference with complex SVs implanted by the vacsim grammar) and are aligned to the reference
+        from vacmap_amd import vacsim
+        tq = time.time()
+        donor, pieces, events = vacsim.implant(contigs, VACSIM_TEXT % {'n': args.vacsim_svs}, seed=172)
+        ev_c, ev_p = [], []
+        for ci_ in range(len(pieces)):                # an event's place in the donor: through the forward piece of its own contig that holds its left end
+            own = [(ss, se, ds) for ds, de, sc, ss, se, st in pieces[ci_] if sc == ci_ and st > 0]
+            keys = np.asarray([ev['start'] for ev in events if ev['contig'] == ci_], dtype=np.int64)
+            if not own or not len(keys):
+                continue
+            ss_a, se_a, ds_a = (np.asarray([o[i] for o in own], dtype=np.int64) for i in range(3))
+            j = np.clip(np.searchsorted(ss_a, keys, side='right') - 1, 0, len(own) - 1)
+            ok = (ss_a[j] <= keys) & (keys <= se_a[j])
+            ev_c += [ci_] * int(ok.sum()); ev_p += (ds_a[j][ok] + keys[ok] - ss_a[j][ok]).tolist()
+        source, around = donor, (np.asarray(ev_c, dtype=np.int64), np.asarray(ev_p, dtype=np.int64))
+        types = {}
+        for ev in events:
+            types[ev['type']] = types.get(ev['type'], 0) + 1
+        vacsim_info = {'complex_svs': 6 * args.vacsim_svs, 'events': len(events), 'events_by_type': types, 'events_reads_are_drawn_around': len(ev_c), 'implant_s': time.time() - tq}
     for s in range(nsteps):
         seed = 1000 + 7919 * (s * world + rank)
-        cat, off, truth = synth.sample_reads_concat(contigs, args.reads_per_step, mean_len=mean_len, err=err, seed=seed, shape=cfg['shape'], min_len=cfg['min_len'])
+        cat, off, truth = synth.sample_reads_concat(source, args.reads_per_step, mean_len=mean_len, err=err, seed=seed, shape=cfg['shape'], min_len=cfg['min_len'], around=around)
         pool_cat.append(cat); pool_off.extend((off[1:] + pool_off[-1]).tolist())
     pool_cat = np.concatenate(pool_cat); pool_off = np.asarray(pool_off, dtype=np.int64)
     lens = np.diff(pool_off)
@@ -136,12 +205,6 @@ def main():
     t_reads = time.time() - t0 - t_ref
 
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
     from vacmap_amd.lib import Context, Index, load
     ctx = Context(local_rank)                 # raises without the HIP library / a GPU: no fallback
     lib = load()
@@ -152,13 +215,18 @@ def main():
     index = Index.from_seqs(ctx, names, contigs, k=k, w=10) if rank == 0 else None
     t_index = time.time() - t1
     t_bcast = None
-    if world > 1:
+    if dist is not None:
         from vacmap_amd.dist import broadcast_index
-        index, t_bcast = broadcast_index(ctx, index, src=0, device=torch.device('cuda', local_rank))
+        index, t_bcast = broadcast_index(ctx, index, src=0, device=torch.device('cuda', local_rank), self_replica=(world == 1))
     n_minimizers = index.n_minimizers()
 
     resident = pipeline.upload_batches(ctx, pool_cat, pool_off, plan)        # inputs resident in HBM before timing
     pipe = pipeline.Pipeline(index, prm, device=local_rank, inflight=max(1, min(args.streams, nsteps)), first_ctx=ctx)
+    if world > 1 and os.environ.get('VMX_SPIN_SYNC') != '1':
+        # N ranks on one host: the contexts' threads SLEEP while they wait for the GPU (the driver's setting) — five spinning threads per rank times eight ranks
+        # would take forty cores for nothing; host threads per rank in the timed region: `streams` mostly-sleeping aligner threads + the main thread
+        for cx in pipe.ctxs:
+            cx.set_blocking_sync(True)
     t_setup = time.time() - t0
 
     def barrier():
@@ -208,10 +276,14 @@ def main():
 
     host_rate = None
     if args.host_input and rank == 0 and world == 1:
+        # the same batches as HOST buffers: page-locked ones from the driver's pool (vacmap_amd.lib.PinnedPool: the driver gathers every batch's reads into
+        # one), so that the upload inside vm_align_batch is a DMA that runs under the other contexts' kernels
+        from vacmap_amd.lib import PinnedPool
+        pinned = PinnedPool(lib, local_rank)
         blobs = []
         for idx in plan:
             ln = lens[idx]; off = np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
-            cat = np.empty(int(off[-1]), np.uint8)
+            cat = pinned.get(int(off[-1]))[:int(off[-1])]
             for j, i in enumerate(idx):
                 cat[off[j]:off[j + 1]] = pool_cat[pool_off[i]:pool_off[i + 1]]
             blobs.append((cat, off))
@@ -222,8 +294,12 @@ def main():
         barrier(); th = time.time()
         pipe.run_host_blobs(blobs, on_result=on_host)
         barrier(); dth = time.time() - th
-        host_rate = {'aligned_Gbp_per_s': hagg['aligned'] / dth / 1e9, 'ms_per_step': dth / len(blobs) * 1e3,
-                     'note': 'same batches, same schedule, reads handed over in pageable host memory (1 B/base) and uploaded inside vm_align_batch'}
+        host_rate = {'aligned_Gbp_per_s': hagg['aligned'] / dth / 1e9, 'ms_per_step': dth / len(blobs) * 1e3, 'over_value': (hagg['aligned'] / dth) / (agg['aligned_bases'] / dt),
+                     'note': 'second timed pass: same batches, same schedule, reads handed over in page-locked HOST memory (1 B/base) and uploaded inside vm_align_batch; '
+                             'results downloaded inside the call in both passes'}
+        for cat, off in blobs:
+            pinned.release(cat)
+        pinned.close()
 
     vals = torch.tensor([dt, float(agg['aligned_bases']), float(agg['n_reads']), float(agg['read_bases']), float(agg['n_failed'])], dtype=torch.float64, device='cuda')
     if dist is not None:
@@ -270,7 +346,7 @@ def main():
         if pj is not None and pj.get('valu_wave_insts_per_step'):
             floor_ms = pj['valu_wave_insts_per_step'] / pj['valu_peak_wave_insts_per_s'] * 1e3
             pipeline_valu = {'wave_insts_per_step': pj['valu_wave_insts_per_step'], 'floor_ms_per_step': floor_ms, 'ms_per_step_over_floor': (dt_all * 1e3 / K) / floor_ms,
-                             'note': 'all kernels of a step: SQ_INSTS_VALU / calibrated issue peak (profiles/r02_valu_calibration.md) against the measured step'}
+                             'note': 'all kernels of a step: SQ_INSTS_VALU / calibrated issue peak (profiles/r04_q_valu_calibration.md; tools/pmc_traffic.py holds the constant) against the measured step'}
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                     'traffic': per_kernel[dom]['traffic'], 'traffic_source': src, 'traffic_over_kernel_algorithmic': per_kernel[dom]['traffic_over_algorithmic'],
                     'avg_kernel_ms_per_step': dom_ms, 'algorithmic_bytes_per_step': algo_bytes / K,
@@ -332,6 +408,10 @@ def main():
             'local_general_reads': int(agg.get('n_local_general', 0)),
             'roofline': roofline, 'cpu_baseline': cpu,
         }
+        if vacsim_info is not None:
+            out['vacsim'] = vacsim_info
+        if dist is not None and world == 1:
+            out['forced_dist_world_1'] = True
         if extra is not None:
             out['extra'] = extra
         if host_rate is not None:

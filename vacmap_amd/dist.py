@@ -37,9 +37,12 @@ def index_blobs(index, device):
     return [blob_tensor(p, n, device) for p, n in index.blobs()]
 
 
-def broadcast_index(ctx, index, src=0, device=None, group=None, chunk_bytes=1 << 30):
+def broadcast_index(ctx, index, src=0, device=None, group=None, chunk_bytes=1 << 30, self_replica=False):
     """every rank calls this; `index` is the built index on rank `src` and None elsewhere. Returns (index on this rank, seconds).
-    Pieces larger than `chunk_bytes` go in slices so that one collective never exceeds a few hundred ms of link time."""
+    Pieces larger than `chunk_bytes` go in slices so that one collective never exceeds a few hundred ms of link time.
+    self_replica (the world-1 test of this code on ONE GPU, VMX_FORCE_DIST=1): rank `src` also builds a replica from the metadata the way a
+    receiving rank does, the collectives run on the source's pieces (zero-copy views of raw hipMalloc blocks handed to RCCL), the replica's
+    pieces — the same kind of view — are filled from them by a torch copy, and the REPLICA is returned."""
     import torch
     import torch.distributed as dist
     rank = dist.get_rank(group)
@@ -48,11 +51,18 @@ def broadcast_index(ctx, index, src=0, device=None, group=None, chunk_bytes=1 <<
     t0 = time.time()
     meta = [index.meta() if rank == src else None]
     dist.broadcast_object_list(meta, src=src, group=group)
+    replica = None
     if rank != src:
         index = Index.from_meta(ctx, meta[0])
+    elif self_replica:
+        replica = Index.from_meta(ctx, meta[0])
     for t in index_blobs(index, device):
         for a in range(0, t.numel(), chunk_bytes):
             dist.broadcast(t[a:a + chunk_bytes], src=src, group=group)
+    if replica is not None:
+        for t, r in zip(index_blobs(index, device), index_blobs(replica, device)):
+            r.copy_(t)
+        index = replica
     if torch.device(device).type == 'cuda':
         torch.cuda.synchronize()
     dist.barrier(group=group)

@@ -354,12 +354,15 @@ def main(argv=None, comm=None):
         sys.exit("Output path must end with .sam, .bam, .sorted.bam, or be '-' for stdout.")
     world, rank, local_rank = 1, 0, 0
     own_group = False
-    if comm is None and int(os.environ.get('WORLD_SIZE', '1')) > 1:
+    # VMX_FORCE_DIST=1: the N-rank start-up at world 1 too (process group over nccl = RCCL, gloo text group, index through a replica built from the
+    # broadcast metadata): what an 8-GPU run executes, testable on one GPU (tests/test_gpu_dist.py)
+    force_dist = comm is None and os.environ.get('VMX_FORCE_DIST') == '1'
+    if comm is None and (int(os.environ.get('WORLD_SIZE', '1')) > 1 or force_dist):
         import torch, torch.distributed as comm
         local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29541')
         torch.cuda.set_device(local_rank)
-        comm.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        comm.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank), rank=int(os.environ.get('RANK', '0')), world_size=int(os.environ.get('WORLD_SIZE', '1')))
         own_group = True
     text_group = None
     if own_group:
@@ -384,11 +387,13 @@ def main(argv=None, comm=None):
     if rank == 0:
         from .indexfile import find_index
         index = find_index(ctx, args.ref, k, w, write=not args.nowriteindex)
-    if world > 1:
+    if world > 1 or force_dist:
         import torch
         from .dist import broadcast_index
         dev = torch.device('cuda', device) if torch.cuda.is_available() else torch.device('cpu')
-        index, _ = broadcast_index(ctx, index, src=0, device=dev)
+        index, t_bc = broadcast_index(ctx, index, src=0, device=dev, self_replica=(world == 1))
+        if force_dist and rank == 0:
+            sys.stderr.write('vacmapx: VMX_FORCE_DIST: process group %s, world %d, index through broadcast_index in %.2f s\n' % (comm.get_backend(), world, t_bc))
     prm = lib.params(args.mode)                     # mode defaults (vacmap:257-296), then the explicit options
     prm.check_num = args.c; prm.global_maxdiff = args.globalmaxdiff; prm.local_maxdiff = args.localmaxdiff
     prm.eqx = 1 if args.eqx else 0; prm.hardclip = 1 if args.H else 0

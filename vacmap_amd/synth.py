@@ -149,10 +149,11 @@ def tostr(a):
     return np.asarray(a, dtype=np.uint8).tobytes().decode()
 
 
-def sample_reads_concat(contigs, n, mean_len=15000, err=0.10, seed=2, shape='ont', min_len=1000, max_len=100000, sd=2000):
+def sample_reads_concat(contigs, n, mean_len=15000, err=0.10, seed=2, shape='ont', min_len=1000, max_len=100000, sd=2000, around=None):
     """Vectorised variant of sample_reads for large batches: returns (uint8 concatenation, int64 offsets[n+1], truth arrays).
     Same read model (Gamma(2, mean/2) or Normal lengths, uniform start, 50/50 strand, i.i.d. errors 4:3:3) but all reads of
-    the batch are mutated in one pass over the concatenated fragments."""
+    the batch are mutated in one pass over the concatenated fragments. around = (contig indices, positions): every read is drawn
+    ACROSS one of these places, picked at random, which lies 20-80 % into the read (reads over the implanted SVs of a donor genome)."""
     rng = np.random.default_rng(seed)
     lens_c = np.array([len(c) for c in contigs], dtype=np.int64)
     cum = np.concatenate([[0], np.cumsum(lens_c)])
@@ -161,7 +162,13 @@ def sample_reads_concat(contigs, n, mean_len=15000, err=0.10, seed=2, shape='ont
     else:
         L = np.maximum(rng.normal(mean_len, sd, size=n), min_len).astype(np.int64)
     ci = np.zeros(n, np.int64); st = np.zeros(n, np.int64)
-    for i in range(n):
+    if around is not None:
+        pick = rng.integers(0, len(around[0]), size=n)
+        ci = np.asarray(around[0], dtype=np.int64)[pick]
+        L = np.minimum(L, lens_c[ci])
+        st = np.asarray(around[1], dtype=np.int64)[pick] - (L * rng.uniform(0.2, 0.8, size=n)).astype(np.int64)
+        st = np.clip(st, 0, lens_c[ci] - L)
+    for i in range(n if around is None else 0):
         while True:
             g = int(rng.integers(0, cum[-1]))
             c = int(np.searchsorted(cum, g, side='right') - 1)
