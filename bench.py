@@ -291,15 +291,23 @@ def main():
 
         def on_host(i, st):
             hagg['aligned'] += st['aligned_bases']
+        prefetch = os.environ.get('VMX_BENCH_HOST_PREFETCH', '1') != '0'
+        if prefetch:
+            pipe.upload_slots(max(blobs, key=lambda b: int(b[1][-1])))          # the uploader's context and its reusable device slots, sized like the work pools before anything is timed
         barrier(); th = time.time()
-        pipe.run_host_blobs(blobs, on_result=on_host)
+        pipe.run_host_blobs(blobs, on_result=on_host, prefetch=prefetch)
         barrier(); dth = time.time() - th
         host_rate = {'aligned_Gbp_per_s': hagg['aligned'] / dth / 1e9, 'ms_per_step': dth / len(blobs) * 1e3, 'over_value': (hagg['aligned'] / dth) / (agg['aligned_bases'] / dt),
-                     'note': 'second timed pass: same batches, same schedule, reads handed over in page-locked HOST memory (1 B/base) and uploaded inside vm_align_batch; '
-                             'results downloaded inside the call in both passes'}
+                     'note': 'second timed pass: same batches, same schedule, reads handed over in page-locked HOST memory (1 B/base); ' + (
+                             'an uploader thread with a context of its own streams them into HBM ahead of the aligning contexts (vm_reads_reupload, at most streams + 2 batches ahead), ' if prefetch else
+                             'uploaded inside vm_align_batch in front of the batch\'s own kernels, ') + 'results downloaded inside the call in both passes'}
         for cat, off in blobs:
             pinned.release(cat)
         pinned.close()
+        if os.environ.get('VMX_BENCH_REPEAT_RESIDENT') == '1':       # tuning aid: the resident pass once more, AFTER the host pass (is a later pass slower whatever it does?)
+            barrier(); tr = time.time()
+            pipe.run_resident(resident, want_records=False, on_result=None)
+            barrier(); host_rate['resident_again_ms_per_step'] = (time.time() - tr) / len(resident) * 1e3
 
     vals = torch.tensor([dt, float(agg['aligned_bases']), float(agg['n_reads']), float(agg['read_bases']), float(agg['n_failed'])], dtype=torch.float64, device='cuda')
     if dist is not None:

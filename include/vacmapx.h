@@ -252,6 +252,9 @@ int vm_align_batch(vm_ctx*, const vm_index*, const vm_params*, int64_t n_reads, 
  * vm_reads_upload copies host reads to the device once; vm_align_resident runs the path on them. */
 typedef struct vm_reads vm_reads;
 int vm_reads_upload(vm_ctx*, int64_t n_reads, const char* seqs, const int64_t* offsets, vm_reads** out);
+/* upload another batch into an existing reads object: its device buffers are reused (grow-only); no alignment of it may be in flight. A host thread with a context of
+ * its own streams batches into HBM ahead of the aligning contexts — the upload of batch i + 1 runs under the kernels of batch i */
+int vm_reads_reupload(vm_ctx*, vm_reads*, int64_t n_reads, const char* seqs, const int64_t* offsets);
 void vm_reads_free(vm_reads*);
 int vm_align_resident(vm_ctx*, const vm_index*, const vm_params*, const vm_reads*, vm_record** recs, int64_t* n_recs,
                       char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats);

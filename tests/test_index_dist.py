@@ -503,3 +503,26 @@ def test_driver_mode_asm_ignores_c_and_maxdivergence_reads_bam(ctx, tmp_path, mo
     assert seen and all(s == (-1, 1.0, 1) for s in seen), seen
     body = [l.split('\t')[0] for l in open(out) if not l.startswith('@')]
     assert sorted(set(body)) == ['k0', 'k1']
+
+
+def test_host_blobs_prefetch_uploader_matches_inline_upload(ctx, oracle):
+    """Pipeline.run_host_blobs(prefetch=True): an uploader thread streams the batches into reusable device slots (vm_reads_reupload) ahead of the
+    aligning contexts; per-batch results equal the inline-upload path's (same aligned bases, records and reads per batch), slots are reused"""
+    from vacmap_amd import synth, pipeline
+    from vacmap_amd.lib import Index
+    contigs = synth.make_reference([60000], seed=7)
+    gi = Index.from_seqs(ctx, ['c'], [synth.tostr(contigs[0])], k=15, w=10)
+    prm = ctx.lib.params('H')
+    blobs = []
+    for b in range(5):
+        cat, off, _ = synth.sample_reads_concat(contigs, 3 + b % 2, mean_len=1500, err=0.08, seed=100 + b, min_len=600, max_len=3000)
+        blobs.append((cat, off))
+    pipe = pipeline.Pipeline(gi, prm, inflight=2, first_ctx=ctx)
+    got = {}
+    for pf in (False, True):
+        res = {}
+        pipe.run_host_blobs(blobs, on_result=lambda i, st: res.__setitem__(i, (st['n_reads'], st['aligned_bases'], st['n_records'])), prefetch=pf)
+        got[pf] = res
+    assert got[True] == got[False] and len(got[True]) == 5 and all(v[1] > 0 for v in got[True].values())
+    assert len(pipe._up[1]) == 4                       # inflight + 2 slots served five batches
+    pipe.close()

@@ -672,6 +672,18 @@ int vm_reads_upload(vm_ctx* c, int64_t n, const char* seqs, const int64_t* offse
     *out = R;
     return VM_OK;
 }
+// the same into an existing object (its device buffers are kept and only grow): an uploader that streams batches ahead of the aligning contexts
+// cycles a few of these instead of paying a hipMalloc / hipFree pair per batch (hipFree waits for the whole device). No alignment of R may be in flight.
+int vm_reads_reupload(vm_ctx* c, vm_reads* R, int64_t n, const char* seqs, const int64_t* offsets) {
+    if (!c || !R) { set_error("no context / reads object"); return VM_ERR_NO_CTX; }
+    VMX_HIP(hipSetDevice(c->device));
+    R->n = n; R->h_off.assign(offsets, offsets + n + 1);
+    const int64_t tot = offsets[n];
+    VMX_TRY(upload(R->raw, seqs, (size_t)tot, c->stream)); VMX_TRY(R->codes.reserve((size_t)tot + 64)); VMX_TRY(upload(R->off, offsets, (size_t)n + 1, c->stream));
+    if (tot) LAUNCH1D(k_encode, tot, R->raw.as<char>(), R->codes.as<uint8_t>(), tot);
+    VMX_HIP(vmx_stream_sync(c));
+    return VM_OK;
+}
 void vm_reads_free(vm_reads* R) { if (!R) return; R->raw.release(); R->codes.release(); R->off.release(); delete R; }
 
 int vm_align_resident(vm_ctx* c, const vm_index* mi, const vm_params* prm, const vm_reads* R, vm_record** recs, int64_t* n_recs, char** cigar_blob,

@@ -173,6 +173,7 @@ class VmxLib:
         L.vm_fastx_read.argtypes = [vp, i64, i64] + [P(vp), P(P(i64))] * 4; L.vm_fastx_read.restype = i64
         L.vm_reads_upload.argtypes = [vp, i64, cp, vp, P(vp)]
         L.vm_reads_free.argtypes = [vp]
+        L.vm_reads_reupload.argtypes = [vp, vp, i64, vp, vp]
         L.vm_align_resident.argtypes = [vp, vp, P(Params), vp, P(P(Record)), P(i64), P(vp), vp, P(BatchStats)]
 
     def err(self):
@@ -208,7 +209,7 @@ class Context:
         self.lib = lib or load()
         h = C.c_void_p()
         self.lib.check(self.lib.L.vm_ctx_create(device, C.byref(h)))
-        self.h = h
+        self.h = h; self.device = int(device)
 
     def set_inflight(self, n_contexts):
         """tell the context how many contexts share its GPU (vm_ctx_set_inflight)"""
@@ -657,6 +658,14 @@ class ResidentReads:
         h = C.c_void_p()
         ctx.lib.check(ctx.lib.L.vm_reads_upload(ctx.h, self.n, s, off.ctypes.data, C.byref(h)))
         self.h = h
+
+    def reupload(self, concat, offsets, ctx=None):
+        """another batch into this object's device buffers (vm_reads_reupload): `concat` a uint8 array (page-locked memory makes the copy a DMA), no
+        alignment of this object in flight"""
+        arr = _u8(concat); off = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(off) - 1
+        self.ctx.lib.check(self.ctx.lib.L.vm_reads_reupload((ctx or self.ctx).h, self.h, n, arr.ctypes.data, off.ctypes.data))
+        self.n = n; self.bases = int(off[-1])
 
     def align(self, index, prm, want_records=True, ctx=None):
         """ctx: the context (streams + work pools) to run on; default = the one that uploaded the reads"""

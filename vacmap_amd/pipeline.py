@@ -76,11 +76,16 @@ class Pipeline:
         self.index, self.prm = index, prm
         self.inflight = max(1, int(inflight))
         first = first_ctx or index.ctx
+        self.device = device
         self.ctxs = [first] + [Context(device, lib=first.lib) for _ in range(self.inflight - 1)]
         for cx in self.ctxs:
             cx.set_inflight(self.inflight)
 
     def close(self):
+        if getattr(self, '_up', None) is not None:
+            for sl in self._up[1]:
+                sl.close()
+            self._up[0].close(); self._up = None
         for cx in self.ctxs[1:]:
             cx.close()
         self.ctxs = self.ctxs[:1]
@@ -198,10 +203,67 @@ class Pipeline:
         """batches: list of lists of read sequences (host memory; uploaded by vm_align_batch). on_result(i, (status, records, stats))"""
         self._run(len(batches), lambda i, cx: align_batch(cx, self.index, self.prm, batches[i]), on_result)
 
-    def run_host_blobs(self, blobs, on_result=None):
-        """blobs: list of (uint8 array of the batch's reads back to back, int64 offsets[n + 1]) in HOST memory: vm_align_batch uploads them
-        inside the call (the PCIe-inclusive path). on_result(i, stats dict)"""
+    def upload_slots(self, largest_blob, n_slots=None):
+        """the uploader's side of run_host_blobs(prefetch=True): a context of its own (its stream carries the copies and the base encoding) and a few
+        reusable ResidentReads sized by the largest batch, made before anything is timed (like the contexts' work pools)"""
+        if getattr(self, '_up', None) is None:
+            first = self.ctxs[0]
+            up_ctx = Context(self.device, lib=first.lib)
+            self._up = (up_ctx, [ResidentReads(up_ctx, concat=largest_blob[0], offsets=largest_blob[1]) for _ in range(n_slots or self.inflight + 2)])
+        return self._up
+
+    def run_host_blobs(self, blobs, on_result=None, prefetch=False):
+        """blobs: list of (uint8 array of the batch's reads back to back, int64 offsets[n + 1]) in HOST memory (the PCIe-inclusive path).
+        prefetch=False: vm_align_batch uploads a batch inside the call, in front of its own kernels. prefetch=True: an uploader thread with a context of
+        its own streams the batches into HBM ahead of the aligning contexts (vm_reads_reupload into a few reusable slots, at most inflight + 2 batches
+        ahead), so the copy of batch i + 1 runs under the kernels of batch i; the aligners then run vm_align_resident. on_result(i, stats dict)"""
         from .lib import align_batch_raw
+        if prefetch and blobs:
+            import queue
+            big = max(blobs, key=lambda b: int(b[1][-1]))
+            up_ctx, slots = self.upload_slots(big)
+            free_q, ready_q = queue.Queue(), queue.Queue()
+            for sl in slots:
+                free_q.put(sl)
+            errs = []
+
+            def producer():
+                try:
+                    for i, (cat, off) in enumerate(blobs):
+                        sl = free_q.get()
+                        if sl is None:
+                            return
+                        sl.reupload(cat, off, ctx=up_ctx)
+                        ready_q.put((i, sl))
+                except BaseException as e:
+                    errs.append(e)
+                finally:
+                    for _ in range(self.inflight):
+                        ready_q.put(None)
+            lock = threading.Lock()
+
+            def consumer(cx):
+                try:
+                    while not errs:
+                        item = ready_q.get()
+                        if item is None:
+                            return
+                        i, sl = item
+                        _st, _r, sd = sl.align(self.index, self.prm, want_records=False, ctx=cx)
+                        free_q.put(sl)
+                        if on_result is not None:
+                            with lock:
+                                on_result(i, sd)
+                except BaseException as e:
+                    errs.append(e); free_q.put(None)
+            th = [threading.Thread(target=producer)] + [threading.Thread(target=consumer, args=(cx,)) for cx in list(self.ctxs[:self.inflight])]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            if errs:
+                raise errs[0]
+            return
 
         def job(i, cx):
             raw = align_batch_raw(cx, self.index, self.prm, blobs[i][0], blobs[i][1])
