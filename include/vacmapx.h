@@ -302,6 +302,9 @@ int vm_sam_emit(const vm_index*, const vm_sam_opts*, int64_t n_reads, const char
 /* entries idx[0..n) of a blob copied back to back (out may be NULL to size it): returns the byte count, out_off[n + 1] */
 int64_t vm_blob_gather(const char* blob, const int64_t* off, const int64_t* idx, int64_t n, char* out, int64_t* out_off);
 /* the same over several blobs: output entry j = entry idx[j] of blob part[j]; returns the bytes written (out must hold them) */
+/* the same merge into a regular file through a shared mapping, copied by nthreads threads: the file is extended from file_off (its current end) by the
+ * merged size. Returns the bytes written, -1 on error, -2 when fd cannot be mapped (pipe, terminal): use vm_blob_write_parts then */
+int64_t vm_blob_write_parts_mmap(int fd, int64_t file_off, const char* const* blobs, const int64_t* const* offs, const int32_t* part, const int64_t* idx, int64_t n, int nthreads);
 int64_t vm_blob_gather_parts(const char* const* blobs, const int64_t* const* offs, const int32_t* part, const int64_t* idx, int64_t n, char* out);
 /* page-locked host memory for the read blobs a caller hands to vm_align_batch: the upload is then a DMA the host thread does not wait for
  * (from pageable memory the runtime stages it through bounce buffers on the calling thread: ~10 ms per 60 MB batch, more under memory load) */

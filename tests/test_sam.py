@@ -174,6 +174,29 @@ def test_blob_gather_parts_restores_input_order():
         assert w == sum(len(t) for t in big)
         f.seek(0)
         assert f.read() == b'head\n' + b''.join(big)
+    # the same through the shared mapping (vm_blob_write_parts_mmap: several threads copy into the file's own pages; the file grows from an offset
+    # that is not page-aligned, twice in a row), then text written the ordinary way behind it
+    huge = [bytes(rng.integers(65, 91, int(rng.integers(2000, 9000)), dtype=np.uint8)) for _ in range(6000)]      # ~33 MB: above the one-thread limit
+    perm3 = rng.permutation(6000)
+    b3, o3, k3 = [], [], []
+    for a, b in ((0, 3100), (3100, 6000)):
+        idx = np.sort(perm3[a:b])
+        b3.append(np.frombuffer(b''.join(huge[i] for i in idx), dtype=np.uint8)); k3.append(idx.astype(np.int64))
+        o3.append(np.concatenate([[0], np.cumsum([len(huge[i]) for i in idx])]).astype(np.int64))
+    with tempfile.TemporaryFile() as f:
+        f.write(b'head\n'); f.flush()
+        w = VL.blob_write_parts(L, f.fileno(), b3, o3, k3, file_off=5, nthreads=4)
+        w2 = VL.blob_write_parts(L, f.fileno(), b2, o2, k2, file_off=5 + w, nthreads=4)
+        assert w == sum(len(t) for t in huge) and w2 == sum(len(t) for t in big)
+        f.write(b'tail\n'); f.flush()
+        f.seek(0)
+        assert f.read() == b'head\n' + b''.join(huge) + b''.join(big) + b'tail\n'
+    r_, w_ = os.pipe()                                             # a descriptor that cannot be mapped: the writev stream takes over
+    try:
+        assert VL.blob_write_parts(L, w_, [np.frombuffer(b'abc', dtype=np.uint8)], [np.array([0, 3], np.int64)], [np.array([0], np.int64)], file_off=0) == 3
+        assert os.read(r_, 10) == b'abc'
+    finally:
+        os.close(r_); os.close(w_)
 
 
 def _asm_sam_entries():

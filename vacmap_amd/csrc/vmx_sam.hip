@@ -19,6 +19,9 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <sys/uio.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <algorithm>
 #include <errno.h>
 
 using namespace vmx;
@@ -430,6 +433,50 @@ int64_t vm_blob_write_parts(int fd, const char* const* blobs, const int64_t* con
     }
     if (!flush()) { set_error("write failed"); return -1; }
     return total;
+}
+
+// The same merge written into a REGULAR file through a shared mapping, by several threads: the file is extended by the window's size, the new
+// range is mapped, and `nthreads` threads copy the lines to their places (the page faults and the copies run in parallel; buffered write() calls
+// to one file serialise on its inode lock, and one thread moves ~5 GB/s of cold text — less than one GPU produces: at 4 aligned Gbp/s the SAM
+// text is ~8 GB/s). file_off: the current end of the file (the caller keeps count). Returns the bytes written, -1 on an error, -2 when the
+// descriptor cannot be mapped (a pipe, a terminal, a file system without mmap): the caller falls back to vm_blob_write_parts.
+int64_t vm_blob_write_parts_mmap(int fd, int64_t file_off, const char* const* blobs, const int64_t* const* offs, const int32_t* part, const int64_t* idx, int64_t n, int nthreads) {
+    std::vector<int64_t> at((size_t)n + 1);
+    int64_t w = 0;
+    for (int64_t j = 0; j < n; ++j) { const int64_t* off = offs[part[j]]; at[(size_t)j] = w; w += off[idx[j] + 1] - off[idx[j]]; }
+    at[(size_t)n] = w;
+    if (w == 0) return 0;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return -2;
+    if (ftruncate(fd, (off_t)(file_off + w)) != 0) return -2;
+    const long pg = sysconf(_SC_PAGESIZE);
+    const int64_t map_off = file_off / pg * pg, lead = file_off - map_off;
+    void* m = mmap(nullptr, (size_t)(w + lead), PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)map_off);
+    if (m == MAP_FAILED) { (void)!ftruncate(fd, (off_t)file_off); return -2; }
+    char* out = (char*)m + lead;
+    auto copy = [&](int64_t j0, int64_t j1) {
+        for (int64_t j = j0; j < j1; ++j) {
+            const int64_t* off = offs[part[j]];
+            const int64_t a = off[idx[j]], b = off[idx[j] + 1];
+            if (b > a) memcpy(out + at[(size_t)j], blobs[part[j]] + a, (size_t)(b - a));
+        }
+    };
+    const int T = (w > ((int64_t)16 << 20) && n >= 64) ? std::max(1, std::min(nthreads, 16)) : 1;
+    if (T == 1) copy(0, n);
+    else {
+        std::vector<std::thread> th;
+        int64_t j0 = 0;
+        for (int t = 0; t < T; ++t) {                            // cut by bytes, not by entries
+            const int64_t target = w * (t + 1) / T;
+            int64_t j1 = t + 1 == T ? n : (int64_t)(std::lower_bound(at.begin() + j0, at.begin() + n, target) - at.begin());
+            if (j1 < j0) j1 = j0;
+            th.emplace_back(copy, j0, j1);
+            j0 = j1;
+        }
+        for (auto& t : th) t.join();
+    }
+    munmap(m, (size_t)(w + lead));
+    return w;
 }
 
 int64_t vm_blob_gather_parts(const char* const* blobs, const int64_t* const* offs, const int32_t* part, const int64_t* idx, int64_t n, char* out) {

@@ -227,7 +227,7 @@ def _open_output(path):
     if path == '-':
         return sys.stdout.buffer, None
     if path.endswith('.sam'):
-        return open(path, 'wb'), None
+        return open(path, 'w+b'), None            # (read + write: the writer maps the file's end to copy a window's lines in by several threads)
     if not shutil.which('samtools'):
         sys.exit('writing %s needs the samtools binary on PATH (the reference pipes SAM text into it too); write .sam instead' % path)
     cmd = ['samtools', 'sort', '-@', '8', '--write-index', '-o', path, '-'] if path.endswith('sorted.bam') else ['samtools', 'view', '-b', '-@', '8', '-o', path, '-']
@@ -436,9 +436,9 @@ def main(argv=None, comm=None):
     part_path = '%s.part%03d' % (args.o, rank) if range_mode else None
     out, proc = (None, None)
     if range_mode and rank != 0:
-        out = open(part_path, 'wb')
+        out = open(part_path, 'w+b')
     if rank == 0:
-        out, proc = (open(part_path, 'wb'), None) if range_mode else _open_output(args.o)
+        out, proc = (open(part_path, 'w+b'), None) if range_mode else _open_output(args.o)
         for ln in sam.header_lines([(n, ln_) for n, ln_ in zip(names, index.lens)], ' '.join(sys.argv if argv is None else ['vacmapx'] + list(argv)), rg):
             out.write(ln.encode() + b'\n')
     if args.mode == 'asm':
@@ -635,6 +635,9 @@ def main(argv=None, comm=None):
         except Exception:
             out_fd = None
 
+    mmap_out = os.environ.get('VMX_DRIVER_MMAP_OUT', '1') != '0'
+    write_threads = max(1, int(os.environ.get('VMX_WRITE_THREADS', '0')) or min(6, max(2, args.t // 3)))
+
     def writer():
         """a window's lines in input order (one more gather over the concatenated batch texts) while later windows align and emit"""
         try:
@@ -658,9 +661,15 @@ def main(argv=None, comm=None):
                         parts = []
                 counts['lines'] += nl; counts['skipped'] += ns
                 if parts:
-                    if out_fd is not None:           # straight from the batches' texts to the file: writev, no assembled copy of the window
-                        out.flush()
-                        blob_write_parts(lib, out_fd, [p[1] for p in parts], [p[2] for p in parts], [p[0] for p in parts])
+                    if out_fd is not None:           # straight from the batches' texts to the file, no assembled copy of the window: into the file's own pages
+                        out.flush()                  # by a few threads when it is a regular file (mmap), else one writev stream
+                        pos = None
+                        if mmap_out:
+                            try:
+                                pos = os.lseek(out_fd, 0, os.SEEK_CUR)
+                            except OSError:
+                                pos = None
+                        blob_write_parts(lib, out_fd, [p[1] for p in parts], [p[2] for p in parts], [p[0] for p in parts], file_off=pos, nthreads=write_threads)
                     else:
                         txt = blob_gather_parts(lib, [p[1] for p in parts], [p[2] for p in parts], [p[0] for p in parts])
                         out.write(memoryview(txt))

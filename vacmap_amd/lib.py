@@ -169,6 +169,7 @@ class VmxLib:
         L.vm_pinned_alloc.argtypes = [i64, C.c_int]; L.vm_pinned_alloc.restype = vp
         L.vm_pinned_free.argtypes = [vp]; L.vm_pinned_free.restype = None
         L.vm_blob_gather_parts.argtypes = [vp, vp, vp, vp, i64, vp]; L.vm_blob_gather_parts.restype = i64
+        L.vm_blob_write_parts_mmap.argtypes = [C.c_int, i64, vp, vp, vp, vp, i64, C.c_int]; L.vm_blob_write_parts_mmap.restype = i64
         L.vm_fastx_open.argtypes = [cp, P(vp)]; L.vm_fastx_close.argtypes = [vp]; L.vm_fastx_open_range.argtypes = [cp, i64, i64, P(vp)]
         L.vm_fastx_read.argtypes = [vp, i64, i64] + [P(vp), P(P(i64))] * 4; L.vm_fastx_read.restype = i64
         L.vm_reads_upload.argtypes = [vp, i64, cp, vp, P(vp)]
@@ -593,11 +594,20 @@ def _parts_order(blobs, offs, order_keys):
     return np.ascontiguousarray(part[order]), np.ascontiguousarray(local[order])
 
 
-def blob_write_parts(lib, fd, blobs, offs, order_keys):
-    """blob_gather_parts written to the file descriptor `fd` (writev, no assembled copy): returns the bytes written"""
+def blob_write_parts(lib, fd, blobs, offs, order_keys, file_off=None, nthreads=4):
+    """blob_gather_parts written to the file descriptor `fd`: returns the bytes written. file_off = the current end of a regular file: the lines are
+    copied by `nthreads` threads straight into the file's pages (vm_blob_write_parts_mmap; the descriptor's own position is moved past them); a
+    descriptor that cannot be mapped, or file_off None: one writev stream, no assembled copy"""
     blobs = [_u8(b) for b in blobs]; offs = [np.ascontiguousarray(o, dtype=np.int64) for o in offs]
     part, local = _parts_order(blobs, offs, order_keys)
     bp = (C.c_void_p * len(blobs))(*[b.ctypes.data for b in blobs]); op = (C.c_void_p * len(offs))(*[o.ctypes.data for o in offs])
+    if file_off is not None:
+        w = lib.L.vm_blob_write_parts_mmap(int(fd), int(file_off), bp, op, part.ctypes.data, local.ctypes.data, len(local), int(nthreads))
+        if w >= 0:
+            os.lseek(int(fd), int(file_off) + int(w), os.SEEK_SET)
+            return int(w)
+        if w == -1:
+            raise VmxError(-1, lib.err())
     w = lib.L.vm_blob_write_parts(int(fd), bp, op, part.ctypes.data, local.ctypes.data, len(local))
     if w < 0:
         raise VmxError(-1, lib.err())
