@@ -21,12 +21,14 @@ def main():
     ap.add_argument('--t', type=int, default=16); ap.add_argument('--out', default=None); ap.add_argument('--tmp', default='/tmp/vmx_driver_bench')
     ap.add_argument('--replicate', type=int, default=1, help='write the generated reads this many times under different names (a long input from a short '
                     'generation: --reads 163840 --replicate 10 = 1.6 M reads, ~48 GB of FASTQ; use --tmp /dev/shm/... for that); the quarter run is skipped')
-    ap.add_argument('--inflight', type=int, default=5)
+    ap.add_argument('--inflight', type=int, default=5); ap.add_argument('--sam-dir', default=None, help='directory of the SAM output (default: --tmp)')
     args = ap.parse_args()
     from vacmap_amd import synth, driver, pipeline
     os.makedirs(args.tmp, exist_ok=True)
+    if args.sam_dir:
+        os.makedirs(args.sam_dir, exist_ok=True)
     ref = synth.make_reference([int(args.ref_mb * 1e6)], seed=1)[0]
-    fa = os.path.join(args.tmp, 'ref.fa'); fq = os.path.join(args.tmp, 'reads.fq'); sam_path = os.path.join(args.tmp, 'out.sam')
+    fa = os.path.join(args.tmp, 'ref.fa'); fq = os.path.join(args.tmp, 'reads.fq'); sam_path = os.path.join(args.sam_dir or args.tmp, 'out.sam')
     with open(fa, 'wb') as f:
         f.write(b'>chr1\n'); f.write(ref.tobytes()); f.write(b'\n')
     cat, off = [], [0]
