@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--replicate', type=int, default=1, help='write the generated reads this many times under different names (a long input from a short '
                     'generation: --reads 163840 --replicate 10 = 1.6 M reads, ~48 GB of FASTQ; use --tmp /dev/shm/... for that); the quarter run is skipped')
     ap.add_argument('--inflight', type=int, default=5); ap.add_argument('--sam-dir', default=None, help='directory of the SAM output (default: --tmp)')
+    ap.add_argument('--driver-args', default='', help='extra arguments for the driver command line, e.g. "--window-batches 16"')
     args = ap.parse_args()
     from vacmap_amd import synth, driver, pipeline
     os.makedirs(args.tmp, exist_ok=True)
@@ -60,7 +61,7 @@ def main():
         env = dict(os.environ, VMX_DRIVER_TIMING='1', PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
         t0_ = time.time()
         pr = subprocess.run([sys.executable, '-m', 'vacmap_amd.driver', '-ref', fa, '-read', reads, '-mode', 'H', '-o', sam_path, '-t', str(args.t), '--nowriteindex', '--force',
-                             '--inflight', str(args.inflight)], env=env, stderr=subprocess.PIPE, text=True)
+                             '--inflight', str(args.inflight)] + args.driver_args.split(), env=env, stderr=subprocess.PIPE, text=True)
         dt_ = time.time() - t0_
         tm_ = {}
         progress.clear()

@@ -212,7 +212,7 @@ def build_parser():
     for a, _ in RG_ARGS:
         p.add_argument('--' + a, dest=a.replace('-', '_'))
     p.add_argument('--device', type=int, default=None); p.add_argument('--batch-reads', type=int, default=4096)
-    p.add_argument('--window-batches', type=int, default=8); p.add_argument('--inflight', type=int, default=5)
+    p.add_argument('--window-batches', type=int, default=4); p.add_argument('--inflight', type=int, default=5)
     # N ranks (torchrun): 'range' = every rank parses its own byte range of each plain FASTA / FASTQ input and writes its own part of the SAM file
     # (<out>.partNNN, concatenated by rank 0 at the end unless --parts); 'batch' = every rank parses everything and keeps every N-th batch, rank 0
     # gathers the text (compressed / BAM input, stdout or BAM output); 'auto' picks 'range' whenever input and output allow it
@@ -539,7 +539,7 @@ def main(argv=None, comm=None):
     tm = {'setup': time.time() - t_start, 'wait_input': 0.0, 'assemble_write': 0.0, 'job_gather': 0.0, 'job_align': 0.0, 'job_emit': 0.0}
     tml = threading.Lock()
     errs = []
-    n_slots = max(2, int(os.environ.get('VMX_DRIVER_WINDOWS', '3')))
+    n_slots = max(2, int(os.environ.get('VMX_DRIVER_WINDOWS', '10')))      # (1.6 M-read run, profiles/r05_driver_long_*: 3 windows of 8 batches 145 k reads/s, 6 x 8: 180 k, 4 x 16: 195 k, 10 x 4: 205 k)
     slots = threading.Semaphore(n_slots)                # windows in memory at a time (input blobs + SAM text)
     oq = queue.Queue()                                  # windows in input order -> writer
     emit_pool = ThreadPoolExecutor(max_workers=emit_jobs)
