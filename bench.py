@@ -80,6 +80,7 @@ def main():
     ap.add_argument('--reads-per-step', type=int, default=4096)
     ap.add_argument('--ref-mb', type=float, default=0.0, help='0 (default): hg38-size 3.1 Gb / 24 contigs; M > 0: one contig of M Mb (100 = BASELINE configs[1])')
     ap.add_argument('--mean-len', type=int, default=0, help='0: the config\'s (15000 ONT, 18000 HiFi)')
+    ap.add_argument('--max-len', type=int, default=100000, help='longest read drawn (ONT shape: the Gamma tail is clipped here; 200000 with --mean-len 30000 = the ultra-long robustness run)')
     ap.add_argument('--err', type=float, default=None, help='default: the config\'s (0.10 ONT, 0.005 HiFi)')
     ap.add_argument('--cpu-sample', type=int, default=96, help='minimum reads for the CPU baseline leg (rank 0, N=1 only); 0 disables')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='target wall time of the CPU baseline leg (the sample is sized by a pilot)')
@@ -167,6 +168,8 @@ def main():
             contigs = synth.make_reference_fast(synth.hg38_like_lengths(), seed=3, threads=cores)
         workload_id = cfg['tag']
         workload = cfg['what'] % (mean_len, err * 100)
+    if args.mean_len or args.max_len != 100000 or args.err is not None:
+        workload_id += '_mean%d_max%d_err%g' % (mean_len, args.max_len, err)          # (not the BASELINE shape: no PMC summary of another shape may stand in)
     t_ref = time.time() - t0
 
     nsteps = args.steps
@@ -196,7 +199,7 @@ def main():
         vacsim_info = {'complex_svs': 6 * args.vacsim_svs, 'events': len(events), 'events_by_type': types, 'events_reads_are_drawn_around': len(ev_c), 'implant_s': time.time() - tq}
     for s in range(nsteps):
         seed = 1000 + 7919 * (s * world + rank)
-        cat, off, truth = synth.sample_reads_concat(source, args.reads_per_step, mean_len=mean_len, err=err, seed=seed, shape=cfg['shape'], min_len=cfg['min_len'], around=around)
+        cat, off, truth = synth.sample_reads_concat(source, args.reads_per_step, mean_len=mean_len, err=err, seed=seed, shape=cfg['shape'], min_len=cfg['min_len'], max_len=args.max_len, around=around)
         pool_cat.append(cat); pool_off.extend((off[1:] + pool_off[-1]).tolist())
     pool_cat = np.concatenate(pool_cat); pool_off = np.asarray(pool_off, dtype=np.int64)
     lens = np.diff(pool_off)
@@ -257,7 +260,7 @@ def main():
                 ok += int((st[j] == 0) == (ost == 0) and mine == [t[1:] for t in orecs])
             verified = '%d/%d' % (ok, nv)
         pipe.warm(resident[longest]); warm_runs += pipe.inflight
-    pipe.trim_to_memory()          # (the product's rule: a context is given up when the sized pools leave < 10 GB of HBM free; not the case at these sizes)
+    ctx_dropped = pipe.trim_to_memory()          # (the product's rule: a context is given up when the sized pools leave < 10 GB of HBM free; not the case at the default sizes)
 
     agg = {}
 
@@ -413,7 +416,7 @@ def main():
             'dp_redo_per_step': agg.get('n_dp_redo', 0) / K, 'dp_redo_tb_bytes_per_step': agg.get('dp_redo_tb_bytes', 0) / K,
             'oracle_crosscheck': verified, 'setup_s': t_setup, 'reference_gen_s': t_ref, 'read_gen_s': t_reads, 'index_build_s': t_index, 'index_broadcast_s': t_bcast,
             'index_minimizers': int(n_minimizers), 'index_mid_occ': int(index.mid_occ), 'oracle_index_build_s': t_oracle_index, 'hbm_used_gb': hbm_used_gb,
-            'local_general_reads': int(agg.get('n_local_general', 0)),
+            'local_general_reads': int(agg.get('n_local_general', 0)), 'contexts_given_up_for_memory': int(ctx_dropped), 'longest_read': int(lens.max()),
             'roofline': roofline, 'cpu_baseline': cpu,
         }
         if vacsim_info is not None:
