@@ -242,7 +242,7 @@ def main():
     # long-running mapper reaches that state after its first large batch). The first pass is cross-checked against the oracle.
     longest = int(np.argmax([lens[p].sum() for p in plan]))
     verified = None; oi = None; t_oracle_index = None
-    warm_runs = 0
+    warm_runs = 0; warm_oom = 0
     for s in range(args.warmup):
         if s == 0 and args.verify > 0 and rank == 0:
             st, recs, _ = resident[longest].align(index, prm, want_records=True, ctx=ctx); warm_runs += 1
@@ -259,8 +259,9 @@ def main():
                 mine = [t[1:] for t in recs if t[0] == j]
                 ok += int((st[j] == 0) == (ost == 0) and mine == [t[1:] for t in orecs])
             verified = '%d/%d' % (ok, nv)
-        pipe.warm(resident[longest]); warm_runs += pipe.inflight
-    ctx_dropped = pipe.trim_to_memory()          # (the product's rule: a context is given up when the sized pools leave < 10 GB of HBM free; not the case at the default sizes)
+        n_before = pipe.inflight
+        warm_oom += pipe.warm(resident[longest]); warm_runs += min(n_before, pipe.inflight + 1)
+    ctx_dropped = warm_oom + pipe.trim_to_memory()          # (the product's rule: a context is given up when the sized pools leave < 10 GB of HBM free; not the case at the default sizes)
 
     agg = {}
 

@@ -164,3 +164,26 @@ def test_pipeline_gives_up_a_context_when_hbm_runs_low():
     assert not p.retire_if_low(p.ctxs[1]) and len(p.ctxs) == 2     # `keep` contexts remain
     p.ctxs = [FakeCtx(50.0) for _ in range(4)]; p.inflight = 4
     assert not p.retire_if_low(p.ctxs[3]) and len(p.ctxs) == 4     # enough memory: nothing happens
+
+
+def test_pipeline_warm_gives_up_contexts_without_memory():
+    """the sizing run of a context that finds no HBM left (VM_ERR_OOM) drops that context and the ones after it; an OOM below `keep` still raises"""
+    import pytest
+    from vacmap_amd import pipeline
+    from vacmap_amd.lib import VmxError
+
+    class FakeCtx:
+        def __init__(self, ok): self.ok, self.closed, self.inflight = ok, False, None
+        def close(self): self.closed = True
+        def set_inflight(self, n): self.inflight = n
+
+    def run(cx):
+        if not cx.ok:
+            raise VmxError(-4, 'out of memory')
+    p = object.__new__(pipeline.Pipeline)
+    p.ctxs = [FakeCtx(True), FakeCtx(True), FakeCtx(True), FakeCtx(False), FakeCtx(True)]; p.inflight = 5
+    gone = p.ctxs[3:]
+    assert p.warm(run=run, keep=2) == 2 and len(p.ctxs) == 3 and p.inflight == 3 and all(c.closed for c in gone) and all(c.inflight == 3 for c in p.ctxs)
+    p.ctxs = [FakeCtx(True), FakeCtx(False), FakeCtx(True)]; p.inflight = 3
+    with pytest.raises(VmxError):
+        p.warm(run=run, keep=2)

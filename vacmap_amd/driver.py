@@ -714,16 +714,14 @@ def main(argv=None, comm=None):
                 ix0 = max(plan0, key=lambda ix: int(np.diff(first['seqs_off'])[ix].sum()))
                 sb0, so0 = blob_gather(lib, first['seqs'], first['seqs_off'], ix0)
 
-                def warm(cx):
-                    try:
-                        align_batch_raw(cx, index, prm, sb0, so0).close()
-                    except BaseException as e:
-                        errs.append(e)
-                wth = [threading.Thread(target=warm, args=(cx,)) for cx in pipe.ctxs]
-                for t_ in wth:
-                    t_.start()
-                for t_ in wth:
-                    t_.join()
+                # (one context after the other: hipMalloc serialises anyway, and a context that finds no memory left for its pools — a first window of
+                # very long reads — is given up with the ones after it instead of failing the run: Pipeline.warm)
+                try:
+                    n_oom = pipe.warm(run=lambda cx: align_batch_raw(cx, index, prm, sb0, so0).close(), keep=2)
+                    if n_oom and rank == 0:
+                        sys.stderr.write('vacmapx: %d of %d batches in flight given up: no HBM left for their work pools\n' % (n_oom, n_oom + pipe.inflight))
+                except BaseException as e:
+                    errs.append(e)
         dropped = pipe.trim_to_memory(float(os.environ.get('VMX_MIN_FREE_GB', '10')))
         if dropped and rank == 0:
             sys.stderr.write('vacmapx: %d of %d batches in flight given up to keep HBM head-room\n' % (dropped, dropped + pipe.inflight))

@@ -272,10 +272,30 @@ class Pipeline:
             return st
         self._run(len(blobs), job, on_result)
 
-    def warm(self, resident):
-        """run every context once on `resident` (the largest batch): sizes the grow-only work pools so that no hipMalloc happens later"""
-        for cx in self.ctxs:
-            resident.align(self.index, self.prm, want_records=False, ctx=cx)
+    def warm(self, resident=None, run=None, keep=1):
+        """run every context once on `resident` (the largest batch), or call run(ctx): sizes the grow-only work pools so that no hipMalloc happens
+        later. A context whose sizing run finds no memory left (VM_ERR_OOM: the pools of a batch of very long reads times the contexts before it) is
+        given up together with the ones after it, as long as `keep` remain — fewer batches in flight, not a failed run. Returns the contexts dropped."""
+        from .lib import VmxError
+        dropped = 0
+        for i, cx in enumerate(list(self.ctxs)):
+            try:
+                if run is not None:
+                    run(cx)
+                else:
+                    resident.align(self.index, self.prm, want_records=False, ctx=cx)
+            except VmxError as e:
+                if e.code != -4 or i < max(1, keep):              # VM_ERR_OOM
+                    raise
+                for c2 in self.ctxs[i:]:
+                    c2.close(); dropped += 1
+                self.ctxs = self.ctxs[:i]
+                break
+        if dropped:
+            self.inflight = len(self.ctxs)
+            for cx in self.ctxs:
+                cx.set_inflight(self.inflight)
+        return dropped
 
 
 def upload_batches(ctx, concat, offsets, plan):
