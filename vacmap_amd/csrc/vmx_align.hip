@@ -656,6 +656,67 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     return VM_OK;
 }
 
+// One call = at most max_bases bases and VMX_MAX_BATCH_READS reads per pass over the path: a larger one is processed as consecutive sub-batches of the same
+// context and its results are concatenated. run_one(a, b, ...) aligns the reads [a, b). A range the device has no memory for (the grow-only pools of
+// this and the other contexts, the index and the reads share the HBM) is cut in two and tried again instead of failing the whole call with VM_ERR_OOM —
+// down to single reads.
+template <class RunOne>
+static int align_in_sub_batches(int64_t n, const int64_t* offsets, int64_t max_bases, RunOne run_one, vm_record** recs, int64_t* n_recs, char** cigar_blob, vm_batch_stats* stats) {
+    if (n <= VMX_MAX_BATCH_READS && offsets[n] - offsets[0] <= max_bases) {
+        const int rc = run_one(0, n, recs, n_recs, cigar_blob, stats);
+        if (rc != VM_ERR_OOM || n <= 1) return rc;
+        free(*recs); free(*cigar_blob);                          // fall through: the batch is cut into pieces that fit
+    }
+    *recs = nullptr; *n_recs = 0; *cigar_blob = nullptr;
+    std::vector<vm_record> all; std::string blob;
+    vm_batch_stats tot; memset(&tot, 0, sizeof tot);
+    std::vector<std::pair<int64_t, int64_t>> work;
+    for (int64_t a = 0; a < n;) {
+        int64_t b = a + 1;                                       // at least one read per sub-batch, whatever its length
+        while (b < n && b - a < VMX_MAX_BATCH_READS && offsets[b + 1] - offsets[a] <= max_bases) ++b;
+        work.emplace_back(a, b); a = b;
+    }
+    for (size_t wi = 0; wi < work.size(); ++wi) {
+        const int64_t a = work[wi].first, b = work[wi].second;
+        vm_record* r = nullptr; int64_t nr = 0; char* cb = nullptr; vm_batch_stats st;
+        const int rc = run_one(a, b, &r, &nr, &cb, &st);
+        if (rc == VM_ERR_OOM && b - a > 1) {
+            free(r); free(cb);
+            vmx::devbuf_retired().flush();                       // parked (outgrown) allocations go back to the device first
+            const int64_t mid = a + (b - a) / 2;
+            work[wi] = std::make_pair(a, mid); work.insert(work.begin() + (std::ptrdiff_t)wi + 1, std::make_pair(mid, b));
+            --wi; continue;
+        }
+        if (rc < 0) { free(r); free(cb); return rc; }
+        int64_t bl = 0; for (int64_t i = 0; i < nr; ++i) bl = std::max(bl, r[i].cigar_off + r[i].cigar_len);
+        for (int64_t i = 0; i < nr; ++i) { vm_record x = r[i]; x.read_idx += (int32_t)a; x.cigar_off += (int64_t)blob.size(); all.push_back(x); }
+        blob.append(cb, (size_t)bl); blob.push_back('\0');
+        free(r); free(cb);
+        {   // counters and times add up; sizes are per call
+            int64_t* d = (int64_t*)&tot; const int64_t* s2 = (const int64_t*)&st;
+            for (size_t i = 0; i < offsetof(vm_batch_stats, ms_total) / 8; ++i) d[i] += s2[i];
+            tot.ms_total += st.ms_total; for (int i = 0; i < 16; ++i) tot.ms_stage[i] += st.ms_stage[i];
+            tot.ms_gapfill_fill += st.ms_gapfill_fill; tot.ms_gapfill_trace += st.ms_gapfill_trace; tot.n_gapfill_launches += st.n_gapfill_launches;
+            tot.n_ed_full += st.n_ed_full; tot.n_ed_tier2 += st.n_ed_tier2; tot.n_ed_tier1 += st.n_ed_tier1;
+            tot.n_dp_redo += st.n_dp_redo; tot.dp_redo_tb_bytes += st.dp_redo_tb_bytes; tot.ms_local_seed += st.ms_local_seed; tot.ms_cluster += st.ms_cluster; tot.n_host_syncs += st.n_host_syncs; tot.n_local_general += st.n_local_general;
+        }
+    }
+    *recs = (vm_record*)malloc(sizeof(vm_record) * std::max<size_t>(all.size(), 1)); *cigar_blob = (char*)malloc(std::max<size_t>(blob.size(), 1));
+    if (!*recs || !*cigar_blob) { free(*recs); free(*cigar_blob); *recs = nullptr; *cigar_blob = nullptr; set_error("out of host memory"); return VM_ERR_OOM; }
+    memcpy(*recs, all.data(), sizeof(vm_record) * all.size()); memcpy(*cigar_blob, blob.data(), blob.size());
+    *n_recs = (int64_t)all.size();
+    if (stats) *stats = tot;
+    return VM_OK;
+}
+// the bases one pass over the path takes (VMX_MAX_BATCH_BASES). The work pools of a context grow with the pass (~0.85 KB per read base at hg38 size) and never
+// shrink, and a scheduler that cuts its batches by read count meets a batch of its longest reads now and then — 4096 reads of 40-100 kb are 160 Mbases
+// where the average batch holds 60: every context then keeps pools for 160 Mbases and uses them for 60. With the budget near the AVERAGE batch the
+// long-read batch runs as two or three passes of its context and the pools of all contexts are ~2.5 times smaller: more batches in flight fit the HBM.
+static int64_t vmx_pass_bases() {
+    static const int64_t v = [] { const char* e = getenv("VMX_MAX_BATCH_BASES"); const long long x = e ? atoll(e) : 0; return x > 0 ? (int64_t)x : (int64_t)VMX_MAX_BATCH_BASES; }();
+    return v;
+}
+
 extern "C" {
 
 int vm_reads_upload(vm_ctx* c, int64_t n, const char* seqs, const int64_t* offsets, vm_reads** out) {
@@ -690,7 +751,17 @@ int vm_align_resident(vm_ctx* c, const vm_index* mi, const vm_params* prm, const
                       int32_t* status_per_read, vm_batch_stats* stats) {
     if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
     VMX_HIP(hipSetDevice(c->device));
-    return align_device(c, mi, prm, R->n, R->codes.as<uint8_t>(), R->off.as<int64_t>(), R->h_off, recs, n_recs, cigar_blob, status_per_read, stats);
+    if (R->n <= VMX_MAX_BATCH_READS && R->h_off[(size_t)R->n] <= vmx_pass_bases())
+        return align_device(c, mi, prm, R->n, R->codes.as<uint8_t>(), R->off.as<int64_t>(), R->h_off, recs, n_recs, cigar_blob, status_per_read, stats);
+    // more bases than one pass takes: consecutive ranges of the resident reads (their codes stay where they are; a range's offsets are rebased and uploaded)
+    vmx_batch_bufs& B = *batch_bufs(c);
+    auto run_one = [&](int64_t a, int64_t b, vm_record** r, int64_t* nr, char** cb, vm_batch_stats* st) -> int {
+        std::vector<int64_t> h((size_t)(b - a) + 1);
+        for (int64_t i = a; i <= b; ++i) h[(size_t)(i - a)] = R->h_off[(size_t)i] - R->h_off[(size_t)a];
+        VMX_TRY(upload(B.off, h.data(), h.size(), c->stream));
+        return align_device(c, mi, prm, b - a, R->codes.as<uint8_t>() + R->h_off[(size_t)a], B.off.as<int64_t>(), h, r, nr, cb, status_per_read ? status_per_read + a : nullptr, st);
+    };
+    return align_in_sub_batches(R->n, R->h_off.data(), vmx_pass_bases(), run_one, recs, n_recs, cigar_blob, stats);
 }
 
 int vm_align_trace(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const char* seqs, const int64_t* offsets, int stage, int64_t** rows, int64_t** row_off) {
@@ -737,61 +808,14 @@ int vm_align_batch(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t 
     if (prm->mode == VM_MODE_ASM)        // contigs of 500 kb and more take the linked path (vmx_asm.hip), one by one
         for (int64_t r = 0; r < n; ++r)
             if (offsets[r + 1] - offsets[r] >= 500000) return vmx_align_batch_asm_mixed(c, mi, prm, n, seqs, offsets, recs, n_recs, cigar_blob, status_per_read, stats);
-    static const int64_t max_bases = [] { const char* e = getenv("VMX_MAX_BATCH_BASES"); const long long v = e ? atoll(e) : 0; return v > 0 ? (int64_t)v : (int64_t)VMX_MAX_BATCH_BASES; }();
-    // test hook: pretend the device is out of memory for any sub-batch above this many bases (exercises the degradation below)
+    // test hook: pretend the device is out of memory for any sub-batch above this many bases (exercises the degradation)
     const char* oom_env = getenv("VMX_TEST_OOM_ABOVE_BASES");
     const int64_t fake_oom = oom_env ? atoll(oom_env) : 0;
     auto run_one = [&](int64_t a, int64_t b, vm_record** r, int64_t* nr, char** cb, vm_batch_stats* st) -> int {
         if (fake_oom > 0 && offsets[b] - offsets[a] > fake_oom) { *r = nullptr; *nr = 0; *cb = nullptr; set_error("out of device memory (test hook)"); return VM_ERR_OOM; }
         return align_batch_one(c, mi, prm, b - a, seqs, offsets + a, r, nr, cb, status_per_read ? status_per_read + a : nullptr, st);
     };
-    if (n <= VMX_MAX_BATCH_READS && offsets[n] - offsets[0] <= max_bases) {
-        const int rc = run_one(0, n, recs, n_recs, cigar_blob, stats);
-        if (rc != VM_ERR_OOM || n <= 1) return rc;
-        free(*recs); free(*cigar_blob);                          // fall through: the batch is cut into pieces that fit
-    }
-    *recs = nullptr; *n_recs = 0; *cigar_blob = nullptr;
-    std::vector<vm_record> all; std::string blob;
-    vm_batch_stats tot; memset(&tot, 0, sizeof tot);
-    // work list of read ranges in order; a range the device has no memory for (the grow-only pools of this and the other contexts, the
-    // index and the reads share the HBM) is cut in two and tried again instead of failing the whole call with VM_ERR_OOM — down to single reads
-    std::vector<std::pair<int64_t, int64_t>> work;
-    for (int64_t a = 0; a < n;) {
-        int64_t b = a + 1;                                       // at least one read per sub-batch, whatever its length
-        while (b < n && b - a < VMX_MAX_BATCH_READS && offsets[b + 1] - offsets[a] <= max_bases) ++b;
-        work.emplace_back(a, b); a = b;
-    }
-    for (size_t wi = 0; wi < work.size(); ++wi) {
-        const int64_t a = work[wi].first, b = work[wi].second;
-        vm_record* r = nullptr; int64_t nr = 0; char* cb = nullptr; vm_batch_stats st;
-        const int rc = run_one(a, b, &r, &nr, &cb, &st);
-        if (rc == VM_ERR_OOM && b - a > 1) {
-            free(r); free(cb);
-            vmx::devbuf_retired().flush();                       // parked (outgrown) allocations go back to the device first
-            const int64_t mid = a + (b - a) / 2;
-            work[wi] = std::make_pair(a, mid); work.insert(work.begin() + (std::ptrdiff_t)wi + 1, std::make_pair(mid, b));
-            --wi; continue;
-        }
-        if (rc < 0) { free(r); free(cb); return rc; }
-        int64_t bl = 0; for (int64_t i = 0; i < nr; ++i) bl = std::max(bl, r[i].cigar_off + r[i].cigar_len);
-        for (int64_t i = 0; i < nr; ++i) { vm_record x = r[i]; x.read_idx += (int32_t)a; x.cigar_off += (int64_t)blob.size(); all.push_back(x); }
-        blob.append(cb, (size_t)bl); blob.push_back('\0');
-        free(r); free(cb);
-        {   // counters and times add up; sizes are per call
-            int64_t* d = (int64_t*)&tot; const int64_t* s2 = (const int64_t*)&st;
-            for (size_t i = 0; i < offsetof(vm_batch_stats, ms_total) / 8; ++i) d[i] += s2[i];
-            tot.ms_total += st.ms_total; for (int i = 0; i < 16; ++i) tot.ms_stage[i] += st.ms_stage[i];
-            tot.ms_gapfill_fill += st.ms_gapfill_fill; tot.ms_gapfill_trace += st.ms_gapfill_trace; tot.n_gapfill_launches += st.n_gapfill_launches;
-            tot.n_ed_full += st.n_ed_full; tot.n_ed_tier2 += st.n_ed_tier2; tot.n_ed_tier1 += st.n_ed_tier1;
-            tot.n_dp_redo += st.n_dp_redo; tot.dp_redo_tb_bytes += st.dp_redo_tb_bytes; tot.ms_local_seed += st.ms_local_seed; tot.ms_cluster += st.ms_cluster; tot.n_host_syncs += st.n_host_syncs; tot.n_local_general += st.n_local_general;
-        }
-    }
-    *recs = (vm_record*)malloc(sizeof(vm_record) * std::max<size_t>(all.size(), 1)); *cigar_blob = (char*)malloc(std::max<size_t>(blob.size(), 1));
-    if (!*recs || !*cigar_blob) { free(*recs); free(*cigar_blob); *recs = nullptr; *cigar_blob = nullptr; set_error("out of host memory"); return VM_ERR_OOM; }
-    memcpy(*recs, all.data(), sizeof(vm_record) * all.size()); memcpy(*cigar_blob, blob.data(), blob.size());
-    *n_recs = (int64_t)all.size();
-    if (stats) *stats = tot;
-    return VM_OK;
+    return align_in_sub_batches(n, offsets, vmx_pass_bases(), run_one, recs, n_recs, cigar_blob, stats);
 }
 
 }  // extern "C"
