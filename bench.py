@@ -313,7 +313,8 @@ def main():
             pipe.run_resident(resident, want_records=False, on_result=None)
             barrier(); host_rate['resident_again_ms_per_step'] = (time.time() - tr) / len(resident) * 1e3
 
-    vals = torch.tensor([dt, float(agg['aligned_bases']), float(agg['n_reads']), float(agg['read_bases']), float(agg['n_failed'])], dtype=torch.float64, device='cuda')
+    # (a device tensor only where a collective needs one: after a run that filled the HBM with work pools torch may not find room for its first block)
+    vals = torch.tensor([dt, float(agg['aligned_bases']), float(agg['n_reads']), float(agg['read_bases']), float(agg['n_failed'])], dtype=torch.float64, device='cuda' if dist is not None else 'cpu')
     if dist is not None:
         tmax = vals[0:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         sums = vals[1:].clone(); dist.all_reduce(sums, op=dist.ReduceOp.SUM)
@@ -327,7 +328,7 @@ def main():
         # they run on (vm_batch_stats: gap-fill fill, local re-seeding, hit clustering); the one with the largest time per step in THIS
         # run is reported. achieved = SURVEY 8(d)'s path-level algorithmic bytes per step / that kernel's time per step:
         #   B(read) = L + 16 M + 8 n + (L + 14000)/4 + 40 R + C   with measured M (minimizers), n (anchors), R (records), C (CIGAR bytes)
-        _free, _tot = torch.cuda.mem_get_info(local_rank); hbm_used_gb = (_tot - _free) / 1e9      # index + reads + every context's work pools
+        _free, _tot = ctx.mem_info(); hbm_used_gb = (_tot - _free) / 1e9      # index + reads + every context's work pools
         algo_bytes = (agg['read_bases'] + 16 * agg['n_minimizers'] + 8 * agg['n_anchors'] + (agg['read_bases'] + 14000 * agg['n_reads']) / 4.0 +
                       40 * agg['n_records'] + agg['cigar_bytes'])
         # ('k_local_seed' = the local stage's main launch: k_local_seed_band since round 4)
