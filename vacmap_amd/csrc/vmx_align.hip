@@ -485,9 +485,13 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
                 vmx_size_order_wide(c, B.dpsz[0].as<int64_t>() + p0, B.chunkn.as<int32_t>() + q, pn, (int64_t)VMX_HEAD_THRESH, B.order.as<int32_t>(), d_range, d_cnt, B.szh.as<int32_t>());
                 (void)hipMemsetAsync(d_redo_cnt, 0, 16, c->stream); (void)hipMemsetAsync(d_redo_bytes, 0, 8, c->stream);
                 if (ke) (void)hipEventRecord(ke[0], c->stream);
-                hipLaunchKernelGGL(k_gapfill_fill_ns, dim3((unsigned)std::min<int64_t>(pn, (int64_t)c->num_cu * fill_waves)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
-                                   B.dptab.as<vmx_dp_prob>() + p0, pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_range, d_cnt,
-                                   d_redo_list, d_redo_cnt, 0, ad_pct, (uint8_t*)nullptr, d_redo_bytes);
+                {
+                    vmx_lowprio lp(c);                            // the long launch at the lowest dispatch priority (vmx_host.h)
+                    hipLaunchKernelGGL(k_gapfill_fill_ns, dim3((unsigned)std::min<int64_t>(pn, (int64_t)c->num_cu * fill_waves)), dim3(64), 0, lp.stream(), B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
+                                       B.dptab.as<vmx_dp_prob>() + p0, pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_range, d_cnt,
+                                       d_redo_list, d_redo_cnt, 0, ad_pct, (uint8_t*)nullptr, d_redo_bytes);
+                    lp.join();
+                }
                 // sizing sync #4: full-matrix traceback space of the problems the first launch queued for the second one (a few per cent of them)
                 unsigned long long redo_bytes = 0; int32_t n_redo = 0;
                 int32_t qr[20];                                   // the queue block holds both numbers: one copy

@@ -62,11 +62,15 @@ int vm_ctx_create(int device_id, vm_ctx** out) {
     c->device = device_id;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
-    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; set_error("hipStreamCreate failed"); return VM_ERR_HIP; }
+    int prio_least = 0, prio_greatest = 0;
+    const bool prio = vmx_stream_prio_on() && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_least != prio_greatest;
+    if ((prio ? hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_greatest) : hipStreamCreate(&c->stream)) != hipSuccess) { delete c; set_error("hipStreamCreate failed"); return VM_ERR_HIP; }
+    if (prio && hipStreamCreateWithPriority(&c->low, hipStreamDefault, prio_least) == hipSuccess) { (void)hipEventCreateWithFlags(&c->low_ev[0], hipEventDisableTiming); (void)hipEventCreateWithFlags(&c->low_ev[1], hipEventDisableTiming); }
+    else c->low = nullptr;
     for (int i = 0; i < 24; ++i) (void)hipEventCreate(&c->ev[i]);
     for (int i = 0; i < 48; ++i) (void)hipEventCreate(&c->gev[i]);
     for (int i = 0; i < 4; ++i) (void)hipEventCreate(&c->kev[i]);
-    for (int i = 0; i < 4; ++i) { (void)hipStreamCreate(&c->aux[i]); (void)hipEventCreate(&c->join_ev[i]); }
+    for (int i = 0; i < 4; ++i) { if (prio) (void)hipStreamCreateWithPriority(&c->aux[i], hipStreamDefault, prio_greatest); else (void)hipStreamCreate(&c->aux[i]); (void)hipEventCreate(&c->join_ev[i]); }
     (void)hipEventCreate(&c->fork_ev);
     // cost tables -> one device blob
     const HostTables& T = host_tables();
@@ -120,6 +124,7 @@ void vm_ctx_destroy(vm_ctx* c) {
     for (int i = 0; i < 4; ++i) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); (void)hipEventDestroy(c->join_ev[i]); }
     (void)hipEventDestroy(c->fork_ev);
     if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
+    if (c->low) { (void)hipStreamSynchronize(c->low); (void)hipStreamDestroy(c->low); (void)hipEventDestroy(c->low_ev[0]); (void)hipEventDestroy(c->low_ev[1]); }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -111,10 +111,24 @@ struct vm_ctx {
     double res_rec_per_read = 0.0, res_blob_per_base = 0.0;   // largest records per read / CIGAR bytes per base a batch of this context produced (result copy size guess)
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams for independent launches (LDS-bucketed kernels)
     hipEvent_t fork_ev = nullptr, join_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t low = nullptr;                   // low-priority stream for the long VALU-bound launches (the gap fill's first launch): see vmx_lowprio_begin
+    hipEvent_t low_ev[2] = {nullptr, nullptr};
     int64_t last_n_minimizers = 0;               // of the last seed stage (stats)
     struct vmx_local_bufs* lbufs = nullptr;      // vmx_stage.h
     struct vmx_extend_bufs* ebufs = nullptr;
     struct vmx_batch_bufs* bbufs = nullptr;
+};
+
+// With several batches in flight a batch is made of ~170 small launches (a few to a few hundred microseconds each) around a handful of long VALU-bound
+// ones, and what stretches it from 27 ms alone to 77 ms with four others is the small launches queueing behind the other batches' long ones (seed stage
+// 2.6 -> 12.8 ms, edge extension 0.8 -> 5.4 ms). The contexts' streams are created at the device's HIGHEST priority and the long launches go to a stream
+// of the LOWEST: when a workgroup of a long launch retires, the waiting small launch is dispatched first. VMX_STREAM_PRIO=0: every stream at the default.
+static inline bool vmx_stream_prio_on() { static const bool on = [] { const char* e = getenv("VMX_STREAM_PRIO"); return !e || atoi(e) != 0; }(); return on; }
+struct vmx_lowprio {
+    vm_ctx* c; bool on;
+    explicit vmx_lowprio(vm_ctx* ctx) : c(ctx), on(ctx->low != nullptr) { if (on) { (void)hipEventRecord(c->low_ev[0], c->stream); (void)hipStreamWaitEvent(c->low, c->low_ev[0], 0); } }
+    hipStream_t stream() const { return on ? c->low : c->stream; }
+    void join() { if (on) { (void)hipEventRecord(c->low_ev[1], c->low); (void)hipStreamWaitEvent(c->stream, c->low_ev[1], 0); on = false; } }
 };
 
 // wait for the context's main stream. Default: hipStreamSynchronize (the runtime spins: lowest latency, one busy core per waiting thread).
