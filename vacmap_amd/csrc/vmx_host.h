@@ -122,8 +122,10 @@ struct vm_ctx {
 // With several batches in flight a batch is made of ~170 small launches (a few to a few hundred microseconds each) around a handful of long VALU-bound
 // ones, and what stretches it from 27 ms alone to 77 ms with four others is the small launches queueing behind the other batches' long ones (seed stage
 // 2.6 -> 12.8 ms, edge extension 0.8 -> 5.4 ms). The contexts' streams are created at the device's HIGHEST priority and the long launches go to a stream
-// of the LOWEST: when a workgroup of a long launch retires, the waiting small launch is dispatched first. VMX_STREAM_PRIO=0: every stream at the default.
-static inline bool vmx_stream_prio_on() { static const bool on = [] { const char* e = getenv("VMX_STREAM_PRIO"); return !e || atoi(e) != 0; }(); return on; }
+// of the LOWEST: when a workgroup of a long launch retires, the waiting small launch should be dispatched first. MEASURED (round 5, two alternating
+// pairs of the default bench): 16.57 / 16.93 ms per step with the priorities against 16.45 / 15.51 without — the hardware queues' priority does not
+// shorten the small launches' wait here. Off unless VMX_STREAM_PRIO=1.
+static inline bool vmx_stream_prio_on() { static const bool on = [] { const char* e = getenv("VMX_STREAM_PRIO"); return e && atoi(e) != 0; }(); return on; }
 struct vmx_lowprio {
     vm_ctx* c; bool on;
     explicit vmx_lowprio(vm_ctx* ctx) : c(ctx), on(ctx->low != nullptr) { if (on) { (void)hipEventRecord(c->low_ev[0], c->stream); (void)hipStreamWaitEvent(c->low, c->low_ev[0], 0); } }
