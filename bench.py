@@ -84,7 +84,8 @@ def main():
     ap.add_argument('--err', type=float, default=None, help='default: the config\'s (0.10 ONT, 0.005 HiFi)')
     ap.add_argument('--cpu-sample', type=int, default=96, help='minimum reads for the CPU baseline leg (rank 0, N=1 only); 0 disables')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='target wall time of the CPU baseline leg (the sample is sized by a pilot)')
-    ap.add_argument('--streams', type=int, default=5, help='batches in flight per GPU (vacmap_amd.pipeline)')
+    ap.add_argument('--streams', type=int, default=0, help='batches in flight per GPU (vacmap_amd.pipeline); 0 (default): five, then as many more (up to eight) as the HBM has room '
+                    'for after the sizing run — the scheduler\'s own rule (Pipeline.grow_to_memory)')
     ap.add_argument('--window-batches', type=int, default=16, help='length binning window of the scheduler, in batches')
     ap.add_argument('--arrival-order', action='store_true', help='no length binning: batches in arrival order (measured once for comparison)')
     ap.add_argument('--no-host-input', dest='host_input', action='store_false', help='skip the second timed pass, in which the same batches are handed over as HOST buffers (page-locked, as the '
@@ -224,7 +225,7 @@ def main():
     n_minimizers = index.n_minimizers()
 
     resident = pipeline.upload_batches(ctx, pool_cat, pool_off, plan)        # inputs resident in HBM before timing
-    pipe = pipeline.Pipeline(index, prm, device=local_rank, inflight=max(1, min(args.streams, nsteps)), first_ctx=ctx)
+    pipe = pipeline.Pipeline(index, prm, device=local_rank, inflight=max(1, min(args.streams or 5, nsteps)), first_ctx=ctx)
     if world > 1 and os.environ.get('VMX_SPIN_SYNC') != '1':
         # N ranks on one host: the contexts' threads SLEEP while they wait for the GPU (the driver's setting) — five spinning threads per rank times eight ranks
         # would take forty cores for nothing; host threads per rank in the timed region: `streams` mostly-sleeping aligner threads + the main thread
@@ -261,7 +262,13 @@ def main():
             verified = '%d/%d' % (ok, nv)
         n_before = pipe.inflight
         warm_oom += pipe.warm(resident[longest]); warm_runs += min(n_before, pipe.inflight + 1)
-    ctx_dropped = warm_oom + pipe.trim_to_memory()          # (the product's rule: a context is given up when the sized pools leave < 10 GB of HBM free; not the case at the default sizes)
+    ctx_dropped = warm_oom + pipe.trim_to_memory()
+    ctx_added = 0
+    if args.streams == 0 and not ctx_dropped and args.warmup > 0:
+        ctx_added = pipe.grow_to_memory(resident[longest], max_inflight=min(8, nsteps)); warm_runs += ctx_added
+        if world > 1 and os.environ.get('VMX_SPIN_SYNC') != '1':
+            for cx in pipe.ctxs:
+                cx.set_blocking_sync(True)          # (the product's rule: a context is given up when the sized pools leave < 10 GB of HBM free; not the case at the default sizes)
 
     agg = {}
 
@@ -418,7 +425,7 @@ def main():
             'dp_redo_per_step': agg.get('n_dp_redo', 0) / K, 'dp_redo_tb_bytes_per_step': agg.get('dp_redo_tb_bytes', 0) / K,
             'oracle_crosscheck': verified, 'setup_s': t_setup, 'reference_gen_s': t_ref, 'read_gen_s': t_reads, 'index_build_s': t_index, 'index_broadcast_s': t_bcast,
             'index_minimizers': int(n_minimizers), 'index_mid_occ': int(index.mid_occ), 'oracle_index_build_s': t_oracle_index, 'hbm_used_gb': hbm_used_gb,
-            'local_general_reads': int(agg.get('n_local_general', 0)), 'contexts_given_up_for_memory': int(ctx_dropped), 'longest_read': int(lens.max()),
+            'local_general_reads': int(agg.get('n_local_general', 0)), 'contexts_given_up_for_memory': int(ctx_dropped), 'contexts_added_for_memory': int(ctx_added), 'longest_read': int(lens.max()),
             'roofline': roofline, 'cpu_baseline': cpu,
         }
         if vacsim_info is not None:

@@ -187,3 +187,28 @@ def test_pipeline_warm_gives_up_contexts_without_memory():
     p.ctxs = [FakeCtx(True), FakeCtx(False), FakeCtx(True)]; p.inflight = 3
     with pytest.raises(VmxError):
         p.warm(run=run, keep=2)
+
+
+def test_pipeline_grows_batches_in_flight_to_memory(monkeypatch):
+    """Pipeline.grow_to_memory: contexts are added while the HBM holds another context's pools (measured on the first one added) plus the head-room;
+    a sizing run that finds no memory ends the growth without an error"""
+    from vacmap_amd import pipeline
+    state = {'free': 150e9, 'per': 35e9, 'made': 0}
+
+    class FakeCtx:
+        def __init__(self, device=0, lib=None): self.lib, self.closed, self.inflight = lib, False, None; state['made'] += 1
+        def mem_info(self): return int(state['free']), int(309e9)
+        def close(self): self.closed = True
+        def set_inflight(self, n): self.inflight = n
+    monkeypatch.setattr(pipeline, 'Context', FakeCtx)
+
+    def run(cx):
+        state['free'] -= state['per']
+    p = object.__new__(pipeline.Pipeline)
+    p.device = 0; p.ctxs = [FakeCtx() for _ in range(5)]; p.inflight = 5
+    # 150 GB free, 35 GB per context, 14 GB head-room: 115 -> 80 -> 45 -> (45 < 35 + 14) stop: three added
+    assert p.grow_to_memory(run=run, max_inflight=12) == 3 and p.inflight == 8 and all(c.inflight == 8 for c in p.ctxs)
+    state['free'] = 200e9
+    assert p.grow_to_memory(run=run, max_inflight=9) == 1 and p.inflight == 9          # the cap
+    state['free'] = 50e9
+    assert p.grow_to_memory(run=run, max_inflight=12) == 0                              # nothing known about the pools and little room: not tried

@@ -610,14 +610,62 @@ def main(argv=None, comm=None):
             if pinned is not None:
                 pinned.release(sb)
 
+    # Feeders (VMX_DRIVER_FEEDERS, default 2; 0 = the round-4 form: gather and upload on the aligner thread, inside vm_align_batch): threads with a context of
+    # their own take the next batch of the schedule, gather its reads into page-locked memory and stream them into HBM (vm_reads_reupload into a few reusable
+    # slots) AHEAD of the aligning contexts, which then run vm_align_resident — the aligner thread's context no longer idles through the gather, and the copy of
+    # batch i + 1 runs under the kernels of batch i (bench.py's host-input pass: Pipeline.run_host_blobs(prefetch=True))
+    n_feed = int(os.environ.get('VMX_DRIVER_FEEDERS', '2')) if pinned is not None else 0
+    feed = {'free': queue.Queue(), 'ready': queue.Queue(), 'ctxs': [], 'slots': [], 'lock': threading.Lock()}
+
+    def feeder(fcx, src):
+        try:
+            while not errs:
+                with feed['lock']:
+                    job = next(src, None)
+                if job is None:
+                    break
+                w, i = job
+                ix = w.plan[i]
+                t0 = time.time()
+                sb, so = blob_gather(lib, w.wnd['seqs'], w.wnd['seqs_off'], ix, alloc=pinned.get)
+                sl = feed['free'].get()
+                while sl is None:                        # (a None is only queued to wake a feeder up on an error)
+                    if errs:
+                        return
+                    sl = feed['free'].get()
+                sl.reupload(sb, so, ctx=fcx)
+                with tml:
+                    tm['job_gather'] += time.time() - t0
+                feed['ready'].put((w, i, ix, sb, so, sl))
+        except BaseException as e:
+            errs.append(e)
+        finally:
+            feed['ready'].put(None)
+
+    def fed_jobs(n_feeders):
+        """what the feeders prepared, in completion order, until all of them are done"""
+        done = 0
+        while done < n_feeders:
+            item = feed['ready'].get()
+            if item is None:
+                done += 1
+                continue
+            yield item
+
     def align(job, cx):
         """one batch: gather its reads from the window, align (GPU), hand the records to the emit pool; the library calls release the GIL"""
-        w, i = job
-        ix = w.plan[i]
-        t0 = time.time()
-        sb, so = blob_gather(lib, w.wnd['seqs'], w.wnd['seqs_off'], ix, alloc=pinned.get if pinned is not None else None)
-        t1 = time.time()
-        raw = align_batch_raw(cx, index, prm, sb, so)
+        if len(job) == 6:                                # prepared by a feeder: reads already in HBM
+            w, i, ix, sb, so, sl = job
+            t0 = t1 = time.time()
+            raw = sl.align_raw(index, prm, ctx=cx)
+            feed['free'].put(sl)
+        else:
+            w, i = job
+            ix = w.plan[i]
+            t0 = time.time()
+            sb, so = blob_gather(lib, w.wnd['seqs'], w.wnd['seqs_off'], ix, alloc=pinned.get if pinned is not None else None)
+            t1 = time.time()
+            raw = align_batch_raw(cx, index, prm, sb, so)
         t2 = time.time()
         w.futs[i] = emit_pool.submit(emit, w, i, ix, sb, so, raw)
         with tml:
@@ -702,6 +750,7 @@ def main(argv=None, comm=None):
     # (its result is dropped). Without this a context meets its first long-read batch windows later, outgrows the pools its earlier,
     # shorter batches sized, and pays for ~50 GB of re-allocation next to two other contexts' pools — seconds with the GPU idle
     # (rocprofv3 trace of a 131 k-read run: no kernel resident 73 % of the time, 2 s batches; `profiles/r03_l_*`).
+    sb0_keep = None                                     # the sizing batch: also sizes the feeders' upload slots
     if os.environ.get('VMX_NO_WARM') != '1':
         first = wq.get()
         tm['first_window'] = time.time() - t_loop
@@ -713,6 +762,7 @@ def main(argv=None, comm=None):
             if plan0:
                 ix0 = max(plan0, key=lambda ix: int(np.diff(first['seqs_off'])[ix].sum()))
                 sb0, so0 = blob_gather(lib, first['seqs'], first['seqs_off'], ix0)
+                sb0_keep = (sb0, so0)
 
                 # (one context after the other: hipMalloc serialises anyway, and a context that finds no memory left for its pools — a first window of
                 # very long reads — is given up with the ones after it instead of failing the run: Pipeline.warm)
@@ -726,12 +776,36 @@ def main(argv=None, comm=None):
         if dropped and rank == 0:
             sys.stderr.write('vacmapx: %d of %d batches in flight given up to keep HBM head-room\n' % (dropped, dropped + pipe.inflight))
         tm['warm'] = time.time() - t_loop
+    fth = []
     try:
-        pipe.run_stream(job_source(), align, errs)
+        if n_feed > 0 and sb0_keep is not None:
+            from .lib import Context as _Ctx, ResidentReads as _RR
+            src = job_source()
+            for f in range(n_feed):
+                fcx = _Ctx(device, lib=lib)
+                if os.environ.get('VMX_SPIN_SYNC') != '1':
+                    fcx.set_blocking_sync(True)
+                feed['ctxs'].append(fcx)
+            for _ in range(pipe.inflight + n_feed + 1):
+                sl = _RR(feed['ctxs'][0], concat=sb0_keep[0], offsets=sb0_keep[1]); feed['slots'].append(sl); feed['free'].put(sl)
+            fth = [threading.Thread(target=feeder, args=(fcx, src)) for fcx in feed['ctxs']]
+            for t_ in fth:
+                t_.start()
+            pipe.run_stream(fed_jobs(n_feed), align, errs)
+        else:
+            pipe.run_stream(job_source(), align, errs)
         tm['aligners_done'] = time.time() - t_loop
     finally:
         if errs:
             oq.put(None)
+            for _ in fth:
+                feed['free'].put(None)
+        for t_ in fth:
+            t_.join()
+        for sl in feed['slots']:
+            sl.close()
+        for fcx in feed['ctxs']:
+            fcx.close()
         wt.join()
         emit_pool.shutdown(wait=True)
     if errs:

@@ -677,6 +677,14 @@ class ResidentReads:
         self.ctx.lib.check(self.ctx.lib.L.vm_reads_reupload((ctx or self.ctx).h, self.h, n, arr.ctypes.data, off.ctypes.data))
         self.n = n; self.bases = int(off[-1])
 
+    def align_raw(self, index, prm, ctx=None):
+        """vm_align_resident with the records left in library memory (RawBatch: what the native SAM emitter consumes)"""
+        status = np.zeros(max(self.n, 1), np.int32)
+        recs = C.POINTER(Record)(); nrec = C.c_int64(); blob = C.c_void_p(); stats = BatchStats()
+        self.ctx.lib.check(self.ctx.lib.L.vm_align_resident((ctx or self.ctx).h, index.h, C.byref(prm), self.h, C.byref(recs), C.byref(nrec), C.byref(blob),
+                                                            status.ctypes.data, C.byref(stats)))
+        return RawBatch(self.ctx, status[:self.n], recs, nrec.value, blob, stats)
+
     def align(self, index, prm, want_records=True, ctx=None):
         """ctx: the context (streams + work pools) to run on; default = the one that uploaded the reads"""
         status = np.zeros(max(self.n, 1), np.int32)

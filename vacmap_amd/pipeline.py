@@ -106,6 +106,44 @@ class Pipeline:
                 cx.set_inflight(self.inflight)
         return dropped
 
+    def grow_to_memory(self, resident=None, run=None, max_inflight=8, min_free_gb=14.0):
+        """after warm(): more batches in flight while the HBM has room for another context's pools. What a context's pools take is measured on the first
+        one added (free memory before and after its sizing run on the same batch the others were sized with); a context is added while that much plus
+        `min_free_gb` is free. Throughput is batches in flight / the latency of a batch under load wherever the step is not bound by the VALUs (HiFi:
+        the step is 2.4x its VALU floor; uniform 18 kb reads leave room for seven contexts where the ONT workload's long-read batches fill the HBM with
+        five). Returns the number of contexts added."""
+        from .lib import VmxError
+        added, per_ctx = 0, None
+        while len(self.ctxs) < max_inflight:
+            free, _ = self.ctxs[0].mem_info()
+            need = (per_ctx if per_ctx is not None else 0.0) + min_free_gb * 1e9
+            if per_ctx is None and free < 60e9:                   # nothing is known yet: only try with plenty of room
+                break
+            if per_ctx is not None and free < need:
+                break
+            cx = Context(self.device, lib=self.ctxs[0].lib)
+            try:
+                if run is not None:
+                    run(cx)
+                else:
+                    resident.align(self.index, self.prm, want_records=False, ctx=cx)
+            except VmxError as e:
+                cx.close()
+                if e.code != -4:
+                    raise
+                break
+            free2, _ = self.ctxs[0].mem_info()
+            per_ctx = max(float(free - free2), 1e9)
+            if free2 < min_free_gb * 1e9:                          # it fitted, but left too little: give it back
+                cx.close()
+                break
+            self.ctxs.append(cx); added += 1
+        if added:
+            self.inflight = len(self.ctxs)
+            for cx in self.ctxs:
+                cx.set_inflight(self.inflight)
+        return added
+
     def retire_if_low(self, cx, low_water_gb=4.0, keep=2):
         """called by a worker thread between two batches (under the scheduler's lock): the pools are grow-only, and a later window with longer
         reads regrows every context's pools after trim_to_memory has run. When less than `low_water_gb` of HBM is free and more than
