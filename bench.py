@@ -96,7 +96,7 @@ def main():
     ap.add_argument('--vacsim-svs', type=int, default=1000, help='vacsim_r: complex SVs per grammar line (six lines)')
     ap.add_argument('--extra-configs', default='ont_100mb,hifi_hg38,vacsim_r', help='other single-GPU BASELINE configs timed in their own short runs of this script (N = 1 only) and '
                     'reported under extra.configs next to the headline; "" disables')
-    ap.add_argument('--extra-steps', type=int, default=15)
+    ap.add_argument('--extra-steps', type=int, default=24)
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     if args.ref_mb > 0:                               # (kept: --ref-mb M = the ONT workload against one contig of M Mb)
