@@ -149,22 +149,7 @@ def main():
         if world > 1:
             # rank 0 generates the 3.1 Gb once, with every core, into /dev/shm; the other ranks map it (shared pages): eight ranks regenerating it on cores / 8
             # threads each was the longest part of an 8-rank start
-            lens_c = synth.hg38_like_lengths(); shm = '/dev/shm/vacmapx_bench_ref_seed3_%s.u8' % os.environ.get('MASTER_PORT', '0')
-            if rank == 0:
-                cs = synth.make_reference_fast(lens_c, seed=3, threads=cores)
-                mm = np.lib.format.open_memmap(shm + '.tmp', mode='w+', dtype=np.uint8, shape=(int(sum(lens_c)),))
-                o = 0
-                for c_ in cs:
-                    mm[o:o + len(c_)] = c_; o += len(c_)
-                mm.flush(); del mm, cs
-                os.replace(shm + '.tmp', shm)
-            dist.barrier()
-            whole = np.load(shm, mmap_mode='r')
-            offs = np.concatenate([[0], np.cumsum(lens_c)])
-            contigs = [whole[offs[i]:offs[i + 1]] for i in range(len(lens_c))]
-            dist.barrier()
-            if rank == 0:
-                os.unlink(shm)                        # (the mappings keep the pages until every rank is done)
+            contigs = synth.shared_reference(synth.hg38_like_lengths(), 3, rank, dist.barrier, threads=cores, tag=os.environ.get('MASTER_PORT', '0'))
         else:
             contigs = synth.make_reference_fast(synth.hg38_like_lengths(), seed=3, threads=cores)
         workload_id = cfg['tag']

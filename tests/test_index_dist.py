@@ -526,3 +526,33 @@ def test_host_blobs_prefetch_uploader_matches_inline_upload(ctx, oracle):
     assert got[True] == got[False] and len(got[True]) == 5 and all(v[1] > 0 for v in got[True].values())
     assert len(pipe._up[1]) == 4                       # inflight + 2 slots served five batches
     pipe.close()
+
+
+_SHM_WORKER = r'''
+import os, sys, zlib
+sys.path.insert(0, %r)
+import numpy as np
+import torch.distributed as dist
+dist.init_process_group(backend='gloo')
+from vacmap_amd import synth
+lens = [70001, 1234, 50000]
+cs = synth.shared_reference(lens, 9, dist.get_rank(), dist.barrier, threads=2, tag=os.environ['MASTER_PORT'], shm_dir=sys.argv[1])
+want = synth.make_reference_fast(lens, seed=9, threads=1)
+assert [len(c) for c in cs] == lens and all(np.array_equal(a, b) for a, b in zip(cs, want))
+cat, off, tr = synth.sample_reads_concat(cs, 5, mean_len=800, err=0.05, seed=3 + dist.get_rank(), min_len=200)      # read-only mapped contigs feed the read sampler
+assert len(off) == 6 and off[-1] == len(cat)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_shared_reference_two_ranks(tmp_path):
+    """bench.py at N ranks: rank 0 generates the synthetic reference once into a shared-memory file, the other ranks map it (identical contigs in both,
+    usable by the read sampler); the file is gone afterwards"""
+    script = tmp_path / 'w.py'
+    script.write_text(_SHM_WORKER % ROOT)
+    shm = tmp_path / 'shm'; shm.mkdir()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29671')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', '29671',
+                          str(script), str(shm)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert os.listdir(shm) == []

@@ -40,6 +40,30 @@ def hg38_like_lengths(total=3_100_000_000):
     return ln
 
 
+def shared_reference(lengths, seed, rank, barrier, threads=None, tag='0', shm_dir='/dev/shm'):
+    """make_reference_fast for N processes of one host: rank 0 generates the contigs once (with `threads` threads) into a file under /dev/shm, every
+    rank maps it (shared pages) — eight ranks regenerating 3.1 Gb on cores / 8 threads each was the longest part of an 8-rank start. `barrier()` is the
+    caller's collective barrier (torch.distributed.barrier). Returns read-only uint8 views, one per contig."""
+    import os
+    path = os.path.join(shm_dir, 'vacmapx_ref_seed%d_%s.u8' % (int(seed), tag))
+    if rank == 0:
+        cs = make_reference_fast(lengths, seed=seed, threads=threads)
+        mm = np.lib.format.open_memmap(path + '.tmp', mode='w+', dtype=np.uint8, shape=(int(sum(int(x) for x in lengths)),))
+        o = 0
+        for c in cs:
+            mm[o:o + len(c)] = c; o += len(c)
+        mm.flush(); del mm, cs
+        os.replace(path + '.tmp', path)
+    barrier()
+    whole = np.load(path, mmap_mode='r')
+    offs = np.concatenate([[0], np.cumsum([int(x) for x in lengths])])
+    contigs = [whole[offs[i]:offs[i + 1]] for i in range(len(lengths))]
+    barrier()
+    if rank == 0:
+        os.unlink(path)                          # (the mappings keep the pages until every rank is done)
+    return contigs
+
+
 _LUT4 = None
 
 
