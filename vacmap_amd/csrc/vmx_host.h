@@ -5,6 +5,8 @@
 #include "vmx_kernels.h"
 #include "../../include/vacmapx.h"
 #include <algorithm>
+#include <map>
+#include <cstring>
 #include <string>
 #include <vector>
 #include <chrono>
@@ -79,13 +81,20 @@ struct HostTables {
 };
 const HostTables& host_tables();
 
-template <class T> int upload(DevBuf& b, const T* host, size_t n, hipStream_t st) {
+// VMX_DBG_COPIES=1: the copies of the helpers below by call site (file line), printed at exit — a tuning aid: which of a batch's ~75 small copies to go after
+struct CopyCensus {
+    std::mutex m; std::map<std::pair<std::string, int>, std::pair<long long, long long>> by_line; bool on = getenv("VMX_DBG_COPIES") != nullptr;
+    void add(const char* file, int line, size_t bytes) { if (!on) return; std::lock_guard<std::mutex> g(m); const char* b = strrchr(file, '/'); auto& e = by_line[std::make_pair(std::string(b ? b + 1 : file), line)]; e.first++; e.second += (long long)bytes; }
+    ~CopyCensus() { if (!on) return; for (auto& kv : by_line) fprintf(stderr, "[copies] %s:%d (%s): %lld copies, %lld bytes\n", kv.first.first.c_str(), kv.first.second < 0 ? -kv.first.second : kv.first.second, kv.first.second < 0 ? "download" : "upload", kv.second.first, kv.second.second); }
+};
+inline CopyCensus& copy_census() { static CopyCensus c; return c; }
+template <class T> int upload(DevBuf& b, const T* host, size_t n, hipStream_t st, int line = __builtin_LINE(), const char* file = __builtin_FILE()) {
     VMX_TRY(b.reserve(sizeof(T) * (n ? n : 1)));
-    if (n) VMX_HIP(hipMemcpyAsync(b.p, host, sizeof(T) * n, hipMemcpyHostToDevice, st));
+    if (n) { VMX_HIP(hipMemcpyAsync(b.p, host, sizeof(T) * n, hipMemcpyHostToDevice, st)); copy_census().add(file, line, sizeof(T) * n); }
     return 0;
 }
-template <class T> int download(T* host, const void* dev, size_t n, hipStream_t st) {
-    if (n) VMX_HIP(hipMemcpyAsync(host, dev, sizeof(T) * n, hipMemcpyDeviceToHost, st));
+template <class T> int download(T* host, const void* dev, size_t n, hipStream_t st, int line = __builtin_LINE(), const char* file = __builtin_FILE()) {
+    if (n) { VMX_HIP(hipMemcpyAsync(host, dev, sizeof(T) * n, hipMemcpyDeviceToHost, st)); copy_census().add(file, -line, sizeof(T) * n); }
     return 0;
 }
 
