@@ -21,7 +21,7 @@ def main():
     ap.add_argument('--t', type=int, default=16); ap.add_argument('--out', default=None); ap.add_argument('--tmp', default='/tmp/vmx_driver_bench')
     ap.add_argument('--replicate', type=int, default=1, help='write the generated reads this many times under different names (a long input from a short '
                     'generation: --reads 163840 --replicate 10 = 1.6 M reads, ~48 GB of FASTQ; use --tmp /dev/shm/... for that); the quarter run is skipped')
-    ap.add_argument('--inflight', type=int, default=5); ap.add_argument('--sam-dir', default=None, help='directory of the SAM output (default: --tmp)')
+    ap.add_argument('--inflight', type=int, default=0); ap.add_argument('--sam-dir', default=None, help='directory of the SAM output (default: --tmp)')
     ap.add_argument('--driver-args', default='', help='extra arguments for the driver command line, e.g. "--window-batches 16"')
     args = ap.parse_args()
     from vacmap_amd import synth, driver, pipeline
@@ -91,8 +91,10 @@ def main():
     # the bench's figure for these reads (inputs resident, no SAM): the product's scheduler on length-binned batches
     plan = pipeline.plan_batches(np.diff(off), 4096, 16)
     res = pipeline.upload_batches(ctx, cat, off, plan)
-    pipe = pipeline.Pipeline(idx, prm, inflight=args.inflight, first_ctx=ctx)
+    pipe = pipeline.Pipeline(idx, prm, inflight=args.inflight or 5, first_ctx=ctx)
     pipe.warm(res[0])
+    if args.inflight == 0:
+        pipe.grow_to_memory(res[0], max_inflight=8)
     agg = {'aligned': 0}
 
     def on(i, r):

@@ -212,7 +212,7 @@ def build_parser():
     for a, _ in RG_ARGS:
         p.add_argument('--' + a, dest=a.replace('-', '_'))
     p.add_argument('--device', type=int, default=None); p.add_argument('--batch-reads', type=int, default=4096)
-    p.add_argument('--window-batches', type=int, default=4); p.add_argument('--inflight', type=int, default=5)
+    p.add_argument('--window-batches', type=int, default=4); p.add_argument('--inflight', type=int, default=0, help='batches in flight on the GPU; 0 (default): five, then as many more (up to eight) as the HBM has room for after the sizing run')
     # N ranks (torchrun): 'range' = every rank parses its own byte range of each plain FASTA / FASTQ input and writes its own part of the SAM file
     # (<out>.partNNN, concatenated by rank 0 at the end unless --parts); 'batch' = every rank parses everything and keeps every N-th batch, rank 0
     # gathers the text (compressed / BAM input, stdout or BAM output); 'auto' picks 'range' whenever input and output allow it
@@ -447,7 +447,7 @@ def main(argv=None, comm=None):
         if own_group:                                   # no rank leaves while rank 0 still gathers and writes
             comm.barrier(); comm.destroy_process_group()
         return rc
-    pipe = pipeline.Pipeline(index, prm, device=device, inflight=args.inflight, first_ctx=ctx)
+    pipe = pipeline.Pipeline(index, prm, device=device, inflight=args.inflight or 5, first_ctx=ctx)
     if os.environ.get('VMX_SPIN_SYNC') != '1':
         for cx in pipe.ctxs:
             cx.set_blocking_sync(True)                    # the emitters need the cores the waiting aligner threads would spin on
@@ -775,6 +775,15 @@ def main(argv=None, comm=None):
         dropped = pipe.trim_to_memory(float(os.environ.get('VMX_MIN_FREE_GB', '10')))
         if dropped and rank == 0:
             sys.stderr.write('vacmapx: %d of %d batches in flight given up to keep HBM head-room\n' % (dropped, dropped + pipe.inflight))
+        if args.inflight == 0 and not dropped and sb0_keep is not None and not errs:
+            # the scheduler's rule (bench.py runs the same): more batches in flight while another context's pools + head-room fit the HBM
+            try:
+                added = pipe.grow_to_memory(run=lambda cx: align_batch_raw(cx, index, prm, sb0_keep[0], sb0_keep[1]).close(), max_inflight=8)
+                if added and os.environ.get('VMX_SPIN_SYNC') != '1':
+                    for cx in pipe.ctxs:
+                        cx.set_blocking_sync(True)
+            except BaseException as e:
+                errs.append(e)
         tm['warm'] = time.time() - t_loop
     fth = []
     try:
