@@ -403,6 +403,8 @@ def main():
             'device_ms_per_step': agg['ms_total'] / K, 'stage_ms_per_step': [x / K for x in agg['ms_stage'][:8]],
             'stage_names': ['seed', 'global_chain', 'local', 'divergence_filter', 'edge_extension', 'gapfill+records', 'nofilter_redo', 'download'],
             'gapfill_trace_ms_per_step': agg['ms_gapfill_trace'] / K, 'host_syncs_per_step': agg.get('n_host_syncs', 0) / K,
+            # per batch, seen from its host thread: wall time of the library call, of it spent inside waits for the stream; the rest is host work with the context's stream empty
+            'host_call_ms_per_batch': agg['ms_stage'][15] / K, 'host_wait_ms_per_batch': agg['ms_stage'][14] / K, 'host_active_ms_per_batch': (agg['ms_stage'][15] - agg['ms_stage'][14]) / K,
             'per_read': {'minimizers': agg['n_minimizers'] / max(agg['n_reads'], 1), 'hits': agg['n_hits'] / max(agg['n_reads'], 1), 'anchors': agg['n_anchors'] / max(agg['n_reads'], 1),
                          'local_anchors': agg['n_local_anchors'] / max(agg['n_reads'], 1), 'dp_problems': agg['n_dp_problems'] / max(agg['n_reads'], 1),
                          'dp_cells': agg['dp_cells'] / max(agg['n_reads'], 1), 'records': agg['n_records'] / max(agg['n_reads'], 1)},

@@ -195,7 +195,8 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     vm_batch_stats st; memset(&st, 0, sizeof st);
     st.n_reads = n; st.read_bases = total_bases;
     hipEvent_t* ev = c->ev; int nev = 0;
-    c->n_syncs = 0; c->n_bandfall = 0; c->kev_set = 0;
+    c->n_syncs = 0; c->n_bandfall = 0; c->kev_set = 0; c->sync_wait_ns = 0; download_wait_ns() = 0;
+    c->call_t0_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));
     if (n == 0) { *recs = (vm_record*)malloc(sizeof(vm_record)); *cigar_blob = (char*)malloc(1); if (stats) *stats = st; return VM_OK; }
 
@@ -637,6 +638,10 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     if ((c->kev_set & 1) && hipEventElapsedTime(&ms, c->kev[0], c->kev[1]) == hipSuccess) st.ms_local_seed = ms;
     if ((c->kev_set & 2) && hipEventElapsedTime(&ms, c->kev[2], c->kev[3]) == hipSuccess) st.ms_cluster = ms;
     st.n_host_syncs = c->n_syncs; st.n_local_general = c->n_bandfall;
+    // host-side view of the batch (tuning): [14] ms the thread spent inside its waits for the stream, [15] wall ms of the call up to here — the difference is host
+    // work done while this context's stream was EMPTY (sizing, vector work, launches between a wait's return and the next kernel)
+    st.ms_stage[14] = (float)((c->sync_wait_ns + download_wait_ns()) * 1e-6);
+    st.ms_stage[15] = (float)((std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() - c->call_t0_ns) * 1e-6);
     for (int pass = 0; pass < 2; ++pass)
         for (int q = 0; q < c->n_gev[pass]; ++q) {
             hipEvent_t* ke = c->gev + 24 * pass + 3 * q;

@@ -88,13 +88,20 @@ struct CopyCensus {
     ~CopyCensus() { if (!on) return; for (auto& kv : by_line) fprintf(stderr, "[copies] %s:%d (%s): %lld copies, %lld bytes\n", kv.first.first.c_str(), kv.first.second < 0 ? -kv.first.second : kv.first.second, kv.first.second < 0 ? "download" : "upload", kv.second.first, kv.second.second); }
 };
 inline CopyCensus& copy_census() { static CopyCensus c; return c; }
+inline long long& download_wait_ns() { static thread_local long long v = 0; return v; }      // per host thread = per context in flight
 template <class T> int upload(DevBuf& b, const T* host, size_t n, hipStream_t st, int line = __builtin_LINE(), const char* file = __builtin_FILE()) {
     VMX_TRY(b.reserve(sizeof(T) * (n ? n : 1)));
     if (n) { VMX_HIP(hipMemcpyAsync(b.p, host, sizeof(T) * n, hipMemcpyHostToDevice, st)); copy_census().add(file, line, sizeof(T) * n); }
     return 0;
 }
 template <class T> int download(T* host, const void* dev, size_t n, hipStream_t st, int line = __builtin_LINE(), const char* file = __builtin_FILE()) {
-    if (n) { VMX_HIP(hipMemcpyAsync(host, dev, sizeof(T) * n, hipMemcpyDeviceToHost, st)); copy_census().add(file, -line, sizeof(T) * n); }
+    if (n) {
+        // (a copy into pageable host memory returns when the data has arrived, i.e. after everything queued on the stream before it: these calls are where a
+        // batch's host thread really waits for the GPU — counted with vmx_stream_sync's time in the tuning counters)
+        const auto t0 = std::chrono::steady_clock::now();
+        VMX_HIP(hipMemcpyAsync(host, dev, sizeof(T) * n, hipMemcpyDeviceToHost, st)); copy_census().add(file, -line, sizeof(T) * n);
+        download_wait_ns() += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    }
     return 0;
 }
 
@@ -117,6 +124,7 @@ struct vm_ctx {
     int kev_set = 0;                              // bit 0: [0,1] recorded, bit 1: [2,3] recorded
     int64_t n_bandfall = 0;                       // reads k_local_seed_band handed back to k_local_seed (reset per batch)
     int64_t n_syncs = 0;                          // host waits on this context's stream (reset per batch)
+    int64_t sync_wait_ns = 0, call_t0_ns = 0;     // time inside those waits; wall clock at the start of the batch (tuning: ms_stage[14] / [15])
     double res_rec_per_read = 0.0, res_blob_per_base = 0.0;   // largest records per read / CIGAR bytes per base a batch of this context produced (result copy size guess)
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams for independent launches (LDS-bucketed kernels)
     hipEvent_t fork_ev = nullptr, join_ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -147,10 +155,15 @@ struct vmx_lowprio {
 // SAM emitters under a CPU quota: spinning waiters push the process over its quota and the whole process, aligners included, is throttled).
 static inline hipError_t vmx_stream_sync(vm_ctx* c) {
     ++c->n_syncs;
+    const auto t0 = std::chrono::steady_clock::now();            // (time spent waiting: ms_stage[14] of the batch; the rest of the call's wall time is host work with the stream empty)
+    hipError_t e;
 #ifndef VMX_EMU
-    if (c->sync_ev) { const hipError_t e = hipEventRecord(c->sync_ev, c->stream); if (e != hipSuccess) return e; return hipEventSynchronize(c->sync_ev); }
+    if (c->sync_ev) { e = hipEventRecord(c->sync_ev, c->stream); if (e == hipSuccess) e = hipEventSynchronize(c->sync_ev); }
+    else
 #endif
-    return hipStreamSynchronize(c->stream);
+    e = hipStreamSynchronize(c->stream);
+    c->sync_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    return e;
 }
 
 // fork/join of independent launches over the context's side streams (all ordered after / before the main stream)
