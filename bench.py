@@ -248,9 +248,15 @@ def main():
         n_before = pipe.inflight
         warm_oom += pipe.warm(resident[longest]); warm_runs += min(n_before, pipe.inflight + 1)
     ctx_dropped = warm_oom + pipe.trim_to_memory()
-    ctx_added = 0
+    ctx_added = 0; ctx_small = 0
     if args.streams == 0 and not ctx_dropped and args.warmup > 0:
         ctx_added = pipe.grow_to_memory(resident[longest], max_inflight=min(8, nsteps)); warm_runs += ctx_added
+        if not ctx_added and os.environ.get('VMX_SMALL_CTX', '1') != '0' and nsteps >= 8:
+            # no room for another full context (its pools are sized by the window's longest batch): contexts for the shorter batches only, sized on the median batch
+            by_bases = sorted(range(nsteps), key=lambda j: resident[j].bases)
+            med = by_bases[len(by_bases) // 2]
+            ctx_small = pipe.add_small_contexts(resident[med], resident[med].bases, max_inflight=min(9, nsteps))
+            warm_runs += ctx_small * resident[med].bases / float(max(resident[longest].bases, 1))          # (in units of the longest batch: the PMC summaries scale by warm-up bases)
         if world > 1 and os.environ.get('VMX_SPIN_SYNC') != '1':
             for cx in pipe.ctxs:
                 cx.set_blocking_sync(True)          # (the product's rule: a context is given up when the sized pools leave < 10 GB of HBM free; not the case at the default sizes)
@@ -398,7 +404,7 @@ def main():
                        'schedule': 'vacmap_amd.pipeline: %s, %d batches in flight per GPU' % (
                            'arrival-order batches' if args.arrival_order else 'length-binned batches inside windows of %d batches' % args.window_batches, pipe.inflight),
                        'parallelism': 'reads sharded over %d GPU(s), index built by rank 0 and broadcast over RCCL' % world if world > 1 else 'one GPU'},
-            'timed_bases': int(rbases), 'warmup_batches': warm_runs, 'warmup_bases': int(warm_runs * lens[plan[longest]].sum()),
+            'timed_bases': int(rbases), 'warmup_batches': round(warm_runs, 2), 'warmup_bases': int(warm_runs * lens[plan[longest]].sum()),
             'reads_per_s': nreads / dt_all, 'input_Gbp_per_s': rbases / dt_all / 1e9, 'failed_reads': int(nfail), 'unmapped_reads': int(agg['n_unmapped']),
             'device_ms_per_step': agg['ms_total'] / K, 'stage_ms_per_step': [x / K for x in agg['ms_stage'][:8]],
             'stage_names': ['seed', 'global_chain', 'local', 'divergence_filter', 'edge_extension', 'gapfill+records', 'nofilter_redo', 'download'],
@@ -412,7 +418,7 @@ def main():
             'dp_redo_per_step': agg.get('n_dp_redo', 0) / K, 'dp_redo_tb_bytes_per_step': agg.get('dp_redo_tb_bytes', 0) / K,
             'oracle_crosscheck': verified, 'setup_s': t_setup, 'reference_gen_s': t_ref, 'read_gen_s': t_reads, 'index_build_s': t_index, 'index_broadcast_s': t_bcast,
             'index_minimizers': int(n_minimizers), 'index_mid_occ': int(index.mid_occ), 'oracle_index_build_s': t_oracle_index, 'hbm_used_gb': hbm_used_gb,
-            'local_general_reads': int(agg.get('n_local_general', 0)), 'contexts_given_up_for_memory': int(ctx_dropped), 'contexts_added_for_memory': int(ctx_added), 'longest_read': int(lens.max()),
+            'local_general_reads': int(agg.get('n_local_general', 0)), 'contexts_given_up_for_memory': int(ctx_dropped), 'contexts_added_for_memory': int(ctx_added), 'small_contexts_added': int(ctx_small), 'longest_read': int(lens.max()),
             'roofline': roofline, 'cpu_baseline': cpu,
         }
         if vacsim_info is not None:

@@ -212,3 +212,36 @@ def test_pipeline_grows_batches_in_flight_to_memory(monkeypatch):
     assert p.grow_to_memory(run=run, max_inflight=9) == 1 and p.inflight == 9          # the cap
     state['free'] = 50e9
     assert p.grow_to_memory(run=run, max_inflight=12) == 0                              # nothing known about the pools and little room: not tried
+
+
+def test_pipeline_small_contexts_only_take_small_batches():
+    """the size-aware schedule of Pipeline._run: a context added by add_small_contexts never runs a batch above its limit, every batch runs exactly once,
+    and the entries that do not know batch sizes (run_stream, run_host_blobs) leave the small contexts out"""
+    import threading
+    from vacmap_amd import pipeline
+
+    class FakeCtx:
+        def __init__(self, name): self.name = name
+        def mem_info(self): return int(100e9), int(309e9)
+        def set_inflight(self, n): pass
+        def close(self): pass
+    p = object.__new__(pipeline.Pipeline)
+    full = [FakeCtx('F%d' % i) for i in range(2)]; small = [FakeCtx('S%d' % i) for i in range(3)]
+    p.ctxs = full + small; p.small_ctxs = list(small); p.small_limit = 50; p.inflight = 5; p.device = 0
+    bases = [160, 120, 90, 70, 55, 50, 45, 40, 30, 20, 10, 5] * 2            # two windows, longest first inside each
+    ran = {}; lock = threading.Lock()
+
+    def do_job(i, cx):
+        import time; time.sleep(0.002 * bases[i] / 40.0)
+        with lock:
+            assert i not in ran
+            ran[i] = cx.name
+        return i
+    p._run(len(bases), do_job, None, job_bases=bases, horizon=12)
+    assert sorted(ran) == list(range(len(bases)))
+    assert all(bases[i] <= 50 for i, nm in ran.items() if nm.startswith('S')) and any(nm.startswith('S') for nm in ran.values())
+    assert [c.name for c in p.full_ctxs()] == ['F0', 'F1']
+    # without sizes the small contexts stay out
+    ran.clear()
+    p._run(6, do_job, None)
+    assert sorted(ran) == list(range(6)) and all(nm.startswith('F') for nm in ran.values())

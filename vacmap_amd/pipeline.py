@@ -161,18 +161,82 @@ class Pipeline:
             c.set_inflight(self.inflight)
         return True
 
-    def _run(self, n_jobs, do_job, on_result):
-        """`inflight` threads pull job indices in order; do_job(i, ctx) -> result; on_result(i, result) is called under a lock"""
+    def full_ctxs(self):
+        """the contexts that may be handed any batch (the small ones, add_small_contexts, only take part in the size-aware schedule of _run)"""
+        small = set(id(c) for c in getattr(self, 'small_ctxs', []))
+        return [c for c in self.ctxs if id(c) not in small]
+
+    def add_small_contexts(self, resident_small, limit_bases, max_inflight=9, min_free_gb=14.0):
+        """contexts for the SHORTER batches only. The work pools are sized by the largest batch a context has seen, and a length-binned window holds a few
+        batches of long reads among many of short ones (Gamma lengths: 160 Mbases in the longest batch of a window of 16, ~50 in the median one): contexts that
+        will never be handed more than `limit_bases` bases are sized on such a batch (`resident_small`) and take a third of a full context's memory, so that more
+        batches are in flight inside the same HBM. The scheduler (_run with job_bases) gives them the jobs at or below the limit. Returns the number added."""
+        from .lib import VmxError
+        added, per_ctx = 0, None
+        self.small_limit = int(limit_bases)
+        if not hasattr(self, 'small_ctxs'):
+            self.small_ctxs = []
+        while len(self.ctxs) < max_inflight:
+            free, _ = self.ctxs[0].mem_info()
+            if per_ctx is not None and free < per_ctx + min_free_gb * 1e9:
+                break
+            if per_ctx is None and free < (min_free_gb + 8.0) * 1e9:
+                break
+            cx = Context(self.device, lib=self.ctxs[0].lib)
+            try:
+                resident_small.align(self.index, self.prm, want_records=False, ctx=cx)
+            except VmxError as e:
+                cx.close()
+                if e.code != -4:
+                    raise
+                break
+            free2, _ = self.ctxs[0].mem_info()
+            per_ctx = max(float(free - free2), 1e9)
+            if free2 < min_free_gb * 1e9:
+                cx.close()
+                break
+            self.ctxs.append(cx); self.small_ctxs.append(cx); added += 1
+        if added:
+            self.inflight = len(self.ctxs)
+            for cx in self.ctxs:
+                cx.set_inflight(self.inflight)
+        return added
+
+    def _run(self, n_jobs, do_job, on_result, job_bases=None, horizon=DEFAULT_WINDOW_BATCHES):
+        """`inflight` threads pull job indices in order; do_job(i, ctx) -> result; on_result(i, result) is called under a lock.
+        job_bases (with small contexts, add_small_contexts): a full context takes the first job not taken yet; a small one the first job not taken yet that
+        holds at most `small_limit` bases, looking no further than `horizon` jobs ahead of the first untaken one (a stream does not hold more than that)"""
         lock = threading.Lock()
         nxt = [0]
         errs = []
+        small = set(id(c) for c in getattr(self, 'small_ctxs', [])) if job_bases is not None else set()
+        taken = [False] * n_jobs
+        import time as _time
+
+        def take(cx):
+            """index of the job this context runs next, -1: none left, -2: none eligible right now"""
+            while nxt[0] < n_jobs and taken[nxt[0]]:
+                nxt[0] += 1
+            if nxt[0] >= n_jobs:
+                return -1
+            if id(cx) not in small:
+                i = nxt[0]; taken[i] = True
+                return i
+            for i in range(nxt[0], min(n_jobs, nxt[0] + horizon)):
+                if not taken[i] and job_bases[i] <= self.small_limit:
+                    taken[i] = True
+                    return i
+            return -2
 
         def worker(cx):
             try:
                 while not errs:
                     with lock:
-                        i = nxt[0]; nxt[0] += 1
-                    if i >= n_jobs:
+                        i = take(cx)
+                    if i == -2:
+                        _time.sleep(0.0005)
+                        continue
+                    if i < 0:
                         return
                     _roctx.push('vacmapx batch %d' % i)
                     try:
@@ -191,7 +255,8 @@ class Pipeline:
         if self.inflight == 1 or n_jobs <= 1:
             worker(self.ctxs[0])
         else:
-            th = [threading.Thread(target=worker, args=(cx,)) for cx in list(self.ctxs[:min(self.inflight, n_jobs)])]
+            pool = list(self.ctxs) if small else self.full_ctxs()
+            th = [threading.Thread(target=worker, args=(cx,)) for cx in pool[:min(len(pool), n_jobs)]]
             for t in th:
                 t.start()
             for t in th:
@@ -225,7 +290,7 @@ class Pipeline:
             except BaseException as e:
                 errs.append(e)
 
-        th = [threading.Thread(target=worker, args=(cx,)) for cx in list(self.ctxs[:self.inflight])]
+        th = [threading.Thread(target=worker, args=(cx,)) for cx in self.full_ctxs()]
         for t in th:
             t.start()
         for t in th:
@@ -235,7 +300,8 @@ class Pipeline:
 
     def run_resident(self, resident, want_records=False, on_result=None):
         """resident: list of ResidentReads in schedule order (plan_batches). on_result(i, (status, records or None, stats))"""
-        self._run(len(resident), lambda i, cx: resident[i].align(self.index, self.prm, want_records=want_records, ctx=cx), on_result)
+        self._run(len(resident), lambda i, cx: resident[i].align(self.index, self.prm, want_records=want_records, ctx=cx), on_result,
+                  job_bases=[r.bases for r in resident] if getattr(self, 'small_ctxs', None) else None)
 
     def run_host(self, batches, on_result=None):
         """batches: list of lists of read sequences (host memory; uploaded by vm_align_batch). on_result(i, (status, records, stats))"""
@@ -276,7 +342,7 @@ class Pipeline:
                 except BaseException as e:
                     errs.append(e)
                 finally:
-                    for _ in range(self.inflight):
+                    for _ in range(len(self.ctxs)):
                         ready_q.put(None)
             lock = threading.Lock()
 
@@ -294,7 +360,7 @@ class Pipeline:
                                 on_result(i, sd)
                 except BaseException as e:
                     errs.append(e); free_q.put(None)
-            th = [threading.Thread(target=producer)] + [threading.Thread(target=consumer, args=(cx,)) for cx in list(self.ctxs[:self.inflight])]
+            th = [threading.Thread(target=producer)] + [threading.Thread(target=consumer, args=(cx,)) for cx in self.full_ctxs()]
             for t in th:
                 t.start()
             for t in th:
