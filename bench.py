@@ -210,7 +210,7 @@ def main():
     n_minimizers = index.n_minimizers()
 
     resident = pipeline.upload_batches(ctx, pool_cat, pool_off, plan)        # inputs resident in HBM before timing
-    pipe = pipeline.Pipeline(index, prm, device=local_rank, inflight=max(1, min(args.streams or 5, nsteps)), first_ctx=ctx)
+    pipe = pipeline.Pipeline(index, prm, device=local_rank, inflight=max(1, min(args.streams or int(os.environ.get('VMX_FULL_CTX', '5')), nsteps)), first_ctx=ctx)
     if world > 1 and os.environ.get('VMX_SPIN_SYNC') != '1':
         # N ranks on one host: the contexts' threads SLEEP while they wait for the GPU (the driver's setting) — five spinning threads per rank times eight ranks
         # would take forty cores for nothing; host threads per rank in the timed region: `streams` mostly-sleeping aligner threads + the main thread
@@ -250,12 +250,14 @@ def main():
     ctx_dropped = warm_oom + pipe.trim_to_memory()
     ctx_added = 0; ctx_small = 0
     if args.streams == 0 and not ctx_dropped and args.warmup > 0:
-        ctx_added = pipe.grow_to_memory(resident[longest], max_inflight=min(8, nsteps)); warm_runs += ctx_added
-        if not ctx_added and os.environ.get('VMX_SMALL_CTX', '1') != '0' and nsteps >= 8:
-            # no room for another full context (its pools are sized by the window's longest batch): contexts for the shorter batches only, sized on the median batch
+        if os.environ.get('VMX_NO_FULL_GROWTH') != '1':
+            ctx_added = pipe.grow_to_memory(resident[longest], max_inflight=min(8, nsteps)); warm_runs += ctx_added
+        if os.environ.get('VMX_SMALL_CTX', '1') != '0' and nsteps >= 8:
+            # where no (further) full context fits — its pools are sized by the window's longest batch — contexts for the shorter batches only, sized on the median
+            # batch (ONT-hg38: 5 full + 1 small = 283 GB, 15.1-15.7 ms per step against 15.8-15.9; fewer full ones lose: 4 + 3: 15.5-16.1, 4 + 4: 15.4, 3 + 6: 16.1)
             by_bases = sorted(range(nsteps), key=lambda j: resident[j].bases)
-            med = by_bases[len(by_bases) // 2]
-            ctx_small = pipe.add_small_contexts(resident[med], resident[med].bases, max_inflight=min(9, nsteps))
+            med = by_bases[int(len(by_bases) * float(os.environ.get('VMX_SMALL_PCT', '0.5')))]
+            ctx_small = pipe.add_small_contexts(resident[med], resident[med].bases, max_inflight=min(int(os.environ.get('VMX_MAX_CTX', '9')), nsteps))
             warm_runs += ctx_small * resident[med].bases / float(max(resident[longest].bases, 1))          # (in units of the longest batch: the PMC summaries scale by warm-up bases)
         if world > 1 and os.environ.get('VMX_SPIN_SYNC') != '1':
             for cx in pipe.ctxs:
