@@ -313,7 +313,8 @@ class Pipeline:
         if getattr(self, '_up', None) is None:
             first = self.ctxs[0]
             up_ctx = Context(self.device, lib=first.lib)
-            self._up = (up_ctx, [ResidentReads(up_ctx, concat=largest_blob[0], offsets=largest_blob[1]) for _ in range(n_slots or self.inflight + 2)])
+            n_small = len(getattr(self, 'small_ctxs', []))
+            self._up = (up_ctx, [ResidentReads(up_ctx, concat=largest_blob[0], offsets=largest_blob[1]) for _ in range(n_slots or self.inflight + 2 + 2 * n_small)])
         return self._up
 
     def run_host_blobs(self, blobs, on_result=None, prefetch=False):
@@ -326,10 +327,14 @@ class Pipeline:
             import queue
             big = max(blobs, key=lambda b: int(b[1][-1]))
             up_ctx, slots = self.upload_slots(big)
-            free_q, ready_q = queue.Queue(), queue.Queue()
+            free_q = queue.Queue()
             for sl in slots:
                 free_q.put(sl)
             errs = []
+            ready, cv, state = [], threading.Condition(), {'done': False}     # uploaded batches waiting for a context, in upload order
+            small = set(id(c) for c in getattr(self, 'small_ctxs', []))
+            # (with small contexts the uploader runs further ahead — upload_slots makes two more slots per small context: a small context can only take a batch
+            # at or below its limit, and the batches of a window come longest first)
 
             def producer():
                 try:
@@ -338,18 +343,29 @@ class Pipeline:
                         if sl is None:
                             return
                         sl.reupload(cat, off, ctx=up_ctx)
-                        ready_q.put((i, sl))
+                        with cv:
+                            ready.append((i, sl)); cv.notify_all()
                 except BaseException as e:
                     errs.append(e)
                 finally:
-                    for _ in range(len(self.ctxs)):
-                        ready_q.put(None)
+                    with cv:
+                        state['done'] = True; cv.notify_all()
             lock = threading.Lock()
 
             def consumer(cx):
+                is_small = id(cx) in small
                 try:
                     while not errs:
-                        item = ready_q.get()
+                        with cv:
+                            item = None
+                            while item is None and not errs:
+                                for x, (i, sl) in enumerate(ready):
+                                    if not is_small or sl.bases <= self.small_limit:
+                                        item = ready.pop(x); break
+                                if item is None:
+                                    if state['done'] and (not ready or is_small):
+                                        return
+                                    cv.wait(0.05)
                         if item is None:
                             return
                         i, sl = item
@@ -360,7 +376,9 @@ class Pipeline:
                                 on_result(i, sd)
                 except BaseException as e:
                     errs.append(e); free_q.put(None)
-            th = [threading.Thread(target=producer)] + [threading.Thread(target=consumer, args=(cx,)) for cx in self.full_ctxs()]
+                    with cv:
+                        cv.notify_all()
+            th = [threading.Thread(target=producer)] + [threading.Thread(target=consumer, args=(cx,)) for cx in list(self.ctxs)]
             for t in th:
                 t.start()
             for t in th:
