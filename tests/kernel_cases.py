@@ -548,7 +548,7 @@ def check_seed_many_hits(ctx, O, copies=30, unit=2500, read_len=4000, seed=61, m
     gi.close()
 
 
-def check_align_golden(ctx, O, golden, cases=('A', 'B', 'C', 'D'), reads=None):
+def check_align_golden(ctx, O, golden, cases=('A', 'B', 'C', 'D'), reads=None, min_ext_retries=None):
     """the whole batched path (vm_align_batch) vs the reference's records (V6) and vs the oracle run live"""
     from vacmap_amd.lib import align_batch
     meta, arrays = golden
@@ -568,6 +568,8 @@ def check_align_golden(ctx, O, golden, cases=('A', 'B', 'C', 'D'), reads=None):
             assert mine == omine, (cid, ri, 'records differ from the oracle')
             assert (status[x] == 0) == (r['v6_status'] == 0) and mine == r['v6_records'], (cid, ri, 'records differ from the reference golden')
         assert stats['n_reads'] == len(seqs)
+        if min_ext_retries is not None:
+            assert stats['n_ext_retries'] >= min_ext_retries, (cid, stats['n_ext_retries'])
 
 
 _COMP = bytes.maketrans(b'ACGTN', b'TGCAN')
@@ -948,7 +950,7 @@ def check_asm_ragged(ctx, O):
     return n
 
 
-def check_local_many_chains(ctx, O, copies=80, unit=900, seed=91):
+def check_local_many_chains(ctx, O, copies=80, unit=900, seed=91, modes=('S', 'H'), min_copies=64):
     """mode S re-seeds EVERY chain of hit2work_1 (mammap_sensitive.py: no budget): a read with far more than 64 chains (the cap the local stage
     had, DESIGN D5) — one per dispersed copy of its sequence — through vm_local_chain_batch vs the oracle: raw local anchors, variant, score, chain"""
     from vacmap_amd.lib import Index, local_chain_batch
@@ -966,8 +968,8 @@ def check_local_many_chains(ctx, O, copies=80, unit=900, seed=91):
     # one chain per copy, the true one first (descending read order, rows (q, r, strand, len)): anchors every ~150 bases along the copy's diagonal
     qs = list(range(unit - 120, 40, -150))
     paths = [np.array([[q, starts[c] + q, 1, 15] for q in qs], dtype=np.int64) for c in range(copies)]
-    assert len(paths) > 64
-    for mode in ('S', 'H'):
+    assert len(paths) > min_copies
+    for mode in modes:
         prm = ctx.lib.params(mode); oprm = O.params(mode)
         g = local_chain_batch(ctx, gi, prm, [read.encode()], [paths])[0]
         o = O.local_chain(oi, read.encode(), paths, oprm)
@@ -977,5 +979,5 @@ def check_local_many_chains(ctx, O, copies=80, unit=900, seed=91):
         assert g['variant'] == o['variant'] and g['score'] == o['score'] and np.array_equal(g['chain'], o['chain']), mode
         if mode == 'S':
             rr = g['raw'][:, 1]
-            assert sum(bool(np.any((rr >= st) & (rr < st + unit))) for st in starts) > 64      # anchors inside more than 64 copies: every chain was re-seeded
+            assert sum(bool(np.any((rr >= st) & (rr < st + unit))) for st in starts) > min_copies      # anchors inside more than 64 copies: every chain was re-seeded
     gi.close()

@@ -106,8 +106,12 @@ def test_emu_local_general_kernel(ctx, oracle, golden, monkeypatch):
     KC.check_local_golden(ctx, oracle, golden, cases=['B', 'D', 'G'])
 
 
-def test_emu_local_many_chains(ctx, oracle):
+def test_emu_local_many_chains(ctx, oracle, monkeypatch):
     KC.check_local_many_chains(ctx, oracle, copies=70, unit=500)
+    # more guide chains than the general kernel's emission key used to hold (511 until round 4), on both kernels
+    KC.check_local_many_chains(ctx, oracle, copies=530, unit=400, seed=93, modes=('S',), min_copies=500)
+    monkeypatch.setenv('VMX_LSEED_BAND', '0')
+    KC.check_local_many_chains(ctx, oracle, copies=530, unit=400, seed=93, modes=('S',), min_copies=500)
 
 
 def test_emu_local(ctx, oracle, golden):
@@ -123,6 +127,27 @@ def test_emu_align_end_to_end(ctx, oracle, golden):
     KC.check_align_golden(ctx, oracle, golden, cases=['J'], reads=[0, 5, 18]) # mode S (incl. the chimera)
     KC.check_align_golden(ctx, oracle, golden, cases=['K'], reads=[5, 7])     # mode L at k 19 (reads with a strand switch)
     KC.check_align_golden(ctx, oracle, golden, cases=['H'], reads=[3])        # nested SVs from the vacsim-grammar donor, mode R
+
+
+def test_emu_extend_pools_grow_and_retry(ctx, oracle, golden, monkeypatch):
+    """every pool of the extend stage made too small through the test hook (VMX_TEST_EXT_POOL=<mask>:<div>; 1 segment anchors, 2 segments, 4 record blob,
+    8 problems per round, 16 problem strings): the read / batch reports it, the batch is run again with the pools x4 until they hold it, and the records
+    are those of the reference (the extend stage's capacity ends used to stop at VM_READ_CAPACITY / VM_ERR_OOM)"""
+    for mask, div in ((1, 64), (2, 512), (4, 64), (8, 64), (16, 512), (31, 512)):
+        monkeypatch.setenv('VMX_TEST_EXT_POOL', '%d:%d' % (mask, div))
+        KC.check_align_golden(ctx, oracle, golden, cases=['D'], reads=[1], min_ext_retries=1)      # (one read here: every retry is a whole pass of the emulator; all reads on the GPU)
+    monkeypatch.setenv('VMX_TEST_EXT_POOL', '31:2000000000')      # nothing left of any pool: the retries run out (x1024) and the reads are REPORTED, not truncated
+    from vacmap_amd.lib import align_batch
+    meta, arrays = golden
+    gi, _ = KC._case_index(ctx, oracle, meta, arrays, 'D')
+    seqs = [arrays['D_r%d_seq' % ri].tobytes().decode() for ri in (1,)]
+    try:
+        status, recs, stats = align_batch(ctx, gi, ctx.lib.params(meta['D']['mode']), seqs)
+        assert int(status[0]) == -20 and not recs and stats['n_ext_retries'] >= 5
+    except Exception as e:                                           # (or the batch as a whole: the per-batch pools report through the error)
+        assert 'pool' in str(e) or 'memory' in str(e), e
+    monkeypatch.delenv('VMX_TEST_EXT_POOL')
+    KC.check_align_golden(ctx, oracle, golden, cases=['D'], reads=[1], min_ext_retries=0)
 
 
 def test_emu_stage_trace(ctx, oracle, golden):

@@ -102,8 +102,12 @@ def test_local_general_kernel(ctx, oracle, golden, monkeypatch):
     KC.check_local_golden(ctx, oracle, golden, cases=['A', 'B', 'C', 'D', 'G', 'J', 'K'])
 
 
-def test_local_many_chains(ctx, oracle):
+def test_local_many_chains(ctx, oracle, monkeypatch):
     KC.check_local_many_chains(ctx, oracle)
+    # more guide chains than the general kernel's emission key used to hold (511: the guide's number in 9 fixed bits; now a running base), on both kernels
+    KC.check_local_many_chains(ctx, oracle, copies=600, unit=400, seed=93, modes=('S',), min_copies=520)
+    monkeypatch.setenv('VMX_LSEED_BAND', '0')
+    KC.check_local_many_chains(ctx, oracle, copies=600, unit=400, seed=93, modes=('S',), min_copies=520)
 
 
 @pytest.mark.gpu
@@ -113,6 +117,28 @@ def test_local_golden(ctx, oracle, golden):
 
 def test_align_golden(ctx, oracle, golden):
     KC.check_align_golden(ctx, oracle, golden)
+
+
+def test_extend_pools_grow_and_retry(ctx, oracle, golden, monkeypatch):
+    """every pool of the extend stage made too small through the test hook VMX_TEST_EXT_POOL=<mask>:<div> (1 segment anchors, 2 segments, 4 record blob,
+    8 problems per round, 16 problem strings; 31 all): the read (VMX_EXT_CAPACITY_DEV) or the batch (overflow flag) reports it, the batch runs again with
+    the pools x4 until they hold it, the records are the reference's. With nothing left of the pools the retries run out and the reads are REPORTED
+    (VM_READ_CAPACITY), never truncated (sites: k_ext.hip / vmx_extend.h VMX_EXT_CAPACITY_DEV, k_gather's pool_cap)"""
+    from vacmap_amd.lib import align_batch
+    for mask, div in ((1, 64), (2, 4096), (4, 512), (8, 4096), (16, 4096), (31, 512)):
+        monkeypatch.setenv('VMX_TEST_EXT_POOL', '%d:%d' % (mask, div))
+        KC.check_align_golden(ctx, oracle, golden, cases=['D'], min_ext_retries=1)
+    monkeypatch.setenv('VMX_TEST_EXT_POOL', '31:64')
+    KC.check_align_golden(ctx, oracle, golden, cases=['A', 'H', 'I'], min_ext_retries=1)       # modes H, R and the rare branches of the segment surgery
+    monkeypatch.setenv('VMX_TEST_EXT_POOL', '15:2000000000')
+    meta, arrays = golden
+    gi, _ = KC._case_index(ctx, oracle, meta, arrays, 'D')
+    seqs = [arrays['D_r%d_seq' % ri].tobytes().decode() for ri in range(len(meta['D']['reads']))]
+    status, recs, stats = align_batch(ctx, gi, ctx.lib.params(meta['D']['mode']), seqs)
+    assert stats['n_ext_retries'] == 5 and not recs
+    assert all(int(s_) == -20 for s_, r_ in zip(status, meta['D']['reads']) if r_['v6_records'])
+    monkeypatch.delenv('VMX_TEST_EXT_POOL')
+    KC.check_align_golden(ctx, oracle, golden, cases=['D'], min_ext_retries=0)
 
 
 def test_align_random_vs_oracle(ctx, oracle):

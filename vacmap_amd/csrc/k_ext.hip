@@ -76,7 +76,7 @@ __device__ __forceinline__ int vmx_split_alignment_w(vmx_segs& S, int s, long lo
         if (!m) { k += 64; continue; }
         const int e = __ffsll((unsigned long long)m) - 1;
         const vmx_anchor kept = vmx_anchor_from_lane(now, e);
-        if (out && np >= cap) return VM_READ_CAPACITY_DEV;
+        if (out && np >= cap) return VMX_EXT_CAPACITY_DEV;
         vmx_pair_desc d;
         if (fwd) vmx_qt_for_cigar(pre, kept, L, R, &d); else vmx_qt_for_cigar(kept, pre, L, R, &d);
         if (out && lane == 0) out[np] = d;
@@ -97,7 +97,7 @@ __device__ __forceinline__ vmx_anchor vmx_anchor_up1(const vmx_anchor& a) {     
 // lanes behind it are tested again. Same segments, same return codes as the one-lane form.
 __device__ __forceinline__ int vmx_rebuild_chain_break_w(const vmx_anchor* chain_desc, int n, const vmx_ref_view& R, int large_cost, int small_alignment, vmx_segs& S, bool asmv, int lane) {
     S.nseg = 0;
-    if (S.capS < 1 || S.capA < 4) return VM_READ_CAPACITY_DEV;
+    if (S.capS < 1 || S.capA < 4) return VMX_EXT_CAPACITY_DEV;
     vmx_anchor pre = chain_desc[n - 1];
     int w = 2, nseg = 1, st_cur = 1; long long segq0 = pre.q;     // the open segment: A[st_cur .. w), its first anchor's q; closed segments live in st / en
     bool cur_alive = true;
@@ -120,7 +120,7 @@ __device__ __forceinline__ int vmx_rebuild_chain_break_w(const vmx_anchor* chain
             const int e = ev ? __ffsll((unsigned long long)ev) - 1 : nv;
             const int cnt = e - pos;
             if (cnt > 0) {
-                if (w + cnt + 1 > S.capA) return VM_READ_CAPACITY_DEV;
+                if (w + cnt + 1 > S.capA) return VMX_EXT_CAPACITY_DEV;
                 if (lane >= pos && lane < e) S.A[w + lane - pos] = now;
                 w += cnt; pre = vmx_anchor_from_lane(now, e - 1);
             }
@@ -147,7 +147,7 @@ __device__ __forceinline__ int vmx_rebuild_chain_break_w(const vmx_anchor* chain
                 if (!cur_alive) { __threadfence_block(); (void)__ballot(1); last_en = S.en[nseg - 1]; }
                 w = last_en + 2;
             } else w = 1;
-            if (nseg + 1 > S.capS || w + 2 > S.capA) return VM_READ_CAPACITY_DEV;
+            if (nseg + 1 > S.capS || w + 2 > S.capA) return VMX_EXT_CAPACITY_DEV;
             if (lane == 0) { S.st[nseg] = w; S.A[w] = ea; }
             st_cur = w; ++w; ++nseg; pre = ea; segq0 = ea.q; cur_alive = true;
         }
@@ -203,7 +203,7 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
         E.nseg = S.nseg;
         if (A.asm_long) { E.prob_base = 0; E.prob_n = 0; return; }                  // ass_extend_func has no divergence filter
         int b = vmx_alloc_probs(A, S.nseg);
-        if (b < 0) { E.status = VM_READ_CAPACITY_DEV; return; }
+        if (b < 0) { E.status = VMX_EXT_CAPACITY_DEV; return; }
         E.prob_base = b; E.prob_n = S.nseg;
         for (int s = 0; s < S.nseg; ++s) {
             vmx_pair_desc d; vmx_qt_for_cigar(SEG_FIRST(S, s), SEG_LAST(S, s), L, R, &d);
@@ -271,7 +271,7 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
         }
         int b = lane == 0 ? vmx_alloc_probs(A, total) : 0;
         b = __shfl(b, 0);
-        if (b < 0) { if (lane == 0) E.status = VM_READ_CAPACITY_DEV; return; }
+        if (b < 0) { if (lane == 0) E.status = VMX_EXT_CAPACITY_DEV; return; }
         int k = 0;
         for (int s = 0; s < S.nseg; ++s) {
             const int np = vmx_split_alignment_w(S, s, L, R, A.desc + b + k, total - k, A.mode == 4, lane);
@@ -314,7 +314,7 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
                 if (pass == 0) { if (vmx_ext_setup(S, s, 1, L, R, &tmp)) { segprob[s] = k++; } }
                 else if (segprob[s] >= 0) { vmx_ext_setup(S, s, 1, L, R, &tmp); A.desc[b + segprob[s]] = tmp; }
             }
-            if (pass == 0) { np = k; b = vmx_alloc_probs(A, np); if (b < 0) { E.status = VM_READ_CAPACITY_DEV; return; } }
+            if (pass == 0) { np = k; b = vmx_alloc_probs(A, np); if (b < 0) { E.status = VMX_EXT_CAPACITY_DEV; return; } }
         }
         E.prob_base = b < 0 ? 0 : b; E.prob_n = np;
         return;
@@ -328,7 +328,7 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
                 if (pass == 0) { if (vmx_ext_setup(S, s, 0, L, R, &tmp)) { segprob[s] = k++; } }
                 else if (segprob[s] >= 0) { vmx_ext_setup(S, s, 0, L, R, &tmp); A.desc[b + segprob[s]] = tmp; }
             }
-            if (pass == 0) { np = k; b = vmx_alloc_probs(A, np); if (b < 0) { E.status = VM_READ_CAPACITY_DEV; return; } }
+            if (pass == 0) { np = k; b = vmx_alloc_probs(A, np); if (b < 0) { E.status = VMX_EXT_CAPACITY_DEV; return; } }
         }
         E.prob_base = b < 0 ? 0 : b; E.prob_n = np;
         return;
@@ -346,7 +346,7 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
             segprob[s] = np; total += np;
         }
         int b = vmx_alloc_probs(A, total);
-        if (b < 0) { E.status = VM_READ_CAPACITY_DEV; return; }
+        if (b < 0) { E.status = VMX_EXT_CAPACITY_DEV; return; }
         int k = 0;
         for (int s = 0; s < S.nseg; ++s) {
             int np = vmx_split_alignment(S, s, L, R, A.desc + b + k, total - k, A.mode == 4);
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(64) k_ext_records(vmx_ext_args A, const vmx_dp
         long long need = 0, qsum = 0;
         for (int x = lane; x < np; x += 64) { need += cig_len[dp_base + k + x]; qsum += cig_q[dp_base + k + x]; }
         need = vmx_wave_sum_i64(need) + 48; qsum = vmx_wave_sum_i64(qsum);
-        if (w + need > blob_cap) { fail = VM_READ_CAPACITY_DEV; break; }
+        if (w + need > blob_cap) { fail = VMX_EXT_CAPACITY_DEV; break; }
         const long long st = w;
         char tmp[24];
         if (q_st > 0) { const int nd = vmx_put_int(tmp, q_st); if (lane == 0) { for (int i = 0; i < nd; ++i) BLOB[w + i] = tmp[i]; BLOB[w + nd] = clip; } w += nd + 1; }

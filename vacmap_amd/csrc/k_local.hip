@@ -141,8 +141,12 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
         vmx_anchor* SORTED = A.la_sorted + A.la_off[r];
         const int out_cap = A.rd_off ? (int)(A.la_off[r + 1] - A.la_off[r]) : (int)(A.la_slot_len * VMX_LA_SLOT((int64_t)L));     // slot of this read in the local-anchor pools
         int n_out = 0;
-        int status = ng > 511 ? VM_READ_CAPACITY_DEV : 0;          // (the guide index travels in 9 bits of the emission key)
+        int status = 0;
         int gbase = 0;
+        // emission keys (the reference's append order) of guide g live in [ebase, ebase + 2 H_g): flushes inside runs by the stream index of the hit that
+        // triggers them, then the leftovers of the last runs (+ H_g). A running base instead of the guide's number in fixed bits: any number of guides
+        // (round 4 stopped at 511); 37 bits, i.e. 6.9e10 hits over all guides of a read, before the anchor's own 27-bit index
+        uint64_t ebase = 0;
         for (int g = 0; g < ng; ++g) {
             // NOTE: no barrier-skipping break/continue below: a failed guide sets `status` and every later phase of this guide runs on
             // empty ranges, so all waves of the workgroup meet every __syncthreads() (see the ED kernel's note on hardware hangs)
@@ -489,7 +493,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                             if (cl + bouns < 20) { if (strand == 1) { cs = 1; cl += bouns; } else { cr = refloc; cs = -1; cl += bouns; } }
                             else {
                                 const int o = n_out + atomicAdd(&s_emit, 1);
-                                if (o < out_cap) { OUT[o] = vmx_mk_anchor(cq, cr, cs, cl); OKEY[o] = ((uint64_t)g << 28) | sidx; }
+                                if (o < out_cap) { OUT[o] = vmx_mk_anchor(cq, cr, cs, cl); OKEY[o] = ebase + sidx; }
                                 const long long nq = cq + cl;
                                 if (strand == 1) { cr = cr + cl; cs = 1; } else { cr = refloc; cs = -1; }
                                 cq = nq; cl = bouns;
@@ -498,8 +502,8 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                         }
                         {
                             uint64_t ek;
-                            if (j < HH && (HKEY[j] >> 26) == pk) ek = ((uint64_t)g << 28) | (HKEY[j] & ((1ULL << 26) - 1));
-                            else ek = ((uint64_t)g << 28) | (1ULL << 26) | (HKEY[DST[i]] & ((1ULL << 26) - 1));
+                            if (j < HH && (HKEY[j] >> 26) == pk) ek = ebase + (HKEY[j] & ((1ULL << 26) - 1));
+                            else ek = ebase + (uint64_t)HH + (HKEY[DST[i]] & ((1ULL << 26) - 1));
                             const int o = n_out + atomicAdd(&s_emit, 1);
                             if (o < out_cap) { OUT[o] = vmx_mk_anchor(cq, cr, cs, cl); OKEY[o] = ek; }
                         }
@@ -508,6 +512,8 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
                     if (threadIdx.x == 0) s_tot = s_emit;
                     __syncthreads();
                     if (n_out + s_tot > out_cap) status = VM_READ_CAPACITY_DEV;
+                    ebase += 2 * (uint64_t)HH;
+                    if (ebase >> 37) status = VM_READ_CAPACITY_DEV;
                     __syncthreads();
                 }
             }
@@ -521,7 +527,7 @@ __global__ void __launch_bounds__(512, VMX_LSEED_WAVES) k_local_seed(vmx_lseed_a
             if (status == 0 && n_out > 0 && NO > A.hit_cap) status = VM_READ_CAPACITY_DEV;
             const long long no = status ? 0 : n_out;
             const long long NP = no > 0 ? NO : 0;
-            for (long long i = threadIdx.x; i < NP; i += blockDim.x) HKEY[i] = i < no ? ((OKEY[i] << 27) | (uint64_t)i) : ~0ULL;      // guide (< 512) | final flag | stream index (26 bits), then the anchor's index (< 2^27)
+            for (long long i = threadIdx.x; i < NP; i += blockDim.x) HKEY[i] = i < no ? ((OKEY[i] << 27) | (uint64_t)i) : ~0ULL;      // emission key (< 2^37: running base of the guide + final flag * H + stream index), then the anchor's index (< 2^27)
             __syncthreads();
             if (NP > 1) vmx_block_sort_u64_tiled(HKEY, (int)NP, s_sort, VMX_SORT_LDS);
             __syncthreads();

@@ -186,8 +186,28 @@ int vmx_align_batch_asm_mixed(vm_ctx* c, const vm_index* mi, const vm_params* pr
 int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
                  vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats, vmx_seg_trace* trace = nullptr, const vmx_preset* preset = nullptr);
 
+#define VMX_RETRY_EXT_POOLS (-9001)      // align_device_once -> align_device: an extend-stage pool was too small, c->ext_mul has been raised
+static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
+                             vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats, vmx_seg_trace* trace, const vmx_preset* preset);
+// The pools of the extend stage are sized from bounds that hold by construction for the reference's segment surgery (a chain never has more segments than
+// anchors, a round never more problems than anchors, ...) — and where a bound is an estimate (the problem strings of a round: 6 bytes per read base) or a
+// construction turns out wrong for some input, the read or the batch reports it (VMX_EXT_CAPACITY_DEV / the overflow flag) and the batch is run again
+// with every extend-stage pool four times larger, up to x1024, before a read is given up as VM_READ_CAPACITY. VMX_TEST_EXT_POOL=<mask>:<div> (tests) divides
+// the pools the mask names (1 segment anchors, 2 segments, 4 record blob, 8 problems per round, 16 problem strings) so that each of these ends is exercised.
 int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
-                        vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats, vmx_seg_trace* trace, const vmx_preset* preset) {
+                 vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats, vmx_seg_trace* trace, const vmx_preset* preset) {
+    c->ext_mul = 1;
+    int64_t retries = 0;
+    for (;;) {
+        const int rc = align_device_once(c, mi, prm, n, d_codes, d_roff, h_roff, recs, n_recs, cigar_blob, status_per_read, stats, trace, preset);
+        if (rc != VMX_RETRY_EXT_POOLS) { c->ext_mul = 1; if (rc == VM_OK && stats) stats->n_ext_retries = retries; return rc; }
+        ++retries;
+        if (trace) { trace->rows.clear(); trace->off.clear(); }
+    }
+}
+
+static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
+                             vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats, vmx_seg_trace* trace, const vmx_preset* preset) {
     *recs = nullptr; *n_recs = 0; *cigar_blob = nullptr;
     vmx_batch_bufs& B = *batch_bufs(c);
     vm_index_view ix; vmx_index_view(mi, &ix);
@@ -357,10 +377,13 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     // ---------------- E1-E6 extend stage
     // per-read pool geometry from the local anchor count (the chain is never longer than that)
     std::vector<int64_t> coff3((size_t)n + 1), soff2((size_t)n + 1), bloboff((size_t)n + 1);
+    int tmask = 0; int64_t tdiv = 1;                            // test hook: VMX_TEST_EXT_POOL=<mask>:<div>
+    if (const char* e = getenv("VMX_TEST_EXT_POOL")) { long long m_ = 0, d_ = 1; if (sscanf(e, "%lld:%lld", &m_, &d_) == 2 && d_ >= 1) { tmask = (int)m_; tdiv = d_; } }
+    auto pool = [&](int bit, int64_t x) -> int64_t { const int64_t y = x * c->ext_mul; return (tmask & bit) ? std::max<int64_t>(y / tdiv, 1) : y; };
     for (int64_t r = 0; r < n; ++r) {
         const int64_t cl = L.h_la_cnt[r], len = h_roff[r + 1] - h_roff[r];
-        coff3[r + 1] = coff3[r] + (cl > 0 ? 3 * cl + 8 : 0); soff2[r + 1] = soff2[r] + (cl > 0 ? cl + 2 : 0);
-        bloboff[r + 1] = bloboff[r] + (cl > 0 ? ((3 * len + 64 * (cl / 2 + 2) + 63) & ~(int64_t)7) : 0);
+        coff3[r + 1] = coff3[r] + (cl > 0 ? pool(1, 3 * cl + 8) : 0); soff2[r + 1] = soff2[r] + (cl > 0 ? pool(2, cl + 2) : 0);
+        bloboff[r + 1] = bloboff[r] + (cl > 0 ? ((pool(4, 3 * len + 64 * (cl / 2 + 2) + 56) + 7) & ~(int64_t)7) : 0);
     }
     const int64_t cA = coff3[n], cS = soff2[n], cB = bloboff[n];
     VMX_TRY(B.er.reserve(sizeof(vmx_ext_read) * (size_t)(n + 1))); VMX_TRY(upload(B.coff3, coff3.data(), (size_t)n + 1, c->stream)); VMX_TRY(upload(B.soff2, soff2.data(), (size_t)n + 1, c->stream));
@@ -368,8 +391,9 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     VMX_TRY(B.segA.reserve(sizeof(vmx_anchor) * (size_t)(cA + 1))); VMX_TRY(B.segA_s.reserve(sizeof(vmx_anchor) * (size_t)(cA + 1)));
     VMX_TRY(B.st.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.en.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.st_s.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.en_s.reserve(4 * (size_t)(cS + 1)));
     VMX_TRY(B.segprob.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.dup.reserve(4 * (size_t)(cS + 1)));
-    const int64_t round_cap = cS + 16;                       // one problem per anchor at most in any round
-    const int64_t pool_cap = 6 * total_bases + (1 << 20);
+    int64_t cS_full = 0; for (int64_t r = 0; r < n; ++r) if (L.h_la_cnt[r] > 0) cS_full += L.h_la_cnt[r] + 2;
+    const int64_t round_cap = pool(8, cS_full + 16);         // one problem per anchor at most in any round
+    const int64_t pool_cap = pool(16, 6 * total_bases + (1 << 20));
     int64_t Lmax_b = 1; for (int64_t r = 0; r < n; ++r) Lmax_b = std::max(Lmax_b, h_roff[r + 1] - h_roff[r]);
     const int64_t carry_stride = preset ? 32768 : 2 * Lmax_b + 32768;      // (ass_extend_func has no divergence filter: a preset chain never reaches the exact kernel, and a ring per
                                                                            //  workgroup sized by a 100 Mb contig asked for 617 GB)
@@ -611,6 +635,15 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     for (int i = 0; i < 8; ++i) hstat[i] = fin[6 + i];
     st.n_segments = hstat[0]; st.n_ed_problems = hstat[0]; st.n_ext_problems = (int64_t)hstat[1] + hstat[2] + hstat[3] + hstat[4];
     st.n_ed_full = n_full; st.n_ed_tier2 = n_t2; st.n_ed_tier1 = n_t1;
+    {   // a pool of the extend stage was too small (for the batch: overflow flag; for a read: its status): once more with larger pools
+        bool small = oflow != 0;
+        for (int64_t r = 0; r < n && !small; ++r) small = er[(size_t)r].status == VMX_EXT_CAPACITY_DEV;
+        if (small && c->ext_mul < 1024) {
+            c->ext_mul *= 4;
+            if (getenv("VMX_DBG_POOLS")) fprintf(stderr, "[pools] extend stage: a pool was too small (batch flag %d), running the batch again with x%d\n", oflow, c->ext_mul);
+            return VMX_RETRY_EXT_POOLS;
+        }
+    }
     if (oflow) { set_error("extend stage: a per-batch work pool overflowed"); return VM_ERR_OOM; }
     if (nr > g_nr || nb > g_nb) {                                 // the guess was short: fetch the tails
         if (nr > g_nr) { vm_record* p2 = (vm_record*)realloc(*recs, sizeof(vm_record) * (size_t)nr); if (!p2) { set_error("out of host memory"); return VM_ERR_OOM; } *recs = p2;
@@ -621,7 +654,7 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     }
     if (n > 0 && total_bases > 0) { c->res_rec_per_read = std::max(c->res_rec_per_read, (double)nr / (double)n); c->res_blob_per_base = std::max(c->res_blob_per_base, (double)nb / (double)total_bases); }
     for (int64_t r = 0; r < n; ++r) {
-        int stt2 = er[r].status;
+        int stt2 = er[r].status == VMX_EXT_CAPACITY_DEV ? VM_READ_CAPACITY : er[r].status;
         if (h_gmax[r] == -2 && (h_aoff[r + 1] - h_aoff[r]) > 2) stt2 = VM_READ_RAISED;     // GC-fast: the reference raises on this read (k_chain_fast.hip)
         if (h_gmax[r] == -4) stt2 = VM_READ_UNSUPPORTED;                                    // -mode asm: a contig of 500 kb or more inside align_device (vm_align_batch routes those to vmx_asm.hip)
         if (!asm_override.empty() && asm_override[(size_t)r] != 0) stt2 = asm_override[(size_t)r];
@@ -707,7 +740,7 @@ static int align_in_sub_batches(int64_t n, const int64_t* offsets, int64_t max_b
             tot.ms_total += st.ms_total; for (int i = 0; i < 16; ++i) tot.ms_stage[i] += st.ms_stage[i];
             tot.ms_gapfill_fill += st.ms_gapfill_fill; tot.ms_gapfill_trace += st.ms_gapfill_trace; tot.n_gapfill_launches += st.n_gapfill_launches;
             tot.n_ed_full += st.n_ed_full; tot.n_ed_tier2 += st.n_ed_tier2; tot.n_ed_tier1 += st.n_ed_tier1;
-            tot.n_dp_redo += st.n_dp_redo; tot.dp_redo_tb_bytes += st.dp_redo_tb_bytes; tot.ms_local_seed += st.ms_local_seed; tot.ms_cluster += st.ms_cluster; tot.n_host_syncs += st.n_host_syncs; tot.n_local_general += st.n_local_general;
+            tot.n_dp_redo += st.n_dp_redo; tot.dp_redo_tb_bytes += st.dp_redo_tb_bytes; tot.ms_local_seed += st.ms_local_seed; tot.ms_cluster += st.ms_cluster; tot.n_host_syncs += st.n_host_syncs; tot.n_local_general += st.n_local_general; tot.n_ext_retries += st.n_ext_retries;
         }
     }
     *recs = (vm_record*)malloc(sizeof(vm_record) * std::max<size_t>(all.size(), 1)); *cigar_blob = (char*)malloc(std::max<size_t>(blob.size(), 1));

@@ -10,6 +10,9 @@
 #define VMX_EXTEND_H
 #include "vmx_kernels.h"
 #include "vmx_local.h"
+// a pool of the EXTEND stage was too small for this read: the batch is run again with larger pools (vmx_align.hip, align_device); a read that still
+// carries the code when the retries are used up is reported as VM_READ_CAPACITY like a local-stage one
+#define VMX_EXT_CAPACITY_DEV (-21)
 #ifndef __host__
 #define __host__
 #define __device__
@@ -53,13 +56,13 @@ __host__ __device__ inline void vmx_seg_erase(vmx_segs& S, int s) {
     --S.nseg;
 }
 
-// E1 :23437-23484. chain in ASCENDING read order. returns 0, VM_READ_RAISED_DEV (IndexError at :23480) or VM_READ_CAPACITY_DEV
+// E1 :23437-23484. chain in ASCENDING read order. returns 0, VM_READ_RAISED_DEV (IndexError at :23480) or VMX_EXT_CAPACITY_DEV
 // asmv: the -mode asm fork (mammap_asm.py:13256-13295) joins only when refgap >= 0 (no tolerance for a 20-base back-step)
 __host__ __device__ inline int vmx_rebuild_chain_break(const vmx_anchor* chain_desc, int n, const vmx_ref_view& R, int large_cost, int small_alignment, vmx_segs& S, bool asmv = false) {
     S.nseg = 0;
     int w = 1;                                   // write cursor in A (slot 0 = spare before the first segment)
     vmx_anchor pre = chain_desc[n - 1];
-    if (S.capS < 1 || S.capA < 4) return VM_READ_CAPACITY_DEV;
+    if (S.capS < 1 || S.capA < 4) return VMX_EXT_CAPACITY_DEV;
     S.st[0] = w; S.A[w++] = pre; S.en[0] = w; S.nseg = 1;
     // the chain is walked serially (every step depends on the anchor kept before it), but the LOADS do not: VMX_PF anchors are fetched
     // ahead so that their HBM latencies overlap instead of adding up (one lane per read: nothing else hides them)
@@ -77,8 +80,8 @@ __host__ __device__ inline int vmx_rebuild_chain_break(const vmx_anchor* chain_d
             long long d = readgap - refgap; if (d < 0) d = -d;
             if (d <= large_cost && refgap >= (asmv ? 0 : -20) && readgap < 100) {
                 if (vmx_p2c(R, pre.r) == vmx_p2c(R, now.r)) {
-                    if (refgap >= 0) { if (w + 2 > S.capA) return VM_READ_CAPACITY_DEV; S.A[w++] = now; S.en[S.nseg - 1] = w; pre = now; continue; }
-                    else { if (readgap <= 20) continue; if (w + 2 > S.capA) return VM_READ_CAPACITY_DEV; S.A[w++] = now; S.en[S.nseg - 1] = w; pre = now; continue; }
+                    if (refgap >= 0) { if (w + 2 > S.capA) return VMX_EXT_CAPACITY_DEV; S.A[w++] = now; S.en[S.nseg - 1] = w; pre = now; continue; }
+                    else { if (readgap <= 20) continue; if (w + 2 > S.capA) return VMX_EXT_CAPACITY_DEV; S.A[w++] = now; S.en[S.nseg - 1] = w; pre = now; continue; }
                 }
             }
         }
@@ -89,7 +92,7 @@ __host__ __device__ inline int vmx_rebuild_chain_break(const vmx_anchor* chain_d
         }
         // new segment: spare slot after the previous one and before this one
         if (S.nseg > 0) w = S.en[S.nseg - 1] + 2; else w = 1;
-        if (S.nseg + 1 > S.capS || w + 2 > S.capA) return VM_READ_CAPACITY_DEV;
+        if (S.nseg + 1 > S.capS || w + 2 > S.capA) return VMX_EXT_CAPACITY_DEV;
         S.st[S.nseg] = w; S.A[w++] = now; S.en[S.nseg] = w; ++S.nseg;
         pre = now;
       }
@@ -370,7 +373,7 @@ __host__ __device__ inline int vmx_split_alignment(vmx_segs& S, int s, long long
             long long mn = readgap < refgap ? readgap : refgap;
             const long long mx = readgap < refgap ? refgap : readgap;
             if ((!asmv || mx < 2000) && (now.l < 19 || mn < min_gap_forcigar) && i + 1 != en) continue;
-            if (out && np >= cap) return VM_READ_CAPACITY_DEV;
+            if (out && np >= cap) return VMX_EXT_CAPACITY_DEV;
             vmx_pair_desc* d = out ? &out[np] : &tmp;
             vmx_qt_for_cigar(pre, now, L, R, d);
             if (d->t.len <= 0 || d->q.len <= 0) return VM_READ_RAISED_DEV;    // "Failed to compute CIGAR" :21562
@@ -394,7 +397,7 @@ __host__ __device__ inline int vmx_split_alignment(vmx_segs& S, int s, long long
             long long mn = readgap < refgap ? readgap : refgap;
             const long long mx = readgap < refgap ? refgap : readgap;
             if ((!asmv || mx < 2000) && (now.l < 19 || mn < min_gap_forcigar) && i != st) continue;
-            if (out && np >= cap) return VM_READ_CAPACITY_DEV;
+            if (out && np >= cap) return VMX_EXT_CAPACITY_DEV;
             vmx_pair_desc* d = out ? &out[np] : &tmp;
             vmx_qt_for_cigar(now, pre, L, R, d);
             if (d->t.len <= 0 || d->q.len <= 0) return VM_READ_RAISED_DEV;

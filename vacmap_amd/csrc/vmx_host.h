@@ -123,6 +123,7 @@ struct vm_ctx {
     hipEvent_t kev[4] = {nullptr, nullptr, nullptr, nullptr};   // around k_local_seed's main launch [0,1] and the clustering kernels [2,3] of the last batch
     int kev_set = 0;                              // bit 0: [0,1] recorded, bit 1: [2,3] recorded
     int64_t n_bandfall = 0;                       // reads k_local_seed_band handed back to k_local_seed (reset per batch)
+    int ext_mul = 1;                              // extend-stage pool multiplier of the running call (grow-and-retry in align_device)
     int64_t n_syncs = 0;                          // host waits on this context's stream (reset per batch)
     int64_t sync_wait_ns = 0, call_t0_ns = 0;     // time inside those waits; wall clock at the start of the batch (tuning: ms_stage[14] / [15])
     double res_rec_per_read = 0.0, res_blob_per_base = 0.0;   // largest records per read / CIGAR bytes per base a batch of this context produced (result copy size guess)
