@@ -277,6 +277,9 @@ def main():
     pipe.run_resident(resident, want_records=False, on_result=on_result)      # the product's schedule (vacmap_amd/pipeline.py)
     barrier()
     dt = time.time() - t1
+    if getattr(pipe, 'timeline', None):                     # VMX_DBG_TIMELINE=1: when every batch of the timed pass started and ended, on which context
+        for row in sorted(pipe.timeline, key=lambda r_: r_[3]):
+            sys.stderr.write('[timeline] batch %2d ctx %d%s  %7.1f -> %7.1f ms  (%5.1f ms)  %6.1f Mbases\n' % (row[0], row[1], ' small' if row[2] else '      ', row[3] * 1e3, row[4] * 1e3, (row[4] - row[3]) * 1e3, row[5] / 1e6))
 
     host_rate = None
     if args.host_input and rank == 0 and world == 1:

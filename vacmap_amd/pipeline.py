@@ -15,6 +15,7 @@ drives one GPU:
 BAM reader. The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); a batch drives one main
 and four side streams, so the package asks for 16 before the runtime starts (vacmap_amd/__init__.py).
 """
+import os
 import threading
 
 import numpy as np
@@ -212,6 +213,8 @@ class Pipeline:
         small = set(id(c) for c in getattr(self, 'small_ctxs', [])) if job_bases is not None else set()
         taken = [False] * n_jobs
         import time as _time
+        tl = [] if os.environ.get('VMX_DBG_TIMELINE') else None      # tuning aid: (job, context, small?, start s, end s, bases) of every job of this run
+        self.timeline = tl; t_run0 = _time.time()
 
         def take(cx):
             """index of the job this context runs next, -1: none left, -2: none eligible right now"""
@@ -239,10 +242,13 @@ class Pipeline:
                     if i < 0:
                         return
                     _roctx.push('vacmapx batch %d' % i)
+                    t_a = _time.time()
                     try:
                         res = do_job(i, cx)               # ctypes releases the GIL for the library call
                     finally:
                         _roctx.pop()
+                    if tl is not None:
+                        tl.append((i, self.ctxs.index(cx), id(cx) in small, t_a - t_run0, _time.time() - t_run0, int(job_bases[i]) if job_bases is not None else 0))
                     if on_result is not None:
                         with lock:
                             on_result(i, res)
