@@ -214,6 +214,56 @@ def test_pipeline_grows_batches_in_flight_to_memory(monkeypatch):
     assert p.grow_to_memory(run=run, max_inflight=12) == 0                              # nothing known about the pools and little room: not tried
 
 
+def test_pipeline_stream_ramps_contexts_in_the_background(monkeypatch):
+    """Pipeline.run_stream(ramp=...): the stream starts on the one sized context; the others are created, sized (run) and put to work by a background
+    thread while batches already run — by the memory rule (target 0) or up to a fixed number —, every job runs exactly once, a sizing run without
+    memory ends the growth without failing the run, and nothing more is sized once the jobs are exhausted"""
+    import threading, time
+    from vacmap_amd import pipeline
+    from vacmap_amd.lib import VmxError
+    state = {'free': 200e9, 'per': 40e9, 'made': 0, 'oom_at': None}
+
+    class FakeCtx:
+        def __init__(self, device=0, lib=None): self.lib, self.closed, self.inflight, self.blocking = lib, False, None, False; state['made'] += 1
+        def mem_info(self): return int(state['free']), int(309e9)
+        def close(self): self.closed = True
+        def set_inflight(self, n): self.inflight = n
+    monkeypatch.setattr(pipeline, 'Context', FakeCtx)
+
+    def sizing(cx):
+        if state['oom_at'] is not None and state['made'] - 1 >= state['oom_at']:
+            raise VmxError(-4, 'out of device memory')
+        time.sleep(0.01); state['free'] -= state['per']
+
+    def make():
+        p = object.__new__(pipeline.Pipeline)
+        p.device = 0; p.ctxs = [FakeCtx()]; p.inflight = 1
+        return p
+    seen = {}; lk = threading.Lock()
+
+    def do_job(job, cx):
+        time.sleep(0.004)
+        with lk:
+            seen.setdefault(job, []).append(cx)
+    # memory rule: 200 GB free, 40 GB per context, 14 GB head-room: 160 -> 120 -> 80 -> 40 (40 < 40 + 14: stop) = four added
+    p = make(); state['made'] = 1
+    p.run_stream(iter(range(60)), do_job, ramp=dict(run=sizing, target=0, max_inflight=8, on_ctx=lambda cx: setattr(cx, 'blocking', True)))
+    assert sorted(seen) == list(range(60)) and all(len(v) == 1 for v in seen.values())
+    assert p.inflight == 5 and all(c.inflight == 5 for c in p.ctxs) and all(c.blocking for c in p.ctxs[1:])
+    assert len(set(id(v[0]) for v in seen.values())) >= 3                                # the late contexts did take batches
+    assert seen[0][0] is p.ctxs[0]                                                       # and the first batch did not wait for them
+    # fixed target, and a sizing run that finds no memory: growth ends there, the run does not fail
+    seen.clear(); state.update(free=300e9, made=1, oom_at=3)
+    p = make()
+    p.run_stream(iter(range(40)), do_job, ramp=dict(run=sizing, target=6, max_inflight=8))
+    assert sorted(seen) == list(range(40)) and p.inflight == 2 and p.ramp_oom == 1
+    # a short stream: nothing is sized after the jobs are gone
+    seen.clear(); state.update(free=300e9, made=1, oom_at=None)
+    p = make()
+    p.run_stream(iter(range(2)), do_job, ramp=dict(run=sizing, target=8))
+    assert sorted(seen) == [0, 1] and p.inflight <= 2
+
+
 def test_pipeline_small_contexts_only_take_small_batches():
     """the size-aware schedule of Pipeline._run: a context added by add_small_contexts never runs a batch above its limit, every batch runs exactly once,
     and the entries that do not know batch sizes (run_stream, run_host_blobs) leave the small contexts out"""

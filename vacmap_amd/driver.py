@@ -447,7 +447,12 @@ def main(argv=None, comm=None):
         if own_group:                                   # no rank leaves while rank 0 still gathers and writes
             comm.barrier(); comm.destroy_process_group()
         return rc
-    pipe = pipeline.Pipeline(index, prm, device=device, inflight=args.inflight or 5, first_ctx=ctx)
+    # Ramped start (VMX_DRIVER_RAMP=1; off by default): the stream starts on ONE context as soon as its pools are sized, the others are sized in the background and
+    # join one by one (Pipeline.run_stream, ramp). Measured on the 1.64 M-read input: the first batch starts 1.6 s after the loop begins instead of 5.9 s, but
+    # hipMalloc under load is slower than on an idle device and slows the running batches down — the seventh context joins after ~1 M reads, and the loop
+    # takes the same 12.8 s (`profiles/r05_zz_driver_long_ramped_start.json`). Default: every context is sized before the first batch runs.
+    ramp_on = os.environ.get('VMX_DRIVER_RAMP', '0') == '1' and os.environ.get('VMX_NO_WARM') != '1'
+    pipe = pipeline.Pipeline(index, prm, device=device, inflight=1 if ramp_on else (args.inflight or 5), first_ctx=ctx)
     if os.environ.get('VMX_SPIN_SYNC') != '1':
         for cx in pipe.ctxs:
             cx.set_blocking_sync(True)                    # the emitters need the cores the waiting aligner threads would spin on
@@ -775,7 +780,7 @@ def main(argv=None, comm=None):
         dropped = pipe.trim_to_memory(float(os.environ.get('VMX_MIN_FREE_GB', '10')))
         if dropped and rank == 0:
             sys.stderr.write('vacmapx: %d of %d batches in flight given up to keep HBM head-room\n' % (dropped, dropped + pipe.inflight))
-        if args.inflight == 0 and not dropped and sb0_keep is not None and not errs:
+        if args.inflight == 0 and not ramp_on and not dropped and sb0_keep is not None and not errs:
             # the scheduler's rule (bench.py runs the same): more batches in flight while another context's pools + head-room fit the HBM
             try:
                 added = pipe.grow_to_memory(run=lambda cx: align_batch_raw(cx, index, prm, sb0_keep[0], sb0_keep[1]).close(), max_inflight=8)
@@ -786,6 +791,11 @@ def main(argv=None, comm=None):
                 errs.append(e)
         tm['warm'] = time.time() - t_loop
     fth = []
+    ramp = None
+    if ramp_on and sb0_keep is not None and not errs:
+        spin = os.environ.get('VMX_SPIN_SYNC') == '1'
+        ramp = dict(run=lambda cx: align_batch_raw(cx, index, prm, sb0_keep[0], sb0_keep[1]).close(), target=args.inflight, max_inflight=8,
+                    on_ctx=None if spin else (lambda cx: cx.set_blocking_sync(True)))
     try:
         if n_feed > 0 and sb0_keep is not None:
             from .lib import Context as _Ctx, ResidentReads as _RR
@@ -795,15 +805,15 @@ def main(argv=None, comm=None):
                 if os.environ.get('VMX_SPIN_SYNC') != '1':
                     fcx.set_blocking_sync(True)
                 feed['ctxs'].append(fcx)
-            for _ in range(pipe.inflight + n_feed + 1):
+            for _ in range((max(args.inflight or 8, pipe.inflight) if ramp_on else pipe.inflight) + n_feed + 1):
                 sl = _RR(feed['ctxs'][0], concat=sb0_keep[0], offsets=sb0_keep[1]); feed['slots'].append(sl); feed['free'].put(sl)
             fth = [threading.Thread(target=feeder, args=(fcx, src)) for fcx in feed['ctxs']]
             for t_ in fth:
                 t_.start()
-            pipe.run_stream(fed_jobs(n_feed), align, errs)
+            pipe.run_stream(fed_jobs(n_feed), align, errs, ramp=ramp)
         else:
-            pipe.run_stream(job_source(), align, errs)
-        tm['aligners_done'] = time.time() - t_loop
+            pipe.run_stream(job_source(), align, errs, ramp=ramp)
+        tm['aligners_done'] = time.time() - t_loop; tm['contexts'] = float(pipe.inflight)
     finally:
         if errs:
             oq.put(None)

@@ -270,13 +270,21 @@ class Pipeline:
         if errs:
             raise errs[0]
 
-    def run_stream(self, jobs, do_job, errs=None):
+    def run_stream(self, jobs, do_job, errs=None, ramp=None):
         """`inflight` threads pull jobs from the iterator `jobs` (one at a time, under a lock) and run do_job(job, ctx) until it is
         exhausted: no barrier between groups of jobs, the contexts stay busy across the caller's windows. An exception in any thread is
-        appended to `errs` (shared with the caller's other threads), stops the others and is re-raised."""
+        appended to `errs` (shared with the caller's other threads), stops the others and is re-raised.
+        ramp = dict(run=callable(ctx), target=N or 0, max_inflight=8, min_free_gb=14.0, on_ctx=callable(ctx) or None): the stream STARTS on the contexts
+        that exist (the caller has sized the first one) while a background thread creates the others one at a time, sizes each one's work pools
+        (run(ctx): the caller's sizing batch) and starts a worker on it — up to `target` contexts, or with target 0 by grow_to_memory's rule (another
+        context while what one took, measured on the first one added, plus `min_free_gb` is free; at most `max_inflight`). The sizing runs of five to
+        eight contexts take 1-5 s of hipMalloc (~50 GB each) during which the stream used to wait; now the first batches run under them."""
+        from .lib import VmxError
         lock = threading.Lock()
         errs = [] if errs is None else errs
         it = iter(jobs)
+        done = threading.Event()                       # the job iterator is exhausted: no more contexts are worth sizing
+        late = []
 
         def worker(cx):
             try:
@@ -284,6 +292,7 @@ class Pipeline:
                     with lock:
                         job = next(it, None)
                     if job is None:
+                        done.set()
                         return
                     _roctx.push('vacmapx batch')
                     try:
@@ -296,10 +305,53 @@ class Pipeline:
             except BaseException as e:
                 errs.append(e)
 
+        def grower():
+            try:
+                per_ctx = None
+                target = int(ramp.get('target') or 0); cap = int(ramp.get('max_inflight', 8)); min_free = float(ramp.get('min_free_gb', 14.0)) * 1e9
+                while not errs and not done.is_set() and len(self.ctxs) < (target or cap):
+                    free, _ = self.ctxs[0].mem_info()
+                    if not target:
+                        if per_ctx is None and free < 60e9:
+                            break
+                        if per_ctx is not None and free < per_ctx + min_free:
+                            break
+                    cx = Context(self.device, lib=self.ctxs[0].lib)
+                    if ramp.get('on_ctx') is not None:
+                        ramp['on_ctx'](cx)
+                    cx.set_inflight(len(self.ctxs) + 1)
+                    try:
+                        ramp['run'](cx)
+                    except VmxError as e:
+                        cx.close()
+                        if e.code != -4:                          # VM_ERR_OOM: no room for another context's pools — fewer batches in flight, not a failed run
+                            raise
+                        self.ramp_oom = getattr(self, 'ramp_oom', 0) + 1
+                        break
+                    free2, _ = self.ctxs[0].mem_info()
+                    per_ctx = max(float(free - free2), 1e9) if per_ctx is None else max(per_ctx, float(free - free2))
+                    if free2 < min_free and len(self.ctxs) >= 2:   # it fitted, but left too little: give it back
+                        cx.close()
+                        break
+                    with lock:
+                        self.ctxs.append(cx); self.inflight = len(self.ctxs)
+                        for c in self.ctxs:
+                            c.set_inflight(self.inflight)
+                    t = threading.Thread(target=worker, args=(cx,)); late.append(t); t.start()
+            except BaseException as e:
+                errs.append(e)
+
         th = [threading.Thread(target=worker, args=(cx,)) for cx in self.full_ctxs()]
         for t in th:
             t.start()
+        gt = None
+        if ramp is not None:
+            gt = threading.Thread(target=grower); gt.start()
         for t in th:
+            t.join()
+        if gt is not None:
+            gt.join()
+        for t in late:
             t.join()
         if errs:
             raise errs[0]
