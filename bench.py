@@ -251,7 +251,7 @@ def main():
     ctx_added = 0; ctx_small = 0
     if args.streams == 0 and not ctx_dropped and args.warmup > 0:
         if os.environ.get('VMX_NO_FULL_GROWTH') != '1':
-            ctx_added = pipe.grow_to_memory(resident[longest], max_inflight=min(8, nsteps)); warm_runs += ctx_added
+            ctx_added = pipe.grow_to_memory(resident[longest], max_inflight=min(int(os.environ.get('VMX_MAX_FULL_CTX', '8')), nsteps)); warm_runs += ctx_added
         if os.environ.get('VMX_SMALL_CTX', '1') != '0' and nsteps >= 8:
             # where no (further) full context fits — its pools are sized by the window's longest batch — contexts for the shorter batches only, sized on the median
             # batch (ONT-hg38: 5 full + 1 small = 283 GB, 15.1-15.7 ms per step against 15.8-15.9; fewer full ones lose: 4 + 3: 15.5-16.1, 4 + 4: 15.4, 3 + 6: 16.1)
