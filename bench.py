@@ -118,9 +118,11 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank), rank=rank, world_size=world)
     k = cfg['k']
-    extra = None
-    if rank == 0 and world == 1 and args.extra_configs:
-        # the other single-GPU configs, each in its own process BEFORE this one takes the GPU (own reference, index and work pools)
+    def run_extra_configs():
+        # the other single-GPU configs, each in its own process AFTER this one has measured and released the GPU (own reference, index and work pools): the headline is
+        # measured on the device as a fresh process finds it. (They ran first until late in round 5. Back-to-back processes showed no consistent order effect —
+        # the headline config 15.7 / 16.3 / 15.7 ms first and 16.3 / 16.2 / 16.1 second, HiFi 19.6 / 18.7 / 18.6 first and 21.1 / 18.5 / 19.0 second; nor does the socket
+        # the host threads run on, nor sleeping instead of spinning waits: the run-to-run spread of +-3 % is the device's — profiles/r05_knob_ab_negative_results.txt)
         import subprocess
         extra = {'configs': []}
         for name in [c for c in args.extra_configs.split(',') if c and c != args.config]:
@@ -139,6 +141,7 @@ def main():
                                                               'traffic_source': d['roofline']['traffic_source'], 'vacsim': d.get('vacsim')})
             except Exception as e:                                                     # a failed side run is reported, never hidden
                 extra['configs'].append({'config': name, 'error': repr(e)[:300]})
+        return extra
     if cfg['ref_mb'] > 0:
         names = ['chr1']
         contigs = synth.make_reference([int(cfg['ref_mb'] * 1e6)], seed=1)             # configs[1]: 1 contig x 100 Mb, seed 1
@@ -211,7 +214,7 @@ def main():
 
     resident = pipeline.upload_batches(ctx, pool_cat, pool_off, plan)        # inputs resident in HBM before timing
     pipe = pipeline.Pipeline(index, prm, device=local_rank, inflight=max(1, min(args.streams or int(os.environ.get('VMX_FULL_CTX', '5')), nsteps)), first_ctx=ctx)
-    if world > 1 and os.environ.get('VMX_SPIN_SYNC') != '1':
+    if (world > 1 or os.environ.get('VMX_BLOCKING_SYNC') == '1') and os.environ.get('VMX_SPIN_SYNC') != '1':
         # N ranks on one host: the contexts' threads SLEEP while they wait for the GPU (the driver's setting) — five spinning threads per rank times eight ranks
         # would take forty cores for nothing; host threads per rank in the timed region: `streams` mostly-sleeping aligner threads + the main thread
         for cx in pipe.ctxs:
@@ -259,7 +262,7 @@ def main():
             med = by_bases[int(len(by_bases) * float(os.environ.get('VMX_SMALL_PCT', '0.5')))]
             ctx_small = pipe.add_small_contexts(resident[med], resident[med].bases, max_inflight=min(int(os.environ.get('VMX_MAX_CTX', '9')), nsteps))
             warm_runs += ctx_small * resident[med].bases / float(max(resident[longest].bases, 1))          # (in units of the longest batch: the PMC summaries scale by warm-up bases)
-        if world > 1 and os.environ.get('VMX_SPIN_SYNC') != '1':
+        if (world > 1 or os.environ.get('VMX_BLOCKING_SYNC') == '1') and os.environ.get('VMX_SPIN_SYNC') != '1':
             for cx in pipe.ctxs:
                 cx.set_blocking_sync(True)          # (the product's rule: a context is given up when the sized pools leave < 10 GB of HBM free; not the case at the default sizes)
 
@@ -430,8 +433,19 @@ def main():
             out['vacsim'] = vacsim_info
         if dist is not None and world == 1:
             out['forced_dist_world_1'] = True
-        if extra is not None:
-            out['extra'] = extra
+        if world == 1 and args.extra_configs:
+            # release the GPU (work pools, reads, index) and the oracle's index before the side runs take the device
+            try:
+                pipe.close()
+                for r_ in resident:
+                    r_.close()
+                index.close(); ctx.close()
+            except Exception as e:
+                sys.stderr.write('bench: releasing the GPU before the side configs: %r\n' % (e,))
+            oi = None
+            import gc
+            gc.collect()
+            out['extra'] = run_extra_configs()
         if host_rate is not None:
             out['host_input'] = host_rate
         print(json.dumps(out))
