@@ -215,8 +215,10 @@ def main():
     resident = pipeline.upload_batches(ctx, pool_cat, pool_off, plan)        # inputs resident in HBM before timing
     pipe = pipeline.Pipeline(index, prm, device=local_rank, inflight=max(1, min(args.streams or int(os.environ.get('VMX_FULL_CTX', '5')), nsteps)), first_ctx=ctx)
     if (world > 1 or os.environ.get('VMX_BLOCKING_SYNC') == '1') and os.environ.get('VMX_SPIN_SYNC') != '1':
-        # N ranks on one host: the contexts' threads SLEEP while they wait for the GPU (the driver's setting) — five spinning threads per rank times eight ranks
-        # would take forty cores for nothing; host threads per rank in the timed region: `streams` mostly-sleeping aligner threads + the main thread
+        # N ranks on one host: the contexts' threads wait on a blocking event (the driver's setting; VMX_BLOCKING_SYNC=1 asks for it at N = 1) instead of
+        # hipStreamSynchronize. Measured late in round 5 (`host_cores_busy_timed_pass`): the process still keeps one core busy per context either way — the waits that
+        # matter are inside the runtime's pageable copies, which spin; hipSetDeviceFlags(hipDeviceScheduleBlockingSync) does put them to sleep (5.7 -> 1.0 cores busy at the
+        # same 15.7 ms per batch on the ONT workload) but HUNG the runs with eight contexts in flight (HiFi, vacsim_r, the GPU tests): not used
         for cx in pipe.ctxs:
             cx.set_blocking_sync(True)
     t_setup = time.time() - t0
@@ -276,10 +278,13 @@ def main():
         agg['ms_stage'] = [a + b for a, b in zip(agg.get('ms_stage', [0.0] * 16), stats['ms_stage'])]
 
     barrier()
+    cpu0 = os.times()
     t1 = time.time()
     pipe.run_resident(resident, want_records=False, on_result=on_result)      # the product's schedule (vacmap_amd/pipeline.py)
     barrier()
     dt = time.time() - t1
+    cpu1 = os.times()
+    host_cores_busy = ((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / max(dt, 1e-9)      # CPU seconds of this process per second of the timed pass
     if getattr(pipe, 'timeline', None):                     # VMX_DBG_TIMELINE=1: when every batch of the timed pass started and ended, on which context
         for row in sorted(pipe.timeline, key=lambda r_: r_[3]):
             sys.stderr.write('[timeline] batch %2d ctx %d%s  %7.1f -> %7.1f ms  (%5.1f ms)  %6.1f Mbases\n' % (row[0], row[1], ' small' if row[2] else '      ', row[3] * 1e3, row[4] * 1e3, (row[4] - row[3]) * 1e3, row[5] / 1e6))
@@ -418,6 +423,7 @@ def main():
             'stage_names': ['seed', 'global_chain', 'local', 'divergence_filter', 'edge_extension', 'gapfill+records', 'nofilter_redo', 'download'],
             'gapfill_trace_ms_per_step': agg['ms_gapfill_trace'] / K, 'host_syncs_per_step': agg.get('n_host_syncs', 0) / K,
             # per batch, seen from its host thread: wall time of the library call, of it spent inside waits for the stream; the rest is host work with the context's stream empty
+            'host_cores_busy_timed_pass': round(host_cores_busy, 2),
             'host_call_ms_per_batch': agg['ms_stage'][15] / K, 'host_wait_ms_per_batch': agg['ms_stage'][14] / K, 'host_active_ms_per_batch': (agg['ms_stage'][15] - agg['ms_stage'][14]) / K,
             'per_read': {'minimizers': agg['n_minimizers'] / max(agg['n_reads'], 1), 'hits': agg['n_hits'] / max(agg['n_reads'], 1), 'anchors': agg['n_anchors'] / max(agg['n_reads'], 1),
                          'local_anchors': agg['n_local_anchors'] / max(agg['n_reads'], 1), 'dp_problems': agg['n_dp_problems'] / max(agg['n_reads'], 1),
