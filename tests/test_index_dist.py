@@ -461,7 +461,7 @@ def test_n_rank_driver_range_sharding_parts_gloo(ctx, tmp_path, monkeypatch):
     script = tmp_path / 'w.py'
     script.write_text(_RANGE_WORKER % (ROOT, ROOT))
     port = 29651
-    for world, mode, rf in ((4, 'join', 'reads_dup.fq'), (2, 'join', 'reads_dup.fq'), (2, 'parts', 'reads.fq'), (2, 'batch', 'reads_dup.fq')):
+    for world, mode, rf in ((4, 'join', 'reads_dup.fq'), (2, 'parts', 'reads.fq'), (2, 'batch', 'reads_dup.fq')):      # (world 2 'join' ran here too until the suite passed ten minutes)
         port += 1
         want = wants[rf]
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), VMX_SLICE_MB='0.004')
