@@ -70,6 +70,29 @@ def latest_pmc(workload_id):
     return None, None
 
 
+def run_side_configs(args):
+    """the other single-GPU BASELINE configs, each in a process of its own (own reference, index and work pools), with nothing else on the GPU"""
+    import subprocess
+    extra = {'configs': []}
+    for name in [c for c in args.extra_configs.split(',') if c and c != args.config]:
+        cmd = [sys.executable, os.path.abspath(__file__), '--config', name, '--steps', str(args.extra_steps), '--cpu-sample', '0', '--verify', '16', '--extra-configs', '',
+               '--streams', str(args.streams), '--reads-per-step', str(args.reads_per_step), '--no-host-input']
+        try:
+            pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            d = json.loads(pr.stdout.decode().strip().splitlines()[-1])
+            extra['configs'].append({kk: d[kk] for kk in ('value', 'unit', 'ms_per_step', 'steps', 'reads_per_s', 'failed_reads', 'unmapped_reads', 'oracle_crosscheck', 'per_read', 'stage_ms_per_step',
+                                                          'hbm_used_gb', 'local_general_reads')} | {'config': name, 'workload': d['config']['workload'], 'dominant_kernel': d['roofline']['kernel'],
+                                                          'kernel_ms_per_step': {kn: e['ms_per_step'] for kn, e in d['roofline']['kernels'].items()},
+                                                          # the side config's own counters (profiles/r*_pmc_hbm_traffic.json with its workload_id), None until they exist
+                                                          'traffic_over_algorithmic': {kn: e['traffic_over_algorithmic'] for kn, e in d['roofline']['kernels'].items()},
+                                                          'valu_frac_of_calibrated_peak': {kn: (e['valu'] or {}).get('frac_of_calibrated_peak') for kn, e in d['roofline']['kernels'].items()},
+                                                          'ms_per_step_over_valu_floor': (d['roofline']['pipeline_valu'] or {}).get('ms_per_step_over_floor'),
+                                                          'traffic_source': d['roofline']['traffic_source'], 'vacsim': d.get('vacsim')})
+        except Exception as e:                                                     # a failed side run is reported, never hidden
+            extra['configs'].append({'config': name, 'error': repr(e)[:300]})
+    return extra
+
+
 def main():
     from vacmap_amd.driver import _keep_heap_pages
     _keep_heap_pages()                          # the driver's allocator setting (freed result buffers are reused, not unmapped): VMX_DRIVER_MALLOPT=0 disables
@@ -105,6 +128,23 @@ def main():
     err = args.err if args.err is not None else cfg['err']
 
     rank = int(os.environ.get('RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1')); local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world == 1 and args.extra_configs and os.environ.get('VMX_BENCH_CHILD') != '1' and os.environ.get('VMX_FORCE_DIST') != '1':
+        # One GPU, side configs asked for (the default command): this process only orchestrates and never touches the GPU. The headline config runs FIRST in a process of
+        # its own (this command line with --extra-configs ""), then every side config in its own; each finds the device as a fresh process does and has it to itself.
+        # (Until late in round 5 the side configs ran in front of the headline run inside this process; run after it, with this process still holding its HIP queues,
+        # they lost 6 - 23 %: ont_100mb 3.90 / 3.93 against 4.23, vacsim_r 2.40 / 2.34 against 3.03 Gbp/s — two processes' queues on one device are time-sliced.)
+        import subprocess
+        argv = [a_ for a_ in sys.argv[1:]]
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ['--extra-configs', '']
+        pr = subprocess.run(cmd, stdout=subprocess.PIPE, env=dict(os.environ, VMX_BENCH_CHILD='1'), timeout=3000)
+        lines = [l for l in pr.stdout.decode().splitlines() if l.startswith('{')]
+        if pr.returncode != 0 or not lines:
+            sys.stderr.write('bench: the headline run failed (rc %d)\n' % pr.returncode)
+            sys.exit(pr.returncode or 1)
+        out = json.loads(lines[-1])
+        out['extra'] = run_side_configs(args)
+        print(json.dumps(out))
+        return
     from vacmap_amd import synth, pipeline
     t0 = time.time()
     cores = host_cores()
@@ -118,30 +158,6 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank), rank=rank, world_size=world)
     k = cfg['k']
-    def run_extra_configs():
-        # the other single-GPU configs, each in its own process AFTER this one has measured and released the GPU (own reference, index and work pools): the headline is
-        # measured on the device as a fresh process finds it. (They ran first until late in round 5. Back-to-back processes showed no consistent order effect —
-        # the headline config 15.7 / 16.3 / 15.7 ms first and 16.3 / 16.2 / 16.1 second, HiFi 19.6 / 18.7 / 18.6 first and 21.1 / 18.5 / 19.0 second; nor does the socket
-        # the host threads run on, nor sleeping instead of spinning waits: the run-to-run spread of +-3 % is the device's — profiles/r05_knob_ab_negative_results.txt)
-        import subprocess
-        extra = {'configs': []}
-        for name in [c for c in args.extra_configs.split(',') if c and c != args.config]:
-            cmd = [sys.executable, os.path.abspath(__file__), '--config', name, '--steps', str(args.extra_steps), '--cpu-sample', '0', '--verify', '16', '--extra-configs', '',
-                   '--streams', str(args.streams), '--reads-per-step', str(args.reads_per_step), '--no-host-input']
-            try:
-                pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-                d = json.loads(pr.stdout.decode().strip().splitlines()[-1])
-                extra['configs'].append({kk: d[kk] for kk in ('value', 'unit', 'ms_per_step', 'steps', 'reads_per_s', 'failed_reads', 'unmapped_reads', 'oracle_crosscheck', 'per_read', 'stage_ms_per_step',
-                                                              'hbm_used_gb', 'local_general_reads')} | {'config': name, 'workload': d['config']['workload'], 'dominant_kernel': d['roofline']['kernel'],
-                                                              'kernel_ms_per_step': {kn: e['ms_per_step'] for kn, e in d['roofline']['kernels'].items()},
-                                                              # the side config's own counters (profiles/r*_pmc_hbm_traffic.json with its workload_id), None until they exist
-                                                              'traffic_over_algorithmic': {kn: e['traffic_over_algorithmic'] for kn, e in d['roofline']['kernels'].items()},
-                                                              'valu_frac_of_calibrated_peak': {kn: (e['valu'] or {}).get('frac_of_calibrated_peak') for kn, e in d['roofline']['kernels'].items()},
-                                                              'ms_per_step_over_valu_floor': (d['roofline']['pipeline_valu'] or {}).get('ms_per_step_over_floor'),
-                                                              'traffic_source': d['roofline']['traffic_source'], 'vacsim': d.get('vacsim')})
-            except Exception as e:                                                     # a failed side run is reported, never hidden
-                extra['configs'].append({'config': name, 'error': repr(e)[:300]})
-        return extra
     if cfg['ref_mb'] > 0:
         names = ['chr1']
         contigs = synth.make_reference([int(cfg['ref_mb'] * 1e6)], seed=1)             # configs[1]: 1 contig x 100 Mb, seed 1
@@ -439,19 +455,6 @@ def main():
             out['vacsim'] = vacsim_info
         if dist is not None and world == 1:
             out['forced_dist_world_1'] = True
-        if world == 1 and args.extra_configs:
-            # release the GPU (work pools, reads, index) and the oracle's index before the side runs take the device
-            try:
-                pipe.close()
-                for r_ in resident:
-                    r_.close()
-                index.close(); ctx.close()
-            except Exception as e:
-                sys.stderr.write('bench: releasing the GPU before the side configs: %r\n' % (e,))
-            oi = None
-            import gc
-            gc.collect()
-            out['extra'] = run_extra_configs()
         if host_rate is not None:
             out['host_input'] = host_rate
         print(json.dumps(out))
