@@ -198,8 +198,12 @@ def test_emu_asm_linked(ctx, oracle):
     KC.check_asm_linked_fast_golden(ctx, oracle)                 # the fork's GC-fast, plain and linked, against the reference's direct calls
 
 
-def test_emu_mode_asm_long_contig(ctx, oracle):
-    """the long-contig loop of -mode asm (vm_align_asm) with shrunk sizes: linked first round, re-seeded second round, ass_extend_func"""
+def test_emu_mode_asm_long_contig(ctx, oracle, monkeypatch):
+    """the long-contig loop of -mode asm (vm_align_asm) with shrunk sizes: linked first round, re-seeded second round, ass_extend_func; then with the
+    second round's anchor slots and hit pools made too small (VMX_TEST_ASM_RESEED_DIV): the launch is repeated with larger pools, the records stay
+    the reference's (it used to end in VM_READ_CAPACITY for the contig)"""
+    assert KC.check_asm_long_golden(ctx, oracle, 'AS3', contigs=[2]) == 1
+    monkeypatch.setenv('VMX_TEST_ASM_RESEED_DIV', '256')
     assert KC.check_asm_long_golden(ctx, oracle, 'AS3', contigs=[2]) == 1
 
 

@@ -382,6 +382,13 @@ def test_mode_asm_long_contigs(ctx, oracle):
     contigs with the shrunk sizes their goldens were made with (5-7 linked first-round batches each) — records = reference goldens = oracle"""
     assert KC.check_asm_long_golden(ctx, oracle, 'AS3') == 3
     assert KC.check_asm_long_golden(ctx, oracle, 'AS2') == 1
+    # the second round's anchor slots and hit pools made too small: the launch is repeated with larger pools (it used to end in VM_READ_CAPACITY for the contig)
+    import os
+    os.environ['VMX_TEST_ASM_RESEED_DIV'] = '256'
+    try:
+        assert KC.check_asm_long_golden(ctx, oracle, 'AS3') == 3
+    finally:
+        del os.environ['VMX_TEST_ASM_RESEED_DIV']
 
 
 def test_mode_asm_long_contig_bail_out(ctx, oracle, monkeypatch):

@@ -278,8 +278,23 @@ void dump_rows(const char* name, const std::vector<vmx_anchor>& v, bool append =
 }
 
 // collect_second_round_anchors (:22477-22756) for every second-round batch at once: one k_local_seed launch, one unit per batch
+#define VMX_RETRY_RESEED (-9002)          // second_round_seed_once -> second_round_seed: a pool of the launch was too small for one of its batches
+static int second_round_seed_once(vm_ctx* c, const vm_index_view& ix, int k, const uint8_t* d_codes, int64_t L, const std::vector<vmx_anchor>& raw_asc, const std::vector<Tuple>& tuples,
+                                  std::vector<std::vector<vmx_anchor>>& out, int64_t mult, int64_t div);
+// the anchor slots and hit pools of the launch are estimates (8 x the per-read slot of the span, 4 hits per position): a batch that overflows them is not given up — the
+// launch is repeated with the pools x4, up to x256, before the contig is reported as VM_READ_CAPACITY (round 5; VMX_TEST_ASM_RESEED_DIV=<d> divides the pools in the tests)
 int second_round_seed(vm_ctx* c, const vm_index_view& ix, int k, const uint8_t* d_codes, int64_t L, const std::vector<vmx_anchor>& raw_asc, const std::vector<Tuple>& tuples,
                       std::vector<std::vector<vmx_anchor>>& out) {
+    int64_t div = 1; if (const char* e = getenv("VMX_TEST_ASM_RESEED_DIV")) { const long long v = atoll(e); if (v >= 1) div = v; }
+    for (int64_t mult = 1;; mult *= 4) {
+        const int rc = second_round_seed_once(c, ix, k, d_codes, L, raw_asc, tuples, out, mult, div);
+        if (rc != VMX_RETRY_RESEED) return rc;
+        if (mult >= 256 * div) { set_error("asm: a second-round re-seeding batch overflowed its device pools"); return VM_READ_CAPACITY; }
+        if (getenv("VMX_DBG_POOLS")) fprintf(stderr, "[pools] asm second-round re-seeding: a pool was too small, once more with x%lld\n", (long long)(mult * 4));
+    }
+}
+static int second_round_seed_once(vm_ctx* c, const vm_index_view& ix, int k, const uint8_t* d_codes, int64_t L, const std::vector<vmx_anchor>& raw_asc, const std::vector<Tuple>& tuples,
+                                  std::vector<std::vector<vmx_anchor>>& out, int64_t mult, int64_t div) {
     const int64_t nt = (int64_t)tuples.size();
     out.assign((size_t)nt, {});
     if (!nt) return 0;
@@ -296,7 +311,7 @@ int second_round_seed(vm_ctx* c, const vm_index_view& ix, int k, const uint8_t* 
         rst[(size_t)t] = (int32_t)u.st_read; ren[(size_t)t] = (int32_t)u.en_read;
         const int64_t span = u.en_read - u.st_read;
         span_max = std::max(span_max, span); glen_max = std::max(glen_max, u.hi - u.lo);
-        la_off[(size_t)t + 1] = la_off[(size_t)t] + 8 * VMX_LA_SLOT(span);
+        la_off[(size_t)t + 1] = la_off[(size_t)t] + std::max<int64_t>(16, 8 * mult * VMX_LA_SLOT(span) / div);
         order[(size_t)t + 1] = (int32_t)t;
     }
     aoff[(size_t)nt] = (int64_t)guide.size();
@@ -314,8 +329,8 @@ int second_round_seed(vm_ctx* c, const vm_index_view& ix, int k, const uint8_t* 
     const int64_t nkey = (int64_t)1 << (2 * k);
     const int64_t head_stride = (2 * k > 14 && nkey <= (int64_t)VMX_SORT_LDS * 64) ? ((int64_t)1 << 14) : nkey;
     // the guide of a batch spans about its read range on the reference (+ 2000 on either side of every window, :22526-22530)
-    const int64_t tpos_cap = std::min<int64_t>(4 * span_max + 64 * 4000 + 65536, ((int64_t)1 << 23) - 2);
-    int64_t hit_cap = 1; while (hit_cap < 4 * (span_max + 14000)) hit_cap <<= 1;
+    const int64_t tpos_cap = std::min<int64_t>(mult * (4 * span_max + 64 * 4000 + 65536), ((int64_t)1 << 23) - 2);
+    int64_t hit_cap = 1; while (hit_cap < std::max<int64_t>(64, 4 * mult * (span_max + 14000) / div)) hit_cap <<= 1;
     if (hit_cap > ((int64_t)1 << 26)) hit_cap = (int64_t)1 << 26;
     const int64_t pcnt_cap = span_max + 16;
     int64_t gkey_cap = 1; while (gkey_cap < glen_max) gkey_cap <<= 1;
@@ -354,7 +369,7 @@ int second_round_seed(vm_ctx* c, const vm_index_view& ix, int k, const uint8_t* 
     VMX_HIP(vmx_stream_sync(c));
     VMX_HIP(hipGetLastError());
     for (int64_t t = 0; t < nt; ++t) {
-        if (stt[(size_t)t] != 0) { set_error("asm: a second-round re-seeding batch overflowed its device pools"); return VM_READ_CAPACITY; }
+        if (stt[(size_t)t] != 0) return VMX_RETRY_RESEED;
         out[(size_t)t].resize((size_t)cnt[(size_t)t]);
         VMX_TRY(download(out[(size_t)t].data(), B.la_sorted.as<vmx_anchor>() + la_off[(size_t)t], (size_t)cnt[(size_t)t], c->stream));
     }
