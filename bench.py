@@ -4,6 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--reads-per-step R] [--ref-mb M] [--cpu-sample S]
     python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...   (one rank per GPU)
 
+`--gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset) starts the N ranks ITSELF (launch_ranks below: one child of this same command
+line per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, rank 0's JSON line relayed, any rank's non-zero exit code
+propagated) — the reference's `-t` forks its own workers too (/root/reference/src/vacmap/vacmap:414-420). Fewer than N devices: a loud error,
+never a silent world-1 run. Under torchrun (WORLD_SIZE set) `--gpus` must agree with WORLD_SIZE.
+
 Default workload = the configuration the metric is quoted on: synthetic ONT-shape reads (Gamma lengths, mean 15 kb, 10 % error 4:3:3
 sub:del:ins) against the hg38-size synthetic reference (24 contigs with hg38's chromosome proportions, 3.1 Gb, seed 3; SURVEY §8(d)
 config 3/4 reference), -mode H -k 15 -w 10 -c 100. `--ref-mb 100` selects BASELINE configs[1] instead (one 100 Mb contig, seed 1).
@@ -93,6 +98,80 @@ def run_side_configs(args):
     return extra
 
 
+def visible_devices():
+    """number of GPUs a rank of this command would see (vm_device_count through the HIP library), asked in a CHILD process: the launcher itself never
+    starts the HIP runtime (a parent holding queues on the device is time-sliced against its children). 0 when the library or the device is missing."""
+    import subprocess
+    code = 'import sys; sys.path.insert(0, %r)\nfrom vacmap_amd.lib import load\nprint("VMX_DEVICES", load().L.vm_device_count())' % ROOT
+    try:
+        pr = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        for l in pr.stdout.decode().splitlines():
+            if l.startswith('VMX_DEVICES'):
+                return max(0, int(l.split()[1]))
+    except Exception:
+        pass
+    return 0
+
+
+def rank_environments(n, port=None):
+    """the N environments of the ranks this launcher starts (what torch.distributed.run would set, for one node)"""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]
+    return [{'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(n), 'LOCAL_WORLD_SIZE': str(n), 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port),
+             'VMX_BENCH_LAUNCHED': '1', 'HSA_ENABLE_IPC_MODE_LEGACY': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')} for r in range(n)]
+
+
+def launch_ranks(n, argv, dry_run=False):
+    """start the N ranks of `bench.py --gpus N` (one process per GPU), relay rank 0's JSON line, return the first non-zero exit code of any rank.
+    A rank that fails takes the others down with it (their exact PIDs), so a half-started group cannot hang in a collective."""
+    import subprocess, threading
+    envs = rank_environments(n, port=int(os.environ['VMX_BENCH_PORT']) if os.environ.get('VMX_BENCH_PORT') else None)
+    cmd = [sys.executable, os.path.abspath(__file__)] + [a_ for a_ in argv if a_ != '--launch-dry-run']
+    if dry_run:
+        print(json.dumps({'launcher': 'bench.py', 'n_ranks': n, 'command': cmd, 'environments': envs}))
+        return 0
+    have = int(os.environ['VMX_BENCH_ASSUME_DEVICES']) if os.environ.get('VMX_BENCH_ASSUME_DEVICES') else visible_devices()      # (the variable: the launcher's own unit test)
+    if have < n:
+        sys.stderr.write('bench: --gpus %d asked for, but %d GPU(s) are visible to this process (vm_device_count): refusing to run fewer ranks than asked\n' % (n, have))
+        return 2
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, env=dict(os.environ, **e)) for e in envs]
+    lines = [[] for _ in procs]
+
+    def pump(r):                        # rank 0's stdout is the result; the other ranks' goes to stderr with a prefix
+        for raw in procs[r].stdout:
+            l = raw.decode(errors='replace').rstrip('\n')
+            lines[r].append(l)
+            if r != 0 or not l.startswith('{'):
+                sys.stderr.write('[rank %d] %s\n' % (r, l))
+    th = [threading.Thread(target=pump, args=(r,), daemon=True) for r in range(n)]
+    for t_ in th:
+        t_.start()
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            live.discard(r)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 128 - c
+                sys.stderr.write('bench: rank %d exited with code %d; stopping the other ranks\n' % (r, c))
+                for q in live:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    for t_ in th:
+        t_.join(timeout=5)
+    js = [l for l in lines[0] if l.startswith('{')]
+    if rc == 0 and not js:
+        sys.stderr.write('bench: rank 0 printed no result line\n'); rc = 1
+    if rc == 0:
+        print(js[-1])
+    return rc
+
+
 def main():
     from vacmap_amd.driver import _keep_heap_pages
     _keep_heap_pages()                          # the driver's allocator setting (freed result buffers are reused, not unmapped): VMX_DRIVER_MALLOPT=0 disables
@@ -120,7 +199,17 @@ def main():
     ap.add_argument('--extra-configs', default='ont_100mb,hifi_hg38,vacsim_r', help='other single-GPU BASELINE configs timed in their own short runs of this script (N = 1 only) and '
                     'reported under extra.configs next to the headline; "" disables')
     ap.add_argument('--extra-steps', type=int, default=24)
+    ap.add_argument('--launch-dry-run', action='store_true', help='with --gpus N: print the N rank environments and the command the launcher would start, and exit')
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
+    if 'WORLD_SIZE' in os.environ:
+        if int(os.environ['WORLD_SIZE']) != args.gpus:       # under a launcher (torchrun): one rank per GPU asked for, nothing else
+            sys.stderr.write('bench: --gpus %d does not agree with WORLD_SIZE=%s of the launcher\n' % (args.gpus, os.environ['WORLD_SIZE']))
+            sys.exit(2)
+    elif args.gpus > 1 or args.launch_dry_run or os.environ.get('VMX_FORCE_DIST') == '1':
+        # no launcher around this process: it becomes the launcher (VMX_FORCE_DIST=1: the N-rank code at world 1 goes through it as well)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], dry_run=args.launch_dry_run))
     cfg = dict(CONFIGS[args.config])
     if args.ref_mb > 0:                               # (kept: --ref-mb M = the ONT workload against one contig of M Mb)
         cfg = dict(CONFIGS['ont_100mb']); cfg['ref_mb'] = args.ref_mb
@@ -346,8 +435,14 @@ def main():
         tmax = vals[0:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         sums = vals[1:].clone(); dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         dt_all = float(tmax[0]); aligned, nreads, rbases, nfail = [float(x) for x in sums]
+        mine = torch.tensor([dt, host_cores_busy], dtype=torch.float64, device='cuda')
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                        # every rank's own timed pass and host load, for the line
+        per_rank_dt = [float(e[0]) for e in every]; per_rank_cores = [float(e[1]) for e in every]
+        world_seen = dist.get_world_size()
     else:
         dt_all = dt; aligned, nreads, rbases, nfail = [float(x) for x in vals[1:]]
+        per_rank_dt = [dt]; per_rank_cores = [host_cores_busy]; world_seen = 1
 
     if rank == 0:
         K = args.steps
@@ -427,7 +522,7 @@ def main():
                    'seconds': tcpu, 'reads_per_s': ns / tcpu}
         out = {
             'metric': METRIC, 'value': aligned / dt_all / 1e9, 'unit': 'Gbp/s',
-            'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': dt_all * 1e3 / K, 'higher_is_better': True, 'scaling': 'weak',
+            'n_gpus': world_seen, 'rccl_ranks': world_seen if dist is not None else 0, 'steps': K, 'warmup': args.warmup, 'ms_per_step': dt_all * 1e3 / K, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'i16/i32 DP + f64 chains', 'data': 'synthetic',
             'config': {'workload': workload, 'workload_id': workload_id, 'reads_per_step_per_gpu': args.reads_per_step, 'reads_timed': int(nreads),
                        'schedule': 'vacmap_amd.pipeline: %s, %d batches in flight per GPU' % (
@@ -439,7 +534,8 @@ def main():
             'stage_names': ['seed', 'global_chain', 'local', 'divergence_filter', 'edge_extension', 'gapfill+records', 'nofilter_redo', 'download'],
             'gapfill_trace_ms_per_step': agg['ms_gapfill_trace'] / K, 'host_syncs_per_step': agg.get('n_host_syncs', 0) / K,
             # per batch, seen from its host thread: wall time of the library call, of it spent inside waits for the stream; the rest is host work with the context's stream empty
-            'host_cores_busy_timed_pass': round(host_cores_busy, 2),
+            'host_cores_busy_timed_pass': round(host_cores_busy, 2), 'host_cores_busy_all_ranks': round(sum(per_rank_cores), 2), 'host_cores': cores,
+            'ms_per_step_per_rank': [round(x * 1e3 / K, 3) for x in per_rank_dt], 'launched_by': 'bench.py' if os.environ.get('VMX_BENCH_LAUNCHED') == '1' else ('launcher' if 'WORLD_SIZE' in os.environ else 'direct'),
             'host_call_ms_per_batch': agg['ms_stage'][15] / K, 'host_wait_ms_per_batch': agg['ms_stage'][14] / K, 'host_active_ms_per_batch': (agg['ms_stage'][15] - agg['ms_stage'][14]) / K,
             'per_read': {'minimizers': agg['n_minimizers'] / max(agg['n_reads'], 1), 'hits': agg['n_hits'] / max(agg['n_reads'], 1), 'anchors': agg['n_anchors'] / max(agg['n_reads'], 1),
                          'local_anchors': agg['n_local_anchors'] / max(agg['n_reads'], 1), 'dp_problems': agg['n_dp_problems'] / max(agg['n_reads'], 1),

@@ -15,15 +15,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_distributed_path_world_1_nccl():
     """bench.py --gpus 1 with the N-rank code forced: nccl group, index through broadcast_index's replica, all-reduced totals; the records of the
     cross-checked reads still equal the oracle's (they were mapped with the REPLICA of the index)"""
-    env = dict(os.environ, VMX_FORCE_DIST='1', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
+    env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['VMX_FORCE_DIST'] = '1'                # no launcher variables: bench.py's OWN launcher (launch_ranks) starts the rank, as `bench.py --gpus N` does for N > 1
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--ref-mb', '20', '--steps', '3', '--reads-per-step', '256', '--streams', '2',
                           '--cpu-sample', '0', '--verify', '8', '--extra-configs', '', '--no-host-input'], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
-    assert d.get('forced_dist_world_1') is True and d['n_gpus'] == 1
+    assert d.get('forced_dist_world_1') is True and d['n_gpus'] == 1 and d['rccl_ranks'] == 1 and d['launched_by'] == 'bench.py'
+    assert len(d['ms_per_step_per_rank']) == 1 and d['host_cores_busy_all_ranks'] > 0
     assert d['index_broadcast_s'] is not None and d['index_broadcast_s'] > 0
     assert d['oracle_crosscheck'] == '8/8' and d['failed_reads'] == 0 and d['value'] > 0
     assert d['config']['reads_timed'] == 3 * 256                                    # the all-reduced read count
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`bench.py --gpus N` on a box with fewer than N GPUs exits non-zero with a message — never a silent world-1 run that prints n_gpus 1"""
+    sys.path.insert(0, ROOT)
+    from vacmap_amd.lib import load
+    have = load().L.vm_device_count()
+    assert have >= 1
+    env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(have + 1), '--steps', '2'], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode != 0 and 'refusing to run fewer ranks than asked' in out.stderr, out.stderr[-2000:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith('{')]
 
 
 def test_driver_distributed_start_world_1_nccl(tmp_path):

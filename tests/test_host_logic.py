@@ -295,3 +295,40 @@ def test_pipeline_small_contexts_only_take_small_batches():
     ran.clear()
     p._run(6, do_job, None)
     assert sorted(ran) == list(range(6)) and all(nm.startswith('F') for nm in ran.values())
+
+
+def _bench(args, env_extra=None, drop=('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')):
+    env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True, timeout=600, env=env)
+
+
+def test_bench_launcher_dry_run_prints_the_rank_environments():
+    """`bench.py --gpus N` starts its N ranks itself (launch_ranks; the reference's -t forks its own workers, /root/reference/src/vacmap/vacmap:414-420):
+    the dry run shows one environment per rank, a shared rendezvous on 127.0.0.1, and the child command = this command line"""
+    import json
+    out = _bench(['--gpus', '8', '--steps', '20', '--warmup', '5', '--launch-dry-run'])
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    envs = d['environments']
+    assert d['n_ranks'] == 8 and len(envs) == 8
+    assert [e['RANK'] for e in envs] == [str(r) for r in range(8)] and [e['LOCAL_RANK'] for e in envs] == [str(r) for r in range(8)]
+    assert {e['WORLD_SIZE'] for e in envs} == {'8'} and {e['MASTER_ADDR'] for e in envs} == {'127.0.0.1'} and len({e['MASTER_PORT'] for e in envs}) == 1
+    assert d['command'][1].endswith('bench.py') and d['command'][2:] == ['--gpus', '8', '--steps', '20', '--warmup', '5']
+
+
+def test_bench_launcher_refuses_missing_devices_and_disagreeing_world():
+    """fewer devices than --gpus: non-zero exit and a message, no result line (this container has no GPU at all); under a launcher, --gpus must equal WORLD_SIZE"""
+    out = _bench(['--gpus', '2', '--steps', '2'])
+    assert out.returncode != 0 and 'refusing to run fewer ranks than asked' in out.stderr and '{' not in out.stdout
+    out = _bench(['--gpus', '2'], env_extra={'WORLD_SIZE': '4', 'RANK': '0'})
+    assert out.returncode != 0 and 'does not agree with WORLD_SIZE' in out.stderr
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    """a rank that dies takes the launcher's exit code with it and the other ranks are stopped (here every rank fails at vm_ctx_create: no device)"""
+    if os.path.exists('/dev/kfd'):
+        pytest.skip('needs a box without a GPU: the ranks are meant to fail at context creation')
+    out = _bench(['--gpus', '2', '--steps', '2', '--ref-mb', '1', '--reads-per-step', '8', '--extra-configs', ''], env_extra={'VMX_BENCH_ASSUME_DEVICES': '2'})
+    assert out.returncode != 0 and 'exited with code' in out.stderr, out.stderr[-2000:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith('{')]
