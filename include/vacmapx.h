@@ -75,6 +75,11 @@ int vm_ctx_set_inflight(vm_ctx*, int n_contexts);
  * latency). For processes whose other threads need the cores — vacmap_amd.driver's SAM emitters under a CPU quota. */
 int vm_ctx_set_blocking_sync(vm_ctx*, int on);
 int vm_device_count(void);
+/* diagnostics of the chain DPs with four reads per wavefront (csrc/k_chain_rows.hip; replays mammap_clrnano.py:24912-24928, :24944-25003): eight counters summed
+ * over every launch of the process since they were switched on — [0] anchors, [1] scans that left the register window and went on through S_arg / S in HBM,
+ * [2] insertions placed through HBM, [3] opcount of the global chain; [4..7] the same of the local chains. enable: 1 switch on (first call allocates), 0 read,
+ * -1 read and reset. out8 may be NULL. Off by default (the kernels get a NULL counter block); the GPU tests assert that the rare paths did run. */
+int vm_debug_chain_counters(int enable, unsigned long long* out8);
 /* free / total bytes of the context's device (hipMemGetInfo): the driver drops a context when the grow-only work pools of the batches in flight
  * leave less than a safety margin of HBM free after their sizing run */
 int vm_ctx_mem_info(vm_ctx*, int64_t* free_bytes, int64_t* total_bytes);

@@ -80,17 +80,30 @@ def test_hg38_size_index_map_and_records(ctx, oracle, hg38_ref, mode, k, shape):
         assert (status[i] == 0) == (ost == 0) and mine == [t[1:] for t in orecs], 'records of read %d %r differ' % (i, where[i])
         nrec += len(mine)
     assert nrec >= len(reads) and stats['n_failed'] == 0
-    # the bulk sample: 208 more reads of the configuration's own read model, whole path, records vs the oracle
+    # the bulk sample (round 6: tools/bigverify.py's hg38-size leg promoted to this test): 2000 (ONT) / 1000 (HiFi) more
+    # reads of the configuration's own read model, whole path, records vs the oracle — and the row chain kernels' rare paths (scan past the 16-entry window,
+    # insertion through HBM) must have been reached by this sample with the PRODUCT's window, with the records still equal
     import os
     from vacmap_amd import synth
-    cat, off, _ = synth.sample_reads_concat(contigs, 208, mean_len=15000 if shape == 'ont' else 18000, err=0.10 if shape == 'ont' else 0.005, seed=900 + k,
+    from vacmap_amd.lib import chain_counters
+    chain_counters(ctx.lib, 1); chain_counters(ctx.lib, -1)
+    n_bulk = 2000 if shape == 'ont' else 1000
+    cat, off, _ = synth.sample_reads_concat(contigs, n_bulk, mean_len=15000 if shape == 'ont' else 18000, err=0.10 if shape == 'ont' else 0.005, seed=900 + k,
                                             shape=shape, **({'min_len': 5000} if shape == 'hifi' else {}))
-    bulk = [cat[off[i]:off[i + 1]].tobytes() for i in range(208)]
+    bulk = [cat[off[i]:off[i + 1]].tobytes() for i in range(n_bulk)]
     bst, brecs, bstats = align_batch(ctx, gi, prm, bulk)
     ost, orecs = oracle.align_batch(oi, bulk, op, nthreads=min(os.cpu_count() or 1, 32))
     assert [(int(x) == 0) for x in bst] == [(int(x) == 0) for x in ost]
-    assert brecs == orecs, 'bulk sample: records differ from the oracle'
-    assert len(orecs) >= 200
+    if brecs != orecs:
+        a, b = {}, {}
+        for t_ in brecs: a.setdefault(t_[0], []).append(t_[1:])
+        for t_ in orecs: b.setdefault(t_[0], []).append(t_[1:])
+        bad = [i for i in range(n_bulk) if a.get(i) != b.get(i)]
+        assert not bad, 'bulk sample: %d of %d reads differ from the oracle (first: read %d)' % (len(bad), n_bulk, bad[0])
+    assert len(orecs) >= n_bulk - 8 and bstats['n_failed'] == 0
+    cc = chain_counters(ctx.lib, -1)
+    assert cc['global_anchors'] > 50 * n_bulk and cc['local_anchors'] > 50 * n_bulk, cc
+    assert cc['global_scans_past_window'] + cc['local_scans_past_window'] > 0 and cc['global_insertions_through_hbm'] + cc['local_insertions_through_hbm'] > 0, cc
     if mode == 'H':
         # -mode asm at this size: assembly contigs with SVs against the same index — one below 500 kb (the fork's per-read
         # function), one above (the batch-linked path; noise hits outnumber the true ones nine to one here), one from the last contig (> 2^31)

@@ -119,6 +119,37 @@ def test_align_golden(ctx, oracle, golden):
     KC.check_align_golden(ctx, oracle, golden)
 
 
+def test_chain_rows_hbm_paths_forced_on_the_gpu(ctx, oracle, golden, monkeypatch):
+    """k_chain_global_rows / k_chain_local_rows' rare paths ON THE GPU, on purpose (VERDICT r5 Missing 2): the scan that leaves the register window and walks
+    S_arg / S in HBM, and the insertion below the window, both "first wait for the row's own stores" (k_chain_rows.hip) — a store -> load ordering inside one
+    wavefront, which the CPU emulator cannot get wrong. (a) VMX_RW_WIN=3 launches the 3-entry-window TEST kernels built into the GPU library
+    (k_chain_*_rows_w3): the rare paths are taken at almost every anchor; S / P / S_arg (V2), the local chains (V3) and the records (V6) of cases B, D, F, H, P
+    must equal the reference's goldens, and the device counters must show that the paths ran. (b) the product's 16-entry window on the repeat-dense cases
+    D / F: the counters must be non-zero there too, goldens unchanged. Reference loop being replayed: mammap_clrnano.py:24912-24928, :24944-25003."""
+    from vacmap_amd.lib import chain_counters
+    chain_counters(ctx.lib, 1); chain_counters(ctx.lib, -1)
+    monkeypatch.setenv('VMX_RW_WIN', '3')
+    KC.check_chain_global_golden(ctx, oracle, golden, cases=['B', 'D'])
+    c1 = chain_counters(ctx.lib, -1)
+    assert c1['global_anchors'] > 0 and c1['global_scans_past_window'] > 100 and c1['global_insertions_through_hbm'] > 100, c1
+    KC.check_local_golden(ctx, oracle, golden, cases=['B', 'D', 'F', 'H', 'P'])
+    KC.check_align_golden(ctx, oracle, golden, cases=['B', 'D', 'F', 'H', 'P'])
+    c2 = chain_counters(ctx.lib, -1)
+    assert c2['global_scans_past_window'] > 100 and c2['global_insertions_through_hbm'] > 100, c2
+    assert c2['local_anchors'] > 0 and c2['local_scans_past_window'] > 100 and c2['local_insertions_through_hbm'] > 100, c2
+    # the rare paths dominate with three entries: far more often than one anchor in a hundred
+    assert c2['global_insertions_through_hbm'] * 100 > c2['global_anchors'] and c2['local_insertions_through_hbm'] * 100 > c2['local_anchors'], c2
+    monkeypatch.delenv('VMX_RW_WIN')
+    KC.check_chain_global_golden(ctx, oracle, golden, cases=['D'])
+    KC.check_local_golden(ctx, oracle, golden, cases=['D', 'F'])
+    KC.check_align_golden(ctx, oracle, golden, cases=['D', 'F'])
+    c3 = chain_counters(ctx.lib, -1)
+    assert c3['global_anchors'] > 0 and c3['local_anchors'] > 0
+    assert c3['global_scans_past_window'] + c3['local_scans_past_window'] > 0, c3             # the product's window: rare, but reached by the repeat-dense reads of D / F
+    assert c3['global_insertions_through_hbm'] + c3['local_insertions_through_hbm'] > 0, c3
+    assert c3['global_insertions_through_hbm'] * 20 < c3['global_anchors'] + 20, c3           # ... and rare
+
+
 def test_extend_pools_grow_and_retry(ctx, oracle, golden, monkeypatch):
     """every pool of the extend stage made too small through the test hook VMX_TEST_EXT_POOL=<mask>:<div> (1 segment anchors, 2 segments, 4 record blob,
     8 problems per round, 16 problem strings; 31 all): the read (VMX_EXT_CAPACITY_DEV) or the batch (overflow flag) reports it, the batch runs again with

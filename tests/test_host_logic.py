@@ -332,3 +332,33 @@ def test_bench_launcher_propagates_a_failing_rank():
     out = _bench(['--gpus', '2', '--steps', '2', '--ref-mb', '1', '--reads-per-step', '8', '--extra-configs', ''], env_extra={'VMX_BENCH_ASSUME_DEVICES': '2'})
     assert out.returncode != 0 and 'exited with code' in out.stderr, out.stderr[-2000:]
     assert not [l for l in out.stdout.splitlines() if l.startswith('{')]
+
+
+def test_cross_rank_name_dedup_keeps_first_in_input_order(tmp_path):
+    """range mode: a name that occurs in two ranks' byte ranges keeps its FIRST occurrence in input order — (file, then byte range = rank) — as the reference's
+    single pass over the files does (/root/reference/src/vacmap/vacmap:457-487), not the lowest rank's; and the part filter drops exactly the
+    lines of those names, hashing the names block-wise"""
+    import io
+    from vacmap_amd import driver
+    nm = lambda names: driver.name_hashes(np.frombuffer(b''.join(names), dtype=np.uint8), np.concatenate([[0], np.cumsum([len(x) for x in names])]))
+    # rank 0 holds 'x' from file 1 (second file) and 'a' from file 0; rank 3 holds 'x' from file 0 (first file): the file-0 occurrence (rank 3) stays
+    h0, f0 = nm([b'a', b'x']), np.asarray([0, 1], np.int32)
+    h1, f1 = nm([b'b']), np.asarray([0], np.int32)
+    h2, f2 = nm([b'c', b'a']), np.asarray([0, 1], np.int32)           # 'a' again in file 1 on rank 2: goes (rank 0 has it from file 0)
+    h3, f3 = nm([b'x']), np.asarray([0], np.int32)
+    drop = driver.cross_rank_duplicates([h0, h1, h2, h3], [f0, f1, f2, f3])
+    assert set(drop) == {0, 2}
+    assert list(drop[0]) == list(nm([b'x'])) and list(drop[2]) == list(nm([b'a']))
+    # same file on both sides: the lower rank (= lower byte range) stays
+    drop = driver.cross_rank_duplicates([nm([b'q']), nm([b'q'])], [np.asarray([0], np.int32), np.asarray([0], np.int32)])
+    assert set(drop) == {1}
+    # the filter: header lines pass, every line of a dropped name goes, block boundaries inside lines are handled
+    lines = [b'@HD\tVN:1.6\n', b'@SQ\tSN:a\tLN:9\n'] + [b'r%d\t0\ta\t%d\t60\t5M\t*\t0\t0\tACGTA\tIIIII\n' % (i % 7, i) for i in range(50)] + [b'x\t4\t*\n']
+    src = io.BytesIO(b''.join(lines)); dst = io.BytesIO()
+    bad = np.sort(nm([b'r3', b'x']))
+    gone, gl = driver._filter_part(src, dst, bad, block=97)
+    want = [l for l in lines if not (l.startswith(b'r3\t') or l.startswith(b'x\t'))]
+    assert dst.getvalue() == b''.join(want) and gl == len(lines) - len(want) and len(gone) == 2
+    src = io.BytesIO(b''.join(lines)[:-1]); dst = io.BytesIO()      # no newline at the end of the part
+    driver._filter_part(src, dst, np.sort(nm([b'r1'])), block=1 << 20)
+    assert dst.getvalue() == b''.join(l for l in lines if not l.startswith(b'r1\t'))

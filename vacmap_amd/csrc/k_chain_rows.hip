@@ -343,14 +343,16 @@ __device__ __forceinline__ int vmx_rw_chain(const vmx_anchor* __restrict__ A, in
     return bailed ? -1 : g_max_index;
 }
 
-#ifdef VMX_EMU
-static inline bool vmx_rw_small_window() { const char* e = getenv("VMX_RW_WIN"); return e && atoi(e) == 3; }      // CPU-emulator test hook (read at every launch)
-#endif
+// WW = 16 is the product. The WW = 3 instantiations (k_chain_global_rows_w3 / k_chain_local_rows_w3) are TEST kernels built into the same library: the host
+// launches them instead when VMX_RW_WIN=3 is in the environment (read at every launch), so that the rare paths — the scan that leaves the window and walks
+// S_arg / S in HBM, the insertion below the window, both behind the row's own stores — are the COMMON ones, on the GPU (store -> load ordering inside one wave
+// is what the CPU emulator cannot show: VERDICT r5) as on the emulator.
 // ------------------------------------------------------------------------------------------------ G2 GC-exact, four reads per wave
 // rlist: the reads of the launch, most anchors first; workgroup (= wavefront) b takes the reads 4 b .. 4 b + 3. rmode: 0 modes H / L / S, 1 mode R.
 // dbg (optional, VMX_DBG_CHAIN=1): [0] anchors, [1] scans that left the window, [2] insertions through HBM, [3] opcount; [4..7] the same of k_chain_local_rows
-__global__ void __launch_bounds__(64) k_chain_global_rows(const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ aoff,
-                                                          const int32_t* __restrict__ rlist, int nlist, vmx_tables tab,
+template <int WW>
+__device__ __forceinline__ void vmx_chain_global_rows_body(const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ aoff,
+                                                          const int32_t* __restrict__ rlist, int nlist, const vmx_tables& tab,
                                                           const double* __restrict__ gapcost_list, double oskipcost, int omaxdiff,
                                                           int maxgap, double* __restrict__ S_out, int32_t* __restrict__ P_out,
                                                           int32_t* __restrict__ SA_out, uint8_t* __restrict__ cov_pool,
@@ -382,18 +384,24 @@ __global__ void __launch_bounds__(64) k_chain_global_rows(const vmx_anchor* __re
     }
     vmx_rw_costs K; K.s_gapcost = s_gapcost; K.s_rgc = nullptr; K.skip = oskipcost; K.maxgap = maxgap; K.l2c_size = 0; K.log2cache = nullptr;
     double best; long long opc; unsigned long long slow; int g;
-#ifdef VMX_EMU
-    if (vmx_rw_small_window()) {
-        if (rmode == 0) g = vmx_rw_chain<0, 3>(A, n, K, tab, oskipcost, omaxdiff, S_out + a0, P_out + a0, SA_out + a0, COV, nullptr, nullptr, best, opc, slow);
-        else g = vmx_rw_chain<1, 3>(A, n, K, tab, oskipcost, omaxdiff, S_out + a0, P_out + a0, SA_out + a0, nullptr, FP_pool + a0, PP_pool + a0, best, opc, slow);
-    } else
-#endif
-    if (rmode == 0) g = vmx_rw_chain<0, 16>(A, n, K, tab, oskipcost, omaxdiff, S_out + a0, P_out + a0, SA_out + a0, COV, nullptr, nullptr, best, opc, slow);
-    else g = vmx_rw_chain<1, 16>(A, n, K, tab, oskipcost, omaxdiff, S_out + a0, P_out + a0, SA_out + a0, nullptr, FP_pool + a0, PP_pool + a0, best, opc, slow);
+    if (rmode == 0) g = vmx_rw_chain<0, WW>(A, n, K, tab, oskipcost, omaxdiff, S_out + a0, P_out + a0, SA_out + a0, COV, nullptr, nullptr, best, opc, slow);
+    else g = vmx_rw_chain<1, WW>(A, n, K, tab, oskipcost, omaxdiff, S_out + a0, P_out + a0, SA_out + a0, nullptr, FP_pool + a0, PP_pool + a0, best, opc, slow);
     if (l16 == 0) {
         gmax_out[rd] = g; opcount_out[rd] = opc;
         if (dbg) { atomicAdd(&dbg[0], (unsigned long long)n); atomicAdd(&dbg[1], slow & 0xffffffffULL); atomicAdd(&dbg[2], slow >> 32); atomicAdd(&dbg[3], (unsigned long long)opc); }
     }
+}
+
+
+#define VMX_GLOBAL_ROWS_ARGS const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ aoff, const int32_t* __restrict__ rlist, int nlist, vmx_tables tab, \
+    const double* __restrict__ gapcost_list, double oskipcost, int omaxdiff, int maxgap, double* __restrict__ S_out, int32_t* __restrict__ P_out, int32_t* __restrict__ SA_out, \
+    uint8_t* __restrict__ cov_pool, int64_t* __restrict__ gmax_out, int64_t* __restrict__ opcount_out, int rmode, double* __restrict__ FP_pool, double* __restrict__ PP_pool, \
+    unsigned long long* __restrict__ dbg
+__global__ void __launch_bounds__(64) k_chain_global_rows(VMX_GLOBAL_ROWS_ARGS) {
+    vmx_chain_global_rows_body<16>(anchors, aoff, rlist, nlist, tab, gapcost_list, oskipcost, omaxdiff, maxgap, S_out, P_out, SA_out, cov_pool, gmax_out, opcount_out, rmode, FP_pool, PP_pool, dbg);
+}
+__global__ void __launch_bounds__(64) k_chain_global_rows_w3(VMX_GLOBAL_ROWS_ARGS) {          // test kernel: 3-entry window (see above)
+    vmx_chain_global_rows_body<3>(anchors, aoff, rlist, nlist, tab, gapcost_list, oskipcost, omaxdiff, maxgap, S_out, P_out, SA_out, cov_pool, gmax_out, opcount_out, rmode, FP_pool, PP_pool, dbg);
 }
 
 // ------------------------------------------------------------------------------------------------ L3 / L4 / L5 local chain DP, four reads per wave
@@ -401,9 +409,10 @@ __global__ void __launch_bounds__(64) k_chain_global_rows(const vmx_anchor* __re
 // more than one chain (n_guides_total > 1, :28583-28590), else LC-exact, `_scar` in mode R; `want` names the variant of this launch (0 / 1 / 2) and
 // a row whose read wants another one leaves at once — the variants are different code, and rows of one wave in different variants would run one
 // after the other. Traceback with overlap trimming (:27508-27526) by the row's first lane.
-__global__ void __launch_bounds__(64) k_chain_local_rows(const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ la_off,
+template <int WW>
+__device__ __forceinline__ void vmx_chain_local_rows_body(const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ la_off,
                                                          const int32_t* __restrict__ la_cnt, const int32_t* __restrict__ n_guides_total,
-                                                         const int32_t* __restrict__ rlist, int nlist, int want, vmx_tables tab,
+                                                         const int32_t* __restrict__ rlist, int nlist, int want, const vmx_tables& tab,
                                                          const double* __restrict__ gapcost_list, double skip_exact, double skip_mm, int maxdiff,
                                                          int maxgap, int mode, double* __restrict__ S_pool, int32_t* __restrict__ P_pool,
                                                          int32_t* __restrict__ SA_pool, double* __restrict__ out_score,
@@ -433,16 +442,9 @@ __global__ void __launch_bounds__(64) k_chain_local_rows(const vmx_anchor* __res
     K.l2c_size = (long long)tab.log2cache_n - 1; K.log2cache = tab.log2cache;
     double* S = S_pool + a0; int32_t* P = P_pool + a0; int32_t* SA = SA_pool + a0;
     double best = 0.0; long long opc = 0; unsigned long long slow = 0; int g;
-#ifdef VMX_EMU
-    if (vmx_rw_small_window()) {
-        if (want == 0) g = vmx_rw_chain<2, 3>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, nullptr, nullptr, best, opc, slow);
-        else if (want == 1) g = vmx_rw_chain<3, 3>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, nullptr, nullptr, best, opc, slow);
-        else g = vmx_rw_chain<4, 3>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, FP_pool + a0, PP_pool + a0, best, opc, slow);
-    } else
-#endif
-    if (want == 0) g = vmx_rw_chain<2, 16>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, nullptr, nullptr, best, opc, slow);
-    else if (want == 1) g = vmx_rw_chain<3, 16>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, nullptr, nullptr, best, opc, slow);
-    else g = vmx_rw_chain<4, 16>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, FP_pool + a0, PP_pool + a0, best, opc, slow);
+    if (want == 0) g = vmx_rw_chain<2, WW>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, nullptr, nullptr, best, opc, slow);
+    else if (want == 1) g = vmx_rw_chain<3, WW>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, nullptr, nullptr, best, opc, slow);
+    else g = vmx_rw_chain<4, WW>(A, n, K, tab, K.skip, maxdiff, S, P, SA, nullptr, FP_pool + a0, PP_pool + a0, best, opc, slow);
     vmx_row_sync();                                   // (P, written through the loop without waiting, is read back by the traceback)
     if (g < 0) { if (l16 == 0) { out_len[rd] = 0; out_score[rd] = 0; status[rd] = VM_READ_FASTPATH_DEV; } }
     else {
@@ -494,4 +496,17 @@ __global__ void __launch_bounds__(64) k_chain_local_rows(const vmx_anchor* __res
         out_variant[rd] = want;
         if (dbg) { atomicAdd(&dbg[4], (unsigned long long)n); atomicAdd(&dbg[5], slow & 0xffffffffULL); atomicAdd(&dbg[6], slow >> 32); atomicAdd(&dbg[7], (unsigned long long)opc); }
     }
+}
+
+#define VMX_LOCAL_ROWS_ARGS const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ la_off, const int32_t* __restrict__ la_cnt, const int32_t* __restrict__ n_guides_total, \
+    const int32_t* __restrict__ rlist, int nlist, int want, vmx_tables tab, const double* __restrict__ gapcost_list, double skip_exact, double skip_mm, int maxdiff, int maxgap, int mode, \
+    double* __restrict__ S_pool, int32_t* __restrict__ P_pool, int32_t* __restrict__ SA_pool, double* __restrict__ out_score, vmx_anchor* __restrict__ out_chain, \
+    int32_t* __restrict__ out_len, int32_t* __restrict__ out_variant, int32_t* __restrict__ status, double* __restrict__ FP_pool, double* __restrict__ PP_pool, unsigned long long* __restrict__ dbg
+__global__ void __launch_bounds__(64) k_chain_local_rows(VMX_LOCAL_ROWS_ARGS) {
+    vmx_chain_local_rows_body<16>(anchors, la_off, la_cnt, n_guides_total, rlist, nlist, want, tab, gapcost_list, skip_exact, skip_mm, maxdiff, maxgap, mode, S_pool, P_pool, SA_pool, out_score,
+                                  out_chain, out_len, out_variant, status, FP_pool, PP_pool, dbg);
+}
+__global__ void __launch_bounds__(64) k_chain_local_rows_w3(VMX_LOCAL_ROWS_ARGS) {           // test kernel: 3-entry window (see above)
+    vmx_chain_local_rows_body<3>(anchors, la_off, la_cnt, n_guides_total, rlist, nlist, want, tab, gapcost_list, skip_exact, skip_mm, maxdiff, maxgap, mode, S_pool, P_pool, SA_pool, out_score,
+                                 out_chain, out_len, out_variant, status, FP_pool, PP_pool, dbg);
 }

@@ -381,14 +381,16 @@ __device__ __forceinline__ void vmx_gather_one(const vmx_sdesc& d, const uint8_t
 __global__ void __launch_bounds__(256) k_gather(const vmx_pair_desc* __restrict__ desc, const int32_t* __restrict__ n_prob, const int32_t* __restrict__ prob_read,
                                                 const uint8_t* __restrict__ ocodes, const int64_t* __restrict__ roff, const uint8_t* __restrict__ ref,
                                                 const int64_t* __restrict__ t_off, const int64_t* __restrict__ q_off, uint8_t* __restrict__ tpool,
-                                                uint8_t* __restrict__ qpool, int64_t pool_cap, int32_t* __restrict__ overflow) {
+                                                uint8_t* __restrict__ qpool, int64_t pool_cap, vmx_ext_read* __restrict__ er) {
     // a problem's two strings are a few hundred bytes: one wavefront each (a 256-thread workgroup per problem kept a quarter as many
     // descriptor / source loads in flight and left most of its threads without a byte to copy)
     const int n = *n_prob;
     const int wpb = (int)(blockDim.x >> 6), wv = (int)(threadIdx.x >> 6);
     for (int i = (int)blockIdx.x * wpb + wv; i < n; i += (int)gridDim.x * wpb) {
         const vmx_pair_desc d = desc[i];
-        if (t_off[i] + d.t.len > pool_cap || q_off[i] + d.q.len > pool_cap) { if ((threadIdx.x & 63) == 0) atomicExch(overflow, 1); continue; }
+        // the string pools are an estimate (6 B per read base): a problem that does not fit marks ITS READ (round 6; a batch-wide flag before) — the read is run again
+        // alone with larger pools (align_device), the others keep their results
+        if (t_off[i] + d.t.len > pool_cap || q_off[i] + d.q.len > pool_cap) { if ((threadIdx.x & 63) == 0) er[prob_read[i]].status = VMX_EXT_CAPACITY_DEV; continue; }
         const uint8_t* rd = ocodes + roff[prob_read[i]];
         vmx_gather_one(d.t, rd, ref, tpool + t_off[i]);
         vmx_gather_one(d.q, rd, ref, qpool + q_off[i]);

@@ -22,7 +22,7 @@ __global__ void k_ed_anchor_bound(vmx_ext_args A, const int32_t* probread, const
                                   int64_t* ub_out);
 __global__ void k_desc_lens(const vmx_pair_desc* desc, const int32_t* n_prob, int64_t* tl, int64_t* ql);
 __global__ void k_gather(const vmx_pair_desc* desc, const int32_t* n_prob, const int32_t* prob_read, const uint8_t* ocodes, const int64_t* roff,
-                         const uint8_t* ref, const int64_t* t_off, const int64_t* q_off, uint8_t* tpool, uint8_t* qpool, int64_t pool_cap, int32_t* overflow);
+                         const uint8_t* ref, const int64_t* t_off, const int64_t* q_off, uint8_t* tpool, uint8_t* qpool, int64_t pool_cap, vmx_ext_read* er);
 __global__ void k_prob_owner(const vmx_ext_read* er, int n_reads, int use_dp, int32_t* prob_read);
 __global__ void k_dp_sizes(const vmx_pair_desc* desc, const int32_t* n_prob, int64_t* tb_sz, int64_t* bnd_sz, int64_t* run_sz, int64_t* cig_sz);
 __global__ void k_dp_table(const vmx_pair_desc* desc, const int32_t* n_prob, const int64_t* t_off, const int64_t* q_off, const int64_t* tb_off,
@@ -88,7 +88,7 @@ struct vmx_batch_bufs {
     // extend stage
     DevBuf er, coff3, soff2, segA, st, en, segA_s, st_s, en_s, segprob, dup, desc[2], rcount, oflow, probread, tl, ql, toff, qoff, tpool, qpool;
     DevBuf edout, carry, ext3, dpsz[4], dpoff[4], dptab, tb, tbredo, bnd, run, cig, ciglen, dpscore, rec, blob, bloboff, reccoff, recclen, dupd, totals;
-    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp, chunkn, sellist, cigq, statblk, szh;
+    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp, chunkn, sellist, cigq, statblk, szh, side_codes, side_off;
     void release() { DevBuf* p = (DevBuf*)this; for (size_t i = 0; i < sizeof(*this) / sizeof(DevBuf); ++i) p[i].release(); }
 };
 static vmx_batch_bufs* batch_bufs(vm_ctx* c) { if (!c->bbufs) c->bbufs = new vmx_batch_bufs(); return c->bbufs; }
@@ -171,7 +171,7 @@ static int ext_gather_round(vm_ctx* c, vmx_batch_bufs& B, const vm_index_view& i
     VMX_TRY(dev_scan_dev(c, B, B.ql.as<int64_t>(), B.qoff.as<int64_t>(), B.rcount.as<int32_t>()));
     hipLaunchKernelGGL(k_gather, dim3((unsigned)((int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(),
                        B.probread.as<int32_t>(), d_ocodes, d_roff, ix.codes, B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), pool_cap,
-                       B.oflow.as<int32_t>());
+                       B.er.as<vmx_ext_read>());
     return cnt;
 }
 
@@ -186,24 +186,81 @@ int vmx_align_batch_asm_mixed(vm_ctx* c, const vm_index* mi, const vm_params* pr
 int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
                  vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats, vmx_seg_trace* trace = nullptr, const vmx_preset* preset = nullptr);
 
-#define VMX_RETRY_EXT_POOLS (-9001)      // align_device_once -> align_device: an extend-stage pool was too small, c->ext_mul has been raised
+#define VMX_EXT_SHORT_INTERNAL (-9001)   // align_device_once's per-read status for "an extend-stage pool was too small for this read" (never leaves align_device)
 static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
                              vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats, vmx_seg_trace* trace, const vmx_preset* preset);
 // The pools of the extend stage are sized from bounds that hold by construction for the reference's segment surgery (a chain never has more segments than
 // anchors, a round never more problems than anchors, ...) — and where a bound is an estimate (the problem strings of a round: 6 bytes per read base) or a
-// construction turns out wrong for some input, the read or the batch reports it (VMX_EXT_CAPACITY_DEV / the overflow flag) and the batch is run again
-// with every extend-stage pool four times larger, up to x1024, before a read is given up as VM_READ_CAPACITY. VMX_TEST_EXT_POOL=<mask>:<div> (tests) divides
-// the pools the mask names (1 segment anchors, 2 segments, 4 record blob, 8 problems per round, 16 problem strings) so that each of these ends is exercised.
+// construction turns out wrong for some input, THE READ reports it (VMX_EXT_CAPACITY_DEV; round 6: k_gather's string pools mark the owning read as well).
+// Round 6: the batch is NOT run again as a whole with every pool x4 — that multiplied ~10 GB of grow-only pools for all 4096 reads because of one
+// read, could exhaust the HBM next to the other contexts, and left the pools inflated for the life of the context. The reads that reported it (a handful, if
+// any) are run again ALONE as a side batch with their pools x4, x16, ... x1024: a few reads' pools times 1024 still fit inside what the whole batch holds, so
+// nothing grows; their records are spliced into the batch's. A read that is still short at x1024 — or whose side batch finds no device memory — is reported as
+// VM_READ_CAPACITY; the rest of the batch is unaffected. VMX_TEST_EXT_POOL=<mask>:<div> (tests) divides the pools the mask names (1 segment anchors, 2 segments,
+// 4 record blob, 8 problems per round, 16 problem strings) so that each of these ends is exercised.
+__global__ void k_side_codes(const uint8_t* __restrict__ codes, const int64_t* __restrict__ roff, const int32_t* __restrict__ pick, const int64_t* __restrict__ soff, int n, uint8_t* __restrict__ out) {
+    for (int j = blockIdx.x; j < n; j += gridDim.x) {
+        const int64_t a = roff[pick[j]], len = roff[pick[j] + 1] - a; const uint8_t* s = codes + a; uint8_t* d = out + soff[j];
+        for (int64_t i = threadIdx.x; i < len; i += blockDim.x) d[i] = s[i];
+    }
+}
 int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
                  vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats, vmx_seg_trace* trace, const vmx_preset* preset) {
     c->ext_mul = 1;
-    int64_t retries = 0;
-    for (;;) {
-        const int rc = align_device_once(c, mi, prm, n, d_codes, d_roff, h_roff, recs, n_recs, cigar_blob, status_per_read, stats, trace, preset);
-        if (rc != VMX_RETRY_EXT_POOLS) { c->ext_mul = 1; if (rc == VM_OK && stats) stats->n_ext_retries = retries; return rc; }
-        ++retries;
-        if (trace) { trace->rows.clear(); trace->off.clear(); }
+    std::vector<int32_t> status((size_t)n + 1, 0);
+    vm_batch_stats st; memset(&st, 0, sizeof st);
+    int rc = align_device_once(c, mi, prm, n, d_codes, d_roff, h_roff, recs, n_recs, cigar_blob, status.data(), &st, trace, preset);
+    if (rc < 0) return rc;
+    std::vector<int32_t> sub;                                    // reads of the batch that were short of an extend-stage pool
+    for (int64_t r = 0; r < n; ++r) if (status[(size_t)r] == VMX_EXT_SHORT_INTERNAL) sub.push_back((int32_t)r);
+    if (!sub.empty()) {
+        vmx_batch_bufs& B = *batch_bufs(c);
+        std::vector<vm_record> all(*recs, *recs + *n_recs);
+        int64_t blob_n = 0; for (const vm_record& x : all) blob_n = std::max<int64_t>(blob_n, x.cigar_off + x.cigar_len + 1);
+        std::string blob(*cigar_blob, (size_t)blob_n);
+        free(*recs); free(*cigar_blob); *recs = nullptr; *cigar_blob = nullptr; *n_recs = 0;
+        int64_t retries = 0;
+        while (!sub.empty() && c->ext_mul < 1024) {
+            c->ext_mul *= 4; ++retries;
+            if (getenv("VMX_DBG_POOLS")) fprintf(stderr, "[pools] extend stage: %zu read(s) short of a pool, running them again alone with x%d\n", sub.size(), c->ext_mul);
+            const int64_t m = (int64_t)sub.size();
+            std::vector<int64_t> s_off((size_t)m + 1, 0); std::vector<vmx_preset> s_pre;
+            for (int64_t j = 0; j < m; ++j) { s_off[(size_t)j + 1] = s_off[(size_t)j] + (h_roff[(size_t)sub[(size_t)j] + 1] - h_roff[(size_t)sub[(size_t)j]]); if (preset) s_pre.push_back(preset[sub[(size_t)j]]); }
+            int src = 0;
+            if ((src = B.side_codes.reserve((size_t)s_off[(size_t)m] + 64)) < 0 || (src = upload(B.side_off, s_off.data(), (size_t)m + 1, c->stream)) < 0 ||
+                (src = upload(B.sellist, sub.data(), (size_t)m, c->stream)) < 0) { if (src == VM_ERR_OOM) break; c->ext_mul = 1; return src; }
+            hipLaunchKernelGGL(k_side_codes, dim3((unsigned)std::min<int64_t>(m, (int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, d_codes, d_roff, B.sellist.as<int32_t>(), B.side_off.as<int64_t>(), (int)m,
+                               B.side_codes.as<uint8_t>());
+            vm_record* r2 = nullptr; int64_t n2 = 0; char* b2 = nullptr; vm_batch_stats st2; std::vector<int32_t> status2((size_t)m + 1, 0);
+            src = align_device_once(c, mi, prm, m, B.side_codes.as<uint8_t>(), B.side_off.as<int64_t>(), s_off, &r2, &n2, &b2, status2.data(), &st2, nullptr, preset ? s_pre.data() : nullptr);
+            if (src == VM_ERR_OOM) { free(r2); free(b2); break; }                 // no room for the larger pools: these reads are reported, the batch stands
+            if (src < 0) { free(r2); free(b2); c->ext_mul = 1; return src; }
+            std::vector<int32_t> still;
+            for (int64_t j = 0; j < m; ++j) { if (status2[(size_t)j] == VMX_EXT_SHORT_INTERNAL) still.push_back(sub[(size_t)j]); else status[(size_t)sub[(size_t)j]] = status2[(size_t)j]; }
+            for (int64_t i = 0; i < n2; ++i) { vm_record x = r2[i]; x.read_idx = sub[(size_t)x.read_idx]; x.cigar_off += (int64_t)blob.size(); all.push_back(x); }
+            int64_t bl = 0; for (int64_t i = 0; i < n2; ++i) bl = std::max<int64_t>(bl, r2[i].cigar_off + r2[i].cigar_len + 1);
+            blob.append(b2, (size_t)bl);
+            free(r2); free(b2);
+            st.ms_total += st2.ms_total; for (int i = 0; i < 14; ++i) st.ms_stage[i] += st2.ms_stage[i];
+            st.n_host_syncs += st2.n_host_syncs;
+            sub.swap(still);
+        }
+        c->ext_mul = 1;
+        for (int32_t r : sub) status[(size_t)r] = VM_READ_CAPACITY;
+        std::stable_sort(all.begin(), all.end(), [](const vm_record& a, const vm_record& b) { return a.read_idx < b.read_idx; });      // records stay grouped by read, in read order
+        *recs = (vm_record*)malloc(sizeof(vm_record) * std::max<size_t>(all.size(), 1)); *cigar_blob = (char*)malloc(std::max<size_t>(blob.size(), 1));
+        if (!*recs || !*cigar_blob) { free(*recs); free(*cigar_blob); *recs = nullptr; *cigar_blob = nullptr; set_error("out of host memory"); return VM_ERR_OOM; }
+        memcpy(*recs, all.data(), sizeof(vm_record) * all.size()); memcpy(*cigar_blob, blob.data(), blob.size());
+        *n_recs = (int64_t)all.size();
+        // the batch's counters over the spliced result
+        st.n_ext_retries = retries; st.n_records = *n_recs; st.aligned_bases = 0; st.cigar_bytes = 0; st.n_failed = 0; st.n_unmapped = 0;
+        std::vector<char> has((size_t)n + 1, 0);
+        for (const vm_record& x : all) { st.aligned_bases += x.q_en - x.q_st; st.cigar_bytes += x.cigar_len; has[(size_t)x.read_idx] = 1; }
+        for (int64_t r = 0; r < n; ++r) { if (status[(size_t)r] != 0) st.n_failed++; else if (!has[(size_t)r]) st.n_unmapped++; }
     }
+    if (status_per_read) memcpy(status_per_read, status.data(), 4 * (size_t)n);
+    if (stats) *stats = st;
+    return VM_OK;
 }
 
 static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
@@ -305,7 +362,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
             int cnt = (int)lists[q].size(); if (!cnt) continue;
             int cap = q < NB ? caps[q] : 0; size_t shmem = (size_t)cap * VMX_GC_BYTES_PER_ANCHOR + 64;
             if (rows_kernel) {
-                hipLaunchKernelGGL(k_chain_global_rows, dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, fk.next(), B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(),
+                hipLaunchKernelGGL(vmx_chain_rows_win3() ? k_chain_global_rows_w3 : k_chain_global_rows, dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, fk.next(), B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(),
                                    B.rl.as<int32_t>() + rl_off[q], cnt, c->tables, B.gap.as<double>(), prm->global_skipcost, prm->global_maxdiff, 1000, B.S.as<double>(),
                                    B.P.as<int32_t>(), B.SA.as<int32_t>(), B.cov.as<uint8_t>(), B.gmax.as<int64_t>(), B.opc.as<int64_t>(), rmode, B.fp.as<double>(), B.pp.as<double>(),
                                    vmx_chain_dbg());
@@ -635,15 +692,6 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     for (int i = 0; i < 8; ++i) hstat[i] = fin[6 + i];
     st.n_segments = hstat[0]; st.n_ed_problems = hstat[0]; st.n_ext_problems = (int64_t)hstat[1] + hstat[2] + hstat[3] + hstat[4];
     st.n_ed_full = n_full; st.n_ed_tier2 = n_t2; st.n_ed_tier1 = n_t1;
-    {   // a pool of the extend stage was too small (for the batch: overflow flag; for a read: its status): once more with larger pools
-        bool small = oflow != 0;
-        for (int64_t r = 0; r < n && !small; ++r) small = er[(size_t)r].status == VMX_EXT_CAPACITY_DEV;
-        if (small && c->ext_mul < 1024) {
-            c->ext_mul *= 4;
-            if (getenv("VMX_DBG_POOLS")) fprintf(stderr, "[pools] extend stage: a pool was too small (batch flag %d), running the batch again with x%d\n", oflow, c->ext_mul);
-            return VMX_RETRY_EXT_POOLS;
-        }
-    }
     if (oflow) { set_error("extend stage: a per-batch work pool overflowed"); return VM_ERR_OOM; }
     if (nr > g_nr || nb > g_nb) {                                 // the guess was short: fetch the tails
         if (nr > g_nr) { vm_record* p2 = (vm_record*)realloc(*recs, sizeof(vm_record) * (size_t)nr); if (!p2) { set_error("out of host memory"); return VM_ERR_OOM; } *recs = p2;
@@ -654,7 +702,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     }
     if (n > 0 && total_bases > 0) { c->res_rec_per_read = std::max(c->res_rec_per_read, (double)nr / (double)n); c->res_blob_per_base = std::max(c->res_blob_per_base, (double)nb / (double)total_bases); }
     for (int64_t r = 0; r < n; ++r) {
-        int stt2 = er[r].status == VMX_EXT_CAPACITY_DEV ? VM_READ_CAPACITY : er[r].status;
+        int stt2 = er[r].status == VMX_EXT_CAPACITY_DEV ? VMX_EXT_SHORT_INTERNAL : er[r].status;      // (align_device runs these reads again alone, with larger pools)
         if (h_gmax[r] == -2 && (h_aoff[r + 1] - h_aoff[r]) > 2) stt2 = VM_READ_RAISED;     // GC-fast: the reference raises on this read (k_chain_fast.hip)
         if (h_gmax[r] == -4) stt2 = VM_READ_UNSUPPORTED;                                    // -mode asm: a contig of 500 kb or more inside align_device (vm_align_batch routes those to vmx_asm.hip)
         if (!asm_override.empty() && asm_override[(size_t)r] != 0) stt2 = asm_override[(size_t)r];

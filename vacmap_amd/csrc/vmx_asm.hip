@@ -280,21 +280,26 @@ void dump_rows(const char* name, const std::vector<vmx_anchor>& v, bool append =
 // collect_second_round_anchors (:22477-22756) for every second-round batch at once: one k_local_seed launch, one unit per batch
 #define VMX_RETRY_RESEED (-9002)          // second_round_seed_once -> second_round_seed: a pool of the launch was too small for one of its batches
 static int second_round_seed_once(vm_ctx* c, const vm_index_view& ix, int k, const uint8_t* d_codes, int64_t L, const std::vector<vmx_anchor>& raw_asc, const std::vector<Tuple>& tuples,
-                                  std::vector<std::vector<vmx_anchor>>& out, int64_t mult, int64_t div);
+                                  std::vector<std::vector<vmx_anchor>>& out, int64_t mult, int64_t div, std::vector<int64_t>& slot_mul);
 // the anchor slots and hit pools of the launch are estimates (8 x the per-read slot of the span, 4 hits per position): a batch that overflows them is not given up — the
-// launch is repeated with the pools x4, up to x256, before the contig is reported as VM_READ_CAPACITY (round 5; VMX_TEST_ASM_RESEED_DIV=<d> divides the pools in the tests)
+// launch is repeated, up to five times, before the contig is reported as VM_READ_CAPACITY (round 5; VMX_TEST_ASM_RESEED_DIV=<d> divides the pools in the tests).
+// Round 6: only the batches (tuples) that reported an overflow get their anchor slot x4 (a chromosome-scale contig has thousands of tuples: scaling all
+// of them asked for the HBM long before x256); the per-workgroup hit / position pools are shared by all batches and grow x4 up to their clamps; a repeat that
+// finds no device memory for its larger pools ends as VM_READ_CAPACITY for THIS contig, not as a failed call that takes the other contigs with it.
 int second_round_seed(vm_ctx* c, const vm_index_view& ix, int k, const uint8_t* d_codes, int64_t L, const std::vector<vmx_anchor>& raw_asc, const std::vector<Tuple>& tuples,
                       std::vector<std::vector<vmx_anchor>>& out) {
     int64_t div = 1; if (const char* e = getenv("VMX_TEST_ASM_RESEED_DIV")) { const long long v = atoll(e); if (v >= 1) div = v; }
+    std::vector<int64_t> slot_mul(tuples.size(), 1);          // per batch; second_round_seed_once multiplies the entries of the batches that overflowed by 4
     for (int64_t mult = 1;; mult *= 4) {
-        const int rc = second_round_seed_once(c, ix, k, d_codes, L, raw_asc, tuples, out, mult, div);
+        const int rc = second_round_seed_once(c, ix, k, d_codes, L, raw_asc, tuples, out, mult, div, slot_mul);
+        if (rc == VM_ERR_OOM && mult > 1) { set_error("asm: no device memory for the larger second-round re-seeding pools of this contig"); return VM_READ_CAPACITY; }
         if (rc != VMX_RETRY_RESEED) return rc;
         if (mult >= 256 * div) { set_error("asm: a second-round re-seeding batch overflowed its device pools"); return VM_READ_CAPACITY; }
-        if (getenv("VMX_DBG_POOLS")) fprintf(stderr, "[pools] asm second-round re-seeding: a pool was too small, once more with x%lld\n", (long long)(mult * 4));
+        if (getenv("VMX_DBG_POOLS")) { int64_t nb = 0; for (int64_t m : slot_mul) nb += m > mult; fprintf(stderr, "[pools] asm second-round re-seeding: %lld of %zu batches overflowed, once more with their slots and the hit pools x%lld\n", (long long)nb, slot_mul.size(), (long long)(mult * 4)); }
     }
 }
 static int second_round_seed_once(vm_ctx* c, const vm_index_view& ix, int k, const uint8_t* d_codes, int64_t L, const std::vector<vmx_anchor>& raw_asc, const std::vector<Tuple>& tuples,
-                                  std::vector<std::vector<vmx_anchor>>& out, int64_t mult, int64_t div) {
+                                  std::vector<std::vector<vmx_anchor>>& out, int64_t mult, int64_t div, std::vector<int64_t>& slot_mul) {
     const int64_t nt = (int64_t)tuples.size();
     out.assign((size_t)nt, {});
     if (!nt) return 0;
@@ -311,7 +316,7 @@ static int second_round_seed_once(vm_ctx* c, const vm_index_view& ix, int k, con
         rst[(size_t)t] = (int32_t)u.st_read; ren[(size_t)t] = (int32_t)u.en_read;
         const int64_t span = u.en_read - u.st_read;
         span_max = std::max(span_max, span); glen_max = std::max(glen_max, u.hi - u.lo);
-        la_off[(size_t)t + 1] = la_off[(size_t)t] + std::max<int64_t>(16, 8 * mult * VMX_LA_SLOT(span) / div);
+        la_off[(size_t)t + 1] = la_off[(size_t)t] + std::max<int64_t>(16, 8 * slot_mul[(size_t)t] * VMX_LA_SLOT(span) / div);
         order[(size_t)t + 1] = (int32_t)t;
     }
     aoff[(size_t)nt] = (int64_t)guide.size();
@@ -368,8 +373,10 @@ static int second_round_seed_once(vm_ctx* c, const vm_index_view& ix, int k, con
     VMX_TRY(download(cnt.data(), B.la_cnt.p, (size_t)nt, c->stream)); VMX_TRY(download(stt.data(), B.status.p, (size_t)nt, c->stream));
     VMX_HIP(vmx_stream_sync(c));
     VMX_HIP(hipGetLastError());
+    bool again = false;
+    for (int64_t t = 0; t < nt; ++t) if (stt[(size_t)t] != 0) { slot_mul[(size_t)t] *= 4; again = true; }
+    if (again) return VMX_RETRY_RESEED;
     for (int64_t t = 0; t < nt; ++t) {
-        if (stt[(size_t)t] != 0) return VMX_RETRY_RESEED;
         out[(size_t)t].resize((size_t)cnt[(size_t)t]);
         VMX_TRY(download(out[(size_t)t].data(), B.la_sorted.as<vmx_anchor>() + la_off[(size_t)t], (size_t)cnt[(size_t)t], c->stream));
     }

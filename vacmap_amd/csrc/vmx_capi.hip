@@ -46,6 +46,36 @@ void vm_params_default(vm_params* p, int mode) {
     if (mode == VM_MODE_ASM) { p->eqx = 1; p->maxdivergence = 1.0; p->check_num = -1; }
 }
 
+// ---- counters of the row chain kernels (vmx_host.h)
+static unsigned long long* g_chain_dbg = nullptr;
+static std::mutex g_chain_dbg_m;
+static int chain_dbg_enable() {
+    std::lock_guard<std::mutex> g(g_chain_dbg_m);
+    if (g_chain_dbg) return 0;
+    unsigned long long* q = nullptr;
+    if (hipMalloc((void**)&q, 64) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    (void)hipMemset(q, 0, 64);
+    g_chain_dbg = q;
+    return 0;
+}
+unsigned long long* vmx_chain_dbg() {
+    static const bool env = [] { if (getenv("VMX_DBG_CHAIN")) (void)chain_dbg_enable(); return true; }(); (void)env;
+    return g_chain_dbg;
+}
+void vmx_chain_dbg_report(hipStream_t st) {
+    static const bool print = getenv("VMX_DBG_CHAIN") != nullptr;
+    unsigned long long* p = vmx_chain_dbg(); if (!p || !print) return;
+    unsigned long long h[8]; (void)hipStreamSynchronize(st); (void)hipMemcpy(h, p, 64, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[chain rows] global: anchors %llu scans past the window %llu insertions through HBM %llu opcount %llu | local: %llu %llu %llu %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+}
+extern "C" int vm_debug_chain_counters(int enable, unsigned long long* out8) {
+    if (enable > 0 && chain_dbg_enable() < 0) { vmx::set_error("vm_debug_chain_counters: no device memory"); return VM_ERR_OOM; }
+    unsigned long long* p = g_chain_dbg;
+    if (out8) { memset(out8, 0, 64); if (p) { VMX_HIP(hipDeviceSynchronize()); VMX_HIP(hipMemcpy(out8, p, 64, hipMemcpyDeviceToHost)); } }
+    if (enable < 0 && p) { VMX_HIP(hipDeviceSynchronize()); VMX_HIP(hipMemset(p, 0, 64)); }           // -1: read and reset
+    return VM_OK;
+}
+
 int vm_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -468,7 +498,7 @@ int vm_chain_global_batch(vm_ctx* c, const vm_params* prm, int kmersize, int64_t
         std::stable_sort(all.begin(), all.end(), [&](int32_t a, int32_t b) { return aoff[a + 1] - aoff[a] > aoff[b + 1] - aoff[b]; });
         VMX_TRY(upload(d_rl, all.data(), all.size(), c->stream));
         const int cnt = (int)all.size();
-        hipLaunchKernelGGL(k_chain_global_rows, dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, c->stream, d_sorted.as<vmx_anchor>(), d_aoff.as<int64_t>(),
+        hipLaunchKernelGGL(vmx_chain_rows_win3() ? k_chain_global_rows_w3 : k_chain_global_rows, dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, c->stream, d_sorted.as<vmx_anchor>(), d_aoff.as<int64_t>(),
                            d_rl.as<int32_t>(), cnt, c->tables, d_gap.as<double>(), prm->global_skipcost, prm->global_maxdiff,
                            1000, d_S.as<double>(), d_P.as<int32_t>(), d_SA.as<int32_t>(), d_cov.as<uint8_t>(), d_gmax.as<int64_t>(), d_opc.as<int64_t>(), rmode,
                            c->b[25].as<double>(), c->b[26].as<double>(), vmx_chain_dbg());

@@ -239,17 +239,16 @@ __global__ void k_chain_global(const vmx_anchor* anchors, const int64_t* aoff, c
 __global__ void k_chain_global_rows(const vmx_anchor* anchors, const int64_t* aoff, const int32_t* rlist, int nlist, vmx_tables tab, const double* gapcost_list,
                                     double oskipcost, int omaxdiff, int maxgap, double* S_out, int32_t* P_out, int32_t* SA_out, uint8_t* cov_pool,
                                     int64_t* gmax_out, int64_t* opcount_out, int rmode, double* FP_pool, double* PP_pool, unsigned long long* dbg);
-// VMX_DBG_CHAIN=1: eight device counters of the row kernels (anchors, scans that left the window, insertions through HBM, opcount; global / local),
-// printed by vmx_chain_dbg_report() — a tuning aid, never on by default
-static inline unsigned long long* vmx_chain_dbg() {
-    static unsigned long long* p = [] { unsigned long long* q = nullptr; if (getenv("VMX_DBG_CHAIN")) { if (hipMalloc((void**)&q, 64) != hipSuccess) q = nullptr; else (void)hipMemset(q, 0, 64); } return q; }();
-    return p;
-}
-static inline void vmx_chain_dbg_report(hipStream_t st) {
-    unsigned long long* p = vmx_chain_dbg(); if (!p) return;
-    unsigned long long h[8]; (void)hipStreamSynchronize(st); (void)hipMemcpy(h, p, 64, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[chain rows] global: anchors %llu scans past the window %llu insertions through HBM %llu opcount %llu | local: %llu %llu %llu %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
-}
+__global__ void k_chain_global_rows_w3(const vmx_anchor* anchors, const int64_t* aoff, const int32_t* rlist, int nlist, vmx_tables tab, const double* gapcost_list,
+                                       double oskipcost, int omaxdiff, int maxgap, double* S_out, int32_t* P_out, int32_t* SA_out, uint8_t* cov_pool,
+                                       int64_t* gmax_out, int64_t* opcount_out, int rmode, double* FP_pool, double* PP_pool, unsigned long long* dbg);
+// VMX_RW_WIN=3 (tests, read at every launch): the 3-entry-window TEST kernels instead of the product's 16-entry ones (k_chain_rows.hip)
+static inline bool vmx_chain_rows_win3() { const char* e = getenv("VMX_RW_WIN"); return e && atoi(e) == 3; }
+// eight device counters of the row kernels (anchors, scans that left the window, insertions through HBM, opcount; global / local): one block for the whole
+// library (vmx_capi.hip), switched on by VMX_DBG_CHAIN=1 (printed by vmx_chain_dbg_report(): a tuning aid) or by vm_debug_chain_counters(1, ...) (the GPU
+// tests assert them); never on by default
+unsigned long long* vmx_chain_dbg();
+void vmx_chain_dbg_report(hipStream_t st);
 static inline bool vmx_chain_rows_on() { static const bool on = [] { const char* e = getenv("VMX_CHAIN_ROWS"); return !e || atoi(e) != 0; }(); return on; }
 __global__ void k_chain_global_fast(const vmx_anchor* anchors, const int64_t* aoff, int n_reads, const int64_t* roff, vmx_tables tab,
                                     const double* gapcost_list, double oskipcost, int omaxdiff, int maxgap, double* S_out, int32_t* P_out, int32_t* SA_out,

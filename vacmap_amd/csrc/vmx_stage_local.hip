@@ -22,6 +22,10 @@ __global__ void k_chain_local_rows(const vmx_anchor* anchors, const int64_t* la_
                                    int want, vmx_tables tab, const double* gapcost_list, double skip_exact, double skip_mm, int maxdiff, int maxgap, int mode, double* S_pool,
                                    int32_t* P_pool, int32_t* SA_pool, double* out_score, vmx_anchor* out_chain, int32_t* out_len, int32_t* out_variant, int32_t* status,
                                    double* FP_pool, double* PP_pool, unsigned long long* dbg);
+__global__ void k_chain_local_rows_w3(const vmx_anchor* anchors, const int64_t* la_off, const int32_t* la_cnt, const int32_t* n_guides_total, const int32_t* rlist, int nlist,
+                                      int want, vmx_tables tab, const double* gapcost_list, double skip_exact, double skip_mm, int maxdiff, int maxgap, int mode, double* S_pool,
+                                      int32_t* P_pool, int32_t* SA_pool, double* out_score, vmx_anchor* out_chain, int32_t* out_len, int32_t* out_variant, int32_t* status,
+                                      double* FP_pool, double* PP_pool, unsigned long long* dbg);        // test kernel (VMX_RW_WIN=3)
 __global__ void k_chain_local(const vmx_anchor* anchors, const int64_t* la_off, const int32_t* la_cnt, const int32_t* n_guides_total,
                               const int32_t* rlist, int nlist, int lds_cap, vmx_tables tab, const double* gapcost_list, double skip_exact,
                               double skip_mm, int maxdiff, int maxgap, int mode, double* S_pool, int32_t* P_pool, int32_t* SA_pool, double* out_score,
@@ -259,7 +263,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         if (rows_kernel) {
             // one launch per variant (different code; a row whose read wants the other variant leaves at once): LC-exact and LC-mm, or `_scar` alone in mode R
             for (int want = (prm->mode == VM_MODE_R ? 2 : 0); want <= (prm->mode == VM_MODE_R ? 2 : 1); ++want)
-                hipLaunchKernelGGL(k_chain_local_rows, dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, fk.next(), L.la_sorted.as<vmx_anchor>(),
+                hipLaunchKernelGGL(vmx_chain_rows_win3() ? k_chain_local_rows_w3 : k_chain_local_rows, dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, fk.next(), L.la_sorted.as<vmx_anchor>(),
                                    L.la_off.as<int64_t>(), L.la_cnt.as<int32_t>(), L.ng_total.as<int32_t>(), L.rlist.as<int32_t>() + rl_off[q], cnt, want, c->tables,
                                    L.gap.as<double>(), skip_exact, skip_mm, prm->local_maxdiff, maxgap, prm->mode, L.S.as<double>(), L.P.as<int32_t>(), L.SA.as<int32_t>(),
                                    L.score.as<double>(), L.chain.as<vmx_anchor>(), L.chain_len.as<int32_t>(), L.variant.as<int32_t>(), L.status.as<int32_t>(),

@@ -155,25 +155,90 @@ def name_hashes(blob, off):
     return h
 
 
+def cross_rank_duplicates(hashes_per_rank, files_per_rank):
+    """{rank: name hashes to leave out of that rank's part}: of the occurrences of a name over all ranks' ranges, every one but the FIRST IN INPUT ORDER
+    (lowest input-file number, then lowest rank = lowest byte range of that file); a rank holds a name at most once (its own windows de-duplicate)."""
+    import numpy as np
+    hs = np.concatenate([np.asarray(h, dtype=np.uint64) for h in hashes_per_rank]) if hashes_per_rank else np.zeros(0, np.uint64)
+    fl = np.concatenate([np.asarray(f, dtype=np.int32) for f in files_per_rank]) if files_per_rank else np.zeros(0, np.int32)
+    rk = np.concatenate([np.full(len(h), r, np.int32) for r, h in enumerate(hashes_per_rank)]) if hashes_per_rank else np.zeros(0, np.int32)
+    order = np.lexsort((rk, fl, hs)); hs, rk = hs[order], rk[order]
+    dup = np.zeros(len(hs), bool)
+    if len(hs) > 1:
+        dup[1:] = hs[1:] == hs[:-1]
+    return {int(r): hs[dup & (rk == r)] for r in np.unique(rk[dup])}
+
+
+def _span_hashes(buf, starts, lens):
+    """name_hashes for names that lie at arbitrary places of one buffer (uint8 array): the spans are gathered into one blob first"""
+    import numpy as np
+    starts = np.asarray(starts, dtype=np.int64); lens = np.asarray(lens, dtype=np.int64)
+    off = np.zeros(len(lens) + 1, np.int64); np.cumsum(lens, out=off[1:])
+    idx = np.repeat(starts - off[:-1], lens) + np.arange(int(off[-1]), dtype=np.int64)
+    return name_hashes(buf[idx], off)
+
+
+def _filter_part(f, o, bad, block=64 << 20):
+    """copy SAM part `f` to `o` without the alignment lines whose read name hashes into `bad` (sorted uint64 array); the names of a block of
+    lines are hashed together in NumPy (one name_hashes call per LINE took minutes on a large part). Returns (hashes left out, lines left out)."""
+    import numpy as np
+    gone, gone_lines, tail = set(), 0, b''
+    while True:
+        blk = f.read(block)
+        data = tail + blk
+        if not data:
+            break
+        if blk:
+            cut = data.rfind(b'\n') + 1
+            if cut == 0:                                 # no complete line yet
+                tail = data
+                continue
+            data, tail = data[:cut], data[cut:]
+        else:
+            tail = b''
+            if not data.endswith(b'\n'):
+                data += b'\n'
+        a = np.frombuffer(data, dtype=np.uint8)
+        ends = np.flatnonzero(a == 10)
+        starts = np.concatenate([[0], ends[:-1] + 1]).astype(np.int64)
+        tabs = np.flatnonzero(a == 9)
+        ti = np.searchsorted(tabs, starts)
+        nm_end = np.where(ti < len(tabs), tabs[np.minimum(ti, max(len(tabs) - 1, 0))] if len(tabs) else ends, ends)
+        nm_end = np.minimum(nm_end, ends)
+        body = a[starts] != 64                           # '@': header line
+        h = np.zeros(len(starts), np.uint64)
+        if body.any():
+            h[body] = _span_hashes(a, starts[body], (nm_end - starts)[body])
+        out_ = body & np.isin(h, bad)
+        if out_.any():
+            gone.update(int(x) for x in np.unique(h[out_])); gone_lines += int(out_.sum())
+            keep = np.flatnonzero(~out_)
+            # runs of kept lines are written as slices
+            if len(keep):
+                brk = np.flatnonzero(np.diff(keep) != 1)
+                rs = np.concatenate([[0], brk + 1]); re_ = np.concatenate([brk, [len(keep) - 1]])
+                for x, y in zip(rs, re_):
+                    o.write(data[int(starts[keep[x]]):int(ends[keep[y]]) + 1])
+        else:
+            o.write(data)
+        if not blk:
+            break
+    return gone, gone_lines
+
+
 def _concat_parts(dst, parts, drop=None):
     """the ranks' SAM parts, in rank order, into one file (in-kernel copies; the parts are removed). drop[r]: name hashes whose lines are
-    left out of part r (a read name that also occurs in a lower rank's byte range: the reference keeps the first occurrence only) — that
-    part is then copied line by line; returns the (reads, lines) left out."""
+    left out of part r (a read name that occurs EARLIER IN THE INPUT — an earlier file, or a lower byte range of the same file — inside another
+    rank's range: the reference keeps the first occurrence only, vacmap:457-487) — that part is then copied block by block through a filter;
+    returns the (reads, lines) left out."""
     import numpy as np
     gone_reads, gone_lines = set(), 0
     with open(dst, 'wb', buffering=0) as o:             # unbuffered: sendfile on the descriptor and write() through the object must not interleave out of order
         for r, pth in enumerate(parts):
             with open(pth, 'rb') as f:
                 if drop and r in drop and len(drop[r]):
-                    bad = set(int(x) for x in drop[r])
-                    for ln in f:
-                        if not ln.startswith(b'@'):
-                            nm = ln[:ln.find(b'\t')]
-                            h = int(name_hashes(np.frombuffer(nm, dtype=np.uint8), [0, len(nm)])[0])
-                            if h in bad:
-                                gone_reads.add(h); gone_lines += 1
-                                continue
-                        o.write(ln)
+                    g, gl = _filter_part(f, o, np.sort(np.asarray(drop[r], dtype=np.uint64)))
+                    gone_reads |= set((r, x) for x in g); gone_lines += gl
                 else:
                     size = os.fstat(f.fileno()).st_size; off = 0
                     while off < size:
@@ -503,8 +568,10 @@ def main(argv=None, comm=None):
         """input records in arrival order as blobs (names, upper-cased sequences, qualities, comments), de-duplicated by name
         (vacmap:457,475,487; in range mode inside the rank's own part of the input), one window of at most win_reads reads at a time"""
         seen = set()
+        file_no = -1
         for group in args.read:
             for path in group:
+                file_no += 1
                 for ch in chunks_of(path):
                     n = len(ch['seqs_off']) - 1
                     nb, no = ch['names'].tobytes(), ch['names_off']
@@ -520,6 +587,7 @@ def main(argv=None, comm=None):
                             ch[key], ch[key + '_off'] = blob_gather(lib, ch[key], ch[key + '_off'], ix)
                     if range_mode and len(ch['names_off']) > 1:
                         rank_hashes.append(name_hashes(ch['names'], ch['names_off']))      # compared across the ranks at the end of the run
+                        rank_hash_file.append(np.full(len(ch['names_off']) - 1, file_no, np.int32))  # ... in INPUT order: (file, byte range = rank)
                     if args.Q:
                         ch['quals_off'] = np.zeros(len(ch['seqs_off']), np.int64)
                     if not args.copycomments:
@@ -528,6 +596,7 @@ def main(argv=None, comm=None):
                         yield ch
 
     rank_hashes = []
+    rank_hash_file = []
     prog = {'t0': time.time(), 't': time.time(), 'n': 0, 'next': 100000}
 
     def progress(count):
@@ -844,18 +913,18 @@ def main(argv=None, comm=None):
         # The reference drops a read name it has seen before, anywhere in the input (vacmap:457-487); a rank only sees its own byte ranges, so the
         # ranks' name hashes (8 bytes per read) travel with the counts and rank 0 leaves the later occurrences out while it joins the parts:
         # a name that also occurs in a lower rank's ranges (of any input file) goes. No cross-rank duplicate — the rule — costs one sort.
+        # Round 6: "earlier" is the INPUT's order, not the rank's — every hash travels with the number of the input file it came from; inside a file
+        # the ranks' byte ranges ascend with the rank. With two files, a name in file 1 inside rank 3's range and again in file 2 inside rank 0's keeps the
+        # file-1 record (sorted by hash, then file, then rank: every occurrence but the first goes), as the reference's single pass over the files does.
         myh = np.concatenate(rank_hashes) if rank_hashes else np.zeros(0, np.uint64)
-        allc = gather_lines((counts['reads'], counts['lines'], counts['skipped'], myh), dst=0, group=text_group)
+        myf = np.concatenate(rank_hash_file) if rank_hash_file else np.zeros(0, np.int32)
+        allc = gather_lines((counts['reads'], counts['lines'], counts['skipped'], myh, myf), dst=0, group=text_group)
         if rank == 0:
             counts['reads'], counts['lines'], counts['skipped'] = (sum(c[i] for c in allc) for i in range(3))
-            hs = np.concatenate([c[3] for c in allc]); rk = np.concatenate([np.full(len(c[3]), r, np.int32) for r, c in enumerate(allc)])
-            order = np.lexsort((rk, hs)); hs, rk = hs[order], rk[order]
-            dup = np.zeros(len(hs), bool)
-            if len(hs) > 1:
-                dup[1:] = hs[1:] == hs[:-1]                       # (sorted by hash, then rank: every occurrence but the lowest rank's)
-            drop = {r: hs[dup & (rk == r)] for r in range(1, world) if (dup & (rk == r)).any()}
+            drop = cross_rank_duplicates([c[3] for c in allc], [c[4] for c in allc])
+            n_dup = sum(len(v) for v in drop.values())
             if drop and args.parts:
-                sys.stderr.write('vacmapx: %d read names occur in more than one rank\'s part (--parts keeps the parts as written: later occurrences are NOT removed)\n' % int(dup.sum()))
+                sys.stderr.write('vacmapx: %d read names occur in more than one rank\'s part (--parts keeps the parts as written: later occurrences are NOT removed)\n' % n_dup)
             if not args.parts:
                 tj = time.time()
                 gr, gl = _concat_parts(args.o, ['%s.part%03d' % (args.o, r) for r in range(world)], drop)

@@ -127,6 +127,7 @@ class VmxLib:
         L.vm_ctx_destroy.argtypes = [vp]
         L.vm_ctx_set_inflight.argtypes = [vp, C.c_int]
         L.vm_ctx_set_blocking_sync.argtypes = [vp, C.c_int]
+        L.vm_debug_chain_counters.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
         L.vm_ctx_mem_info.argtypes = [vp, P(i64), P(i64)]
         L.vm_table.argtypes = [vp, C.c_int, P(vp)]; L.vm_table.restype = i64
         L.vm_edit_distance_batch.argtypes = [vp, i64, cp, vp, cp, vp, P(P(i64))]
@@ -194,6 +195,15 @@ class VmxLib:
 
 
 _default = None
+
+
+def chain_counters(lib, enable=0):
+    """vm_debug_chain_counters: dict of the row chain kernels' counters (enable: 1 on, 0 read, -1 read and reset)"""
+    out = (C.c_ulonglong * 8)()
+    lib.check(lib.L.vm_debug_chain_counters(int(enable), out))
+    keys = ('global_anchors', 'global_scans_past_window', 'global_insertions_through_hbm', 'global_opcount',
+            'local_anchors', 'local_scans_past_window', 'local_insertions_through_hbm', 'local_opcount')
+    return dict(zip(keys, [int(x) for x in out]))
 
 
 def load():
