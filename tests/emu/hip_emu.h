@@ -32,7 +32,7 @@
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100, hipErrorNotReady = 600, hipErrorUnknown = 999 };
 typedef void* hipStream_t;
 typedef struct hipEmuEvent { double t; }* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
@@ -191,9 +191,11 @@ template <class T> inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v,
 // host API subset
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
-enum { hipHostMallocDefault = 0, hipHostMallocPortable = 1 };
+enum { hipHostMallocDefault = 0, hipHostMallocPortable = 1, hipHostMallocMapped = 2 };
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
+inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { if (n) memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }

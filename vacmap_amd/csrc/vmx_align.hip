@@ -115,7 +115,7 @@ int vmx_launch_chain_select(vm_ctx* c, int64_t n, const int64_t* h_aoff, DevBuf&
         std::stable_sort(lists[q].begin(), lists[q].end(), [&](int32_t a, int32_t b) { return h_aoff[a + 1] - h_aoff[a] > h_aoff[b + 1] - h_aoff[b]; });
         off[q] = rl.size(); rl.insert(rl.end(), lists[q].begin(), lists[q].end());
     }
-    VMX_TRY(upload(d_list, rl.data(), rl.size(), c->stream));
+    VMX_TRY(vmx_push(c, d_list, rl.data(), rl.size()));
     vmx_fork fk(c);
     for (int q = NC - 1; q >= 0; --q) {                          // the classes with the longest walks first
         const int cnt = (int)lists[q].size(); if (!cnt) continue;
@@ -166,7 +166,7 @@ static int ext_gather_round(vm_ctx* c, vmx_batch_bufs& B, const vm_index_view& i
     (void)round_cap;                              // vmx_alloc_probs never lets the published count pass the capacity
     hipLaunchKernelGGL(k_stat_put, dim3(1), dim3(1), 0, c->stream, B.rcount.as<int32_t>(), B.statblk.as<int32_t>() + stat_slot);
     int32_t cnt = 0;
-    if (want_cnt) { VMX_TRY(download(&cnt, B.rcount.p, 1, c->stream)); VMX_HIP(vmx_stream_sync(c)); }
+    if (want_cnt) { VMX_TRY(vmx_fetch(c, &cnt, B.rcount.p, 1)); VMX_HIP(vmx_stream_sync(c)); }
     VMX_TRY(dev_scan_dev(c, B, B.tl.as<int64_t>(), B.toff.as<int64_t>(), B.rcount.as<int32_t>()));
     VMX_TRY(dev_scan_dev(c, B, B.ql.as<int64_t>(), B.qoff.as<int64_t>(), B.rcount.as<int32_t>()));
     hipLaunchKernelGGL(k_gather, dim3((unsigned)((int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(),
@@ -227,8 +227,8 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
             std::vector<int64_t> s_off((size_t)m + 1, 0); std::vector<vmx_preset> s_pre;
             for (int64_t j = 0; j < m; ++j) { s_off[(size_t)j + 1] = s_off[(size_t)j] + (h_roff[(size_t)sub[(size_t)j] + 1] - h_roff[(size_t)sub[(size_t)j]]); if (preset) s_pre.push_back(preset[sub[(size_t)j]]); }
             int src = 0;
-            if ((src = B.side_codes.reserve((size_t)s_off[(size_t)m] + 64)) < 0 || (src = upload(B.side_off, s_off.data(), (size_t)m + 1, c->stream)) < 0 ||
-                (src = upload(B.sellist, sub.data(), (size_t)m, c->stream)) < 0) { if (src == VM_ERR_OOM) break; c->ext_mul = 1; return src; }
+            if ((src = B.side_codes.reserve((size_t)s_off[(size_t)m] + 64)) < 0 || (src = vmx_push(c, B.side_off, s_off.data(), (size_t)m + 1)) < 0 ||
+                (src = vmx_push(c, B.sellist, sub.data(), (size_t)m)) < 0) { if (src == VM_ERR_OOM) break; c->ext_mul = 1; return src; }
             hipLaunchKernelGGL(k_side_codes, dim3((unsigned)std::min<int64_t>(m, (int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, d_codes, d_roff, B.sellist.as<int32_t>(), B.side_off.as<int64_t>(), (int)m,
                                B.side_codes.as<uint8_t>());
             vm_record* r2 = nullptr; int64_t n2 = 0; char* b2 = nullptr; vm_batch_stats st2; std::vector<int32_t> status2((size_t)m + 1, 0);
@@ -273,6 +273,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     st.n_reads = n; st.read_bases = total_bases;
     hipEvent_t* ev = c->ev; int nev = 0;
     c->n_syncs = 0; c->n_bandfall = 0; c->kev_set = 0; c->sync_wait_ns = 0; download_wait_ns() = 0;
+    c->mb.pend.clear(); c->mb.dn_used = 0; c->mb.big_used = 0;      // (fetches a failed call left behind must not be delivered into its dead buffers)
     c->call_t0_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));
     if (n == 0) { *recs = (vm_record*)malloc(sizeof(vm_record)); *cigar_blob = (char*)malloc(1); if (stats) *stats = st; return VM_OK; }
@@ -295,7 +296,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     VMX_TRY(B.nanc64.reserve(8 * (size_t)(n + 2))); VMX_TRY(B.aoff.reserve(8 * (size_t)(n + 2)));
     LAUNCH1D(k_i32_to_i64, n, B.seed[11].as<int32_t>(), B.nanc64.as<int64_t>(), n);
     hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, B.nanc64.as<int64_t>(), B.aoff.as<int64_t>(), n, 0);
-    VMX_TRY(download(h_aoff.data(), B.aoff.p, (size_t)n + 1, c->stream));
+    VMX_TRY(vmx_fetch(c, h_aoff.data(), B.aoff.p, (size_t)n + 1));
     VMX_HIP(vmx_stream_sync(c));
     const int64_t tot = h_aoff[n];
     st.n_anchors = tot;
@@ -314,7 +315,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
         koff[r] = kt; kt += N; soff[r] = stt; stt += (vmx_select_scratch_bytes(m) + 15) & ~(int64_t)15;
     }
     koff[n] = kt; soff[n] = stt;
-    VMX_TRY(B.keys.reserve(8 * (size_t)(kt + 1))); VMX_TRY(upload(B.koff, koff.data(), (size_t)n + 1, c->stream));
+    VMX_TRY(B.keys.reserve(8 * (size_t)(kt + 1))); VMX_TRY(vmx_push(c, B.koff, koff.data(), (size_t)n + 1));
     VMX_TRY(B.sorted.reserve(sizeof(vmx_anchor) * (size_t)(tot + 1))); VMX_TRY(B.flip.reserve(4 * (size_t)(n + 1)));
     hipLaunchKernelGGL(k_flip_sort, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, B.rows.as<int64_t>(), B.aoff.as<int64_t>(), B.lens.as<int64_t>(),
                        (int)n, B.keys.as<uint64_t>(), B.koff.as<int64_t>(), B.sorted.as<vmx_anchor>(), B.flip.as<int32_t>());
@@ -325,7 +326,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
         if (prm->global_maxdiff > 62) { set_error("global_maxdiff > 62 unsupported"); return VM_ERR_UNSUPPORTED; }
         std::vector<double> gap(64, 0.0);
         for (int g = 1; g <= prm->global_maxdiff; ++g) gap[g] = (0.01 * ix.k * g + 0.5 * T.log2int[g]);
-        VMX_TRY(upload(B.gap, gap.data(), 64, c->stream));
+        VMX_TRY(vmx_push(c, B.gap, gap.data(), 64));
     }
     if (rmode == 1) { VMX_TRY(B.fp.reserve(8 * (size_t)(tot + 1))); VMX_TRY(B.pp.reserve(8 * (size_t)(tot + 1))); }   // fixed_penatly / pre_penatly of mode R's chain
     // LDS buckets by anchor count (25 B per anchor), reads longest-first inside a bucket, one workgroup per read (see vmx_local_stage)
@@ -351,7 +352,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
             std::stable_sort(lists[q].begin(), lists[q].end(), [&](int32_t a, int32_t b) { return h_aoff[a + 1] - h_aoff[a] > h_aoff[b + 1] - h_aoff[b]; });
             rl_off[q] = (int64_t)rl.size(); rl.insert(rl.end(), lists[q].begin(), lists[q].end());
         }
-        VMX_TRY(upload(B.rl, rl.data(), rl.size(), c->stream));
+        VMX_TRY(vmx_push(c, B.rl, rl.data(), rl.size()));
         VMX_HIP(hipMemsetAsync(B.gmax.p, 0xff, 8 * (size_t)n, c->stream));
         { static const int64_t kUnsupported = -4; for (int64_t r : asm_long) VMX_HIP(hipMemcpyAsync(B.gmax.as<int64_t>() + r, &kUnsupported, 8, hipMemcpyHostToDevice, c->stream)); }
 #ifndef VMX_EMU
@@ -362,7 +363,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
             int cnt = (int)lists[q].size(); if (!cnt) continue;
             int cap = q < NB ? caps[q] : 0; size_t shmem = (size_t)cap * VMX_GC_BYTES_PER_ANCHOR + 64;
             if (rows_kernel) {
-                hipLaunchKernelGGL(vmx_chain_rows_win3() ? k_chain_global_rows_w3 : k_chain_global_rows, dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, fk.next(), B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(),
+                hipLaunchKernelGGL((vmx_chain_rows_win3() ? k_chain_global_rows_w3 : k_chain_global_rows), dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, fk.next(), B.sorted.as<vmx_anchor>(), B.aoff.as<int64_t>(),
                                    B.rl.as<int32_t>() + rl_off[q], cnt, c->tables, B.gap.as<double>(), prm->global_skipcost, prm->global_maxdiff, 1000, B.S.as<double>(),
                                    B.P.as<int32_t>(), B.SA.as<int32_t>(), B.cov.as<uint8_t>(), B.gmax.as<int64_t>(), B.opc.as<int64_t>(), rmode, B.fp.as<double>(), B.pp.as<double>(),
                                    vmx_chain_dbg());
@@ -381,7 +382,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
                            B.gap.as<double>(), prm->global_skipcost, prm->global_maxdiff, 1000, B.S.as<double>(), B.P.as<int32_t>(), B.SA.as<int32_t>(), B.cov.as<uint8_t>(),
                            B.si.as<int32_t>(), B.tg.as<int64_t>(), B.cntp.as<int32_t>(), B.gmax.as<int64_t>(), (int32_t*)nullptr, rmode, B.fp.as<double>(), B.pp.as<double>());
     }
-    VMX_TRY(B.scr.reserve((size_t)stt + 64)); VMX_TRY(upload(B.soff, soff.data(), (size_t)n + 1, c->stream));
+    VMX_TRY(B.scr.reserve((size_t)stt + 64)); VMX_TRY(vmx_push(c, B.soff, soff.data(), (size_t)n + 1));
     VMX_TRY(B.res.reserve(16 * (size_t)(n + 2) + 64));
     d_gscore = B.res.as<double>(); d_mapq = (int32_t*)(d_gscore + n + 1); d_np = d_mapq + n + 1;
     VMX_TRY(B.plen.reserve(4 * (size_t)(tot + 1))); VMX_TRY(B.prow.reserve(sizeof(vmx_anchor) * (size_t)(tot + 1)));
@@ -421,10 +422,10 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
         VMX_HIP(hipMemcpyAsync(d_gscore, gs.data(), 8 * (size_t)n, hipMemcpyHostToDevice, c->stream)); VMX_HIP(hipMemcpyAsync(d_mapq, mq.data(), 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
         VMX_HIP(hipMemcpyAsync(d_np, one.data(), 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
         VMX_TRY(B.gmax.reserve(8 * (size_t)(n + 1))); VMX_HIP(hipMemsetAsync(B.gmax.p, 0, 8 * (size_t)n, c->stream));
-        VMX_TRY(upload(L.la_off, L.h_la_off.data(), (size_t)n + 1, c->stream));
-        VMX_TRY(upload(L.chain, chains.data(), chains.size(), c->stream));
-        VMX_TRY(upload(L.chain_len, len32.data(), (size_t)n, c->stream));
-        VMX_TRY(upload(L.status, zero.data(), (size_t)n, c->stream));
+        VMX_TRY(vmx_push(c, L.la_off, L.h_la_off.data(), (size_t)n + 1));
+        VMX_TRY(vmx_push(c, L.chain, chains.data(), chains.size()));
+        VMX_TRY(vmx_push(c, L.chain_len, len32.data(), (size_t)n));
+        VMX_TRY(vmx_push(c, L.status, zero.data(), (size_t)n));
         VMX_HIP(vmx_stream_sync(c));                              // the host vectors above are on their way
         for (int e = 0; e < 3; ++e) VMX_HIP(hipEventRecord(ev[nev++], c->stream));
         return 0;
@@ -443,8 +444,8 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
         bloboff[r + 1] = bloboff[r] + (cl > 0 ? ((pool(4, 3 * len + 64 * (cl / 2 + 2) + 56) + 7) & ~(int64_t)7) : 0);
     }
     const int64_t cA = coff3[n], cS = soff2[n], cB = bloboff[n];
-    VMX_TRY(B.er.reserve(sizeof(vmx_ext_read) * (size_t)(n + 1))); VMX_TRY(upload(B.coff3, coff3.data(), (size_t)n + 1, c->stream)); VMX_TRY(upload(B.soff2, soff2.data(), (size_t)n + 1, c->stream));
-    VMX_TRY(upload(B.bloboff, bloboff.data(), (size_t)n + 1, c->stream));
+    VMX_TRY(B.er.reserve(sizeof(vmx_ext_read) * (size_t)(n + 1))); VMX_TRY(vmx_push(c, B.coff3, coff3.data(), (size_t)n + 1)); VMX_TRY(vmx_push(c, B.soff2, soff2.data(), (size_t)n + 1));
+    VMX_TRY(vmx_push(c, B.bloboff, bloboff.data(), (size_t)n + 1));
     VMX_TRY(B.segA.reserve(sizeof(vmx_anchor) * (size_t)(cA + 1))); VMX_TRY(B.segA_s.reserve(sizeof(vmx_anchor) * (size_t)(cA + 1)));
     VMX_TRY(B.st.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.en.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.st_s.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.en_s.reserve(4 * (size_t)(cS + 1)));
     VMX_TRY(B.segprob.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.dup.reserve(4 * (size_t)(cS + 1)));
@@ -533,7 +534,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
         int64_t plan[8 + 2 * (VMX_MAX_CHUNKS + 1)];
         hipLaunchKernelGGL(k_tb_plan, dim3(1), dim3(1), 0, c->stream, B.dpoff[0].as<int64_t>(), B.dpoff[1].as<int64_t>(), B.dpoff[2].as<int64_t>(), B.dpoff[3].as<int64_t>(),
                            B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.rcount.as<int32_t>(), tb_chunk, B.statblk.as<int64_t>() + 64);
-        VMX_TRY(download(plan, B.statblk.as<int64_t>() + 64, sizeof(plan) / 8, c->stream));
+        VMX_TRY(vmx_fetch(c, plan, B.statblk.as<int64_t>() + 64, sizeof(plan) / 8));
         VMX_HIP(vmx_stream_sync(c));
         const int cnt = (int)plan[0];
         int64_t totals[4] = {plan[1], plan[2], plan[3], plan[4]}, tq[2] = {plan[5], plan[6]};
@@ -555,7 +556,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
             unsigned long long* d_redo_bytes = (unsigned long long*)(d_range + 16);
             int32_t* d_redo_list = B.order.as<int32_t>() + round_cap + 32; int32_t* d_redo_cnt = d_range + 12;     // problems whose band was not proven
             std::vector<int32_t> csz; for (size_t q = 0; q + 1 < cuts.size(); ++q) csz.push_back(cuts[q + 1] - cuts[q]);
-            VMX_TRY(upload(B.chunkn, csz.data(), csz.size(), c->stream));
+            VMX_TRY(vmx_push(c, B.chunkn, csz.data(), csz.size()));
             const int ad_pct = vmx_ad_pct_env(prm->mode);
             int fill_waves = 16;                                  // waves per CU of the fill kernel (tuning knob: VMX_FILL_WAVES)
             if (const char* e = getenv("VMX_FILL_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 32) fill_waves = v; }
@@ -577,7 +578,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
                 // sizing sync #4: full-matrix traceback space of the problems the first launch queued for the second one (a few per cent of them)
                 unsigned long long redo_bytes = 0; int32_t n_redo = 0;
                 int32_t qr[20];                                   // the queue block holds both numbers: one copy
-                VMX_TRY(download(qr, d_range, 20, c->stream));
+                VMX_TRY(vmx_fetch(c, qr, d_range, 20));
                 VMX_HIP(vmx_stream_sync(c));
                 n_redo = qr[12]; memcpy(&redo_bytes, &qr[16], 8);
                 VMX_TRY(B.tbredo.reserve((size_t)redo_bytes + 64));
@@ -632,7 +633,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
             // the exact tier is hardly ever needed (0 problems per step on the bench workload), and its wide workgroups wait for room on a
             // GPU the other batches keep full — an empty launch cost more than this 4-byte read-back does: launch only when something is left
             int32_t h_nfull = 0;
-            VMX_TRY(download(&h_nfull, d_nfull, 1, c->stream)); VMX_HIP(vmx_stream_sync(c));
+            VMX_TRY(vmx_fetch(c, &h_nfull, d_nfull, 1)); VMX_HIP(vmx_stream_sync(c));
             if (h_nfull > 0)
             for (int which = 0; which < 2; ++which)
                 hipLaunchKernelGGL(k_edit_distance, dim3((unsigned)std::min<int64_t>(cnt, ed_wgs * (which == 0 ? 1 : 2))), dim3(which == 0 ? 64 * VMX_ED_WAVES : 256), 0, c->stream,
@@ -682,9 +683,9 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     // every error return below hands the caller NULL outputs (callers raise without calling vm_free: ADVICE r3)
     struct OutGuard { vm_record** r; char** b; bool keep = false; ~OutGuard() { if (!keep) { free(*r); free(*b); *r = nullptr; *b = nullptr; } } } out_guard{recs, cigar_blob};
     if (!*recs || !*cigar_blob) { set_error("out of host memory"); return VM_ERR_OOM; }
-    VMX_TRY(download(fin, B.statblk.as<int64_t>() + 32, 14, c->stream));          // record / blob totals, overflow flag, tier counters, per-round problem counts: one copy
-    VMX_TRY(download(er.data(), B.er.p, (size_t)n, c->stream)); VMX_TRY(download(h_gmax.data(), B.gmax.p, (size_t)n, c->stream));
-    VMX_TRY(download(*recs, B.totals.p, (size_t)g_nr, c->stream)); VMX_TRY(download(*cigar_blob, B.dupd.p, (size_t)g_nb, c->stream));
+    VMX_TRY(vmx_fetch(c, fin, B.statblk.as<int64_t>() + 32, 14));          // record / blob totals, overflow flag, tier counters, per-round problem counts: one copy
+    VMX_TRY(vmx_fetch(c, er.data(), B.er.p, (size_t)n)); VMX_TRY(vmx_fetch(c, h_gmax.data(), B.gmax.p, (size_t)n));
+    VMX_TRY(vmx_fetch(c, *recs, B.totals.p, (size_t)g_nr)); VMX_TRY(vmx_fetch(c, *cigar_blob, B.dupd.p, (size_t)g_nb));
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));
     VMX_HIP(vmx_stream_sync(c));
     VMX_HIP(hipGetLastError());
@@ -695,9 +696,9 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     if (oflow) { set_error("extend stage: a per-batch work pool overflowed"); return VM_ERR_OOM; }
     if (nr > g_nr || nb > g_nb) {                                 // the guess was short: fetch the tails
         if (nr > g_nr) { vm_record* p2 = (vm_record*)realloc(*recs, sizeof(vm_record) * (size_t)nr); if (!p2) { set_error("out of host memory"); return VM_ERR_OOM; } *recs = p2;
-                         VMX_TRY(download(*recs + g_nr, B.totals.as<vm_record>() + g_nr, (size_t)(nr - g_nr), c->stream)); }
+                         VMX_TRY(vmx_fetch(c, *recs + g_nr, B.totals.as<vm_record>() + g_nr, (size_t)(nr - g_nr))); }
         if (nb > g_nb) { char* p2 = (char*)realloc(*cigar_blob, (size_t)nb); if (!p2) { set_error("out of host memory"); return VM_ERR_OOM; } *cigar_blob = p2;
-                         VMX_TRY(download(*cigar_blob + g_nb, B.dupd.as<char>() + g_nb, (size_t)(nb - g_nb), c->stream)); }
+                         VMX_TRY(vmx_fetch(c, *cigar_blob + g_nb, B.dupd.as<char>() + g_nb, (size_t)(nb - g_nb))); }
         VMX_HIP(vmx_stream_sync(c));
     }
     if (n > 0 && total_bases > 0) { c->res_rec_per_read = std::max(c->res_rec_per_read, (double)nr / (double)n); c->res_blob_per_base = std::max(c->res_blob_per_base, (double)nb / (double)total_bases); }
@@ -848,7 +849,7 @@ int vm_align_resident(vm_ctx* c, const vm_index* mi, const vm_params* prm, const
     auto run_one = [&](int64_t a, int64_t b, vm_record** r, int64_t* nr, char** cb, vm_batch_stats* st) -> int {
         std::vector<int64_t> h((size_t)(b - a) + 1);
         for (int64_t i = a; i <= b; ++i) h[(size_t)(i - a)] = R->h_off[(size_t)i] - R->h_off[(size_t)a];
-        VMX_TRY(upload(B.off, h.data(), h.size(), c->stream));
+        VMX_TRY(vmx_push(c, B.off, h.data(), h.size()));
         return align_device(c, mi, prm, b - a, R->codes.as<uint8_t>() + R->h_off[(size_t)a], B.off.as<int64_t>(), h, r, nr, cb, status_per_read ? status_per_read + a : nullptr, st);
     };
     return align_in_sub_batches(R->n, R->h_off.data(), vmx_pass_bases(), run_one, recs, n_recs, cigar_blob, stats);
@@ -882,7 +883,7 @@ static int align_batch_one(vm_ctx* c, const vm_index* mi, const vm_params* prm, 
     const int64_t base = offsets[0], tot = offsets[n] - base;
     std::vector<int64_t> h_off((size_t)n + 1);
     for (int64_t i = 0; i <= n; ++i) h_off[(size_t)i] = offsets[i] - base;
-    VMX_TRY(upload(B.raw, seqs + base, (size_t)tot, c->stream)); VMX_TRY(B.codes.reserve((size_t)tot + 64)); VMX_TRY(upload(B.off, h_off.data(), (size_t)n + 1, c->stream));
+    VMX_TRY(vmx_push(c, B.raw, seqs + base, (size_t)tot)); VMX_TRY(B.codes.reserve((size_t)tot + 64)); VMX_TRY(vmx_push(c, B.off, h_off.data(), (size_t)n + 1));
     if (tot) LAUNCH1D(k_encode, tot, B.raw.as<char>(), B.codes.as<uint8_t>(), tot);
     return align_device(c, mi, prm, n, B.codes.as<uint8_t>(), B.off.as<int64_t>(), h_off, recs, n_recs, cigar_blob, status_per_read, stats);
 }

@@ -1,6 +1,7 @@
 // vmx_capi.hip — C-ABI entry points of libvacmapx.so (include/vacmapx.h): context, tables, DP and chain stage entries.
 // Everything that computes runs the HIP kernels of this directory on the context's stream; there is no CPU path.
 #include "vmx_host.h"
+#include <time.h>
 #include "vmx_select.h"
 #include "vmx_stage.h"
 #include <algorithm>
@@ -46,6 +47,78 @@ void vm_params_default(vm_params* p, int mode) {
     if (mode == VM_MODE_ASM) { p->eqx = 1; p->maxdivergence = 1.0; p->check_num = -1; }
 }
 
+}  // extern "C"
+// ---- the mailbox (vmx_host.h)
+__global__ void k_signal(unsigned long long* word, unsigned long long v) {
+#ifdef VMX_EMU
+    *word = v;
+#else
+    __hip_atomic_store(word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
+static int mailbox_create(vm_ctx* c) {
+    vmx_mailbox& m = c->mb;
+    const char* mode = getenv("VMX_WAIT_MODE");
+    if (mode && !strcmp(mode, "spin")) { m.on = false; return 0; }
+    if (const char* e = getenv("VMX_POLL_US")) { const long long v = atoll(e); if (v >= 1 && v <= 100000) m.poll_ns = v * 1000; }
+    const size_t up = (size_t)8 << 20, dn = (size_t)8 << 20, tot = 4096 + up + dn;
+    void* hp = nullptr;
+    if (hipHostMalloc(&hp, tot, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); m.on = false; return 0; }       // no page-locked memory: the legacy waits
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(hp); m.on = false; return 0; }
+    memset(hp, 0, 4096);
+    m.h = (char*)hp; m.d = (char*)dp; m.up_off = 4096; m.up_cap = up; m.dn_off = 4096 + up; m.dn_cap = dn; m.on = true;
+    return 0;
+}
+static void mailbox_destroy(vm_ctx* c) {
+    vmx_mailbox& m = c->mb;
+    if (m.h) (void)hipHostFree(m.h);
+    if (m.big) (void)hipHostFree(m.big);
+    m = vmx_mailbox();
+}
+int vmx_mailbox_wait(vm_ctx* c) {
+    vmx_mailbox& m = c->mb;
+    const unsigned long long want = ++m.seq;
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, c->stream, (unsigned long long*)m.d, want);
+    volatile unsigned long long* w = (volatile unsigned long long*)m.h;
+    struct timespec ts; ts.tv_sec = 0; ts.tv_nsec = (long)m.poll_ns;
+    long long slept = 0, next_query = 500000000LL;
+    while (__atomic_load_n(w, __ATOMIC_ACQUIRE) < want) {
+        nanosleep(&ts, nullptr);
+        slept += m.poll_ns;
+        if (slept >= next_query) {                                    // a stream that died (a faulting kernel) never delivers the word
+            next_query += 500000000LL;
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q != hipSuccess && q != hipErrorNotReady) { m.pend.clear(); m.dn_used = 0; m.big_used = 0; m.up_used = 0; return vmx::hip_fail(q, "hipStreamQuery (mailbox wait)", __FILE__, __LINE__); }
+        }
+    }
+    for (const vmx_mailbox::Pending& p : m.pend) memcpy(p.dst, p.src, p.bytes);
+    m.pend.clear(); m.dn_used = 0; m.big_used = 0; m.up_used = 0;
+    return 0;
+}
+int vmx_fetch_bytes(vm_ctx* c, void* host, const void* dev, size_t bytes) {
+    vmx_mailbox& m = c->mb;
+    char* land = nullptr;
+    const size_t at = (m.dn_used + 63) & ~(size_t)63;
+    if (at + bytes <= m.dn_cap) { land = m.h + m.dn_off + at; m.dn_used = at + bytes; }
+    else {
+        const size_t bat = (m.big_used + 63) & ~(size_t)63;
+        if (bat + bytes > m.big_cap && m.big_used == 0) {             // grow the landing block while nothing is on its way into it
+            if (m.big) { (void)hipHostFree(m.big); m.big = nullptr; m.big_cap = 0; }
+            const size_t want = bytes + bytes / 2 + ((size_t)4 << 20);
+            void* hp = nullptr;
+            if (hipHostMalloc(&hp, want, hipHostMallocDefault) == hipSuccess) { m.big = (char*)hp; m.big_cap = want; } else (void)hipGetLastError();
+        }
+        if (bat + bytes <= m.big_cap) { land = m.big + bat; m.big_used = bat + bytes; }
+    }
+    if (!land) {                                                      // no page-locked room: the plain copy (waits inside the call)
+        VMX_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        return 0;
+    }
+    VMX_HIP(hipMemcpyAsync(land, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    m.pend.push_back(vmx_mailbox::Pending{host, land, bytes});
+    return 0;
+}
 // ---- counters of the row chain kernels (vmx_host.h)
 static unsigned long long* g_chain_dbg = nullptr;
 static std::mutex g_chain_dbg_m;
@@ -68,7 +141,8 @@ void vmx_chain_dbg_report(hipStream_t st) {
     unsigned long long h[8]; (void)hipStreamSynchronize(st); (void)hipMemcpy(h, p, 64, hipMemcpyDeviceToHost);
     fprintf(stderr, "[chain rows] global: anchors %llu scans past the window %llu insertions through HBM %llu opcount %llu | local: %llu %llu %llu %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
 }
-extern "C" int vm_debug_chain_counters(int enable, unsigned long long* out8) {
+extern "C" {
+int vm_debug_chain_counters(int enable, unsigned long long* out8) {
     if (enable > 0 && chain_dbg_enable() < 0) { vmx::set_error("vm_debug_chain_counters: no device memory"); return VM_ERR_OOM; }
     unsigned long long* p = g_chain_dbg;
     if (out8) { memset(out8, 0, 64); if (p) { VMX_HIP(hipDeviceSynchronize()); VMX_HIP(hipMemcpy(out8, p, 64, hipMemcpyDeviceToHost)); } }
@@ -102,6 +176,7 @@ int vm_ctx_create(int device_id, vm_ctx** out) {
     for (int i = 0; i < 4; ++i) (void)hipEventCreate(&c->kev[i]);
     for (int i = 0; i < 4; ++i) { if (prio) (void)hipStreamCreateWithPriority(&c->aux[i], hipStreamDefault, prio_greatest); else (void)hipStreamCreate(&c->aux[i]); (void)hipEventCreate(&c->join_ev[i]); }
     (void)hipEventCreate(&c->fork_ev);
+    (void)mailbox_create(c);
     // cost tables -> one device blob
     const HostTables& T = host_tables();
     size_t o_extra = 0, o_rh = o_extra + T.extra.size() * 4, o_rr = o_rh + 400, o_lr = o_rr + 400;
@@ -156,6 +231,7 @@ void vm_ctx_destroy(vm_ctx* c) {
     if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
     if (c->low) { (void)hipStreamSynchronize(c->low); (void)hipStreamDestroy(c->low); (void)hipEventDestroy(c->low_ev[0]); (void)hipEventDestroy(c->low_ev[1]); }
     (void)hipStreamDestroy(c->stream);
+    mailbox_destroy(c);
     delete c;
 }
 
@@ -181,13 +257,9 @@ int vm_ctx_mem_info(vm_ctx* c, int64_t* free_bytes, int64_t* total_bytes) {
 
 int vm_ctx_set_blocking_sync(vm_ctx* c, int on) {
     if (!c) { set_error("no context"); return VM_ERR_NO_CTX; }
-#ifndef VMX_EMU
-    VMX_HIP(hipSetDevice(c->device));
-    if (on && !c->sync_ev) VMX_HIP(hipEventCreateWithFlags(&c->sync_ev, hipEventBlockingSync | hipEventDisableTiming));
-    if (!on && c->sync_ev) { (void)hipEventDestroy(c->sync_ev); c->sync_ev = nullptr; }
-#else
-    (void)on;
-#endif
+    // round 6: sleeping waits are the default (the mailbox of vmx_host.h); on == 0 switches this context to the legacy spinning waits (A/B runs)
+    if (on && !c->mb.h) { VMX_HIP(hipSetDevice(c->device)); (void)mailbox_create(c); }
+    c->mb.on = on != 0 && c->mb.h != nullptr;
     return VM_OK;
 }
 
@@ -498,7 +570,7 @@ int vm_chain_global_batch(vm_ctx* c, const vm_params* prm, int kmersize, int64_t
         std::stable_sort(all.begin(), all.end(), [&](int32_t a, int32_t b) { return aoff[a + 1] - aoff[a] > aoff[b + 1] - aoff[b]; });
         VMX_TRY(upload(d_rl, all.data(), all.size(), c->stream));
         const int cnt = (int)all.size();
-        hipLaunchKernelGGL(vmx_chain_rows_win3() ? k_chain_global_rows_w3 : k_chain_global_rows, dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, c->stream, d_sorted.as<vmx_anchor>(), d_aoff.as<int64_t>(),
+        hipLaunchKernelGGL((vmx_chain_rows_win3() ? k_chain_global_rows_w3 : k_chain_global_rows), dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, c->stream, d_sorted.as<vmx_anchor>(), d_aoff.as<int64_t>(),
                            d_rl.as<int32_t>(), cnt, c->tables, d_gap.as<double>(), prm->global_skipcost, prm->global_maxdiff,
                            1000, d_S.as<double>(), d_P.as<int32_t>(), d_SA.as<int32_t>(), d_cov.as<uint8_t>(), d_gmax.as<int64_t>(), d_opc.as<int64_t>(), rmode,
                            c->b[25].as<double>(), c->b[26].as<double>(), vmx_chain_dbg());

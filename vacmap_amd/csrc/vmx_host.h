@@ -107,6 +107,30 @@ template <class T> int download(T* host, const void* dev, size_t n, hipStream_t 
 
 }  // namespace vmx
 
+// ---- the context's MAILBOX (round 6): how the host thread of a batch waits and exchanges its small data with the device WITHOUT a HIP wait call.
+// Measured in round 5: hipStreamSynchronize, a blocking event's hipEventSynchronize and the runtime's copies to / from pageable memory all SPIN on this
+// runtime — one busy core per batch in flight (5.9 cores for six contexts), 47-66 spinning cores for eight ranks. The mailbox is one page-locked,
+// device-mapped host block per context:
+//   * a sequence word. vmx_stream_sync() launches k_signal(word, ++seq) on the stream and polls the word with nanosleep between looks: the thread is
+//     ASLEEP while the GPU works (VMX_POLL_US, default 40 microseconds between looks; hipStreamQuery twice a second to notice a dead stream);
+//   * an upload ring: vmx_push() copies a small host vector into the ring and queues an asynchronous copy from there (page-locked source: the call
+//     returns at once and the source vector may die); the ring restarts after every completed wait (everything queued before it has been consumed);
+//   * a download area: vmx_fetch() queues an asynchronous copy into the area (page-locked destination: no wait inside the call) and notes where the bytes
+//     have to go; the next completed wait copies them there. Large results (records, CIGAR text: tens of MB per batch) land in a second block that grows.
+// VMX_WAIT_MODE=spin (or vm_ctx_set_blocking_sync(ctx, 0)) keeps hipStreamSynchronize and pageable copies for A/B runs.
+struct vmx_mailbox {
+    char* h = nullptr; char* d = nullptr;                 // the block as the host / the device address it
+    size_t up_off = 0, up_cap = 0, up_used = 0;           // upload ring
+    size_t dn_off = 0, dn_cap = 0, dn_used = 0;           // download area
+    char* big = nullptr; size_t big_cap = 0, big_used = 0; // page-locked landing block of the large results (grows)
+    unsigned long long seq = 0;
+    struct Pending { void* dst; const char* src; size_t bytes; };
+    std::vector<Pending> pend;
+    bool on = false;                                       // false: legacy waits (spinning)
+    long long poll_ns = 40000;
+};
+__global__ void k_signal(unsigned long long* word, unsigned long long v);
+
 enum { VMX_NBUF = 64 };
 struct vm_ctx {
     int device = 0;
@@ -116,7 +140,8 @@ struct vm_ctx {
     vmx::DevBuf b[VMX_NBUF];     // scratch buffers reused by the entry points (grow-only)
     int num_cu = 256;
     int inflight = 1;                            // contexts sharing the GPU (vm_ctx_set_inflight)
-    hipEvent_t sync_ev = nullptr;                // blocking-sync event (vm_ctx_set_blocking_sync): the host thread sleeps in its waits instead of spinning
+    hipEvent_t sync_ev = nullptr;                // (legacy, unused since round 6: a blocking event's wait spins on this runtime)
+    vmx_mailbox mb;                              // sleeping waits + page-locked exchange of the small data (above)
     hipEvent_t ev[24];
     hipEvent_t gev[48];                          // gap-fill chunk events: [redo][chunk 0..7][before fill, after fill, after trace]
     int n_gev[2] = {0, 0};                        // chunks recorded by the last batch per pass
@@ -151,20 +176,47 @@ struct vmx_lowprio {
     void join() { if (on) { (void)hipEventRecord(c->low_ev[1], c->low); (void)hipStreamWaitEvent(c->stream, c->low_ev[1], 0); on = false; } }
 };
 
-// wait for the context's main stream. Default: hipStreamSynchronize (the runtime spins: lowest latency, one busy core per waiting thread).
-// With vm_ctx_set_blocking_sync the thread sleeps on an interrupt instead — for callers whose other threads need the cores (the driver's
-// SAM emitters under a CPU quota: spinning waiters push the process over its quota and the whole process, aligners included, is throttled).
+// wait for the context's main stream (and finish the queued vmx_fetch copies). Default since round 6: the mailbox's sleeping wait (above); legacy:
+// hipStreamSynchronize (the runtime spins: one busy core per waiting thread).
+int vmx_mailbox_wait(vm_ctx* c);                 // vmx_capi.hip
 static inline hipError_t vmx_stream_sync(vm_ctx* c) {
     ++c->n_syncs;
     const auto t0 = std::chrono::steady_clock::now();            // (time spent waiting: ms_stage[14] of the batch; the rest of the call's wall time is host work with the stream empty)
-    hipError_t e;
-#ifndef VMX_EMU
-    if (c->sync_ev) { e = hipEventRecord(c->sync_ev, c->stream); if (e == hipSuccess) e = hipEventSynchronize(c->sync_ev); }
-    else
-#endif
-    e = hipStreamSynchronize(c->stream);
+    hipError_t e = hipSuccess;
+    if (c->mb.on) { if (vmx_mailbox_wait(c) < 0) e = hipErrorUnknown; }
+    else e = hipStreamSynchronize(c->stream);
     c->sync_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     return e;
+}
+// small host vector -> device buffer through the upload ring (asynchronous; `host` may be reused at once). Falls back to a plain copy when the ring is full / off.
+template <class T> int vmx_push(vm_ctx* c, vmx::DevBuf& b, const T* host, size_t n, int line = __builtin_LINE(), const char* file = __builtin_FILE()) {
+    const size_t bytes = sizeof(T) * n;
+    vmx_mailbox& m = c->mb;
+    const size_t at = (m.up_used + 63) & ~(size_t)63;
+    if (!m.on || !n || at + bytes > m.up_cap) return vmx::upload(b, host, n, c->stream, line, file);
+    VMX_TRY(b.reserve(bytes));
+    memcpy(m.h + m.up_off + at, host, bytes); m.up_used = at + bytes;
+    VMX_HIP(hipMemcpyAsync(b.p, m.h + m.up_off + at, bytes, hipMemcpyHostToDevice, c->stream)); vmx::copy_census().add(file, line, bytes);
+    return 0;
+}
+// the same into a raw device address
+template <class T> int vmx_push_to(vm_ctx* c, void* dev, const T* host, size_t n) {
+    const size_t bytes = sizeof(T) * n;
+    vmx_mailbox& m = c->mb;
+    const size_t at = (m.up_used + 63) & ~(size_t)63;
+    if (!n) return 0;
+    if (!m.on || at + bytes > m.up_cap) { VMX_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream)); return 0; }
+    memcpy(m.h + m.up_off + at, host, bytes); m.up_used = at + bytes;
+    VMX_HIP(hipMemcpyAsync(dev, m.h + m.up_off + at, bytes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+// device -> host, delivered by the NEXT vmx_stream_sync(c) (the caller must not look at `host` before). Falls back to the plain (waiting) copy when off.
+int vmx_fetch_bytes(vm_ctx* c, void* host, const void* dev, size_t bytes);      // vmx_capi.hip
+template <class T> int vmx_fetch(vm_ctx* c, T* host, const void* dev, size_t n, int line = __builtin_LINE(), const char* file = __builtin_FILE()) {
+    if (!n) return 0;
+    if (!c->mb.on) return vmx::download(host, dev, n, c->stream, line, file);
+    vmx::copy_census().add(file, -line, sizeof(T) * n);
+    return vmx_fetch_bytes(c, (void*)host, dev, sizeof(T) * n);
 }
 
 // fork/join of independent launches over the context's side streams (all ordered after / before the main stream)

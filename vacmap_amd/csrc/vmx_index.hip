@@ -637,9 +637,9 @@ int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, in
                        mst.as<uint32_t>(), mcn.as<uint32_t>(), mho.as<uint32_t>(), nh.as<int64_t>());
     hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(256), 0, c->stream, nh.as<int64_t>(), koff.as<int64_t>(), n, 1);
     h_koff.resize((size_t)n + 1); h_nhits.resize((size_t)n);
-    VMX_TRY(download(h_koff.data(), koff.p, (size_t)n + 1, c->stream)); VMX_TRY(download(h_nhits.data(), nh.p, (size_t)n, c->stream));
+    VMX_TRY(vmx_fetch(c, h_koff.data(), koff.p, (size_t)n + 1)); VMX_TRY(vmx_fetch(c, h_nhits.data(), nh.p, (size_t)n));
     std::vector<int32_t> h_mzc((size_t)n);
-    VMX_TRY(download(h_mzc.data(), mzc.p, (size_t)n, c->stream));
+    VMX_TRY(vmx_fetch(c, h_mzc.data(), mzc.p, (size_t)n));
     VMX_HIP(vmx_stream_sync(c));   // sizing sync #1: total (power-of-two padded) hits of the batch
     c->last_n_minimizers = 0; for (int64_t r = 0; r < n; ++r) c->last_n_minimizers += h_mzc[r];
     const int64_t ktot = h_koff[n];
@@ -669,7 +669,7 @@ int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int mid_occ, in
         std::vector<int32_t> rl(small); rl.insert(rl.end(), big.begin(), big.end());
         const size_t decl_at = rl.size();
         rl.resize(decl_at + 2 * (big.size() + 1), 0);
-        VMX_TRY(upload(B[12], rl.data(), rl.size(), c->stream));
+        VMX_TRY(vmx_push(c, B[12], rl.data(), rl.size()));
         const int32_t* d_rl = B[12].as<int32_t>();
         int32_t* d_decl = B[12].as<int32_t>() + decl_at; int32_t* d_ndecl = d_decl + big.size();
         int32_t* d_decl2 = d_ndecl + 1; int32_t* d_ndecl2 = d_decl2 + big.size();

@@ -84,7 +84,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         for (int64_t r = 0; r < n; ++r) ord[(size_t)r + 1] = (int32_t)r;
         std::stable_sort(ord.begin() + 1, ord.end(), [&](int32_t a, int32_t b) { return h_roff[a + 1] - h_roff[a] > h_roff[b + 1] - h_roff[b]; });
         ord[0] = 0;                                               // [0] = queue head, [1..n] = read order
-        VMX_TRY(upload(L.rorder, ord.data(), ord.size(), c->stream));
+        VMX_TRY(vmx_push(c, L.rorder, ord.data(), ord.size()));
     }
     const int64_t nkey = (int64_t)1 << (2 * k);
     const int64_t head_stride = (2 * k > 14 && nkey <= (int64_t)VMX_SORT_LDS * 64) ? ((int64_t)1 << 14) : nkey;     // bucketed heads (k_local_seed)
@@ -120,7 +120,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         VMX_TRY(L.gkey.reserve(8 * (size_t)G * (size_t)gkey_cap));
         VMX_TRY(L.la_rows.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1))); VMX_TRY(L.la_ekey.reserve(8 * (size_t)(la_tot + 1)));
         VMX_TRY(L.la_sorted.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1)));
-        VMX_TRY(upload(L.la_off, L.h_la_off.data(), (size_t)n + 1, c->stream));
+        VMX_TRY(vmx_push(c, L.la_off, L.h_la_off.data(), (size_t)n + 1));
         VMX_TRY(L.la_cnt.reserve(4 * (size_t)(n + 1))); VMX_TRY(L.status.reserve(4 * (size_t)(n + 1)));
         A.ocodes = d_ocodes; A.roff = d_roff; A.ref = ix.codes; A.coff = ix.coff; A.nseq = ix.nseq;
         A.guide_rows = L.guide_rows.as<vmx_anchor>(); A.guide_len = L.guide_len.as<int32_t>(); A.n_guides_used = L.ng_used.as<int32_t>(); A.aoff = d_aoff;
@@ -142,7 +142,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         if (dbg_on) { VMX_TRY(L.dbg.reserve(128)); VMX_HIP(hipMemsetAsync(L.dbg.p, 0, 128, c->stream)); A.dbg = L.dbg.as<unsigned long long>(); }
         if (band) hipLaunchKernelGGL(k_local_seed_band, dim3((unsigned)G), dim3(64), VMX_LB_LDS_BYTES, c->stream, A);
         else hipLaunchKernelGGL(k_local_seed, dim3((unsigned)G), dim3(TPB), 0, c->stream, A);
-        if (dbg_on) { unsigned long long h[16]; VMX_TRY(download(h, L.dbg.p, 16, c->stream)); VMX_HIP(vmx_stream_sync(c));
+        if (dbg_on) { unsigned long long h[16]; VMX_TRY(vmx_fetch(c, h, L.dbg.p, 16)); VMX_HIP(vmx_stream_sync(c));
                       fprintf(stderr, band ? "k_local_seed_band phase ticks (100MHz, summed over blocks): guide+windows %llu stream %llu hit sort %llu walk %llu log %llu emission+final sorts %llu | slice+closest+items %llu pieces %llu table %llu | band positions %llu chunks %llu hits %llu read positions %llu\n"
                                            : "k_local_seed phase ticks (100MHz, summed over blocks): guide+windows %llu table %llu passA %llu passB+sort %llu merge %llu finalsort %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12]); }
         return 0;
@@ -155,9 +155,9 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     (void)hipEventRecord(c->kev[1], c->stream); c->kev_set |= 1;
     // sizing sync #2: local anchor counts decide the LDS bucket of every read in the local chain DP
     L.h_la_cnt.resize((size_t)n);
-    VMX_TRY(download(L.h_la_cnt.data(), L.la_cnt.p, (size_t)n, c->stream));
+    VMX_TRY(vmx_fetch(c, L.h_la_cnt.data(), L.la_cnt.p, (size_t)n));
     std::vector<int32_t> h_lstatus((size_t)n);
-    VMX_TRY(download(h_lstatus.data(), L.status.p, (size_t)n, c->stream));
+    VMX_TRY(vmx_fetch(c, h_lstatus.data(), L.status.p, (size_t)n));
     VMX_HIP(vmx_stream_sync(c));
     VMX_HIP(hipGetLastError());
     if (band_on) {   // reads the banded form handed back (hit tile / open-run list / key width exceeded): the general kernel, same slots
@@ -173,10 +173,10 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         }
         if (cnt) {
             std::stable_sort(ord.begin() + 1, ord.end(), [&](int32_t a, int32_t b) { return h_roff[a + 1] - h_roff[a] > h_roff[b + 1] - h_roff[b]; });
-            VMX_TRY(upload(L.rorder, ord.data(), ord.size(), c->stream));
+            VMX_TRY(vmx_push(c, L.rorder, ord.data(), ord.size()));
             VMX_TRY(run_seed(cnt, std::min(cnt, G), hit_cap, false));
-            VMX_TRY(download(L.h_la_cnt.data(), L.la_cnt.p, (size_t)n, c->stream));
-            VMX_TRY(download(h_lstatus.data(), L.status.p, (size_t)n, c->stream));
+            VMX_TRY(vmx_fetch(c, L.h_la_cnt.data(), L.la_cnt.p, (size_t)n));
+            VMX_TRY(vmx_fetch(c, h_lstatus.data(), L.status.p, (size_t)n));
             VMX_HIP(vmx_stream_sync(c));
             VMX_HIP(hipGetLastError());
         }
@@ -197,14 +197,14 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
             }
             const int cnt = (int)ord.size() - 1;
             if (!cnt) break;
-            VMX_TRY(upload(L.rorder, ord.data(), ord.size(), c->stream));
-            VMX_TRY(upload(L.la_off, L.h_la_off.data(), (size_t)n + 1, c->stream));
+            VMX_TRY(vmx_push(c, L.rorder, ord.data(), ord.size()));
+            VMX_TRY(vmx_push(c, L.la_off, L.h_la_off.data(), (size_t)n + 1));
             int64_t hcap = 1; while (hcap < mult * 4 * (lmax_f + 14000)) hcap <<= 1;
             if (hcap > ((int64_t)1 << 26)) hcap = (int64_t)1 << 26;          // stream indices are 26-bit
             A.la_slot_len = mult;                                            // slot length = mult * VMX_LA_SLOT(len) for the listed reads
             VMX_TRY(run_seed(cnt, std::min(cnt, 8), hcap, false));
-            VMX_TRY(download(L.h_la_cnt.data(), L.la_cnt.p, (size_t)n, c->stream));
-            VMX_TRY(download(h_lstatus.data(), L.status.p, (size_t)n, c->stream));
+            VMX_TRY(vmx_fetch(c, L.h_la_cnt.data(), L.la_cnt.p, (size_t)n));
+            VMX_TRY(vmx_fetch(c, h_lstatus.data(), L.status.p, (size_t)n));
             VMX_HIP(vmx_stream_sync(c));
             VMX_HIP(hipGetLastError());
         }
@@ -214,7 +214,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     std::vector<double> gap(64, 0.0);
     for (int g = 1; g <= prm->local_maxdiff; ++g)
         gap[g] = (g <= 10 || prm->mode == VM_MODE_R || prm->mode == VM_MODE_ASM) ? (0.01 * k * g + 0.5 * T.log2int[g]) : (0.01 * k * g + 2 * T.log2int[g]);   // :27317-27322; _scar: 0.5*log2 throughout (mammap_noprefercloser.py:23432)
-    VMX_TRY(upload(L.gap, gap.data(), 64, c->stream));
+    VMX_TRY(vmx_push(c, L.gap, gap.data(), 64));
     // LDS buckets by anchor count (24 B per anchor): a workgroup claims only what its read needs, so 4-12 reads share a CU.
     // Inside a bucket the reads are ordered longest first and every read is its own workgroup: the dispatcher hands them out in
     // that order, which is the longest-first dynamic schedule.
@@ -241,7 +241,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         rl_off[q] = (int64_t)rl.size(); rl.insert(rl.end(), lists[q].begin(), lists[q].end());
     }
     rl_off[NB + 1] = (int64_t)rl.size();
-    VMX_TRY(upload(L.rlist, rl.data(), rl.size(), c->stream));
+    VMX_TRY(vmx_push(c, L.rlist, rl.data(), rl.size()));
     VMX_TRY(L.S.reserve(8 * (size_t)(la_tot + 1))); VMX_TRY(L.P.reserve(4 * (size_t)(la_tot + 1))); VMX_TRY(L.SA.reserve(4 * (size_t)(la_tot + 1)));
     VMX_TRY(L.chain.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1)));
     VMX_TRY(L.chain_len.reserve(4 * (size_t)(n + 1))); VMX_TRY(L.score.reserve(8 * (size_t)(n + 1))); VMX_TRY(L.variant.reserve(4 * (size_t)(n + 1)));
@@ -263,7 +263,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         if (rows_kernel) {
             // one launch per variant (different code; a row whose read wants the other variant leaves at once): LC-exact and LC-mm, or `_scar` alone in mode R
             for (int want = (prm->mode == VM_MODE_R ? 2 : 0); want <= (prm->mode == VM_MODE_R ? 2 : 1); ++want)
-                hipLaunchKernelGGL(vmx_chain_rows_win3() ? k_chain_local_rows_w3 : k_chain_local_rows, dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, fk.next(), L.la_sorted.as<vmx_anchor>(),
+                hipLaunchKernelGGL((vmx_chain_rows_win3() ? k_chain_local_rows_w3 : k_chain_local_rows), dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, fk.next(), L.la_sorted.as<vmx_anchor>(),
                                    L.la_off.as<int64_t>(), L.la_cnt.as<int32_t>(), L.ng_total.as<int32_t>(), L.rlist.as<int32_t>() + rl_off[q], cnt, want, c->tables,
                                    L.gap.as<double>(), skip_exact, skip_mm, prm->local_maxdiff, maxgap, prm->mode, L.S.as<double>(), L.P.as<int32_t>(), L.SA.as<int32_t>(),
                                    L.score.as<double>(), L.chain.as<vmx_anchor>(), L.chain_len.as<int32_t>(), L.variant.as<int32_t>(), L.status.as<int32_t>(),
