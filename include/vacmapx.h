@@ -247,6 +247,7 @@ typedef struct vm_batch_stats {     /* measured on the device, for bench.py's ro
     int64_t n_host_syncs;           /* host waits for the device inside this batch (sizing read-backs + result download) */
     int64_t n_local_general;        /* reads the guide-banded local seeding kernel handed to the general one (k_local_seed) */
     int64_t n_ext_retries;          /* times the batch was run again because a pool of the extend stage was too small (pools x4 per retry) */
+    int64_t n_batch_retries;        /* times the whole batch was run again because an assumption made instead of a host wait did not hold (a pool sized from the context's history) */
 } vm_batch_stats;
 
 /* Align n reads (replaces get_readmap_DP_test per read). seqs concatenated, offsets[n+1].

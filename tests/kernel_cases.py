@@ -453,6 +453,30 @@ def check_align_random(ctx, O, mode='R', n=8, seed=51, reflen=120000, mean_len=5
     return len(orecs)
 
 
+def check_align_indel_donor(ctx, O, mode='H', n=10, seed=5, reflen=200000, mean_len=7000, err=0.08):
+    """whole path on reads from a donor with an insertion or deletion of 30-600 bp every ~2.5 kb (tools/bigverify.py's third leg, small): CIGARs with paired indels, i.e. reads
+    the reference runs a second time with nofilter (mammap_clrnano.py:24079-24080: pass 1 of the extend stage); records vs the oracle. Returns the batch statistics."""
+    from vacmap_amd import synth
+    from vacmap_amd.lib import Index, align_batch
+    rng = np.random.default_rng(seed)
+    ref = synth.make_reference([reflen], seed=seed + 2)
+    ops = []
+    for p_ in range(5000, reflen - 5000, 2500):
+        n_ = int(rng.integers(30, 600))
+        ops.append(('DEL', p_, n_) if rng.random() < 0.5 else ('INS', p_, n_, int(rng.integers(1 << 30))))
+    donor = synth.implant_svs(ref[0], ops)
+    cat, off, _ = synth.sample_reads_concat([donor], n, seed=seed + 94, mean_len=mean_len, err=err)
+    seqs = [cat[off[i]:off[i + 1]].tobytes().decode() for i in range(n)]
+    gi = Index.from_seqs(ctx, ['chr1'], [ref[0].tobytes()], k=15, w=10)
+    oi = O.Index.from_seqs(['chr1'], [ref[0].tobytes()], k=15, w=10)
+    status, recs, stats = align_batch(ctx, gi, ctx.lib.params(mode), seqs)
+    ost, orecs = O.align_batch(oi, seqs, O.params(mode), nthreads=8)
+    assert [(int(x) == 0) for x in status] == [(int(x) == 0) for x in ost]
+    assert recs == orecs, 'indel donor, mode %s: records differ from the oracle' % mode
+    assert len(orecs) >= n // 2
+    return stats
+
+
 def check_seed_sparse_noise(ctx, O, ref_mb=10, read_len=4000, seed=71, min_hits=900):
     """`.map()` in the regime of an hg38-size index: one true locus plus a thousand-odd ISOLATED stray hits (22-mers of the read planted every
     7 kb of a random reference, some in pairs 3 kb apart = small clusters, some 6 kb apart = neighbours that are not a cluster) — the
@@ -570,6 +594,7 @@ def check_align_golden(ctx, O, golden, cases=('A', 'B', 'C', 'D'), reads=None, m
         assert stats['n_reads'] == len(seqs)
         if min_ext_retries is not None:
             assert stats['n_ext_retries'] >= min_ext_retries, (cid, stats['n_ext_retries'])
+    return stats
 
 
 _COMP = bytes.maketrans(b'ACGTN', b'TGCAN')

@@ -150,6 +150,17 @@ def test_emu_extend_pools_grow_and_retry(ctx, oracle, golden, monkeypatch):
     KC.check_align_golden(ctx, oracle, golden, cases=['D'], reads=[1], min_ext_retries=0)
 
 
+def test_emu_side_batches_of_the_rare_parts(ctx, oracle, golden, monkeypatch):
+    """round 6: reads that need a part of the path a batch does not run (later tiers of the divergence filter, pass 1 = the nofilter re-run of mammap_clrnano.py:24079-24080)
+    are run again alone with every part of it; the test hook sends every second read through that side batch — records unchanged"""
+    monkeypatch.setenv('VMX_TEST_SIDE_EVERY', '2')
+    st = KC.check_align_golden(ctx, oracle, golden, cases=['D'], reads=[0, 1, 2])
+    assert st['n_ext_retries'] >= 1
+    st = KC.check_align_golden(ctx, oracle, golden, cases=['I'], reads=[0, 3])
+    assert st['n_ext_retries'] >= 1
+    monkeypatch.delenv('VMX_TEST_SIDE_EVERY')
+
+
 def test_emu_stage_trace(ctx, oracle, golden):
     """E1 / E3 / E4 stage by stage against the reference's captured segment lists (golden V4)"""
     n = KC.check_stage_trace_golden(ctx, oracle, golden, cases=['I'], reads=[0, 3])

@@ -149,6 +149,41 @@ def test_chain_rows_hbm_paths_forced_on_the_gpu(ctx, oracle, golden, monkeypatch
     assert c3['global_insertions_through_hbm'] + c3['local_insertions_through_hbm'] > 0, c3
 
 
+def test_batch_runs_again_when_an_assumed_size_did_not_hold(oracle, golden, monkeypatch):
+    """round 6: the gap fill no longer asks the host between its two launches — the second launch's traceback pool is sized from the context's history. The assumption is made
+    to fail here on a FRESH context (test hook: a 4 KB first guess of the pool): the batch must notice (n_batch_retries), grow the pool, run again, and deliver the reference's
+    records; the following batch of the same context must not retry again."""
+    from vacmap_amd.lib import Context
+    cx = Context(0)
+    monkeypatch.setenv('VMX_TEST_REDO_POOL_BYTES', '4096')
+    tot = 0
+    for cid in ('B', 'D', 'A'):
+        st = KC.check_align_golden(cx, oracle, golden, cases=[cid])
+        tot += st['n_batch_retries']
+    assert tot >= 1, tot
+    monkeypatch.delenv('VMX_TEST_REDO_POOL_BYTES')
+    st = KC.check_align_golden(cx, oracle, golden, cases=['B'])
+    assert st['n_batch_retries'] == 0
+    cx.close()
+
+
+def test_rare_parts_of_the_path_run_in_side_batches(ctx, oracle, golden, monkeypatch):
+    """round 6: a batch runs the COMMON path only — tier 0 of the divergence filter (the anchor bound, mammap_clrnano.py:19251's edlib call bounded from above) and pass 0 of
+    the extend stage. A read that needs more — a segment the bound could not settle (banded and exact tiers), or the nofilter re-run of :24079-24080 (pass 1) — is marked on
+    the device and run again ALONE with every part of the path (align_device's side batch). Reads from a donor with an indel of 30-600 bp every ~2.5 kb reach both; the
+    records must equal the oracle's with the side batches (default) and with every batch running everything (VMX_FORCE_EXACT / VMX_FORCE_PASS1: rounds 1-5)."""
+    st = KC.check_align_indel_donor(ctx, oracle, n=600, reflen=3_000_000, mean_len=9000)
+    print('side batches on the indel donor (no hook):', st['n_ext_retries'])
+    # hardly any read asks for the rare parts (none of the goldens, none of these 600): the hook sends every third read of a batch through the side batch, whatever it needs
+    monkeypatch.setenv('VMX_TEST_SIDE_EVERY', '3')
+    for cid in ('A', 'B', 'D', 'H', 'I', 'K'):
+        st = KC.check_align_golden(ctx, oracle, golden, cases=[cid])
+        assert st['n_ext_retries'] >= 1, cid
+    st = KC.check_align_indel_donor(ctx, oracle, n=200, reflen=1_000_000, mean_len=9000, seed=7)
+    assert st['n_ext_retries'] >= 1
+    monkeypatch.delenv('VMX_TEST_SIDE_EVERY')
+
+
 def test_extend_pools_grow_and_retry(ctx, oracle, golden, monkeypatch):
     """every pool of the extend stage made too small through the test hook VMX_TEST_EXT_POOL=<mask>:<div> (1 segment anchors, 2 segments, 4 record blob,
     8 problems per round, 16 problem strings; 31 all): the read (VMX_EXT_CAPACITY_DEV) or the batch (overflow flag) reports it, the batch runs again with

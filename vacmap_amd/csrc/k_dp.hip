@@ -499,7 +499,8 @@ __device__ __forceinline__ void vmx_gapfill_fill_body(const uint8_t* __restrict_
 __device__ __forceinline__ void vmx_gapfill_ad_pass(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes, vmx_dp_prob* __restrict__ probs, int n_prob,
                                                    int match, int mismatch, int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb_pool, int32_t* __restrict__ bnd_pool,
                                                    int32_t* __restrict__ out_score, const int32_t* __restrict__ order, const int32_t* __restrict__ range, int32_t* __restrict__ counter,
-                                                   int32_t* __restrict__ redo_list, int32_t* __restrict__ redo_cnt, int ad_pct, unsigned long long* __restrict__ redo_bytes) {
+                                                   int32_t* __restrict__ redo_list, int32_t* __restrict__ redo_cnt, int ad_pct, unsigned long long* __restrict__ redo_bytes,
+                                                   unsigned long long redo_cap) {
     const int lane = vmx_lane();
     const int pct = ad_pct & 0xffff, pct_min = (ad_pct >> 16) & 0xffff;
     // the head of the longest-first queue (range[0] entries: the size classes above the small one) goes one problem per task: eight of them in
@@ -543,11 +544,23 @@ __device__ __forceinline__ void vmx_gapfill_ad_pass(const uint8_t* __restrict__ 
             // a problem for the second launch takes its full-matrix traceback space out of the second pool
             if (x4X) {
                 out_score[pX] = keepX ? VMX_AD_FLAG + ns : 0;
-                if (!keepX) { probs[pX].tb_off = -(int64_t)atomicAdd(redo_bytes, (unsigned long long)VMX_REDO_TB_BYTES(prX.tl, prX.ql)) - 1; redo_list[atomicAdd(redo_cnt, 1)] = pX; }
+                if (!keepX) {
+                    // (round 6: the second pool is sized from history, not from a read-back of this counter: an allocation that does not fit EMPTIES the problem — no
+                    //  fill, an empty CIGAR — and the host, which reads the counter with the batch's results, grows the pool and runs the batch again)
+                    const unsigned long long need = (unsigned long long)VMX_REDO_TB_BYTES(prX.tl, prX.ql), at = atomicAdd(redo_bytes, need);
+                    if (at + need > redo_cap) { probs[pX].tl = 0; probs[pX].ql = 0; probs[pX].tb_off = 0; }
+                    else { probs[pX].tb_off = -(int64_t)at - 1; redo_list[atomicAdd(redo_cnt, 1)] = pX; }
+                }
             }
             if (x4Y) {
                 out_score[pY] = keepY ? VMX_AD_FLAG + ns : 0;
-                if (!keepY) { probs[pY].tb_off = -(int64_t)atomicAdd(redo_bytes, (unsigned long long)VMX_REDO_TB_BYTES(prY.tl, prY.ql)) - 1; redo_list[atomicAdd(redo_cnt, 1)] = pY; }
+                if (!keepY) {
+                    // (round 6: the second pool is sized from history, not from a read-back of this counter: an allocation that does not fit EMPTIES the problem — no
+                    //  fill, an empty CIGAR — and the host, which reads the counter with the batch's results, grows the pool and runs the batch again)
+                    const unsigned long long need = (unsigned long long)VMX_REDO_TB_BYTES(prY.tl, prY.ql), at = atomicAdd(redo_bytes, need);
+                    if (at + need > redo_cap) { probs[pY].tl = 0; probs[pY].ql = 0; probs[pY].tb_off = 0; }
+                    else { probs[pY].tb_off = -(int64_t)at - 1; redo_list[atomicAdd(redo_cnt, 1)] = pY; }
+                }
             }
         }
         for (int gk = 0; gk < 8; ++gk) {
@@ -571,17 +584,21 @@ __global__ void __launch_bounds__(64, 4) k_gapfill_fill_ns(const uint8_t* __rest
                                                         int32_t* __restrict__ bnd_pool, int32_t* __restrict__ out_score,
                                                         const int32_t* __restrict__ order, const int32_t* __restrict__ range, int32_t* __restrict__ counter,
                                                         int32_t* __restrict__ redo_list, int32_t* __restrict__ redo_cnt, int redo_pass, int ad_pct,
-                                                        uint8_t* __restrict__ redo_pool, unsigned long long* __restrict__ redo_bytes) {
+                                                        uint8_t* __restrict__ redo_pool, unsigned long long* __restrict__ redo_bytes, const int32_t* __restrict__ n_ptr,
+                                                        unsigned long long redo_cap) {
+    if (n_ptr) n_prob = *n_ptr;                        // the count on the device (an unplanned pass: the host launched for an upper bound)
     if (redo_pass) vmx_gapfill_fill_body<false>(tcodes, qcodes, probs, n_prob, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, order, counter, redo_list, redo_cnt, 1, redo_pool);
-    else vmx_gapfill_ad_pass(tcodes, qcodes, probs, n_prob, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, order, range, counter, redo_list, redo_cnt, ad_pct, redo_bytes);
+    else vmx_gapfill_ad_pass(tcodes, qcodes, probs, n_prob, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, order, range, counter, redo_list, redo_cnt, ad_pct, redo_bytes, redo_cap);
 }
 
 // serial traceback, one THREAD per problem (thousands of independent dependent-load chains hide each other's latency)
 __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_t* __restrict__ qcodes,
                                 const vmx_dp_prob* __restrict__ probs, int n_prob, int eqx, const uint8_t* __restrict__ tb_pool,
                                 uint32_t* __restrict__ run_pool, char* __restrict__ cig_pool, int32_t* __restrict__ cig_len,
-                                const int32_t* __restrict__ band_flag, const uint8_t* __restrict__ redo_pool, int spread, int32_t* __restrict__ cig_q) {
+                                const int32_t* __restrict__ band_flag, const uint8_t* __restrict__ redo_pool, int spread, int32_t* __restrict__ cig_q,
+                                const int32_t* __restrict__ n_ptr) {
     VMX_SETPRIO(3);
+    if (n_ptr) n_prob = *n_ptr;
     // one lane in `spread` works (like k_ext_phase: the walks of the 64 problems of a full wave diverge at every step)
     const int gt = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (spread > 1 && gt % spread) return;

@@ -16,6 +16,7 @@
 // its S from the S and the delta handed over by the block above.
 #include "vmx_device.h"
 #include "vmx_kernels.h"
+#include "vmx_ext_state.h"
 
 __global__ void __launch_bounds__(64) k_ed_banded(const uint8_t* __restrict__ qcodes, const int64_t* __restrict__ q_off,
                                                   const uint8_t* __restrict__ tcodes, const int64_t* __restrict__ t_off,
@@ -106,7 +107,8 @@ __global__ void __launch_bounds__(64) k_ed_banded(const uint8_t* __restrict__ qc
 // thresholds: a problem stays flagged (size = pattern length, for the unbanded kernel) unless its upper bound already proves
 // editDistance / min(len) <= maxdiv; unflagged problems get size -1 and ed = ub
 __global__ void k_ed_flag(const int64_t* __restrict__ ub, const int64_t* __restrict__ q_off, const int64_t* __restrict__ t_off, const int32_t* __restrict__ n_ptr,
-                          double maxdiv, int64_t* __restrict__ sizes, int64_t* __restrict__ ed_out, int32_t* __restrict__ n_flagged, int first) {
+                          double maxdiv, int64_t* __restrict__ sizes, int64_t* __restrict__ ed_out, int32_t* __restrict__ n_flagged, int first,
+                          const int32_t* __restrict__ prob_read, vmx_ext_read* __restrict__ er) {
     const int n = *n_ptr;
     for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x * blockDim.x)) {
         if (!first && sizes[i] < 0) continue;                         // settled by an earlier tier
@@ -116,7 +118,12 @@ __global__ void k_ed_flag(const int64_t* __restrict__ ub, const int64_t* __restr
         if (mn == 0) keep = true;                                    // the consumer raises on an empty side; no DP needed
         else if (u >= 0 && ((double)u / (double)mn) <= maxdiv) keep = true;
         if (keep) { sizes[i] = -1; ed_out[i] = u >= 0 ? u : (m > t ? m : t); }
-        else { sizes[i] = m; atomicAdd(n_flagged, 1); }
+        else {
+            sizes[i] = m; atomicAdd(n_flagged, 1);
+            // last tier before the exact kernel, which this batch does not launch (round 6: hardly any problem gets here — 0 per batch on ONT / HiFi reads, one in fifteen
+            // batches on the vacsim workload — and learning the count cost a host wait per batch): the problem's READ is marked and run again alone, exact tier included
+            if (er) er[prob_read[i]].status = VMX_EXT_NEED_EXACT_DEV;
+        }
     }
 }
 

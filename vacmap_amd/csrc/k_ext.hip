@@ -23,7 +23,9 @@ __device__ __forceinline__ vmx_segs vmx_read_segs(const vmx_ext_args& A, int r, 
 }
 
 // allocate n contiguous problem slots of the current round
-__device__ __forceinline__ int vmx_alloc_probs(const vmx_ext_args& A, int n) {
+// (round 6: the slots' owner — prob_read[slot] = read — is written here by the allocating lane, or by the caller's whole wavefront with `own` false;
+//  k_prob_owner, a launch per round, did that before)
+__device__ __forceinline__ int vmx_alloc_probs(const vmx_ext_args& A, int n, int r, bool own = true) {
     if (n <= 0) return 0;
     // one atomic add (a compare-and-swap loop on this single word serialises thousands of lanes: measured 14 -> 100 ms per batch); a
     // request that does not fit is rolled back, so that once the kernel has finished the published count is the sum of the granted
@@ -31,6 +33,7 @@ __device__ __forceinline__ int vmx_alloc_probs(const vmx_ext_args& A, int n) {
     // inside the pools. The read that does not fit is reported (VM_READ_CAPACITY); the batch goes on.
     const int b = atomicAdd(A.round_count, n);
     if ((long long)b + n > A.round_cap) { atomicAdd(A.round_count, -n); return -1; }
+    if (own) for (int i = 0; i < n; ++i) A.prob_read[b + i] = r;
     return b;
 }
 
@@ -202,7 +205,7 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
         if (rc < 0) { E.status = rc; return; }
         E.nseg = S.nseg;
         if (A.asm_long) { E.prob_base = 0; E.prob_n = 0; return; }                  // ass_extend_func has no divergence filter
-        int b = vmx_alloc_probs(A, S.nseg);
+        int b = vmx_alloc_probs(A, S.nseg, r);
         if (b < 0) { E.status = VMX_EXT_CAPACITY_DEV; return; }
         E.prob_base = b; E.prob_n = S.nseg;
         for (int s = 0; s < S.nseg; ++s) {
@@ -269,9 +272,10 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
             if (lane == 0) segprob[s] = np;
             total += np;
         }
-        int b = lane == 0 ? vmx_alloc_probs(A, total) : 0;
+        int b = lane == 0 ? vmx_alloc_probs(A, total, r, false) : 0;
         b = __shfl(b, 0);
         if (b < 0) { if (lane == 0) E.status = VMX_EXT_CAPACITY_DEV; return; }
+        for (int i = lane; i < total; i += 64) A.prob_read[b + i] = r;
         int k = 0;
         for (int s = 0; s < S.nseg; ++s) {
             const int np = vmx_split_alignment_w(S, s, L, R, A.desc + b + k, total - k, A.mode == 4, lane);
@@ -314,7 +318,7 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
                 if (pass == 0) { if (vmx_ext_setup(S, s, 1, L, R, &tmp)) { segprob[s] = k++; } }
                 else if (segprob[s] >= 0) { vmx_ext_setup(S, s, 1, L, R, &tmp); A.desc[b + segprob[s]] = tmp; }
             }
-            if (pass == 0) { np = k; b = vmx_alloc_probs(A, np); if (b < 0) { E.status = VMX_EXT_CAPACITY_DEV; return; } }
+            if (pass == 0) { np = k; b = vmx_alloc_probs(A, np, r); if (b < 0) { E.status = VMX_EXT_CAPACITY_DEV; return; } }
         }
         E.prob_base = b < 0 ? 0 : b; E.prob_n = np;
         return;
@@ -328,7 +332,7 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
                 if (pass == 0) { if (vmx_ext_setup(S, s, 0, L, R, &tmp)) { segprob[s] = k++; } }
                 else if (segprob[s] >= 0) { vmx_ext_setup(S, s, 0, L, R, &tmp); A.desc[b + segprob[s]] = tmp; }
             }
-            if (pass == 0) { np = k; b = vmx_alloc_probs(A, np); if (b < 0) { E.status = VMX_EXT_CAPACITY_DEV; return; } }
+            if (pass == 0) { np = k; b = vmx_alloc_probs(A, np, r); if (b < 0) { E.status = VMX_EXT_CAPACITY_DEV; return; } }
         }
         E.prob_base = b < 0 ? 0 : b; E.prob_n = np;
         return;
@@ -345,7 +349,7 @@ __global__ void k_ext_phase(vmx_ext_args A, int phase) {
             if (np < 0) { E.status = np; return; }
             segprob[s] = np; total += np;
         }
-        int b = vmx_alloc_probs(A, total);
+        int b = vmx_alloc_probs(A, total, r);
         if (b < 0) { E.status = VMX_EXT_CAPACITY_DEV; return; }
         int k = 0;
         for (int s = 0; s < S.nseg; ++s) {

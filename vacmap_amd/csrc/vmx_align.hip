@@ -6,6 +6,7 @@
 #include "vmx_stage.h"
 #include "vmx_select.h"
 #include "vmx_ext_state.h"
+#include "vmx_round.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -50,31 +51,7 @@ __global__ void k_readlens(const int64_t* __restrict__ roff, int64_t* __restrict
 // scalars the host wants are gathered by one-thread kernels into one block and read back with ONE copy (a hipMemcpyAsync per scalar is a
 // runtime copy kernel each: ~100 of them per batch before)
 __global__ void k_stat_put(const int32_t* __restrict__ src, int32_t* __restrict__ dst) { *dst = *src; }
-// gap-fill sizing on the device: the totals of the four per-problem pools and of the string pools, and the cut of the problems into chunks
-// of at most `limit` traceback bytes (a chunk ends before the first problem that would pass the limit; a single larger problem is a chunk
-// of its own) — found by bisection on the offsets. out: [0] n, [1..4] pool totals, [5] target bytes, [6] query bytes, [7] number of chunks m,
-// [8 .. 8 + VMX_MAX_CHUNKS] first problem of every chunk (m + 1 entries), then the traceback offsets at those problems (m + 1 entries);
-// m = -1 when more than VMX_MAX_CHUNKS chunks would be needed.
-#define VMX_MAX_CHUNKS 24
-__global__ void k_tb_plan(const int64_t* __restrict__ tboff, const int64_t* bnd, const int64_t* run, const int64_t* cig, const int64_t* toff, const int64_t* qoff,
-                          const int32_t* __restrict__ n_ptr, int64_t limit, int64_t* __restrict__ out) {
-    const int n = *n_ptr;
-    out[0] = n; out[1] = tboff[n]; out[2] = bnd[n]; out[3] = run[n]; out[4] = cig[n]; out[5] = toff[n]; out[6] = qoff[n];
-    int64_t* cuts = out + 8; int64_t* offs = out + 8 + VMX_MAX_CHUNKS + 1;
-    int m = 0, p = 0;
-    cuts[0] = 0; offs[0] = 0;
-    while (p < n) {
-        const int64_t base = tboff[p];
-        // the largest e in (p, n] with tboff[e] - base <= limit; at least one problem per chunk
-        int lo = p + 1, hi = n;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tboff[mid] - base <= limit) lo = mid; else hi = mid - 1; }
-        p = lo; ++m;
-        if (m > VMX_MAX_CHUNKS) { m = -1; break; }
-        cuts[m] = p; offs[m] = tboff[p];
-    }
-    out[7] = m;
-}
-
+// (gap-fill sizing on the device — pool totals and the cut of the problems into traceback chunks — is the last step of k_round_prep<true>, k_round.hip)
 __global__ void k_final_scalars(const int64_t* nr, const int64_t* nb, const int32_t* oflow, const int32_t* edc, const int32_t* rounds, int64_t* __restrict__ out) {
     out[0] = *nr; out[1] = *nb; out[2] = *oflow; out[3] = edc[0]; out[4] = edc[1]; out[5] = edc[2];
     for (int i = 0; i < 8; ++i) out[6 + i] = rounds[i];
@@ -88,7 +65,7 @@ struct vmx_batch_bufs {
     // extend stage
     DevBuf er, coff3, soff2, segA, st, en, segA_s, st_s, en_s, segprob, dup, desc[2], rcount, oflow, probread, tl, ql, toff, qoff, tpool, qpool;
     DevBuf edout, carry, ext3, dpsz[4], dpoff[4], dptab, tb, tbredo, bnd, run, cig, ciglen, dpscore, rec, blob, bloboff, reccoff, recclen, dupd, totals;
-    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp, chunkn, sellist, cigq, statblk, szh, side_codes, side_off;
+    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp, chunkn, sellist, cigq, statblk, szh, side_codes, side_off, roundpart, gfctl;
     void release() { DevBuf* p = (DevBuf*)this; for (size_t i = 0; i < sizeof(*this) / sizeof(DevBuf); ++i) p[i].release(); }
 };
 static vmx_batch_bufs* batch_bufs(vm_ctx* c) { if (!c->bbufs) c->bbufs = new vmx_batch_bufs(); return c->bbufs; }
@@ -159,20 +136,24 @@ static int dev_scan_dev(vm_ctx* c, vmx_batch_bufs& B, const int64_t* in, int64_t
 // slot `stat_slot` of the batch's counter block, which the host reads once at the end. want_cnt: also return a host copy (one wait) —
 // only the gap-fill rounds, whose pools are sized by it, ask for that.
 static int ext_gather_round(vm_ctx* c, vmx_batch_bufs& B, const vm_index_view& ix, int64_t n, const uint8_t* d_ocodes, const int64_t* d_roff, int cur, int redo_only,
-                            int64_t round_cap, int64_t pool_cap, int stat_slot, bool want_cnt) {
-    const int G = c->num_cu * 4;
-    hipLaunchKernelGGL(k_prob_owner, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, B.er.as<vmx_ext_read>(), (int)n, redo_only, B.probread.as<int32_t>());
-    hipLaunchKernelGGL(k_desc_lens, dim3(G), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.tl.as<int64_t>(), B.ql.as<int64_t>());
-    (void)round_cap;                              // vmx_alloc_probs never lets the published count pass the capacity
-    hipLaunchKernelGGL(k_stat_put, dim3(1), dim3(1), 0, c->stream, B.rcount.as<int32_t>(), B.statblk.as<int32_t>() + stat_slot);
-    int32_t cnt = 0;
-    if (want_cnt) { VMX_TRY(vmx_fetch(c, &cnt, B.rcount.p, 1)); VMX_HIP(vmx_stream_sync(c)); }
-    VMX_TRY(dev_scan_dev(c, B, B.tl.as<int64_t>(), B.toff.as<int64_t>(), B.rcount.as<int32_t>()));
-    VMX_TRY(dev_scan_dev(c, B, B.ql.as<int64_t>(), B.qoff.as<int64_t>(), B.rcount.as<int32_t>()));
+                            int64_t round_cap, int64_t pool_cap, int stat_slot, bool dp, int64_t tb_limit, const int64_t* caps = nullptr, int64_t* plan_out = nullptr) {
+    (void)n; (void)redo_only; (void)round_cap;    // (the slots' owners are written when the phase kernel allocates them; vmx_alloc_probs never lets the published count pass the capacity)
+    if (!B.roundpart.p) { VMX_TRY(B.roundpart.reserve(8 * (size_t)VMX_ROUND_PART_WORDS)); VMX_HIP(hipMemsetAsync(B.roundpart.p, 0, 8 * (size_t)VMX_ROUND_PART_WORDS, c->stream)); }
+    vmx_round_args R; memset(&R, 0, sizeof R);
+    R.desc = B.desc[cur].as<vmx_pair_desc>(); R.n_prob = B.rcount.as<int32_t>();
+    R.off[0] = B.toff.as<int64_t>(); R.off[1] = B.qoff.as<int64_t>();
+    R.part = B.roundpart.as<int64_t>(); R.stat_out = B.statblk.as<int32_t>() + stat_slot; R.epoch = ++c->round_epoch;
+    if (dp) {
+        for (int i = 0; i < 4; ++i) R.off[2 + i] = B.dpoff[i].as<int64_t>();
+        R.tb_size = B.dpsz[0].as<int64_t>(); R.probs = B.dptab.as<vmx_dp_prob>(); R.plan_out = plan_out; R.tb_limit = tb_limit;
+        if (caps) for (int i = 0; i < 4; ++i) R.cap[i] = caps[i];          // unplanned pass: every problem is checked against the pools (k_round.hip)
+        hipLaunchKernelGGL(k_round_prep<true>, dim3(VMX_ROUND_WGS), dim3(256), 0, c->stream, R);
+    } else
+        hipLaunchKernelGGL(k_round_prep<false>, dim3(VMX_ROUND_WGS), dim3(256), 0, c->stream, R);
     hipLaunchKernelGGL(k_gather, dim3((unsigned)((int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(),
                        B.probread.as<int32_t>(), d_ocodes, d_roff, ix.codes, B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), pool_cap,
                        B.er.as<vmx_ext_read>());
-    return cnt;
+    return 0;
 }
 
 // diagnostic capture for the stage tests (vm_align_trace): the segment lists of every read as they stand after one phase of the
@@ -186,6 +167,9 @@ int vmx_align_batch_asm_mixed(vm_ctx* c, const vm_index* mi, const vm_params* pr
 int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
                  vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats, vmx_seg_trace* trace = nullptr, const vmx_preset* preset = nullptr);
 
+#define VMX_EXT_EXACT_INTERNAL (-9002)   // ... "this read needs a part of the path that a batch does not run: the later tiers of the divergence filter, or pass 1" (never leaves align_device)
+#define VMX_RETRY_BATCH (-9003)          // align_device_once -> align_device: an assumption the batch ran on instead of a host wait did not hold (a pool sized from the context's
+                                        // history, the unplanned pass 1): the pools have been grown / the assumption dropped, run the batch again
 #define VMX_EXT_SHORT_INTERNAL (-9001)   // align_device_once's per-read status for "an extend-stage pool was too small for this read" (never leaves align_device)
 static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n, const uint8_t* d_codes, const int64_t* d_roff, const std::vector<int64_t>& h_roff,
                              vm_record** recs, int64_t* n_recs, char** cigar_blob, int32_t* status_per_read, vm_batch_stats* stats, vmx_seg_trace* trace, const vmx_preset* preset);
@@ -209,10 +193,16 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     c->ext_mul = 1;
     std::vector<int32_t> status((size_t)n + 1, 0);
     vm_batch_stats st; memset(&st, 0, sizeof st);
-    int rc = align_device_once(c, mi, prm, n, d_codes, d_roff, h_roff, recs, n_recs, cigar_blob, status.data(), &st, trace, preset);
+    int rc = VMX_RETRY_BATCH; int64_t batch_retries = 0;
+    for (int attempt = 0; attempt < 6 && rc == VMX_RETRY_BATCH; ++attempt) {
+        if (attempt) { ++batch_retries; if (trace) { trace->rows.clear(); trace->off.clear(); } }
+        rc = align_device_once(c, mi, prm, n, d_codes, d_roff, h_roff, recs, n_recs, cigar_blob, status.data(), &st, trace, preset);
+    }
+    if (rc == VMX_RETRY_BATCH) { set_error("the batch was run again five times and its pools still did not hold it"); return VM_ERR_OOM; }
     if (rc < 0) return rc;
+    st.n_batch_retries = batch_retries;
     std::vector<int32_t> sub;                                    // reads of the batch that were short of an extend-stage pool
-    for (int64_t r = 0; r < n; ++r) if (status[(size_t)r] == VMX_EXT_SHORT_INTERNAL) sub.push_back((int32_t)r);
+    for (int64_t r = 0; r < n; ++r) if (status[(size_t)r] == VMX_EXT_SHORT_INTERNAL || status[(size_t)r] == VMX_EXT_EXACT_INTERNAL) sub.push_back((int32_t)r);
     if (!sub.empty()) {
         vmx_batch_bufs& B = *batch_bufs(c);
         std::vector<vm_record> all(*recs, *recs + *n_recs);
@@ -220,32 +210,37 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
         std::string blob(*cigar_blob, (size_t)blob_n);
         free(*recs); free(*cigar_blob); *recs = nullptr; *cigar_blob = nullptr; *n_recs = 0;
         int64_t retries = 0;
-        while (!sub.empty() && c->ext_mul < 1024) {
-            c->ext_mul *= 4; ++retries;
-            if (getenv("VMX_DBG_POOLS")) fprintf(stderr, "[pools] extend stage: %zu read(s) short of a pool, running them again alone with x%d\n", sub.size(), c->ext_mul);
+        while (!sub.empty()) {
+            bool any_short = false; for (int32_t r : sub) any_short = any_short || status[(size_t)r] == VMX_EXT_SHORT_INTERNAL;
+            if (any_short) { if (c->ext_mul >= 1024) break; c->ext_mul *= 4; }       // (reads that only need the filter's later tiers keep the pools as they are)
+            c->force_exact = true; c->run_pass1 = true; ++retries;
+            if (getenv("VMX_DBG_POOLS")) fprintf(stderr, "[pools] extend stage: %zu read(s) run again alone (pools x%d, every tier of the divergence filter)\n", sub.size(), c->ext_mul);
             const int64_t m = (int64_t)sub.size();
             std::vector<int64_t> s_off((size_t)m + 1, 0); std::vector<vmx_preset> s_pre;
             for (int64_t j = 0; j < m; ++j) { s_off[(size_t)j + 1] = s_off[(size_t)j] + (h_roff[(size_t)sub[(size_t)j] + 1] - h_roff[(size_t)sub[(size_t)j]]); if (preset) s_pre.push_back(preset[sub[(size_t)j]]); }
             int src = 0;
             if ((src = B.side_codes.reserve((size_t)s_off[(size_t)m] + 64)) < 0 || (src = vmx_push(c, B.side_off, s_off.data(), (size_t)m + 1)) < 0 ||
-                (src = vmx_push(c, B.sellist, sub.data(), (size_t)m)) < 0) { if (src == VM_ERR_OOM) break; c->ext_mul = 1; return src; }
+                (src = vmx_push(c, B.sellist, sub.data(), (size_t)m)) < 0) { if (src == VM_ERR_OOM) break; c->ext_mul = 1; c->force_exact = false; c->run_pass1 = false; return src; }
             hipLaunchKernelGGL(k_side_codes, dim3((unsigned)std::min<int64_t>(m, (int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, d_codes, d_roff, B.sellist.as<int32_t>(), B.side_off.as<int64_t>(), (int)m,
                                B.side_codes.as<uint8_t>());
             vm_record* r2 = nullptr; int64_t n2 = 0; char* b2 = nullptr; vm_batch_stats st2; std::vector<int32_t> status2((size_t)m + 1, 0);
-            src = align_device_once(c, mi, prm, m, B.side_codes.as<uint8_t>(), B.side_off.as<int64_t>(), s_off, &r2, &n2, &b2, status2.data(), &st2, nullptr, preset ? s_pre.data() : nullptr);
+            src = VMX_RETRY_BATCH;
+            for (int attempt = 0; attempt < 6 && src == VMX_RETRY_BATCH; ++attempt)
+                src = align_device_once(c, mi, prm, m, B.side_codes.as<uint8_t>(), B.side_off.as<int64_t>(), s_off, &r2, &n2, &b2, status2.data(), &st2, nullptr, preset ? s_pre.data() : nullptr);
+            if (src == VMX_RETRY_BATCH) src = VM_ERR_OOM;
             if (src == VM_ERR_OOM) { free(r2); free(b2); break; }                 // no room for the larger pools: these reads are reported, the batch stands
-            if (src < 0) { free(r2); free(b2); c->ext_mul = 1; return src; }
+            if (src < 0) { free(r2); free(b2); c->ext_mul = 1; c->force_exact = false; c->run_pass1 = false; return src; }
             std::vector<int32_t> still;
-            for (int64_t j = 0; j < m; ++j) { if (status2[(size_t)j] == VMX_EXT_SHORT_INTERNAL) still.push_back(sub[(size_t)j]); else status[(size_t)sub[(size_t)j]] = status2[(size_t)j]; }
+            for (int64_t j = 0; j < m; ++j) { status[(size_t)sub[(size_t)j]] = status2[(size_t)j]; if (status2[(size_t)j] == VMX_EXT_SHORT_INTERNAL) still.push_back(sub[(size_t)j]); }
             for (int64_t i = 0; i < n2; ++i) { vm_record x = r2[i]; x.read_idx = sub[(size_t)x.read_idx]; x.cigar_off += (int64_t)blob.size(); all.push_back(x); }
             int64_t bl = 0; for (int64_t i = 0; i < n2; ++i) bl = std::max<int64_t>(bl, r2[i].cigar_off + r2[i].cigar_len + 1);
             blob.append(b2, (size_t)bl);
             free(r2); free(b2);
             st.ms_total += st2.ms_total; for (int i = 0; i < 14; ++i) st.ms_stage[i] += st2.ms_stage[i];
-            st.n_host_syncs += st2.n_host_syncs;
+            st.n_host_syncs += st2.n_host_syncs; st.n_ed_tier2 += st2.n_ed_tier2; st.n_ed_full += st2.n_ed_full;
             sub.swap(still);
         }
-        c->ext_mul = 1;
+        c->ext_mul = 1; c->force_exact = false; c->run_pass1 = false;
         for (int32_t r : sub) status[(size_t)r] = VM_READ_CAPACITY;
         std::stable_sort(all.begin(), all.end(), [](const vm_record& a, const vm_record& b) { return a.read_idx < b.read_idx; });      // records stay grouped by read, in read order
         *recs = (vm_record*)malloc(sizeof(vm_record) * std::max<size_t>(all.size(), 1)); *cigar_blob = (char*)malloc(std::max<size_t>(blob.size(), 1));
@@ -465,14 +460,16 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     VMX_TRY(B.rec.reserve(sizeof(vm_record) * (size_t)(cS + 1))); VMX_TRY(B.blob.reserve((size_t)cB + 64)); VMX_TRY(B.reccoff.reserve(8 * (size_t)(cS + 1)));
     VMX_TRY(B.recclen.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.dupd.reserve((size_t)cB + 64));
     VMX_HIP(hipMemsetAsync(B.oflow.p, 0, 4, c->stream));
-    VMX_TRY(B.statblk.reserve(1024)); VMX_HIP(hipMemsetAsync(B.statblk.p, 0, 1024, c->stream));     // [0..7] i32 round counts | i64 [16..21] gap-fill totals | i64 [32..45] final scalars
+    VMX_TRY(B.statblk.reserve(2048)); VMX_HIP(hipMemsetAsync(B.statblk.p, 0, 2048, c->stream));     // [0..7] i32 round counts | i64 [32..45] final scalars | i64 [64..121] chunk plan of pass 0 | i64 [128..185] of pass 1
+    const size_t gfctl_bytes = (size_t)2 * (VMX_MAX_CHUNKS + 1) * (32 + 544) * 4;
+    VMX_TRY(B.gfctl.reserve(gfctl_bytes)); VMX_HIP(hipMemsetAsync(B.gfctl.p, 0, gfctl_bytes, c->stream));      // the gap fill's per-chunk control blocks and size-order scratch (below), cleared once
     vmx_ext_args A; memset(&A, 0, sizeof A);
     A.n_reads = (int)n; A.nseq = ix.nseq; A.local_maxdiff = preset ? 50 : prm->local_maxdiff /* ass_extend_func: large_cost 50, mammap_asm.py:23426 */; A.asm_long = preset ? 1 : 0; A.nodiscard = prm->nodiscard; A.hardclip = prm->hardclip; A.redo_only = 0; A.mode = prm->mode; A.maxdivergence = prm->maxdivergence;
     A.ocodes = B.ocodes.as<uint8_t>(); A.roff = d_roff; A.ref = ix.codes; A.coff = ix.coff;
     A.chain = L.chain.as<vmx_anchor>(); A.chain_len = L.chain_len.as<int32_t>(); A.la_off = L.la_off.as<int64_t>(); A.lstatus = L.status.as<int32_t>();
     A.gscore = d_gscore; A.mapq = d_mapq; A.er = B.er.as<vmx_ext_read>(); A.coff3 = B.coff3.as<int64_t>(); A.soff = B.soff2.as<int64_t>();
     A.segA = B.segA.as<vmx_anchor>(); A.st = B.st.as<int32_t>(); A.en = B.en.as<int32_t>(); A.segA_snap = B.segA_s.as<vmx_anchor>(); A.st_snap = B.st_s.as<int32_t>(); A.en_snap = B.en_s.as<int32_t>();
-    A.seg_prob = B.segprob.as<int32_t>(); A.dup = B.dup.as<int32_t>(); A.round_count = B.rcount.as<int32_t>(); A.round_cap = round_cap; A.overflow = B.oflow.as<int32_t>();
+    A.seg_prob = B.segprob.as<int32_t>(); A.dup = B.dup.as<int32_t>(); A.round_count = B.rcount.as<int32_t>(); A.round_cap = round_cap; A.overflow = B.oflow.as<int32_t>(); A.prob_read = B.probread.as<int32_t>();
     A.ed_out = B.edout.as<int64_t>(); A.ext_te = B.ext3.as<int32_t>(); A.ext_qe = B.ext3.as<int32_t>() + round_cap;
     A.rec = B.rec.as<vm_record>(); A.rec_blob = B.blob.as<char>(); A.blob_off = B.bloboff.as<int64_t>(); A.rec_coff = B.reccoff.as<int64_t>(); A.rec_clen = B.recclen.as<int32_t>();
     A.dup_d = B.dupd.as<double>();
@@ -511,7 +508,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
                                } };
     int ext_rounds = 0;
     auto ext_round = [&](int redo_only) -> int {   // x-drop extension of the problems of the current round (their count stays on the device)
-        int rc = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, redo_only, round_cap, pool_cap, 1 + ext_rounds++, false);
+        int rc = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, redo_only, round_cap, pool_cap, 1 + ext_rounds++, false, 0);
         if (rc < 0) return rc;
         hipLaunchKernelGGL(k_extend, dim3((unsigned)((int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.qpool.as<uint8_t>(),
                            B.qoff.as<int64_t>(), 0, 2, -4, 4, 4, 100, 50, B.ext3.as<int32_t>(), B.ext3.as<int32_t>() + round_cap, B.ext3.as<int32_t>() + 2 * round_cap, B.rcount.as<int32_t>());
@@ -519,91 +516,100 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
         return 0;
     };
     std::vector<int64_t> dp_tot(5, 0);
+    // ---- gap fill of one pass (E5). Round 6: ONE host wait per batch in here (the chunk plan of pass 0), none per chunk and none in pass 1.
+    //  * every chunk has its own control block (queue range / counters / redo list length / redo bytes: 32 ints) and its own zeroed scratch for the size ordering
+    //    in B.gfctl, cleared once per batch: nothing is cleared between chunks, and the host reads all of them with the batch's final results;
+    //  * the full-matrix traceback space of the problems whose band was not proven (the SECOND launch's pool) is sized from the context's history (largest chunk
+    //    seen x 1.3, 512 MB to begin with) instead of by a read-back between the two launches; the band pass checks every allocation against the pool and a problem
+    //    that does not fit is emptied (tl = ql = 0: no fill, empty CIGAR) — the host sees the need at the end, grows the pool and runs the batch again;
+    //  * pass 1 (the nofilter re-run of a read whose segment filter removed something and whose CIGARs carry paired indels, :24079-24080) is not part of a batch at all:
+    //    hardly any read asks for it (none of the 150 golden reads, a handful per 100 k synthetic reads), and its eleven launches and one host wait were paid by every batch.
+    //    A read that asks for it (E.redo) is run again alone by align_device with both passes (c->run_pass1), like the reads that need the later tiers of the divergence filter.
+    constexpr int GF_SLOT = 32 + 544;                                  // ints per chunk slot of B.gfctl: control block, then the size-order scratch (513 used)
+    auto gf_slot = [&](int pass, int q) -> int32_t* { return B.gfctl.as<int32_t>() + (size_t)(pass * (VMX_MAX_CHUNKS + 1) + q) * GF_SLOT; };
+    const int ad_pct = vmx_ad_pct_env(prm->mode);
+    int fill_waves = 16;                                              // waves per CU of the fill kernel (tuning knob: VMX_FILL_WAVES)
+    if (const char* e = getenv("VMX_FILL_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 32) fill_waves = v; }
+    static const int tr_spread = [] { const char* e = getenv("VMX_TRACE_SPREAD"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 64 ? v : 1; }();
+    static const int64_t tb_chunk = [] { const char* e = getenv("VMX_TB_CHUNK_GB"); const double v = e ? atof(e) : 0.0; return v > 0.5 ? (int64_t)(v * (double)(1 << 30)) : (int64_t)VMX_TB_CHUNK; }();     // tuning knob
+    int gf_chunks[2] = {0, 0}; int64_t gf_redo_cap = 0;
+    // one chunk: problems [p0, p0 + pn) — pn an upper bound when n_ptr names the count on the device
+    auto gf_chunk = [&](int pass, int q, int p0, int64_t pn, const int32_t* n_ptr, int64_t tb_off0) -> int {
+        int32_t* ctl = gf_slot(pass, q); int32_t* d_range = ctl; int32_t* d_cnt = ctl + 4; int32_t* d_redo_cnt = ctl + 12;
+        unsigned long long* d_redo_bytes = (unsigned long long*)(ctl + 16); int32_t* scratch = ctl + 32;
+        int32_t* d_redo_list = B.order.as<int32_t>() + round_cap + 32;
+        uint8_t* tb_base = B.tb.as<uint8_t>() - tb_off0;           // the problems' absolute traceback offsets index a buffer that holds this chunk only
+        hipEvent_t* ke = q < 8 ? c->gev + (pass ? 24 : 0) + 3 * q : nullptr;      // HIP events around the dominant kernel, on the stream it runs on
+        const unsigned Gs = (unsigned)std::max<int64_t>(1, std::min<int64_t>((pn + 1023) / 1024, (int64_t)c->num_cu * 2));
+        hipLaunchKernelGGL(k_size_hist, dim3(Gs), dim3(256), 0, c->stream, B.dpsz[0].as<int64_t>() + p0, n_ptr, (int64_t)VMX_HEAD_THRESH, scratch);
+        hipLaunchKernelGGL(k_size_scatter, dim3(Gs), dim3(256), 0, c->stream, B.dpsz[0].as<int64_t>() + p0, n_ptr, (const int32_t*)scratch, scratch + 257, B.order.as<int32_t>(), d_range, d_cnt);
+        if (ke) (void)hipEventRecord(ke[0], c->stream);
+        {
+            vmx_lowprio lp(c);                                    // the long launch at the lowest dispatch priority (vmx_host.h)
+            hipLaunchKernelGGL(k_gapfill_fill_ns, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(pn, (int64_t)c->num_cu * fill_waves))), dim3(64), 0, lp.stream(), B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
+                               B.dptab.as<vmx_dp_prob>() + p0, (int)pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_range, d_cnt,
+                               d_redo_list, d_redo_cnt, 0, ad_pct, (uint8_t*)nullptr, d_redo_bytes, n_ptr, (unsigned long long)gf_redo_cap);
+            lp.join();
+        }
+        // second launch: the problems whose band was not proven (a few per cent), in full: the larger ones on a whole wave, the others four per wave (its queue is the list the
+        // first launch left; any grid works)
+        hipLaunchKernelGGL(k_gapfill_fill_ns, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(pn, (int64_t)c->num_cu * 4))), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
+                           B.dptab.as<vmx_dp_prob>() + p0, (int)pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_range, d_cnt,
+                           d_redo_list, d_redo_cnt, 1, ad_pct, B.tbredo.as<uint8_t>(), d_redo_bytes, n_ptr, (unsigned long long)gf_redo_cap);
+        if (ke) (void)hipEventRecord(ke[1], c->stream);
+        hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)std::max<int64_t>(1, (pn * tr_spread + 63) / 64)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>() + p0, (int)pn, prm->eqx,
+                           tb_base, B.run.as<uint32_t>(), B.cig.as<char>(), B.ciglen.as<int32_t>() + p0, B.dpscore.as<int32_t>() + p0, B.tbredo.as<uint8_t>(), tr_spread, B.cigq.as<int32_t>() + p0, n_ptr);
+        if (ke) { (void)hipEventRecord(ke[2], c->stream); c->n_gev[pass] = q + 1; }
+        gf_chunks[pass] = q + 1;
+        return 0;
+    };
     auto gapfill = [&](int redo_only) -> int {
-        int rcg = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, redo_only, round_cap, pool_cap, 6 + redo_only, false);
-        if (rcg < 0) return rcg;
-        // per-problem tables are sized for the round's capacity; the count, the pool totals and the chunk cuts come back in ONE read
+        // per-problem tables are sized for the round's capacity
         for (int i = 0; i < 4; ++i) { VMX_TRY(B.dpsz[i].reserve(8 * (size_t)(round_cap + 2))); VMX_TRY(B.dpoff[i].reserve(8 * (size_t)(round_cap + 2))); }
         VMX_TRY(B.dptab.reserve(sizeof(vmx_dp_prob) * (size_t)(round_cap + 1))); VMX_TRY(B.ciglen.reserve(4 * (size_t)(round_cap + 1))); VMX_TRY(B.cigq.reserve(4 * (size_t)(round_cap + 1))); VMX_TRY(B.dpscore.reserve(4 * (size_t)(round_cap + 1)));
-        const int G = c->num_cu * 4;
-        hipLaunchKernelGGL(k_dp_sizes, dim3(G), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.dpsz[0].as<int64_t>(), B.dpsz[1].as<int64_t>(),
-                           B.dpsz[2].as<int64_t>(), B.dpsz[3].as<int64_t>());
-        for (int i = 0; i < 4; ++i) VMX_TRY(dev_scan_dev(c, B, B.dpsz[i].as<int64_t>(), B.dpoff[i].as<int64_t>(), B.rcount.as<int32_t>()));
-        static const int64_t tb_chunk = [] { const char* e = getenv("VMX_TB_CHUNK_GB"); const double v = e ? atof(e) : 0.0; return v > 0.5 ? (int64_t)(v * (double)(1 << 30)) : (int64_t)VMX_TB_CHUNK; }();     // tuning knob
-        // sizing sync #3 (the only one of the round): problem count, pool totals, chunk cuts (at most VMX_TB_CHUNK traceback bytes per chunk)
-        int64_t plan[8 + 2 * (VMX_MAX_CHUNKS + 1)];
-        hipLaunchKernelGGL(k_tb_plan, dim3(1), dim3(1), 0, c->stream, B.dpoff[0].as<int64_t>(), B.dpoff[1].as<int64_t>(), B.dpoff[2].as<int64_t>(), B.dpoff[3].as<int64_t>(),
-                           B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.rcount.as<int32_t>(), tb_chunk, B.statblk.as<int64_t>() + 64);
-        VMX_TRY(vmx_fetch(c, plan, B.statblk.as<int64_t>() + 64, sizeof(plan) / 8));
-        VMX_HIP(vmx_stream_sync(c));
-        const int cnt = (int)plan[0];
-        int64_t totals[4] = {plan[1], plan[2], plan[3], plan[4]}, tq[2] = {plan[5], plan[6]};
-        if (plan[7] < 0) { set_error("gap fill: more traceback chunks than VMX_MAX_CHUNKS"); return VM_ERR_OOM; }
-        std::vector<int32_t> cuts; std::vector<int64_t> h_tboff_at;            // chunk q = problems [cuts[q], cuts[q+1]); traceback offset at every cut
-        for (int q = 0; q <= (int)plan[7]; ++q) { cuts.push_back((int32_t)plan[8 + q]); h_tboff_at.push_back(plan[8 + VMX_MAX_CHUNKS + 1 + q]); }
-        if (cuts.size() < 2) { cuts.assign(2, 0); h_tboff_at.assign(2, 0); }
-        int64_t tbmax = 0;
-        for (size_t q = 0; q + 1 < cuts.size(); ++q) tbmax = std::max(tbmax, h_tboff_at[q + 1] - h_tboff_at[q]);
-        VMX_TRY(B.tb.reserve((size_t)tbmax + 64)); VMX_TRY(B.bnd.reserve(4 * (size_t)(totals[1] + 4))); VMX_TRY(B.run.reserve(4 * (size_t)(totals[2] + 4))); VMX_TRY(B.cig.reserve((size_t)totals[3] + 16));
-        st.n_dp_problems += cnt; st.dp_cells += totals[0];
-        hipLaunchKernelGGL(k_dp_table, dim3(G), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(), B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.dpoff[0].as<int64_t>(),
-                           B.dpoff[1].as<int64_t>(), B.dpoff[2].as<int64_t>(), B.dpoff[3].as<int64_t>(), B.dptab.as<vmx_dp_prob>());
-        st.dp_string_bytes += tq[0] + tq[1];
+        VMX_TRY(B.order.reserve(4 * (size_t)(2 * round_cap + 64)));
+        if (!redo_only) {
+            // the second launch's pool, from the context's history
+            gf_redo_cap = std::max<int64_t>((int64_t)((double)c->redo_need_max * 1.3), std::min<int64_t>((int64_t)512 << 20, std::max<int64_t>(tb_chunk / 8, 1 << 20)));
+            if (const char* e = getenv("VMX_TEST_REDO_POOL_BYTES")) { const long long v = atoll(e); if (v > 0 && c->redo_need_max == 0) gf_redo_cap = v; }      // test hook: the first guess of a fresh context
+            VMX_TRY(B.tbredo.reserve((size_t)gf_redo_cap + 64));
+            gf_redo_cap = (int64_t)B.tbredo.cap - 64;
+        }
         c->n_gev[redo_only ? 1 : 0] = 0;
-        if (cnt) {
-            VMX_TRY(B.order.reserve(4 * (size_t)(2 * round_cap + 64))); VMX_TRY(B.qrange.reserve(128)); VMX_TRY(B.szh.reserve(4 * 520));
-            int32_t* d_range = B.qrange.as<int32_t>(); int32_t* d_cnt = d_range + 4;
-            unsigned long long* d_redo_bytes = (unsigned long long*)(d_range + 16);
-            int32_t* d_redo_list = B.order.as<int32_t>() + round_cap + 32; int32_t* d_redo_cnt = d_range + 12;     // problems whose band was not proven
-            std::vector<int32_t> csz; for (size_t q = 0; q + 1 < cuts.size(); ++q) csz.push_back(cuts[q + 1] - cuts[q]);
-            VMX_TRY(vmx_push(c, B.chunkn, csz.data(), csz.size()));
-            const int ad_pct = vmx_ad_pct_env(prm->mode);
-            int fill_waves = 16;                                  // waves per CU of the fill kernel (tuning knob: VMX_FILL_WAVES)
-            if (const char* e = getenv("VMX_FILL_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 32) fill_waves = v; }
-            for (size_t q = 0; q + 1 < cuts.size(); ++q) {
-                const int p0 = cuts[q], pn = cuts[q + 1] - cuts[q];
-                // the problems' absolute traceback offsets index a buffer that holds this chunk only
-                uint8_t* tb_base = B.tb.as<uint8_t>() - h_tboff_at[q];
-                hipEvent_t* ke = q < 8 ? c->gev + (redo_only ? 24 : 0) + 3 * q : nullptr;      // HIP events around the dominant kernel, on the stream it runs on
-                vmx_size_order_wide(c, B.dpsz[0].as<int64_t>() + p0, B.chunkn.as<int32_t>() + q, pn, (int64_t)VMX_HEAD_THRESH, B.order.as<int32_t>(), d_range, d_cnt, B.szh.as<int32_t>());
-                (void)hipMemsetAsync(d_redo_cnt, 0, 16, c->stream); (void)hipMemsetAsync(d_redo_bytes, 0, 8, c->stream);
-                if (ke) (void)hipEventRecord(ke[0], c->stream);
-                {
-                    vmx_lowprio lp(c);                            // the long launch at the lowest dispatch priority (vmx_host.h)
-                    hipLaunchKernelGGL(k_gapfill_fill_ns, dim3((unsigned)std::min<int64_t>(pn, (int64_t)c->num_cu * fill_waves)), dim3(64), 0, lp.stream(), B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
-                                       B.dptab.as<vmx_dp_prob>() + p0, pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_range, d_cnt,
-                                       d_redo_list, d_redo_cnt, 0, ad_pct, (uint8_t*)nullptr, d_redo_bytes);
-                    lp.join();
-                }
-                // sizing sync #4: full-matrix traceback space of the problems the first launch queued for the second one (a few per cent of them)
-                unsigned long long redo_bytes = 0; int32_t n_redo = 0;
-                int32_t qr[20];                                   // the queue block holds both numbers: one copy
-                VMX_TRY(vmx_fetch(c, qr, d_range, 20));
-                VMX_HIP(vmx_stream_sync(c));
-                n_redo = qr[12]; memcpy(&redo_bytes, &qr[16], 8);
-                VMX_TRY(B.tbredo.reserve((size_t)redo_bytes + 64));
-                st.dp_redo_tb_bytes += (int64_t)redo_bytes; st.n_dp_redo += n_redo; st.dp_cells += (int64_t)redo_bytes;
-                // second launch: the problems whose band was not proven (a few per cent), in full: the larger ones on a whole wave, the others four per wave
-                hipLaunchKernelGGL(k_gapfill_fill_ns, dim3((unsigned)std::min<int64_t>(std::max<int64_t>(n_redo, 1), (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
-                                   B.dptab.as<vmx_dp_prob>() + p0, pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_range, d_cnt,
-                                   d_redo_list, d_redo_cnt, 1, ad_pct, B.tbredo.as<uint8_t>(), d_redo_bytes);
-                if (ke) (void)hipEventRecord(ke[1], c->stream);
-                static const int tr_spread = [] { const char* e = getenv("VMX_TRACE_SPREAD"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 64 ? v : 1; }();
-                hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)(((int64_t)pn * tr_spread + 63) / 64)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>() + p0, pn, prm->eqx,
-                                   tb_base, B.run.as<uint32_t>(), B.cig.as<char>(), B.ciglen.as<int32_t>() + p0, B.dpscore.as<int32_t>() + p0, B.tbredo.as<uint8_t>(), tr_spread, B.cigq.as<int32_t>() + p0);
-                if (ke) { (void)hipEventRecord(ke[2], c->stream); c->n_gev[redo_only ? 1 : 0] = (int)q + 1; }
+        {
+            // ONE launch: string offsets, the four pool-size scans, the problem table and the chunk plan (at most VMX_TB_CHUNK traceback bytes per chunk), then the gather
+            int rcg = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, redo_only, round_cap, pool_cap, 6 + redo_only, true, tb_chunk, nullptr, B.statblk.as<int64_t>() + 64 + (redo_only ? 64 : 0));
+            if (rcg < 0) return rcg;
+            // the sizing wait of the batch: problem count, pool totals, chunk cuts
+            int64_t plan[8 + 2 * (VMX_MAX_CHUNKS + 1)];
+            VMX_TRY(vmx_fetch(c, plan, B.statblk.as<int64_t>() + 64 + (redo_only ? 64 : 0), sizeof(plan) / 8));
+            VMX_HIP(vmx_stream_sync(c));
+            const int cnt = (int)plan[0];
+            int64_t totals[4] = {plan[1], plan[2], plan[3], plan[4]};
+            if (plan[7] < 0) { set_error("gap fill: more traceback chunks than VMX_MAX_CHUNKS"); return VM_ERR_OOM; }
+            st.n_dp_problems += cnt; st.dp_cells += totals[0]; st.dp_string_bytes += plan[5] + plan[6];
+            std::vector<int32_t> cuts; std::vector<int64_t> h_tboff_at;            // chunk q = problems [cuts[q], cuts[q+1]); traceback offset at every cut
+            for (int q = 0; q <= (int)plan[7]; ++q) { cuts.push_back((int32_t)plan[8 + q]); h_tboff_at.push_back(plan[8 + VMX_MAX_CHUNKS + 1 + q]); }
+            if (cuts.size() < 2) { cuts.assign(2, 0); h_tboff_at.assign(2, 0); }
+            int64_t tbmax = 0;
+            for (size_t q = 0; q + 1 < cuts.size(); ++q) tbmax = std::max(tbmax, h_tboff_at[q + 1] - h_tboff_at[q]);
+            VMX_TRY(B.tb.reserve((size_t)tbmax + 64)); VMX_TRY(B.bnd.reserve(4 * (size_t)(totals[1] + 4))); VMX_TRY(B.run.reserve(4 * (size_t)(totals[2] + 4))); VMX_TRY(B.cig.reserve((size_t)totals[3] + 16));
+            if (cnt) {
+                std::vector<int32_t> csz; for (size_t q = 0; q + 1 < cuts.size(); ++q) csz.push_back(cuts[q + 1] - cuts[q]);
+                VMX_TRY(vmx_push(c, B.chunkn, csz.data(), csz.size()));
+                for (size_t q = 0; q + 1 < cuts.size(); ++q) VMX_TRY(gf_chunk(redo_only, (int)q, cuts[q], cuts[q + 1] - cuts[q], B.chunkn.as<int32_t>() + q, h_tboff_at[q]));
             }
         }
         A.redo_only = redo_only;
         A.spread = rec_spread;
         hipLaunchKernelGGL(k_ext_records, dim3((unsigned)n), dim3(64), 0, c->stream, A, B.dptab.as<vmx_dp_prob>(), B.cig.as<char>(), B.ciglen.as<int32_t>(), B.cigq.as<int32_t>());     // one wavefront per read
         cur ^= 1;
-        return cnt;
+        return 0;
     };
     // pass 0
     phase(0);
     {   // divergence filter: edit distance of every segment (:19251)
-        int rc0 = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, 0, round_cap, pool_cap, 0, false);
+        int rc0 = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, 0, round_cap, pool_cap, 0, false, 0);
         if (rc0 < 0) return rc0;
         const int64_t cnt = round_cap;                           // launch widths only: every kernel below reads the real count on the device
         {
@@ -617,29 +623,33 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
             (void)hipMemsetAsync(d_nfull, 0, 12, c->stream);
             hipLaunchKernelGGL(k_ed_anchor_bound, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, A, B.probread.as<int32_t>(),
                                B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.dpsz[1].as<int64_t>());
+            // Round 6: the tiers behind the anchor bound are hardly ever needed (problems left after tier 0 per batch: 0 on ONT and HiFi reads at hg38 size, 0.07 on the
+            // vacsim workload), yet every batch paid for them: two size-ordered banded launches, three flag passes, and a host wait to learn whether the exact kernel —
+            // whose wide workgroups wait for room on a full GPU even when empty — had anything to do. Now a batch runs tier 0 and ONE flag pass that marks the READ of every
+            // problem it could not settle (VMX_EXT_NEED_EXACT_DEV); align_device runs those reads again alone with all tiers (c->force_exact), exact kernel included.
+            static const bool always_all = getenv("VMX_FORCE_EXACT") != nullptr;        // A/B and test knob: every batch runs every tier
+            const bool all_tiers = c->force_exact || always_all;
             hipLaunchKernelGGL(k_ed_flag, dim3((unsigned)std::min<int64_t>((cnt + 255) / 256, 1024)), dim3(256), 0, c->stream, B.dpsz[1].as<int64_t>(), B.qoff.as<int64_t>(), B.toff.as<int64_t>(),
-                               B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_n1, 1);
+                               B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_n1, 1, B.probread.as<int32_t>(), all_tiers ? (vmx_ext_read*)nullptr : B.er.as<vmx_ext_read>());
+            if (all_tiers) {
             vmx_size_order_wide(c, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), cnt, (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt, B.szh.as<int32_t>());
             hipLaunchKernelGGL(k_ed_banded4, dim3((unsigned)std::min<int64_t>((cnt + 3) / 4, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(),
                                B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.order.as<int32_t>(), d_range, d_cnt + 2, B.dpsz[1].as<int64_t>());
             hipLaunchKernelGGL(k_ed_flag, dim3((unsigned)std::min<int64_t>((cnt + 255) / 256, 1024)), dim3(256), 0, c->stream, B.dpsz[1].as<int64_t>(), B.qoff.as<int64_t>(), B.toff.as<int64_t>(),
-                               B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_n2, 0);
+                               B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_n2, 0, (const int32_t*)nullptr, (vmx_ext_read*)nullptr);
             vmx_size_order_wide(c, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), cnt, (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt, B.szh.as<int32_t>());
             hipLaunchKernelGGL(k_ed_banded, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(),
                                B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.order.as<int32_t>(), d_range, d_cnt + 2, B.dpsz[1].as<int64_t>());
             hipLaunchKernelGGL(k_ed_flag, dim3((unsigned)std::min<int64_t>((cnt + 255) / 256, 1024)), dim3(256), 0, c->stream, B.dpsz[1].as<int64_t>(), B.qoff.as<int64_t>(), B.toff.as<int64_t>(),
-                               B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_nfull, 0);
+                               B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_nfull, 0, (const int32_t*)nullptr, (vmx_ext_read*)nullptr);
             vmx_size_order_wide(c, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), cnt, (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt, B.szh.as<int32_t>());
-            // the exact tier is hardly ever needed (0 problems per step on the bench workload), and its wide workgroups wait for room on a
-            // GPU the other batches keep full — an empty launch cost more than this 4-byte read-back does: launch only when something is left
-            int32_t h_nfull = 0;
-            VMX_TRY(vmx_fetch(c, &h_nfull, d_nfull, 1)); VMX_HIP(vmx_stream_sync(c));
-            if (h_nfull > 0)
+            // the exact tier, unconditionally (no read-back of the count: these are side batches of a few reads, or the A/B knob)
             for (int which = 0; which < 2; ++which)
                 hipLaunchKernelGGL(k_edit_distance, dim3((unsigned)std::min<int64_t>(cnt, ed_wgs * (which == 0 ? 1 : 2))), dim3(which == 0 ? 64 * VMX_ED_WAVES : 256), 0, c->stream,
                                    B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(), B.toff.as<int64_t>(),
                                    B.carry.as<int8_t>() + (which ? (size_t)VMX_ED_WAVES * (size_t)carry_stride * (size_t)ed_wgs : 0), B.order.as<int32_t>(), d_range, d_cnt, which,
                                    B.edout.as<int64_t>(), carry_stride, B.oflow.as<int32_t>());
+            }
         }
         cur ^= 1;
     }
@@ -652,9 +662,14 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     phase(5); VMX_TRY(gapfill(0));
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));
     // pass 1: reads whose CIGARs carry paired indels are re-run with nofilter (:24079-24080)
-    A.redo_only = 1;
-    phase(3); phase(4); phase(5); VMX_TRY(gapfill(1));
-    A.redo_only = 0;
+    int64_t test_side_every = 0; if (const char* e = getenv("VMX_TEST_SIDE_EVERY")) test_side_every = atoll(e);      // test hook: every k-th read of a batch is sent through the side batch
+    static const bool always_pass1 = getenv("VMX_FORCE_PASS1") != nullptr;        // A/B and test knob: every batch runs pass 1 (rounds 1-5)
+    const bool do_pass1 = c->run_pass1 || always_pass1;
+    if (do_pass1) {
+        A.redo_only = 1;
+        phase(3); phase(4); phase(5); VMX_TRY(gapfill(1));
+        A.redo_only = 0;
+    }
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));
 
     // ---------------- results
@@ -684,12 +699,27 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     struct OutGuard { vm_record** r; char** b; bool keep = false; ~OutGuard() { if (!keep) { free(*r); free(*b); *r = nullptr; *b = nullptr; } } } out_guard{recs, cigar_blob};
     if (!*recs || !*cigar_blob) { set_error("out of host memory"); return VM_ERR_OOM; }
     VMX_TRY(vmx_fetch(c, fin, B.statblk.as<int64_t>() + 32, 14));          // record / blob totals, overflow flag, tier counters, per-round problem counts: one copy
+    std::vector<int32_t> h_ctl(gfctl_bytes / 4);
+    VMX_TRY(vmx_fetch(c, h_ctl.data(), B.gfctl.p, h_ctl.size()));          // the gap fill's per-chunk control blocks (second-launch queue length and pool need)
     VMX_TRY(vmx_fetch(c, er.data(), B.er.p, (size_t)n)); VMX_TRY(vmx_fetch(c, h_gmax.data(), B.gmax.p, (size_t)n));
     VMX_TRY(vmx_fetch(c, *recs, B.totals.p, (size_t)g_nr)); VMX_TRY(vmx_fetch(c, *cigar_blob, B.dupd.p, (size_t)g_nb));
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));
     VMX_HIP(vmx_stream_sync(c));
     VMX_HIP(hipGetLastError());
     nr = fin[0]; nb = fin[1]; oflow = (int32_t)fin[2]; n_full = (int32_t)fin[3]; n_t2 = (int32_t)fin[4]; n_t1 = (int32_t)fin[5];
+    {   // what the gap fill assumed instead of asking (above): did it hold?
+        bool again = false; int64_t need_max = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int q = 0; q < gf_chunks[pass]; ++q) {
+                const int32_t* ctl = h_ctl.data() + (size_t)(pass * (VMX_MAX_CHUNKS + 1) + q) * GF_SLOT;
+                unsigned long long rb = 0; memcpy(&rb, ctl + 16, 8);
+                st.n_dp_redo += ctl[12]; st.dp_redo_tb_bytes += (int64_t)rb; st.dp_cells += (int64_t)rb;
+                need_max = std::max<int64_t>(need_max, (int64_t)rb);
+            }
+        c->redo_need_max = std::max<long long>(c->redo_need_max, need_max);
+        if (need_max > gf_redo_cap) { again = true; if (getenv("VMX_DBG_POOLS")) fprintf(stderr, "[pools] gap fill: a chunk's second launch needs %.3f GB of traceback space, the pool held %.3f: running the batch again\n", need_max / 1e9, gf_redo_cap / 1e9); }
+        if (again) return VMX_RETRY_BATCH;
+    }
     for (int i = 0; i < 8; ++i) hstat[i] = fin[6 + i];
     st.n_segments = hstat[0]; st.n_ed_problems = hstat[0]; st.n_ext_problems = (int64_t)hstat[1] + hstat[2] + hstat[3] + hstat[4];
     st.n_ed_full = n_full; st.n_ed_tier2 = n_t2; st.n_ed_tier1 = n_t1;
@@ -703,7 +733,9 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     }
     if (n > 0 && total_bases > 0) { c->res_rec_per_read = std::max(c->res_rec_per_read, (double)nr / (double)n); c->res_blob_per_base = std::max(c->res_blob_per_base, (double)nb / (double)total_bases); }
     for (int64_t r = 0; r < n; ++r) {
-        int stt2 = er[r].status == VMX_EXT_CAPACITY_DEV ? VMX_EXT_SHORT_INTERNAL : er[r].status;      // (align_device runs these reads again alone, with larger pools)
+        int stt2 = er[r].status == VMX_EXT_CAPACITY_DEV ? VMX_EXT_SHORT_INTERNAL : (er[r].status == VMX_EXT_NEED_EXACT_DEV ? VMX_EXT_EXACT_INTERNAL : er[r].status);
+        if (stt2 == 0 && !do_pass1 && er[r].active && er[r].redo == 1 && er[r].pass == 1) stt2 = VMX_EXT_EXACT_INTERNAL;      // asks for pass 1, which this batch did not run: again, alone
+        if (stt2 == 0 && test_side_every > 0 && !c->force_exact && r % test_side_every == 0) stt2 = VMX_EXT_EXACT_INTERNAL;       // (test hook)      // (align_device runs these reads again alone: larger pools / all tiers of the divergence filter)
         if (h_gmax[r] == -2 && (h_aoff[r + 1] - h_aoff[r]) > 2) stt2 = VM_READ_RAISED;     // GC-fast: the reference raises on this read (k_chain_fast.hip)
         if (h_gmax[r] == -4) stt2 = VM_READ_UNSUPPORTED;                                    // -mode asm: a contig of 500 kb or more inside align_device (vm_align_batch routes those to vmx_asm.hip)
         if (!asm_override.empty() && asm_override[(size_t)r] != 0) stt2 = asm_override[(size_t)r];
@@ -789,7 +821,7 @@ static int align_in_sub_batches(int64_t n, const int64_t* offsets, int64_t max_b
             tot.ms_total += st.ms_total; for (int i = 0; i < 16; ++i) tot.ms_stage[i] += st.ms_stage[i];
             tot.ms_gapfill_fill += st.ms_gapfill_fill; tot.ms_gapfill_trace += st.ms_gapfill_trace; tot.n_gapfill_launches += st.n_gapfill_launches;
             tot.n_ed_full += st.n_ed_full; tot.n_ed_tier2 += st.n_ed_tier2; tot.n_ed_tier1 += st.n_ed_tier1;
-            tot.n_dp_redo += st.n_dp_redo; tot.dp_redo_tb_bytes += st.dp_redo_tb_bytes; tot.ms_local_seed += st.ms_local_seed; tot.ms_cluster += st.ms_cluster; tot.n_host_syncs += st.n_host_syncs; tot.n_local_general += st.n_local_general; tot.n_ext_retries += st.n_ext_retries;
+            tot.n_dp_redo += st.n_dp_redo; tot.dp_redo_tb_bytes += st.dp_redo_tb_bytes; tot.ms_local_seed += st.ms_local_seed; tot.ms_cluster += st.ms_cluster; tot.n_host_syncs += st.n_host_syncs; tot.n_local_general += st.n_local_general; tot.n_ext_retries += st.n_ext_retries; tot.n_batch_retries += st.n_batch_retries;
         }
     }
     *recs = (vm_record*)malloc(sizeof(vm_record) * std::max<size_t>(all.size(), 1)); *cigar_blob = (char*)malloc(std::max<size_t>(blob.size(), 1));

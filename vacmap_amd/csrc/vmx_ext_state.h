@@ -32,6 +32,7 @@ struct vmx_ext_args {
     int32_t* seg_prob; int32_t* dup;
     // problems of the current round
     vmx_pair_desc* desc; const vmx_pair_desc* desc_prev; int32_t* round_count; int64_t round_cap; int32_t* overflow;
+    int32_t* prob_read;          // owner (read) of every problem slot of the round, written when the slots are allocated
     const int64_t* ed_out; const int32_t* ext_te; const int32_t* ext_qe;
     // records
     vm_record* rec; char* rec_blob; const int64_t* blob_off; int64_t* rec_coff; int32_t* rec_clen; double* dup_d;

@@ -13,6 +13,10 @@
 // a pool of the EXTEND stage was too small for this read: the batch is run again with larger pools (vmx_align.hip, align_device); a read that still
 // carries the code when the retries are used up is reported as VM_READ_CAPACITY like a local-stage one
 #define VMX_EXT_CAPACITY_DEV (-24)
+// a segment of this read reached the last (exact, unbanded) tier of the divergence filter in a batch that does not launch it: the read is run again alone with the
+// exact tier (vmx_align.hip, align_device); never leaves the library
+#define VMX_EXT_NEED_EXACT_DEV (-25)
+static_assert(VMX_EXT_NEED_EXACT_DEV != VM_READ_FASTPATH_DEV && VMX_EXT_NEED_EXACT_DEV != VM_READ_CAPACITY_DEV && VMX_EXT_NEED_EXACT_DEV != VM_READ_RAISED_DEV && VMX_EXT_NEED_EXACT_DEV != -22, "distinct device codes");
 static_assert(VMX_EXT_CAPACITY_DEV != VM_READ_FASTPATH_DEV && VMX_EXT_CAPACITY_DEV != VM_READ_CAPACITY_DEV && VMX_EXT_CAPACITY_DEV != VM_READ_RAISED_DEV && VMX_EXT_CAPACITY_DEV != -22,
               "the internal per-read device codes must be distinct (E.status is seeded from the local stage's status)");
 #ifndef __host__

@@ -149,6 +149,10 @@ struct vm_ctx {
     int kev_set = 0;                              // bit 0: [0,1] recorded, bit 1: [2,3] recorded
     int64_t n_bandfall = 0;                       // reads k_local_seed_band handed back to k_local_seed (reset per batch)
     int ext_mul = 1;                              // extend-stage pool multiplier of the running call (grow-and-retry in align_device)
+    long long redo_need_max = 0;                  // largest full-matrix traceback need of one gap-fill chunk this context has seen (sizes the second launch's pool)
+    bool run_pass1 = false;                       // this call runs pass 1 of the extend stage (the nofilter re-run; side batches of align_device)
+    bool force_exact = false;                     // this call launches the exact edit-distance tier whatever the banded tiers left (side batches of align_device)
+    long long round_epoch = 0;                    // launches of k_round_prep by this context (k_round.hip: its publication flags carry the launch number)
     int64_t n_syncs = 0;                          // host waits on this context's stream (reset per batch)
     int64_t sync_wait_ns = 0, call_t0_ns = 0;     // time inside those waits; wall clock at the start of the batch (tuning: ms_stage[14] / [15])
     double res_rec_per_read = 0.0, res_blob_per_base = 0.0;   // largest records per read / CIGAR bytes per base a batch of this context produced (result copy size guess)
@@ -260,7 +264,7 @@ struct vmx_ext_args;
 __global__ void k_ed_banded4(const uint8_t* qcodes, const int64_t* q_off, const uint8_t* tcodes, const int64_t* t_off, const int32_t* order,
                              const int32_t* range, int32_t* counter, int64_t* ub_out);
 __global__ void k_ed_flag(const int64_t* ub, const int64_t* q_off, const int64_t* t_off, const int32_t* n_ptr, double maxdiv, int64_t* sizes,
-                          int64_t* ed_out, int32_t* n_flagged, int first);
+                          int64_t* ed_out, int32_t* n_flagged, int first, const int32_t* prob_read, struct vmx_ext_read* er);
 __global__ void k_extend(const uint8_t* tcodes, const int64_t* t_off, const uint8_t* qcodes, const int64_t* q_off, int n_prob,
                          int match, int mismatch, int o, int e, int bw_in, int zdrop, int32_t* out_te, int32_t* out_qe, int32_t* out_sc, const int32_t* n_ptr);
 __global__ void k_gapfill_fill(const uint8_t* tcodes, const uint8_t* qcodes, const vmx_dp_prob* probs, int n_prob, int match,
@@ -269,7 +273,7 @@ __global__ void k_gapfill_fill(const uint8_t* tcodes, const uint8_t* qcodes, con
 __global__ void k_gapfill_fill_ns(const uint8_t* tcodes, const uint8_t* qcodes, vmx_dp_prob* probs, int n_prob, int match,
                                   int mismatch, int o1, int e1, int o2, int e2, uint8_t* tb_pool, int32_t* bnd_pool, int32_t* out_score,
                                   const int32_t* order, const int32_t* range, int32_t* counter, int32_t* redo_list, int32_t* redo_cnt, int redo_pass, int ad_pct,
-                                  uint8_t* redo_pool, unsigned long long* redo_bytes);
+                                  uint8_t* redo_pool, unsigned long long* redo_bytes, const int32_t* n_ptr = nullptr, unsigned long long redo_cap = ~0ULL);
 // band-width rule of the anti-diagonal gap fill (vmx_ad_ns): pct | pct_min << 16; tuning knobs VMX_AD_PCT / VMX_AD_PCT_MIN
 // (round 4: the default follows the read mode — HiFi problems score near the all-match bound, so a band whose margin covers 40 % of the problem
 // is proven as often as one that covers 100 %: fill 7.0 -> 6.0 ms per batch; ONT modes 100 -> 90: 8.9 -> 8.6; profiles/r04_x_*)
@@ -280,7 +284,7 @@ static inline int vmx_ad_pct_env(int mode = 0) {
     return pct | (pmin << 16);
 }
 __global__ void k_gapfill_trace(const uint8_t* tcodes, const uint8_t* qcodes, const vmx_dp_prob* probs, int n_prob, int eqx,
-                                const uint8_t* tb_pool, uint32_t* run_pool, char* cig_pool, int32_t* cig_len, const int32_t* band_flag, const uint8_t* redo_pool, int spread, int32_t* cig_q);
+                                const uint8_t* tb_pool, uint32_t* run_pool, char* cig_pool, int32_t* cig_len, const int32_t* band_flag, const uint8_t* redo_pool, int spread, int32_t* cig_q, const int32_t* n_ptr = nullptr);
 __global__ void k_flip_sort(const int64_t* rows, const int64_t* aoff, const int64_t* readlens, int n_reads, uint64_t* key_pool,
                             const int64_t* key_off, vmx_anchor* sorted, int32_t* need_reverse);
 __global__ void k_chain_global(const vmx_anchor* anchors, const int64_t* aoff, const int32_t* rlist, int nlist, int lds_cap,

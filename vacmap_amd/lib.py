@@ -73,7 +73,7 @@ class BatchStats(C.Structure):
                                           'dp_string_bytes')] + \
                [('ms_total', C.c_double), ('ms_stage', C.c_double * 16), ('ms_gapfill_fill', C.c_double), ('ms_gapfill_trace', C.c_double),
                 ('n_gapfill_launches', C.c_int64), ('n_ed_full', C.c_int64), ('n_ed_tier2', C.c_int64), ('n_ed_tier1', C.c_int64),
-                ('n_dp_redo', C.c_int64), ('dp_redo_tb_bytes', C.c_int64), ('ms_local_seed', C.c_double), ('ms_cluster', C.c_double), ('n_host_syncs', C.c_int64), ('n_local_general', C.c_int64), ('n_ext_retries', C.c_int64)]
+                ('n_dp_redo', C.c_int64), ('dp_redo_tb_bytes', C.c_int64), ('ms_local_seed', C.c_double), ('ms_cluster', C.c_double), ('n_host_syncs', C.c_int64), ('n_local_general', C.c_int64), ('n_ext_retries', C.c_int64), ('n_batch_retries', C.c_int64)]
 
 
 def _b(s):
