@@ -140,7 +140,7 @@ static int ext_gather_round(vm_ctx* c, vmx_batch_bufs& B, const vm_index_view& i
     (void)n; (void)redo_only; (void)round_cap;    // (the slots' owners are written when the phase kernel allocates them; vmx_alloc_probs never lets the published count pass the capacity)
     if (!B.roundpart.p) { VMX_TRY(B.roundpart.reserve(8 * (size_t)VMX_ROUND_PART_WORDS)); VMX_HIP(hipMemsetAsync(B.roundpart.p, 0, 8 * (size_t)VMX_ROUND_PART_WORDS, c->stream)); }
     vmx_round_args R; memset(&R, 0, sizeof R);
-    R.desc = B.desc[cur].as<vmx_pair_desc>(); R.n_prob = B.rcount.as<int32_t>();
+    R.desc = B.desc[cur].as<vmx_pair_desc>(); R.n_prob = c->rc_cur;
     R.off[0] = B.toff.as<int64_t>(); R.off[1] = B.qoff.as<int64_t>();
     R.part = B.roundpart.as<int64_t>(); R.stat_out = B.statblk.as<int32_t>() + stat_slot; R.epoch = ++c->round_epoch;
     if (dp) {
@@ -150,7 +150,7 @@ static int ext_gather_round(vm_ctx* c, vmx_batch_bufs& B, const vm_index_view& i
         hipLaunchKernelGGL(k_round_prep<true>, dim3(VMX_ROUND_WGS), dim3(256), 0, c->stream, R);
     } else
         hipLaunchKernelGGL(k_round_prep<false>, dim3(VMX_ROUND_WGS), dim3(256), 0, c->stream, R);
-    hipLaunchKernelGGL(k_gather, dim3((unsigned)((int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), B.rcount.as<int32_t>(),
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)((int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, B.desc[cur].as<vmx_pair_desc>(), c->rc_cur,
                        B.probread.as<int32_t>(), d_ocodes, d_roff, ix.codes, B.toff.as<int64_t>(), B.qoff.as<int64_t>(), B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), pool_cap,
                        B.er.as<vmx_ext_read>());
     return 0;
@@ -205,7 +205,11 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
     for (int64_t r = 0; r < n; ++r) if (status[(size_t)r] == VMX_EXT_SHORT_INTERNAL || status[(size_t)r] == VMX_EXT_EXACT_INTERNAL) sub.push_back((int32_t)r);
     if (!sub.empty()) {
         vmx_batch_bufs& B = *batch_bufs(c);
-        std::vector<vm_record> all(*recs, *recs + *n_recs);
+        std::vector<vm_record> all; all.reserve((size_t)*n_recs);
+        {   // (a read that is run again delivers its records from there: the batch's own — none, for every real reason to run a read again — are dropped)
+            std::vector<char> again((size_t)n + 1, 0); for (int32_t r : sub) again[(size_t)r] = 1;
+            for (int64_t i = 0; i < *n_recs; ++i) if (!again[(size_t)(*recs)[i].read_idx]) all.push_back((*recs)[i]);
+        }
         int64_t blob_n = 0; for (const vm_record& x : all) blob_n = std::max<int64_t>(blob_n, x.cigar_off + x.cigar_len + 1);
         std::string blob(*cigar_blob, (size_t)blob_n);
         free(*recs); free(*cigar_blob); *recs = nullptr; *cigar_blob = nullptr; *n_recs = 0;
@@ -439,8 +443,8 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
         bloboff[r + 1] = bloboff[r] + (cl > 0 ? ((pool(4, 3 * len + 64 * (cl / 2 + 2) + 56) + 7) & ~(int64_t)7) : 0);
     }
     const int64_t cA = coff3[n], cS = soff2[n], cB = bloboff[n];
-    VMX_TRY(B.er.reserve(sizeof(vmx_ext_read) * (size_t)(n + 1))); VMX_TRY(vmx_push(c, B.coff3, coff3.data(), (size_t)n + 1)); VMX_TRY(vmx_push(c, B.soff2, soff2.data(), (size_t)n + 1));
-    VMX_TRY(vmx_push(c, B.bloboff, bloboff.data(), (size_t)n + 1));
+    VMX_TRY(B.er.reserve(sizeof(vmx_ext_read) * (size_t)(n + 1)));
+    { const vmx_push_req rq[3] = {{&B.coff3, coff3.data(), 8 * ((size_t)n + 1)}, {&B.soff2, soff2.data(), 8 * ((size_t)n + 1)}, {&B.bloboff, bloboff.data(), 8 * ((size_t)n + 1)}}; VMX_TRY(vmx_push_many(c, rq, 3)); }
     VMX_TRY(B.segA.reserve(sizeof(vmx_anchor) * (size_t)(cA + 1))); VMX_TRY(B.segA_s.reserve(sizeof(vmx_anchor) * (size_t)(cA + 1)));
     VMX_TRY(B.st.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.en.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.st_s.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.en_s.reserve(4 * (size_t)(cS + 1)));
     VMX_TRY(B.segprob.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.dup.reserve(4 * (size_t)(cS + 1)));
@@ -453,7 +457,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     const int64_t ed_wgs = std::min<int64_t>(c->num_cu, 64);   // workgroups of the exact kernel (x1 long, x2 short patterns): the last tier of the filter, hardly ever
                                                                // reached (0 problems per step on the bench workload), so its carry rings are kept small (0.8 instead of 3.2 GB)        // exact edit-distance kernel: one carry ring per workgroup (1 + 2 per CU), longest text it takes
     VMX_TRY(B.desc[0].reserve(sizeof(vmx_pair_desc) * (size_t)round_cap)); VMX_TRY(B.desc[1].reserve(sizeof(vmx_pair_desc) * (size_t)round_cap));
-    VMX_TRY(B.rcount.reserve(64)); VMX_TRY(B.oflow.reserve(64)); VMX_TRY(B.probread.reserve(4 * (size_t)round_cap));
+    VMX_TRY(B.rcount.reserve(256)); VMX_HIP(hipMemsetAsync(B.rcount.p, 0, 256, c->stream)); c->rc_next = 0; c->rc_cur = B.rcount.as<int32_t>(); VMX_TRY(B.oflow.reserve(64)); VMX_TRY(B.probread.reserve(4 * (size_t)round_cap));
     VMX_TRY(B.tl.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.ql.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.toff.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.qoff.reserve(8 * (size_t)(round_cap + 1)));
     VMX_TRY(B.tpool.reserve((size_t)pool_cap + 64)); VMX_TRY(B.qpool.reserve((size_t)pool_cap + 64));
     VMX_TRY(B.edout.reserve(8 * (size_t)(round_cap + 1))); VMX_TRY(B.carry.reserve((size_t)VMX_ED_WAVES * (size_t)carry_stride * (size_t)ed_wgs * 3 + 64)); VMX_TRY(B.ext3.reserve(12 * (size_t)(round_cap + 1)));
@@ -484,7 +488,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     static const bool ext_wave = [] { const char* e = getenv("VMX_EXT_WAVE"); return !(e && atoi(e) == 0); }();
     int cur = 0;
     auto phase = [&](int ph) { A.desc = B.desc[cur].as<vmx_pair_desc>(); A.desc_prev = B.desc[cur ^ 1].as<vmx_pair_desc>();
-                               (void)hipMemsetAsync(B.rcount.p, 0, 4, c->stream);
+                               c->rc_cur = B.rcount.as<int32_t>() + (c->rc_next++ & 63); A.round_count = c->rc_cur;      // a fresh, already cleared counter per phase (one clearing per batch)
                                // the phases that walk every anchor (0 rebuild, 3 snapshot copy, 5 checkpoints) run one wavefront per read; VMX_EXT_WAVE=0: the one-lane form
                                const bool wv = ext_wave && (ph == 0 || ph == 3 || ph == 5);
                                A.spread = wv ? 64 : ext_spread; hipLaunchKernelGGL(k_ext_phase, dim3(wv ? (unsigned)n : gridX), dim3(64), 0, c->stream, A, ph);
@@ -511,7 +515,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
         int rc = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, redo_only, round_cap, pool_cap, 1 + ext_rounds++, false, 0);
         if (rc < 0) return rc;
         hipLaunchKernelGGL(k_extend, dim3((unsigned)((int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.qpool.as<uint8_t>(),
-                           B.qoff.as<int64_t>(), 0, 2, -4, 4, 4, 100, 50, B.ext3.as<int32_t>(), B.ext3.as<int32_t>() + round_cap, B.ext3.as<int32_t>() + 2 * round_cap, B.rcount.as<int32_t>());
+                           B.qoff.as<int64_t>(), 0, 2, -4, 4, 4, 100, 50, B.ext3.as<int32_t>(), B.ext3.as<int32_t>() + round_cap, B.ext3.as<int32_t>() + 2 * round_cap, c->rc_cur);
         cur ^= 1;
         return 0;
     };
@@ -630,19 +634,19 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
             static const bool always_all = getenv("VMX_FORCE_EXACT") != nullptr;        // A/B and test knob: every batch runs every tier
             const bool all_tiers = c->force_exact || always_all;
             hipLaunchKernelGGL(k_ed_flag, dim3((unsigned)std::min<int64_t>((cnt + 255) / 256, 1024)), dim3(256), 0, c->stream, B.dpsz[1].as<int64_t>(), B.qoff.as<int64_t>(), B.toff.as<int64_t>(),
-                               B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_n1, 1, B.probread.as<int32_t>(), all_tiers ? (vmx_ext_read*)nullptr : B.er.as<vmx_ext_read>());
+                               c->rc_cur, prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_n1, 1, B.probread.as<int32_t>(), all_tiers ? (vmx_ext_read*)nullptr : B.er.as<vmx_ext_read>());
             if (all_tiers) {
-            vmx_size_order_wide(c, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), cnt, (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt, B.szh.as<int32_t>());
+            vmx_size_order_wide(c, B.dpsz[0].as<int64_t>(), c->rc_cur, cnt, (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt, B.szh.as<int32_t>());
             hipLaunchKernelGGL(k_ed_banded4, dim3((unsigned)std::min<int64_t>((cnt + 3) / 4, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(),
                                B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.order.as<int32_t>(), d_range, d_cnt + 2, B.dpsz[1].as<int64_t>());
             hipLaunchKernelGGL(k_ed_flag, dim3((unsigned)std::min<int64_t>((cnt + 255) / 256, 1024)), dim3(256), 0, c->stream, B.dpsz[1].as<int64_t>(), B.qoff.as<int64_t>(), B.toff.as<int64_t>(),
-                               B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_n2, 0, (const int32_t*)nullptr, (vmx_ext_read*)nullptr);
-            vmx_size_order_wide(c, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), cnt, (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt, B.szh.as<int32_t>());
+                               c->rc_cur, prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_n2, 0, (const int32_t*)nullptr, (vmx_ext_read*)nullptr);
+            vmx_size_order_wide(c, B.dpsz[0].as<int64_t>(), c->rc_cur, cnt, (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt, B.szh.as<int32_t>());
             hipLaunchKernelGGL(k_ed_banded, dim3((unsigned)std::min<int64_t>(cnt, (int64_t)c->num_cu * 16)), dim3(64), 0, c->stream, B.qpool.as<uint8_t>(), B.qoff.as<int64_t>(),
                                B.tpool.as<uint8_t>(), B.toff.as<int64_t>(), B.order.as<int32_t>(), d_range, d_cnt + 2, B.dpsz[1].as<int64_t>());
             hipLaunchKernelGGL(k_ed_flag, dim3((unsigned)std::min<int64_t>((cnt + 255) / 256, 1024)), dim3(256), 0, c->stream, B.dpsz[1].as<int64_t>(), B.qoff.as<int64_t>(), B.toff.as<int64_t>(),
-                               B.rcount.as<int32_t>(), prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_nfull, 0, (const int32_t*)nullptr, (vmx_ext_read*)nullptr);
-            vmx_size_order_wide(c, B.dpsz[0].as<int64_t>(), B.rcount.as<int32_t>(), cnt, (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt, B.szh.as<int32_t>());
+                               c->rc_cur, prm->maxdivergence, B.dpsz[0].as<int64_t>(), B.edout.as<int64_t>(), d_nfull, 0, (const int32_t*)nullptr, (vmx_ext_read*)nullptr);
+            vmx_size_order_wide(c, B.dpsz[0].as<int64_t>(), c->rc_cur, cnt, (int64_t)VMX_ED_LONG, B.order.as<int32_t>(), d_range, d_cnt, B.szh.as<int32_t>());
             // the exact tier, unconditionally (no read-back of the count: these are side batches of a few reads, or the A/B knob)
             for (int which = 0; which < 2; ++which)
                 hipLaunchKernelGGL(k_edit_distance, dim3((unsigned)std::min<int64_t>(cnt, ed_wgs * (which == 0 ? 1 : 2))), dim3(which == 0 ? 64 * VMX_ED_WAVES : 256), 0, c->stream,

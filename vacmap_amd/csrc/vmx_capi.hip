@@ -56,6 +56,64 @@ __global__ void k_signal(unsigned long long* word, unsigned long long v) {
     __hip_atomic_store(word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 #endif
 }
+// every piece is cut into 16 KB slices dealt round-robin to the workgroups; the last workgroup to finish publishes the sequence word (system scope: the host polls it)
+__global__ void __launch_bounds__(256) k_export(vmx_export_args A) {
+    __shared__ int s_last;
+    const unsigned G = gridDim.x, b = blockIdx.x;
+    unsigned long long slice0 = 0;
+    for (int p = 0; p < A.n; ++p) {
+        const unsigned long long nb = A.bytes[p], ns = (nb + 16383ULL) >> 14;
+        for (unsigned long long sl = (b + G - (unsigned)(slice0 % G)) % G; sl < ns; sl += G) {
+            const unsigned long long lo = sl << 14, hi = lo + 16384ULL < nb ? lo + 16384ULL : nb;
+            const char* s = A.src[p] + lo; char* d = A.dst[p] + lo;
+            const unsigned long long n = hi - lo;
+            if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+                const unsigned long long nv = n >> 4;
+                struct b16 { unsigned long long x, y; };
+                for (unsigned long long i = threadIdx.x; i < nv; i += blockDim.x) ((b16*)d)[i] = ((const b16*)s)[i];
+                for (unsigned long long i = (nv << 4) + threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+            } else for (unsigned long long i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+        }
+        slice0 += ns;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#ifdef VMX_EMU
+        const unsigned long long old = __atomic_fetch_add(A.done, 1ULL, __ATOMIC_ACQ_REL);
+#else
+        __threadfence_system();
+        const unsigned long long old = __hip_atomic_fetch_add(A.done, 1ULL, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        s_last = old + 1ULL == (unsigned long long)G;
+        if (s_last) {
+#ifdef VMX_EMU
+            *A.done = 0ULL; *A.word = A.seq;
+#else
+            __hip_atomic_store(A.done, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(A.word, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+        }
+    }
+}
+// the pieces of an upload group out of the ring (device-mapped host memory) into their places, 16 KB slices dealt round-robin to the workgroups
+__global__ void __launch_bounds__(256) k_import(vmx_import_args A) {
+    const unsigned G = gridDim.x, b = blockIdx.x;
+    unsigned long long slice0 = 0;
+    for (int p = 0; p < A.n; ++p) {
+        const unsigned long long nb = A.bytes[p], ns = (nb + 16383ULL) >> 14;
+        for (unsigned long long sl = (b + G - (unsigned)(slice0 % G)) % G; sl < ns; sl += G) {
+            const unsigned long long lo = sl << 14, hi = lo + 16384ULL < nb ? lo + 16384ULL : nb, n = hi - lo;
+            const char* s = A.src[p] + lo; char* d = A.dst[p] + lo;
+            if ((((uintptr_t)s | (uintptr_t)d) & 7) == 0) {
+                const unsigned long long nv = n >> 3;
+                for (unsigned long long i = threadIdx.x; i < nv; i += blockDim.x) ((unsigned long long*)d)[i] = ((const unsigned long long*)s)[i];
+                for (unsigned long long i = (nv << 3) + threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+            } else for (unsigned long long i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+        }
+        slice0 += ns;
+    }
+}
 static int mailbox_create(vm_ctx* c) {
     vmx_mailbox& m = c->mb;
     const char* mode = getenv("VMX_WAIT_MODE");
@@ -68,18 +126,42 @@ static int mailbox_create(vm_ctx* c) {
     if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(hp); m.on = false; return 0; }
     memset(hp, 0, 4096);
     m.h = (char*)hp; m.d = (char*)dp; m.up_off = 4096; m.up_cap = up; m.dn_off = 4096 + up; m.dn_cap = dn; m.on = true;
+    void* dc = nullptr;
+    if (hipMalloc(&dc, 64) == hipSuccess) { (void)hipMemset(dc, 0, 64); m.done_ctr = (unsigned long long*)dc; } else (void)hipGetLastError();      // (without it: copies + k_signal)
     return 0;
 }
 static void mailbox_destroy(vm_ctx* c) {
     vmx_mailbox& m = c->mb;
     if (m.h) (void)hipHostFree(m.h);
     if (m.big) (void)hipHostFree(m.big);
+    if (m.done_ctr) (void)hipFree(m.done_ctr);
     m = vmx_mailbox();
 }
 int vmx_mailbox_wait(vm_ctx* c) {
     vmx_mailbox& m = c->mb;
     const unsigned long long want = ++m.seq;
-    hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, c->stream, (unsigned long long*)m.d, want);
+    {   // the noted downloads: one kernel per VMX_EXPORT_MAX pieces, the last of them carries the sequence word (no piece: the bare signal)
+        vmx_export_args E; memset(&E, 0, sizeof E);
+        unsigned long long tot = 0; bool signalled = false;
+        auto flush = [&](bool last) {
+            if (!E.n && !last) return;
+            if (!E.n) { hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, c->stream, (unsigned long long*)m.d, want); signalled = true; return; }
+            // the word of a kernel that is not the last one of this wait is a scratch word of the mailbox (offset 64): only the last launch moves the real one
+            E.word = (unsigned long long*)(m.d + (last ? 0 : 64)); E.seq = want; E.done = m.done_ctr;
+            const unsigned G = (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>((tot + 16383ULL) >> 14, 64ULL));
+            hipLaunchKernelGGL(k_export, dim3(G), dim3(256), 0, c->stream, E);
+            if (last) signalled = true;
+            memset(&E, 0, sizeof E); tot = 0;
+        };
+        size_t left = 0; for (const vmx_mailbox::Pending& p : m.pend) left += p.dev ? 1 : 0;
+        for (const vmx_mailbox::Pending& p : m.pend) {
+            if (!p.dev) continue;
+            const char* land_d = (p.src >= m.h && p.src < m.h + m.dn_off + m.dn_cap) ? m.d + (p.src - m.h) : m.big_d + (p.src - m.big);
+            E.src[E.n] = (const char*)p.dev; E.dst[E.n] = (char*)land_d; E.bytes[E.n] = p.bytes; ++E.n; tot += p.bytes; --left;
+            if (E.n == VMX_EXPORT_MAX) flush(left == 0);
+        }
+        if (!signalled) flush(true);
+    }
     volatile unsigned long long* w = (volatile unsigned long long*)m.h;
     struct timespec ts; ts.tv_sec = 0; ts.tv_nsec = (long)m.poll_ns;
     long long slept = 0, next_query = 500000000LL;
@@ -104,10 +186,13 @@ int vmx_fetch_bytes(vm_ctx* c, void* host, const void* dev, size_t bytes) {
     else {
         const size_t bat = (m.big_used + 63) & ~(size_t)63;
         if (bat + bytes > m.big_cap && m.big_used == 0) {             // grow the landing block while nothing is on its way into it
-            if (m.big) { (void)hipHostFree(m.big); m.big = nullptr; m.big_cap = 0; }
+            if (m.big) { (void)hipHostFree(m.big); m.big = nullptr; m.big_cap = 0; m.big_d = nullptr; }
             const size_t want = bytes + bytes / 2 + ((size_t)4 << 20);
-            void* hp = nullptr;
-            if (hipHostMalloc(&hp, want, hipHostMallocDefault) == hipSuccess) { m.big = (char*)hp; m.big_cap = want; } else (void)hipGetLastError();
+            void* hp = nullptr; void* dp = nullptr;
+            if (hipHostMalloc(&hp, want, hipHostMallocMapped) == hipSuccess) {
+                if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) { m.big = (char*)hp; m.big_d = (char*)dp; m.big_cap = want; }
+                else { (void)hipGetLastError(); (void)hipHostFree(hp); }
+            } else (void)hipGetLastError();
         }
         if (bat + bytes <= m.big_cap) { land = m.big + bat; m.big_used = bat + bytes; }
     }
@@ -115,8 +200,9 @@ int vmx_fetch_bytes(vm_ctx* c, void* host, const void* dev, size_t bytes) {
         VMX_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
         return 0;
     }
-    VMX_HIP(hipMemcpyAsync(land, dev, bytes, hipMemcpyDeviceToHost, c->stream));
-    m.pend.push_back(vmx_mailbox::Pending{host, land, bytes});
+    static const bool by_copy = getenv("VMX_FETCH_COPIES") != nullptr;      // A/B knob: a runtime copy per piece + k_signal (the first form of the mailbox)
+    if (by_copy || !m.done_ctr) { VMX_HIP(hipMemcpyAsync(land, dev, bytes, hipMemcpyDeviceToHost, c->stream)); m.pend.push_back(vmx_mailbox::Pending{host, land, bytes, nullptr}); }
+    else m.pend.push_back(vmx_mailbox::Pending{host, land, bytes, dev});
     return 0;
 }
 // ---- counters of the row chain kernels (vmx_host.h)

@@ -124,12 +124,20 @@ struct vmx_mailbox {
     size_t dn_off = 0, dn_cap = 0, dn_used = 0;           // download area
     char* big = nullptr; size_t big_cap = 0, big_used = 0; // page-locked landing block of the large results (grows)
     unsigned long long seq = 0;
-    struct Pending { void* dst; const char* src; size_t bytes; };
+    struct Pending { void* dst; const char* src; size_t bytes; const void* dev; };      // dev != null: not copied yet — the export kernel of the next wait moves it
     std::vector<Pending> pend;
+    char* big_d = nullptr;                                 // the landing block as the device addresses it
+    unsigned long long* done_ctr = nullptr;                // device word: workgroups of the running export kernel that have finished
     bool on = false;                                       // false: legacy waits (spinning)
     long long poll_ns = 40000;
 };
 __global__ void k_signal(unsigned long long* word, unsigned long long v);
+// Round 6, second step: the downloads of a wait are not copies at all. vmx_fetch only NOTES (device source, landing place); the wait launches ONE kernel that
+// moves every noted piece into the page-locked landing area over the bus (16 B per lane, all pieces side by side) and — its last workgroup to finish — writes
+// the sequence word behind them: one launch instead of a runtime copy per piece plus the signal (a batch made ~40 such copies).
+#define VMX_EXPORT_MAX 12
+struct vmx_export_args { const char* src[VMX_EXPORT_MAX]; char* dst[VMX_EXPORT_MAX]; unsigned long long bytes[VMX_EXPORT_MAX]; int n; unsigned long long* word; unsigned long long seq; unsigned long long* done; };
+__global__ void k_export(vmx_export_args A);
 
 enum { VMX_NBUF = 64 };
 struct vm_ctx {
@@ -151,6 +159,7 @@ struct vm_ctx {
     int ext_mul = 1;                              // extend-stage pool multiplier of the running call (grow-and-retry in align_device)
     long long redo_need_max = 0;                  // largest full-matrix traceback need of one gap-fill chunk this context has seen (sizes the second launch's pool)
     bool run_pass1 = false;                       // this call runs pass 1 of the extend stage (the nofilter re-run; side batches of align_device)
+    int32_t* rc_cur = nullptr; int rc_next = 0;    // the running extend-stage phase's problem counter inside the batch's counter block (64 counters, cleared once per batch)
     bool force_exact = false;                     // this call launches the exact edit-distance tier whatever the banded tiers left (side batches of align_device)
     long long round_epoch = 0;                    // launches of k_round_prep by this context (k_round.hip: its publication flags carry the launch number)
     int64_t n_syncs = 0;                          // host waits on this context's stream (reset per batch)
@@ -192,27 +201,51 @@ static inline hipError_t vmx_stream_sync(vm_ctx* c) {
     c->sync_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     return e;
 }
-// small host vector -> device buffer through the upload ring (asynchronous; `host` may be reused at once). Falls back to a plain copy when the ring is full / off.
+// small host vector(s) -> device buffer(s) through the upload ring: the data is copied into the ring (page-locked, device-mapped) and ONE kernel (k_import) reads it
+// from there over the bus into its place(s) — asynchronous, `host` may be reused at once. (A runtime copy from the ring cost two or three blit launches per piece:
+// head, body, tail of an unaligned size. 48 copy launches per batch for 14 pieces.) Falls back to a plain copy when the ring is full / off.
+struct vmx_import_args { const char* src[4]; char* dst[4]; unsigned long long bytes[4]; int n; };
+__global__ void k_import(vmx_import_args A);
+struct vmx_push_piece { void* dev; const void* host; size_t bytes; };
+static inline int vmx_push_pieces(vm_ctx* c, const vmx_push_piece* pc, int np) {
+    vmx_mailbox& m = c->mb;
+    static const bool by_copy = getenv("VMX_PUSH_COPIES") != nullptr;        // A/B knob: runtime copies from the ring
+    size_t at = (m.up_used + 63) & ~(size_t)63, need = 0;
+    for (int i = 0; i < np; ++i) need += (pc[i].bytes + 63) & ~(size_t)63;
+    if (!m.on || at + need > m.up_cap) { for (int i = 0; i < np; ++i) if (pc[i].bytes) VMX_HIP(hipMemcpyAsync(pc[i].dev, pc[i].host, pc[i].bytes, hipMemcpyHostToDevice, c->stream)); return 0; }
+    vmx_import_args A; memset(&A, 0, sizeof A);
+    unsigned long long tot = 0;
+    for (int i = 0; i < np; ++i) {
+        if (!pc[i].bytes) continue;
+        memcpy(m.h + m.up_off + at, pc[i].host, pc[i].bytes);
+        if (by_copy) VMX_HIP(hipMemcpyAsync(pc[i].dev, m.h + m.up_off + at, pc[i].bytes, hipMemcpyHostToDevice, c->stream));
+        else { A.src[A.n] = m.d + m.up_off + at; A.dst[A.n] = (char*)pc[i].dev; A.bytes[A.n] = pc[i].bytes; ++A.n; tot += pc[i].bytes; }
+        at += (pc[i].bytes + 63) & ~(size_t)63;
+    }
+    m.up_used = at;
+    if (A.n) hipLaunchKernelGGL(k_import, dim3((unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>((tot + 16383ULL) >> 14, 32ULL))), dim3(256), 0, c->stream, A);
+    return 0;
+}
 template <class T> int vmx_push(vm_ctx* c, vmx::DevBuf& b, const T* host, size_t n, int line = __builtin_LINE(), const char* file = __builtin_FILE()) {
     const size_t bytes = sizeof(T) * n;
-    vmx_mailbox& m = c->mb;
-    const size_t at = (m.up_used + 63) & ~(size_t)63;
-    if (!m.on || !n || at + bytes > m.up_cap) return vmx::upload(b, host, n, c->stream, line, file);
+    if (!c->mb.on || !n) return vmx::upload(b, host, n, c->stream, line, file);
     VMX_TRY(b.reserve(bytes));
-    memcpy(m.h + m.up_off + at, host, bytes); m.up_used = at + bytes;
-    VMX_HIP(hipMemcpyAsync(b.p, m.h + m.up_off + at, bytes, hipMemcpyHostToDevice, c->stream)); vmx::copy_census().add(file, line, bytes);
-    return 0;
+    vmx::copy_census().add(file, line, bytes);
+    const vmx_push_piece pc{b.p, host, bytes};
+    return vmx_push_pieces(c, &pc, 1);
+}
+// up to four vectors in one launch
+struct vmx_push_req { vmx::DevBuf* b; const void* host; size_t bytes; };
+static inline int vmx_push_many(vm_ctx* c, const vmx_push_req* rq, int np) {
+    vmx_push_piece pc[4];
+    for (int i = 0; i < np; ++i) { VMX_TRY(rq[i].b->reserve(rq[i].bytes ? rq[i].bytes : 1)); pc[i] = vmx_push_piece{rq[i].b->p, rq[i].host, rq[i].bytes}; }
+    return vmx_push_pieces(c, pc, np);
 }
 // the same into a raw device address
 template <class T> int vmx_push_to(vm_ctx* c, void* dev, const T* host, size_t n) {
-    const size_t bytes = sizeof(T) * n;
-    vmx_mailbox& m = c->mb;
-    const size_t at = (m.up_used + 63) & ~(size_t)63;
     if (!n) return 0;
-    if (!m.on || at + bytes > m.up_cap) { VMX_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream)); return 0; }
-    memcpy(m.h + m.up_off + at, host, bytes); m.up_used = at + bytes;
-    VMX_HIP(hipMemcpyAsync(dev, m.h + m.up_off + at, bytes, hipMemcpyHostToDevice, c->stream));
-    return 0;
+    const vmx_push_piece pc{dev, host, sizeof(T) * n};
+    return vmx_push_pieces(c, &pc, 1);
 }
 // device -> host, delivered by the NEXT vmx_stream_sync(c) (the caller must not look at `host` before). Falls back to the plain (waiting) copy when off.
 int vmx_fetch_bytes(vm_ctx* c, void* host, const void* dev, size_t bytes);      // vmx_capi.hip
