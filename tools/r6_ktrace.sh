@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout 1200 rocprofv3 --kernel-trace -d $O/prof -o p -- python $GRAFT_REPO_ROOT/bench.py --config $CFG --cpu-sample 0 --verify 0 --extra-configs "" --no-host-input --steps $STEPS > $O/bench_prof.json 2>/dev/null
 cd $GRAFT_REPO_ROOT
 DB=$(find $O/prof -name '*.db' | head -1)
-python tools/trace_db.py $DB --csv gpurun_out/${TAG}_kernel_stats.csv --skip 5 > gpurun_out/${TAG}_concurrency.txt 2>&1
+python tools/trace_db.py $DB --csv gpurun_out/${TAG}_kernel_stats.csv --timed $STEPS > gpurun_out/${TAG}_concurrency.txt 2>&1
 cp $O/bench_prof.json gpurun_out/${TAG}_bench_line_under_rocprof.json
 rm -rf $O/prof
 head -12 gpurun_out/${TAG}_concurrency.txt

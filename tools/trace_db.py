@@ -28,6 +28,8 @@ def main():
     # timed region: from the k_sketch launch that follows the warm-up batches to the end
     sk = [r for r in rows if r[0] in ('k_sketch', 'k_sketch32')]
     skip = int(sys.argv[sys.argv.index('--skip') + 1]) if '--skip' in sys.argv else 4      # verify batch + 3 warm-ups
+    if '--timed' in sys.argv:      # round 6: the number of TIMED batches is what the caller knows (the warm-up runs follow the number of contexts the HBM has room for)
+        skip = max(0, len(sk) - int(sys.argv[sys.argv.index('--timed') + 1]))
     t0 = sk[skip][1] if len(sk) > skip else rows[0][1]
     sel = [r for r in rows if r[1] >= t0 and not r[0].startswith('__amd')]
     t1 = max(r[2] for r in sel)
