@@ -500,7 +500,7 @@ __device__ __forceinline__ void vmx_gapfill_ad_pass(const uint8_t* __restrict__ 
                                                    int match, int mismatch, int o1, int e1, int o2, int e2, uint8_t* __restrict__ tb_pool, int32_t* __restrict__ bnd_pool,
                                                    int32_t* __restrict__ out_score, const int32_t* __restrict__ order, const int32_t* __restrict__ range, int32_t* __restrict__ counter,
                                                    int32_t* __restrict__ redo_list, int32_t* __restrict__ redo_cnt, int ad_pct, unsigned long long* __restrict__ redo_bytes,
-                                                   unsigned long long redo_cap) {
+                                                   unsigned long long redo_cap, int tb_by_ns) {
     const int lane = vmx_lane();
     const int pct = ad_pct & 0xffff, pct_min = (ad_pct >> 16) & 0xffff;
     // the head of the longest-first queue (range[0] entries: the size classes above the small one) goes one problem per task: eight of them in
@@ -527,16 +527,21 @@ __device__ __forceinline__ void vmx_gapfill_ad_pass(const uint8_t* __restrict__ 
         const bool x4X = pX >= 0 && prX.tl > 0 && prX.ql > 0 && VMX_DP16X4_OK(prX.tl, prX.ql), x4Y = pY >= 0 && prY.tl > 0 && prY.ql > 0 && VMX_DP16X4_OK(prY.tl, prY.ql);
         const int nsX = x4X ? vmx_ad_ns(prX.tl, prX.ql, match, o1, e1, o2, e2, pct, pct_min) : 0, nsY = x4Y ? vmx_ad_ns(prY.tl, prY.ql, match, o1, e1, o2, e2, pct, pct_min) : 0;
         const int ns = vmx_uniform_i32(vmx_wave_max_i32(nsX > nsY ? nsX : nsY));
-        bool keepX = false, keepY = false;
+        bool keepX = false, keepY = false, triedX = false, triedY = false;
         if (ns > 0) {
             int dloX = 0, dloY = 0;
-            const int gX = nsX > 0 ? vmx_ad_geom(prX.tl, prX.ql, ns, &dloX) : 0, gY = nsY > 0 ? vmx_ad_geom(prY.tl, prY.ql, ns, &dloY) : 0;
+            // tb_by_ns (the batched path, round 6): a problem's traceback space was sized for the slot width of ITS OWN band (k_round_prep: VMX_AD_W(own ns) bytes per lane
+            // and anti-diagonal) and the queue is ordered by that width, so the eight problems of a task agree as a rule; one whose own width differs from the task's
+            // (a class boundary inside the task) cannot store the wider slots and goes to the second launch instead
+            const bool fitX = !tb_by_ns || VMX_AD_W(nsX) == VMX_AD_W(ns), fitY = !tb_by_ns || VMX_AD_W(nsY) == VMX_AD_W(ns);
+            const int gX = (nsX > 0 && fitX) ? vmx_ad_geom(prX.tl, prX.ql, ns, &dloX) : 0, gY = (nsY > 0 && fitY) ? vmx_ad_geom(prY.tl, prY.ql, ns, &dloY) : 0;
             const int tlX = gX > 0 ? prX.tl : 0, qlX = gX > 0 ? prX.ql : 0, tlY = gY > 0 ? prY.tl : 0, qlY = gY > 0 ? prY.ql : 0;
             int scX = 0, scY = 0;
 #define VMX_AD_RUN(NSV) vmx_gapfill_fill_ad<NSV>(tcodes + prX.t_off, qcodes + prX.q_off, tlX, qlX, dloX, tb_pool + prX.tb_off, tcodes + prY.t_off, qcodes + prY.q_off, tlY, qlY, dloY, \
                                                  tb_pool + prY.tb_off, match, mismatch, o1, e1, o2, e2, lane, scX, scY)
             if (ns == 1) VMX_AD_RUN(1); else if (ns == 2) VMX_AD_RUN(2); else if (ns == 3) VMX_AD_RUN(3); else VMX_AD_RUN(4);
 #undef VMX_AD_RUN
+            triedX = gX > 0; triedY = gY > 0;
             keepX = gX > 0 && vmx_ad_proven(scX, prX.tl, prX.ql, gX, match, o1, e1, o2, e2);
             keepY = gY > 0 && vmx_ad_proven(scY, prY.tl, prY.ql, gY, match, o1, e1, o2, e2);
         }
@@ -545,6 +550,7 @@ __device__ __forceinline__ void vmx_gapfill_ad_pass(const uint8_t* __restrict__ 
             if (x4X) {
                 out_score[pX] = keepX ? VMX_AD_FLAG + ns : 0;
                 if (!keepX) {
+                    if (triedX) atomicAdd(redo_cnt + 3, 1);          // tried in a band and not proven (the host adapts the band-width rule to this rate)
                     // (round 6: the second pool is sized from history, not from a read-back of this counter: an allocation that does not fit EMPTIES the problem — no
                     //  fill, an empty CIGAR — and the host, which reads the counter with the batch's results, grows the pool and runs the batch again)
                     const unsigned long long need = (unsigned long long)VMX_REDO_TB_BYTES(prX.tl, prX.ql), at = atomicAdd(redo_bytes, need);
@@ -555,6 +561,7 @@ __device__ __forceinline__ void vmx_gapfill_ad_pass(const uint8_t* __restrict__ 
             if (x4Y) {
                 out_score[pY] = keepY ? VMX_AD_FLAG + ns : 0;
                 if (!keepY) {
+                    if (triedY) atomicAdd(redo_cnt + 3, 1);          // tried in a band and not proven (the host adapts the band-width rule to this rate)
                     // (round 6: the second pool is sized from history, not from a read-back of this counter: an allocation that does not fit EMPTIES the problem — no
                     //  fill, an empty CIGAR — and the host, which reads the counter with the batch's results, grows the pool and runs the batch again)
                     const unsigned long long need = (unsigned long long)VMX_REDO_TB_BYTES(prY.tl, prY.ql), at = atomicAdd(redo_bytes, need);
@@ -585,10 +592,10 @@ __global__ void __launch_bounds__(64, 4) k_gapfill_fill_ns(const uint8_t* __rest
                                                         const int32_t* __restrict__ order, const int32_t* __restrict__ range, int32_t* __restrict__ counter,
                                                         int32_t* __restrict__ redo_list, int32_t* __restrict__ redo_cnt, int redo_pass, int ad_pct,
                                                         uint8_t* __restrict__ redo_pool, unsigned long long* __restrict__ redo_bytes, const int32_t* __restrict__ n_ptr,
-                                                        unsigned long long redo_cap) {
+                                                        unsigned long long redo_cap, int tb_by_ns) {
     if (n_ptr) n_prob = *n_ptr;                        // the count on the device (an unplanned pass: the host launched for an upper bound)
     if (redo_pass) vmx_gapfill_fill_body<false>(tcodes, qcodes, probs, n_prob, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, order, counter, redo_list, redo_cnt, 1, redo_pool);
-    else vmx_gapfill_ad_pass(tcodes, qcodes, probs, n_prob, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, order, range, counter, redo_list, redo_cnt, ad_pct, redo_bytes, redo_cap);
+    else vmx_gapfill_ad_pass(tcodes, qcodes, probs, n_prob, match, mismatch, o1, e1, o2, e2, tb_pool, bnd_pool, out_score, order, range, counter, redo_list, redo_cnt, ad_pct, redo_bytes, redo_cap, tb_by_ns);
 }
 
 // serial traceback, one THREAD per problem (thousands of independent dependent-load chains hide each other's latency)
@@ -618,6 +625,7 @@ __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_
     if (flag == VMX_PK_FLAG) { x4 = false; pk = true; }                  // a small-class problem the second launch ran on the whole wave
     int dlo = 0;
     if (ns) vmx_ad_geom(tl, ql, ns, &dlo);
+    const int AW = ns ? VMX_AD_W(ns) : 4;                                // bytes of a lane's slot in the anti-diagonal layout (vmx_kernels.h)
     const int W = x4 ? VMX_X4_W(ql) : ql + (pk ? 127 : 63);
     int nruns = 0; int cur_op = -1; uint32_t cur_len = 0;
 #define VMX_EMIT(op)                                                                   \
@@ -634,12 +642,12 @@ __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_
             // diagonal are loaded TOGETHER and consumed as long as the path stays on it: one memory latency per eight steps instead
             // of one per step (the walk is a chain of dependent loads, this kernel's whole cost).
             const int x = (j - i) - dlo, l = x / (2 * ns), k = (x - 2 * ns * l) >> 1;
-            const uint8_t* cell = tb + VMX_AD_TB_OFF(0, l) + k;
+            const uint8_t* cell = tb + VMX_AD_TB_OFF_W(0, l, AW) + k;
             const int s0 = i + j - 1;
             int m = i < j ? i : j; if (m > 8) m = 8;
             uint8_t bb[8], ta[8], qa[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (u < m) { bb[u] = cell[VMX_AD_TB_OFF(s0 - 2 * u, 0)]; if (eqx) { ta[u] = T[i - 1 - u]; qa[u] = Q[j - 1 - u]; } }
+            for (int u = 0; u < 8; ++u) if (u < m) { bb[u] = cell[VMX_AD_TB_OFF_W(s0 - 2 * u, 0, AW)]; if (eqx) { ta[u] = T[i - 1 - u]; qa[u] = Q[j - 1 - u]; } }
             int u = 0;
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
@@ -652,7 +660,7 @@ __global__ void k_gapfill_trace(const uint8_t* __restrict__ tcodes, const uint8_
             if (state == 0) continue;                 // the whole batch was diagonal (or the matrix edge was reached)
             // a gap starts at cell (i, j): the generic step below re-reads its byte in the gap state
         }
-        if (ns) { const int x = (j - i) - dlo, l = x / (2 * ns), k = (x - 2 * ns * l) >> 1; b = tb[VMX_AD_TB_OFF(i + j - 1, l) + k]; }
+        if (ns) { const int x = (j - i) - dlo, l = x / (2 * ns), k = (x - 2 * ns * l) >> 1; b = tb[VMX_AD_TB_OFF_W(i + j - 1, l, AW) + k]; }
         else if (x4) { const int s = (i - 1) >> 5, r = (i - 1) & 31, t = (j - 1) + r; b = tb[(((size_t)s * (size_t)W + (size_t)t) * 16 + (r >> 1)) * 2 + (r & 1)]; }
         else if (pk) { const int s = (i - 1) >> 7, r = (i - 1) & 127, t = (j - 1) + r; b = tb[(((size_t)s * (size_t)W + (size_t)t) * 64 + (r >> 1)) * 2 + (r & 1)]; }
         else { const int s = (i - 1) >> 6, l = (i - 1) & 63, t = (j - 1) + l; b = tb[((size_t)s * (size_t)W + (size_t)t) * 64 + l]; }

@@ -28,11 +28,32 @@
 
 template <bool DP> struct vmx_round_vals { static constexpr int NV = DP ? 6 : 2; };
 
+// slot width of a small-class problem's own band (0: no band is tried, the problem is filled in full by the second launch out of its pool)
+__device__ __forceinline__ int vmx_round_w(const vmx_round_args& A, long long tl, long long ql) {
+    return VMX_AD_W(vmx_ad_ns((int)tl, (int)ql, A.ad_match, A.ad_o1, A.ad_e1, A.ad_o2, A.ad_e2, A.ad_pct & 0xffff, (A.ad_pct >> 16) & 0xffff));
+}
 template <bool DP>
-__device__ __forceinline__ void vmx_round_values(const vmx_pair_desc& d, long long* v) {
+__device__ __forceinline__ void vmx_round_values(const vmx_round_args& A, const vmx_pair_desc& d, long long* v) {
     const long long tl = d.t.len, ql = d.q.len;
     v[0] = tl; v[1] = ql;
-    if constexpr (DP) { v[2] = VMX_TB_BYTES_NS(tl, ql); v[3] = 3 * (ql + 1); v[4] = tl + ql + 2; v[5] = 2 * (tl + ql) + 16; }      // (k_dp_sizes of round 1-5)
+    if constexpr (DP) {
+        const bool small = tl > 0 && ql > 0 && VMX_DP16X4_OK(tl, ql);
+        v[2] = (small && A.ad_on) ? VMX_AD_TB_BYTES_W(tl, ql, vmx_round_w(A, tl, ql)) : VMX_TB_BYTES_NS(tl, ql);
+        v[3] = 3 * (ql + 1); v[4] = tl + ql + 2; v[5] = 2 * (tl + ql) + 16;      // (k_dp_sizes of round 1-5)
+    }
+}
+// the queue key of a gap-fill problem (vmx_round.h)
+__device__ __forceinline__ long long vmx_round_key(const vmx_round_args& A, long long tl, long long ql) {
+    if (tl <= 0 || ql <= 0) return 0;
+    if (!VMX_DP16X4_OK(tl, ql)) {
+        const long long b = VMX_TB_BYTES(tl, ql);
+        if (b > VMX_HEAD_THRESH) return (b < (1LL << 38) ? b : (1LL << 38)) << 24;
+        return b << 23;
+    }
+    const long long b64 = VMX_AD_TB_BYTES(tl, ql);                       // (tl + ql) * 64: 2^7 .. 2^16
+    if (!A.ad_on) return b64;
+    const int w = vmx_round_w(A, tl, ql);
+    return w == 4 ? b64 << 16 : (w == 2 ? b64 << 6 : (w == 1 ? b64 >> 4 : (b64 >> 14) + 1));
 }
 
 // the traceback chunk plan of a gap-fill round (k_tb_plan of rounds 2-5, unchanged): chunks of at most `limit` traceback bytes, found by bisection on tboff
@@ -70,7 +91,7 @@ __global__ void __launch_bounds__(256) k_round_prep(vmx_round_args A) {
     // ---- slice sums
     long long s[NV];
     for (int v = 0; v < NV; ++v) s[v] = 0;
-    for (long long i = lo + tid; i < hi; i += 256) { long long x[NV]; vmx_round_values<DP>(A.desc[i], x); for (int v = 0; v < NV; ++v) s[v] += x[v]; }
+    for (long long i = lo + tid; i < hi; i += 256) { long long x[NV]; vmx_round_values<DP>(A, A.desc[i], x); for (int v = 0; v < NV; ++v) s[v] += x[v]; }
     for (int v = 0; v < NV; ++v) { s[v] = vmx_wave_sum_i64(s[v]); if (lane == 0) s_w[wv][v] = s[v]; }
     __syncthreads();
     if (tid == 0) {
@@ -95,7 +116,7 @@ __global__ void __launch_bounds__(256) k_round_prep(vmx_round_args A) {
         long long x[NV], inc[NV];
         vmx_pair_desc d; d.t.len = 0; d.q.len = 0;
         if (i < hi) d = A.desc[i];
-        if (i < hi) vmx_round_values<DP>(d, x); else for (int v = 0; v < NV; ++v) x[v] = 0;
+        if (i < hi) vmx_round_values<DP>(A, d, x); else for (int v = 0; v < NV; ++v) x[v] = 0;
         for (int v = 0; v < NV; ++v) {
             long long c = x[v];
             for (int o = 1; o < 64; o <<= 1) { const long long y = __shfl_up(c, o); if (lane >= o) c += y; }
@@ -108,7 +129,7 @@ __global__ void __launch_bounds__(256) k_round_prep(vmx_round_args A) {
         if (i < hi) {
             for (int v = 0; v < NV; ++v) A.off[v][i] = off[v];
             if constexpr (DP) {
-                A.tb_size[i] = x[2];
+                A.tb_size[i] = vmx_round_key(A, x[0], x[1]);
                 vmx_dp_prob p; p.t_off = off[0]; p.q_off = off[1]; p.tl = (int32_t)x[0]; p.ql = (int32_t)x[1]; p.tb_off = off[2]; p.bnd_off = off[3]; p.run_off = off[4]; p.cig_off = off[5];
                 if (A.cap[0] > 0 && (off[2] + x[2] > A.cap[0] || off[3] + x[3] > A.cap[1] || off[4] + x[4] > A.cap[2] || off[5] + x[5] > A.cap[3])) {
                     p.tl = 0; p.ql = 0; p.t_off = 0; p.q_off = 0; p.tb_off = 0; p.bnd_off = 0; p.run_off = 0; p.cig_off = 0; A.tb_size[i] = 0;      // (run / CIGAR slot 0 of the pools: 2 words / 16 bytes are always there)

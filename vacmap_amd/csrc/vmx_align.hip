@@ -136,7 +136,7 @@ static int dev_scan_dev(vm_ctx* c, vmx_batch_bufs& B, const int64_t* in, int64_t
 // slot `stat_slot` of the batch's counter block, which the host reads once at the end. want_cnt: also return a host copy (one wait) —
 // only the gap-fill rounds, whose pools are sized by it, ask for that.
 static int ext_gather_round(vm_ctx* c, vmx_batch_bufs& B, const vm_index_view& ix, int64_t n, const uint8_t* d_ocodes, const int64_t* d_roff, int cur, int redo_only,
-                            int64_t round_cap, int64_t pool_cap, int stat_slot, bool dp, int64_t tb_limit, const int64_t* caps = nullptr, int64_t* plan_out = nullptr) {
+                            int64_t round_cap, int64_t pool_cap, int stat_slot, bool dp, int64_t tb_limit, const int64_t* caps = nullptr, int64_t* plan_out = nullptr, int ad_pct = 0) {
     (void)n; (void)redo_only; (void)round_cap;    // (the slots' owners are written when the phase kernel allocates them; vmx_alloc_probs never lets the published count pass the capacity)
     if (!B.roundpart.p) { VMX_TRY(B.roundpart.reserve(8 * (size_t)VMX_ROUND_PART_WORDS)); VMX_HIP(hipMemsetAsync(B.roundpart.p, 0, 8 * (size_t)VMX_ROUND_PART_WORDS, c->stream)); }
     vmx_round_args R; memset(&R, 0, sizeof R);
@@ -147,6 +147,7 @@ static int ext_gather_round(vm_ctx* c, vmx_batch_bufs& B, const vm_index_view& i
         for (int i = 0; i < 4; ++i) R.off[2 + i] = B.dpoff[i].as<int64_t>();
         R.tb_size = B.dpsz[0].as<int64_t>(); R.probs = B.dptab.as<vmx_dp_prob>(); R.plan_out = plan_out; R.tb_limit = tb_limit;
         if (caps) for (int i = 0; i < 4; ++i) R.cap[i] = caps[i];          // unplanned pass: every problem is checked against the pools (k_round.hip)
+        R.ad_on = 1; R.ad_match = 2; R.ad_o1 = 4; R.ad_e1 = 2; R.ad_o2 = 24; R.ad_e2 = 1; R.ad_pct = ad_pct;      // the fill's own scoring and band-width rule (gf_chunk)
         hipLaunchKernelGGL(k_round_prep<true>, dim3(VMX_ROUND_WGS), dim3(256), 0, c->stream, R);
     } else
         hipLaunchKernelGGL(k_round_prep<false>, dim3(VMX_ROUND_WGS), dim3(256), 0, c->stream, R);
@@ -531,7 +532,16 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     //    A read that asks for it (E.redo) is run again alone by align_device with both passes (c->run_pass1), like the reads that need the later tiers of the divergence filter.
     constexpr int GF_SLOT = 32 + 544;                                  // ints per chunk slot of B.gfctl: control block, then the size-order scratch (513 used)
     auto gf_slot = [&](int pass, int q) -> int32_t* { return B.gfctl.as<int32_t>() + (size_t)(pass * (VMX_MAX_CHUNKS + 1) + q) * GF_SLOT; };
-    const int ad_pct = vmx_ad_pct_env(prm->mode);
+    // The band-width rule (vmx_ad_ns: the narrowest band whose margin covers pct % of the problem) only decides which problems are TRIED in a band and how wide — the
+    // proof decides what is kept, so the records do not depend on it. Round 6: pct follows the reads instead of the mode alone. Each context starts at the mode's
+    // default (90; mode L 40) and steps down by 10 while fewer than 2.5 % of a batch's problems fail the proof (they are filled again in full: ~4x a band attempt), back
+    // up when more than 3 % do, and then holds that floor for 256 batches. HiFi-shape reads in mode R (configs[4]) settle at 40: 3.23 -> 3.70 Gbp/s; ONT reads at
+    // 80-90 (70 fails 6 %, 55 fails 29 %): `profiles/r06_q_band_width_rule_sweep.txt`. VMX_AD_PCT / VMX_AD_PCT_MIN pin the rule (tuning runs).
+    static std::mutex ad_m; static struct { int pct = 0, floor = 40, hold = 0; } ad_tab[16][8];      // per device and read mode, shared by the contexts of the process
+    auto& adr = ad_tab[c->device & 15][prm->mode & 7];
+    int ad_cur; { std::lock_guard<std::mutex> g(ad_m); if (adr.pct == 0) adr.pct = vmx_ad_pct_env(prm->mode) & 0xffff; ad_cur = adr.pct; }
+    const bool ad_pinned = getenv("VMX_AD_PCT") != nullptr || getenv("VMX_AD_PCT_MIN") != nullptr;
+    const int ad_pct = ad_pinned ? vmx_ad_pct_env(prm->mode) : (ad_cur | (std::max(40, ad_cur - 25) << 16));
     int fill_waves = 16;                                              // waves per CU of the fill kernel (tuning knob: VMX_FILL_WAVES)
     if (const char* e = getenv("VMX_FILL_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 32) fill_waves = v; }
     static const int tr_spread = [] { const char* e = getenv("VMX_TRACE_SPREAD"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 64 ? v : 1; }();
@@ -545,21 +555,21 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
         uint8_t* tb_base = B.tb.as<uint8_t>() - tb_off0;           // the problems' absolute traceback offsets index a buffer that holds this chunk only
         hipEvent_t* ke = q < 8 ? c->gev + (pass ? 24 : 0) + 3 * q : nullptr;      // HIP events around the dominant kernel, on the stream it runs on
         const unsigned Gs = (unsigned)std::max<int64_t>(1, std::min<int64_t>((pn + 1023) / 1024, (int64_t)c->num_cu * 2));
-        hipLaunchKernelGGL(k_size_hist, dim3(Gs), dim3(256), 0, c->stream, B.dpsz[0].as<int64_t>() + p0, n_ptr, (int64_t)VMX_HEAD_THRESH, scratch);
+        hipLaunchKernelGGL(k_size_hist, dim3(Gs), dim3(256), 0, c->stream, B.dpsz[0].as<int64_t>() + p0, n_ptr, (int64_t)((1LL << 42) - 1), scratch);        // (queue keys: k_round.hip)
         hipLaunchKernelGGL(k_size_scatter, dim3(Gs), dim3(256), 0, c->stream, B.dpsz[0].as<int64_t>() + p0, n_ptr, (const int32_t*)scratch, scratch + 257, B.order.as<int32_t>(), d_range, d_cnt);
         if (ke) (void)hipEventRecord(ke[0], c->stream);
         {
             vmx_lowprio lp(c);                                    // the long launch at the lowest dispatch priority (vmx_host.h)
             hipLaunchKernelGGL(k_gapfill_fill_ns, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(pn, (int64_t)c->num_cu * fill_waves))), dim3(64), 0, lp.stream(), B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
                                B.dptab.as<vmx_dp_prob>() + p0, (int)pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_range, d_cnt,
-                               d_redo_list, d_redo_cnt, 0, ad_pct, (uint8_t*)nullptr, d_redo_bytes, n_ptr, (unsigned long long)gf_redo_cap);
+                               d_redo_list, d_redo_cnt, 0, ad_pct, (uint8_t*)nullptr, d_redo_bytes, n_ptr, (unsigned long long)gf_redo_cap, 1);
             lp.join();
         }
         // second launch: the problems whose band was not proven (a few per cent), in full: the larger ones on a whole wave, the others four per wave (its queue is the list the
         // first launch left; any grid works)
         hipLaunchKernelGGL(k_gapfill_fill_ns, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(pn, (int64_t)c->num_cu * 4))), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(),
                            B.dptab.as<vmx_dp_prob>() + p0, (int)pn, 2, -4, 4, 2, 24, 1, tb_base, B.bnd.as<int32_t>(), B.dpscore.as<int32_t>() + p0, B.order.as<int32_t>(), d_range, d_cnt,
-                           d_redo_list, d_redo_cnt, 1, ad_pct, B.tbredo.as<uint8_t>(), d_redo_bytes, n_ptr, (unsigned long long)gf_redo_cap);
+                           d_redo_list, d_redo_cnt, 1, ad_pct, B.tbredo.as<uint8_t>(), d_redo_bytes, n_ptr, (unsigned long long)gf_redo_cap, 1);
         if (ke) (void)hipEventRecord(ke[1], c->stream);
         hipLaunchKernelGGL(k_gapfill_trace, dim3((unsigned)std::max<int64_t>(1, (pn * tr_spread + 63) / 64)), dim3(64), 0, c->stream, B.tpool.as<uint8_t>(), B.qpool.as<uint8_t>(), B.dptab.as<vmx_dp_prob>() + p0, (int)pn, prm->eqx,
                            tb_base, B.run.as<uint32_t>(), B.cig.as<char>(), B.ciglen.as<int32_t>() + p0, B.dpscore.as<int32_t>() + p0, B.tbredo.as<uint8_t>(), tr_spread, B.cigq.as<int32_t>() + p0, n_ptr);
@@ -582,7 +592,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
         c->n_gev[redo_only ? 1 : 0] = 0;
         {
             // ONE launch: string offsets, the four pool-size scans, the problem table and the chunk plan (at most VMX_TB_CHUNK traceback bytes per chunk), then the gather
-            int rcg = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, redo_only, round_cap, pool_cap, 6 + redo_only, true, tb_chunk, nullptr, B.statblk.as<int64_t>() + 64 + (redo_only ? 64 : 0));
+            int rcg = ext_gather_round(c, B, ix, n, B.ocodes.as<uint8_t>(), d_roff, cur, redo_only, round_cap, pool_cap, 6 + redo_only, true, tb_chunk, nullptr, B.statblk.as<int64_t>() + 64 + (redo_only ? 64 : 0), ad_pct);
             if (rcg < 0) return rcg;
             // the sizing wait of the batch: problem count, pool totals, chunk cuts
             int64_t plan[8 + 2 * (VMX_MAX_CHUNKS + 1)];
@@ -712,17 +722,26 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     VMX_HIP(hipGetLastError());
     nr = fin[0]; nb = fin[1]; oflow = (int32_t)fin[2]; n_full = (int32_t)fin[3]; n_t2 = (int32_t)fin[4]; n_t1 = (int32_t)fin[5];
     {   // what the gap fill assumed instead of asking (above): did it hold?
-        bool again = false; int64_t need_max = 0;
+        bool again = false; int64_t need_max = 0, ad_failed = 0;
         for (int pass = 0; pass < 2; ++pass)
             for (int q = 0; q < gf_chunks[pass]; ++q) {
                 const int32_t* ctl = h_ctl.data() + (size_t)(pass * (VMX_MAX_CHUNKS + 1) + q) * GF_SLOT;
                 unsigned long long rb = 0; memcpy(&rb, ctl + 16, 8);
-                st.n_dp_redo += ctl[12]; st.dp_redo_tb_bytes += (int64_t)rb; st.dp_cells += (int64_t)rb;
+                st.n_dp_redo += ctl[12]; st.dp_redo_tb_bytes += (int64_t)rb; st.dp_cells += (int64_t)rb; ad_failed += ctl[15];
                 need_max = std::max<int64_t>(need_max, (int64_t)rb);
             }
         c->redo_need_max = std::max<long long>(c->redo_need_max, need_max);
         if (need_max > gf_redo_cap) { again = true; if (getenv("VMX_DBG_POOLS")) fprintf(stderr, "[pools] gap fill: a chunk's second launch needs %.3f GB of traceback space, the pool held %.3f: running the batch again\n", need_max / 1e9, gf_redo_cap / 1e9); }
         if (again) return VMX_RETRY_BATCH;
+        if (!ad_pinned && !c->force_exact && st.n_dp_problems >= 2000) {      // adapt the band-width rule (above) to the rate of band attempts that were not proven
+            const double f = (double)ad_failed / (double)st.n_dp_problems;
+            std::lock_guard<std::mutex> g(ad_m);
+            if (ad_cur == adr.pct) {                                      // (a batch that ran on an older value does not vote on the current one)
+                if (f > 0.03 && adr.pct < 100) { adr.pct = std::min(100, adr.pct + 10); adr.floor = adr.pct; adr.hold = 256; }
+                else if (adr.hold > 0) { if (--adr.hold == 0) adr.floor = 40; }
+                else if (f < 0.025 && adr.pct > adr.floor) adr.pct = std::max(adr.floor, adr.pct - (f < 0.01 ? 20 : 10));
+            }
+        }
     }
     for (int i = 0; i < 8; ++i) hstat[i] = fin[6 + i];
     st.n_segments = hstat[0]; st.n_ed_problems = hstat[0]; st.n_ext_problems = (int64_t)hstat[1] + hstat[2] + hstat[3] + hstat[4];

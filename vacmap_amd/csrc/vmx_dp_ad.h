@@ -14,8 +14,8 @@
 // cells past tl / ql compute garbage that only ever feeds other garbage. Target codes move down the lanes one diagonal pair per two
 // steps, query codes move up (one DPP each per step pair), fed at lane 0 / lane 15 from 16-entry chunk registers that rotate one lane
 // per use and are refilled with one coalesced load every 16 pairs.
-// Traceback bytes: tb[VMX_AD_TB_OFF(a - 1, l) + k] for the cell of anti-diagonal a on diagonal x = 2 NS l + 2 k + (a & 1): one dword per lane,
-// problem and step (vmx_kernels.h: lines of VMX_AD_AB anti-diagonals x 16 / VMX_AD_AB lanes).
+// Traceback bytes: tb[VMX_AD_TB_OFF_W(a - 1, l, W) + k] for the cell of anti-diagonal a on diagonal x = 2 NS l + 2 k + (a & 1): W = VMX_AD_W(NS) bytes per lane,
+// problem and step (vmx_kernels.h: 64-byte lines of VMX_AD_AB anti-diagonals x 64 / (AB W) lanes).
 #ifndef VMX_DP_AD_H
 #define VMX_DP_AD_H
 
@@ -119,8 +119,14 @@ __device__ __forceinline__ void vmx_gapfill_fill_ad(const uint8_t* __restrict__ 
     const int xfX = (qlX - tlX) - dloX, xfY = (qlY - tlY) - dloY;
     const int lfX = xfX / (2 * NS), kfX = (xfX % (2 * NS)) >> 1, lfY = xfY / (2 * NS), kfY = (xfY % (2 * NS)) >> 1;
     int finX = 0, finY = 0;
-    uint8_t* const pX = tbX + VMX_AD_TB_OFF(0, l);            // the lane's slot of anti-diagonal 0; the step's part of the offset is added per store
-    uint8_t* const pY = tbY + VMX_AD_TB_OFF(0, l);
+    constexpr int W = VMX_AD_W(NS);                           // bytes of the lane's slot: as many as the lane has cells per step (round 6; 4 before, whatever NS)
+    uint8_t* const pX = tbX + VMX_AD_TB_OFF_W(0, l, W);       // the lane's slot of anti-diagonal 0; the step's part of the offset is added per store
+    uint8_t* const pY = tbY + VMX_AD_TB_OFF_W(0, l, W);
+    auto put = [&](uint8_t* at, unsigned w01, unsigned w23, bool hi) {
+        if constexpr (W == 1) *at = (uint8_t)(hi ? (w01 >> 16) : w01);
+        else if constexpr (W == 2) *(uint16_t*)at = (uint16_t)(hi ? (w01 >> 16) : w01);
+        else *(uint32_t*)at = vmx_perm(w23, w01, hi ? 0x07060302u : 0x05040100u);
+    };
     // chunk of block b (pairs 16 b + 1 .. 16 b + 16): lane m holds the target code lane 0 takes in the block's pair m (row 16 b + 1 + m - h),
     // lane 15 - m the query code lane 15 takes in it (column 16 b + m + h + 16 NS)
     auto load_chunks = [&](int b16, unsigned& tch, unsigned& qch) {
@@ -159,9 +165,9 @@ __device__ __forceinline__ void vmx_gapfill_fill_ad(const uint8_t* __restrict__ 
                 if (NS > 1) w01 |= bb[NS > 1 ? 1 : 0] << 8;
                 if (NS > 2) w23 = bb[NS > 2 ? 2 : 0];
                 if (NS > 3) w23 |= bb[NS > 3 ? 3 : 0] << 8;
-                const size_t so = VMX_AD_TB_OFF(2 * p - 2, 0);        // anti-diagonal a = 2p - 1 is step s = a - 1
-                if (p <= poX) *(uint32_t*)(pX + so) = vmx_perm(w23, w01, 0x05040100u);
-                if (p <= poY) *(uint32_t*)(pY + so) = vmx_perm(w23, w01, 0x07060302u);
+                const size_t so = VMX_AD_TB_OFF_W(2 * p - 2, 0, W);   // anti-diagonal a = 2p - 1 is step s = a - 1
+                if (p <= poX) put(pX + so, w01, w23, false);
+                if (p <= poY) put(pY + so, w01, w23, true);
             }
             // target codes move down one diagonal pair
             {
@@ -186,9 +192,9 @@ __device__ __forceinline__ void vmx_gapfill_fill_ad(const uint8_t* __restrict__ 
                 if (NS > 1) w01 |= bb[NS > 1 ? 1 : 0] << 8;
                 if (NS > 2) w23 = bb[NS > 2 ? 2 : 0];
                 if (NS > 3) w23 |= bb[NS > 3 ? 3 : 0] << 8;
-                const size_t so = VMX_AD_TB_OFF(2 * p - 1, 0);
-                if (p <= peX) *(uint32_t*)(pX + so) = vmx_perm(w23, w01, 0x05040100u);
-                if (p <= peY) *(uint32_t*)(pY + so) = vmx_perm(w23, w01, 0x07060302u);
+                const size_t so = VMX_AD_TB_OFF_W(2 * p - 1, 0, W);
+                if (p <= peX) put(pX + so, w01, w23, false);
+                if (p <= peY) put(pY + so, w01, w23, true);
             }
             // the pair that holds the problem's last anti-diagonal: its cell (tl, ql) was written by this pair's odd or even step
             if (__any(p == poX || p == poY)) {

@@ -306,7 +306,7 @@ __global__ void k_gapfill_fill(const uint8_t* tcodes, const uint8_t* qcodes, con
 __global__ void k_gapfill_fill_ns(const uint8_t* tcodes, const uint8_t* qcodes, vmx_dp_prob* probs, int n_prob, int match,
                                   int mismatch, int o1, int e1, int o2, int e2, uint8_t* tb_pool, int32_t* bnd_pool, int32_t* out_score,
                                   const int32_t* order, const int32_t* range, int32_t* counter, int32_t* redo_list, int32_t* redo_cnt, int redo_pass, int ad_pct,
-                                  uint8_t* redo_pool, unsigned long long* redo_bytes, const int32_t* n_ptr = nullptr, unsigned long long redo_cap = ~0ULL);
+                                  uint8_t* redo_pool, unsigned long long* redo_bytes, const int32_t* n_ptr = nullptr, unsigned long long redo_cap = ~0ULL, int tb_by_ns = 0);
 // band-width rule of the anti-diagonal gap fill (vmx_ad_ns): pct | pct_min << 16; tuning knobs VMX_AD_PCT / VMX_AD_PCT_MIN
 // (round 4: the default follows the read mode — HiFi problems score near the all-match bound, so a band whose margin covers 40 % of the problem
 // is proven as often as one that covers 100 %: fill 7.0 -> 6.0 ms per batch; ONT modes 100 -> 90: 8.9 -> 8.6; profiles/r04_x_*)

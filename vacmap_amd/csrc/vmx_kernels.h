@@ -212,8 +212,14 @@ __host__ __device__ static inline int vmx_ad_ns(int tl, int ql, int match, int o
 #ifndef VMX_AD_AB
 #define VMX_AD_AB 8
 #endif
-#define VMX_AD_TB_OFF(s, l) ((((size_t)(s) & ~(size_t)(VMX_AD_AB - 1)) << 6) + ((size_t)(s) & (VMX_AD_AB - 1)) * (64 / VMX_AD_AB) + ((size_t)(l) / (16 / VMX_AD_AB)) * 64 + ((size_t)(l) % (16 / VMX_AD_AB)) * 4)   /* byte offset of lane l's slot on anti-diagonal s (0-based) */
+#define VMX_AD_TB_OFF(s, l) ((((size_t)(s) & ~(size_t)(VMX_AD_AB - 1)) << 6) + ((size_t)(s) & (VMX_AD_AB - 1)) * (64 / VMX_AD_AB) + ((size_t)(l) / (16 / VMX_AD_AB)) * 64 + ((size_t)(l) % (16 / VMX_AD_AB)) * 4)   /* byte offset of lane l's slot on anti-diagonal s (0-based), 4-byte slots */
 #define VMX_AD_TB_BYTES(tl, ql) ((int64_t)(((tl) + (ql) + VMX_AD_AB - 1) & ~(VMX_AD_AB - 1)) * 64)
+/* Round 6: the slot is as wide as the band needs — W = 1 byte per lane and anti-diagonal for ns = 1 (one cell per lane and step), 2 for ns = 2, 4 for ns = 3 / 4.
+   A HiFi problem (ns = 1 under the mode-L rule) wrote 64 bytes per anti-diagonal of which 16 were cells: its fill ran at 0.38 of the VALU peak behind 1.95 TB/s
+   of stores. Lines stay 64 bytes = VMX_AD_AB anti-diagonals x 64 / (AB W) lanes, so the traceback walk still reads a line per AB / 2 diagonal steps. */
+#define VMX_AD_W(ns) ((ns) <= 0 ? 0 : ((ns) == 1 ? 1 : ((ns) == 2 ? 2 : 4)))
+#define VMX_AD_TB_OFF_W(s, l, W) (((size_t)(s) / VMX_AD_AB) * (size_t)(VMX_AD_AB * 16 * (W)) + ((size_t)(l) / (64 / (VMX_AD_AB * (W)))) * 64 + ((size_t)(s) % VMX_AD_AB) * (64 / VMX_AD_AB) + ((size_t)(l) % (64 / (VMX_AD_AB * (W)))) * (W))
+#define VMX_AD_TB_BYTES_W(tl, ql, W) ((int64_t)(((tl) + (ql) + VMX_AD_AB - 1) & ~(VMX_AD_AB - 1)) * 16 * (W))
 #define VMX_X4_TB_BYTES(tl, ql) ((int64_t)(((tl) + 31) / 32) * VMX_X4_W(ql) * 32)
 // traceback bytes of a problem. VMX_TB_BYTES: the full-matrix forms (k_gapfill_fill). VMX_TB_BYTES_NS: the batched path (k_gapfill_fill_ns), whose
 // small problems get the anti-diagonal layout's (tl + ql) * 64 bytes only; the few that have to be filled again in full take
