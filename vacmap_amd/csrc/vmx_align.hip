@@ -534,14 +534,15 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     auto gf_slot = [&](int pass, int q) -> int32_t* { return B.gfctl.as<int32_t>() + (size_t)(pass * (VMX_MAX_CHUNKS + 1) + q) * GF_SLOT; };
     // The band-width rule (vmx_ad_ns: the narrowest band whose margin covers pct % of the problem) only decides which problems are TRIED in a band and how wide — the
     // proof decides what is kept, so the records do not depend on it. Round 6: pct follows the reads instead of the mode alone. Each context starts at the mode's
-    // default (90; mode L 40) and steps down by 10 while fewer than 2.5 % of a batch's problems fail the proof (they are filled again in full: ~4x a band attempt), back
-    // up when more than 3 % do, and then holds that floor for 256 batches. HiFi-shape reads in mode R (configs[4]) settle at 40: 3.23 -> 3.70 Gbp/s; ONT reads at
-    // 80-90 (70 fails 6 %, 55 fails 29 %): `profiles/r06_q_band_width_rule_sweep.txt`. VMX_AD_PCT / VMX_AD_PCT_MIN pin the rule (tuning runs).
-    static std::mutex ad_m; static struct { int pct = 0, floor = 40, hold = 0; } ad_tab[16][8];      // per device and read mode, shared by the contexts of the process
+    // default (90; mode L 40) and steps down (to 20 at the least) by 20 / 10 while fewer than 1 / 2.5 % of a batch's problems are tried in a band and not proven (they are
+    // filled again in full: ~4x a band attempt), back up when more than 3 % are, and then holds that floor for 256 batches. HiFi-shape reads settle at 20 (a 270-base
+    // problem runs on ONE diagonal pair per lane: margin 104 against ~8 points of errors), ONT reads at 80-90 (70 fails 6 %, 55 fails 29 %):
+    // `profiles/r06_q_band_width_rule_sweep.txt`. VMX_AD_PCT / VMX_AD_PCT_MIN pin the rule (tuning runs).
+    static std::mutex ad_m; static struct { int pct = 0, floor = 20, hold = 0; } ad_tab[16][8];      // per device and read mode, shared by the contexts of the process
     auto& adr = ad_tab[c->device & 15][prm->mode & 7];
     int ad_cur; { std::lock_guard<std::mutex> g(ad_m); if (adr.pct == 0) adr.pct = vmx_ad_pct_env(prm->mode) & 0xffff; ad_cur = adr.pct; }
     const bool ad_pinned = getenv("VMX_AD_PCT") != nullptr || getenv("VMX_AD_PCT_MIN") != nullptr;
-    const int ad_pct = ad_pinned ? vmx_ad_pct_env(prm->mode) : (ad_cur | (std::max(40, ad_cur - 25) << 16));
+    const int ad_pct = ad_pinned ? vmx_ad_pct_env(prm->mode) : (ad_cur | (std::max(20, ad_cur - 25) << 16));
     int fill_waves = 16;                                              // waves per CU of the fill kernel (tuning knob: VMX_FILL_WAVES)
     if (const char* e = getenv("VMX_FILL_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 32) fill_waves = v; }
     static const int tr_spread = [] { const char* e = getenv("VMX_TRACE_SPREAD"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 64 ? v : 1; }();
@@ -738,7 +739,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
             std::lock_guard<std::mutex> g(ad_m);
             if (ad_cur == adr.pct) {                                      // (a batch that ran on an older value does not vote on the current one)
                 if (f > 0.03 && adr.pct < 100) { adr.pct = std::min(100, adr.pct + 10); adr.floor = adr.pct; adr.hold = 256; }
-                else if (adr.hold > 0) { if (--adr.hold == 0) adr.floor = 40; }
+                else if (adr.hold > 0) { if (--adr.hold == 0) adr.floor = 20; }
                 else if (f < 0.025 && adr.pct > adr.floor) adr.pct = std::max(adr.floor, adr.pct - (f < 0.01 ? 20 : 10));
             }
         }
