@@ -122,7 +122,14 @@ __device__ __forceinline__ bool lb_sort_hits(int n) {      // s_hit[0 .. n) -> s
     return sw;
 }
 
+#ifndef VMX_LB_PRIO
+#define VMX_LB_PRIO 2
+#endif
 __global__ void __launch_bounds__(64, VMX_LB_WAVES) k_local_seed_band(vmx_lseed_args A) {
+    // Round 6: this kernel's waves hold the LDS-limited slots of the CUs (eight 17.8 KB wavefronts each) for 13.5 of a 16 ms HiFi step while the gap fill of the other
+    // batches shares their SIMDs, and a lone wave per read is bound by instruction issue and LDS latency: at the default priority it ran 1.7x slower under load than
+    // alone. Its instructions now go first (s_setprio 2, below the one-wave chain kernels' 3); the fill, which is throughput-bound, takes the issue slots left over.
+    VMX_SETPRIO(VMX_LB_PRIO);
     VMX_DYN_SHARED(uint64_t, s_u);                 // VMX_LB_LDS_BYTES
     uint64_t* const s_sort = s_u;                  // [0, 8 VMX_LB_SORTK): sorts / the sorted hits of a chunk
     uint32_t* const s_head = (uint32_t*)s_u;       // LB_NB bucket heads (entry index + 1, 0 = empty) ...
