@@ -167,6 +167,22 @@ def test_batch_runs_again_when_an_assumed_size_did_not_hold(oracle, golden, monk
     cx.close()
 
 
+def test_local_stage_without_a_host_wait(oracle, golden):
+    """round 6: after a context's first batch the local stage (L1-L4, mammap_clrnano.py:23069-23345, :27305) runs without a host wait — the local-anchor counts stay on the
+    device, the local chain DP's read list and the extend stage's per-read pool geometry are built there inside the pools the context already holds; reads the banded
+    seeding kernel hands back or that do not fit are run again alone on the waiting path. Records = the reference's on both paths; the second batch waits less often."""
+    from vacmap_amd.lib import Context
+    cx = Context(0)
+    st1 = KC.check_align_golden(cx, oracle, golden, cases=['B'])           # first batch of the context: the waiting path (it sizes the pools)
+    st2 = KC.check_align_golden(cx, oracle, golden, cases=['B'])
+    assert st2['n_host_syncs'] < st1['n_host_syncs'], (st1['n_host_syncs'], st2['n_host_syncs'])
+    assert st2['n_local_anchors'] == st1['n_local_anchors'] > 0
+    for cid in ('D', 'F', 'A', 'H', 'K', 'O'):                             # repeat-dense reads (hand-backs), modes R and L, larger batches than the first
+        KC.check_align_golden(cx, oracle, golden, cases=[cid])
+    KC.check_align_indel_donor(cx, oracle, n=300, reflen=1_500_000, mean_len=9000, seed=11)
+    cx.close()
+
+
 def test_rare_parts_of_the_path_run_in_side_batches(ctx, oracle, golden, monkeypatch):
     """round 6: a batch runs the COMMON path only — tier 0 of the divergence filter (the anchor bound, mammap_clrnano.py:19251's edlib call bounded from above) and pass 0 of
     the extend stage. A read that needs more — a segment the bound could not settle (banded and exact tiers), or the nofilter re-run of :24079-24080 (pass 1) — is marked on

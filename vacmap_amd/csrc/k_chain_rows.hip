@@ -418,8 +418,9 @@ __device__ __forceinline__ void vmx_chain_local_rows_body(const vmx_anchor* __re
                                                          int32_t* __restrict__ SA_pool, double* __restrict__ out_score,
                                                          vmx_anchor* __restrict__ out_chain, int32_t* __restrict__ out_len, int32_t* __restrict__ out_variant,
                                                          int32_t* __restrict__ status, double* __restrict__ FP_pool, double* __restrict__ PP_pool,
-                                                         unsigned long long* __restrict__ dbg) {
+                                                         unsigned long long* __restrict__ dbg, const int32_t* __restrict__ nlist_dev) {
     VMX_SETPRIO(3);
+    if (nlist_dev) nlist = *nlist_dev;                 // the list was built on the device (the local stage without a host wait): the launch covers an upper bound
     __shared__ double s_gapcost[64];
     __shared__ float s_rgc[128];
     const int lane = vmx_lane(), l16 = lane & 15;
@@ -501,12 +502,13 @@ __device__ __forceinline__ void vmx_chain_local_rows_body(const vmx_anchor* __re
 #define VMX_LOCAL_ROWS_ARGS const vmx_anchor* __restrict__ anchors, const int64_t* __restrict__ la_off, const int32_t* __restrict__ la_cnt, const int32_t* __restrict__ n_guides_total, \
     const int32_t* __restrict__ rlist, int nlist, int want, vmx_tables tab, const double* __restrict__ gapcost_list, double skip_exact, double skip_mm, int maxdiff, int maxgap, int mode, \
     double* __restrict__ S_pool, int32_t* __restrict__ P_pool, int32_t* __restrict__ SA_pool, double* __restrict__ out_score, vmx_anchor* __restrict__ out_chain, \
-    int32_t* __restrict__ out_len, int32_t* __restrict__ out_variant, int32_t* __restrict__ status, double* __restrict__ FP_pool, double* __restrict__ PP_pool, unsigned long long* __restrict__ dbg
+    int32_t* __restrict__ out_len, int32_t* __restrict__ out_variant, int32_t* __restrict__ status, double* __restrict__ FP_pool, double* __restrict__ PP_pool, unsigned long long* __restrict__ dbg, \
+    const int32_t* __restrict__ nlist_dev
 __global__ void __launch_bounds__(64) k_chain_local_rows(VMX_LOCAL_ROWS_ARGS) {
     vmx_chain_local_rows_body<16>(anchors, la_off, la_cnt, n_guides_total, rlist, nlist, want, tab, gapcost_list, skip_exact, skip_mm, maxdiff, maxgap, mode, S_pool, P_pool, SA_pool, out_score,
-                                  out_chain, out_len, out_variant, status, FP_pool, PP_pool, dbg);
+                                  out_chain, out_len, out_variant, status, FP_pool, PP_pool, dbg, nlist_dev);
 }
 __global__ void __launch_bounds__(64) k_chain_local_rows_w3(VMX_LOCAL_ROWS_ARGS) {           // test kernel: 3-entry window (see above)
     vmx_chain_local_rows_body<3>(anchors, la_off, la_cnt, n_guides_total, rlist, nlist, want, tab, gapcost_list, skip_exact, skip_mm, maxdiff, maxgap, mode, S_pool, P_pool, SA_pool, out_score,
-                                 out_chain, out_len, out_variant, status, FP_pool, PP_pool, dbg);
+                                 out_chain, out_len, out_variant, status, FP_pool, PP_pool, dbg, nlist_dev);
 }

@@ -160,3 +160,68 @@ __global__ void __launch_bounds__(256) k_round_prep(vmx_round_args A) {
 }
 template __global__ void k_round_prep<false>(vmx_round_args A);
 template __global__ void k_round_prep<true>(vmx_round_args A);
+
+// ---- the local stage without a host wait (round 6): the local-anchor counts stay on the device
+// queue keys of the local chain DP: reads with local anchors, most first (k_size_hist / k_size_scatter); the others are not queued
+__global__ void k_la_sizes(const int32_t* __restrict__ la_cnt, int n, int64_t* __restrict__ size, int32_t* __restrict__ n_dev) {
+    const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r == 0) *n_dev = n;
+    if (r < n) size[r] = la_cnt[r] > 0 ? (int64_t)la_cnt[r] : -1;
+}
+// The per-read pool geometry of the extend stage (segment anchors 3 cl + 8, segments cl + 2, record text 3 len + 64 (cl / 2 + 2) + 56 for a read with cl local anchors) as
+// three exclusive scans over the reads, ONE workgroup. The pools themselves are sized from the context's history: a read whose slice would pass the end of a pool
+// gets an EMPTY slice (the phase kernels then mark it VMX_EXT_CAPACITY_DEV and it is run again alone). tot[0..5] = segment anchors, segments, text bytes, problem
+// slots (cl + 2 per read with anchors), local anchors, reads that were cut.
+__global__ void __launch_bounds__(1024) k_ext_geometry(const int32_t* __restrict__ la_cnt, const int64_t* __restrict__ roff, int n, int mul, int tmask, long long tdiv,
+                                                       long long capA, long long capS, long long capB, int64_t* __restrict__ coff3, int64_t* __restrict__ soff2,
+                                                       int64_t* __restrict__ bloboff, int64_t* __restrict__ tot) {
+    __shared__ long long s_w[16][3];
+    __shared__ long long s_base[3];
+    __shared__ long long s_acc[3];
+    const int tid = (int)threadIdx.x, lane = vmx_lane(), wv = tid >> 6;
+    auto pool = [&](int bit, long long x) -> long long { const long long y = x * mul; return (tmask & bit) ? (y / tdiv > 1 ? y / tdiv : 1) : y; };
+    if (tid < 3) s_base[tid] = 0;
+    if (tid == 0) { s_acc[0] = 0; s_acc[1] = 0; s_acc[2] = 0; }
+    __syncthreads();
+    long long full = 0, la = 0, cut = 0;
+    for (int r0 = 0; r0 < n; r0 += 1024) {
+        const int r = r0 + tid;
+        long long x[3] = {0, 0, 0};
+        if (r < n) {
+            const long long cl = la_cnt[r], len = roff[r + 1] - roff[r];
+            if (cl > 0) { x[0] = pool(1, 3 * cl + 8); x[1] = pool(2, cl + 2); x[2] = (pool(4, 3 * len + 64 * (cl / 2 + 2) + 56) + 7) & ~7LL; full += cl + 2; la += cl; }
+        }
+        long long inc[3];
+        for (int v = 0; v < 3; ++v) {
+            long long c = x[v];
+            for (int o = 1; o < 64; o <<= 1) { const long long y = __shfl_up(c, o); if (lane >= o) c += y; }
+            inc[v] = c;
+            if (lane == 63) s_w[wv][v] = c;
+        }
+        __syncthreads();
+        long long off[3];
+        for (int v = 0; v < 3; ++v) { long long wb = 0; for (int w = 0; w < wv; ++w) wb += s_w[w][v]; off[v] = s_base[v] + wb + inc[v] - x[v]; }
+        // (a cut read keeps its place in the scan — the offsets stay monotonic — but its slice is emptied by giving the NEXT read the same offset: done in the pass below)
+        if (r < n) { coff3[r] = off[0]; soff2[r] = off[1]; bloboff[r] = off[2]; }
+        __syncthreads();
+        if (tid == 0) for (int v = 0; v < 3; ++v) { long long t = 0; for (int w = 0; w < 16; ++w) t += s_w[w][v]; s_base[v] += t; }
+        __syncthreads();
+    }
+    if (tid == 0) { coff3[n] = s_base[0]; soff2[n] = s_base[1]; bloboff[n] = s_base[2]; }
+    __syncthreads();
+    // the pools end at capA / capS / capB: every offset is clamped there, so a read that starts beyond an end, or reaches over it, owns less than it needs (the
+    // phase kernels check a read's slice before they use it)
+    for (int r = tid; r <= n; r += 1024) {
+        if (r < n && (coff3[r + 1] > capA || soff2[r + 1] > capS || bloboff[r + 1] > capB) && la_cnt[r] > 0) ++cut;
+    }
+    __syncthreads();
+    for (int r = tid; r <= n; r += 1024) {
+        if (coff3[r] > capA) coff3[r] = capA;
+        if (soff2[r] > capS) soff2[r] = capS;
+        if (bloboff[r] > capB) bloboff[r] = capB;
+    }
+    full = vmx_wave_sum_i64(full); la = vmx_wave_sum_i64(la); cut = vmx_wave_sum_i64(cut);
+    if (lane == 0) { atomicAdd((unsigned long long*)&s_acc[0], (unsigned long long)full); atomicAdd((unsigned long long*)&s_acc[1], (unsigned long long)la); atomicAdd((unsigned long long*)&s_acc[2], (unsigned long long)cut); }
+    __syncthreads();
+    if (tid == 0) { tot[0] = s_base[0]; tot[1] = s_base[1]; tot[2] = s_base[2]; tot[3] = s_acc[0]; tot[4] = s_acc[1]; tot[5] = s_acc[2]; }
+}

@@ -65,7 +65,7 @@ struct vmx_batch_bufs {
     // extend stage
     DevBuf er, coff3, soff2, segA, st, en, segA_s, st_s, en_s, segprob, dup, desc[2], rcount, oflow, probread, tl, ql, toff, qoff, tpool, qpool;
     DevBuf edout, carry, ext3, dpsz[4], dpoff[4], dptab, tb, tbredo, bnd, run, cig, ciglen, dpscore, rec, blob, bloboff, reccoff, recclen, dupd, totals;
-    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp, chunkn, sellist, cigq, statblk, szh, side_codes, side_off, roundpart, gfctl;
+    DevBuf raw, codes, off, order, qrange, scanpart, scanoff, si, tg, cntp, fp, pp, chunkn, sellist, cigq, statblk, szh, side_codes, side_off, roundpart, gfctl, geotot;
     void release() { DevBuf* p = (DevBuf*)this; for (size_t i = 0; i < sizeof(*this) / sizeof(DevBuf); ++i) p[i].release(); }
 };
 static vmx_batch_bufs* batch_bufs(vm_ctx* c) { if (!c->bbufs) c->bbufs = new vmx_batch_bufs(); return c->bbufs; }
@@ -105,6 +105,8 @@ int vmx_launch_chain_select(vm_ctx* c, int64_t n, const int64_t* h_aoff, DevBuf&
 
 #define LAUNCH1D(kernel, n, ...) hipLaunchKernelGGL(kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(((n) + 255) / 256, 4096))), dim3(256), 0, c->stream, __VA_ARGS__)
 
+__global__ void k_ext_geometry(const int32_t* la_cnt, const int64_t* roff, int n, int mul, int tmask, long long tdiv, long long capA, long long capS, long long capB, int64_t* coff3,
+                               int64_t* soff2, int64_t* bloboff, int64_t* tot);
 __global__ void k_scan_part_dev(const int64_t* in, int64_t* part, const int32_t* n_ptr);
 __global__ void k_scan_apply_dev(const int64_t* in, int64_t* out, const int64_t* part_off, const int32_t* n_ptr);
 __global__ void k_scan_part(const int64_t* in, int64_t* part, int64_t n, int64_t chunk);
@@ -242,7 +244,7 @@ int align_device(vm_ctx* c, const vm_index* mi, const vm_params* prm, int64_t n,
             blob.append(b2, (size_t)bl);
             free(r2); free(b2);
             st.ms_total += st2.ms_total; for (int i = 0; i < 14; ++i) st.ms_stage[i] += st2.ms_stage[i];
-            st.n_host_syncs += st2.n_host_syncs; st.n_ed_tier2 += st2.n_ed_tier2; st.n_ed_full += st2.n_ed_full;
+            st.n_host_syncs += st2.n_host_syncs; st.n_ed_tier2 += st2.n_ed_tier2; st.n_ed_full += st2.n_ed_full; st.n_local_anchors += st2.n_local_anchors; st.n_local_general += st2.n_local_general;
             sub.swap(still);
         }
         c->ext_mul = 1; c->force_exact = false; c->run_pass1 = false;
@@ -283,6 +285,13 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     const int rmode = prm->mode == VM_MODE_R ? 1 : (prm->mode == VM_MODE_ASM ? 2 : 0);      // the GC kernels' variant: H / L / S, R, the asm fork
     double* d_gscore = nullptr; int32_t* d_mapq = nullptr; int32_t* d_np = nullptr;
     vmx_local_bufs& L = *vmx_ctx_local_bufs(c);
+    // Round 6: after a context's first batch the LOCAL stage runs without a host wait (vmx_local_stage's fast form) and the extend stage's per-read pool geometry is made
+    // on the device (k_ext_geometry) inside pools sized from the context's history — one wait less per batch. A read whose slice does not fit, whose anchors overflow
+    // their slot or that the banded seeding kernel hands back is run again alone on the waiting path (side batches, below). VMX_LOCAL_SYNC=1: the waiting path always.
+    int tmask = 0; int64_t tdiv = 1;                            // test hook: VMX_TEST_EXT_POOL=<mask>:<div> (pools of exact size divided: the waiting path)
+    if (const char* e = getenv("VMX_TEST_EXT_POOL")) { long long m_ = 0, d_ = 1; if (sscanf(e, "%lld:%lld", &m_, &d_) == 2 && d_ >= 1) { tmask = (int)m_; tdiv = d_; } }
+    static const bool local_sync_env = getenv("VMX_LOCAL_SYNC") != nullptr;
+    const bool fast_local = !preset && !trace && !c->force_exact && !local_sync_env && vmx_chain_rows_on() && rmode != 2 && c->geo_valid && c->ext_mul == 1 && tmask == 0;
     // the stages in front of the extension: seed, global chain, local chain
     auto front = [&]() -> int {
     // ---------------- S1 seed
@@ -396,8 +405,8 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     // ---------------- orient + L1-L4 local stage
     VMX_TRY(B.ocodes.reserve((size_t)total_bases + 64));
     hipLaunchKernelGGL(k_orient, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 8)), dim3(256), 0, c->stream, d_codes, d_roff, d_gscore, (int)n, B.ocodes.as<uint8_t>());
-    VMX_TRY(vmx_local_stage(c, ix, prm, n, B.ocodes.as<uint8_t>(), d_roff, h_roff, B.prow.as<vmx_anchor>(), B.plen.as<int32_t>(), d_np, B.aoff.as<int64_t>(), h_aoff, d_gscore, L));
-    for (int64_t r = 0; r < n; ++r) st.n_local_anchors += L.h_la_cnt[r];
+    VMX_TRY(vmx_local_stage(c, ix, prm, n, B.ocodes.as<uint8_t>(), d_roff, h_roff, B.prow.as<vmx_anchor>(), B.plen.as<int32_t>(), d_np, B.aoff.as<int64_t>(), h_aoff, d_gscore, L, fast_local));
+    if (!fast_local) for (int64_t r = 0; r < n; ++r) st.n_local_anchors += L.h_la_cnt[r];
     VMX_HIP(hipEventRecord(ev[nev++], c->stream));
 
     return 0;
@@ -435,21 +444,36 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     // ---------------- E1-E6 extend stage
     // per-read pool geometry from the local anchor count (the chain is never longer than that)
     std::vector<int64_t> coff3((size_t)n + 1), soff2((size_t)n + 1), bloboff((size_t)n + 1);
-    int tmask = 0; int64_t tdiv = 1;                            // test hook: VMX_TEST_EXT_POOL=<mask>:<div>
-    if (const char* e = getenv("VMX_TEST_EXT_POOL")) { long long m_ = 0, d_ = 1; if (sscanf(e, "%lld:%lld", &m_, &d_) == 2 && d_ >= 1) { tmask = (int)m_; tdiv = d_; } }
     auto pool = [&](int bit, int64_t x) -> int64_t { const int64_t y = x * c->ext_mul; return (tmask & bit) ? std::max<int64_t>(y / tdiv, 1) : y; };
-    for (int64_t r = 0; r < n; ++r) {
-        const int64_t cl = L.h_la_cnt[r], len = h_roff[r + 1] - h_roff[r];
-        coff3[r + 1] = coff3[r] + (cl > 0 ? pool(1, 3 * cl + 8) : 0); soff2[r + 1] = soff2[r] + (cl > 0 ? pool(2, cl + 2) : 0);
-        bloboff[r + 1] = bloboff[r] + (cl > 0 ? ((pool(4, 3 * len + 64 * (cl / 2 + 2) + 56) + 7) & ~(int64_t)7) : 0);
+    int64_t cA = 0, cS = 0, cB = 0, cS_full = 0;
+    if (!fast_local) {
+        for (int64_t r = 0; r < n; ++r) {
+            const int64_t cl = L.h_la_cnt[r], len = h_roff[r + 1] - h_roff[r];
+            coff3[r + 1] = coff3[r] + (cl > 0 ? pool(1, 3 * cl + 8) : 0); soff2[r + 1] = soff2[r] + (cl > 0 ? pool(2, cl + 2) : 0);
+            bloboff[r + 1] = bloboff[r] + (cl > 0 ? ((pool(4, 3 * len + 64 * (cl / 2 + 2) + 56) + 7) & ~(int64_t)7) : 0);
+            if (cl > 0) cS_full += cl + 2;
+        }
+        cA = coff3[n]; cS = soff2[n]; cB = bloboff[n];
+        if (!preset && c->ext_mul == 1 && tmask == 0) {      // the pools now hold at least this much: what the batches that do not ask may use
+            c->geo_cap[0] = std::max<long long>(c->geo_cap[0], cA); c->geo_cap[1] = std::max<long long>(c->geo_cap[1], cS); c->geo_cap[2] = std::max<long long>(c->geo_cap[2], cB);
+            c->geo_cap[3] = std::max<long long>(c->geo_cap[3], cS_full);
+            c->geo_valid = true;
+        }
+    } else {
+        // exactly what the pools already hold (no pool grows on this path: a growth is a hipMalloc of gigabytes with the GPU idle); a batch that needs more has its last
+        // reads cut (k_ext_geometry) and run again alone, and this context's next batch takes the waiting path once, which sizes the pools for it
+        cA = c->geo_cap[0]; cS = c->geo_cap[1]; cB = c->geo_cap[2]; cS_full = c->geo_cap[3];
     }
-    const int64_t cA = coff3[n], cS = soff2[n], cB = bloboff[n];
     VMX_TRY(B.er.reserve(sizeof(vmx_ext_read) * (size_t)(n + 1)));
-    { const vmx_push_req rq[3] = {{&B.coff3, coff3.data(), 8 * ((size_t)n + 1)}, {&B.soff2, soff2.data(), 8 * ((size_t)n + 1)}, {&B.bloboff, bloboff.data(), 8 * ((size_t)n + 1)}}; VMX_TRY(vmx_push_many(c, rq, 3)); }
+    if (!fast_local) { const vmx_push_req rq[3] = {{&B.coff3, coff3.data(), 8 * ((size_t)n + 1)}, {&B.soff2, soff2.data(), 8 * ((size_t)n + 1)}, {&B.bloboff, bloboff.data(), 8 * ((size_t)n + 1)}}; VMX_TRY(vmx_push_many(c, rq, 3)); }
+    else {
+        VMX_TRY(B.coff3.reserve(8 * ((size_t)n + 2))); VMX_TRY(B.soff2.reserve(8 * ((size_t)n + 2))); VMX_TRY(B.bloboff.reserve(8 * ((size_t)n + 2))); VMX_TRY(B.geotot.reserve(64));
+        hipLaunchKernelGGL(k_ext_geometry, dim3(1), dim3(1024), 0, c->stream, L.la_cnt.as<int32_t>(), d_roff, (int)n, c->ext_mul, tmask, (long long)tdiv, (long long)cA, (long long)cS, (long long)cB,
+                           B.coff3.as<int64_t>(), B.soff2.as<int64_t>(), B.bloboff.as<int64_t>(), B.geotot.as<int64_t>());
+    }
     VMX_TRY(B.segA.reserve(sizeof(vmx_anchor) * (size_t)(cA + 1))); VMX_TRY(B.segA_s.reserve(sizeof(vmx_anchor) * (size_t)(cA + 1)));
     VMX_TRY(B.st.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.en.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.st_s.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.en_s.reserve(4 * (size_t)(cS + 1)));
     VMX_TRY(B.segprob.reserve(4 * (size_t)(cS + 1))); VMX_TRY(B.dup.reserve(4 * (size_t)(cS + 1)));
-    int64_t cS_full = 0; for (int64_t r = 0; r < n; ++r) if (L.h_la_cnt[r] > 0) cS_full += L.h_la_cnt[r] + 2;
     const int64_t round_cap = pool(8, cS_full + 16);         // one problem per anchor at most in any round
     const int64_t pool_cap = pool(16, 6 * total_bases + (1 << 20));
     int64_t Lmax_b = 1; for (int64_t r = 0; r < n; ++r) Lmax_b = std::max(Lmax_b, h_roff[r + 1] - h_roff[r]);
@@ -705,7 +729,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     VMX_TRY(B.totals.reserve(sizeof(vm_record) * (size_t)(cS + 1))); VMX_TRY(B.dupd.reserve((size_t)cB + 64));
     hipLaunchKernelGGL(k_res_pack, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 8)), dim3(64), 0, c->stream, B.er.as<vmx_ext_read>(), B.rec.as<vm_record>(), B.blob.as<char>(),
                        B.soff2.as<int64_t>(), B.bloboff.as<int64_t>(), (int)n, B.dpoff[0].as<int64_t>(), B.dpoff[1].as<int64_t>(), B.totals.as<vm_record>(), B.dupd.as<char>());
-    int64_t g_nr = std::min<int64_t>(cS, (int64_t)(c->res_rec_per_read * 1.15 * (double)n) + 64), g_nb = std::min<int64_t>(cB, (int64_t)(c->res_blob_per_base * 1.15 * (double)total_bases) + 4096);
+    int64_t g_nr = std::min<int64_t>(cS, (int64_t)(c->res_rec_per_read * 1.15 * (double)n) + 64), g_nb = std::min<int64_t>(cB, (int64_t)(c->res_blob_per_base * 1.4 * (double)total_bases) + 65536);
     if (c->res_rec_per_read <= 0.0) { g_nr = 0; g_nb = 0; }
     std::vector<vmx_ext_read> er((size_t)n);
     std::vector<int64_t> h_gmax((size_t)n);
@@ -714,6 +738,8 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     struct OutGuard { vm_record** r; char** b; bool keep = false; ~OutGuard() { if (!keep) { free(*r); free(*b); *r = nullptr; *b = nullptr; } } } out_guard{recs, cigar_blob};
     if (!*recs || !*cigar_blob) { set_error("out of host memory"); return VM_ERR_OOM; }
     VMX_TRY(vmx_fetch(c, fin, B.statblk.as<int64_t>() + 32, 14));          // record / blob totals, overflow flag, tier counters, per-round problem counts: one copy
+    int64_t geo[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (fast_local) VMX_TRY(vmx_fetch(c, geo, B.geotot.p, 6));             // what the geometry kernel found: totals (history), local anchors (statistics)
     std::vector<int32_t> h_ctl(gfctl_bytes / 4);
     VMX_TRY(vmx_fetch(c, h_ctl.data(), B.gfctl.p, h_ctl.size()));          // the gap fill's per-chunk control blocks (second-launch queue length and pool need)
     VMX_TRY(vmx_fetch(c, er.data(), B.er.p, (size_t)n)); VMX_TRY(vmx_fetch(c, h_gmax.data(), B.gmax.p, (size_t)n));
@@ -722,6 +748,11 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     VMX_HIP(vmx_stream_sync(c));
     VMX_HIP(hipGetLastError());
     nr = fin[0]; nb = fin[1]; oflow = (int32_t)fin[2]; n_full = (int32_t)fin[3]; n_t2 = (int32_t)fin[4]; n_t1 = (int32_t)fin[5];
+    if (fast_local) {
+        st.n_local_anchors = geo[4];
+        if (geo[5] > 0 || geo[3] + 16 > c->geo_cap[3]) c->geo_valid = false;       // this batch outgrew the pools: the next one of this context asks (and grows them)
+        if (geo[5] && getenv("VMX_DBG_POOLS")) fprintf(stderr, "[pools] extend stage: %lld read(s) did not fit the history-sized pools (run again alone)\n", (long long)geo[5]);
+    }
     {   // what the gap fill assumed instead of asking (above): did it hold?
         bool again = false; int64_t need_max = 0, ad_failed = 0;
         for (int pass = 0; pass < 2; ++pass)
@@ -758,6 +789,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     if (n > 0 && total_bases > 0) { c->res_rec_per_read = std::max(c->res_rec_per_read, (double)nr / (double)n); c->res_blob_per_base = std::max(c->res_blob_per_base, (double)nb / (double)total_bases); }
     for (int64_t r = 0; r < n; ++r) {
         int stt2 = er[r].status == VMX_EXT_CAPACITY_DEV ? VMX_EXT_SHORT_INTERNAL : (er[r].status == VMX_EXT_NEED_EXACT_DEV ? VMX_EXT_EXACT_INTERNAL : er[r].status);
+        if (fast_local && (er[r].status == VM_READ_CAPACITY_DEV || er[r].status == VM_READ_BANDFALL_DEV)) stt2 = VMX_EXT_EXACT_INTERNAL;      // the local stage's retries live on the waiting path
         if (stt2 == 0 && !do_pass1 && er[r].active && er[r].redo == 1 && er[r].pass == 1) stt2 = VMX_EXT_EXACT_INTERNAL;      // asks for pass 1, which this batch did not run: again, alone
         if (stt2 == 0 && test_side_every > 0 && !c->force_exact && r % test_side_every == 0) stt2 = VMX_EXT_EXACT_INTERNAL;       // (test hook)      // (align_device runs these reads again alone: larger pools / all tiers of the divergence filter)
         if (h_gmax[r] == -2 && (h_aoff[r + 1] - h_aoff[r]) > 2) stt2 = VM_READ_RAISED;     // GC-fast: the reference raises on this read (k_chain_fast.hip)

@@ -158,6 +158,7 @@ struct vm_ctx {
     int64_t n_bandfall = 0;                       // reads k_local_seed_band handed back to k_local_seed (reset per batch)
     int ext_mul = 1;                              // extend-stage pool multiplier of the running call (grow-and-retry in align_device)
     long long redo_need_max = 0;                  // largest full-matrix traceback need of one gap-fill chunk this context has seen (sizes the second launch's pool)
+    long long geo_cap[4] = {0, 0, 0, 0}; bool geo_valid = false;      // what the extend-stage pools of this context hold (segment anchors, segments, record text, problem slots): the room of the batches that do not ask
     bool run_pass1 = false;                       // this call runs pass 1 of the extend stage (the nofilter re-run; side batches of align_device)
     int32_t* rc_cur = nullptr; int rc_next = 0;    // the running extend-stage phase's problem counter inside the batch's counter block (64 counters, cleared once per batch)
     bool force_exact = false;                     // this call launches the exact edit-distance tier whatever the banded tiers left (side batches of align_device)

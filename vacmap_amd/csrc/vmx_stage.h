@@ -31,7 +31,7 @@ extern "C" int vmx_seed_stage(vm_ctx* c, const vm_index* mi, int check_num, int 
                    vmx::DevBuf* B, std::vector<int64_t>& h_koff, std::vector<int64_t>& h_nhits, vmx::DevBuf* arena = nullptr, int64_t** rows_out = nullptr);
 int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, int64_t n, const uint8_t* d_ocodes, const int64_t* d_roff,
                     const std::vector<int64_t>& h_roff, const vmx_anchor* d_path_rows, const int32_t* d_path_len, const int32_t* d_npaths,
-                    const int64_t* d_aoff, const std::vector<int64_t>& h_aoff, const double* d_gscore, vmx_local_bufs& L);
+                    const int64_t* d_aoff, const std::vector<int64_t>& h_aoff, const double* d_gscore, vmx_local_bufs& L, bool fast = false);
 // G1 selection (k_chain_select) over n reads, one launch per LDS size class of the reads' anchor counts (h_aoff), side by side
 int vmx_launch_chain_select(vm_ctx* c, int64_t n, const int64_t* h_aoff, vmx::DevBuf& d_list, const vmx_anchor* sorted, const int64_t* d_aoff, const int64_t* d_lens,
                             const double* S, const int32_t* P, const int32_t* SA, const int64_t* gmax, const int32_t* flip, int mode, char* scr, const int64_t* soff,

@@ -12,6 +12,7 @@ using namespace vmx;
 
 __global__ void k_local_prep(const vmx_anchor* path_rows, const int32_t* path_len, const int32_t* n_paths, const int64_t* aoff, const double* gscore,
                              int n_reads, int mode, vmx_anchor* guide_rows, int32_t* guide_len, int32_t* n_guides_used, int32_t* n_guides_total, int32_t* ws_pool);
+__global__ void k_la_sizes(const int32_t* la_cnt, int n, int64_t* size, int32_t* n_dev);
 __global__ void k_local_seed(vmx_lseed_args A);
 __global__ void k_local_seed_band(vmx_lseed_args A);
 __global__ void k_chain_local_fast(const vmx_anchor* anchors, const int64_t* la_off, const int32_t* la_cnt, const int32_t* n_guides_total, int n_reads,
@@ -21,11 +22,11 @@ __global__ void k_chain_local_fast(const vmx_anchor* anchors, const int64_t* la_
 __global__ void k_chain_local_rows(const vmx_anchor* anchors, const int64_t* la_off, const int32_t* la_cnt, const int32_t* n_guides_total, const int32_t* rlist, int nlist,
                                    int want, vmx_tables tab, const double* gapcost_list, double skip_exact, double skip_mm, int maxdiff, int maxgap, int mode, double* S_pool,
                                    int32_t* P_pool, int32_t* SA_pool, double* out_score, vmx_anchor* out_chain, int32_t* out_len, int32_t* out_variant, int32_t* status,
-                                   double* FP_pool, double* PP_pool, unsigned long long* dbg);
+                                   double* FP_pool, double* PP_pool, unsigned long long* dbg, const int32_t* nlist_dev);
 __global__ void k_chain_local_rows_w3(const vmx_anchor* anchors, const int64_t* la_off, const int32_t* la_cnt, const int32_t* n_guides_total, const int32_t* rlist, int nlist,
                                       int want, vmx_tables tab, const double* gapcost_list, double skip_exact, double skip_mm, int maxdiff, int maxgap, int mode, double* S_pool,
                                       int32_t* P_pool, int32_t* SA_pool, double* out_score, vmx_anchor* out_chain, int32_t* out_len, int32_t* out_variant, int32_t* status,
-                                      double* FP_pool, double* PP_pool, unsigned long long* dbg);        // test kernel (VMX_RW_WIN=3)
+                                      double* FP_pool, double* PP_pool, unsigned long long* dbg, const int32_t* nlist_dev);        // test kernel (VMX_RW_WIN=3)
 __global__ void k_chain_local(const vmx_anchor* anchors, const int64_t* la_off, const int32_t* la_cnt, const int32_t* n_guides_total,
                               const int32_t* rlist, int nlist, int lds_cap, vmx_tables tab, const double* gapcost_list, double skip_exact,
                               double skip_mm, int maxdiff, int maxgap, int mode, double* S_pool, int32_t* P_pool, int32_t* SA_pool, double* out_score,
@@ -35,7 +36,10 @@ __global__ void k_chain_local(const vmx_anchor* anchors, const int64_t* la_off, 
 // h_roff / h_aoff are the host copies of the offsets. Leaves in L: la_off (device+host), chain rows / len / score / variant / status.
 int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, int64_t n, const uint8_t* d_ocodes, const int64_t* d_roff,
                     const std::vector<int64_t>& h_roff, const vmx_anchor* d_path_rows, const int32_t* d_path_len, const int32_t* d_npaths,
-                    const int64_t* d_aoff, const std::vector<int64_t>& h_aoff, const double* d_gscore, vmx_local_bufs& L) {
+                    const int64_t* d_aoff, const std::vector<int64_t>& h_aoff, const double* d_gscore, vmx_local_bufs& L, bool fast) {
+    // fast (round 6, the batched path after a context's first batch): NO host wait in this stage. The local-anchor counts stay on the device: the read list of the local
+    // chain DP is built there (size-class order, most anchors first), a read the banded kernel hands back or whose anchors overflow its slot keeps that status and is
+    // run again alone by align_device — through this function with fast = false, where the general kernel and the larger slots are.
     const int k = prm->local_kmersize;
     if (k < 5 || k > 11) { set_error("local k-mer size must be in [5,11]"); return VM_ERR_UNSUPPORTED; }
     if (prm->local_maxdiff > 62) { set_error("local_maxdiff > 62 unsupported"); return VM_ERR_UNSUPPORTED; }
@@ -153,6 +157,9 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     int64_t hit_cap_b = 1; while (hit_cap_b < Lmax / 2 + 8192) hit_cap_b <<= 1;        // >= the read's anchor slot (len / 2 + 4096) and its chunk log (~0.25 records per base)
     VMX_TRY(run_seed((int)n, band_on ? GB : G, band_on ? hit_cap_b : hit_cap, band_on));
     (void)hipEventRecord(c->kev[1], c->stream); c->kev_set |= 1;
+    const bool rows_kernel = vmx_chain_rows_on() && prm->mode != VM_MODE_ASM;      // four reads per wavefront (k_chain_rows.hip); -mode asm keeps the one-wave kernel
+    if (fast && !rows_kernel) { set_error("vmx_local_stage: the fast form needs the row chain kernels"); return VM_ERR_ARG; }
+    if (!fast) {
     // sizing sync #2: local anchor counts decide the LDS bucket of every read in the local chain DP
     L.h_la_cnt.resize((size_t)n);
     VMX_TRY(vmx_fetch(c, L.h_la_cnt.data(), L.la_cnt.p, (size_t)n));
@@ -209,6 +216,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
             VMX_HIP(hipGetLastError());
         }
     }
+    } else L.h_la_cnt.clear();
     // LC DP
     const HostTables& T = host_tables();
     std::vector<double> gap(64, 0.0);
@@ -227,8 +235,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     // 46.3 / 46.1 / 44.9 / 43.9 / 44.0 / 43.4 — LDS residency pays for a context that runs alone, not when batches share the GPU.
     static const int lds_env = [] { const char* e = getenv("VMX_LC_LDS_MAX"); return e ? atoi(e) : -1; }();
     const int lds_max = lds_env >= 0 ? lds_env : VMX_CHAIN_LDS_MAX_SHARED;
-    const bool rows_kernel = vmx_chain_rows_on() && prm->mode != VM_MODE_ASM;      // four reads per wavefront (k_chain_rows.hip); -mode asm keeps the one-wave kernel
-    for (int64_t r = 0; r < n; ++r) {
+    for (int64_t r = 0; r < n && !fast; ++r) {
         int m = L.h_la_cnt[r];
         if (m <= 0) continue;   // no guide / capacity failure: nothing to chain (status already set by the seeding kernel or stays 0 for unmapped reads)
         int bk = NB; for (int q = 0; q < NB; ++q) if (m <= caps[q] && caps[q] <= lds_max) { bk = q; break; }
@@ -241,6 +248,20 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
         rl_off[q] = (int64_t)rl.size(); rl.insert(rl.end(), lists[q].begin(), lists[q].end());
     }
     rl_off[NB + 1] = (int64_t)rl.size();
+    const int32_t* d_nlist = nullptr;
+    if (fast) {
+        // the list on the device: L.rlist = [read order (n) | queue range (4) | counters (4) | n (4) | scratch (513, zeroed)], keys in L.hq
+        VMX_TRY(L.rlist.reserve(4 * (size_t)(n + 16 + 520))); VMX_TRY(L.hq.reserve(8 * (size_t)(n + 1)));
+        int32_t* ord = L.rlist.as<int32_t>(); int32_t* rng = ord + n; int32_t* ctr = rng + 4; int32_t* ndev = ctr + 4; int32_t* scratch = ndev + 4;
+        VMX_HIP(hipMemsetAsync(scratch, 0, 4 * 513, c->stream));
+        hipLaunchKernelGGL(k_la_sizes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, L.la_cnt.as<int32_t>(), (int)n, L.hq.as<int64_t>(), ndev);
+        const unsigned Gs = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 1023) / 1024, (int64_t)c->num_cu * 2));
+        hipLaunchKernelGGL(k_size_hist, dim3(Gs), dim3(256), 0, c->stream, L.hq.as<int64_t>(), (const int32_t*)ndev, (int64_t)1 << 62, scratch);
+        hipLaunchKernelGGL(k_size_scatter, dim3(Gs), dim3(256), 0, c->stream, L.hq.as<int64_t>(), (const int32_t*)ndev, (const int32_t*)scratch, scratch + 257, ord, rng, ctr);
+        d_nlist = rng + 1;                                            // reads queued (those with local anchors)
+        lists[NB].assign(1, 0);                                       // (one launch per variant below, over the upper bound n)
+        rl_off[NB] = 0;
+    } else
     VMX_TRY(vmx_push(c, L.rlist, rl.data(), rl.size()));
     VMX_TRY(L.S.reserve(8 * (size_t)(la_tot + 1))); VMX_TRY(L.P.reserve(4 * (size_t)(la_tot + 1))); VMX_TRY(L.SA.reserve(4 * (size_t)(la_tot + 1)));
     VMX_TRY(L.chain.reserve(sizeof(vmx_anchor) * (size_t)(la_tot + 1)));
@@ -258,6 +279,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
     for (int q = NB; q >= 0; --q) {
         int cnt = (int)lists[q].size();
         if (!cnt) continue;
+        if (fast) cnt = (int)n;
         int cap = q < NB ? caps[q] : 0;
         size_t shmem = (size_t)cap * VMX_LC_BYTES_PER_ANCHOR + 64;
         if (rows_kernel) {
@@ -267,7 +289,7 @@ int vmx_local_stage(vm_ctx* c, const vm_index_view& ix, const vm_params* prm, in
                                    L.la_off.as<int64_t>(), L.la_cnt.as<int32_t>(), L.ng_total.as<int32_t>(), L.rlist.as<int32_t>() + rl_off[q], cnt, want, c->tables,
                                    L.gap.as<double>(), skip_exact, skip_mm, prm->local_maxdiff, maxgap, prm->mode, L.S.as<double>(), L.P.as<int32_t>(), L.SA.as<int32_t>(),
                                    L.score.as<double>(), L.chain.as<vmx_anchor>(), L.chain_len.as<int32_t>(), L.variant.as<int32_t>(), L.status.as<int32_t>(),
-                                   L.fp.as<double>(), L.pp.as<double>(), vmx_chain_dbg());
+                                   L.fp.as<double>(), L.pp.as<double>(), vmx_chain_dbg(), d_nlist);
             continue;
         }
         hipLaunchKernelGGL(k_chain_local, dim3((unsigned)cnt), dim3(64), shmem, fk.next(), L.la_sorted.as<vmx_anchor>(),
