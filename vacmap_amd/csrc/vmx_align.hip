@@ -729,7 +729,7 @@ static int align_device_once(vm_ctx* c, const vm_index* mi, const vm_params* prm
     VMX_TRY(B.totals.reserve(sizeof(vm_record) * (size_t)(cS + 1))); VMX_TRY(B.dupd.reserve((size_t)cB + 64));
     hipLaunchKernelGGL(k_res_pack, dim3((unsigned)std::min<int64_t>(n, (int64_t)c->num_cu * 8)), dim3(64), 0, c->stream, B.er.as<vmx_ext_read>(), B.rec.as<vm_record>(), B.blob.as<char>(),
                        B.soff2.as<int64_t>(), B.bloboff.as<int64_t>(), (int)n, B.dpoff[0].as<int64_t>(), B.dpoff[1].as<int64_t>(), B.totals.as<vm_record>(), B.dupd.as<char>());
-    int64_t g_nr = std::min<int64_t>(cS, (int64_t)(c->res_rec_per_read * 1.15 * (double)n) + 64), g_nb = std::min<int64_t>(cB, (int64_t)(c->res_blob_per_base * 1.4 * (double)total_bases) + 65536);
+    int64_t g_nr = std::min<int64_t>(cS, (int64_t)(c->res_rec_per_read * 2.0 * (double)n) + 256), g_nb = std::min<int64_t>(cB, (int64_t)(c->res_blob_per_base * 1.5 * (double)total_bases) + 65536);      // (records are 40 B: a generous guess costs nothing; a short one costs a second wait)
     if (c->res_rec_per_read <= 0.0) { g_nr = 0; g_nb = 0; }
     std::vector<vmx_ext_read> er((size_t)n);
     std::vector<int64_t> h_gmax((size_t)n);
