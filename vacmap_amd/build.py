@@ -10,6 +10,13 @@ OUT = os.path.join(HERE, 'libvacmapx.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math', '-Wno-unused-result'] + os.environ.get('VMX_EXTRA_FLAGS', '').split()   # e.g. -DVMX_BAND_W=48 for tuning runs
 
 
+# per-file flags after the common ones (the last -O wins). VMX_FILE_FLAGS="k_local_band.hip:-Os;k_dp.hip:-O2" overrides / adds for tuning runs.
+FILE_FLAGS = {}
+for _it in os.environ.get('VMX_FILE_FLAGS', '').split(';'):
+    if ':' in _it:
+        FILE_FLAGS[_it.split(':', 1)[0].strip()] = _it.split(':', 1)[1].split()
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True
@@ -28,7 +35,7 @@ def build(force=False, verbose=False):
     for src in sorted(glob.glob(os.path.join(CSRC, '*.hip'))):
         obj = os.path.join(HERE, '_build', os.path.basename(src) + '.o')
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
