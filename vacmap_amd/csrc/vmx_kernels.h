@@ -210,8 +210,10 @@ __host__ __device__ static inline int vmx_ad_ns(int tl, int ql, int match, int o
    traceback walk — nine steps in ten go down a diagonal, two anti-diagonals back in the same lane — fetched a new 64-byte sector per step
    (5.2 GB per step of the pipeline for ~80 MB of bytes used). With AB anti-diagonals per line a diagonal stretch reads a line per AB / 2 steps. */
 #ifndef VMX_AD_AB
-#define VMX_AD_AB 8
+#define VMX_AD_AB 4     /* round 6: 4 (8 in rounds 4-5). With the step bound by the fill and the walk a narrow kernel that rides along, the fill's coalescing is worth more than the walk's
+                           locality: ONT 15.35 / 15.68 -> 14.96 / 15.16 ms per step, HiFi unchanged (profiles/r06_u_traceback_line_blocking_ab.txt) */
 #endif
+static_assert(VMX_AD_AB == 1 || 64 / VMX_AD_AB <= 16, "a 64-byte line of the anti-diagonal traceback holds at most the 16 lanes of a row per anti-diagonal (1-byte slots): AB = 1, 4 or 8");
 #define VMX_AD_TB_OFF(s, l) ((((size_t)(s) & ~(size_t)(VMX_AD_AB - 1)) << 6) + ((size_t)(s) & (VMX_AD_AB - 1)) * (64 / VMX_AD_AB) + ((size_t)(l) / (16 / VMX_AD_AB)) * 64 + ((size_t)(l) % (16 / VMX_AD_AB)) * 4)   /* byte offset of lane l's slot on anti-diagonal s (0-based), 4-byte slots */
 #define VMX_AD_TB_BYTES(tl, ql) ((int64_t)(((tl) + (ql) + VMX_AD_AB - 1) & ~(VMX_AD_AB - 1)) * 64)
 /* Round 6: the slot is as wide as the band needs — W = 1 byte per lane and anti-diagonal for ns = 1 (one cell per lane and step), 2 for ns = 2, 4 for ns = 3 / 4.
