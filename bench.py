@@ -276,17 +276,8 @@ def main():
         from vacmap_amd import vacsim
         tq = time.time()
         donor, pieces, events = vacsim.implant(contigs, VACSIM_TEXT % {'n': args.vacsim_svs}, seed=172)
-        ev_c, ev_p = [], []
-        for ci_ in range(len(pieces)):                # an event's place in the donor: through the forward piece of its own contig that holds its left end
-            own = [(ss, se, ds) for ds, de, sc, ss, se, st in pieces[ci_] if sc == ci_ and st > 0]
-            keys = np.asarray([ev['start'] for ev in events if ev['contig'] == ci_], dtype=np.int64)
-            if not own or not len(keys):
-                continue
-            ss_a, se_a, ds_a = (np.asarray([o[i] for o in own], dtype=np.int64) for i in range(3))
-            j = np.clip(np.searchsorted(ss_a, keys, side='right') - 1, 0, len(own) - 1)
-            ok = (ss_a[j] <= keys) & (keys <= se_a[j])
-            ev_c += [ci_] * int(ok.sum()); ev_p += (ds_a[j][ok] + keys[ok] - ss_a[j][ok]).tolist()
-        source, around = donor, (np.asarray(ev_c, dtype=np.int64), np.asarray(ev_p, dtype=np.int64))
+        around = vacsim.event_positions(pieces, events)
+        source, ev_c = donor, around[0]
         types = {}
         for ev in events:
             types[ev['type']] = types.get(ev['type'], 0) + 1

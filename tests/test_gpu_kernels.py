@@ -389,6 +389,37 @@ Random{eventset=["DEL:100:200,INV:300:600","INS:100:1000,NML:100:200","NML:100:2
                                                             # algorithm itself misses short flanks — the records equal the oracle's read by read)
 
 
+@pytest.mark.parametrize('mode,k,n,kw', [('R', 15, 400, dict(mean_len=18000, err=0.005, shape='hifi', min_len=5000)), ('H', 15, 300, dict(mean_len=15000, err=0.10)),
+                                          ('S', 15, 150, dict(mean_len=12000, err=0.12)), ('L', 19, 200, dict(mean_len=18000, err=0.005, shape='hifi', min_len=5000))])
+def test_reads_across_complex_svs_in_bulk(ctx, oracle, mode, k, n, kw):
+    """the bench's vacsim_r grammar (bench.VACSIM_TEXT, 40 per line) on a 9 Mb reference of three contigs, reads drawn around the events (about ten
+    records per read): whole batches through vm_align_batch in every mode, records identical to the oracle's read by read
+    (tools/bigverify.py runs the same at 1 500 reads per mode: profiles/r06_zzz_bigverify_with_vacsim_donor_*.log)"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    import bench
+    from vacmap_amd import synth, vacsim
+    from vacmap_amd.lib import Index, align_batch
+    contigs = synth.make_reference([4_000_000, 3_000_000, 2_000_000], seed=181)
+    donor, pieces, events = vacsim.implant(contigs, bench.VACSIM_TEXT % {'n': 40}, seed=182)
+    around = vacsim.event_positions(pieces, events)
+    assert len(around[0]) >= 500
+    cat, off, _ = synth.sample_reads_concat(donor, n, seed=183, around=around, **kw)
+    seqs = [cat[off[i]:off[i + 1]].tobytes().decode() for i in range(n)]
+    names = ['chrA', 'chrB', 'chrC']
+    gi = Index.from_seqs(ctx, names, [c.tobytes() for c in contigs], k=k, w=10)
+    oi = oracle.Index.from_seqs(names, [c.tobytes() for c in contigs], k=k, w=10)
+    status, recs, stats = align_batch(ctx, gi, ctx.lib.params(mode), seqs)
+    ost, orecs = oracle.align_batch(oi, seqs, oracle.params(mode), nthreads=min(os.cpu_count(), 64))
+    assert [(int(x) == 0) for x in status] == [(int(x) == 0) for x in ost]
+    a, b = {}, {}
+    for t in recs: a.setdefault(t[0], []).append(t[1:])
+    for t in orecs: b.setdefault(t[0], []).append(t[1:])
+    bad = [i for i in range(n) if a.get(i) != b.get(i)]
+    assert not bad, 'reads whose records differ from the oracle: %s' % bad[:10]
+    assert len(orecs) >= 4 * n                           # the reads do cross the SVs (measured 9 - 12 records per read)
+
+
 def test_driver_sam_end_to_end(ctx, golden, tmp_path):
     """§8(f) rank 1: FASTA + FASTQ in, SAM out through the command-line driver; body lines equal the reference's get_bam_dict_str
     output for the testdata pair (golden case A: three alignments +, -, +) and the SV-donor reads of case B"""

@@ -67,3 +67,28 @@ for mode, n, kw in (('H', 1500, dict(mean_len=12000, err=0.08)), ('R', 800, dict
     bad = sum(1 for i in range(n) if a.get(i) != b.get(i))
     print('indel donor, mode', mode, 'reads', n, 'records', len(orecs), 'status equal', [(int(x) == 0) for x in status] == [(int(x) == 0) for x in ost], 'reads with different records', bad, flush=True)
     del gi, oi
+
+# reads across COMPLEX SVs: a donor made from a 30 Mb reference of three contigs by the vacsim grammar (nested INV / DUP / TRA / INS / DEL: bench.py's vacsim_r
+# text, 150 per line), reads drawn around the events — split alignments, inversions inside duplications, the cases the non-linear chain exists for
+if '--no-vacsim' not in sys.argv:
+    from vacmap_amd import vacsim
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    import bench as _bench
+    refv = synth.make_reference([12_000_000, 10_000_000, 8_000_000], seed=11); namesv = ['chrA', 'chrB', 'chrC']
+    donor, pieces, events = vacsim.implant(refv, _bench.VACSIM_TEXT % {'n': 150}, seed=172 + SO)
+    around = vacsim.event_positions(pieces, events)
+    for mode, k, n, kw in (('R', 15, 1500, dict(mean_len=18000, err=0.005, shape='hifi', min_len=5000)), ('H', 15, 1500, dict(mean_len=15000, err=0.10)),
+                            ('S', 15, 800, dict(mean_len=12000, err=0.12)), ('L', 19, 1000, dict(mean_len=18000, err=0.005, shape='hifi', min_len=5000))):
+        cat, off, _ = synth.sample_reads_concat(donor, n, seed=55 + SO, around=around, **kw)
+        seqs = [cat[off[i]:off[i + 1]].tobytes().decode() for i in range(n)]
+        gi = Index.from_seqs(ctx, namesv, [c_.tobytes() for c_ in refv], k=k, w=10)
+        oi = O.Index.from_seqs(namesv, [c_.tobytes() for c_ in refv], k=k, w=10)
+        status, recs, stats = align_batch(ctx, gi, lib.params(mode), seqs)
+        ost, orecs = O.align_batch(oi, seqs, O.params(mode), nthreads=min(os.cpu_count(), 128))
+        a = {}; b = {}
+        for t_ in recs: a.setdefault(t_[0], []).append(t_[1:])
+        for t_ in orecs: b.setdefault(t_[0], []).append(t_[1:])
+        bad = sum(1 for i in range(n) if a.get(i) != b.get(i))
+        print('vacsim donor (%d events), mode' % len(events), mode, 'reads', n, 'records', len(orecs), 'records per read %.2f' % (len(orecs) / n), 'status equal',
+              [(int(x) == 0) for x in status] == [(int(x) == 0) for x in ost], 'reads with different records', bad, flush=True)
+        del gi, oi

@@ -182,6 +182,24 @@ def implant(contigs, text, seed=0):
     return donor, pieces, events
 
 
+def event_positions(pieces, events):
+    """where the implanted events lie in the DONOR: (contig index array, donor position array), through the forward piece of an event's own
+    contig that holds its left end (events whose left end fell into a moved or inverted piece are left out) — the `around` argument of
+    synth.sample_reads_concat, so that reads are drawn across the SVs"""
+    import numpy as np
+    ev_c, ev_p = [], []
+    for ci in range(len(pieces)):
+        own = [(ss, se, ds) for ds, de, sc, ss, se, st in pieces[ci] if sc == ci and st > 0]
+        keys = np.asarray([ev['start'] for ev in events if ev['contig'] == ci], dtype=np.int64)
+        if not own or not len(keys):
+            continue
+        ss_a, se_a, ds_a = (np.asarray([o[i] for o in own], dtype=np.int64) for i in range(3))
+        j = np.clip(np.searchsorted(ss_a, keys, side='right') - 1, 0, len(own) - 1)
+        ok = (ss_a[j] <= keys) & (keys <= se_a[j])
+        ev_c += [ci] * int(ok.sum()); ev_p += (ds_a[j][ok] + keys[ok] - ss_a[j][ok]).tolist()
+    return np.asarray(ev_c, dtype=np.int64), np.asarray(ev_p, dtype=np.int64)
+
+
 def read_truth(pieces_of_contig, d_start, d_end, strand, min_piece=1):
     """the reference pieces a donor interval [d_start, d_end) is made of, in READ order: [(src_contig, src_start, src_end, strand)];
     strand '-' reads see the pieces reversed and flipped. Pieces shorter than min_piece (after clipping) are dropped."""
