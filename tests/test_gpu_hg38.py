@@ -132,3 +132,36 @@ def test_hg38_size_index_map_and_records(ctx, oracle, hg38_ref, mode, k, shape):
     assert all(np.array_equal(x, y) for x, y in zip(ra, anchors[:6]))
     assert rep.seq(len(names) - 1, 1000, 1060) == contigs[-1][1000:1060].tobytes().decode()
     rep.close(); gi.close()
+
+
+def test_batches_in_flight_do_not_change_a_record(ctx, hg38_ref):
+    """The schedule the bench and the driver run (vacmap_amd/pipeline.py: plan_batches -> upload_batches -> Pipeline.run_resident with several contexts
+    in flight, twice over so that every context meets batches of both sizes) against the same batches run one after the other on ONE context:
+    every status and every record identical, batch by batch — contexts share the index and the device, nothing else"""
+    import os
+    from vacmap_amd import pipeline, synth
+    from vacmap_amd.lib import Index
+    names, contigs = hg38_ref
+    gi = Index.from_seqs(ctx, names, contigs, k=15, w=10)
+    prm = ctx.lib.params('H')
+    n_reads, per_batch = 12288, 1024
+    cat, off, _ = synth.sample_reads_concat(contigs, n_reads, mean_len=15000, err=0.10, seed=4242)
+    plan = pipeline.plan_batches(np.diff(off), per_batch, 16)
+    assert len(plan) == 12
+    resident = pipeline.upload_batches(ctx, cat, off, plan)
+    alone = [r.align(gi, prm, want_records=True, ctx=ctx) for r in resident]
+    pipe = pipeline.Pipeline(gi, prm, device=0, inflight=6, first_ctx=ctx)
+    try:
+        pipe.warm(resident[0])
+        for rep in range(2):
+            got = {}
+            pipe.run_resident(resident, want_records=True, on_result=lambda i, res: got.__setitem__(i, res))
+            assert sorted(got) == list(range(len(plan)))
+            for i in range(len(plan)):
+                assert np.array_equal(got[i][0], alone[i][0]), 'pass %d batch %d: status differs with batches in flight' % (rep, i)
+                assert got[i][1] == alone[i][1], 'pass %d batch %d: records differ with batches in flight' % (rep, i)
+    finally:
+        pipe.close()
+    assert sum(len(a[1]) for a in alone) >= n_reads - 24          # (the records themselves are pinned to the oracle by the test above: same index, same read model, one context)
+    for r in resident:
+        r.close()
