@@ -289,7 +289,9 @@ def main():
     pool_cat = np.concatenate(pool_cat); pool_off = np.asarray(pool_off, dtype=np.int64)
     lens = np.diff(pool_off)
     plan = pipeline.plan_batches(lens, args.reads_per_step, args.window_batches, sort=not args.arrival_order)
-    assert len(plan) == nsteps
+    assert len(plan) >= nsteps and sum(len(p_) for p_ in plan) == nsteps * args.reads_per_step      # (a step = one batch of reads_per_step reads; a batch above the
+                                                                                                        # scheduler's bases limit runs as several jobs: pipeline.plan_batches)
+    njobs = len(plan)
     t_reads = time.time() - t0 - t_ref
 
     import torch
@@ -328,6 +330,13 @@ def main():
     # warm-up: every context runs the batch with the longest reads (sizes its grow-only pools: no hipMalloc inside the timed region; a
     # long-running mapper reaches that state after its first large batch). The first pass is cross-checked against the oracle.
     longest = int(np.argmax([lens[p].sum() for p in plan]))
+    # (with a bases limit per job the job with most bases and the job with most READS are different ones, and each is the largest user of some pools)
+    full_jobs = [j for j in range(njobs) if len(plan[j]) == max(len(p_) for p_ in plan)]
+    warm_set = [longest] + [j for j in [max(full_jobs, key=lambda j_: resident[j_].bases)] if j != longest]
+
+    def size_pools(cx):
+        for j in warm_set:
+            resident[j].align(index, prm, want_records=False, ctx=cx)
     verified = None; oi = None; t_oracle_index = None
     warm_runs = 0; warm_oom = 0
     for s in range(args.warmup):
@@ -347,16 +356,16 @@ def main():
                 ok += int((st[j] == 0) == (ost == 0) and mine == [t[1:] for t in orecs])
             verified = '%d/%d' % (ok, nv)
         n_before = pipe.inflight
-        warm_oom += pipe.warm(resident[longest]); warm_runs += min(n_before, pipe.inflight + 1)
+        warm_oom += pipe.warm(run=size_pools); warm_runs += min(n_before, pipe.inflight + 1)
     ctx_dropped = warm_oom + pipe.trim_to_memory()
     ctx_added = 0; ctx_small = 0
     if args.streams == 0 and not ctx_dropped and args.warmup > 0:
         if os.environ.get('VMX_NO_FULL_GROWTH') != '1':
-            ctx_added = pipe.grow_to_memory(resident[longest], max_inflight=min(int(os.environ.get('VMX_MAX_FULL_CTX', '8')), nsteps)); warm_runs += ctx_added
+            ctx_added = pipe.grow_to_memory(run=size_pools, max_inflight=min(int(os.environ.get('VMX_MAX_FULL_CTX', '8')), nsteps)); warm_runs += ctx_added
         if os.environ.get('VMX_SMALL_CTX', '1') != '0' and nsteps >= 8:
             # where no (further) full context fits — its pools are sized by the window's longest batch — contexts for the shorter batches only, sized on the median
             # batch (ONT-hg38: 5 full + 1 small = 283 GB, 15.1-15.7 ms per step against 15.8-15.9; fewer full ones lose: 4 + 3: 15.5-16.1, 4 + 4: 15.4, 3 + 6: 16.1)
-            by_bases = sorted(range(nsteps), key=lambda j: resident[j].bases)
+            by_bases = sorted(range(njobs), key=lambda j: resident[j].bases)
             med = by_bases[int(len(by_bases) * float(os.environ.get('VMX_SMALL_PCT', '0.5')))]
             ctx_small = pipe.add_small_contexts(resident[med], resident[med].bases, max_inflight=min(int(os.environ.get('VMX_MAX_CTX', '9')), nsteps))
             warm_runs += ctx_small * resident[med].bases / float(max(resident[longest].bases, 1))          # (in units of the longest batch: the PMC summaries scale by warm-up bases)
@@ -408,7 +417,7 @@ def main():
         barrier(); th = time.time()
         pipe.run_host_blobs(blobs, on_result=on_host, prefetch=prefetch)
         barrier(); dth = time.time() - th
-        host_rate = {'aligned_Gbp_per_s': hagg['aligned'] / dth / 1e9, 'ms_per_step': dth / len(blobs) * 1e3, 'over_value': (hagg['aligned'] / dth) / (agg['aligned_bases'] / dt),
+        host_rate = {'aligned_Gbp_per_s': hagg['aligned'] / dth / 1e9, 'ms_per_step': dth / nsteps * 1e3, 'over_value': (hagg['aligned'] / dth) / (agg['aligned_bases'] / dt),
                      'note': 'second timed pass: same batches, same schedule, reads handed over in page-locked HOST memory (1 B/base); ' + (
                              'an uploader thread with a context of its own streams them into HBM ahead of the aligning contexts (vm_reads_reupload, at most streams + 2 batches ahead), ' if prefetch else
                              'uploaded inside vm_align_batch in front of the batch\'s own kernels, ') + 'results downloaded inside the call in both passes'}
@@ -536,6 +545,7 @@ def main():
             'oracle_crosscheck': verified, 'setup_s': t_setup, 'reference_gen_s': t_ref, 'read_gen_s': t_reads, 'index_build_s': t_index, 'index_broadcast_s': t_bcast,
             'index_minimizers': int(n_minimizers), 'index_mid_occ': int(index.mid_occ), 'oracle_index_build_s': t_oracle_index, 'hbm_used_gb': hbm_used_gb,
             'local_general_reads': int(agg.get('n_local_general', 0)), 'contexts_given_up_for_memory': int(ctx_dropped), 'contexts_added_for_memory': int(ctx_added), 'small_contexts_added': int(ctx_small), 'longest_read': int(lens.max()),
+            'jobs_per_step': njobs / float(K), 'largest_job_bases': int(max(r_.bases for r_ in resident)), 'contexts_in_flight': int(len(pipe.ctxs)),
             'roofline': roofline, 'cpu_baseline': cpu,
         }
         if vacsim_info is not None:

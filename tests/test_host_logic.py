@@ -362,3 +362,27 @@ def test_cross_rank_name_dedup_keeps_first_in_input_order(tmp_path):
     src = io.BytesIO(b''.join(lines)[:-1]); dst = io.BytesIO()      # no newline at the end of the part
     driver._filter_part(src, dst, np.sort(nm([b'r1'])), block=1 << 20)
     assert dst.getvalue() == b''.join(l for l in lines if not l.startswith(b'r1\t'))
+
+
+def test_plan_batches_bases_limit_per_job():
+    """pipeline.plan_batches(max_bases=...): a batch above the limit becomes equal-bases jobs of consecutive reads (the longest reads' part first), every read
+    exactly once, the other batches untouched; off (0) by default"""
+    import numpy as np
+    from vacmap_amd import pipeline
+    rng = np.random.default_rng(5)
+    ln = np.clip(rng.gamma(2.0, 7500, size=4096 * 4 + 100), 1000, 100000).astype(np.int64)
+    base = pipeline.plan_batches(ln, 4096, 16, max_bases=0)
+    assert [len(b) for b in base] == [4096] * 4 + [100] and pipeline.DEFAULT_BATCH_MAX_BASES == 0
+    assert [b.tolist() for b in pipeline.plan_batches(ln, 4096, 16)] == [b.tolist() for b in base]
+    lim = 60_000_000
+    cut = pipeline.plan_batches(ln, 4096, 16, max_bases=lim)
+    assert sorted(np.concatenate(cut).tolist()) == list(range(len(ln))) and len(cut) > len(base)
+    assert max(int(ln[b].sum()) for b in cut) <= lim * 1.02 and int(ln[base[0]].sum()) > lim
+    first = [b for b in cut if set(b.tolist()) <= set(base[0].tolist())]
+    assert len(first) >= 2 and np.array_equal(np.concatenate(first[::-1]), base[0])          # consecutive slices, listed from the long end
+    shares = [int(ln[b].sum()) for b in first]
+    assert max(shares) - min(shares) <= 2 * int(ln.max())
+    small = [b for b in base if int(ln[b].sum()) <= lim]
+    assert all(any(np.array_equal(b, c) for c in cut) for b in small)
+    one = pipeline.split_by_bases(base[0][:1], ln, 10)
+    assert len(one) == 1 and np.array_equal(one[0], base[0][:1])              # a single read is never cut

@@ -51,25 +51,58 @@ _roctx = _Roctx()
 DEFAULT_INFLIGHT = 5
 DEFAULT_BATCH_READS = 4096
 DEFAULT_WINDOW_BATCHES = 16
+DEFAULT_BATCH_MAX_BASES = 0          # plan_batches: bases a job holds at most (0: no limit)
 
 
-def plan_batches(lengths, batch_reads=DEFAULT_BATCH_READS, window_batches=DEFAULT_WINDOW_BATCHES, sort=True):
+def _max_bases_default():
+    v = os.environ.get('VMX_BATCH_MAX_BASES', '')
+    try:
+        return int(float(v)) if v else DEFAULT_BATCH_MAX_BASES
+    except ValueError:
+        return DEFAULT_BATCH_MAX_BASES
+
+
+def plan_batches(lengths, batch_reads=DEFAULT_BATCH_READS, window_batches=DEFAULT_WINDOW_BATCHES, sort=True, max_bases=None):
     """read lengths in arrival order -> list of int64 index arrays (one per batch), window by window; inside a window the batches
     hold reads of ascending length and are listed LONGEST FIRST (the streams finish on the short ones). sort=False keeps arrival
-    order (the unsorted schedule, measured once for comparison)."""
+    order (the unsorted schedule, measured once for comparison).
+    max_bases (default: VMX_BATCH_MAX_BASES, else DEFAULT_BATCH_MAX_BASES; 0 = no limit): a batch of `batch_reads` reads that holds more bases than this is
+    cut into parts of equal bases, each a job of its own. A context's grow-only pools are sized by the LARGEST job it ever runs; with reads sorted by
+    length the batch of a window's longest reads holds three times the bases of the median one (ONT shape: 175 against 61 Mbases) and sized every context
+    for itself — 50 GB, five contexts in the HBM next to an hg38-size index. Reads are independent: the records do not change."""
     lengths = np.asarray(lengths, dtype=np.int64)
     n = len(lengths)
     win = max(1, int(batch_reads) * max(1, int(window_batches)))
+    if max_bases is None:
+        max_bases = _max_bases_default()
     out = []
     for w0 in range(0, n, win):
         idx = np.arange(w0, min(n, w0 + win), dtype=np.int64)
         if sort:
             idx = idx[np.argsort(lengths[idx], kind='stable')]
         if sort:            # cut from the long end: the longest reads fill whole batches, a short remainder holds the shortest
-            out.extend(idx[max(0, e - batch_reads):e] for e in range(len(idx), 0, -batch_reads))
+            batches = [idx[max(0, e - batch_reads):e] for e in range(len(idx), 0, -batch_reads)]
         else:
-            out.extend(idx[i:i + batch_reads] for i in range(0, len(idx), batch_reads))
+            batches = [idx[i:i + batch_reads] for i in range(0, len(idx), batch_reads)]
+        for b in batches:
+            out.extend(split_by_bases(b, lengths, max_bases))
     return out
+
+
+def split_by_bases(batch, lengths, max_bases):
+    """one batch (index array) -> its parts of at most ~max_bases bases each (equal shares of the batch's bases, consecutive reads, the part listed
+    first holds the batch's last reads — the longest ones of a sorted batch); [batch] when it fits or the limit is off"""
+    if not max_bases or max_bases <= 0 or len(batch) <= 1:
+        return [batch]
+    ln = lengths[batch]
+    total = int(ln.sum())
+    if total <= max_bases:
+        return [batch]
+    parts = min(len(batch), -(-total // int(max_bases)))
+    cum = np.cumsum(ln)
+    cuts = [0] + [int(np.searchsorted(cum, total * j / parts, side='left')) + 1 for j in range(1, parts)] + [len(batch)]
+    cuts = sorted(set(min(max(c, 0), len(batch)) for c in cuts))
+    return [batch[a:b] for a, b in zip(cuts[:-1], cuts[1:]) if b > a][::-1]
 
 
 class Pipeline:
