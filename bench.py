@@ -377,6 +377,8 @@ def main():
 
     def on_result(i, res):
         stats = res[2]
+        if os.environ.get('VMX_DBG_SYNCS'):                   # tuning aid: which batches wait more often than the rest
+            sys.stderr.write('[syncs] batch %d reads %d bases %d waits %d records %d cigar bytes %d\n' % (i, stats['n_reads'], stats['read_bases'], stats['n_host_syncs'], stats['n_records'], stats['cigar_bytes']))
         for kk, v in stats.items():
             if kk != 'ms_stage':
                 agg[kk] = agg.get(kk, 0) + v
@@ -541,6 +543,7 @@ def main():
                          'local_anchors': agg['n_local_anchors'] / max(agg['n_reads'], 1), 'dp_problems': agg['n_dp_problems'] / max(agg['n_reads'], 1),
                          'dp_cells': agg['dp_cells'] / max(agg['n_reads'], 1), 'records': agg['n_records'] / max(agg['n_reads'], 1)},
             'ed_problems_per_step': agg['n_ed_problems'] / K, 'ed_tier1_per_step': agg.get('n_ed_tier1', 0) / K, 'ed_tier2_per_step': agg.get('n_ed_tier2', 0) / K, 'ed_unbanded_per_step': agg.get('n_ed_full', 0) / K,
+            'side_batches_per_step': agg.get('n_ext_retries', 0) / K, 'batch_retries_per_step': agg.get('n_batch_retries', 0) / K,      # reads run again alone (rare parts of the path) / batches run again (an assumed pool size did not hold)
             'dp_redo_per_step': agg.get('n_dp_redo', 0) / K, 'dp_redo_tb_bytes_per_step': agg.get('dp_redo_tb_bytes', 0) / K,
             'oracle_crosscheck': verified, 'setup_s': t_setup, 'reference_gen_s': t_ref, 'read_gen_s': t_reads, 'index_build_s': t_index, 'index_broadcast_s': t_bcast,
             'index_minimizers': int(n_minimizers), 'index_mid_occ': int(index.mid_occ), 'oracle_index_build_s': t_oracle_index, 'hbm_used_gb': hbm_used_gb,
