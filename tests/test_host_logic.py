@@ -386,3 +386,24 @@ def test_plan_batches_bases_limit_per_job():
     assert all(any(np.array_equal(b, c) for c in cut) for b in small)
     one = pipeline.split_by_bases(base[0][:1], ln, 10)
     assert len(one) == 1 and np.array_equal(one[0], base[0][:1])              # a single read is never cut
+
+
+def test_vacsim_event_positions_point_into_the_donor():
+    """vacsim.event_positions: every position it returns is the donor coordinate of an implanted event's left end (mapped back through the
+    contig's own forward pieces it is an event's `start`), and `sample_reads_concat(around=...)` takes them"""
+    import numpy as np
+    from vacmap_amd import synth, vacsim
+    contigs = synth.make_reference([400_000, 300_000], seed=5)
+    text = 'Specified{INV:300:600,DUP:300:600:1:2,TRA:400:800:1;number=4}\nSpecified{DEL:100:200,INS:100:1000;number=6}\nSpecified{INV:300:900;number=5}\n'
+    donor, pieces, events = vacsim.implant(contigs, text, seed=7)
+    ev_c, ev_p = vacsim.event_positions(pieces, events)
+    assert len(ev_c) == len(ev_p) and 10 <= len(ev_c) <= len(events)
+    starts = {}
+    for ev in events:
+        starts.setdefault(ev['contig'], set()).add(int(ev['start']))
+    for c, p in zip(ev_c.tolist(), ev_p.tolist()):
+        assert 0 <= p <= len(donor[c])
+        back = [ss + (p - ds) for ds, de, sc, ss, se, st in pieces[c] if sc == c and st > 0 and ds <= p <= ds + (se - ss)]      # the reference coordinate(s) a forward piece of the
+        assert any(x in starts[c] for x in back), (c, p, back)                                                                # contig itself maps this donor position to: an event's start
+    cat, off, truth = synth.sample_reads_concat(donor, 20, seed=3, around=(ev_c, ev_p), mean_len=8000, err=0.0, min_len=4000)
+    assert len(off) == 21 and off[-1] == len(cat)
